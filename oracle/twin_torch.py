@@ -1,0 +1,160 @@
+"""torch-autograd twin of the oracle, for GRADIENT checks.  TEST INFRASTRUCTURE ONLY
+(see ``oracle/__init__.py``; parity unpinned by the reference).
+
+The reference never writes a backward pass: TF1 autodiff differentiates the graph
+(train/train.py:877-878).  This twin re-expresses the same forward ops with torch
+CPU tensors (float64 by default) so autograd gives the gradients the HIP backward
+kernels are compared against.  Tie / mask conventions follow TF1:
+  * tf.maximum(x, 0): gradient flows to x where x >= 0;
+  * tf.where(cond, a, 0): no gradient through cond (mining masks are constants);
+  * reduce_min / reduce_max: gradient split evenly among ties (torch.amin/amax do
+    the same).
+"""
+import torch
+
+
+def _t(x, dtype):
+    if isinstance(x, torch.Tensor):
+        return x.to(dtype)
+    return torch.as_tensor(x, dtype=dtype)
+
+
+def l2_normalize(x, axis, epsilon=1e-12):
+    ss = (x * x).sum(dim=axis, keepdim=True)
+    return x * torch.rsqrt(torch.clamp_min(ss, epsilon))
+
+
+def _relu_tf(x):
+    # forward max(x, 0); backward passes where x >= 0 (tf.maximum convention)
+    return torch.where(x >= 0, x, torch.zeros_like(x))
+
+
+def _ms_core(sim_mat, mask_pos, mask_neg, alpha, beta, lamb, eps, ms_mining,
+             sumfunction='ms'):
+    sim_mat = _relu_tf(sim_mat)
+    pos_mat = sim_mat * mask_pos
+    neg_mat = sim_mat * mask_neg
+    if ms_mining:
+        with torch.no_grad():
+            max_val = neg_mat.amax(dim=1, keepdim=True)
+            tmp = pos_mat.amax(dim=1, keepdim=True)
+            min_val = ((sim_mat - tmp) * mask_pos).amin(dim=1, keepdim=True) + tmp
+            keep_p = pos_mat < max_val + eps
+            keep_n = neg_mat > min_val - eps
+        mask_pos = torch.where(keep_p, mask_pos, torch.zeros_like(mask_pos))
+        mask_neg = torch.where(keep_n, mask_neg, torch.zeros_like(mask_neg))
+    sel_p = mask_pos > 0
+    sel_n = mask_neg > 0
+    if sumfunction == 'plain':
+        pos_term = torch.where(sel_p, pos_mat, torch.zeros_like(pos_mat)).sum(dim=1)
+        neg_term = torch.where(sel_n, neg_mat, torch.zeros_like(neg_mat)).sum(dim=1)
+        return (neg_term - pos_term).mean()
+    pos_exp = torch.where(sel_p, torch.exp(-alpha * (pos_mat - lamb)),
+                          torch.zeros_like(pos_mat))
+    neg_exp = torch.where(sel_n, torch.exp(beta * (neg_mat - lamb)),
+                          torch.zeros_like(neg_mat))
+    pos_term = torch.log(1.0 + pos_exp.sum(dim=1)) / alpha
+    neg_term = torch.log(1.0 + neg_exp.sum(dim=1)) / beta
+    return (pos_term + neg_term).mean()
+
+
+def wms_loss(distances, embeddings, d_alpha, d_beta, alpha=2.0, beta=50.0, lamb=1.0,
+             eps=0.1, ms_mining=True, wfunction='exp', sumfunction='ms',
+             dtype=torch.float64):
+    d = _t(distances, dtype)
+    emb = l2_normalize(_t(embeddings, dtype), 1)
+    batch = emb.shape[0]
+    if wfunction == 'lin':
+        mask_pos = torch.where(d < d_beta, 1.0 - d / d_beta, torch.zeros_like(d))
+        mask_neg = torch.where(d < d_beta, d / d_beta, torch.ones_like(d))
+    elif wfunction == 'tanh':
+        mask_pos = 1.0 - torch.tanh(d / d_beta)
+        mask_neg = torch.tanh(d / d_beta)
+    else:
+        mask_pos = 1.0 / (1.0 + torch.exp(d_alpha * (d - d_beta)))
+        mask_neg = 1.0 / (1.0 + torch.exp(d_alpha * (d_beta - d)))
+    mask_pos = mask_pos - torch.eye(batch, dtype=dtype)
+    sim = emb @ emb.T
+    return _ms_core(sim, mask_pos, mask_neg, alpha, beta, lamb, eps, ms_mining,
+                    sumfunction)
+
+
+def ms_loss(labels, embeddings, alpha=2.0, beta=50.0, lamb=1.0, eps=0.1,
+            ms_mining=True, dtype=torch.float64):
+    emb = l2_normalize(_t(embeddings, dtype), 1)
+    lab = torch.as_tensor(labels).reshape(-1, 1)
+    batch = emb.shape[0]
+    adj = lab == lab.T
+    mask_pos = adj.to(dtype) - torch.eye(batch, dtype=dtype)
+    mask_neg = (~adj).to(dtype)
+    sim = emb @ emb.T
+    return _ms_core(sim, mask_pos, mask_neg, alpha, beta, lamb, eps, ms_mining)
+
+
+def logratio_loss(a_feature, pos_features, neg_features, squared_pos_dists,
+                  squared_neg_dists, dtype=torch.float64):
+    a, p, n = _t(a_feature, dtype), _t(pos_features, dtype), _t(neg_features, dtype)
+    spd, snd = _t(squared_pos_dists, dtype), _t(squared_neg_dists, dtype)
+    pr = ((a - p) ** 2).sum(dim=2)
+    nr = ((a - n) ** 2).sum(dim=2)
+    fr = torch.log(pr / nr.permute(*reversed(range(nr.dim()))))
+    dr = torch.log(spd / snd.permute(*reversed(range(snd.dim()))))
+    sq = (fr - dr) ** 2
+    return sq.mean(dim=1).mean(dim=1).mean(dim=0)
+
+
+def _sq_dists_to(anchor, vecs):
+    return ((vecs - anchor) ** 2).sum(dim=2)
+
+
+def _tuple_loss(q, pos, neg, other, m1, m2, pos_red, neg_red, dtype):
+    q, pos, neg = _t(q, dtype), _t(pos, dtype), _t(neg, dtype)
+    dp = _sq_dists_to(q, pos)
+    ref = dp.amin(dim=1) if pos_red == 'min' else dp.amax(dim=1)
+
+    def part(anchor, margin):
+        h = margin + (ref.reshape(-1, 1) - _sq_dists_to(anchor, neg))
+        h = _relu_tf(h)
+        per = h.sum(dim=1) if neg_red == 'sum' else h.amax(dim=1)
+        return per.mean()
+
+    loss = part(q, m1)
+    if other is not None:
+        loss = loss + part(_t(other, dtype), m2)
+    return loss
+
+
+def triplet_loss(q, pos, neg, margin, dtype=torch.float64):
+    return _tuple_loss(q, pos, neg, None, margin, None, 'min', 'sum', dtype)
+
+
+def lazy_triplet_loss(q, pos, neg, margin, dtype=torch.float64):
+    return _tuple_loss(q, pos, neg, None, margin, None, 'min', 'max', dtype)
+
+
+def evil_triplet_loss(q, pos, neg, margin, dtype=torch.float64):
+    return _tuple_loss(q, pos, neg, None, margin, None, 'max', 'sum', dtype)
+
+
+def quadruplet_loss(q, pos, neg, other, m1, m2, dtype=torch.float64):
+    return _tuple_loss(q, pos, neg, other, m1, m2, 'min', 'sum', dtype)
+
+
+def lazy_quadruplet_loss(q, pos, neg, other, m1, m2, dtype=torch.float64):
+    return _tuple_loss(q, pos, neg, other, m1, m2, 'min', 'max', dtype)
+
+
+def evil_quadruplet_loss(q, pos, neg, other, m1, m2, dtype=torch.float64):
+    return _tuple_loss(q, pos, neg, other, m1, m2, 'max', 'sum', dtype)
+
+
+def netvlad(x, assign_w, centers, pre_l2=True, dtype=torch.float64):
+    """x [B,N,D], assign_w [D,K], centers [D,K] -> [B, D*K] (see oracle.netvlad_np)."""
+    x, w, c = _t(x, dtype), _t(assign_w, dtype), _t(centers, dtype)
+    if pre_l2:
+        x = l2_normalize(x, -1)
+    a = torch.softmax(x @ w, dim=-1)
+    v = torch.einsum('bnd,bnk->bdk', x, a) + c[None] * a.sum(dim=1)[:, None, :]
+    v = v / torch.sqrt((v * v).sum(dim=1, keepdim=True) + 1e-12)     # over D per k
+    v = v.reshape(v.shape[0], -1)
+    return v / torch.sqrt((v * v).sum(dim=1, keepdim=True) + 1e-12)
