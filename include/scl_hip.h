@@ -1,0 +1,184 @@
+/*
+ * scl_hip.h — C-ABI of the MI355X (gfx950) soft-contrastive hot path.
+ *
+ * This is the drop-in boundary.  The reference has no FFI of its
+ * own: its boundary is two Python modules of free functions,
+ *   model/nets.py   (vgg16Netvlad :7-69, vgg16 :72-131)
+ *   model/losses.py (wms_loss :5-60, ms_loss :76-122, logratio_loss :125-135,
+ *                    evil_* :63-73,197-222, _pairwise_squared_distances :656-661)
+ * plus the third-party netvlad_tf.layers.netVLAD (call site model/nets.py:67) and
+ * pointnetvlad_cls.{triplet,quadruplet,lazy_*}_loss (call sites
+ * train/train.py:700-712), and the KDTree query of evaluation/top-n.py:103-108.
+ * Each entry point below names the reference interface it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into caller-owned memory (HBM); the
+ *     library allocates nothing and keeps no global state, so all entry points are
+ *     re-entrant (the reference drives one session from three threads,
+ *     train/train.py:967-975);
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and
+ *     no entry point synchronises;
+ *   - every function returns 0 on success, a negative SCL_E_* code for a rejected
+ *     call (nothing enqueued) or a positive hipError_t from the launch;
+ *   - tensors are row-major, contiguous unless a stride argument says otherwise;
+ *   - scratch comes from the caller: ask scl_*_workspace_bytes first.  Workspaces
+ *     must be 256-byte aligned.
+ */
+#ifndef SCL_HIP_H
+#define SCL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCL_ABI_VERSION 1
+
+/* error codes (negative = rejected before any launch) */
+#define SCL_OK 0
+#define SCL_E_SHAPE -1       /* unsupported or inconsistent shape            */
+#define SCL_E_KIND -2        /* unknown loss / mask / dtype selector         */
+#define SCL_E_NULL -3        /* required pointer is NULL                     */
+#define SCL_E_WORKSPACE -4   /* workspace too small or misaligned            */
+
+/* element types of the conv5_3 feature map handed to NetVLAD */
+#define SCL_DT_F32 0
+#define SCL_DT_BF16 1
+
+/* NetVLAD is specialised to the reference's only configuration:
+ * D = 512 VGG16 conv5_3 channels, K = 64 clusters (model/nets.py:67). */
+#define SCL_VLAD_D 512
+#define SCL_VLAD_K 64
+
+/* pair-mask kinds of the Gram-matrix loss family */
+#define SCL_MASK_WMS_EXP 0   /* wms_loss wfunction='exp'  (model/losses.py:17-19) */
+#define SCL_MASK_WMS_LIN 1   /* wms_loss wfunction='lin'  (:11-13)                */
+#define SCL_MASK_WMS_TANH 2  /* wms_loss wfunction='tanh' (:14-16)                */
+#define SCL_MASK_LABELS 3    /* ms_loss / ms_det label adjacency (:88-92)         */
+
+#define SCL_SUM_MS 0         /* sumfunction='ms'    (model/losses.py:48-58)       */
+#define SCL_SUM_PLAIN 1      /* sumfunction='plain' (:39-46)                      */
+
+/* tuple-loss kinds: reduction over positives (best=min / worst=max) and over
+ * negatives (sum / lazy=max), with or without the second ("other negative") term */
+#define SCL_TUPLE_TRIPLET 0          /* pointnetvlad_cls.triplet_loss             */
+#define SCL_TUPLE_LAZY_TRIPLET 1     /* pointnetvlad_cls.lazy_triplet_loss        */
+#define SCL_TUPLE_EVIL_TRIPLET 2     /* model/losses.py:63-73                     */
+#define SCL_TUPLE_QUADRUPLET 3       /* pointnetvlad_cls.quadruplet_loss          */
+#define SCL_TUPLE_LAZY_QUADRUPLET 4  /* pointnetvlad_cls.lazy_quadruplet_loss     */
+#define SCL_TUPLE_EVIL_QUADRUPLET 5  /* model/losses.py:197-214                   */
+
+int scl_abi_version(void);
+const char* scl_error_string(int code);
+
+/* ------------------------------------------------------------------------- *
+ * NetVLAD head — replaces tf.nn.l2_normalize(x, axis=-1) + layers.netVLAD(x, 64)
+ * (model/nets.py:66-67; upstream netvlad_tf/layers.py).
+ *
+ *   x        [B, N, 512]  conv5_3 map, channels last, N = H'*W' (f32 or bf16)
+ *   assign_w [512, 64]    = assignment/kernel[0,0]
+ *   centers  [512, 64]    = cluster_centers[0,0,0]
+ *   out      [B, 32768]   index d*64 + k, unit L2 norm
+ * For training the forward also leaves, in caller buffers, what the backward
+ * re-uses (pass NULL for all four when only inferring):
+ *   save_assign [B,N,64] soft-assignment a;  save_logit [B,N,64] logits;
+ *   save_rnorm  [B,N] per-location 1/||x||;  save_vlad  [B,512,64] pre-norm VLAD.
+ * save_assign and save_rnorm double as forward scratch: when NULL they are carved
+ * from the workspace.
+ * ------------------------------------------------------------------------- */
+size_t scl_netvlad_fwd_workspace_bytes(int B, int N);
+int scl_netvlad_fwd(const void* x, int x_dtype, const float* assign_w, const float* centers,
+                    int B, int N, int pre_l2, float* out, float* save_assign,
+                    float* save_logit, float* save_rnorm, float* save_vlad, void* workspace,
+                    size_t workspace_bytes, void* stream);
+
+/* Backward of the above (TF autodiff of the same graph, train/train.py:877-878).
+ *   grad_out [B,32768];  grad_x [B,N,512] in x's dtype;  grad_w, grad_c [512,64]
+ *   (sums over the batch, overwritten). */
+size_t scl_netvlad_bwd_workspace_bytes(int B, int N);
+int scl_netvlad_bwd(const void* x, int x_dtype, const float* assign_w, const float* centers,
+                    const float* grad_out, const float* save_assign, const float* save_logit,
+                    const float* save_rnorm, const float* save_vlad, int B, int N, int pre_l2,
+                    void* grad_x, float* grad_w, float* grad_c, void* workspace,
+                    size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Gram-matrix losses — replace wms_loss (model/losses.py:5-60) and
+ * ms_loss / ms_det (:76-122, :139-185).
+ *
+ *   emb        [B, E] rows at stride ld_emb floats (not required unit norm: the
+ *              op L2-normalises rows like losses.py:7,82)
+ *   distances  [B,B] f32 geographic distances (wms kinds) or NULL
+ *   dist_rank3 1 when the reference caller fed the rank-3 [1,B,B] placeholder
+ *              (train/train.py:684-686): axis=1 then reduces over rows
+ *   labels     [B] int64 class ids (SCL_MASK_LABELS) or NULL
+ *   loss_out   device scalar
+ *   coef       [B,B] f32 or NULL: matrix M with d loss / d emb = M @ emb,
+ *              consumed by scl_gram_loss_bwd
+ * ------------------------------------------------------------------------- */
+size_t scl_gram_loss_workspace_bytes(int B, int E);
+int scl_gram_loss_fwd(const float* emb, int64_t ld_emb, int B, int E, int mask_kind,
+                      const float* distances, int dist_rank3, float d_alpha, float d_beta,
+                      const int64_t* labels, float alpha, float beta, float lamb, float eps,
+                      int ms_mining, int sum_kind, float* loss_out, float* coef,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* grad_emb[r, :] = (*grad_loss) * sum_j coef[row_begin + r, j] * emb[j, :]
+ * for r in [0, row_count): a data-parallel rank asks only for its own rows.
+ * grad_loss is a device scalar (NULL means 1). */
+int scl_gram_loss_bwd(const float* emb, int64_t ld_emb, int B, int E, const float* coef,
+                      const float* grad_loss, int row_begin, int row_count, float* grad_emb,
+                      int64_t ld_grad, void* stream);
+
+/* _pairwise_squared_distances (model/losses.py:656-661): [T,S,E] -> [T,S,S]. */
+size_t scl_pairwise_sqdist_workspace_bytes(int T, int S, int E);
+int scl_pairwise_sqdist(const float* feats, int T, int S, int E, float* out, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Tuple losses — replace pointnetvlad_cls.{triplet,lazy_triplet,quadruplet,
+ * lazy_quadruplet}_loss (train/train.py:700-712) and the in-tree evil_* twins.
+ *
+ *   q [T,1,E], pos [T,P,E], neg [T,N,E], other [T,1,E] (quadruplet kinds) are
+ *   views into the trainer's [T,S,E] output (train/train.py:654): each has a
+ *   tuple stride (floats between tuples) and rows E floats apart.
+ *   sqd   [T, P + 2N] out: squared distances anchor-pos | anchor-neg | other-neg
+ *   coef  [T, P + 2N] out: d loss / d sqd (consumed by the backward)
+ * ------------------------------------------------------------------------- */
+int scl_tuple_loss_fwd(int kind, const float* q, int64_t q_tstride, const float* pos,
+                       int64_t pos_tstride, const float* neg, int64_t neg_tstride,
+                       const float* other, int64_t other_tstride, int T, int P, int N, int E,
+                       float m1, float m2, float* loss_out, float* sqd, float* coef,
+                       void* stream);
+/* grads are written with the same strides as their inputs; grad_other may be NULL. */
+int scl_tuple_loss_bwd(const float* q, int64_t q_tstride, const float* pos, int64_t pos_tstride,
+                       const float* neg, int64_t neg_tstride, const float* other,
+                       int64_t other_tstride, int T, int P, int N, int E, const float* coef,
+                       const float* grad_loss, float* grad_q, float* grad_pos, float* grad_neg,
+                       float* grad_other, void* stream);
+
+/* logratio_loss (model/losses.py:125-135) for the only shape its literal
+ * broadcasting admits: T == 1 and P == N.  sq_pos_d / sq_neg_d are the [P] / [N]
+ * squared geographic distances; sqd / coef are [P + N] like above (no third block). */
+int scl_logratio_fwd(const float* a, const float* pos, const float* neg, int P, int N, int E,
+                     const float* sq_pos_d, const float* sq_neg_d, float* loss_out, float* sqd,
+                     float* coef, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Retrieval — replaces KDTree(ref).query(query, k=n, sort_results=True)
+ * (evaluation/top-n.py:103-108; train/train.py:1181-1182): exact Euclidean top-n,
+ * ascending.  ref [R,d], query [Q,d] f32, d a multiple of 8, n <= 25.
+ *   idx_out  [Q,n] int64 (ref row + idx_offset, for sharded reference sets)
+ *   dist_out [Q,n] float64 Euclidean distances
+ * ------------------------------------------------------------------------- */
+size_t scl_topn_l2_workspace_bytes(int R, int Q, int d, int n);
+int scl_topn_l2(const float* ref, int R, const float* query, int Q, int d, int n,
+                int64_t idx_offset, int64_t* idx_out, double* dist_out, void* workspace,
+                size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCL_HIP_H */

@@ -1,0 +1,111 @@
+"""ctypes binding of ``libscl_hip.so`` (the C-ABI in ``include/scl_hip.h``).
+
+There is no CPU fallback: if the shared library is missing, or a tensor is not on a
+HIP device, the call raises.  PyTorch is used only for device memory and streams.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libscl_hip.so")
+
+# constants of include/scl_hip.h
+ABI_VERSION = 1
+DT_F32, DT_BF16 = 0, 1
+MASK_WMS_EXP, MASK_WMS_LIN, MASK_WMS_TANH, MASK_LABELS = 0, 1, 2, 3
+SUM_MS, SUM_PLAIN = 0, 1
+TUPLE_TRIPLET, TUPLE_LAZY_TRIPLET, TUPLE_EVIL_TRIPLET = 0, 1, 2
+TUPLE_QUADRUPLET, TUPLE_LAZY_QUADRUPLET, TUPLE_EVIL_QUADRUPLET = 3, 4, 5
+VLAD_D, VLAD_K = 512, 64
+
+_p = ctypes.c_void_p
+_i = ctypes.c_int
+_l = ctypes.c_int64
+_f = ctypes.c_float
+_z = ctypes.c_size_t
+
+# name -> (restype, argtypes); every symbol include/scl_hip.h declares
+SIGNATURES = {
+    "scl_abi_version": (_i, []),
+    "scl_error_string": (ctypes.c_char_p, [_i]),
+    "scl_netvlad_fwd_workspace_bytes": (_z, [_i, _i]),
+    "scl_netvlad_fwd": (_i, [_p, _i, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _z, _p]),
+    "scl_netvlad_bwd_workspace_bytes": (_z, [_i, _i]),
+    "scl_netvlad_bwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _z,
+                             _p]),
+    "scl_gram_loss_workspace_bytes": (_z, [_i, _i]),
+    "scl_gram_loss_fwd": (_i, [_p, _l, _i, _i, _i, _p, _i, _f, _f, _p, _f, _f, _f, _f, _i, _i, _p,
+                               _p, _p, _z, _p]),
+    "scl_gram_loss_bwd": (_i, [_p, _l, _i, _i, _p, _p, _i, _i, _p, _l, _p]),
+    "scl_pairwise_sqdist_workspace_bytes": (_z, [_i, _i, _i]),
+    "scl_pairwise_sqdist": (_i, [_p, _i, _i, _i, _p, _p, _z, _p]),
+    "scl_tuple_loss_fwd": (_i, [_i, _p, _l, _p, _l, _p, _l, _p, _l, _i, _i, _i, _i, _f, _f, _p, _p,
+                                _p, _p]),
+    "scl_tuple_loss_bwd": (_i, [_p, _l, _p, _l, _p, _l, _p, _l, _i, _i, _i, _i, _p, _p, _p, _p, _p,
+                                _p, _p]),
+    "scl_logratio_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
+    "scl_topn_l2_workspace_bytes": (_z, [_i, _i, _i, _i]),
+    "scl_topn_l2": (_i, [_p, _i, _p, _i, _i, _i, _l, _p, _p, _p, _z, _p]),
+}
+
+_lib = None
+
+
+class SclError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library once; raise loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SclError(
+            "libscl_hip.so not found at %s: build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C soft_contrastive_learning_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.scl_abi_version() != ABI_VERSION:
+        raise SclError("libscl_hip.so ABI %d != expected %d" % (lib.scl_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(code):
+    """Map a C-ABI return code onto the reference's error behaviour: bad shapes and
+    selectors are ValueError (TF raised at graph-build time), HIP errors RuntimeError."""
+    if code == 0:
+        return
+    msg = load().scl_error_string(code).decode()
+    if code < 0:
+        raise ValueError("scl: %s (code %d)" % (msg, code))
+    raise SclError("scl: HIP error %d: %s" % (code, msg))
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not isinstance(t, torch.Tensor) or not t.is_cuda:
+            raise SclError("soft_contrastive_learning_amd ops need tensors on a HIP device "
+                           "(no CPU fallback exists); got %r" % (getattr(t, 'device', type(t)),))
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_of(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def workspace(nbytes, device):
+    """Caller-owned scratch from torch's caching allocator (512-byte aligned)."""
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)

@@ -1,0 +1,597 @@
+// NetVLAD head on gfx950: channel L2 norm + soft-assignment + residual aggregation +
+// intra / global normalisation, forward and backward.
+//
+// Reference semantics: model/nets.py:66-67 = tf.nn.l2_normalize(x, axis=-1) followed
+// by netvlad_tf.layers.netVLAD(x, 64) (external, restated in oracle/netvlad_np.py).
+// The TF graph materialises the 5-D tensor [B,H',W',D,K] (157 MB per 640x480 image)
+// in forward and again in autodiff; here nothing larger than [B,N,64] is ever written.
+//
+// Both contractions (N x 512 x 64 each) run on v_mfma_f32_32x32x2_f32: exact f32
+// (bitwise a k-ordered fmaf chain) at the f32 vector rate, so the governing roofline
+// is f32 FMA (157.3 TF), not HBM.  Linearity is used to keep x raw:
+//   s[n,k] = rn[n] * sum_d x[n,d] W[d,k],      rn[n] = rsqrt(max(sum_d x^2, 1e-12))
+//   V[d,k] = sum_n (a[n,k] rn[n]) x[n,d] + C[d,k] * sum_n a[n,k]
+//
+// Forward kernels
+//   transpose_w_kernel       W[512,64] -> Wt[64,512] (LDS image source)
+//   rowtile_kernel<ASSIGN>   per 32-location tile: x·W from an LDS-resident Wt, row
+//                            norms from the same operand loads, softmax over K by
+//                            half-wave butterflies -> a, rn (+ logits for training)
+//   aggregate_kernel         per (image, 32-channel tile, location half): x^T·(a rn),
+//                            split over 4 waves along n, LDS reduce -> partial slabs
+//   finish_kernel            slabs + C*asum, intra-norm over D, global norm -> out
+// Backward kernels
+//   bwd_prep_kernel          grad through both norms -> dU (both layouts), c·dU
+//   rowtile_kernel<DASSIGN>  x·dU[b] -> d a -> softmax backward -> ds, <dxhat,xhat>
+//   aggregate_kernel         x^T·(ds rn) -> per-image dW slabs
+//   dx_kernel                [a | ds]·[dU | W]^T and the l2-norm Jacobian -> grad_x
+//   wgrad_finish_kernel      sums over the batch -> grad_w, grad_c
+#include <mutex>
+
+#include "scl_common.h"
+
+namespace {
+
+constexpr int D = SCL_VLAD_D;   // 512
+constexpr int K = SCL_VLAD_K;   // 64
+constexpr int WT_LD = D + 4;    // padded LDS row: conflict-free ds_read_b128 over 16 rows
+constexpr int NSPLIT = 2;       // location halves with their own slab in aggregate_kernel
+
+// ------------------------------------------------------------------ small kernels
+__global__ __launch_bounds__(256) void transpose_w_kernel(const float* __restrict__ w,
+                                                          float* __restrict__ wt) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;  // over D*K, k fastest
+  if (idx < D * K) wt[(idx % K) * D + idx / K] = w[idx];
+}
+
+enum RowMode { ASSIGN = 0, DASSIGN = 1 };
+
+struct RowTileArgs {
+  const void* x;       // [B,N,512]
+  const float* bt;     // ASSIGN: Wt [64][512];  DASSIGN: dUt [B][64][512]
+  int64_t bt_stride;   // floats between images (0 for ASSIGN)
+  int B, N, pre_l2;
+  // ASSIGN outputs
+  float* assign;       // [B,N,64]
+  float* logit;        // [B,N,64] or NULL
+  float* rnorm;        // [B,N]
+  // DASSIGN inputs / outputs
+  const float* a_in;     // [B,N,64]
+  const float* logit_in; // [B,N,64]
+  const float* rn_in;    // [B,N]
+  const float* cdu;      // [B,64]
+  float* ds;             // [B,N,64]
+  float* rowdot;         // [B,N]
+};
+
+// grid (ceil(tiles/4), B); block 256: every wave owns one 32-location tile of image b and
+// contracts it over all 512 channels against the LDS image of the [64][512] operand.
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void rowtile_kernel(RowTileArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float bt_lds[];  // [64][WT_LD]
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int b = blockIdx.y;
+  // stage the B operand: 64 rows x 512 floats, float4 per thread, coalesced
+  {
+    const float* src = p.bt + (int64_t)b * p.bt_stride;
+    for (int idx = threadIdx.x; idx < K * (D / 4); idx += 256) {
+      const int row = idx / (D / 4), c4 = idx % (D / 4);
+      *reinterpret_cast<f32x4*>(&bt_lds[row * WT_LD + c4 * 4]) =
+          *reinterpret_cast<const f32x4*>(src + row * D + c4 * 4);
+    }
+  }
+  __syncthreads();
+  const int n0 = (blockIdx.x * 4 + wid) * 32;
+  if (n0 >= p.N) return;
+  const int n = n0 + r;
+  const bool row_ok = n < p.N;
+  const T* xrow = reinterpret_cast<const T*>(p.x) + ((int64_t)b * p.N + (row_ok ? n : 0)) * D + 4 * h;
+  const float* b0 = &bt_lds[r * WT_LD + 4 * h];
+  const float* b1 = &bt_lds[(32 + r) * WT_LD + 4 * h];
+
+  f32x16 acc0 = zero16(), acc1 = zero16();
+  float ss = 0.f;
+  // 64 groups of 8 channels; half h takes channels 8t+4h..8t+4h+3 of each group (the same
+  // permutation on both operands).  Loads run one 8-group chunk ahead of the MFMAs.
+  f32x4 cur[8], nxt[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) cur[u] = Elem<T>::ld4(xrow + 8 * u);
+#pragma unroll 1
+  for (int chunk = 0; chunk < 8; ++chunk) {
+    if (chunk < 7) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) nxt[u] = Elem<T>::ld4(xrow + 64 * (chunk + 1) + 8 * u);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      f32x4 xa = cur[u];
+      if (!row_ok) xa = f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(b0 + 64 * chunk + 8 * u);
+      const f32x4 w1 = *reinterpret_cast<const f32x4*>(b1 + 64 * chunk + 8 * u);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        acc0 = mfma32(xa[c], w0[c], acc0);
+        acc1 = mfma32(xa[c], w1[c], acc1);
+        ss = fmaf(xa[c], xa[c], ss);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
+  }
+
+  if (MODE == ASSIGN) {
+    ss += __shfl_xor(ss, 32, 64);
+    const float rn = p.pre_l2 ? 1.0f / sqrtf(fmaxf(ss, 1e-12f)) : 1.0f;
+    if (h == 0 && row_ok) p.rnorm[(int64_t)b * p.N + n] = rn;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int row = acc_row(q, h);
+      const float rnr = __shfl(rn, row, 64);
+      const float s0 = acc0[q] * rnr, s1 = acc1[q] * rnr;
+      const float m = half_max(fmaxf(s0, s1));
+      const float e0 = expf(s0 - m), e1 = expf(s1 - m);
+      const float inv = 1.0f / half_sum(e0 + e1);
+      if (n0 + row < p.N) {
+        const int64_t o = ((int64_t)b * p.N + n0 + row) * K + r;
+        p.assign[o] = e0 * inv;
+        p.assign[o + 32] = e1 * inv;
+        if (p.logit) {
+          p.logit[o] = s0;
+          p.logit[o + 32] = s1;
+        }
+      }
+    }
+  } else {
+    const float c0 = p.cdu[b * K + r], c1 = p.cdu[b * K + 32 + r];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int row = acc_row(q, h);
+      const bool ok = n0 + row < p.N;
+      const int64_t g = (int64_t)b * p.N + (ok ? n0 + row : 0);
+      const int64_t o = g * K + r;
+      const float rnr = p.rn_in[g];
+      const float a0 = ok ? p.a_in[o] : 0.f, a1 = ok ? p.a_in[o + 32] : 0.f;
+      const float l0 = ok ? p.logit_in[o] : 0.f, l1 = ok ? p.logit_in[o + 32] : 0.f;
+      const float t0 = acc0[q] * rnr, t1 = acc1[q] * rnr;   // xhat · dU
+      const float da0 = t0 + c0, da1 = t1 + c1;             // + c · dU
+      const float dot = half_sum(a0 * da0 + a1 * da1);
+      const float ds0 = a0 * (da0 - dot), ds1 = a1 * (da1 - dot);
+      // <d xhat[n,:], xhat[n,:]> = sum_k a (xhat·dU) + ds (xhat·W)
+      const float rd = half_sum(a0 * t0 + a1 * t1 + ds0 * l0 + ds1 * l1);
+      if (ok) {
+        p.ds[o] = ds0;
+        p.ds[o + 32] = ds1;
+        if (r == 0) p.rowdot[g] = rd;
+      }
+    }
+  }
+}
+
+// V_part[b, half, d, k] = sum_{n in half} x[b,n,d] * (coefn[b,n,k] * rn[b,n])
+// grid (16 channel tiles, NSPLIT, B); block 256; wave w contracts its quarter of the half.
+template <typename T>
+__global__ __launch_bounds__(256) void aggregate_kernel(const void* __restrict__ xv,
+                                                        const float* __restrict__ coefn,
+                                                        const float* __restrict__ rn, int N,
+                                                        float* __restrict__ part,
+                                                        float* __restrict__ colsum_part) {
+  __shared__ float red[4][2][16][64];
+  __shared__ float csum[4][64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int d0 = blockIdx.x * 32, half = blockIdx.y, b = blockIdx.z;
+  int per = (N + NSPLIT * 4 - 1) / (NSPLIT * 4);
+  per = (per + 1) & ~1;
+  const int chunk = half * 4 + wid;
+  const int n_begin = chunk * per;
+  int n_end = n_begin + per;
+  if (n_end > N) n_end = N;
+  const T* x = reinterpret_cast<const T*>(xv) + (int64_t)b * N * D + d0 + r;
+  const float* cf = coefn + (int64_t)b * N * K + r;
+  const float* rnb = rn + (int64_t)b * N;
+  f32x16 acc0 = zero16(), acc1 = zero16();
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll 4
+  for (int nn = n_begin; nn < n_end; nn += 2) {
+    const int n = nn + h;
+    const bool ok = n < n_end;
+    const int ns = ok ? n : n_begin;
+    const float xval = Elem<T>::ld(x + (int64_t)ns * D);
+    const float wgt = ok ? rnb[ns] : 0.f;
+    const float a0 = cf[(int64_t)ns * K], a1 = cf[(int64_t)ns * K + 32];
+    acc0 = mfma32(xval, a0 * wgt, acc0);
+    acc1 = mfma32(xval, a1 * wgt, acc1);
+    s0 += ok ? a0 : 0.f;
+    s1 += ok ? a1 : 0.f;
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    red[wid][0][q][lane] = acc0[q];
+    red[wid][1][q][lane] = acc1[q];
+  }
+  s0 += __shfl_xor(s0, 32, 64);
+  s1 += __shfl_xor(s1, 32, 64);
+  if (h == 0) {
+    csum[wid][r] = s0;
+    csum[wid][32 + r] = s1;
+  }
+  __syncthreads();
+  float* out = part + (((int64_t)b * NSPLIT + half) * D + d0) * K;
+  for (int idx = threadIdx.x; idx < 2 * 16 * 64; idx += 256) {
+    const int kt = idx >> 10, q = (idx >> 6) & 15, l = idx & 63;
+    const float v = (red[0][kt][q][l] + red[1][kt][q][l]) + (red[2][kt][q][l] + red[3][kt][q][l]);
+    out[acc_row(q, l >> 5) * K + kt * 32 + (l & 31)] = v;
+  }
+  if (colsum_part && blockIdx.x == 0 && threadIdx.x < 64) {
+    const int k = threadIdx.x;
+    colsum_part[((int64_t)b * NSPLIT + half) * K + k] =
+        (csum[0][k] + csum[1][k]) + (csum[2][k] + csum[3][k]);
+  }
+}
+
+// per-image normalisation state shared by finish (forward) and bwd_prep (backward)
+struct VladNorm {
+  float u[32];   // this thread's 32 elements: d = dg*32 + i, k = threadIdx % 64
+  float q;       // intra-norm factor of column k
+  float g;       // global factor
+};
+
+// block 1024: thread -> k = t & 63, dg = t >> 6 (16 groups of 32 channels)
+__device__ __forceinline__ void vlad_norms(VladNorm& v, float* colbuf /*[16][64]*/,
+                                           float* scratch) {
+  const int k = threadIdx.x & 63, dg = threadIdx.x >> 6;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) ss = fmaf(v.u[i], v.u[i], ss);
+  colbuf[dg * 64 + k] = ss;
+  __syncthreads();
+  float col = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) col += colbuf[j * 64 + k];
+  __syncthreads();
+  // matconvnetNormalize: x / sqrt(sum x^2 + 1e-12), epsilon inside the sqrt
+  v.q = 1.0f / sqrtf(col + 1e-12f);
+  float tot = 0.f;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const float vn = v.u[i] * v.q;
+    tot = fmaf(vn, vn, tot);
+  }
+  tot = block_reduce<0>(tot, scratch);
+  v.g = 1.0f / sqrtf(tot + 1e-12f);
+}
+
+// grid B; block 1024.
+__global__ __launch_bounds__(1024) void finish_kernel(const float* __restrict__ part,
+                                                      const float* __restrict__ colsum_part,
+                                                      const float* __restrict__ centers,
+                                                      float* __restrict__ out,
+                                                      float* __restrict__ save_vlad) {
+  __shared__ float colbuf[16 * 64];
+  __shared__ float scratch[32];
+  const int b = blockIdx.x, k = threadIdx.x & 63, dg = threadIdx.x >> 6;
+  const float asum = colsum_part[((int64_t)b * NSPLIT + 0) * K + k] +
+                     colsum_part[((int64_t)b * NSPLIT + 1) * K + k];
+  VladNorm v;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const int d = dg * 32 + i;
+    const float p0 = part[(((int64_t)b * NSPLIT + 0) * D + d) * K + k];
+    const float p1 = part[(((int64_t)b * NSPLIT + 1) * D + d) * K + k];
+    v.u[i] = (p0 + p1) + centers[d * K + k] * asum;
+  }
+  if (save_vlad) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) save_vlad[((int64_t)b * (D + 1) + dg * 32 + i) * K + k] = v.u[i];
+    if (dg == 0) save_vlad[((int64_t)b * (D + 1) + D) * K + k] = asum;
+  }
+  vlad_norms(v, colbuf, scratch);
+#pragma unroll
+  for (int i = 0; i < 32; ++i)
+    out[(int64_t)b * D * K + (dg * 32 + i) * K + k] = v.u[i] * v.q * v.g;
+}
+
+// grid B; block 1024.  Gradient through the global and the intra normalisation.
+__global__ __launch_bounds__(1024) void bwd_prep_kernel(const float* __restrict__ save_vlad,
+                                                        const float* __restrict__ grad_out,
+                                                        const float* __restrict__ centers,
+                                                        float* __restrict__ du,
+                                                        float* __restrict__ dut,
+                                                        float* __restrict__ cdu) {
+  __shared__ float colbuf[16 * 64];
+  __shared__ float scratch[32];
+  const int b = blockIdx.x, k = threadIdx.x & 63, dg = threadIdx.x >> 6;
+  VladNorm v;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) v.u[i] = save_vlad[((int64_t)b * (D + 1) + dg * 32 + i) * K + k];
+  vlad_norms(v, colbuf, scratch);
+  float go[32];
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    go[i] = grad_out[(int64_t)b * D * K + (dg * 32 + i) * K + k];
+    t = fmaf(go[i], v.u[i] * v.q * v.g, t);
+  }
+  t = block_reduce<0>(t, scratch);
+  // out = Vn g, g = (sum Vn^2 + eps)^-1/2  ->  dVn = g (dOut - out <dOut,out>)
+  float rk = 0.f;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const float vn = v.u[i] * v.q;
+    go[i] = v.g * (go[i] - vn * v.g * t);
+    rk = fmaf(go[i], vn, rk);
+  }
+  __syncthreads();
+  colbuf[dg * 64 + k] = rk;
+  __syncthreads();
+  float r = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) r += colbuf[j * 64 + k];
+  __syncthreads();
+  // Vn[:,k] = U[:,k] q_k  ->  dU = q (dVn - Vn <dVn,Vn>_k)
+  float cd = 0.f;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const int d = dg * 32 + i;
+    const float vn = v.u[i] * v.q;
+    const float val = v.q * (go[i] - vn * r);
+    du[((int64_t)b * D + d) * K + k] = val;
+    dut[((int64_t)b * K + k) * D + d] = val;
+    cd = fmaf(val, centers[d * K + k], cd);
+  }
+  colbuf[dg * 64 + k] = cd;
+  __syncthreads();
+  if (dg == 0) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s += colbuf[j * 64 + k];
+    cdu[b * K + k] = s;
+  }
+}
+
+// grad_x tile: dxhat[n, d] = sum_k a[n,k] dU[d,k] + ds[n,k] W[d,k]; then the Jacobian of
+// the channel L2 norm.  grid (ceil(N/32), B); block 256; wave w owns channels [128w, 128w+128).
+template <typename T>
+__global__ __launch_bounds__(256) void dx_kernel(const void* __restrict__ xv,
+                                                 const float* __restrict__ a,
+                                                 const float* __restrict__ ds,
+                                                 const float* __restrict__ rn,
+                                                 const float* __restrict__ rowdot,
+                                                 const float* __restrict__ du,
+                                                 const float* __restrict__ w, int N, int pre_l2,
+                                                 void* __restrict__ gxv) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int b = blockIdx.y, n0 = blockIdx.x * 32;
+  const int n = n0 + r;
+  const bool row_ok = n < N;
+  const int64_t grow = (int64_t)b * N + (row_ok ? n : 0);
+  const int dbase = wid * 128;
+  f32x16 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = zero16();
+  const float* dub = du + (int64_t)b * D * K;
+#pragma unroll 1
+  for (int src = 0; src < 2; ++src) {
+    const float* arow = (src == 0 ? a : ds) + grow * K + 4 * h;
+    const float* bmat = (src == 0 ? dub : w) + (int64_t)(dbase + r) * K + 4 * h;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      f32x4 av = *reinterpret_cast<const f32x4*>(arow + 8 * t);
+      if (!row_ok) av = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 bv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        bv[j] = *reinterpret_cast<const f32x4*>(bmat + (int64_t)j * 32 * K + 8 * t);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = mfma32(av[c], bv[j][c], acc[j]);
+    }
+  }
+  const T* x = reinterpret_cast<const T*>(xv);
+  T* gx = reinterpret_cast<T*>(gxv);
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int row = n0 + acc_row(q, h);
+    if (row >= N) continue;
+    const int64_t g = (int64_t)b * N + row;
+    const float rnr = pre_l2 ? rn[g] : 1.0f;
+    const float rd = rowdot[g];
+    // x * rsqrt(max(ss, eps)): when the clamp is active the op is a plain scale
+    const bool proj = pre_l2 && rnr < 1.0e6f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t o = g * D + dbase + j * 32 + r;
+      float val = acc[j][q];
+      if (proj) val -= Elem<T>::ld(x + o) * rnr * rd;
+      Elem<T>::st(gx + o, val * rnr);
+    }
+  }
+}
+
+// grad_w[d,k] = sum_b (slab0 + slab1);  grad_c[d,k] = sum_b dU[b,d,k] * asum[b,k]
+__global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restrict__ wpart,
+                                                           const float* __restrict__ du,
+                                                           const float* __restrict__ save_vlad,
+                                                           int B, float* __restrict__ grad_w,
+                                                           float* __restrict__ grad_c) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= D * K) return;
+  const int k = idx % K;
+  float gw = 0.f, gc = 0.f;
+  for (int b = 0; b < B; ++b) {
+    gw += wpart[((int64_t)b * NSPLIT + 0) * D * K + idx] + wpart[((int64_t)b * NSPLIT + 1) * D * K + idx];
+    gc = fmaf(du[(int64_t)b * D * K + idx], save_vlad[((int64_t)b * (D + 1) + D) * K + k], gc);
+  }
+  grad_w[idx] = gw;
+  grad_c[idx] = gc;
+}
+
+// ---------------------------------------------------------------------- host side
+constexpr size_t kRowTileLds = (size_t)K * WT_LD * sizeof(float);  // 132,096 B
+
+template <typename T, int MODE>
+void launch_rowtile(const RowTileArgs& a, hipStream_t st) {
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowtile_kernel<T, MODE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRowTileLds);
+  });
+  const int tiles = (a.N + 31) / 32;
+  hipLaunchKernelGGL((rowtile_kernel<T, MODE>), dim3((tiles + 3) / 4, a.B), dim3(256), kRowTileLds,
+                     st, a);
+}
+
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(void* p) : base((char*)p) {}
+  float* take(size_t floats) {
+    float* ptr = (float*)(base + off);
+    off += scl_round256(floats * sizeof(float));
+    return ptr;
+  }
+};
+
+struct FwdWs {
+  float *wt, *part, *colsum, *assign, *rnorm;
+  size_t total;
+};
+inline FwdWs carve_fwd(void* ws, int B, int N) {
+  Carver c(ws);
+  FwdWs w;
+  w.wt = c.take((size_t)D * K);
+  w.part = c.take((size_t)B * NSPLIT * D * K);
+  w.colsum = c.take((size_t)B * NSPLIT * K);
+  w.assign = c.take((size_t)B * N * K);
+  w.rnorm = c.take((size_t)B * N);
+  w.total = c.off;
+  return w;
+}
+
+struct BwdWs {
+  float *du, *dut, *cdu, *ds, *rowdot, *wpart;
+  size_t total;
+};
+inline BwdWs carve_bwd(void* ws, int B, int N) {
+  Carver c(ws);
+  BwdWs w;
+  w.du = c.take((size_t)B * D * K);
+  w.dut = c.take((size_t)B * D * K);
+  w.cdu = c.take((size_t)B * K);
+  w.ds = c.take((size_t)B * N * K);
+  w.rowdot = c.take((size_t)B * N);
+  w.wpart = c.take((size_t)B * NSPLIT * D * K);
+  w.total = c.off;
+  return w;
+}
+
+inline bool shape_ok(int B, int N) { return B >= 1 && N >= 1 && B <= 65535 && N <= (1 << 22); }
+
+}  // namespace
+
+extern "C" size_t scl_netvlad_fwd_workspace_bytes(int B, int N) {
+  if (!shape_ok(B, N)) return 0;
+  return carve_fwd(nullptr, B, N).total;
+}
+
+extern "C" int scl_netvlad_fwd(const void* x, int x_dtype, const float* assign_w,
+                               const float* centers, int B, int N, int pre_l2, float* out,
+                               float* save_assign, float* save_logit, float* save_rnorm,
+                               float* save_vlad, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+  if (!x || !assign_w || !centers || !out || !workspace) return SCL_E_NULL;
+  if (!shape_ok(B, N)) return SCL_E_SHAPE;
+  if (x_dtype != SCL_DT_F32 && x_dtype != SCL_DT_BF16) return SCL_E_KIND;
+  if (((uintptr_t)x % 16) != 0) return SCL_E_SHAPE;
+  if (!scl_aligned256(workspace)) return SCL_E_WORKSPACE;
+  FwdWs w = carve_fwd(workspace, B, N);
+  if (workspace_bytes < w.total) return SCL_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  float* assign = save_assign ? save_assign : w.assign;
+  float* rnorm = save_rnorm ? save_rnorm : w.rnorm;
+
+  hipLaunchKernelGGL(transpose_w_kernel, dim3(D * K / 256), dim3(256), 0, st, assign_w, w.wt);
+  RowTileArgs a{};
+  a.x = x;
+  a.bt = w.wt;
+  a.bt_stride = 0;
+  a.B = B;
+  a.N = N;
+  a.pre_l2 = pre_l2 ? 1 : 0;
+  a.assign = assign;
+  a.logit = save_logit;
+  a.rnorm = rnorm;
+  if (x_dtype == SCL_DT_F32) {
+    launch_rowtile<float, ASSIGN>(a, st);
+    hipLaunchKernelGGL(aggregate_kernel<float>, dim3(D / 32, NSPLIT, B), dim3(256), 0, st, x,
+                       (const float*)assign, (const float*)rnorm, N, w.part, w.colsum);
+  } else {
+    launch_rowtile<unsigned short, ASSIGN>(a, st);
+    hipLaunchKernelGGL(aggregate_kernel<unsigned short>, dim3(D / 32, NSPLIT, B), dim3(256), 0, st,
+                       x, (const float*)assign, (const float*)rnorm, N, w.part, w.colsum);
+  }
+  hipLaunchKernelGGL(finish_kernel, dim3(B), dim3(1024), 0, st, (const float*)w.part,
+                     (const float*)w.colsum, centers, out, save_vlad);
+  return scl_launch_status();
+}
+
+extern "C" size_t scl_netvlad_bwd_workspace_bytes(int B, int N) {
+  if (!shape_ok(B, N)) return 0;
+  return carve_bwd(nullptr, B, N).total;
+}
+
+extern "C" int scl_netvlad_bwd(const void* x, int x_dtype, const float* assign_w,
+                               const float* centers, const float* grad_out,
+                               const float* save_assign, const float* save_logit,
+                               const float* save_rnorm, const float* save_vlad, int B, int N,
+                               int pre_l2, void* grad_x, float* grad_w, float* grad_c,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+  if (!x || !assign_w || !centers || !grad_out || !save_assign || !save_logit || !save_rnorm ||
+      !save_vlad || !grad_x || !grad_w || !grad_c || !workspace)
+    return SCL_E_NULL;
+  if (!shape_ok(B, N)) return SCL_E_SHAPE;
+  if (x_dtype != SCL_DT_F32 && x_dtype != SCL_DT_BF16) return SCL_E_KIND;
+  if (((uintptr_t)x % 16) != 0) return SCL_E_SHAPE;
+  if (!scl_aligned256(workspace)) return SCL_E_WORKSPACE;
+  BwdWs w = carve_bwd(workspace, B, N);
+  if (workspace_bytes < w.total) return SCL_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+
+  hipLaunchKernelGGL(bwd_prep_kernel, dim3(B), dim3(1024), 0, st, save_vlad, grad_out, centers,
+                     w.du, w.dut, w.cdu);
+  RowTileArgs a{};
+  a.x = x;
+  a.bt = w.dut;
+  a.bt_stride = (int64_t)D * K;
+  a.B = B;
+  a.N = N;
+  a.pre_l2 = pre_l2 ? 1 : 0;
+  a.a_in = save_assign;
+  a.logit_in = save_logit;
+  a.rn_in = save_rnorm;
+  a.cdu = w.cdu;
+  a.ds = w.ds;
+  a.rowdot = w.rowdot;
+  const dim3 dxgrid((N + 31) / 32, B);
+  if (x_dtype == SCL_DT_F32) {
+    launch_rowtile<float, DASSIGN>(a, st);
+    hipLaunchKernelGGL(aggregate_kernel<float>, dim3(D / 32, NSPLIT, B), dim3(256), 0, st, x,
+                       (const float*)w.ds, save_rnorm, N, w.wpart, (float*)nullptr);
+    hipLaunchKernelGGL(dx_kernel<float>, dxgrid, dim3(256), 0, st, x, save_assign,
+                       (const float*)w.ds, save_rnorm, (const float*)w.rowdot,
+                       (const float*)w.du, assign_w, N, pre_l2 ? 1 : 0, grad_x);
+  } else {
+    launch_rowtile<unsigned short, DASSIGN>(a, st);
+    hipLaunchKernelGGL(aggregate_kernel<unsigned short>, dim3(D / 32, NSPLIT, B), dim3(256), 0, st,
+                       x, (const float*)w.ds, save_rnorm, N, w.wpart, (float*)nullptr);
+    hipLaunchKernelGGL(dx_kernel<unsigned short>, dxgrid, dim3(256), 0, st, x, save_assign,
+                       (const float*)w.ds, save_rnorm, (const float*)w.rowdot,
+                       (const float*)w.du, assign_w, N, pre_l2 ? 1 : 0, grad_x);
+  }
+  hipLaunchKernelGGL(wgrad_finish_kernel, dim3(D * K / 256), dim3(256), 0, st,
+                     (const float*)w.wpart, (const float*)w.du, save_vlad, B, grad_w, grad_c);
+  return scl_launch_status();
+}

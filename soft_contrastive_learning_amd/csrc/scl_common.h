@@ -1,0 +1,112 @@
+// Shared device helpers for the gfx950 kernels.  Wave = 64 lanes, hard-coded.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "scl_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+
+#define SCL_WAVE 64
+
+// v_mfma_f32_32x32x2_f32: D[32x32] += A[32x2] * B[2x32], exact f32 (a k-ordered
+// fmaf chain).  Lane l supplies A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31].
+// Accumulator register r of lane l is D[row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)][col = l & 31].
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int acc_row(int reg, int half) {
+  return (reg & 3) + 8 * (reg >> 2) + 4 * half;
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+
+__device__ __forceinline__ float bf16_to_f32(unsigned short v) {
+  return __uint_as_float(((unsigned)v) << 16);
+}
+// round-to-nearest-even f32 -> bf16 (a plain cast keeps NaN a NaN on gfx950)
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, b);
+}
+
+// element loads for the two feature-map dtypes
+template <typename T>
+struct Elem;
+template <>
+struct Elem<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ f32x4 ld4(const float* p) {
+    return *reinterpret_cast<const f32x4*>(p);
+  }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <>
+struct Elem<unsigned short> {
+  static __device__ __forceinline__ float ld(const unsigned short* p) { return bf16_to_f32(*p); }
+  static __device__ __forceinline__ f32x4 ld4(const unsigned short* p) {
+    u16x4 v = *reinterpret_cast<const u16x4*>(p);
+    f32x4 r;
+    r[0] = bf16_to_f32(v[0]);
+    r[1] = bf16_to_f32(v[1]);
+    r[2] = bf16_to_f32(v[2]);
+    r[3] = bf16_to_f32(v[3]);
+    return r;
+  }
+  static __device__ __forceinline__ void st(unsigned short* p, float v) { *p = f32_to_bf16(v); }
+};
+
+// butterfly reductions inside one 32-lane half of the wave (xor 1..16)
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+  for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+__device__ __forceinline__ float half_max(float v) {
+#pragma unroll
+  for (int m = 1; m < 32; m <<= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v = fminf(v, __shfl_xor(v, m, 64));
+  return v;
+}
+
+// block-wide reductions through a caller-provided LDS scratch of >= 32 floats
+template <int OP>  // 0 sum, 1 max, 2 min
+__device__ __forceinline__ float block_reduce(float v, float* scratch) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = OP == 0 ? wave_sum(v) : (OP == 1 ? wave_max(v) : wave_min(v));
+  __syncthreads();
+  if (lane == 0) scratch[wid] = v;
+  __syncthreads();
+  float r = scratch[0];
+  for (int i = 1; i < nw; ++i) {
+    float o = scratch[i];
+    r = OP == 0 ? r + o : (OP == 1 ? fmaxf(r, o) : fminf(r, o));
+  }
+  return r;
+}
+
+static inline int scl_launch_status() { return (int)hipGetLastError(); }
+static inline bool scl_aligned256(const void* p) { return (((uintptr_t)p) & 255u) == 0; }
+static inline size_t scl_round256(size_t n) { return (n + 255u) & ~(size_t)255u; }

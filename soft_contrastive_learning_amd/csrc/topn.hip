@@ -1,0 +1,376 @@
+// Exact Euclidean top-n retrieval on gfx950.
+//
+// Reference semantics: KDTree(ref_f).query(query_f, k=N, return_distance=True,
+// sort_results=True) (evaluation/top-n.py:103-108; train/train.py:1181-1182) — exact
+// L2 nearest neighbours in ascending order, float64 inside scikit-learn.  At d=256 a
+// tree degenerates to brute force; here the brute force is a fused contraction +
+// selection so the Q x R distance matrix (4 GB at 10k x 100k) never exists:
+//   refnorm_kernel     ||r||^2 per reference row
+//   topn_scan_kernel   per (128-query tile, reference split): score = ||r||^2 - 2 q.r on
+//                      v_mfma_f32_32x32x2_f32 (queries resident in registers, reference
+//                      tiles double-buffered through LDS), threshold-and-append
+//                      selection into per-query LDS lists of 64, compacted by rank
+//                      counting to the best 32 whenever a list could overflow
+//   topn_rerank_kernel merges the per-split lists by f32 score, recomputes the best 32
+//                      candidates' distances exactly in float64 as sum (q - r)^2, sorts by
+//                      (distance, index) and emits the first n
+// The f32 pass only nominates candidates (n <= 25 of 32 kept); the emitted
+// order and distances are float64-exact.
+#include <limits.h>
+
+#include <mutex>
+
+#include "scl_common.h"
+
+namespace {
+
+constexpr int KEEP = 32;   // candidates kept per (query, split)
+constexpr int CAP = 64;    // list capacity = KEEP + one 32-reference tile
+constexpr int QW = 4;      // waves (32-query tiles) per workgroup
+constexpr int kMaxN = 25;
+
+__global__ __launch_bounds__(256) void refnorm_kernel(const float* __restrict__ ref, int R, int d,
+                                                      float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const float* p = ref + (int64_t)row * d;
+  float s = 0.f;
+  for (int e = lane * 4; e < d; e += 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p + e);
+    s = fmaf(v[0], v[0], s);
+    s = fmaf(v[1], v[1], s);
+    s = fmaf(v[2], v[2], s);
+    s = fmaf(v[3], v[3], s);
+  }
+  s = wave_sum(s);
+  if (lane == 0) out[row] = s;
+}
+
+// Rank-count compaction of one query's list by one wave: entry e = lane.  Keeps the
+// KEEP smallest (score, index) pairs in sorted order and returns the new threshold.
+__device__ __forceinline__ float compact_list(float* sc, int* ix, int count, int lane) {
+  const bool valid = lane < count;
+  const float ms = valid ? sc[lane] : INFINITY;
+  const int mi = valid ? ix[lane] : INT_MAX;
+  int rank = 0;
+  for (int e = 0; e < CAP; ++e) {
+    const float os = e < count ? sc[e] : INFINITY;
+    const int oi = e < count ? ix[e] : INT_MAX;
+    rank += (os < ms) || (os == ms && oi < mi);
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (valid && rank < KEEP) {
+    sc[rank] = ms;
+    ix[rank] = mi;
+  }
+  __builtin_amdgcn_wave_barrier();
+  return count >= KEEP ? sc[KEEP - 1] : INFINITY;
+}
+
+// grid (ceil(Q/128), splits); block 256.  Dynamic LDS:
+//   tile[2][32][d+4] | refn[2][32] | lsc[QW][32][CAP] | lix[QW][32][CAP] | cnt[QW][32] | tau[QW][32]
+template <int D8>
+__global__ __launch_bounds__(256) void topn_scan_kernel(const float* __restrict__ ref,
+                                                        const float* __restrict__ refnorm, int R,
+                                                        const float* __restrict__ query, int Q,
+                                                        int refs_per_split,
+                                                        float* __restrict__ cand_sc,
+                                                        int* __restrict__ cand_ix) {
+  constexpr int d = D8 * 8;
+  constexpr int LD = d + 4;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* tile = lds;                                   // 2 * 32 * LD
+  float* refn = tile + 2 * 32 * LD;                    // 2 * 32
+  float* lsc = refn + 64;                              // QW * 32 * CAP
+  int* lix = reinterpret_cast<int*>(lsc + QW * 32 * CAP);
+  int* cnt = lix + QW * 32 * CAP;                      // QW * 32
+  float* tau = reinterpret_cast<float*>(cnt + QW * 32);
+
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int q0 = (blockIdx.x * QW + wid) * 32;
+  const int split = blockIdx.y;
+  const int r_begin = split * refs_per_split;
+  int r_end = r_begin + refs_per_split;
+  if (r_end > R) r_end = R;
+  const int ntiles = (r_end - r_begin + 31) / 32;
+
+  // query fragments: lane (r, h) keeps q[q0 + r][8t + 4h .. +3] for every t
+  f32x4 qf[D8];
+  {
+    const int qrow = q0 + r;
+    const float* qp = query + (int64_t)(qrow < Q ? qrow : 0) * d + 4 * h;
+#pragma unroll
+    for (int t = 0; t < D8; ++t) {
+      qf[t] = *reinterpret_cast<const f32x4*>(qp + 8 * t);
+      if (qrow >= Q) qf[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  float* my_sc = lsc + wid * 32 * CAP;
+  int* my_ix = lix + wid * 32 * CAP;
+  int* my_cnt = cnt + wid * 32;
+  float* my_tau = tau + wid * 32;
+  if (lane < 32) {
+    my_cnt[lane] = 0;
+    my_tau[lane] = INFINITY;
+  }
+
+  // staging: 256 threads move one [32][d] tile as float4 (D8*2*32/256 = D8/4 per thread)
+  constexpr int V4 = (32 * d / 4) / 256;  // float4 per thread
+  static_assert(V4 >= 1, "d too small for the staging layout");
+  f32x4 stage[V4];
+  float stage_n = 0.f;
+  auto stage_load = [&](int t) {
+    const int rb = r_begin + t * 32;
+#pragma unroll
+    for (int v = 0; v < V4; ++v) {
+      const int idx = v * 256 + threadIdx.x;
+      const int row = idx / (d / 4), c4 = idx % (d / 4);
+      const int rr = rb + row;
+      stage[v] = rr < r_end ? *reinterpret_cast<const f32x4*>(ref + (int64_t)rr * d + c4 * 4)
+                            : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (threadIdx.x < 32) {
+      const int rr = rb + threadIdx.x;
+      stage_n = rr < r_end ? refnorm[rr] : INFINITY;  // padding rows never qualify
+    }
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int v = 0; v < V4; ++v) {
+      const int idx = v * 256 + threadIdx.x;
+      const int row = idx / (d / 4), c4 = idx % (d / 4);
+      *reinterpret_cast<f32x4*>(&tile[(buf * 32 + row) * LD + c4 * 4]) = stage[v];
+    }
+    if (threadIdx.x < 32) refn[buf * 32 + threadIdx.x] = stage_n;
+  };
+
+  if (ntiles > 0) {
+    stage_load(0);
+    stage_store(0);
+  }
+  __syncthreads();
+  float tq[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) tq[q] = INFINITY;
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < ntiles) stage_load(t + 1);
+    const float* bp = &tile[(buf * 32 + r) * LD + 4 * h];
+    f32x16 acc = zero16();
+#pragma unroll
+    for (int u = 0; u < D8; ++u) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(bp + 8 * u);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc = mfma32(qf[u][c], bv[c], acc);
+    }
+    const float rnj = refn[buf * 32 + r];
+    const int ridx = r_begin + t * 32 + r;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const float sc = rnj - 2.0f * acc[q];
+      if (sc < tq[q]) {
+        const int row = acc_row(q, h);
+        const int pos = atomicAdd(&my_cnt[row], 1);
+        my_sc[row * CAP + pos] = sc;
+        my_ix[row * CAP + pos] = ridx;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // compaction whenever a list could overflow on the next tile
+    const int c = lane < 32 ? my_cnt[lane] : 0;
+    unsigned long long need = __ballot(c > KEEP);
+    if (need) {
+      while (need) {
+        const int row = __ffsll((long long)need) - 1;
+        need &= need - 1;
+        const int count = my_cnt[row];
+        const float nt = compact_list(my_sc + row * CAP, my_ix + row * CAP, count, lane);
+        if (lane == 0) {
+          my_cnt[row] = KEEP;
+          my_tau[row] = nt;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < 16; ++q) tq[q] = my_tau[acc_row(q, h)];
+    }
+    if (t + 1 < ntiles) stage_store(buf ^ 1);
+    __syncthreads();
+  }
+
+  // final ordering of every list and hand-off: [Q][splits][KEEP]
+  for (int row = 0; row < 32; ++row) {
+    const int count = my_cnt[row];
+    compact_list(my_sc + row * CAP, my_ix + row * CAP, count, lane);
+    const int qrow = q0 + row;
+    if (qrow < Q && lane < KEEP) {
+      const int64_t o = ((int64_t)qrow * gridDim.y + split) * KEEP + lane;
+      const bool have = lane < (count < KEEP ? count : KEEP);
+      cand_sc[o] = have ? my_sc[row * CAP + lane] : INFINITY;
+      cand_ix[o] = have ? my_ix[row * CAP + lane] : -1;
+    }
+  }
+}
+
+// One workgroup per query.  LDS: sc[M] | ix[M] with M = splits * KEEP.
+__global__ __launch_bounds__(256) void topn_rerank_kernel(const float* __restrict__ ref,
+                                                          const float* __restrict__ query, int d,
+                                                          int splits, int n, int64_t idx_offset,
+                                                          const float* __restrict__ cand_sc,
+                                                          const int* __restrict__ cand_ix,
+                                                          int64_t* __restrict__ idx_out,
+                                                          double* __restrict__ dist_out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ int best_ix[KEEP];
+  __shared__ double best_d[KEEP];
+  const int M = splits * KEEP;
+  float* sc = lds;
+  int* ix = reinterpret_cast<int*>(lds + M);
+  const int qi = blockIdx.x;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int e = threadIdx.x; e < M; e += 256) {
+    sc[e] = cand_sc[(int64_t)qi * M + e];
+    ix[e] = cand_ix[(int64_t)qi * M + e];
+  }
+  if (threadIdx.x < KEEP) best_ix[threadIdx.x] = -1;
+  __syncthreads();
+  // stage 1: best KEEP by f32 score over all splits
+  for (int e = threadIdx.x; e < M; e += 256) {
+    const float ms = sc[e];
+    const int mi = ix[e];
+    if (mi < 0) continue;
+    int rank = 0;
+    for (int o = 0; o < M; ++o) {
+      const float os = sc[o];
+      const int oi = ix[o];
+      rank += oi >= 0 && ((os < ms) || (os == ms && oi < mi));
+    }
+    if (rank < KEEP) best_ix[rank] = mi;
+  }
+  __syncthreads();
+  // stage 2: exact float64 squared distance, direct (q - r)^2 form, one wave per candidate
+  const float* qp = query + (int64_t)qi * d;
+  for (int c = wid; c < KEEP; c += 4) {
+    const int ri = best_ix[c];
+    double s = 0.0;
+    if (ri >= 0) {
+      const float* rp = ref + (int64_t)ri * d;
+      for (int e = lane; e < d; e += 64) {
+        const double df = (double)qp[e] - (double)rp[e];
+        s = fma(df, df, s);
+      }
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) s += __shfl_xor(s, m, 64);
+    if (lane == 0) best_d[c] = ri >= 0 ? s : INFINITY;
+  }
+  __syncthreads();
+  // stage 3: order by (distance, index), emit the first n
+  if (threadIdx.x < KEEP) {
+    const double md = best_d[threadIdx.x];
+    const int mi = best_ix[threadIdx.x];
+    if (mi >= 0) {
+      int rank = 0;
+      for (int o = 0; o < KEEP; ++o) {
+        const int oi = best_ix[o];
+        const double od = best_d[o];
+        rank += oi >= 0 && ((od < md) || (od == md && oi < mi));
+      }
+      if (rank < n) {
+        idx_out[(int64_t)qi * n + rank] = (int64_t)mi + idx_offset;
+        dist_out[(int64_t)qi * n + rank] = sqrt(md);
+      }
+    }
+  }
+}
+
+struct TopnPlan {
+  int qtiles, splits, refs_per_split;
+};
+inline TopnPlan topn_plan(int R, int Q) {
+  TopnPlan p;
+  p.qtiles = (Q + 32 * QW - 1) / (32 * QW);
+  const int max_splits = (R + 32 * KEEP - 1) / (32 * KEEP);  // keep >= 32 tiles per split
+  int best = 1;
+  double best_cost = 1e30;
+  for (int s = 1; s <= 64 && s <= (max_splits < 1 ? 1 : max_splits); ++s) {
+    const long wgs = (long)p.qtiles * s;
+    const long rounds = (wgs + 255) / 256;
+    // time ~ rounds * (R / s); prefer fewer splits on ties (less merge work)
+    const double cost = (double)rounds * ((double)R / s) * (1.0 + 0.002 * s);
+    if (cost < best_cost) {
+      best_cost = cost;
+      best = s;
+    }
+  }
+  p.splits = best;
+  int per = (R + best - 1) / best;
+  per = (per + 31) / 32 * 32;
+  p.refs_per_split = per;
+  p.splits = (R + per - 1) / per;
+  return p;
+}
+
+inline size_t scan_lds_bytes(int d) {
+  return ((size_t)2 * 32 * (d + 4) + 64 + (size_t)QW * 32 * CAP * 2 + QW * 32 * 2) * sizeof(float);
+}
+
+template <int D8>
+void launch_scan(const TopnPlan& p, const float* ref, const float* refnorm, int R,
+                 const float* query, int Q, float* cs, int* ci, hipStream_t st) {
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&topn_scan_kernel<D8>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)scan_lds_bytes(D8 * 8));
+  });
+  hipLaunchKernelGGL((topn_scan_kernel<D8>), dim3(p.qtiles, p.splits), dim3(256),
+                     scan_lds_bytes(D8 * 8), st, ref, refnorm, R, query, Q, p.refs_per_split, cs,
+                     ci);
+}
+
+inline bool topn_shape_ok(int R, int Q, int d, int n) {
+  const bool d_ok = d == 32 || d == 64 || d == 128 || d == 256;
+  return R >= 1 && Q >= 1 && d_ok && n >= 1 && n <= kMaxN && n <= R;
+}
+
+}  // namespace
+
+extern "C" size_t scl_topn_l2_workspace_bytes(int R, int Q, int d, int n) {
+  if (!topn_shape_ok(R, Q, d, n)) return 0;
+  const TopnPlan p = topn_plan(R, Q);
+  return scl_round256((size_t)R * sizeof(float)) +
+         2 * scl_round256((size_t)Q * p.splits * KEEP * sizeof(float));
+}
+
+extern "C" int scl_topn_l2(const float* ref, int R, const float* query, int Q, int d, int n,
+                           int64_t idx_offset, int64_t* idx_out, double* dist_out, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+  if (!ref || !query || !idx_out || !dist_out || !workspace) return SCL_E_NULL;
+  if (!topn_shape_ok(R, Q, d, n)) return SCL_E_SHAPE;
+  if (((uintptr_t)ref % 16) || ((uintptr_t)query % 16)) return SCL_E_SHAPE;
+  if (!scl_aligned256(workspace) || workspace_bytes < scl_topn_l2_workspace_bytes(R, Q, d, n))
+    return SCL_E_WORKSPACE;
+  const TopnPlan p = topn_plan(R, Q);
+  char* base = (char*)workspace;
+  float* refnorm = (float*)base;
+  base += scl_round256((size_t)R * sizeof(float));
+  float* cs = (float*)base;
+  base += scl_round256((size_t)Q * p.splits * KEEP * sizeof(float));
+  int* ci = (int*)base;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(refnorm_kernel, dim3((R + 3) / 4), dim3(256), 0, st, ref, R, d, refnorm);
+  switch (d) {
+    case 32: launch_scan<4>(p, ref, refnorm, R, query, Q, cs, ci, st); break;
+    case 64: launch_scan<8>(p, ref, refnorm, R, query, Q, cs, ci, st); break;
+    case 128: launch_scan<16>(p, ref, refnorm, R, query, Q, cs, ci, st); break;
+    default: launch_scan<32>(p, ref, refnorm, R, query, Q, cs, ci, st); break;
+  }
+  const size_t lds = (size_t)p.splits * KEEP * 2 * sizeof(float);
+  hipLaunchKernelGGL(topn_rerank_kernel, dim3(Q), dim3(256), lds, st, ref, query, d, p.splits, n,
+                     idx_offset, (const float*)cs, (const int*)ci, idx_out, dist_out);
+  return scl_launch_status();
+}

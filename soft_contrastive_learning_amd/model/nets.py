@@ -1,0 +1,230 @@
+"""Drop-in counterpart of the reference's ``model/nets.py``.
+
+``vgg16Netvlad(image_batch)`` and ``vgg16(image_batch)`` keep the reference names and
+the NHWC / raw-0..255-RGB input convention (model/nets.py:7-69, :72-131).  The VGG16
+convolutions run on PyTorch-ROCm (MIOpen, channels-last; bf16 optional); the channel L2
+norm + NetVLAD head (model/nets.py:66-67) is one autograd op over the hand-written
+gfx950 kernels of csrc/netvlad.hip.
+
+TF1 keeps variables in the graph scope ``vgg16_netvlad_pca``; here they live in a
+``VGG16NetVLAD`` module.  ``state_dict_tf`` / ``load_state_dict_tf`` expose them under
+the reference's checkpoint names and shapes (HWIO kernels, [1,1,512,64] assignment,
+[1,1,1,512,64] centres) so checkpoints stay layout-compatible.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from .. import _lib as L
+
+SCOPE = 'vgg16_netvlad_pca'
+
+# (name, out_channels, relu directly after the conv) — model/nets.py:39-63.
+# A pool (and the ReLU that follows it) comes after the last conv of blocks 1-4.
+VGG_LAYERS = [
+    ('1_1', 64, True), ('1_2', 64, False), 'pool',
+    ('2_1', 128, True), ('2_2', 128, False), 'pool',
+    ('3_1', 256, True), ('3_2', 256, True), ('3_3', 256, False), 'pool',
+    ('4_1', 512, True), ('4_2', 512, True), ('4_3', 512, False), 'pool',
+    ('5_1', 512, True), ('5_2', 512, True), ('5_3', 512, False),
+]
+
+
+class _NetVLADFn(torch.autograd.Function):
+    """l2_normalize(axis=-1) + netVLAD(x, 64) on a channels-last feature map."""
+
+    @staticmethod
+    def forward(ctx, x, assign_w, centers, pre_l2):
+        lib = L.load()
+        L.require_device(x, assign_w, centers)
+        if x.dim() != 4 or x.shape[3] != L.VLAD_D:
+            raise ValueError("feature map must be [B,H,W,512] channels-last, got %s"
+                             % (tuple(x.shape),))
+        if x.dtype == torch.float32:
+            dt = L.DT_F32
+        elif x.dtype == torch.bfloat16:
+            dt = L.DT_BF16
+        else:
+            raise ValueError("feature map dtype must be float32 or bfloat16, got %s" % x.dtype)
+        x = x.contiguous()
+        w = assign_w.reshape(L.VLAD_D, L.VLAD_K).float().contiguous()
+        c = centers.reshape(L.VLAD_D, L.VLAD_K).float().contiguous()
+        b, n = x.shape[0], x.shape[1] * x.shape[2]
+        dev = x.device
+        out = torch.empty((b, L.VLAD_D * L.VLAD_K), dtype=torch.float32, device=dev)
+        train = any(ctx.needs_input_grad[:3])
+        sa = sl = sr = sv = None
+        if train:
+            sa = torch.empty((b, n, L.VLAD_K), dtype=torch.float32, device=dev)
+            sl = torch.empty((b, n, L.VLAD_K), dtype=torch.float32, device=dev)
+            sr = torch.empty((b, n), dtype=torch.float32, device=dev)
+            sv = torch.empty((b, L.VLAD_D + 1, L.VLAD_K), dtype=torch.float32, device=dev)
+        ws = L.workspace(lib.scl_netvlad_fwd_workspace_bytes(b, n), dev)
+        L.check(lib.scl_netvlad_fwd(L.ptr(x), dt, L.ptr(w), L.ptr(c), b, n, int(bool(pre_l2)),
+                                    L.ptr(out), L.ptr(sa), L.ptr(sl), L.ptr(sr), L.ptr(sv),
+                                    L.ptr(ws), ws.numel(), L.stream_of(x)))
+        if train:
+            ctx.save_for_backward(x, w, c, sa, sl, sr, sv)
+            ctx.meta = (dt, b, n, int(bool(pre_l2)), assign_w.shape, centers.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = L.load()
+        x, w, c, sa, sl, sr, sv = ctx.saved_tensors
+        dt, b, n, pre_l2, w_shape, c_shape = ctx.meta
+        go = grad_out.float().contiguous()
+        gx = torch.empty_like(x)
+        gw = torch.empty_like(w)
+        gc = torch.empty_like(c)
+        ws = L.workspace(lib.scl_netvlad_bwd_workspace_bytes(b, n), x.device)
+        L.check(lib.scl_netvlad_bwd(L.ptr(x), dt, L.ptr(w), L.ptr(c), L.ptr(go), L.ptr(sa),
+                                    L.ptr(sl), L.ptr(sr), L.ptr(sv), b, n, pre_l2, L.ptr(gx),
+                                    L.ptr(gw), L.ptr(gc), L.ptr(ws), ws.numel(), L.stream_of(x)))
+        return gx, gw.reshape(w_shape), gc.reshape(c_shape), None
+
+
+def netvlad(x_nhwc, assign_w, centers, pre_l2=True):
+    """``tf.nn.l2_normalize(x, axis=-1)`` then ``layers.netVLAD(x, 64)``
+    (model/nets.py:66-67).  x_nhwc [B,H',W',512] -> [B,32768]."""
+    return _NetVLADFn.apply(x_nhwc, assign_w, centers, pre_l2)
+
+
+class VGG16NetVLAD(torch.nn.Module):
+    """Variables of the reference's ``vgg16_netvlad_pca`` scope."""
+
+    def __init__(self, compute_dtype=torch.float32, seed=1234):
+        super().__init__()
+        self.compute_dtype = compute_dtype
+        g = torch.Generator().manual_seed(seed)
+        self.average_rgb = torch.nn.Parameter(torch.tensor([123.68, 116.78, 103.94]))
+        self.conv_names = []
+        cin = 3
+        for item in VGG_LAYERS:
+            if item == 'pool':
+                continue
+            name, cout, _ = item
+            w = torch.randn(cout, cin, 3, 3, generator=g) * math.sqrt(2.0 / (cin * 9))  # He
+            self.register_parameter('conv%s_kernel' % name, torch.nn.Parameter(
+                w.contiguous(memory_format=torch.channels_last)))
+            self.register_parameter('conv%s_bias' % name, torch.nn.Parameter(torch.zeros(cout)))
+            self.conv_names.append(name)
+            cin = cout
+        self.assignment_kernel = torch.nn.Parameter(
+            torch.randn(1, 1, L.VLAD_D, L.VLAD_K, generator=g) / math.sqrt(L.VLAD_D))
+        self.cluster_centers = torch.nn.Parameter(
+            torch.randn(1, 1, 1, L.VLAD_D, L.VLAD_K, generator=g) * 0.05)
+
+    # ---- forward pieces -------------------------------------------------------
+    def features(self, image_batch):
+        """model/nets.py:10-63 -> conv5_3 map as a channels-last [B,H',W',512] tensor
+        (not yet L2-normalised)."""
+        if image_batch.dim() != 4:
+            raise AssertionError("image batch must be rank 4 [B,H,W,C]")   # nets.py:10
+        ch = image_batch.shape[3]
+        if ch == 1:
+            image_batch = image_batch.expand(-1, -1, -1, 3)              # nets.py:15-16
+        elif ch != 3:
+            raise AssertionError("last axis must be 1 or 3")               # nets.py:18
+        x = image_batch - self.average_rgb.to(image_batch.dtype)          # nets.py:22-24
+        # NHWC storage viewed as NCHW == channels_last: no copy
+        x = x.permute(0, 3, 1, 2)
+        dt = self.compute_dtype
+        if x.dtype != dt:
+            x = x.to(dt)
+        x = x.contiguous(memory_format=torch.channels_last)
+        for item in VGG_LAYERS:
+            if item == 'pool':
+                x = F.relu(F.max_pool2d(x, 2, 2))                        # pool, then ReLU
+                continue
+            name, _, relu = item
+            w = getattr(self, 'conv%s_kernel' % name)
+            bias = getattr(self, 'conv%s_bias' % name)
+            if w.dtype != dt:
+                w, bias = w.to(dt), bias.to(dt)
+            x = F.conv2d(x, w, bias, stride=1, padding=1)
+            if relu:
+                x = F.relu(x)
+        return x.permute(0, 2, 3, 1)                                      # [B,H',W',512] view
+
+    def forward(self, image_batch):
+        x = self.features(image_batch)
+        return netvlad(x, self.assignment_kernel, self.cluster_centers, True)
+
+    def forward_vgg16(self, image_batch):
+        """model/nets.py:72-131: backbone + channel L2 norm, no VLAD."""
+        x = self.features(image_batch).float()
+        return x * torch.rsqrt(torch.clamp_min((x * x).sum(dim=-1, keepdim=True), 1e-12))
+
+    # ---- checkpoint layout (TF variable names and shapes) ----------------------
+    def state_dict_tf(self):
+        sd = {SCOPE + '/average_rgb': self.average_rgb.detach()}
+        for name in self.conv_names:
+            w = getattr(self, 'conv%s_kernel' % name).detach()
+            sd['%s/conv%s/kernel' % (SCOPE, name)] = w.permute(2, 3, 1, 0).contiguous()  # HWIO
+            sd['%s/conv%s/bias' % (SCOPE, name)] = getattr(self, 'conv%s_bias' % name).detach()
+        sd[SCOPE + '/assignment/kernel'] = self.assignment_kernel.detach()
+        sd[SCOPE + '/cluster_centers'] = self.cluster_centers.detach()
+        return sd
+
+    def load_state_dict_tf(self, sd, strict=True):
+        """Restore by TF variable name like restore_weights (train/train.py:882-905):
+        only names containing the scope are taken."""
+        own = self.state_dict_tf()
+        missing = [k for k in own if k not in sd]
+        if strict and missing:
+            raise KeyError("checkpoint lacks %s" % missing)
+        with torch.no_grad():
+            for key, val in sd.items():
+                if SCOPE not in key or key not in own:
+                    continue
+                val = torch.as_tensor(val, dtype=torch.float32)
+                if tuple(val.shape) != tuple(own[key].shape):
+                    raise ValueError("%s: shape %s != %s" % (key, tuple(val.shape),
+                                                             tuple(own[key].shape)))
+                short = key[len(SCOPE) + 1:]
+                if short == 'average_rgb':
+                    self.average_rgb.copy_(val)
+                elif short == 'assignment/kernel':
+                    self.assignment_kernel.copy_(val)
+                elif short == 'cluster_centers':
+                    self.cluster_centers.copy_(val)
+                else:
+                    layer, kind = short.split('/')
+                    name = layer[len('conv'):]
+                    if kind == 'kernel':
+                        getattr(self, 'conv%s_kernel' % name).copy_(val.permute(3, 2, 0, 1))
+                    else:
+                        getattr(self, 'conv%s_bias' % name).copy_(val)
+        return missing
+
+
+_DEFAULT = None
+
+
+def default_model():
+    """Process-wide variable store, the analogue of TF's reusable variable scope."""
+    global _DEFAULT
+    if _DEFAULT is None:
+        _DEFAULT = VGG16NetVLAD()
+        if torch.cuda.is_available():
+            _DEFAULT = _DEFAULT.cuda()
+    return _DEFAULT
+
+
+def set_default_model(model):
+    global _DEFAULT
+    _DEFAULT = model
+    return model
+
+
+def vgg16Netvlad(image_batch, model=None):
+    """model/nets.py:7-69.  image_batch [B,H,W,{1|3}] float, raw 0..255 RGB ->
+    [B, 32768] unit-norm VLAD descriptors."""
+    return (model or default_model())(image_batch)
+
+
+def vgg16(image_batch, model=None):
+    """model/nets.py:72-131 -> [B,H',W',512] channel-normalised conv5_3 map."""
+    return (model or default_model()).forward_vgg16(image_batch)

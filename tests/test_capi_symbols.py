@@ -1,0 +1,72 @@
+"""The C-ABI library builds, loads without a GPU, and exports every symbol that
+include/scl_hip.h declares (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "scl_hip.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    g.build()
+    from soft_contrastive_learning_amd import _lib
+    return _lib.load()
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(scl_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_the_expected_surface():
+    names = _declared()
+    for want in ("scl_netvlad_fwd", "scl_netvlad_bwd", "scl_gram_loss_fwd", "scl_gram_loss_bwd",
+                 "scl_tuple_loss_fwd", "scl_tuple_loss_bwd", "scl_logratio_fwd",
+                 "scl_pairwise_sqdist", "scl_topn_l2", "scl_abi_version", "scl_error_string"):
+        assert want in names
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from soft_contrastive_learning_amd import _lib
+    declared = _declared()
+    assert sorted(_lib.SIGNATURES) == declared
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_abi_version_and_error_strings(lib):
+    assert lib.scl_abi_version() == 1
+    assert lib.scl_error_string(0) == b"ok"
+    assert b"shape" in lib.scl_error_string(-1)
+    assert b"NULL" in lib.scl_error_string(-3)
+
+
+def test_workspace_queries_are_pure_host_functions(lib):
+    # NetVLAD forward at the bench shape: Wt + slabs + a + rn, all 256-byte rounded
+    n = lib.scl_netvlad_fwd_workspace_bytes(24, 1200)
+    assert n >= 24 * 2 * 512 * 64 * 4 + 24 * 1200 * 64 * 4
+    assert n % 256 == 0
+    assert lib.scl_netvlad_fwd_workspace_bytes(0, 10) == 0
+    assert lib.scl_netvlad_bwd_workspace_bytes(24, 1200) % 256 == 0
+    assert lib.scl_gram_loss_workspace_bytes(24, 32768) > 0
+    assert lib.scl_gram_loss_workspace_bytes(5000, 32768) == 0          # B above the cap
+    assert lib.scl_topn_l2_workspace_bytes(100000, 10000, 256, 25) > 100000 * 4
+    assert lib.scl_topn_l2_workspace_bytes(100, 10, 100, 5) == 0         # unsupported d
+    assert lib.scl_topn_l2_workspace_bytes(100, 10, 64, 26) == 0         # n above the cap
+
+
+def test_argument_validation_happens_before_any_launch(lib):
+    # NULL pointers and bad selectors are rejected on the host: safe without a GPU
+    assert lib.scl_gram_loss_fwd(None, 0, 4, 8, 0, None, 0, 0.8, 15.0, None, 2.0, 50.0, 1.0, 0.1,
+                                 1, 0, None, None, None, 0, None) == -3
+    assert lib.scl_tuple_loss_fwd(99, None, 0, None, 0, None, 0, None, 0, 1, 1, 1, 8, 0.1, 0.2,
+                                  None, None, None, None) == -2
+    assert lib.scl_netvlad_fwd(None, 0, None, None, 1, 1, 1, None, None, None, None, None, None, 0,
+                               None) == -3
+    assert lib.scl_topn_l2(None, 1, None, 1, 64, 1, 0, None, None, None, 0, None) == -3

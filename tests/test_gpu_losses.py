@@ -1,0 +1,245 @@
+"""GPU parity: HIP loss kernels (through the C-ABI) vs the CPU oracle.
+
+Tolerance: BASELINE.json's north_star asks for loss values within 1e-4 relative fp32 of
+the CPU reference; gradients are compared to the float64 autograd twin with a
+norm-relative bound of 2e-4 (fp32 Gram of 32768-term dot products feeding exp(50 x)).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import losses_np as O
+from oracle import twin_torch as TT
+from tests import util_data as U
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-4
+GRAD_REL = 2e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def _rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def _close(got, want, rel=REL, abs_=1e-7):
+    assert abs(float(got) - float(want)) <= rel * abs(float(want)) + abs_, (float(got), float(want))
+
+
+def _twin_grad(fn, emb_np):
+    e = torch.tensor(emb_np, dtype=torch.float64, requires_grad=True)
+    loss = fn(e)
+    loss.backward()
+    return float(loss), e.grad.numpy()
+
+
+# ------------------------------------------------------------------ KATs on the GPU
+def test_kat_ms_two_rows(dev):
+    from soft_contrastive_learning_amd.model import losses as M
+    e = torch.tensor([[1.0, 0.0], [1.0, 0.0]], device=dev)
+    _close(M.ms_loss([7, 7], e, ms_mining=False), np.log(2.0) / 2.0)      # K4
+    assert float(M.ms_loss([7, 7], e)) == 0.0                              # K4b
+    _close(M.ms_loss([0, 1], e), np.log(2.0) / 50.0)                       # K5
+    eo = torch.tensor([[1.0, 0.0], [0.0, 1.0]], device=dev)
+    assert float(M.ms_loss([0, 1], eo)) == 0.0                             # K6
+
+
+def test_kat_pairwise_sqdist(dev):
+    from soft_contrastive_learning_amd.model import losses as M
+    c = torch.tensor([[[1.0, 1], [2, 2], [3, 3]], [[1, 1], [2, 2], [4, 4]]], device=dev)
+    want = np.array([[[0, 2, 8], [2, 0, 2], [8, 2, 0]], [[0, 2, 18], [2, 0, 8], [18, 8, 0]]],
+                    dtype=np.float32)
+    np.testing.assert_array_equal(M._pairwise_squared_distances(c).cpu().numpy(), want)
+
+
+def test_kat_tuple_losses(dev):
+    from soft_contrastive_learning_amd import pointnetvlad_cls as P
+    from soft_contrastive_learning_amd.model import losses as M
+    q = torch.tensor([[[0.0, 0.0]]], device=dev)
+    pos = torch.tensor([[[1.0, 0.0], [0.0, 2.0]]], device=dev)
+    neg = torch.tensor([[[3.0, 0.0], [0.0, 1.0]]], device=dev)
+    oth = torch.tensor([[[3.0, 1.0]]], device=dev)
+    assert float(P.triplet_loss(q, pos, neg, 0.5)) == 0.5                  # K2
+    assert float(P.lazy_triplet_loss(q, pos, neg, 0.5)) == 0.5
+    assert float(M.evil_triplet_loss(q, pos, neg, 0.5)) == 3.5
+    _close(P.quadruplet_loss(q, pos, neg, oth, 0.5, 0.2), 0.7, rel=1e-6)   # K3
+    _close(P.lazy_quadruplet_loss(q, pos, neg, oth, 0.5, 0.2), 0.7, rel=1e-6)
+    _close(M.evil_quadruplet_loss(q, pos, neg, oth, 0.5, 0.2), 6.7, rel=1e-6)
+    assert float(P.best_pos_distance(q, pos)[0]) == 1.0
+    assert float(M.worst_pos_distance(q, pos)[0]) == 4.0
+
+
+# --------------------------------------------------------------- wms / ms parity sweep
+@pytest.mark.parametrize("b,e", [(24, 32768), (25, 32768), (7, 100), (64, 4096), (192, 32768)])
+@pytest.mark.parametrize("wf,sf", [("exp", "ms"), ("lin", "ms"), ("tanh", "plain"), ("exp", "plain")])
+def test_wms_loss_and_grad(dev, b, e, wf, sf):
+    from soft_contrastive_learning_amd.model import losses as M
+    if b == 192 and (wf, sf) != ("exp", "ms"):
+        pytest.skip("B=192 is covered for the default configuration only")
+    emb = U.embeddings(b, e)
+    dist = U.positions_distances(b, side=60.0 if b < 64 else 200.0)
+    want = O.wms_loss(dist[None], emb, 0.8, 15.0, wfunction=wf, sumfunction=sf)
+    want64, grad64 = _twin_grad(
+        lambda t: TT.wms_loss(dist[None], t, 0.8, 15.0, wfunction=wf, sumfunction=sf), emb)
+    et = torch.tensor(emb, device=dev, requires_grad=True)
+    dt = torch.tensor(dist[None], device=dev)
+    loss = M.wms_loss(dt, et, d_alpha=0.8, d_beta=15.0, wfunction=wf, sumfunction=sf)
+    loss.backward()
+    _close(loss, want)
+    _close(loss, want64)
+    assert _rel(et.grad.cpu().numpy(), grad64) < GRAD_REL
+    # rank-2 distances give the same value for symmetric inputs
+    _close(M.wms_loss(dt[0], et.detach(), 0.8, 15.0, wfunction=wf, sumfunction=sf), want)
+
+
+def test_wms_rank3_asymmetric_is_literal(dev):
+    from soft_contrastive_learning_amd.model import losses as M
+    emb = U.embeddings(12, 256, seed=3)
+    dist = U.positions_distances(12, side=50.0)
+    dist = dist + np.triu(np.ones_like(dist), 1) * 9.0
+    et = torch.tensor(emb, device=dev)
+    got3 = M.wms_loss(torch.tensor(dist[None], device=dev), et, 0.8, 15.0)
+    got2 = M.wms_loss(torch.tensor(dist, device=dev), et, 0.8, 15.0)
+    _close(got3, O.wms_loss(dist[None], emb, 0.8, 15.0))
+    _close(got2, O.wms_loss(dist, emb, 0.8, 15.0))
+    assert abs(float(got3) - float(got2)) > 1e-6
+
+
+def test_wms_no_mining_and_upstream_grad_scale(dev):
+    from soft_contrastive_learning_amd.model import losses as M
+    emb = U.embeddings(24, 2048, seed=4)
+    dist = U.positions_distances(24, side=80.0)
+    want64, grad64 = _twin_grad(lambda t: 3.0 * TT.wms_loss(dist, t, 0.8, 15.0, ms_mining=False), emb)
+    et = torch.tensor(emb, device=dev, requires_grad=True)
+    loss = 3.0 * M.wms_loss(torch.tensor(dist, device=dev), et, 0.8, 15.0, ms_mining=False)
+    loss.backward()
+    _close(loss, want64)
+    assert _rel(et.grad.cpu().numpy(), grad64) < GRAD_REL
+
+
+@pytest.mark.parametrize("t,p,n", [(1, 12, 12), (2, 2, 3), (8, 12, 12)])
+@pytest.mark.parametrize("mining", [True, False])
+def test_ms_loss_and_grad(dev, t, p, n, mining):
+    from soft_contrastive_learning_amd.model import losses as M
+    b = t * (1 + p + n)
+    emb = U.embeddings(b, 32768 if t == 1 else 1024, seed=17)
+    labels = O.trainer_ms_labels(t, p, n)
+    want = O.ms_loss(labels, emb, ms_mining=mining)
+    want64, grad64 = _twin_grad(lambda x: TT.ms_loss(labels, x, ms_mining=mining), emb)
+    et = torch.tensor(emb, device=dev, requires_grad=True)
+    loss = M.ms_loss(labels, et, ms_mining=mining)
+    loss.backward()
+    _close(loss, want)
+    _close(loss, want64)
+    assert _rel(et.grad.cpu().numpy(), grad64) < GRAD_REL
+    _close(M.ms_det(labels, et.detach()), O.ms_det(labels, emb))
+
+
+def test_wms_data_parallel_rows_match_full_gradient(dev):
+    from soft_contrastive_learning_amd.model import losses as M
+    emb = U.embeddings(48, 4096, seed=8)
+    dist = U.positions_distances(48)
+    dt = torch.tensor(dist[None], device=dev)
+    full = torch.tensor(emb, device=dev, requires_grad=True)
+    M.wms_loss(dt, full, 0.8, 15.0).backward()
+    part = torch.tensor(emb, device=dev, requires_grad=True)
+    M.wms_loss(dt, part, 0.8, 15.0, _rows=(24, 24)).backward()
+    np.testing.assert_array_equal(part.grad[24:].cpu().numpy(), full.grad[24:].cpu().numpy())
+    assert float(part.grad[:24].abs().max()) == 0.0
+
+
+def test_wms_bitwise_reproducible(dev):
+    from soft_contrastive_learning_amd.model import losses as M
+    emb = torch.tensor(U.embeddings(24, 32768), device=dev)
+    dt = torch.tensor(U.positions_distances(24)[None], device=dev)
+    vals = {float(M.wms_loss(dt, emb, 0.8, 15.0)) for _ in range(5)}
+    assert len(vals) == 1
+
+
+# ------------------------------------------------------------------- tuple losses
+TUPLE_CASES = [("triplet_loss", False), ("lazy_triplet_loss", False), ("evil_triplet_loss", False),
+               ("quadruplet_loss", True), ("lazy_quadruplet_loss", True),
+               ("evil_quadruplet_loss", True)]
+
+
+@pytest.mark.parametrize("name,quad", TUPLE_CASES)
+@pytest.mark.parametrize("t,p,n,e", [(1, 12, 12, 32768), (2, 1, 2, 32768), (3, 4, 5, 100)])
+def test_tuple_losses_and_grads(dev, name, quad, t, p, n, e):
+    from soft_contrastive_learning_amd import pointnetvlad_cls as P
+    from soft_contrastive_learning_amd.model import losses as M
+    fn = getattr(P, name, None) or getattr(M, name)
+    shape = [1, p, n] + ([1] if quad else [])
+    out = U.tuple_batch(t, p, n, e, quad=quad)
+    flat = out.reshape(t * sum(shape), e)
+    parts = O.split_tuples(flat, t, shape)
+    margins = (0.5, 0.2) if quad else (0.5,)
+    want = getattr(O, name)(*parts, *margins)
+
+    x64 = torch.tensor(flat, dtype=torch.float64, requires_grad=True)
+    parts64 = torch.split(x64.reshape(t, sum(shape), e), shape, dim=1)
+    l64 = getattr(TT, name)(*parts64, *margins)
+    l64.backward()
+
+    xt = torch.tensor(flat, device=dev, requires_grad=True)
+    # the trainer's glue: reshape + split (train/train.py:654)
+    parts_t = torch.split(xt.reshape(t, sum(shape), e), shape, dim=1)
+    loss = fn(*parts_t, *margins)
+    loss.backward()
+    _close(loss, want, rel=1e-5)
+    _close(loss, float(l64), rel=1e-5)
+    assert _rel(xt.grad.cpu().numpy(), x64.grad.numpy()) < 1e-5
+
+
+def test_logratio_loss_and_grad(dev):
+    from soft_contrastive_learning_amd.model import losses as M
+    p = n = 12
+    e = 32768
+    out = U.tuple_batch(1, p, n, e, seed=33)
+    rng = np.random.default_rng(34)
+    spd = rng.uniform(1, 200, (1, p, 1)).astype(np.float32)
+    snd = rng.uniform(300, 4000, (1, n, 1)).astype(np.float32)
+    a, pos, neg = O.split_tuples(out.reshape(-1, e), 1, [1, p, n])
+    want = O.logratio_loss(a, pos, neg, spd, snd)
+    x64 = torch.tensor(out, dtype=torch.float64, requires_grad=True)
+    a64, p64, n64 = torch.split(x64, [1, p, n], dim=1)
+    l64 = TT.logratio_loss(a64, p64, n64, spd, snd)
+    l64.backward()
+    xt = torch.tensor(out, device=dev, requires_grad=True)
+    at, pt, nt = torch.split(xt, [1, p, n], dim=1)
+    loss = M.logratio_loss(at, pt, nt, torch.tensor(spd, device=dev), torch.tensor(snd, device=dev))
+    loss.backward()
+    _close(loss, want, rel=1e-5)
+    _close(loss, float(l64), rel=1e-5)
+    assert _rel(xt.grad.cpu().numpy(), x64.grad.numpy()) < 1e-5
+
+
+def test_pairwise_sqdist_random(dev):
+    from soft_contrastive_learning_amd.model import losses as M
+    f = U.tuple_batch(3, 6, 6, 4096, seed=40, scale=1.0)
+    want = O.pairwise_squared_distances(f)
+    got = M._pairwise_squared_distances(torch.tensor(f, device=dev)).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-3 * float(np.abs(want).max()) * 1e-2)
+
+
+# ------------------------------------------------------------------ error behaviour
+def test_shape_errors_raise_like_the_reference(dev):
+    from soft_contrastive_learning_amd.model import losses as M
+    emb = torch.zeros(8, 64, device=dev)
+    with pytest.raises(ValueError):
+        M.wms_loss(torch.zeros(2, 4, 4, device=dev), emb, 0.8, 15.0)      # T > 1 rank-3
+    with pytest.raises(ValueError):
+        M.wms_loss(torch.zeros(7, 7, device=dev), emb, 0.8, 15.0)
+    with pytest.raises(ValueError):
+        M.ms_loss([0, 1, 2], emb)
+    with pytest.raises(ValueError):
+        M.logratio_loss(torch.zeros(1, 1, 8, device=dev), torch.zeros(1, 3, 8, device=dev),
+                        torch.zeros(1, 4, 8, device=dev), torch.ones(1, 3, 1, device=dev),
+                        torch.ones(1, 4, 1, device=dev))

@@ -1,0 +1,50 @@
+"""GPU parity: fused pairwise-L2 + top-n (csrc/topn.hip) vs the reference's KDTree call
+(evaluation/top-n.py:103-106).  Index lists must be bit-exact; distances are float64."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import topn_np as TN
+from tests import util_data as U
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("r,q,d,n", [(25, 1, 32, 25), (100, 7, 64, 5), (1000, 130, 128, 25),
+                                     (5000, 300, 256, 25), (40000, 64, 256, 25)])
+def test_topn_matches_kdtree(dev, r, q, d, n):
+    from soft_contrastive_learning_amd.evaluation import retrieval
+    ref, qry = U.retrieval_sets(r, q, d)
+    want_d, want_i = TN.topn_kdtree(ref, qry, n)
+    got_d, got_i = retrieval.topn_l2(torch.tensor(ref, device=dev), torch.tensor(qry, device=dev), n)
+    np.testing.assert_array_equal(got_i.cpu().numpy(), want_i)
+    np.testing.assert_allclose(got_d.cpu().numpy(), want_d, rtol=1e-12, atol=0)
+
+
+def test_topn_duplicates_and_offset(dev):
+    from soft_contrastive_learning_amd.evaluation import retrieval
+    ref, qry = U.retrieval_sets(300, 10, 64)
+    ref[150] = ref[3]          # exact tie: lower index first
+    qry[0] = ref[3]
+    d, i = retrieval.topn_l2(torch.tensor(ref, device=dev), torch.tensor(qry, device=dev), 5,
+                             idx_offset=1000)
+    i = i.cpu().numpy()
+    assert list(i[0, :2]) == [1003, 1150]
+    assert float(d[0, 0]) == 0.0 and float(d[0, 1]) == 0.0
+
+
+def test_topn_sharded_reference_merge_equals_single(dev):
+    from soft_contrastive_learning_amd.evaluation import retrieval
+    ref, qry = U.retrieval_sets(4000, 50, 256)
+    rt, qt = torch.tensor(ref, device=dev), torch.tensor(qry, device=dev)
+    d0, i0 = retrieval.topn_l2(rt, qt, 25)
+    parts = [retrieval.topn_l2(rt[s:s + 1000], qt, 25, idx_offset=s) for s in range(0, 4000, 1000)]
+    d1, i1 = retrieval.merge_topn([p[0] for p in parts], [p[1] for p in parts], 25)
+    assert torch.equal(i0, i1)
+    assert torch.equal(d0, d1)

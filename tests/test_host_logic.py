@@ -1,0 +1,83 @@
+"""Host-side logic that needs no GPU: checkpoint layout, input checks, the loud failure
+when an op is asked to run without a HIP device."""
+import numpy as np
+import pytest
+import torch
+
+from soft_contrastive_learning_amd import _lib
+from soft_contrastive_learning_amd.model import losses, nets
+
+
+def test_tf_checkpoint_names_and_shapes():
+    m = nets.VGG16NetVLAD()
+    sd = m.state_dict_tf()
+    assert sd['vgg16_netvlad_pca/average_rgb'].shape == (3,)
+    assert sd['vgg16_netvlad_pca/conv1_1/kernel'].shape == (3, 3, 3, 64)       # HWIO
+    assert sd['vgg16_netvlad_pca/conv5_3/kernel'].shape == (3, 3, 512, 512)
+    assert sd['vgg16_netvlad_pca/conv3_2/bias'].shape == (256,)
+    assert sd['vgg16_netvlad_pca/assignment/kernel'].shape == (1, 1, 512, 64)
+    assert sd['vgg16_netvlad_pca/cluster_centers'].shape == (1, 1, 1, 512, 64)
+    assert len(sd) == 1 + 13 * 2 + 2
+    n_conv = sum(v.numel() for k, v in sd.items() if '/conv' in k)
+    assert n_conv == 14714688                                                   # 14.71 M
+
+
+def test_tf_state_dict_roundtrip_and_scope_filter():
+    a, b = nets.VGG16NetVLAD(seed=1), nets.VGG16NetVLAD(seed=2)
+    sd = {k: v.numpy() for k, v in a.state_dict_tf().items()}
+    sd['Variable'] = np.zeros(1)                      # ignored like train/train.py:884-892
+    b.load_state_dict_tf(sd)
+    for k, v in b.state_dict_tf().items():
+        assert torch.equal(v, a.state_dict_tf()[k]), k
+    with pytest.raises(KeyError):
+        b.load_state_dict_tf({'vgg16_netvlad_pca/average_rgb': np.zeros(3)})
+    with pytest.raises(ValueError):
+        bad = dict(sd)
+        bad['vgg16_netvlad_pca/conv1_1/kernel'] = np.zeros((64, 3, 3, 3))
+        b.load_state_dict_tf(bad)
+
+
+def test_backbone_layer_order_and_output_geometry():
+    m = nets.VGG16NetVLAD()
+    with torch.no_grad():
+        f = m.features(torch.zeros(1, 64, 80, 3))
+    assert f.shape == (1, 4, 5, 512)                 # floor(H/16) x floor(W/16), no pool5
+    assert f.is_contiguous()
+    with pytest.raises(AssertionError):
+        m.features(torch.zeros(1, 64, 80, 2))
+    with pytest.raises(AssertionError):
+        m.features(torch.zeros(64, 80, 3))
+    with torch.no_grad():
+        v = m.forward_vgg16(torch.rand(1, 32, 32, 3) * 255)
+    np.testing.assert_allclose(v.norm(dim=-1).numpy(), 1.0, rtol=1e-5)
+
+
+def test_ops_fail_loudly_without_a_hip_device():
+    emb = torch.zeros(4, 8)
+    with pytest.raises(_lib.SclError):
+        losses.wms_loss(torch.zeros(4, 4), emb, 0.8, 15.0)
+    with pytest.raises(_lib.SclError):
+        losses.ms_loss([0, 0, 1, 1], emb)
+    with pytest.raises(_lib.SclError):
+        nets.netvlad(torch.zeros(1, 2, 2, 512), torch.zeros(512, 64), torch.zeros(512, 64))
+
+
+def test_wms_rejects_bad_sumfunction_before_touching_the_device():
+    with pytest.raises(ValueError):
+        losses.wms_loss(torch.zeros(4, 4), torch.zeros(4, 8), 0.8, 15.0, sumfunction='bogus')
+
+
+def test_label_ids_keep_equality_structure():
+    lab = losses._label_ids(np.array([0.0, 0.0, 2.5, 7.0, 2.5]), torch.device('cpu'))
+    assert lab.dtype == torch.int64
+    a = lab.reshape(-1, 1) == lab.reshape(1, -1)
+    want = np.array([0.0, 0.0, 2.5, 7.0, 2.5])
+    np.testing.assert_array_equal(a.numpy(), want[:, None] == want[None, :])
+
+
+def test_merge_topn_orders_by_distance_then_index():
+    from soft_contrastive_learning_amd.evaluation import retrieval
+    d = [torch.tensor([[1.0, 3.0]], dtype=torch.float64), torch.tensor([[1.0, 2.0]], dtype=torch.float64)]
+    i = [torch.tensor([[7, 1]]), torch.tensor([[4, 9]])]
+    md, mi = retrieval.merge_topn(d, i, 3)
+    assert mi.tolist() == [[4, 7, 9]] and md.tolist() == [[1.0, 1.0, 2.0]]
