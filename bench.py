@@ -1,0 +1,241 @@
+#!/usr/bin/env python
+"""Headline benchmark: train-step images/sec, VGG16-NetVLAD + soft contrastive (wms) loss,
+640x480, on N MI355X (BASELINE.json metric; workload = configs[1], per-GPU batch 24).
+
+One step = VGG16 forward (PyTorch-ROCm, bf16 channels-last) -> NetVLAD (HIP) ->
+[all-gather of the embeddings when N > 1] -> wms loss forward+backward (HIP) -> NetVLAD
+backward (HIP) -> VGG backward -> [bucketed gradient all-reduce] -> Adam update.
+Inputs are synthetic and resident in HBM before the timed region.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     live HIP-event timing of the dominant hand-written kernel over the timed
+               steps (scl_prof_* sink in the C library), priced on its governing roofline
+  kernels      the same for every hand-written kernel on the path
+  cpu_baseline the CPU restatement of the same step timed on the host cores (N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+# MI355X peaks, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3     # f32 vector == f32-input MFMA
+PEAK_HBM_GBPS = 8000.0
+
+D, K, E = 512, 64, 32768
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=24, help='images per GPU')
+    ap.add_argument('--height', type=int, default=480)
+    ap.add_argument('--width', type=int, default=640)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'], help='backbone dtype')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-images', type=int, default=2, help='images in the CPU-baseline sample')
+    return ap.parse_args()
+
+
+def kernel_models(b, n, gb, x_bytes):
+    """Algorithmic flops / bytes per LAUNCH of each hand-written kernel.
+    b = images on this GPU, n = locations per image, gb = global batch."""
+    bn = b * n
+    return {
+        # x·W over all locations; reads x once, writes a (+ logits) and rn
+        'rowtile_assign': dict(flops=2.0 * bn * D * K, bytes=bn * D * x_bytes + bn * K * 8 + bn * 4),
+        # x^T·(a rn); reads x and a once, writes 2 slabs per image
+        'aggregate_kernel': dict(flops=2.0 * bn * D * K, bytes=bn * D * x_bytes + bn * K * 4 + b * 2 * D * K * 4),
+        'finish_kernel': dict(flops=6.0 * b * D * K, bytes=b * D * K * 4 * 4),
+        'bwd_prep_kernel': dict(flops=12.0 * b * D * K, bytes=b * D * K * 4 * 4),
+        'rowtile_dassign': dict(flops=2.0 * bn * D * K, bytes=bn * D * x_bytes + bn * K * 12 + b * D * K * 4),
+        'aggregate_dw': dict(flops=2.0 * bn * D * K, bytes=bn * D * x_bytes + bn * K * 4 + b * 2 * D * K * 4),
+        # [a|ds]·[dU|W]^T then the norm Jacobian; reads x, writes grad_x
+        'dx_kernel': dict(flops=4.0 * bn * D * K, bytes=2 * bn * D * x_bytes + bn * K * 8),
+        'wgrad_finish_kernel': dict(flops=4.0 * b * D * K, bytes=b * D * K * 12),
+        # loss: raw Gram (upper-triangular 32x32 tiles), reads E once
+        'gram_partial_kernel': dict(flops=2.0 * gb * gb * E, bytes=gb * E * 4),
+        'gram_rows_kernel': dict(flops=40.0 * gb * gb, bytes=gb * gb * 16),
+        'gram_coef_kernel': dict(flops=8.0 * gb * gb, bytes=gb * gb * 12),
+        # grad_E[own rows] = M E: reads E once, writes b rows
+        'gram_bwd_kernel': dict(flops=2.0 * b * gb * E, bytes=gb * E * 4 + b * E * 4),
+        'transpose_w_kernel': dict(flops=0.0, bytes=D * K * 8),
+    }
+
+
+def price(name, launches, mean_ms, model):
+    sec = mean_ms * 1e-3
+    tf = model['flops'] / sec / 1e12 if sec > 0 else 0.0
+    gbs = model['bytes'] / sec / 1e9 if sec > 0 else 0.0
+    t_mfma = model['flops'] / (PEAK_F32_TFLOPS * 1e12)
+    t_hbm = model['bytes'] / (PEAK_HBM_GBPS * 1e9)
+    bound = 'mfma' if t_mfma >= t_hbm else 'hbm'
+    frac = tf / PEAK_F32_TFLOPS if bound == 'mfma' else gbs / PEAK_HBM_GBPS
+    return dict(kernel=name, launches=launches, us=round(mean_ms * 1e3, 2), bound=bound,
+                tflops=round(tf, 2), gbps=round(gbs, 1), frac=round(frac, 4))
+
+
+def cpu_baseline(args, threads):
+    """The same train step restated on the CPU (oracle: torch-CPU f32 backbone + the
+    autograd twin of NetVLAD and wms_loss), on a bounded sample."""
+    from oracle import twin_torch as TT
+    from soft_contrastive_learning_amd.model import nets
+    nb = max(2, args.cpu_images)
+    torch.manual_seed(0)
+    model = nets.VGG16NetVLAD(compute_dtype=torch.float32)
+    img = torch.randint(0, 256, (nb, args.height, args.width, 3),
+                        generator=torch.Generator().manual_seed(42)).float()
+    rng = np.random.default_rng(7)
+    xy = rng.uniform(0, 200, size=(nb, 2))
+    dist_m = np.sqrt(((xy[:, None] - xy[None]) ** 2).sum(2)).astype(np.float32)
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        fmap = model.features(img)
+        emb = TT.netvlad(fmap.reshape(nb, -1, D), model.assignment_kernel.reshape(D, K),
+                         model.cluster_centers.reshape(D, K), dtype=torch.float32)
+        loss = TT.wms_loss(dist_m[None], emb, 0.8, 15.0, dtype=torch.float32)
+        loss.backward()
+        return float(loss)
+
+    step()                                   # warm-up (allocator, oneDNN primitives)
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        step()
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt > 10.0 or reps >= 5:
+            break
+    return dict(value=round(nb * reps / dt, 3), unit='images/sec', cores=threads, kind='port',
+                sample='%d steps of %d images %dx%d fwd+bwd (torch-CPU f32 VGG16 + oracle '
+                       'NetVLAD/wms autograd twin), no optimizer' % (reps, nb, args.width, args.height))
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a HIP device (no CPU path exists)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    from soft_contrastive_learning_amd import _lib, parallel
+    from soft_contrastive_learning_amd.model import losses, nets
+    _lib.load()
+
+    b, gb = args.batch, args.batch * world
+    cdt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    model = nets.VGG16NetVLAD(compute_dtype=cdt, seed=1234).to(dev)
+    params = list(model.parameters())
+    buckets = parallel.GradBuckets(params)
+    opt = torch.optim.Adam(params, lr=5e-6)     # train/train.py:1270 base_lr
+
+    # synthetic RobotCar-shaped batch, resident in HBM
+    g = torch.Generator().manual_seed(42 + rank)
+    images = torch.randint(0, 256, (b, args.height, args.width, 3), generator=g).float().to(dev)
+    rng = np.random.default_rng(7)
+    xy = rng.uniform(0.0, 200.0, size=(gb, 2))
+    dmat = np.sqrt(((xy[:, None] - xy[None]) ** 2).sum(2)).astype(np.float32)
+    distances = torch.tensor(dmat[None], device=dev)
+
+    def step():
+        buckets.zero()
+        emb = model(images)
+        if world > 1:
+            loss = parallel.wms_loss_dp(distances, emb, 0.8, 15.0)
+        else:
+            loss = losses.wms_loss(distances, emb, d_alpha=0.8, d_beta=15.0)
+        loss.backward()
+        buckets.finish()
+        opt.step()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    with _lib.KernelTimer(capacity=64 * max(args.steps, 1)) as kt:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        fence()
+        elapsed = time.perf_counter() - t0
+    loss_val = float(loss)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+
+    if rank == 0:
+        n_loc = (args.height // 16) * (args.width // 16)
+        models = kernel_models(b, n_loc, gb, 2 if cdt == torch.bfloat16 else 4)
+        summ = kt.summary()
+        kernels = [price(k, c, ms, models[k]) for k, (c, ms) in sorted(summ.items()) if k in models]
+        dom = max(kernels, key=lambda r: r['us'] * r['launches']) if kernels else None
+        roofline = None
+        if dom:
+            roofline = dict(kernel=dom['kernel'], bound=dom['bound'],
+                            achieved=dom['tflops'] if dom['bound'] == 'mfma' else dom['gbps'],
+                            peak=PEAK_F32_TFLOPS if dom['bound'] == 'mfma' else PEAK_HBM_GBPS,
+                            unit='TFLOP/s' if dom['bound'] == 'mfma' else 'GB/s',
+                            frac=dom['frac'], traffic=None, us_per_launch=dom['us'])
+        hip_ms = sum(r['us'] * r['launches'] for r in kernels) / 1e3 / max(args.steps, 1)
+        out = {
+            'metric': 'train-step images/sec (VGG16-NetVLAD soft-MS, 640x480)',
+            'value': round(gb * args.steps / elapsed, 2),
+            'unit': 'images/sec',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': args.dtype,
+            'data': 'synthetic',
+            'config': {'workload': 'configs[1]: wms soft-contrastive train step, VGG16-NetVLAD K=64, '
+                                   '%d images/GPU %dx%d, %s backbone, f32 NetVLAD+loss'
+                                   % (b, args.width, args.height, args.dtype),
+                       'global_batch': gb, 'locations': n_loc, 'parallelism': 'dp%d' % world,
+                       'optimizer': 'adam', 'loss': float('%.6g' % loss_val)},
+            'roofline': roofline,
+            'kernels': kernels,
+            'hip_path_ms_per_step': round(hip_ms, 3),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args, torch.get_num_threads())
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -178,6 +178,17 @@ int scl_topn_l2(const float* ref, int R, const float* query, int Q, int d, int n
                 int64_t idx_offset, int64_t* idx_out, double* dist_out, void* workspace,
                 size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * Diagnostics (bench.py's live per-kernel timing; the reference has no counterpart
+ * beyond its wall-clock prints, train/train.py:135-161).  Between scl_prof_begin and
+ * scl_prof_end every kernel launched by THIS thread through the library is bracketed by
+ * HIP events on its launch stream.  scl_prof_end waits for them and returns per-launch
+ * milliseconds and kernel names (static strings).
+ * ------------------------------------------------------------------------- */
+int scl_prof_begin(int capacity);
+int scl_prof_count(void);
+int scl_prof_end(float* ms, const char** names, int capacity);
+
 #ifdef __cplusplus
 }
 #endif

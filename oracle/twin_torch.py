@@ -61,18 +61,17 @@ def _ms_core(sim_mat, mask_pos, mask_neg, alpha, beta, lamb, eps, ms_mining,
 def wms_loss(distances, embeddings, d_alpha, d_beta, alpha=2.0, beta=50.0, lamb=1.0,
              eps=0.1, ms_mining=True, wfunction='exp', sumfunction='ms',
              dtype=torch.float64):
-    d = _t(distances, dtype)
+    # The geographic masks are data, not differentiated, and their float32 evaluation is
+    # part of the reference semantics: exp() overflows to +inf for far pairs and makes the
+    # mask EXACTLY 0 / 1, which decides `mask > 0`.  So the twin takes them
+    # from the float32 oracle and only widens the differentiable part.
+    from .losses_np import wms_masks
+    import numpy as _np
+    mp32, mn32 = wms_masks(_np.asarray(distances, dtype=_np.float32), d_alpha, d_beta, wfunction)
+    mask_pos = torch.as_tensor(mp32).to(dtype)
+    mask_neg = torch.as_tensor(mn32).to(dtype)
     emb = l2_normalize(_t(embeddings, dtype), 1)
     batch = emb.shape[0]
-    if wfunction == 'lin':
-        mask_pos = torch.where(d < d_beta, 1.0 - d / d_beta, torch.zeros_like(d))
-        mask_neg = torch.where(d < d_beta, d / d_beta, torch.ones_like(d))
-    elif wfunction == 'tanh':
-        mask_pos = 1.0 - torch.tanh(d / d_beta)
-        mask_neg = torch.tanh(d / d_beta)
-    else:
-        mask_pos = 1.0 / (1.0 + torch.exp(d_alpha * (d - d_beta)))
-        mask_neg = 1.0 / (1.0 + torch.exp(d_alpha * (d_beta - d)))
     mask_pos = mask_pos - torch.eye(batch, dtype=dtype)
     sim = emb @ emb.T
     return _ms_core(sim, mask_pos, mask_neg, alpha, beta, lamb, eps, ms_mining,

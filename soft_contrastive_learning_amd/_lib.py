@@ -48,6 +48,9 @@ SIGNATURES = {
     "scl_logratio_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
     "scl_topn_l2_workspace_bytes": (_z, [_i, _i, _i, _i]),
     "scl_topn_l2": (_i, [_p, _i, _p, _i, _i, _i, _l, _p, _p, _p, _z, _p]),
+    "scl_prof_begin": (_i, [_i]),
+    "scl_prof_count": (_i, []),
+    "scl_prof_end": (_i, [_p, _p, _i]),
 }
 
 _lib = None
@@ -109,3 +112,31 @@ def stream_of(t):
 def workspace(nbytes, device):
     """Caller-owned scratch from torch's caching allocator (512-byte aligned)."""
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+class KernelTimer:
+    """Context manager over scl_prof_begin / scl_prof_end: per-launch kernel durations
+    (HIP events on the launch stream) of every library call made by this thread."""
+
+    def __init__(self, capacity=4096):
+        self.capacity = capacity
+        self.records = []          # (kernel name, milliseconds)
+
+    def __enter__(self):
+        check(load().scl_prof_begin(self.capacity))
+        return self
+
+    def __exit__(self, *exc):
+        ms = (ctypes.c_float * self.capacity)()
+        names = (ctypes.c_char_p * self.capacity)()
+        n = load().scl_prof_end(ms, names, self.capacity)
+        self.records = [(names[i].decode(), float(ms[i])) for i in range(n)]
+        return False
+
+    def summary(self):
+        """name -> (launches, mean ms)"""
+        acc = {}
+        for name, t in self.records:
+            c, s = acc.get(name, (0, 0.0))
+            acc[name] = (c + 1, s + t)
+        return {k: (c, s / c) for k, (c, s) in acc.items()}

@@ -404,7 +404,7 @@ extern "C" int scl_gram_loss_fwd(const float* emb, int64_t ld_emb, int B, int E,
   if (workspace_bytes < w.total) return SCL_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const int vec_ok = (ld_emb % 4 == 0) && ((uintptr_t)emb % 16 == 0);
-  hipLaunchKernelGGL(gram_partial_kernel, dim3(p.splits, p.npairs, 1), dim3(256), 0, st, emb,
+  SCL_LAUNCH("gram_partial_kernel", gram_partial_kernel, dim3(p.splits, p.npairs, 1), dim3(256), 0, st, emb,
                      ld_emb, (int64_t)0, B, E, p.tiles, p.kchunk, vec_ok, w.slabs);
   LossParams lp;
   lp.mask_kind = mask_kind;
@@ -419,10 +419,10 @@ extern "C" int scl_gram_loss_fwd(const float* emb, int64_t ld_emb, int B, int E,
   lp.eps = eps;
   const int Bp = (B + 63) / 64 * 64;
   const size_t lds_bytes = (size_t)(kRowWaves + 5) * Bp * sizeof(float);
-  hipLaunchKernelGGL(gram_rows_kernel, dim3(B), dim3(kRowThreads), lds_bytes, st, w.slabs,
+  SCL_LAUNCH("gram_rows_kernel", gram_rows_kernel, dim3(B), dim3(kRowThreads), lds_bytes, st, w.slabs,
                      p.splits, p.npairs, p.tiles, B, distances, labels, lp, w.gn, w.gc, w.rn,
                      w.rowloss);
-  hipLaunchKernelGGL(gram_coef_kernel, dim3(coef ? B : 1), dim3(256), 0, st, w.gn, w.gc, w.rn,
+  SCL_LAUNCH("gram_coef_kernel", gram_coef_kernel, dim3(coef ? B : 1), dim3(256), 0, st, w.gn, w.gc, w.rn,
                      w.rowloss, B, coef, loss_out);
   return scl_launch_status();
 }
@@ -434,7 +434,7 @@ extern "C" int scl_gram_loss_bwd(const float* emb, int64_t ld_emb, int B, int E,
   if (B < 1 || E < 1 || ld_emb < E || ld_grad < E) return SCL_E_SHAPE;
   if (row_begin < 0 || row_count < 1 || row_begin + row_count > B) return SCL_E_SHAPE;
   dim3 grid((E + 127) / 128, (row_count + kTile - 1) / kTile);
-  hipLaunchKernelGGL(gram_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, emb, ld_emb, B, E,
+  SCL_LAUNCH("gram_bwd_kernel", gram_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, emb, ld_emb, B, E,
                      coef, grad_loss, row_begin, row_count, grad_emb, ld_grad);
   return scl_launch_status();
 }
@@ -454,10 +454,10 @@ extern "C" int scl_pairwise_sqdist(const float* feats, int T, int S, int E, floa
   const GramPlan p = make_plan(S, E);
   hipStream_t st = (hipStream_t)stream;
   const int vec_ok = (E % 4 == 0) && ((uintptr_t)feats % 16 == 0);
-  hipLaunchKernelGGL(gram_partial_kernel, dim3(p.splits, p.npairs, T), dim3(256), 0, st, feats,
+  SCL_LAUNCH("gram_partial_kernel", gram_partial_kernel, dim3(p.splits, p.npairs, T), dim3(256), 0, st, feats,
                      (int64_t)E, (int64_t)S * E, S, E, p.tiles, p.kchunk, vec_ok,
                      (float*)workspace);
-  hipLaunchKernelGGL(sqdist_finish_kernel, dim3(S, T), dim3(256), 0, st, (const float*)workspace,
+  SCL_LAUNCH("sqdist_finish_kernel", sqdist_finish_kernel, dim3(S, T), dim3(256), 0, st, (const float*)workspace,
                      p.splits, p.npairs, p.tiles, S, out);
   return scl_launch_status();
 }

@@ -440,7 +440,7 @@ void launch_rowtile(const RowTileArgs& a, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRowTileLds);
   });
   const int tiles = (a.N + 31) / 32;
-  hipLaunchKernelGGL((rowtile_kernel<T, MODE>), dim3((tiles + 3) / 4, a.B), dim3(256), kRowTileLds,
+  SCL_LAUNCH(MODE == ASSIGN ? "rowtile_assign" : "rowtile_dassign", (rowtile_kernel<T, MODE>), dim3((tiles + 3) / 4, a.B), dim3(256), kRowTileLds,
                      st, a);
 }
 
@@ -513,7 +513,7 @@ extern "C" int scl_netvlad_fwd(const void* x, int x_dtype, const float* assign_w
   float* assign = save_assign ? save_assign : w.assign;
   float* rnorm = save_rnorm ? save_rnorm : w.rnorm;
 
-  hipLaunchKernelGGL(transpose_w_kernel, dim3(D * K / 256), dim3(256), 0, st, assign_w, w.wt);
+  SCL_LAUNCH("transpose_w_kernel", transpose_w_kernel, dim3(D * K / 256), dim3(256), 0, st, assign_w, w.wt);
   RowTileArgs a{};
   a.x = x;
   a.bt = w.wt;
@@ -526,14 +526,14 @@ extern "C" int scl_netvlad_fwd(const void* x, int x_dtype, const float* assign_w
   a.rnorm = rnorm;
   if (x_dtype == SCL_DT_F32) {
     launch_rowtile<float, ASSIGN>(a, st);
-    hipLaunchKernelGGL(aggregate_kernel<float>, dim3(D / 32, NSPLIT, B), dim3(256), 0, st, x,
+    SCL_LAUNCH("aggregate_kernel", aggregate_kernel<float>, dim3(D / 32, NSPLIT, B), dim3(256), 0, st, x,
                        (const float*)assign, (const float*)rnorm, N, w.part, w.colsum);
   } else {
     launch_rowtile<unsigned short, ASSIGN>(a, st);
-    hipLaunchKernelGGL(aggregate_kernel<unsigned short>, dim3(D / 32, NSPLIT, B), dim3(256), 0, st,
+    SCL_LAUNCH("aggregate_kernel", aggregate_kernel<unsigned short>, dim3(D / 32, NSPLIT, B), dim3(256), 0, st,
                        x, (const float*)assign, (const float*)rnorm, N, w.part, w.colsum);
   }
-  hipLaunchKernelGGL(finish_kernel, dim3(B), dim3(1024), 0, st, (const float*)w.part,
+  SCL_LAUNCH("finish_kernel", finish_kernel, dim3(B), dim3(1024), 0, st, (const float*)w.part,
                      (const float*)w.colsum, centers, out, save_vlad);
   return scl_launch_status();
 }
@@ -560,7 +560,7 @@ extern "C" int scl_netvlad_bwd(const void* x, int x_dtype, const float* assign_w
   if (workspace_bytes < w.total) return SCL_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
 
-  hipLaunchKernelGGL(bwd_prep_kernel, dim3(B), dim3(1024), 0, st, save_vlad, grad_out, centers,
+  SCL_LAUNCH("bwd_prep_kernel", bwd_prep_kernel, dim3(B), dim3(1024), 0, st, save_vlad, grad_out, centers,
                      w.du, w.dut, w.cdu);
   RowTileArgs a{};
   a.x = x;
@@ -578,20 +578,20 @@ extern "C" int scl_netvlad_bwd(const void* x, int x_dtype, const float* assign_w
   const dim3 dxgrid((N + 31) / 32, B);
   if (x_dtype == SCL_DT_F32) {
     launch_rowtile<float, DASSIGN>(a, st);
-    hipLaunchKernelGGL(aggregate_kernel<float>, dim3(D / 32, NSPLIT, B), dim3(256), 0, st, x,
+    SCL_LAUNCH("aggregate_dw", aggregate_kernel<float>, dim3(D / 32, NSPLIT, B), dim3(256), 0, st, x,
                        (const float*)w.ds, save_rnorm, N, w.wpart, (float*)nullptr);
-    hipLaunchKernelGGL(dx_kernel<float>, dxgrid, dim3(256), 0, st, x, save_assign,
+    SCL_LAUNCH("dx_kernel", dx_kernel<float>, dxgrid, dim3(256), 0, st, x, save_assign,
                        (const float*)w.ds, save_rnorm, (const float*)w.rowdot,
                        (const float*)w.du, assign_w, N, pre_l2 ? 1 : 0, grad_x);
   } else {
     launch_rowtile<unsigned short, DASSIGN>(a, st);
-    hipLaunchKernelGGL(aggregate_kernel<unsigned short>, dim3(D / 32, NSPLIT, B), dim3(256), 0, st,
+    SCL_LAUNCH("aggregate_dw", aggregate_kernel<unsigned short>, dim3(D / 32, NSPLIT, B), dim3(256), 0, st,
                        x, (const float*)w.ds, save_rnorm, N, w.wpart, (float*)nullptr);
-    hipLaunchKernelGGL(dx_kernel<unsigned short>, dxgrid, dim3(256), 0, st, x, save_assign,
+    SCL_LAUNCH("dx_kernel", dx_kernel<unsigned short>, dxgrid, dim3(256), 0, st, x, save_assign,
                        (const float*)w.ds, save_rnorm, (const float*)w.rowdot,
                        (const float*)w.du, assign_w, N, pre_l2 ? 1 : 0, grad_x);
   }
-  hipLaunchKernelGGL(wgrad_finish_kernel, dim3(D * K / 256), dim3(256), 0, st,
+  SCL_LAUNCH("wgrad_finish_kernel", wgrad_finish_kernel, dim3(D * K / 256), dim3(256), 0, st,
                      (const float*)w.wpart, (const float*)w.du, save_vlad, B, grad_w, grad_c);
   return scl_launch_status();
 }

@@ -15,3 +15,47 @@ extern "C" const char* scl_error_string(int code) {
   if (code > 0) return hipGetErrorString((hipError_t)code);
   return "unknown error";
 }
+
+// ---- per-kernel timing sink (diagnostics; see SCL_LAUNCH in scl_common.h) ---------------
+thread_local SclProfSink* scl_prof_sink = nullptr;
+
+extern "C" int scl_prof_begin(int capacity) {
+  if (scl_prof_sink || capacity < 1) return SCL_E_SHAPE;
+  SclProfSink* s = new SclProfSink;
+  s->capacity = capacity;
+  s->count = 0;
+  s->ev = new hipEvent_t[2 * (size_t)capacity];
+  s->name = new const char*[capacity];
+  for (int i = 0; i < 2 * capacity; ++i) {
+    hipError_t e = hipEventCreate(&s->ev[i]);
+    if (e != hipSuccess) return (int)e;
+  }
+  scl_prof_sink = s;
+  return SCL_OK;
+}
+
+extern "C" int scl_prof_count(void) { return scl_prof_sink ? scl_prof_sink->count : 0; }
+
+// Waits for the recorded launches; fills ms[i] and names[i] for i < min(count, capacity),
+// destroys the sink and returns the number of entries.
+extern "C" int scl_prof_end(float* ms, const char** names, int capacity) {
+  SclProfSink* s = scl_prof_sink;
+  if (!s) return 0;
+  scl_prof_sink = nullptr;
+  int n = 0;
+  for (int i = 0; i < s->count; ++i) {
+    (void)hipEventSynchronize(s->ev[2 * i + 1]);
+    if (i < capacity && ms && names) {
+      float t = 0.f;
+      (void)hipEventElapsedTime(&t, s->ev[2 * i], s->ev[2 * i + 1]);
+      ms[i] = t;
+      names[i] = s->name[i];
+      ++n;
+    }
+  }
+  for (int i = 0; i < 2 * s->capacity; ++i) (void)hipEventDestroy(s->ev[i]);
+  delete[] s->ev;
+  delete[] s->name;
+  delete s;
+  return n;
+}

@@ -107,6 +107,28 @@ __device__ __forceinline__ float block_reduce(float v, float* scratch) {
   return r;
 }
 
+// ---- optional per-kernel timing (bench.py's live roofline measurement) ----------------
+// A thread-local sink set by scl_prof_begin(); when present every launch is bracketed by
+// HIP events on the launch stream.  No sink (the normal case) = plain launches.
+struct SclProfSink {
+  int capacity, count;
+  hipEvent_t* ev;         // 2 * capacity
+  const char** name;      // capacity
+};
+extern thread_local SclProfSink* scl_prof_sink;
+
+#define SCL_LAUNCH(kname, kernel, grid, block, lds, st, ...)                     \
+  do {                                                                           \
+    SclProfSink* ps_ = scl_prof_sink;                                            \
+    const bool rec_ = ps_ && ps_->count < ps_->capacity;                         \
+    if (rec_) (void)hipEventRecord(ps_->ev[2 * ps_->count], (st));               \
+    hipLaunchKernelGGL(kernel, grid, block, lds, (st), __VA_ARGS__);             \
+    if (rec_) {                                                                  \
+      (void)hipEventRecord(ps_->ev[2 * ps_->count + 1], (st));                   \
+      ps_->name[ps_->count++] = (kname);                                         \
+    }                                                                            \
+  } while (0)
+
 static inline int scl_launch_status() { return (int)hipGetLastError(); }
 static inline bool scl_aligned256(const void* p) { return (((uintptr_t)p) & 255u) == 0; }
 static inline size_t scl_round256(size_t n) { return (n + 255u) & ~(size_t)255u; }

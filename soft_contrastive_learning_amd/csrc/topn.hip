@@ -327,7 +327,7 @@ void launch_scan(const TopnPlan& p, const float* ref, const float* refnorm, int 
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)scan_lds_bytes(D8 * 8));
   });
-  hipLaunchKernelGGL((topn_scan_kernel<D8>), dim3(p.qtiles, p.splits), dim3(256),
+  SCL_LAUNCH("topn_scan_kernel", (topn_scan_kernel<D8>), dim3(p.qtiles, p.splits), dim3(256),
                      scan_lds_bytes(D8 * 8), st, ref, refnorm, R, query, Q, p.refs_per_split, cs,
                      ci);
 }
@@ -362,7 +362,7 @@ extern "C" int scl_topn_l2(const float* ref, int R, const float* query, int Q, i
   base += scl_round256((size_t)Q * p.splits * KEEP * sizeof(float));
   int* ci = (int*)base;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(refnorm_kernel, dim3((R + 3) / 4), dim3(256), 0, st, ref, R, d, refnorm);
+  SCL_LAUNCH("refnorm_kernel", refnorm_kernel, dim3((R + 3) / 4), dim3(256), 0, st, ref, R, d, refnorm);
   switch (d) {
     case 32: launch_scan<4>(p, ref, refnorm, R, query, Q, cs, ci, st); break;
     case 64: launch_scan<8>(p, ref, refnorm, R, query, Q, cs, ci, st); break;
@@ -370,7 +370,7 @@ extern "C" int scl_topn_l2(const float* ref, int R, const float* query, int Q, i
     default: launch_scan<32>(p, ref, refnorm, R, query, Q, cs, ci, st); break;
   }
   const size_t lds = (size_t)p.splits * KEEP * 2 * sizeof(float);
-  hipLaunchKernelGGL(topn_rerank_kernel, dim3(Q), dim3(256), lds, st, ref, query, d, p.splits, n,
+  SCL_LAUNCH("topn_rerank_kernel", topn_rerank_kernel, dim3(Q), dim3(256), lds, st, ref, query, d, p.splits, n,
                      idx_offset, (const float*)cs, (const int*)ci, idx_out, dist_out);
   return scl_launch_status();
 }

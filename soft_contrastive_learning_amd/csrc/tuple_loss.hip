@@ -220,9 +220,9 @@ extern "C" int scl_tuple_loss_fwd(int kind, const float* q, int64_t q_tstride, c
   const int vec = vec4_ok(q, q_tstride, E) && vec4_ok(pos, pos_tstride, E) &&
                   vec4_ok(neg, neg_tstride, E) && vec4_ok(v.other, other_tstride, E);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(tuple_sqd_kernel, dim3(P + N + (quad ? N : 0), T), dim3(256), 0, st, v, P, N,
+  SCL_LAUNCH("tuple_sqd_kernel", tuple_sqd_kernel, dim3(P + N + (quad ? N : 0), T), dim3(256), 0, st, v, P, N,
                      E, vec, sqd);
-  hipLaunchKernelGGL(tuple_finish_kernel, dim3(1), dim3(256), 0, st, kind, T, P, N, m1, m2,
+  SCL_LAUNCH("tuple_finish_kernel", tuple_finish_kernel, dim3(1), dim3(256), 0, st, kind, T, P, N, m1, m2,
                      (const float*)sqd, coef, loss_out);
   return scl_launch_status();
 }
@@ -237,7 +237,7 @@ extern "C" int scl_tuple_loss_bwd(const float* q, int64_t q_tstride, const float
   if (T < 1 || P < 1 || N < 1 || E < 1 || T > 65535) return SCL_E_SHAPE;
   TupleView v{q, pos, neg, other, q_tstride, pos_tstride, neg_tstride, other_tstride};
   TupleGrads g{grad_q, grad_pos, grad_neg, grad_other};
-  hipLaunchKernelGGL(tuple_bwd_kernel, dim3((E + 255) / 256, T), dim3(256), 0,
+  SCL_LAUNCH("tuple_bwd_kernel", tuple_bwd_kernel, dim3((E + 255) / 256, T), dim3(256), 0,
                      (hipStream_t)stream, v, g, P, N, E, coef, grad_loss);
   return scl_launch_status();
 }
@@ -252,8 +252,8 @@ extern "C" int scl_logratio_fwd(const float* a, const float* pos, const float* n
   TupleView v{a, pos, neg, nullptr, 0, 0, 0, 0};
   const int vec = vec4_ok(a, 0, E) && vec4_ok(pos, 0, E) && vec4_ok(neg, 0, E);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(tuple_sqd_kernel, dim3(P + N, 1), dim3(256), 0, st, v, P, N, E, vec, sqd);
-  hipLaunchKernelGGL(logratio_finish_kernel, dim3(1), dim3(256), 0, st, P, N, sq_pos_d, sq_neg_d,
+  SCL_LAUNCH("tuple_sqd_kernel", tuple_sqd_kernel, dim3(P + N, 1), dim3(256), 0, st, v, P, N, E, vec, sqd);
+  SCL_LAUNCH("logratio_finish_kernel", logratio_finish_kernel, dim3(1), dim3(256), 0, st, P, N, sq_pos_d, sq_neg_d,
                      (const float*)sqd, coef, loss_out);
   return scl_launch_status();
 }

@@ -106,8 +106,7 @@ class VGG16NetVLAD(torch.nn.Module):
                 continue
             name, cout, _ = item
             w = torch.randn(cout, cin, 3, 3, generator=g) * math.sqrt(2.0 / (cin * 9))  # He
-            self.register_parameter('conv%s_kernel' % name, torch.nn.Parameter(
-                w.contiguous(memory_format=torch.channels_last)))
+            self.register_parameter('conv%s_kernel' % name, torch.nn.Parameter(w))
             self.register_parameter('conv%s_bias' % name, torch.nn.Parameter(torch.zeros(cout)))
             self.conv_names.append(name)
             cin = cout
@@ -141,8 +140,10 @@ class VGG16NetVLAD(torch.nn.Module):
             name, _, relu = item
             w = getattr(self, 'conv%s_kernel' % name)
             bias = getattr(self, 'conv%s_bias' % name)
-            if w.dtype != dt:
-                w, bias = w.to(dt), bias.to(dt)
+            # OIHW master weights -> channels-last (and bf16) operands for MIOpen
+            w = w.to(dtype=dt, memory_format=torch.channels_last)
+            if bias.dtype != dt:
+                bias = bias.to(dt)
             x = F.conv2d(x, w, bias, stride=1, padding=1)
             if relu:
                 x = F.relu(x)

@@ -1,0 +1,139 @@
+"""Data-parallel step for the soft-contrastive path (new work: the reference is
+single-process, single-GPU — SURVEY.md F2 / §8e).
+
+One process per GPU, ``torch.distributed`` (backend "nccl" = RCCL over xGMI on the GPU
+box, "gloo" in the CPU tests).  The batch shards by image:
+
+  1. each rank embeds its ``b`` images -> [b, 32768] unit-norm descriptors;
+  2. ONE all-gather makes the full [B, 32768] matrix on every rank (3.1 MB per rank at
+     b=24), so every rank forms the same B x B pairwise matrix and the same loss;
+  3. every rank asks the loss backward for ITS OWN rows only (``_rows``): because
+     d loss / d E_i needs both row and column terms of the pair matrix, replicating the
+     B x B work is cheaper than a second exchange, and the all-gather's backward is then
+     a plain slice — no reduce-scatter;
+  4. parameter gradients are SUMMED over ranks (each rank back-propagated the same loss
+     through its own images only), in buckets launched as soon as their gradients are
+     final so the collective overlaps the rest of the VGG backward.
+"""
+import torch
+import torch.distributed as dist
+
+
+class _AllGatherRows(torch.autograd.Function):
+    """[b,E] per rank -> [world*b,E] on every rank; backward = own rows of the gradient."""
+
+    @staticmethod
+    def forward(ctx, local, group):
+        world = dist.get_world_size(group)
+        ctx.rank = dist.get_rank(group)
+        ctx.b = local.shape[0]
+        local = local.contiguous()
+        full = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]),
+                           dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(full, local, group=group)
+        return full
+
+    @staticmethod
+    def backward(ctx, grad_full):
+        return grad_full[ctx.rank * ctx.b:(ctx.rank + 1) * ctx.b].contiguous(), None
+
+
+def all_gather_rows(local, group=None):
+    return _AllGatherRows.apply(local, group)
+
+
+def local_rows(local_batch, group=None):
+    """(row_begin, row_count) of this rank's images inside the gathered batch."""
+    return dist.get_rank(group) * local_batch, local_batch
+
+
+def wms_loss_dp(distances, local_embeddings, d_alpha, d_beta, group=None, **kw):
+    """``model.losses.wms_loss`` on the global batch: ``distances`` is the replicated
+    [1,B,B] / [B,B] matrix of ALL images, ``local_embeddings`` this rank's [b,E]."""
+    from .model import losses
+    full = all_gather_rows(local_embeddings, group)
+    rows = local_rows(local_embeddings.shape[0], group)
+    return losses.wms_loss(distances, full, d_alpha, d_beta, _rows=rows, **kw)
+
+
+def ms_loss_dp(labels, local_embeddings, group=None, **kw):
+    """``model.losses.ms_loss`` on the global batch; ``labels`` must be globally unique
+    across ranks."""
+    from .model import losses
+    full = all_gather_rows(local_embeddings, group)
+    rows = local_rows(local_embeddings.shape[0], group)
+    return losses.ms_loss(labels, full, _rows=rows, **kw)
+
+
+class GradBuckets:
+    """Flat gradient storage + bucketed asynchronous all-reduce (SUM).
+
+    Every parameter's ``.grad`` is a view into one flat buffer, so a bucket is a
+    contiguous slice and needs no packing.  Buckets follow reverse registration order
+    (≈ the order gradients become final in backward); a bucket's collective is launched
+    from the post-accumulate hook of its last parameter.  14.78 M f32 parameters = 59 MB:
+    the default 16 MB buckets give 4 collectives, each large enough to run at link rate
+    on the point-to-point xGMI fabric and small enough to hide under the conv backward.
+    """
+
+    def __init__(self, params, group=None, bucket_bytes=16 << 20):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = group
+        total = sum(p.numel() for p in self.params)
+        ref = self.params[0]
+        self.flat = torch.zeros(total, dtype=ref.dtype, device=ref.device)
+        self.buckets = []          # (begin, end) element ranges
+        self._bucket_of = {}
+        self._pending = []
+        self._handles = []
+        order = list(reversed(self.params))
+        off = 0
+        begin, count = 0, 0
+        members = []
+        for p in order:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            members.append(p)
+            off += n
+            count += n
+            if count * self.flat.element_size() >= bucket_bytes:
+                self._close(begin, off, members)
+                begin, count, members = off, 0, []
+        if members:
+            self._close(begin, off, members)
+        self.enabled = dist.is_available() and dist.is_initialized() and \
+            dist.get_world_size(group) > 1
+        for p in self.params:
+            p.register_post_accumulate_grad_hook(self._hook)
+        self._remaining = [len(m) for m in self._members]
+
+    def _close(self, begin, end, members):
+        if not hasattr(self, '_members'):
+            self._members = []
+        idx = len(self.buckets)
+        self.buckets.append((begin, end))
+        self._members.append(list(members))
+        for p in members:
+            self._bucket_of[id(p)] = idx
+
+    def _hook(self, p):
+        if not self.enabled:
+            return
+        idx = self._bucket_of[id(p)]
+        self._remaining[idx] -= 1
+        if self._remaining[idx] == 0:
+            b, e = self.buckets[idx]
+            self._handles.append(dist.all_reduce(self.flat[b:e], op=dist.ReduceOp.SUM,
+                                                 group=self.group, async_op=True))
+
+    def zero(self):
+        """Zero all gradients in one memset and re-arm the buckets."""
+        self.flat.zero_()
+        self._remaining = [len(m) for m in self._members]
+        self._handles = []
+
+    def finish(self):
+        """Wait for the collectives launched during backward (call before optimizer.step)."""
+        for h in self._handles:
+            h.wait()
+        self._handles = []
