@@ -48,6 +48,8 @@ def parse():
     ap.add_argument('--width', type=int, default=640)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'], help='backbone dtype')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--miopen-find', type=int, default=1,
+                    help='1: let MIOpen benchmark its solvers per conv shape during warm-up')
     ap.add_argument('--cpu-images', type=int, default=2, help='images in the CPU-baseline sample')
     return ap.parse_args()
 
@@ -137,6 +139,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device (no CPU path exists)')
     torch.cuda.set_device(local_rank)
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')

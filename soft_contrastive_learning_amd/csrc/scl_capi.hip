@@ -17,7 +17,7 @@ extern "C" const char* scl_error_string(int code) {
 }
 
 // ---- per-kernel timing sink (diagnostics; see SCL_LAUNCH in scl_common.h) ---------------
-thread_local SclProfSink* scl_prof_sink = nullptr;
+SclProfSink* volatile scl_prof_sink = nullptr;
 
 extern "C" int scl_prof_begin(int capacity) {
   if (scl_prof_sink || capacity < 1) return SCL_E_SHAPE;
@@ -26,6 +26,7 @@ extern "C" int scl_prof_begin(int capacity) {
   s->count = 0;
   s->ev = new hipEvent_t[2 * (size_t)capacity];
   s->name = new const char*[capacity];
+  for (int i = 0; i < capacity; ++i) s->name[i] = nullptr;
   for (int i = 0; i < 2 * capacity; ++i) {
     hipError_t e = hipEventCreate(&s->ev[i]);
     if (e != hipSuccess) return (int)e;
@@ -34,22 +35,30 @@ extern "C" int scl_prof_begin(int capacity) {
   return SCL_OK;
 }
 
-extern "C" int scl_prof_count(void) { return scl_prof_sink ? scl_prof_sink->count : 0; }
+extern "C" int scl_prof_count(void) {
+  SclProfSink* s = scl_prof_sink;
+  if (!s) return 0;
+  const int c = __atomic_load_n(&s->count, __ATOMIC_RELAXED);
+  return c < s->capacity ? c : s->capacity;
+}
 
-// Waits for the recorded launches; fills ms[i] and names[i] for i < min(count, capacity),
-// destroys the sink and returns the number of entries.
+// Call after the launching threads are quiescent (e.g. after a device synchronize).  Waits
+// for the recorded launches; fills ms[i] and names[i], destroys the sink and returns the
+// number of entries.
 extern "C" int scl_prof_end(float* ms, const char** names, int capacity) {
   SclProfSink* s = scl_prof_sink;
   if (!s) return 0;
   scl_prof_sink = nullptr;
+  int used = __atomic_load_n(&s->count, __ATOMIC_RELAXED);
+  if (used > s->capacity) used = s->capacity;
   int n = 0;
-  for (int i = 0; i < s->count; ++i) {
+  for (int i = 0; i < used; ++i) {
     (void)hipEventSynchronize(s->ev[2 * i + 1]);
     if (i < capacity && ms && names) {
       float t = 0.f;
       (void)hipEventElapsedTime(&t, s->ev[2 * i], s->ev[2 * i + 1]);
-      ms[i] = t;
-      names[i] = s->name[i];
+      ms[n] = t;
+      names[n] = s->name[i];
       ++n;
     }
   }

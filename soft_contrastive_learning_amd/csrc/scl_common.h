@@ -111,22 +111,29 @@ __device__ __forceinline__ float block_reduce(float v, float* scratch) {
 // A thread-local sink set by scl_prof_begin(); when present every launch is bracketed by
 // HIP events on the launch stream.  No sink (the normal case) = plain launches.
 struct SclProfSink {
-  int capacity, count;
+  int capacity;
+  int count;              // claimed slots (atomic)
   hipEvent_t* ev;         // 2 * capacity
   const char** name;      // capacity
 };
-extern thread_local SclProfSink* scl_prof_sink;
+// Process-wide (PyTorch runs backward on its own autograd thread, so a thread-local sink
+// would miss every backward kernel); slots are claimed atomically.
+extern SclProfSink* volatile scl_prof_sink;
 
 #define SCL_LAUNCH(kname, kernel, grid, block, lds, st, ...)                     \
   do {                                                                           \
     SclProfSink* ps_ = scl_prof_sink;                                            \
-    const bool rec_ = ps_ && ps_->count < ps_->capacity;                         \
-    if (rec_) (void)hipEventRecord(ps_->ev[2 * ps_->count], (st));               \
-    hipLaunchKernelGGL(kernel, grid, block, lds, (st), __VA_ARGS__);             \
-    if (rec_) {                                                                  \
-      (void)hipEventRecord(ps_->ev[2 * ps_->count + 1], (st));                   \
-      ps_->name[ps_->count++] = (kname);                                         \
+    int slot_ = -1;                                                              \
+    if (ps_) {                                                                   \
+      slot_ = __atomic_fetch_add(&ps_->count, 1, __ATOMIC_RELAXED);              \
+      if (slot_ >= ps_->capacity) slot_ = -1;                                    \
     }                                                                            \
+    if (slot_ >= 0) {                                                            \
+      ps_->name[slot_] = (kname);                                                \
+      (void)hipEventRecord(ps_->ev[2 * slot_], (st));                            \
+    }                                                                            \
+    hipLaunchKernelGGL(kernel, grid, block, lds, (st), __VA_ARGS__);             \
+    if (slot_ >= 0) (void)hipEventRecord(ps_->ev[2 * slot_ + 1], (st));          \
   } while (0)
 
 static inline int scl_launch_status() { return (int)hipGetLastError(); }

@@ -1,0 +1,114 @@
+"""World-size-2 checks of the data-parallel layer on CPU (gloo).
+
+The HIP loss cannot run here, so a differentiable torch stand-in plays the role of the
+pairwise loss; what is under test is the communication contract of
+``soft_contrastive_learning_amd.parallel``:
+  * the autograd-aware all-gather (backward = own rows, no reduce-scatter),
+  * "own rows only" loss gradients + SUM all-reduce == the single-process gradient of the
+    global-batch loss,
+  * bucketed flat-gradient all-reduce launched from post-accumulate hooks.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+WORLD = 2
+B_LOCAL, F_IN, E = 3, 5, 7
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _pair_loss(full):
+    """Stand-in for the B x B pairwise loss: couples every row with every other row."""
+    g = full @ full.T
+    return (torch.tanh(g) * torch.arange(1, g.numel() + 1, dtype=g.dtype).reshape(g.shape)).mean()
+
+
+def _make(seed=0):
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(WORLD * B_LOCAL, F_IN, generator=gen, dtype=torch.float64)
+    w1 = torch.randn(F_IN, 6, generator=gen, dtype=torch.float64)
+    w2 = torch.randn(6, E, generator=gen, dtype=torch.float64)
+    return x, w1, w2
+
+
+def _reference():
+    x, w1, w2 = _make()
+    w1.requires_grad_(True)
+    w2.requires_grad_(True)
+    loss = _pair_loss(torch.tanh(x @ w1) @ w2)
+    loss.backward()
+    return float(loss), w1.grad.clone(), w2.grad.clone()
+
+
+def _worker(rank, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=WORLD)
+    try:
+        from soft_contrastive_learning_amd import parallel
+        x, w1, w2 = _make()
+        xl = x[rank * B_LOCAL:(rank + 1) * B_LOCAL]
+        p1 = torch.nn.Parameter(w1.clone())
+        p2 = torch.nn.Parameter(w2.clone())
+        # tiny buckets: every parameter gets its own collective
+        buckets = parallel.GradBuckets([p1, p2], bucket_bytes=8)
+        assert len(buckets.buckets) == 2
+        for it in range(2):                      # second pass checks zero()/re-arming
+            buckets.zero()
+            local = torch.tanh(xl @ p1) @ p2
+            full = parallel.all_gather_rows(local)
+            assert full.shape == (WORLD * B_LOCAL, E)
+            begin, count = parallel.local_rows(B_LOCAL)
+            assert (begin, count) == (rank * B_LOCAL, B_LOCAL)
+
+            def own_rows_only(g, begin=begin, count=count):
+                m = torch.zeros_like(g)
+                m[begin:begin + count] = g[begin:begin + count]
+                return m
+            full.register_hook(own_rows_only)    # what `_rows` does inside the HIP backward
+            loss = _pair_loss(full)
+            loss.backward()
+            buckets.finish()
+        out[rank] = (float(loss), p1.grad.clone(), p2.grad.clone())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_dp_gradients_equal_single_process():
+    want_loss, g1, g2 = _reference()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(_free_port(), out), nprocs=WORLD, join=True)
+    assert sorted(out.keys()) == [0, 1]
+    for rank in range(WORLD):
+        loss, q1, q2 = out[rank]
+        assert abs(loss - want_loss) < 1e-12           # same loss on every rank
+        torch.testing.assert_close(q1, g1, rtol=1e-10, atol=1e-12)
+        torch.testing.assert_close(q2, g2, rtol=1e-10, atol=1e-12)
+
+
+def test_grad_buckets_layout_without_process_group():
+    from soft_contrastive_learning_amd import parallel
+    ps = [torch.nn.Parameter(torch.zeros(4, 3)), torch.nn.Parameter(torch.zeros(5)),
+          torch.nn.Parameter(torch.zeros(2, 2))]
+    gb = parallel.GradBuckets(ps, bucket_bytes=4 * 9)
+    assert gb.flat.numel() == 21 and not gb.enabled
+    # reverse registration order: [2x2 | 5] fill the first bucket (9 floats), [4x3] the next
+    assert gb.buckets == [(0, 9), (9, 21)]
+    (ps[0].sum() * 2 + ps[1].sum() * 3 + ps[2].sum() * 5).backward()
+    assert gb.flat.tolist() == [5.0] * 4 + [3.0] * 5 + [2.0] * 12
+    assert ps[0].grad.data_ptr() == gb.flat[9:].data_ptr()          # grads are views
+    gb.zero()
+    assert float(gb.flat.abs().sum()) == 0.0

@@ -143,4 +143,4 @@ def test_vgg16netvlad_end_to_end_vs_cpu(dev):
     with torch.no_grad():
         g1 = nets.vgg16Netvlad(grey, model=model)
         g3 = nets.vgg16Netvlad(grey.expand(-1, -1, -1, 3).contiguous(), model=model)
-    assert torch.equal(g1, g3)
+    assert _maxrel(g1.cpu().numpy(), g3.cpu().numpy()) < 1e-5   # MIOpen may pick another solver
