@@ -27,6 +27,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# MIOpen's find step (torch.backends.cudnn.benchmark) would otherwise also time its naive
+# reference solvers — seconds per call at this size — during warm-up.
+for _k in ('FWD', 'BWD', 'WRW'):
+    os.environ.setdefault('MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_' + _k, '0')
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -50,6 +55,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--miopen-find', type=int, default=1,
                     help='1: let MIOpen benchmark its solvers per conv shape during warm-up')
+    ap.add_argument('--fused-relu', type=int, default=0,
+                    help='1: MIOpen fused conv+bias+ReLU for the convs followed by a ReLU')
     ap.add_argument('--cpu-images', type=int, default=2, help='images in the CPU-baseline sample')
     return ap.parse_args()
 
@@ -151,7 +158,7 @@ def main():
 
     b, gb = args.batch, args.batch * world
     cdt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
-    model = nets.VGG16NetVLAD(compute_dtype=cdt, seed=1234).to(dev)
+    model = nets.VGG16NetVLAD(compute_dtype=cdt, seed=1234, fused_relu=bool(args.fused_relu)).to(dev)
     params = list(model.parameters())
     buckets = parallel.GradBuckets(params)
     opt = torch.optim.Adam(params, lr=5e-6)     # train/train.py:1270 base_lr

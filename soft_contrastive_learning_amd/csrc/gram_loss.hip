@@ -132,9 +132,15 @@ struct LossParams {
 };
 
 constexpr int kRowThreads = 512;
-constexpr int kRowWaves = kRowThreads / 64;
 
-// One workgroup per (reduction) row i.  Dynamic LDS: part[kRowWaves][Bp] | gdiag[Bp] | grow[Bp]
+// floats of scratch at the head of gram_rows_kernel's LDS
+__host__ __device__ inline int rows_part_floats(int B) {
+  const int Bp = (B + 63) / 64 * 64;
+  const int a = 2 * (Bp > kRowThreads ? Bp : kRowThreads), b = 4 * Bp;
+  return a > b ? a : b;
+}
+
+// One workgroup per (reduction) row i.  Dynamic LDS: part[rows_part_floats] | gdiag[Bp] | grow[Bp]
 // | S[Bp] | mp[Bp] | mn[Bp]  with Bp = B rounded up to 64.
 __global__ __launch_bounds__(kRowThreads) void gram_rows_kernel(
     const float* __restrict__ slabs, int splits, int npairs, int tiles, int B,
@@ -144,34 +150,64 @@ __global__ __launch_bounds__(kRowThreads) void gram_rows_kernel(
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ float scratch[32];
   const int Bp = (B + 63) / 64 * 64;
-  float* part = lds;                     // [kRowWaves][Bp]
-  float* gdiag = part + kRowWaves * Bp;  // raw G[j,j]
+  const int PN = rows_part_floats(B);    // >= 2 * max(kRowThreads, Bp) and >= 4 * Bp
+  float* part = lds;                     // [PN] scratch: slab partial sums, later pair terms
+  float* gdiag = part + PN;              // raw G[j,j]
   float* grow = gdiag + Bp;              // raw G[i,j], later normalised Gn[i,j]
   float* sS = grow + Bp;
   float* sMp = sS + Bp;
   float* sMn = sMp + Bp;
   const int i = blockIdx.x;
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 
-  // --- slab reduction: every wave sums a residue class of the splits, lanes over j
-  for (int j = lane; j < B; j += 64)
-    part[wid * Bp + j] = slab_entry(slabs, splits, npairs, tiles, i, j, wid, kRowWaves);
-  __syncthreads();
-  for (int j = threadIdx.x; j < B; j += kRowThreads) {
-    float a = 0.f;
-    for (int w = 0; w < kRowWaves; ++w) a += part[w * Bp + j];
-    grow[j] = a;
+  // --- slab reduction.  All 512 threads take part: thread (g, jj) sums the residue class g
+  //     (mod G) of the K-splits for column jj — row entry and diagonal entry in the same loop
+  //     so their loads overlap — and the G partial sums are then added in fixed order.
+  {
+    const int Bq = B < kRowThreads ? B : kRowThreads;   // columns handled per pass
+    const int G = kRowThreads / Bq;                     // split classes (1 when B >= 512)
+    const int g = threadIdx.x / Bq, jj = threadIdx.x % Bq;
+    float* pdiag = part + PN / 2;
+    const int64_t stride = (int64_t)npairs * (kTile * kTile);
+    if (g < G) {
+      for (int j = jj; j < B; j += Bq) {                // one j per thread unless B > 512
+        int ti = i / kTile, tj = j / kTile, ri = i % kTile, rj = j % kTile;
+        if (ti > tj) {
+          int t = ti; ti = tj; tj = t;
+          t = ri; ri = rj; rj = t;
+        }
+        const float* pr =
+            slabs + (int64_t)pair_index(ti, tj, tiles) * (kTile * kTile) + ri * kTile + rj;
+        const int td = j / kTile, rd = j % kTile;
+        const float* pd =
+            slabs + (int64_t)pair_index(td, td, tiles) * (kTile * kTile) + rd * kTile + rd;
+        float ar = 0.f, ad = 0.f;
+#pragma unroll 4
+        for (int s = g; s < splits; s += G) {
+          ar += pr[s * stride];
+          ad += pd[s * stride];
+        }
+        // slot: [g][j] when G > 1 (then j < Bq), [j] when G == 1
+        part[g * Bq + j] = ar;
+        pdiag[g * Bq + j] = ad;
+      }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < B; j += kRowThreads) {
+      float ar = 0.f, ad = 0.f;
+      if (G == 1) {
+        ar = part[j];
+        ad = pdiag[j];
+      } else {
+        for (int gg = 0; gg < G; ++gg) {
+          ar += part[gg * Bq + j];
+          ad += pdiag[gg * Bq + j];
+        }
+      }
+      grow[j] = ar;
+      gdiag[j] = ad;
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  for (int j = lane; j < B; j += 64)
-    part[wid * Bp + j] = slab_entry(slabs, splits, npairs, tiles, j, j, wid, kRowWaves);
-  __syncthreads();
-  for (int j = threadIdx.x; j < B; j += kRowThreads) {
-    float a = 0.f;
-    for (int w = 0; w < kRowWaves; ++w) a += part[w * Bp + j];
-    gdiag[j] = a;
-  }
-  __syncthreads();
 
   // --- tf.nn.l2_normalize folded into the Gram: Gn = G * rn_i * rn_j,
   //     rn = rsqrt(max(sum x^2, 1e-12))  (model/losses.py:7,82)
@@ -418,7 +454,7 @@ extern "C" int scl_gram_loss_fwd(const float* emb, int64_t ld_emb, int B, int E,
   lp.lamb = lamb;
   lp.eps = eps;
   const int Bp = (B + 63) / 64 * 64;
-  const size_t lds_bytes = (size_t)(kRowWaves + 5) * Bp * sizeof(float);
+  const size_t lds_bytes = ((size_t)rows_part_floats(B) + 5 * (size_t)Bp) * sizeof(float);
   SCL_LAUNCH("gram_rows_kernel", gram_rows_kernel, dim3(B), dim3(kRowThreads), lds_bytes, st, w.slabs,
                      p.splits, p.npairs, p.tiles, B, distances, labels, lp, w.gn, w.gc, w.rn,
                      w.rowloss);

@@ -35,7 +35,7 @@ namespace {
 constexpr int D = SCL_VLAD_D;   // 512
 constexpr int K = SCL_VLAD_K;   // 64
 constexpr int WT_LD = D + 4;    // padded LDS row: conflict-free ds_read_b128 over 16 rows
-constexpr int NSPLIT = 2;       // location halves with their own slab in aggregate_kernel
+constexpr int NSPLIT = 4;       // location splits with their own slab in aggregate_kernel
 
 // ------------------------------------------------------------------ small kernels
 __global__ __launch_bounds__(256) void transpose_w_kernel(const float* __restrict__ w,
@@ -169,46 +169,79 @@ __global__ __launch_bounds__(256) void rowtile_kernel(RowTileArgs p) {
 }
 
 // V_part[b, half, d, k] = sum_{n in half} x[b,n,d] * (coefn[b,n,k] * rn[b,n])
-// grid (16 channel tiles, NSPLIT, B); block 256; wave w contracts its quarter of the half.
+// grid (8 channel blocks of 64, NSPLIT, B); block 256; wave w contracts n-chunk split*4+w.
 template <typename T>
 __global__ __launch_bounds__(256) void aggregate_kernel(const void* __restrict__ xv,
                                                         const float* __restrict__ coefn,
                                                         const float* __restrict__ rn, int N,
                                                         float* __restrict__ part,
                                                         float* __restrict__ colsum_part) {
-  __shared__ float red[4][2][16][64];
+  // Each wave owns one n-chunk and a [64 channels x 64 clusters] block = 2 x 2 accumulator
+  // tiles.  Channel tile t holds channels d0 + 2*i + t (i = tile row), so one 4-byte (bf16)
+  // or 8-byte (f32) load per lane covers both tiles and a half-wave reads a full 128/256-B
+  // line of the location.  Operands run one 8-step batch ahead of the MFMAs.
+  __shared__ float red[2][4][16][64];   // 32 KB: tree reduction over the 4 waves
   __shared__ float csum[4][64];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int d0 = blockIdx.x * 32, half = blockIdx.y, b = blockIdx.z;
+  const int d0 = blockIdx.x * 64, split = blockIdx.y, b = blockIdx.z;
   int per = (N + NSPLIT * 4 - 1) / (NSPLIT * 4);
   per = (per + 1) & ~1;
-  const int chunk = half * 4 + wid;
+  const int chunk = split * 4 + wid;
   const int n_begin = chunk * per;
   int n_end = n_begin + per;
   if (n_end > N) n_end = N;
-  const T* x = reinterpret_cast<const T*>(xv) + (int64_t)b * N * D + d0 + r;
+  const int steps = n_end > n_begin ? (n_end - n_begin + 1) / 2 : 0;
+  const int n_safe = n_begin < N ? n_begin : 0;
+  const T* x = reinterpret_cast<const T*>(xv) + (int64_t)b * N * D + d0 + 2 * r;
   const float* cf = coefn + (int64_t)b * N * K + r;
   const float* rnb = rn + (int64_t)b * N;
-  f32x16 acc0 = zero16(), acc1 = zero16();
-  float s0 = 0.f, s1 = 0.f;
-#pragma unroll 4
-  for (int nn = n_begin; nn < n_end; nn += 2) {
-    const int n = nn + h;
-    const bool ok = n < n_end;
-    const int ns = ok ? n : n_begin;
-    const float xval = Elem<T>::ld(x + (int64_t)ns * D);
-    const float wgt = ok ? rnb[ns] : 0.f;
-    const float a0 = cf[(int64_t)ns * K], a1 = cf[(int64_t)ns * K + 32];
-    acc0 = mfma32(xval, a0 * wgt, acc0);
-    acc1 = mfma32(xval, a1 * wgt, acc1);
-    s0 += ok ? a0 : 0.f;
-    s1 += ok ? a1 : 0.f;
-  }
+  f32x16 acc[2][2];
 #pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    red[wid][0][q][lane] = acc0[q];
-    red[wid][1][q][lane] = acc1[q];
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) acc[t][kt] = zero16();
+  float s0 = 0.f, s1 = 0.f;
+
+  constexpr int U = 8;
+  f32x2 xc[U], xn[U];
+  float a0c[U], a1c[U], a0n[U], a1n[U];
+  auto load_batch = [&](int sb, f32x2* xb, float* a0b, float* a1b) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int n = n_begin + 2 * (sb + u) + h;
+      const bool ok = n < n_end;
+      const int ns = ok ? n : n_safe;
+      xb[u] = Elem<T>::ld2(x + (int64_t)ns * D);
+      const float wgt = rnb[ns];
+      const float a0 = cf[(int64_t)ns * K], a1 = cf[(int64_t)ns * K + 32];
+      // padding steps contribute nothing: zero B operand, and keep x finite-safe
+      a0b[u] = ok ? a0 * wgt : 0.f;
+      a1b[u] = ok ? a1 * wgt : 0.f;
+      if (!ok) xb[u] = f32x2{0.f, 0.f};
+      s0 += ok ? a0 : 0.f;
+      s1 += ok ? a1 : 0.f;
+    }
+  };
+  if (steps > 0) load_batch(0, xc, a0c, a1c);
+#pragma unroll 1
+  for (int sb = 0; sb < steps; sb += U) {
+    if (sb + U < steps) load_batch(sb + U, xn, a0n, a1n);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (sb + u < steps) {
+        acc[0][0] = mfma32(xc[u][0], a0c[u], acc[0][0]);
+        acc[0][1] = mfma32(xc[u][0], a1c[u], acc[0][1]);
+        acc[1][0] = mfma32(xc[u][1], a0c[u], acc[1][0]);
+        acc[1][1] = mfma32(xc[u][1], a1c[u], acc[1][1]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      xc[u] = xn[u];
+      a0c[u] = a0n[u];
+      a1c[u] = a1n[u];
+    }
   }
   s0 += __shfl_xor(s0, 32, 64);
   s1 += __shfl_xor(s1, 32, 64);
@@ -216,17 +249,50 @@ __global__ __launch_bounds__(256) void aggregate_kernel(const void* __restrict__
     csum[wid][r] = s0;
     csum[wid][32 + r] = s1;
   }
+  // fixed-order tree: (w0 + w2) + (w1 + w3)
+  if (wid >= 2) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) red[wid - 2][t * 2 + kt][q][lane] = acc[t][kt][q];
+  }
   __syncthreads();
-  float* out = part + (((int64_t)b * NSPLIT + half) * D + d0) * K;
-  for (int idx = threadIdx.x; idx < 2 * 16 * 64; idx += 256) {
-    const int kt = idx >> 10, q = (idx >> 6) & 15, l = idx & 63;
-    const float v = (red[0][kt][q][l] + red[1][kt][q][l]) + (red[2][kt][q][l] + red[3][kt][q][l]);
-    out[acc_row(q, l >> 5) * K + kt * 32 + (l & 31)] = v;
+  if (wid < 2) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[t][kt][q] += red[wid][t * 2 + kt][q][lane];
+  }
+  __syncthreads();
+  if (wid == 1) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) red[0][t * 2 + kt][q][lane] = acc[t][kt][q];
+  }
+  __syncthreads();
+  if (wid == 0) {
+    float* out = part + (((int64_t)b * NSPLIT + split) * D + d0) * K;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int ch = 2 * acc_row(q, h) + t;
+          out[ch * K + kt * 32 + r] = acc[t][kt][q] + red[0][t * 2 + kt][q][lane];
+        }
   }
   if (colsum_part && blockIdx.x == 0 && threadIdx.x < 64) {
     const int k = threadIdx.x;
-    colsum_part[((int64_t)b * NSPLIT + half) * K + k] =
-        (csum[0][k] + csum[1][k]) + (csum[2][k] + csum[3][k]);
+    colsum_part[((int64_t)b * NSPLIT + split) * K + k] =
+        (csum[0][k] + csum[2][k]) + (csum[1][k] + csum[3][k]);
   }
 }
 
@@ -271,15 +337,17 @@ __global__ __launch_bounds__(1024) void finish_kernel(const float* __restrict__ 
   __shared__ float colbuf[16 * 64];
   __shared__ float scratch[32];
   const int b = blockIdx.x, k = threadIdx.x & 63, dg = threadIdx.x >> 6;
-  const float asum = colsum_part[((int64_t)b * NSPLIT + 0) * K + k] +
-                     colsum_part[((int64_t)b * NSPLIT + 1) * K + k];
+  float asum = 0.f;
+#pragma unroll
+  for (int s = 0; s < NSPLIT; ++s) asum += colsum_part[((int64_t)b * NSPLIT + s) * K + k];
   VladNorm v;
 #pragma unroll
   for (int i = 0; i < 32; ++i) {
     const int d = dg * 32 + i;
-    const float p0 = part[(((int64_t)b * NSPLIT + 0) * D + d) * K + k];
-    const float p1 = part[(((int64_t)b * NSPLIT + 1) * D + d) * K + k];
-    v.u[i] = (p0 + p1) + centers[d * K + k] * asum;
+    float p = 0.f;
+#pragma unroll
+    for (int s = 0; s < NSPLIT; ++s) p += part[(((int64_t)b * NSPLIT + s) * D + d) * K + k];
+    v.u[i] = p + centers[d * K + k] * asum;
   }
   if (save_vlad) {
 #pragma unroll
@@ -422,7 +490,8 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restri
   const int k = idx % K;
   float gw = 0.f, gc = 0.f;
   for (int b = 0; b < B; ++b) {
-    gw += wpart[((int64_t)b * NSPLIT + 0) * D * K + idx] + wpart[((int64_t)b * NSPLIT + 1) * D * K + idx];
+#pragma unroll
+    for (int s = 0; s < NSPLIT; ++s) gw += wpart[((int64_t)b * NSPLIT + s) * D * K + idx];
     gc = fmaf(du[(int64_t)b * D * K + idx], save_vlad[((int64_t)b * (D + 1) + D) * K + k], gc);
   }
   grad_w[idx] = gw;
@@ -526,11 +595,11 @@ extern "C" int scl_netvlad_fwd(const void* x, int x_dtype, const float* assign_w
   a.rnorm = rnorm;
   if (x_dtype == SCL_DT_F32) {
     launch_rowtile<float, ASSIGN>(a, st);
-    SCL_LAUNCH("aggregate_kernel", aggregate_kernel<float>, dim3(D / 32, NSPLIT, B), dim3(256), 0, st, x,
+    SCL_LAUNCH("aggregate_kernel", aggregate_kernel<float>, dim3(D / 64, NSPLIT, B), dim3(256), 0, st, x,
                        (const float*)assign, (const float*)rnorm, N, w.part, w.colsum);
   } else {
     launch_rowtile<unsigned short, ASSIGN>(a, st);
-    SCL_LAUNCH("aggregate_kernel", aggregate_kernel<unsigned short>, dim3(D / 32, NSPLIT, B), dim3(256), 0, st,
+    SCL_LAUNCH("aggregate_kernel", aggregate_kernel<unsigned short>, dim3(D / 64, NSPLIT, B), dim3(256), 0, st,
                        x, (const float*)assign, (const float*)rnorm, N, w.part, w.colsum);
   }
   SCL_LAUNCH("finish_kernel", finish_kernel, dim3(B), dim3(1024), 0, st, (const float*)w.part,
@@ -578,14 +647,14 @@ extern "C" int scl_netvlad_bwd(const void* x, int x_dtype, const float* assign_w
   const dim3 dxgrid((N + 31) / 32, B);
   if (x_dtype == SCL_DT_F32) {
     launch_rowtile<float, DASSIGN>(a, st);
-    SCL_LAUNCH("aggregate_dw", aggregate_kernel<float>, dim3(D / 32, NSPLIT, B), dim3(256), 0, st, x,
+    SCL_LAUNCH("aggregate_dw", aggregate_kernel<float>, dim3(D / 64, NSPLIT, B), dim3(256), 0, st, x,
                        (const float*)w.ds, save_rnorm, N, w.wpart, (float*)nullptr);
     SCL_LAUNCH("dx_kernel", dx_kernel<float>, dxgrid, dim3(256), 0, st, x, save_assign,
                        (const float*)w.ds, save_rnorm, (const float*)w.rowdot,
                        (const float*)w.du, assign_w, N, pre_l2 ? 1 : 0, grad_x);
   } else {
     launch_rowtile<unsigned short, DASSIGN>(a, st);
-    SCL_LAUNCH("aggregate_dw", aggregate_kernel<unsigned short>, dim3(D / 32, NSPLIT, B), dim3(256), 0, st,
+    SCL_LAUNCH("aggregate_dw", aggregate_kernel<unsigned short>, dim3(D / 64, NSPLIT, B), dim3(256), 0, st,
                        x, (const float*)w.ds, save_rnorm, N, w.wpart, (float*)nullptr);
     SCL_LAUNCH("dx_kernel", dx_kernel<unsigned short>, dxgrid, dim3(256), 0, st, x, save_assign,
                        (const float*)w.ds, save_rnorm, (const float*)w.rowdot,

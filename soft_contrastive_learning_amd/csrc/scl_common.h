@@ -47,6 +47,9 @@ struct Elem<float> {
   static __device__ __forceinline__ f32x4 ld4(const float* p) {
     return *reinterpret_cast<const f32x4*>(p);
   }
+  static __device__ __forceinline__ f32x2 ld2(const float* p) {
+    return *reinterpret_cast<const f32x2*>(p);
+  }
   static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
 };
 template <>
@@ -59,6 +62,13 @@ struct Elem<unsigned short> {
     r[1] = bf16_to_f32(v[1]);
     r[2] = bf16_to_f32(v[2]);
     r[3] = bf16_to_f32(v[3]);
+    return r;
+  }
+  static __device__ __forceinline__ f32x2 ld2(const unsigned short* p) {
+    const unsigned v = *reinterpret_cast<const unsigned*>(p);
+    f32x2 r;
+    r[0] = __uint_as_float(v << 16);
+    r[1] = __uint_as_float(v & 0xffff0000u);
     return r;
   }
   static __device__ __forceinline__ void st(unsigned short* p, float v) { *p = f32_to_bf16(v); }

@@ -85,6 +85,27 @@ class _NetVLADFn(torch.autograd.Function):
         return gx, gw.reshape(w_shape), gc.reshape(c_shape), None
 
 
+class _ConvBiasReLU(torch.autograd.Function):
+    """3x3 same-padding conv + bias + ReLU as ONE MIOpen fused op (conv-bias-activation),
+    instead of conv, bias-add and ReLU kernels each streaming the activation map.  Only the
+    post-ReLU output is kept for backward (ReLU' = [y > 0])."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        y = torch.ops.aten.miopen_convolution_relu(x, w, b, [1, 1], [1, 1], [1, 1], 1)
+        ctx.save_for_backward(x, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        g = torch.ops.aten.threshold_backward(gy, y, 0)
+        gx, gw, gb = torch.ops.aten.convolution_backward(
+            g, x, w, [w.shape[0]], [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+            [ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]])
+        return gx, gw, gb
+
+
 def netvlad(x_nhwc, assign_w, centers, pre_l2=True):
     """``tf.nn.l2_normalize(x, axis=-1)`` then ``layers.netVLAD(x, 64)``
     (model/nets.py:66-67).  x_nhwc [B,H',W',512] -> [B,32768]."""
@@ -94,9 +115,10 @@ def netvlad(x_nhwc, assign_w, centers, pre_l2=True):
 class VGG16NetVLAD(torch.nn.Module):
     """Variables of the reference's ``vgg16_netvlad_pca`` scope."""
 
-    def __init__(self, compute_dtype=torch.float32, seed=1234):
+    def __init__(self, compute_dtype=torch.float32, seed=1234, fused_relu=False):
         super().__init__()
         self.compute_dtype = compute_dtype
+        self.fused_relu = fused_relu
         g = torch.Generator().manual_seed(seed)
         self.average_rgb = torch.nn.Parameter(torch.tensor([123.68, 116.78, 103.94]))
         self.conv_names = []
@@ -133,17 +155,27 @@ class VGG16NetVLAD(torch.nn.Module):
         if x.dtype != dt:
             x = x.to(dt)
         x = x.contiguous(memory_format=torch.channels_last)
-        for item in VGG_LAYERS:
+        # On a HIP device every conv that is followed by a ReLU — directly, or after the
+        # max-pool (nets.py:40-42: pool then ReLU; max and ReLU commute exactly) — runs as
+        # MIOpen's fused conv+bias+ReLU.  conv5_3 has neither (nets.py:63).
+        fuse = self.fused_relu and x.is_cuda
+        for idx, item in enumerate(VGG_LAYERS):
             if item == 'pool':
-                x = F.relu(F.max_pool2d(x, 2, 2))                        # pool, then ReLU
+                x = F.max_pool2d(x, 2, 2)
+                if not fuse:
+                    x = F.relu(x)                                        # pool, then ReLU
                 continue
             name, _, relu = item
+            relu_after_pool = idx + 1 < len(VGG_LAYERS) and VGG_LAYERS[idx + 1] == 'pool'
             w = getattr(self, 'conv%s_kernel' % name)
             bias = getattr(self, 'conv%s_bias' % name)
             # OIHW master weights -> channels-last (and bf16) operands for MIOpen
             w = w.to(dtype=dt, memory_format=torch.channels_last)
             if bias.dtype != dt:
                 bias = bias.to(dt)
+            if fuse and (relu or relu_after_pool):
+                x = _ConvBiasReLU.apply(x, w, bias)
+                continue
             x = F.conv2d(x, w, bias, stride=1, padding=1)
             if relu:
                 x = F.relu(x)
