@@ -168,6 +168,192 @@ __global__ __launch_bounds__(256) void rowtile_kernel(RowTileArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// rowtile16_kernel: the same contraction on 16-location tiles with v_mfma_f32_16x16x4_f32.
+//   * 1800 tiles at 24 x 1200 locations -> two resident workgroups per CU, so one wave's
+//     staging / softmax epilogue overlaps the other's MFMAs (the 32-row version has one
+//     900-tile wave per SIMD and exposes both);
+//   * the [64][512] operand is staged in four 128-channel chunks, double-buffered: chunk
+//     c+1 is loaded to registers before chunk c is contracted and written to LDS after it,
+//     so only the first 32 KB fill is exposed (a full 128 KB image costs >= 5 us per CU);
+//   * LDS chunk image = 4 planes (one per k-group g of the MFMA) x 64 rows x 36 floats:
+//     lane (i, g) reads plane g, row 16 kt + i with ds_read_b128; the plane stride is a
+//     multiple of 64 floats and the row stride 36 floats = 9 slots, so the 16 lanes of every
+//     ds_read_b128 service group hit 16 different 16-byte slots (conflict-free).
+// Accumulator register j of lane l is S[row = 4 (l >> 4) + j][cluster = 16 kt + (l & 15)].
+constexpr int RT_CH = 128;                      // channels per staged chunk
+constexpr int RT_LD = 36;                       // floats per plane row
+constexpr int RT_PLANE = K * RT_LD;             // 2304 floats (= 36 x 64)
+constexpr int RT_CHUNK = 4 * RT_PLANE;          // 9216 floats per buffer
+constexpr size_t kRowTile16Lds = 2 * (size_t)RT_CHUNK * sizeof(float);   // 73,728 B
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float q16_sum(float v) {
+#pragma unroll
+  for (int m = 1; m < 16; m <<= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+__device__ __forceinline__ float q16_max(float v) {
+#pragma unroll
+  for (int m = 1; m < 16; m <<= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+  return v;
+}
+
+// grid (ceil(ceil(N/16) / 4), B); block 256: wave w owns 16-location tile 4 * blockIdx.x + w.
+template <typename T, int MODE>
+__global__ __launch_bounds__(256, 2) void rowtile16_kernel(RowTileArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float bt_lds[];  // [2][4][64][RT_LD]
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int b = blockIdx.y;
+  const int n0 = (blockIdx.x * 4 + wid) * 16;
+  const bool active = n0 < p.N;          // wave-uniform; idle waves still stage and sync
+  const int n = n0 + i;
+  const bool row_ok = n < p.N;
+  const float* src = p.bt + (int64_t)b * p.bt_stride;
+  const T* xrow = reinterpret_cast<const T*>(p.x) + ((int64_t)b * p.N + (row_ok ? n : 0)) * D + 4 * g;
+
+  f32x4 st[8];
+  auto stage_load = [&](int chunk) {
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+      const int idx = v * 256 + threadIdx.x;
+      const int k = idx >> 5, c4 = idx & 31;
+      st[v] = *reinterpret_cast<const f32x4*>(src + k * D + chunk * RT_CH + c4 * 4);
+    }
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+      const int idx = v * 256 + threadIdx.x;
+      const int k = idx >> 5, c4 = idx & 31;
+      // logical 4-channel group c4 = 4 t + g  ->  plane g, row k, column 4 t
+      *reinterpret_cast<f32x4*>(&bt_lds[buf * RT_CHUNK + (c4 & 3) * RT_PLANE + k * RT_LD +
+                                        4 * (c4 >> 2)]) = st[v];
+    }
+  };
+  f32x4 xc[8], xn[8];
+  auto x_load = [&](int chunk, f32x4* dst) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) dst[t] = Elem<T>::ld4(xrow + chunk * RT_CH + 16 * t);
+  };
+
+  f32x4 acc[4];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) acc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float ss = 0.f;
+
+  stage_load(0);
+  if (active) x_load(0, xc);
+  stage_store(0);
+  __syncthreads();
+#pragma unroll 1
+  for (int c = 0; c < D / RT_CH; ++c) {
+    const bool more = c + 1 < D / RT_CH;
+    if (more) {
+      stage_load(c + 1);
+      if (active) x_load(c + 1, xn);
+    }
+    if (active) {
+      const float* wb = &bt_lds[(c & 1) * RT_CHUNK + g * RT_PLANE + i * RT_LD];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        f32x4 xa = xc[t];
+        if (!row_ok) xa = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 wv[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+          wv[kt] = *reinterpret_cast<const f32x4*>(wb + kt * 16 * RT_LD + 4 * t);
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt) acc[kt] = mfma16(xa[cc], wv[kt][cc], acc[kt]);
+          ss = fmaf(xa[cc], xa[cc], ss);
+        }
+      }
+    }
+    if (more) stage_store((c + 1) & 1);
+    __syncthreads();
+    if (more) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) xc[t] = xn[t];
+    }
+  }
+  if (!active) return;
+
+  if (MODE == ASSIGN) {
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    const float rn = p.pre_l2 ? 1.0f / sqrtf(fmaxf(ss, 1e-12f)) : 1.0f;
+    if (g == 0 && row_ok) p.rnorm[(int64_t)b * p.N + n] = rn;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = 4 * g + j;
+      const float rnr = __shfl(rn, row, 64);
+      float s[4], e[4];
+      float m = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        s[kt] = acc[kt][j] * rnr;
+        m = fmaxf(m, s[kt]);
+      }
+      m = q16_max(m);
+      float sum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        e[kt] = expf(s[kt] - m);
+        sum += e[kt];
+      }
+      const float inv = 1.0f / q16_sum(sum);
+      if (n0 + row < p.N) {
+        const int64_t o = ((int64_t)b * p.N + n0 + row) * K + i;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          p.assign[o + 16 * kt] = e[kt] * inv;
+          if (p.logit) p.logit[o + 16 * kt] = s[kt];
+        }
+      }
+    }
+  } else {
+    float cd[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) cd[kt] = p.cdu[b * K + 16 * kt + i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = 4 * g + j;
+      const bool ok = n0 + row < p.N;
+      const int64_t gr = (int64_t)b * p.N + (ok ? n0 + row : 0);
+      const int64_t o = gr * K + i;
+      const float rnr = p.rn_in[gr];
+      float a[4], t[4], ds[4], lg[4];
+      float dot = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        a[kt] = ok ? p.a_in[o + 16 * kt] : 0.f;
+        lg[kt] = ok ? p.logit_in[o + 16 * kt] : 0.f;
+        t[kt] = acc[kt][j] * rnr;                         // xhat · dU
+        dot += a[kt] * (t[kt] + cd[kt]);                  // + c · dU
+      }
+      dot = q16_sum(dot);
+      float rd = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        ds[kt] = a[kt] * ((t[kt] + cd[kt]) - dot);
+        // <d xhat[n,:], xhat[n,:]> = sum_k a (xhat·dU) + ds (xhat·W)
+        rd += a[kt] * t[kt] + ds[kt] * lg[kt];
+      }
+      rd = q16_sum(rd);
+      if (ok) {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) p.ds[o + 16 * kt] = ds[kt];
+        if (i == 0) p.rowdot[gr] = rd;
+      }
+    }
+  }
+}
+
 // V_part[b, half, d, k] = sum_{n in half} x[b,n,d] * (coefn[b,n,k] * rn[b,n])
 // grid (8 channel blocks of 64, NSPLIT, B); block 256; wave w contracts n-chunk split*4+w.
 template <typename T>
@@ -479,6 +665,179 @@ __global__ __launch_bounds__(256) void dx_kernel(const void* __restrict__ xv,
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// dx16_kernel: grad_x on 16-location tiles (v_mfma_f32_16x16x4_f32), 2-3 workgroups per CU.
+//   dxhat[n, d] = sum_{k<64} a[n,k] dU[b][d,k] + ds[n,k] W[d,k]        (K = 128)
+//   grad_x[n,d] = rn[n] * (dxhat[n,d] - x[n,d] * rn[n] * rowdot[n])
+// A operand (a | ds rows of the tile) stays in 8 registers per lane; the B operand
+// [dU[b] | W] is streamed in 32-channel chunks, double-buffered through the same
+// conflict-free plane image as rowtile16 (shared by the 4 waves); each finished
+// [16 x 32] accumulator block is transposed through a per-wave LDS scratch so every lane
+// loads / stores 8 consecutive channels of one location (16-byte bf16 accesses).
+constexpr int DX_CH = 32;
+constexpr int DX_PLANE = DX_CH * RT_LD;       // 1152 floats (= 18 x 64)
+constexpr int DX_CHUNK = 4 * DX_PLANE;        // 4608 floats per buffer
+constexpr int DX_SCR = 16 * RT_LD;            // per-wave transpose scratch
+constexpr size_t kDx16Lds = (2 * (size_t)DX_CHUNK + 4 * DX_SCR) * sizeof(float);   // 46,080 B
+
+template <typename T>
+struct Elem8;
+template <>
+struct Elem8<float> {
+  static __device__ __forceinline__ void ld(const float* p, float* v) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      v[c] = a[c];
+      v[4 + c] = b[c];
+    }
+  }
+  static __device__ __forceinline__ void st(float* p, const float* v) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+  }
+};
+template <>
+struct Elem8<unsigned short> {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ void ld(const unsigned short* p, float* v) {
+    const u32x4 w = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      v[2 * c] = __uint_as_float(w[c] << 16);
+      v[2 * c + 1] = __uint_as_float(w[c] & 0xffff0000u);
+    }
+  }
+  static __device__ __forceinline__ void st(unsigned short* p, const float* v) {
+    u32x4 w;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      w[c] = (unsigned)f32_to_bf16(v[2 * c]) | ((unsigned)f32_to_bf16(v[2 * c + 1]) << 16);
+    *reinterpret_cast<u32x4*>(p) = w;
+  }
+};
+
+// grid (ceil(ceil(N/16) / 4), B); block 256.
+template <typename T>
+__global__ __launch_bounds__(256, 2) void dx16_kernel(const void* __restrict__ xv,
+                                                      const float* __restrict__ a,
+                                                      const float* __restrict__ ds,
+                                                      const float* __restrict__ rn,
+                                                      const float* __restrict__ rowdot,
+                                                      const float* __restrict__ du,
+                                                      const float* __restrict__ w, int N,
+                                                      int pre_l2, void* __restrict__ gxv) {
+  extern __shared__ __attribute__((aligned(16))) float dx_lds[];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int b = blockIdx.y;
+  const int n0 = (blockIdx.x * 4 + wid) * 16;
+  const bool active = n0 < N;
+  float* scr = dx_lds + 2 * DX_CHUNK + wid * DX_SCR;
+  const float* dub = du + (int64_t)b * D * K;
+
+  // A operand: lane (i, g) holds a[n0+i][16t+4g..] (t < 4) and ds[n0+i][16(t-4)+4g..]
+  f32x4 af[8];
+  {
+    const bool ok = active && n0 + i < N;
+    const int64_t gr = (int64_t)b * N + (ok ? n0 + i : 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      af[t] = *reinterpret_cast<const f32x4*>(a + gr * K + 16 * t + 4 * g);
+      af[4 + t] = *reinterpret_cast<const f32x4*>(ds + gr * K + 16 * t + 4 * g);
+      if (!ok) {
+        af[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        af[4 + t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  }
+  // epilogue role of this lane: location row_e, channels 8 seg .. 8 seg + 7 of each chunk
+  const int row_e = lane >> 2, seg = lane & 3;
+  const bool ok_e = active && n0 + row_e < N;
+  const int64_t gr_e = (int64_t)b * N + (ok_e ? n0 + row_e : 0);
+  const float rn_e = pre_l2 ? rn[gr_e] : 1.0f;
+  const float rd_e = rowdot[gr_e];
+  // x * rsqrt(max(ss, eps)): with the clamp active the op is a plain scale (no projection)
+  const bool proj = pre_l2 && rn_e < 1.0e6f;
+  const T* x = reinterpret_cast<const T*>(xv) + gr_e * D + seg * 8;
+  T* gx = reinterpret_cast<T*>(gxv) + gr_e * D + seg * 8;
+
+  f32x4 st[4];
+  auto stage_load = [&](int chunk) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int idx = v * 256 + threadIdx.x;
+      const int dl = idx >> 5, c4 = idx & 31;
+      const float* s = c4 < 16 ? dub + (int64_t)(chunk * DX_CH + dl) * K + 4 * c4
+                               : w + (int64_t)(chunk * DX_CH + dl) * K + 4 * (c4 - 16);
+      st[v] = *reinterpret_cast<const f32x4*>(s);
+    }
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int idx = v * 256 + threadIdx.x;
+      const int dl = idx >> 5, c4 = idx & 31;
+      *reinterpret_cast<f32x4*>(&dx_lds[buf * DX_CHUNK + (c4 & 3) * DX_PLANE + dl * RT_LD +
+                                        4 * (c4 >> 2)]) = st[v];
+    }
+  };
+
+  stage_load(0);
+  stage_store(0);
+  __syncthreads();
+#pragma unroll 1
+  for (int c = 0; c < D / DX_CH; ++c) {
+    const bool more = c + 1 < D / DX_CH;
+    if (more) stage_load(c + 1);
+    float xin[8];
+    if (active && proj) Elem8<T>::ld(x + c * DX_CH, xin);
+    if (active) {
+      const float* wb = &dx_lds[(c & 1) * DX_CHUNK + g * DX_PLANE + i * RT_LD];
+      f32x4 acc[2];
+      acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(wb + 4 * t);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(wb + 16 * RT_LD + 4 * t);
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          acc[0] = mfma16(af[t][cc], b0[cc], acc[0]);
+          acc[1] = mfma16(af[t][cc], b1[cc], acc[1]);
+        }
+      }
+      // transpose the [16 x 32] block: accumulator (row 4g+j, channel 16dt+i) -> rows
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) scr[(4 * g + j) * RT_LD + 16 * dt + i] = acc[dt][j];
+      __builtin_amdgcn_wave_barrier();
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(&scr[row_e * RT_LD + 8 * seg]);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(&scr[row_e * RT_LD + 8 * seg + 4]);
+      __builtin_amdgcn_wave_barrier();
+      if (ok_e) {
+        float out[8];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          out[cc] = v0[cc];
+          out[4 + cc] = v1[cc];
+        }
+        if (proj) {
+          const float f = rn_e * rd_e;
+#pragma unroll
+          for (int cc = 0; cc < 8; ++cc) out[cc] -= xin[cc] * f;
+        }
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) out[cc] *= rn_e;
+        Elem8<T>::st(gx + c * DX_CH, out);
+      }
+    }
+    if (more) stage_store((c + 1) & 1);
+    __syncthreads();
+  }
+}
+
 // grad_w[d,k] = sum_b (slab0 + slab1);  grad_c[d,k] = sum_b dU[b,d,k] * asum[b,k]
 __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restrict__ wpart,
                                                            const float* __restrict__ du,
@@ -505,9 +864,14 @@ template <typename T, int MODE>
 void launch_rowtile(const RowTileArgs& a, hipStream_t st) {
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowtile_kernel<T, MODE>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRowTileLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowtile16_kernel<T, MODE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRowTile16Lds);
   });
+  const int tiles16 = (a.N + 15) / 16;
+  SCL_LAUNCH(MODE == ASSIGN ? "rowtile_assign" : "rowtile_dassign", (rowtile16_kernel<T, MODE>),
+             dim3((tiles16 + 3) / 4, a.B), dim3(256), kRowTile16Lds, st, a);
+  return;
+  // previous 32-location-tile version, kept for A/B builds
   const int tiles = (a.N + 31) / 32;
   SCL_LAUNCH(MODE == ASSIGN ? "rowtile_assign" : "rowtile_dassign", (rowtile_kernel<T, MODE>), dim3((tiles + 3) / 4, a.B), dim3(256), kRowTileLds,
                      st, a);
@@ -644,19 +1008,19 @@ extern "C" int scl_netvlad_bwd(const void* x, int x_dtype, const float* assign_w
   a.cdu = w.cdu;
   a.ds = w.ds;
   a.rowdot = w.rowdot;
-  const dim3 dxgrid((N + 31) / 32, B);
+  const dim3 dxgrid(((N + 15) / 16 + 3) / 4, B);
   if (x_dtype == SCL_DT_F32) {
     launch_rowtile<float, DASSIGN>(a, st);
     SCL_LAUNCH("aggregate_dw", aggregate_kernel<float>, dim3(D / 64, NSPLIT, B), dim3(256), 0, st, x,
                        (const float*)w.ds, save_rnorm, N, w.wpart, (float*)nullptr);
-    SCL_LAUNCH("dx_kernel", dx_kernel<float>, dxgrid, dim3(256), 0, st, x, save_assign,
+    SCL_LAUNCH("dx_kernel", dx16_kernel<float>, dxgrid, dim3(256), kDx16Lds, st, x, save_assign,
                        (const float*)w.ds, save_rnorm, (const float*)w.rowdot,
                        (const float*)w.du, assign_w, N, pre_l2 ? 1 : 0, grad_x);
   } else {
     launch_rowtile<unsigned short, DASSIGN>(a, st);
     SCL_LAUNCH("aggregate_dw", aggregate_kernel<unsigned short>, dim3(D / 64, NSPLIT, B), dim3(256), 0, st,
                        x, (const float*)w.ds, save_rnorm, N, w.wpart, (float*)nullptr);
-    SCL_LAUNCH("dx_kernel", dx_kernel<unsigned short>, dxgrid, dim3(256), 0, st, x, save_assign,
+    SCL_LAUNCH("dx_kernel", dx16_kernel<unsigned short>, dxgrid, dim3(256), kDx16Lds, st, x, save_assign,
                        (const float*)w.ds, save_rnorm, (const float*)w.rowdot,
                        (const float*)w.du, assign_w, N, pre_l2 ? 1 : 0, grad_x);
   }
