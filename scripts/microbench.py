@@ -1,0 +1,116 @@
+#!/usr/bin/env python
+"""Kernel-only microbenchmarks of the hand-written hot path (no VGG backbone, so no MIOpen
+warm-up): NetVLAD forward+backward at the bench shape, the Gram-loss B-sweep of SURVEY H3,
+and the retrieval configuration (BASELINE.json configs[4]).
+
+    python scripts/microbench.py [--what netvlad,loss,topn] [--iters 20] [--json out.json]
+
+Per-kernel durations come from the library's scl_prof_* sink (HIP events on the launch
+stream).  Under rocprofv3 run this file directly:  rocprofv3 ... -- python3 scripts/microbench.py
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import bench  # noqa: E402  (kernel_models / price)
+from soft_contrastive_learning_amd import _lib  # noqa: E402
+from soft_contrastive_learning_amd.evaluation import retrieval  # noqa: E402
+from soft_contrastive_learning_amd.model import losses, nets  # noqa: E402
+from tests import util_data as U  # noqa: E402
+
+
+def run_netvlad(dev, b, n, dtype, iters):
+    x = torch.tensor(U.feature_map(b, n, seed=5), device=dev).to(dtype).reshape(b, 1, n, 512)
+    x.requires_grad_(True)
+    w, c = U.vlad_params()
+    wt = torch.tensor(w, device=dev, requires_grad=True)
+    ct = torch.tensor(c, device=dev, requires_grad=True)
+    g = torch.randn(b, 32768, device=dev)
+    for _ in range(3):
+        nets.netvlad(x, wt, ct, True).backward(g)
+    torch.cuda.synchronize()
+    with _lib.KernelTimer(capacity=32 * iters) as kt:
+        for _ in range(iters):
+            nets.netvlad(x, wt, ct, True).backward(g)
+        torch.cuda.synchronize()
+    models = bench.kernel_models(b, n, b, 2 if dtype == torch.bfloat16 else 4)
+    return [bench.price(k, cnt, ms, models[k]) for k, (cnt, ms) in sorted(kt.summary().items())]
+
+
+def run_loss(dev, b, iters):
+    emb = torch.tensor(U.embeddings(b, 32768), device=dev, requires_grad=True)
+    dist = torch.tensor(U.positions_distances(b)[None], device=dev)
+    for _ in range(3):
+        losses.wms_loss(dist, emb, 0.8, 15.0).backward()
+    torch.cuda.synchronize()
+    with _lib.KernelTimer(capacity=16 * iters) as kt:
+        for _ in range(iters):
+            losses.wms_loss(dist, emb, 0.8, 15.0).backward()
+        torch.cuda.synchronize()
+    models = bench.kernel_models(b, 1200, b, 4)
+    rows = [bench.price(k, cnt, ms, models[k]) for k, (cnt, ms) in sorted(kt.summary().items())]
+    for r in rows:
+        r['B'] = b
+    return rows
+
+
+def run_topn(dev, r, q, d, n, iters):
+    ref, qry = U.retrieval_sets(r, q, d)
+    rt, qt = torch.tensor(ref, device=dev), torch.tensor(qry, device=dev)
+    retrieval.topn_l2(rt, qt, n)
+    torch.cuda.synchronize()
+    with _lib.KernelTimer(capacity=8 * iters) as kt:
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            retrieval.topn_l2(rt, qt, n)
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / iters
+    out = []
+    for k, (cnt, ms) in sorted(kt.summary().items()):
+        row = dict(kernel=k, launches=cnt, us=round(ms * 1e3, 1))
+        if k == 'topn_scan_kernel':
+            tf = 2.0 * q * r * d / (ms * 1e-3) / 1e12
+            row.update(bound='mfma', tflops=round(tf, 2), frac=round(tf / bench.PEAK_F32_TFLOPS, 4))
+        out.append(row)
+    out.append(dict(kernel='topn_l2 (whole call)', us=round(wall * 1e6, 1),
+                    queries_per_sec=round(q / wall, 1), R=r, Q=q, d=d, n=n))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--what', default='netvlad,loss,topn')
+    ap.add_argument('--iters', type=int, default=20)
+    ap.add_argument('--json', default='')
+    ap.add_argument('--topn-refs', type=int, default=100000)
+    ap.add_argument('--topn-queries', type=int, default=10000)
+    args = ap.parse_args()
+    dev = torch.device('cuda:0')
+    what = args.what.split(',')
+    res = {}
+    if 'netvlad' in what:
+        res['netvlad_bf16_b24_n1200'] = run_netvlad(dev, 24, 1200, torch.bfloat16, args.iters)
+        res['netvlad_f32_b24_n1200'] = run_netvlad(dev, 24, 1200, torch.float32, args.iters)
+    if 'loss' in what:
+        res['wms_loss_sweep'] = sum((run_loss(dev, b, args.iters) for b in (24, 48, 96, 192)), [])
+    if 'topn' in what:
+        res['topn'] = run_topn(dev, args.topn_refs, args.topn_queries, 256, 25, max(2, args.iters // 10))
+    for name, rows in res.items():
+        print('==', name)
+        for r in rows:
+            print('  ', json.dumps(r))
+    if args.json:
+        with open(args.json, 'w') as f:
+            json.dump(res, f, indent=1)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,87 @@
+"""Feature-extraction counterpart of the reference's ``evaluation/inference.py``.
+
+Reproduces ``infer()`` (evaluation/inference.py:147-192): the image list is padded with
+copies of image 0 up to a multiple of ``images_per_pass`` (:172-175), batches go through
+``vgg16Netvlad`` forward-only (:89-90, :46), results are re-ordered by original index,
+padding rows are dropped (:186-191) and the product is a pickle holding a ``list`` of
+``np.ndarray(32768,) float32`` in list order (:192).
+
+Image decoding / resizing (cv2, util/cv.py) is dataset-bound and out of scope; callers
+hand in a loader ``index -> np.ndarray[H,W,3] uint8/float`` (a synthetic one is provided).
+"""
+import argparse
+import os
+import pickle
+
+import numpy as np
+import torch
+
+from .. import checkpoint
+from ..model import nets
+
+
+def pad_indices(num, images_per_pass):
+    """evaluation/inference.py:172-175 — note the reference pads a FULL extra pass when
+    ``num`` is already a multiple (``images_per_pass - num % images_per_pass``)."""
+    padding = [0] * (images_per_pass - (num % images_per_pass))
+    return np.concatenate((np.arange(num), np.array(padding, dtype=int))).astype(int)
+
+
+def extract_features(model, loader, num, images_per_pass=4, device=None):
+    """Returns ``list`` of ``num`` float32 vectors of length 32768, in index order."""
+    device = device or next(model.parameters()).device
+    order = pad_indices(num, images_per_pass)
+    feats = [None] * len(order)
+    with torch.no_grad():
+        for s in range(0, len(order), images_per_pass):
+            idx = order[s:s + images_per_pass]
+            batch = np.stack([np.asarray(loader(int(i)), dtype=np.float32) for i in idx])
+            out = nets.vgg16Netvlad(torch.from_numpy(batch).to(device), model=model)
+            out = out.float().cpu().numpy()
+            for slot, f in zip(range(s, s + len(idx)), out):
+                feats[slot] = f
+    return feats[:num]
+
+
+def save_pickle(data, out_file):
+    with open(out_file, 'wb') as f:
+        pickle.dump(data, f)
+
+
+def synthetic_loader(height, width, seed=42):
+    def load(i):
+        rng = np.random.default_rng(seed + i)
+        return rng.integers(0, 256, size=(height, width, 3)).astype(np.float32)
+    return load
+
+
+def main(argv=None):
+    p = argparse.ArgumentParser()
+    # flag names of evaluation/inference.py:204-230
+    p.add_argument('--small_side', default=180, type=int)
+    p.add_argument('--large_side', default=240, type=int)
+    p.add_argument('--set', default='synthetic')
+    p.add_argument('--checkpoint', default='')
+    p.add_argument('--out_name', default='scl_amd')
+    p.add_argument('--reduction', default='none')
+    p.add_argument('--vlad_cores', default=64, type=int)
+    p.add_argument('--out_root', default='./scl_lv')
+    p.add_argument('--images_per_pass', type=int, default=4)
+    p.add_argument('--num_images', type=int, default=10, help='synthetic set size')
+    flags = p.parse_args(argv)
+    if flags.vlad_cores != 64 or flags.reduction not in ('none', 'pca'):
+        raise SystemExit('only --vlad_cores 64 with --reduction none|pca is on the hot path')
+    np.random.seed(42)                                       # inference.py:270-271
+    model = nets.VGG16NetVLAD().cuda()
+    if flags.checkpoint:
+        checkpoint.load(model, flags.checkpoint)
+    feats = extract_features(model, synthetic_loader(flags.small_side, flags.large_side),
+                             flags.num_images, flags.images_per_pass)
+    os.makedirs(flags.out_root, exist_ok=True)
+    out = os.path.join(flags.out_root, '{}_{}.pickle'.format(flags.set, flags.out_name))
+    save_pickle(feats, out)
+    print('wrote', out, len(feats), feats[0].shape, feats[0].dtype)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,74 @@
+"""Retrieval counterpart of the reference's ``evaluation/top-n.py``.
+
+``get_top_n`` reproduces the body of the reference function (evaluation/top-n.py:65-119):
+PCA(whiten=True, n_components=d) fitted on a PCA set and applied to reference and query
+features (:74-77, CPU / scikit-learn like the reference: SURVEY §8f keeps the fit on the
+host), greedy thinning of the reference list by distance ``l`` (:91-94), exact L2 top-N of
+every query (:103-108) — here the fused HIP kernel instead of ``KDTree.query`` —
+geographic distances of the hits (:110), ground truth (:112-113), translation back to the
+original indices (:116-117) and the output list
+``[top_i, top_g_dists, top_f_dists, gt_i, gt_g_dist, ref_idx]`` (:119).
+"""
+import numpy as np
+import torch
+
+from . import retrieval
+
+
+def thin_reference(ref_xy, l):
+    """evaluation/top-n.py:91-94."""
+    ref_idx = [0]
+    for i in range(len(ref_xy)):
+        if sum((ref_xy[i, :] - ref_xy[ref_idx[-1], :]) ** 2) >= l ** 2:
+            ref_idx.append(i)
+    return ref_idx
+
+
+def _pad_dim(a, d):
+    """the HIP kernel takes d in {32,64,128,256}: zero-pad (distances are unchanged)."""
+    for cand in (32, 64, 128, 256):
+        if d <= cand:
+            if a.shape[1] == cand:
+                return a
+            out = np.zeros((a.shape[0], cand), dtype=np.float32)
+            out[:, :a.shape[1]] = a
+            return out
+    raise ValueError("feature dimension %d > 256 is not supported by the top-n kernel" % d)
+
+
+def get_top_n(pca_f, full_ref_f, full_query_f, full_ref_xy, full_query_xy, n=25, d=256, l=0.0,
+              device='cuda'):
+    """Arrays in, the reference's pickle payload out (None when fewer than n references
+    survive the thinning, like the reference's ``continue`` at :96-97)."""
+    from sklearn.decomposition import PCA
+    from sklearn.metrics import pairwise_distances
+    full_xy_dists = pairwise_distances(full_query_xy, full_ref_xy, metric='euclidean')
+    pca = PCA(whiten=True, n_components=d).fit(np.asarray(pca_f))
+    pca_ref_f = pca.transform(np.asarray(full_ref_f))
+    pca_query_f = pca.transform(np.asarray(full_query_f))
+
+    ref_idx = thin_reference(np.asarray(full_ref_xy), l)
+    if len(ref_idx) < n:
+        return None
+    ref_f = pca_ref_f[ref_idx].astype(np.float32)
+    xy_dists = full_xy_dists[:, ref_idx]
+    num_q = pca_query_f.shape[0]
+
+    dist, idx = retrieval.topn_l2(torch.from_numpy(_pad_dim(ref_f, d)).to(device),
+                                  torch.from_numpy(_pad_dim(pca_query_f.astype(np.float32), d))
+                                  .to(device), n)
+    top_f_dists = dist.cpu().numpy()
+    top_i = idx.cpu().numpy().astype(int)
+    top_g_dists = [[xy_dists[q, r] for r in top_i[q, :]] for q in range(num_q)]
+    gt_i = np.argmin(xy_dists, axis=1)
+    gt_g_dist = np.min(xy_dists, axis=1)
+    top_i = [[ref_idx[r] for r in top_i[q, :]] for q in range(num_q)]
+    gt_i = [ref_idx[r] for r in gt_i]
+    return [top_i, top_g_dists, top_f_dists, gt_i, gt_g_dist, ref_idx]
+
+
+def recall_at(top_g_dists, thresholds, n=1):
+    """% of queries whose best geographic distance over the first n hits is below each
+    threshold (train/train.py:363-376; evaluation/roc.py:213-216 uses n=1)."""
+    g = np.asarray(top_g_dists, dtype=np.float64)[:, :n].min(axis=1)
+    return np.array([np.mean(g < x) for x in thresholds])
