@@ -70,7 +70,8 @@ def kernel_models(b, n, gb, x_bytes):
         'rowtile_assign': dict(flops=2.0 * bn * D * K, bytes=bn * D * x_bytes + bn * K * 8 + bn * 4),
         # x^T·(a rn); reads x and a once, writes 2 slabs per image
         'aggregate_kernel': dict(flops=2.0 * bn * D * K, bytes=bn * D * x_bytes + bn * K * 4 + b * 2 * D * K * 4),
-        'finish_kernel': dict(flops=6.0 * b * D * K, bytes=b * D * K * 4 * 4),
+        'finish_sum_kernel': dict(flops=6.0 * b * D * K, bytes=b * D * K * 4 * 6),
+        'finish_norm_kernel': dict(flops=2.0 * b * D * K, bytes=b * D * K * 4 * 2),
         'bwd_prep_kernel': dict(flops=12.0 * b * D * K, bytes=b * D * K * 4 * 4),
         'rowtile_dassign': dict(flops=2.0 * bn * D * K, bytes=bn * D * x_bytes + bn * K * 12 + b * D * K * 4),
         'aggregate_dw': dict(flops=2.0 * bn * D * K, bytes=bn * D * x_bytes + bn * K * 4 + b * 2 * D * K * 4),

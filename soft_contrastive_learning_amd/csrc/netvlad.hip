@@ -19,7 +19,7 @@
 //                            half-wave butterflies -> a, rn (+ logits for training)
 //   aggregate_kernel         per (image, 32-channel tile, location half): x^T·(a rn),
 //                            split over 4 waves along n, LDS reduce -> partial slabs
-//   finish_kernel            slabs + C*asum, intra-norm over D, global norm -> out
+//   finish_sum/norm_kernel   slabs + C*asum, intra-norm over D, global norm -> out
 // Backward kernels
 //   bwd_prep_kernel          grad through both norms -> dU (both layouts), c·dU
 //   rowtile_kernel<DASSIGN>  x·dU[b] -> d a -> softmax backward -> ds, <dxhat,xhat>
@@ -220,7 +220,9 @@ __global__ __launch_bounds__(256, 2) void rowtile16_kernel(RowTileArgs p) {
 #pragma unroll
     for (int v = 0; v < 8; ++v) {
       const int idx = v * 256 + threadIdx.x;
-      const int k = idx >> 5, c4 = idx & 31;
+      // 8 consecutive lanes take the 8 groups of one plane (conflict-free ds_write_b128);
+      // a 32-lane run still covers one whole 512-byte row segment
+      const int k = idx >> 5, c4 = 4 * (idx & 7) + ((idx >> 3) & 3);
       st[v] = *reinterpret_cast<const f32x4*>(src + k * D + chunk * RT_CH + c4 * 4);
     }
   };
@@ -228,7 +230,9 @@ __global__ __launch_bounds__(256, 2) void rowtile16_kernel(RowTileArgs p) {
 #pragma unroll
     for (int v = 0; v < 8; ++v) {
       const int idx = v * 256 + threadIdx.x;
-      const int k = idx >> 5, c4 = idx & 31;
+      // 8 consecutive lanes take the 8 groups of one plane (conflict-free ds_write_b128);
+      // a 32-lane run still covers one whole 512-byte row segment
+      const int k = idx >> 5, c4 = 4 * (idx & 7) + ((idx >> 3) & 3);
       // logical 4-channel group c4 = 4 t + g  ->  plane g, row k, column 4 t
       *reinterpret_cast<f32x4*>(&bt_lds[buf * RT_CHUNK + (c4 & 3) * RT_PLANE + k * RT_LD +
                                         4 * (c4 >> 2)]) = st[v];
@@ -514,36 +518,59 @@ __device__ __forceinline__ void vlad_norms(VladNorm& v, float* colbuf /*[16][64]
   v.g = 1.0f / sqrtf(tot + 1e-12f);
 }
 
-// grid B; block 1024.
-__global__ __launch_bounds__(1024) void finish_kernel(const float* __restrict__ part,
-                                                      const float* __restrict__ colsum_part,
-                                                      const float* __restrict__ centers,
-                                                      float* __restrict__ out,
-                                                      float* __restrict__ save_vlad) {
-  __shared__ float colbuf[16 * 64];
-  __shared__ float scratch[32];
-  const int b = blockIdx.x, k = threadIdx.x & 63, dg = threadIdx.x >> 6;
+// Forward finish in two small launches of 8 x B workgroups (a single workgroup per image
+// left 232 CUs idle and took 3x longer):
+//   finish_sum_kernel   U = slabs + C * asum for one 64-channel block -> vlad[b] (the saved
+//                       pre-norm VLAD) and the block's column sums of squares
+//   finish_norm_kernel  q_k = rsqrt(col_k + eps), g = rsqrt(sum_k q_k^2 col_k + eps) — the
+//                       global norm needs only the column sums — then out = U q g
+// grid (8, B); block 256: thread -> k = t & 63, dq = t >> 6 (4 groups of 16 channels).
+__global__ __launch_bounds__(256) void finish_sum_kernel(const float* __restrict__ part,
+                                                         const float* __restrict__ colsum_part,
+                                                         const float* __restrict__ centers,
+                                                         float* __restrict__ vlad,
+                                                         float* __restrict__ colsq_part) {
+  __shared__ float colbuf[4 * 64];
+  const int blk = blockIdx.x, b = blockIdx.y, k = threadIdx.x & 63, dq = threadIdx.x >> 6;
   float asum = 0.f;
 #pragma unroll
   for (int s = 0; s < NSPLIT; ++s) asum += colsum_part[((int64_t)b * NSPLIT + s) * K + k];
-  VladNorm v;
+  float ss = 0.f;
 #pragma unroll
-  for (int i = 0; i < 32; ++i) {
-    const int d = dg * 32 + i;
+  for (int i = 0; i < 16; ++i) {
+    const int d = blk * 64 + dq * 16 + i;
     float p = 0.f;
 #pragma unroll
     for (int s = 0; s < NSPLIT; ++s) p += part[(((int64_t)b * NSPLIT + s) * D + d) * K + k];
-    v.u[i] = p + centers[d * K + k] * asum;
+    const float u = p + centers[d * K + k] * asum;
+    vlad[((int64_t)b * (D + 1) + d) * K + k] = u;
+    ss = fmaf(u, u, ss);
   }
-  if (save_vlad) {
+  if (blk == 0 && dq == 0) vlad[((int64_t)b * (D + 1) + D) * K + k] = asum;
+  colbuf[dq * 64 + k] = ss;
+  __syncthreads();
+  if (dq == 0)
+    colsq_part[((int64_t)b * 8 + blk) * K + k] =
+        (colbuf[k] + colbuf[64 + k]) + (colbuf[128 + k] + colbuf[192 + k]);
+}
+
+__global__ __launch_bounds__(256) void finish_norm_kernel(const float* __restrict__ vlad,
+                                                          const float* __restrict__ colsq_part,
+                                                          float* __restrict__ out) {
+  const int blk = blockIdx.x, b = blockIdx.y, k = threadIdx.x & 63, dq = threadIdx.x >> 6;
+  float col = 0.f;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) save_vlad[((int64_t)b * (D + 1) + dg * 32 + i) * K + k] = v.u[i];
-    if (dg == 0) save_vlad[((int64_t)b * (D + 1) + D) * K + k] = asum;
+  for (int j = 0; j < 8; ++j) col += colsq_part[((int64_t)b * 8 + j) * K + k];
+  // matconvnetNormalize: x / sqrt(sum x^2 + 1e-12), epsilon inside the sqrt
+  const float q = 1.0f / sqrtf(col + 1e-12f);
+  // every one of the 4 waves holds all 64 columns: a wave sum gives sum_k (q_k^2 col_k)
+  const float tot = wave_sum(q * q * col);
+  const float g = 1.0f / sqrtf(tot + 1e-12f);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int d = blk * 64 + dq * 16 + i;
+    out[(int64_t)b * D * K + d * K + k] = vlad[((int64_t)b * (D + 1) + d) * K + k] * q * g;
   }
-  vlad_norms(v, colbuf, scratch);
-#pragma unroll
-  for (int i = 0; i < 32; ++i)
-    out[(int64_t)b * D * K + (dg * 32 + i) * K + k] = v.u[i] * v.q * v.g;
 }
 
 // grid B; block 1024.  Gradient through the global and the intra normalisation.
@@ -767,7 +794,7 @@ __global__ __launch_bounds__(256, 2) void dx16_kernel(const void* __restrict__ x
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       const int idx = v * 256 + threadIdx.x;
-      const int dl = idx >> 5, c4 = idx & 31;
+      const int dl = idx >> 5, c4 = 4 * (idx & 7) + ((idx >> 3) & 3);
       const float* s = c4 < 16 ? dub + (int64_t)(chunk * DX_CH + dl) * K + 4 * c4
                                : w + (int64_t)(chunk * DX_CH + dl) * K + 4 * (c4 - 16);
       st[v] = *reinterpret_cast<const f32x4*>(s);
@@ -777,7 +804,7 @@ __global__ __launch_bounds__(256, 2) void dx16_kernel(const void* __restrict__ x
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       const int idx = v * 256 + threadIdx.x;
-      const int dl = idx >> 5, c4 = idx & 31;
+      const int dl = idx >> 5, c4 = 4 * (idx & 7) + ((idx >> 3) & 3);
       *reinterpret_cast<f32x4*>(&dx_lds[buf * DX_CHUNK + (c4 & 3) * DX_PLANE + dl * RT_LD +
                                         4 * (c4 >> 2)]) = st[v];
     }
@@ -889,7 +916,7 @@ struct Carver {
 };
 
 struct FwdWs {
-  float *wt, *part, *colsum, *assign, *rnorm;
+  float *wt, *part, *colsum, *colsq, *vlad, *assign, *rnorm;
   size_t total;
 };
 inline FwdWs carve_fwd(void* ws, int B, int N) {
@@ -898,6 +925,8 @@ inline FwdWs carve_fwd(void* ws, int B, int N) {
   w.wt = c.take((size_t)D * K);
   w.part = c.take((size_t)B * NSPLIT * D * K);
   w.colsum = c.take((size_t)B * NSPLIT * K);
+  w.colsq = c.take((size_t)B * 8 * K);
+  w.vlad = c.take((size_t)B * (D + 1) * K);
   w.assign = c.take((size_t)B * N * K);
   w.rnorm = c.take((size_t)B * N);
   w.total = c.off;
@@ -966,8 +995,11 @@ extern "C" int scl_netvlad_fwd(const void* x, int x_dtype, const float* assign_w
     SCL_LAUNCH("aggregate_kernel", aggregate_kernel<unsigned short>, dim3(D / 64, NSPLIT, B), dim3(256), 0, st,
                        x, (const float*)assign, (const float*)rnorm, N, w.part, w.colsum);
   }
-  SCL_LAUNCH("finish_kernel", finish_kernel, dim3(B), dim3(1024), 0, st, (const float*)w.part,
-                     (const float*)w.colsum, centers, out, save_vlad);
+  float* vlad = save_vlad ? save_vlad : w.vlad;
+  SCL_LAUNCH("finish_sum_kernel", finish_sum_kernel, dim3(8, B), dim3(256), 0, st,
+             (const float*)w.part, (const float*)w.colsum, centers, vlad, w.colsq);
+  SCL_LAUNCH("finish_norm_kernel", finish_norm_kernel, dim3(8, B), dim3(256), 0, st,
+             (const float*)vlad, (const float*)w.colsq, out);
   return scl_launch_status();
 }
 

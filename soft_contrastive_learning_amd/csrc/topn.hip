@@ -25,7 +25,6 @@
 namespace {
 
 constexpr int KEEP = 32;   // candidates kept per (query, split)
-constexpr int CAP = 64;    // list capacity = KEEP + one 32-reference tile
 constexpr int QW = 4;      // waves (32-query tiles) per workgroup
 constexpr int kMaxN = 25;
 
@@ -47,45 +46,49 @@ __global__ __launch_bounds__(256) void refnorm_kernel(const float* __restrict__ 
   if (lane == 0) out[row] = s;
 }
 
-// Rank-count compaction of one query's list by one wave: entry e = lane.  Keeps the
-// KEEP smallest (score, index) pairs in sorted order and returns the new threshold.
-__device__ __forceinline__ float compact_list(float* sc, int* ix, int count, int lane) {
-  const bool valid = lane < count;
-  const float ms = valid ? sc[lane] : INFINITY;
-  const int mi = valid ? ix[lane] : INT_MAX;
+// Rank-count sort of one query's KEEP-entry list by one wave (entry e = lane & 31):
+// afterwards the list is ascending by (score, index).
+__device__ __forceinline__ void sort_list(float* sc, int* ix, int lane) {
+  const int e = lane & (KEEP - 1);
+  const float ms = sc[e];
+  const int mi = ix[e];
   int rank = 0;
-  for (int e = 0; e < CAP; ++e) {
-    const float os = e < count ? sc[e] : INFINITY;
-    const int oi = e < count ? ix[e] : INT_MAX;
+  for (int o = 0; o < KEEP; ++o) {
+    const float os = sc[o];
+    const int oi = ix[o];
     rank += (os < ms) || (os == ms && oi < mi);
   }
   __builtin_amdgcn_wave_barrier();
-  if (valid && rank < KEEP) {
+  if (lane < KEEP) {
     sc[rank] = ms;
     ix[rank] = mi;
   }
   __builtin_amdgcn_wave_barrier();
-  return count >= KEEP ? sc[KEEP - 1] : INFINITY;
 }
 
 // grid (ceil(Q/128), splits); block 256.  Dynamic LDS:
-//   tile[2][32][d+4] | refn[2][32] | lsc[QW][32][CAP] | lix[QW][32][CAP] | cnt[QW][32] | tau[QW][32]
+//   tile[32][d+4] | refn[32] | lsc[QW][32][KEEP] | lix[QW][32][KEEP] | tau[QW][32]
+// Every query keeps a SORTED list of its KEEP best (score, index) pairs.  The first tile of
+// a split fills the lists (one rank-count sort each); afterwards a score below the query's
+// threshold (its current KEEP-th best) is inserted by the whole wave in O(1): position by
+// ballot + popcount, shift by one lane, write back — no per-candidate sort.  Single tile
+// buffer + register prefetch (65 KB of LDS: two workgroups per CU, so one workgroup's
+// selection overlaps the other's MFMAs).
 template <int D8>
-__global__ __launch_bounds__(256) void topn_scan_kernel(const float* __restrict__ ref,
-                                                        const float* __restrict__ refnorm, int R,
-                                                        const float* __restrict__ query, int Q,
-                                                        int refs_per_split,
-                                                        float* __restrict__ cand_sc,
-                                                        int* __restrict__ cand_ix) {
+__global__ __launch_bounds__(256, 2) void topn_scan_kernel(const float* __restrict__ ref,
+                                                           const float* __restrict__ refnorm,
+                                                           int R, const float* __restrict__ query,
+                                                           int Q, int refs_per_split,
+                                                           float* __restrict__ cand_sc,
+                                                           int* __restrict__ cand_ix) {
   constexpr int d = D8 * 8;
   constexpr int LD = d + 4;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* tile = lds;                                   // 2 * 32 * LD
-  float* refn = tile + 2 * 32 * LD;                    // 2 * 32
-  float* lsc = refn + 64;                              // QW * 32 * CAP
-  int* lix = reinterpret_cast<int*>(lsc + QW * 32 * CAP);
-  int* cnt = lix + QW * 32 * CAP;                      // QW * 32
-  float* tau = reinterpret_cast<float*>(cnt + QW * 32);
+  float* tile = lds;                                   // 32 * LD
+  float* refn = tile + 32 * LD;                        // 32
+  float* lsc = refn + 32;                              // QW * 32 * KEEP
+  int* lix = reinterpret_cast<int*>(lsc + QW * 32 * KEEP);
+  float* tau = reinterpret_cast<float*>(lix + QW * 32 * KEEP);   // QW * 32
 
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -107,17 +110,12 @@ __global__ __launch_bounds__(256) void topn_scan_kernel(const float* __restrict_
       if (qrow >= Q) qf[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
-  float* my_sc = lsc + wid * 32 * CAP;
-  int* my_ix = lix + wid * 32 * CAP;
-  int* my_cnt = cnt + wid * 32;
+  float* my_sc = lsc + wid * 32 * KEEP;
+  int* my_ix = lix + wid * 32 * KEEP;
   float* my_tau = tau + wid * 32;
-  if (lane < 32) {
-    my_cnt[lane] = 0;
-    my_tau[lane] = INFINITY;
-  }
 
-  // staging: 256 threads move one [32][d] tile as float4 (D8*2*32/256 = D8/4 per thread)
-  constexpr int V4 = (32 * d / 4) / 256;  // float4 per thread
+  // staging: 256 threads move one [32][d] tile as float4
+  constexpr int V4 = (32 * d / 4) / 256;
   static_assert(V4 >= 1, "d too small for the staging layout");
   f32x4 stage[V4];
   float stage_n = 0.f;
@@ -136,19 +134,19 @@ __global__ __launch_bounds__(256) void topn_scan_kernel(const float* __restrict_
       stage_n = rr < r_end ? refnorm[rr] : INFINITY;  // padding rows never qualify
     }
   };
-  auto stage_store = [&](int buf) {
+  auto stage_store = [&]() {
 #pragma unroll
     for (int v = 0; v < V4; ++v) {
       const int idx = v * 256 + threadIdx.x;
       const int row = idx / (d / 4), c4 = idx % (d / 4);
-      *reinterpret_cast<f32x4*>(&tile[(buf * 32 + row) * LD + c4 * 4]) = stage[v];
+      *reinterpret_cast<f32x4*>(&tile[row * LD + c4 * 4]) = stage[v];
     }
-    if (threadIdx.x < 32) refn[buf * 32 + threadIdx.x] = stage_n;
+    if (threadIdx.x < 32) refn[threadIdx.x] = stage_n;
   };
 
   if (ntiles > 0) {
     stage_load(0);
-    stage_store(0);
+    stage_store();
   }
   __syncthreads();
   float tq[16];
@@ -156,9 +154,8 @@ __global__ __launch_bounds__(256) void topn_scan_kernel(const float* __restrict_
   for (int q = 0; q < 16; ++q) tq[q] = INFINITY;
 
   for (int t = 0; t < ntiles; ++t) {
-    const int buf = t & 1;
     if (t + 1 < ntiles) stage_load(t + 1);
-    const float* bp = &tile[(buf * 32 + r) * LD + 4 * h];
+    const float* bp = &tile[r * LD + 4 * h];
     f32x16 acc = zero16();
 #pragma unroll
     for (int u = 0; u < D8; ++u) {
@@ -166,51 +163,77 @@ __global__ __launch_bounds__(256) void topn_scan_kernel(const float* __restrict_
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc = mfma32(qf[u][c], bv[c], acc);
     }
-    const float rnj = refn[buf * 32 + r];
+    const float rnj = refn[r];
     const int ridx = r_begin + t * 32 + r;
+    __syncthreads();                       // every wave is done reading the tile
+    if (t + 1 < ntiles) stage_store();     // refill it under the selection below
+
+    if (t == 0) {
+      // first tile of the split: every list takes the 32 scores as they are, then sorts
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const float sc = rnj - 2.0f * acc[q];
-      if (sc < tq[q]) {
+      for (int q = 0; q < 16; ++q) {
         const int row = acc_row(q, h);
-        const int pos = atomicAdd(&my_cnt[row], 1);
-        my_sc[row * CAP + pos] = sc;
-        my_ix[row * CAP + pos] = ridx;
+        my_sc[row * KEEP + r] = rnj - 2.0f * acc[q];
+        my_ix[row * KEEP + r] = ridx;
       }
-    }
-    __builtin_amdgcn_wave_barrier();
-    // compaction whenever a list could overflow on the next tile
-    const int c = lane < 32 ? my_cnt[lane] : 0;
-    unsigned long long need = __ballot(c > KEEP);
-    if (need) {
-      while (need) {
-        const int row = __ffsll((long long)need) - 1;
-        need &= need - 1;
-        const int count = my_cnt[row];
-        const float nt = compact_list(my_sc + row * CAP, my_ix + row * CAP, count, lane);
-        if (lane == 0) {
-          my_cnt[row] = KEEP;
-          my_tau[row] = nt;
-        }
-      }
+      __builtin_amdgcn_wave_barrier();
+      for (int row = 0; row < 32; ++row) sort_list(my_sc + row * KEEP, my_ix + row * KEEP, lane);
+      if (lane < 32) my_tau[lane] = my_sc[lane * KEEP + KEEP - 1];
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int q = 0; q < 16; ++q) tq[q] = my_tau[acc_row(q, h)];
+    } else {
+      bool any = false;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float sc = rnj - 2.0f * acc[q];
+        unsigned long long m = __ballot(sc < tq[q]);
+        while (m) {
+          const int L = __ffsll((long long)m) - 1;
+          m &= m - 1;
+          any = true;
+          const int row = acc_row(q, L >> 5);
+          const float s = __shfl(sc, L, 64);
+          const int id = r_begin + t * 32 + (L & 31);
+          // sorted insertion by the whole wave: lanes 0..31 mirror the list entries
+          float* ls = my_sc + row * KEEP;
+          int* li = my_ix + row * KEEP;
+          const int e = lane & (KEEP - 1);
+          const float cs = ls[e];
+          const int ci = li[e];
+          const bool before = (cs < s) || (cs == s && ci < id);
+          const int pos = __popcll(__ballot(before) & 0xffffffffull);
+          if (pos < KEEP) {
+            const float ps = __shfl_up(cs, 1, 64);
+            const int pi = __shfl_up(ci, 1, 64);
+            const float ns = e < pos ? cs : (e == pos ? s : ps);
+            const int ni = e < pos ? ci : (e == pos ? id : pi);
+            __builtin_amdgcn_wave_barrier();
+            if (lane < KEEP) {
+              ls[e] = ns;
+              li[e] = ni;
+              if (e == KEEP - 1) my_tau[row] = ns;
+            }
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
+      }
+      if (any) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tq[q] = my_tau[acc_row(q, h)];
+      }
     }
-    if (t + 1 < ntiles) stage_store(buf ^ 1);
-    __syncthreads();
+    __syncthreads();                       // refilled tile visible to everyone
   }
 
-  // final ordering of every list and hand-off: [Q][splits][KEEP]
+  // hand-off: [Q][splits][KEEP], already sorted; +inf scores mark empty slots
   for (int row = 0; row < 32; ++row) {
-    const int count = my_cnt[row];
-    compact_list(my_sc + row * CAP, my_ix + row * CAP, count, lane);
     const int qrow = q0 + row;
     if (qrow < Q && lane < KEEP) {
       const int64_t o = ((int64_t)qrow * gridDim.y + split) * KEEP + lane;
-      const bool have = lane < (count < KEEP ? count : KEEP);
-      cand_sc[o] = have ? my_sc[row * CAP + lane] : INFINITY;
-      cand_ix[o] = have ? my_ix[row * CAP + lane] : -1;
+      const float s = ntiles > 0 ? my_sc[row * KEEP + lane] : INFINITY;
+      cand_sc[o] = s;
+      cand_ix[o] = s < INFINITY ? my_ix[row * KEEP + lane] : -1;
     }
   }
 }
@@ -298,7 +321,7 @@ inline TopnPlan topn_plan(int R, int Q) {
   double best_cost = 1e30;
   for (int s = 1; s <= 64 && s <= (max_splits < 1 ? 1 : max_splits); ++s) {
     const long wgs = (long)p.qtiles * s;
-    const long rounds = (wgs + 255) / 256;
+    const long rounds = (wgs + 511) / 512;   // two resident workgroups per CU
     // time ~ rounds * (R / s); prefer fewer splits on ties (less merge work)
     const double cost = (double)rounds * ((double)R / s) * (1.0 + 0.002 * s);
     if (cost < best_cost) {
@@ -315,7 +338,7 @@ inline TopnPlan topn_plan(int R, int Q) {
 }
 
 inline size_t scan_lds_bytes(int d) {
-  return ((size_t)2 * 32 * (d + 4) + 64 + (size_t)QW * 32 * CAP * 2 + QW * 32 * 2) * sizeof(float);
+  return ((size_t)32 * (d + 4) + 32 + (size_t)QW * 32 * KEEP * 2 + QW * 32) * sizeof(float);
 }
 
 template <int D8>
