@@ -179,6 +179,32 @@ int scl_topn_l2(const float* ref, int R, const float* query, int Q, int d, int n
                 size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- *
+ * VGG16 backbone glue — the elementwise ops between the convolutions of
+ * model/nets.py:27-63 (tf.layers.conv2d's bias add, tf.nn.relu,
+ * tf.layers.max_pooling2d(2, 2)) and their TF-autodiff backward ops, fused so each
+ * activation map is streamed once.  The convolutions stay on PyTorch-ROCm/MIOpen.
+ * Activations are channels-last [M = B*H*W, C] (f32 or bf16), C % 8 == 0 and
+ * (C / 8) | 256; bias and bias gradients are f32 [C].
+ *   scl_vgg_bias_act   y = [relu](y + bias), in place
+ *   scl_vgg_act_bwd    gz = g * [a > 0] (a == NULL: no activation, gz untouched) and
+ *                      bias_grad[c] = sum_m gz[m, c]
+ *   scl_vgg_pool_fwd   a[B,H/2,W/2,C] = relu(maxpool2x2/2 'valid'(z) + bias)
+ *                      (== ReLU(pool(z + bias)), nets.py:40-42: max and ReLU commute)
+ *   scl_vgg_pool_bwd   gz[B,H,W,C] = gradient of the above w.r.t. z (first maximum of
+ *                      each window, recomputed from z) and bias_grad
+ * ------------------------------------------------------------------------- */
+size_t scl_vgg_workspace_bytes(int C);
+int scl_vgg_bias_act(void* y, int dtype, const float* bias, int64_t M, int C, int relu,
+                     void* stream);
+int scl_vgg_act_bwd(const void* g, const void* a, int dtype, int64_t M, int C, void* gz,
+                    float* bias_grad, void* workspace, size_t workspace_bytes, void* stream);
+int scl_vgg_pool_fwd(const void* z, int dtype, const float* bias, int B, int H, int W, int C,
+                     void* a, void* stream);
+int scl_vgg_pool_bwd(const void* g, const void* a, const void* z, int dtype, int B, int H, int W,
+                     int C, void* gz, float* bias_grad, void* workspace, size_t workspace_bytes,
+                     void* stream);
+
+/* ------------------------------------------------------------------------- *
  * Diagnostics (bench.py's live per-kernel timing; the reference has no counterpart
  * beyond its wall-clock prints, train/train.py:135-161).  Between scl_prof_begin and
  * scl_prof_end every kernel launched by THIS thread through the library is bracketed by

@@ -48,6 +48,11 @@ SIGNATURES = {
     "scl_logratio_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
     "scl_topn_l2_workspace_bytes": (_z, [_i, _i, _i, _i]),
     "scl_topn_l2": (_i, [_p, _i, _p, _i, _i, _i, _l, _p, _p, _p, _z, _p]),
+    "scl_vgg_workspace_bytes": (_z, [_i]),
+    "scl_vgg_bias_act": (_i, [_p, _i, _p, _l, _i, _i, _p]),
+    "scl_vgg_act_bwd": (_i, [_p, _p, _i, _l, _i, _p, _p, _p, _z, _p]),
+    "scl_vgg_pool_fwd": (_i, [_p, _i, _p, _i, _i, _i, _i, _p, _p]),
+    "scl_vgg_pool_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _z, _p]),
     "scl_prof_begin": (_i, [_i]),
     "scl_prof_count": (_i, []),
     "scl_prof_end": (_i, [_p, _p, _i]),

@@ -85,25 +85,112 @@ class _NetVLADFn(torch.autograd.Function):
         return gx, gw.reshape(w_shape), gc.reshape(c_shape), None
 
 
-class _ConvBiasReLU(torch.autograd.Function):
-    """3x3 same-padding conv + bias + ReLU as ONE MIOpen fused op (conv-bias-activation),
-    instead of conv, bias-add and ReLU kernels each streaming the activation map.  Only the
-    post-ReLU output is kept for backward (ReLU' = [y > 0])."""
+_CL = torch.channels_last
+_ONES = [1, 1]
+
+
+def _conv3x3(x, w):
+    """MIOpen 3x3 / stride 1 / same-padding convolution without bias."""
+    return torch.ops.aten.convolution(x, w, None, _ONES, _ONES, _ONES, False, [0, 0], 1)
+
+
+def _conv3x3_backward(gz, x, w, need_x):
+    gx, gw, _ = torch.ops.aten.convolution_backward(gz, x, w, None, _ONES, _ONES, _ONES, False,
+                                                    [0, 0], 1, [bool(need_x), True, False])
+    return gx, gw
+
+
+def _glue_dtype(t):
+    if t.dtype == torch.float32:
+        return L.DT_F32
+    if t.dtype == torch.bfloat16:
+        return L.DT_BF16
+    raise ValueError("backbone activations must be float32 or bfloat16, got %s" % t.dtype)
+
+
+class _ConvBiasAct(torch.autograd.Function):
+    """conv -> (+bias, optional ReLU) with the elementwise part in ONE in-place HIP pass
+    (csrc/vgg_glue.hip) instead of separate bias-add and ReLU kernels; the backward fuses
+    ReLU' with the bias-gradient reduction.  Only the post-activation map is kept."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
-        y = torch.ops.aten.miopen_convolution_relu(x, w, b, [1, 1], [1, 1], [1, 1], 1)
-        ctx.save_for_backward(x, w, y)
+    def forward(ctx, x, w, bias, relu):
+        lib = L.load()
+        y = _conv3x3(x, w).contiguous(memory_format=_CL)
+        b, c, h, wd = y.shape
+        L.check(lib.scl_vgg_bias_act(L.ptr(y), _glue_dtype(y), L.ptr(bias), b * h * wd, c,
+                                     int(relu), L.stream_of(y)))
+        ctx.relu = relu
+        ctx.save_for_backward(x, w, y if relu else None)
         return y
 
     @staticmethod
     def backward(ctx, gy):
+        lib = L.load()
         x, w, y = ctx.saved_tensors
-        g = torch.ops.aten.threshold_backward(gy, y, 0)
-        gx, gw, gb = torch.ops.aten.convolution_backward(
-            g, x, w, [w.shape[0]], [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-            [ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]])
+        gy = gy.contiguous(memory_format=_CL)
+        b, c, h, wd = gy.shape
+        gb = torch.empty(c, dtype=torch.float32, device=gy.device)
+        ws = L.workspace(lib.scl_vgg_workspace_bytes(c), gy.device)
+        gz = torch.empty_like(gy) if ctx.relu else gy
+        L.check(lib.scl_vgg_act_bwd(L.ptr(gy), L.ptr(y), _glue_dtype(gy), b * h * wd, c,
+                                    L.ptr(gz) if ctx.relu else None, L.ptr(gb), L.ptr(ws),
+                                    ws.numel(), L.stream_of(gy)))
+        gx, gw = _conv3x3_backward(gz, x, w, ctx.needs_input_grad[0])
+        return gx, gw, gb, None
+
+
+class _ConvBiasPoolReLU(torch.autograd.Function):
+    """conv -> +bias -> max-pool 2x2/2 -> ReLU (model/nets.py:40-42) with the three
+    elementwise ops in one HIP pass; the backward recomputes the arg-max from the saved
+    conv output (no int64 index tensor) and fuses ReLU' and the bias gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        lib = L.load()
+        z = _conv3x3(x, w).contiguous(memory_format=_CL)
+        b, c, h, wd = z.shape
+        a = torch.empty((b, c, h // 2, wd // 2), dtype=z.dtype, device=z.device,
+                        memory_format=_CL)
+        L.check(lib.scl_vgg_pool_fwd(L.ptr(z), _glue_dtype(z), L.ptr(bias), b, h, wd, c, L.ptr(a),
+                                     L.stream_of(z)))
+        ctx.save_for_backward(x, w, z, a)
+        return a
+
+    @staticmethod
+    def backward(ctx, ga):
+        lib = L.load()
+        x, w, z, a = ctx.saved_tensors
+        ga = ga.contiguous(memory_format=_CL)
+        b, c, h, wd = z.shape
+        gz = torch.empty_like(z)
+        gb = torch.empty(c, dtype=torch.float32, device=z.device)
+        ws = L.workspace(lib.scl_vgg_workspace_bytes(c), z.device)
+        L.check(lib.scl_vgg_pool_bwd(L.ptr(ga), L.ptr(a), L.ptr(z), _glue_dtype(z), b, h, wd, c,
+                                     L.ptr(gz), L.ptr(gb), L.ptr(ws), ws.numel(), L.stream_of(z)))
+        gx, gw = _conv3x3_backward(gz, x, w, ctx.needs_input_grad[0])
         return gx, gw, gb
+
+
+class _SubMean(torch.autograd.Function):
+    """x - average_rgb (model/nets.py:22-24) straight into the compute dtype; the gradient
+    of the trainable mean is a [M,3] column sum, done as two well-shaped reductions instead
+    of one reduction over a 3-wide inner dimension."""
+
+    @staticmethod
+    def forward(ctx, img_nhwc, avg, dtype):
+        out = (img_nhwc - avg.to(img_nhwc.dtype)).to(dtype)
+        return out.permute(0, 3, 1, 2)                 # NHWC storage == channels-last NCHW
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.permute(0, 2, 3, 1).reshape(-1, 3)
+        m = g.shape[0]
+        if g.is_contiguous() and m % 256 == 0:
+            s = g.view(m // 256, 768).sum(0, dtype=torch.float32).view(256, 3).sum(0)
+        else:
+            s = g.float().sum(0)
+        return None, -s, None
 
 
 def netvlad(x_nhwc, assign_w, centers, pre_l2=True):
@@ -115,7 +202,7 @@ def netvlad(x_nhwc, assign_w, centers, pre_l2=True):
 class VGG16NetVLAD(torch.nn.Module):
     """Variables of the reference's ``vgg16_netvlad_pca`` scope."""
 
-    def __init__(self, compute_dtype=torch.float32, seed=1234, fused_relu=False):
+    def __init__(self, compute_dtype=torch.float32, seed=1234, fused_relu=True):
         super().__init__()
         self.compute_dtype = compute_dtype
         self.fused_relu = fused_relu
@@ -148,34 +235,43 @@ class VGG16NetVLAD(torch.nn.Module):
             image_batch = image_batch.expand(-1, -1, -1, 3)              # nets.py:15-16
         elif ch != 3:
             raise AssertionError("last axis must be 1 or 3")               # nets.py:18
-        x = image_batch - self.average_rgb.to(image_batch.dtype)          # nets.py:22-24
-        # NHWC storage viewed as NCHW == channels_last: no copy
-        x = x.permute(0, 3, 1, 2)
         dt = self.compute_dtype
-        if x.dtype != dt:
-            x = x.to(dt)
+        # On a HIP device the elementwise ops between the convolutions run as fused HIP
+        # passes (csrc/vgg_glue.hip); the plain PyTorch composition below is the same math
+        # and is what runs on CPU (tests, CPU baseline).
+        fuse = self.fused_relu and image_batch.is_cuda
+        if fuse:
+            x = _SubMean.apply(image_batch, self.average_rgb, dt)          # nets.py:22-24
+        else:
+            x = image_batch - self.average_rgb.to(image_batch.dtype)      # nets.py:22-24
+            # NHWC storage viewed as NCHW == channels_last: no copy
+            x = x.permute(0, 3, 1, 2)
+            if x.dtype != dt:
+                x = x.to(dt)
         x = x.contiguous(memory_format=torch.channels_last)
-        # On a HIP device every conv that is followed by a ReLU — directly, or after the
-        # max-pool (nets.py:40-42: pool then ReLU; max and ReLU commute exactly) — runs as
-        # MIOpen's fused conv+bias+ReLU.  conv5_3 has neither (nets.py:63).
-        fuse = self.fused_relu and x.is_cuda
+        skip_pool = False
         for idx, item in enumerate(VGG_LAYERS):
             if item == 'pool':
-                x = F.max_pool2d(x, 2, 2)
-                if not fuse:
-                    x = F.relu(x)                                        # pool, then ReLU
+                if not skip_pool:
+                    x = F.relu(F.max_pool2d(x, 2, 2))                    # pool, then ReLU
+                skip_pool = False
                 continue
             name, _, relu = item
-            relu_after_pool = idx + 1 < len(VGG_LAYERS) and VGG_LAYERS[idx + 1] == 'pool'
+            pool_next = idx + 1 < len(VGG_LAYERS) and VGG_LAYERS[idx + 1] == 'pool'
             w = getattr(self, 'conv%s_kernel' % name)
             bias = getattr(self, 'conv%s_bias' % name)
             # OIHW master weights -> channels-last (and bf16) operands for MIOpen
             w = w.to(dtype=dt, memory_format=torch.channels_last)
+            if fuse:
+                if pool_next:
+                    # conv -> bias -> pool -> ReLU in one elementwise pass (nets.py:40-42)
+                    x = _ConvBiasPoolReLU.apply(x, w, bias)
+                    skip_pool = True
+                else:
+                    x = _ConvBiasAct.apply(x, w, bias, relu)
+                continue
             if bias.dtype != dt:
                 bias = bias.to(dt)
-            if fuse and (relu or relu_after_pool):
-                x = _ConvBiasReLU.apply(x, w, bias)
-                continue
             x = F.conv2d(x, w, bias, stride=1, padding=1)
             if relu:
                 x = F.relu(x)

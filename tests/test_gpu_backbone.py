@@ -1,0 +1,136 @@
+"""GPU checks of the fused backbone glue (csrc/vgg_glue.hip): the fused path must equal
+the plain PyTorch composition of conv -> bias -> [pool] -> ReLU (model/nets.py:27-63) in
+forward and in every gradient, and the raw kernels must match torch ops elementwise."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _pair(dev, dtype):
+    from soft_contrastive_learning_amd.model import nets
+    a = nets.VGG16NetVLAD(compute_dtype=dtype, seed=11, fused_relu=True).to(dev)
+    b = nets.VGG16NetVLAD(compute_dtype=dtype, seed=11, fused_relu=False).to(dev)
+    return a, b
+
+
+def _nrel(x, y):
+    x, y = x.double(), y.double()
+    return float((x - y).norm() / y.norm().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 80), (1, 48, 32)])
+def test_fused_backbone_equals_plain_composition_f32(dev, shape):
+    fused, plain = _pair(dev, torch.float32)
+    b, h, w = shape
+    img = torch.randint(0, 256, (b, h, w, 3), generator=torch.Generator().manual_seed(1)).float().to(dev)
+    gseed = torch.Generator().manual_seed(2)
+    xf = fused.features(img)
+    xp = plain.features(img)
+    assert xf.shape == xp.shape == (b, h // 16, w // 16, 512)
+    assert _nrel(xf, xp) < 1e-5
+    g = torch.randn(xf.shape, generator=gseed).to(dev)
+    xf.backward(g)
+    xp.backward(g)
+    for (n1, p1), (_, p2) in zip(fused.named_parameters(), plain.named_parameters()):
+        if p2.grad is None:
+            assert p1.grad is None, n1
+            continue
+        assert _nrel(p1.grad, p2.grad) < 2e-4, n1
+
+
+def test_fused_backbone_bf16_close_to_plain(dev):
+    fused, plain = _pair(dev, torch.bfloat16)
+    img = torch.randint(0, 256, (2, 64, 80, 3), generator=torch.Generator().manual_seed(3)).float().to(dev)
+    xf, xp = fused.features(img).float(), plain.features(img).float()
+    assert _nrel(xf, xp) < 3e-2            # bf16 storage; the fused path rounds once less
+    g = torch.randn(xf.shape, generator=torch.Generator().manual_seed(4)).to(dev)
+    fused.features(img).backward(g.bfloat16())
+    plain.features(img).backward(g.bfloat16())
+    for (n1, p1), (_, p2) in zip(fused.named_parameters(), plain.named_parameters()):
+        if p2.grad is not None:
+            assert _nrel(p1.grad, p2.grad) < 0.1, n1
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("c", [64, 128, 512])
+def test_raw_glue_kernels_match_torch(dev, dtype, c):
+    from soft_contrastive_learning_amd import _lib as L
+    lib = L.load()
+    code = L.DT_F32 if dtype == torch.float32 else L.DT_BF16
+    gen = torch.Generator().manual_seed(c)
+    b, h, w = 2, 6, 10
+    z = torch.randn(b, h, w, c, generator=gen).to(dev).to(dtype)            # channels-last storage
+    bias = torch.randn(c, generator=gen).to(dev)
+    st = L.stream_of(z)
+    # bias + relu in place
+    y = z.clone()
+    L.check(lib.scl_vgg_bias_act(L.ptr(y), code, L.ptr(bias), b * h * w, c, 1, st))
+    want = F.relu(z.float() + bias).to(dtype)
+    assert torch.equal(y, want)
+    # pool forward
+    a = torch.empty(b, h // 2, w // 2, c, dtype=dtype, device=dev)
+    L.check(lib.scl_vgg_pool_fwd(L.ptr(z), code, L.ptr(bias), b, h, w, c, L.ptr(a), st))
+    zp = z.float().permute(0, 3, 1, 2)
+    want_a = F.relu(F.max_pool2d(zp, 2, 2) + bias.view(1, -1, 1, 1)).permute(0, 2, 3, 1).to(dtype)
+    assert torch.equal(a, want_a)
+    # pool backward vs autograd of the same composition (ties are measure-zero for randn f32;
+    # for bf16 compare the bias gradient and the total mass instead of positions)
+    g = torch.randn(a.shape, generator=gen).to(dev).to(dtype)
+    gz = torch.empty_like(z)
+    gb = torch.empty(c, device=dev)
+    ws = L.workspace(lib.scl_vgg_workspace_bytes(c), dev)
+    L.check(lib.scl_vgg_pool_bwd(L.ptr(g), L.ptr(a), L.ptr(z), code, b, h, w, c, L.ptr(gz), L.ptr(gb),
+                                 L.ptr(ws), ws.numel(), st))
+    zr = z.float().permute(0, 3, 1, 2).clone().requires_grad_(True)
+    br = bias.clone().requires_grad_(True)
+    out = F.relu(F.max_pool2d(zr, 2, 2) + br.view(1, -1, 1, 1))
+    out.backward(g.float().permute(0, 3, 1, 2))
+    np.testing.assert_allclose(gb.cpu().numpy(), br.grad.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    if dtype == torch.float32:
+        assert torch.equal(gz.permute(0, 3, 1, 2), zr.grad)
+    else:
+        np.testing.assert_allclose(gz.float().sum().item(), zr.grad.sum().item(), rtol=1e-2, atol=1e-2)
+    # relu backward + bias gradient
+    gy = torch.randn(b, h, w, c, generator=gen).to(dev).to(dtype)
+    gz2 = torch.empty_like(gy)
+    L.check(lib.scl_vgg_act_bwd(L.ptr(gy), L.ptr(y), code, b * h * w, c, L.ptr(gz2), L.ptr(gb),
+                                L.ptr(ws), ws.numel(), st))
+    want_g = torch.where(y.float() > 0, gy.float(), torch.zeros_like(gy.float()))
+    assert torch.equal(gz2.float(), want_g)
+    np.testing.assert_allclose(gb.cpu().numpy(), want_g.sum(dim=(0, 1, 2)).cpu().numpy(),
+                               rtol=1e-4, atol=1e-3)
+    # bias gradient only (no activation)
+    L.check(lib.scl_vgg_act_bwd(L.ptr(gy), None, code, b * h * w, c, None, L.ptr(gb), L.ptr(ws),
+                                ws.numel(), st))
+    np.testing.assert_allclose(gb.cpu().numpy(), gy.float().sum(dim=(0, 1, 2)).cpu().numpy(),
+                               rtol=1e-4, atol=1e-3)
+
+
+def test_pool_bwd_odd_sizes_zero_the_uncovered_border(dev):
+    from soft_contrastive_learning_amd import _lib as L
+    lib = L.load()
+    b, h, w, c = 1, 5, 7, 64
+    z = torch.randn(b, h, w, c, device=dev)
+    bias = torch.zeros(c, device=dev)
+    a = torch.empty(b, h // 2, w // 2, c, device=dev)
+    st = L.stream_of(z)
+    L.check(lib.scl_vgg_pool_fwd(L.ptr(z), L.DT_F32, L.ptr(bias), b, h, w, c, L.ptr(a), st))
+    g = torch.ones_like(a)
+    gz = torch.full_like(z, 7.0)
+    gb = torch.empty(c, device=dev)
+    ws = L.workspace(lib.scl_vgg_workspace_bytes(c), dev)
+    L.check(lib.scl_vgg_pool_bwd(L.ptr(g), L.ptr(a), L.ptr(z), L.DT_F32, b, h, w, c, L.ptr(gz),
+                                 L.ptr(gb), L.ptr(ws), ws.numel(), st))
+    assert float(gz[:, 4].abs().max()) == 0.0 and float(gz[:, :, 6].abs().max()) == 0.0
+    zr = z.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    F.relu(F.max_pool2d(zr, 2, 2)).backward(g.permute(0, 3, 1, 2))
+    assert torch.equal(gz.permute(0, 3, 1, 2), zr.grad)
