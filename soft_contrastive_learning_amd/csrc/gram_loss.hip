@@ -16,11 +16,14 @@
 //   4. gram_bwd_kernel       grad_E[rows] = g * M[rows,:] E   on the f32 MFMA.
 // All reductions are fixed-order (no float atomics): results are bitwise
 // reproducible run to run.
+#include <mutex>
+
 #include "scl_common.h"
 
 namespace {
 
 constexpr int kTile = 32;
+constexpr int kMaxB = 1024;  // rows kernel LDS and the backward's M tile are sized for this
 
 struct GramPlan {
   int tiles;    // ceil(B / 32)
@@ -33,8 +36,10 @@ inline GramPlan make_plan(int B, int E) {
   GramPlan p;
   p.tiles = (B + kTile - 1) / kTile;
   p.npairs = p.tiles * (p.tiles + 1) / 2;
+  // K-splits: enough workgroups to cover the chip, but every split costs the row kernel one
+  // more slab entry per pair (B=24: 64 splits x 4 waves already stream the 3 MB in ~4 us)
   int s = 1024 / p.npairs;
-  if (s > 256) s = 256;
+  if (s > 64) s = 64;
   if (s < 1) s = 1;
   int kc = (E + s - 1) / s;
   kc = (kc + 31) / 32 * 32;
@@ -342,37 +347,56 @@ __global__ __launch_bounds__(256) void gram_coef_kernel(const float* __restrict_
   }
 }
 
-// grad[r, e] = g * sum_j M[row_begin + r, j] * emb[j, e].  grid (ceil(E/128), row tiles); block 256,
-// one wave per 32x32 output tile.
+// grad[r, e] = g * sum_j M[row_begin + r, j] * emb[j, e].
+// grid (ceil(E/512), row tiles); block 256.  The workgroup's [32 x B] slice of M sits in LDS
+// (odd row stride: conflict-free ds_read_b32); every wave owns 128 columns as 4 accumulator
+// tiles whose columns are interleaved (tile t holds columns e0 + 4 i + t), so one 16-byte
+// load per lane per contraction step feeds 4 MFMAs and a half-wave reads 512 contiguous
+// bytes of the embedding row.
 __global__ __launch_bounds__(256) void gram_bwd_kernel(const float* __restrict__ emb, int64_t ld,
                                                        int B, int E, const float* __restrict__ coef,
                                                        const float* __restrict__ grad_loss,
-                                                       int row_begin, int row_count,
+                                                       int row_begin, int row_count, int vec_ok,
                                                        float* __restrict__ grad, int64_t ldg) {
+  extern __shared__ __attribute__((aligned(16))) float mt[];   // [32][B | 1]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int e0 = (blockIdx.x * 4 + wid) * kTile;
+  const int ldm = B | 1;
+  for (int idx = threadIdx.x; idx < kTile * B; idx += 256) {
+    const int rr = idx / B, j = idx % B;
+    const int lr = blockIdx.y * kTile + rr;
+    mt[rr * ldm + j] = lr < row_count ? coef[(int64_t)(row_begin + lr) * B + j] : 0.f;
+  }
+  __syncthreads();
+  const int e0 = (blockIdx.x * 4 + wid) * 128;
   if (e0 >= E) return;
-  const int lr = blockIdx.y * kTile + r;  // local row of the A operand
-  const bool row_ok = lr < row_count;
-  const float* mrow = coef + (int64_t)(row_begin + lr) * B;
-  const int e = e0 + r;
-  const bool col_ok = e < E;
-  f32x16 acc = zero16();
+  const int e = e0 + 4 * r;                 // this lane's 4 columns (one per tile)
+  f32x16 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = zero16();
+  const float* ma = mt + r * ldm;
 #pragma unroll 4
   for (int j0 = 0; j0 < B; j0 += 2) {
     const int j = j0 + h;
     const bool jok = j < B;
-    const float a = (row_ok && jok) ? mrow[j] : 0.f;
-    const float b = (col_ok && jok) ? emb[(int64_t)j * ld + e] : 0.f;
-    acc = mfma32(a, b, acc);
+    const float a = jok ? ma[j] : 0.f;
+    const f32x4 b = load4_guard(emb + (int64_t)(jok ? j : 0) * ld, e, E, jok, vec_ok);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = mfma32(a, b[t], acc[t]);
   }
   const float g = grad_loss ? *grad_loss : 1.0f;
-  if (col_ok) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int orow = blockIdx.y * kTile + acc_row(q, h);
-      if (orow < row_count) grad[(int64_t)orow * ldg + e] = g * acc[q];
+  for (int q = 0; q < 16; ++q) {
+    const int orow = blockIdx.y * kTile + acc_row(q, h);
+    if (orow >= row_count) continue;
+    float* dst = grad + (int64_t)orow * ldg + e;
+    if (vec_ok && e + 4 <= E) {
+      *reinterpret_cast<f32x4*>(dst) =
+          f32x4{g * acc[0][q], g * acc[1][q], g * acc[2][q], g * acc[3][q]};
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (e + t < E) dst[t] = g * acc[t][q];
     }
   }
 }
@@ -414,7 +438,6 @@ inline GramWs carve(void* ws, int B, const GramPlan& p, int batch) {
   return w;
 }
 
-constexpr int kMaxB = 1024;  // rows kernel keeps 13 * B floats of LDS (< 64 KB)
 
 }  // namespace
 
@@ -468,10 +491,19 @@ extern "C" int scl_gram_loss_bwd(const float* emb, int64_t ld_emb, int B, int E,
                                  float* grad_emb, int64_t ld_grad, void* stream) {
   if (!emb || !coef || !grad_emb) return SCL_E_NULL;
   if (B < 1 || E < 1 || ld_emb < E || ld_grad < E) return SCL_E_SHAPE;
-  if (row_begin < 0 || row_count < 1 || row_begin + row_count > B) return SCL_E_SHAPE;
-  dim3 grid((E + 127) / 128, (row_count + kTile - 1) / kTile);
-  SCL_LAUNCH("gram_bwd_kernel", gram_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, emb, ld_emb, B, E,
-                     coef, grad_loss, row_begin, row_count, grad_emb, ld_grad);
+  if (row_begin < 0 || row_count < 1 || row_begin + row_count > B || B > kMaxB) return SCL_E_SHAPE;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_bwd_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(kTile * (kMaxB | 1) * sizeof(float)));
+  });
+  const int vec_ok = (ld_emb % 4 == 0) && (ld_grad % 4 == 0) && ((uintptr_t)emb % 16 == 0) &&
+                     ((uintptr_t)grad_emb % 16 == 0);
+  const size_t lds = (size_t)kTile * (B | 1) * sizeof(float);
+  dim3 grid((E + 511) / 512, (row_count + kTile - 1) / kTile);
+  SCL_LAUNCH("gram_bwd_kernel", gram_bwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, emb,
+             ld_emb, B, E, coef, grad_loss, row_begin, row_count, vec_ok, grad_emb, ld_grad);
   return scl_launch_status();
 }
 
