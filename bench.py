@@ -55,8 +55,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--miopen-find', type=int, default=1,
                     help='1: let MIOpen benchmark its solvers per conv shape during warm-up')
-    ap.add_argument('--fused-relu', type=int, default=0,
-                    help='1: MIOpen fused conv+bias+ReLU for the convs followed by a ReLU')
+    ap.add_argument('--fused-relu', type=int, default=1,
+                    help='1: fused HIP bias/ReLU/pool glue around the MIOpen convs (csrc/vgg_glue.hip)')
     ap.add_argument('--cpu-images', type=int, default=2, help='images in the CPU-baseline sample')
     return ap.parse_args()
 
@@ -86,6 +86,26 @@ def kernel_models(b, n, gb, x_bytes):
         'gram_bwd_kernel': dict(flops=2.0 * b * gb * E, bytes=gb * E * 4 + b * E * 4),
         'transpose_w_kernel': dict(flops=0.0, bytes=D * K * 8),
     }
+
+
+def vgg_glue_bytes(b, h, w, s):
+    """Algorithmic HBM bytes PER STEP of the fused backbone glue kernels (csrc/vgg_glue.hip):
+    every activation element is counted once per read and once per write."""
+    # (channels, resolution divisor, pooled after) of the 13 convs, model/nets.py:39-63
+    layers = [(64, 1, False), (64, 1, True), (128, 2, False), (128, 2, True), (256, 4, False),
+              (256, 4, False), (256, 4, True), (512, 8, False), (512, 8, False), (512, 8, True),
+              (512, 16, False), (512, 16, False), (512, 16, False)]
+    out = {'vgg_bias_act': 0.0, 'vgg_pool_fwd': 0.0, 'vgg_act_bwd': 0.0, 'vgg_pool_bwd': 0.0}
+    for i, (c, div, pooled) in enumerate(layers):
+        full = float(b * (h // div) * (w // div) * c * s)
+        if pooled:
+            out['vgg_pool_fwd'] += full * 1.25            # read z, write a (1/4)
+            out['vgg_pool_bwd'] += full * 2.5             # read g, a (1/4 each), z; write gz
+        else:
+            last = i == len(layers) - 1                   # conv5_3: bias only, no ReLU
+            out['vgg_bias_act'] += full * 2.0
+            out['vgg_act_bwd'] += full * (1.0 if last else 3.0)
+    return out
 
 
 def price(name, launches, mean_ms, model):
@@ -210,7 +230,17 @@ def main():
         models = kernel_models(b, n_loc, gb, 2 if cdt == torch.bfloat16 else 4)
         summ = kt.summary()
         kernels = [price(k, c, ms, models[k]) for k, (c, ms) in sorted(summ.items()) if k in models]
+        # `roofline` = the dominant kernel of the hot path proper (NetVLAD + pairwise loss,
+        # SURVEY.md §8a); the backbone's elementwise glue is listed separately below
         dom = max(kernels, key=lambda r: r['us'] * r['launches']) if kernels else None
+        glue = vgg_glue_bytes(b, args.height, args.width, 2 if cdt == torch.bfloat16 else 4)
+        for k, (c, ms) in sorted(summ.items()):
+            if k in glue:
+                per_step_ms = ms * c / max(args.steps, 1)
+                gbs = glue[k] / (per_step_ms * 1e-3) / 1e9
+                kernels.append(dict(kernel=k, launches=c, us=round(ms * 1e3, 2), bound='hbm',
+                                    tflops=0.0, gbps=round(gbs, 1),
+                                    frac=round(gbs / PEAK_HBM_GBPS, 4)))
         roofline = None
         if dom:
             roofline = dict(kernel=dom['kernel'], bound=dom['bound'],

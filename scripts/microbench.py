@@ -90,6 +90,7 @@ def main():
     ap.add_argument('--what', default='netvlad,loss,topn')
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--json', default='')
+    ap.add_argument('--netvlad-batches', default='24')
     ap.add_argument('--topn-refs', type=int, default=100000)
     ap.add_argument('--topn-queries', type=int, default=10000)
     args = ap.parse_args()
@@ -97,8 +98,9 @@ def main():
     what = args.what.split(',')
     res = {}
     if 'netvlad' in what:
-        res['netvlad_bf16_b24_n1200'] = run_netvlad(dev, 24, 1200, torch.bfloat16, args.iters)
-        res['netvlad_f32_b24_n1200'] = run_netvlad(dev, 24, 1200, torch.float32, args.iters)
+        for b in [int(v) for v in args.netvlad_batches.split(',')]:
+            res['netvlad_bf16_b%d_n1200' % b] = run_netvlad(dev, b, 1200, torch.bfloat16, args.iters)
+            res['netvlad_f32_b%d_n1200' % b] = run_netvlad(dev, b, 1200, torch.float32, args.iters)
     if 'loss' in what:
         res['wms_loss_sweep'] = sum((run_loss(dev, b, args.iters) for b in (24, 48, 96, 192)), [])
     if 'topn' in what:

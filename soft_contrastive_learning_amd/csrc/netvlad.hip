@@ -262,18 +262,28 @@ __global__ __launch_bounds__(256, 2) void rowtile16_kernel(RowTileArgs p) {
     }
     if (active) {
       const float* wb = &bt_lds[(c & 1) * RT_CHUNK + g * RT_PLANE + i * RT_LD];
+      // B fragments are double-buffered in registers: the ds_read_b128 of step t+1 are in
+      // flight under the 16 MFMAs of step t (with one register set hipcc issues them only
+      // after the last MFMA and exposes the LDS latency 32 times per tile)
+      f32x4 wv[2][4];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+        wv[0][kt] = *reinterpret_cast<const f32x4*>(wb + kt * 16 * RT_LD);
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         f32x4 xa = xc[t];
         if (!row_ok) xa = f32x4{0.f, 0.f, 0.f, 0.f};
-        f32x4 wv[4];
+        if (t + 1 < 8) {
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-          wv[kt] = *reinterpret_cast<const f32x4*>(wb + kt * 16 * RT_LD + 4 * t);
+          for (int kt = 0; kt < 4; ++kt)
+            wv[(t + 1) & 1][kt] =
+                *reinterpret_cast<const f32x4*>(wb + kt * 16 * RT_LD + 4 * (t + 1));
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this step's MFMAs
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
 #pragma unroll
-          for (int kt = 0; kt < 4; ++kt) acc[kt] = mfma16(xa[cc], wv[kt][cc], acc[kt]);
+          for (int kt = 0; kt < 4; ++kt) acc[kt] = mfma16(xa[cc], wv[t & 1][kt][cc], acc[kt]);
           ss = fmaf(xa[cc], xa[cc], ss);
         }
       }
@@ -824,14 +834,21 @@ __global__ __launch_bounds__(256, 2) void dx16_kernel(const void* __restrict__ x
       f32x4 acc[2];
       acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
       acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // B fragments double-buffered in registers (see rowtile16_kernel)
+      f32x4 bq[2][2];
+      bq[0][0] = *reinterpret_cast<const f32x4*>(wb);
+      bq[0][1] = *reinterpret_cast<const f32x4*>(wb + 16 * RT_LD);
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(wb + 4 * t);
-        const f32x4 b1 = *reinterpret_cast<const f32x4*>(wb + 16 * RT_LD + 4 * t);
+        if (t + 1 < 8) {
+          bq[(t + 1) & 1][0] = *reinterpret_cast<const f32x4*>(wb + 4 * (t + 1));
+          bq[(t + 1) & 1][1] = *reinterpret_cast<const f32x4*>(wb + 16 * RT_LD + 4 * (t + 1));
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
-          acc[0] = mfma16(af[t][cc], b0[cc], acc[0]);
-          acc[1] = mfma16(af[t][cc], b1[cc], acc[1]);
+          acc[0] = mfma16(af[t][cc], bq[t & 1][0][cc], acc[0]);
+          acc[1] = mfma16(af[t][cc], bq[t & 1][1][cc], acc[1]);
         }
       }
       // transpose the [16 x 32] block: accumulator (row 4g+j, channel 16dt+i) -> rows

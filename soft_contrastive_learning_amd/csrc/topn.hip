@@ -157,11 +157,16 @@ __global__ __launch_bounds__(256, 2) void topn_scan_kernel(const float* __restri
     if (t + 1 < ntiles) stage_load(t + 1);
     const float* bp = &tile[r * LD + 4 * h];
     f32x16 acc = zero16();
+    // reference fragments run two steps ahead of the MFMAs in a 3-deep register ring
+    f32x4 bv[3];
+    bv[0] = *reinterpret_cast<const f32x4*>(bp);
+    if (D8 > 1) bv[1] = *reinterpret_cast<const f32x4*>(bp + 8);
 #pragma unroll
     for (int u = 0; u < D8; ++u) {
-      const f32x4 bv = *reinterpret_cast<const f32x4*>(bp + 8 * u);
+      if (u + 2 < D8) bv[(u + 2) % 3] = *reinterpret_cast<const f32x4*>(bp + 8 * (u + 2));
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) acc = mfma32(qf[u][c], bv[c], acc);
+      for (int c = 0; c < 4; ++c) acc = mfma32(qf[u][c], bv[u % 3][c], acc);
     }
     const float rnj = refn[r];
     const int ridx = r_begin + t * 32 + r;

@@ -172,6 +172,65 @@ class _ConvBiasPoolReLU(torch.autograd.Function):
         return gx, gw, gb
 
 
+def avg_rgb_grad(gz, w, gb):
+    """Gradient of the loss w.r.t. ``average_rgb`` WITHOUT the conv1_1 input gradient.
+
+    x0 = img - avg feeds a 3x3 same-padding conv; d loss / d avg[c] = -sum_{b,h,w} dx0[b,c,h,w]
+    and the spatial sum of a transposed convolution only needs, per output channel o and tap
+    (kh, kw), the sum of gz over the positions whose tap stays inside the image:
+        S[o,kh,kw] = T[o] - R_kh[o] - C_kw[o] + X_khkw[o]
+    (T total = the bias gradient, R / C the first or last row / column sums, X the corners).
+    gz [B,64,H,W] is the gradient at the conv1_1 pre-activation, w [64,3,3,3], gb [64] f32.
+    Exact, and replaces a full bwd-data pass over the 24x480x640x64 map plus an 88 MB
+    reduction by four thin slices."""
+    gzf = gz
+    zero = torch.zeros_like(gb)
+    r0 = gzf[:, :, 0, :].float().sum(dim=(0, 2))
+    r2 = gzf[:, :, -1, :].float().sum(dim=(0, 2))
+    c0 = gzf[:, :, :, 0].float().sum(dim=(0, 2))
+    c2 = gzf[:, :, :, -1].float().sum(dim=(0, 2))
+    rows = torch.stack([r0, zero, r2], dim=1)                      # [O,3] by kh
+    cols = torch.stack([c0, zero, c2], dim=1)                      # [O,3] by kw
+    corner = torch.zeros(gb.shape[0], 3, 3, dtype=torch.float32, device=gb.device)
+    corner[:, 0, 0] = gzf[:, :, 0, 0].float().sum(0)
+    corner[:, 0, 2] = gzf[:, :, 0, -1].float().sum(0)
+    corner[:, 2, 0] = gzf[:, :, -1, 0].float().sum(0)
+    corner[:, 2, 2] = gzf[:, :, -1, -1].float().sum(0)
+    s = gb[:, None, None] - rows[:, :, None] - cols[:, None, :] + corner    # [O,3,3]
+    return -torch.einsum('ockl,okl->c', w.float(), s)
+
+
+class _FirstConv(torch.autograd.Function):
+    """(img - average_rgb) -> conv1_1 -> +bias -> ReLU (model/nets.py:22-24, 39) in one
+    node: the only consumer of the image gradient is the trainable mean, whose gradient has
+    the closed form of ``avg_rgb_grad`` — so conv1_1's bwd-data pass is never run."""
+
+    @staticmethod
+    def forward(ctx, img_nhwc, avg, w, bias, dtype):
+        lib = L.load()
+        x0 = (img_nhwc - avg.to(img_nhwc.dtype)).to(dtype).permute(0, 3, 1, 2)
+        y = _conv3x3(x0, w).contiguous(memory_format=_CL)
+        b, c, h, wd = y.shape
+        L.check(lib.scl_vgg_bias_act(L.ptr(y), _glue_dtype(y), L.ptr(bias), b * h * wd, c, 1,
+                                     L.stream_of(y)))
+        ctx.save_for_backward(x0, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = L.load()
+        x0, w, y = ctx.saved_tensors
+        gy = gy.contiguous(memory_format=_CL)
+        b, c, h, wd = gy.shape
+        gb = torch.empty(c, dtype=torch.float32, device=gy.device)
+        ws = L.workspace(lib.scl_vgg_workspace_bytes(c), gy.device)
+        gz = torch.empty_like(gy)
+        L.check(lib.scl_vgg_act_bwd(L.ptr(gy), L.ptr(y), _glue_dtype(gy), b * h * wd, c, L.ptr(gz),
+                                    L.ptr(gb), L.ptr(ws), ws.numel(), L.stream_of(gy)))
+        _, gw = _conv3x3_backward(gz, x0, w, False)
+        return None, avg_rgb_grad(gz, w, gb), gw, gb, None
+
+
 class _SubMean(torch.autograd.Function):
     """x - average_rgb (model/nets.py:22-24) straight into the compute dtype; the gradient
     of the trainable mean is a [M,3] column sum, done as two well-shaped reductions instead
@@ -241,14 +300,15 @@ class VGG16NetVLAD(torch.nn.Module):
         # and is what runs on CPU (tests, CPU baseline).
         fuse = self.fused_relu and image_batch.is_cuda
         if fuse:
-            x = _SubMean.apply(image_batch, self.average_rgb, dt)          # nets.py:22-24
+            x = None                                       # mean subtraction lives in _FirstConv
         else:
             x = image_batch - self.average_rgb.to(image_batch.dtype)      # nets.py:22-24
             # NHWC storage viewed as NCHW == channels_last: no copy
             x = x.permute(0, 3, 1, 2)
             if x.dtype != dt:
                 x = x.to(dt)
-        x = x.contiguous(memory_format=torch.channels_last)
+        if x is not None:
+            x = x.contiguous(memory_format=torch.channels_last)
         skip_pool = False
         for idx, item in enumerate(VGG_LAYERS):
             if item == 'pool':
@@ -263,7 +323,10 @@ class VGG16NetVLAD(torch.nn.Module):
             # OIHW master weights -> channels-last (and bf16) operands for MIOpen
             w = w.to(dtype=dt, memory_format=torch.channels_last)
             if fuse:
-                if pool_next:
+                if x is None:
+                    # nets.py:22-24 + conv1_1 + ReLU; no image gradient is ever formed
+                    x = _FirstConv.apply(image_batch, self.average_rgb, w, bias, dt)
+                elif pool_next:
                     # conv -> bias -> pool -> ReLU in one elementwise pass (nets.py:40-42)
                     x = _ConvBiasPoolReLU.apply(x, w, bias)
                     skip_pool = True

@@ -52,6 +52,23 @@ def test_backbone_layer_order_and_output_geometry():
     np.testing.assert_allclose(v.norm(dim=-1).numpy(), 1.0, rtol=1e-5)
 
 
+def test_closed_form_average_rgb_gradient_equals_autograd():
+    # nets.avg_rgb_grad: d loss / d average_rgb from the conv1_1 pre-activation gradient alone
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(0)
+    img = torch.randint(0, 256, (2, 7, 9, 3), generator=gen).double()
+    avg = torch.tensor([123.68, 116.78, 103.94], dtype=torch.float64, requires_grad=True)
+    w = torch.randn(8, 3, 3, 3, generator=gen, dtype=torch.float64)
+    bias = torch.randn(8, generator=gen, dtype=torch.float64)
+    x0 = (img - avg).permute(0, 3, 1, 2)
+    z = F.conv2d(x0, w, bias, padding=1)
+    z.retain_grad()
+    (torch.relu(z) * torch.randn(z.shape, generator=gen, dtype=torch.float64)).sum().backward()
+    gz = z.grad
+    got = nets.avg_rgb_grad(gz, w, gz.sum(dim=(0, 2, 3)).float())
+    torch.testing.assert_close(got.double(), avg.grad, rtol=1e-5, atol=1e-4)
+
+
 def test_ops_fail_loudly_without_a_hip_device():
     emb = torch.zeros(4, 8)
     with pytest.raises(_lib.SclError):
