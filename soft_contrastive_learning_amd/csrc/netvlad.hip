@@ -238,10 +238,10 @@ __global__ __launch_bounds__(256, 2) void rowtile16_kernel(RowTileArgs p) {
                                         4 * (c4 >> 2)]) = st[v];
     }
   };
-  f32x4 xc[8], xn[8];
-  auto x_load = [&](int chunk, f32x4* dst) {
+  typename Raw<T>::v4 xc[8], xn[8];   // raw prefetch registers: converted when consumed
+  auto x_load = [&](int chunk, typename Raw<T>::v4* dst) {
 #pragma unroll
-    for (int t = 0; t < 8; ++t) dst[t] = Elem<T>::ld4(xrow + chunk * RT_CH + 16 * t);
+    for (int t = 0; t < 8; ++t) dst[t] = Raw<T>::ld4(xrow + chunk * RT_CH + 16 * t);
   };
 
   f32x4 acc[4];
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void rowtile16_kernel(RowTileArgs p) {
         wv[0][kt] = *reinterpret_cast<const f32x4*>(wb + kt * 16 * RT_LD);
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        f32x4 xa = xc[t];
+        f32x4 xa = Raw<T>::cvt4(xc[t]);
         if (!row_ok) xa = f32x4{0.f, 0.f, 0.f, 0.f};
         if (t + 1 < 8) {
 #pragma unroll
@@ -403,44 +403,48 @@ __global__ __launch_bounds__(256) void aggregate_kernel(const void* __restrict__
     for (int kt = 0; kt < 2; ++kt) acc[t][kt] = zero16();
   float s0 = 0.f, s1 = 0.f;
 
+  // The prefetch registers are written by loads ONLY; every use of a loaded value (scaling
+  // by rn, masking of padding steps, the column sums) happens when its batch is consumed.
+  // Touching them at load time makes hipcc wait vmcnt(0) right after issuing the prefetch.
   constexpr int U = 8;
-  f32x2 xc[U], xn[U];
-  float a0c[U], a1c[U], a0n[U], a1n[U];
-  auto load_batch = [&](int sb, f32x2* xb, float* a0b, float* a1b) {
+  typename Raw<T>::v2 xc[U], xn[U];
+  float a0c[U], a1c[U], wc[U], a0n[U], a1n[U], wn[U];
+  auto load_batch = [&](int sb, typename Raw<T>::v2* xb, float* a0b, float* a1b, float* wb) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int n = n_begin + 2 * (sb + u) + h;
-      const bool ok = n < n_end;
-      const int ns = ok ? n : n_safe;
-      xb[u] = Elem<T>::ld2(x + (int64_t)ns * D);
-      const float wgt = rnb[ns];
-      const float a0 = cf[(int64_t)ns * K], a1 = cf[(int64_t)ns * K + 32];
-      // padding steps contribute nothing: zero B operand, and keep x finite-safe
-      a0b[u] = ok ? a0 * wgt : 0.f;
-      a1b[u] = ok ? a1 * wgt : 0.f;
-      if (!ok) xb[u] = f32x2{0.f, 0.f};
-      s0 += ok ? a0 : 0.f;
-      s1 += ok ? a1 : 0.f;
+      const int ns = n < n_end ? n : n_safe;
+      xb[u] = Raw<T>::ld2(x + (int64_t)ns * D);
+      wb[u] = rnb[ns];
+      a0b[u] = cf[(int64_t)ns * K];
+      a1b[u] = cf[(int64_t)ns * K + 32];
     }
   };
-  if (steps > 0) load_batch(0, xc, a0c, a1c);
+  if (steps > 0) load_batch(0, xc, a0c, a1c, wc);
 #pragma unroll 1
   for (int sb = 0; sb < steps; sb += U) {
-    if (sb + U < steps) load_batch(sb + U, xn, a0n, a1n);
+    if (sb + U < steps) load_batch(sb + U, xn, a0n, a1n, wn);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if (sb + u < steps) {
-        acc[0][0] = mfma32(xc[u][0], a0c[u], acc[0][0]);
-        acc[0][1] = mfma32(xc[u][0], a1c[u], acc[0][1]);
-        acc[1][0] = mfma32(xc[u][1], a0c[u], acc[1][0]);
-        acc[1][1] = mfma32(xc[u][1], a1c[u], acc[1][1]);
-      }
+      // padding steps (beyond n_end) contribute nothing: zero operands
+      const bool ok = n_begin + 2 * (sb + u) + h < n_end;
+      const float b0 = ok ? a0c[u] * wc[u] : 0.f;
+      const float b1 = ok ? a1c[u] * wc[u] : 0.f;
+      const f32x2 xf = Raw<T>::cvt2(xc[u]);
+      const float x0 = ok ? xf[0] : 0.f, x1 = ok ? xf[1] : 0.f;
+      s0 += ok ? a0c[u] : 0.f;
+      s1 += ok ? a1c[u] : 0.f;
+      acc[0][0] = mfma32(x0, b0, acc[0][0]);
+      acc[0][1] = mfma32(x0, b1, acc[0][1]);
+      acc[1][0] = mfma32(x1, b0, acc[1][0]);
+      acc[1][1] = mfma32(x1, b1, acc[1][1]);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       xc[u] = xn[u];
       a0c[u] = a0n[u];
       a1c[u] = a1n[u];
+      wc[u] = wn[u];
     }
   }
   s0 += __shfl_xor(s0, 32, 64);
@@ -721,12 +725,17 @@ template <typename T>
 struct Elem8;
 template <>
 struct Elem8<float> {
-  static __device__ __forceinline__ void ld(const float* p, float* v) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+  struct raw {
+    f32x4 a, b;
+  };
+  static __device__ __forceinline__ raw ldraw(const float* p) {
+    return raw{*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4)};
+  }
+  static __device__ __forceinline__ void cvt(const raw& r, float* v) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      v[c] = a[c];
-      v[4 + c] = b[c];
+      v[c] = r.a[c];
+      v[4 + c] = r.b[c];
     }
   }
   static __device__ __forceinline__ void st(float* p, const float* v) {
@@ -737,8 +746,11 @@ struct Elem8<float> {
 template <>
 struct Elem8<unsigned short> {
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  static __device__ __forceinline__ void ld(const unsigned short* p, float* v) {
-    const u32x4 w = *reinterpret_cast<const u32x4*>(p);
+  typedef u32x4 raw;
+  static __device__ __forceinline__ raw ldraw(const unsigned short* p) {
+    return *reinterpret_cast<const u32x4*>(p);
+  }
+  static __device__ __forceinline__ void cvt(const raw& w, float* v) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       v[2 * c] = __uint_as_float(w[c] << 16);
@@ -827,8 +839,8 @@ __global__ __launch_bounds__(256, 2) void dx16_kernel(const void* __restrict__ x
   for (int c = 0; c < D / DX_CH; ++c) {
     const bool more = c + 1 < D / DX_CH;
     if (more) stage_load(c + 1);
-    float xin[8];
-    if (active && proj) Elem8<T>::ld(x + c * DX_CH, xin);
+    typename Elem8<T>::raw xraw{};     // raw prefetch: converted in the epilogue below
+    if (active && proj) xraw = Elem8<T>::ldraw(x + c * DX_CH);
     if (active) {
       const float* wb = &dx_lds[(c & 1) * DX_CHUNK + g * DX_PLANE + i * RT_LD];
       f32x4 acc[2];
@@ -869,6 +881,8 @@ __global__ __launch_bounds__(256, 2) void dx16_kernel(const void* __restrict__ x
         }
         if (proj) {
           const float f = rn_e * rd_e;
+          float xin[8];
+          Elem8<T>::cvt(xraw, xin);
 #pragma unroll
           for (int cc = 0; cc < 8; ++cc) out[cc] -= xin[cc] * f;
         }

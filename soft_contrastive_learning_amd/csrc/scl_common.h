@@ -74,6 +74,38 @@ struct Elem<unsigned short> {
   static __device__ __forceinline__ void st(unsigned short* p, float v) { *p = f32_to_bf16(v); }
 };
 
+// Raw (unconverted) vector loads: a prefetch must leave its destination registers untouched
+// until the data is consumed — converting bf16 at load time makes the compiler wait for the
+// load right after issuing it.  ldN returns the memory image, cvtN widens it to f32.
+template <typename T>
+struct Raw;
+template <>
+struct Raw<float> {
+  typedef f32x4 v4;
+  typedef f32x2 v2;
+  static __device__ __forceinline__ v4 ld4(const float* p) { return *reinterpret_cast<const v4*>(p); }
+  static __device__ __forceinline__ v2 ld2(const float* p) { return *reinterpret_cast<const v2*>(p); }
+  static __device__ __forceinline__ f32x4 cvt4(v4 r) { return r; }
+  static __device__ __forceinline__ f32x2 cvt2(v2 r) { return r; }
+};
+template <>
+struct Raw<unsigned short> {
+  typedef u16x4 v4;
+  typedef unsigned v2;
+  static __device__ __forceinline__ v4 ld4(const unsigned short* p) {
+    return *reinterpret_cast<const v4*>(p);
+  }
+  static __device__ __forceinline__ v2 ld2(const unsigned short* p) {
+    return *reinterpret_cast<const v2*>(p);
+  }
+  static __device__ __forceinline__ f32x4 cvt4(v4 r) {
+    return f32x4{bf16_to_f32(r[0]), bf16_to_f32(r[1]), bf16_to_f32(r[2]), bf16_to_f32(r[3])};
+  }
+  static __device__ __forceinline__ f32x2 cvt2(v2 r) {
+    return f32x2{__uint_as_float(r << 16), __uint_as_float(r & 0xffff0000u)};
+  }
+};
+
 // butterfly reductions inside one 32-lane half of the wave (xor 1..16)
 __device__ __forceinline__ float half_sum(float v) {
 #pragma unroll
