@@ -248,6 +248,19 @@ def main():
                             peak=PEAK_F32_TFLOPS if dom['bound'] == 'mfma' else PEAK_HBM_GBPS,
                             unit='TFLOP/s' if dom['bound'] == 'mfma' else 'GB/s',
                             frac=dom['frac'], traffic=None, us_per_launch=dom['us'])
+        if roofline:
+            # HBM bytes per launch measured offline with rocprofv3 PMC on this exact shape
+            # (profiles/pmc_traffic.json); null when the shape / dtype was not profiled
+            try:
+                with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
+                    pmc = json.load(f)
+                ent = pmc.get(args.dtype, {}).get(roofline['kernel'])
+                if ent and pmc['shape'] == {'batch': b, 'locations': n_loc}:
+                    roofline['traffic'] = ent['read'] + ent['write']
+                    roofline['traffic_algorithmic'] = int(models[roofline['kernel']]['bytes'])
+                    roofline['traffic_source'] = 'rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01'
+            except (OSError, ValueError, KeyError):
+                pass
         hip_ms = sum(r['us'] * r['launches'] for r in kernels) / 1e3 / max(args.steps, 1)
         out = {
             'metric': 'train-step images/sec (VGG16-NetVLAD soft-MS, 640x480)',

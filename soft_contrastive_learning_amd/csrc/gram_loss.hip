@@ -24,6 +24,7 @@ namespace {
 
 constexpr int kTile = 32;
 constexpr int kMaxB = 1024;  // rows kernel LDS and the backward's M tile are sized for this
+constexpr int kMaxSqdist = 4096;  // _pairwise_squared_distances only needs the slab pass
 
 struct GramPlan {
   int tiles;    // ceil(B / 32)
@@ -508,7 +509,7 @@ extern "C" int scl_gram_loss_bwd(const float* emb, int64_t ld_emb, int B, int E,
 }
 
 extern "C" size_t scl_pairwise_sqdist_workspace_bytes(int T, int S, int E) {
-  if (T < 1 || S < 1 || E < 1 || S > kMaxB) return 0;
+  if (T < 1 || S < 1 || E < 1 || S > kMaxSqdist) return 0;
   const GramPlan p = make_plan(S, E);
   return scl_round256((size_t)T * p.splits * p.npairs * kTile * kTile * sizeof(float));
 }
@@ -516,7 +517,7 @@ extern "C" size_t scl_pairwise_sqdist_workspace_bytes(int T, int S, int E) {
 extern "C" int scl_pairwise_sqdist(const float* feats, int T, int S, int E, float* out,
                                    void* workspace, size_t workspace_bytes, void* stream) {
   if (!feats || !out || !workspace) return SCL_E_NULL;
-  if (T < 1 || S < 1 || E < 1 || S > kMaxB || T > 65535) return SCL_E_SHAPE;
+  if (T < 1 || S < 1 || E < 1 || S > kMaxSqdist || T > 65535) return SCL_E_SHAPE;
   if (!scl_aligned256(workspace) || workspace_bytes < scl_pairwise_sqdist_workspace_bytes(T, S, E))
     return SCL_E_WORKSPACE;
   const GramPlan p = make_plan(S, E);

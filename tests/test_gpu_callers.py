@@ -42,6 +42,65 @@ def test_trainer_step_runs_and_updates_every_variable(dev, loss):
     assert len(changed) == len(before), sorted(set(before) - set(changed))
 
 
+def test_baseline_config0_triplet_pipeline_matches_cpu_restatement(dev):
+    """BASELINE.json configs[0]: triplet loss, VGG16-NetVLAD K=64, batch=4 synthetic 224x224 —
+    the whole HIP pipeline (f32) against the CPU restatement of the same step: torch-CPU
+    backbone + NumPy NetVLAD + NumPy pointnetvlad triplet_loss."""
+    from oracle import losses_np as O
+    from oracle import netvlad_np as NV
+    from soft_contrastive_learning_amd import pointnetvlad_cls as P
+    from soft_contrastive_learning_amd.model import nets
+    torch.manual_seed(0)
+    cpu_model = nets.VGG16NetVLAD(seed=1234)
+    img = torch.randint(0, 256, (4, 224, 224, 3), generator=torch.Generator().manual_seed(42)).float()
+    with torch.no_grad():
+        fmap = cpu_model.features(img)                                     # [4,14,14,512]
+        want_emb = NV.netvlad_fused(fmap.reshape(4, -1, 512).numpy(),
+                                    cpu_model.assignment_kernel.reshape(512, 64).numpy(),
+                                    cpu_model.cluster_centers.reshape(512, 64).numpy())
+    q, pos, neg = O.split_tuples(want_emb, 1, [1, 1, 2])                  # T=1, P=1, N=2
+    want = float(O.triplet_loss(q, pos, neg, 0.5))
+    gpu_model = nets.VGG16NetVLAD(seed=1234).to(dev)
+    emb = nets.vgg16Netvlad(img.to(dev), model=gpu_model)
+    assert emb.shape == (4, 32768)
+    parts = torch.split(emb.reshape(1, 4, -1), [1, 1, 2], dim=1)
+    loss = P.triplet_loss(*parts, 0.5)
+    loss.backward()
+    err = float((emb.detach().cpu() - torch.from_numpy(want_emb)).abs().max()) / float(np.abs(want_emb).max())
+    assert err < 2e-3                      # MIOpen vs oneDNN convolution algorithms, 13 layers deep
+    assert abs(float(loss) - want) <= 2e-3 * abs(want) + 1e-6, (float(loss), want)
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in gpu_model.parameters())
+
+
+def test_mining_cache_ranks_like_the_reference_kdtree(dev):
+    """train/train.py:446-453: per cached image, the whole cache sorted by descriptor
+    distance.  1250 = mining_cache_size 1000 + mining_step 250 rows of 32768-d."""
+    from sklearn.neighbors import KDTree
+    from soft_contrastive_learning_amd.train import mining
+    c, e = 1250, 32768
+    feats = U.embeddings(c, e, seed=31, mix=2.0)
+    feats /= np.linalg.norm(feats, axis=1, keepdims=True)
+    ids = np.random.default_rng(3).permutation(50000)[:c]
+    cache = mining.MiningCache()
+    cache.update(torch.tensor(feats, device=dev), ids)
+    assert cache.sorted_neighbours(-1) is None
+    tree = KDTree(feats[:, :])                      # the reference's structure (float64 inside)
+    for probe in (0, 17, c - 1):
+        got = cache.sorted_neighbours(int(ids[probe]))
+        assert got[0] == ids[probe] and sorted(got) == sorted(ids.tolist())
+        want_d, want_i = tree.query(feats[probe:probe + 1], k=c, sort_results=True)
+        # same ordering up to float32 resolution of near-equal distances: the distance
+        # sequence of OUR order, evaluated exactly, must be non-decreasing within 1e-5
+        pos = {int(v): k for k, v in enumerate(ids)}
+        ours = np.array([pos[g] for g in got])
+        exact = np.linalg.norm(feats[ours].astype(np.float64) - feats[probe].astype(np.float64), axis=1)
+        assert np.all(np.diff(exact) > -1e-5)
+        # and the nearest 20 agree exactly where the reference's gaps exceed that resolution
+        gaps = np.diff(want_d[0][:21])
+        if np.all(gaps > 1e-4):
+            assert got[:20] == ids[want_i[0][:20]].tolist()
+
+
 def test_inference_product_is_the_reference_pickle(dev, tmp_path):
     from soft_contrastive_learning_amd.evaluation import inference
     from soft_contrastive_learning_amd.model import nets
