@@ -211,6 +211,11 @@ int scl_vgg_pool_bwd(const void* g, const void* a, const void* z, int dtype, int
  * HIP events on its launch stream.  scl_prof_end waits for them and returns per-launch
  * milliseconds and kernel names (static strings).
  * ------------------------------------------------------------------------- */
+/* Ablation switch for scripts/ablate_rowtile.py: a non-zero variant makes the forward
+ * row-tile kernel skip its epilogue stores (bit 0), its x loads (bit 1) and/or its operand
+ * staging and barriers (bit 2).  Results are then meaningless; 0 restores production
+ * kernels.  Returns the previous value. */
+int scl_debug_set_variant(int variant);
 int scl_prof_begin(int capacity);
 int scl_prof_count(void);
 int scl_prof_end(float* ms, const char** names, int capacity);

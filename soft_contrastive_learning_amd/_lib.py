@@ -53,6 +53,7 @@ SIGNATURES = {
     "scl_vgg_act_bwd": (_i, [_p, _p, _i, _l, _i, _p, _p, _p, _z, _p]),
     "scl_vgg_pool_fwd": (_i, [_p, _i, _p, _i, _i, _i, _i, _p, _p]),
     "scl_vgg_pool_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _z, _p]),
+    "scl_debug_set_variant": (_i, [_i]),
     "scl_prof_begin": (_i, [_i]),
     "scl_prof_count": (_i, []),
     "scl_prof_end": (_i, [_p, _p, _i]),

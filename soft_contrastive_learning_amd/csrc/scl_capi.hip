@@ -16,6 +16,14 @@ extern "C" const char* scl_error_string(int code) {
   return "unknown error";
 }
 
+// ---- ablation switch for diagnostic kernel variants (scripts/ablate_rowtile.py) ----------
+volatile int scl_debug_variant = 0;
+extern "C" int scl_debug_set_variant(int v) {
+  const int old = scl_debug_variant;
+  scl_debug_variant = v;
+  return old;
+}
+
 // ---- per-kernel timing sink (diagnostics; see SCL_LAUNCH in scl_common.h) ---------------
 SclProfSink* volatile scl_prof_sink = nullptr;
 

@@ -87,6 +87,7 @@ struct Raw<float> {
   static __device__ __forceinline__ v2 ld2(const float* p) { return *reinterpret_cast<const v2*>(p); }
   static __device__ __forceinline__ f32x4 cvt4(v4 r) { return r; }
   static __device__ __forceinline__ f32x2 cvt2(v2 r) { return r; }
+  static __device__ __forceinline__ v4 ones4() { return v4{1.f, 1.f, 1.f, 1.f}; }
 };
 template <>
 struct Raw<unsigned short> {
@@ -104,6 +105,7 @@ struct Raw<unsigned short> {
   static __device__ __forceinline__ f32x2 cvt2(v2 r) {
     return f32x2{__uint_as_float(r << 16), __uint_as_float(r & 0xffff0000u)};
   }
+  static __device__ __forceinline__ v4 ones4() { return v4{0x3f80, 0x3f80, 0x3f80, 0x3f80}; }
 };
 
 // butterfly reductions inside one 32-lane half of the wave (xor 1..16)
@@ -177,6 +179,9 @@ extern SclProfSink* volatile scl_prof_sink;
     hipLaunchKernelGGL(kernel, grid, block, lds, (st), __VA_ARGS__);             \
     if (slot_ >= 0) (void)hipEventRecord(ps_->ev[2 * slot_ + 1], (st));          \
   } while (0)
+
+// diagnostic kernel variant selector (0 = production kernels); set by scl_debug_set_variant
+extern volatile int scl_debug_variant;
 
 static inline int scl_launch_status() { return (int)hipGetLastError(); }
 static inline bool scl_aligned256(const void* p) { return (((uintptr_t)p) & 255u) == 0; }

@@ -24,6 +24,16 @@ def topn_l2(ref, query, n, idx_offset=0):
                                                                      tuple(query.shape)))
     r, d = ref.shape
     q = query.shape[0]
+    if n > MAX_N or n > r or n < 1:
+        raise ValueError("n must be in [1, min(%d, R)], got n=%d R=%d" % (MAX_N, n, r))
+    if d > 256:
+        return _topn_wide(ref, query, n, idx_offset)
+    if d not in (32, 64, 128, 256):
+        # zero-padding the feature axis leaves every distance unchanged
+        pad = next(c for c in (32, 64, 128, 256) if d <= c)
+        ref = torch.nn.functional.pad(ref, (0, pad - d))
+        query = torch.nn.functional.pad(query, (0, pad - d))
+        d = pad
     nbytes = lib.scl_topn_l2_workspace_bytes(r, q, d, n)
     if nbytes == 0:
         raise ValueError("unsupported retrieval shape R=%d Q=%d d=%d n=%d "
@@ -34,6 +44,50 @@ def topn_l2(ref, query, n, idx_offset=0):
     L.check(lib.scl_topn_l2(L.ptr(ref), r, L.ptr(query), q, d, n, int(idx_offset), L.ptr(idx),
                             L.ptr(dist), L.ptr(ws), ws.numel(), L.stream_of(ref)))
     return dist, idx
+
+
+_KEEP = 32          # candidates nominated in float32 before the float64 re-rank
+
+
+def _topn_wide(ref, query, n, idx_offset):
+    """Descriptors wider than 256 (the in-training localisation check runs the KDTree on the
+    raw 32768-d vectors, train/train.py:1181-1182; evaluation/top-n.py sweeps d up to 4096):
+    blocks of queries x references go through the exact-f32 pairwise-distance kernel
+    (``scl_pairwise_sqdist``), the best 32 per query are kept across blocks and re-ranked in
+    float64 with the direct (q - r)^2 form, like the fused kernel does for d <= 256."""
+    from ..model import losses
+    r, d = ref.shape
+    q = query.shape[0]
+    qb_max, cap = 512, 4096
+    out_d = torch.empty((q, n), dtype=torch.float64, device=ref.device)
+    out_i = torch.empty((q, n), dtype=torch.int64, device=ref.device)
+    for qs in range(0, q, qb_max):
+        qq = query[qs:qs + qb_max]
+        qb = qq.shape[0]
+        cand_s, cand_i = [], []
+        for rs in range(0, r, cap - qb):
+            rr = ref[rs:rs + cap - qb]
+            d2 = losses._pairwise_squared_distances(torch.cat([qq, rr], 0)[None])[0][:qb, qb:]
+            k = min(_KEEP, rr.shape[0])
+            s, i = torch.topk(d2, k, dim=1, largest=False)
+            cand_s.append(s)
+            cand_i.append(i + rs)
+        s, i = torch.cat(cand_s, 1), torch.cat(cand_i, 1)
+        k = min(_KEEP, s.shape[1])
+        _, pick = torch.topk(s, k, dim=1, largest=False)
+        cand = torch.gather(i, 1, pick)                                   # [qb, k]
+        exact = torch.empty((qb, k), dtype=torch.float64, device=ref.device)
+        step = max(1, (1 << 25) // (k * d))                               # <= 256 MB of float64
+        for a in range(0, qb, step):
+            diff = qq[a:a + step].double()[:, None, :] - ref[cand[a:a + step]].double()
+            exact[a:a + step] = (diff * diff).sum(-1)
+        # order by (distance, index): stable sort by index first, then by distance
+        o = torch.argsort(cand, dim=1, stable=True)
+        exact, cand = torch.gather(exact, 1, o), torch.gather(cand, 1, o)
+        o = torch.argsort(exact, dim=1, stable=True)[:, :n]
+        out_d[qs:qs + qb] = torch.gather(exact, 1, o).sqrt()
+        out_i[qs:qs + qb] = torch.gather(cand, 1, o) + int(idx_offset)
+    return out_d, out_i
 
 
 def merge_topn(dists, idxs, n):

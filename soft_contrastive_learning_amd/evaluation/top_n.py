@@ -24,18 +24,6 @@ def thin_reference(ref_xy, l):
     return ref_idx
 
 
-def _pad_dim(a, d):
-    """the HIP kernel takes d in {32,64,128,256}: zero-pad (distances are unchanged)."""
-    for cand in (32, 64, 128, 256):
-        if d <= cand:
-            if a.shape[1] == cand:
-                return a
-            out = np.zeros((a.shape[0], cand), dtype=np.float32)
-            out[:, :a.shape[1]] = a
-            return out
-    raise ValueError("feature dimension %d > 256 is not supported by the top-n kernel" % d)
-
-
 def get_top_n(pca_f, full_ref_f, full_query_f, full_ref_xy, full_query_xy, n=25, d=256, l=0.0,
               device='cuda'):
     """Arrays in, the reference's pickle payload out (None when fewer than n references
@@ -54,9 +42,9 @@ def get_top_n(pca_f, full_ref_f, full_query_f, full_ref_xy, full_query_xy, n=25,
     xy_dists = full_xy_dists[:, ref_idx]
     num_q = pca_query_f.shape[0]
 
-    dist, idx = retrieval.topn_l2(torch.from_numpy(_pad_dim(ref_f, d)).to(device),
-                                  torch.from_numpy(_pad_dim(pca_query_f.astype(np.float32), d))
-                                  .to(device), n)
+    # any d: the retrieval layer pads to the kernel's widths or takes its wide-descriptor path
+    dist, idx = retrieval.topn_l2(torch.from_numpy(ref_f).to(device),
+                                  torch.from_numpy(pca_query_f.astype(np.float32)).to(device), n)
     top_f_dists = dist.cpu().numpy()
     top_i = idx.cpu().numpy().astype(int)
     top_g_dists = [[xy_dists[q, r] for r in top_i[q, :]] for q in range(num_q)]

@@ -27,6 +27,26 @@ def test_topn_matches_kdtree(dev, r, q, d, n):
     np.testing.assert_allclose(got_d.cpu().numpy(), want_d, rtol=1e-12, atol=0)
 
 
+@pytest.mark.parametrize("r,q,d,n", [(700, 33, 96, 25), (900, 20, 40, 7),      # padded to 128 / 64
+                                     (3000, 50, 32768, 5),                     # train/train.py:1181-1182
+                                     (6000, 70, 1024, 25)])                    # top-n.py D sweep, 2 ref blocks
+def test_topn_other_widths_match_kdtree(dev, r, q, d, n):
+    from soft_contrastive_learning_amd.evaluation import retrieval
+    ref, qry = U.retrieval_sets(r, q, d)
+    if d <= 1024:
+        want_d, want_i = TN.topn_bruteforce(ref, qry, n, chunk=8)
+    else:
+        # float64 Gram expansion (the [Q,R,d] broadcast of the brute force would need GBs);
+        # distances are then recomputed directly for the winners
+        r64, q64 = ref.astype(np.float64), qry.astype(np.float64)
+        d2 = (q64 ** 2).sum(1)[:, None] + (r64 ** 2).sum(1)[None] - 2.0 * q64 @ r64.T
+        want_i = np.argsort(d2, axis=1, kind='stable')[:, :n]
+        want_d = np.sqrt(((q64[:, None, :] - r64[want_i]) ** 2).sum(-1))
+    got_d, got_i = retrieval.topn_l2(torch.tensor(ref, device=dev), torch.tensor(qry, device=dev), n)
+    np.testing.assert_array_equal(got_i.cpu().numpy(), want_i)
+    np.testing.assert_allclose(got_d.cpu().numpy(), want_d, rtol=1e-10, atol=0)
+
+
 def test_topn_duplicates_and_offset(dev):
     from soft_contrastive_learning_amd.evaluation import retrieval
     ref, qry = U.retrieval_sets(300, 10, 64)
