@@ -243,73 +243,99 @@ __global__ __launch_bounds__(256, 2) void topn_scan_kernel(const float* __restri
   }
 }
 
-// One workgroup per query.  LDS: sc[M] | ix[M] with M = splits * KEEP.
+// One WAVE per query (4 queries per workgroup).  Per-wave LDS: sc[M] | ix[M] | best_ix[KEEP]
+// | best_d[KEEP] with M = splits * KEEP.  NE = entries per lane (M <= 64 * NE).
+//   stage 1  best KEEP of the M per-split candidates by f32 score (rank counting)
+//   stage 2  exact float64 sum (q - r)^2 of those KEEP: four 16-lane groups work on four
+//            candidates at a time and all loads of a round are issued before any reduction,
+//            so the 32 scattered reference rows are fetched with 4-8 rows in flight
+//   stage 3  order by (distance, index), emit the first n
+template <int NE>
 __global__ __launch_bounds__(256) void topn_rerank_kernel(const float* __restrict__ ref,
-                                                          const float* __restrict__ query, int d,
-                                                          int splits, int n, int64_t idx_offset,
+                                                          const float* __restrict__ query, int Q,
+                                                          int d, int splits, int n,
+                                                          int64_t idx_offset,
                                                           const float* __restrict__ cand_sc,
                                                           const int* __restrict__ cand_ix,
                                                           int64_t* __restrict__ idx_out,
                                                           double* __restrict__ dist_out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  __shared__ int best_ix[KEEP];
-  __shared__ double best_d[KEEP];
   const int M = splits * KEEP;
-  float* sc = lds;
-  int* ix = reinterpret_cast<int*>(lds + M);
-  const int qi = blockIdx.x;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  for (int e = threadIdx.x; e < M; e += 256) {
-    sc[e] = cand_sc[(int64_t)qi * M + e];
-    ix[e] = cand_ix[(int64_t)qi * M + e];
-  }
-  if (threadIdx.x < KEEP) best_ix[threadIdx.x] = -1;
-  __syncthreads();
-  // stage 1: best KEEP by f32 score over all splits
-  for (int e = threadIdx.x; e < M; e += 256) {
-    const float ms = sc[e];
-    const int mi = ix[e];
-    if (mi < 0) continue;
-    int rank = 0;
-    for (int o = 0; o < M; ++o) {
-      const float os = sc[o];
-      const int oi = ix[o];
-      rank += oi >= 0 && ((os < ms) || (os == ms && oi < mi));
+  const int per_wave = 2 * M + KEEP + 2 * KEEP;          // floats (best_d as 2 floats each)
+  float* sc = lds + wid * per_wave;
+  int* ix = reinterpret_cast<int*>(sc + M);
+  int* best_ix = ix + M;
+  double* best_d = reinterpret_cast<double*>(best_ix + KEEP);
+  const int qi = blockIdx.x * 4 + wid;
+  if (qi >= Q) return;                                   // wave-uniform; no block barriers below
+
+  float es[NE];
+  int ei[NE];
+#pragma unroll
+  for (int k = 0; k < NE; ++k) {
+    const int e = k * 64 + lane;
+    es[k] = e < M ? cand_sc[(int64_t)qi * M + e] : INFINITY;
+    ei[k] = e < M ? cand_ix[(int64_t)qi * M + e] : -1;
+    if (e < M) {
+      sc[e] = es[k];
+      ix[e] = ei[k];
     }
-    if (rank < KEEP) best_ix[rank] = mi;
   }
-  __syncthreads();
-  // stage 2: exact float64 squared distance, direct (q - r)^2 form, one wave per candidate
+  if (lane < KEEP) best_ix[lane] = -1;
+  __builtin_amdgcn_wave_barrier();
+  int rank[NE];
+#pragma unroll
+  for (int k = 0; k < NE; ++k) rank[k] = 0;
+  for (int o = 0; o < M; ++o) {
+    const float os = sc[o];
+    const int oi = ix[o];
+    if (oi < 0) continue;                                // wave-uniform (broadcast read)
+#pragma unroll
+    for (int k = 0; k < NE; ++k) rank[k] += (os < es[k]) || (os == es[k] && oi < ei[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < NE; ++k)
+    if (ei[k] >= 0 && rank[k] < KEEP) best_ix[rank[k]] = ei[k];
+  __builtin_amdgcn_wave_barrier();
+
+  const int grp = lane >> 4, gl = lane & 15;
   const float* qp = query + (int64_t)qi * d;
-  for (int c = wid; c < KEEP; c += 4) {
+#pragma unroll 2
+  for (int t = 0; t < KEEP / 4; ++t) {
+    const int c = 4 * t + grp;
     const int ri = best_ix[c];
     double s = 0.0;
     if (ri >= 0) {
       const float* rp = ref + (int64_t)ri * d;
-      for (int e = lane; e < d; e += 64) {
-        const double df = (double)qp[e] - (double)rp[e];
-        s = fma(df, df, s);
+      for (int e = 4 * gl; e < d; e += 64) {
+        const f32x4 qv = *reinterpret_cast<const f32x4*>(qp + e);
+        const f32x4 rv = *reinterpret_cast<const f32x4*>(rp + e);
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const double df = (double)qv[cc] - (double)rv[cc];
+          s = fma(df, df, s);
+        }
       }
     }
 #pragma unroll
-    for (int m = 1; m < 64; m <<= 1) s += __shfl_xor(s, m, 64);
-    if (lane == 0) best_d[c] = ri >= 0 ? s : INFINITY;
+    for (int m = 1; m < 16; m <<= 1) s += __shfl_xor(s, m, 64);
+    if (gl == 0) best_d[c] = ri >= 0 ? s : INFINITY;
   }
-  __syncthreads();
-  // stage 3: order by (distance, index), emit the first n
-  if (threadIdx.x < KEEP) {
-    const double md = best_d[threadIdx.x];
-    const int mi = best_ix[threadIdx.x];
+  __builtin_amdgcn_wave_barrier();
+  if (lane < KEEP) {
+    const double md = best_d[lane];
+    const int mi = best_ix[lane];
     if (mi >= 0) {
-      int rank = 0;
+      int rk = 0;
       for (int o = 0; o < KEEP; ++o) {
         const int oi = best_ix[o];
         const double od = best_d[o];
-        rank += oi >= 0 && ((od < md) || (od == md && oi < mi));
+        rk += oi >= 0 && ((od < md) || (od == md && oi < mi));
       }
-      if (rank < n) {
-        idx_out[(int64_t)qi * n + rank] = (int64_t)mi + idx_offset;
-        dist_out[(int64_t)qi * n + rank] = sqrt(md);
+      if (rk < n) {
+        idx_out[(int64_t)qi * n + rk] = (int64_t)mi + idx_offset;
+        dist_out[(int64_t)qi * n + rk] = sqrt(md);
       }
     }
   }
@@ -324,7 +350,8 @@ inline TopnPlan topn_plan(int R, int Q) {
   const int max_splits = (R + 32 * KEEP - 1) / (32 * KEEP);  // keep >= 32 tiles per split
   int best = 1;
   double best_cost = 1e30;
-  for (int s = 1; s <= 64 && s <= (max_splits < 1 ? 1 : max_splits); ++s) {
+  // <= 32 splits: the re-rank keeps 32 * splits candidates per query in LDS (one wave each)
+  for (int s = 1; s <= 32 && s <= (max_splits < 1 ? 1 : max_splits); ++s) {
     const long wgs = (long)p.qtiles * s;
     const long rounds = (wgs + 511) / 512;   // two resident workgroups per CU
     // time ~ rounds * (R / s); prefer fewer splits on ties (less merge work)
@@ -397,8 +424,17 @@ extern "C" int scl_topn_l2(const float* ref, int R, const float* query, int Q, i
     case 128: launch_scan<16>(p, ref, refnorm, R, query, Q, cs, ci, st); break;
     default: launch_scan<32>(p, ref, refnorm, R, query, Q, cs, ci, st); break;
   }
-  const size_t lds = (size_t)p.splits * KEEP * 2 * sizeof(float);
-  SCL_LAUNCH("topn_rerank_kernel", topn_rerank_kernel, dim3(Q), dim3(256), lds, st, ref, query, d, p.splits, n,
-                     idx_offset, (const float*)cs, (const int*)ci, idx_out, dist_out);
+  const int M = p.splits * KEEP;
+  const size_t lds = (size_t)4 * (2 * M + 3 * KEEP) * sizeof(float);
+  const dim3 rgrid((Q + 3) / 4);
+  if (M <= 256)
+    SCL_LAUNCH("topn_rerank_kernel", topn_rerank_kernel<4>, rgrid, dim3(256), lds, st, ref, query,
+               Q, d, p.splits, n, idx_offset, (const float*)cs, (const int*)ci, idx_out, dist_out);
+  else if (M <= 512)
+    SCL_LAUNCH("topn_rerank_kernel", topn_rerank_kernel<8>, rgrid, dim3(256), lds, st, ref, query,
+               Q, d, p.splits, n, idx_offset, (const float*)cs, (const int*)ci, idx_out, dist_out);
+  else
+    SCL_LAUNCH("topn_rerank_kernel", topn_rerank_kernel<16>, rgrid, dim3(256), lds, st, ref, query,
+               Q, d, p.splits, n, idx_offset, (const float*)cs, (const int*)ci, idx_out, dist_out);
   return scl_launch_status();
 }
