@@ -7,13 +7,13 @@
 // selection so the Q x R distance matrix (4 GB at 10k x 100k) never exists:
 //   refnorm_kernel     ||r||^2 per reference row
 //   topn_scan_kernel   per (128-query tile, reference split): score = ||r||^2 - 2 q.r on
-//                      v_mfma_f32_32x32x2_f32 (queries resident in registers, reference
-//                      tiles double-buffered through LDS), threshold-and-append
-//                      selection into per-query LDS lists of 64, compacted by rank
-//                      counting to the best 32 whenever a list could overflow
-//   topn_rerank_kernel merges the per-split lists by f32 score, recomputes the best 32
-//                      candidates' distances exactly in float64 as sum (q - r)^2, sorts by
-//                      (distance, index) and emits the first n
+//                      v_mfma_f32_32x32x2_f32 (queries resident in registers, the reference
+//                      tile in LDS with a register prefetch of the next one); every query
+//                      keeps a sorted list of its best 32 and a score under its threshold
+//                      is inserted by the whole wave in O(1)
+//   topn_rerank_kernel one wave per query: merges the per-split lists by f32 score,
+//                      recomputes the best 32 candidates' distances exactly in float64 as
+//                      sum (q - r)^2, sorts by (distance, index) and emits the first n
 // The f32 pass only nominates candidates (n <= 25 of 32 kept); the emitted
 // order and distances are float64-exact.
 #include <limits.h>
