@@ -284,19 +284,57 @@ __global__ __launch_bounds__(256) void topn_rerank_kernel(const float* __restric
   }
   if (lane < KEEP) best_ix[lane] = -1;
   __builtin_amdgcn_wave_barrier();
-  int rank[NE];
+  // Stage 1 is a radix select of the KEEP-th smallest score (32 bit-steps of a wave-wide
+  // count) instead of rank counting, which costs M^2/64 compares per wave (the dominant
+  // cost of this kernel at M = 608).  Keys: order-preserving map f32 -> u32; empty = max.
+  unsigned eu[NE];
+  int nvalid = 0;
 #pragma unroll
-  for (int k = 0; k < NE; ++k) rank[k] = 0;
-  for (int o = 0; o < M; ++o) {
-    const float os = sc[o];
-    const int oi = ix[o];
-    if (oi < 0) continue;                                // wave-uniform (broadcast read)
-#pragma unroll
-    for (int k = 0; k < NE; ++k) rank[k] += (os < es[k]) || (os == es[k] && oi < ei[k]);
+  for (int k = 0; k < NE; ++k) {
+    const unsigned bits = __float_as_uint(es[k]);
+    eu[k] = ei[k] >= 0 ? (bits ^ ((bits >> 31) ? 0xffffffffu : 0x80000000u)) : 0xffffffffu;
+    nvalid += ei[k] >= 0;
   }
 #pragma unroll
-  for (int k = 0; k < NE; ++k)
-    if (ei[k] >= 0 && rank[k] < KEEP) best_ix[rank[k]] = ei[k];
+  for (int m = 1; m < 64; m <<= 1) nvalid += __shfl_xor(nvalid, m, 64);
+  unsigned tau_key = 0xffffffffu;                         // fewer than KEEP entries: all win
+  if (nvalid > KEEP) {
+    unsigned prefix = 0;
+    int need = KEEP;
+    for (int bit = 31; bit >= 0; --bit) {
+      const unsigned hi_mask = bit == 31 ? 0u : (0xffffffffu << (bit + 1));
+      int c0 = 0;
+#pragma unroll
+      for (int k = 0; k < NE; ++k)
+        c0 += ((eu[k] & hi_mask) == (prefix & hi_mask)) && !((eu[k] >> bit) & 1u);
+#pragma unroll
+      for (int m = 1; m < 64; m <<= 1) c0 += __shfl_xor(c0, m, 64);
+      if (need > c0) {
+        need -= c0;
+        prefix |= 1u << bit;
+      }
+    }
+    tau_key = prefix;                                     // key of the KEEP-th smallest
+  }
+  {
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int base = 0;
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {                        // strictly below the threshold
+      const bool sel = ei[k] >= 0 && eu[k] < tau_key;
+      const unsigned long long m = __ballot(sel);
+      if (sel) best_ix[base + __popcll(m & lt)] = ei[k];
+      base += __popcll(m);
+    }
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {                        // ties at the threshold fill the rest
+      const bool sel = ei[k] >= 0 && eu[k] == tau_key;
+      const unsigned long long m = __ballot(sel);
+      const int pos = base + __popcll(m & lt);
+      if (sel && pos < KEEP) best_ix[pos] = ei[k];
+      base += __popcll(m);
+    }
+  }
   __builtin_amdgcn_wave_barrier();
 
   const int grp = lane >> 4, gl = lane & 15;
