@@ -17,6 +17,7 @@
 // The f32 pass only nominates candidates (n <= 25 of 32 kept); the emitted
 // order and distances are float64-exact.
 #include <limits.h>
+#include <math.h>
 
 #include <mutex>
 
@@ -392,8 +393,13 @@ inline TopnPlan topn_plan(int R, int Q) {
   for (int s = 1; s <= 32 && s <= (max_splits < 1 ? 1 : max_splits); ++s) {
     const long wgs = (long)p.qtiles * s;
     const long rounds = (wgs + 511) / 512;   // two resident workgroups per CU
-    // time ~ rounds * (R / s); prefer fewer splits on ties (less merge work)
-    const double cost = (double)rounds * ((double)R / s) * (1.0 + 0.002 * s);
+    // Cycles per workgroup ~ MFMA time of its tiles + list insertions.  Every split restarts
+    // its thresholds at +inf, and a wave inserts ~1024 ln(tiles) candidates per split at
+    // ~240 cycles each (measured: 19 splits spent as long inserting as multiplying), so
+    // more splits buy parallelism with extra selection work.
+    const double tiles = ((double)R / s) / 32.0;
+    const double cost =
+        (double)rounds * (8192.0 * tiles + 245760.0 * log(tiles + 1.0)) * (1.0 + 0.002 * s);
     if (cost < best_cost) {
       best_cost = cost;
       best = s;
