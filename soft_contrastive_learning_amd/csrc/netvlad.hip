@@ -6,26 +6,27 @@
 // The TF graph materialises the 5-D tensor [B,H',W',D,K] (157 MB per 640x480 image)
 // in forward and again in autodiff; here nothing larger than [B,N,64] is ever written.
 //
-// Both contractions (N x 512 x 64 each) run on v_mfma_f32_32x32x2_f32: exact f32
-// (bitwise a k-ordered fmaf chain) at the f32 vector rate, so the governing roofline
-// is f32 FMA (157.3 TF), not HBM.  Linearity is used to keep x raw:
+// Every contraction runs on the f32-input matrix cores (v_mfma_f32_16x16x4_f32 for the
+// location-tile kernels, v_mfma_f32_32x32x2_f32 for the aggregation): exact f32 (bitwise a
+// k-ordered fmaf chain), so the governing roofline is the 157.3 TF f32 MFMA peak, not HBM
+// (SURVEY.md H1).  Linearity is used to keep x raw:
 //   s[n,k] = rn[n] * sum_d x[n,d] W[d,k],      rn[n] = rsqrt(max(sum_d x^2, 1e-12))
 //   V[d,k] = sum_n (a[n,k] rn[n]) x[n,d] + C[d,k] * sum_n a[n,k]
 //
 // Forward kernels
-//   transpose_w_kernel       W[512,64] -> Wt[64,512] (LDS image source)
-//   rowtile_kernel<ASSIGN>   per 32-location tile: x·W from an LDS-resident Wt, row
-//                            norms from the same operand loads, softmax over K by
-//                            half-wave butterflies -> a, rn (+ logits for training)
-//   aggregate_kernel         per (image, 32-channel tile, location half): x^T·(a rn),
-//                            split over 4 waves along n, LDS reduce -> partial slabs
-//   finish_sum/norm_kernel   slabs + C*asum, intra-norm over D, global norm -> out
+//   transpose_w_kernel         W[512,64] -> Wt[64,512] (source of the LDS operand image)
+//   rowtile16_kernel<ASSIGN>   per 16-location tile: x.W against a double-buffered LDS image
+//                              of Wt, row norms from the same x loads, softmax over K by
+//                              16-lane butterflies -> a, rn (+ logits for training)
+//   aggregate_kernel           per (image, 64-channel tile, location split): x^T.(a rn),
+//                              4 waves along n, LDS tree reduce -> partial slabs
+//   finish_sum/norm_kernel     slabs + C*asum, intra-norm over D, global norm -> out
 // Backward kernels
-//   bwd_prep_kernel          grad through both norms -> dU (both layouts), c·dU
-//   rowtile_kernel<DASSIGN>  x·dU[b] -> d a -> softmax backward -> ds, <dxhat,xhat>
-//   aggregate_kernel         x^T·(ds rn) -> per-image dW slabs
-//   dx_kernel                [a | ds]·[dU | W]^T and the l2-norm Jacobian -> grad_x
-//   wgrad_finish_kernel      sums over the batch -> grad_w, grad_c
+//   bwd_prep_kernel            grad through both norms -> dU (both layouts), c.dU
+//   rowtile16_kernel<DASSIGN>  x.dU[b] -> d a -> softmax backward -> ds, <dxhat,xhat>
+//   aggregate_kernel           x^T.(ds rn) -> per-image dW slabs
+//   dx16_kernel                [a | ds].[dU | W]^T and the l2-norm Jacobian -> grad_x
+//   wgrad_finish_kernel        sums over the batch -> grad_w, grad_c
 #include <mutex>
 
 #include "scl_common.h"
@@ -34,7 +35,6 @@ namespace {
 
 constexpr int D = SCL_VLAD_D;   // 512
 constexpr int K = SCL_VLAD_K;   // 64
-constexpr int WT_LD = D + 4;    // padded LDS row: conflict-free ds_read_b128 over 16 rows
 constexpr int NSPLIT = 4;       // location splits with their own slab in aggregate_kernel
 
 // ------------------------------------------------------------------ small kernels
@@ -64,114 +64,11 @@ struct RowTileArgs {
   float* rowdot;         // [B,N]
 };
 
-// grid (ceil(tiles/4), B); block 256: every wave owns one 32-location tile of image b and
-// contracts it over all 512 channels against the LDS image of the [64][512] operand.
-template <typename T, int MODE>
-__global__ __launch_bounds__(256) void rowtile_kernel(RowTileArgs p) {
-  extern __shared__ __attribute__((aligned(16))) float bt_lds[];  // [64][WT_LD]
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int r = lane & 31, h = lane >> 5;
-  const int b = blockIdx.y;
-  // stage the B operand: 64 rows x 512 floats, float4 per thread, coalesced
-  {
-    const float* src = p.bt + (int64_t)b * p.bt_stride;
-    for (int idx = threadIdx.x; idx < K * (D / 4); idx += 256) {
-      const int row = idx / (D / 4), c4 = idx % (D / 4);
-      *reinterpret_cast<f32x4*>(&bt_lds[row * WT_LD + c4 * 4]) =
-          *reinterpret_cast<const f32x4*>(src + row * D + c4 * 4);
-    }
-  }
-  __syncthreads();
-  const int n0 = (blockIdx.x * 4 + wid) * 32;
-  if (n0 >= p.N) return;
-  const int n = n0 + r;
-  const bool row_ok = n < p.N;
-  const T* xrow = reinterpret_cast<const T*>(p.x) + ((int64_t)b * p.N + (row_ok ? n : 0)) * D + 4 * h;
-  const float* b0 = &bt_lds[r * WT_LD + 4 * h];
-  const float* b1 = &bt_lds[(32 + r) * WT_LD + 4 * h];
-
-  f32x16 acc0 = zero16(), acc1 = zero16();
-  float ss = 0.f;
-  // 64 groups of 8 channels; half h takes channels 8t+4h..8t+4h+3 of each group (the same
-  // permutation on both operands).  Loads run one 8-group chunk ahead of the MFMAs.
-  f32x4 cur[8], nxt[8];
-#pragma unroll
-  for (int u = 0; u < 8; ++u) cur[u] = Elem<T>::ld4(xrow + 8 * u);
-#pragma unroll 1
-  for (int chunk = 0; chunk < 8; ++chunk) {
-    if (chunk < 7) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) nxt[u] = Elem<T>::ld4(xrow + 64 * (chunk + 1) + 8 * u);
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      f32x4 xa = cur[u];
-      if (!row_ok) xa = f32x4{0.f, 0.f, 0.f, 0.f};
-      const f32x4 w0 = *reinterpret_cast<const f32x4*>(b0 + 64 * chunk + 8 * u);
-      const f32x4 w1 = *reinterpret_cast<const f32x4*>(b1 + 64 * chunk + 8 * u);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        acc0 = mfma32(xa[c], w0[c], acc0);
-        acc1 = mfma32(xa[c], w1[c], acc1);
-        ss = fmaf(xa[c], xa[c], ss);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) cur[u] = nxt[u];
-  }
-
-  if (MODE == ASSIGN) {
-    ss += __shfl_xor(ss, 32, 64);
-    const float rn = p.pre_l2 ? 1.0f / sqrtf(fmaxf(ss, 1e-12f)) : 1.0f;
-    if (h == 0 && row_ok) p.rnorm[(int64_t)b * p.N + n] = rn;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int row = acc_row(q, h);
-      const float rnr = __shfl(rn, row, 64);
-      const float s0 = acc0[q] * rnr, s1 = acc1[q] * rnr;
-      const float m = half_max(fmaxf(s0, s1));
-      const float e0 = expf(s0 - m), e1 = expf(s1 - m);
-      const float inv = 1.0f / half_sum(e0 + e1);
-      if (n0 + row < p.N) {
-        const int64_t o = ((int64_t)b * p.N + n0 + row) * K + r;
-        p.assign[o] = e0 * inv;
-        p.assign[o + 32] = e1 * inv;
-        if (p.logit) {
-          p.logit[o] = s0;
-          p.logit[o + 32] = s1;
-        }
-      }
-    }
-  } else {
-    const float c0 = p.cdu[b * K + r], c1 = p.cdu[b * K + 32 + r];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int row = acc_row(q, h);
-      const bool ok = n0 + row < p.N;
-      const int64_t g = (int64_t)b * p.N + (ok ? n0 + row : 0);
-      const int64_t o = g * K + r;
-      const float rnr = p.rn_in[g];
-      const float a0 = ok ? p.a_in[o] : 0.f, a1 = ok ? p.a_in[o + 32] : 0.f;
-      const float l0 = ok ? p.logit_in[o] : 0.f, l1 = ok ? p.logit_in[o + 32] : 0.f;
-      const float t0 = acc0[q] * rnr, t1 = acc1[q] * rnr;   // xhat · dU
-      const float da0 = t0 + c0, da1 = t1 + c1;             // + c · dU
-      const float dot = half_sum(a0 * da0 + a1 * da1);
-      const float ds0 = a0 * (da0 - dot), ds1 = a1 * (da1 - dot);
-      // <d xhat[n,:], xhat[n,:]> = sum_k a (xhat·dU) + ds (xhat·W)
-      const float rd = half_sum(a0 * t0 + a1 * t1 + ds0 * l0 + ds1 * l1);
-      if (ok) {
-        p.ds[o] = ds0;
-        p.ds[o + 32] = ds1;
-        if (r == 0) p.rowdot[g] = rd;
-      }
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------------------
-// rowtile16_kernel: the same contraction on 16-location tiles with v_mfma_f32_16x16x4_f32.
+// rowtile16_kernel: [16 locations] x [512 channels] x [64 clusters] per wave on
+// v_mfma_f32_16x16x4_f32.
 //   * 1800 tiles at 24 x 1200 locations -> two resident workgroups per CU, so one wave's
-//     staging / softmax epilogue overlaps the other's MFMAs (the 32-row version has one
+//     staging / softmax epilogue can overlap another's MFMAs (a 32-location tile leaves one
 //     900-tile wave per SIMD and exposes both);
 //   * the [64][512] operand is staged in four 128-channel chunks, double-buffered: chunk
 //     c+1 is loaded to registers before chunk c is contracted and written to LDS after it,
@@ -704,67 +601,6 @@ __global__ __launch_bounds__(1024) void bwd_prep_kernel(const float* __restrict_
   }
 }
 
-// grad_x tile: dxhat[n, d] = sum_k a[n,k] dU[d,k] + ds[n,k] W[d,k]; then the Jacobian of
-// the channel L2 norm.  grid (ceil(N/32), B); block 256; wave w owns channels [128w, 128w+128).
-template <typename T>
-__global__ __launch_bounds__(256) void dx_kernel(const void* __restrict__ xv,
-                                                 const float* __restrict__ a,
-                                                 const float* __restrict__ ds,
-                                                 const float* __restrict__ rn,
-                                                 const float* __restrict__ rowdot,
-                                                 const float* __restrict__ du,
-                                                 const float* __restrict__ w, int N, int pre_l2,
-                                                 void* __restrict__ gxv) {
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int r = lane & 31, h = lane >> 5;
-  const int b = blockIdx.y, n0 = blockIdx.x * 32;
-  const int n = n0 + r;
-  const bool row_ok = n < N;
-  const int64_t grow = (int64_t)b * N + (row_ok ? n : 0);
-  const int dbase = wid * 128;
-  f32x16 acc[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) acc[j] = zero16();
-  const float* dub = du + (int64_t)b * D * K;
-#pragma unroll 1
-  for (int src = 0; src < 2; ++src) {
-    const float* arow = (src == 0 ? a : ds) + grow * K + 4 * h;
-    const float* bmat = (src == 0 ? dub : w) + (int64_t)(dbase + r) * K + 4 * h;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      f32x4 av = *reinterpret_cast<const f32x4*>(arow + 8 * t);
-      if (!row_ok) av = f32x4{0.f, 0.f, 0.f, 0.f};
-      f32x4 bv[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        bv[j] = *reinterpret_cast<const f32x4*>(bmat + (int64_t)j * 32 * K + 8 * t);
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = mfma32(av[c], bv[j][c], acc[j]);
-    }
-  }
-  const T* x = reinterpret_cast<const T*>(xv);
-  T* gx = reinterpret_cast<T*>(gxv);
-#pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const int row = n0 + acc_row(q, h);
-    if (row >= N) continue;
-    const int64_t g = (int64_t)b * N + row;
-    const float rnr = pre_l2 ? rn[g] : 1.0f;
-    const float rd = rowdot[g];
-    // x * rsqrt(max(ss, eps)): when the clamp is active the op is a plain scale
-    const bool proj = pre_l2 && rnr < 1.0e6f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t o = g * D + dbase + j * 32 + r;
-      float val = acc[j][q];
-      if (proj) val -= Elem<T>::ld(x + o) * rnr * rd;
-      Elem<T>::st(gx + o, val * rnr);
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------------------
 // dx16_kernel: grad_x on 16-location tiles (v_mfma_f32_16x16x4_f32), 2-3 workgroups per CU.
 //   dxhat[n, d] = sum_{k<64} a[n,k] dU[b][d,k] + ds[n,k] W[d,k]        (K = 128)
@@ -975,8 +811,6 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------------- host side
-constexpr size_t kRowTileLds = (size_t)K * WT_LD * sizeof(float);  // 132,096 B
-
 template <typename T, int VAR>
 void launch_variant_one(const RowTileArgs& a, dim3 grid, hipStream_t st) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowtile16_kernel<T, ASSIGN, VAR>),
@@ -1012,11 +846,6 @@ void launch_rowtile(const RowTileArgs& a, hipStream_t st) {
   }
   SCL_LAUNCH(MODE == ASSIGN ? "rowtile_assign" : "rowtile_dassign", (rowtile16_kernel<T, MODE>),
              grid, dim3(256), kRowTile16Lds, st, a);
-  return;
-  // previous 32-location-tile version, kept for A/B builds
-  const int tiles = (a.N + 31) / 32;
-  SCL_LAUNCH(MODE == ASSIGN ? "rowtile_assign" : "rowtile_dassign", (rowtile_kernel<T, MODE>), dim3((tiles + 3) / 4, a.B), dim3(256), kRowTileLds,
-                     st, a);
 }
 
 struct Carver {
