@@ -220,6 +220,14 @@ int scl_prof_begin(int capacity);
 int scl_prof_count(void);
 int scl_prof_end(float* ms, const char** names, int capacity);
 
+/* ------------------------------------------------------------------------- *
+ * Host utility for the checkpoint bundle reader / writer (tf_bundle.py; the reference
+ * restores and saves through tf.train.Saver, train/train.py:882-905, 984, 1079, 1102):
+ * CRC-32C (Castagnoli, reflected 0x82F63B78) of n bytes continued from `crc` (0 to start),
+ * unmasked.  Runs on the host; touches no device.
+ * ------------------------------------------------------------------------- */
+unsigned scl_crc32c(unsigned crc, const void* data, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

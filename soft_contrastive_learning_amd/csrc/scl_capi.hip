@@ -76,3 +76,41 @@ extern "C" int scl_prof_end(float* ms, const char** names, int capacity) {
   delete s;
   return n;
 }
+
+// ---- CRC-32C for checkpoint bundles (host only; slice-by-8 tables) ------------------------
+namespace {
+struct Crc32cTables {
+  unsigned t[8][256];
+  Crc32cTables() {
+    for (unsigned i = 0; i < 256; ++i) {
+      unsigned c = i;
+      for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+      t[0][i] = c;
+    }
+    for (unsigned i = 0; i < 256; ++i)
+      for (int s = 1; s < 8; ++s) t[s][i] = (t[s - 1][i] >> 8) ^ t[0][t[s - 1][i] & 0xffu];
+  }
+};
+}  // namespace
+
+extern "C" unsigned scl_crc32c(unsigned crc, const void* data, size_t n) {
+  static const Crc32cTables tab;
+  const unsigned char* p = static_cast<const unsigned char*>(data);
+  unsigned c = ~crc;
+  while (n && (reinterpret_cast<uintptr_t>(p) & 7u)) {
+    c = tab.t[0][(c ^ *p++) & 0xffu] ^ (c >> 8);
+    --n;
+  }
+  while (n >= 8) {
+    unsigned long long w;
+    __builtin_memcpy(&w, p, 8);
+    w ^= c;
+    c = tab.t[7][w & 0xff] ^ tab.t[6][(w >> 8) & 0xff] ^ tab.t[5][(w >> 16) & 0xff] ^
+        tab.t[4][(w >> 24) & 0xff] ^ tab.t[3][(w >> 32) & 0xff] ^ tab.t[2][(w >> 40) & 0xff] ^
+        tab.t[1][(w >> 48) & 0xff] ^ tab.t[0][(w >> 56) & 0xff];
+    p += 8;
+    n -= 8;
+  }
+  while (n--) c = tab.t[0][(c ^ *p++) & 0xffu] ^ (c >> 8);
+  return ~c;
+}

@@ -202,13 +202,14 @@ def main(argv=None):
                                   flags.negatives_per_tuple)
     cdt = torch.bfloat16 if flags.dtype == 'bf16' else torch.float32
     model = nets.set_default_model(nets.VGG16NetVLAD(compute_dtype=cdt).to(dev))
-    step = checkpoint.load(model, flags.checkpoint) if flags.checkpoint else 0
     params = list(model.parameters())
     buckets = parallel.GradBuckets(params, group)
     if flags.optimizer == 'momentum':
         opt = torch.optim.SGD(params, lr=flags.base_lr, momentum=flags.momentum)
     else:
         opt = torch.optim.Adam(params, lr=flags.base_lr)
+    # restore_weights (:882-905) + the slot variables a tf.train.Saver checkpoint carries
+    step = checkpoint.load(model, flags.checkpoint, optimizer=opt) if flags.checkpoint else 0
     out_dir = os.path.join(flags.out_root, flags.out_folder or flags.loss)
     saver = checkpoint.Saver(out_dir, flags.max_to_keep)
     data = SyntheticTuples(flags, tuple_shape, dev, rank, world)
@@ -236,11 +237,11 @@ def main(argv=None):
                 log.write(json.dumps(rec) + '\n')
                 log.flush()
                 if step % flags.eval_step == 0:
-                    saver.save_rolling(model, step)                # :1079
+                    saver.save_rolling(model, step, opt)              # :1079
                 if step % flags.save_step == 0:
-                    saver.save_part(model, step)                   # :1102
+                    saver.save_part(model, step, opt)                 # :1102
         if rank == 0:
-            saver.save_epoch(model, epoch, step)                   # :984
+            saver.save_epoch(model, epoch, step, opt)                 # :984
     if world > 1:
         dist.destroy_process_group()
 

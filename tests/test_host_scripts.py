@@ -76,7 +76,7 @@ def test_thin_reference_and_recall():
 
 def test_checkpoint_roundtrip_and_saver_cadence(tmp_path):
     a, b = nets.VGG16NetVLAD(seed=3), nets.VGG16NetVLAD(seed=4)
-    f = checkpoint.save(a, str(tmp_path / 'checkpoint-7'), global_step=7)
+    f = checkpoint.save(a, str(tmp_path / 'checkpoint-7'), global_step=7, fmt='npz')
     assert f.endswith('checkpoint-7.npz')
     with np.load(f) as z:
         assert z['vgg16_netvlad_pca/conv2_1/kernel'].shape == (3, 3, 64, 128)
@@ -84,13 +84,17 @@ def test_checkpoint_roundtrip_and_saver_cadence(tmp_path):
     assert checkpoint.load(b, str(tmp_path / 'checkpoint-7')) == 7
     for k, v in b.state_dict_tf().items():
         assert torch.equal(v, a.state_dict_tf()[k])
-    s = checkpoint.Saver(str(tmp_path / 'run'), max_to_keep=1)
-    s.save_rolling(a, 100)
-    s.save_rolling(a, 200)
-    s.save_epoch(a, 0, 200)
-    s.save_part(a, 500)
-    names = sorted(os.path.basename(p) for p in glob.glob(str(tmp_path / 'run' / '*.npz')))
-    assert names == ['checkpoint-200.npz', 'epoch-checkpoint-0.npz', 'part-checkpoint-500.npz']
+    for fmt, ext in (('npz', '.npz'), ('tf', '.index')):
+        run = tmp_path / ('run_' + fmt)
+        s = checkpoint.Saver(str(run), max_to_keep=1, fmt=fmt)
+        s.save_rolling(a, 100)
+        s.save_rolling(a, 200)
+        s.save_epoch(a, 0, 200)
+        s.save_part(a, 500)
+        names = sorted(os.path.basename(p) for p in glob.glob(str(run / ('*' + ext))))
+        assert names == ['checkpoint-200' + ext, 'epoch-checkpoint-0' + ext,
+                         'part-checkpoint-500' + ext]
+    assert not glob.glob(str(tmp_path / 'run_tf' / 'checkpoint-100*'))
 
 
 def test_compute_loss_rejects_losses_outside_the_hot_path():
