@@ -2,8 +2,9 @@
 
 ``get_top_n`` reproduces the body of the reference function (evaluation/top-n.py:65-119):
 PCA(whiten=True, n_components=d) fitted on a PCA set and applied to reference and query
-features (:74-77, CPU / scikit-learn like the reference: SURVEY §8f keeps the fit on the
-host), greedy thinning of the reference list by distance ``l`` (:91-94), exact L2 top-N of
+features (:74-77; ``pca_backend='device'`` = the exact float64 Gram eigen-solve of
+evaluation/pca.py on the GPU, ``'sklearn'`` = scikit-learn on the host like the reference),
+greedy thinning of the reference list by distance ``l`` (:91-94), exact L2 top-N of
 every query (:103-108) — here the fused HIP kernel instead of ``KDTree.query`` —
 geographic distances of the hits (:110), ground truth (:112-113), translation back to the
 original indices (:116-117) and the output list
@@ -13,6 +14,7 @@ import numpy as np
 import torch
 
 from . import retrieval
+from .pca import PCAWhitening
 
 
 def thin_reference(ref_xy, l):
@@ -24,27 +26,36 @@ def thin_reference(ref_xy, l):
     return ref_idx
 
 
+def whiten(pca_f, feature_sets, d, device='cuda', backend='device'):
+    """Fit on pca_f, transform every array of feature_sets -> float32 device tensors."""
+    if backend == 'device':
+        pca = PCAWhitening(d, device=device).fit(np.asarray(pca_f, dtype=np.float32))
+        return [pca.transform(np.asarray(f, dtype=np.float32)) for f in feature_sets]
+    if backend != 'sklearn':
+        raise ValueError("pca_backend must be 'device' or 'sklearn', got %r" % (backend,))
+    from sklearn.decomposition import PCA
+    pca = PCA(whiten=True, n_components=d).fit(np.asarray(pca_f))
+    return [torch.from_numpy(pca.transform(np.asarray(f)).astype(np.float32)).to(device)
+            for f in feature_sets]
+
+
 def get_top_n(pca_f, full_ref_f, full_query_f, full_ref_xy, full_query_xy, n=25, d=256, l=0.0,
-              device='cuda'):
+              device='cuda', pca_backend='device'):
     """Arrays in, the reference's pickle payload out (None when fewer than n references
     survive the thinning, like the reference's ``continue`` at :96-97)."""
-    from sklearn.decomposition import PCA
     from sklearn.metrics import pairwise_distances
     full_xy_dists = pairwise_distances(full_query_xy, full_ref_xy, metric='euclidean')
-    pca = PCA(whiten=True, n_components=d).fit(np.asarray(pca_f))
-    pca_ref_f = pca.transform(np.asarray(full_ref_f))
-    pca_query_f = pca.transform(np.asarray(full_query_f))
+    pca_ref_f, pca_query_f = whiten(pca_f, [full_ref_f, full_query_f], d, device, pca_backend)
 
     ref_idx = thin_reference(np.asarray(full_ref_xy), l)
     if len(ref_idx) < n:
         return None
-    ref_f = pca_ref_f[ref_idx].astype(np.float32)
+    ref_f = pca_ref_f[torch.as_tensor(ref_idx, device=pca_ref_f.device)].contiguous()
     xy_dists = full_xy_dists[:, ref_idx]
     num_q = pca_query_f.shape[0]
 
     # any d: the retrieval layer pads to the kernel's widths or takes its wide-descriptor path
-    dist, idx = retrieval.topn_l2(torch.from_numpy(ref_f).to(device),
-                                  torch.from_numpy(pca_query_f.astype(np.float32)).to(device), n)
+    dist, idx = retrieval.topn_l2(ref_f, pca_query_f, n)
     top_f_dists = dist.cpu().numpy()
     top_i = idx.cpu().numpy().astype(int)
     top_g_dists = [[xy_dists[q, r] for r in top_i[q, :]] for q in range(num_q)]

@@ -128,7 +128,8 @@ def test_top_n_harness_matches_the_reference_pipeline(dev):
     qry_f = rng.standard_normal((40, 96)).astype(np.float32)
     ref_xy = np.cumsum(rng.uniform(0.2, 1.5, size=(300, 2)), axis=0)
     qry_xy = rng.uniform(0, 250, size=(40, 2))
-    got = top_n.get_top_n(pca_f, ref_f, qry_f, ref_xy, qry_xy, n=25, d=64, l=1.0)
+    got = top_n.get_top_n(pca_f, ref_f, qry_f, ref_xy, qry_xy, n=25, d=64, l=1.0,
+                          pca_backend='sklearn')
     top_i, top_g, top_f, gt_i, gt_g, ref_idx = got
     # the reference's pipeline with its own calls (evaluation/top-n.py:74-117)
     pca = PCA(whiten=True, n_components=64).fit(pca_f)
@@ -144,3 +145,29 @@ def test_top_n_harness_matches_the_reference_pipeline(dev):
     np.testing.assert_array_equal(gt_i, np.asarray(want_idx)[xy.argmin(axis=1)])
     np.testing.assert_allclose(gt_g, xy.min(axis=1))
     assert top_n.get_top_n(pca_f, ref_f[:10], qry_f, ref_xy[:10], qry_xy, n=25, d=64) is None
+    # device PCA (float64 Gram eigen-solve): same neighbours, distances to solver tolerance
+    dev_out = top_n.get_top_n(pca_f, ref_f, qry_f, ref_xy, qry_xy, n=25, d=64, l=1.0)
+    same = np.mean(np.asarray(dev_out[0]) == np.asarray(top_i))
+    assert same > 0.99, same
+    np.testing.assert_allclose(dev_out[2], top_f, rtol=2e-4)
+
+
+def test_device_pca_whitening_matches_sklearn_full_solver(dev):
+    from sklearn.decomposition import PCA
+    from soft_contrastive_learning_amd.evaluation.pca import PCAWhitening
+    rng = np.random.default_rng(7)
+    # n << E like the 32768-d descriptors, with a decaying spectrum
+    basis = rng.standard_normal((120, 2048)).astype(np.float32)
+    x = (rng.standard_normal((500, 120)) * np.linspace(3.0, 0.2, 120)).astype(np.float32) @ basis
+    x += 5.0
+    y = (rng.standard_normal((64, 120)) * np.linspace(3.0, 0.2, 120)).astype(np.float32) @ basis
+    y += 5.0
+    want = PCA(whiten=True, n_components=48, svd_solver='full').fit(x)
+    pca = PCAWhitening(48, device=dev).fit(x)
+    np.testing.assert_allclose(pca.explained_variance_.cpu().numpy(), want.explained_variance_,
+                               rtol=1e-4)
+    got = pca.transform(y).cpu().numpy()
+    ref = want.transform(y)
+    sign = np.sign(np.sum(got * ref, axis=0))           # sklearn versions differ in svd_flip
+    np.testing.assert_allclose(got * sign, ref, rtol=0, atol=2e-3 * np.abs(ref).max())
+    assert abs(np.var(pca.transform(x).cpu().numpy(), axis=0, ddof=1) - 1.0).max() < 1e-3

@@ -74,6 +74,30 @@ def test_thin_reference_and_recall():
     assert top_n.recall_at(g, [2.0, 10.0], n=2).tolist() == [0.5, 1.0]
 
 
+def test_pca_whitening_on_the_host_matches_sklearn():
+    # the device PCA is torch plumbing, so its algebra can be checked without a GPU
+    from sklearn.decomposition import PCA
+    from soft_contrastive_learning_amd.evaluation.pca import PCAWhitening
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal((90, 30)) * np.linspace(2.0, 0.3, 30)).astype(np.float32) \
+        @ rng.standard_normal((30, 300)).astype(np.float32) + 1.5
+    for d, data in ((12, x), (10, x[:, :40])):                # n < E and n > E code paths
+        want = PCA(whiten=True, n_components=d, svd_solver='full').fit(data)
+        pca = PCAWhitening(d, device='cpu', chunk=64).fit(data)
+        np.testing.assert_allclose(pca.explained_variance_.numpy(), want.explained_variance_,
+                                   rtol=1e-4)
+        got, ref = pca.transform(data[:17]).numpy(), want.transform(data[:17])
+        sign = np.sign(np.sum(got * ref, axis=0))
+        np.testing.assert_allclose(got * sign, ref, atol=2e-3)
+        # every component's largest-magnitude entry is positive (svd_flip, v-based)
+        c = pca.components_.numpy()
+        assert (c[np.arange(d), np.abs(c).argmax(axis=1)] > 0).all()
+    with pytest.raises(ValueError):
+        PCAWhitening(91, device='cpu').fit(x)
+    with pytest.raises(RuntimeError):
+        PCAWhitening(4, device='cpu').transform(x)
+
+
 def test_checkpoint_roundtrip_and_saver_cadence(tmp_path):
     a, b = nets.VGG16NetVLAD(seed=3), nets.VGG16NetVLAD(seed=4)
     f = checkpoint.save(a, str(tmp_path / 'checkpoint-7'), global_step=7, fmt='npz')
