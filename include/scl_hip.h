@@ -152,6 +152,21 @@ int scl_tuple_loss_fwd(int kind, const float* q, int64_t q_tstride, const float*
                        const float* other, int64_t other_tstride, int T, int P, int N, int E,
                        float m1, float m2, float* loss_out, float* sqd, float* coef,
                        void* stream);
+/* distance_triplet_loss / distance_quadruplet_loss (model/losses.py:239-307; trainer losses
+ * [huber_]distance_[lazy_]{triplet,quadruplet}, train/train.py:719-763):
+ *   kind  SCL_TUPLE_TRIPLET or SCL_TUPLE_LAZY_TRIPLET  (triplet_loss_name)
+ *   quad  0: loss = triplet(m1) + lam * dist_term
+ *         1: ... + mean_t max_n max(m2 + min_p term_p - |neg_n - other|^2 / f_max, 0)
+ *   huber 1: tf.losses.huber_loss (delta 1) on the scaled distances, 0: squared difference
+ *   sq_d_dists [T,P]: squared geographic anchor-positive distances (ops['distances'])
+ * sqd / coef as in scl_tuple_loss_fwd; the backward is scl_tuple_loss_bwd. */
+int scl_distance_tuple_loss_fwd(int kind, int quad, int huber, const float* q, int64_t q_tstride,
+                                const float* pos, int64_t pos_tstride, const float* neg,
+                                int64_t neg_tstride, const float* other, int64_t other_tstride,
+                                int T, int P, int N, int E, float m1, float m2, float lam,
+                                const float* sq_d_dists, float d_max_squared,
+                                float f_max_squared, float* loss_out, float* sqd, float* coef,
+                                void* stream);
 /* grads are written with the same strides as their inputs; grad_other may be NULL. */
 int scl_tuple_loss_bwd(const float* q, int64_t q_tstride, const float* pos, int64_t pos_tstride,
                        const float* neg, int64_t neg_tstride, const float* other,

@@ -198,6 +198,65 @@ def evil_quadruplet_loss(q_vec, pos_vecs, neg_vecs, other_neg, m1, m2):
     return F32(first + F32(np.mean(np.sum(h2, axis=1, dtype=F32), dtype=F32)))
 
 
+# ---- distance-term losses (model/losses.py:225-307, 664-690) ----
+
+def _scale_distances(a_feature, pos_feature, squared_d_dists, d_max_squared, f_max_squared):
+    """model/losses.py:678-690: both squared distances divided by their maxima, [T,P]."""
+    sf = _sq_dists_to(a_feature, pos_feature)
+    sd = _f32(squared_d_dists).reshape(sf.shape)
+    return (sd / F32(d_max_squared)).astype(F32), (sf / F32(f_max_squared)).astype(F32)
+
+
+def _huber(labels, predictions, delta=1.0):
+    """tf.losses.huber_loss element-wise part (TF 1.10 losses_impl.py)."""
+    err = (predictions - labels).astype(F32)
+    a = np.abs(err)
+    quad = np.minimum(a, F32(delta))
+    lin = a - quad
+    return (F32(0.5) * quad * quad + F32(delta) * lin).astype(F32)
+
+
+def distance_loss(a_feature, pos_feature, squared_d_dists, d_max_squared, f_max_squared):
+    """model/losses.py:225-230."""
+    sd, sf = _scale_distances(a_feature, pos_feature, squared_d_dists, d_max_squared, f_max_squared)
+    return F32(np.mean(np.mean((sf - sd) ** 2, axis=1, dtype=F32), dtype=F32))
+
+
+def huber_distance_loss(a_feature, pos_feature, squared_d_dists, d_max_squared, f_max_squared):
+    """model/losses.py:233-236: tf.losses.huber_loss(labels=scaled_d, predictions=scaled_f),
+    delta 1, SUM_BY_NONZERO_WEIGHTS = mean over all elements."""
+    sd, sf = _scale_distances(a_feature, pos_feature, squared_d_dists, d_max_squared, f_max_squared)
+    return F32(np.mean(_huber(sd, sf), dtype=F32))
+
+
+def distance_triplet_loss(a_feature, pos_features, neg_features, margin, lam, squared_d_dists,
+                          d_max_squared, f_max_squared, triplet_loss_name='triplet_loss',
+                          distance_loss_name='huber_distance_loss'):
+    """model/losses.py:239-264."""
+    trip = {'triplet_loss': triplet_loss, 'lazy_triplet_loss': lazy_triplet_loss}[triplet_loss_name]
+    dist = huber_distance_loss if 'huber' in distance_loss_name else distance_loss
+    return F32(trip(a_feature, pos_features, neg_features, margin) +
+               F32(lam) * dist(a_feature, pos_features, squared_d_dists, d_max_squared,
+                               f_max_squared))
+
+
+def distance_quadruplet_loss(a_feature, pos_features, neg_features, other_neg, m1, m2, lam,
+                             squared_d_dists, d_max_squared, f_max_squared,
+                             triplet_loss_name='triplet_loss',
+                             distance_loss_name='huber_distance_loss'):
+    """model/losses.py:267-307: the second term always takes the max over negatives."""
+    trip = distance_triplet_loss(a_feature, pos_features, neg_features, m1, lam, squared_d_dists,
+                                 d_max_squared, f_max_squared, triplet_loss_name,
+                                 distance_loss_name)
+    sd, sf = _scale_distances(a_feature, pos_features, squared_d_dists, d_max_squared,
+                              f_max_squared)
+    per_pos = _huber(sf, sd) if 'huber' in distance_loss_name else ((sf - sd) ** 2).astype(F32)
+    best_pos = np.min(per_pos, axis=1).reshape(-1, 1)                     # :664-675
+    on = (_sq_dists_to(other_neg, neg_features) / F32(f_max_squared)).astype(F32)
+    second = np.mean(np.max(np.maximum(F32(m2) + (best_pos - on), F32(0.0)), axis=1), dtype=F32)
+    return F32(trip + second)
+
+
 def pairwise_squared_distances(features):
     """model/losses.py:656-661: [T,S,E] -> [T,S,S] = r_i - 2 F F^T + r_j."""
     f = _f32(features)

@@ -147,6 +147,30 @@ def evil_quadruplet_loss(q, pos, neg, other, m1, m2, dtype=torch.float64):
     return _tuple_loss(q, pos, neg, other, m1, m2, 'max', 'sum', dtype)
 
 
+def _huber_t(labels, predictions, delta=1.0):
+    err = predictions - labels
+    a = err.abs()
+    quad = torch.minimum(a, torch.full_like(a, delta))
+    return 0.5 * quad * quad + delta * (a - quad)
+
+
+def distance_tuple_loss(q, pos, neg, other, m1, m2, lam, squared_d_dists, d_max_squared,
+                        f_max_squared, lazy=False, huber=True, dtype=torch.float64):
+    """distance_triplet_loss (other=None) / distance_quadruplet_loss, model/losses.py:239-307."""
+    q, pos, neg = _t(q, dtype), _t(pos, dtype), _t(neg, dtype)
+    sf = _sq_dists_to(q, pos) / f_max_squared
+    sd = _t(squared_d_dists, dtype).reshape(sf.shape) / d_max_squared
+    loss = _tuple_loss(q, pos, neg, None, m1, None, 'min', 'max' if lazy else 'sum', dtype)
+    term = _huber_t(sd, sf) if huber else (sf - sd) ** 2
+    loss = loss + lam * term.mean()
+    if other is not None:
+        per_pos = _huber_t(sf, sd) if huber else (sf - sd) ** 2
+        best = per_pos.amin(dim=1).reshape(-1, 1)
+        on = _sq_dists_to(_t(other, dtype), neg) / f_max_squared
+        loss = loss + _relu_tf(m2 + (best - on)).amax(dim=1).mean()
+    return loss
+
+
 def netvlad(x, assign_w, centers, pre_l2=True, dtype=torch.float64):
     """x [B,N,D], assign_w [D,K], centers [D,K] -> [B, D*K] (see oracle.netvlad_np)."""
     x, w, c = _t(x, dtype), _t(assign_w, dtype), _t(centers, dtype)

@@ -45,6 +45,8 @@ SIGNATURES = {
                                 _p, _p]),
     "scl_tuple_loss_bwd": (_i, [_p, _l, _p, _l, _p, _l, _p, _l, _i, _i, _i, _i, _p, _p, _p, _p, _p,
                                 _p, _p]),
+    "scl_distance_tuple_loss_fwd": (_i, [_i, _i, _i, _p, _l, _p, _l, _p, _l, _p, _l, _i, _i, _i, _i,
+                                         _f, _f, _f, _p, _f, _f, _p, _p, _p, _p]),
     "scl_logratio_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
     "scl_topn_l2_workspace_bytes": (_z, [_i, _i, _i, _i]),
     "scl_topn_l2": (_i, [_p, _i, _p, _i, _i, _i, _l, _p, _p, _p, _z, _p]),

@@ -12,6 +12,7 @@
 //   2. tuple_finish_kernel   hinges, min/max over positives, sum/max over negatives,
 //                            loss and d loss / d sqd (TF tie conventions)
 //      logratio_finish_kernel  the log-ratio variant
+//      distance_term_kernel    the (Huber) distance term of distance_{triplet,quadruplet}_loss
 //   3. tuple_bwd_kernel      one pass writing grad_q / grad_pos / grad_neg / grad_other
 // Fixed-order reductions only: bitwise reproducible.
 #include "scl_common.h"
@@ -123,6 +124,80 @@ __global__ __launch_bounds__(256) void tuple_finish_kernel(int kind, int T, int 
   if (threadIdx.x == 0) *loss_out = total * invT;
 }
 
+// Distance-term add-on of distance_triplet_loss / distance_quadruplet_loss
+// (model/losses.py:225-307, 664-690).  Runs after tuple_finish_kernel of the plain (lazy)
+// triplet: adds lam * mean_{t,p} term(sf, sd) with sf = sqd_pos / f_max, sd = d_dists / d_max
+// (term = squared difference, or Huber with delta 1) and, for the quadruplet form,
+// mean_t max_n max(m2 + min_p term - sqd_other_neg / f_max, 0), to the loss and their
+// derivatives to coef.  One thread per tuple, one workgroup.
+__global__ __launch_bounds__(256) void distance_term_kernel(int huber, int quad, int T, int P,
+                                                            int N, float m2, float lam,
+                                                            float d_max, float f_max,
+                                                            const float* __restrict__ d_dists,
+                                                            const float* __restrict__ sqd,
+                                                            float* __restrict__ coef,
+                                                            float* __restrict__ loss_inout) {
+  __shared__ float scratch[32];
+  const int width = P + 2 * N;
+  const float invT = 1.0f / (float)T, invTP = 1.0f / ((float)T * (float)P);
+  float total = 0.f;
+  for (int t = threadIdx.x; t < T; t += 256) {
+    const float* s = sqd + (int64_t)t * width;
+    float* c = coef + (int64_t)t * width;
+    float tsum = 0.f, best = INFINITY;
+    for (int p = 0; p < P; ++p) {
+      const float err = s[p] / f_max - d_dists[(int64_t)t * P + p] / d_max;
+      float v, dv;
+      if (huber) {
+        const float a = fabsf(err), qd = fminf(a, 1.0f);
+        v = 0.5f * qd * qd + (a - qd);
+        dv = fminf(fmaxf(err, -1.0f), 1.0f);
+      } else {
+        v = err * err;
+        dv = 2.0f * err;
+      }
+      tsum += v;
+      best = fminf(best, v);
+      c[p] += lam * dv * invTP / f_max;
+    }
+    float second = 0.f;
+    if (quad) {
+      const float* on = s + P + N;
+      float* con = c + P + N;
+      float hmax = -INFINITY;
+      for (int n = 0; n < N; ++n) hmax = fmaxf(hmax, fmaxf(m2 + (best - on[n] / f_max), 0.f));
+      int hties = 0;
+      for (int n = 0; n < N; ++n) hties += fmaxf(m2 + (best - on[n] / f_max), 0.f) == hmax;
+      float cbest = 0.f;
+      for (int n = 0; n < N; ++n) {
+        const float x = m2 + (best - on[n] / f_max);
+        float w = fmaxf(x, 0.f) == hmax ? 1.0f / (float)hties : 0.f;
+        w = x >= 0.f ? w : 0.f;
+        con[n] += -w * invT / f_max;
+        cbest += w;
+      }
+      // reduce_min over positives: gradient split evenly over ties
+      int ties = 0;
+      for (int p = 0; p < P; ++p) {
+        const float err = s[p] / f_max - d_dists[(int64_t)t * P + p] / d_max;
+        const float a = fabsf(err), qd = fminf(a, 1.0f);
+        ties += (huber ? 0.5f * qd * qd + (a - qd) : err * err) == best;
+      }
+      for (int p = 0; p < P; ++p) {
+        const float err = s[p] / f_max - d_dists[(int64_t)t * P + p] / d_max;
+        const float a = fabsf(err), qd = fminf(a, 1.0f);
+        const float v = huber ? 0.5f * qd * qd + (a - qd) : err * err;
+        const float dv = huber ? fminf(fmaxf(err, -1.0f), 1.0f) : 2.0f * err;
+        if (v == best) c[p] += cbest * invT * dv / ((float)ties * f_max);
+      }
+      second = hmax;
+    }
+    total += lam * tsum * invTP + second * invT;
+  }
+  total = block_reduce<0>(total, scratch);
+  if (threadIdx.x == 0) *loss_inout += total;
+}
+
 // logratio_loss, T == 1, P == N.  Single workgroup.
 //   loss = mean_{i<N, j<P} (log(pr_j / nr_i) - log(spd_i / snd_i))^2
 __global__ __launch_bounds__(256) void logratio_finish_kernel(int P, int N,
@@ -224,6 +299,35 @@ extern "C" int scl_tuple_loss_fwd(int kind, const float* q, int64_t q_tstride, c
                      E, vec, sqd);
   SCL_LAUNCH("tuple_finish_kernel", tuple_finish_kernel, dim3(1), dim3(256), 0, st, kind, T, P, N, m1, m2,
                      (const float*)sqd, coef, loss_out);
+  return scl_launch_status();
+}
+
+extern "C" int scl_distance_tuple_loss_fwd(int kind, int quad, int huber, const float* q,
+                                           int64_t q_tstride, const float* pos,
+                                           int64_t pos_tstride, const float* neg,
+                                           int64_t neg_tstride, const float* other,
+                                           int64_t other_tstride, int T, int P, int N, int E,
+                                           float m1, float m2, float lam,
+                                           const float* sq_d_dists, float d_max_squared,
+                                           float f_max_squared, float* loss_out, float* sqd,
+                                           float* coef, void* stream) {
+  if (kind != SCL_TUPLE_TRIPLET && kind != SCL_TUPLE_LAZY_TRIPLET) return SCL_E_KIND;
+  if (!q || !pos || !neg || !sq_d_dists || !loss_out || !sqd || !coef || (quad && !other))
+    return SCL_E_NULL;
+  if (T < 1 || P < 1 || N < 1 || E < 1 || T > 65535) return SCL_E_SHAPE;
+  if (!(d_max_squared > 0.f) || !(f_max_squared > 0.f)) return SCL_E_SHAPE;
+  TupleView v{q, pos, neg, quad ? other : nullptr, q_tstride, pos_tstride, neg_tstride,
+              other_tstride};
+  const int vec = vec4_ok(q, q_tstride, E) && vec4_ok(pos, pos_tstride, E) &&
+                  vec4_ok(neg, neg_tstride, E) && vec4_ok(v.other, other_tstride, E);
+  hipStream_t st = (hipStream_t)stream;
+  SCL_LAUNCH("tuple_sqd_kernel", tuple_sqd_kernel, dim3(P + N + (quad ? N : 0), T), dim3(256), 0,
+             st, v, P, N, E, vec, sqd);
+  SCL_LAUNCH("tuple_finish_kernel", tuple_finish_kernel, dim3(1), dim3(256), 0, st, kind, T, P, N,
+             m1, 0.0f, (const float*)sqd, coef, loss_out);
+  SCL_LAUNCH("distance_term_kernel", distance_term_kernel, dim3(1), dim3(256), 0, st, huber ? 1 : 0,
+             quad ? 1 : 0, T, P, N, m2, lam, d_max_squared, f_max_squared, sq_d_dists,
+             (const float*)sqd, coef, loss_out);
   return scl_launch_status();
 }
 

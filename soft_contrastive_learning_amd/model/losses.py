@@ -11,6 +11,8 @@ and backward are the hand-written gfx950 kernels behind ``include/scl_hip.h``.
   evil_triplet_loss      model/losses.py:63-73
   evil_quadruplet_loss   model/losses.py:197-214
   worst_pos_distance     model/losses.py:217-222
+  distance_loss / huber_distance_loss         model/losses.py:225-236
+  distance_triplet_loss / distance_quadruplet_loss   model/losses.py:239-307
   _pairwise_squared_distances  model/losses.py:656-661
 The pointnetvlad_cls losses the trainer imports beside them (train/train.py:25)
 live in ``soft_contrastive_learning_amd.pointnetvlad_cls``.
@@ -20,7 +22,9 @@ import torch
 from .. import _lib as L
 
 __all__ = ['wms_loss', 'ms_loss', 'ms_det', 'logratio_loss', 'evil_triplet_loss',
-           'evil_quadruplet_loss', 'worst_pos_distance', '_pairwise_squared_distances']
+           'evil_quadruplet_loss', 'worst_pos_distance', '_pairwise_squared_distances',
+           'distance_loss', 'huber_distance_loss', 'distance_triplet_loss',
+           'distance_quadruplet_loss']
 
 
 def _as_f32(t):
@@ -214,6 +218,101 @@ def _tuple(kind, q, pos, neg, other, m1, m2):
     # gradient buffers (empty_strided) are compact
     return _TupleLoss.apply(q.contiguous(), pos.contiguous(), neg.contiguous(),
                             None if other is None else other.contiguous(), kind, m1, m2)
+
+
+class _DistanceTupleLoss(torch.autograd.Function):
+    """(lazy) triplet + lam * distance term (+ the quadruplet second term); the backward is
+    the tuple backward kernel on the summed d loss / d sqd coefficients."""
+
+    @staticmethod
+    def forward(ctx, q, pos, neg, other, d_dists, kind, huber, m1, m2, lam, d_max, f_max):
+        lib = L.load()
+        L.require_device(q, pos, neg, other, d_dists)
+        q, q_ts = _rows_view(q, 'a_feature')
+        pos, p_ts = _rows_view(pos, 'pos_features')
+        neg, n_ts = _rows_view(neg, 'neg_features')
+        o_ts = 0
+        if other is not None:
+            other, o_ts = _rows_view(other, 'other_neg')
+        t, p, e = pos.shape
+        n = neg.shape[1]
+        if q.shape != (t, 1, e) or neg.shape[0] != t or neg.shape[2] != e or (
+                other is not None and other.shape != (t, 1, e)):
+            raise ValueError("inconsistent tuple shapes a%s pos%s neg%s" % (
+                tuple(q.shape), tuple(pos.shape), tuple(neg.shape)))
+        dd = _as_f32(d_dists).reshape(-1).contiguous()
+        if dd.numel() != t * p:
+            raise ValueError("squared_d_dists must hold T*P = %d values, got %d"
+                             % (t * p, dd.numel()))
+        width = p + 2 * n
+        loss = torch.empty((), dtype=torch.float32, device=q.device)
+        sqd = torch.empty((t, width), dtype=torch.float32, device=q.device)
+        coef = torch.empty((t, width), dtype=torch.float32, device=q.device)
+        L.check(lib.scl_distance_tuple_loss_fwd(
+            kind, 0 if other is None else 1, 1 if huber else 0, L.ptr(q), q_ts, L.ptr(pos), p_ts,
+            L.ptr(neg), n_ts, L.ptr(other), o_ts, t, p, n, e, float(m1), float(m2), float(lam),
+            L.ptr(dd), float(d_max), float(f_max), L.ptr(loss), L.ptr(sqd), L.ptr(coef),
+            L.stream_of(q)))
+        ctx.save_for_backward(q, pos, neg, other, coef)
+        ctx.strides = (q_ts, p_ts, n_ts, o_ts)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        return _TupleLoss.backward(ctx, grad_loss)[:4] + (None,) * 8
+
+
+_TRIPLET_KINDS = {'triplet_loss': L.TUPLE_TRIPLET, 'lazy_triplet_loss': L.TUPLE_LAZY_TRIPLET}
+
+
+def _distance_tuple(a, pos, neg, other, m1, m2, lam, d_dists, d_max, f_max, triplet_loss_name,
+                    distance_loss_name):
+    if triplet_loss_name not in _TRIPLET_KINDS:
+        # the reference resolves the name with getattr(pointnetvlad_cls, ...)
+        raise AttributeError("pointnetvlad_cls has no loss %r" % (triplet_loss_name,))
+    return _DistanceTupleLoss.apply(
+        a.contiguous(), pos.contiguous(), neg.contiguous(),
+        None if other is None else other.contiguous(), d_dists,
+        _TRIPLET_KINDS[triplet_loss_name], 'huber' in distance_loss_name, m1, m2, lam, d_max, f_max)
+
+
+def distance_triplet_loss(a_feature, pos_features, neg_features, margin, lam, squared_d_dists,
+                          d_max_squared, f_max_squared, triplet_loss_name='triplet_loss',
+                          distance_loss_name='huber_distance_loss'):
+    """model/losses.py:239-264: triplet + lam * (Huber) distance loss."""
+    return _distance_tuple(a_feature, pos_features, neg_features, None, margin, 0.0, lam,
+                           squared_d_dists, d_max_squared, f_max_squared, triplet_loss_name,
+                           distance_loss_name)
+
+
+def distance_quadruplet_loss(a_feature, pos_features, neg_features, other_neg, m1, m2, lam,
+                             squared_d_dists, d_max_squared, f_max_squared,
+                             triplet_loss_name='triplet_loss',
+                             distance_loss_name='huber_distance_loss'):
+    """model/losses.py:267-307."""
+    return _distance_tuple(a_feature, pos_features, neg_features, other_neg, m1, m2, lam,
+                           squared_d_dists, d_max_squared, f_max_squared, triplet_loss_name,
+                           distance_loss_name)
+
+
+def _distance_only(a_feature, pos_feature, squared_d_dists, d_max_squared, f_max_squared, huber):
+    # the distance term alone: lam = 1 and a triplet whose hinge can never be active
+    # (margin -inf would poison the sum; use the positives as negatives with margin -1e30)
+    return _distance_tuple(a_feature, pos_feature, pos_feature, None, -1.0e30, 0.0, 1.0,
+                           squared_d_dists, d_max_squared, f_max_squared, 'triplet_loss',
+                           'huber_distance_loss' if huber else 'distance_loss')
+
+
+def distance_loss(a_feature, pos_feature, squared_d_dists, d_max_squared, f_max_squared):
+    """model/losses.py:225-230."""
+    return _distance_only(a_feature, pos_feature, squared_d_dists, d_max_squared, f_max_squared,
+                          False)
+
+
+def huber_distance_loss(a_feature, pos_feature, squared_d_dists, d_max_squared, f_max_squared):
+    """model/losses.py:233-236."""
+    return _distance_only(a_feature, pos_feature, squared_d_dists, d_max_squared, f_max_squared,
+                          True)
 
 
 def evil_triplet_loss(q_vec, pos_vecs, neg_vecs, margin):

@@ -45,6 +45,7 @@ def make_parser():
     p.add_argument('--wfunction', default='exp', help='exp, lin, tanh')
     p.add_argument('--sumfunction', default='ms', help='ms, plain')
     p.add_argument('--msmining', type=bool, default=False)   # type=bool as in the reference
+    p.add_argument('--lam', type=float, default=0.5, help='Scaling factor between loss components.')
     p.add_argument('--max_pos_radius', type=float, default=15)
     p.add_argument('--min_neg_radius', type=float, default=15)
     # training (:1269-1281)
@@ -102,7 +103,11 @@ def get_learning_rate(epoch, flags):
 
 
 SUPPORTED_LOSSES = ('triplet', 'lazy_triplet', 'evil_triplet', 'quadruplet', 'lazy_quadruplet',
-                    'evil_quadruplet', 'ms_loss', 'wms', 'logratio')
+                    'evil_quadruplet', 'ms_loss', 'wms', 'logratio',
+                    'distance_triplet', 'distance_lazy_triplet', 'distance_quadruplet',
+                    'distance_lazy_quadruplet', 'huber_distance_triplet',
+                    'huber_distance_lazy_triplet', 'huber_distance_quadruplet',
+                    'huber_distance_lazy_quadruplet')
 
 
 def compute_loss(flags, tuple_shape, output, distances, local_rows=None, group=None):
@@ -131,6 +136,18 @@ def compute_loss(flags, tuple_shape, output, distances, local_rows=None, group=N
     if loss == 'evil_quadruplet':
         return losses.evil_quadruplet_loss(outs[0], outs[1], outs[2], outs[3], flags.margin_1,
                                            flags.margin_2)
+    if loss in SUPPORTED_LOSSES and 'distance' in loss:                        # :719-763
+        d_max_squared = float(flags.max_pos_radius) ** 2                       # :695
+        f_max_squared = 2.0                                                    # :696
+        trip = 'lazy_triplet_loss' if 'lazy' in loss else 'triplet_loss'
+        dist = 'huber_distance_loss' if 'huber' in loss else 'distance_loss'
+        if 'quadruplet' in loss:
+            return losses.distance_quadruplet_loss(outs[0], outs[1], outs[2], outs[3],
+                                                   flags.margin_1, flags.margin_2, flags.lam,
+                                                   distances, d_max_squared, f_max_squared, trip,
+                                                   dist)
+        return losses.distance_triplet_loss(outs[0], outs[1], outs[2], flags.margin_1, flags.lam,
+                                            distances, d_max_squared, f_max_squared, trip, dist)
     if loss == 'ms_loss':
         return losses.ms_loss(distances, output, ms_mining=flags.msmining)     # :821-827
     if loss == 'wms':
@@ -164,6 +181,10 @@ class SyntheticTuples:
         if dtype == 'wms':
             # sklearn pairwise_distances(all, all, 'euclidean') (:557-563), rank-3 [T,S,S]
             d = np.sqrt(((xy[:, None] - xy[None]) ** 2).sum(2)).astype(np.float32)[None]
+        elif dtype == 'anchor':
+            # squared metres anchor -> positives inside max_pos_radius (:529-533), [T,P]
+            d = self.rng.uniform(0.0, f.max_pos_radius ** 2,
+                                 (t, f.positives_per_tuple)).astype(np.float32)
         elif dtype == 'logratio':
             p, n = f.positives_per_tuple, f.negatives_per_tuple      # squared metres (:569-571)
             d = np.concatenate([self.rng.uniform(1, 15 ** 2, (t, p)),

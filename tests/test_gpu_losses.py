@@ -199,6 +199,78 @@ def test_tuple_losses_and_grads(dev, name, quad, t, p, n, e):
     assert _rel(xt.grad.cpu().numpy(), x64.grad.numpy()) < GRAD_REL
 
 
+@pytest.mark.parametrize('huber', [True, False])
+@pytest.mark.parametrize('lazy', [False, True])
+@pytest.mark.parametrize('quad,t,p,n,e', [(False, 1, 12, 12, 32768), (True, 1, 12, 11, 32768),
+                                          (False, 3, 4, 5, 300), (True, 4, 2, 6, 257)])
+def test_distance_tuple_losses_and_grads(dev, huber, lazy, quad, t, p, n, e):
+    """[huber_]distance_[lazy_]{triplet,quadruplet} (model/losses.py:239-307)."""
+    from soft_contrastive_learning_amd.model import losses as M
+    shape = [1, p, n] + ([1] if quad else [])
+    out = U.tuple_batch(t, p, n, e, quad=quad, seed=50 + p)
+    rng = np.random.default_rng(51 + t)
+    # scaled geographic distances straddle the scaled feature distances so that both Huber
+    # branches and both signs occur
+    dd = rng.uniform(0.0, 15.0 ** 2, (t, p)).astype(np.float32)
+    dmax, fmax, lam, m1, m2 = 15.0 ** 2, 2.0, 0.5, 0.5, 0.2
+    if not huber:
+        fmax = 0.05                      # |err| > 1 somewhere: the squared term keeps growing
+    flat = out.reshape(t * sum(shape), e)
+    parts = O.split_tuples(flat, t, shape)
+    tl = 'lazy_triplet_loss' if lazy else 'triplet_loss'
+    dl = 'huber_distance_loss' if huber else 'distance_loss'
+    if quad:
+        want = O.distance_quadruplet_loss(parts[0], parts[1], parts[2], parts[3], m1, m2, lam, dd,
+                                          dmax, fmax, tl, dl)
+    else:
+        want = O.distance_triplet_loss(parts[0], parts[1], parts[2], m1, lam, dd, dmax, fmax, tl, dl)
+    x64 = torch.tensor(flat, dtype=torch.float64, requires_grad=True)
+    p64 = torch.split(x64.reshape(t, sum(shape), e), shape, dim=1)
+    l64 = TT.distance_tuple_loss(p64[0], p64[1], p64[2], p64[3] if quad else None, m1, m2, lam, dd,
+                                 dmax, fmax, lazy=lazy, huber=huber)
+    l64.backward()
+    xt = torch.tensor(flat, device=dev, requires_grad=True)
+    pt = torch.split(xt.reshape(t, sum(shape), e), shape, dim=1)
+    ddt = torch.tensor(dd, device=dev)
+    if quad:
+        loss = M.distance_quadruplet_loss(pt[0], pt[1], pt[2], pt[3], m1, m2, lam, ddt, dmax, fmax,
+                                          tl, dl)
+    else:
+        loss = M.distance_triplet_loss(pt[0], pt[1], pt[2], m1, lam, ddt, dmax, fmax, tl, dl)
+    loss.backward()
+    _close(loss, want)
+    _close(loss, float(l64))
+    assert _rel(xt.grad.cpu().numpy(), x64.grad.numpy()) < GRAD_REL
+
+
+def test_distance_terms_alone_and_their_kat(dev):
+    from soft_contrastive_learning_amd.model import losses as M
+    # hand-derivable: E=2, a=(0,0), pos={(1,0),(0,2)}: sqd = (1,4); f_max=2 -> sf=(0.5,2);
+    # d=(50,25), d_max=100 -> sd=(0.5,0.25); err=(0,1.75)
+    a = np.zeros((1, 1, 2), np.float32)
+    pos = np.array([[[1.0, 0.0], [0.0, 2.0]]], np.float32)
+    dd = np.array([[50.0, 25.0]], np.float32)
+    want_sq = (0.0 + 1.75 ** 2) / 2
+    want_hub = (0.0 + (1.75 - 0.5)) / 2
+    assert np.isclose(O.distance_loss(a, pos, dd, 100.0, 2.0), want_sq)
+    assert np.isclose(O.huber_distance_loss(a, pos, dd, 100.0, 2.0), want_hub)
+    at = torch.tensor(a, device=dev, requires_grad=True)
+    pt = torch.tensor(pos, device=dev, requires_grad=True)
+    ddt = torch.tensor(dd, device=dev)
+    got_sq = M.distance_loss(at, pt, ddt, 100.0, 2.0)
+    got_hub = M.huber_distance_loss(at, pt, ddt, 100.0, 2.0)
+    _close(got_sq, want_sq)
+    _close(got_hub, want_hub)
+    got_hub.backward()
+    # d/d pos_2 = clamp(err,-1,1)/(P f_max) * 2 (pos_2 - a) = 1/4 * (0,4) = (0,1); pos_1: err=0
+    np.testing.assert_allclose(pt.grad.cpu().numpy(), [[[0.0, 0.0], [0.0, 1.0]]], atol=1e-6)
+    np.testing.assert_allclose(at.grad.cpu().numpy(), [[[0.0, -1.0]]], atol=1e-6)
+    with pytest.raises(AttributeError):
+        M.distance_triplet_loss(at, pt, pt, 0.1, 0.5, ddt, 100.0, 2.0, 'evil_triplet_loss')
+    with pytest.raises(ValueError):
+        M.distance_triplet_loss(at, pt, pt, 0.1, 0.5, ddt[:, :1], 100.0, 2.0)
+
+
 def test_logratio_loss_and_grad(dev):
     from soft_contrastive_learning_amd.model import losses as M
     p = n = 12
