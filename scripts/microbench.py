@@ -93,6 +93,8 @@ def main():
     ap.add_argument('--netvlad-batches', default='24')
     ap.add_argument('--topn-refs', type=int, default=100000)
     ap.add_argument('--topn-queries', type=int, default=10000)
+    ap.add_argument('--topn-splits', default='',
+                    help='comma list of forced reference-split counts (tuning; default: planner)')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     what = args.what.split(',')
@@ -105,6 +107,15 @@ def main():
         res['wms_loss_sweep'] = sum((run_loss(dev, b, args.iters) for b in (24, 48, 96, 192)), [])
     if 'topn' in what:
         res['topn'] = run_topn(dev, args.topn_refs, args.topn_queries, 256, 25, max(2, args.iters // 10))
+        for sp in [int(v) for v in args.topn_splits.split(',') if v]:
+            # < 100: forced split count; otherwise a raw scl_debug_set_variant value
+            # (1000 * ablation bits [1 no selection, 2 no staging, 4 no MFMAs] + 100 + splits)
+            _lib.load().scl_debug_set_variant(100 + sp if sp < 100 else sp)
+            try:
+                res['topn_splits_%d' % sp] = run_topn(dev, args.topn_refs, args.topn_queries, 256,
+                                                      25, max(2, args.iters // 10))
+            finally:
+                _lib.load().scl_debug_set_variant(0)
     for name, rows in res.items():
         print('==', name)
         for r in rows:

@@ -73,13 +73,15 @@ __device__ __forceinline__ void sort_list(float* sc, int* ix, int lane) {
 // a split fills the lists (one rank-count sort each); afterwards a score below the query's
 // threshold (its current KEEP-th best) is inserted by the whole wave in O(1): position by
 // ballot + popcount, shift by one lane, write back — no per-candidate sort.  Single tile
-// buffer + register prefetch (65 KB of LDS: two workgroups per CU, so one workgroup's
-// selection overlaps the other's MFMAs).
+// buffer + register prefetch (65 KB of LDS: two workgroups per CU hide each other's LDS /
+// HBM latencies; their MFMA and VALU work does not overlap on a SIMD).
+// dbg (scl_debug_set_variant / 1000, diagnostics only): bit 0 no selection, bit 1 no staging,
+// bit 2 no MFMAs — timing ablations, results are then meaningless.
 template <int D8>
 __global__ __launch_bounds__(256, 2) void topn_scan_kernel(const float* __restrict__ ref,
                                                            const float* __restrict__ refnorm,
                                                            int R, const float* __restrict__ query,
-                                                           int Q, int refs_per_split,
+                                                           int Q, int refs_per_split, int dbg,
                                                            float* __restrict__ cand_sc,
                                                            int* __restrict__ cand_ix) {
   constexpr int d = D8 * 8;
@@ -155,24 +157,26 @@ __global__ __launch_bounds__(256, 2) void topn_scan_kernel(const float* __restri
   for (int q = 0; q < 16; ++q) tq[q] = INFINITY;
 
   for (int t = 0; t < ntiles; ++t) {
-    if (t + 1 < ntiles) stage_load(t + 1);
+    if (t + 1 < ntiles && !(dbg & 2)) stage_load(t + 1);
     const float* bp = &tile[r * LD + 4 * h];
     f32x16 acc = zero16();
     // reference fragments run two steps ahead of the MFMAs in a 3-deep register ring
     f32x4 bv[3];
     bv[0] = *reinterpret_cast<const f32x4*>(bp);
     if (D8 > 1) bv[1] = *reinterpret_cast<const f32x4*>(bp + 8);
+    if (!(dbg & 4)) {
 #pragma unroll
-    for (int u = 0; u < D8; ++u) {
-      if (u + 2 < D8) bv[(u + 2) % 3] = *reinterpret_cast<const f32x4*>(bp + 8 * (u + 2));
-      __builtin_amdgcn_sched_barrier(0);
+      for (int u = 0; u < D8; ++u) {
+        if (u + 2 < D8) bv[(u + 2) % 3] = *reinterpret_cast<const f32x4*>(bp + 8 * (u + 2));
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) acc = mfma32(qf[u][c], bv[u % 3][c], acc);
+        for (int c = 0; c < 4; ++c) acc = mfma32(qf[u][c], bv[u % 3][c], acc);
+      }
     }
     const float rnj = refn[r];
     const int ridx = r_begin + t * 32 + r;
     __syncthreads();                       // every wave is done reading the tile
-    if (t + 1 < ntiles) stage_store();     // refill it under the selection below
+    if (t + 1 < ntiles && !(dbg & 2)) stage_store();   // refill it under the selection below
 
     if (t == 0) {
       // first tile of the split: every list takes the 32 scores as they are, then sorts
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void topn_scan_kernel(const float* __restri
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int q = 0; q < 16; ++q) tq[q] = my_tau[acc_row(q, h)];
-    } else {
+    } else if (!(dbg & 1)) {
       bool any = false;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
@@ -405,6 +409,12 @@ inline TopnPlan topn_plan(int R, int Q) {
       best = s;
     }
   }
+  if (scl_debug_variant % 1000 >= 100) {   // tuning override (microbench.py --topn-splits)
+    best = scl_debug_variant % 1000 - 100;
+    if (best > 32) best = 32;
+    if (best > max_splits) best = max_splits;
+    if (best < 1) best = 1;
+  }
   p.splits = best;
   int per = (R + best - 1) / best;
   per = (per + 31) / 32 * 32;
@@ -427,8 +437,8 @@ void launch_scan(const TopnPlan& p, const float* ref, const float* refnorm, int 
                               (int)scan_lds_bytes(D8 * 8));
   });
   SCL_LAUNCH("topn_scan_kernel", (topn_scan_kernel<D8>), dim3(p.qtiles, p.splits), dim3(256),
-                     scan_lds_bytes(D8 * 8), st, ref, refnorm, R, query, Q, p.refs_per_split, cs,
-                     ci);
+                     scan_lds_bytes(D8 * 8), st, ref, refnorm, R, query, Q, p.refs_per_split,
+                     scl_debug_variant / 1000, cs, ci);
 }
 
 inline bool topn_shape_ok(int R, int Q, int d, int n) {
