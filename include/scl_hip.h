@@ -222,14 +222,18 @@ int scl_vgg_pool_bwd(const void* g, const void* a, const void* z, int dtype, int
 /* ------------------------------------------------------------------------- *
  * Diagnostics (bench.py's live per-kernel timing; the reference has no counterpart
  * beyond its wall-clock prints, train/train.py:135-161).  Between scl_prof_begin and
- * scl_prof_end every kernel launched by THIS thread through the library is bracketed by
- * HIP events on its launch stream.  scl_prof_end waits for them and returns per-launch
- * milliseconds and kernel names (static strings).
+ * scl_prof_end every kernel launched through the library BY ANY THREAD of the process
+ * (PyTorch runs backward on its own thread) is bracketed by HIP events on its launch stream;
+ * one sink at a time.  scl_prof_end waits for them and returns per-launch milliseconds and
+ * kernel names (static strings); call it once the launching threads are quiescent.
  * ------------------------------------------------------------------------- */
-/* Ablation switch for scripts/ablate_rowtile.py: a non-zero variant makes the forward
- * row-tile kernel skip its epilogue stores (bit 0), its x loads (bit 1) and/or its operand
- * staging and barriers (bit 2).  Results are then meaningless; 0 restores production
- * kernels.  Returns the previous value. */
+/* Ablation / tuning switch (scripts/ablate_rowtile.py, scripts/microbench.py); 0 restores
+ * the production kernels, any other value makes RESULTS MEANINGLESS.  Returns the old value.
+ *   1..7          forward row-tile kernel: bit 0 no epilogue stores, bit 1 no x loads,
+ *                 bit 2 no operand staging / barriers
+ *   100 + s       top-n: force s reference splits (1..32) instead of the planner's choice
+ *   1000 * b (+ 100 + s)   top-n scan: b bit 0 no selection, bit 1 no tile staging,
+ *                 bit 2 no MFMAs */
 int scl_debug_set_variant(int variant);
 int scl_prof_begin(int capacity);
 int scl_prof_count(void);
