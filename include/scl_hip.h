@@ -193,6 +193,18 @@ int scl_topn_l2(const float* ref, int R, const float* query, int Q, int d, int n
                 int64_t idx_offset, int64_t* idx_out, double* dist_out, void* workspace,
                 size_t workspace_bytes, void* stream);
 
+/* Same call with a scoring-mode flag.  SCL_TOPN_SCORE_BF16X3 nominates the KEEP = 32
+ * candidates per (query, reference split) with q.r = q_hi.r_hi + q_hi.r_lo + q_lo.r_hi on the
+ * bf16 matrix cores (x = hi + lo, two bf16 each): |score error| <= 1.2e-5 |q||r| instead of
+ * the float32 pass's ~1e-7; emitted order and distances are the same float64-exact re-rank.
+ * Needs 4 * R * d more workspace bytes (the two reference planes). */
+#define SCL_TOPN_SCORE_F32 0
+#define SCL_TOPN_SCORE_BF16X3 1
+size_t scl_topn_l2_ex_workspace_bytes(int R, int Q, int d, int n, int flags);
+int scl_topn_l2_ex(const float* ref, int R, const float* query, int Q, int d, int n,
+                   int64_t idx_offset, int64_t* idx_out, double* dist_out, void* workspace,
+                   size_t workspace_bytes, int flags, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * VGG16 backbone glue — the elementwise ops between the convolutions of
  * model/nets.py:27-63 (tf.layers.conv2d's bias add, tf.nn.relu,

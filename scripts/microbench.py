@@ -62,26 +62,26 @@ def run_loss(dev, b, iters):
     return rows
 
 
-def run_topn(dev, r, q, d, n, iters):
+def run_topn(dev, r, q, d, n, iters, score='f32'):
     ref, qry = U.retrieval_sets(r, q, d)
     rt, qt = torch.tensor(ref, device=dev), torch.tensor(qry, device=dev)
-    retrieval.topn_l2(rt, qt, n)
+    retrieval.topn_l2(rt, qt, n, score=score)
     torch.cuda.synchronize()
     with _lib.KernelTimer(capacity=8 * iters) as kt:
         t0 = time.perf_counter()
         for _ in range(iters):
-            retrieval.topn_l2(rt, qt, n)
+            retrieval.topn_l2(rt, qt, n, score=score)
         torch.cuda.synchronize()
         wall = (time.perf_counter() - t0) / iters
     out = []
     for k, (cnt, ms) in sorted(kt.summary().items()):
         row = dict(kernel=k, launches=cnt, us=round(ms * 1e3, 1))
-        if k == 'topn_scan_kernel':
+        if k.startswith('topn_scan'):
             tf = 2.0 * q * r * d / (ms * 1e-3) / 1e12
             row.update(bound='mfma', tflops=round(tf, 2), frac=round(tf / bench.PEAK_F32_TFLOPS, 4))
         out.append(row)
     out.append(dict(kernel='topn_l2 (whole call)', us=round(wall * 1e6, 1),
-                    queries_per_sec=round(q / wall, 1), R=r, Q=q, d=d, n=n))
+                    queries_per_sec=round(q / wall, 1), R=r, Q=q, d=d, n=n, score=score))
     return out
 
 
@@ -93,6 +93,7 @@ def main():
     ap.add_argument('--netvlad-batches', default='24')
     ap.add_argument('--topn-refs', type=int, default=100000)
     ap.add_argument('--topn-queries', type=int, default=10000)
+    ap.add_argument('--topn-score', default='f32', help="f32, bf16x3 or both (comma list)")
     ap.add_argument('--topn-splits', default='',
                     help='comma list of forced reference-split counts (tuning; default: planner)')
     args = ap.parse_args()
@@ -106,14 +107,18 @@ def main():
     if 'loss' in what:
         res['wms_loss_sweep'] = sum((run_loss(dev, b, args.iters) for b in (24, 48, 96, 192)), [])
     if 'topn' in what:
-        res['topn'] = run_topn(dev, args.topn_refs, args.topn_queries, 256, 25, max(2, args.iters // 10))
+        scores = args.topn_score.split(',')
+        for sc in scores:
+            res['topn' if sc == 'f32' else 'topn_' + sc] = run_topn(
+                dev, args.topn_refs, args.topn_queries, 256, 25, max(2, args.iters // 10), sc)
         for sp in [int(v) for v in args.topn_splits.split(',') if v]:
             # < 100: forced split count; otherwise a raw scl_debug_set_variant value
             # (1000 * ablation bits [1 no selection, 2 no staging, 4 no MFMAs] + 100 + splits)
             _lib.load().scl_debug_set_variant(100 + sp if sp < 100 else sp)
             try:
-                res['topn_splits_%d' % sp] = run_topn(dev, args.topn_refs, args.topn_queries, 256,
-                                                      25, max(2, args.iters // 10))
+                res['topn_%s_splits_%d' % (scores[-1], sp)] = run_topn(
+                    dev, args.topn_refs, args.topn_queries, 256, 25, max(2, args.iters // 10),
+                    scores[-1])
             finally:
                 _lib.load().scl_debug_set_variant(0)
     for name, rows in res.items():

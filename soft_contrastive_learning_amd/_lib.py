@@ -19,6 +19,7 @@ SUM_MS, SUM_PLAIN = 0, 1
 TUPLE_TRIPLET, TUPLE_LAZY_TRIPLET, TUPLE_EVIL_TRIPLET = 0, 1, 2
 TUPLE_QUADRUPLET, TUPLE_LAZY_QUADRUPLET, TUPLE_EVIL_QUADRUPLET = 3, 4, 5
 VLAD_D, VLAD_K = 512, 64
+TOPN_SCORE_F32, TOPN_SCORE_BF16X3 = 0, 1
 
 _p = ctypes.c_void_p
 _i = ctypes.c_int
@@ -50,6 +51,8 @@ SIGNATURES = {
     "scl_logratio_fwd": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
     "scl_topn_l2_workspace_bytes": (_z, [_i, _i, _i, _i]),
     "scl_topn_l2": (_i, [_p, _i, _p, _i, _i, _i, _l, _p, _p, _p, _z, _p]),
+    "scl_topn_l2_ex_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
+    "scl_topn_l2_ex": (_i, [_p, _i, _p, _i, _i, _i, _l, _p, _p, _p, _z, _i, _p]),
     "scl_vgg_workspace_bytes": (_z, [_i]),
     "scl_vgg_bias_act": (_i, [_p, _i, _p, _l, _i, _i, _p]),
     "scl_vgg_act_bwd": (_i, [_p, _p, _i, _l, _i, _p, _p, _p, _z, _p]),

@@ -840,7 +840,7 @@ void launch_rowtile(const RowTileArgs& a, hipStream_t st) {
   });
   const int tiles16 = (a.N + 15) / 16;
   const dim3 grid((tiles16 + 3) / 4, a.B);
-  if (MODE == ASSIGN && scl_debug_variant != 0) {   // ablation builds (scripts/ablate_rowtile.py)
+  if (MODE == ASSIGN && scl_debug_variant >= 1 && scl_debug_variant <= 7) {   // ablate_rowtile.py
     launch_rowtile_variant<T>(a, grid, st);
     return;
   }

@@ -47,6 +47,49 @@ __global__ __launch_bounds__(256) void refnorm_kernel(const float* __restrict__ 
   if (lane == 0) out[row] = s;
 }
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                 __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// x = hi + lo + O(2^-17 |x|): hi = bf16(x), lo = bf16(x - hi), both round-to-nearest-even.
+__device__ __forceinline__ void split_bf16(float x, unsigned& hi, unsigned& lo) {
+  const unsigned short h = f32_to_bf16(x);
+  hi = h;
+  lo = f32_to_bf16(x - bf16_to_f32(h));
+}
+// 8 consecutive floats -> 8 packed bf16 high parts and 8 packed low parts
+__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, u32x4& hi, u32x4& lo) {
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    unsigned h0, l0, h1, l1;
+    split_bf16(a[2 * c], h0, l0);
+    split_bf16(a[2 * c + 1], h1, l1);
+    hi[c] = h0 | (h1 << 16);
+    lo[c] = l0 | (l1 << 16);
+    split_bf16(b[2 * c], h0, l0);
+    split_bf16(b[2 * c + 1], h1, l1);
+    hi[2 + c] = h0 | (h1 << 16);
+    lo[2 + c] = l0 | (l1 << 16);
+  }
+}
+
+// Reference rows as two bf16 planes for the bf16x3 scoring mode (one pass, 8 floats/thread).
+__global__ __launch_bounds__(256) void ref_split_kernel(const float* __restrict__ ref,
+                                                        int64_t n8, u32x4* __restrict__ hi,
+                                                        u32x4* __restrict__ lo) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const f32x4 a = *reinterpret_cast<const f32x4*>(ref + 8 * i);
+  const f32x4 b = *reinterpret_cast<const f32x4*>(ref + 8 * i + 4);
+  u32x4 h, l;
+  split8(a, b, h, l);
+  hi[i] = h;
+  lo[i] = l;
+}
+
 // Rank-count sort of one query's KEEP-entry list by one wave (entry e = lane & 31):
 // afterwards the list is ascending by (score, index).
 __device__ __forceinline__ void sort_list(float* sc, int* ix, int lane) {
@@ -77,18 +120,28 @@ __device__ __forceinline__ void sort_list(float* sc, int* ix, int lane) {
 // HBM latencies; their MFMA and VALU work does not overlap on a SIMD).
 // dbg (scl_debug_set_variant / 1000, diagnostics only): bit 0 no selection, bit 1 no staging,
 // bit 2 no MFMAs — timing ablations, results are then meaningless.
-template <int D8>
-__global__ __launch_bounds__(256, 2) void topn_scan_kernel(const float* __restrict__ ref,
+// BF = 1 (bf16x3 scoring): q.r = q_hi.r_hi + q_hi.r_lo + q_lo.r_hi on v_mfma_f32_32x32x16_bf16
+// (every product of two 8-bit mantissas is exact in f32; what is dropped is q_lo.r_lo and the
+// 2^-17 split residue, |error| <= 1.2e-5 |q||r|).  `ref` then points at the high plane and
+// `ref_lo` at the low plane written by ref_split_kernel; the LDS tile holds both planes with
+// rows of d/2 + 4 dwords.  The float64 re-rank still reads the float32 rows.
+template <int D8, int BF>
+__global__ __launch_bounds__(256, 2) void topn_scan_kernel(const void* __restrict__ refv,
+                                                           const void* __restrict__ ref_lov,
                                                            const float* __restrict__ refnorm,
                                                            int R, const float* __restrict__ query,
                                                            int Q, int refs_per_split, int dbg,
                                                            float* __restrict__ cand_sc,
                                                            int* __restrict__ cand_ix) {
   constexpr int d = D8 * 8;
-  constexpr int LD = d + 4;
+  constexpr int LD = d + 4;          // f32 tile: floats per row
+  constexpr int LDB = d / 2 + 4;     // bf16 planes: dwords per row
+  constexpr int KS = d / 16;         // bf16 k-steps
+  constexpr int TILE_DW = BF ? 2 * 32 * LDB : 32 * LD;
+  const float* ref = reinterpret_cast<const float*>(refv);
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* tile = lds;                                   // 32 * LD
-  float* refn = tile + 32 * LD;                        // 32
+  float* tile = lds;                                   // TILE_DW
+  float* refn = tile + TILE_DW;                        // 32
   float* lsc = refn + 32;                              // QW * 32 * KEEP
   int* lix = reinterpret_cast<int*>(lsc + QW * 32 * KEEP);
   float* tau = reinterpret_cast<float*>(lix + QW * 32 * KEEP);   // QW * 32
@@ -102,24 +155,37 @@ __global__ __launch_bounds__(256, 2) void topn_scan_kernel(const float* __restri
   if (r_end > R) r_end = R;
   const int ntiles = (r_end - r_begin + 31) / 32;
 
-  // query fragments: lane (r, h) keeps q[q0 + r][8t + 4h .. +3] for every t
-  f32x4 qf[D8];
+  // query fragments.  f32: lane (r, h) keeps q[q0 + r][8t + 4h .. +3] for every t.
+  // bf16x3: q[q0 + r][16u + 8h .. +7] split into packed high / low parts for every k-step u.
+  f32x4 qf[BF ? 1 : D8];
+  u32x4 qh[BF ? KS : 1], ql[BF ? KS : 1];
   {
     const int qrow = q0 + r;
-    const float* qp = query + (int64_t)(qrow < Q ? qrow : 0) * d + 4 * h;
+    const float* qp = query + (int64_t)(qrow < Q ? qrow : 0) * d;
+    if constexpr (BF) {
 #pragma unroll
-    for (int t = 0; t < D8; ++t) {
-      qf[t] = *reinterpret_cast<const f32x4*>(qp + 8 * t);
-      if (qrow >= Q) qf[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int u = 0; u < KS; ++u) {
+        f32x4 a = *reinterpret_cast<const f32x4*>(qp + 16 * u + 8 * h);
+        f32x4 b = *reinterpret_cast<const f32x4*>(qp + 16 * u + 8 * h + 4);
+        if (qrow >= Q) a = b = f32x4{0.f, 0.f, 0.f, 0.f};
+        split8(a, b, qh[u], ql[u]);
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < D8; ++t) {
+        qf[t] = *reinterpret_cast<const f32x4*>(qp + 4 * h + 8 * t);
+        if (qrow >= Q) qf[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
     }
   }
   float* my_sc = lsc + wid * 32 * KEEP;
   int* my_ix = lix + wid * 32 * KEEP;
   float* my_tau = tau + wid * 32;
 
-  // staging: 256 threads move one [32][d] tile as float4
-  constexpr int V4 = (32 * d / 4) / 256;
-  static_assert(V4 >= 1, "d too small for the staging layout");
+  // staging: 256 threads move one tile as 16-byte pieces.  f32: [32][d] floats; bf16x3: the
+  // two [32][d] bf16 planes (same byte count).
+  constexpr int V4 = (32 * d / 4 + 255) / 256;
+  constexpr int ROW16 = BF ? d / 8 : d / 4;            // 16-byte pieces per row (per plane)
   f32x4 stage[V4];
   float stage_n = 0.f;
   auto stage_load = [&](int t) {
@@ -127,10 +193,17 @@ __global__ __launch_bounds__(256, 2) void topn_scan_kernel(const float* __restri
 #pragma unroll
     for (int v = 0; v < V4; ++v) {
       const int idx = v * 256 + threadIdx.x;
-      const int row = idx / (d / 4), c4 = idx % (d / 4);
+      const int prow = idx / ROW16, c = idx % ROW16;   // prow: row, or plane * 32 + row
+      const int row = BF ? (prow & 31) : prow;
       const int rr = rb + row;
-      stage[v] = rr < r_end ? *reinterpret_cast<const f32x4*>(ref + (int64_t)rr * d + c4 * 4)
-                            : f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* src;
+      if constexpr (BF)
+        src = reinterpret_cast<const float*>(prow < 32 ? refv : ref_lov) +
+              ((int64_t)rr * d) / 2 + c * 4;
+      else
+        src = ref + (int64_t)rr * d + c * 4;
+      const bool ok = idx < 32 * d / 4 && rr < r_end;
+      stage[v] = ok ? *reinterpret_cast<const f32x4*>(src) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     if (threadIdx.x < 32) {
       const int rr = rb + threadIdx.x;
@@ -141,8 +214,9 @@ __global__ __launch_bounds__(256, 2) void topn_scan_kernel(const float* __restri
 #pragma unroll
     for (int v = 0; v < V4; ++v) {
       const int idx = v * 256 + threadIdx.x;
-      const int row = idx / (d / 4), c4 = idx % (d / 4);
-      *reinterpret_cast<f32x4*>(&tile[row * LD + c4 * 4]) = stage[v];
+      const int prow = idx / ROW16, c = idx % ROW16;
+      if (idx < 32 * d / 4)
+        *reinterpret_cast<f32x4*>(&tile[prow * (BF ? LDB : LD) + c * 4]) = stage[v];
     }
     if (threadIdx.x < 32) refn[threadIdx.x] = stage_n;
   };
@@ -158,19 +232,42 @@ __global__ __launch_bounds__(256, 2) void topn_scan_kernel(const float* __restri
 
   for (int t = 0; t < ntiles; ++t) {
     if (t + 1 < ntiles && !(dbg & 2)) stage_load(t + 1);
-    const float* bp = &tile[r * LD + 4 * h];
     f32x16 acc = zero16();
-    // reference fragments run two steps ahead of the MFMAs in a 3-deep register ring
-    f32x4 bv[3];
-    bv[0] = *reinterpret_cast<const f32x4*>(bp);
-    if (D8 > 1) bv[1] = *reinterpret_cast<const f32x4*>(bp + 8);
-    if (!(dbg & 4)) {
+    if constexpr (BF) {
+      // planes: hi rows at tile[row * LDB], lo rows at tile[(32 + row) * LDB]; lane (r, h) reads
+      // the 16 bytes of reference row r holding elements 16u + 8h .. +7
+      const float* bh = &tile[r * LDB + 4 * h];
+      const float* bl = bh + 32 * LDB;
+      u32x4 vh[2], vl[2];
+      vh[0] = *reinterpret_cast<const u32x4*>(bh);
+      vl[0] = *reinterpret_cast<const u32x4*>(bl);
+      if (!(dbg & 4)) {
 #pragma unroll
-      for (int u = 0; u < D8; ++u) {
-        if (u + 2 < D8) bv[(u + 2) % 3] = *reinterpret_cast<const f32x4*>(bp + 8 * (u + 2));
-        __builtin_amdgcn_sched_barrier(0);
+        for (int u = 0; u < KS; ++u) {
+          if (u + 1 < KS) {
+            vh[(u + 1) & 1] = *reinterpret_cast<const u32x4*>(bh + 8 * (u + 1));
+            vl[(u + 1) & 1] = *reinterpret_cast<const u32x4*>(bl + 8 * (u + 1));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          acc = mfma_bf16(qh[u], vh[u & 1], acc);
+          acc = mfma_bf16(qh[u], vl[u & 1], acc);
+          acc = mfma_bf16(ql[u], vh[u & 1], acc);
+        }
+      }
+    } else {
+      const float* bp = &tile[r * LD + 4 * h];
+      // reference fragments run two steps ahead of the MFMAs in a 3-deep register ring
+      f32x4 bv[3];
+      bv[0] = *reinterpret_cast<const f32x4*>(bp);
+      if (D8 > 1) bv[1] = *reinterpret_cast<const f32x4*>(bp + 8);
+      if (!(dbg & 4)) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc = mfma32(qf[u][c], bv[u % 3][c], acc);
+        for (int u = 0; u < D8; ++u) {
+          if (u + 2 < D8) bv[(u + 2) % 3] = *reinterpret_cast<const f32x4*>(bp + 8 * (u + 2));
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc = mfma32(qf[u][c], bv[u % 3][c], acc);
+        }
       }
     }
     const float rnj = refn[r];
@@ -387,7 +484,7 @@ __global__ __launch_bounds__(256) void topn_rerank_kernel(const float* __restric
 struct TopnPlan {
   int qtiles, splits, refs_per_split;
 };
-inline TopnPlan topn_plan(int R, int Q) {
+inline TopnPlan topn_plan(int R, int Q, int bf) {
   TopnPlan p;
   p.qtiles = (Q + 32 * QW - 1) / (32 * QW);
   const int max_splits = (R + 32 * KEEP - 1) / (32 * KEEP);  // keep >= 32 tiles per split
@@ -402,8 +499,10 @@ inline TopnPlan topn_plan(int R, int Q) {
     // ~240 cycles each (measured: 19 splits spent as long inserting as multiplying), so
     // more splits buy parallelism with extra selection work.
     const double tiles = ((double)R / s) / 32.0;
+    // per tile: 128 f32 MFMAs x 64 cycles, or 48 bf16 MFMAs x 32 cycles (+ barriers, LDS latency)
+    const double tile_cycles = bf ? 3000.0 : 8192.0;
     const double cost =
-        (double)rounds * (8192.0 * tiles + 245760.0 * log(tiles + 1.0)) * (1.0 + 0.002 * s);
+        (double)rounds * (tile_cycles * tiles + 245760.0 * log(tiles + 1.0)) * (1.0 + 0.002 * s);
     if (cost < best_cost) {
       best_cost = cost;
       best = s;
@@ -423,22 +522,23 @@ inline TopnPlan topn_plan(int R, int Q) {
   return p;
 }
 
-inline size_t scan_lds_bytes(int d) {
-  return ((size_t)32 * (d + 4) + 32 + (size_t)QW * 32 * KEEP * 2 + QW * 32) * sizeof(float);
+inline size_t scan_lds_bytes(int d, int bf) {
+  const size_t tile = bf ? (size_t)2 * 32 * (d / 2 + 4) : (size_t)32 * (d + 4);
+  return (tile + 32 + (size_t)QW * 32 * KEEP * 2 + QW * 32) * sizeof(float);
 }
 
-template <int D8>
-void launch_scan(const TopnPlan& p, const float* ref, const float* refnorm, int R,
-                 const float* query, int Q, float* cs, int* ci, hipStream_t st) {
+template <int D8, int BF>
+void launch_scan(const TopnPlan& p, const void* ref, const void* ref_lo, const float* refnorm,
+                 int R, const float* query, int Q, float* cs, int* ci, hipStream_t st) {
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&topn_scan_kernel<D8>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&topn_scan_kernel<D8, BF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)scan_lds_bytes(D8 * 8));
+                              (int)scan_lds_bytes(D8 * 8, BF));
   });
-  SCL_LAUNCH("topn_scan_kernel", (topn_scan_kernel<D8>), dim3(p.qtiles, p.splits), dim3(256),
-                     scan_lds_bytes(D8 * 8), st, ref, refnorm, R, query, Q, p.refs_per_split,
-                     scl_debug_variant / 1000, cs, ci);
+  SCL_LAUNCH(BF ? "topn_scan_bf16x3_kernel" : "topn_scan_kernel", (topn_scan_kernel<D8, BF>),
+             dim3(p.qtiles, p.splits), dim3(256), scan_lds_bytes(D8 * 8, BF), st, ref, ref_lo,
+             refnorm, R, query, Q, p.refs_per_split, scl_debug_variant / 1000, cs, ci);
 }
 
 inline bool topn_shape_ok(int R, int Q, int d, int n) {
@@ -448,35 +548,66 @@ inline bool topn_shape_ok(int R, int Q, int d, int n) {
 
 }  // namespace
 
-extern "C" size_t scl_topn_l2_workspace_bytes(int R, int Q, int d, int n) {
-  if (!topn_shape_ok(R, Q, d, n)) return 0;
-  const TopnPlan p = topn_plan(R, Q);
+extern "C" size_t scl_topn_l2_ex_workspace_bytes(int R, int Q, int d, int n, int flags) {
+  if (!topn_shape_ok(R, Q, d, n) || (flags & ~SCL_TOPN_SCORE_BF16X3)) return 0;
+  const int bf = flags & SCL_TOPN_SCORE_BF16X3;
+  const TopnPlan p = topn_plan(R, Q, bf);
   return scl_round256((size_t)R * sizeof(float)) +
-         2 * scl_round256((size_t)Q * p.splits * KEEP * sizeof(float));
+         2 * scl_round256((size_t)Q * p.splits * KEEP * sizeof(float)) +
+         (bf ? 2 * scl_round256((size_t)R * d * sizeof(unsigned short)) : 0);
 }
 
-extern "C" int scl_topn_l2(const float* ref, int R, const float* query, int Q, int d, int n,
-                           int64_t idx_offset, int64_t* idx_out, double* dist_out, void* workspace,
-                           size_t workspace_bytes, void* stream) {
+extern "C" size_t scl_topn_l2_workspace_bytes(int R, int Q, int d, int n) {
+  return scl_topn_l2_ex_workspace_bytes(R, Q, d, n, 0);
+}
+
+extern "C" int scl_topn_l2_ex(const float* ref, int R, const float* query, int Q, int d, int n,
+                              int64_t idx_offset, int64_t* idx_out, double* dist_out,
+                              void* workspace, size_t workspace_bytes, int flags, void* stream) {
   if (!ref || !query || !idx_out || !dist_out || !workspace) return SCL_E_NULL;
   if (!topn_shape_ok(R, Q, d, n)) return SCL_E_SHAPE;
+  if (flags & ~SCL_TOPN_SCORE_BF16X3) return SCL_E_KIND;
   if (((uintptr_t)ref % 16) || ((uintptr_t)query % 16)) return SCL_E_SHAPE;
-  if (!scl_aligned256(workspace) || workspace_bytes < scl_topn_l2_workspace_bytes(R, Q, d, n))
+  if (!scl_aligned256(workspace) ||
+      workspace_bytes < scl_topn_l2_ex_workspace_bytes(R, Q, d, n, flags))
     return SCL_E_WORKSPACE;
-  const TopnPlan p = topn_plan(R, Q);
+  const int bf = flags & SCL_TOPN_SCORE_BF16X3;
+  const TopnPlan p = topn_plan(R, Q, bf);
   char* base = (char*)workspace;
   float* refnorm = (float*)base;
   base += scl_round256((size_t)R * sizeof(float));
   float* cs = (float*)base;
   base += scl_round256((size_t)Q * p.splits * KEEP * sizeof(float));
   int* ci = (int*)base;
+  base += scl_round256((size_t)Q * p.splits * KEEP * sizeof(float));
   hipStream_t st = (hipStream_t)stream;
   SCL_LAUNCH("refnorm_kernel", refnorm_kernel, dim3((R + 3) / 4), dim3(256), 0, st, ref, R, d, refnorm);
-  switch (d) {
-    case 32: launch_scan<4>(p, ref, refnorm, R, query, Q, cs, ci, st); break;
-    case 64: launch_scan<8>(p, ref, refnorm, R, query, Q, cs, ci, st); break;
-    case 128: launch_scan<16>(p, ref, refnorm, R, query, Q, cs, ci, st); break;
-    default: launch_scan<32>(p, ref, refnorm, R, query, Q, cs, ci, st); break;
+  const void* scan_ref = ref;
+  const void* scan_lo = nullptr;
+  if (bf) {
+    u32x4* hi = (u32x4*)base;
+    base += scl_round256((size_t)R * d * sizeof(unsigned short));
+    u32x4* lo = (u32x4*)base;
+    const int64_t n8 = (int64_t)R * d / 8;
+    SCL_LAUNCH("ref_split_kernel", ref_split_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256),
+               0, st, ref, n8, hi, lo);
+    scan_ref = hi;
+    scan_lo = lo;
+  }
+  if (bf) {
+    switch (d) {
+      case 32: launch_scan<4, 1>(p, scan_ref, scan_lo, refnorm, R, query, Q, cs, ci, st); break;
+      case 64: launch_scan<8, 1>(p, scan_ref, scan_lo, refnorm, R, query, Q, cs, ci, st); break;
+      case 128: launch_scan<16, 1>(p, scan_ref, scan_lo, refnorm, R, query, Q, cs, ci, st); break;
+      default: launch_scan<32, 1>(p, scan_ref, scan_lo, refnorm, R, query, Q, cs, ci, st); break;
+    }
+  } else {
+    switch (d) {
+      case 32: launch_scan<4, 0>(p, scan_ref, scan_lo, refnorm, R, query, Q, cs, ci, st); break;
+      case 64: launch_scan<8, 0>(p, scan_ref, scan_lo, refnorm, R, query, Q, cs, ci, st); break;
+      case 128: launch_scan<16, 0>(p, scan_ref, scan_lo, refnorm, R, query, Q, cs, ci, st); break;
+      default: launch_scan<32, 0>(p, scan_ref, scan_lo, refnorm, R, query, Q, cs, ci, st); break;
+    }
   }
   const int M = p.splits * KEEP;
   const size_t lds = (size_t)4 * (2 * M + 3 * KEEP) * sizeof(float);
@@ -491,4 +622,11 @@ extern "C" int scl_topn_l2(const float* ref, int R, const float* query, int Q, i
     SCL_LAUNCH("topn_rerank_kernel", topn_rerank_kernel<16>, rgrid, dim3(256), lds, st, ref, query,
                Q, d, p.splits, n, idx_offset, (const float*)cs, (const int*)ci, idx_out, dist_out);
   return scl_launch_status();
+}
+
+extern "C" int scl_topn_l2(const float* ref, int R, const float* query, int Q, int d, int n,
+                           int64_t idx_offset, int64_t* idx_out, double* dist_out, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+  return scl_topn_l2_ex(ref, R, query, Q, d, n, idx_offset, idx_out, dist_out, workspace,
+                        workspace_bytes, 0, stream);
 }

@@ -12,10 +12,21 @@ from .. import _lib as L
 MAX_N = 25
 
 
-def topn_l2(ref, query, n, idx_offset=0):
+SCORE_MODES = {'f32': L.TOPN_SCORE_F32, 'bf16x3': L.TOPN_SCORE_BF16X3}
+
+
+def topn_l2(ref, query, n, idx_offset=0, score='f32'):
     """ref [R,d], query [Q,d] float32 on a HIP device -> (dists [Q,n] float64 ascending,
-    idx [Q,n] int64), like ``KDTree(ref).query(query, k=n, sort_results=True)``."""
+    idx [Q,n] int64), like ``KDTree(ref).query(query, k=n, sort_results=True)``.
+
+    ``score`` picks how the 32 candidates per (query, reference split) are nominated before
+    the float64 re-rank: 'f32' (exact-float32 matrix instructions, score error ~1e-7) or
+    'bf16x3' (three bf16 matrix products of the high/low operand halves: |score error| <=
+    1.2e-5 |q||r|, about 1.8x faster).  The emitted distances are float64-exact either way;
+    the index lists agree whenever the true top-n lie within the nominated 32."""
     lib = L.load()
+    if score not in SCORE_MODES:
+        raise ValueError("score must be one of %s, got %r" % (sorted(SCORE_MODES), score))
     L.require_device(ref, query)
     ref = ref.float().contiguous()
     query = query.float().contiguous()
@@ -34,15 +45,16 @@ def topn_l2(ref, query, n, idx_offset=0):
         ref = torch.nn.functional.pad(ref, (0, pad - d))
         query = torch.nn.functional.pad(query, (0, pad - d))
         d = pad
-    nbytes = lib.scl_topn_l2_workspace_bytes(r, q, d, n)
+    flags = SCORE_MODES[score]
+    nbytes = lib.scl_topn_l2_ex_workspace_bytes(r, q, d, n, flags)
     if nbytes == 0:
         raise ValueError("unsupported retrieval shape R=%d Q=%d d=%d n=%d "
                          "(d in {32,64,128,256}, n <= %d, n <= R)" % (r, q, d, n, MAX_N))
     idx = torch.empty((q, n), dtype=torch.int64, device=ref.device)
     dist = torch.empty((q, n), dtype=torch.float64, device=ref.device)
     ws = L.workspace(nbytes, ref.device)
-    L.check(lib.scl_topn_l2(L.ptr(ref), r, L.ptr(query), q, d, n, int(idx_offset), L.ptr(idx),
-                            L.ptr(dist), L.ptr(ws), ws.numel(), L.stream_of(ref)))
+    L.check(lib.scl_topn_l2_ex(L.ptr(ref), r, L.ptr(query), q, d, n, int(idx_offset), L.ptr(idx),
+                               L.ptr(dist), L.ptr(ws), ws.numel(), flags, L.stream_of(ref)))
     return dist, idx
 
 

@@ -16,13 +16,15 @@ def dev():
     return torch.device("cuda:0")
 
 
+@pytest.mark.parametrize("score", ['f32', 'bf16x3'])
 @pytest.mark.parametrize("r,q,d,n", [(25, 1, 32, 25), (100, 7, 64, 5), (1000, 130, 128, 25),
                                      (5000, 300, 256, 25), (40000, 64, 256, 25)])
-def test_topn_matches_kdtree(dev, r, q, d, n):
+def test_topn_matches_kdtree(dev, r, q, d, n, score):
     from soft_contrastive_learning_amd.evaluation import retrieval
     ref, qry = U.retrieval_sets(r, q, d)
     want_d, want_i = TN.topn_kdtree(ref, qry, n)
-    got_d, got_i = retrieval.topn_l2(torch.tensor(ref, device=dev), torch.tensor(qry, device=dev), n)
+    got_d, got_i = retrieval.topn_l2(torch.tensor(ref, device=dev), torch.tensor(qry, device=dev), n,
+                                     score=score)
     np.testing.assert_array_equal(got_i.cpu().numpy(), want_i)
     np.testing.assert_allclose(got_d.cpu().numpy(), want_d, rtol=1e-12, atol=0)
 
@@ -47,13 +49,14 @@ def test_topn_other_widths_match_kdtree(dev, r, q, d, n):
     np.testing.assert_allclose(got_d.cpu().numpy(), want_d, rtol=1e-10, atol=0)
 
 
-def test_topn_duplicates_and_offset(dev):
+@pytest.mark.parametrize("score", ['f32', 'bf16x3'])
+def test_topn_duplicates_and_offset(dev, score):
     from soft_contrastive_learning_amd.evaluation import retrieval
     ref, qry = U.retrieval_sets(300, 10, 64)
     ref[150] = ref[3]          # exact tie: lower index first
     qry[0] = ref[3]
     d, i = retrieval.topn_l2(torch.tensor(ref, device=dev), torch.tensor(qry, device=dev), 5,
-                             idx_offset=1000)
+                             idx_offset=1000, score=score)
     i = i.cpu().numpy()
     assert list(i[0, :2]) == [1003, 1150]
     assert float(d[0, 0]) == 0.0 and float(d[0, 1]) == 0.0
@@ -68,3 +71,20 @@ def test_topn_sharded_reference_merge_equals_single(dev):
     d1, i1 = retrieval.merge_topn([p[0] for p in parts], [p[1] for p in parts], 25)
     assert torch.equal(i0, i1)
     assert torch.equal(d0, d1)
+
+
+def test_topn_bf16x3_on_scaled_and_offset_features(dev):
+    """The split scoring must survive features that are neither unit-scale nor centred
+    (PCA-whitened descriptors are; raw ones are not): large common offset, mixed magnitudes."""
+    from soft_contrastive_learning_amd.evaluation import retrieval
+    rng = np.random.default_rng(77)
+    ref = (rng.standard_normal((20000, 128)) * rng.uniform(0.01, 30.0, 128) + 5.0).astype(np.float32)
+    qry = (rng.standard_normal((200, 128)) * rng.uniform(0.01, 30.0, 128) + 5.0).astype(np.float32)
+    want_d, want_i = TN.topn_kdtree(ref, qry, 25)
+    rt, qt = torch.tensor(ref, device=dev), torch.tensor(qry, device=dev)
+    for score in ('f32', 'bf16x3'):
+        got_d, got_i = retrieval.topn_l2(rt, qt, 25, score=score)
+        np.testing.assert_array_equal(got_i.cpu().numpy(), want_i)
+        np.testing.assert_allclose(got_d.cpu().numpy(), want_d, rtol=1e-12, atol=0)
+    with pytest.raises(ValueError):
+        retrieval.topn_l2(rt, qt, 25, score='fp8')
