@@ -39,6 +39,7 @@ import torch.distributed as dist  # noqa: E402
 # MI355X peaks, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3     # f32 vector == f32-input MFMA
 PEAK_HBM_GBPS = 8000.0
+PEAK_BF16_TFLOPS = 2500.0    # dense bf16 MFMA (no sparsity)
 
 D, K, E = 512, 64, 32768
 
@@ -65,15 +66,22 @@ def kernel_models(b, n, gb, x_bytes):
     """Algorithmic flops / bytes per LAUNCH of each hand-written kernel.
     b = images on this GPU, n = locations per image, gb = global batch."""
     bn = b * n
+    # bf16 feature maps: the row-tile contractions run as three bf16 MFMAs per step (x exact,
+    # the float32 operand split into three bf16 planes) -> priced against the bf16 dense peak
+    # with 3x the algorithmic flops executed
+    b3 = dict(peak_tflops=PEAK_BF16_TFLOPS, exec_mult=3.0) if x_bytes == 2 else {}
     return {
         # x·W over all locations; reads x once, writes a (+ logits) and rn
-        'rowtile_assign': dict(flops=2.0 * bn * D * K, bytes=bn * D * x_bytes + bn * K * 8 + bn * 4),
+        'rowtile_assign': dict(flops=2.0 * bn * D * K, bytes=bn * D * x_bytes + bn * K * 8 + bn * 4,
+                               **b3),
         # x^T·(a rn); reads x and a once, writes 2 slabs per image
         'aggregate_kernel': dict(flops=2.0 * bn * D * K, bytes=bn * D * x_bytes + bn * K * 4 + b * 2 * D * K * 4),
         'finish_sum_kernel': dict(flops=6.0 * b * D * K, bytes=b * D * K * 4 * 6),
         'finish_norm_kernel': dict(flops=2.0 * b * D * K, bytes=b * D * K * 4 * 2),
-        'bwd_prep_kernel': dict(flops=12.0 * b * D * K, bytes=b * D * K * 4 * 4),
-        'rowtile_dassign': dict(flops=2.0 * bn * D * K, bytes=bn * D * x_bytes + bn * K * 12 + b * D * K * 4),
+        'bwd_dots_kernel': dict(flops=8.0 * b * D * K, bytes=b * D * K * 4 * 2),
+        'bwd_du_kernel': dict(flops=4.0 * b * D * K, bytes=b * D * K * 4 * 4),
+        'rowtile_dassign': dict(flops=2.0 * bn * D * K,
+                                bytes=bn * D * x_bytes + bn * K * 12 + b * D * K * 4, **b3),
         'aggregate_dw': dict(flops=2.0 * bn * D * K, bytes=bn * D * x_bytes + bn * K * 4 + b * 2 * D * K * 4),
         # [a|ds]·[dU|W]^T then the norm Jacobian; reads x, writes grad_x
         'dx_kernel': dict(flops=4.0 * bn * D * K, bytes=2 * bn * D * x_bytes + bn * K * 8),
@@ -85,6 +93,7 @@ def kernel_models(b, n, gb, x_bytes):
         # grad_E[own rows] = M E: reads E once, writes b rows
         'gram_bwd_kernel': dict(flops=2.0 * b * gb * E, bytes=gb * E * 4 + b * E * 4),
         'transpose_w_kernel': dict(flops=0.0, bytes=D * K * 8),
+        'split_w_kernel': dict(flops=0.0, bytes=D * K * 10),
     }
 
 
@@ -112,10 +121,12 @@ def price(name, launches, mean_ms, model):
     sec = mean_ms * 1e-3
     tf = model['flops'] / sec / 1e12 if sec > 0 else 0.0
     gbs = model['bytes'] / sec / 1e9 if sec > 0 else 0.0
-    t_mfma = model['flops'] / (PEAK_F32_TFLOPS * 1e12)
+    peak_tf = model.get('peak_tflops', PEAK_F32_TFLOPS)
+    mult = model.get('exec_mult', 1.0)
+    t_mfma = mult * model['flops'] / (peak_tf * 1e12)
     t_hbm = model['bytes'] / (PEAK_HBM_GBPS * 1e9)
     bound = 'mfma' if t_mfma >= t_hbm else 'hbm'
-    frac = tf / PEAK_F32_TFLOPS if bound == 'mfma' else gbs / PEAK_HBM_GBPS
+    frac = mult * tf / peak_tf if bound == 'mfma' else gbs / PEAK_HBM_GBPS
     return dict(kernel=name, launches=launches, us=round(mean_ms * 1e3, 2), bound=bound,
                 tflops=round(tf, 2), gbps=round(gbs, 1), frac=round(frac, 4))
 

@@ -22,7 +22,8 @@
 //                              4 waves along n, LDS tree reduce -> partial slabs
 //   finish_sum/norm_kernel     slabs + C*asum, intra-norm over D, global norm -> out
 // Backward kernels
-//   bwd_prep_kernel            grad through both norms -> dU (both layouts), c.dU
+//   bwd_dots/bwd_du_kernel     grad through both norms (closed form from four column dots)
+//                              -> dU (both layouts, + bf16 planes), c.dU
 //   rowtile16_kernel<DASSIGN>  x.dU[b] -> d a -> softmax backward -> ds, <dxhat,xhat>
 //   aggregate_kernel           x^T.(ds rn) -> per-image dW slabs
 //   dx16_kernel                [a | ds].[dU | W]^T and the l2-norm Jacobian -> grad_x
@@ -44,12 +45,23 @@ __global__ __launch_bounds__(256) void transpose_w_kernel(const float* __restric
   if (idx < D * K) wt[(idx % K) * D + idx / K] = w[idx];
 }
 
+// x = h1 + h2 + h3 exactly (up to the float32 subnormal range): three bf16 roundings.
+__device__ __forceinline__ void split3_bf16(float x, unsigned short& h1, unsigned short& h2,
+                                            unsigned short& h3) {
+  h1 = f32_to_bf16(x);
+  const float r1 = x - bf16_to_f32(h1);
+  h2 = f32_to_bf16(r1);
+  h3 = f32_to_bf16(r1 - bf16_to_f32(h2));
+}
+
 enum RowMode { ASSIGN = 0, DASSIGN = 1 };
 
 struct RowTileArgs {
   const void* x;       // [B,N,512]
   const float* bt;     // ASSIGN: Wt [64][512];  DASSIGN: dUt [B][64][512]
   int64_t bt_stride;   // floats between images (0 for ASSIGN)
+  const unsigned short* btp;   // bf16 input: the same operand as three bf16 planes [3][64][512]
+  int64_t btp_stride;          // elements between images (0 for ASSIGN)
   int B, N, pre_l2;
   // ASSIGN outputs
   float* assign;       // [B,N,64]
@@ -96,6 +108,127 @@ __device__ __forceinline__ float q16_max(float v) {
 #pragma unroll
   for (int m = 1; m < 16; m <<= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
   return v;
+}
+
+// Shared epilogue of the row-tile kernels: acc[kt][j] = raw contraction of row 4 g + j with
+// cluster 16 kt + i; ss = this lane's partial sum of squares of row i (ASSIGN only).
+template <int MODE>
+__device__ __forceinline__ void rowtile_epilogue(const RowTileArgs& p, f32x4 (&acc)[4], float ss,
+                                                 float* bt_lds, int b, int n0) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int n = n0 + i;
+  const bool row_ok = n < p.N;
+  // Epilogue I/O goes through a per-wave [16][68] LDS scratch (the operand buffers are free:
+  // every wave passed the last barrier) so each lane moves 16 bytes and 4 lanes cover one
+  // location's 64 clusters contiguously; accumulator-layout accesses would be 4 bytes per
+  // lane in 64-byte pieces (measured: 4.6 us of a 30 us kernel).
+  //   accumulator layout: value (row 4g+j, cluster 16kt+i);  row layout: lane -> row lane>>2,
+  //   cluster groups 4(4m + (lane&3)) .. +3 for m = 0..3
+  float* scr = bt_lds + wid * (16 * 68);
+  const int row_e = lane >> 2, seg = lane & 3;
+  const bool ok_e = n0 + row_e < p.N;
+  const int64_t o_e = ((int64_t)b * p.N + (ok_e ? n0 + row_e : 0)) * K + 4 * seg;
+  auto put_acc_layout = [&](const float (&v)[4][4]) {      // v[j][kt]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) scr[(4 * g + j) * 68 + 16 * kt + i] = v[j][kt];
+  };
+  auto get_acc_layout = [&](float (&v)[4][4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) v[j][kt] = scr[(4 * g + j) * 68 + 16 * kt + i];
+  };
+  auto store_rows = [&](float* dst) {                      // scratch -> global, 16 B per lane
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(&scr[row_e * 68 + 16 * m + 4 * seg]);
+      if (ok_e) *reinterpret_cast<f32x4*>(dst + o_e + 16 * m) = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+  auto load_rows = [&](const float* src_rows) {            // global -> scratch, 16 B per lane
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src_rows + o_e + 16 * m);
+      *reinterpret_cast<f32x4*>(&scr[row_e * 68 + 16 * m + 4 * seg]) =
+          ok_e ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  if (MODE == ASSIGN) {
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    const float rn = p.pre_l2 ? 1.0f / sqrtf(fmaxf(ss, 1e-12f)) : 1.0f;
+    if (g == 0 && row_ok) p.rnorm[(int64_t)b * p.N + n] = rn;
+    float av[4][4], sv[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float rnr = __shfl(rn, 4 * g + j, 64);
+      float m = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        sv[j][kt] = acc[kt][j] * rnr;
+        m = fmaxf(m, sv[j][kt]);
+      }
+      m = q16_max(m);
+      float sum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        av[j][kt] = expf(sv[j][kt] - m);
+        sum += av[j][kt];
+      }
+      const float inv = 1.0f / q16_sum(sum);
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) av[j][kt] *= inv;
+    }
+    put_acc_layout(av);
+    store_rows(p.assign);
+    if (p.logit) {
+      put_acc_layout(sv);
+      store_rows(p.logit);
+    }
+  } else {
+    float cd[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) cd[kt] = p.cdu[b * K + 16 * kt + i];
+    float a[4][4], lg[4][4], ds[4][4];
+    load_rows(p.a_in);
+    get_acc_layout(a);
+    load_rows(p.logit_in);
+    get_acc_layout(lg);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = 4 * g + j;
+      const bool ok = n0 + row < p.N;
+      const int64_t gr = (int64_t)b * p.N + (ok ? n0 + row : 0);
+      const float rnr = p.rn_in[gr];
+      float t[4];
+      float dot = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        t[kt] = acc[kt][j] * rnr;                         // xhat · dU
+        dot += a[j][kt] * (t[kt] + cd[kt]);               // + c · dU
+      }
+      dot = q16_sum(dot);
+      float rd = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        ds[j][kt] = a[j][kt] * ((t[kt] + cd[kt]) - dot);
+        // <d xhat[n,:], xhat[n,:]> = sum_k a (xhat·dU) + ds (xhat·W)
+        rd += a[j][kt] * t[kt] + ds[j][kt] * lg[j][kt];
+      }
+      rd = q16_sum(rd);
+      if (ok && i == 0) p.rowdot[gr] = rd;
+    }
+    put_acc_layout(ds);
+    store_rows(p.ds);
+  }
 }
 
 // grid (ceil(ceil(N/16) / 4), B); block 256: wave w owns 16-location tile 4 * blockIdx.x + w.
@@ -212,116 +345,147 @@ __global__ __launch_bounds__(256, 2) void rowtile16_kernel(RowTileArgs p) {
     return;
   }
 
-  // Epilogue I/O goes through a per-wave [16][68] LDS scratch (the operand buffers are free:
-  // every wave passed the last barrier) so each lane moves 16 bytes and 4 lanes cover one
-  // location's 64 clusters contiguously; accumulator-layout accesses would be 4 bytes per
-  // lane in 64-byte pieces (measured: 4.6 us of a 30 us kernel).
-  //   accumulator layout: value (row 4g+j, cluster 16kt+i);  row layout: lane -> row lane>>2,
-  //   cluster groups 4(4m + (lane&3)) .. +3 for m = 0..3
-  float* scr = bt_lds + wid * (16 * 68);
-  const int row_e = lane >> 2, seg = lane & 3;
-  const bool ok_e = n0 + row_e < p.N;
-  const int64_t o_e = ((int64_t)b * p.N + (ok_e ? n0 + row_e : 0)) * K + 4 * seg;
-  auto put_acc_layout = [&](const float (&v)[4][4]) {      // v[j][kt]
+  rowtile_epilogue<MODE>(p, acc, ss, bt_lds, b, n0);
+}
+
+// ---------------------------------------------------------------------------------------
+// rowtile16b_kernel: the same tile for a bf16 feature map on the bf16 matrix cores
+// (v_mfma_f32_16x16x32_bf16).  x is bf16 already; the float32 operand (W^T, or dU^T of the
+// image) arrives split into three bf16 planes o = o1 + o2 + o3 (24 mantissa bits), so every
+// product x * o_p is exact in float32 and x.o = x.o1 + x.o2 + x.o3 differs from the float32
+// contraction only by accumulation order — at 3 x 16 cycles per 16x16x32 step instead of
+// 8 x 32 cycles of 16x16x4 float32 steps, and with no bf16 -> f32 conversion of x at all.
+//   * planes [3][64][512] bf16 (per image for DASSIGN), staged in eight 64-channel chunks,
+//     double-buffered: LDS chunk image [3][64 rows][36 dwords] (32 data + 4 pad: the 16 lanes
+//     of a ds_read_b128 group hit 16 different 16-byte slots);
+//   * lane (i, g) feeds A with the 16 bytes x[n0 + i][32 s + 8 g .. +7] straight from HBM;
+//   * row norms by float32 FMAs on the same registers.
+constexpr int RB_CH = 64;                       // channels per staged chunk
+constexpr int RB_PLANE = K * RT_LD;             // dwords per plane of a chunk (64 x 36)
+constexpr int RB_CHUNK = 3 * RB_PLANE;          // 6912 dwords per buffer
+constexpr size_t kRowTileB3Lds = 2 * (size_t)RB_CHUNK * sizeof(float);   // 55,296 B
+static_assert(kRowTileB3Lds >= 4 * 16 * 68 * sizeof(float), "epilogue scratch must fit");
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x4 mfma16b(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                 __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// W [512][64] float32 -> planes [3][64][512] bf16 of W^T.  grid 128, block 256.
+__global__ __launch_bounds__(256) void split_w_kernel(const float* __restrict__ w,
+                                                      unsigned short* __restrict__ planes) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;  // over D*K, k fastest (coalesced read)
+  if (idx >= D * K) return;
+  unsigned short h1, h2, h3;
+  split3_bf16(w[idx], h1, h2, h3);
+  const int o = (idx % K) * D + idx / K;
+  planes[o] = h1;
+  planes[D * K + o] = h2;
+  planes[2 * D * K + o] = h3;
+}
+
+// grid (ceil(ceil(N/16) / 4), B); block 256: wave w owns 16-location tile 4 * blockIdx.x + w.
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void rowtile16b_kernel(RowTileArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float bt_lds[];  // [2][3][64][RT_LD] dwords
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int b = blockIdx.y;
+  const int n0 = (blockIdx.x * 4 + wid) * 16;
+  const bool active = n0 < p.N;          // wave-uniform; idle waves still stage and sync
+  const int n = n0 + i;
+  const bool row_ok = n < p.N;
+  const unsigned short* src = p.btp + (int64_t)b * p.btp_stride;
+  const unsigned short* xrow = reinterpret_cast<const unsigned short*>(p.x) +
+                               ((int64_t)b * p.N + (row_ok ? n : 0)) * D + 8 * g;
+
+  // operand staging: 3 planes x 64 rows x 8 sixteen-byte pieces per chunk, 6 per thread
+  u32x4 st[6];
+  auto stage_load = [&](int chunk) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt) scr[(4 * g + j) * 68 + 16 * kt + i] = v[j][kt];
-  };
-  auto get_acc_layout = [&](float (&v)[4][4]) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt) v[j][kt] = scr[(4 * g + j) * 68 + 16 * kt + i];
-  };
-  auto store_rows = [&](float* dst) {                      // scratch -> global, 16 B per lane
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(&scr[row_e * 68 + 16 * m + 4 * seg]);
-      if (ok_e) *reinterpret_cast<f32x4*>(dst + o_e + 16 * m) = v;
+    for (int v = 0; v < 6; ++v) {
+      const int idx = v * 256 + threadIdx.x;
+      const int plane = idx >> 9, row = (idx >> 3) & 63, c = idx & 7;
+      st[v] = *reinterpret_cast<const u32x4*>(src + (int64_t)plane * D * K + row * D +
+                                              chunk * RB_CH + c * 8);
     }
-    __builtin_amdgcn_wave_barrier();
   };
-  auto load_rows = [&](const float* src_rows) {            // global -> scratch, 16 B per lane
-    __builtin_amdgcn_wave_barrier();
+  auto stage_store = [&](int buf) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(src_rows + o_e + 16 * m);
-      *reinterpret_cast<f32x4*>(&scr[row_e * 68 + 16 * m + 4 * seg]) =
-          ok_e ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int v = 0; v < 6; ++v) {
+      const int idx = v * 256 + threadIdx.x;
+      const int plane = idx >> 9, row = (idx >> 3) & 63, c = idx & 7;
+      *reinterpret_cast<u32x4*>(&bt_lds[buf * RB_CHUNK + plane * RB_PLANE + row * RT_LD + 4 * c]) =
+          st[v];
     }
-    __builtin_amdgcn_wave_barrier();
+  };
+  u32x4 xc[2], xn[2];
+  auto x_load = [&](int chunk, u32x4* dst) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+      dst[s2] = *reinterpret_cast<const u32x4*>(xrow + chunk * RB_CH + 32 * s2);
   };
 
-  if (MODE == ASSIGN) {
-    ss += __shfl_xor(ss, 16, 64);
-    ss += __shfl_xor(ss, 32, 64);
-    const float rn = p.pre_l2 ? 1.0f / sqrtf(fmaxf(ss, 1e-12f)) : 1.0f;
-    if (g == 0 && row_ok) p.rnorm[(int64_t)b * p.N + n] = rn;
-    float av[4][4], sv[4][4];
+  f32x4 acc[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float rnr = __shfl(rn, 4 * g + j, 64);
-      float m = -INFINITY;
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt) {
-        sv[j][kt] = acc[kt][j] * rnr;
-        m = fmaxf(m, sv[j][kt]);
-      }
-      m = q16_max(m);
-      float sum = 0.f;
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt) {
-        av[j][kt] = expf(sv[j][kt] - m);
-        sum += av[j][kt];
-      }
-      const float inv = 1.0f / q16_sum(sum);
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt) av[j][kt] *= inv;
+  for (int kt = 0; kt < 4; ++kt) acc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float ss = 0.f;
+
+  stage_load(0);
+  if (active) x_load(0, xc);
+  stage_store(0);
+  __syncthreads();
+#pragma unroll 1
+  for (int c = 0; c < D / RB_CH; ++c) {
+    const bool more = c + 1 < D / RB_CH;
+    if (more) {
+      stage_load(c + 1);
+      if (active) x_load(c + 1, xn);
     }
-    put_acc_layout(av);
-    store_rows(p.assign);
-    if (p.logit) {
-      put_acc_layout(sv);
-      store_rows(p.logit);
-    }
-  } else {
-    float cd[4];
+    if (active) {
+      const float* wb = &bt_lds[(c & 1) * RB_CHUNK + i * RT_LD + 4 * g];
+      // fragments of the next (k-step, cluster tile) are in flight under this one's MFMAs
+      u32x4 wv[2][3];
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) cd[kt] = p.cdu[b * K + 16 * kt + i];
-    float a[4][4], lg[4][4], ds[4][4];
-    load_rows(p.a_in);
-    get_acc_layout(a);
-    load_rows(p.logit_in);
-    get_acc_layout(lg);
+      for (int pl = 0; pl < 3; ++pl) wv[0][pl] = *reinterpret_cast<const u32x4*>(wb + pl * RB_PLANE);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = 4 * g + j;
-      const bool ok = n0 + row < p.N;
-      const int64_t gr = (int64_t)b * p.N + (ok ? n0 + row : 0);
-      const float rnr = p.rn_in[gr];
-      float t[4];
-      float dot = 0.f;
+      for (int q = 0; q < 8; ++q) {            // q = 4 * k-step + cluster tile
+        const int s2 = q >> 2, kt = q & 3;
+        u32x4 xa = xc[s2];
+        if (!row_ok) xa = u32x4{0u, 0u, 0u, 0u};
+        if (q + 1 < 8) {
+          const int s3 = (q + 1) >> 2, kt3 = (q + 1) & 3;
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt) {
-        t[kt] = acc[kt][j] * rnr;                         // xhat · dU
-        dot += a[j][kt] * (t[kt] + cd[kt]);               // + c · dU
+          for (int pl = 0; pl < 3; ++pl)
+            wv[(q + 1) & 1][pl] = *reinterpret_cast<const u32x4*>(
+                wb + pl * RB_PLANE + kt3 * 16 * RT_LD + 16 * s3);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) acc[kt] = mfma16b(xa, wv[q & 1][pl], acc[kt]);
+        if (MODE == ASSIGN && kt == 0) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            // (v_dot2c_f32_bf16 measured 2-7 % off on these sums: plain f32 FMAs instead)
+            const float lo = __uint_as_float(xa[e] << 16), hi = __uint_as_float(xa[e] & 0xffff0000u);
+            ss = fmaf(lo, lo, ss);
+            ss = fmaf(hi, hi, ss);
+          }
+        }
       }
-      dot = q16_sum(dot);
-      float rd = 0.f;
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt) {
-        ds[j][kt] = a[j][kt] * ((t[kt] + cd[kt]) - dot);
-        // <d xhat[n,:], xhat[n,:]> = sum_k a (xhat·dU) + ds (xhat·W)
-        rd += a[j][kt] * t[kt] + ds[j][kt] * lg[j][kt];
-      }
-      rd = q16_sum(rd);
-      if (ok && i == 0) p.rowdot[gr] = rd;
     }
-    put_acc_layout(ds);
-    store_rows(p.ds);
+    if (more) stage_store((c + 1) & 1);
+    __syncthreads();
+    if (more) {
+      xc[0] = xn[0];
+      xc[1] = xn[1];
+    }
   }
+  if (!active) return;
+  rowtile_epilogue<MODE>(p, acc, ss, bt_lds, b, n0);
 }
 
 // V_part[b, half, d, k] = sum_{n in half} x[b,n,d] * (coefn[b,n,k] * rn[b,n])
@@ -457,37 +621,6 @@ __global__ __launch_bounds__(256) void aggregate_kernel(const void* __restrict__
 }
 
 // per-image normalisation state shared by finish (forward) and bwd_prep (backward)
-struct VladNorm {
-  float u[32];   // this thread's 32 elements: d = dg*32 + i, k = threadIdx % 64
-  float q;       // intra-norm factor of column k
-  float g;       // global factor
-};
-
-// block 1024: thread -> k = t & 63, dg = t >> 6 (16 groups of 32 channels)
-__device__ __forceinline__ void vlad_norms(VladNorm& v, float* colbuf /*[16][64]*/,
-                                           float* scratch) {
-  const int k = threadIdx.x & 63, dg = threadIdx.x >> 6;
-  float ss = 0.f;
-#pragma unroll
-  for (int i = 0; i < 32; ++i) ss = fmaf(v.u[i], v.u[i], ss);
-  colbuf[dg * 64 + k] = ss;
-  __syncthreads();
-  float col = 0.f;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) col += colbuf[j * 64 + k];
-  __syncthreads();
-  // matconvnetNormalize: x / sqrt(sum x^2 + 1e-12), epsilon inside the sqrt
-  v.q = 1.0f / sqrtf(col + 1e-12f);
-  float tot = 0.f;
-#pragma unroll
-  for (int i = 0; i < 32; ++i) {
-    const float vn = v.u[i] * v.q;
-    tot = fmaf(vn, vn, tot);
-  }
-  tot = block_reduce<0>(tot, scratch);
-  v.g = 1.0f / sqrtf(tot + 1e-12f);
-}
-
 // Forward finish in two small launches of 8 x B workgroups (a single workgroup per image
 // left 232 CUs idle and took 3x longer):
 //   finish_sum_kernel   U = slabs + C * asum for one 64-channel block -> vlad[b] (the saved
@@ -543,62 +676,103 @@ __global__ __launch_bounds__(256) void finish_norm_kernel(const float* __restric
   }
 }
 
-// grid B; block 1024.  Gradient through the global and the intra normalisation.
-__global__ __launch_bounds__(1024) void bwd_prep_kernel(const float* __restrict__ save_vlad,
-                                                        const float* __restrict__ grad_out,
-                                                        const float* __restrict__ centers,
-                                                        float* __restrict__ du,
-                                                        float* __restrict__ dut,
-                                                        float* __restrict__ cdu) {
-  __shared__ float colbuf[16 * 64];
-  __shared__ float scratch[32];
-  const int b = blockIdx.x, k = threadIdx.x & 63, dg = threadIdx.x >> 6;
-  VladNorm v;
+// Gradient through the global and the intra normalisation, in closed form from four column
+// dots so that 8 x B workgroups can work on an image (one 1024-thread workgroup per image
+// took 17.7 us at B = 24).  With U the pre-norm VLAD, q_k = rsqrt(col_k + eps),
+// Vn = U q, g = rsqrt(sum_k q_k^2 col_k + eps), out = Vn g and go = d loss / d out:
+//   A_k = sum_d go U,  col_k = sum_d U^2,  Bc_k = sum_d go C,  Dc_k = sum_d U C
+//   S1 = sum_k q_k A_k                       (= <go, Vn>)
+//   r_k = g (q_k A_k - g^2 S1 q_k^2 col_k)   (= <dVn, Vn>_k)
+//   dU  = q_k g go - q_k^2 (g^3 S1 + r_k) U
+//   c.dU_k = q_k g Bc_k - q_k^2 (g^3 S1 + r_k) Dc_k
+// bwd_dots_kernel: grid (8, B), block 256 (k = t & 63, dq = t >> 6): the four partial dots of
+// one 64-channel block -> dots[b][blk][4][64].
+__global__ __launch_bounds__(256) void bwd_dots_kernel(const float* __restrict__ save_vlad,
+                                                       const float* __restrict__ grad_out,
+                                                       const float* __restrict__ centers,
+                                                       float* __restrict__ dots) {
+  __shared__ float buf[4][4 * 64];
+  const int blk = blockIdx.x, b = blockIdx.y, k = threadIdx.x & 63, dq = threadIdx.x >> 6;
+  float sa = 0.f, sc = 0.f, sb = 0.f, sd = 0.f;
 #pragma unroll
-  for (int i = 0; i < 32; ++i) v.u[i] = save_vlad[((int64_t)b * (D + 1) + dg * 32 + i) * K + k];
-  vlad_norms(v, colbuf, scratch);
-  float go[32];
-  float t = 0.f;
-#pragma unroll
-  for (int i = 0; i < 32; ++i) {
-    go[i] = grad_out[(int64_t)b * D * K + (dg * 32 + i) * K + k];
-    t = fmaf(go[i], v.u[i] * v.q * v.g, t);
+  for (int i = 0; i < 16; ++i) {
+    const int d = blk * 64 + dq * 16 + i;
+    const float u = save_vlad[((int64_t)b * (D + 1) + d) * K + k];
+    const float go = grad_out[(int64_t)b * D * K + d * K + k];
+    const float c = centers[d * K + k];
+    sa = fmaf(go, u, sa);
+    sc = fmaf(u, u, sc);
+    sb = fmaf(go, c, sb);
+    sd = fmaf(u, c, sd);
   }
-  t = block_reduce<0>(t, scratch);
-  // out = Vn g, g = (sum Vn^2 + eps)^-1/2  ->  dVn = g (dOut - out <dOut,out>)
-  float rk = 0.f;
+  buf[0][dq * 64 + k] = sa;
+  buf[1][dq * 64 + k] = sc;
+  buf[2][dq * 64 + k] = sb;
+  buf[3][dq * 64 + k] = sd;
+  __syncthreads();
+  // wave dq finishes dot number dq
+  const float* src = buf[dq];
+  dots[(((int64_t)b * 8 + blk) * 4 + dq) * K + k] =
+      (src[k] + src[64 + k]) + (src[128 + k] + src[192 + k]);
+}
+
+// bwd_du_kernel: grid (8, B), block 256: dU of one 64-channel block in both layouts (and as
+// three bf16 planes of dU^T when dplanes != NULL), c.dU from block 0.
+__global__ __launch_bounds__(256) void bwd_du_kernel(const float* __restrict__ save_vlad,
+                                                     const float* __restrict__ grad_out,
+                                                     const float* __restrict__ dots,
+                                                     float* __restrict__ du,
+                                                     float* __restrict__ dut,
+                                                     unsigned short* __restrict__ dplanes,
+                                                     float* __restrict__ cdu) {
+  const int blk = blockIdx.x, b = blockIdx.y, k = threadIdx.x & 63, dq = threadIdx.x >> 6;
+  float dot[4];
 #pragma unroll
-  for (int i = 0; i < 32; ++i) {
-    const float vn = v.u[i] * v.q;
-    go[i] = v.g * (go[i] - vn * v.g * t);
-    rk = fmaf(go[i], vn, rk);
-  }
-  __syncthreads();
-  colbuf[dg * 64 + k] = rk;
-  __syncthreads();
-  float r = 0.f;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) r += colbuf[j * 64 + k];
-  __syncthreads();
-  // Vn[:,k] = U[:,k] q_k  ->  dU = q (dVn - Vn <dVn,Vn>_k)
-  float cd = 0.f;
-#pragma unroll
-  for (int i = 0; i < 32; ++i) {
-    const int d = dg * 32 + i;
-    const float vn = v.u[i] * v.q;
-    const float val = v.q * (go[i] - vn * r);
-    du[((int64_t)b * D + d) * K + k] = val;
-    dut[((int64_t)b * K + k) * D + d] = val;
-    cd = fmaf(val, centers[d * K + k], cd);
-  }
-  colbuf[dg * 64 + k] = cd;
-  __syncthreads();
-  if (dg == 0) {
+  for (int j = 0; j < 4; ++j) {
     float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) s += colbuf[j * 64 + k];
-    cdu[b * K + k] = s;
+    for (int bl = 0; bl < 8; ++bl) s += dots[(((int64_t)b * 8 + bl) * 4 + j) * K + k];
+    dot[j] = s;
   }
+  const float ak = dot[0], col = dot[1], bk = dot[2], dk = dot[3];
+  const float q = 1.0f / sqrtf(col + 1e-12f);
+  const float tot = wave_sum(q * q * col);
+  const float g = 1.0f / sqrtf(tot + 1e-12f);
+  const float s1 = wave_sum(q * ak);
+  const float r = g * (q * ak - g * g * s1 * q * q * col);
+  const float cu = q * q * (g * g * g * s1 + r);   // coefficient of U
+  const float cg = q * g;                          // coefficient of go
+  float vals[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int d = blk * 64 + dq * 16 + i;
+    const float u = save_vlad[((int64_t)b * (D + 1) + d) * K + k];
+    const float go = grad_out[(int64_t)b * D * K + d * K + k];
+    vals[i] = cg * go - cu * u;
+    du[((int64_t)b * D + d) * K + k] = vals[i];
+  }
+  // transposed copy: 16 consecutive channels of cluster k
+  float* trow = dut + ((int64_t)b * K + k) * D + blk * 64 + dq * 16;
+#pragma unroll
+  for (int i = 0; i < 16; i += 4)
+    *reinterpret_cast<f32x4*>(trow + i) = f32x4{vals[i], vals[i + 1], vals[i + 2], vals[i + 3]};
+  if (dplanes) {
+    unsigned short h[3][16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) split3_bf16(vals[i], h[0][i], h[1][i], h[2][i]);
+    unsigned short* prow = dplanes + (int64_t)b * 3 * D * K + k * D + blk * 64 + dq * 16;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      unsigned w[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        w[i] = (unsigned)h[pl][2 * i] | ((unsigned)h[pl][2 * i + 1] << 16);
+      uint4* o = reinterpret_cast<uint4*>(prow + (int64_t)pl * D * K);
+      o[0] = make_uint4(w[0], w[1], w[2], w[3]);
+      o[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+  }
+  if (blk == 0 && dq == 0) cdu[b * K + k] = cg * bk - cu * dk;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -848,6 +1022,21 @@ void launch_rowtile(const RowTileArgs& a, hipStream_t st) {
              grid, dim3(256), kRowTile16Lds, st, a);
 }
 
+// bf16 feature maps: the bf16x3 kernel (scl_debug_set_variant(8) forces the float32-MFMA
+// kernel on them for A/B timing and parity runs)
+template <int MODE>
+void launch_rowtile_b3(const RowTileArgs& a, hipStream_t st) {
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowtile16b_kernel<MODE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRowTileB3Lds);
+  });
+  const int tiles16 = (a.N + 15) / 16;
+  SCL_LAUNCH(MODE == ASSIGN ? "rowtile_assign" : "rowtile_dassign", (rowtile16b_kernel<MODE>),
+             dim3((tiles16 + 3) / 4, a.B), dim3(256), kRowTileB3Lds, st, a);
+}
+inline bool use_b3() { return scl_debug_variant < 1 || scl_debug_variant > 8; }
+
 struct Carver {
   char* base;
   size_t off = 0;
@@ -861,6 +1050,7 @@ struct Carver {
 
 struct FwdWs {
   float *wt, *part, *colsum, *colsq, *vlad, *assign, *rnorm;
+  unsigned short* wplanes;   // [3][64][512] bf16
   size_t total;
 };
 inline FwdWs carve_fwd(void* ws, int B, int N) {
@@ -873,12 +1063,14 @@ inline FwdWs carve_fwd(void* ws, int B, int N) {
   w.vlad = c.take((size_t)B * (D + 1) * K);
   w.assign = c.take((size_t)B * N * K);
   w.rnorm = c.take((size_t)B * N);
+  w.wplanes = (unsigned short*)c.take((size_t)3 * D * K / 2);
   w.total = c.off;
   return w;
 }
 
 struct BwdWs {
-  float *du, *dut, *cdu, *ds, *rowdot, *wpart;
+  float *du, *dut, *cdu, *ds, *rowdot, *wpart, *dots;
+  unsigned short* dplanes;   // [B][3][64][512] bf16
   size_t total;
 };
 inline BwdWs carve_bwd(void* ws, int B, int N) {
@@ -890,6 +1082,8 @@ inline BwdWs carve_bwd(void* ws, int B, int N) {
   w.ds = c.take((size_t)B * N * K);
   w.rowdot = c.take((size_t)B * N);
   w.wpart = c.take((size_t)B * NSPLIT * D * K);
+  w.dplanes = (unsigned short*)c.take((size_t)B * 3 * D * K / 2);
+  w.dots = c.take((size_t)B * 8 * 4 * K);
   w.total = c.off;
   return w;
 }
@@ -935,7 +1129,15 @@ extern "C" int scl_netvlad_fwd(const void* x, int x_dtype, const float* assign_w
     SCL_LAUNCH("aggregate_kernel", aggregate_kernel<float>, dim3(D / 64, NSPLIT, B), dim3(256), 0, st, x,
                        (const float*)assign, (const float*)rnorm, N, w.part, w.colsum);
   } else {
-    launch_rowtile<unsigned short, ASSIGN>(a, st);
+    if (use_b3()) {
+      SCL_LAUNCH("split_w_kernel", split_w_kernel, dim3(D * K / 256), dim3(256), 0, st, assign_w,
+                 w.wplanes);
+      a.btp = w.wplanes;
+      a.btp_stride = 0;
+      launch_rowtile_b3<ASSIGN>(a, st);
+    } else {
+      launch_rowtile<unsigned short, ASSIGN>(a, st);
+    }
     SCL_LAUNCH("aggregate_kernel", aggregate_kernel<unsigned short>, dim3(D / 64, NSPLIT, B), dim3(256), 0, st,
                        x, (const float*)assign, (const float*)rnorm, N, w.part, w.colsum);
   }
@@ -969,8 +1171,11 @@ extern "C" int scl_netvlad_bwd(const void* x, int x_dtype, const float* assign_w
   if (workspace_bytes < w.total) return SCL_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
 
-  SCL_LAUNCH("bwd_prep_kernel", bwd_prep_kernel, dim3(B), dim3(1024), 0, st, save_vlad, grad_out, centers,
-                     w.du, w.dut, w.cdu);
+  const bool b3 = x_dtype == SCL_DT_BF16 && use_b3();
+  SCL_LAUNCH("bwd_dots_kernel", bwd_dots_kernel, dim3(8, B), dim3(256), 0, st, save_vlad, grad_out,
+             centers, w.dots);
+  SCL_LAUNCH("bwd_du_kernel", bwd_du_kernel, dim3(8, B), dim3(256), 0, st, save_vlad, grad_out,
+             (const float*)w.dots, w.du, w.dut, b3 ? w.dplanes : (unsigned short*)nullptr, w.cdu);
   RowTileArgs a{};
   a.x = x;
   a.bt = w.dut;
@@ -993,7 +1198,13 @@ extern "C" int scl_netvlad_bwd(const void* x, int x_dtype, const float* assign_w
                        (const float*)w.ds, save_rnorm, (const float*)w.rowdot,
                        (const float*)w.du, assign_w, N, pre_l2 ? 1 : 0, grad_x);
   } else {
-    launch_rowtile<unsigned short, DASSIGN>(a, st);
+    if (b3) {
+      a.btp = w.dplanes;
+      a.btp_stride = (int64_t)3 * D * K;
+      launch_rowtile_b3<DASSIGN>(a, st);
+    } else {
+      launch_rowtile<unsigned short, DASSIGN>(a, st);
+    }
     SCL_LAUNCH("aggregate_dw", aggregate_kernel<unsigned short>, dim3(D / 64, NSPLIT, B), dim3(256), 0, st,
                        x, (const float*)w.ds, save_rnorm, N, w.wpart, (float*)nullptr);
     SCL_LAUNCH("dx_kernel", dx16_kernel<unsigned short>, dxgrid, dim3(256), kDx16Lds, st, x, save_assign,
