@@ -66,25 +66,27 @@ def kernel_models(b, n, gb, x_bytes):
     """Algorithmic flops / bytes per LAUNCH of each hand-written kernel.
     b = images on this GPU, n = locations per image, gb = global batch."""
     bn = b * n
-    # bf16 feature maps: the row-tile contractions run as three bf16 MFMAs per step (x exact,
-    # the float32 operand split into three bf16 planes) -> priced against the bf16 dense peak
-    # with 3x the algorithmic flops executed
+    # bf16 feature maps: the NetVLAD contractions run as three bf16 MFMAs per step (x exact and
+    # the float32 operand split into three bf16 planes; two planes each in the grad_x kernel)
+    # -> priced against the bf16 dense peak with 3x the algorithmic flops executed
     b3 = dict(peak_tflops=PEAK_BF16_TFLOPS, exec_mult=3.0) if x_bytes == 2 else {}
     return {
         # x·W over all locations; reads x once, writes a (+ logits) and rn
         'rowtile_assign': dict(flops=2.0 * bn * D * K, bytes=bn * D * x_bytes + bn * K * 8 + bn * 4,
                                **b3),
         # x^T·(a rn); reads x and a once, writes 2 slabs per image
-        'aggregate_kernel': dict(flops=2.0 * bn * D * K, bytes=bn * D * x_bytes + bn * K * 4 + b * 2 * D * K * 4),
+        'aggregate_kernel': dict(flops=2.0 * bn * D * K,
+                                 bytes=bn * D * x_bytes + bn * K * 4 + b * 2 * D * K * 4, **b3),
         'finish_sum_kernel': dict(flops=6.0 * b * D * K, bytes=b * D * K * 4 * 6),
         'finish_norm_kernel': dict(flops=2.0 * b * D * K, bytes=b * D * K * 4 * 2),
         'bwd_dots_kernel': dict(flops=8.0 * b * D * K, bytes=b * D * K * 4 * 2),
         'bwd_du_kernel': dict(flops=4.0 * b * D * K, bytes=b * D * K * 4 * 4),
         'rowtile_dassign': dict(flops=2.0 * bn * D * K,
                                 bytes=bn * D * x_bytes + bn * K * 12 + b * D * K * 4, **b3),
-        'aggregate_dw': dict(flops=2.0 * bn * D * K, bytes=bn * D * x_bytes + bn * K * 4 + b * 2 * D * K * 4),
+        'aggregate_dw': dict(flops=2.0 * bn * D * K,
+                             bytes=bn * D * x_bytes + bn * K * 4 + b * 2 * D * K * 4, **b3),
         # [a|ds]·[dU|W]^T then the norm Jacobian; reads x, writes grad_x
-        'dx_kernel': dict(flops=4.0 * bn * D * K, bytes=2 * bn * D * x_bytes + bn * K * 8),
+        'dx_kernel': dict(flops=4.0 * bn * D * K, bytes=2 * bn * D * x_bytes + bn * K * 8, **b3),
         'wgrad_finish_kernel': dict(flops=4.0 * b * D * K, bytes=b * D * K * 12),
         # loss: raw Gram (upper-triangular 32x32 tiles), reads E once
         'gram_partial_kernel': dict(flops=2.0 * gb * gb * E, bytes=gb * E * 4),

@@ -62,6 +62,10 @@ struct RowTileArgs {
   int64_t bt_stride;   // floats between images (0 for ASSIGN)
   const unsigned short* btp;   // bf16 input: the same operand as three bf16 planes [3][64][512]
   int64_t btp_stride;          // elements between images (0 for ASSIGN)
+  // bf16 input: operands for aggregate16b_kernel, written by the epilogue (NULL: not wanted)
+  unsigned short* cft;         // [B][NT][3][64][16] bf16 planes of (a or ds) * rn, n fastest
+  float* colpart;              // ASSIGN: [B][NT][64] per-tile sums of a over valid rows
+  int NT;                      // ceil(N / 16)
   int B, N, pre_l2;
   // ASSIGN outputs
   float* assign;       // [B,N,64]
@@ -161,15 +165,36 @@ __device__ __forceinline__ void rowtile_epilogue(const RowTileArgs& p, f32x4 (&a
     __builtin_amdgcn_wave_barrier();
   };
 
+  // (a or ds) * rn of this tile as three bf16 planes [plane][cluster][16 n]: lane (i, g) owns
+  // rows 4g .. 4g+3 of cluster 16 kt + i -> one 8-byte store, 512 contiguous bytes per wave
+  auto put_cft = [&](const float (&v)[4][4], const float (&rrow)[4]) {
+    unsigned short* base = p.cft + ((int64_t)b * p.NT + (n0 >> 4)) * 3 * K * 16;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      unsigned short h[3][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float cf = n0 + 4 * g + j < p.N ? v[j][kt] * rrow[j] : 0.f;
+        split3_bf16(cf, h[0][j], h[1][j], h[2][j]);
+      }
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        *reinterpret_cast<uint2*>(base + (pl * K + 16 * kt + i) * 16 + 4 * g) =
+            make_uint2((unsigned)h[pl][0] | ((unsigned)h[pl][1] << 16),
+                       (unsigned)h[pl][2] | ((unsigned)h[pl][3] << 16));
+    }
+  };
+
   if (MODE == ASSIGN) {
     ss += __shfl_xor(ss, 16, 64);
     ss += __shfl_xor(ss, 32, 64);
     const float rn = p.pre_l2 ? 1.0f / sqrtf(fmaxf(ss, 1e-12f)) : 1.0f;
     if (g == 0 && row_ok) p.rnorm[(int64_t)b * p.N + n] = rn;
-    float av[4][4], sv[4][4];
+    float av[4][4], sv[4][4], rrow[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float rnr = __shfl(rn, 4 * g + j, 64);
+      rrow[j] = rnr;
       float m = -INFINITY;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
@@ -187,6 +212,18 @@ __device__ __forceinline__ void rowtile_epilogue(const RowTileArgs& p, f32x4 (&a
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) av[j][kt] *= inv;
     }
+    if (p.cft) {
+      put_cft(av, rrow);
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        float cs = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cs += n0 + 4 * g + j < p.N ? av[j][kt] : 0.f;
+        cs += __shfl_xor(cs, 16, 64);
+        cs += __shfl_xor(cs, 32, 64);
+        if (g == 0) p.colpart[((int64_t)b * p.NT + (n0 >> 4)) * K + 16 * kt + i] = cs;
+      }
+    }
     put_acc_layout(av);
     store_rows(p.assign);
     if (p.logit) {
@@ -197,7 +234,7 @@ __device__ __forceinline__ void rowtile_epilogue(const RowTileArgs& p, f32x4 (&a
     float cd[4];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) cd[kt] = p.cdu[b * K + 16 * kt + i];
-    float a[4][4], lg[4][4], ds[4][4];
+    float a[4][4], lg[4][4], ds[4][4], rrow[4];
     load_rows(p.a_in);
     get_acc_layout(a);
     load_rows(p.logit_in);
@@ -208,6 +245,7 @@ __device__ __forceinline__ void rowtile_epilogue(const RowTileArgs& p, f32x4 (&a
       const bool ok = n0 + row < p.N;
       const int64_t gr = (int64_t)b * p.N + (ok ? n0 + row : 0);
       const float rnr = p.rn_in[gr];
+      rrow[j] = rnr;
       float t[4];
       float dot = 0.f;
 #pragma unroll
@@ -226,6 +264,7 @@ __device__ __forceinline__ void rowtile_epilogue(const RowTileArgs& p, f32x4 (&a
       rd = q16_sum(rd);
       if (ok && i == 0) p.rowdot[gr] = rd;
     }
+    if (p.cft) put_cft(ds, rrow);
     put_acc_layout(ds);
     store_rows(p.ds);
   }
@@ -621,6 +660,154 @@ __global__ __launch_bounds__(256) void aggregate_kernel(const void* __restrict__
 }
 
 // per-image normalisation state shared by finish (forward) and bwd_prep (backward)
+// ---------------------------------------------------------------------------------------
+// aggregate16b_kernel: V_part[b, split, d, k] = sum_{n in split} x[b,n,d] cf[b,n,k] for a bf16
+// feature map on v_mfma_f32_16x16x32_bf16, cf = (a or ds) * rn as the three bf16 planes the
+// row-tile epilogue wrote ([tile of 16 n][plane][cluster][n], so a B fragment — 8 consecutive
+// n of one cluster — is 16 contiguous bytes).  The contraction runs over n, the SLOW index
+// of x[n][d]: each wave stages its [32 n][64 d] piece of x row-major in LDS and reads the A
+// fragments with ds_read_b64_tr_b16 (4 rows x 16 columns delivered column-major).
+// grid (2 channel halves, NSPLIT, B); block 256: the four waves share a 32-location step
+// (its cf planes are staged once per workgroup) and own 64 channels each, so no cross-wave
+// reduction is needed.  LDS: 2 x ([3][64][40] cf + 4 x [32][72] x) bf16 = 67,584 B.
+constexpr int AB_XLD = 72;                                 // bf16 per staged x row (64 + 8 pad)
+constexpr int AB_CFLD = 40;                                // bf16 per staged cf row (32 n + 8 pad:
+                                                           // 16 lanes -> 16 different 16-B slots)
+constexpr int AB_CF = 3 * K * AB_CFLD;                     // bf16 per staged cf step
+constexpr int AB_X = 32 * AB_XLD;                          // bf16 per wave x tile
+constexpr int AB_BUF = AB_CF + 4 * AB_X;                   // bf16 per buffer
+constexpr size_t kAgg16bLds = 2 * (size_t)AB_BUF * sizeof(unsigned short);   // 67,584 B
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256, 2) void aggregate16b_kernel(
+    const unsigned short* __restrict__ x, const unsigned short* __restrict__ cft,
+    const float* __restrict__ colpart, int N, int NT, float* __restrict__ part,
+    float* __restrict__ colsum_part) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short ab_lds[];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int half = blockIdx.x, split = blockIdx.y, b = blockIdx.z;
+  const int d0 = half * 256 + wid * 64;                    // this wave's 64 channels
+  const int nsteps = (N + 31) / 32;
+  const int per = (nsteps + NSPLIT - 1) / NSPLIT;
+  const int s_begin = split * per;
+  const int s_end = s_begin + per < nsteps ? s_begin + per : nsteps;
+
+  // staging registers: 3 sixteen-byte pieces of the cf planes, 4 of the wave's x tile
+  u32x4 st_cf[3], st_x[4];
+  auto stage_load = [&](int s) {
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      const int idx = v * 256 + threadIdx.x;               // 768 pieces: [tile 2][plane 3][k 64][2]
+      const int tl = idx / 384, rem = idx % 384;           // rem = (plane * 64 + k) * 2 + h8
+      const int tile = 2 * s + tl;
+      st_cf[v] = tile < NT ? *reinterpret_cast<const u32x4*>(
+                                 cft + (((int64_t)b * NT + tile) * 3 * K * 16) + rem * 8)
+                           : u32x4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int idx = v * 64 + lane;                       // 256 pieces: [row 32][8]
+      int n = 32 * s + (idx >> 3);
+      if (n >= N) n = N - 1;                               // cf is zero there
+      st_x[v] = *reinterpret_cast<const u32x4*>(x + ((int64_t)b * N + n) * D + d0 + 8 * (idx & 7));
+    }
+  };
+  auto stage_store = [&](int buf) {
+    unsigned short* cfb = ab_lds + buf * AB_BUF;
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      const int idx = v * 256 + threadIdx.x;
+      const int tl = idx / 384, rem = idx % 384;
+      const int row = rem >> 1, h8 = rem & 1;              // row = plane * 64 + k
+      // staged as [plane * 64 + k][32 n (+ pad)]: tile tl holds n 16 tl .. 16 tl + 15
+      *reinterpret_cast<u32x4*>(cfb + row * AB_CFLD + 16 * tl + 8 * h8) = st_cf[v];
+    }
+    unsigned short* xb = cfb + AB_CF + wid * AB_X;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int idx = v * 64 + lane;
+      *reinterpret_cast<u32x4*>(xb + (idx >> 3) * AB_XLD + 8 * (idx & 7)) = st_x[v];
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) acc[mt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // column sums of a over this split's tiles (forward only): wave w takes tiles t0 + w + 4 j;
+  // the loads fly under the main loop, the four partials are combined in a fixed order below
+  float cs_part = 0.f;
+  const bool want_cs = colsum_part != nullptr && half == 0;
+  if (want_cs) {
+    const int t_end = 2 * s_end < NT ? 2 * s_end : NT;
+    for (int t = 2 * s_begin + wid; t < t_end; t += 4)
+      cs_part += colpart[((int64_t)b * NT + t) * K + lane];
+  }
+
+  if (s_begin < s_end) {
+    stage_load(s_begin);
+    stage_store(0);
+  }
+  __syncthreads();
+  for (int s = s_begin; s < s_end; ++s) {
+    const int buf = (s - s_begin) & 1;
+    const bool more = s + 1 < s_end;
+    if (more) stage_load(s + 1);
+    const unsigned short* cfb = ab_lds + buf * AB_BUF;
+    const unsigned short* xb = cfb + AB_CF + wid * AB_X;
+    // A fragments: channel 16 mt + i, locations 8g .. 8g+7 of the step (two transposed reads:
+    // lane 4q + p of a 16-lane group addresses row q, columns 4p .. 4p+3 of the 4 x 16 block)
+    u32x4 af[4];
+    {
+      const int q = (lane >> 2) & 3, pp = lane & 3;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const unsigned short* a0 = xb + (8 * g + q) * AB_XLD + 16 * mt + 4 * pp;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (s16x4 __attribute__((address_space(3)))*)(a0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (s16x4 __attribute__((address_space(3)))*)(a0 + 4 * AB_XLD));
+        const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+        af[mt] = u32x4{l2.x, l2.y, h2.x, h2.y};
+      }
+    }
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      u32x4 bf[3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        bf[pl] = *reinterpret_cast<const u32x4*>(cfb + (pl * K + 16 * kt + i) * AB_CFLD + 8 * g);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) acc[mt][kt] = mfma16b(af[mt], bf[pl], acc[mt][kt]);
+    }
+    if (more) stage_store(buf ^ 1);
+    __syncthreads();
+  }
+
+  // slab: rows d0 + 16 mt + 4 g + reg, columns 16 kt + i
+  float* out = part + (((int64_t)b * NSPLIT + split) * D + d0) * K;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg)
+        out[(16 * mt + 4 * g + reg) * K + 16 * kt + i] = acc[mt][kt][reg];
+  if (want_cs) {   // every wave is past the last barrier: the staging buffers are free
+    float* red = reinterpret_cast<float*>(ab_lds);
+    red[wid * K + lane] = cs_part;
+    __syncthreads();
+    if (wid == 0)
+      colsum_part[((int64_t)b * NSPLIT + split) * K + lane] =
+          (red[lane] + red[K + lane]) + (red[2 * K + lane] + red[3 * K + lane]);
+  }
+}
+
 // Forward finish in two small launches of 8 x B workgroups (a single workgroup per image
 // left 232 CUs idle and took 3x longer):
 //   finish_sum_kernel   U = slabs + C * asum for one 64-channel block -> vlad[b] (the saved
@@ -724,6 +911,9 @@ __global__ __launch_bounds__(256) void bwd_du_kernel(const float* __restrict__ s
                                                      float* __restrict__ du,
                                                      float* __restrict__ dut,
                                                      unsigned short* __restrict__ dplanes,
+                                                     unsigned short* __restrict__ du2,
+                                                     const float* __restrict__ assign_w,
+                                                     unsigned short* __restrict__ w2,
                                                      float* __restrict__ cdu) {
   const int blk = blockIdx.x, b = blockIdx.y, k = threadIdx.x & 63, dq = threadIdx.x >> 6;
   float dot[4];
@@ -770,6 +960,23 @@ __global__ __launch_bounds__(256) void bwd_du_kernel(const float* __restrict__ s
       uint4* o = reinterpret_cast<uint4*>(prow + (int64_t)pl * D * K);
       o[0] = make_uint4(w[0], w[1], w[2], w[3]);
       o[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+  }
+  if (du2) {
+    // operands of dx16b_kernel: dU[b] and (from image 0's workgroups) W as high / low bf16
+    // planes [plane][d][k]
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int d = blk * 64 + dq * 16 + i;
+      unsigned short h = f32_to_bf16(vals[i]);
+      du2[((int64_t)b * 2 * D + d) * K + k] = h;
+      du2[((int64_t)b * 2 * D + D + d) * K + k] = f32_to_bf16(vals[i] - bf16_to_f32(h));
+      if (b == 0) {
+        const float wv = assign_w[d * K + k];
+        h = f32_to_bf16(wv);
+        w2[d * K + k] = h;
+        w2[(D + d) * K + k] = f32_to_bf16(wv - bf16_to_f32(h));
+      }
     }
   }
   if (blk == 0 && dq == 0) cdu[b * K + k] = cg * bk - cu * dk;
@@ -965,6 +1172,154 @@ __global__ __launch_bounds__(256, 2) void dx16_kernel(const void* __restrict__ x
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// dx16b_kernel: the same tile for a bf16 feature map on v_mfma_f32_16x16x32_bf16.  grad_x is
+// stored as bf16 (8 mantissa bits), so both operands are taken as TWO bf16 planes and
+// A.B = A_hi.B_hi + A_hi.B_lo + A_lo.B_hi (|error| <= 1.2e-5 of the term magnitudes, three
+// orders below the output rounding): 24 MFMAs of 16 cycles per 32-channel chunk instead of
+// 64 of 32.  A = [a | ds] rows of the tile, split in registers; B = [dU[b] | W] planes
+// [plane][d][k] written by bwd_du_kernel, staged per chunk as [plane][32 d][128 k (+8 pad)].
+constexpr int DXB_LD = 136;                               // bf16 per staged row (128 k + 8 pad)
+constexpr int DXB_CHUNK = 2 * DX_CH * DXB_LD;             // bf16 per buffer (two planes)
+constexpr size_t kDx16bLds = 2 * (size_t)DXB_CHUNK * sizeof(unsigned short) +
+                             4 * (size_t)DX_SCR * sizeof(float);   // 34,816 + 9,216 B
+
+__device__ __forceinline__ void split2x8(const f32x4& a, const f32x4& b, u32x4& hi, u32x4& lo) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float v0 = c < 2 ? a[2 * c] : b[2 * c - 4], v1 = c < 2 ? a[2 * c + 1] : b[2 * c - 3];
+    const unsigned short h0 = f32_to_bf16(v0), h1 = f32_to_bf16(v1);
+    hi[c] = (unsigned)h0 | ((unsigned)h1 << 16);
+    lo[c] = (unsigned)f32_to_bf16(v0 - bf16_to_f32(h0)) |
+            ((unsigned)f32_to_bf16(v1 - bf16_to_f32(h1)) << 16);
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void dx16b_kernel(const unsigned short* __restrict__ xin,
+                                                       const float* __restrict__ a,
+                                                       const float* __restrict__ ds,
+                                                       const float* __restrict__ rn,
+                                                       const float* __restrict__ rowdot,
+                                                       const unsigned short* __restrict__ du2,
+                                                       const unsigned short* __restrict__ w2,
+                                                       int N, int pre_l2,
+                                                       unsigned short* __restrict__ gxo) {
+  extern __shared__ __attribute__((aligned(16))) float dx_lds[];
+  unsigned short* bl = reinterpret_cast<unsigned short*>(dx_lds);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int b = blockIdx.y;
+  const int n0 = (blockIdx.x * 4 + wid) * 16;
+  const bool active = n0 < N;
+  float* scr = dx_lds + (2 * DXB_CHUNK) / 2 + wid * DX_SCR;
+  const unsigned short* dub = du2 + (int64_t)b * 2 * D * K;
+
+  // A operand: k-step s (32 of the 128 contraction indices): lane (i, g) holds
+  // [a | ds][n0 + i][32 s + 8 g .. + 7] as packed high and low bf16
+  u32x4 ah[4], al[4];
+  {
+    const bool ok = active && n0 + i < N;
+    const int64_t gr = (int64_t)b * N + (ok ? n0 + i : 0);
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+      const float* src = (s2 < 2 ? a : ds) + gr * K + 32 * (s2 & 1) + 8 * g;
+      f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+      if (!ok) v0 = v1 = f32x4{0.f, 0.f, 0.f, 0.f};
+      split2x8(v0, v1, ah[s2], al[s2]);
+    }
+  }
+  // epilogue role of this lane: location row_e, channels 8 seg .. 8 seg + 7 of each chunk
+  const int row_e = lane >> 2, seg = lane & 3;
+  const bool ok_e = active && n0 + row_e < N;
+  const int64_t gr_e = (int64_t)b * N + (ok_e ? n0 + row_e : 0);
+  const float rn_e = pre_l2 ? rn[gr_e] : 1.0f;
+  const float rd_e = rowdot[gr_e];
+  const bool proj = pre_l2 && rn_e < 1.0e6f;
+  const unsigned short* x = xin + gr_e * D + seg * 8;
+  unsigned short* gx = gxo + gr_e * D + seg * 8;
+
+  // staging: 2 planes x 32 channels x 16 sixteen-byte pieces (8 of dU, 8 of W) = 1024 pieces
+  u32x4 st[4];
+  auto stage_load = [&](int chunk) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int idx = v * 256 + threadIdx.x;
+      const int pl = idx >> 9, dl = (idx >> 4) & 31, c = idx & 15;
+      const unsigned short* src =
+          c < 8 ? dub + ((int64_t)pl * D + chunk * DX_CH + dl) * K + 8 * c
+                : w2 + ((int64_t)pl * D + chunk * DX_CH + dl) * K + 8 * (c - 8);
+      st[v] = *reinterpret_cast<const u32x4*>(src);
+    }
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int idx = v * 256 + threadIdx.x;
+      const int pl = idx >> 9, dl = (idx >> 4) & 31, c = idx & 15;
+      *reinterpret_cast<u32x4*>(bl + buf * DXB_CHUNK + (pl * DX_CH + dl) * DXB_LD + 8 * c) = st[v];
+    }
+  };
+
+  stage_load(0);
+  stage_store(0);
+  __syncthreads();
+#pragma unroll 1
+  for (int c = 0; c < D / DX_CH; ++c) {
+    const bool more = c + 1 < D / DX_CH;
+    if (more) stage_load(c + 1);
+    u32x4 xraw{0u, 0u, 0u, 0u};
+    if (active && proj) xraw = *reinterpret_cast<const u32x4*>(x + c * DX_CH);
+    if (active) {
+      // B fragment of (channel tile dt, k-step s, plane pl): channel 16 dt + i, k 32 s + 8 g ..
+      const unsigned short* wb = bl + (c & 1) * DXB_CHUNK + i * DXB_LD + 8 * g;
+      f32x4 acc[2];
+      acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const u32x4 bh = *reinterpret_cast<const u32x4*>(wb + (16 * dt) * DXB_LD + 32 * s2);
+          const u32x4 blo =
+              *reinterpret_cast<const u32x4*>(wb + (DX_CH + 16 * dt) * DXB_LD + 32 * s2);
+          acc[dt] = mfma16b(ah[s2], bh, acc[dt]);
+          acc[dt] = mfma16b(ah[s2], blo, acc[dt]);
+          acc[dt] = mfma16b(al[s2], bh, acc[dt]);
+        }
+      }
+      // transpose the [16 x 32] block: accumulator (row 4g+j, channel 16dt+i) -> rows
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) scr[(4 * g + j) * RT_LD + 16 * dt + i] = acc[dt][j];
+      __builtin_amdgcn_wave_barrier();
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(&scr[row_e * RT_LD + 8 * seg]);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(&scr[row_e * RT_LD + 8 * seg + 4]);
+      __builtin_amdgcn_wave_barrier();
+      if (ok_e) {
+        float out[8];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          out[cc] = v0[cc];
+          out[4 + cc] = v1[cc];
+        }
+        if (proj) {
+          const float f = rn_e * rd_e;
+          float xv8[8];
+          Elem8<unsigned short>::cvt(xraw, xv8);
+#pragma unroll
+          for (int cc = 0; cc < 8; ++cc) out[cc] -= xv8[cc] * f;
+        }
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) out[cc] *= rn_e;
+        Elem8<unsigned short>::st(gx + c * DX_CH, out);
+      }
+    }
+    if (more) stage_store((c + 1) & 1);
+    __syncthreads();
+  }
+}
+
 // grad_w[d,k] = sum_b (slab0 + slab1);  grad_c[d,k] = sum_b dU[b,d,k] * asum[b,k]
 __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restrict__ wpart,
                                                            const float* __restrict__ du,
@@ -1035,6 +1390,17 @@ void launch_rowtile_b3(const RowTileArgs& a, hipStream_t st) {
   SCL_LAUNCH(MODE == ASSIGN ? "rowtile_assign" : "rowtile_dassign", (rowtile16b_kernel<MODE>),
              dim3((tiles16 + 3) / 4, a.B), dim3(256), kRowTileB3Lds, st, a);
 }
+inline void launch_aggregate_b3(const char* name, const void* x, const unsigned short* cft,
+                                const float* colpart, int B, int N, int NT, float* part,
+                                float* colsum, hipStream_t st) {
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aggregate16b_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAgg16bLds);
+  });
+  SCL_LAUNCH(name, aggregate16b_kernel, dim3(2, NSPLIT, B), dim3(256), kAgg16bLds, st,
+             (const unsigned short*)x, cft, colpart, N, NT, part, colsum);
+}
 inline bool use_b3() { return scl_debug_variant < 1 || scl_debug_variant > 8; }
 
 struct Carver {
@@ -1051,6 +1417,8 @@ struct Carver {
 struct FwdWs {
   float *wt, *part, *colsum, *colsq, *vlad, *assign, *rnorm;
   unsigned short* wplanes;   // [3][64][512] bf16
+  unsigned short* cft;       // [B][NT][3][64][16] bf16
+  float* colpart;            // [B][NT][64]
   size_t total;
 };
 inline FwdWs carve_fwd(void* ws, int B, int N) {
@@ -1064,6 +1432,9 @@ inline FwdWs carve_fwd(void* ws, int B, int N) {
   w.assign = c.take((size_t)B * N * K);
   w.rnorm = c.take((size_t)B * N);
   w.wplanes = (unsigned short*)c.take((size_t)3 * D * K / 2);
+  const size_t nt = (size_t)(N + 15) / 16;
+  w.cft = (unsigned short*)c.take((size_t)B * nt * 3 * K * 16 / 2);
+  w.colpart = c.take((size_t)B * nt * K);
   w.total = c.off;
   return w;
 }
@@ -1071,6 +1442,9 @@ inline FwdWs carve_fwd(void* ws, int B, int N) {
 struct BwdWs {
   float *du, *dut, *cdu, *ds, *rowdot, *wpart, *dots;
   unsigned short* dplanes;   // [B][3][64][512] bf16
+  unsigned short* cft;       // [B][NT][3][64][16] bf16 (ds * rn)
+  unsigned short* du2;       // [B][2][512][64] bf16 planes of dU
+  unsigned short* w2;        // [2][512][64] bf16 planes of W
   size_t total;
 };
 inline BwdWs carve_bwd(void* ws, int B, int N) {
@@ -1084,6 +1458,9 @@ inline BwdWs carve_bwd(void* ws, int B, int N) {
   w.wpart = c.take((size_t)B * NSPLIT * D * K);
   w.dplanes = (unsigned short*)c.take((size_t)B * 3 * D * K / 2);
   w.dots = c.take((size_t)B * 8 * 4 * K);
+  w.cft = (unsigned short*)c.take((size_t)B * ((size_t)(N + 15) / 16) * 3 * K * 16 / 2);
+  w.du2 = (unsigned short*)c.take((size_t)B * 2 * D * K / 2);
+  w.w2 = (unsigned short*)c.take((size_t)2 * D * K / 2);
   w.total = c.off;
   return w;
 }
@@ -1134,12 +1511,16 @@ extern "C" int scl_netvlad_fwd(const void* x, int x_dtype, const float* assign_w
                  w.wplanes);
       a.btp = w.wplanes;
       a.btp_stride = 0;
+      a.cft = w.cft;
+      a.colpart = w.colpart;
+      a.NT = (N + 15) / 16;
       launch_rowtile_b3<ASSIGN>(a, st);
+      launch_aggregate_b3("aggregate_kernel", x, w.cft, w.colpart, B, N, a.NT, w.part, w.colsum, st);
     } else {
       launch_rowtile<unsigned short, ASSIGN>(a, st);
+      SCL_LAUNCH("aggregate_kernel", aggregate_kernel<unsigned short>, dim3(D / 64, NSPLIT, B), dim3(256), 0, st,
+                         x, (const float*)assign, (const float*)rnorm, N, w.part, w.colsum);
     }
-    SCL_LAUNCH("aggregate_kernel", aggregate_kernel<unsigned short>, dim3(D / 64, NSPLIT, B), dim3(256), 0, st,
-                       x, (const float*)assign, (const float*)rnorm, N, w.part, w.colsum);
   }
   float* vlad = save_vlad ? save_vlad : w.vlad;
   SCL_LAUNCH("finish_sum_kernel", finish_sum_kernel, dim3(8, B), dim3(256), 0, st,
@@ -1175,7 +1556,8 @@ extern "C" int scl_netvlad_bwd(const void* x, int x_dtype, const float* assign_w
   SCL_LAUNCH("bwd_dots_kernel", bwd_dots_kernel, dim3(8, B), dim3(256), 0, st, save_vlad, grad_out,
              centers, w.dots);
   SCL_LAUNCH("bwd_du_kernel", bwd_du_kernel, dim3(8, B), dim3(256), 0, st, save_vlad, grad_out,
-             (const float*)w.dots, w.du, w.dut, b3 ? w.dplanes : (unsigned short*)nullptr, w.cdu);
+             (const float*)w.dots, w.du, w.dut, b3 ? w.dplanes : (unsigned short*)nullptr,
+             b3 ? w.du2 : (unsigned short*)nullptr, assign_w, w.w2, w.cdu);
   RowTileArgs a{};
   a.x = x;
   a.bt = w.dut;
@@ -1201,15 +1583,25 @@ extern "C" int scl_netvlad_bwd(const void* x, int x_dtype, const float* assign_w
     if (b3) {
       a.btp = w.dplanes;
       a.btp_stride = (int64_t)3 * D * K;
+      a.cft = w.cft;
+      a.NT = (N + 15) / 16;
       launch_rowtile_b3<DASSIGN>(a, st);
+      launch_aggregate_b3("aggregate_dw", x, w.cft, nullptr, B, N, a.NT, w.wpart, nullptr, st);
     } else {
       launch_rowtile<unsigned short, DASSIGN>(a, st);
+      SCL_LAUNCH("aggregate_dw", aggregate_kernel<unsigned short>, dim3(D / 64, NSPLIT, B), dim3(256), 0, st,
+                         x, (const float*)w.ds, save_rnorm, N, w.wpart, (float*)nullptr);
     }
-    SCL_LAUNCH("aggregate_dw", aggregate_kernel<unsigned short>, dim3(D / 64, NSPLIT, B), dim3(256), 0, st,
-                       x, (const float*)w.ds, save_rnorm, N, w.wpart, (float*)nullptr);
-    SCL_LAUNCH("dx_kernel", dx16_kernel<unsigned short>, dxgrid, dim3(256), kDx16Lds, st, x, save_assign,
-                       (const float*)w.ds, save_rnorm, (const float*)w.rowdot,
-                       (const float*)w.du, assign_w, N, pre_l2 ? 1 : 0, grad_x);
+    if (b3) {
+      SCL_LAUNCH("dx_kernel", dx16b_kernel, dxgrid, dim3(256), kDx16bLds, st,
+                 (const unsigned short*)x, save_assign, (const float*)w.ds, save_rnorm,
+                 (const float*)w.rowdot, (const unsigned short*)w.du2,
+                 (const unsigned short*)w.w2, N, pre_l2 ? 1 : 0, (unsigned short*)grad_x);
+    } else {
+      SCL_LAUNCH("dx_kernel", dx16_kernel<unsigned short>, dxgrid, dim3(256), kDx16Lds, st, x, save_assign,
+                         (const float*)w.ds, save_rnorm, (const float*)w.rowdot,
+                         (const float*)w.du, assign_w, N, pre_l2 ? 1 : 0, grad_x);
+    }
   }
   SCL_LAUNCH("wgrad_finish_kernel", wgrad_finish_kernel, dim3(D * K / 256), dim3(256), 0, st,
                      (const float*)w.wpart, (const float*)w.du, save_vlad, B, grad_w, grad_c);
