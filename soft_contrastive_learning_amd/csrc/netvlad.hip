@@ -941,11 +941,12 @@ __global__ __launch_bounds__(256) void bwd_du_kernel(const float* __restrict__ s
     vals[i] = cg * go - cu * u;
     du[((int64_t)b * D + d) * K + k] = vals[i];
   }
-  // transposed copy: 16 consecutive channels of cluster k
-  float* trow = dut + ((int64_t)b * K + k) * D + blk * 64 + dq * 16;
+  if (dut) {   // transposed float32 copy (float32-MFMA row-tile kernel only)
+    float* trow = dut + ((int64_t)b * K + k) * D + blk * 64 + dq * 16;
 #pragma unroll
-  for (int i = 0; i < 16; i += 4)
-    *reinterpret_cast<f32x4*>(trow + i) = f32x4{vals[i], vals[i + 1], vals[i + 2], vals[i + 3]};
+    for (int i = 0; i < 16; i += 4)
+      *reinterpret_cast<f32x4*>(trow + i) = f32x4{vals[i], vals[i + 1], vals[i + 2], vals[i + 3]};
+  }
   if (dplanes) {
     unsigned short h[3][16];
 #pragma unroll
@@ -1320,23 +1321,32 @@ __global__ __launch_bounds__(256, 2) void dx16b_kernel(const unsigned short* __r
   }
 }
 
-// grad_w[d,k] = sum_b (slab0 + slab1);  grad_c[d,k] = sum_b dU[b,d,k] * asum[b,k]
+// grad_w[d,k] = sum_b sum_s slab[b][s][d,k];  grad_c[d,k] = sum_b dU[b,d,k] * asum[b,k].
+// grid D*K/64, block 256: thread (j, q) sums the images b = q, q + 4, ... of element
+// 64 * blockIdx.x + j; the four partials are combined in a fixed order (512 workgroups
+// instead of 128 threads-per-element chains of 4 B loads each).
 __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restrict__ wpart,
                                                            const float* __restrict__ du,
                                                            const float* __restrict__ save_vlad,
                                                            int B, float* __restrict__ grad_w,
                                                            float* __restrict__ grad_c) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= D * K) return;
+  __shared__ float red[2][4][64];
+  const int j = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + j;
   const int k = idx % K;
   float gw = 0.f, gc = 0.f;
-  for (int b = 0; b < B; ++b) {
+  for (int b = q; b < B; b += 4) {
 #pragma unroll
     for (int s = 0; s < NSPLIT; ++s) gw += wpart[((int64_t)b * NSPLIT + s) * D * K + idx];
     gc = fmaf(du[(int64_t)b * D * K + idx], save_vlad[((int64_t)b * (D + 1) + D) * K + k], gc);
   }
-  grad_w[idx] = gw;
-  grad_c[idx] = gc;
+  red[0][q][j] = gw;
+  red[1][q][j] = gc;
+  __syncthreads();
+  if (q == 0) {
+    grad_w[idx] = (red[0][0][j] + red[0][1][j]) + (red[0][2][j] + red[0][3][j]);
+    grad_c[idx] = (red[1][0][j] + red[1][1][j]) + (red[1][2][j] + red[1][3][j]);
+  }
 }
 
 // ---------------------------------------------------------------------- host side
@@ -1490,7 +1500,10 @@ extern "C" int scl_netvlad_fwd(const void* x, int x_dtype, const float* assign_w
   float* assign = save_assign ? save_assign : w.assign;
   float* rnorm = save_rnorm ? save_rnorm : w.rnorm;
 
-  SCL_LAUNCH("transpose_w_kernel", transpose_w_kernel, dim3(D * K / 256), dim3(256), 0, st, assign_w, w.wt);
+  const bool fwd_b3 = x_dtype == SCL_DT_BF16 && use_b3();
+  if (!fwd_b3)
+    SCL_LAUNCH("transpose_w_kernel", transpose_w_kernel, dim3(D * K / 256), dim3(256), 0, st, assign_w,
+               w.wt);
   RowTileArgs a{};
   a.x = x;
   a.bt = w.wt;
@@ -1506,7 +1519,7 @@ extern "C" int scl_netvlad_fwd(const void* x, int x_dtype, const float* assign_w
     SCL_LAUNCH("aggregate_kernel", aggregate_kernel<float>, dim3(D / 64, NSPLIT, B), dim3(256), 0, st, x,
                        (const float*)assign, (const float*)rnorm, N, w.part, w.colsum);
   } else {
-    if (use_b3()) {
+    if (fwd_b3) {
       SCL_LAUNCH("split_w_kernel", split_w_kernel, dim3(D * K / 256), dim3(256), 0, st, assign_w,
                  w.wplanes);
       a.btp = w.wplanes;
@@ -1556,7 +1569,8 @@ extern "C" int scl_netvlad_bwd(const void* x, int x_dtype, const float* assign_w
   SCL_LAUNCH("bwd_dots_kernel", bwd_dots_kernel, dim3(8, B), dim3(256), 0, st, save_vlad, grad_out,
              centers, w.dots);
   SCL_LAUNCH("bwd_du_kernel", bwd_du_kernel, dim3(8, B), dim3(256), 0, st, save_vlad, grad_out,
-             (const float*)w.dots, w.du, w.dut, b3 ? w.dplanes : (unsigned short*)nullptr,
+             (const float*)w.dots, w.du, b3 ? (float*)nullptr : w.dut,
+             b3 ? w.dplanes : (unsigned short*)nullptr,
              b3 ? w.du2 : (unsigned short*)nullptr, assign_w, w.w2, w.cdu);
   RowTileArgs a{};
   a.x = x;
@@ -1603,7 +1617,7 @@ extern "C" int scl_netvlad_bwd(const void* x, int x_dtype, const float* assign_w
                          (const float*)w.du, assign_w, N, pre_l2 ? 1 : 0, grad_x);
     }
   }
-  SCL_LAUNCH("wgrad_finish_kernel", wgrad_finish_kernel, dim3(D * K / 256), dim3(256), 0, st,
+  SCL_LAUNCH("wgrad_finish_kernel", wgrad_finish_kernel, dim3(D * K / 64), dim3(256), 0, st,
                      (const float*)w.wpart, (const float*)w.du, save_vlad, B, grad_w, grad_c);
   return scl_launch_status();
 }
