@@ -129,8 +129,11 @@ def price(name, launches, mean_ms, model):
     t_hbm = model['bytes'] / (PEAK_HBM_GBPS * 1e9)
     bound = 'mfma' if t_mfma >= t_hbm else 'hbm'
     frac = mult * tf / peak_tf if bound == 'mfma' else gbs / PEAK_HBM_GBPS
-    return dict(kernel=name, launches=launches, us=round(mean_ms * 1e3, 2), bound=bound,
-                tflops=round(tf, 2), gbps=round(gbs, 1), frac=round(frac, 4))
+    out = dict(kernel=name, launches=launches, us=round(mean_ms * 1e3, 2), bound=bound,
+               tflops=round(tf, 2), gbps=round(gbs, 1), frac=round(frac, 4))
+    if mult != 1.0:      # bf16x3 kernels: flops executed on the bf16 matrix cores
+        out.update(executed_tflops=round(mult * tf, 2), mfma_peak_tflops=peak_tf)
+    return out
 
 
 def cpu_baseline(args, threads):
@@ -257,8 +260,10 @@ def main():
         roofline = None
         if dom:
             roofline = dict(kernel=dom['kernel'], bound=dom['bound'],
-                            achieved=dom['tflops'] if dom['bound'] == 'mfma' else dom['gbps'],
-                            peak=PEAK_F32_TFLOPS if dom['bound'] == 'mfma' else PEAK_HBM_GBPS,
+                            achieved=dom.get('executed_tflops', dom['tflops'])
+                            if dom['bound'] == 'mfma' else dom['gbps'],
+                            peak=dom.get('mfma_peak_tflops', PEAK_F32_TFLOPS)
+                            if dom['bound'] == 'mfma' else PEAK_HBM_GBPS,
                             unit='TFLOP/s' if dom['bound'] == 'mfma' else 'GB/s',
                             frac=dom['frac'], traffic=None, us_per_launch=dom['us'])
         if roofline:
@@ -289,7 +294,7 @@ def main():
             'dtype': args.dtype,
             'data': 'synthetic',
             'config': {'workload': 'configs[1]: wms soft-contrastive train step, VGG16-NetVLAD K=64, '
-                                   '%d images/GPU %dx%d, %s backbone, f32 NetVLAD+loss'
+                                   '%d images/GPU %dx%d, %s backbone, float32-accurate NetVLAD + f32 loss'
                                    % (b, args.width, args.height, args.dtype),
                        'global_batch': gb, 'locations': n_loc, 'parallelism': 'dp%d' % world,
                        'optimizer': 'adam', 'loss': float('%.6g' % loss_val)},
