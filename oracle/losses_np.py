@@ -60,6 +60,36 @@ def _ms_core(sim_mat, mask_pos, mask_neg, alpha, beta, lamb, eps, ms_mining,
     return F32(np.mean((pos_term + neg_term).astype(F32), dtype=F32))
 
 
+def eigen_fast_tanh_f32(x):
+    """tf.tanh on a float32 CPU tensor = Eigen's generic_fast_tanh_float (TF 1.10 bundles Eigen
+    3.3.90; unsupported/../MathFunctionsImpl.h, recalled — not part of /root/reference): clamp to
+    [-9, 9], odd 13th-degree / even 6th-degree rational approximation, every operation rounded
+    to float32 (the stock x86 wheels are built without FMA).  Restated op for op because
+    ``1 - tanh(d / d_beta)`` decides pair membership through ``mask_pos > 0``: near saturation
+    (d / d_beta in [8.2, 10]) libm, ocml and this approximation disagree in the last bit, this
+    one is not even monotone there (8.5 -> 1.0, 8.7 -> 0.99999994, >= 9 -> 1.0), and the wms
+    loss at B=192 / 200 m moves by 1.8 % with the choice."""
+    x = np.asarray(x, dtype=F32)
+    x = np.maximum(F32(-9.0), np.minimum(F32(9.0), x))
+    a1, a3, a5, a7, a9, a11, a13 = (F32(v) for v in (
+        4.89352455891786e-03, 6.37261928875436e-04, 1.48572235717979e-05, 5.12229709037114e-08,
+        -8.60467152213735e-11, 2.00018790482477e-13, -2.76076847742355e-16))
+    b0, b2, b4, b6 = (F32(v) for v in (
+        4.89352518554385e-03, 2.26843463243900e-03, 1.18534705686654e-04, 1.19825839466702e-06))
+    x2 = x * x
+    p = x2 * a13 + a11
+    p = x2 * p + a9
+    p = x2 * p + a7
+    p = x2 * p + a5
+    p = x2 * p + a3
+    p = x2 * p + a1
+    p = x * p
+    q = x2 * b6 + b4
+    q = x2 * q + b2
+    q = x2 * q + b0
+    return (p / q).astype(F32)
+
+
 def wms_masks(distances, d_alpha, d_beta, wfunction='exp'):
     """Geographic soft masks of wms_loss before the ``- eye`` (model/losses.py:11-19)."""
     d = _f32(distances)
@@ -68,8 +98,9 @@ def wms_masks(distances, d_alpha, d_beta, wfunction='exp'):
         mask_pos = np.where(d < d_beta, F32(1.0) - d / d_beta, F32(0.0))
         mask_neg = np.where(d < d_beta, d / d_beta, F32(1.0))
     elif wfunction == 'tanh':
-        mask_pos = F32(1.0) - np.tanh(d / d_beta)
-        mask_neg = np.tanh(d / d_beta)
+        t = eigen_fast_tanh_f32(d / d_beta)
+        mask_pos = F32(1.0) - t
+        mask_neg = t
     else:  # 'exp' and anything else, like the reference's bare else
         with np.errstate(over='ignore'):
             mask_pos = F32(1.0) / (F32(1.0) + np.exp(d_alpha * (d - d_beta)))

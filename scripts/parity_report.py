@@ -1,0 +1,161 @@
+#!/usr/bin/env python
+"""Measured parity of the HIP path against the CPU oracle, as numbers (the tests assert the
+same comparisons against fixed tolerances; this prints / stores what was actually reached).
+
+    python scripts/parity_report.py [--json profiles/rNN/parity_report.json]
+
+Rows: relative loss error vs the float32 NumPy oracle (north_star gate: 1e-4), norm-relative
+gradient error vs the float64 autograd twin, descriptor error of the NetVLAD head for both
+input dtypes, and index-list equality of the retrieval against scikit-learn's KDTree.
+Needs an MI355X; uses oracle/ as the checker only.
+"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from oracle import losses_np as O  # noqa: E402
+from oracle import netvlad_np as NV  # noqa: E402
+from oracle import topn_np as TN  # noqa: E402
+from oracle import twin_torch as TT  # noqa: E402
+from soft_contrastive_learning_amd import pointnetvlad_cls as P  # noqa: E402
+from soft_contrastive_learning_amd.evaluation import retrieval  # noqa: E402
+from soft_contrastive_learning_amd.model import losses as M  # noqa: E402
+from soft_contrastive_learning_amd.model import nets  # noqa: E402
+from tests import util_data as U  # noqa: E402
+
+
+def rel(a, b):
+    a, b = float(a), float(b)
+    return abs(a - b) / max(abs(b), 1e-30)
+
+
+def nrel(got, want):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    return float(np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30))
+
+
+def maxrel(got, want):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    return float(np.abs(got - want).max() / np.abs(want).max())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--json', default='')
+    args = ap.parse_args()
+    dev = torch.device('cuda:0')
+    rows = []
+
+    def add(name, **kw):
+        rows.append(dict(case=name, **kw))
+        print('%-58s %s' % (name, '  '.join('%s=%.3g' % (k, v) if isinstance(v, float)
+                                              else '%s=%s' % (k, v) for k, v in kw.items())))
+
+    # ---- pairwise losses -----------------------------------------------------------------
+    for b in (24, 192):
+        emb = U.embeddings(b, 32768)
+        dist = U.positions_distances(b, side=60.0 if b < 64 else 200.0)
+        for wf, sf in (('exp', 'ms'), ('lin', 'plain'), ('tanh', 'ms')):
+            want = O.wms_loss(dist[None], emb, 0.8, 15.0, wfunction=wf, sumfunction=sf)
+            e64 = torch.tensor(emb, dtype=torch.float64, requires_grad=True)
+            l64 = TT.wms_loss(dist[None], e64, 0.8, 15.0, wfunction=wf, sumfunction=sf)
+            l64.backward()
+            et = torch.tensor(emb, device=dev, requires_grad=True)
+            loss = M.wms_loss(torch.tensor(dist[None], device=dev), et, 0.8, 15.0, wfunction=wf,
+                              sumfunction=sf)
+            loss.backward()
+            add('wms_loss B=%d %s/%s' % (b, wf, sf), loss_rel_vs_f32_oracle=rel(loss, want),
+                loss_rel_vs_f64_twin=rel(loss, l64), grad_nrel_vs_f64_twin=nrel(
+                    et.grad.cpu().numpy(), e64.grad.numpy()))
+    labels = O.trainer_ms_labels(1, 12, 12)
+    emb = U.embeddings(25, 32768, seed=5)
+    for mining in (True, False):
+        want = O.ms_loss(labels, emb, ms_mining=mining)
+        et = torch.tensor(emb, device=dev)
+        add('ms_loss T=1 P=N=12 mining=%s' % mining,
+            loss_rel_vs_f32_oracle=rel(M.ms_loss(torch.tensor(labels, device=dev), et,
+                                                 ms_mining=mining), want))
+
+    # ---- tuple losses --------------------------------------------------------------------
+    for name, quad in (('triplet_loss', False), ('lazy_triplet_loss', False),
+                       ('evil_triplet_loss', False), ('quadruplet_loss', True),
+                       ('lazy_quadruplet_loss', True), ('evil_quadruplet_loss', True)):
+        fn = getattr(P, name, None) or getattr(M, name)
+        p_, n_ = 12, (11 if quad else 12)
+        shape = [1, p_, n_] + ([1] if quad else [])
+        out = U.tuple_batch(1, p_, n_, 32768, quad=quad)
+        flat = out.reshape(sum(shape), 32768)
+        margins = (0.5, 0.2) if quad else (0.5,)
+        want = getattr(O, name)(*O.split_tuples(flat, 1, shape), *margins)
+        x64 = torch.tensor(flat, dtype=torch.float64, requires_grad=True)
+        getattr(TT, name)(*torch.split(x64.reshape(1, sum(shape), -1), shape, dim=1),
+                          *margins).backward()
+        xt = torch.tensor(flat, device=dev, requires_grad=True)
+        loss = fn(*torch.split(xt.reshape(1, sum(shape), -1), shape, dim=1), *margins)
+        loss.backward()
+        add(name, loss_rel_vs_f32_oracle=rel(loss, want),
+            grad_nrel_vs_f64_twin=nrel(xt.grad.cpu().numpy(), x64.grad.numpy()))
+    out = U.tuple_batch(1, 12, 12, 32768, seed=33)
+    rng = np.random.default_rng(34)
+    spd = rng.uniform(1, 200, (1, 12, 1)).astype(np.float32)
+    snd = rng.uniform(300, 4000, (1, 12, 1)).astype(np.float32)
+    want = O.logratio_loss(*O.split_tuples(out.reshape(-1, 32768), 1, [1, 12, 12]), spd, snd)
+    xt = torch.tensor(out, device=dev)
+    at, pt, nt = torch.split(xt, [1, 12, 12], dim=1)
+    add('logratio_loss', loss_rel_vs_f32_oracle=rel(
+        M.logratio_loss(at, pt, nt, torch.tensor(spd, device=dev), torch.tensor(snd, device=dev)),
+        want))
+    dd = rng.uniform(0.0, 225.0, (1, 12)).astype(np.float32)
+    parts = O.split_tuples(out.reshape(-1, 32768), 1, [1, 12, 12])
+    want = O.distance_triplet_loss(parts[0], parts[1], parts[2], 0.5, 0.5, dd, 225.0, 2.0)
+    add('huber_distance_triplet', loss_rel_vs_f32_oracle=rel(
+        M.distance_triplet_loss(at, pt, nt, 0.5, 0.5, torch.tensor(dd, device=dev), 225.0, 2.0),
+        want))
+
+    # ---- NetVLAD head --------------------------------------------------------------------
+    w, c = U.vlad_params()
+    x = U.feature_map(4, 1200, seed=5)
+    g = np.random.default_rng(3).standard_normal((4, 32768)).astype(np.float32)
+    for dt, label in ((torch.float32, 'f32 x (float32 MFMA)'), (torch.bfloat16, 'bf16 x (bf16x3)')):
+        xin = torch.tensor(x).to(dt).float().numpy()        # what the kernel really sees
+        want = NV.netvlad_fused(xin, w, c)
+        xt = torch.tensor(xin, device=dev).to(dt).reshape(4, 1, 1200, 512).requires_grad_(True)
+        wt = torch.tensor(w, device=dev).reshape(1, 1, 512, 64).requires_grad_(True)
+        ct = torch.tensor(c, device=dev).reshape(1, 1, 1, 512, 64).requires_grad_(True)
+        got = nets.netvlad(xt, wt, ct, True)
+        got.backward(torch.tensor(g, device=dev))
+        x64 = torch.tensor(xin, dtype=torch.float64, requires_grad=True)
+        w64 = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+        c64 = torch.tensor(c, dtype=torch.float64, requires_grad=True)
+        TT.netvlad(x64, w64, c64).backward(torch.tensor(g, dtype=torch.float64))
+        add('netvlad 4x1200x512 %s' % label,
+            descriptor_maxrel_vs_f32_oracle=maxrel(got.detach().cpu().numpy(), want),
+            grad_x_nrel=nrel(xt.grad.float().cpu().numpy().reshape(4, 1200, 512), x64.grad.numpy()),
+            grad_w_nrel=nrel(wt.grad.cpu().numpy().reshape(512, 64), w64.grad.numpy()),
+            grad_c_nrel=nrel(ct.grad.cpu().numpy().reshape(512, 64), c64.grad.numpy()))
+
+    # ---- retrieval -----------------------------------------------------------------------
+    ref, qry = U.retrieval_sets(40000, 500, 256)
+    want_d, want_i = TN.topn_kdtree(ref, qry, 25)
+    rt, qt = torch.tensor(ref, device=dev), torch.tensor(qry, device=dev)
+    for score in ('f32', 'bf16x3'):
+        d, i = retrieval.topn_l2(rt, qt, 25, score=score)
+        add('top-25 of 40000 x 500 x 256, score=%s' % score,
+            index_lists_equal=bool(np.array_equal(i.cpu().numpy(), want_i)),
+            dist_maxrel_vs_kdtree=float(np.abs(d.cpu().numpy() - want_d).max() / want_d.max()))
+
+    if args.json:
+        with open(args.json, 'w') as f:
+            json.dump(rows, f, indent=1)
+        print('wrote', args.json)
+
+
+if __name__ == '__main__':
+    main()

@@ -75,6 +75,29 @@ __device__ __forceinline__ f32x4 load4_guard(const float* row, int e, int E, boo
   return v;
 }
 
+// tf.tanh of a float32 CPU tensor (Eigen's generic_fast_tanh_float, restated op for op in
+// oracle/losses_np.py::eigen_fast_tanh_f32): clamp to [-9, 9], rational approximation, every
+// operation individually rounded.  1 - tanh(d / d_beta) decides pair membership through
+// mask_pos > 0, so the last bit near saturation matters; ocml's tanhf differs there.
+__device__ __forceinline__ float eigen_fast_tanh(float a) {
+  // HIP's __fmul_rn / __fadd_rn are plain operators, so only this pragma keeps hipcc from
+  // contracting the Horner steps into FMAs (Eigen's pmadd is mul-then-add on non-FMA builds)
+#pragma clang fp contract(off)
+  const float x = fmaxf(-9.0f, fminf(9.0f, a));
+  const float x2 = x * x;
+  float p = x2 * -2.76076847742355e-16f + 2.00018790482477e-13f;
+  p = x2 * p + -8.60467152213735e-11f;
+  p = x2 * p + 5.12229709037114e-08f;
+  p = x2 * p + 1.48572235717979e-05f;
+  p = x2 * p + 6.37261928875436e-04f;
+  p = x2 * p + 4.89352455891786e-03f;
+  p = x * p;
+  float q = x2 * 1.19825839466702e-06f + 1.18534705686654e-04f;
+  q = x2 * q + 2.26843463243900e-03f;
+  q = x2 * q + 4.89352518554385e-03f;
+  return __fdiv_rn(p, q);
+}
+
 // grid (splits, npairs, batch); block 256.  Slab layout: [batch][split][pair][32*32] row-major.
 __global__ __launch_bounds__(256) void gram_partial_kernel(const float* __restrict__ emb,
                                                            int64_t ld, int64_t batch_stride,
@@ -235,7 +258,7 @@ __global__ __launch_bounds__(kRowThreads) void gram_rows_kernel(
         mp = d < lp.d_beta ? 1.0f - d / lp.d_beta : 0.f;
         mn = d < lp.d_beta ? d / lp.d_beta : 1.f;
       } else if (lp.mask_kind == SCL_MASK_WMS_TANH) {
-        const float t = tanhf(d / lp.d_beta);
+        const float t = eigen_fast_tanh(__fdiv_rn(d, lp.d_beta));
         mp = 1.0f - t;
         mn = t;
       } else {

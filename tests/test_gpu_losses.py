@@ -79,11 +79,12 @@ def test_kat_tuple_losses(dev):
 
 # --------------------------------------------------------------- wms / ms parity sweep
 @pytest.mark.parametrize("b,e", [(24, 32768), (25, 32768), (7, 100), (64, 4096), (192, 32768)])
-@pytest.mark.parametrize("wf,sf", [("exp", "ms"), ("lin", "ms"), ("tanh", "plain"), ("exp", "plain")])
+@pytest.mark.parametrize("wf,sf", [("exp", "ms"), ("lin", "ms"), ("tanh", "plain"), ("exp", "plain"),
+                                   ("tanh", "ms")])
 def test_wms_loss_and_grad(dev, b, e, wf, sf):
+    # (192, tanh, ms) at 200 m is the case where the last bit of tanh near saturation decides
+    # pair membership: oracle and kernel evaluate the same rational approximation op for op
     from soft_contrastive_learning_amd.model import losses as M
-    if b == 192 and (wf, sf) != ("exp", "ms"):
-        pytest.skip("B=192 is covered for the default configuration only")
     emb = U.embeddings(b, e)
     dist = U.positions_distances(b, side=60.0 if b < 64 else 200.0)
     want = O.wms_loss(dist[None], emb, 0.8, 15.0, wfunction=wf, sumfunction=sf)

@@ -245,3 +245,20 @@ def test_tuple_losses_twin_agreement_random():
     for name in ('quadruplet_loss', 'lazy_quadruplet_loss', 'evil_quadruplet_loss'):
         got = getattr(L, name)(q, pos, neg, oth, 0.5, 0.2)
         assert got == pytest.approx(float(getattr(TT, name)(q, pos, neg, oth, 0.5, 0.2)), rel=1e-5)
+
+
+def test_k7c_tanh_is_the_eigen_rational_approximation():
+    """tf.tanh on float32 CPU tensors (model/losses.py:14-16) is Eigen's clamp-to-9 rational
+    approximation, not libm: accurate to ~1e-7 in the bulk, exactly 1.0 from 9 upwards, and
+    NOT monotone in the last bit just below — which is what decides ``mask_pos > 0``."""
+    x = np.array([0.0, 0.1, 0.5, 1.0, 2.0, 4.0, 6.0, -0.5, -3.0], np.float32)
+    got = L.eigen_fast_tanh_f32(x)
+    assert got.dtype == np.float32
+    np.testing.assert_allclose(got, np.tanh(x.astype(np.float64)), atol=2e-7)
+    sat = L.eigen_fast_tanh_f32(np.array([8.5, 8.7, 9.0, 9.5, 19.0, -30.0], np.float32))
+    assert sat.tolist() == [1.0, np.float32(0.99999994), 1.0, 1.0, 1.0, -1.0]
+    # masks: far pairs drop out exactly, a pair at 8.7 d_beta stays in with weight 2^-24
+    d = np.array([[0.0, 8.7 * 15.0], [9.5 * 15.0, 300.0]], np.float32)
+    mp, mn = L.wms_masks(d, 0.8, 15.0, 'tanh')
+    assert mp[0, 1] == np.float32(2.0 ** -24) and mp[1, 0] == 0.0 and mp[1, 1] == 0.0
+    assert mn[1, 1] == 1.0 and mp[0, 0] == 1.0
