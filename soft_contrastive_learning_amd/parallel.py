@@ -65,6 +65,28 @@ def ms_loss_dp(labels, local_embeddings, group=None, **kw):
     return losses.ms_loss(labels, full, _rows=rows, **kw)
 
 
+def topn_l2_sharded(ref_shard, query, n, shard_offset, group=None, score='f32', local_fn=None):
+    """Retrieval with the reference set sharded over ranks: every rank scans
+    its own rows ``[shard_offset, shard_offset + len(ref_shard))`` for all (replicated)
+    queries, the [Q, n] (distance, index) candidates are all-gathered (Q * n * 16 bytes per
+    rank) and merged by (distance, index) — the same lists on every rank as the single-device
+    call on the concatenated reference set.  ``local_fn`` replaces the HIP kernel in the
+    CPU tests of the exchange."""
+    from .evaluation import retrieval
+    if local_fn is None:
+        d, i = retrieval.topn_l2(ref_shard, query, n, idx_offset=shard_offset, score=score)
+    else:
+        d, i = local_fn(ref_shard, query, n, shard_offset)
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    if world == 1:
+        return d, i
+    ds = [torch.empty_like(d) for _ in range(world)]
+    idx = [torch.empty_like(i) for _ in range(world)]
+    dist.all_gather(ds, d.contiguous(), group=group)
+    dist.all_gather(idx, i.contiguous(), group=group)
+    return retrieval.merge_topn(ds, idx, n)
+
+
 class GradBuckets:
     """Flat gradient storage + bucketed asynchronous all-reduce (SUM).
 

@@ -112,3 +112,48 @@ def test_grad_buckets_layout_without_process_group():
     assert ps[0].grad.data_ptr() == gb.flat[9:].data_ptr()          # grads are views
     gb.zero()
     assert float(gb.flat.abs().sum()) == 0.0
+
+
+def _bruteforce_local(ref, query, n, offset):
+    d2 = ((query[:, None, :].double() - ref[None, :, :].double()) ** 2).sum(-1)
+    idx = torch.arange(ref.shape[0])[None].expand_as(d2)
+    o = torch.argsort(d2, dim=1, stable=True)[:, :n]
+    return torch.gather(d2, 1, o).sqrt(), torch.gather(idx, 1, o) + offset
+
+
+def _retrieval_worker(rank, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=WORLD)
+    try:
+        from soft_contrastive_learning_amd import parallel
+        gen = torch.Generator().manual_seed(5)
+        ref = torch.randn(90, 16, generator=gen)
+        ref[70] = ref[3]                         # an exact tie across the two shards
+        qry = torch.cat([torch.randn(11, 16, generator=gen), ref[3:4]])
+        per = 45
+        d, i = parallel.topn_l2_sharded(ref[rank * per:(rank + 1) * per], qry, 7, rank * per,
+                                        local_fn=_bruteforce_local)
+        out[rank] = (d, i)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_retrieval_equals_single_process():
+    """Reference set split over two ranks, queries replicated (SURVEY.md §8e retrieval row)."""
+    port = _free_port()
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_retrieval_worker, args=(port, out), nprocs=WORLD, join=True)
+        res = dict(out)
+    gen = torch.Generator().manual_seed(5)
+    ref = torch.randn(90, 16, generator=gen)
+    ref[70] = ref[3]
+    qry = torch.cat([torch.randn(11, 16, generator=gen), ref[3:4]])
+    want_d, want_i = _bruteforce_local(ref, qry, 7, 0)
+    # ties: (distance, index) order, i.e. index 3 before its duplicate 70
+    assert want_i[-1, :2].tolist() == [3, 70]
+    for rank in range(WORLD):
+        d, i = res[rank]
+        assert torch.equal(i, want_i)
+        assert torch.allclose(d, want_d, rtol=0, atol=0)
