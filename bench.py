@@ -235,7 +235,7 @@ def main():
             loss = step()
         fence()
         elapsed = time.perf_counter() - t0
-    loss_val = float(loss)
+    loss_val = float(loss.detach())
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

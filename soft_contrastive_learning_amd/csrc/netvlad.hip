@@ -774,16 +774,24 @@ __global__ __launch_bounds__(256, 2) void aggregate16b_kernel(
         af[mt] = u32x4{l2.x, l2.y, h2.x, h2.y};
       }
     }
+    u32x4 bf[2][3];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+      bf[0][pl] = *reinterpret_cast<const u32x4*>(cfb + (pl * K + i) * AB_CFLD + 8 * g);
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
-      u32x4 bf[3];
+      if (kt + 1 < 4) {
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
-        bf[pl] = *reinterpret_cast<const u32x4*>(cfb + (pl * K + 16 * kt + i) * AB_CFLD + 8 * g);
+        for (int pl = 0; pl < 3; ++pl)
+          bf[(kt + 1) & 1][pl] = *reinterpret_cast<const u32x4*>(
+              cfb + (pl * K + 16 * (kt + 1) + i) * AB_CFLD + 8 * g);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) acc[mt][kt] = mfma16b(af[mt], bf[pl], acc[mt][kt]);
+        for (int pl = 0; pl < 3; ++pl)
+          acc[mt][kt] = mfma16b(af[mt], bf[kt & 1][pl], acc[mt][kt]);
     }
     if (more) stage_store(buf ^ 1);
     __syncthreads();
@@ -1181,9 +1189,10 @@ __global__ __launch_bounds__(256, 2) void dx16_kernel(const void* __restrict__ x
 // 64 of 32.  A = [a | ds] rows of the tile, split in registers; B = [dU[b] | W] planes
 // [plane][d][k] written by bwd_du_kernel, staged per chunk as [plane][32 d][128 k (+8 pad)].
 constexpr int DXB_LD = 136;                               // bf16 per staged row (128 k + 8 pad)
-constexpr int DXB_CHUNK = 2 * DX_CH * DXB_LD;             // bf16 per buffer (two planes)
+constexpr int DXB_CH = 64;                                // channels per staged chunk / barrier
+constexpr int DXB_CHUNK = 2 * DXB_CH * DXB_LD;            // bf16 per buffer (two planes)
 constexpr size_t kDx16bLds = 2 * (size_t)DXB_CHUNK * sizeof(unsigned short) +
-                             4 * (size_t)DX_SCR * sizeof(float);   // 34,816 + 9,216 B
+                             4 * (size_t)DX_SCR * sizeof(float);   // 69,632 + 9,216 B
 
 __device__ __forceinline__ void split2x8(const f32x4& a, const f32x4& b, u32x4& hi, u32x4& lo) {
 #pragma unroll
@@ -1239,25 +1248,25 @@ __global__ __launch_bounds__(256, 2) void dx16b_kernel(const unsigned short* __r
   const unsigned short* x = xin + gr_e * D + seg * 8;
   unsigned short* gx = gxo + gr_e * D + seg * 8;
 
-  // staging: 2 planes x 32 channels x 16 sixteen-byte pieces (8 of dU, 8 of W) = 1024 pieces
-  u32x4 st[4];
+  // staging: 2 planes x 64 channels x 16 sixteen-byte pieces (8 of dU, 8 of W) = 2048 pieces
+  u32x4 st[8];
   auto stage_load = [&](int chunk) {
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
+    for (int v = 0; v < 8; ++v) {
       const int idx = v * 256 + threadIdx.x;
-      const int pl = idx >> 9, dl = (idx >> 4) & 31, c = idx & 15;
+      const int pl = idx >> 10, dl = (idx >> 4) & 63, c = idx & 15;
       const unsigned short* src =
-          c < 8 ? dub + ((int64_t)pl * D + chunk * DX_CH + dl) * K + 8 * c
-                : w2 + ((int64_t)pl * D + chunk * DX_CH + dl) * K + 8 * (c - 8);
+          c < 8 ? dub + ((int64_t)pl * D + chunk * DXB_CH + dl) * K + 8 * c
+                : w2 + ((int64_t)pl * D + chunk * DXB_CH + dl) * K + 8 * (c - 8);
       st[v] = *reinterpret_cast<const u32x4*>(src);
     }
   };
   auto stage_store = [&](int buf) {
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
+    for (int v = 0; v < 8; ++v) {
       const int idx = v * 256 + threadIdx.x;
-      const int pl = idx >> 9, dl = (idx >> 4) & 31, c = idx & 15;
-      *reinterpret_cast<u32x4*>(bl + buf * DXB_CHUNK + (pl * DX_CH + dl) * DXB_LD + 8 * c) = st[v];
+      const int pl = idx >> 10, dl = (idx >> 4) & 63, c = idx & 15;
+      *reinterpret_cast<u32x4*>(bl + buf * DXB_CHUNK + (pl * DXB_CH + dl) * DXB_LD + 8 * c) = st[v];
     }
   };
 
@@ -1265,28 +1274,42 @@ __global__ __launch_bounds__(256, 2) void dx16b_kernel(const unsigned short* __r
   stage_store(0);
   __syncthreads();
 #pragma unroll 1
-  for (int c = 0; c < D / DX_CH; ++c) {
-    const bool more = c + 1 < D / DX_CH;
+  for (int c = 0; c < D / DXB_CH; ++c) {
+    const bool more = c + 1 < D / DXB_CH;
     if (more) stage_load(c + 1);
-    u32x4 xraw{0u, 0u, 0u, 0u};
-    if (active && proj) xraw = *reinterpret_cast<const u32x4*>(x + c * DX_CH);
-    if (active) {
+    u32x4 xraw2[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
+    if (active && proj) {
+      xraw2[0] = *reinterpret_cast<const u32x4*>(x + c * DXB_CH);
+      xraw2[1] = *reinterpret_cast<const u32x4*>(x + c * DXB_CH + DX_CH);
+    }
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {      // two 32-channel blocks per staged chunk
+     const u32x4 xraw = xraw2[sub];
+     if (active) {
       // B fragment of (channel tile dt, k-step s, plane pl): channel 16 dt + i, k 32 s + 8 g ..
-      const unsigned short* wb = bl + (c & 1) * DXB_CHUNK + i * DXB_LD + 8 * g;
+      const unsigned short* wb =
+          bl + (c & 1) * DXB_CHUNK + (DX_CH * sub + i) * DXB_LD + 8 * g;
       f32x4 acc[2];
       acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
       acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      // fragments of step q + 1 (q = 2 * k-step + channel tile) fly under the MFMAs of step q
+      u32x4 bq[2][2];
+      bq[0][0] = *reinterpret_cast<const u32x4*>(wb);
+      bq[0][1] = *reinterpret_cast<const u32x4*>(wb + DXB_CH * DXB_LD);
 #pragma unroll
-      for (int s2 = 0; s2 < 4; ++s2) {
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          const u32x4 bh = *reinterpret_cast<const u32x4*>(wb + (16 * dt) * DXB_LD + 32 * s2);
-          const u32x4 blo =
-              *reinterpret_cast<const u32x4*>(wb + (DX_CH + 16 * dt) * DXB_LD + 32 * s2);
-          acc[dt] = mfma16b(ah[s2], bh, acc[dt]);
-          acc[dt] = mfma16b(ah[s2], blo, acc[dt]);
-          acc[dt] = mfma16b(al[s2], bh, acc[dt]);
+      for (int q = 0; q < 8; ++q) {
+        const int s2 = q >> 1, dt = q & 1;
+        if (q + 1 < 8) {
+          const int s3 = (q + 1) >> 1, d3 = (q + 1) & 1;
+          bq[(q + 1) & 1][0] =
+              *reinterpret_cast<const u32x4*>(wb + (16 * d3) * DXB_LD + 32 * s3);
+          bq[(q + 1) & 1][1] =
+              *reinterpret_cast<const u32x4*>(wb + (DXB_CH + 16 * d3) * DXB_LD + 32 * s3);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        acc[dt] = mfma16b(ah[s2], bq[q & 1][0], acc[dt]);
+        acc[dt] = mfma16b(ah[s2], bq[q & 1][1], acc[dt]);
+        acc[dt] = mfma16b(al[s2], bq[q & 1][0], acc[dt]);
       }
       // transpose the [16 x 32] block: accumulator (row 4g+j, channel 16dt+i) -> rows
 #pragma unroll
@@ -1313,8 +1336,9 @@ __global__ __launch_bounds__(256, 2) void dx16b_kernel(const unsigned short* __r
         }
 #pragma unroll
         for (int cc = 0; cc < 8; ++cc) out[cc] *= rn_e;
-        Elem8<unsigned short>::st(gx + c * DX_CH, out);
+        Elem8<unsigned short>::st(gx + c * DXB_CH + DX_CH * sub, out);
       }
+     }
     }
     if (more) stage_store((c + 1) & 1);
     __syncthreads();
