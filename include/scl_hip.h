@@ -231,6 +231,19 @@ int scl_vgg_pool_bwd(const void* g, const void* a, const void* z, int dtype, int
                      int C, void* gz, float* bias_grad, void* workspace, size_t workspace_bytes,
                      void* stream);
 
+/* 3x3 / stride 1 / same-padding convolution, 64 -> 64 channels, bf16 channels-last
+ * activations, float32 accumulation — VGG16's conv1_2 (model/nets.py:41-42), forward and
+ * backward-data, in place of the library kernel.
+ *   x, out   [B,H,W,64] bf16
+ *   w        bf16 weights, logical [k_out][c_in][3][3] addressed through its element strides
+ *   transposed 0: out = conv(x, w)                       (forward)
+ *              1: out = conv_transpose(x, w) = d loss / d input for x = d loss / d output
+ *   workspace scl_conv64_workspace_bytes() bytes (the packed weight image). */
+size_t scl_conv64_workspace_bytes(void);
+int scl_conv64(const void* x, const void* w, int64_t w_stride_k, int64_t w_stride_c,
+               int64_t w_stride_h, int64_t w_stride_w, int transposed, int B, int H, int W,
+               void* out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Diagnostics (bench.py's live per-kernel timing; the reference has no counterpart
  * beyond its wall-clock prints, train/train.py:135-161).  Between scl_prof_begin and

@@ -58,6 +58,8 @@ SIGNATURES = {
     "scl_vgg_act_bwd": (_i, [_p, _p, _i, _l, _i, _p, _p, _p, _z, _p]),
     "scl_vgg_pool_fwd": (_i, [_p, _i, _p, _i, _i, _i, _i, _p, _p]),
     "scl_vgg_pool_bwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _z, _p]),
+    "scl_conv64_workspace_bytes": (_z, []),
+    "scl_conv64": (_i, [_p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _p, _p, _z, _p]),
     "scl_debug_set_variant": (_i, [_i]),
     "scl_prof_begin": (_i, [_i]),
     "scl_prof_count": (_i, []),

@@ -1,0 +1,213 @@
+// 3x3 / stride 1 / same-padding convolution with 64 input and 64 output channels on bf16
+// channels-last activations — VGG16's conv1_2 at full resolution (model/nets.py:41-42), the
+// one layer where the library kernels run at half the rate of its equal-FLOP siblings
+// (DESIGN.md §7).  Used for the forward pass and, with the weights transposed and the taps
+// flipped, for the backward-data pass.
+//
+// Implicit GEMM on v_mfma_f32_32x32x16_bf16: out[p][k] = sum_{tap, c} x[p + s_tap][c] W[tap][c][k],
+// M = pixels, N = 64, K = 9 taps x 64 channels = 36 k-steps of 16.  The contraction index c is
+// the FAST index of x, so an A fragment (pixel r, 8 consecutive channels) is one ds_read_b128
+// out of a [10 rows][34 cols][64 ch] halo window in LDS at a per-tap offset — no im2col.
+//   * persistent grid, one 256-thread workgroup per CU; each loops over 8 x 32-pixel tiles;
+//   * wave (nt, half) owns output channels 32 nt .. +31 of tile rows 4 half .. +3; its whole
+//     weight slice [36 k-steps][8 bf16 per lane] = 144 VGPRs stays in REGISTERS for the life
+//     of the kernel (occupancy 1: 512 registers per lane), so LDS holds only the window;
+//   * the next tile's window is loaded into registers before the MFMAs of the current one and
+//     written to the other LDS buffer after them (zero padding at image borders by
+//     predication); one barrier per tile;
+//   * epilogue: f32 accumulators -> bf16 through a per-wave LDS transpose -> 16-byte stores.
+#include <mutex>
+
+#include "scl_common.h"
+
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int C64 = 64;
+constexpr int TH = 8, TW = 32;                       // output tile
+constexpr int WR = TH + 2, WC = TW + 2;              // halo window
+constexpr int PIX_LD = 72;                           // bf16 per staged pixel (64 + 8 pad = 144 B:
+                                                     // rows 9 slots apart -> conflict-free b128)
+constexpr int WIN = WR * WC * PIX_LD;                // bf16 per window buffer (24,480)
+constexpr int PIECES = WR * WC * 8;                  // 16-byte pieces per window (2720)
+constexpr int NPT = (PIECES + 255) / 256;            // pieces per thread (11)
+constexpr int SCR_LD = 40;                           // bf16 per scratch row (32 ch + 8 pad)
+constexpr int SCR = 32 * SCR_LD;                     // per-wave epilogue scratch (one tile row)
+constexpr size_t kConv64Lds = (2 * (size_t)WIN + 4 * (size_t)SCR) * sizeof(unsigned short);
+
+__device__ __forceinline__ f32x16 mfma32b(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                 __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// Weights -> register image [nt 2][ks 36][lane 64][8 bf16].
+//   transposed = 0 (forward):       B[c][k] = w[k][c][kh][kw]
+//   transposed = 1 (backward-data): B[k][c] = w[k][c][2-kh][2-kw]  (contraction over k)
+// w is addressed through its element strides (OIHW logical, any memory format).
+__global__ __launch_bounds__(256) void conv64_pack_kernel(const unsigned short* __restrict__ w,
+                                                          int64_t sk, int64_t sc, int64_t sh,
+                                                          int64_t sw, int transposed,
+                                                          unsigned short* __restrict__ packed) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;      // over 2 * 36 * 64 * 8
+  if (idx >= 2 * 36 * 64 * 8) return;
+  const int e = idx & 7, lane = (idx >> 3) & 63, ks = (idx >> 9) % 36, nt = idx / (36 * 512);
+  const int j = lane & 31, h = lane >> 5;
+  const int tap = ks >> 2, kh = tap / 3, kw = tap % 3;
+  const int cin = 16 * (ks & 3) + 8 * h + e;           // contraction index
+  const int cout = 32 * nt + j;                        // output channel of this pass
+  int64_t off;
+  if (!transposed)
+    off = cout * sk + cin * sc + kh * sh + kw * sw;
+  else
+    off = cin * sk + cout * sc + (2 - kh) * sh + (2 - kw) * sw;
+  packed[idx] = w[off];
+}
+
+// grid = number of CUs (persistent); block 256.
+__global__ __launch_bounds__(256, 1) void conv64_kernel(const unsigned short* __restrict__ x,
+                                                        const unsigned short* __restrict__ packed,
+                                                        int B, int H, int W,
+                                                        unsigned short* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int nt = wid & 1, half = wid >> 1;
+  unsigned short* scr = lds + 2 * WIN + wid * SCR;
+
+  // the wave's weight slice: 36 fragments of 16 bytes per lane
+  u32x4 wf[36];
+#pragma unroll
+  for (int ks = 0; ks < 36; ++ks)
+    wf[ks] = *reinterpret_cast<const u32x4*>(packed + (((int64_t)nt * 36 + ks) * 64 + lane) * 8);
+
+  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+  const int per_img = tiles_x * tiles_y;
+  const int ntiles = B * per_img;
+
+  u32x4 st[NPT];
+  auto stage_load = [&](int tile) {
+    const int b = tile / per_img, t2 = tile % per_img;
+    const int y0 = (t2 / tiles_x) * TH - 1, x0 = (t2 % tiles_x) * TW - 1;
+#pragma unroll
+    for (int v = 0; v < NPT; ++v) {
+      const int idx = v * 256 + threadIdx.x;
+      const int pix = idx >> 3, c = idx & 7;
+      const int wy = pix / WC, wx = pix % WC;
+      const int y = y0 + wy, xx = x0 + wx;
+      const bool ok = idx < PIECES && y >= 0 && y < H && xx >= 0 && xx < W;
+      st[v] = ok ? *reinterpret_cast<const u32x4*>(
+                       x + (((int64_t)b * H + y) * W + xx) * C64 + 8 * c)
+                 : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int v = 0; v < NPT; ++v) {
+      const int idx = v * 256 + threadIdx.x;
+      if (idx < PIECES)
+        *reinterpret_cast<u32x4*>(lds + buf * WIN + (idx >> 3) * PIX_LD + 8 * (idx & 7)) = st[v];
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < ntiles) {
+    stage_load(tile);
+    stage_store(0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int next = tile + gridDim.x;
+    if (next < ntiles) stage_load(next);
+
+    // A fragment of (tile row mt, k-step ks): window pixel (4 half + mt + kh, r + kw),
+    // channels 16 (ks & 3) + 8 h .. + 7
+    const unsigned short* wb = lds + buf * WIN + ((4 * half) * WC + r) * PIX_LD + 8 * h;
+    f32x16 acc[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[mt] = zero16();
+    u32x4 af[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+      af[0][mt] = *reinterpret_cast<const u32x4*>(wb + mt * WC * PIX_LD);
+#pragma unroll
+    for (int ks = 0; ks < 36; ++ks) {
+      if (ks + 1 < 36) {
+        const int tap = (ks + 1) >> 2, kh = tap / 3, kw = tap % 3;
+        const int off = (kh * WC + kw) * PIX_LD + 16 * ((ks + 1) & 3);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+          af[(ks + 1) & 1][mt] =
+              *reinterpret_cast<const u32x4*>(wb + mt * WC * PIX_LD + off);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma32b(af[ks & 1][mt], wf[ks], acc[mt]);
+    }
+
+    // epilogue: tile row 4 half + mt, accumulator register q <-> column acc_row(q, h),
+    // lane r <-> output channel 32 nt + r
+    const int b = tile / per_img, t2 = tile % per_img;
+    const int oy0 = (t2 / tiles_x) * TH + 4 * half, ox0 = (t2 % tiles_x) * TW;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) scr[acc_row(q, h) * SCR_LD + r] = f32_to_bf16(acc[mt][q]);
+      __builtin_amdgcn_wave_barrier();
+      // 32 pixels x 64 bytes: lane -> pixel lane >> 1 (+ 0), 32-byte half lane & 1
+      const int px = lane >> 1, hf = lane & 1;
+      const u32x4 v0 = *reinterpret_cast<const u32x4*>(scr + px * SCR_LD + 16 * hf);
+      const u32x4 v1 = *reinterpret_cast<const u32x4*>(scr + px * SCR_LD + 16 * hf + 8);
+      __builtin_amdgcn_wave_barrier();
+      const int oy = oy0 + mt, ox = ox0 + px;
+      if (oy < H && ox < W) {
+        unsigned short* o = out + (((int64_t)b * H + oy) * W + ox) * C64 + 32 * nt + 16 * hf;
+        *reinterpret_cast<u32x4*>(o) = v0;
+        *reinterpret_cast<u32x4*>(o + 8) = v1;
+      }
+    }
+
+    if (next < ntiles) stage_store(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+}
+
+}  // namespace
+
+extern "C" size_t scl_conv64_workspace_bytes(void) {
+  return scl_round256((size_t)2 * 36 * 64 * 8 * sizeof(unsigned short));
+}
+
+extern "C" int scl_conv64(const void* x, const void* w, int64_t w_stride_k, int64_t w_stride_c,
+                          int64_t w_stride_h, int64_t w_stride_w, int transposed, int B, int H,
+                          int W, void* out, void* workspace, size_t workspace_bytes,
+                          void* stream) {
+  if (!x || !w || !out || !workspace) return SCL_E_NULL;
+  if (B < 1 || H < 1 || W < 1 || (int64_t)B * H * W > (int64_t)1 << 30) return SCL_E_SHAPE;
+  if (((uintptr_t)x % 16) || ((uintptr_t)out % 16)) return SCL_E_SHAPE;
+  if (!scl_aligned256(workspace) || workspace_bytes < scl_conv64_workspace_bytes())
+    return SCL_E_WORKSPACE;
+  static std::once_flag once;
+  static int cus = 256;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv64_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kConv64Lds);
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+      cus = n;
+  });
+  hipStream_t st = (hipStream_t)stream;
+  unsigned short* packed = (unsigned short*)workspace;
+  SCL_LAUNCH("conv64_pack_kernel", conv64_pack_kernel, dim3(2 * 36 * 64 * 8 / 256), dim3(256), 0, st,
+             (const unsigned short*)w, w_stride_k, w_stride_c, w_stride_h, w_stride_w,
+             transposed ? 1 : 0, packed);
+  const int tiles = B * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+  SCL_LAUNCH("conv64_kernel", conv64_kernel, dim3(tiles < cus ? tiles : cus), dim3(256), kConv64Lds,
+             st, (const unsigned short*)x, (const unsigned short*)packed, B, H, W,
+             (unsigned short*)out);
+  return scl_launch_status();
+}

@@ -13,6 +13,8 @@ the reference's checkpoint names and shapes (HWIO kernels, [1,1,512,64] assignme
 """
 import math
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -89,12 +91,44 @@ _CL = torch.channels_last
 _ONES = [1, 1]
 
 
+# conv1_2 (64 -> 64 channels at full resolution) runs on csrc/conv64.hip: the library kernels
+# take twice as long there as on the equal-FLOP layers.  SCL_CONV64=0 restores MIOpen.
+USE_CONV64 = os.environ.get('SCL_CONV64', '1') != '0'
+
+
+def _conv64_ok(x, w):
+    return (USE_CONV64 and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
+            and x.dim() == 4 and x.shape[1] == 64 and tuple(w.shape) == (64, 64, 3, 3))
+
+
+def conv64(x, w, transposed=False):
+    """3x3 same-padding convolution 64 -> 64 on bf16 channels-last activations
+    (``scl_conv64``); ``transposed`` gives the gradient with respect to the input."""
+    lib = L.load()
+    L.require_device(x, w)
+    x = x.contiguous(memory_format=_CL)
+    b, _, h, wd = x.shape
+    out = torch.empty_like(x, memory_format=_CL)
+    ws = L.workspace(lib.scl_conv64_workspace_bytes(), x.device)
+    sk, sc, sh, sw = w.stride()
+    L.check(lib.scl_conv64(L.ptr(x), L.ptr(w), sk, sc, sh, sw, int(bool(transposed)), b, h, wd,
+                           L.ptr(out), L.ptr(ws), ws.numel(), L.stream_of(x)))
+    return out
+
+
 def _conv3x3(x, w):
-    """MIOpen 3x3 / stride 1 / same-padding convolution without bias."""
+    """3x3 / stride 1 / same-padding convolution without bias (MIOpen, or conv64)."""
+    if _conv64_ok(x, w):
+        return conv64(x, w, False)
     return torch.ops.aten.convolution(x, w, None, _ONES, _ONES, _ONES, False, [0, 0], 1)
 
 
 def _conv3x3_backward(gz, x, w, need_x):
+    if _conv64_ok(gz, w):
+        gx = conv64(gz, w, True) if need_x else None
+        _, gw, _ = torch.ops.aten.convolution_backward(gz, x, w, None, _ONES, _ONES, _ONES, False,
+                                                       [0, 0], 1, [False, True, False])
+        return gx, gw
     gx, gw, _ = torch.ops.aten.convolution_backward(gz, x, w, None, _ONES, _ONES, _ONES, False,
                                                     [0, 0], 1, [bool(need_x), True, False])
     return gx, gw

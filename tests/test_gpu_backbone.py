@@ -136,3 +136,26 @@ def test_pool_bwd_odd_sizes_zero_the_uncovered_border(dev):
     zr = z.permute(0, 3, 1, 2).clone().requires_grad_(True)
     F.relu(F.max_pool2d(zr, 2, 2)).backward(g.permute(0, 3, 1, 2))
     assert torch.equal(gz.permute(0, 3, 1, 2), zr.grad)
+
+
+@pytest.mark.parametrize('shape', [(2, 20, 40), (1, 13, 37), (3, 8, 32), (1, 33, 70)])
+def test_conv64_forward_and_backward_data(dev, shape):
+    """csrc/conv64.hip (conv1_2's kernel) against a float32 convolution of the same bf16 data."""
+    from soft_contrastive_learning_amd.model import nets
+    b, h, w = shape
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(b, 64, h, w, generator=g).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(64, 64, 3, 3, generator=g) * 0.05).to(dev).bfloat16()
+    for wv in (wt, wt.contiguous(memory_format=torch.channels_last)):     # any weight strides
+        got = nets.conv64(x, wv, False)
+        want = torch.nn.functional.conv2d(x.float(), wv.float(), padding=1)
+        assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+        err = (got.float() - want).abs().max() / want.abs().max()
+        assert float(err) < 6e-3, float(err)                      # bf16 output rounding
+        gx = nets.conv64(x, wv, True)
+        want_gx = torch.nn.functional.conv_transpose2d(x.float(), wv.float(), padding=1)
+        err = (gx.float() - want_gx).abs().max() / want_gx.abs().max()
+        assert float(err) < 6e-3, float(err)
+    # agrees with the library kernel to bf16 rounding as well
+    lib_out = torch.ops.aten.convolution(x, wt, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1)
+    assert float((got.float() - lib_out.float()).abs().max() / lib_out.float().abs().max()) < 1.2e-2
