@@ -244,6 +244,14 @@ int scl_conv64(const void* x, const void* w, int64_t w_stride_k, int64_t w_strid
                int64_t w_stride_h, int64_t w_stride_w, int transposed, int B, int H, int W,
                void* out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Weight gradient of the same layer: gw[k][c][kh][kw] = sum_{b,y,x} gz[b,y,x,k] *
+ * x[b, y+kh-1, x+kw-1, c]; x, gz [B,H,W,64] bf16, gw bf16 written at the given element
+ * strides (logical [64][64][3][3]).  Deterministic (per-CU slabs summed in a fixed order). */
+size_t scl_wrw64_workspace_bytes(void);
+int scl_wrw64(const void* x, const void* gz, int B, int H, int W, void* gw, int64_t w_stride_k,
+              int64_t w_stride_c, int64_t w_stride_h, int64_t w_stride_w, void* workspace,
+              size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Diagnostics (bench.py's live per-kernel timing; the reference has no counterpart
  * beyond its wall-clock prints, train/train.py:135-161).  Between scl_prof_begin and

@@ -175,6 +175,148 @@ __global__ __launch_bounds__(256, 1) void conv64_kernel(const unsigned short* __
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// wrw64_kernel: weight gradient of the same layer,
+//   dW[k][c][kh][kw] = sum_{b,y,x} gz[b,y,x,k] * x[b, y+kh-1, x+kw-1, c].
+// The contraction runs over pixels — the SLOW index of both channels-last operands — so both
+// MFMA operands are read with ds_read_b64_tr_b16 out of row-major LDS tiles (the x halo
+// window of conv64_kernel and the gz tile); a tap is again just an address offset.
+//   * v_mfma_f32_32x32x16_bf16 with M = 32 input channels, N = 32 output channels, 16 pixels
+//     per step; wave (mt, nt) keeps all nine taps of its 32 x 32 block: 144 accumulators;
+//   * persistent grid, one workgroup per CU accumulating over all its tiles, then ONE slab
+//     [9][64][64] float32 per workgroup; wrw64_reduce_kernel sums the slabs in a fixed order
+//     into the weight's own layout (bf16).
+constexpr int GZ = TH * TW * PIX_LD;                 // bf16 of the staged gz tile
+constexpr int GPIECES = TH * TW * 8;                 // 2048
+constexpr size_t kWrw64Lds = ((size_t)WIN + (size_t)GZ) * sizeof(unsigned short);   // 85,824 B
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ u32x4 tr_pair(const unsigned short* a0, int step4) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (s16x4 __attribute__((address_space(3)))*)(a0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (s16x4 __attribute__((address_space(3)))*)(a0 + step4));
+  const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+  return u32x4{l2.x, l2.y, h2.x, h2.y};
+}
+
+__global__ __launch_bounds__(256, 1) void wrw64_kernel(const unsigned short* __restrict__ x,
+                                                       const unsigned short* __restrict__ gz,
+                                                       int B, int H, int W,
+                                                       float* __restrict__ slabs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+  unsigned short* gl = lds + WIN;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int mt = wid & 1, nt = wid >> 1;
+  // transposed-read role of this lane: 16-lane group gq = lane >> 4 covers channels
+  // 16 (gq & 1) .. + 15 and pixels 8 (gq >> 1) + q (+ 4); lane 4q + p addresses row q,
+  // columns 4p .. 4p + 3
+  const int q = (lane >> 2) & 3, pp = lane & 3, gq = lane >> 4;
+  const int pix0 = 8 * (gq >> 1) + q, ch0 = 16 * (gq & 1) + 4 * pp;
+
+  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+  const int per_img = tiles_x * tiles_y;
+  const int ntiles = B * per_img;
+
+  u32x4 st_x[NPT], st_g[GPIECES / 256];
+  auto stage_load = [&](int tile) {
+    const int b = tile / per_img, t2 = tile % per_img;
+    const int ty = (t2 / tiles_x) * TH, tx = (t2 % tiles_x) * TW;
+#pragma unroll
+    for (int v = 0; v < NPT; ++v) {
+      const int idx = v * 256 + threadIdx.x;
+      const int pix = idx >> 3, c = idx & 7;
+      const int y = ty - 1 + pix / WC, xx = tx - 1 + pix % WC;
+      const bool ok = idx < PIECES && y >= 0 && y < H && xx >= 0 && xx < W;
+      st_x[v] = ok ? *reinterpret_cast<const u32x4*>(
+                         x + (((int64_t)b * H + y) * W + xx) * C64 + 8 * c)
+                   : u32x4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int v = 0; v < GPIECES / 256; ++v) {
+      const int idx = v * 256 + threadIdx.x;
+      const int pix = idx >> 3, c = idx & 7;
+      const int y = ty + pix / TW, xx = tx + pix % TW;
+      const bool ok = y < H && xx < W;
+      st_g[v] = ok ? *reinterpret_cast<const u32x4*>(
+                         gz + (((int64_t)b * H + y) * W + xx) * C64 + 8 * c)
+                   : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  auto stage_store = [&]() {
+#pragma unroll
+    for (int v = 0; v < NPT; ++v) {
+      const int idx = v * 256 + threadIdx.x;
+      if (idx < PIECES)
+        *reinterpret_cast<u32x4*>(lds + (idx >> 3) * PIX_LD + 8 * (idx & 7)) = st_x[v];
+    }
+#pragma unroll
+    for (int v = 0; v < GPIECES / 256; ++v) {
+      const int idx = v * 256 + threadIdx.x;
+      *reinterpret_cast<u32x4*>(gl + (idx >> 3) * PIX_LD + 8 * (idx & 7)) = st_g[v];
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = zero16();
+
+  int tile = blockIdx.x;
+  if (tile < ntiles) {
+    stage_load(tile);
+    stage_store();
+  }
+  __syncthreads();
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int next = tile + gridDim.x;
+    if (next < ntiles) stage_load(next);
+#pragma unroll 1
+    for (int step = 0; step < 2 * TH; ++step) {
+      const int ry = step >> 1, cx = 16 * (step & 1);
+      // B: gz pixels (ry, cx + 8h .. + 7) x output channels 32 nt ..
+      const u32x4 bf = tr_pair(gl + (ry * TW + cx + pix0) * PIX_LD + 32 * nt + ch0, 4 * PIX_LD);
+      // A of tap (kh, kw): x window pixels (ry + kh, cx + kw + 8h ..) x channels 32 mt ..
+      const unsigned short* ab = lds + (ry * WC + cx + pix0) * PIX_LD + 32 * mt + ch0;
+      u32x4 af[2];
+      af[0] = tr_pair(ab, 4 * PIX_LD);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        if (t + 1 < 9) {
+          const int kh = (t + 1) / 3, kw = (t + 1) % 3;
+          af[(t + 1) & 1] = tr_pair(ab + (kh * WC + kw) * PIX_LD, 4 * PIX_LD);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc[t] = mfma32b(af[t & 1], bf, acc[t]);
+      }
+    }
+    __syncthreads();                     // every wave is done with the staged tile
+    if (next < ntiles) stage_store();
+    __syncthreads();
+  }
+
+  // slab[wg][tap][c][k]: accumulator register qq <-> c = 32 mt + acc_row(qq, h), lane r <-> k
+  float* out = slabs + (int64_t)blockIdx.x * 9 * C64 * C64;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int qq = 0; qq < 16; ++qq)
+      out[(t * C64 + 32 * mt + acc_row(qq, h)) * C64 + 32 * nt + r] = acc[t][qq];
+}
+
+// dW element (k, c, kh, kw) = sum over workgroup slabs, written as bf16 at the weight's strides.
+__global__ __launch_bounds__(256) void wrw64_reduce_kernel(const float* __restrict__ slabs,
+                                                           int nslabs, int64_t sk, int64_t sc,
+                                                           int64_t sh, int64_t sw,
+                                                           unsigned short* __restrict__ gw) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;      // over 9 * 64 * 64, k fastest
+  if (idx >= 9 * C64 * C64) return;
+  float s = 0.f;
+  for (int i = 0; i < nslabs; ++i) s += slabs[(int64_t)i * 9 * C64 * C64 + idx];
+  const int k = idx & 63, c = (idx >> 6) & 63, t = idx >> 12;
+  gw[k * sk + c * sc + (t / 3) * sh + (t % 3) * sw] = f32_to_bf16(s);
+}
+
 }  // namespace
 
 extern "C" size_t scl_conv64_workspace_bytes(void) {
@@ -209,5 +351,45 @@ extern "C" int scl_conv64(const void* x, const void* w, int64_t w_stride_k, int6
   SCL_LAUNCH("conv64_kernel", conv64_kernel, dim3(tiles < cus ? tiles : cus), dim3(256), kConv64Lds,
              st, (const unsigned short*)x, (const unsigned short*)packed, B, H, W,
              (unsigned short*)out);
+  return scl_launch_status();
+}
+
+static int conv64_cus() {
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) == hipSuccess &&
+      hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+    return n;
+  return 256;
+}
+
+extern "C" size_t scl_wrw64_workspace_bytes(void) {
+  return scl_round256((size_t)1024 * 9 * 64 * 64 * sizeof(float));   // up to 1024 CUs
+}
+
+extern "C" int scl_wrw64(const void* x, const void* gz, int B, int H, int W, void* gw,
+                         int64_t w_stride_k, int64_t w_stride_c, int64_t w_stride_h,
+                         int64_t w_stride_w, void* workspace, size_t workspace_bytes,
+                         void* stream) {
+  if (!x || !gz || !gw || !workspace) return SCL_E_NULL;
+  if (B < 1 || H < 1 || W < 1 || (int64_t)B * H * W > (int64_t)1 << 30) return SCL_E_SHAPE;
+  if (((uintptr_t)x % 16) || ((uintptr_t)gz % 16)) return SCL_E_SHAPE;
+  if (!scl_aligned256(workspace) || workspace_bytes < scl_wrw64_workspace_bytes())
+    return SCL_E_WORKSPACE;
+  static std::once_flag once;
+  static int cus = 256;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wrw64_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWrw64Lds);
+    cus = conv64_cus();
+    if (cus > 1024) cus = 1024;
+  });
+  const int tiles = B * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+  const int grid = tiles < cus ? tiles : cus;
+  hipStream_t st = (hipStream_t)stream;
+  SCL_LAUNCH("wrw64_kernel", wrw64_kernel, dim3(grid), dim3(256), kWrw64Lds, st,
+             (const unsigned short*)x, (const unsigned short*)gz, B, H, W, (float*)workspace);
+  SCL_LAUNCH("wrw64_reduce_kernel", wrw64_reduce_kernel, dim3(9 * 64 * 64 / 256), dim3(256), 0, st,
+             (const float*)workspace, grid, w_stride_k, w_stride_c, w_stride_h, w_stride_w,
+             (unsigned short*)gw);
   return scl_launch_status();
 }

@@ -116,6 +116,22 @@ def conv64(x, w, transposed=False):
     return out
 
 
+def wrw64(x, gz, w_like):
+    """Weight gradient of the 64 -> 64 convolution (``scl_wrw64``): [64,64,3,3] bf16 with the
+    strides of ``w_like``."""
+    lib = L.load()
+    L.require_device(x, gz)
+    x = x.contiguous(memory_format=_CL)
+    gz = gz.contiguous(memory_format=_CL)
+    b, _, h, wd = x.shape
+    gw = torch.empty_like(w_like)
+    ws = L.workspace(lib.scl_wrw64_workspace_bytes(), x.device)
+    sk, sc, sh, sw = gw.stride()
+    L.check(lib.scl_wrw64(L.ptr(x), L.ptr(gz), b, h, wd, L.ptr(gw), sk, sc, sh, sw, L.ptr(ws),
+                          ws.numel(), L.stream_of(x)))
+    return gw
+
+
 def _conv3x3(x, w):
     """3x3 / stride 1 / same-padding convolution without bias (MIOpen, or conv64)."""
     if _conv64_ok(x, w):
@@ -126,9 +142,7 @@ def _conv3x3(x, w):
 def _conv3x3_backward(gz, x, w, need_x):
     if _conv64_ok(gz, w):
         gx = conv64(gz, w, True) if need_x else None
-        _, gw, _ = torch.ops.aten.convolution_backward(gz, x, w, None, _ONES, _ONES, _ONES, False,
-                                                       [0, 0], 1, [False, True, False])
-        return gx, gw
+        return gx, wrw64(x, gz, w)
     gx, gw, _ = torch.ops.aten.convolution_backward(gz, x, w, None, _ONES, _ONES, _ONES, False,
                                                     [0, 0], 1, [bool(need_x), True, False])
     return gx, gw

@@ -159,3 +159,25 @@ def test_conv64_forward_and_backward_data(dev, shape):
     # agrees with the library kernel to bf16 rounding as well
     lib_out = torch.ops.aten.convolution(x, wt, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1)
     assert float((got.float() - lib_out.float()).abs().max() / lib_out.float().abs().max()) < 1.2e-2
+
+
+@pytest.mark.parametrize('shape', [(2, 20, 40), (1, 13, 37), (3, 8, 32), (2, 33, 70)])
+def test_wrw64_weight_gradient(dev, shape):
+    from soft_contrastive_learning_amd.model import nets
+    b, h, w = shape
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(b, 64, h, w, generator=g).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    gz = torch.randn(b, 64, h, w, generator=g).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    xf = x.float().requires_grad_(False)
+    wf = torch.zeros(64, 64, 3, 3, device=dev, requires_grad=True)
+    torch.nn.functional.conv2d(xf, wf, padding=1).backward(gz.float())
+    want = wf.grad
+    for like in (torch.empty(64, 64, 3, 3, device=dev, dtype=torch.bfloat16),
+                 torch.empty(64, 64, 3, 3, device=dev, dtype=torch.bfloat16).contiguous(
+                     memory_format=torch.channels_last)):
+        got = nets.wrw64(x, gz, like)
+        assert got.stride() == like.stride()
+        err = (got.float() - want).abs().max() / want.abs().max()
+        assert float(err) < 6e-3, float(err)
+    again = nets.wrw64(x, gz, like)
+    assert torch.equal(got, again)                       # fixed-order slab reduction
