@@ -305,16 +305,29 @@ __global__ __launch_bounds__(256, 1) void wrw64_kernel(const unsigned short* __r
 }
 
 // dW element (k, c, kh, kw) = sum over workgroup slabs, written as bf16 at the weight's strides.
+// grid 9*64*64/64, block 256: thread (j, g) sums the slabs i = g, g + 4, ... of element
+// 64 * blockIdx.x + j; the four partials are combined in a fixed order.
 __global__ __launch_bounds__(256) void wrw64_reduce_kernel(const float* __restrict__ slabs,
                                                            int nslabs, int64_t sk, int64_t sc,
                                                            int64_t sh, int64_t sw,
                                                            unsigned short* __restrict__ gw) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;      // over 9 * 64 * 64, k fastest
-  if (idx >= 9 * C64 * C64) return;
-  float s = 0.f;
-  for (int i = 0; i < nslabs; ++i) s += slabs[(int64_t)i * 9 * C64 * C64 + idx];
-  const int k = idx & 63, c = (idx >> 6) & 63, t = idx >> 12;
-  gw[k * sk + c * sc + (t / 3) * sh + (t % 3) * sw] = f32_to_bf16(s);
+  __shared__ float red[4][64];
+  const int j = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + j;                 // over 9 * 64 * 64, k fastest
+  float s0 = 0.f, s1 = 0.f;
+  int i = g;
+  for (; i + 4 < nslabs; i += 8) {
+    s0 += slabs[(int64_t)i * 9 * C64 * C64 + idx];
+    s1 += slabs[(int64_t)(i + 4) * 9 * C64 * C64 + idx];
+  }
+  if (i < nslabs) s0 += slabs[(int64_t)i * 9 * C64 * C64 + idx];
+  red[g][j] = s0 + s1;
+  __syncthreads();
+  if (g == 0) {
+    const float s = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+    const int k = idx & 63, c = (idx >> 6) & 63, t = idx >> 12;
+    gw[k * sk + c * sc + (t / 3) * sh + (t % 3) * sw] = f32_to_bf16(s);
+  }
 }
 
 }  // namespace
@@ -388,7 +401,7 @@ extern "C" int scl_wrw64(const void* x, const void* gz, int B, int H, int W, voi
   hipStream_t st = (hipStream_t)stream;
   SCL_LAUNCH("wrw64_kernel", wrw64_kernel, dim3(grid), dim3(256), kWrw64Lds, st,
              (const unsigned short*)x, (const unsigned short*)gz, B, H, W, (float*)workspace);
-  SCL_LAUNCH("wrw64_reduce_kernel", wrw64_reduce_kernel, dim3(9 * 64 * 64 / 256), dim3(256), 0, st,
+  SCL_LAUNCH("wrw64_reduce_kernel", wrw64_reduce_kernel, dim3(9 * 64 * 64 / 64), dim3(256), 0, st,
              (const float*)workspace, grid, w_stride_k, w_stride_c, w_stride_h, w_stride_w,
              (unsigned short*)gw);
   return scl_launch_status();
