@@ -244,6 +244,16 @@ int scl_conv64(const void* x, const void* w, int64_t w_stride_k, int64_t w_strid
                int64_t w_stride_h, int64_t w_stride_w, int transposed, int B, int H, int W,
                void* out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same kernel for the other shapes whose weight slice fits the register file:
+ * (cin, kout) in {(64,64), (64,128), (128,64), (128,128)} — conv1_2 and conv2_x, forward and
+ * backward-data (for transposed = 1, cin is the weight's k dimension and kout its c dimension).
+ * x [B,H,W,cin], out [B,H,W,kout] bf16. */
+size_t scl_conv3x3_workspace_bytes(void);
+int scl_conv3x3(const void* x, const void* w, int64_t w_stride_k, int64_t w_stride_c,
+                int64_t w_stride_h, int64_t w_stride_w, int transposed, int B, int H, int W,
+                int cin, int kout, void* out, void* workspace, size_t workspace_bytes,
+                void* stream);
+
 /* Weight gradient of the same layer: gw[k][c][kh][kw] = sum_{b,y,x} gz[b,y,x,k] *
  * x[b, y+kh-1, x+kw-1, c]; x, gz [B,H,W,64] bf16, gw bf16 written at the given element
  * strides (logical [64][64][3][3]).  Deterministic (per-CU slabs summed in a fixed order). */

@@ -71,9 +71,11 @@ def main():
         t = [timed(fwd), timed(bwd) if cin > 3 else float('nan'), timed(wrw)]
         cells = ['%8.1f (%6.0f)' % (v, gf / v * 1e3) for v in t]
         print('%-5s %4d %4d %9.1f | %22s | %22s | %22s' % (name, cin, cout, gf, *cells))
-        if cin == 64 and cout == 64:
-            t = [timed(lambda: nets.conv64(x, wt, False)), timed(lambda: nets.conv64(gy, wt, True)),
-                 timed(lambda: nets.wrw64(x, gy, wt))]
+        if nets._conv64_ok(x, wt):
+            t = [timed(lambda: nets.conv64(x, wt, False)),
+                 timed(lambda: nets.conv64(gy, wt, True)) if nets._conv64_ok(gy, wt, True)
+                 else float('nan'),
+                 timed(lambda: nets.wrw64(x, gy, wt)) if (cin, cout) == (64, 64) else float('nan')]
             cells = ['%8.1f (%6.0f)' % (v, gf / v * 1e3) for v in t]
             print('%-5s %4s %4s %9s | %22s | %22s | %22s' % ('  own', '', '', '', *cells))
 

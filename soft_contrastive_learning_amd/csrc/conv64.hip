@@ -42,20 +42,45 @@ __device__ __forceinline__ f32x16 mfma32b(u32x4 a, u32x4 b, f32x16 c) {
                                                  __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// Weights -> register image [nt 2][ks 36][lane 64][8 bf16].
+// Generalisation to the other VGG shapes whose weight slice still fits the register file:
+//   (CIN, KOUT) in {(64,64) conv1_2 fwd+bwd, (64,128) conv2_1 fwd, (128,64) conv2_1 bwd,
+//   (128,128) conv2_2 fwd+bwd}.  A wave always owns 32 output channels (KOUT / 32 n-tiles)
+// and, when KOUT = 64, one half of the tile's rows; its weights are 9 * CIN / 16 fragments =
+// 144 (CIN = 64) or 288 (CIN = 128) VGPRs.  CIN = 128 uses 4-row tiles so that two halo
+// windows fit LDS.
+template <int CIN, int KOUT>
+struct ConvCfg {
+  static constexpr int TH_ = CIN == 64 ? 8 : 4;
+  static constexpr int WR_ = TH_ + 2;
+  static constexpr int PIX = CIN + 8;                  // bf16 per staged pixel
+  static constexpr int WIN_ = WR_ * WC * PIX;          // bf16 per window buffer
+  static constexpr int PPP = CIN / 8;                  // 16-byte pieces per pixel
+  static constexpr int PIECES_ = WR_ * WC * PPP;
+  static constexpr int NPT_ = (PIECES_ + 255) / 256;
+  static constexpr int SPT = CIN / 16;                 // k-steps per tap
+  static constexpr int KS = 9 * SPT;                   // 36 or 72
+  static constexpr int NT = KOUT / 32;                 // n-tiles: 2 or 4
+  static constexpr int PARTS = 4 / NT;                 // row groups of the tile: 2 or 1
+  static constexpr int MT = TH_ / PARTS;               // tile rows per wave
+  static constexpr size_t LDS = (2 * (size_t)WIN_ + 4 * (size_t)SCR) * sizeof(unsigned short);
+};
+
+// Weights -> register image [nt][ks][lane 64][8 bf16].
 //   transposed = 0 (forward):       B[c][k] = w[k][c][kh][kw]
 //   transposed = 1 (backward-data): B[k][c] = w[k][c][2-kh][2-kw]  (contraction over k)
 // w is addressed through its element strides (OIHW logical, any memory format).
-__global__ __launch_bounds__(256) void conv64_pack_kernel(const unsigned short* __restrict__ w,
-                                                          int64_t sk, int64_t sc, int64_t sh,
-                                                          int64_t sw, int transposed,
-                                                          unsigned short* __restrict__ packed) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;      // over 2 * 36 * 64 * 8
-  if (idx >= 2 * 36 * 64 * 8) return;
-  const int e = idx & 7, lane = (idx >> 3) & 63, ks = (idx >> 9) % 36, nt = idx / (36 * 512);
+template <int CIN, int KOUT>
+__global__ __launch_bounds__(256) void conv3x3_pack_kernel(const unsigned short* __restrict__ w,
+                                                           int64_t sk, int64_t sc, int64_t sh,
+                                                           int64_t sw, int transposed,
+                                                           unsigned short* __restrict__ packed) {
+  using Cfg = ConvCfg<CIN, KOUT>;
+  const int idx = blockIdx.x * 256 + threadIdx.x;      // over NT * KS * 64 * 8
+  if (idx >= Cfg::NT * Cfg::KS * 512) return;
+  const int e = idx & 7, lane = (idx >> 3) & 63, ks = (idx >> 9) % Cfg::KS, nt = idx / (Cfg::KS * 512);
   const int j = lane & 31, h = lane >> 5;
-  const int tap = ks >> 2, kh = tap / 3, kw = tap % 3;
-  const int cin = 16 * (ks & 3) + 8 * h + e;           // contraction index
+  const int tap = ks / Cfg::SPT, kh = tap / 3, kw = tap % 3;
+  const int cin = 16 * (ks % Cfg::SPT) + 8 * h + e;    // contraction index
   const int cout = 32 * nt + j;                        // output channel of this pass
   int64_t off;
   if (!transposed)
@@ -66,48 +91,52 @@ __global__ __launch_bounds__(256) void conv64_pack_kernel(const unsigned short* 
 }
 
 // grid = number of CUs (persistent); block 256.
-__global__ __launch_bounds__(256, 1) void conv64_kernel(const unsigned short* __restrict__ x,
-                                                        const unsigned short* __restrict__ packed,
-                                                        int B, int H, int W,
-                                                        unsigned short* __restrict__ out) {
+template <int CIN, int KOUT>
+__global__ __launch_bounds__(256, 1) void conv3x3_kernel(const unsigned short* __restrict__ x,
+                                                         const unsigned short* __restrict__ packed,
+                                                         int B, int H, int W,
+                                                         unsigned short* __restrict__ out) {
+  using Cfg = ConvCfg<CIN, KOUT>;
+  constexpr int TH_ = Cfg::TH_, PIX = Cfg::PIX, WIN_ = Cfg::WIN_, KS = Cfg::KS, MT = Cfg::MT;
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int nt = wid & 1, half = wid >> 1;
-  unsigned short* scr = lds + 2 * WIN + wid * SCR;
+  const int nt = wid % Cfg::NT, part = wid / Cfg::NT;
+  unsigned short* scr = lds + 2 * WIN_ + wid * SCR;
 
-  // the wave's weight slice: 36 fragments of 16 bytes per lane
-  u32x4 wf[36];
+  // the wave's weight slice: KS fragments of 16 bytes per lane
+  u32x4 wf[KS];
 #pragma unroll
-  for (int ks = 0; ks < 36; ++ks)
-    wf[ks] = *reinterpret_cast<const u32x4*>(packed + (((int64_t)nt * 36 + ks) * 64 + lane) * 8);
+  for (int ks = 0; ks < KS; ++ks)
+    wf[ks] = *reinterpret_cast<const u32x4*>(packed + (((int64_t)nt * KS + ks) * 64 + lane) * 8);
 
-  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH_ - 1) / TH_;
   const int per_img = tiles_x * tiles_y;
   const int ntiles = B * per_img;
 
-  u32x4 st[NPT];
+  u32x4 st[Cfg::NPT_];
   auto stage_load = [&](int tile) {
     const int b = tile / per_img, t2 = tile % per_img;
-    const int y0 = (t2 / tiles_x) * TH - 1, x0 = (t2 % tiles_x) * TW - 1;
+    const int y0 = (t2 / tiles_x) * TH_ - 1, x0 = (t2 % tiles_x) * TW - 1;
 #pragma unroll
-    for (int v = 0; v < NPT; ++v) {
+    for (int v = 0; v < Cfg::NPT_; ++v) {
       const int idx = v * 256 + threadIdx.x;
-      const int pix = idx >> 3, c = idx & 7;
+      const int pix = idx / Cfg::PPP, c = idx % Cfg::PPP;
       const int wy = pix / WC, wx = pix % WC;
       const int y = y0 + wy, xx = x0 + wx;
-      const bool ok = idx < PIECES && y >= 0 && y < H && xx >= 0 && xx < W;
+      const bool ok = idx < Cfg::PIECES_ && y >= 0 && y < H && xx >= 0 && xx < W;
       st[v] = ok ? *reinterpret_cast<const u32x4*>(
-                       x + (((int64_t)b * H + y) * W + xx) * C64 + 8 * c)
+                       x + (((int64_t)b * H + y) * W + xx) * CIN + 8 * c)
                  : u32x4{0u, 0u, 0u, 0u};
     }
   };
   auto stage_store = [&](int buf) {
 #pragma unroll
-    for (int v = 0; v < NPT; ++v) {
+    for (int v = 0; v < Cfg::NPT_; ++v) {
       const int idx = v * 256 + threadIdx.x;
-      if (idx < PIECES)
-        *reinterpret_cast<u32x4*>(lds + buf * WIN + (idx >> 3) * PIX_LD + 8 * (idx & 7)) = st[v];
+      if (idx < Cfg::PIECES_)
+        *reinterpret_cast<u32x4*>(lds + buf * WIN_ + (idx / Cfg::PPP) * PIX + 8 * (idx % Cfg::PPP)) =
+            st[v];
     }
   };
 
@@ -122,48 +151,47 @@ __global__ __launch_bounds__(256, 1) void conv64_kernel(const unsigned short* __
     const int next = tile + gridDim.x;
     if (next < ntiles) stage_load(next);
 
-    // A fragment of (tile row mt, k-step ks): window pixel (4 half + mt + kh, r + kw),
-    // channels 16 (ks & 3) + 8 h .. + 7
-    const unsigned short* wb = lds + buf * WIN + ((4 * half) * WC + r) * PIX_LD + 8 * h;
-    f32x16 acc[4];
+    // A fragment of (tile row mt, k-step ks): window pixel (MT part + mt + kh, r + kw),
+    // channels 16 (ks % SPT) + 8 h .. + 7
+    const unsigned short* wb = lds + buf * WIN_ + ((MT * part) * WC + r) * PIX + 8 * h;
+    f32x16 acc[MT];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) acc[mt] = zero16();
-    u32x4 af[2][4];
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = zero16();
+    u32x4 af[2][MT];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-      af[0][mt] = *reinterpret_cast<const u32x4*>(wb + mt * WC * PIX_LD);
+    for (int mt = 0; mt < MT; ++mt)
+      af[0][mt] = *reinterpret_cast<const u32x4*>(wb + mt * WC * PIX);
 #pragma unroll
-    for (int ks = 0; ks < 36; ++ks) {
-      if (ks + 1 < 36) {
-        const int tap = (ks + 1) >> 2, kh = tap / 3, kw = tap % 3;
-        const int off = (kh * WC + kw) * PIX_LD + 16 * ((ks + 1) & 3);
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks + 1 < KS) {
+        const int tap = (ks + 1) / Cfg::SPT, kh = tap / 3, kw = tap % 3;
+        const int off = (kh * WC + kw) * PIX + 16 * ((ks + 1) % Cfg::SPT);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-          af[(ks + 1) & 1][mt] =
-              *reinterpret_cast<const u32x4*>(wb + mt * WC * PIX_LD + off);
+        for (int mt = 0; mt < MT; ++mt)
+          af[(ks + 1) & 1][mt] = *reinterpret_cast<const u32x4*>(wb + mt * WC * PIX + off);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma32b(af[ks & 1][mt], wf[ks], acc[mt]);
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma32b(af[ks & 1][mt], wf[ks], acc[mt]);
     }
 
-    // epilogue: tile row 4 half + mt, accumulator register q <-> column acc_row(q, h),
+    // epilogue: tile row MT part + mt, accumulator register q <-> column acc_row(q, h),
     // lane r <-> output channel 32 nt + r
     const int b = tile / per_img, t2 = tile % per_img;
-    const int oy0 = (t2 / tiles_x) * TH + 4 * half, ox0 = (t2 % tiles_x) * TW;
+    const int oy0 = (t2 / tiles_x) * TH_ + MT * part, ox0 = (t2 % tiles_x) * TW;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) scr[acc_row(q, h) * SCR_LD + r] = f32_to_bf16(acc[mt][q]);
       __builtin_amdgcn_wave_barrier();
-      // 32 pixels x 64 bytes: lane -> pixel lane >> 1 (+ 0), 32-byte half lane & 1
+      // 32 pixels x 64 bytes: lane -> pixel lane >> 1, 32-byte half lane & 1
       const int px = lane >> 1, hf = lane & 1;
       const u32x4 v0 = *reinterpret_cast<const u32x4*>(scr + px * SCR_LD + 16 * hf);
       const u32x4 v1 = *reinterpret_cast<const u32x4*>(scr + px * SCR_LD + 16 * hf + 8);
       __builtin_amdgcn_wave_barrier();
       const int oy = oy0 + mt, ox = ox0 + px;
       if (oy < H && ox < W) {
-        unsigned short* o = out + (((int64_t)b * H + oy) * W + ox) * C64 + 32 * nt + 16 * hf;
+        unsigned short* o = out + (((int64_t)b * H + oy) * W + ox) * KOUT + 32 * nt + 16 * hf;
         *reinterpret_cast<u32x4*>(o) = v0;
         *reinterpret_cast<u32x4*>(o + 8) = v1;
       }
@@ -332,39 +360,65 @@ __global__ __launch_bounds__(256) void wrw64_reduce_kernel(const float* __restri
 
 }  // namespace
 
-extern "C" size_t scl_conv64_workspace_bytes(void) {
-  return scl_round256((size_t)2 * 36 * 64 * 8 * sizeof(unsigned short));
+static int conv64_cus();
+
+template <int CIN, int KOUT>
+int launch_conv3x3(const void* x, const void* w, int64_t sk, int64_t sc, int64_t sh, int64_t sw,
+                   int transposed, int B, int H, int W, void* out, void* workspace,
+                   hipStream_t st) {
+  using Cfg = ConvCfg<CIN, KOUT>;
+  static std::once_flag once;
+  static int cus = 256;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<CIN, KOUT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
+    cus = conv64_cus();
+  });
+  unsigned short* packed = (unsigned short*)workspace;
+  SCL_LAUNCH("conv3x3_pack_kernel", (conv3x3_pack_kernel<CIN, KOUT>),
+             dim3(Cfg::NT * Cfg::KS * 512 / 256), dim3(256), 0, st, (const unsigned short*)w, sk, sc,
+             sh, sw, transposed ? 1 : 0, packed);
+  const int tiles = B * ((H + Cfg::TH_ - 1) / Cfg::TH_) * ((W + TW - 1) / TW);
+  SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT>), dim3(tiles < cus ? tiles : cus),
+             dim3(256), Cfg::LDS, st, (const unsigned short*)x, (const unsigned short*)packed, B, H,
+             W, (unsigned short*)out);
+  return scl_launch_status();
 }
+
+extern "C" size_t scl_conv3x3_workspace_bytes(void) {
+  return scl_round256((size_t)4 * 72 * 512 * sizeof(unsigned short));   // largest packed image
+}
+
+extern "C" int scl_conv3x3(const void* x, const void* w, int64_t w_stride_k, int64_t w_stride_c,
+                           int64_t w_stride_h, int64_t w_stride_w, int transposed, int B, int H,
+                           int W, int cin, int kout, void* out, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+  if (!x || !w || !out || !workspace) return SCL_E_NULL;
+  if (B < 1 || H < 1 || W < 1 || (int64_t)B * H * W > (int64_t)1 << 30) return SCL_E_SHAPE;
+  if (((uintptr_t)x % 16) || ((uintptr_t)out % 16)) return SCL_E_SHAPE;
+  if (!scl_aligned256(workspace) || workspace_bytes < scl_conv3x3_workspace_bytes())
+    return SCL_E_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+#define SCL_CONV_CASE(CI, KO)                                                                  \
+  if (cin == CI && kout == KO)                                                                 \
+    return launch_conv3x3<CI, KO>(x, w, w_stride_k, w_stride_c, w_stride_h, w_stride_w,        \
+                                  transposed, B, H, W, out, workspace, st);
+  SCL_CONV_CASE(64, 64)
+  SCL_CONV_CASE(64, 128)
+  SCL_CONV_CASE(128, 64)
+  SCL_CONV_CASE(128, 128)
+#undef SCL_CONV_CASE
+  return SCL_E_SHAPE;
+}
+
+extern "C" size_t scl_conv64_workspace_bytes(void) { return scl_conv3x3_workspace_bytes(); }
 
 extern "C" int scl_conv64(const void* x, const void* w, int64_t w_stride_k, int64_t w_stride_c,
                           int64_t w_stride_h, int64_t w_stride_w, int transposed, int B, int H,
                           int W, void* out, void* workspace, size_t workspace_bytes,
                           void* stream) {
-  if (!x || !w || !out || !workspace) return SCL_E_NULL;
-  if (B < 1 || H < 1 || W < 1 || (int64_t)B * H * W > (int64_t)1 << 30) return SCL_E_SHAPE;
-  if (((uintptr_t)x % 16) || ((uintptr_t)out % 16)) return SCL_E_SHAPE;
-  if (!scl_aligned256(workspace) || workspace_bytes < scl_conv64_workspace_bytes())
-    return SCL_E_WORKSPACE;
-  static std::once_flag once;
-  static int cus = 256;
-  std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv64_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kConv64Lds);
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-      cus = n;
-  });
-  hipStream_t st = (hipStream_t)stream;
-  unsigned short* packed = (unsigned short*)workspace;
-  SCL_LAUNCH("conv64_pack_kernel", conv64_pack_kernel, dim3(2 * 36 * 64 * 8 / 256), dim3(256), 0, st,
-             (const unsigned short*)w, w_stride_k, w_stride_c, w_stride_h, w_stride_w,
-             transposed ? 1 : 0, packed);
-  const int tiles = B * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
-  SCL_LAUNCH("conv64_kernel", conv64_kernel, dim3(tiles < cus ? tiles : cus), dim3(256), kConv64Lds,
-             st, (const unsigned short*)x, (const unsigned short*)packed, B, H, W,
-             (unsigned short*)out);
-  return scl_launch_status();
+  return scl_conv3x3(x, w, w_stride_k, w_stride_c, w_stride_h, w_stride_w, transposed, B, H, W,
+                     64, 64, out, workspace, workspace_bytes, stream);
 }
 
 static int conv64_cus() {

@@ -91,28 +91,35 @@ _CL = torch.channels_last
 _ONES = [1, 1]
 
 
-# conv1_2 (64 -> 64 channels at full resolution) runs on csrc/conv64.hip: the library kernels
-# take twice as long there as on the equal-FLOP layers.  SCL_CONV64=0 restores MIOpen.
+# conv1_2 and conv2_x (64 / 128 channels at full and half resolution) run on csrc/conv64.hip:
+# the library kernels take up to twice as long there as on the equal-FLOP deeper layers.
+# SCL_CONV64=0 restores MIOpen everywhere.
 USE_CONV64 = os.environ.get('SCL_CONV64', '1') != '0'
+_OWN_CONV_SHAPES = {(64, 64), (64, 128), (128, 64), (128, 128)}      # (contraction, output)
 
 
-def _conv64_ok(x, w):
-    return (USE_CONV64 and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
-            and x.dim() == 4 and x.shape[1] == 64 and tuple(w.shape) == (64, 64, 3, 3))
+def _conv64_ok(x, w, transposed=False):
+    if not (USE_CONV64 and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
+            and x.dim() == 4 and w.dim() == 4 and tuple(w.shape[2:]) == (3, 3)):
+        return False
+    cin, kout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
+    return x.shape[1] == cin and (cin, kout) in _OWN_CONV_SHAPES
 
 
 def conv64(x, w, transposed=False):
-    """3x3 same-padding convolution 64 -> 64 on bf16 channels-last activations
-    (``scl_conv64``); ``transposed`` gives the gradient with respect to the input."""
+    """3x3 same-padding convolution on bf16 channels-last activations (``scl_conv3x3``) for
+    the shapes of ``_OWN_CONV_SHAPES``; ``transposed`` gives the gradient with respect to the
+    input of ``conv(., w)``."""
     lib = L.load()
     L.require_device(x, w)
     x = x.contiguous(memory_format=_CL)
     b, _, h, wd = x.shape
-    out = torch.empty_like(x, memory_format=_CL)
-    ws = L.workspace(lib.scl_conv64_workspace_bytes(), x.device)
+    cin, kout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
+    out = torch.empty((b, kout, h, wd), dtype=x.dtype, device=x.device, memory_format=_CL)
+    ws = L.workspace(lib.scl_conv3x3_workspace_bytes(), x.device)
     sk, sc, sh, sw = w.stride()
-    L.check(lib.scl_conv64(L.ptr(x), L.ptr(w), sk, sc, sh, sw, int(bool(transposed)), b, h, wd,
-                           L.ptr(out), L.ptr(ws), ws.numel(), L.stream_of(x)))
+    L.check(lib.scl_conv3x3(L.ptr(x), L.ptr(w), sk, sc, sh, sw, int(bool(transposed)), b, h, wd,
+                            cin, kout, L.ptr(out), L.ptr(ws), ws.numel(), L.stream_of(x)))
     return out
 
 
@@ -140,9 +147,13 @@ def _conv3x3(x, w):
 
 
 def _conv3x3_backward(gz, x, w, need_x):
-    if _conv64_ok(gz, w):
+    if _conv64_ok(gz, w, True):
         gx = conv64(gz, w, True) if need_x else None
-        return gx, wrw64(x, gz, w)
+        if tuple(w.shape[:2]) == (64, 64):
+            return gx, wrw64(x, gz, w)
+        _, gw, _ = torch.ops.aten.convolution_backward(gz, x, w, None, _ONES, _ONES, _ONES, False,
+                                                       [0, 0], 1, [False, True, False])
+        return gx, gw
     gx, gw, _ = torch.ops.aten.convolution_backward(gz, x, w, None, _ONES, _ONES, _ONES, False,
                                                     [0, 0], 1, [bool(need_x), True, False])
     return gx, gw

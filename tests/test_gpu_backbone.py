@@ -181,3 +181,25 @@ def test_wrw64_weight_gradient(dev, shape):
         assert float(err) < 6e-3, float(err)
     again = nets.wrw64(x, gz, like)
     assert torch.equal(got, again)                       # fixed-order slab reduction
+
+
+@pytest.mark.parametrize('cin,cout', [(64, 128), (128, 128), (64, 64)])
+@pytest.mark.parametrize('shape', [(2, 12, 40), (1, 13, 37)])
+def test_own_conv_other_shapes(dev, shape, cin, cout):
+    """conv2_1 / conv2_2 shapes of csrc/conv64.hip, forward and backward-data."""
+    from soft_contrastive_learning_amd.model import nets
+    b, h, w = shape
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(b, cin, h, w, generator=g).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(b, cout, h, w, generator=g).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).to(dev).bfloat16().contiguous(
+        memory_format=torch.channels_last)
+    assert nets._conv64_ok(x, wt) and nets._conv64_ok(gy, wt, True)
+    got = nets.conv64(x, wt, False)
+    want = torch.nn.functional.conv2d(x.float(), wt.float(), padding=1)
+    assert got.shape == want.shape
+    assert float((got.float() - want).abs().max() / want.abs().max()) < 6e-3
+    gx = nets.conv64(gy, wt, True)
+    want_gx = torch.nn.functional.conv_transpose2d(gy.float(), wt.float(), padding=1)
+    assert gx.shape == want_gx.shape
+    assert float((gx.float() - want_gx).abs().max() / want_gx.abs().max()) < 6e-3
