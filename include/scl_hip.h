@@ -254,6 +254,16 @@ int scl_conv3x3(const void* x, const void* w, int64_t w_stride_k, int64_t w_stri
                 int cin, int kout, void* out, void* workspace, size_t workspace_bytes,
                 void* stream);
 
+/* ... with the layer's elementwise tail fused into the epilogue (model/nets.py:32-63):
+ *   pooled == NULL: out = conv + bias (bias may be NULL), ReLU if relu
+ *   pooled != NULL: out = raw conv (kept for the backward pass),
+ *                   pooled [B,H/2,W/2,kout] = relu(maxpool2x2(out) + bias)
+ * bias is float32 [kout]. */
+int scl_conv3x3_fused(const void* x, const void* w, int64_t w_stride_k, int64_t w_stride_c,
+                      int64_t w_stride_h, int64_t w_stride_w, int transposed, int B, int H,
+                      int W, int cin, int kout, void* out, const float* bias, int relu,
+                      void* pooled, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Weight gradient of the same layer: gw[k][c][kh][kw] = sum_{b,y,x} gz[b,y,x,k] *
  * x[b, y+kh-1, x+kw-1, c]; x, gz [B,H,W,64] bf16, gw bf16 written at the given element
  * strides (logical [64][64][3][3]).  Deterministic (per-CU slabs summed in a fixed order). */

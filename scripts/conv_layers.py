@@ -78,6 +78,11 @@ def main():
                  timed(lambda: nets.wrw64(x, gy, wt)) if (cin, cout) == (64, 64) else float('nan')]
             cells = ['%8.1f (%6.0f)' % (v, gf / v * 1e3) for v in t]
             print('%-5s %4s %4s %9s | %22s | %22s | %22s' % ('  own', '', '', '', *cells))
+            bias = torch.randn(cout, device=dev)
+            t = [timed(lambda: nets.conv64(x, wt, False, bias=bias, relu=True)),
+                 timed(lambda: nets.conv64(x, wt, False, bias=bias, pool=True)), float('nan')]
+            cells = ['%8.1f (%6.0f)' % (v, gf / v * 1e3) for v in t]
+            print('%-5s %4s %4s %9s | %22s | %22s | %22s' % (' +b/p', '', '', '', *cells))
 
 
 if __name__ == '__main__':

@@ -90,12 +90,15 @@ __global__ __launch_bounds__(256) void conv3x3_pack_kernel(const unsigned short*
   packed[idx] = w[off];
 }
 
-// grid = number of CUs (persistent); block 256.
-template <int CIN, int KOUT>
+// grid = number of CUs (persistent); block 256.  EPI (compile-time, so that the plain kernel
+// keeps its register allocation): 0 plain, 1 + bias (+ ReLU), 2 raw + pooled output.
+template <int CIN, int KOUT, int EPI>
 __global__ __launch_bounds__(256, 1) void conv3x3_kernel(const unsigned short* __restrict__ x,
                                                          const unsigned short* __restrict__ packed,
                                                          int B, int H, int W,
-                                                         unsigned short* __restrict__ out) {
+                                                         unsigned short* __restrict__ out,
+                                                         const float* __restrict__ bias, int relu,
+                                                         unsigned short* __restrict__ pooled) {
   using Cfg = ConvCfg<CIN, KOUT>;
   constexpr int TH_ = Cfg::TH_, PIX = Cfg::PIX, WIN_ = Cfg::WIN_, KS = Cfg::KS, MT = Cfg::MT;
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
@@ -103,6 +106,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(const unsigned short* _
   const int r = lane & 31, h = lane >> 5;
   const int nt = wid % Cfg::NT, part = wid / Cfg::NT;
   unsigned short* scr = lds + 2 * WIN_ + wid * SCR;
+  // epilogue fusions (lane r <-> output channel 32 nt + r):
+  //   pooled == NULL: out = acc (+ bias) (ReLU if relu)            conv + bias + activation
+  //   pooled != NULL: out = acc raw, pooled = relu(max2x2(acc) + bias)   conv + pool + ReLU
+  const float bias_r = EPI != 0 ? bias[32 * nt + r] : 0.f;
+  const float add_r = EPI == 1 ? bias_r : 0.f;
 
   // the wave's weight slice: KS fragments of 16 bytes per lane
   u32x4 wf[KS];
@@ -182,7 +190,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(const unsigned short* _
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-      for (int q = 0; q < 16; ++q) scr[acc_row(q, h) * SCR_LD + r] = f32_to_bf16(acc[mt][q]);
+      for (int q = 0; q < 16; ++q) {
+        float v = acc[mt][q] + add_r;
+        if (EPI == 1 && relu) v = fmaxf(v, 0.f);
+        scr[acc_row(q, h) * SCR_LD + r] = f32_to_bf16(v);
+      }
       __builtin_amdgcn_wave_barrier();
       // 32 pixels x 64 bytes: lane -> pixel lane >> 1, 32-byte half lane & 1
       const int px = lane >> 1, hf = lane & 1;
@@ -194,6 +206,29 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(const unsigned short* _
         unsigned short* o = out + (((int64_t)b * H + oy) * W + ox) * KOUT + 32 * nt + 16 * hf;
         *reinterpret_cast<u32x4*>(o) = v0;
         *reinterpret_cast<u32x4*>(o + 8) = v1;
+      }
+    }
+    if (EPI == 2) {
+      // 2x2 / stride 2 max-pool of the raw outputs, lane-local: rows mt, mt + 1 are two
+      // accumulators, columns acc_row(q, h), acc_row(q + 1, h) two registers (q even)
+      const int PH2 = H / 2, PW2 = W / 2;
+#pragma unroll
+      for (int mp = 0; mp < MT / 2; ++mp) {
+#pragma unroll
+        for (int q = 0; q < 16; q += 2) {
+          const float m0 = fmaxf(acc[2 * mp][q], acc[2 * mp][q + 1]);
+          const float m1 = fmaxf(acc[2 * mp + 1][q], acc[2 * mp + 1][q + 1]);
+          scr[(acc_row(q, h) >> 1) * SCR_LD + r] = f32_to_bf16(fmaxf(fmaxf(m0, m1) + bias_r, 0.f));
+        }
+        __builtin_amdgcn_wave_barrier();
+        // 16 pooled pixels x 64 bytes: lane -> pixel lane >> 2, 16-byte quarter lane & 3
+        const int px = lane >> 2, qu = lane & 3;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(scr + px * SCR_LD + 8 * qu);
+        __builtin_amdgcn_wave_barrier();
+        const int py = (oy0 >> 1) + mp, pxg = (ox0 >> 1) + px;
+        if (py < PH2 && pxg < PW2)
+          *reinterpret_cast<u32x4*>(pooled + (((int64_t)b * PH2 + py) * PW2 + pxg) * KOUT +
+                                    32 * nt + 8 * qu) = v;
       }
     }
 
@@ -364,13 +399,17 @@ static int conv64_cus();
 
 template <int CIN, int KOUT>
 int launch_conv3x3(const void* x, const void* w, int64_t sk, int64_t sc, int64_t sh, int64_t sw,
-                   int transposed, int B, int H, int W, void* out, void* workspace,
-                   hipStream_t st) {
+                   int transposed, int B, int H, int W, void* out, const float* bias, int relu,
+                   void* pooled, void* workspace, hipStream_t st) {
   using Cfg = ConvCfg<CIN, KOUT>;
   static std::once_flag once;
   static int cus = 256;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<CIN, KOUT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<CIN, KOUT, 0>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<CIN, KOUT, 1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<CIN, KOUT, 2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
     cus = conv64_cus();
   });
@@ -379,9 +418,19 @@ int launch_conv3x3(const void* x, const void* w, int64_t sk, int64_t sc, int64_t
              dim3(Cfg::NT * Cfg::KS * 512 / 256), dim3(256), 0, st, (const unsigned short*)w, sk, sc,
              sh, sw, transposed ? 1 : 0, packed);
   const int tiles = B * ((H + Cfg::TH_ - 1) / Cfg::TH_) * ((W + TW - 1) / TW);
-  SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT>), dim3(tiles < cus ? tiles : cus),
-             dim3(256), Cfg::LDS, st, (const unsigned short*)x, (const unsigned short*)packed, B, H,
-             W, (unsigned short*)out);
+  const dim3 grid(tiles < cus ? tiles : cus);
+  if (pooled)
+    SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 2>), grid, dim3(256), Cfg::LDS, st,
+               (const unsigned short*)x, (const unsigned short*)packed, B, H, W,
+               (unsigned short*)out, bias, relu, (unsigned short*)pooled);
+  else if (bias)
+    SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 1>), grid, dim3(256), Cfg::LDS, st,
+               (const unsigned short*)x, (const unsigned short*)packed, B, H, W,
+               (unsigned short*)out, bias, relu, (unsigned short*)pooled);
+  else
+    SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 0>), grid, dim3(256), Cfg::LDS, st,
+               (const unsigned short*)x, (const unsigned short*)packed, B, H, W,
+               (unsigned short*)out, bias, relu, (unsigned short*)pooled);
   return scl_launch_status();
 }
 
@@ -389,11 +438,13 @@ extern "C" size_t scl_conv3x3_workspace_bytes(void) {
   return scl_round256((size_t)4 * 72 * 512 * sizeof(unsigned short));   // largest packed image
 }
 
-extern "C" int scl_conv3x3(const void* x, const void* w, int64_t w_stride_k, int64_t w_stride_c,
-                           int64_t w_stride_h, int64_t w_stride_w, int transposed, int B, int H,
-                           int W, int cin, int kout, void* out, void* workspace,
-                           size_t workspace_bytes, void* stream) {
+extern "C" int scl_conv3x3_fused(const void* x, const void* w, int64_t w_stride_k,
+                                 int64_t w_stride_c, int64_t w_stride_h, int64_t w_stride_w,
+                                 int transposed, int B, int H, int W, int cin, int kout,
+                                 void* out, const float* bias, int relu, void* pooled,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
   if (!x || !w || !out || !workspace) return SCL_E_NULL;
+  if (pooled && (!bias || ((uintptr_t)pooled % 16))) return SCL_E_NULL;
   if (B < 1 || H < 1 || W < 1 || (int64_t)B * H * W > (int64_t)1 << 30) return SCL_E_SHAPE;
   if (((uintptr_t)x % 16) || ((uintptr_t)out % 16)) return SCL_E_SHAPE;
   if (!scl_aligned256(workspace) || workspace_bytes < scl_conv3x3_workspace_bytes())
@@ -402,13 +453,23 @@ extern "C" int scl_conv3x3(const void* x, const void* w, int64_t w_stride_k, int
 #define SCL_CONV_CASE(CI, KO)                                                                  \
   if (cin == CI && kout == KO)                                                                 \
     return launch_conv3x3<CI, KO>(x, w, w_stride_k, w_stride_c, w_stride_h, w_stride_w,        \
-                                  transposed, B, H, W, out, workspace, st);
+                                  transposed, B, H, W, out, bias, relu ? 1 : 0, pooled,        \
+                                  workspace, st);
   SCL_CONV_CASE(64, 64)
   SCL_CONV_CASE(64, 128)
   SCL_CONV_CASE(128, 64)
   SCL_CONV_CASE(128, 128)
 #undef SCL_CONV_CASE
   return SCL_E_SHAPE;
+}
+
+extern "C" int scl_conv3x3(const void* x, const void* w, int64_t w_stride_k, int64_t w_stride_c,
+                           int64_t w_stride_h, int64_t w_stride_w, int transposed, int B, int H,
+                           int W, int cin, int kout, void* out, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+  return scl_conv3x3_fused(x, w, w_stride_k, w_stride_c, w_stride_h, w_stride_w, transposed, B, H,
+                           W, cin, kout, out, nullptr, 0, nullptr, workspace, workspace_bytes,
+                           stream);
 }
 
 extern "C" size_t scl_conv64_workspace_bytes(void) { return scl_conv3x3_workspace_bytes(); }

@@ -106,21 +106,31 @@ def _conv64_ok(x, w, transposed=False):
     return x.shape[1] == cin and (cin, kout) in _OWN_CONV_SHAPES
 
 
-def conv64(x, w, transposed=False):
-    """3x3 same-padding convolution on bf16 channels-last activations (``scl_conv3x3``) for
-    the shapes of ``_OWN_CONV_SHAPES``; ``transposed`` gives the gradient with respect to the
-    input of ``conv(., w)``."""
+def conv64(x, w, transposed=False, bias=None, relu=False, pool=False):
+    """3x3 same-padding convolution on bf16 channels-last activations (``scl_conv3x3_fused``)
+    for the shapes of ``_OWN_CONV_SHAPES``; ``transposed`` gives the gradient with respect to
+    the input of ``conv(., w)``.  ``bias`` (float32 [kout]) and ``relu`` fuse the layer's tail
+    into the epilogue; ``pool=True`` returns ``(raw conv, relu(maxpool2x2(raw) + bias))``."""
     lib = L.load()
-    L.require_device(x, w)
+    L.require_device(x, w, bias)
     x = x.contiguous(memory_format=_CL)
     b, _, h, wd = x.shape
     cin, kout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
     out = torch.empty((b, kout, h, wd), dtype=x.dtype, device=x.device, memory_format=_CL)
+    pooled = None
+    if pool:
+        if bias is None:
+            raise ValueError("pool=True needs the bias (the pooled map is relu(pool + bias))")
+        pooled = torch.empty((b, kout, h // 2, wd // 2), dtype=x.dtype, device=x.device,
+                             memory_format=_CL)
+    if bias is not None:
+        bias = bias.float().contiguous()
     ws = L.workspace(lib.scl_conv3x3_workspace_bytes(), x.device)
     sk, sc, sh, sw = w.stride()
-    L.check(lib.scl_conv3x3(L.ptr(x), L.ptr(w), sk, sc, sh, sw, int(bool(transposed)), b, h, wd,
-                            cin, kout, L.ptr(out), L.ptr(ws), ws.numel(), L.stream_of(x)))
-    return out
+    L.check(lib.scl_conv3x3_fused(L.ptr(x), L.ptr(w), sk, sc, sh, sw, int(bool(transposed)), b, h,
+                                  wd, cin, kout, L.ptr(out), L.ptr(bias), int(bool(relu)),
+                                  L.ptr(pooled), L.ptr(ws), ws.numel(), L.stream_of(x)))
+    return (out, pooled) if pool else out
 
 
 def wrw64(x, gz, w_like):
@@ -175,10 +185,13 @@ class _ConvBiasAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, relu):
         lib = L.load()
-        y = _conv3x3(x, w).contiguous(memory_format=_CL)
-        b, c, h, wd = y.shape
-        L.check(lib.scl_vgg_bias_act(L.ptr(y), _glue_dtype(y), L.ptr(bias), b * h * wd, c,
-                                     int(relu), L.stream_of(y)))
+        if _conv64_ok(x, w):
+            y = conv64(x, w, False, bias=bias, relu=relu)         # tail fused in the epilogue
+        else:
+            y = _conv3x3(x, w).contiguous(memory_format=_CL)
+            b, c, h, wd = y.shape
+            L.check(lib.scl_vgg_bias_act(L.ptr(y), _glue_dtype(y), L.ptr(bias), b * h * wd, c,
+                                         int(relu), L.stream_of(y)))
         ctx.relu = relu
         ctx.save_for_backward(x, w, y if relu else None)
         return y
@@ -207,12 +220,17 @@ class _ConvBiasPoolReLU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias):
         lib = L.load()
-        z = _conv3x3(x, w).contiguous(memory_format=_CL)
-        b, c, h, wd = z.shape
-        a = torch.empty((b, c, h // 2, wd // 2), dtype=z.dtype, device=z.device,
-                        memory_format=_CL)
-        L.check(lib.scl_vgg_pool_fwd(L.ptr(z), _glue_dtype(z), L.ptr(bias), b, h, wd, c, L.ptr(a),
-                                     L.stream_of(z)))
+        if _conv64_ok(x, w) and tuple(w.shape[:2]) == (64, 64):
+            # pooled map from the epilogue (the 128-channel variant of that epilogue runs out
+            # of registers and is slower than the plain kernel + the pooling pass)
+            z, a = conv64(x, w, False, bias=bias, pool=True)
+        else:
+            z = _conv3x3(x, w).contiguous(memory_format=_CL)
+            b, c, h, wd = z.shape
+            a = torch.empty((b, c, h // 2, wd // 2), dtype=z.dtype, device=z.device,
+                            memory_format=_CL)
+            L.check(lib.scl_vgg_pool_fwd(L.ptr(z), _glue_dtype(z), L.ptr(bias), b, h, wd, c,
+                                         L.ptr(a), L.stream_of(z)))
         ctx.save_for_backward(x, w, z, a)
         return a
 

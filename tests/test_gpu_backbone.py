@@ -203,3 +203,28 @@ def test_own_conv_other_shapes(dev, shape, cin, cout):
     want_gx = torch.nn.functional.conv_transpose2d(gy.float(), wt.float(), padding=1)
     assert gx.shape == want_gx.shape
     assert float((gx.float() - want_gx).abs().max() / want_gx.abs().max()) < 6e-3
+
+
+@pytest.mark.parametrize('cin,cout,shape', [(64, 64, (2, 16, 40)), (128, 128, (1, 10, 37)),
+                                            (64, 128, (1, 9, 33))])
+def test_own_conv_fused_tails(dev, cin, cout, shape):
+    """bias + ReLU and bias + max-pool + ReLU fused into the convolution epilogue."""
+    from soft_contrastive_learning_amd.model import nets
+    b, h, w = shape
+    g = torch.Generator().manual_seed(19)
+    x = torch.randn(b, cin, h, w, generator=g).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).to(dev).bfloat16()
+    bias = torch.randn(cout, generator=g).to(dev)
+    z32 = torch.nn.functional.conv2d(x.float(), wt.float(), padding=1)
+    scale = float(z32.abs().max())
+    y = nets.conv64(x, wt, False, bias=bias, relu=True)
+    want = torch.relu(z32 + bias[None, :, None, None])
+    assert float((y.float() - want).abs().max()) < 6e-3 * scale
+    y = nets.conv64(x, wt, False, bias=bias, relu=False)
+    assert float((y.float() - (z32 + bias[None, :, None, None])).abs().max()) < 6e-3 * scale
+    z, a = nets.conv64(x, wt, False, bias=bias, pool=True)
+    assert float((z.float() - z32).abs().max()) < 6e-3 * scale
+    assert a.shape == (b, cout, h // 2, w // 2)
+    # the pooled map is computed from the float32 accumulators, the library path from the bf16 z
+    want_a = torch.relu(torch.nn.functional.max_pool2d(z32, 2) + bias[None, :, None, None])
+    assert float((a.float() - want_a).abs().max()) < 6e-3 * scale
