@@ -264,6 +264,15 @@ int scl_conv3x3_fused(const void* x, const void* w, int64_t w_stride_k, int64_t 
                       int W, int cin, int kout, void* out, const float* bias, int relu,
                       void* pooled, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The deeper layers (conv3_x .. conv5_x: cin % 32 == 0, kout % 128 == 0, up to 1024): weights
+ * streamed through LDS, [12 x 40 pixel] x 128-channel workgroup tiles (csrc/convg.hip).
+ * Same arguments as scl_conv3x3_fused without the pooled output. */
+size_t scl_convg_workspace_bytes(int cin, int kout);
+int scl_convg(const void* x, const void* w, int64_t w_stride_k, int64_t w_stride_c,
+              int64_t w_stride_h, int64_t w_stride_w, int transposed, int B, int H, int W,
+              int cin, int kout, void* out, const float* bias, int relu, void* workspace,
+              size_t workspace_bytes, void* stream);
+
 /* Weight gradient of the same layer: gw[k][c][kh][kw] = sum_{b,y,x} gz[b,y,x,k] *
  * x[b, y+kh-1, x+kw-1, c]; x, gz [B,H,W,64] bf16, gw bf16 written at the given element
  * strides (logical [64][64][3][3]).  Deterministic (per-CU slabs summed in a fixed order). */

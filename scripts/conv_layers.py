@@ -22,6 +22,8 @@ from soft_contrastive_learning_amd.model import nets  # noqa: E402
 LAYERS = [('1_1', 3, 64, 1), ('1_2', 64, 64, 1), ('2_1', 64, 128, 2), ('2_2', 128, 128, 2),
           ('3_1', 128, 256, 4), ('3_2', 256, 256, 4), ('4_1', 256, 512, 8), ('4_2', 512, 512, 8),
           ('5_1', 512, 512, 16)]
+if os.environ.get('SCL_LAYERS'):
+    LAYERS = [l for l in LAYERS if l[0] in os.environ['SCL_LAYERS'].split(',')]
 ONES = [1, 1]
 
 
@@ -80,7 +82,8 @@ def main():
             print('%-5s %4s %4s %9s | %22s | %22s | %22s' % ('  own', '', '', '', *cells))
             bias = torch.randn(cout, device=dev)
             t = [timed(lambda: nets.conv64(x, wt, False, bias=bias, relu=True)),
-                 timed(lambda: nets.conv64(x, wt, False, bias=bias, pool=True)), float('nan')]
+                 timed(lambda: nets.conv64(x, wt, False, bias=bias, pool=True))
+                 if nets._own_conv_kind(x, wt) == 'reg' else float('nan'), float('nan')]
             cells = ['%8.1f (%6.0f)' % (v, gf / v * 1e3) for v in t]
             print('%-5s %4s %4s %9s | %22s | %22s | %22s' % (' +b/p', '', '', '', *cells))
 

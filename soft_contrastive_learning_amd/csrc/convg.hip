@@ -1,0 +1,241 @@
+// 3x3 / stride 1 / same-padding convolution for the deeper VGG16 layers (128 .. 512
+// channels, model/nets.py:44-63) on bf16 channels-last activations: forward and, with the
+// weights transposed and the taps flipped, backward-data.  The register-resident-weights
+// kernel of conv64.hip does not scale past 128 channels; here the weights stream through LDS.
+//
+// Implicit GEMM on v_mfma_f32_32x32x16_bf16 with a large M tile so that a staged weight chunk
+// is reused by many pixels:
+//   * workgroup = [12 rows x 40 cols] of output pixels (15 m-tiles of 4 x 8 pixels; 40
+//     divides the widths 160 / 80 / 40 of conv3_x .. conv5_x) x 128 output channels; wave w
+//     owns output channels 32 w .. + 31 of the block and all 15 m-tiles: 240 accumulators;
+//   * K loop over (32-channel chunk, tap): the [14][42][32 ch] halo window of the chunk is
+//     staged once per chunk, the [128 k][32 c] weight slice once per (chunk, tap), both
+//     double-buffered in LDS behind register prefetches; one barrier per (chunk, tap) =
+//     per 30 MFMAs per wave;
+//   * A fragment = 16 bytes (8 channels of one window pixel) at a per-tap address offset —
+//     no im2col; B fragment = 16 bytes of a weight row.
+//   * epilogue as conv64.hip: bf16 through a per-wave LDS transpose, optional bias (+ ReLU).
+#include <mutex>
+
+#include "scl_common.h"
+
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int BH = 12, BW = 40;                     // output block
+constexpr int GWR = BH + 2, GWC = BW + 2;           // halo window
+constexpr int CCH = 32;                             // channels per staged chunk
+constexpr int GPIX = CCH + 8;                       // bf16 per staged pixel / weight row (80 B)
+constexpr int GWIN = GWR * GWC * GPIX;              // bf16 per window buffer (23,520)
+constexpr int GWP = GWR * GWC * 4;                  // 16-byte pieces per window chunk (2352)
+constexpr int GNPT = (GWP + 255) / 256;             // 10
+constexpr int NB = 128;                             // output channels per workgroup
+constexpr int GWT = NB * GPIX;                      // bf16 per weight buffer (5120)
+constexpr int GSCR_LD = 40;
+constexpr int GSCR = 32 * GSCR_LD;
+constexpr size_t kConvgLds = (2 * (size_t)GWIN + 2 * (size_t)GWT + 4 * (size_t)GSCR) * 2;
+constexpr int NMT = 15;                             // m-tiles: 3 rows x 5 cols of 4 x 8 pixels
+
+__device__ __forceinline__ f32x16 mfma32b(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                 __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// Weights -> [n-block][chunk][tap][k 128][c 32] bf16 (8 KB slices in the order the kernel
+// stages them).  transposed as in conv64.hip.
+__global__ __launch_bounds__(256) void convg_pack_kernel(const unsigned short* __restrict__ w,
+                                                         int64_t sk, int64_t sc, int64_t sh,
+                                                         int64_t sw, int transposed, int cin,
+                                                         int kout,
+                                                         unsigned short* __restrict__ packed) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)9 * cin * kout;
+  if (idx >= total) return;
+  const int c = idx & 31, k = (idx >> 5) & 127;
+  const int64_t rest = idx >> 12;                    // (nb * CC + cc) * 9 + tap
+  const int tap = rest % 9;
+  const int cc = (rest / 9) % (cin / CCH), nb = rest / 9 / (cin / CCH);
+  const int kh = tap / 3, kw = tap % 3;
+  const int ci = CCH * cc + c, co = NB * nb + k;
+  int64_t off;
+  if (!transposed)
+    off = co * sk + ci * sc + kh * sh + kw * sw;
+  else
+    off = ci * sk + co * sc + (2 - kh) * sh + (2 - kw) * sw;
+  packed[idx] = w[off];
+}
+
+// grid (pixel blocks, kout / 128); block 256.  EPI: 0 plain, 1 + bias (+ ReLU).
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void convg_kernel(const unsigned short* __restrict__ x,
+                                                       const unsigned short* __restrict__ packed,
+                                                       int B, int H, int W, int cin, int kout,
+                                                       unsigned short* __restrict__ out,
+                                                       const float* __restrict__ bias, int relu) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+  unsigned short* win = lds;
+  unsigned short* wts = lds + 2 * GWIN;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  unsigned short* scr = wts + 2 * GWT + wid * GSCR;
+  const int nb = blockIdx.y;
+  const int blocks_x = (W + BW - 1) / BW, blocks_y = (H + BH - 1) / BH;
+  const int b = blockIdx.x / (blocks_x * blocks_y), t2 = blockIdx.x % (blocks_x * blocks_y);
+  const int y0 = (t2 / blocks_x) * BH, x0 = (t2 % blocks_x) * BW;
+  const int CC = cin / CCH, S = 9 * CC;
+  const float bias_r = EPI == 1 ? bias[NB * nb + 32 * wid + r] : 0.f;
+
+  u32x4 st_w[2], st_x[GNPT];
+  auto load_wts = [&](int s) {
+    const unsigned short* src = packed + ((int64_t)nb * S + s) * (NB * CCH);
+#pragma unroll
+    for (int v = 0; v < 2; ++v)
+      st_w[v] = *reinterpret_cast<const u32x4*>(src + (v * 256 + threadIdx.x) * 8);
+  };
+  auto store_wts = [&](int buf) {
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const int idx = v * 256 + threadIdx.x;
+      *reinterpret_cast<u32x4*>(wts + buf * GWT + (idx >> 2) * GPIX + 8 * (idx & 3)) = st_w[v];
+    }
+  };
+  auto load_win = [&](int cc) {
+#pragma unroll
+    for (int v = 0; v < GNPT; ++v) {
+      const int idx = v * 256 + threadIdx.x;
+      const int pix = idx >> 2, c4 = idx & 3;
+      const int y = y0 - 1 + pix / GWC, xx = x0 - 1 + pix % GWC;
+      const bool ok = idx < GWP && y >= 0 && y < H && xx >= 0 && xx < W;
+      st_x[v] = ok ? *reinterpret_cast<const u32x4*>(
+                         x + (((int64_t)b * H + y) * W + xx) * cin + CCH * cc + 8 * c4)
+                   : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  auto store_win = [&](int buf) {
+#pragma unroll
+    for (int v = 0; v < GNPT; ++v) {
+      const int idx = v * 256 + threadIdx.x;
+      if (idx < GWP)
+        *reinterpret_cast<u32x4*>(win + buf * GWIN + (idx >> 2) * GPIX + 8 * (idx & 3)) = st_x[v];
+    }
+  };
+
+  f32x16 acc[NMT];
+#pragma unroll
+  for (int mt = 0; mt < NMT; ++mt) acc[mt] = zero16();
+
+  load_win(0);
+  load_wts(0);
+  store_win(0);
+  store_wts(0);
+  __syncthreads();
+
+  // lane (r, h): pixel (r >> 3, r & 7) of an m-tile, channels 8 h .. + 7 of a k-step
+  const int lane_a = ((r >> 3) * GWC + (r & 7)) * GPIX + 8 * h;
+  const int lane_b = (32 * wid + r) * GPIX + 8 * h;
+#pragma unroll 1
+  for (int s = 0; s < S; ++s) {
+    const int cc = s / 9, tap = s - 9 * cc;
+    if (s + 1 < S) load_wts(s + 1);
+    if (tap == 0 && cc + 1 < CC) load_win(cc + 1);
+    const unsigned short* wa = win + (cc & 1) * GWIN + lane_a + ((tap / 3) * GWC + tap % 3) * GPIX;
+    const unsigned short* wbp = wts + (s & 1) * GWT + lane_b;
+    // 6 groups per tap: (k-step ks2, m-tile row mr) with 5 m-tiles each; the A fragments of
+    // the next group fly under the MFMAs of the current one
+    const u32x4 bf0 = *reinterpret_cast<const u32x4*>(wbp);
+    const u32x4 bf1 = *reinterpret_cast<const u32x4*>(wbp + 16);
+    u32x4 af[2][5];
+#pragma unroll
+    for (int mc = 0; mc < 5; ++mc)
+      af[0][mc] = *reinterpret_cast<const u32x4*>(wa + (8 * mc) * GPIX);
+#pragma unroll
+    for (int g = 0; g < 6; ++g) {
+      const int ks2 = g / 3, mr = g % 3;
+      if (g + 1 < 6) {
+        const int k3 = (g + 1) / 3, m3 = (g + 1) % 3;
+#pragma unroll
+        for (int mc = 0; mc < 5; ++mc)
+          af[(g + 1) & 1][mc] = *reinterpret_cast<const u32x4*>(
+              wa + ((4 * m3) * GWC + 8 * mc) * GPIX + 16 * k3);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mc = 0; mc < 5; ++mc)
+        acc[5 * mr + mc] = mfma32b(af[g & 1][mc], ks2 ? bf1 : bf0, acc[5 * mr + mc]);
+    }
+    if (s + 1 < S) store_wts((s + 1) & 1);
+    if (tap == 8 && cc + 1 < CC) store_win((cc + 1) & 1);
+    __syncthreads();
+  }
+
+  // epilogue: m-tile (mr, mc), accumulator register q <-> pixel acc_row(q, h) of the tile,
+  // lane r <-> output channel 128 nb + 32 wid + r
+#pragma unroll
+  for (int mt = 0; mt < NMT; ++mt) {
+    const int mr = mt / 5, mc = mt % 5;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      float v = acc[mt][q] + bias_r;
+      if (EPI == 1 && relu) v = fmaxf(v, 0.f);
+      scr[acc_row(q, h) * GSCR_LD + r] = f32_to_bf16(v);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int px = lane >> 1, hf = lane & 1;
+    const u32x4 v0 = *reinterpret_cast<const u32x4*>(scr + px * GSCR_LD + 16 * hf);
+    const u32x4 v1 = *reinterpret_cast<const u32x4*>(scr + px * GSCR_LD + 16 * hf + 8);
+    __builtin_amdgcn_wave_barrier();
+    const int oy = y0 + 4 * mr + (px >> 3), ox = x0 + 8 * mc + (px & 7);
+    if (oy < H && ox < W) {
+      unsigned short* o =
+          out + (((int64_t)b * H + oy) * W + ox) * kout + NB * nb + 32 * wid + 16 * hf;
+      *reinterpret_cast<u32x4*>(o) = v0;
+      *reinterpret_cast<u32x4*>(o + 8) = v1;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" size_t scl_convg_workspace_bytes(int cin, int kout) {
+  if (cin < 32 || kout < 128 || cin % 32 || kout % 128 || cin > 1024 || kout > 1024) return 0;
+  return scl_round256((size_t)9 * cin * kout * sizeof(unsigned short));
+}
+
+// Same contract as scl_conv3x3_fused (include/scl_hip.h) without the pooled output, for
+// cin % 32 == 0 and kout % 128 == 0.
+extern "C" int scl_convg(const void* x, const void* w, int64_t w_stride_k, int64_t w_stride_c,
+                         int64_t w_stride_h, int64_t w_stride_w, int transposed, int B, int H,
+                         int W, int cin, int kout, void* out, const float* bias, int relu,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+  if (!x || !w || !out || !workspace) return SCL_E_NULL;
+  const size_t need = scl_convg_workspace_bytes(cin, kout);
+  if (need == 0 || B < 1 || H < 1 || W < 1 || (int64_t)B * H * W > (int64_t)1 << 30)
+    return SCL_E_SHAPE;
+  if (((uintptr_t)x % 16) || ((uintptr_t)out % 16)) return SCL_E_SHAPE;
+  if (!scl_aligned256(workspace) || workspace_bytes < need) return SCL_E_WORKSPACE;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convg_kernel<0>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kConvgLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convg_kernel<1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kConvgLds);
+  });
+  hipStream_t st = (hipStream_t)stream;
+  unsigned short* packed = (unsigned short*)workspace;
+  const int64_t total = (int64_t)9 * cin * kout;
+  SCL_LAUNCH("convg_pack_kernel", convg_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256),
+             0, st, (const unsigned short*)w, w_stride_k, w_stride_c, w_stride_h, w_stride_w,
+             transposed ? 1 : 0, cin, kout, packed);
+  const dim3 grid(B * ((H + BH - 1) / BH) * ((W + BW - 1) / BW), kout / NB);
+  if (bias)
+    SCL_LAUNCH("convg_kernel", convg_kernel<1>, grid, dim3(256), kConvgLds, st,
+               (const unsigned short*)x, (const unsigned short*)packed, B, H, W, cin, kout,
+               (unsigned short*)out, bias, relu ? 1 : 0);
+  else
+    SCL_LAUNCH("convg_kernel", convg_kernel<0>, grid, dim3(256), kConvgLds, st,
+               (const unsigned short*)x, (const unsigned short*)packed, B, H, W, cin, kout,
+               (unsigned short*)out, bias, 0);
+  return scl_launch_status();
+}

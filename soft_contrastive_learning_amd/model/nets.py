@@ -95,15 +95,36 @@ _ONES = [1, 1]
 # the library kernels take up to twice as long there as on the equal-FLOP deeper layers.
 # SCL_CONV64=0 restores MIOpen everywhere.
 USE_CONV64 = os.environ.get('SCL_CONV64', '1') != '0'
+USE_CONVG = os.environ.get('SCL_CONVG', '1') != '0'
 _OWN_CONV_SHAPES = {(64, 64), (64, 128), (128, 64), (128, 128)}      # (contraction, output)
 
 
-def _conv64_ok(x, w, transposed=False):
+def _own_conv_kind(x, w, transposed=False):
+    """'reg' (weights in registers, csrc/conv64.hip), 'lds' (weights streamed through LDS,
+    csrc/convg.hip) or None (library)."""
     if not (USE_CONV64 and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
             and x.dim() == 4 and w.dim() == 4 and tuple(w.shape[2:]) == (3, 3)):
-        return False
+        return None
     cin, kout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
-    return x.shape[1] == cin and (cin, kout) in _OWN_CONV_SHAPES
+    if x.shape[1] != cin:
+        return None
+    if (cin, kout) in _OWN_CONV_SHAPES:
+        return 'reg'
+    if USE_CONVG and cin % 32 == 0 and kout % 128 == 0 and cin >= 128 and max(cin, kout) <= 1024:
+        return 'lds'
+    return None
+
+
+def _lds_conv_pays(x, transposed):
+    """Measured on MI355X (scripts/conv_layers.py): the LDS-weights kernel beats the library on
+    the backward-data passes of conv3_x / conv4_x (750-800 vs 550-670 TFLOP/s) but not on
+    their forward passes (library 790-970) and not on maps too small to fill the chip
+    (conv5_x: 30 x 40)."""
+    return transposed and x.shape[2] * x.shape[3] >= 60 * 80
+
+
+def _conv64_ok(x, w, transposed=False):
+    return _own_conv_kind(x, w, transposed) is not None
 
 
 def conv64(x, w, transposed=False, bias=None, relu=False, pool=False):
@@ -125,8 +146,16 @@ def conv64(x, w, transposed=False, bias=None, relu=False, pool=False):
                              memory_format=_CL)
     if bias is not None:
         bias = bias.float().contiguous()
-    ws = L.workspace(lib.scl_conv3x3_workspace_bytes(), x.device)
     sk, sc, sh, sw = w.stride()
+    if (cin, kout) not in _OWN_CONV_SHAPES:
+        if pool:
+            raise ValueError("the fused pooling epilogue exists for the register kernels only")
+        ws = L.workspace(lib.scl_convg_workspace_bytes(cin, kout), x.device)
+        L.check(lib.scl_convg(L.ptr(x), L.ptr(w), sk, sc, sh, sw, int(bool(transposed)), b, h, wd,
+                              cin, kout, L.ptr(out), L.ptr(bias), int(bool(relu)), L.ptr(ws),
+                              ws.numel(), L.stream_of(x)))
+        return out
+    ws = L.workspace(lib.scl_conv3x3_workspace_bytes(), x.device)
     L.check(lib.scl_conv3x3_fused(L.ptr(x), L.ptr(w), sk, sc, sh, sw, int(bool(transposed)), b, h,
                                   wd, cin, kout, L.ptr(out), L.ptr(bias), int(bool(relu)),
                                   L.ptr(pooled), L.ptr(ws), ws.numel(), L.stream_of(x)))
@@ -151,13 +180,14 @@ def wrw64(x, gz, w_like):
 
 def _conv3x3(x, w):
     """3x3 / stride 1 / same-padding convolution without bias (MIOpen, or conv64)."""
-    if _conv64_ok(x, w):
+    if _own_conv_kind(x, w) == 'reg':
         return conv64(x, w, False)
     return torch.ops.aten.convolution(x, w, None, _ONES, _ONES, _ONES, False, [0, 0], 1)
 
 
 def _conv3x3_backward(gz, x, w, need_x):
-    if _conv64_ok(gz, w, True):
+    kind = _own_conv_kind(gz, w, True)
+    if kind == 'reg' or (kind == 'lds' and _lds_conv_pays(gz, True)):
         gx = conv64(gz, w, True) if need_x else None
         if tuple(w.shape[:2]) == (64, 64):
             return gx, wrw64(x, gz, w)
@@ -185,7 +215,7 @@ class _ConvBiasAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, relu):
         lib = L.load()
-        if _conv64_ok(x, w):
+        if _own_conv_kind(x, w) == 'reg':
             y = conv64(x, w, False, bias=bias, relu=relu)         # tail fused in the epilogue
         else:
             y = _conv3x3(x, w).contiguous(memory_format=_CL)
@@ -220,7 +250,7 @@ class _ConvBiasPoolReLU(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias):
         lib = L.load()
-        if _conv64_ok(x, w) and tuple(w.shape[:2]) == (64, 64):
+        if _own_conv_kind(x, w) == 'reg' and tuple(w.shape[:2]) == (64, 64):
             # pooled map from the epilogue (the 128-channel variant of that epilogue runs out
             # of registers and is slower than the plain kernel + the pooling pass)
             z, a = conv64(x, w, False, bias=bias, pool=True)

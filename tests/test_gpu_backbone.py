@@ -228,3 +228,29 @@ def test_own_conv_fused_tails(dev, cin, cout, shape):
     # the pooled map is computed from the float32 accumulators, the library path from the bf16 z
     want_a = torch.relu(torch.nn.functional.max_pool2d(z32, 2) + bias[None, :, None, None])
     assert float((a.float() - want_a).abs().max()) < 6e-3 * scale
+
+
+@pytest.mark.parametrize('cin,cout,shape', [(128, 256, (2, 12, 40)), (256, 256, (1, 30, 40)),
+                                            (256, 512, (1, 15, 80)), (512, 512, (1, 7, 23))])
+def test_lds_weight_conv_deeper_layers(dev, cin, cout, shape):
+    """csrc/convg.hip: conv3_x .. conv5_x shapes, forward (+ bias / ReLU) and backward-data."""
+    from soft_contrastive_learning_amd.model import nets
+    b, h, w = shape
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(b, cin, h, w, generator=g).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(b, cout, h, w, generator=g).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * 0.03).to(dev).bfloat16().contiguous(
+        memory_format=torch.channels_last)
+    bias = torch.randn(cout, generator=g).to(dev)
+    assert nets._own_conv_kind(x, wt) == 'lds' and nets._own_conv_kind(gy, wt, True) == 'lds'
+    z32 = torch.nn.functional.conv2d(x.float(), wt.float(), padding=1)
+    scale = float(z32.abs().max())
+    got = nets.conv64(x, wt, False)
+    assert got.shape == z32.shape and got.is_contiguous(memory_format=torch.channels_last)
+    assert float((got.float() - z32).abs().max()) < 6e-3 * scale
+    y = nets.conv64(x, wt, False, bias=bias, relu=True)
+    assert float((y.float() - torch.relu(z32 + bias[None, :, None, None])).abs().max()) < 6e-3 * scale
+    gx = nets.conv64(gy, wt, True)
+    want_gx = torch.nn.functional.conv_transpose2d(gy.float(), wt.float(), padding=1)
+    assert gx.shape == want_gx.shape
+    assert float((gx.float() - want_gx).abs().max()) < 6e-3 * float(want_gx.abs().max())
