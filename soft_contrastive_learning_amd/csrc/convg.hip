@@ -10,8 +10,8 @@
 //     owns output channels 32 w .. + 31 of the block and all 15 m-tiles: 240 accumulators;
 //   * K loop over (32-channel chunk, tap): the [14][42][32 ch] halo window of the chunk is
 //     staged once per chunk, the [128 k][32 c] weight slice once per (chunk, tap), both
-//     double-buffered in LDS behind register prefetches; one barrier per (chunk, tap) =
-//     per 30 MFMAs per wave;
+//     double-buffered in LDS behind register prefetches; one barrier per TWO (chunk, tap)
+//     steps = per 60 MFMAs per wave;
 //   * A fragment = 16 bytes (8 channels of one window pixel) at a per-tap address offset —
 //     no im2col; B fragment = 16 bytes of a weight row.
 //   * epilogue as conv64.hip: bf16 through a per-wave LDS transpose, optional bias (+ ReLU).
@@ -35,7 +35,8 @@ constexpr int NB = 128;                             // output channels per workg
 constexpr int GWT = NB * GPIX;                      // bf16 per weight buffer (5120)
 constexpr int GSCR_LD = 40;
 constexpr int GSCR = 32 * GSCR_LD;
-constexpr size_t kConvgLds = (2 * (size_t)GWIN + 2 * (size_t)GWT + 4 * (size_t)GSCR) * 2;
+constexpr int TPB = 2;                              // (chunk, tap) steps per barrier
+constexpr size_t kConvgLds = (2 * (size_t)GWIN + 2 * TPB * (size_t)GWT + 4 * (size_t)GSCR) * 2;
 constexpr int NMT = 15;                             // m-tiles: 3 rows x 5 cols of 4 x 8 pixels
 
 __device__ __forceinline__ f32x16 mfma32b(u32x4 a, u32x4 b, f32x16 c) {
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256, 1) void convg_kernel(const unsigned short* __r
   unsigned short* wts = lds + 2 * GWIN;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
-  unsigned short* scr = wts + 2 * GWT + wid * GSCR;
+  unsigned short* scr = wts + 2 * TPB * GWT + wid * GSCR;
   const int nb = blockIdx.y;
   const int blocks_x = (W + BW - 1) / BW, blocks_y = (H + BH - 1) / BH;
   const int b = blockIdx.x / (blocks_x * blocks_y), t2 = blockIdx.x % (blocks_x * blocks_y);
@@ -87,18 +88,19 @@ __global__ __launch_bounds__(256, 1) void convg_kernel(const unsigned short* __r
   const int CC = cin / CCH, S = 9 * CC;
   const float bias_r = EPI == 1 ? bias[NB * nb + 32 * wid + r] : 0.f;
 
-  u32x4 st_w[2], st_x[GNPT];
+  u32x4 st_w[2 * TPB], st_x[GNPT];
+  // weight slices of steps s, s + 1 (16 KB contiguous in the packed image)
   auto load_wts = [&](int s) {
     const unsigned short* src = packed + ((int64_t)nb * S + s) * (NB * CCH);
 #pragma unroll
-    for (int v = 0; v < 2; ++v)
+    for (int v = 0; v < 2 * TPB; ++v)
       st_w[v] = *reinterpret_cast<const u32x4*>(src + (v * 256 + threadIdx.x) * 8);
   };
   auto store_wts = [&](int buf) {
 #pragma unroll
-    for (int v = 0; v < 2; ++v) {
-      const int idx = v * 256 + threadIdx.x;
-      *reinterpret_cast<u32x4*>(wts + buf * GWT + (idx >> 2) * GPIX + 8 * (idx & 3)) = st_w[v];
+    for (int v = 0; v < 2 * TPB; ++v) {
+      const int idx = v * 256 + threadIdx.x;        // [step 2][k 128][4 pieces]
+      *reinterpret_cast<u32x4*>(wts + buf * TPB * GWT + (idx >> 2) * GPIX + 8 * (idx & 3)) = st_w[v];
     }
   };
   auto load_win = [&](int cc) {
@@ -135,38 +137,54 @@ __global__ __launch_bounds__(256, 1) void convg_kernel(const unsigned short* __r
   // lane (r, h): pixel (r >> 3, r & 7) of an m-tile, channels 8 h .. + 7 of a k-step
   const int lane_a = ((r >> 3) * GWC + (r & 7)) * GPIX + 8 * h;
   const int lane_b = (32 * wid + r) * GPIX + 8 * h;
+  // S = 9 * CC is even (CC = cin / 32 is even for every supported shape): pairs of steps.
+  // The window of chunk cc + 1 is loaded at tap 0 / 1 of chunk cc and stored four or five
+  // steps later, i.e. at least one barrier before a pair can reach into that chunk.
+  int win_loaded = 0;                                 // chunk whose window sits in st_x (+1)
 #pragma unroll 1
-  for (int s = 0; s < S; ++s) {
-    const int cc = s / 9, tap = s - 9 * cc;
-    if (s + 1 < S) load_wts(s + 1);
-    if (tap == 0 && cc + 1 < CC) load_win(cc + 1);
-    const unsigned short* wa = win + (cc & 1) * GWIN + lane_a + ((tap / 3) * GWC + tap % 3) * GPIX;
-    const unsigned short* wbp = wts + (s & 1) * GWT + lane_b;
-    // 6 groups per tap: (k-step ks2, m-tile row mr) with 5 m-tiles each; the A fragments of
-    // the next group fly under the MFMAs of the current one
-    const u32x4 bf0 = *reinterpret_cast<const u32x4*>(wbp);
-    const u32x4 bf1 = *reinterpret_cast<const u32x4*>(wbp + 16);
-    u32x4 af[2][5];
+  for (int s = 0; s < S; s += TPB) {
+    if (s + TPB < S) load_wts(s + TPB);
+    const int cc0 = s / 9, tap0 = s - 9 * cc0;
+    if (tap0 <= 1 && cc0 + 1 < CC) {
+      load_win(cc0 + 1);
+      win_loaded = cc0 + 2;
+    }
 #pragma unroll
-    for (int mc = 0; mc < 5; ++mc)
-      af[0][mc] = *reinterpret_cast<const u32x4*>(wa + (8 * mc) * GPIX);
-#pragma unroll
-    for (int g = 0; g < 6; ++g) {
-      const int ks2 = g / 3, mr = g % 3;
-      if (g + 1 < 6) {
-        const int k3 = (g + 1) / 3, m3 = (g + 1) % 3;
-#pragma unroll
-        for (int mc = 0; mc < 5; ++mc)
-          af[(g + 1) & 1][mc] = *reinterpret_cast<const u32x4*>(
-              wa + ((4 * m3) * GWC + 8 * mc) * GPIX + 16 * k3);
-      }
-      __builtin_amdgcn_sched_barrier(0);
+    for (int u = 0; u < TPB; ++u) {
+      const int su = s + u;
+      const int cc = su / 9, tap = su - 9 * cc;
+      const unsigned short* wa =
+          win + (cc & 1) * GWIN + lane_a + ((tap / 3) * GWC + tap % 3) * GPIX;
+      const unsigned short* wbp = wts + (((s / TPB) & 1) * TPB + u) * GWT + lane_b;
+      // 6 groups per tap: (k-step ks2, m-tile row mr) with 5 m-tiles each; the A fragments
+      // of the next group fly under the MFMAs of the current one
+      const u32x4 bf0 = *reinterpret_cast<const u32x4*>(wbp);
+      const u32x4 bf1 = *reinterpret_cast<const u32x4*>(wbp + 16);
+      u32x4 af[2][5];
 #pragma unroll
       for (int mc = 0; mc < 5; ++mc)
-        acc[5 * mr + mc] = mfma32b(af[g & 1][mc], ks2 ? bf1 : bf0, acc[5 * mr + mc]);
+        af[0][mc] = *reinterpret_cast<const u32x4*>(wa + (8 * mc) * GPIX);
+#pragma unroll
+      for (int g = 0; g < 6; ++g) {
+        const int ks2 = g / 3, mr = g % 3;
+        if (g + 1 < 6) {
+          const int k3 = (g + 1) / 3, m3 = (g + 1) % 3;
+#pragma unroll
+          for (int mc = 0; mc < 5; ++mc)
+            af[(g + 1) & 1][mc] = *reinterpret_cast<const u32x4*>(
+                wa + ((4 * m3) * GWC + 8 * mc) * GPIX + 16 * k3);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mc = 0; mc < 5; ++mc)
+          acc[5 * mr + mc] = mfma32b(af[g & 1][mc], ks2 ? bf1 : bf0, acc[5 * mr + mc]);
+      }
     }
-    if (s + 1 < S) store_wts((s + 1) & 1);
-    if (tap == 8 && cc + 1 < CC) store_win((cc + 1) & 1);
+    if (s + TPB < S) store_wts(((s / TPB) + 1) & 1);
+    if (win_loaded && tap0 >= 4) {                    // stored once, well before tap 8
+      store_win((win_loaded - 1) & 1);
+      win_loaded = 0;
+    }
     __syncthreads();
   }
 
