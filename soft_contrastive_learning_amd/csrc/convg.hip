@@ -6,8 +6,9 @@
 // Implicit GEMM on v_mfma_f32_32x32x16_bf16 with a large M tile so that a staged weight chunk
 // is reused by many pixels:
 //   * workgroup = [12 rows x 40 cols] of output pixels (15 m-tiles of 4 x 8 pixels; 40
-//     divides the widths 160 / 80 / 40 of conv3_x .. conv5_x) x 128 output channels; wave w
-//     owns output channels 32 w .. + 31 of the block and all 15 m-tiles: 240 accumulators;
+//     divides the widths 160 / 80 / 40 of conv3_x .. conv5_x) x 128 output channels; wave
+//     (mg, ng) owns 8 of the m-tiles x 64 of the channels: 256 accumulators, and 10 LDS
+//     fragment reads per 16 MFMAs;
 //   * K loop over (32-channel chunk, tap): the [14][42][32 ch] halo window of the chunk is
 //     staged once per chunk, the [128 k][32 c] weight slice once per (chunk, tap), both
 //     double-buffered in LDS behind register prefetches; one barrier per TWO (chunk, tap)
@@ -86,8 +87,6 @@ __global__ __launch_bounds__(256, 1) void convg_kernel(const unsigned short* __r
   const int b = blockIdx.x / (blocks_x * blocks_y), t2 = blockIdx.x % (blocks_x * blocks_y);
   const int y0 = (t2 / blocks_x) * BH, x0 = (t2 % blocks_x) * BW;
   const int CC = cin / CCH, S = 9 * CC;
-  const float bias_r = EPI == 1 ? bias[NB * nb + 32 * wid + r] : 0.f;
-
   u32x4 st_w[2 * TPB], st_x[GNPT];
   // weight slices of steps s, s + 1 (16 KB contiguous in the packed image)
   auto load_wts = [&](int s) {
@@ -124,9 +123,9 @@ __global__ __launch_bounds__(256, 1) void convg_kernel(const unsigned short* __r
     }
   };
 
-  f32x16 acc[NMT];
+  f32x16 acc[16];                                     // [m-tile slot 8][n-tile 2]
 #pragma unroll
-  for (int mt = 0; mt < NMT; ++mt) acc[mt] = zero16();
+  for (int mt = 0; mt < 16; ++mt) acc[mt] = zero16();
 
   load_win(0);
   load_wts(0);
@@ -134,9 +133,20 @@ __global__ __launch_bounds__(256, 1) void convg_kernel(const unsigned short* __r
   store_wts(0);
   __syncthreads();
 
+  // Wave (mg, ng) owns m-tiles 8 mg .. 8 mg + 7 (the block has 15: the last slot of mg = 1
+  // repeats tile 14 and is dropped in the epilogue) and output channels 64 ng .. + 63 (two
+  // n-tiles): 16 accumulators, and per k-step 8 A + 2 B fragment reads for 16 MFMAs — the
+  // split over BOTH dimensions halves the LDS operand traffic of an n-only split.
   // lane (r, h): pixel (r >> 3, r & 7) of an m-tile, channels 8 h .. + 7 of a k-step
+  const int mg = wid >> 1, ng = wid & 1;
+  int aoff[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int mt = 8 * mg + j < NMT ? 8 * mg + j : NMT - 1;
+    aoff[j] = ((4 * (mt / 5)) * GWC + 8 * (mt % 5)) * GPIX;
+  }
   const int lane_a = ((r >> 3) * GWC + (r & 7)) * GPIX + 8 * h;
-  const int lane_b = (32 * wid + r) * GPIX + 8 * h;
+  const int lane_b = (64 * ng + r) * GPIX + 8 * h;
   // S = 9 * CC is even (CC = cin / 32 is even for every supported shape): pairs of steps.
   // The window of chunk cc + 1 is loaded at tap 0 / 1 of chunk cc and stored four or five
   // steps later, i.e. at least one barrier before a pair can reach into that chunk.
@@ -156,28 +166,33 @@ __global__ __launch_bounds__(256, 1) void convg_kernel(const unsigned short* __r
       const unsigned short* wa =
           win + (cc & 1) * GWIN + lane_a + ((tap / 3) * GWC + tap % 3) * GPIX;
       const unsigned short* wbp = wts + (((s / TPB) & 1) * TPB + u) * GWT + lane_b;
-      // 6 groups per tap: (k-step ks2, m-tile row mr) with 5 m-tiles each; the A fragments
-      // of the next group fly under the MFMAs of the current one
-      const u32x4 bf0 = *reinterpret_cast<const u32x4*>(wbp);
-      const u32x4 bf1 = *reinterpret_cast<const u32x4*>(wbp + 16);
-      u32x4 af[2][5];
+      u32x4 bf[2][2];
 #pragma unroll
-      for (int mc = 0; mc < 5; ++mc)
-        af[0][mc] = *reinterpret_cast<const u32x4*>(wa + (8 * mc) * GPIX);
+      for (int ks2 = 0; ks2 < 2; ++ks2)
 #pragma unroll
-      for (int g = 0; g < 6; ++g) {
-        const int ks2 = g / 3, mr = g % 3;
-        if (g + 1 < 6) {
-          const int k3 = (g + 1) / 3, m3 = (g + 1) % 3;
+        for (int n = 0; n < 2; ++n)
+          bf[ks2][n] = *reinterpret_cast<const u32x4*>(wbp + (32 * n) * GPIX + 16 * ks2);
+      // 4 groups per tap: (k-step ks2, half of the wave's m-tiles); the A fragments of the
+      // next group fly under the 8 MFMAs of the current one
+      u32x4 af[2][4];
 #pragma unroll
-          for (int mc = 0; mc < 5; ++mc)
-            af[(g + 1) & 1][mc] = *reinterpret_cast<const u32x4*>(
-                wa + ((4 * m3) * GWC + 8 * mc) * GPIX + 16 * k3);
+      for (int j = 0; j < 4; ++j) af[0][j] = *reinterpret_cast<const u32x4*>(wa + aoff[j]);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int ks2 = g >> 1, hm = g & 1;
+        if (g + 1 < 4) {
+          const int k3 = (g + 1) >> 1, h3 = (g + 1) & 1;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            af[(g + 1) & 1][j] =
+                *reinterpret_cast<const u32x4*>(wa + aoff[4 * h3 + j] + 16 * k3);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int mc = 0; mc < 5; ++mc)
-          acc[5 * mr + mc] = mfma32b(af[g & 1][mc], ks2 ? bf1 : bf0, acc[5 * mr + mc]);
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+            acc[2 * (4 * hm + j) + n] = mfma32b(af[g & 1][j], bf[ks2][n], acc[2 * (4 * hm + j) + n]);
       }
     }
     if (s + TPB < S) store_wts(((s / TPB) + 1) & 1);
@@ -188,28 +203,34 @@ __global__ __launch_bounds__(256, 1) void convg_kernel(const unsigned short* __r
     __syncthreads();
   }
 
-  // epilogue: m-tile (mr, mc), accumulator register q <-> pixel acc_row(q, h) of the tile,
-  // lane r <-> output channel 128 nb + 32 wid + r
+  // epilogue: slot j <-> m-tile 8 mg + j, n <-> channels 64 ng + 32 n ..; accumulator register
+  // q <-> pixel acc_row(q, h) of the tile, lane r <-> channel r of the n-tile
 #pragma unroll
-  for (int mt = 0; mt < NMT; ++mt) {
+  for (int j = 0; j < 8; ++j) {
+    const int mt = 8 * mg + j;
+    if (mt >= NMT) break;                             // wave-uniform
     const int mr = mt / 5, mc = mt % 5;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      float v = acc[mt][q] + bias_r;
-      if (EPI == 1 && relu) v = fmaxf(v, 0.f);
-      scr[acc_row(q, h) * GSCR_LD + r] = f32_to_bf16(v);
-    }
-    __builtin_amdgcn_wave_barrier();
-    const int px = lane >> 1, hf = lane & 1;
-    const u32x4 v0 = *reinterpret_cast<const u32x4*>(scr + px * GSCR_LD + 16 * hf);
-    const u32x4 v1 = *reinterpret_cast<const u32x4*>(scr + px * GSCR_LD + 16 * hf + 8);
-    __builtin_amdgcn_wave_barrier();
-    const int oy = y0 + 4 * mr + (px >> 3), ox = x0 + 8 * mc + (px & 7);
-    if (oy < H && ox < W) {
-      unsigned short* o =
-          out + (((int64_t)b * H + oy) * W + ox) * kout + NB * nb + 32 * wid + 16 * hf;
-      *reinterpret_cast<u32x4*>(o) = v0;
-      *reinterpret_cast<u32x4*>(o + 8) = v1;
+    for (int n = 0; n < 2; ++n) {
+      const float bias_r = EPI == 1 ? bias[NB * nb + 64 * ng + 32 * n + r] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        float v = acc[2 * j + n][q] + bias_r;
+        if (EPI == 1 && relu) v = fmaxf(v, 0.f);
+        scr[acc_row(q, h) * GSCR_LD + r] = f32_to_bf16(v);
+      }
+      __builtin_amdgcn_wave_barrier();
+      const int px = lane >> 1, hf = lane & 1;
+      const u32x4 v0 = *reinterpret_cast<const u32x4*>(scr + px * GSCR_LD + 16 * hf);
+      const u32x4 v1 = *reinterpret_cast<const u32x4*>(scr + px * GSCR_LD + 16 * hf + 8);
+      __builtin_amdgcn_wave_barrier();
+      const int oy = y0 + 4 * mr + (px >> 3), ox = x0 + 8 * mc + (px & 7);
+      if (oy < H && ox < W) {
+        unsigned short* o = out + (((int64_t)b * H + oy) * W + ox) * kout + NB * nb + 64 * ng +
+                            32 * n + 16 * hf;
+        *reinterpret_cast<u32x4*>(o) = v0;
+        *reinterpret_cast<u32x4*>(o + 8) = v1;
+      }
     }
   }
 }

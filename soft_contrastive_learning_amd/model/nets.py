@@ -115,12 +115,12 @@ def _own_conv_kind(x, w, transposed=False):
     return None
 
 
-def _lds_conv_pays(x, transposed):
+def _lds_conv_pays(x, transposed, fused_tail=False):
     """Measured on MI355X (scripts/conv_layers.py): the LDS-weights kernel beats the library on
-    the backward-data passes of conv3_x / conv4_x (750-800 vs 550-670 TFLOP/s) but not on
-    their forward passes (library 790-970) and not on maps too small to fill the chip
-    (conv5_x: 30 x 40)."""
-    return transposed and x.shape[2] * x.shape[3] >= 60 * 80
+    the backward-data passes of conv3_x / conv4_x (870-950 vs 570-650 TFLOP/s); forward it
+    only ties (780-960 vs 770-970), so it pays there when it also absorbs the bias + ReLU pass
+    (43-86 us per layer); on maps too small to fill the chip (conv5_x: 30 x 40) it loses."""
+    return (transposed or fused_tail) and x.shape[2] * x.shape[3] >= 60 * 80
 
 
 def _conv64_ok(x, w, transposed=False):
@@ -215,7 +215,8 @@ class _ConvBiasAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, relu):
         lib = L.load()
-        if _own_conv_kind(x, w) == 'reg':
+        kind = _own_conv_kind(x, w)
+        if kind == 'reg' or (kind == 'lds' and _lds_conv_pays(x, False, True)):
             y = conv64(x, w, False, bias=bias, relu=relu)         # tail fused in the epilogue
         else:
             y = _conv3x3(x, w).contiguous(memory_format=_CL)
