@@ -281,6 +281,14 @@ int scl_wrw64(const void* x, const void* gz, int B, int H, int W, void* gw, int6
               int64_t w_stride_c, int64_t w_stride_h, int64_t w_stride_w, void* workspace,
               size_t workspace_bytes, void* stream);
 
+/* The weight gradient for any cin, kout that are multiples of 64 (up to 1024): the same kernel
+ * per [64 c] x [64 k] block, pixels split over workgroups, slabs reduced in a fixed order.
+ * x [B,H,W,cin], gz [B,H,W,kout] bf16; gw bf16 logical [kout][cin][3][3] at the given strides. */
+size_t scl_wrw3x3_workspace_bytes(int cin, int kout);
+int scl_wrw3x3(const void* x, const void* gz, int B, int H, int W, int cin, int kout, void* gw,
+               int64_t w_stride_k, int64_t w_stride_c, int64_t w_stride_h, int64_t w_stride_w,
+               void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Diagnostics (bench.py's live per-kernel timing; the reference has no counterpart
  * beyond its wall-clock prints, train/train.py:135-161).  Between scl_prof_begin and

@@ -77,7 +77,7 @@ def main():
             t = [timed(lambda: nets.conv64(x, wt, False)),
                  timed(lambda: nets.conv64(gy, wt, True)) if nets._conv64_ok(gy, wt, True)
                  else float('nan'),
-                 timed(lambda: nets.wrw64(x, gy, wt)) if (cin, cout) == (64, 64) else float('nan')]
+                 timed(lambda: nets.wrw64(x, gy, wt)) if nets._own_wrw_ok(x, gy, wt) else float('nan')]
             cells = ['%8.1f (%6.0f)' % (v, gf / v * 1e3) for v in t]
             print('%-5s %4s %4s %9s | %22s | %22s | %22s' % ('  own', '', '', '', *cells))
             bias = torch.randn(cout, device=dev)

@@ -263,9 +263,11 @@ __device__ __forceinline__ u32x4 tr_pair(const unsigned short* a0, int step4) {
   return u32x4{l2.x, l2.y, h2.x, h2.y};
 }
 
+// grid (pixel splits P, C / 64, K / 64): workgroup (p, cb, kb) accumulates the [9][64][64]
+// block (input channels 64 cb .., output channels 64 kb ..) over the tiles p, p + P, ...
 __global__ __launch_bounds__(256, 1) void wrw64_kernel(const unsigned short* __restrict__ x,
                                                        const unsigned short* __restrict__ gz,
-                                                       int B, int H, int W,
+                                                       int B, int H, int W, int C, int K,
                                                        float* __restrict__ slabs) {
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
   unsigned short* gl = lds + WIN;
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(256, 1) void wrw64_kernel(const unsigned short* __r
       const int y = ty - 1 + pix / WC, xx = tx - 1 + pix % WC;
       const bool ok = idx < PIECES && y >= 0 && y < H && xx >= 0 && xx < W;
       st_x[v] = ok ? *reinterpret_cast<const u32x4*>(
-                         x + (((int64_t)b * H + y) * W + xx) * C64 + 8 * c)
+                         x + (((int64_t)b * H + y) * W + xx) * C + C64 * blockIdx.y + 8 * c)
                    : u32x4{0u, 0u, 0u, 0u};
     }
 #pragma unroll
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(256, 1) void wrw64_kernel(const unsigned short* __r
       const int y = ty + pix / TW, xx = tx + pix % TW;
       const bool ok = y < H && xx < W;
       st_g[v] = ok ? *reinterpret_cast<const u32x4*>(
-                         gz + (((int64_t)b * H + y) * W + xx) * C64 + 8 * c)
+                         gz + (((int64_t)b * H + y) * W + xx) * K + C64 * blockIdx.z + 8 * c)
                    : u32x4{0u, 0u, 0u, 0u};
     }
   };
@@ -358,8 +360,10 @@ __global__ __launch_bounds__(256, 1) void wrw64_kernel(const unsigned short* __r
     __syncthreads();
   }
 
-  // slab[wg][tap][c][k]: accumulator register qq <-> c = 32 mt + acc_row(qq, h), lane r <-> k
-  float* out = slabs + (int64_t)blockIdx.x * 9 * C64 * C64;
+  // slab[p][cb][kb][tap][c][k]: accumulator register qq <-> c = 32 mt + acc_row(qq, h),
+  // lane r <-> k
+  float* out = slabs + (((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z) *
+                           9 * C64 * C64;
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -367,28 +371,32 @@ __global__ __launch_bounds__(256, 1) void wrw64_kernel(const unsigned short* __r
       out[(t * C64 + 32 * mt + acc_row(qq, h)) * C64 + 32 * nt + r] = acc[t][qq];
 }
 
-// dW element (k, c, kh, kw) = sum over workgroup slabs, written as bf16 at the weight's strides.
-// grid 9*64*64/64, block 256: thread (j, g) sums the slabs i = g, g + 4, ... of element
-// 64 * blockIdx.x + j; the four partials are combined in a fixed order.
+// dW element (k, c, kh, kw) = sum over the pixel-split slabs of its (cb, kb) block, written as
+// bf16 at the weight's strides.  grid (9*64*64/64, CB * KB), block 256: thread (j, g) sums the
+// slabs p = g, g + 4, ... of element 64 * blockIdx.x + j; the four partials are combined in a
+// fixed order.
 __global__ __launch_bounds__(256) void wrw64_reduce_kernel(const float* __restrict__ slabs,
-                                                           int nslabs, int64_t sk, int64_t sc,
-                                                           int64_t sh, int64_t sw,
+                                                           int nsplit, int KB, int64_t sk,
+                                                           int64_t sc, int64_t sh, int64_t sw,
                                                            unsigned short* __restrict__ gw) {
   __shared__ float red[4][64];
   const int j = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int idx = blockIdx.x * 64 + j;                 // over 9 * 64 * 64, k fastest
+  const int blk = blockIdx.y, nblk = gridDim.y;        // blk = cb * KB + kb
+  const int64_t stride = (int64_t)nblk * 9 * C64 * C64;
+  const float* base = slabs + (int64_t)blk * 9 * C64 * C64 + idx;
   float s0 = 0.f, s1 = 0.f;
   int i = g;
-  for (; i + 4 < nslabs; i += 8) {
-    s0 += slabs[(int64_t)i * 9 * C64 * C64 + idx];
-    s1 += slabs[(int64_t)(i + 4) * 9 * C64 * C64 + idx];
+  for (; i + 4 < nsplit; i += 8) {
+    s0 += base[(int64_t)i * stride];
+    s1 += base[(int64_t)(i + 4) * stride];
   }
-  if (i < nslabs) s0 += slabs[(int64_t)i * 9 * C64 * C64 + idx];
+  if (i < nsplit) s0 += base[(int64_t)i * stride];
   red[g][j] = s0 + s1;
   __syncthreads();
   if (g == 0) {
     const float s = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
-    const int k = idx & 63, c = (idx >> 6) & 63, t = idx >> 12;
+    const int k = 64 * (blk % KB) + (idx & 63), c = 64 * (blk / KB) + ((idx >> 6) & 63), t = idx >> 12;
     gw[k * sk + c * sc + (t / 3) * sh + (t % 3) * sw] = f32_to_bf16(s);
   }
 }
@@ -490,19 +498,32 @@ static int conv64_cus() {
   return 256;
 }
 
-extern "C" size_t scl_wrw64_workspace_bytes(void) {
-  return scl_round256((size_t)1024 * 9 * 64 * 64 * sizeof(float));   // up to 1024 CUs
+static int wrw_splits(int C, int K, int tiles, int cus) {
+  const int blocks = (C / 64) * (K / 64);
+  int p = (cus + blocks - 1) / blocks;                 // about one workgroup per CU
+  if (p > tiles) p = tiles;
+  if (p > 1024) p = 1024;
+  return p < 1 ? 1 : p;
 }
 
-extern "C" int scl_wrw64(const void* x, const void* gz, int B, int H, int W, void* gw,
-                         int64_t w_stride_k, int64_t w_stride_c, int64_t w_stride_h,
-                         int64_t w_stride_w, void* workspace, size_t workspace_bytes,
-                         void* stream) {
+extern "C" size_t scl_wrw3x3_workspace_bytes(int cin, int kout) {
+  if (cin < 64 || kout < 64 || cin % 64 || kout % 64 || cin > 1024 || kout > 1024) return 0;
+  // slabs: at most (1024 CUs rounded up to whole (cb, kb) block sets) x 147,456 B
+  const size_t blocks = (size_t)(cin / 64) * (kout / 64);
+  const size_t p = (1024 + blocks - 1) / blocks;
+  return scl_round256(p * blocks * 9 * 64 * 64 * sizeof(float));
+}
+
+extern "C" int scl_wrw3x3(const void* x, const void* gz, int B, int H, int W, int cin, int kout,
+                          void* gw, int64_t w_stride_k, int64_t w_stride_c, int64_t w_stride_h,
+                          int64_t w_stride_w, void* workspace, size_t workspace_bytes,
+                          void* stream) {
   if (!x || !gz || !gw || !workspace) return SCL_E_NULL;
-  if (B < 1 || H < 1 || W < 1 || (int64_t)B * H * W > (int64_t)1 << 30) return SCL_E_SHAPE;
+  const size_t need = scl_wrw3x3_workspace_bytes(cin, kout);
+  if (need == 0 || B < 1 || H < 1 || W < 1 || (int64_t)B * H * W > (int64_t)1 << 30)
+    return SCL_E_SHAPE;
   if (((uintptr_t)x % 16) || ((uintptr_t)gz % 16)) return SCL_E_SHAPE;
-  if (!scl_aligned256(workspace) || workspace_bytes < scl_wrw64_workspace_bytes())
-    return SCL_E_WORKSPACE;
+  if (!scl_aligned256(workspace) || workspace_bytes < need) return SCL_E_WORKSPACE;
   static std::once_flag once;
   static int cus = 256;
   std::call_once(once, [] {
@@ -512,12 +533,23 @@ extern "C" int scl_wrw64(const void* x, const void* gz, int B, int H, int W, voi
     if (cus > 1024) cus = 1024;
   });
   const int tiles = B * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
-  const int grid = tiles < cus ? tiles : cus;
+  const int P = wrw_splits(cin, kout, tiles, cus);
   hipStream_t st = (hipStream_t)stream;
-  SCL_LAUNCH("wrw64_kernel", wrw64_kernel, dim3(grid), dim3(256), kWrw64Lds, st,
-             (const unsigned short*)x, (const unsigned short*)gz, B, H, W, (float*)workspace);
-  SCL_LAUNCH("wrw64_reduce_kernel", wrw64_reduce_kernel, dim3(9 * 64 * 64 / 64), dim3(256), 0, st,
-             (const float*)workspace, grid, w_stride_k, w_stride_c, w_stride_h, w_stride_w,
-             (unsigned short*)gw);
+  SCL_LAUNCH("wrw64_kernel", wrw64_kernel, dim3(P, cin / 64, kout / 64), dim3(256), kWrw64Lds, st,
+             (const unsigned short*)x, (const unsigned short*)gz, B, H, W, cin, kout,
+             (float*)workspace);
+  SCL_LAUNCH("wrw64_reduce_kernel", wrw64_reduce_kernel, dim3(9 * 64 * 64 / 64, (cin / 64) * (kout / 64)),
+             dim3(256), 0, st, (const float*)workspace, P, kout / 64, w_stride_k, w_stride_c,
+             w_stride_h, w_stride_w, (unsigned short*)gw);
   return scl_launch_status();
+}
+
+extern "C" size_t scl_wrw64_workspace_bytes(void) { return scl_wrw3x3_workspace_bytes(64, 64); }
+
+extern "C" int scl_wrw64(const void* x, const void* gz, int B, int H, int W, void* gw,
+                         int64_t w_stride_k, int64_t w_stride_c, int64_t w_stride_h,
+                         int64_t w_stride_w, void* workspace, size_t workspace_bytes,
+                         void* stream) {
+  return scl_wrw3x3(x, gz, B, H, W, 64, 64, gw, w_stride_k, w_stride_c, w_stride_h, w_stride_w,
+                    workspace, workspace_bytes, stream);
 }

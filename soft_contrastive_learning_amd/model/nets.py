@@ -96,6 +96,7 @@ _ONES = [1, 1]
 # SCL_CONV64=0 restores MIOpen everywhere.
 USE_CONV64 = os.environ.get('SCL_CONV64', '1') != '0'
 USE_CONVG = os.environ.get('SCL_CONVG', '1') != '0'
+USE_WRW = os.environ.get('SCL_WRW', '1') != '0'
 _OWN_CONV_SHAPES = {(64, 64), (64, 128), (128, 64), (128, 128)}      # (contraction, output)
 
 
@@ -162,19 +163,27 @@ def conv64(x, w, transposed=False, bias=None, relu=False, pool=False):
     return (out, pooled) if pool else out
 
 
+def _own_wrw_ok(x, gz, w):
+    return (USE_CONV64 and USE_WRW and x.is_cuda and x.dtype == torch.bfloat16
+            and gz.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and w.dim() == 4
+            and tuple(w.shape[2:]) == (3, 3) and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0
+            and max(w.shape[0], w.shape[1]) <= 1024)
+
+
 def wrw64(x, gz, w_like):
-    """Weight gradient of the 64 -> 64 convolution (``scl_wrw64``): [64,64,3,3] bf16 with the
-    strides of ``w_like``."""
+    """Weight gradient of a 3x3 same-padding convolution whose channel counts are multiples
+    of 64 (``scl_wrw3x3``): bf16 [kout,cin,3,3] with the strides of ``w_like``."""
     lib = L.load()
     L.require_device(x, gz)
     x = x.contiguous(memory_format=_CL)
     gz = gz.contiguous(memory_format=_CL)
-    b, _, h, wd = x.shape
+    b, cin, h, wd = x.shape
+    kout = gz.shape[1]
     gw = torch.empty_like(w_like)
-    ws = L.workspace(lib.scl_wrw64_workspace_bytes(), x.device)
+    ws = L.workspace(lib.scl_wrw3x3_workspace_bytes(cin, kout), x.device)
     sk, sc, sh, sw = gw.stride()
-    L.check(lib.scl_wrw64(L.ptr(x), L.ptr(gz), b, h, wd, L.ptr(gw), sk, sc, sh, sw, L.ptr(ws),
-                          ws.numel(), L.stream_of(x)))
+    L.check(lib.scl_wrw3x3(L.ptr(x), L.ptr(gz), b, h, wd, cin, kout, L.ptr(gw), sk, sc, sh, sw,
+                           L.ptr(ws), ws.numel(), L.stream_of(x)))
     return gw
 
 
@@ -185,14 +194,27 @@ def _conv3x3(x, w):
     return torch.ops.aten.convolution(x, w, None, _ONES, _ONES, _ONES, False, [0, 0], 1)
 
 
+def _wrw_pays(x):
+    """scripts/conv_layers.py: own 760-880 vs library 370-750 TFLOP/s down to 120 x 160 maps
+    (conv1_2 .. conv3_x); a tie at 60 x 80 and a loss at 30 x 40 (ragged 8 x 32 tiles)."""
+    return x.shape[2] * x.shape[3] >= 120 * 160
+
+
 def _conv3x3_backward(gz, x, w, need_x):
     kind = _own_conv_kind(gz, w, True)
-    if kind == 'reg' or (kind == 'lds' and _lds_conv_pays(gz, True)):
-        gx = conv64(gz, w, True) if need_x else None
-        if tuple(w.shape[:2]) == (64, 64):
-            return gx, wrw64(x, gz, w)
-        _, gw, _ = torch.ops.aten.convolution_backward(gz, x, w, None, _ONES, _ONES, _ONES, False,
-                                                       [0, 0], 1, [False, True, False])
+    own_gx = kind == 'reg' or (kind == 'lds' and _lds_conv_pays(gz, True))
+    own_gw = _own_wrw_ok(x, gz, w) and _wrw_pays(x)
+    if own_gx and own_gw:
+        return (conv64(gz, w, True) if need_x else None), wrw64(x, gz, w)
+    if own_gx or own_gw:
+        gx = conv64(gz, w, True) if (own_gx and need_x) else None
+        gw = wrw64(x, gz, w) if own_gw else None
+        if (gx is None and need_x) or gw is None:
+            lx, lw, _ = torch.ops.aten.convolution_backward(
+                gz, x, w, None, _ONES, _ONES, _ONES, False, [0, 0], 1,
+                [bool(need_x) and gx is None, gw is None, False])
+            gx = lx if gx is None else gx
+            gw = lw if gw is None else gw
         return gx, gw
     gx, gw, _ = torch.ops.aten.convolution_backward(gz, x, w, None, _ONES, _ONES, _ONES, False,
                                                     [0, 0], 1, [bool(need_x), True, False])

@@ -254,3 +254,22 @@ def test_lds_weight_conv_deeper_layers(dev, cin, cout, shape):
     want_gx = torch.nn.functional.conv_transpose2d(gy.float(), wt.float(), padding=1)
     assert gx.shape == want_gx.shape
     assert float((gx.float() - want_gx).abs().max()) < 6e-3 * float(want_gx.abs().max())
+
+
+@pytest.mark.parametrize('cin,cout,shape', [(64, 128, (2, 12, 40)), (128, 128, (1, 13, 37)),
+                                            (256, 256, (1, 16, 40)), (512, 512, (1, 7, 23))])
+def test_wrw_other_shapes(dev, cin, cout, shape):
+    from soft_contrastive_learning_amd.model import nets
+    b, h, w = shape
+    g = torch.Generator().manual_seed(29)
+    x = torch.randn(b, cin, h, w, generator=g).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    gz = torch.randn(b, cout, h, w, generator=g).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    wf = torch.zeros(cout, cin, 3, 3, device=dev, requires_grad=True)
+    torch.nn.functional.conv2d(x.float(), wf, padding=1).backward(gz.float())
+    like = torch.empty(cout, cin, 3, 3, device=dev, dtype=torch.bfloat16).contiguous(
+        memory_format=torch.channels_last)
+    assert nets._own_wrw_ok(x, gz, like)
+    got = nets.wrw64(x, gz, like)
+    assert got.shape == wf.grad.shape and got.stride() == like.stride()
+    assert float((got.float() - wf.grad).abs().max() / wf.grad.abs().max()) < 6e-3
+    assert torch.equal(got, nets.wrw64(x, gz, like))
