@@ -273,6 +273,14 @@ int scl_convg(const void* x, const void* w, int64_t w_stride_k, int64_t w_stride
               int cin, int kout, void* out, const float* bias, int relu, void* workspace,
               size_t workspace_bytes, void* stream);
 
+/* The first layer in one pass (model/nets.py:22-24, 39): x0 = bf16(img - average_rgb),
+ * y = relu(conv3x3(x0, w) + bias).  img [B,H,W,3] float32 (raw 0..255), avg [3], w bf16 logical
+ * [64][3][3][3] at the given element strides, bias float32 [64]; x0 [B,H,W,3] bf16 (kept for the
+ * weight gradient), y [B,H,W,64] bf16. */
+int scl_conv_first(const float* img, const float* avg, const void* w, int64_t w_stride_k,
+                   int64_t w_stride_c, int64_t w_stride_h, int64_t w_stride_w, const float* bias,
+                   int B, int H, int W, void* x0, void* y, void* stream);
+
 /* Weight gradient of the same layer: gw[k][c][kh][kw] = sum_{b,y,x} gz[b,y,x,k] *
  * x[b, y+kh-1, x+kw-1, c]; x, gz [B,H,W,64] bf16, gw bf16 written at the given element
  * strides (logical [64][64][3][3]).  Deterministic (per-CU slabs summed in a fixed order). */

@@ -401,6 +401,126 @@ __global__ __launch_bounds__(256) void wrw64_reduce_kernel(const float* __restri
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// conv_first_kernel: the whole first layer in one pass (model/nets.py:22-24, 39),
+//   x0 = bf16(img - average_rgb),  y = relu(conv3x3(x0, w) + bias),
+// from the float32 NHWC image: 3 input channels, 64 output channels.  K = 27 (padded to 32 =
+// two k-steps of v_mfma_f32_32x32x16_bf16); an A fragment is gathered from a [10][34][3+1]
+// bf16 halo window in LDS (eight 2-byte reads per lane per k-step — the kernel is bound by
+// writing its 64-channel output, not by this).  x0 is written out for the weight gradient.
+constexpr int F_PIX = 4;                              // bf16 per staged pixel (3 + 1 pad)
+constexpr int F_WIN = WR * WC * F_PIX;                // 1360 bf16
+constexpr size_t kFirstLds = ((size_t)F_WIN + 4 * (size_t)SCR) * sizeof(unsigned short);
+
+__global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict__ img,
+                                                         const float* __restrict__ avg,
+                                                         const unsigned short* __restrict__ w,
+                                                         int64_t sk, int64_t sc, int64_t sh,
+                                                         int64_t sw, const float* __restrict__ bias,
+                                                         int B, int H, int W,
+                                                         unsigned short* __restrict__ x0,
+                                                         unsigned short* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  unsigned short* scr = lds + F_WIN + wid * SCR;
+
+  // weights: B[k][n], k = 3 * tap + c (k >= 27: zero); lane (j, h) holds k = 16 ks + 8 h + e
+  u32x4 wf[2][2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      unsigned short v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = 16 * ks + 8 * h + e;
+        const int tap = k / 3, c = k % 3;
+        v[e] = k < 27 ? w[(32 * nt + r) * sk + c * sc + (tap / 3) * sh + (tap % 3) * sw] : 0;
+      }
+      wf[ks][nt] = u32x4{(unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16),
+                         (unsigned)v[4] | ((unsigned)v[5] << 16), (unsigned)v[6] | ((unsigned)v[7] << 16)};
+    }
+  // A gather offsets (bf16 units, relative to the lane's pixel): window (kh, kw), channel c
+  int goff[2][8];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = 16 * ks + 8 * h + e;
+      const int tap = k < 27 ? k / 3 : 0, c = k < 27 ? k % 3 : 3;     // pad slot holds zero
+      goff[ks][e] = ((tap / 3) * WC + tap % 3) * F_PIX + c;
+    }
+  const float a0 = avg[0], a1 = avg[1], a2 = avg[2];
+  const float bias0 = bias[r], bias1 = bias[32 + r];
+
+  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+  const int per_img = tiles_x * tiles_y;
+  const int ntiles = B * per_img;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int b = tile / per_img, t2 = tile % per_img;
+    const int ty = (t2 / tiles_x) * TH, tx = (t2 % tiles_x) * TW;
+    __syncthreads();                                   // previous tile's window is consumed
+    for (int pix = threadIdx.x; pix < WR * WC; pix += 256) {
+      const int wy = pix / WC, wx = pix % WC;
+      const int yy = ty - 1 + wy, xx = tx - 1 + wx;
+      unsigned short v0 = 0, v1 = 0, v2 = 0;
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+        const int64_t p = ((int64_t)b * H + yy) * W + xx;
+        v0 = f32_to_bf16(img[3 * p] - a0);
+        v1 = f32_to_bf16(img[3 * p + 1] - a1);
+        v2 = f32_to_bf16(img[3 * p + 2] - a2);
+        if (wy >= 1 && wy <= TH && wx >= 1 && wx <= TW) {   // interior: this tile owns it
+          x0[3 * p] = v0;
+          x0[3 * p + 1] = v1;
+          x0[3 * p + 2] = v2;
+        }
+      }
+      *reinterpret_cast<uint2*>(lds + pix * F_PIX) =
+          make_uint2((unsigned)v0 | ((unsigned)v1 << 16), (unsigned)v2);
+    }
+    __syncthreads();
+
+    // wave w: tile rows 2w, 2w + 1 (two m-tiles of 32 pixels) x both n-tiles
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const unsigned short* base = lds + ((2 * wid + mt) * WC + r) * F_PIX;
+      f32x16 acc0 = zero16(), acc1 = zero16();
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        unsigned short v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = base[goff[ks][e]];
+        const u32x4 af = u32x4{(unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16),
+                               (unsigned)v[4] | ((unsigned)v[5] << 16), (unsigned)v[6] | ((unsigned)v[7] << 16)};
+        acc0 = mfma32b(af, wf[ks][0], acc0);
+        acc1 = mfma32b(af, wf[ks][1], acc1);
+      }
+      const int oy = ty + 2 * wid + mt;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const float bb = nt ? bias1 : bias0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          scr[acc_row(q, h) * SCR_LD + r] =
+              f32_to_bf16(fmaxf((nt ? acc1[q] : acc0[q]) + bb, 0.f));
+        __builtin_amdgcn_wave_barrier();
+        const int px = lane >> 1, hf = lane & 1;
+        const u32x4 v0 = *reinterpret_cast<const u32x4*>(scr + px * SCR_LD + 16 * hf);
+        const u32x4 v1 = *reinterpret_cast<const u32x4*>(scr + px * SCR_LD + 16 * hf + 8);
+        __builtin_amdgcn_wave_barrier();
+        const int ox = tx + px;
+        if (oy < H && ox < W) {
+          unsigned short* o = y + (((int64_t)b * H + oy) * W + ox) * C64 + 32 * nt + 16 * hf;
+          *reinterpret_cast<u32x4*>(o) = v0;
+          *reinterpret_cast<u32x4*>(o + 8) = v1;
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 static int conv64_cus();
@@ -552,4 +672,22 @@ extern "C" int scl_wrw64(const void* x, const void* gz, int B, int H, int W, voi
                          void* stream) {
   return scl_wrw3x3(x, gz, B, H, W, 64, 64, gw, w_stride_k, w_stride_c, w_stride_h, w_stride_w,
                     workspace, workspace_bytes, stream);
+}
+
+extern "C" int scl_conv_first(const float* img, const float* avg, const void* w, int64_t w_stride_k,
+                              int64_t w_stride_c, int64_t w_stride_h, int64_t w_stride_w,
+                              const float* bias, int B, int H, int W, void* x0, void* y,
+                              void* stream) {
+  if (!img || !avg || !w || !bias || !x0 || !y) return SCL_E_NULL;
+  if (B < 1 || H < 1 || W < 1 || (int64_t)B * H * W > (int64_t)1 << 30) return SCL_E_SHAPE;
+  if ((uintptr_t)y % 16) return SCL_E_SHAPE;
+  static std::once_flag once;
+  static int cus = 256;
+  std::call_once(once, [] { cus = conv64_cus(); });
+  const int tiles = B * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+  const int grid = tiles < 8 * cus ? tiles : 8 * cus;
+  SCL_LAUNCH("conv_first_kernel", conv_first_kernel, dim3(grid), dim3(256), kFirstLds,
+             (hipStream_t)stream, img, avg, (const unsigned short*)w, w_stride_k, w_stride_c,
+             w_stride_h, w_stride_w, bias, B, H, W, (unsigned short*)x0, (unsigned short*)y);
+  return scl_launch_status();
 }

@@ -97,6 +97,7 @@ _ONES = [1, 1]
 USE_CONV64 = os.environ.get('SCL_CONV64', '1') != '0'
 USE_CONVG = os.environ.get('SCL_CONVG', '1') != '0'
 USE_WRW = os.environ.get('SCL_WRW', '1') != '0'
+USE_FIRST = os.environ.get('SCL_FIRST', '1') != '0'
 _OWN_CONV_SHAPES = {(64, 64), (64, 128), (128, 64), (128, 128)}      # (contraction, output)
 
 
@@ -338,11 +339,26 @@ class _FirstConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img_nhwc, avg, w, bias, dtype):
         lib = L.load()
-        x0 = (img_nhwc - avg.to(img_nhwc.dtype)).to(dtype).permute(0, 3, 1, 2)
-        y = _conv3x3(x0, w).contiguous(memory_format=_CL)
-        b, c, h, wd = y.shape
-        L.check(lib.scl_vgg_bias_act(L.ptr(y), _glue_dtype(y), L.ptr(bias), b * h * wd, c, 1,
-                                     L.stream_of(y)))
+        if (USE_CONV64 and USE_FIRST and dtype == torch.bfloat16 and img_nhwc.is_cuda
+                and img_nhwc.dtype == torch.float32 and w.dtype == torch.bfloat16
+                and tuple(w.shape) == (64, 3, 3, 3)):
+            # mean subtraction, cast, convolution, bias and ReLU in one kernel
+            img = img_nhwc.contiguous()
+            b, h, wd, _ = img.shape
+            x0 = torch.empty((b, h, wd, 3), dtype=torch.bfloat16, device=img.device)
+            y = torch.empty((b, 64, h, wd), dtype=torch.bfloat16, device=img.device,
+                            memory_format=_CL)
+            sk, sc, sh, sw = w.stride()
+            L.check(lib.scl_conv_first(L.ptr(img), L.ptr(avg.float().contiguous()), L.ptr(w), sk, sc,
+                                       sh, sw, L.ptr(bias.float().contiguous()), b, h, wd,
+                                       L.ptr(x0), L.ptr(y), L.stream_of(img)))
+            x0 = x0.permute(0, 3, 1, 2)
+        else:
+            x0 = (img_nhwc - avg.to(img_nhwc.dtype)).to(dtype).permute(0, 3, 1, 2)
+            y = _conv3x3(x0, w).contiguous(memory_format=_CL)
+            b, c, h, wd = y.shape
+            L.check(lib.scl_vgg_bias_act(L.ptr(y), _glue_dtype(y), L.ptr(bias), b * h * wd, c, 1,
+                                         L.stream_of(y)))
         ctx.save_for_backward(x0, w, y)
         return y
 

@@ -273,3 +273,27 @@ def test_wrw_other_shapes(dev, cin, cout, shape):
     assert got.shape == wf.grad.shape and got.stride() == like.stride()
     assert float((got.float() - wf.grad).abs().max() / wf.grad.abs().max()) < 6e-3
     assert torch.equal(got, nets.wrw64(x, gz, like))
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 40), (1, 13, 37), (1, 480, 640)])
+def test_first_layer_kernel(dev, shape):
+    """scl_conv_first: mean subtraction + cast + conv1_1 + bias + ReLU in one pass."""
+    from soft_contrastive_learning_amd import _lib as L
+    b, h, w = shape
+    lib = L.load()
+    g = torch.Generator().manual_seed(31)
+    img = torch.randint(0, 256, (b, h, w, 3), generator=g).float().to(dev)
+    avg = torch.tensor([123.68, 116.78, 103.94], device=dev)
+    wt = (torch.randn(64, 3, 3, 3, generator=g) * 0.1).to(dev).bfloat16().contiguous(
+        memory_format=torch.channels_last)
+    bias = torch.randn(64, generator=g).to(dev)
+    x0 = torch.empty((b, h, w, 3), dtype=torch.bfloat16, device=dev)
+    y = torch.empty((b, 64, h, w), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
+    sk, sc, sh, sw = wt.stride()
+    L.check(lib.scl_conv_first(L.ptr(img), L.ptr(avg), L.ptr(wt), sk, sc, sh, sw, L.ptr(bias), b, h, w,
+                               L.ptr(x0), L.ptr(y), L.stream_of(img)))
+    want_x0 = (img - avg).bfloat16()
+    assert torch.equal(x0, want_x0)
+    want = torch.relu(torch.nn.functional.conv2d(want_x0.float().permute(0, 3, 1, 2), wt.float(),
+                                                 padding=1) + bias[None, :, None, None])
+    assert float((y.float() - want).abs().max()) < 6e-3 * float(want.abs().max())
