@@ -26,11 +26,14 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int BH = 12, BW = 40;                     // output block
-constexpr int GWR = BH + 2, GWC = BW + 2;           // halo window
+constexpr int GWR = BH + 2, GWC = BW + 4;           // halo window: 42 columns used, 44 staged —
+                                                    // with 80-byte pixels and the lane -> pixel
+                                                    // map below every ds_read_b128 service group
+                                                    // of an A fragment hits 16 different slots
 constexpr int CCH = 32;                             // channels per staged chunk
 constexpr int GPIX = CCH + 8;                       // bf16 per staged pixel / weight row (80 B)
-constexpr int GWIN = GWR * GWC * GPIX;              // bf16 per window buffer (23,520)
-constexpr int GWP = GWR * GWC * 4;                  // 16-byte pieces per window chunk (2352)
+constexpr int GWIN = GWR * GWC * GPIX;              // bf16 per window buffer (24,640)
+constexpr int GWP = GWR * GWC * 4;                  // 16-byte pieces per window chunk (2464)
 constexpr int GNPT = (GWP + 255) / 256;             // 10
 constexpr int NB = 128;                             // output channels per workgroup
 constexpr int GWT = NB * GPIX;                      // bf16 per weight buffer (5120)
@@ -39,6 +42,18 @@ constexpr int GSCR = 32 * GSCR_LD;
 constexpr int TPB = 2;                              // (chunk, tap) steps per barrier
 constexpr size_t kConvgLds = (2 * (size_t)GWIN + 2 * TPB * (size_t)GWT + 4 * (size_t)GSCR) * 2;
 constexpr int NMT = 15;                             // m-tiles: 3 rows x 5 cols of 4 x 8 pixels
+
+// Lane -> pixel of a 4 x 8 m-tile.  The hardware serves a ds_read_b128 in the lane groups
+// {0-3, 12-15, 20-27} and {4-11, 16-19, 28-31} (per 32-lane half); giving the first group the
+// tile rows 0 and 2 and the second the rows 1 and 3 makes (row * 44 + col) * 5 cover all 16
+// 16-byte slots within each group (PMC: SQ_LDS_BANK_CONFLICT was 58 % of the LDS cycles with
+// the plain row-major map).
+__device__ __forceinline__ int tile_row(int l) {
+  return l < 4 ? 0 : l < 12 ? 1 : l < 16 ? 0 : l < 20 ? 3 : l < 28 ? 2 : 3;
+}
+__device__ __forceinline__ int tile_col(int l) {
+  return l < 4 ? l : l < 12 ? l - 4 : l < 16 ? l - 8 : l < 20 ? l - 16 : l < 28 ? l - 20 : l - 24;
+}
 
 __device__ __forceinline__ f32x16 mfma32b(u32x4 a, u32x4 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
@@ -137,7 +152,7 @@ __global__ __launch_bounds__(256, 1) void convg_kernel(const unsigned short* __r
   // repeats tile 14 and is dropped in the epilogue) and output channels 64 ng .. + 63 (two
   // n-tiles): 16 accumulators, and per k-step 8 A + 2 B fragment reads for 16 MFMAs — the
   // split over BOTH dimensions halves the LDS operand traffic of an n-only split.
-  // lane (r, h): pixel (r >> 3, r & 7) of an m-tile, channels 8 h .. + 7 of a k-step
+  // lane (r, h): pixel (tile_row(r), tile_col(r)) of an m-tile, channels 8 h .. + 7 of a k-step
   const int mg = wid >> 1, ng = wid & 1;
   int aoff[8];
 #pragma unroll
@@ -145,7 +160,7 @@ __global__ __launch_bounds__(256, 1) void convg_kernel(const unsigned short* __r
     const int mt = 8 * mg + j < NMT ? 8 * mg + j : NMT - 1;
     aoff[j] = ((4 * (mt / 5)) * GWC + 8 * (mt % 5)) * GPIX;
   }
-  const int lane_a = ((r >> 3) * GWC + (r & 7)) * GPIX + 8 * h;
+  const int lane_a = (tile_row(r) * GWC + tile_col(r)) * GPIX + 8 * h;
   const int lane_b = (64 * ng + r) * GPIX + 8 * h;
   // S = 9 * CC is even (CC = cin / 32 is even for every supported shape): pairs of steps.
   // The window of chunk cc + 1 is loaded at tap 0 / 1 of chunk cc and stored four or five
@@ -224,7 +239,7 @@ __global__ __launch_bounds__(256, 1) void convg_kernel(const unsigned short* __r
       const u32x4 v0 = *reinterpret_cast<const u32x4*>(scr + px * GSCR_LD + 16 * hf);
       const u32x4 v1 = *reinterpret_cast<const u32x4*>(scr + px * GSCR_LD + 16 * hf + 8);
       __builtin_amdgcn_wave_barrier();
-      const int oy = y0 + 4 * mr + (px >> 3), ox = x0 + 8 * mc + (px & 7);
+      const int oy = y0 + 4 * mr + tile_row(px), ox = x0 + 8 * mc + tile_col(px);
       if (oy < H && ox < W) {
         unsigned short* o = out + (((int64_t)b * H + oy) * W + ox) * kout + NB * nb + 64 * ng +
                             32 * n + 16 * hf;
