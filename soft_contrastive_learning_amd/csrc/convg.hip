@@ -6,9 +6,9 @@
 // Implicit GEMM on v_mfma_f32_32x32x16_bf16 with a large M tile so that a staged weight chunk
 // is reused by many pixels:
 //   * workgroup = [12 rows x 40 cols] of output pixels (15 m-tiles of 4 x 8 pixels; 40
-//     divides the widths 160 / 80 / 40 of conv3_x .. conv5_x) x 128 output channels; wave
-//     (mg, ng) owns 8 of the m-tiles x 64 of the channels: 256 accumulators, and 10 LDS
-//     fragment reads per 16 MFMAs;
+//     divides the widths 160 / 80 / 40 of conv3_x .. conv5_x) x 128 output channels; eight
+//     waves, wave (mg, ng) owns 4 of the m-tiles x 64 of the channels: 128 accumulators, two
+//     waves per SIMD, 6 LDS fragment reads per 8 MFMAs;
 //   * K loop over (32-channel chunk, tap): the [14][42][32 ch] halo window of the chunk is
 //     staged once per chunk, the [128 k][32 c] weight slice once per (chunk, tap), both
 //     double-buffered in LDS behind register prefetches; one barrier per TWO (chunk, tap)
@@ -34,13 +34,14 @@ constexpr int CCH = 32;                             // channels per staged chunk
 constexpr int GPIX = CCH + 8;                       // bf16 per staged pixel / weight row (80 B)
 constexpr int GWIN = GWR * GWC * GPIX;              // bf16 per window buffer (24,640)
 constexpr int GWP = GWR * GWC * 4;                  // 16-byte pieces per window chunk (2464)
-constexpr int GNPT = (GWP + 255) / 256;             // 10
+constexpr int NTHR = 512;                           // 8 waves: two per SIMD
+constexpr int GNPT = (GWP + NTHR - 1) / NTHR;       // 5
 constexpr int NB = 128;                             // output channels per workgroup
 constexpr int GWT = NB * GPIX;                      // bf16 per weight buffer (5120)
 constexpr int GSCR_LD = 40;
 constexpr int GSCR = 32 * GSCR_LD;
 constexpr int TPB = 2;                              // (chunk, tap) steps per barrier
-constexpr size_t kConvgLds = (2 * (size_t)GWIN + 2 * TPB * (size_t)GWT + 4 * (size_t)GSCR) * 2;
+constexpr size_t kConvgLds = (2 * (size_t)GWIN + 2 * TPB * (size_t)GWT + 8 * (size_t)GSCR) * 2;
 constexpr int NMT = 15;                             // m-tiles: 3 rows x 5 cols of 4 x 8 pixels
 
 // Lane -> pixel of a 4 x 8 m-tile.  The hardware serves a ds_read_b128 in the lane groups
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void convg_pack_kernel(const unsigned short* _
 
 // grid (pixel blocks, kout / 128); block 256.  EPI: 0 plain, 1 + bias (+ ReLU).
 template <int EPI>
-__global__ __launch_bounds__(256, 1) void convg_kernel(const unsigned short* __restrict__ x,
+__global__ __launch_bounds__(NTHR, 1) void convg_kernel(const unsigned short* __restrict__ x,
                                                        const unsigned short* __restrict__ packed,
                                                        int B, int H, int W, int cin, int kout,
                                                        unsigned short* __restrict__ out,
@@ -102,25 +103,25 @@ __global__ __launch_bounds__(256, 1) void convg_kernel(const unsigned short* __r
   const int b = blockIdx.x / (blocks_x * blocks_y), t2 = blockIdx.x % (blocks_x * blocks_y);
   const int y0 = (t2 / blocks_x) * BH, x0 = (t2 % blocks_x) * BW;
   const int CC = cin / CCH, S = 9 * CC;
-  u32x4 st_w[2 * TPB], st_x[GNPT];
+  u32x4 st_w[TPB], st_x[GNPT];
   // weight slices of steps s, s + 1 (16 KB contiguous in the packed image)
   auto load_wts = [&](int s) {
     const unsigned short* src = packed + ((int64_t)nb * S + s) * (NB * CCH);
 #pragma unroll
-    for (int v = 0; v < 2 * TPB; ++v)
-      st_w[v] = *reinterpret_cast<const u32x4*>(src + (v * 256 + threadIdx.x) * 8);
+    for (int v = 0; v < TPB; ++v)
+      st_w[v] = *reinterpret_cast<const u32x4*>(src + (v * NTHR + threadIdx.x) * 8);
   };
   auto store_wts = [&](int buf) {
 #pragma unroll
-    for (int v = 0; v < 2 * TPB; ++v) {
-      const int idx = v * 256 + threadIdx.x;        // [step 2][k 128][4 pieces]
+    for (int v = 0; v < TPB; ++v) {
+      const int idx = v * NTHR + threadIdx.x;       // [step 2][k 128][4 pieces]
       *reinterpret_cast<u32x4*>(wts + buf * TPB * GWT + (idx >> 2) * GPIX + 8 * (idx & 3)) = st_w[v];
     }
   };
   auto load_win = [&](int cc) {
 #pragma unroll
     for (int v = 0; v < GNPT; ++v) {
-      const int idx = v * 256 + threadIdx.x;
+      const int idx = v * NTHR + threadIdx.x;
       const int pix = idx >> 2, c4 = idx & 3;
       const int y = y0 - 1 + pix / GWC, xx = x0 - 1 + pix % GWC;
       const bool ok = idx < GWP && y >= 0 && y < H && xx >= 0 && xx < W;
@@ -132,15 +133,15 @@ __global__ __launch_bounds__(256, 1) void convg_kernel(const unsigned short* __r
   auto store_win = [&](int buf) {
 #pragma unroll
     for (int v = 0; v < GNPT; ++v) {
-      const int idx = v * 256 + threadIdx.x;
+      const int idx = v * NTHR + threadIdx.x;
       if (idx < GWP)
         *reinterpret_cast<u32x4*>(win + buf * GWIN + (idx >> 2) * GPIX + 8 * (idx & 3)) = st_x[v];
     }
   };
 
-  f32x16 acc[16];                                     // [m-tile slot 8][n-tile 2]
+  f32x16 acc[8];                                      // [m-tile slot 4][n-tile 2]
 #pragma unroll
-  for (int mt = 0; mt < 16; ++mt) acc[mt] = zero16();
+  for (int mt = 0; mt < 8; ++mt) acc[mt] = zero16();
 
   load_win(0);
   load_wts(0);
@@ -148,16 +149,16 @@ __global__ __launch_bounds__(256, 1) void convg_kernel(const unsigned short* __r
   store_wts(0);
   __syncthreads();
 
-  // Wave (mg, ng) owns m-tiles 8 mg .. 8 mg + 7 (the block has 15: the last slot of mg = 1
-  // repeats tile 14 and is dropped in the epilogue) and output channels 64 ng .. + 63 (two
-  // n-tiles): 16 accumulators, and per k-step 8 A + 2 B fragment reads for 16 MFMAs — the
-  // split over BOTH dimensions halves the LDS operand traffic of an n-only split.
+  // Wave (mg, ng) of the 8 owns m-tiles 4 mg .. 4 mg + 3 (the block has 15: the last slot of
+  // mg = 3 repeats tile 14 and is dropped in the epilogue) and output channels 64 ng .. + 63
+  // (two n-tiles): 8 accumulators = 128 registers, so TWO waves share a SIMD and cover each
+  // other's LDS / barrier waits; per k-step 4 A + 2 B fragment reads for 8 MFMAs.
   // lane (r, h): pixel (tile_row(r), tile_col(r)) of an m-tile, channels 8 h .. + 7 of a k-step
   const int mg = wid >> 1, ng = wid & 1;
-  int aoff[8];
+  int aoff[4];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int mt = 8 * mg + j < NMT ? 8 * mg + j : NMT - 1;
+  for (int j = 0; j < 4; ++j) {
+    const int mt = 4 * mg + j < NMT ? 4 * mg + j : NMT - 1;
     aoff[j] = ((4 * (mt / 5)) * GWC + 8 * (mt % 5)) * GPIX;
   }
   const int lane_a = (tile_row(r) * GWC + tile_col(r)) * GPIX + 8 * h;
@@ -187,27 +188,24 @@ __global__ __launch_bounds__(256, 1) void convg_kernel(const unsigned short* __r
 #pragma unroll
         for (int n = 0; n < 2; ++n)
           bf[ks2][n] = *reinterpret_cast<const u32x4*>(wbp + (32 * n) * GPIX + 16 * ks2);
-      // 4 groups per tap: (k-step ks2, half of the wave's m-tiles); the A fragments of the
-      // next group fly under the 8 MFMAs of the current one
+      // 2 groups per tap (k-steps); the A fragments of the next group fly under the 8 MFMAs
+      // of the current one
       u32x4 af[2][4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) af[0][j] = *reinterpret_cast<const u32x4*>(wa + aoff[j]);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int ks2 = g >> 1, hm = g & 1;
-        if (g + 1 < 4) {
-          const int k3 = (g + 1) >> 1, h3 = (g + 1) & 1;
+      for (int ks2 = 0; ks2 < 2; ++ks2) {
+        if (ks2 == 0) {
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            af[(g + 1) & 1][j] =
-                *reinterpret_cast<const u32x4*>(wa + aoff[4 * h3 + j] + 16 * k3);
+            af[1][j] = *reinterpret_cast<const u32x4*>(wa + aoff[j] + 16);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
           for (int n = 0; n < 2; ++n)
-            acc[2 * (4 * hm + j) + n] = mfma32b(af[g & 1][j], bf[ks2][n], acc[2 * (4 * hm + j) + n]);
+            acc[2 * j + n] = mfma32b(af[ks2][j], bf[ks2][n], acc[2 * j + n]);
       }
     }
     if (s + TPB < S) store_wts(((s / TPB) + 1) & 1);
@@ -218,11 +216,11 @@ __global__ __launch_bounds__(256, 1) void convg_kernel(const unsigned short* __r
     __syncthreads();
   }
 
-  // epilogue: slot j <-> m-tile 8 mg + j, n <-> channels 64 ng + 32 n ..; accumulator register
+  // epilogue: slot j <-> m-tile 4 mg + j, n <-> channels 64 ng + 32 n ..; accumulator register
   // q <-> pixel acc_row(q, h) of the tile, lane r <-> channel r of the n-tile
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int mt = 8 * mg + j;
+  for (int j = 0; j < 4; ++j) {
+    const int mt = 4 * mg + j;
     if (mt >= NMT) break;                             // wave-uniform
     const int mr = mt / 5, mc = mt % 5;
 #pragma unroll
@@ -284,11 +282,11 @@ extern "C" int scl_convg(const void* x, const void* w, int64_t w_stride_k, int64
              transposed ? 1 : 0, cin, kout, packed);
   const dim3 grid(B * ((H + BH - 1) / BH) * ((W + BW - 1) / BW), kout / NB);
   if (bias)
-    SCL_LAUNCH("convg_kernel", convg_kernel<1>, grid, dim3(256), kConvgLds, st,
+    SCL_LAUNCH("convg_kernel", convg_kernel<1>, grid, dim3(NTHR), kConvgLds, st,
                (const unsigned short*)x, (const unsigned short*)packed, B, H, W, cin, kout,
                (unsigned short*)out, bias, relu ? 1 : 0);
   else
-    SCL_LAUNCH("convg_kernel", convg_kernel<0>, grid, dim3(256), kConvgLds, st,
+    SCL_LAUNCH("convg_kernel", convg_kernel<0>, grid, dim3(NTHR), kConvgLds, st,
                (const unsigned short*)x, (const unsigned short*)packed, B, H, W, cin, kout,
                (unsigned short*)out, bias, 0);
   return scl_launch_status();

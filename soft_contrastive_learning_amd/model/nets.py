@@ -117,12 +117,11 @@ def _own_conv_kind(x, w, transposed=False):
     return None
 
 
-def _lds_conv_pays(x, transposed, fused_tail=False):
+def _lds_conv_pays(x, transposed=False, fused_tail=False):
     """Measured on MI355X (scripts/conv_layers.py): the LDS-weights kernel beats the library on
-    the backward-data passes of conv3_x / conv4_x (870-950 vs 570-650 TFLOP/s); forward it
-    only ties (780-960 vs 770-970), so it pays there when it also absorbs the bias + ReLU pass
-    (43-86 us per layer); on maps too small to fill the chip (conv5_x: 30 x 40) it loses."""
-    return (transposed or fused_tail) and x.shape[2] * x.shape[3] >= 60 * 80
+    conv3_x / conv4_x — backward-data 930-1050 vs 550-650 TFLOP/s, forward 870-1030 vs
+    780-940 — but not on maps too small to fill the chip (conv5_x, 30 x 40: 72 pixel blocks)."""
+    return x.shape[2] * x.shape[3] >= 60 * 80
 
 
 def _conv64_ok(x, w, transposed=False):
@@ -190,7 +189,8 @@ def wrw64(x, gz, w_like):
 
 def _conv3x3(x, w):
     """3x3 / stride 1 / same-padding convolution without bias (MIOpen, or conv64)."""
-    if _own_conv_kind(x, w) == 'reg':
+    kind = _own_conv_kind(x, w)
+    if kind == 'reg' or (kind == 'lds' and _lds_conv_pays(x)):
         return conv64(x, w, False)
     return torch.ops.aten.convolution(x, w, None, _ONES, _ONES, _ONES, False, [0, 0], 1)
 
