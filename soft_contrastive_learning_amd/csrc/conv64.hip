@@ -265,7 +265,7 @@ __device__ __forceinline__ u32x4 tr_pair(const unsigned short* a0, int step4) {
 
 // grid (pixel splits P, C / 64, K / 64): workgroup (p, cb, kb) accumulates the [9][64][64]
 // block (input channels 64 cb .., output channels 64 kb ..) over the tiles p, p + P, ...
-__global__ __launch_bounds__(256, 1) void wrw64_kernel(const unsigned short* __restrict__ x,
+__global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __restrict__ x,
                                                        const unsigned short* __restrict__ gz,
                                                        int B, int H, int W, int C, int K,
                                                        float* __restrict__ slabs) {
@@ -273,7 +273,9 @@ __global__ __launch_bounds__(256, 1) void wrw64_kernel(const unsigned short* __r
   unsigned short* gl = lds + WIN;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int mt = wid & 1, nt = wid >> 1;
+  // eight waves, two per SIMD: wave (mt, nt, ph) accumulates block (mt, nt) over the steps
+  // of tile rows 4 ph .. 4 ph + 3; the two pixel halves write separate slabs
+  const int mt = wid & 1, nt = (wid >> 1) & 1, ph = wid >> 2;
   // transposed-read role of this lane: 16-lane group gq = lane >> 4 covers channels
   // 16 (gq & 1) .. + 15 and pixels 8 (gq >> 1) + q (+ 4); lane 4q + p addresses row q,
   // columns 4p .. 4p + 3
@@ -284,13 +286,14 @@ __global__ __launch_bounds__(256, 1) void wrw64_kernel(const unsigned short* __r
   const int per_img = tiles_x * tiles_y;
   const int ntiles = B * per_img;
 
-  u32x4 st_x[NPT], st_g[GPIECES / 256];
+  constexpr int XPT = (PIECES + 511) / 512, GPT = GPIECES / 512;
+  u32x4 st_x[XPT], st_g[GPT];
   auto stage_load = [&](int tile) {
     const int b = tile / per_img, t2 = tile % per_img;
     const int ty = (t2 / tiles_x) * TH, tx = (t2 % tiles_x) * TW;
 #pragma unroll
-    for (int v = 0; v < NPT; ++v) {
-      const int idx = v * 256 + threadIdx.x;
+    for (int v = 0; v < XPT; ++v) {
+      const int idx = v * 512 + threadIdx.x;
       const int pix = idx >> 3, c = idx & 7;
       const int y = ty - 1 + pix / WC, xx = tx - 1 + pix % WC;
       const bool ok = idx < PIECES && y >= 0 && y < H && xx >= 0 && xx < W;
@@ -299,8 +302,8 @@ __global__ __launch_bounds__(256, 1) void wrw64_kernel(const unsigned short* __r
                    : u32x4{0u, 0u, 0u, 0u};
     }
 #pragma unroll
-    for (int v = 0; v < GPIECES / 256; ++v) {
-      const int idx = v * 256 + threadIdx.x;
+    for (int v = 0; v < GPT; ++v) {
+      const int idx = v * 512 + threadIdx.x;
       const int pix = idx >> 3, c = idx & 7;
       const int y = ty + pix / TW, xx = tx + pix % TW;
       const bool ok = y < H && xx < W;
@@ -311,14 +314,14 @@ __global__ __launch_bounds__(256, 1) void wrw64_kernel(const unsigned short* __r
   };
   auto stage_store = [&]() {
 #pragma unroll
-    for (int v = 0; v < NPT; ++v) {
-      const int idx = v * 256 + threadIdx.x;
+    for (int v = 0; v < XPT; ++v) {
+      const int idx = v * 512 + threadIdx.x;
       if (idx < PIECES)
         *reinterpret_cast<u32x4*>(lds + (idx >> 3) * PIX_LD + 8 * (idx & 7)) = st_x[v];
     }
 #pragma unroll
-    for (int v = 0; v < GPIECES / 256; ++v) {
-      const int idx = v * 256 + threadIdx.x;
+    for (int v = 0; v < GPT; ++v) {
+      const int idx = v * 512 + threadIdx.x;
       *reinterpret_cast<u32x4*>(gl + (idx >> 3) * PIX_LD + 8 * (idx & 7)) = st_g[v];
     }
   };
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(256, 1) void wrw64_kernel(const unsigned short* __r
     const int next = tile + gridDim.x;
     if (next < ntiles) stage_load(next);
 #pragma unroll 1
-    for (int step = 0; step < 2 * TH; ++step) {
+    for (int step = TH * ph; step < TH * ph + TH; ++step) {
       const int ry = step >> 1, cx = 16 * (step & 1);
       // B: gz pixels (ry, cx + 8h .. + 7) x output channels 32 nt ..
       const u32x4 bf = tr_pair(gl + (ry * TW + cx + pix0) * PIX_LD + 32 * nt + ch0, 4 * PIX_LD);
@@ -360,10 +363,10 @@ __global__ __launch_bounds__(256, 1) void wrw64_kernel(const unsigned short* __r
     __syncthreads();
   }
 
-  // slab[p][cb][kb][tap][c][k]: accumulator register qq <-> c = 32 mt + acc_row(qq, h),
+  // slab[2 p + ph][cb][kb][tap][c][k]: accumulator register qq <-> c = 32 mt + acc_row(qq, h),
   // lane r <-> k
-  float* out = slabs + (((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * gridDim.z + blockIdx.z) *
-                           9 * C64 * C64;
+  float* out = slabs + (((int64_t)(2 * blockIdx.x + ph) * gridDim.y + blockIdx.y) * gridDim.z +
+                        blockIdx.z) * 9 * C64 * C64;
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -631,7 +634,7 @@ extern "C" size_t scl_wrw3x3_workspace_bytes(int cin, int kout) {
   // slabs: at most (1024 CUs rounded up to whole (cb, kb) block sets) x 147,456 B
   const size_t blocks = (size_t)(cin / 64) * (kout / 64);
   const size_t p = (1024 + blocks - 1) / blocks;
-  return scl_round256(p * blocks * 9 * 64 * 64 * sizeof(float));
+  return scl_round256(2 * p * blocks * 9 * 64 * 64 * sizeof(float));   // two slabs per workgroup
 }
 
 extern "C" int scl_wrw3x3(const void* x, const void* gz, int B, int H, int W, int cin, int kout,
@@ -655,11 +658,11 @@ extern "C" int scl_wrw3x3(const void* x, const void* gz, int B, int H, int W, in
   const int tiles = B * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
   const int P = wrw_splits(cin, kout, tiles, cus);
   hipStream_t st = (hipStream_t)stream;
-  SCL_LAUNCH("wrw64_kernel", wrw64_kernel, dim3(P, cin / 64, kout / 64), dim3(256), kWrw64Lds, st,
+  SCL_LAUNCH("wrw64_kernel", wrw64_kernel, dim3(P, cin / 64, kout / 64), dim3(512), kWrw64Lds, st,
              (const unsigned short*)x, (const unsigned short*)gz, B, H, W, cin, kout,
              (float*)workspace);
   SCL_LAUNCH("wrw64_reduce_kernel", wrw64_reduce_kernel, dim3(9 * 64 * 64 / 64, (cin / 64) * (kout / 64)),
-             dim3(256), 0, st, (const float*)workspace, P, kout / 64, w_stride_k, w_stride_c,
+             dim3(256), 0, st, (const float*)workspace, 2 * P, kout / 64, w_stride_k, w_stride_c,
              w_stride_h, w_stride_w, (unsigned short*)gw);
   return scl_launch_status();
 }

@@ -196,9 +196,9 @@ def _conv3x3(x, w):
 
 
 def _wrw_pays(x):
-    """scripts/conv_layers.py: own 760-880 vs library 370-750 TFLOP/s down to 120 x 160 maps
-    (conv1_2 .. conv3_x); a tie at 60 x 80 and a loss at 30 x 40 (ragged 8 x 32 tiles)."""
-    return x.shape[2] * x.shape[3] >= 120 * 160
+    """scripts/conv_layers.py: own 850-1010 vs library 370-750 TFLOP/s down to 60 x 80 maps
+    (conv1_2 .. conv4_x); a loss at 30 x 40 (ragged 8 x 32 tiles, too few of them)."""
+    return x.shape[2] * x.shape[3] >= 60 * 80
 
 
 def _conv3x3_backward(gz, x, w, need_x):
