@@ -56,13 +56,18 @@ struct ConvCfg {
   static constexpr int WIN_ = WR_ * WC * PIX;          // bf16 per window buffer
   static constexpr int PPP = CIN / 8;                  // 16-byte pieces per pixel
   static constexpr int PIECES_ = WR_ * WC * PPP;
-  static constexpr int NPT_ = (PIECES_ + 255) / 256;
+  // (64, 64) runs eight waves (two per SIMD: 144 weight + 32 accumulator registers fit 256),
+  // the other shapes four (their register budget needs occupancy 1)
+  static constexpr int WAVES = (CIN == 64 && KOUT == 64) ? 8 : 4;
+  static constexpr int NTHR = 64 * WAVES;
+  static constexpr int NPT_ = (PIECES_ + NTHR - 1) / NTHR;
   static constexpr int SPT = CIN / 16;                 // k-steps per tap
   static constexpr int KS = 9 * SPT;                   // 36 or 72
   static constexpr int NT = KOUT / 32;                 // n-tiles: 2 or 4
-  static constexpr int PARTS = 4 / NT;                 // row groups of the tile: 2 or 1
+  static constexpr int PARTS = WAVES / NT;             // row groups of the tile: 4, 2 or 1
   static constexpr int MT = TH_ / PARTS;               // tile rows per wave
-  static constexpr size_t LDS = (2 * (size_t)WIN_ + 4 * (size_t)SCR) * sizeof(unsigned short);
+  static constexpr size_t LDS =
+      (2 * (size_t)WIN_ + WAVES * (size_t)SCR) * sizeof(unsigned short);
 };
 
 // Weights -> register image [nt][ks][lane 64][8 bf16].
@@ -93,7 +98,7 @@ __global__ __launch_bounds__(256) void conv3x3_pack_kernel(const unsigned short*
 // grid = number of CUs (persistent); block 256.  EPI (compile-time, so that the plain kernel
 // keeps its register allocation): 0 plain, 1 + bias (+ ReLU), 2 raw + pooled output.
 template <int CIN, int KOUT, int EPI>
-__global__ __launch_bounds__(256, 1) void conv3x3_kernel(const unsigned short* __restrict__ x,
+__global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(const unsigned short* __restrict__ x,
                                                          const unsigned short* __restrict__ packed,
                                                          int B, int H, int W,
                                                          unsigned short* __restrict__ out,
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(const unsigned short* _
     const int y0 = (t2 / tiles_x) * TH_ - 1, x0 = (t2 % tiles_x) * TW - 1;
 #pragma unroll
     for (int v = 0; v < Cfg::NPT_; ++v) {
-      const int idx = v * 256 + threadIdx.x;
+      const int idx = v * Cfg::NTHR + threadIdx.x;
       const int pix = idx / Cfg::PPP, c = idx % Cfg::PPP;
       const int wy = pix / WC, wx = pix % WC;
       const int y = y0 + wy, xx = x0 + wx;
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(const unsigned short* _
   auto stage_store = [&](int buf) {
 #pragma unroll
     for (int v = 0; v < Cfg::NPT_; ++v) {
-      const int idx = v * 256 + threadIdx.x;
+      const int idx = v * Cfg::NTHR + threadIdx.x;
       if (idx < Cfg::PIECES_)
         *reinterpret_cast<u32x4*>(lds + buf * WIN_ + (idx / Cfg::PPP) * PIX + 8 * (idx % Cfg::PPP)) =
             st[v];
@@ -551,15 +556,15 @@ int launch_conv3x3(const void* x, const void* w, int64_t sk, int64_t sc, int64_t
   const int tiles = B * ((H + Cfg::TH_ - 1) / Cfg::TH_) * ((W + TW - 1) / TW);
   const dim3 grid(tiles < cus ? tiles : cus);
   if (pooled)
-    SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 2>), grid, dim3(256), Cfg::LDS, st,
+    SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 2>), grid, dim3(Cfg::NTHR), Cfg::LDS, st,
                (const unsigned short*)x, (const unsigned short*)packed, B, H, W,
                (unsigned short*)out, bias, relu, (unsigned short*)pooled);
   else if (bias)
-    SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 1>), grid, dim3(256), Cfg::LDS, st,
+    SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 1>), grid, dim3(Cfg::NTHR), Cfg::LDS, st,
                (const unsigned short*)x, (const unsigned short*)packed, B, H, W,
                (unsigned short*)out, bias, relu, (unsigned short*)pooled);
   else
-    SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 0>), grid, dim3(256), Cfg::LDS, st,
+    SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 0>), grid, dim3(Cfg::NTHR), Cfg::LDS, st,
                (const unsigned short*)x, (const unsigned short*)packed, B, H, W,
                (unsigned short*)out, bias, relu, (unsigned short*)pooled);
   return scl_launch_status();
