@@ -273,6 +273,20 @@ int scl_convg(const void* x, const void* w, int64_t w_stride_k, int64_t w_stride
               int cin, int kout, void* out, const float* bias, int relu, void* workspace,
               size_t workspace_bytes, void* stream);
 
+/* Backward-data with the ReLU' of the layer below in the epilogue (the backward of
+ * model/nets.py:39's relu chained to the conv beneath it): out = conv(x, w) * [mask > 0],
+ * mask [B,H,W,kout] bf16 the post-activation map the gradient flows into — saves the separate
+ * read-modify-write pass over the gradient map.  scl_conv3x3_masked takes the shapes of
+ * scl_conv3x3, scl_convg_masked those of scl_convg; workspaces as for those. */
+int scl_conv3x3_masked(const void* x, const void* w, int64_t w_stride_k, int64_t w_stride_c,
+                       int64_t w_stride_h, int64_t w_stride_w, int transposed, int B, int H,
+                       int W, int cin, int kout, void* out, const void* mask, void* workspace,
+                       size_t workspace_bytes, void* stream);
+int scl_convg_masked(const void* x, const void* w, int64_t w_stride_k, int64_t w_stride_c,
+                     int64_t w_stride_h, int64_t w_stride_w, int transposed, int B, int H, int W,
+                     int cin, int kout, void* out, const void* mask, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
 /* The first layer in one pass (model/nets.py:22-24, 39): x0 = bf16(img - average_rgb),
  * y = relu(conv3x3(x0, w) + bias).  img [B,H,W,3] float32 (raw 0..255), avg [3], w bf16 logical
  * [64][3][3][3] at the given element strides, bias float32 [64]; x0 [B,H,W,3] bf16 (kept for the

@@ -65,6 +65,8 @@ SIGNATURES = {
     "scl_conv3x3_fused": (_i, [_p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p, _p,
                                _z, _p]),
     "scl_convg_workspace_bytes": (_z, [_i, _i]),
+    "scl_conv3x3_masked": (_i, [_p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _p, _p, _p, _z, _p]),
+    "scl_convg_masked": (_i, [_p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _p, _p, _p, _z, _p]),
     "scl_convg": (_i, [_p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p, _z, _p]),
     "scl_wrw64_workspace_bytes": (_z, []),
     "scl_wrw64": (_i, [_p, _p, _i, _i, _i, _p, _l, _l, _l, _l, _p, _z, _p]),

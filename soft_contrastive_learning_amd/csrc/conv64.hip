@@ -96,14 +96,16 @@ __global__ __launch_bounds__(256) void conv3x3_pack_kernel(const unsigned short*
 }
 
 // grid = number of CUs (persistent); block 256.  EPI (compile-time, so that the plain kernel
-// keeps its register allocation): 0 plain, 1 + bias (+ ReLU), 2 raw + pooled output.
+// keeps its register allocation): 0 plain, 1 + bias (+ ReLU), 2 raw + pooled output,
+// 3 out = conv * [mask > 0] (the ReLU' of the layer below, for backward-data).
 template <int CIN, int KOUT, int EPI>
 __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(const unsigned short* __restrict__ x,
                                                          const unsigned short* __restrict__ packed,
                                                          int B, int H, int W,
                                                          unsigned short* __restrict__ out,
                                                          const float* __restrict__ bias, int relu,
-                                                         unsigned short* __restrict__ pooled) {
+                                                         unsigned short* __restrict__ pooled,
+                                                         const unsigned short* __restrict__ mask) {
   using Cfg = ConvCfg<CIN, KOUT>;
   constexpr int TH_ = Cfg::TH_, PIX = Cfg::PIX, WIN_ = Cfg::WIN_, KS = Cfg::KS, MT = Cfg::MT;
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
@@ -114,7 +116,7 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
   // epilogue fusions (lane r <-> output channel 32 nt + r):
   //   pooled == NULL: out = acc (+ bias) (ReLU if relu)            conv + bias + activation
   //   pooled != NULL: out = acc raw, pooled = relu(max2x2(acc) + bias)   conv + pool + ReLU
-  const float bias_r = EPI != 0 ? bias[32 * nt + r] : 0.f;
+  const float bias_r = (EPI == 1 || EPI == 2) ? bias[32 * nt + r] : 0.f;
   const float add_r = EPI == 1 ? bias_r : 0.f;
 
   // the wave's weight slice: KS fragments of 16 bytes per lane
@@ -194,6 +196,16 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
     const int oy0 = (t2 / tiles_x) * TH_ + MT * part, ox0 = (t2 % tiles_x) * TW;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
+      // 32 pixels x 64 bytes: lane -> pixel lane >> 1, 32-byte half lane & 1
+      const int px = lane >> 1, hf = lane & 1;
+      const int oy = oy0 + mt, ox = ox0 + px;
+      const bool inside = oy < H && ox < W;
+      const int64_t o_off = (((int64_t)b * H + oy) * W + ox) * KOUT + 32 * nt + 16 * hf;
+      u32x4 y0v = u32x4{0u, 0u, 0u, 0u}, y1v = y0v;
+      if (EPI == 3 && inside) {                          // in flight under the transpose
+        y0v = *reinterpret_cast<const u32x4*>(mask + o_off);
+        y1v = *reinterpret_cast<const u32x4*>(mask + o_off + 8);
+      }
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         float v = acc[mt][q] + add_r;
@@ -201,16 +213,16 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
         scr[acc_row(q, h) * SCR_LD + r] = f32_to_bf16(v);
       }
       __builtin_amdgcn_wave_barrier();
-      // 32 pixels x 64 bytes: lane -> pixel lane >> 1, 32-byte half lane & 1
-      const int px = lane >> 1, hf = lane & 1;
-      const u32x4 v0 = *reinterpret_cast<const u32x4*>(scr + px * SCR_LD + 16 * hf);
-      const u32x4 v1 = *reinterpret_cast<const u32x4*>(scr + px * SCR_LD + 16 * hf + 8);
+      u32x4 v0 = *reinterpret_cast<const u32x4*>(scr + px * SCR_LD + 16 * hf);
+      u32x4 v1 = *reinterpret_cast<const u32x4*>(scr + px * SCR_LD + 16 * hf + 8);
       __builtin_amdgcn_wave_barrier();
-      const int oy = oy0 + mt, ox = ox0 + px;
-      if (oy < H && ox < W) {
-        unsigned short* o = out + (((int64_t)b * H + oy) * W + ox) * KOUT + 32 * nt + 16 * hf;
-        *reinterpret_cast<u32x4*>(o) = v0;
-        *reinterpret_cast<u32x4*>(o + 8) = v1;
+      if (EPI == 3) {
+        v0 = relu_mask(v0, y0v);
+        v1 = relu_mask(v1, y1v);
+      }
+      if (inside) {
+        *reinterpret_cast<u32x4*>(out + o_off) = v0;
+        *reinterpret_cast<u32x4*>(out + o_off + 8) = v1;
       }
     }
     if (EPI == 2) {
@@ -536,7 +548,7 @@ static int conv64_cus();
 template <int CIN, int KOUT>
 int launch_conv3x3(const void* x, const void* w, int64_t sk, int64_t sc, int64_t sh, int64_t sw,
                    int transposed, int B, int H, int W, void* out, const float* bias, int relu,
-                   void* pooled, void* workspace, hipStream_t st) {
+                   void* pooled, const void* mask, void* workspace, hipStream_t st) {
   using Cfg = ConvCfg<CIN, KOUT>;
   static std::once_flag once;
   static int cus = 256;
@@ -547,6 +559,8 @@ int launch_conv3x3(const void* x, const void* w, int64_t sk, int64_t sc, int64_t
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<CIN, KOUT, 2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<CIN, KOUT, 3>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
     cus = conv64_cus();
   });
   unsigned short* packed = (unsigned short*)workspace;
@@ -555,18 +569,26 @@ int launch_conv3x3(const void* x, const void* w, int64_t sk, int64_t sc, int64_t
              sh, sw, transposed ? 1 : 0, packed);
   const int tiles = B * ((H + Cfg::TH_ - 1) / Cfg::TH_) * ((W + TW - 1) / TW);
   const dim3 grid(tiles < cus ? tiles : cus);
-  if (pooled)
+  if (mask)
+    SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 3>), grid, dim3(Cfg::NTHR), Cfg::LDS, st,
+               (const unsigned short*)x, (const unsigned short*)packed, B, H, W,
+               (unsigned short*)out, bias, 0, (unsigned short*)nullptr,
+               (const unsigned short*)mask);
+  else if (pooled)
     SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 2>), grid, dim3(Cfg::NTHR), Cfg::LDS, st,
                (const unsigned short*)x, (const unsigned short*)packed, B, H, W,
-               (unsigned short*)out, bias, relu, (unsigned short*)pooled);
+               (unsigned short*)out, bias, relu, (unsigned short*)pooled,
+               (const unsigned short*)nullptr);
   else if (bias)
     SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 1>), grid, dim3(Cfg::NTHR), Cfg::LDS, st,
                (const unsigned short*)x, (const unsigned short*)packed, B, H, W,
-               (unsigned short*)out, bias, relu, (unsigned short*)pooled);
+               (unsigned short*)out, bias, relu, (unsigned short*)pooled,
+               (const unsigned short*)nullptr);
   else
     SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 0>), grid, dim3(Cfg::NTHR), Cfg::LDS, st,
                (const unsigned short*)x, (const unsigned short*)packed, B, H, W,
-               (unsigned short*)out, bias, relu, (unsigned short*)pooled);
+               (unsigned short*)out, bias, relu, (unsigned short*)pooled,
+               (const unsigned short*)nullptr);
   return scl_launch_status();
 }
 
@@ -574,12 +596,13 @@ extern "C" size_t scl_conv3x3_workspace_bytes(void) {
   return scl_round256((size_t)4 * 72 * 512 * sizeof(unsigned short));   // largest packed image
 }
 
-extern "C" int scl_conv3x3_fused(const void* x, const void* w, int64_t w_stride_k,
-                                 int64_t w_stride_c, int64_t w_stride_h, int64_t w_stride_w,
-                                 int transposed, int B, int H, int W, int cin, int kout,
-                                 void* out, const float* bias, int relu, void* pooled,
-                                 void* workspace, size_t workspace_bytes, void* stream) {
+static int conv3x3_dispatch(const void* x, const void* w, int64_t w_stride_k, int64_t w_stride_c,
+                            int64_t w_stride_h, int64_t w_stride_w, int transposed, int B, int H,
+                            int W, int cin, int kout, void* out, const float* bias, int relu,
+                            void* pooled, const void* mask, void* workspace,
+                            size_t workspace_bytes, void* stream) {
   if (!x || !w || !out || !workspace) return SCL_E_NULL;
+  if (mask && (bias || pooled || ((uintptr_t)mask % 16))) return SCL_E_NULL;
   if (pooled && (!bias || ((uintptr_t)pooled % 16))) return SCL_E_NULL;
   if (B < 1 || H < 1 || W < 1 || (int64_t)B * H * W > (int64_t)1 << 30) return SCL_E_SHAPE;
   if (((uintptr_t)x % 16) || ((uintptr_t)out % 16)) return SCL_E_SHAPE;
@@ -590,13 +613,34 @@ extern "C" int scl_conv3x3_fused(const void* x, const void* w, int64_t w_stride_
   if (cin == CI && kout == KO)                                                                 \
     return launch_conv3x3<CI, KO>(x, w, w_stride_k, w_stride_c, w_stride_h, w_stride_w,        \
                                   transposed, B, H, W, out, bias, relu ? 1 : 0, pooled,        \
-                                  workspace, st);
+                                  mask, workspace, st);
   SCL_CONV_CASE(64, 64)
   SCL_CONV_CASE(64, 128)
   SCL_CONV_CASE(128, 64)
   SCL_CONV_CASE(128, 128)
 #undef SCL_CONV_CASE
   return SCL_E_SHAPE;
+}
+
+extern "C" int scl_conv3x3_fused(const void* x, const void* w, int64_t w_stride_k,
+                                 int64_t w_stride_c, int64_t w_stride_h, int64_t w_stride_w,
+                                 int transposed, int B, int H, int W, int cin, int kout,
+                                 void* out, const float* bias, int relu, void* pooled,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+  return conv3x3_dispatch(x, w, w_stride_k, w_stride_c, w_stride_h, w_stride_w, transposed, B, H,
+                          W, cin, kout, out, bias, relu, pooled, nullptr, workspace,
+                          workspace_bytes, stream);
+}
+
+extern "C" int scl_conv3x3_masked(const void* x, const void* w, int64_t w_stride_k,
+                                  int64_t w_stride_c, int64_t w_stride_h, int64_t w_stride_w,
+                                  int transposed, int B, int H, int W, int cin, int kout,
+                                  void* out, const void* mask, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  if (!mask) return SCL_E_NULL;
+  return conv3x3_dispatch(x, w, w_stride_k, w_stride_c, w_stride_h, w_stride_w, transposed, B, H,
+                          W, cin, kout, out, nullptr, 0, nullptr, mask, workspace,
+                          workspace_bytes, stream);
 }
 
 extern "C" int scl_conv3x3(const void* x, const void* w, int64_t w_stride_k, int64_t w_stride_c,

@@ -85,13 +85,15 @@ __global__ __launch_bounds__(256) void convg_pack_kernel(const unsigned short* _
   packed[idx] = w[off];
 }
 
-// grid (pixel blocks, kout / 128); block 256.  EPI: 0 plain, 1 + bias (+ ReLU).
+// grid (pixel blocks, kout / 128); block 512.  EPI: 0 plain, 1 + bias (+ ReLU),
+// 2 out = conv * [mask > 0] (the ReLU' of the layer below, for backward-data).
 template <int EPI>
 __global__ __launch_bounds__(NTHR, 1) void convg_kernel(const unsigned short* __restrict__ x,
                                                        const unsigned short* __restrict__ packed,
                                                        int B, int H, int W, int cin, int kout,
                                                        unsigned short* __restrict__ out,
-                                                       const float* __restrict__ bias, int relu) {
+                                                       const float* __restrict__ bias, int relu,
+                                                       const unsigned short* __restrict__ mask) {
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
   unsigned short* win = lds;
   unsigned short* wts = lds + 2 * GWIN;
@@ -226,6 +228,16 @@ __global__ __launch_bounds__(NTHR, 1) void convg_kernel(const unsigned short* __
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
       const float bias_r = EPI == 1 ? bias[NB * nb + 64 * ng + 32 * n + r] : 0.f;
+      const int px = lane >> 1, hf = lane & 1;
+      const int oy = y0 + 4 * mr + tile_row(px), ox = x0 + 8 * mc + tile_col(px);
+      const bool inside = oy < H && ox < W;
+      const int64_t o_off =
+          (((int64_t)b * H + oy) * W + ox) * kout + NB * nb + 64 * ng + 32 * n + 16 * hf;
+      u32x4 y0v = u32x4{0u, 0u, 0u, 0u}, y1v = y0v;
+      if (EPI == 2 && inside) {                          // in flight under the transpose
+        y0v = *reinterpret_cast<const u32x4*>(mask + o_off);
+        y1v = *reinterpret_cast<const u32x4*>(mask + o_off + 8);
+      }
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         float v = acc[2 * j + n][q] + bias_r;
@@ -233,16 +245,16 @@ __global__ __launch_bounds__(NTHR, 1) void convg_kernel(const unsigned short* __
         scr[acc_row(q, h) * GSCR_LD + r] = f32_to_bf16(v);
       }
       __builtin_amdgcn_wave_barrier();
-      const int px = lane >> 1, hf = lane & 1;
-      const u32x4 v0 = *reinterpret_cast<const u32x4*>(scr + px * GSCR_LD + 16 * hf);
-      const u32x4 v1 = *reinterpret_cast<const u32x4*>(scr + px * GSCR_LD + 16 * hf + 8);
+      u32x4 v0 = *reinterpret_cast<const u32x4*>(scr + px * GSCR_LD + 16 * hf);
+      u32x4 v1 = *reinterpret_cast<const u32x4*>(scr + px * GSCR_LD + 16 * hf + 8);
       __builtin_amdgcn_wave_barrier();
-      const int oy = y0 + 4 * mr + tile_row(px), ox = x0 + 8 * mc + tile_col(px);
-      if (oy < H && ox < W) {
-        unsigned short* o = out + (((int64_t)b * H + oy) * W + ox) * kout + NB * nb + 64 * ng +
-                            32 * n + 16 * hf;
-        *reinterpret_cast<u32x4*>(o) = v0;
-        *reinterpret_cast<u32x4*>(o + 8) = v1;
+      if (EPI == 2) {
+        v0 = relu_mask(v0, y0v);
+        v1 = relu_mask(v1, y1v);
+      }
+      if (inside) {
+        *reinterpret_cast<u32x4*>(out + o_off) = v0;
+        *reinterpret_cast<u32x4*>(out + o_off + 8) = v1;
       }
     }
   }
@@ -255,13 +267,15 @@ extern "C" size_t scl_convg_workspace_bytes(int cin, int kout) {
   return scl_round256((size_t)9 * cin * kout * sizeof(unsigned short));
 }
 
-// Same contract as scl_conv3x3_fused (include/scl_hip.h) without the pooled output, for
-// cin % 32 == 0 and kout % 128 == 0.
-extern "C" int scl_convg(const void* x, const void* w, int64_t w_stride_k, int64_t w_stride_c,
-                         int64_t w_stride_h, int64_t w_stride_w, int transposed, int B, int H,
-                         int W, int cin, int kout, void* out, const float* bias, int relu,
-                         void* workspace, size_t workspace_bytes, void* stream) {
+// Same contract as scl_conv3x3_fused / scl_conv3x3_masked (include/scl_hip.h) without the
+// pooled output, for cin % 32 == 0 and kout % 128 == 0.
+static int convg_dispatch(const void* x, const void* w, int64_t w_stride_k, int64_t w_stride_c,
+                          int64_t w_stride_h, int64_t w_stride_w, int transposed, int B, int H,
+                          int W, int cin, int kout, void* out, const float* bias, int relu,
+                          const void* mask, void* workspace, size_t workspace_bytes,
+                          void* stream) {
   if (!x || !w || !out || !workspace) return SCL_E_NULL;
+  if (mask && (bias || ((uintptr_t)mask % 16))) return SCL_E_NULL;
   const size_t need = scl_convg_workspace_bytes(cin, kout);
   if (need == 0 || B < 1 || H < 1 || W < 1 || (int64_t)B * H * W > (int64_t)1 << 30)
     return SCL_E_SHAPE;
@@ -273,6 +287,8 @@ extern "C" int scl_convg(const void* x, const void* w, int64_t w_stride_k, int64
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kConvgLds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convg_kernel<1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kConvgLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convg_kernel<2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kConvgLds);
   });
   hipStream_t st = (hipStream_t)stream;
   unsigned short* packed = (unsigned short*)workspace;
@@ -281,13 +297,35 @@ extern "C" int scl_convg(const void* x, const void* w, int64_t w_stride_k, int64
              0, st, (const unsigned short*)w, w_stride_k, w_stride_c, w_stride_h, w_stride_w,
              transposed ? 1 : 0, cin, kout, packed);
   const dim3 grid(B * ((H + BH - 1) / BH) * ((W + BW - 1) / BW), kout / NB);
-  if (bias)
+  if (mask)
+    SCL_LAUNCH("convg_kernel", convg_kernel<2>, grid, dim3(NTHR), kConvgLds, st,
+               (const unsigned short*)x, (const unsigned short*)packed, B, H, W, cin, kout,
+               (unsigned short*)out, bias, 0, (const unsigned short*)mask);
+  else if (bias)
     SCL_LAUNCH("convg_kernel", convg_kernel<1>, grid, dim3(NTHR), kConvgLds, st,
                (const unsigned short*)x, (const unsigned short*)packed, B, H, W, cin, kout,
-               (unsigned short*)out, bias, relu ? 1 : 0);
+               (unsigned short*)out, bias, relu ? 1 : 0, (const unsigned short*)nullptr);
   else
     SCL_LAUNCH("convg_kernel", convg_kernel<0>, grid, dim3(NTHR), kConvgLds, st,
                (const unsigned short*)x, (const unsigned short*)packed, B, H, W, cin, kout,
-               (unsigned short*)out, bias, 0);
+               (unsigned short*)out, bias, 0, (const unsigned short*)nullptr);
   return scl_launch_status();
+}
+
+extern "C" int scl_convg(const void* x, const void* w, int64_t w_stride_k, int64_t w_stride_c,
+                         int64_t w_stride_h, int64_t w_stride_w, int transposed, int B, int H,
+                         int W, int cin, int kout, void* out, const float* bias, int relu,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+  return convg_dispatch(x, w, w_stride_k, w_stride_c, w_stride_h, w_stride_w, transposed, B, H, W,
+                        cin, kout, out, bias, relu, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int scl_convg_masked(const void* x, const void* w, int64_t w_stride_k,
+                                int64_t w_stride_c, int64_t w_stride_h, int64_t w_stride_w,
+                                int transposed, int B, int H, int W, int cin, int kout, void* out,
+                                const void* mask, void* workspace, size_t workspace_bytes,
+                                void* stream) {
+  if (!mask) return SCL_E_NULL;
+  return convg_dispatch(x, w, w_stride_k, w_stride_c, w_stride_h, w_stride_w, transposed, B, H, W,
+                        cin, kout, out, nullptr, 0, mask, workspace, workspace_bytes, stream);
 }

@@ -38,6 +38,22 @@ __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
   return __builtin_bit_cast(unsigned short, b);
 }
 
+// ReLU' on packed bf16: each 16-bit half of g survives where the matching half of y is > 0
+// (sign clear and not zero) and becomes +0 elsewhere — three packed 16-bit integer ops per
+// word (v_pk_max_i16, v_pk_min_i16, v_pk_mul_lo_u16).
+__device__ __forceinline__ unsigned relu_mask_word(unsigned g, unsigned y) {
+  unsigned keep, out;
+  asm("v_pk_max_i16 %0, %1, 0" : "=v"(keep) : "v"(y));            // negative halves -> 0
+  asm("v_pk_min_i16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(keep) : "v"(keep));   // positive -> 1
+  asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(out) : "v"(g), "v"(keep));
+  return out;
+}
+template <typename V4>   // four packed words (the translation units' own u32x4)
+__device__ __forceinline__ V4 relu_mask(V4 g, V4 y) {
+  return V4{relu_mask_word(g.x, y.x), relu_mask_word(g.y, y.y), relu_mask_word(g.z, y.z),
+               relu_mask_word(g.w, y.w)};
+}
+
 // element loads for the two feature-map dtypes
 template <typename T>
 struct Elem;

@@ -128,13 +128,15 @@ def _conv64_ok(x, w, transposed=False):
     return _own_conv_kind(x, w, transposed) is not None
 
 
-def conv64(x, w, transposed=False, bias=None, relu=False, pool=False):
+def conv64(x, w, transposed=False, bias=None, relu=False, pool=False, mask=None):
     """3x3 same-padding convolution on bf16 channels-last activations (``scl_conv3x3_fused``)
     for the shapes of ``_OWN_CONV_SHAPES``; ``transposed`` gives the gradient with respect to
     the input of ``conv(., w)``.  ``bias`` (float32 [kout]) and ``relu`` fuse the layer's tail
-    into the epilogue; ``pool=True`` returns ``(raw conv, relu(maxpool2x2(raw) + bias))``."""
+    into the epilogue; ``pool=True`` returns ``(raw conv, relu(maxpool2x2(raw) + bias))``;
+    ``mask`` (bf16, the output's shape) multiplies the result by ``[mask > 0]`` — the ReLU' of
+    the layer below fused into a backward-data pass."""
     lib = L.load()
-    L.require_device(x, w, bias)
+    L.require_device(x, w, bias, mask)
     x = x.contiguous(memory_format=_CL)
     b, _, h, wd = x.shape
     cin, kout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
@@ -148,6 +150,19 @@ def conv64(x, w, transposed=False, bias=None, relu=False, pool=False):
     if bias is not None:
         bias = bias.float().contiguous()
     sk, sc, sh, sw = w.stride()
+    if mask is not None:
+        if bias is not None or pool or relu:
+            raise ValueError("mask excludes the forward tails (bias / relu / pool)")
+        if tuple(mask.shape) != tuple(out.shape) or mask.dtype != x.dtype:
+            raise ValueError("mask must have the output's shape and dtype")
+        mask = mask.contiguous(memory_format=_CL)
+        own = (cin, kout) in _OWN_CONV_SHAPES
+        ws = L.workspace(lib.scl_conv3x3_workspace_bytes() if own
+                         else lib.scl_convg_workspace_bytes(cin, kout), x.device)
+        fn = lib.scl_conv3x3_masked if own else lib.scl_convg_masked
+        L.check(fn(L.ptr(x), L.ptr(w), sk, sc, sh, sw, int(bool(transposed)), b, h, wd, cin, kout,
+                   L.ptr(out), L.ptr(mask), L.ptr(ws), ws.numel(), L.stream_of(x)))
+        return out
     if (cin, kout) not in _OWN_CONV_SHAPES:
         if pool:
             raise ValueError("the fused pooling epilogue exists for the register kernels only")
@@ -201,10 +216,45 @@ def _wrw_pays(x):
     return x.shape[2] * x.shape[3] >= 60 * 80
 
 
-def _conv3x3_backward(gz, x, w, need_x):
+class _GradLink:
+    """Hand-off between two ADJACENT layers of a purely sequential chain (the producer's output
+    has this one consumer): the upper layer's backward-data pass applies the lower layer's
+    ReLU' in its epilogue and records the buffer here; the lower layer's backward, which runs
+    next, takes it and skips its own masking pass.  Anything else (a copied or re-accumulated
+    gradient, a library backward) leaves the link empty and the lower layer masks itself —
+    masking twice would be harmless, skipping it is only done on this exact buffer."""
+    __slots__ = ('ptr',)
+
+    def __init__(self):
+        self.ptr = None
+
+    def mark(self, gx):
+        self.ptr = gx.data_ptr()
+
+    def take(self, gy):
+        hit = self.ptr is not None and self.ptr == gy.data_ptr()
+        self.ptr = None
+        return hit
+
+
+USE_MASKED_BWD = os.environ.get('SCL_MASKED_BWD', '1') != '0'
+
+
+def _conv3x3_backward(gz, x, w, need_x, link=None):
+    """(gx, gw) of a 3x3 convolution.  With ``link`` (x is a post-ReLU map whose producer
+    holds the other end) an own backward-data kernel returns gx * [x > 0] and marks the
+    link."""
     kind = _own_conv_kind(gz, w, True)
     own_gx = kind == 'reg' or (kind == 'lds' and _lds_conv_pays(gz, True))
     own_gw = _own_wrw_ok(x, gz, w) and _wrw_pays(x)
+    if own_gx and need_x and link is not None and USE_MASKED_BWD:
+        gx = conv64(gz, w, True, mask=x)
+        link.mark(gx)
+        if own_gw:
+            return gx, wrw64(x, gz, w)
+        _, gw, _ = torch.ops.aten.convolution_backward(gz, x, w, None, _ONES, _ONES, _ONES, False,
+                                                       [0, 0], 1, [False, True, False])
+        return gx, gw
     if own_gx and own_gw:
         return (conv64(gz, w, True) if need_x else None), wrw64(x, gz, w)
     if own_gx or own_gw:
@@ -236,8 +286,9 @@ class _ConvBiasAct(torch.autograd.Function):
     ReLU' with the bias-gradient reduction.  Only the post-activation map is kept."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, relu):
+    def forward(ctx, x, w, bias, relu, link_in=None, link_out=None):
         lib = L.load()
+        ctx.link_in, ctx.link_out = link_in, (link_out if relu else None)
         kind = _own_conv_kind(x, w)
         if kind == 'reg' or (kind == 'lds' and _lds_conv_pays(x, False, True)):
             y = conv64(x, w, False, bias=bias, relu=relu)         # tail fused in the epilogue
@@ -258,12 +309,16 @@ class _ConvBiasAct(torch.autograd.Function):
         b, c, h, wd = gy.shape
         gb = torch.empty(c, dtype=torch.float32, device=gy.device)
         ws = L.workspace(lib.scl_vgg_workspace_bytes(c), gy.device)
-        gz = torch.empty_like(gy) if ctx.relu else gy
-        L.check(lib.scl_vgg_act_bwd(L.ptr(gy), L.ptr(y), _glue_dtype(gy), b * h * wd, c,
-                                    L.ptr(gz) if ctx.relu else None, L.ptr(gb), L.ptr(ws),
+        # ReLU' already applied by the layer above (its backward-data epilogue)?
+        masked = ctx.link_out is not None and ctx.link_out.take(gy)
+        mask_here = ctx.relu and not masked
+        gz = torch.empty_like(gy) if mask_here else gy
+        L.check(lib.scl_vgg_act_bwd(L.ptr(gy), L.ptr(y) if mask_here else None,
+                                    _glue_dtype(gy), b * h * wd, c,
+                                    L.ptr(gz) if mask_here else None, L.ptr(gb), L.ptr(ws),
                                     ws.numel(), L.stream_of(gy)))
-        gx, gw = _conv3x3_backward(gz, x, w, ctx.needs_input_grad[0])
-        return gx, gw, gb, None
+        gx, gw = _conv3x3_backward(gz, x, w, ctx.needs_input_grad[0], ctx.link_in)
+        return gx, gw, gb, None, None, None
 
 
 class _ConvBiasPoolReLU(torch.autograd.Function):
@@ -272,8 +327,9 @@ class _ConvBiasPoolReLU(torch.autograd.Function):
     conv output (no int64 index tensor) and fuses ReLU' and the bias gradient."""
 
     @staticmethod
-    def forward(ctx, x, w, bias):
+    def forward(ctx, x, w, bias, link_in=None):
         lib = L.load()
+        ctx.link_in = link_in
         if _own_conv_kind(x, w) == 'reg' and tuple(w.shape[:2]) == (64, 64):
             # pooled map from the epilogue (the 128-channel variant of that epilogue runs out
             # of registers and is slower than the plain kernel + the pooling pass)
@@ -299,8 +355,8 @@ class _ConvBiasPoolReLU(torch.autograd.Function):
         ws = L.workspace(lib.scl_vgg_workspace_bytes(c), z.device)
         L.check(lib.scl_vgg_pool_bwd(L.ptr(ga), L.ptr(a), L.ptr(z), _glue_dtype(z), b, h, wd, c,
                                      L.ptr(gz), L.ptr(gb), L.ptr(ws), ws.numel(), L.stream_of(z)))
-        gx, gw = _conv3x3_backward(gz, x, w, ctx.needs_input_grad[0])
-        return gx, gw, gb
+        gx, gw = _conv3x3_backward(gz, x, w, ctx.needs_input_grad[0], ctx.link_in)
+        return gx, gw, gb, None
 
 
 def avg_rgb_grad(gz, w, gb):
@@ -337,8 +393,9 @@ class _FirstConv(torch.autograd.Function):
     the closed form of ``avg_rgb_grad`` — so conv1_1's bwd-data pass is never run."""
 
     @staticmethod
-    def forward(ctx, img_nhwc, avg, w, bias, dtype):
+    def forward(ctx, img_nhwc, avg, w, bias, dtype, link_out=None):
         lib = L.load()
+        ctx.link_out = link_out
         if (USE_CONV64 and USE_FIRST and dtype == torch.bfloat16 and img_nhwc.is_cuda
                 and img_nhwc.dtype == torch.float32 and w.dtype == torch.bfloat16
                 and tuple(w.shape) == (64, 3, 3, 3)):
@@ -370,11 +427,13 @@ class _FirstConv(torch.autograd.Function):
         b, c, h, wd = gy.shape
         gb = torch.empty(c, dtype=torch.float32, device=gy.device)
         ws = L.workspace(lib.scl_vgg_workspace_bytes(c), gy.device)
-        gz = torch.empty_like(gy)
-        L.check(lib.scl_vgg_act_bwd(L.ptr(gy), L.ptr(y), _glue_dtype(gy), b * h * wd, c, L.ptr(gz),
-                                    L.ptr(gb), L.ptr(ws), ws.numel(), L.stream_of(gy)))
+        masked = ctx.link_out is not None and ctx.link_out.take(gy)
+        gz = gy if masked else torch.empty_like(gy)
+        L.check(lib.scl_vgg_act_bwd(L.ptr(gy), None if masked else L.ptr(y), _glue_dtype(gy),
+                                    b * h * wd, c, None if masked else L.ptr(gz), L.ptr(gb), L.ptr(ws),
+                                    ws.numel(), L.stream_of(gy)))
         _, gw = _conv3x3_backward(gz, x0, w, False)
-        return None, avg_rgb_grad(gz, w, gb), gw, gb, None
+        return None, avg_rgb_grad(gz, w, gb), gw, gb, None, None
 
 
 class _SubMean(torch.autograd.Function):
@@ -456,11 +515,13 @@ class VGG16NetVLAD(torch.nn.Module):
         if x is not None:
             x = x.contiguous(memory_format=torch.channels_last)
         skip_pool = False
+        link = None        # set while x is the post-ReLU output of the previous conv node
         for idx, item in enumerate(VGG_LAYERS):
             if item == 'pool':
                 if not skip_pool:
                     x = F.relu(F.max_pool2d(x, 2, 2))                    # pool, then ReLU
                 skip_pool = False
+                link = None
                 continue
             name, _, relu = item
             pool_next = idx + 1 < len(VGG_LAYERS) and VGG_LAYERS[idx + 1] == 'pool'
@@ -471,13 +532,17 @@ class VGG16NetVLAD(torch.nn.Module):
             if fuse:
                 if x is None:
                     # nets.py:22-24 + conv1_1 + ReLU; no image gradient is ever formed
-                    x = _FirstConv.apply(image_batch, self.average_rgb, w, bias, dt)
+                    link = _GradLink()
+                    x = _FirstConv.apply(image_batch, self.average_rgb, w, bias, dt, link)
                 elif pool_next:
                     # conv -> bias -> pool -> ReLU in one elementwise pass (nets.py:40-42)
-                    x = _ConvBiasPoolReLU.apply(x, w, bias)
+                    x = _ConvBiasPoolReLU.apply(x, w, bias, link)
                     skip_pool = True
+                    link = None
                 else:
-                    x = _ConvBiasAct.apply(x, w, bias, relu)
+                    link_out = _GradLink() if relu else None
+                    x = _ConvBiasAct.apply(x, w, bias, relu, link, link_out)
+                    link = link_out
                 continue
             if bias.dtype != dt:
                 bias = bias.to(dt)

@@ -297,3 +297,71 @@ def test_first_layer_kernel(dev, shape):
     want = torch.relu(torch.nn.functional.conv2d(want_x0.float().permute(0, 3, 1, 2), wt.float(),
                                                  padding=1) + bias[None, :, None, None])
     assert float((y.float() - want).abs().max()) < 6e-3 * float(want.abs().max())
+
+
+@pytest.mark.parametrize('cin,cout,shape', [(64, 64, (2, 16, 40)), (128, 128, (1, 13, 37)),
+                                            (128, 64, (1, 9, 33)), (256, 128, (2, 12, 40)),
+                                            (512, 256, (1, 15, 80))])
+def test_backward_data_with_relu_mask_in_the_epilogue(dev, cin, cout, shape):
+    """scl_conv3x3_masked / scl_convg_masked: gx * [y > 0] must be the plain kernel's gx with
+    the mask applied afterwards, bit for bit (zeros, negative zeros and negatives in y cut)."""
+    from soft_contrastive_learning_amd.model import nets
+    b, h, w = shape
+    g = torch.Generator().manual_seed(37)
+    # gradient w.r.t. the input of conv(cout <- cin ... ) seen from above: gz has `cin` channels
+    gz = torch.randn(b, cin, h, w, generator=g).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(cin, cout, 3, 3, generator=g) * 0.05).to(dev).bfloat16().contiguous(
+        memory_format=torch.channels_last)
+    y = torch.randn(b, cout, h, w, generator=g)
+    y[y.abs() < 0.3] = 0.0
+    y[(y > 1.0)] = -0.0
+    y = y.to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    plain = nets.conv64(gz, wt, True)
+    got = nets.conv64(gz, wt, True, mask=y)
+    want = torch.where(y > 0, plain, torch.zeros_like(plain))
+    assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(got, want)
+    assert float((want != 0).float().mean()) > 0.1
+
+
+def test_masked_backward_chain_equals_separate_masking_pass(dev):
+    """The hand-off of ReLU' to the layer above (nets._GradLink) must not change a gradient:
+    a three-layer chain of own kernels gives bit-identical results with and without it, and
+    the lower layers really skip their masking pass."""
+    from soft_contrastive_learning_amd.model import nets
+    g = torch.Generator().manual_seed(41)
+    cl = torch.channels_last
+    x0 = torch.randn(1, 64, 60, 80, generator=g).to(dev).bfloat16().contiguous(memory_format=cl)
+    ws = [(torch.randn(co, ci, 3, 3, generator=g) * (2.0 / (9 * ci)) ** 0.5).to(dev).bfloat16()
+          .contiguous(memory_format=cl) for ci, co in ((64, 64), (64, 128), (128, 128))]
+    bs = [(torch.randn(co, generator=g) * 0.1).to(dev) for co in (64, 128, 128)]
+    gout = torch.randn(1, 128, 30, 40, generator=g).to(dev).bfloat16().contiguous(memory_format=cl)
+
+    def run(linked):
+        x = x0.clone().requires_grad_(True)
+        w = [t.clone().requires_grad_(True) for t in ws]
+        b = [t.clone().requires_grad_(True) for t in bs]
+        l1 = nets._GradLink() if linked else None
+        l2 = nets._GradLink() if linked else None
+        y = nets._ConvBiasAct.apply(x, w[0], b[0], True, None, l1)
+        y = nets._ConvBiasAct.apply(y, w[1], b[1], True, l1, l2)
+        y = nets._ConvBiasPoolReLU.apply(y, w[2], b[2], l2)
+        y.backward(gout)
+        return [x.grad] + [t.grad for t in w] + [t.grad for t in b]
+
+    takes = []
+    orig = nets._GradLink.take
+
+    def counting_take(self, gy):
+        hit = orig(self, gy)
+        takes.append(hit)
+        return hit
+    nets._GradLink.take = counting_take
+    try:
+        linked = run(True)
+    finally:
+        nets._GradLink.take = orig
+    assert takes == [True, True]
+    plain = run(False)
+    for a, b_ in zip(linked, plain):
+        assert torch.equal(a, b_)
