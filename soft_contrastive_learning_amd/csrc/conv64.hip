@@ -266,9 +266,41 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
 //   * persistent grid, one workgroup per CU accumulating over all its tiles, then ONE slab
 //     [9][64][64] float32 per workgroup; wrw64_reduce_kernel sums the slabs in a fixed order
 //     into the weight's own layout (bf16).
-constexpr int GZ = TH * TW * PIX_LD;                 // bf16 of the staged gz tile
-constexpr int GPIECES = TH * TW * 8;                 // 2048
-constexpr size_t kWrw64Lds = ((size_t)WIN + (size_t)GZ) * sizeof(unsigned short);   // 85,824 B
+// LDS layout: each staged tile is TWO planes of 32 channels with 64-byte pixels and no padding.
+// A ds_read_b64_tr_b16 is served 32 lanes at a time (8-byte units, 32 of them per cycle); the
+// 32 lanes of a group address 4 pixels x (2 x 16 channels): unit = 8 * pixel + 4 * (channel
+// half) + piece, all distinct mod 32 — conflict-free.  (One 64-channel plane at 144 B per
+// pixel, fine for ds_read_b128, makes every transposed read 2-way conflicted: unit 18 * pixel.)
+// The planes are filled by LDS-DMA (global_load_lds_dwordx4: no staging registers, no
+// ds_write pass, 80 KB in flight per CU): one wave-instruction writes 1 KB = 16 pixels of a
+// plane, lane -> (pixel lane >> 2, 16-byte piece lane & 3) — the image is lane-linear as the
+// DMA requires.  Out-of-image halo pixels are fetched from a zero block.
+constexpr int WPL = 32;                              // bf16 per pixel and plane
+constexpr int XCH = (WR * WC + 15) / 16;             // 1-KB chunks per x plane (22: 352 pixels)
+constexpr int GCH = TH * TW / 16;                    // per gz plane (16)
+constexpr int XPLANE = XCH * 16 * WPL;
+constexpr int GPLANE = GCH * 16 * WPL;
+constexpr int WBUF = 2 * XPLANE + 2 * GPLANE;        // one staged (x window, gz tile) pair
+constexpr int WCHUNKS = 2 * XCH + 2 * GCH;           // 76 wave-instructions per tile
+constexpr size_t kWrw64Lds = 2 * (size_t)WBUF * sizeof(unsigned short);   // double-buffered
+__device__ uint4 zero_block[4];                      // never written: zeros
+
+// Issued as inline asm so that hipcc does not order it against the LDS reads of the OTHER
+// buffer (with the builtin it waits vmcnt(0) before the next ds_read: no overlap at all);
+// the kernel waits vmcnt(0) itself before the barrier that hands the buffer over.
+// lds_byte: wave-uniform LDS byte address of the 1-KB chunk; src: this lane's 16 bytes.
+__device__ __forceinline__ void glds16(const unsigned short* src, unsigned lds_byte) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(src), "s"(lds_byte)
+      : "memory");
+}
+__device__ __forceinline__ unsigned lds_byte_of(const unsigned short* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned short*)p;
+}
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ u32x4 tr_pair(const unsigned short* a0, int step4) {
@@ -282,12 +314,14 @@ __device__ __forceinline__ u32x4 tr_pair(const unsigned short* a0, int step4) {
 
 // grid (pixel splits P, C / 64, K / 64): workgroup (p, cb, kb) accumulates the [9][64][64]
 // block (input channels 64 cb .., output channels 64 kb ..) over the tiles p, p + P, ...
+// DBG (scl_debug_set_variant(2000 + bits), timing diagnostics only — wrong results): bit 0
+// no operand reads in the product loop, bit 1 no staging after the first tile.
+template <int DBG>
 __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __restrict__ x,
                                                        const unsigned short* __restrict__ gz,
                                                        int B, int H, int W, int C, int K,
                                                        float* __restrict__ slabs) {
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
-  unsigned short* gl = lds + WIN;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   // eight waves, two per SIMD: wave (mt, nt, ph) accumulates block (mt, nt) over the steps
@@ -303,43 +337,48 @@ __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __r
   const int per_img = tiles_x * tiles_y;
   const int ntiles = B * per_img;
 
-  constexpr int XPT = (PIECES + 511) / 512, GPT = GPIECES / 512;
-  u32x4 st_x[XPT], st_g[GPT];
-  auto stage_load = [&](int tile) {
+  // wave wid issues chunks j = wid, wid + 8, ... of the 76: [x plane 0][x plane 1][gz 0][gz 1].
+  // Which pixel of the window / tile a lane fetches for its i-th chunk does not depend on
+  // the tile: (row << 8 | column) once, -1 for the slack behind the window.
+  constexpr int NI = (WCHUNKS + 7) / 8;
+  const int wid_s = __builtin_amdgcn_readfirstlane(wid);
+  const int pl = lane >> 2, piece = lane & 3;
+  int rel[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int j = wid_s + 8 * i;
+    if (j < 2 * XCH) {
+      const int pix = 16 * (j >= XCH ? j - XCH : j) + pl;
+      rel[i] = pix < WR * WC ? ((pix / WC) << 8) | (pix % WC) : -1;
+    } else {
+      const int jj = j - 2 * XCH;
+      const int pix = 16 * (jj >= GCH ? jj - GCH : jj) + pl;
+      rel[i] = j < WCHUNKS ? ((pix / TW) << 8) | (pix % TW) : -1;
+    }
+  }
+  const unsigned short* zeros = reinterpret_cast<const unsigned short*>(zero_block);
+  const int xc0 = C64 * blockIdx.y + 8 * piece, gc0 = C64 * blockIdx.z + 8 * piece;
+  auto stage_issue = [&](int tile, int buf) {
     const int b = tile / per_img, t2 = tile % per_img;
     const int ty = (t2 / tiles_x) * TH, tx = (t2 % tiles_x) * TW;
+    const unsigned base = lds_byte_of(lds) + buf * WBUF * 2;
 #pragma unroll
-    for (int v = 0; v < XPT; ++v) {
-      const int idx = v * 512 + threadIdx.x;
-      const int pix = idx >> 3, c = idx & 7;
-      const int y = ty - 1 + pix / WC, xx = tx - 1 + pix % WC;
-      const bool ok = idx < PIECES && y >= 0 && y < H && xx >= 0 && xx < W;
-      st_x[v] = ok ? *reinterpret_cast<const u32x4*>(
-                         x + (((int64_t)b * H + y) * W + xx) * C + C64 * blockIdx.y + 8 * c)
-                   : u32x4{0u, 0u, 0u, 0u};
-    }
-#pragma unroll
-    for (int v = 0; v < GPT; ++v) {
-      const int idx = v * 512 + threadIdx.x;
-      const int pix = idx >> 3, c = idx & 7;
-      const int y = ty + pix / TW, xx = tx + pix % TW;
-      const bool ok = y < H && xx < W;
-      st_g[v] = ok ? *reinterpret_cast<const u32x4*>(
-                         gz + (((int64_t)b * H + y) * W + xx) * K + C64 * blockIdx.z + 8 * c)
-                   : u32x4{0u, 0u, 0u, 0u};
-    }
-  };
-  auto stage_store = [&]() {
-#pragma unroll
-    for (int v = 0; v < XPT; ++v) {
-      const int idx = v * 512 + threadIdx.x;
-      if (idx < PIECES)
-        *reinterpret_cast<u32x4*>(lds + (idx >> 3) * PIX_LD + 8 * (idx & 7)) = st_x[v];
-    }
-#pragma unroll
-    for (int v = 0; v < GPT; ++v) {
-      const int idx = v * 512 + threadIdx.x;
-      *reinterpret_cast<u32x4*>(gl + (idx >> 3) * PIX_LD + 8 * (idx & 7)) = st_g[v];
+    for (int i = 0; i < NI; ++i) {
+      const int j = wid_s + 8 * i;                       // wave-uniform
+      if (j < 2 * XCH) {
+        const int plane = j >= XCH ? 1 : 0, chunk = j - XCH * plane;
+        const int y = ty - 1 + (rel[i] >> 8), xx = tx - 1 + (rel[i] & 255);
+        const bool ok = rel[i] >= 0 && (unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W;
+        const int off = ((b * H + y) * W + xx) * C + xc0 + 32 * plane;       // < 2^31: host check
+        glds16(ok ? x + off : zeros, base + (plane * XPLANE + chunk * 512) * 2);
+      } else if (j < WCHUNKS) {
+        const int jj = j - 2 * XCH;
+        const int plane = jj >= GCH ? 1 : 0, chunk = jj - GCH * plane;
+        const int y = ty + (rel[i] >> 8), xx = tx + (rel[i] & 255);
+        const bool ok = y < H && xx < W;
+        const int off = ((b * H + y) * W + xx) * K + gc0 + 32 * plane;
+        glds16(ok ? gz + off : zeros, base + (2 * XPLANE + plane * GPLANE + chunk * 512) * 2);
+      }
     }
   };
 
@@ -347,37 +386,48 @@ __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __r
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = zero16();
 
+  // The wave's 72 (step, tap) products of a tile run as ONE software pipeline: the A operand
+  // of product i + 3 is in flight while product i multiplies (an LDS transposed read returns
+  // long after one 32-cycle MFMA), the B operand of the next step while the current one runs.
+  // The tiles alternate between two LDS buffers: the DMA of tile n + 1 runs under the whole
+  // of tile n; one barrier per tile (it drains the DMA: hipcc waits vmcnt(0) there).
+  constexpr int DEPTH = 4, AHEAD = 3;
   int tile = blockIdx.x;
-  if (tile < ntiles) {
-    stage_load(tile);
-    stage_store();
-  }
+  if (tile < ntiles) stage_issue(tile, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  int buf = 0;
   for (; tile < ntiles; tile += gridDim.x) {
-    const int next = tile + gridDim.x;
-    if (next < ntiles) stage_load(next);
-#pragma unroll 1
-    for (int step = TH * ph; step < TH * ph + TH; ++step) {
-      const int ry = step >> 1, cx = 16 * (step & 1);
-      // B: gz pixels (ry, cx + 8h .. + 7) x output channels 32 nt ..
-      const u32x4 bf = tr_pair(gl + (ry * TW + cx + pix0) * PIX_LD + 32 * nt + ch0, 4 * PIX_LD);
-      // A of tap (kh, kw): x window pixels (ry + kh, cx + kw + 8h ..) x channels 32 mt ..
-      const unsigned short* ab = lds + (ry * WC + cx + pix0) * PIX_LD + 32 * mt + ch0;
-      u32x4 af[2];
-      af[0] = tr_pair(ab, 4 * PIX_LD);
+    const int next = (DBG & 2) ? ntiles : tile + gridDim.x;
+    if (next < ntiles) stage_issue(next, buf ^ 1);
+    const unsigned short* xl = lds + buf * WBUF + mt * XPLANE + pix0 * WPL + ch0;
+    const unsigned short* gl = lds + buf * WBUF + 2 * XPLANE + nt * GPLANE + pix0 * WPL + ch0;
+    // product i = 9 * s + t: step s (tile row ry = 4 ph + s / 2, pixels 16 (s & 1) ..), tap t
+    auto a_of = [&](int i) {
+      const int s_ = i / 9, t = i % 9;
+      const int ry = TH / 2 * ph + (s_ >> 1), cx = 16 * (s_ & 1);
+      if (DBG & 1) return u32x4{0x3f803f80u + i, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+      return tr_pair(xl + ((ry + t / 3) * WC + cx + t % 3) * WPL, 4 * WPL);
+    };
+    auto b_of = [&](int s_) {
+      const int ry = TH / 2 * ph + (s_ >> 1), cx = 16 * (s_ & 1);
+      if (DBG & 1) return u32x4{0x3f803f80u + s_, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+      return tr_pair(gl + (ry * TW + cx) * WPL, 4 * WPL);
+    };
+    u32x4 af[DEPTH], bf[2];
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        if (t + 1 < 9) {
-          const int kh = (t + 1) / 3, kw = (t + 1) % 3;
-          af[(t + 1) & 1] = tr_pair(ab + (kh * WC + kw) * PIX_LD, 4 * PIX_LD);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        acc[t] = mfma32b(af[t & 1], bf, acc[t]);
-      }
+    for (int i = 0; i < AHEAD; ++i) af[i] = a_of(i);
+    bf[0] = b_of(0);
+#pragma unroll
+    for (int i = 0; i < 9 * TH; ++i) {
+      if (i + AHEAD < 9 * TH) af[(i + AHEAD) % DEPTH] = a_of(i + AHEAD);
+      if (i % 9 == 2 && i / 9 + 1 < TH) bf[(i / 9 + 1) & 1] = b_of(i / 9 + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[i % 9] = mfma32b(af[i % DEPTH], bf[(i / 9) & 1], acc[i % 9]);
     }
-    __syncthreads();                     // every wave is done with the staged tile
-    if (next < ntiles) stage_store();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA chunks have landed
     __syncthreads();
+    buf ^= 1;
   }
 
   // slab[2 p + ph][cb][kb][tap][c][k]: accumulator register qq <-> c = 32 mt + acc_row(qq, h),
@@ -694,12 +744,20 @@ extern "C" int scl_wrw3x3(const void* x, const void* gz, int B, int H, int W, in
   const size_t need = scl_wrw3x3_workspace_bytes(cin, kout);
   if (need == 0 || B < 1 || H < 1 || W < 1 || (int64_t)B * H * W > (int64_t)1 << 30)
     return SCL_E_SHAPE;
+  if ((int64_t)B * H * W * (cin > kout ? cin : kout) >= (int64_t)1 << 31)
+    return SCL_E_SHAPE;                                 // 32-bit element offsets in the kernel
   if (((uintptr_t)x % 16) || ((uintptr_t)gz % 16)) return SCL_E_SHAPE;
   if (!scl_aligned256(workspace) || workspace_bytes < need) return SCL_E_WORKSPACE;
   static std::once_flag once;
   static int cus = 256;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wrw64_kernel),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wrw64_kernel<0>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWrw64Lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wrw64_kernel<1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWrw64Lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wrw64_kernel<2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWrw64Lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wrw64_kernel<3>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWrw64Lds);
     cus = conv64_cus();
     if (cus > 1024) cus = 1024;
@@ -707,9 +765,16 @@ extern "C" int scl_wrw3x3(const void* x, const void* gz, int B, int H, int W, in
   const int tiles = B * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
   const int P = wrw_splits(cin, kout, tiles, cus);
   hipStream_t st = (hipStream_t)stream;
-  SCL_LAUNCH("wrw64_kernel", wrw64_kernel, dim3(P, cin / 64, kout / 64), dim3(512), kWrw64Lds, st,
-             (const unsigned short*)x, (const unsigned short*)gz, B, H, W, cin, kout,
-             (float*)workspace);
+  const int dbg = scl_debug_variant / 1000 == 2 ? scl_debug_variant & 3 : 0;
+#define SCL_WRW_LAUNCH(D)                                                                      \
+  SCL_LAUNCH("wrw64_kernel", wrw64_kernel<D>, dim3(P, cin / 64, kout / 64), dim3(512),         \
+             kWrw64Lds, st, (const unsigned short*)x, (const unsigned short*)gz, B, H, W, cin, \
+             kout, (float*)workspace)
+  if (dbg == 0) SCL_WRW_LAUNCH(0);
+  else if (dbg == 1) SCL_WRW_LAUNCH(1);
+  else if (dbg == 2) SCL_WRW_LAUNCH(2);
+  else SCL_WRW_LAUNCH(3);
+#undef SCL_WRW_LAUNCH
   SCL_LAUNCH("wrw64_reduce_kernel", wrw64_reduce_kernel, dim3(9 * 64 * 64 / 64, (cin / 64) * (kout / 64)),
              dim3(256), 0, st, (const float*)workspace, 2 * P, kout / 64, w_stride_k, w_stride_c,
              w_stride_h, w_stride_w, (unsigned short*)gw);
