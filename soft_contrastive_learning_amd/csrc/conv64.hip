@@ -42,6 +42,27 @@ __device__ __forceinline__ f32x16 mfma32b(u32x4 a, u32x4 b, f32x16 c) {
                                                  __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// LDS-DMA staging (global_load_lds_dwordx4): one wave-instruction copies 64 x 16 bytes from
+// per-lane global addresses to 1 KB of CONSECUTIVE LDS — no staging registers, no ds_write
+// pass, many more bytes in flight per CU.  Out-of-image halo pixels read a zero block.
+__device__ uint4 zero_block[4];                      // never written: zeros
+
+// Issued as inline asm so that hipcc does not order it against the LDS reads of the OTHER
+// buffer (with the builtin it waits vmcnt(0) before the next ds_read: no overlap at all);
+// the kernel waits vmcnt(0) itself before the barrier that hands the buffer over.
+// lds_byte: wave-uniform LDS byte address of the 1-KB chunk; src: this lane's 16 bytes.
+__device__ __forceinline__ void glds16(const unsigned short* src, unsigned lds_byte) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(src), "s"(lds_byte)
+      : "memory");
+}
+__device__ __forceinline__ unsigned lds_byte_of(const unsigned short* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned short*)p;
+}
 // Generalisation to the other VGG shapes whose weight slice still fits the register file:
 //   (CIN, KOUT) in {(64,64) conv1_2 fwd+bwd, (64,128) conv2_1 fwd, (128,64) conv2_1 bwd,
 //   (128,128) conv2_2 fwd+bwd}.  A wave always owns 32 output channels (KOUT / 32 n-tiles)
@@ -60,7 +81,9 @@ struct ConvCfg {
   // the other shapes four (their register budget needs occupancy 1)
   static constexpr int WAVES = (CIN == 64 && KOUT == 64) ? 8 : 4;
   static constexpr int NTHR = 64 * WAVES;
-  static constexpr int NPT_ = (PIECES_ + NTHR - 1) / NTHR;
+  static constexpr int SPP = PPP + 1;                  // 16-byte slots per staged pixel (+ pad)
+  static constexpr int CHUNKS = (WR_ * WC * SPP + 63) / 64;   // 1-KB DMA chunks per window
+  static constexpr int NI = (CHUNKS + WAVES - 1) / WAVES;     // chunks per wave
   static constexpr int SPT = CIN / 16;                 // k-steps per tap
   static constexpr int KS = 9 * SPT;                   // 36 or 72
   static constexpr int NT = KOUT / 32;                 // n-tiles: 2 or 4
@@ -129,42 +152,46 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
   const int per_img = tiles_x * tiles_y;
   const int ntiles = B * per_img;
 
-  u32x4 st[Cfg::NPT_];
-  auto stage_load = [&](int tile) {
+  // The window [pixel][CIN + 8] is filled by LDS-DMA: wave wid issues chunks wid, wid + WAVES,
+  // ...; lane l of chunk j owns slot 64 j + l = (pixel, piece) with piece == PPP the pad (not
+  // fetched).  The slot's place in the window does not depend on the tile: computed once.
+  const int wid_s = __builtin_amdgcn_readfirstlane(wid);
+  int rel[Cfg::NI], roff[Cfg::NI];
+#pragma unroll
+  for (int i = 0; i < Cfg::NI; ++i) {
+    const int slot = 64 * (wid_s + Cfg::WAVES * i) + lane;
+    const int pix = slot / Cfg::SPP, piece = slot % Cfg::SPP;
+    rel[i] = (piece < Cfg::PPP && pix < Cfg::WR_ * WC) ? ((pix / WC) << 8) | (pix % WC) : -1;
+    roff[i] = ((pix / WC) * W + pix % WC) * CIN + 8 * piece;
+  }
+  const unsigned short* zeros = reinterpret_cast<const unsigned short*>(zero_block);
+  auto stage_issue = [&](int tile, int buf) {
     const int b = tile / per_img, t2 = tile % per_img;
     const int y0 = (t2 / tiles_x) * TH_ - 1, x0 = (t2 % tiles_x) * TW - 1;
+    const int xo = ((b * H + y0) * W + x0) * CIN;        // < 2^31 elements: host check
+    const unsigned base = lds_byte_of(lds) + buf * WIN_ * 2;
 #pragma unroll
-    for (int v = 0; v < Cfg::NPT_; ++v) {
-      const int idx = v * Cfg::NTHR + threadIdx.x;
-      const int pix = idx / Cfg::PPP, c = idx % Cfg::PPP;
-      const int wy = pix / WC, wx = pix % WC;
-      const int y = y0 + wy, xx = x0 + wx;
-      const bool ok = idx < Cfg::PIECES_ && y >= 0 && y < H && xx >= 0 && xx < W;
-      st[v] = ok ? *reinterpret_cast<const u32x4*>(
-                       x + (((int64_t)b * H + y) * W + xx) * CIN + 8 * c)
-                 : u32x4{0u, 0u, 0u, 0u};
-    }
-  };
-  auto stage_store = [&](int buf) {
-#pragma unroll
-    for (int v = 0; v < Cfg::NPT_; ++v) {
-      const int idx = v * Cfg::NTHR + threadIdx.x;
-      if (idx < Cfg::PIECES_)
-        *reinterpret_cast<u32x4*>(lds + buf * WIN_ + (idx / Cfg::PPP) * PIX + 8 * (idx % Cfg::PPP)) =
-            st[v];
+    for (int i = 0; i < Cfg::NI; ++i) {
+      const int j = wid_s + Cfg::WAVES * i;
+      if (j < Cfg::CHUNKS) {                             // wave-uniform
+        const int y = y0 + (rel[i] >> 8), xx = x0 + (rel[i] & 255);
+        const bool ok = (unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W;
+        const unsigned short* src = ok ? x + (xo + roff[i]) : zeros;
+        if (rel[i] >= 0) glds16(src, base + j * 1024);
+      }
     }
   };
 
+  const int dbg = relu >> 1;            // timing diagnostics (scl_debug_set_variant(4000 + bits))
+  relu &= 1;
   int tile = blockIdx.x;
-  if (tile < ntiles) {
-    stage_load(tile);
-    stage_store(0);
-  }
+  if (tile < ntiles) stage_issue(tile, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int buf = 0;
   for (; tile < ntiles; tile += gridDim.x) {
-    const int next = tile + gridDim.x;
-    if (next < ntiles) stage_load(next);
+    const int next = (dbg & 1) ? ntiles : tile + gridDim.x;
+    if (next < ntiles) stage_issue(next, buf ^ 1);       // lands under the whole K loop
 
     // A fragment of (tile row mt, k-step ks): window pixel (MT part + mt + kh, r + kw),
     // channels 16 (ks % SPT) + 8 h .. + 7
@@ -189,6 +216,10 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma32b(af[ks & 1][mt], wf[ks], acc[mt]);
     }
+
+    // this wave's share of the next window has landed (waited for here, before the epilogue's
+    // own stores join the queue); the barrier below publishes it
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // epilogue: tile row MT part + mt, accumulator register q <-> column acc_row(q, h),
     // lane r <-> output channel 32 nt + r
@@ -220,7 +251,7 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
         v0 = relu_mask(v0, y0v);
         v1 = relu_mask(v1, y1v);
       }
-      if (inside) {
+      if (inside && !(dbg & 2)) {
         *reinterpret_cast<u32x4*>(out + o_off) = v0;
         *reinterpret_cast<u32x4*>(out + o_off + 8) = v1;
       }
@@ -249,7 +280,6 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
       }
     }
 
-    if (next < ntiles) stage_store(buf ^ 1);
     __syncthreads();
     buf ^= 1;
   }
@@ -283,24 +313,8 @@ constexpr int GPLANE = GCH * 16 * WPL;
 constexpr int WBUF = 2 * XPLANE + 2 * GPLANE;        // one staged (x window, gz tile) pair
 constexpr int WCHUNKS = 2 * XCH + 2 * GCH;           // 76 wave-instructions per tile
 constexpr size_t kWrw64Lds = 2 * (size_t)WBUF * sizeof(unsigned short);   // double-buffered
-__device__ uint4 zero_block[4];                      // never written: zeros
 
-// Issued as inline asm so that hipcc does not order it against the LDS reads of the OTHER
-// buffer (with the builtin it waits vmcnt(0) before the next ds_read: no overlap at all);
-// the kernel waits vmcnt(0) itself before the barrier that hands the buffer over.
-// lds_byte: wave-uniform LDS byte address of the 1-KB chunk; src: this lane's 16 bytes.
-__device__ __forceinline__ void glds16(const unsigned short* src, unsigned lds_byte) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(src), "s"(lds_byte)
-      : "memory");
-}
-__device__ __forceinline__ unsigned lds_byte_of(const unsigned short* p) {
-  return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned short*)p;
-}
+
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ u32x4 tr_pair(const unsigned short* a0, int step4) {
@@ -343,25 +357,31 @@ __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __r
   constexpr int NI = (WCHUNKS + 7) / 8;
   const int wid_s = __builtin_amdgcn_readfirstlane(wid);
   const int pl = lane >> 2, piece = lane & 3;
-  int rel[NI];
+  int rel[NI], roff[NI];      // roff: element offset from the tile's first (halo) pixel
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int j = wid_s + 8 * i;
     if (j < 2 * XCH) {
-      const int pix = 16 * (j >= XCH ? j - XCH : j) + pl;
+      const int plane = j >= XCH ? 1 : 0;
+      const int pix = 16 * (j - XCH * plane) + pl;
       rel[i] = pix < WR * WC ? ((pix / WC) << 8) | (pix % WC) : -1;
+      roff[i] = ((pix / WC) * W + pix % WC) * C + C64 * blockIdx.y + 8 * piece + 32 * plane;
     } else {
       const int jj = j - 2 * XCH;
-      const int pix = 16 * (jj >= GCH ? jj - GCH : jj) + pl;
+      const int plane = jj >= GCH ? 1 : 0;
+      const int pix = 16 * (jj - GCH * plane) + pl;
       rel[i] = j < WCHUNKS ? ((pix / TW) << 8) | (pix % TW) : -1;
+      roff[i] = ((pix / TW) * W + pix % TW) * K + C64 * blockIdx.z + 8 * piece + 32 * plane;
     }
   }
   const unsigned short* zeros = reinterpret_cast<const unsigned short*>(zero_block);
-  const int xc0 = C64 * blockIdx.y + 8 * piece, gc0 = C64 * blockIdx.z + 8 * piece;
   auto stage_issue = [&](int tile, int buf) {
     const int b = tile / per_img, t2 = tile % per_img;
     const int ty = (t2 / tiles_x) * TH, tx = (t2 % tiles_x) * TW;
     const unsigned base = lds_byte_of(lds) + buf * WBUF * 2;
+    // element offsets of the window's / tile's first pixel (< 2^31: host check; the window's
+    // may be negative at the image border — those lanes are masked by `ok`)
+    const int xo = ((b * H + ty - 1) * W + tx - 1) * C, go = ((b * H + ty) * W + tx) * K;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int j = wid_s + 8 * i;                       // wave-uniform
@@ -369,15 +389,14 @@ __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __r
         const int plane = j >= XCH ? 1 : 0, chunk = j - XCH * plane;
         const int y = ty - 1 + (rel[i] >> 8), xx = tx - 1 + (rel[i] & 255);
         const bool ok = rel[i] >= 0 && (unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W;
-        const int off = ((b * H + y) * W + xx) * C + xc0 + 32 * plane;       // < 2^31: host check
-        glds16(ok ? x + off : zeros, base + (plane * XPLANE + chunk * 512) * 2);
+        glds16(ok ? x + (xo + roff[i]) : zeros, base + (plane * XPLANE + chunk * 512) * 2);
       } else if (j < WCHUNKS) {
         const int jj = j - 2 * XCH;
         const int plane = jj >= GCH ? 1 : 0, chunk = jj - GCH * plane;
         const int y = ty + (rel[i] >> 8), xx = tx + (rel[i] & 255);
         const bool ok = y < H && xx < W;
-        const int off = ((b * H + y) * W + xx) * K + gc0 + 32 * plane;
-        glds16(ok ? gz + off : zeros, base + (2 * XPLANE + plane * GPLANE + chunk * 512) * 2);
+        glds16(ok ? gz + (go + roff[i]) : zeros,
+               base + (2 * XPLANE + plane * GPLANE + chunk * 512) * 2);
       }
     }
   };
@@ -619,10 +638,11 @@ int launch_conv3x3(const void* x, const void* w, int64_t sk, int64_t sc, int64_t
              sh, sw, transposed ? 1 : 0, packed);
   const int tiles = B * ((H + Cfg::TH_ - 1) / Cfg::TH_) * ((W + TW - 1) / TW);
   const dim3 grid(tiles < cus ? tiles : cus);
+  if (scl_debug_variant / 1000 == 4) relu |= (scl_debug_variant & 3) << 1;
   if (mask)
     SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 3>), grid, dim3(Cfg::NTHR), Cfg::LDS, st,
                (const unsigned short*)x, (const unsigned short*)packed, B, H, W,
-               (unsigned short*)out, bias, 0, (unsigned short*)nullptr,
+               (unsigned short*)out, bias, relu & ~1, (unsigned short*)nullptr,
                (const unsigned short*)mask);
   else if (pooled)
     SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 2>), grid, dim3(Cfg::NTHR), Cfg::LDS, st,
@@ -653,6 +673,7 @@ static int conv3x3_dispatch(const void* x, const void* w, int64_t w_stride_k, in
                             size_t workspace_bytes, void* stream) {
   if (!x || !w || !out || !workspace) return SCL_E_NULL;
   if (mask && (bias || pooled || ((uintptr_t)mask % 16))) return SCL_E_NULL;
+  if ((int64_t)B * H * W * cin >= (int64_t)1 << 31) return SCL_E_SHAPE;   // 32-bit element offsets
   if (pooled && (!bias || ((uintptr_t)pooled % 16))) return SCL_E_NULL;
   if (B < 1 || H < 1 || W < 1 || (int64_t)B * H * W > (int64_t)1 << 30) return SCL_E_SHAPE;
   if (((uintptr_t)x % 16) || ((uintptr_t)out % 16)) return SCL_E_SHAPE;

@@ -169,11 +169,13 @@ __global__ __launch_bounds__(NTHR, 1) void convg_kernel(const unsigned short* __
   // The window of chunk cc + 1 is loaded at tap 0 / 1 of chunk cc and stored four or five
   // steps later, i.e. at least one barrier before a pair can reach into that chunk.
   int win_loaded = 0;                                 // chunk whose window sits in st_x (+1)
+  const int dbg = relu >> 1;            // timing diagnostics (scl_debug_set_variant(3000 + bits))
+  relu &= 1;
 #pragma unroll 1
   for (int s = 0; s < S; s += TPB) {
-    if (s + TPB < S) load_wts(s + TPB);
+    if (s + TPB < S && !(dbg & 1)) load_wts(s + TPB);
     const int cc0 = s / 9, tap0 = s - 9 * cc0;
-    if (tap0 <= 1 && cc0 + 1 < CC) {
+    if (tap0 <= 1 && cc0 + 1 < CC && !(dbg & 2)) {
       load_win(cc0 + 1);
       win_loaded = cc0 + 2;
     }
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(NTHR, 1) void convg_kernel(const unsigned short* __
             acc[2 * j + n] = mfma32b(af[ks2][j], bf[ks2][n], acc[2 * j + n]);
       }
     }
-    if (s + TPB < S) store_wts(((s / TPB) + 1) & 1);
+    if (s + TPB < S && !(dbg & 1)) store_wts(((s / TPB) + 1) & 1);
     if (win_loaded && tap0 >= 4) {                    // stored once, well before tap 8
       store_win((win_loaded - 1) & 1);
       win_loaded = 0;
@@ -297,6 +299,7 @@ static int convg_dispatch(const void* x, const void* w, int64_t w_stride_k, int6
              0, st, (const unsigned short*)w, w_stride_k, w_stride_c, w_stride_h, w_stride_w,
              transposed ? 1 : 0, cin, kout, packed);
   const dim3 grid(B * ((H + BH - 1) / BH) * ((W + BW - 1) / BW), kout / NB);
+  const int dbgbits = scl_debug_variant / 1000 == 3 ? (scl_debug_variant & 3) << 1 : 0;
   if (mask)
     SCL_LAUNCH("convg_kernel", convg_kernel<2>, grid, dim3(NTHR), kConvgLds, st,
                (const unsigned short*)x, (const unsigned short*)packed, B, H, W, cin, kout,
@@ -308,7 +311,7 @@ static int convg_dispatch(const void* x, const void* w, int64_t w_stride_k, int6
   else
     SCL_LAUNCH("convg_kernel", convg_kernel<0>, grid, dim3(NTHR), kConvgLds, st,
                (const unsigned short*)x, (const unsigned short*)packed, B, H, W, cin, kout,
-               (unsigned short*)out, bias, 0, (const unsigned short*)nullptr);
+               (unsigned short*)out, bias, dbgbits, (const unsigned short*)nullptr);
   return scl_launch_status();
 }
 

@@ -330,9 +330,8 @@ class _ConvBiasPoolReLU(torch.autograd.Function):
     def forward(ctx, x, w, bias, link_in=None):
         lib = L.load()
         ctx.link_in = link_in
-        if _own_conv_kind(x, w) == 'reg' and tuple(w.shape[:2]) == (64, 64):
-            # pooled map from the epilogue (the 128-channel variant of that epilogue runs out
-            # of registers and is slower than the plain kernel + the pooling pass)
+        if _own_conv_kind(x, w) == 'reg' and w.shape[0] == w.shape[1]:
+            # conv1_2 / conv2_2: pooled map from the epilogue (no pooling pass over z)
             z, a = conv64(x, w, False, bias=bias, pool=True)
         else:
             z = _conv3x3(x, w).contiguous(memory_format=_CL)

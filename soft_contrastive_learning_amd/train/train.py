@@ -228,7 +228,7 @@ def main(argv=None):
     if flags.optimizer == 'momentum':
         opt = torch.optim.SGD(params, lr=flags.base_lr, momentum=flags.momentum)
     else:
-        opt = torch.optim.Adam(params, lr=flags.base_lr)
+        opt = torch.optim.Adam(params, lr=flags.base_lr, fused=bool(params) and params[0].is_cuda)
     # restore_weights (:882-905) + the slot variables a tf.train.Saver checkpoint carries
     step = checkpoint.load(model, flags.checkpoint, optimizer=opt) if flags.checkpoint else 0
     out_dir = os.path.join(flags.out_root, flags.out_folder or flags.loss)
