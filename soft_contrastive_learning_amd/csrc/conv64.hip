@@ -610,6 +610,153 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// conv_first_wrw_kernel: weight AND bias gradient of the first layer in ONE pass over its
+// 64-channel gradient map (the layer's only large operand: 944 MB at 24 x 480 x 640),
+//   gw[k][c][kh][kw] = sum_p gz[p][k] * x0[p + (kh-1, kw-1)][c],     gb[k] = sum_p gz[p][k],
+// as a GEMM over pixels: A = gz^T (64 channels = two m-tiles, read with ds_read_b64_tr_b16
+// from the two LDS-DMA planes of wrw64_kernel), B[p][n] = im2col of x0 gathered from a
+// [10][34][3+1] halo window, n = 3 * tap + c < 27, column 27 = 1.0 (its product is the bias
+// gradient), columns 28 .. 31 zero.  Wave w takes tile rows 2w, 2w + 1; per-workgroup slabs
+// [64][32] float32 are summed in a fixed order by conv_first_wrw_reduce_kernel.
+constexpr int FW_WIN = WR * WC * F_PIX;               // bf16 per x0 window (1360)
+constexpr int FW_GBUF = 2 * GPLANE;                   // bf16 per staged gz tile (16,384)
+constexpr size_t kFirstWrwLds = (2 * (size_t)FW_GBUF + 2 * (size_t)FW_WIN) * sizeof(unsigned short);
+
+__global__ __launch_bounds__(256, 2) void conv_first_wrw_kernel(
+    const unsigned short* __restrict__ x0, const unsigned short* __restrict__ gz, int B, int H,
+    int W, float* __restrict__ slabs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+  unsigned short* wl = lds + 2 * FW_GBUF;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int q = (lane >> 2) & 3, pp = lane & 3, gq = lane >> 4;
+  const int pix0 = 8 * (gq >> 1) + q, ch0 = 16 * (gq & 1) + 4 * pp;
+  // this lane's im2col column: tap (kh, kw), input channel c
+  const int tap = r / 3, cc = r % 3, kh = tap / 3, kw = tap % 3;
+  const unsigned ones = r == 27 ? 0x3f803f80u : 0u;
+
+  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+  const int per_img = tiles_x * tiles_y;
+  const int ntiles = B * per_img;
+  const unsigned short* zeros = reinterpret_cast<const unsigned short*>(zero_block);
+  const int wid_s = __builtin_amdgcn_readfirstlane(wid);
+
+  // gz tile: 32 chunks of 1 KB (2 planes x 16), eight per wave
+  auto gz_issue = [&](int tile, int buf) {
+    const int b = tile / per_img, t2 = tile % per_img;
+    const int ty = (t2 / tiles_x) * TH, tx = (t2 % tiles_x) * TW;
+    const unsigned base = lds_byte_of(lds) + buf * FW_GBUF * 2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int j = wid_s + 4 * i, plane = j >> 4, chunk = j & 15;
+      const int pix = 16 * chunk + (lane >> 2);
+      const int y = ty + pix / TW, xx = tx + pix % TW;
+      const bool ok = y < H && xx < W;
+      const int off = ((b * H + y) * W + xx) * C64 + 32 * plane + 8 * (lane & 3);
+      glds16(ok ? gz + off : zeros, base + (plane * GPLANE + chunk * 512) * 2);
+    }
+  };
+  // x0 window: 340 pixels x 3 channels, four 2-byte elements per thread
+  unsigned short wreg[4];
+  auto win_load = [&](int tile) {
+    const int b = tile / per_img, t2 = tile % per_img;
+    const int ty = (t2 / tiles_x) * TH, tx = (t2 % tiles_x) * TW;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int idx = v * 256 + threadIdx.x;
+      const int pix = idx / 3, c = idx - 3 * pix;
+      const int y = ty - 1 + pix / WC, xx = tx - 1 + pix % WC;
+      const bool ok = idx < 3 * WR * WC && y >= 0 && y < H && xx >= 0 && xx < W;
+      wreg[v] = ok ? x0[(((int64_t)b * H + y) * W + xx) * 3 + c] : (unsigned short)0;
+    }
+  };
+  auto win_store = [&](int buf) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int idx = v * 256 + threadIdx.x;
+      const int pix = idx / 3, c = idx - 3 * pix;
+      if (idx < 3 * WR * WC) wl[buf * FW_WIN + pix * F_PIX + c] = wreg[v];
+    }
+  };
+
+  f32x16 acc[2] = {zero16(), zero16()};
+  int tile = blockIdx.x;
+  if (tile < ntiles) {
+    gz_issue(tile, 0);
+    win_load(tile);
+    win_store(0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int buf = 0;
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int next = tile + gridDim.x;
+    if (next < ntiles) {
+      gz_issue(next, buf ^ 1);
+      win_load(next);
+    }
+    const unsigned short* gl = lds + buf * FW_GBUF + pix0 * WPL + ch0;
+    const unsigned short* wb = wl + buf * FW_WIN + (kh * WC + kw + 8 * h) * F_PIX + cc;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int s_ = 4 * wid + u, ry = s_ >> 1, cx = 16 * (s_ & 1);
+      const u32x4 a0 = tr_pair(gl + (ry * TW + cx) * WPL, 4 * WPL);
+      const u32x4 a1 = tr_pair(gl + GPLANE + (ry * TW + cx) * WPL, 4 * WPL);
+      const unsigned short* wp = wb + (ry * WC + cx) * F_PIX;
+      u32x4 bf;
+      bf.x = r < 27 ? (unsigned)wp[0 * F_PIX] | ((unsigned)wp[1 * F_PIX] << 16) : ones;
+      bf.y = r < 27 ? (unsigned)wp[2 * F_PIX] | ((unsigned)wp[3 * F_PIX] << 16) : ones;
+      bf.z = r < 27 ? (unsigned)wp[4 * F_PIX] | ((unsigned)wp[5 * F_PIX] << 16) : ones;
+      bf.w = r < 27 ? (unsigned)wp[6 * F_PIX] | ((unsigned)wp[7 * F_PIX] << 16) : ones;
+      acc[0] = mfma32b(a0, bf, acc[0]);
+      acc[1] = mfma32b(a1, bf, acc[1]);
+    }
+    if (next < ntiles) win_store(buf ^ 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  // fixed-order sum of the four waves' partials through LDS (the staging buffers are free)
+  float* red = reinterpret_cast<float*>(lds);            // [4][64][32]
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int qq = 0; qq < 16; ++qq)
+      red[(wid * 64 + 32 * mt + acc_row(qq, h)) * 32 + r] = acc[mt][qq];
+  __syncthreads();
+  float* out = slabs + (int64_t)blockIdx.x * 2048;
+  for (int e = threadIdx.x; e < 2048; e += 256)
+    out[e] = (red[e] + red[2048 + e]) + (red[4096 + e] + red[6144 + e]);
+}
+
+// gw / gb from the slabs: grid 8, block 256 -> element e = (k, n); n < 27: weight tap
+// (kh, kw), input channel c, written as bf16 at the weight's strides; n == 27: bias gradient.
+__global__ __launch_bounds__(256) void conv_first_wrw_reduce_kernel(
+    const float* __restrict__ slabs, int nslab, int64_t sk, int64_t sc, int64_t sh, int64_t sw,
+    unsigned short* __restrict__ gw, float* __restrict__ gb) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int i = 0;
+  for (; i + 3 < nslab; i += 4) {
+    s0 += slabs[(int64_t)i * 2048 + e];
+    s1 += slabs[(int64_t)(i + 1) * 2048 + e];
+    s2 += slabs[(int64_t)(i + 2) * 2048 + e];
+    s3 += slabs[(int64_t)(i + 3) * 2048 + e];
+  }
+  for (; i < nslab; ++i) s0 += slabs[(int64_t)i * 2048 + e];
+  const float s = (s0 + s1) + (s2 + s3);
+  const int k = e >> 5, n = e & 31;
+  if (n < 27) {
+    const int tap = n / 3, c = n % 3;
+    gw[k * sk + c * sc + (tap / 3) * sh + (tap % 3) * sw] = f32_to_bf16(s);
+  } else if (n == 27) {
+    gb[k] = s;
+  }
+}
+
 }  // namespace
 
 static int conv64_cus();
@@ -827,5 +974,39 @@ extern "C" int scl_conv_first(const float* img, const float* avg, const void* w,
   SCL_LAUNCH("conv_first_kernel", conv_first_kernel, dim3(grid), dim3(256), kFirstLds,
              (hipStream_t)stream, img, avg, (const unsigned short*)w, w_stride_k, w_stride_c,
              w_stride_h, w_stride_w, bias, B, H, W, (unsigned short*)x0, (unsigned short*)y);
+  return scl_launch_status();
+}
+
+static int first_wrw_grid(int tiles, int cus) { return tiles < 2 * cus ? tiles : 2 * cus; }
+
+extern "C" size_t scl_conv_first_wrw_workspace_bytes(void) {
+  return scl_round256((size_t)2 * 1024 * 2048 * sizeof(float));      // up to 2048 slabs
+}
+
+extern "C" int scl_conv_first_wrw(const void* x0, const void* gz, int B, int H, int W, void* gw,
+                                  int64_t w_stride_k, int64_t w_stride_c, int64_t w_stride_h,
+                                  int64_t w_stride_w, float* gb, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  if (!x0 || !gz || !gw || !gb || !workspace) return SCL_E_NULL;
+  if (B < 1 || H < 1 || W < 1 || (int64_t)B * H * W * 64 >= (int64_t)1 << 31) return SCL_E_SHAPE;
+  if ((uintptr_t)gz % 16) return SCL_E_SHAPE;
+  if (!scl_aligned256(workspace) || workspace_bytes < scl_conv_first_wrw_workspace_bytes())
+    return SCL_E_WORKSPACE;
+  static std::once_flag once;
+  static int cus = 256;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_first_wrw_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFirstWrwLds);
+    cus = conv64_cus();
+    if (cus > 1024) cus = 1024;
+  });
+  const int tiles = B * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+  const int grid = first_wrw_grid(tiles, cus);
+  hipStream_t st = (hipStream_t)stream;
+  SCL_LAUNCH("conv_first_wrw_kernel", conv_first_wrw_kernel, dim3(grid), dim3(256), kFirstWrwLds,
+             st, (const unsigned short*)x0, (const unsigned short*)gz, B, H, W, (float*)workspace);
+  SCL_LAUNCH("conv_first_wrw_reduce_kernel", conv_first_wrw_reduce_kernel, dim3(8), dim3(256), 0,
+             st, (const float*)workspace, grid, w_stride_k, w_stride_c, w_stride_h, w_stride_w,
+             (unsigned short*)gw, gb);
   return scl_launch_status();
 }

@@ -386,6 +386,25 @@ def avg_rgb_grad(gz, w, gb):
     return -torch.einsum('ockl,okl->c', w.float(), s)
 
 
+def first_wrw(x0, gz, w_like, gb=None):
+    """conv1_1's weight gradient (bf16, strides of ``w_like``) and bias gradient (float32 [64],
+    written into ``gb`` when given) from x0 [B,3,H,W] (NHWC storage) and gz [B,64,H,W]
+    (channels-last): ``scl_conv_first_wrw``."""
+    lib = L.load()
+    L.require_device(x0, gz)
+    x0 = x0.permute(0, 2, 3, 1).contiguous()
+    gz = gz.contiguous(memory_format=_CL)
+    b, h, wd, _ = x0.shape
+    gw = torch.empty_like(w_like)
+    if gb is None:
+        gb = torch.empty(64, dtype=torch.float32, device=gz.device)
+    ws = L.workspace(lib.scl_conv_first_wrw_workspace_bytes(), gz.device)
+    sk, sc, sh, sw = gw.stride()
+    L.check(lib.scl_conv_first_wrw(L.ptr(x0), L.ptr(gz), b, h, wd, L.ptr(gw), sk, sc, sh, sw,
+                                   L.ptr(gb), L.ptr(ws), ws.numel(), L.stream_of(gz)))
+    return gw
+
+
 class _FirstConv(torch.autograd.Function):
     """(img - average_rgb) -> conv1_1 -> +bias -> ReLU (model/nets.py:22-24, 39) in one
     node: the only consumer of the image gradient is the trainable mean, whose gradient has
@@ -427,11 +446,20 @@ class _FirstConv(torch.autograd.Function):
         gb = torch.empty(c, dtype=torch.float32, device=gy.device)
         ws = L.workspace(lib.scl_vgg_workspace_bytes(c), gy.device)
         masked = ctx.link_out is not None and ctx.link_out.take(gy)
+        own_wrw = (USE_CONV64 and USE_FIRST and gy.dtype == torch.bfloat16
+                   and x0.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
+                   and tuple(w.shape) == (64, 3, 3, 3))
         gz = gy if masked else torch.empty_like(gy)
-        L.check(lib.scl_vgg_act_bwd(L.ptr(gy), None if masked else L.ptr(y), _glue_dtype(gy),
-                                    b * h * wd, c, None if masked else L.ptr(gz), L.ptr(gb), L.ptr(ws),
-                                    ws.numel(), L.stream_of(gy)))
-        _, gw = _conv3x3_backward(gz, x0, w, False)
+        if not (masked and own_wrw):
+            L.check(lib.scl_vgg_act_bwd(L.ptr(gy), None if masked else L.ptr(y), _glue_dtype(gy),
+                                        b * h * wd, c, None if masked else L.ptr(gz), L.ptr(gb),
+                                        L.ptr(ws), ws.numel(), L.stream_of(gy)))
+        if own_wrw:
+            # weight and bias gradient in one pass over gz (the bias gradient is one more
+            # column of the same product)
+            gw = first_wrw(x0, gz, w, gb)
+        else:
+            _, gw = _conv3x3_backward(gz, x0, w, False)
         return None, avg_rgb_grad(gz, w, gb), gw, gb, None, None
 
 

@@ -365,3 +365,25 @@ def test_masked_backward_chain_equals_separate_masking_pass(dev):
     plain = run(False)
     for a, b_ in zip(linked, plain):
         assert torch.equal(a, b_)
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 40), (1, 13, 37), (2, 120, 160)])
+def test_first_layer_weight_and_bias_gradient(dev, shape):
+    """scl_conv_first_wrw: conv1_1's weight gradient and bias gradient from one pass over gz."""
+    from soft_contrastive_learning_amd.model import nets
+    b, h, w = shape
+    g = torch.Generator().manual_seed(43)
+    x0 = torch.randn(b, h, w, 3, generator=g).to(dev).bfloat16().permute(0, 3, 1, 2)
+    gz = torch.randn(b, 64, h, w, generator=g).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    gz[gz.abs() < 0.5] = 0
+    wf = torch.zeros(64, 3, 3, 3, device=dev, requires_grad=True)
+    bf = torch.zeros(64, device=dev, requires_grad=True)
+    torch.nn.functional.conv2d(x0.float(), wf, bf, padding=1).backward(gz.float())
+    like = torch.empty(64, 3, 3, 3, device=dev, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gb = torch.empty(64, device=dev)
+    gw = nets.first_wrw(x0, gz, like, gb)
+    assert gw.shape == wf.grad.shape and gw.stride() == like.stride()
+    assert float((gw.float() - wf.grad).abs().max() / wf.grad.abs().max()) < 6e-3
+    assert float((gb - bf.grad).abs().max() / bf.grad.abs().max()) < 1e-5
+    gb2 = torch.empty(64, device=dev)
+    assert torch.equal(gw, nets.first_wrw(x0, gz, like, gb2)) and torch.equal(gb, gb2)
