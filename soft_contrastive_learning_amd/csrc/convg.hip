@@ -33,15 +33,16 @@ constexpr int GWR = BH + 2, GWC = BW + 4;           // halo window: 42 columns u
 constexpr int CCH = 32;                             // channels per staged chunk
 constexpr int GPIX = CCH + 8;                       // bf16 per staged pixel / weight row (80 B)
 constexpr int GWIN = GWR * GWC * GPIX;              // bf16 per window buffer (24,640)
-constexpr int GWP = GWR * GWC * 4;                  // 16-byte pieces per window chunk (2464)
 constexpr int NTHR = 512;                           // 8 waves: two per SIMD
-constexpr int GNPT = (GWP + NTHR - 1) / NTHR;       // 5
 constexpr int NB = 128;                             // output channels per workgroup
 constexpr int GWT = NB * GPIX;                      // bf16 per weight buffer (5120)
 constexpr int GSCR_LD = 40;
 constexpr int GSCR = 32 * GSCR_LD;
-constexpr int TPB = 2;                              // (chunk, tap) steps per barrier
-constexpr size_t kConvgLds = (2 * (size_t)GWIN + 2 * TPB * (size_t)GWT + 8 * (size_t)GSCR) * 2;
+constexpr int TPB = 3;                              // (chunk, tap) steps per barrier: one
+                                                    // tap row of a chunk
+// two windows + two weight buffers; the epilogue's per-wave scratch reuses the windows
+constexpr size_t kConvgLds = (2 * (size_t)GWIN + 2 * TPB * (size_t)GWT) * 2;   // 160,000 B
+static_assert(8 * GSCR <= 2 * GWIN, "epilogue scratch must fit the window buffers");
 constexpr int NMT = 15;                             // m-tiles: 3 rows x 5 cols of 4 x 8 pixels
 
 // Lane -> pixel of a 4 x 8 m-tile.  The hardware serves a ds_read_b128 in the lane groups
@@ -61,22 +62,27 @@ __device__ __forceinline__ f32x16 mfma32b(u32x4 a, u32x4 b, f32x16 c) {
                                                  __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// Weights -> [n-block][chunk][tap][k 128][c 32] bf16 (8 KB slices in the order the kernel
-// stages them).  transposed as in conv64.hip.
+// Weights -> [n-block][chunk][tap][k 128][c 32 + 8 pad] bf16: the exact LDS image of a step
+// (10 KB slices in the order the kernel stages them, copied by LDS-DMA as they are).
+// transposed as in conv64.hip.
 __global__ __launch_bounds__(256) void convg_pack_kernel(const unsigned short* __restrict__ w,
                                                          int64_t sk, int64_t sc, int64_t sh,
                                                          int64_t sw, int transposed, int cin,
                                                          int kout,
                                                          unsigned short* __restrict__ packed) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t total = (int64_t)9 * cin * kout;
+  const int64_t total = (int64_t)9 * (cin / CCH) * kout * GPIX;
   if (idx >= total) return;
-  const int c = idx & 31, k = (idx >> 5) & 127;
-  const int64_t rest = idx >> 12;                    // (nb * CC + cc) * 9 + tap
+  const int c = idx % GPIX, k = (idx / GPIX) & 127;
+  const int64_t rest = idx / (GPIX * 128);           // (nb * CC + cc) * 9 + tap
   const int tap = rest % 9;
   const int cc = (rest / 9) % (cin / CCH), nb = rest / 9 / (cin / CCH);
   const int kh = tap / 3, kw = tap % 3;
   const int ci = CCH * cc + c, co = NB * nb + k;
+  if (c >= CCH) {
+    packed[idx] = 0;
+    return;
+  }
   int64_t off;
   if (!transposed)
     off = co * sk + ci * sc + kh * sh + kw * sw;
@@ -84,6 +90,28 @@ __global__ __launch_bounds__(256) void convg_pack_kernel(const unsigned short* _
     off = ci * sk + co * sc + (2 - kh) * sh + (2 - kw) * sw;
   packed[idx] = w[off];
 }
+
+__device__ uint4 zero_block[4];                      // never written: zeros
+
+// LDS-DMA (see conv64.hip): 64 lanes x 16 bytes from per-lane global addresses into 1 KB of
+// consecutive LDS at the wave-uniform byte address lds_byte.  Inline asm, so hipcc does not
+// order it against LDS reads of the other buffer; the kernel counts vmcnt itself.
+__device__ __forceinline__ void glds16(const unsigned short* src, unsigned lds_byte) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(src), "s"(lds_byte)
+      : "memory");
+}
+__device__ __forceinline__ unsigned lds_byte_of(const unsigned short* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned short*)p;
+}
+constexpr int GSLOTS = GWR * GWC * 5;                // 16-byte slots of a window (4 data + pad)
+constexpr int GCHUNKS = (GSLOTS + 63) / 64;          // 1-KB DMA chunks per window (49)
+constexpr int GNI = (GCHUNKS + 7) / 8;               // per wave (7)
+constexpr int WCHK = TPB * GWT * 2 / 1024;           // chunks per weight step group (30)
 
 // grid (pixel blocks, kout / 128); block 512.  EPI: 0 plain, 1 + bias (+ ReLU),
 // 2 out = conv * [mask > 0] (the ReLU' of the layer below, for backward-data).
@@ -99,45 +127,43 @@ __global__ __launch_bounds__(NTHR, 1) void convg_kernel(const unsigned short* __
   unsigned short* wts = lds + 2 * GWIN;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
-  unsigned short* scr = wts + 2 * TPB * GWT + wid * GSCR;
+  unsigned short* scr = lds + wid * GSCR;             // after the K loop only
   const int nb = blockIdx.y;
   const int blocks_x = (W + BW - 1) / BW, blocks_y = (H + BH - 1) / BH;
   const int b = blockIdx.x / (blocks_x * blocks_y), t2 = blockIdx.x % (blocks_x * blocks_y);
   const int y0 = (t2 / blocks_x) * BH, x0 = (t2 % blocks_x) * BW;
   const int CC = cin / CCH, S = 9 * CC;
-  u32x4 st_w[TPB], st_x[GNPT];
-  // weight slices of steps s, s + 1 (16 KB contiguous in the packed image)
-  auto load_wts = [&](int s) {
-    const unsigned short* src = packed + ((int64_t)nb * S + s) * (NB * CCH);
+  // Staging is LDS-DMA.  Weights: the packed image IS the LDS image, 20 chunks of 1 KB per
+  // step pair.  Window: lane l of chunk j owns slot 64 j + l = (pixel, piece), piece 4 the
+  // pad (not fetched); where that pixel lies in the image is fixed for the workgroup.
+  const int wid_s = __builtin_amdgcn_readfirstlane(wid);
+  const unsigned short* zeros = reinterpret_cast<const unsigned short*>(zero_block);
+  int woff[GNI];            // element offset at chunk 0; -1 outside the image; -2 not fetched
 #pragma unroll
-    for (int v = 0; v < TPB; ++v)
-      st_w[v] = *reinterpret_cast<const u32x4*>(src + (v * NTHR + threadIdx.x) * 8);
-  };
-  auto store_wts = [&](int buf) {
+  for (int i = 0; i < GNI; ++i) {
+    const int slot = 64 * (wid_s + 8 * i) + lane;
+    const int pix = slot / 5, piece = slot - 5 * pix;
+    const int y = y0 - 1 + pix / GWC, xx = x0 - 1 + pix % GWC;
+    const bool inimg = y >= 0 && y < H && xx >= 0 && xx < W;
+    woff[i] = (piece == 4 || pix >= GWR * GWC) ? -2
+              : inimg ? ((b * H + y) * W + xx) * cin + 8 * piece : -1;
+  }
+  auto issue_win = [&](int cc, int buf) {
+    const unsigned base = lds_byte_of(win) + buf * GWIN * 2;
 #pragma unroll
-    for (int v = 0; v < TPB; ++v) {
-      const int idx = v * NTHR + threadIdx.x;       // [step 2][k 128][4 pieces]
-      *reinterpret_cast<u32x4*>(wts + buf * TPB * GWT + (idx >> 2) * GPIX + 8 * (idx & 3)) = st_w[v];
+    for (int i = 0; i < GNI; ++i) {
+      const int j = wid_s + 8 * i;
+      if (j < GCHUNKS && woff[i] != -2)
+        glds16(woff[i] >= 0 ? x + woff[i] + CCH * cc : zeros, base + j * 1024);
     }
   };
-  auto load_win = [&](int cc) {
+  auto issue_wts = [&](int s, int buf) {
+    const unsigned short* src = packed + ((int64_t)nb * S + s) * GWT + lane * 8;
+    const unsigned base = lds_byte_of(wts) + buf * TPB * GWT * 2;
 #pragma unroll
-    for (int v = 0; v < GNPT; ++v) {
-      const int idx = v * NTHR + threadIdx.x;
-      const int pix = idx >> 2, c4 = idx & 3;
-      const int y = y0 - 1 + pix / GWC, xx = x0 - 1 + pix % GWC;
-      const bool ok = idx < GWP && y >= 0 && y < H && xx >= 0 && xx < W;
-      st_x[v] = ok ? *reinterpret_cast<const u32x4*>(
-                         x + (((int64_t)b * H + y) * W + xx) * cin + CCH * cc + 8 * c4)
-                   : u32x4{0u, 0u, 0u, 0u};
-    }
-  };
-  auto store_win = [&](int buf) {
-#pragma unroll
-    for (int v = 0; v < GNPT; ++v) {
-      const int idx = v * NTHR + threadIdx.x;
-      if (idx < GWP)
-        *reinterpret_cast<u32x4*>(win + buf * GWIN + (idx >> 2) * GPIX + 8 * (idx & 3)) = st_x[v];
+    for (int i = 0; i < (WCHK + 7) / 8; ++i) {
+      const int j = wid_s + 8 * i;
+      if (j < WCHK) glds16(src + j * 512, base + j * 1024);
     }
   };
 
@@ -145,10 +171,9 @@ __global__ __launch_bounds__(NTHR, 1) void convg_kernel(const unsigned short* __
 #pragma unroll
   for (int mt = 0; mt < 8; ++mt) acc[mt] = zero16();
 
-  load_win(0);
-  load_wts(0);
-  store_win(0);
-  store_wts(0);
+  issue_wts(0, 0);
+  issue_win(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   // Wave (mg, ng) of the 8 owns m-tiles 4 mg .. 4 mg + 3 (the block has 15: the last slot of
@@ -165,20 +190,19 @@ __global__ __launch_bounds__(NTHR, 1) void convg_kernel(const unsigned short* __
   }
   const int lane_a = (tile_row(r) * GWC + tile_col(r)) * GPIX + 8 * h;
   const int lane_b = (64 * ng + r) * GPIX + 8 * h;
-  // S = 9 * CC is even (CC = cin / 32 is even for every supported shape): pairs of steps.
-  // The window of chunk cc + 1 is loaded at tap 0 / 1 of chunk cc and stored four or five
-  // steps later, i.e. at least one barrier before a pair can reach into that chunk.
-  int win_loaded = 0;                                 // chunk whose window sits in st_x (+1)
+  // S = 9 * CC steps in groups of three (one tap row of a chunk) per barrier.
+  // The DMA of the next group's weights runs under this group; the window of chunk cc + 1 is
+  // issued (after the weights) at tap row 0 of chunk cc and may stay in flight across this
+  // group's barrier — the DMAs complete in order, so the counted wait below covers the weights
+  // and the next group's full wait covers the window, two groups before it is read.
   const int dbg = relu >> 1;            // timing diagnostics (scl_debug_set_variant(3000 + bits))
   relu &= 1;
 #pragma unroll 1
   for (int s = 0; s < S; s += TPB) {
-    if (s + TPB < S && !(dbg & 1)) load_wts(s + TPB);
+    if (s + TPB < S && !(dbg & 1)) issue_wts(s + TPB, ((s / TPB) + 1) & 1);
     const int cc0 = s / 9, tap0 = s - 9 * cc0;
-    if (tap0 <= 1 && cc0 + 1 < CC && !(dbg & 2)) {
-      load_win(cc0 + 1);
-      win_loaded = cc0 + 2;
-    }
+    const bool win_issued = tap0 == 0 && cc0 + 1 < CC && !(dbg & 2);
+    if (win_issued) issue_win(cc0 + 1, (cc0 + 1) & 1);
 #pragma unroll
     for (int u = 0; u < TPB; ++u) {
       const int su = s + u;
@@ -212,11 +236,12 @@ __global__ __launch_bounds__(NTHR, 1) void convg_kernel(const unsigned short* __
             acc[2 * j + n] = mfma32b(af[ks2][j], bf[ks2][n], acc[2 * j + n]);
       }
     }
-    if (s + TPB < S && !(dbg & 1)) store_wts(((s / TPB) + 1) & 1);
-    if (win_loaded && tap0 >= 4) {                    // stored once, well before tap 8
-      store_win((win_loaded - 1) & 1);
-      win_loaded = 0;
-    }
+    if (!win_issued)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (wid_s < GCHUNKS - 8 * (GNI - 1))           // this wave issued GNI window chunks
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GNI) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GNI - 1) : "memory");
     __syncthreads();
   }
 
@@ -266,7 +291,7 @@ __global__ __launch_bounds__(NTHR, 1) void convg_kernel(const unsigned short* __
 
 extern "C" size_t scl_convg_workspace_bytes(int cin, int kout) {
   if (cin < 32 || kout < 128 || cin % 32 || kout % 128 || cin > 1024 || kout > 1024) return 0;
-  return scl_round256((size_t)9 * cin * kout * sizeof(unsigned short));
+  return scl_round256((size_t)9 * (cin / CCH) * kout * GPIX * sizeof(unsigned short));
 }
 
 // Same contract as scl_conv3x3_fused / scl_conv3x3_masked (include/scl_hip.h) without the
@@ -282,6 +307,7 @@ static int convg_dispatch(const void* x, const void* w, int64_t w_stride_k, int6
   if (need == 0 || B < 1 || H < 1 || W < 1 || (int64_t)B * H * W > (int64_t)1 << 30)
     return SCL_E_SHAPE;
   if (((uintptr_t)x % 16) || ((uintptr_t)out % 16)) return SCL_E_SHAPE;
+  if ((int64_t)B * H * W * cin >= (int64_t)1 << 31) return SCL_E_SHAPE;   // 32-bit offsets
   if (!scl_aligned256(workspace) || workspace_bytes < need) return SCL_E_WORKSPACE;
   static std::once_flag once;
   std::call_once(once, [] {
@@ -294,7 +320,7 @@ static int convg_dispatch(const void* x, const void* w, int64_t w_stride_k, int6
   });
   hipStream_t st = (hipStream_t)stream;
   unsigned short* packed = (unsigned short*)workspace;
-  const int64_t total = (int64_t)9 * cin * kout;
+  const int64_t total = (int64_t)9 * (cin / CCH) * kout * GPIX;
   SCL_LAUNCH("convg_pack_kernel", convg_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256),
              0, st, (const unsigned short*)w, w_stride_k, w_stride_c, w_stride_h, w_stride_w,
              transposed ? 1 : 0, cin, kout, packed);
