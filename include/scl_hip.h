@@ -273,6 +273,22 @@ int scl_convg(const void* x, const void* w, int64_t w_stride_k, int64_t w_stride
               int cin, int kout, void* out, const float* bias, int relu, void* workspace,
               size_t workspace_bytes, void* stream);
 
+/* conv -> +bias -> max-pool 2x2/2 -> ReLU (model/nets.py:40-42) WITHOUT writing the full-size
+ * convolution output: pooled [B,H/2,W/2,kout] bf16 = relu(maxpool2x2(conv) + bias) and
+ * pool_idx [B,H/2,W/2,kout] uint8 = window position 2*dy + dx of the first maximum in raster
+ * order (on the float32 accumulators), which is all the backward pass needs
+ * (scl_vgg_pool_bwd_idx).  Shapes and workspace of scl_conv3x3; forward only. */
+int scl_conv3x3_pool_idx(const void* x, const void* w, int64_t w_stride_k, int64_t w_stride_c,
+                         int64_t w_stride_h, int64_t w_stride_w, int B, int H, int W, int cin,
+                         int kout, const float* bias, void* pooled, void* pool_idx,
+                         void* workspace, size_t workspace_bytes, void* stream);
+/* Pool + ReLU backward from that index map: gz [B,H,W,C] = g * [a > 0] at the stored window
+ * position, zero elsewhere (and on rows / columns no window covers); bias_grad[c] = sum of
+ * g * [a > 0].  Arguments as scl_vgg_pool_bwd with idx in place of z. */
+int scl_vgg_pool_bwd_idx(const void* g, const void* a, const void* idx, int dtype, int B, int H,
+                         int W, int C, void* gz, float* bias_grad, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
 /* Backward-data with the ReLU' of the layer below in the epilogue (the backward of
  * model/nets.py:39's relu chained to the conv beneath it): out = conv(x, w) * [mask > 0],
  * mask [B,H,W,kout] bf16 the post-activation map the gradient flows into — saves the separate

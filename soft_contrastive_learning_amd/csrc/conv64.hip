@@ -120,7 +120,8 @@ __global__ __launch_bounds__(256) void conv3x3_pack_kernel(const unsigned short*
 
 // grid = number of CUs (persistent); block 256.  EPI (compile-time, so that the plain kernel
 // keeps its register allocation): 0 plain, 1 + bias (+ ReLU), 2 raw + pooled output,
-// 3 out = conv * [mask > 0] (the ReLU' of the layer below, for backward-data).
+// 3 out = conv * [mask > 0] (the ReLU' of the layer below, for backward-data),
+// 4 pooled output + the window position of each maximum (one byte), no full-size output.
 template <int CIN, int KOUT, int EPI>
 __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(const unsigned short* __restrict__ x,
                                                          const unsigned short* __restrict__ packed,
@@ -128,7 +129,8 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
                                                          unsigned short* __restrict__ out,
                                                          const float* __restrict__ bias, int relu,
                                                          unsigned short* __restrict__ pooled,
-                                                         const unsigned short* __restrict__ mask) {
+                                                         const unsigned short* __restrict__ mask,
+                                                         unsigned char* __restrict__ pidx) {
   using Cfg = ConvCfg<CIN, KOUT>;
   constexpr int TH_ = Cfg::TH_, PIX = Cfg::PIX, WIN_ = Cfg::WIN_, KS = Cfg::KS, MT = Cfg::MT;
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
@@ -139,7 +141,7 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
   // epilogue fusions (lane r <-> output channel 32 nt + r):
   //   pooled == NULL: out = acc (+ bias) (ReLU if relu)            conv + bias + activation
   //   pooled != NULL: out = acc raw, pooled = relu(max2x2(acc) + bias)   conv + pool + ReLU
-  const float bias_r = (EPI == 1 || EPI == 2) ? bias[32 * nt + r] : 0.f;
+  const float bias_r = (EPI == 1 || EPI == 2 || EPI == 4) ? bias[32 * nt + r] : 0.f;
   const float add_r = EPI == 1 ? bias_r : 0.f;
 
   // the wave's weight slice: KS fragments of 16 bytes per lane
@@ -226,7 +228,7 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
     const int b = tile / per_img, t2 = tile % per_img;
     const int oy0 = (t2 / tiles_x) * TH_ + MT * part, ox0 = (t2 % tiles_x) * TW;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+    for (int mt = 0; mt < (EPI == 4 ? 0 : MT); ++mt) {
       // 32 pixels x 64 bytes: lane -> pixel lane >> 1, 32-byte half lane & 1
       const int px = lane >> 1, hf = lane & 1;
       const int oy = oy0 + mt, ox = ox0 + px;
@@ -256,27 +258,39 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
         *reinterpret_cast<u32x4*>(out + o_off + 8) = v1;
       }
     }
-    if (EPI == 2) {
+    if (EPI == 2 || EPI == 4) {
       // 2x2 / stride 2 max-pool of the raw outputs, lane-local: rows mt, mt + 1 are two
       // accumulators, columns acc_row(q, h), acc_row(q + 1, h) two registers (q even)
       const int PH2 = H / 2, PW2 = W / 2;
+      unsigned char* scr8 = reinterpret_cast<unsigned char*>(scr + 16 * SCR_LD);   // [16][32]
 #pragma unroll
       for (int mp = 0; mp < MT / 2; ++mp) {
 #pragma unroll
         for (int q = 0; q < 16; q += 2) {
           const float m0 = fmaxf(acc[2 * mp][q], acc[2 * mp][q + 1]);
           const float m1 = fmaxf(acc[2 * mp + 1][q], acc[2 * mp + 1][q + 1]);
-          scr[(acc_row(q, h) >> 1) * SCR_LD + r] = f32_to_bf16(fmaxf(fmaxf(m0, m1) + bias_r, 0.f));
+          const float m = fmaxf(m0, m1);
+          scr[(acc_row(q, h) >> 1) * SCR_LD + r] = f32_to_bf16(fmaxf(m + bias_r, 0.f));
+          if (EPI == 4) {
+            // first maximum in raster order (0,0), (0,1), (1,0), (1,1)
+            const int k = acc[2 * mp][q] == m ? 0 : acc[2 * mp][q + 1] == m ? 1
+                          : acc[2 * mp + 1][q] == m ? 2 : 3;
+            scr8[(acc_row(q, h) >> 1) * 32 + r] = (unsigned char)k;
+          }
         }
         __builtin_amdgcn_wave_barrier();
         // 16 pooled pixels x 64 bytes: lane -> pixel lane >> 2, 16-byte quarter lane & 3
         const int px = lane >> 2, qu = lane & 3;
         const u32x4 v = *reinterpret_cast<const u32x4*>(scr + px * SCR_LD + 8 * qu);
+        uint2 kv = uint2{0u, 0u};
+        if (EPI == 4) kv = *reinterpret_cast<const uint2*>(scr8 + px * 32 + 8 * qu);
         __builtin_amdgcn_wave_barrier();
         const int py = (oy0 >> 1) + mp, pxg = (ox0 >> 1) + px;
-        if (py < PH2 && pxg < PW2)
-          *reinterpret_cast<u32x4*>(pooled + (((int64_t)b * PH2 + py) * PW2 + pxg) * KOUT +
-                                    32 * nt + 8 * qu) = v;
+        if (py < PH2 && pxg < PW2) {
+          const int64_t po = (((int64_t)b * PH2 + py) * PW2 + pxg) * KOUT + 32 * nt + 8 * qu;
+          *reinterpret_cast<u32x4*>(pooled + po) = v;
+          if (EPI == 4) *reinterpret_cast<uint2*>(pidx + po) = kv;
+        }
       }
     }
 
@@ -764,7 +778,7 @@ static int conv64_cus();
 template <int CIN, int KOUT>
 int launch_conv3x3(const void* x, const void* w, int64_t sk, int64_t sc, int64_t sh, int64_t sw,
                    int transposed, int B, int H, int W, void* out, const float* bias, int relu,
-                   void* pooled, const void* mask, void* workspace, hipStream_t st) {
+                   void* pooled, const void* mask, void* pidx, void* workspace, hipStream_t st) {
   using Cfg = ConvCfg<CIN, KOUT>;
   static std::once_flag once;
   static int cus = 256;
@@ -777,6 +791,8 @@ int launch_conv3x3(const void* x, const void* w, int64_t sk, int64_t sc, int64_t
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<CIN, KOUT, 3>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<CIN, KOUT, 4>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
     cus = conv64_cus();
   });
   unsigned short* packed = (unsigned short*)workspace;
@@ -786,26 +802,31 @@ int launch_conv3x3(const void* x, const void* w, int64_t sk, int64_t sc, int64_t
   const int tiles = B * ((H + Cfg::TH_ - 1) / Cfg::TH_) * ((W + TW - 1) / TW);
   const dim3 grid(tiles < cus ? tiles : cus);
   if (scl_debug_variant / 1000 == 4) relu |= (scl_debug_variant & 3) << 1;
-  if (mask)
+  if (pidx)
+    SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 4>), grid, dim3(Cfg::NTHR), Cfg::LDS, st,
+               (const unsigned short*)x, (const unsigned short*)packed, B, H, W,
+               (unsigned short*)nullptr, bias, relu & ~1, (unsigned short*)pooled,
+               (const unsigned short*)nullptr, (unsigned char*)pidx);
+  else if (mask)
     SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 3>), grid, dim3(Cfg::NTHR), Cfg::LDS, st,
                (const unsigned short*)x, (const unsigned short*)packed, B, H, W,
                (unsigned short*)out, bias, relu & ~1, (unsigned short*)nullptr,
-               (const unsigned short*)mask);
+               (const unsigned short*)mask, (unsigned char*)nullptr);
   else if (pooled)
     SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 2>), grid, dim3(Cfg::NTHR), Cfg::LDS, st,
                (const unsigned short*)x, (const unsigned short*)packed, B, H, W,
                (unsigned short*)out, bias, relu, (unsigned short*)pooled,
-               (const unsigned short*)nullptr);
+               (const unsigned short*)nullptr, (unsigned char*)nullptr);
   else if (bias)
     SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 1>), grid, dim3(Cfg::NTHR), Cfg::LDS, st,
                (const unsigned short*)x, (const unsigned short*)packed, B, H, W,
                (unsigned short*)out, bias, relu, (unsigned short*)pooled,
-               (const unsigned short*)nullptr);
+               (const unsigned short*)nullptr, (unsigned char*)nullptr);
   else
     SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 0>), grid, dim3(Cfg::NTHR), Cfg::LDS, st,
                (const unsigned short*)x, (const unsigned short*)packed, B, H, W,
                (unsigned short*)out, bias, relu, (unsigned short*)pooled,
-               (const unsigned short*)nullptr);
+               (const unsigned short*)nullptr, (unsigned char*)nullptr);
   return scl_launch_status();
 }
 
@@ -816,14 +837,15 @@ extern "C" size_t scl_conv3x3_workspace_bytes(void) {
 static int conv3x3_dispatch(const void* x, const void* w, int64_t w_stride_k, int64_t w_stride_c,
                             int64_t w_stride_h, int64_t w_stride_w, int transposed, int B, int H,
                             int W, int cin, int kout, void* out, const float* bias, int relu,
-                            void* pooled, const void* mask, void* workspace,
+                            void* pooled, const void* mask, void* pidx, void* workspace,
                             size_t workspace_bytes, void* stream) {
-  if (!x || !w || !out || !workspace) return SCL_E_NULL;
+  if (!x || !w || (!out && !pidx) || !workspace) return SCL_E_NULL;
+  if (pidx && (!pooled || !bias || mask || ((uintptr_t)pidx % 8))) return SCL_E_NULL;
   if (mask && (bias || pooled || ((uintptr_t)mask % 16))) return SCL_E_NULL;
   if ((int64_t)B * H * W * cin >= (int64_t)1 << 31) return SCL_E_SHAPE;   // 32-bit element offsets
   if (pooled && (!bias || ((uintptr_t)pooled % 16))) return SCL_E_NULL;
   if (B < 1 || H < 1 || W < 1 || (int64_t)B * H * W > (int64_t)1 << 30) return SCL_E_SHAPE;
-  if (((uintptr_t)x % 16) || ((uintptr_t)out % 16)) return SCL_E_SHAPE;
+  if (((uintptr_t)x % 16) || (out && ((uintptr_t)out % 16))) return SCL_E_SHAPE;
   if (!scl_aligned256(workspace) || workspace_bytes < scl_conv3x3_workspace_bytes())
     return SCL_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
@@ -831,7 +853,7 @@ static int conv3x3_dispatch(const void* x, const void* w, int64_t w_stride_k, in
   if (cin == CI && kout == KO)                                                                 \
     return launch_conv3x3<CI, KO>(x, w, w_stride_k, w_stride_c, w_stride_h, w_stride_w,        \
                                   transposed, B, H, W, out, bias, relu ? 1 : 0, pooled,        \
-                                  mask, workspace, st);
+                                  mask, pidx, workspace, st);
   SCL_CONV_CASE(64, 64)
   SCL_CONV_CASE(64, 128)
   SCL_CONV_CASE(128, 64)
@@ -846,7 +868,18 @@ extern "C" int scl_conv3x3_fused(const void* x, const void* w, int64_t w_stride_
                                  void* out, const float* bias, int relu, void* pooled,
                                  void* workspace, size_t workspace_bytes, void* stream) {
   return conv3x3_dispatch(x, w, w_stride_k, w_stride_c, w_stride_h, w_stride_w, transposed, B, H,
-                          W, cin, kout, out, bias, relu, pooled, nullptr, workspace,
+                          W, cin, kout, out, bias, relu, pooled, nullptr, nullptr, workspace,
+                          workspace_bytes, stream);
+}
+
+extern "C" int scl_conv3x3_pool_idx(const void* x, const void* w, int64_t w_stride_k,
+                                    int64_t w_stride_c, int64_t w_stride_h, int64_t w_stride_w,
+                                    int B, int H, int W, int cin, int kout, const float* bias,
+                                    void* pooled, void* pool_idx, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+  if (!pool_idx || !pooled || !bias) return SCL_E_NULL;
+  return conv3x3_dispatch(x, w, w_stride_k, w_stride_c, w_stride_h, w_stride_w, 0, B, H, W, cin,
+                          kout, nullptr, bias, 0, pooled, nullptr, pool_idx, workspace,
                           workspace_bytes, stream);
 }
 
@@ -857,7 +890,7 @@ extern "C" int scl_conv3x3_masked(const void* x, const void* w, int64_t w_stride
                                   size_t workspace_bytes, void* stream) {
   if (!mask) return SCL_E_NULL;
   return conv3x3_dispatch(x, w, w_stride_k, w_stride_c, w_stride_h, w_stride_w, transposed, B, H,
-                          W, cin, kout, out, nullptr, 0, nullptr, mask, workspace,
+                          W, cin, kout, out, nullptr, 0, nullptr, mask, nullptr, workspace,
                           workspace_bytes, stream);
 }
 

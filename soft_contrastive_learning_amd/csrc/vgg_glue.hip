@@ -212,6 +212,50 @@ __global__ __launch_bounds__(kThreads) void pool_bwd_kernel(const T* __restrict_
   write_partials(acc, c8n, lds, partial, Cn);
 }
 
+// The same routing from a stored window position (idx in 0..3 = 2 * dy + dx, one byte per
+// pooled element, written by the convolution's pooling epilogue): no read of the full-size z.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void pool_bwd_idx_kernel(
+    const T* __restrict__ g, const T* __restrict__ a, const unsigned char* __restrict__ idx,
+    int H, int W, int Ho, int Wo, int c8n, int Cn, int64_t nvec_out, T* __restrict__ gz,
+    float* __restrict__ partial) {
+  __shared__ float lds[kThreads * 8];
+  const int c8 = threadIdx.x % c8n;
+  const int64_t C = (int64_t)c8n * 8;
+  float acc[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nvec_out;
+       i += (int64_t)gridDim.x * kThreads) {
+    const int64_t pos = i / c8n;
+    const int wo = (int)(pos % Wo);
+    const int64_t bh = pos / Wo;
+    const int ho = (int)(bh % Ho);
+    const int64_t bb = bh / Ho;
+    const int64_t base = ((bb * H + 2 * ho) * W + 2 * wo) * C + c8 * 8;
+    float gv[8], av[8];
+    Vec8<T>::ld(g + i * 8, gv);
+    Vec8<T>::ld(a + i * 8, av);
+    const uint2 iw = *reinterpret_cast<const uint2*>(idx + i * 8);
+    float o0[8], o1[8], o2[8], o3[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float gg = av[c] > 0.f ? gv[c] : 0.f;
+      acc[c] += gg;
+      const unsigned k = ((c < 4 ? iw.x : iw.y) >> (8 * (c & 3))) & 3u;
+      o0[c] = k == 0 ? gg : 0.f;
+      o1[c] = k == 1 ? gg : 0.f;
+      o2[c] = k == 2 ? gg : 0.f;
+      o3[c] = k == 3 ? gg : 0.f;
+    }
+    Vec8<T>::st(gz + base, o0);
+    Vec8<T>::st(gz + base + C, o1);
+    Vec8<T>::st(gz + base + (int64_t)W * C, o2);
+    Vec8<T>::st(gz + base + (int64_t)W * C + C, o3);
+  }
+  write_partials(acc, c8n, lds, partial, Cn);
+}
+
 // rows / columns that no 2x2 window covers (odd H or W) get a zero gradient
 template <typename T>
 __global__ __launch_bounds__(kThreads) void pool_bwd_border_kernel(T* __restrict__ gz, int B,
@@ -356,6 +400,44 @@ extern "C" int scl_vgg_pool_bwd(const void* g, const void* a, const void* z, int
     SCL_LAUNCH("vgg_pool_bwd", pool_bwd_kernel<unsigned short>, dim3(nb), dim3(kThreads), 0, st,
                (const unsigned short*)g, (const unsigned short*)a, (const unsigned short*)z, H, W,
                Ho, Wo, C / 8, C, nvec, (unsigned short*)gz, partial);
+  } else {
+    return SCL_E_KIND;
+  }
+  SCL_LAUNCH("vgg_colsum", colsum_kernel, dim3((C + 31) / 32), dim3(1024), 0,
+             st, (const float*)partial, nb, C, bias_grad);
+  return scl_launch_status();
+}
+
+extern "C" int scl_vgg_pool_bwd_idx(const void* g, const void* a, const void* idx, int dtype,
+                                    int B, int H, int W, int C, void* gz, float* bias_grad,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+  if (!g || !a || !idx || !gz || !bias_grad || !workspace) return SCL_E_NULL;
+  if (B < 1 || H < 2 || W < 2 || !channels_ok(C) || !aligned16(g) || !aligned16(a) ||
+      (((uintptr_t)idx) & 7u) || !aligned16(gz))
+    return SCL_E_SHAPE;
+  if (!scl_aligned256(workspace) || workspace_bytes < scl_vgg_workspace_bytes(C))
+    return SCL_E_WORKSPACE;
+  const int Ho = H / 2, Wo = W / 2;
+  const int64_t nvec = (int64_t)B * Ho * Wo * (C / 8);
+  const int nb = blocks_for(nvec);
+  hipStream_t st = (hipStream_t)stream;
+  float* partial = (float*)workspace;
+  const bool border = (H & 1) || (W & 1);
+  if (dtype == SCL_DT_F32) {
+    if (border)
+      SCL_LAUNCH("vgg_pool_bwd_border", pool_bwd_border_kernel<float>, dim3(kMaxBlocks),
+                 dim3(kThreads), 0, st, (float*)gz, B, H, W, Ho, Wo, C);
+    SCL_LAUNCH("vgg_pool_bwd_idx", pool_bwd_idx_kernel<float>, dim3(nb), dim3(kThreads), 0, st,
+               (const float*)g, (const float*)a, (const unsigned char*)idx, H, W, Ho, Wo, C / 8, C,
+               nvec, (float*)gz, partial);
+  } else if (dtype == SCL_DT_BF16) {
+    if (border)
+      SCL_LAUNCH("vgg_pool_bwd_border", pool_bwd_border_kernel<unsigned short>, dim3(kMaxBlocks),
+                 dim3(kThreads), 0, st, (unsigned short*)gz, B, H, W, Ho, Wo, C);
+    SCL_LAUNCH("vgg_pool_bwd_idx", pool_bwd_idx_kernel<unsigned short>, dim3(nb), dim3(kThreads),
+               0, st, (const unsigned short*)g, (const unsigned short*)a,
+               (const unsigned char*)idx, H, W, Ho, Wo, C / 8, C, nvec, (unsigned short*)gz,
+               partial);
   } else {
     return SCL_E_KIND;
   }

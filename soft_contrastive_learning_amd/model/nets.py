@@ -238,6 +238,27 @@ class _GradLink:
 
 
 USE_MASKED_BWD = os.environ.get('SCL_MASKED_BWD', '1') != '0'
+USE_POOL_IDX = os.environ.get('SCL_POOL_IDX', '1') != '0'
+
+
+def conv_pool_idx(x, w, bias):
+    """conv -> +bias -> max-pool 2x2 -> ReLU with the pooling in the convolution's epilogue and
+    NO full-size output: returns (pooled bf16 [B,K,H/2,W/2], idx uint8 of the same shape: the
+    window position of each maximum) — ``scl_conv3x3_pool_idx``."""
+    lib = L.load()
+    L.require_device(x, w, bias)
+    x = x.contiguous(memory_format=_CL)
+    b, cin, h, wd = x.shape
+    kout = w.shape[0]
+    a = torch.empty((b, kout, h // 2, wd // 2), dtype=x.dtype, device=x.device, memory_format=_CL)
+    idx = torch.empty((b, kout, h // 2, wd // 2), dtype=torch.uint8, device=x.device,
+                      memory_format=_CL)
+    sk, sc, sh, sw = w.stride()
+    ws = L.workspace(lib.scl_conv3x3_workspace_bytes(), x.device)
+    L.check(lib.scl_conv3x3_pool_idx(L.ptr(x), L.ptr(w), sk, sc, sh, sw, b, h, wd, cin, kout,
+                                     L.ptr(bias.float().contiguous()), L.ptr(a), L.ptr(idx),
+                                     L.ptr(ws), ws.numel(), L.stream_of(x)))
+    return a, idx
 
 
 def _conv3x3_backward(gz, x, w, need_x, link=None):
@@ -330,8 +351,16 @@ class _ConvBiasPoolReLU(torch.autograd.Function):
     def forward(ctx, x, w, bias, link_in=None):
         lib = L.load()
         ctx.link_in = link_in
+        ctx.by_idx = False
+        if _own_conv_kind(x, w) == 'reg' and w.shape[0] == w.shape[1] and USE_POOL_IDX:
+            # conv1_2 / conv2_2: pooled map and the position of each maximum from the epilogue;
+            # the full-size convolution output is never written
+            a, idx = conv_pool_idx(x, w, bias)
+            ctx.by_idx = True
+            ctx.save_for_backward(x, w, idx, a)
+            return a
         if _own_conv_kind(x, w) == 'reg' and w.shape[0] == w.shape[1]:
-            # conv1_2 / conv2_2: pooled map from the epilogue (no pooling pass over z)
+            # pooled map from the epilogue (no pooling pass over z)
             z, a = conv64(x, w, False, bias=bias, pool=True)
         else:
             z = _conv3x3(x, w).contiguous(memory_format=_CL)
@@ -348,12 +377,14 @@ class _ConvBiasPoolReLU(torch.autograd.Function):
         lib = L.load()
         x, w, z, a = ctx.saved_tensors
         ga = ga.contiguous(memory_format=_CL)
-        b, c, h, wd = z.shape
-        gz = torch.empty_like(z)
-        gb = torch.empty(c, dtype=torch.float32, device=z.device)
-        ws = L.workspace(lib.scl_vgg_workspace_bytes(c), z.device)
-        L.check(lib.scl_vgg_pool_bwd(L.ptr(ga), L.ptr(a), L.ptr(z), _glue_dtype(z), b, h, wd, c,
-                                     L.ptr(gz), L.ptr(gb), L.ptr(ws), ws.numel(), L.stream_of(z)))
+        b, c = a.shape[0], a.shape[1]
+        h, wd = x.shape[2], x.shape[3]
+        gz = torch.empty((b, c, h, wd), dtype=a.dtype, device=a.device, memory_format=_CL)
+        gb = torch.empty(c, dtype=torch.float32, device=a.device)
+        ws = L.workspace(lib.scl_vgg_workspace_bytes(c), a.device)
+        fn = lib.scl_vgg_pool_bwd_idx if ctx.by_idx else lib.scl_vgg_pool_bwd
+        L.check(fn(L.ptr(ga), L.ptr(a), L.ptr(z), _glue_dtype(a), b, h, wd, c,
+                   L.ptr(gz), L.ptr(gb), L.ptr(ws), ws.numel(), L.stream_of(a)))
         gx, gw = _conv3x3_backward(gz, x, w, ctx.needs_input_grad[0], ctx.link_in)
         return gx, gw, gb, None
 

@@ -387,3 +387,42 @@ def test_first_layer_weight_and_bias_gradient(dev, shape):
     assert float((gb - bf.grad).abs().max() / bf.grad.abs().max()) < 1e-5
     gb2 = torch.empty(64, device=dev)
     assert torch.equal(gw, nets.first_wrw(x0, gz, like, gb2)) and torch.equal(gb, gb2)
+
+
+@pytest.mark.parametrize('cin,shape', [(64, (2, 16, 40)), (128, (1, 10, 38)), (64, (1, 13, 37))])
+def test_pool_index_epilogue_and_its_backward(dev, cin, shape):
+    """scl_conv3x3_pool_idx + scl_vgg_pool_bwd_idx: pooled map as the fused-tail kernel gives
+    it, every stored position points at a maximum of its window, and the backward routes
+    g * [a > 0] there (and only there)."""
+    from soft_contrastive_learning_amd import _lib as L
+    from soft_contrastive_learning_amd.model import nets
+    lib = L.load()
+    b, h, w = shape
+    g = torch.Generator().manual_seed(47)
+    x = torch.randn(b, cin, h, w, generator=g).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(cin, cin, 3, 3, generator=g) * 0.05).to(dev).bfloat16()
+    bias = torch.randn(cin, generator=g).to(dev) * 0.2
+    z, a_ref = nets.conv64(x, wt, False, bias=bias, pool=True)
+    a, idx = nets.conv_pool_idx(x, wt, bias)
+    assert torch.equal(a, a_ref) and idx.dtype == torch.uint8 and int(idx.max()) <= 3
+    ho, wo = h // 2, w // 2
+    z32 = torch.nn.functional.conv2d(x.float(), wt.float(), padding=1)[:, :, :2 * ho, :2 * wo]
+    win = z32.reshape(b, cin, ho, 2, wo, 2).permute(0, 1, 2, 4, 3, 5).reshape(b, cin, ho, wo, 4)
+    picked = torch.gather(win, 4, idx.long().unsqueeze(-1)).squeeze(-1)
+    scale = float(z32.abs().max())
+    assert float((win.max(dim=4).values - picked).abs().max()) < 1e-3 * scale
+    # backward
+    ga = torch.randn(b, cin, ho, wo, generator=g).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    gz = torch.empty((b, cin, h, w), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
+    gz.fill_(7.0)                                     # uncovered borders must be zeroed
+    gb = torch.empty(cin, device=dev)
+    ws = L.workspace(lib.scl_vgg_workspace_bytes(cin), dev)
+    L.check(lib.scl_vgg_pool_bwd_idx(L.ptr(ga), L.ptr(a), L.ptr(idx), L.DT_BF16, b, h, w, cin,
+                                     L.ptr(gz), L.ptr(gb), L.ptr(ws), ws.numel(), L.stream_of(ga)))
+    gg = torch.where(a > 0, ga, torch.zeros_like(ga)).float()
+    want = torch.zeros(b, cin, h, w, device=dev)
+    onehot = torch.nn.functional.one_hot(idx.long(), 4).float() * gg.unsqueeze(-1)   # [b,c,ho,wo,4]
+    want[:, :, :2 * ho, :2 * wo] = onehot.reshape(b, cin, ho, wo, 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(
+        b, cin, 2 * ho, 2 * wo)
+    assert torch.equal(gz.float(), want)
+    assert float((gb - gg.sum(dim=(0, 2, 3))).abs().max()) < 1e-3 * float(gg.abs().sum(dim=(0, 2, 3)).max())
