@@ -344,7 +344,11 @@ __device__ __forceinline__ u32x4 tr_pair(const unsigned short* a0, int step4) {
 // block (input channels 64 cb .., output channels 64 kb ..) over the tiles p, p + P, ...
 // DBG (scl_debug_set_variant(2000 + bits), timing diagnostics only — wrong results): bit 0
 // no operand reads in the product loop, bit 1 no staging after the first tile.
-template <int DBG>
+// TWv: tile width, 32 (8 x 32 tiles, a step = 16 pixels of a row) or 8 (32 x 8 tiles for
+// narrow maps, a step = two rows of 8): the same 256 pixels, 340-pixel windows and LDS image
+// either way — only the pixel <-> address maps differ; the host takes the shape that pads the
+// map less (W = 80: 96 -> 80 columns; 30 x 40: 32 x 64 -> 32 x 40).
+template <int DBG, int TWv>
 __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __restrict__ x,
                                                        const unsigned short* __restrict__ gz,
                                                        int B, int H, int W, int C, int K,
@@ -358,10 +362,13 @@ __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __r
   // transposed-read role of this lane: 16-lane group gq = lane >> 4 covers channels
   // 16 (gq & 1) .. + 15 and pixels 8 (gq >> 1) + q (+ 4); lane 4q + p addresses row q,
   // columns 4p .. 4p + 3
+  constexpr int THv = TH * TW / TWv, WCv = TWv + 2, WRv = THv + 2;
   const int q = (lane >> 2) & 3, pp = lane & 3, gq = lane >> 4;
-  const int pix0 = 8 * (gq >> 1) + q, ch0 = 16 * (gq & 1) + 4 * pp;
+  const int ch0 = 16 * (gq & 1) + 4 * pp;
+  // the lane's pixel inside a step: (row, column) relative to the step's first pixel
+  const int lrow = TWv == 32 ? 0 : (gq >> 1), lcol = TWv == 32 ? 8 * (gq >> 1) + q : q;
 
-  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+  const int tiles_x = (W + TWv - 1) / TWv, tiles_y = (H + THv - 1) / THv;
   const int per_img = tiles_x * tiles_y;
   const int ntiles = B * per_img;
 
@@ -378,20 +385,20 @@ __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __r
     if (j < 2 * XCH) {
       const int plane = j >= XCH ? 1 : 0;
       const int pix = 16 * (j - XCH * plane) + pl;
-      rel[i] = pix < WR * WC ? ((pix / WC) << 8) | (pix % WC) : -1;
-      roff[i] = ((pix / WC) * W + pix % WC) * C + C64 * blockIdx.y + 8 * piece + 32 * plane;
+      rel[i] = pix < WRv * WCv ? ((pix / WCv) << 8) | (pix % WCv) : -1;
+      roff[i] = ((pix / WCv) * W + pix % WCv) * C + C64 * blockIdx.y + 8 * piece + 32 * plane;
     } else {
       const int jj = j - 2 * XCH;
       const int plane = jj >= GCH ? 1 : 0;
       const int pix = 16 * (jj - GCH * plane) + pl;
-      rel[i] = j < WCHUNKS ? ((pix / TW) << 8) | (pix % TW) : -1;
-      roff[i] = ((pix / TW) * W + pix % TW) * K + C64 * blockIdx.z + 8 * piece + 32 * plane;
+      rel[i] = j < WCHUNKS ? ((pix / TWv) << 8) | (pix % TWv) : -1;
+      roff[i] = ((pix / TWv) * W + pix % TWv) * K + C64 * blockIdx.z + 8 * piece + 32 * plane;
     }
   }
   const unsigned short* zeros = reinterpret_cast<const unsigned short*>(zero_block);
   auto stage_issue = [&](int tile, int buf) {
     const int b = tile / per_img, t2 = tile % per_img;
-    const int ty = (t2 / tiles_x) * TH, tx = (t2 % tiles_x) * TW;
+    const int ty = (t2 / tiles_x) * THv, tx = (t2 % tiles_x) * TWv;
     const unsigned base = lds_byte_of(lds) + buf * WBUF * 2;
     // element offsets of the window's / tile's first pixel (< 2^31: host check; the window's
     // may be negative at the image border — those lanes are masked by `ok`)
@@ -433,19 +440,23 @@ __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __r
   for (; tile < ntiles; tile += gridDim.x) {
     const int next = (DBG & 2) ? ntiles : tile + gridDim.x;
     if (next < ntiles) stage_issue(next, buf ^ 1);
-    const unsigned short* xl = lds + buf * WBUF + mt * XPLANE + pix0 * WPL + ch0;
-    const unsigned short* gl = lds + buf * WBUF + 2 * XPLANE + nt * GPLANE + pix0 * WPL + ch0;
-    // product i = 9 * s + t: step s (tile row ry = 4 ph + s / 2, pixels 16 (s & 1) ..), tap t
+    const unsigned short* xl =
+        lds + buf * WBUF + mt * XPLANE + (lrow * WCv + lcol) * WPL + ch0;
+    const unsigned short* gl =
+        lds + buf * WBUF + 2 * XPLANE + nt * GPLANE + (lrow * TWv + lcol) * WPL + ch0;
+    // product i = 9 * s + t: step s of this wave's eight (first pixel (ry, cx)), tap t
     auto a_of = [&](int i) {
       const int s_ = i / 9, t = i % 9;
-      const int ry = TH / 2 * ph + (s_ >> 1), cx = 16 * (s_ & 1);
+      const int ry = TWv == 32 ? 4 * ph + (s_ >> 1) : 16 * ph + 2 * s_;
+      const int cx = TWv == 32 ? 16 * (s_ & 1) : 0;
       if (DBG & 1) return u32x4{0x3f803f80u + i, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-      return tr_pair(xl + ((ry + t / 3) * WC + cx + t % 3) * WPL, 4 * WPL);
+      return tr_pair(xl + ((ry + t / 3) * WCv + cx + t % 3) * WPL, 4 * WPL);
     };
     auto b_of = [&](int s_) {
-      const int ry = TH / 2 * ph + (s_ >> 1), cx = 16 * (s_ & 1);
+      const int ry = TWv == 32 ? 4 * ph + (s_ >> 1) : 16 * ph + 2 * s_;
+      const int cx = TWv == 32 ? 16 * (s_ & 1) : 0;
       if (DBG & 1) return u32x4{0x3f803f80u + s_, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-      return tr_pair(gl + (ry * TW + cx) * WPL, 4 * WPL);
+      return tr_pair(gl + (ry * TWv + cx) * WPL, 4 * WPL);
     };
     u32x4 af[DEPTH], bf[2];
 #pragma unroll
@@ -952,29 +963,36 @@ extern "C" int scl_wrw3x3(const void* x, const void* gz, int B, int H, int W, in
   static std::once_flag once;
   static int cus = 256;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wrw64_kernel<0>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wrw64_kernel<0, 32>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWrw64Lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wrw64_kernel<1>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wrw64_kernel<1, 32>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWrw64Lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wrw64_kernel<2>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wrw64_kernel<2, 32>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWrw64Lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wrw64_kernel<3>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wrw64_kernel<3, 32>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWrw64Lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wrw64_kernel<0, 8>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWrw64Lds);
     cus = conv64_cus();
     if (cus > 1024) cus = 1024;
   });
-  const int tiles = B * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+  // tile shape: 8 x 32, or 32 x 8 where that pads the map less
+  const int tiles_wide = B * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+  const int tiles_tall = B * ((H + 31) / 32) * ((W + 7) / 8);
+  const int dbg = scl_debug_variant / 1000 == 2 ? scl_debug_variant & 3 : 0;
+  const bool tall = tiles_tall < tiles_wide && dbg == 0;
+  const int tiles = tall ? tiles_tall : tiles_wide;
   const int P = wrw_splits(cin, kout, tiles, cus);
   hipStream_t st = (hipStream_t)stream;
-  const int dbg = scl_debug_variant / 1000 == 2 ? scl_debug_variant & 3 : 0;
-#define SCL_WRW_LAUNCH(D)                                                                      \
-  SCL_LAUNCH("wrw64_kernel", wrw64_kernel<D>, dim3(P, cin / 64, kout / 64), dim3(512),         \
+#define SCL_WRW_LAUNCH(D, T)                                                                   \
+  SCL_LAUNCH("wrw64_kernel", (wrw64_kernel<D, T>), dim3(P, cin / 64, kout / 64), dim3(512),    \
              kWrw64Lds, st, (const unsigned short*)x, (const unsigned short*)gz, B, H, W, cin, \
              kout, (float*)workspace)
-  if (dbg == 0) SCL_WRW_LAUNCH(0);
-  else if (dbg == 1) SCL_WRW_LAUNCH(1);
-  else if (dbg == 2) SCL_WRW_LAUNCH(2);
-  else SCL_WRW_LAUNCH(3);
+  if (tall) SCL_WRW_LAUNCH(0, 8);
+  else if (dbg == 0) SCL_WRW_LAUNCH(0, 32);
+  else if (dbg == 1) SCL_WRW_LAUNCH(1, 32);
+  else if (dbg == 2) SCL_WRW_LAUNCH(2, 32);
+  else SCL_WRW_LAUNCH(3, 32);
 #undef SCL_WRW_LAUNCH
   SCL_LAUNCH("wrw64_reduce_kernel", wrw64_reduce_kernel, dim3(9 * 64 * 64 / 64, (cin / 64) * (kout / 64)),
              dim3(256), 0, st, (const float*)workspace, 2 * P, kout / 64, w_stride_k, w_stride_c,

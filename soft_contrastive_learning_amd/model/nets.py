@@ -211,9 +211,9 @@ def _conv3x3(x, w):
 
 
 def _wrw_pays(x):
-    """scripts/conv_layers.py: own 850-1010 vs library 370-750 TFLOP/s down to 60 x 80 maps
-    (conv1_2 .. conv4_x); a loss at 30 x 40 (ragged 8 x 32 tiles, too few of them)."""
-    return x.shape[2] * x.shape[3] >= 60 * 80
+    """scripts/conv_layers.py: own 850-1070 vs library 370-750 TFLOP/s on conv1_2 .. conv4_x,
+    900 vs 600 at 30 x 40 (conv5_x) with the 32 x 8 tile shape for narrow maps."""
+    return x.shape[2] * x.shape[3] >= 30 * 40
 
 
 class _GradLink:

@@ -257,7 +257,10 @@ def test_lds_weight_conv_deeper_layers(dev, cin, cout, shape):
 
 
 @pytest.mark.parametrize('cin,cout,shape', [(64, 128, (2, 12, 40)), (128, 128, (1, 13, 37)),
-                                            (256, 256, (1, 16, 40)), (512, 512, (1, 7, 23))])
+                                            (256, 256, (1, 16, 40)), (512, 512, (1, 7, 23)),
+                                            # narrow maps: the 32 x 8 tile shape
+                                            (64, 64, (1, 30, 40)), (128, 64, (2, 60, 80)),
+                                            (64, 64, (1, 33, 9))])
 def test_wrw_other_shapes(dev, cin, cout, shape):
     from soft_contrastive_learning_amd.model import nets
     b, h, w = shape
