@@ -203,38 +203,32 @@ __global__ __launch_bounds__(NTHR, 1) void convg_kernel(const unsigned short* __
     const int cc0 = s / 9, tap0 = s - 9 * cc0;
     const bool win_issued = tap0 == 0 && cc0 + 1 < CC && !(dbg & 2);
     if (win_issued) issue_win(cc0 + 1, (cc0 + 1) & 1);
-#pragma unroll
-    for (int u = 0; u < TPB; ++u) {
+    // 2 TPB groups of 8 MFMAs (tap u = g / 2, 16-channel k-step g % 2); the fragments of
+    // group g + 1 (4 A + 2 B reads) fly under the MFMAs of group g, also across taps — only
+    // the first group after a barrier waits for its operands
+    u32x4 af[2][4], bf[2][2];
+    auto load_group = [&](int g, u32x4 (&a4)[4], u32x4 (&b2)[2]) {
+      const int u = g >> 1, ks2 = g & 1;
       const int su = s + u;
       const int cc = su / 9, tap = su - 9 * cc;
       const unsigned short* wa =
-          win + (cc & 1) * GWIN + lane_a + ((tap / 3) * GWC + tap % 3) * GPIX;
-      const unsigned short* wbp = wts + (((s / TPB) & 1) * TPB + u) * GWT + lane_b;
-      u32x4 bf[2][2];
+          win + (cc & 1) * GWIN + lane_a + ((tap / 3) * GWC + tap % 3) * GPIX + 16 * ks2;
+      const unsigned short* wbp = wts + (((s / TPB) & 1) * TPB + u) * GWT + lane_b + 16 * ks2;
 #pragma unroll
-      for (int ks2 = 0; ks2 < 2; ++ks2)
+      for (int n = 0; n < 2; ++n) b2[n] = *reinterpret_cast<const u32x4*>(wbp + (32 * n) * GPIX);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a4[j] = *reinterpret_cast<const u32x4*>(wa + aoff[j]);
+    };
+    load_group(0, af[0], bf[0]);
+#pragma unroll
+    for (int g = 0; g < 2 * TPB; ++g) {
+      if (g + 1 < 2 * TPB) load_group(g + 1, af[(g + 1) & 1], bf[(g + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int n = 0; n < 2; ++n)
-          bf[ks2][n] = *reinterpret_cast<const u32x4*>(wbp + (32 * n) * GPIX + 16 * ks2);
-      // 2 groups per tap (k-steps); the A fragments of the next group fly under the 8 MFMAs
-      // of the current one
-      u32x4 af[2][4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) af[0][j] = *reinterpret_cast<const u32x4*>(wa + aoff[j]);
-#pragma unroll
-      for (int ks2 = 0; ks2 < 2; ++ks2) {
-        if (ks2 == 0) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            af[1][j] = *reinterpret_cast<const u32x4*>(wa + aoff[j] + 16);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int n = 0; n < 2; ++n)
-            acc[2 * j + n] = mfma32b(af[ks2][j], bf[ks2][n], acc[2 * j + n]);
-      }
+          acc[2 * j + n] = mfma32b(af[g & 1][j], bf[g & 1][n], acc[2 * j + n]);
     }
     if (!win_issued)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
