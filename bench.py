@@ -99,26 +99,6 @@ def kernel_models(b, n, gb, x_bytes):
     }
 
 
-def vgg_glue_bytes(b, h, w, s):
-    """Algorithmic HBM bytes PER STEP of the fused backbone glue kernels (csrc/vgg_glue.hip):
-    every activation element is counted once per read and once per write."""
-    # (channels, resolution divisor, pooled after) of the 13 convs, model/nets.py:39-63
-    layers = [(64, 1, False), (64, 1, True), (128, 2, False), (128, 2, True), (256, 4, False),
-              (256, 4, False), (256, 4, True), (512, 8, False), (512, 8, False), (512, 8, True),
-              (512, 16, False), (512, 16, False), (512, 16, False)]
-    out = {'vgg_bias_act': 0.0, 'vgg_pool_fwd': 0.0, 'vgg_act_bwd': 0.0, 'vgg_pool_bwd': 0.0}
-    for i, (c, div, pooled) in enumerate(layers):
-        full = float(b * (h // div) * (w // div) * c * s)
-        if pooled:
-            out['vgg_pool_fwd'] += full * 1.25            # read z, write a (1/4)
-            out['vgg_pool_bwd'] += full * 2.5             # read g, a (1/4 each), z; write gz
-        else:
-            last = i == len(layers) - 1                   # conv5_3: bias only, no ReLU
-            out['vgg_bias_act'] += full * 2.0
-            out['vgg_act_bwd'] += full * (1.0 if last else 3.0)
-    return out
-
-
 def price(name, launches, mean_ms, model):
     sec = mean_ms * 1e-3
     tf = model['flops'] / sec / 1e12 if sec > 0 else 0.0
@@ -229,12 +209,14 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    with _lib.KernelTimer(capacity=64 * max(args.steps, 1)) as kt:
+    nets.WORK_LOG = {}        # algorithmic flops / bytes of the backbone kernels, per call site
+    with _lib.KernelTimer(capacity=256 * max(args.steps, 1)) as kt:
         t0 = time.perf_counter()
         for _ in range(args.steps):
             loss = step()
         fence()
         elapsed = time.perf_counter() - t0
+    work, nets.WORK_LOG = nets.WORK_LOG, None
     loss_val = float(loss.detach())
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -246,37 +228,45 @@ def main():
         models = kernel_models(b, n_loc, gb, 2 if cdt == torch.bfloat16 else 4)
         summ = kt.summary()
         kernels = [price(k, c, ms, models[k]) for k, (c, ms) in sorted(summ.items()) if k in models]
-        # `roofline` = the dominant kernel of the hot path proper (NetVLAD + pairwise loss,
-        # SURVEY.md §8a); the backbone's elementwise glue is listed separately below
-        dom = max(kernels, key=lambda r: r['us'] * r['launches']) if kernels else None
-        glue = vgg_glue_bytes(b, args.height, args.width, 2 if cdt == torch.bfloat16 else 4)
+        # the dominant kernel of the NetVLAD + pairwise-loss family ...
+        dom_head = max(kernels, key=lambda r: r['us'] * r['launches']) if kernels else None
+        # the backbone's own kernels (convolutions against the bf16 dense MFMA peak or HBM,
+        # whichever governs; elementwise glue against HBM), work as logged by the call sites
         for k, (c, ms) in sorted(summ.items()):
-            if k in glue:
-                per_step_ms = ms * c / max(args.steps, 1)
-                gbs = glue[k] / (per_step_ms * 1e-3) / 1e9
-                kernels.append(dict(kernel=k, launches=c, us=round(ms * 1e3, 2), bound='hbm',
-                                    tflops=0.0, gbps=round(gbs, 1),
-                                    frac=round(gbs / PEAK_HBM_GBPS, 4)))
-        roofline = None
-        if dom:
-            roofline = dict(kernel=dom['kernel'], bound=dom['bound'],
-                            achieved=dom.get('executed_tflops', dom['tflops'])
-                            if dom['bound'] == 'mfma' else dom['gbps'],
-                            peak=dom.get('mfma_peak_tflops', PEAK_F32_TFLOPS)
-                            if dom['bound'] == 'mfma' else PEAK_HBM_GBPS,
-                            unit='TFLOP/s' if dom['bound'] == 'mfma' else 'GB/s',
-                            frac=dom['frac'], traffic=None, us_per_launch=dom['us'])
+            if k in work and work[k][0] == c:
+                _, fl, by = work[k]
+                kernels.append(price(k, c, ms, dict(flops=fl / c, bytes=by / c,
+                                                    peak_tflops=PEAK_BF16_TFLOPS)))
+        # ... and of the whole step (a backbone convolution): `roofline` is the latter
+        dom = max(kernels, key=lambda r: r['us'] * r['launches']) if kernels else None
+
+        def roof(d):
+            peak_tf = PEAK_BF16_TFLOPS if d['kernel'] in work else PEAK_F32_TFLOPS
+            return dict(kernel=d['kernel'], bound=d['bound'],
+                        achieved=d.get('executed_tflops', d['tflops'])
+                        if d['bound'] == 'mfma' else d['gbps'],
+                        peak=d.get('mfma_peak_tflops', peak_tf)
+                        if d['bound'] == 'mfma' else PEAK_HBM_GBPS,
+                        unit='TFLOP/s' if d['bound'] == 'mfma' else 'GB/s',
+                        frac=d['frac'], traffic=None, us_per_launch=d['us'],
+                        launches_per_step=d['launches'] / max(args.steps, 1))
+        roofline = roof(dom) if dom else None
+        roofline_head = roof(dom_head) if dom_head else None
         if roofline:
             # HBM bytes per launch measured offline with rocprofv3 PMC on this exact shape
             # (profiles/pmc_traffic.json); null when the shape / dtype was not profiled
             try:
                 with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
                     pmc = json.load(f)
-                ent = pmc.get(args.dtype, {}).get(roofline['kernel'])
-                if ent and pmc['shape'] == {'batch': b, 'locations': n_loc}:
-                    roofline['traffic'] = ent['read'] + ent['write']
-                    roofline['traffic_algorithmic'] = int(models[roofline['kernel']]['bytes'])
-                    roofline['traffic_source'] = 'rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01'
+                for rf in (roofline, roofline_head):
+                    ent = pmc.get(args.dtype, {}).get(rf['kernel'])
+                    if ent and pmc['shape'] == {'batch': b, 'locations': n_loc}:
+                        rf['traffic'] = ent['read'] + ent['write']
+                        alg = (work[rf['kernel']][2] / work[rf['kernel']][0]
+                               if rf['kernel'] in work else models[rf['kernel']]['bytes'])
+                        rf['traffic_algorithmic'] = int(alg)
+                        rf['traffic_source'] = ('rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch, '
+                                                'profiles/r01')
             except (OSError, ValueError, KeyError):
                 pass
         hip_ms = sum(r['us'] * r['launches'] for r in kernels) / 1e3 / max(args.steps, 1)
@@ -299,6 +289,7 @@ def main():
                        'global_batch': gb, 'locations': n_loc, 'parallelism': 'dp%d' % world,
                        'optimizer': 'adam', 'loss': float('%.6g' % loss_val)},
             'roofline': roofline,
+            'roofline_netvlad_loss': roofline_head,
             'kernels': kernels,
             'hip_path_ms_per_step': round(hip_ms, 3),
         }

@@ -30,6 +30,9 @@ def main():
     ap.add_argument('root')
     ap.add_argument('--out', default=None)
     ap.add_argument('--only', default='kernel', help='substring a kernel name must contain')
+    ap.add_argument('--merge-templates', action='store_true',
+                    help='drop template arguments: one row per kernel family (mean over all '
+                         'its dispatches)')
     args = ap.parse_args()
     acc = {}
     for path in glob.glob(os.path.join(args.root, '**', '*counter_collection.csv'), recursive=True):
@@ -38,6 +41,8 @@ def main():
                 k, c = short(r['Kernel_Name']), r['Counter_Name']
                 if args.only not in k:
                     continue
+                if args.merge_templates:
+                    k = re.sub(r'<.*$', '', k)
                 s, n = acc.get((k, c), (0.0, 0))
                 acc[(k, c)] = (s + float(r['Counter_Value']), n + 1)
     if not acc:

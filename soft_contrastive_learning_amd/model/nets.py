@@ -100,6 +100,19 @@ USE_WRW = os.environ.get('SCL_WRW', '1') != '0'
 USE_FIRST = os.environ.get('SCL_FIRST', '1') != '0'
 _OWN_CONV_SHAPES = {(64, 64), (64, 128), (128, 64), (128, 128)}      # (contraction, output)
 
+# bench.py sets this to a dict for its timed steps: C-library kernel name -> [calls,
+# algorithmic flops, algorithmic HBM bytes], added up by the call sites below (what a launch
+# must compute / move, not what it happens to do) so that the measured durations can be priced.
+WORK_LOG = None
+
+
+def _work(name, flops, nbytes):
+    if WORK_LOG is not None:
+        e = WORK_LOG.setdefault(name, [0, 0.0, 0.0])
+        e[0] += 1
+        e[1] += flops
+        e[2] += nbytes
+
 
 def _own_conv_kind(x, w, transposed=False):
     """'reg' (weights in registers, csrc/conv64.hip), 'lds' (weights streamed through LDS,
@@ -150,6 +163,10 @@ def conv64(x, w, transposed=False, bias=None, relu=False, pool=False, mask=None)
     if bias is not None:
         bias = bias.float().contiguous()
     sk, sc, sh, sw = w.stride()
+    px = b * h * wd
+    _work('conv3x3_kernel' if (cin, kout) in _OWN_CONV_SHAPES else 'convg_kernel',
+          2.0 * px * cin * kout * 9,
+          2.0 * px * (cin + kout * (1 + (mask is not None) + 0.25 * bool(pool))))
     if mask is not None:
         if bias is not None or pool or relu:
             raise ValueError("mask excludes the forward tails (bias / relu / pool)")
@@ -195,6 +212,7 @@ def wrw64(x, gz, w_like):
     b, cin, h, wd = x.shape
     kout = gz.shape[1]
     gw = torch.empty_like(w_like)
+    _work('wrw64_kernel', 2.0 * b * h * wd * cin * kout * 9, 2.0 * b * h * wd * (cin + kout))
     ws = L.workspace(lib.scl_wrw3x3_workspace_bytes(cin, kout), x.device)
     sk, sc, sh, sw = gw.stride()
     L.check(lib.scl_wrw3x3(L.ptr(x), L.ptr(gz), b, h, wd, cin, kout, L.ptr(gw), sk, sc, sh, sw,
@@ -254,6 +272,8 @@ def conv_pool_idx(x, w, bias):
     idx = torch.empty((b, kout, h // 2, wd // 2), dtype=torch.uint8, device=x.device,
                       memory_format=_CL)
     sk, sc, sh, sw = w.stride()
+    _work('conv3x3_kernel', 2.0 * b * h * wd * cin * kout * 9,
+          b * h * wd * (2.0 * cin + 0.75 * kout))           # in + pooled bf16 / 4 + index / 4
     ws = L.workspace(lib.scl_conv3x3_workspace_bytes(), x.device)
     L.check(lib.scl_conv3x3_pool_idx(L.ptr(x), L.ptr(w), sk, sc, sh, sw, b, h, wd, cin, kout,
                                      L.ptr(bias.float().contiguous()), L.ptr(a), L.ptr(idx),
@@ -316,6 +336,7 @@ class _ConvBiasAct(torch.autograd.Function):
         else:
             y = _conv3x3(x, w).contiguous(memory_format=_CL)
             b, c, h, wd = y.shape
+            _work('vgg_bias_act', 0.0, 2.0 * y.numel() * y.element_size())
             L.check(lib.scl_vgg_bias_act(L.ptr(y), _glue_dtype(y), L.ptr(bias), b * h * wd, c,
                                          int(relu), L.stream_of(y)))
         ctx.relu = relu
@@ -334,6 +355,7 @@ class _ConvBiasAct(torch.autograd.Function):
         masked = ctx.link_out is not None and ctx.link_out.take(gy)
         mask_here = ctx.relu and not masked
         gz = torch.empty_like(gy) if mask_here else gy
+        _work('vgg_act_bwd', 0.0, (3.0 if mask_here else 1.0) * gy.numel() * gy.element_size())
         L.check(lib.scl_vgg_act_bwd(L.ptr(gy), L.ptr(y) if mask_here else None,
                                     _glue_dtype(gy), b * h * wd, c,
                                     L.ptr(gz) if mask_here else None, L.ptr(gb), L.ptr(ws),
@@ -367,6 +389,7 @@ class _ConvBiasPoolReLU(torch.autograd.Function):
             b, c, h, wd = z.shape
             a = torch.empty((b, c, h // 2, wd // 2), dtype=z.dtype, device=z.device,
                             memory_format=_CL)
+            _work('vgg_pool_fwd', 0.0, 1.25 * z.numel() * z.element_size())
             L.check(lib.scl_vgg_pool_fwd(L.ptr(z), _glue_dtype(z), L.ptr(bias), b, h, wd, c,
                                          L.ptr(a), L.stream_of(z)))
         ctx.save_for_backward(x, w, z, a)
@@ -383,6 +406,9 @@ class _ConvBiasPoolReLU(torch.autograd.Function):
         gb = torch.empty(c, dtype=torch.float32, device=a.device)
         ws = L.workspace(lib.scl_vgg_workspace_bytes(c), a.device)
         fn = lib.scl_vgg_pool_bwd_idx if ctx.by_idx else lib.scl_vgg_pool_bwd
+        # read g, a (1/4 each) and the index bytes (1/8) or z (1); write gz
+        _work('vgg_pool_bwd_idx' if ctx.by_idx else 'vgg_pool_bwd', 0.0,
+              (1.625 if ctx.by_idx else 2.5) * gz.numel() * gz.element_size())
         L.check(fn(L.ptr(ga), L.ptr(a), L.ptr(z), _glue_dtype(a), b, h, wd, c,
                    L.ptr(gz), L.ptr(gb), L.ptr(ws), ws.numel(), L.stream_of(a)))
         gx, gw = _conv3x3_backward(gz, x, w, ctx.needs_input_grad[0], ctx.link_in)
@@ -429,6 +455,7 @@ def first_wrw(x0, gz, w_like, gb=None):
     gw = torch.empty_like(w_like)
     if gb is None:
         gb = torch.empty(64, dtype=torch.float32, device=gz.device)
+    _work('conv_first_wrw_kernel', 2.0 * b * h * wd * 64 * 28, b * h * wd * (128.0 + 6.0))
     ws = L.workspace(lib.scl_conv_first_wrw_workspace_bytes(), gz.device)
     sk, sc, sh, sw = gw.stride()
     L.check(lib.scl_conv_first_wrw(L.ptr(x0), L.ptr(gz), b, h, wd, L.ptr(gw), sk, sc, sh, sw,
@@ -455,6 +482,7 @@ class _FirstConv(torch.autograd.Function):
             y = torch.empty((b, 64, h, wd), dtype=torch.bfloat16, device=img.device,
                             memory_format=_CL)
             sk, sc, sh, sw = w.stride()
+            _work('conv_first_kernel', 2.0 * b * h * wd * 27 * 64, b * h * wd * (12.0 + 6.0 + 128.0))
             L.check(lib.scl_conv_first(L.ptr(img), L.ptr(avg.float().contiguous()), L.ptr(w), sk, sc,
                                        sh, sw, L.ptr(bias.float().contiguous()), b, h, wd,
                                        L.ptr(x0), L.ptr(y), L.stream_of(img)))
@@ -482,6 +510,7 @@ class _FirstConv(torch.autograd.Function):
                    and tuple(w.shape) == (64, 3, 3, 3))
         gz = gy if masked else torch.empty_like(gy)
         if not (masked and own_wrw):
+            _work('vgg_act_bwd', 0.0, (1.0 if masked else 3.0) * gy.numel() * gy.element_size())
             L.check(lib.scl_vgg_act_bwd(L.ptr(gy), None if masked else L.ptr(y), _glue_dtype(gy),
                                         b * h * wd, c, None if masked else L.ptr(gz), L.ptr(gb),
                                         L.ptr(ws), ws.numel(), L.stream_of(gy)))
