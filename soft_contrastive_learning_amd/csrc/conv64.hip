@@ -757,28 +757,33 @@ __global__ __launch_bounds__(256, 2) void conv_first_wrw_kernel(
     out[e] = (red[e] + red[2048 + e]) + (red[4096 + e] + red[6144 + e]);
 }
 
-// gw / gb from the slabs: grid 8, block 256 -> element e = (k, n); n < 27: weight tap
-// (kh, kw), input channel c, written as bf16 at the weight's strides; n == 27: bias gradient.
+// gw / gb from the slabs: grid 32, block 256 = 64 elements x 4 slab groups; element
+// e = (k, n); n < 27: weight tap (kh, kw), input channel c, written as bf16 at the weight's
+// strides; n == 27: bias gradient.  Fixed summation order.
 __global__ __launch_bounds__(256) void conv_first_wrw_reduce_kernel(
     const float* __restrict__ slabs, int nslab, int64_t sk, int64_t sc, int64_t sh, int64_t sw,
     unsigned short* __restrict__ gw, float* __restrict__ gb) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int i = 0;
-  for (; i + 3 < nslab; i += 4) {
+  __shared__ float red[4][64];
+  const int j = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + j;
+  float s0 = 0.f, s1 = 0.f;
+  int i = g;
+  for (; i + 4 < nslab; i += 8) {
     s0 += slabs[(int64_t)i * 2048 + e];
-    s1 += slabs[(int64_t)(i + 1) * 2048 + e];
-    s2 += slabs[(int64_t)(i + 2) * 2048 + e];
-    s3 += slabs[(int64_t)(i + 3) * 2048 + e];
+    s1 += slabs[(int64_t)(i + 4) * 2048 + e];
   }
-  for (; i < nslab; ++i) s0 += slabs[(int64_t)i * 2048 + e];
-  const float s = (s0 + s1) + (s2 + s3);
-  const int k = e >> 5, n = e & 31;
-  if (n < 27) {
-    const int tap = n / 3, c = n % 3;
-    gw[k * sk + c * sc + (tap / 3) * sh + (tap % 3) * sw] = f32_to_bf16(s);
-  } else if (n == 27) {
-    gb[k] = s;
+  if (i < nslab) s0 += slabs[(int64_t)i * 2048 + e];
+  red[g][j] = s0 + s1;
+  __syncthreads();
+  if (g == 0) {
+    const float s = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+    const int k = e >> 5, n = e & 31;
+    if (n < 27) {
+      const int tap = n / 3, c = n % 3;
+      gw[k * sk + c * sc + (tap / 3) * sh + (tap % 3) * sw] = f32_to_bf16(s);
+    } else if (n == 27) {
+      gb[k] = s;
+    }
   }
 }
 
@@ -1056,7 +1061,7 @@ extern "C" int scl_conv_first_wrw(const void* x0, const void* gz, int B, int H, 
   hipStream_t st = (hipStream_t)stream;
   SCL_LAUNCH("conv_first_wrw_kernel", conv_first_wrw_kernel, dim3(grid), dim3(256), kFirstWrwLds,
              st, (const unsigned short*)x0, (const unsigned short*)gz, B, H, W, (float*)workspace);
-  SCL_LAUNCH("conv_first_wrw_reduce_kernel", conv_first_wrw_reduce_kernel, dim3(8), dim3(256), 0,
+  SCL_LAUNCH("conv_first_wrw_reduce_kernel", conv_first_wrw_reduce_kernel, dim3(32), dim3(256), 0,
              st, (const float*)workspace, grid, w_stride_k, w_stride_c, w_stride_h, w_stride_w,
              (unsigned short*)gw, gb);
   return scl_launch_status();
