@@ -25,14 +25,13 @@ namespace {
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int BH = 12, BW = 40;                     // output block
-constexpr int GWR = BH + 2, GWC = BW + 4;           // halo window: 42 columns used, 44 staged —
+constexpr int BW = 40;                              // output block width (block height: GCfg)
+constexpr int GWC = BW + 4;                         // halo window: 42 columns used, 44 staged —
                                                     // with 80-byte pixels and the lane -> pixel
                                                     // map below every ds_read_b128 service group
                                                     // of an A fragment hits 16 different slots
 constexpr int CCH = 32;                             // channels per staged chunk
 constexpr int GPIX = CCH + 8;                       // bf16 per staged pixel / weight row (80 B)
-constexpr int GWIN = GWR * GWC * GPIX;              // bf16 per window buffer (24,640)
 constexpr int NTHR = 512;                           // 8 waves: two per SIMD
 constexpr int NB = 128;                             // output channels per workgroup
 constexpr int GWT = NB * GPIX;                      // bf16 per weight buffer (5120)
@@ -41,9 +40,24 @@ constexpr int GSCR = 32 * GSCR_LD;
 constexpr int TPB = 3;                              // (chunk, tap) steps per barrier: one
                                                     // tap row of a chunk
 // two windows + two weight buffers; the epilogue's per-wave scratch reuses the windows
-constexpr size_t kConvgLds = (2 * (size_t)GWIN + 2 * TPB * (size_t)GWT) * 2;   // 160,000 B
-static_assert(8 * GSCR <= 2 * GWIN, "epilogue scratch must fit the window buffers");
-constexpr int NMT = 15;                             // m-tiles: 3 rows x 5 cols of 4 x 8 pixels
+// Block height 12 (15 m-tiles of 4 x 8 pixels; wave = 4 m-tile slots x 2 n-tiles) or 8 (10
+// m-tiles; wave = one tile row of 5 x 1 n-tile) — the lower block for maps whose few 12-row
+// blocks leave CUs idle (30 x 40: 288 workgroups on 256 CUs -> 384 smaller ones).
+template <int BHv>
+struct GCfg {
+  static constexpr int BH = BHv;
+  static constexpr int GWR = BH + 2;
+  static constexpr int GWIN = GWR * GWC * GPIX;       // bf16 per window buffer
+  static constexpr int NMT = BH / 4 * 5;              // m-tiles
+  static constexpr int MS = BH == 12 ? 4 : 5;         // m-tile slots per wave
+  static constexpr int NS = BH == 12 ? 2 : 1;         // 32-channel n-tiles per wave
+  static constexpr int GSLOTS = GWR * GWC * 5;        // 16-byte slots of a window (4 data + pad)
+  static constexpr int GCHUNKS = (GSLOTS + 63) / 64;  // 1-KB DMA chunks per window
+  static constexpr int GNI = (GCHUNKS + 7) / 8;       // per wave
+  // two windows + two weight buffers; the epilogue's per-wave scratch reuses the windows
+  static constexpr size_t LDS = (2 * (size_t)GWIN + 2 * TPB * (size_t)GWT) * 2;
+  static_assert(8 * GSCR <= 2 * GWIN, "epilogue scratch must fit the window buffers");
+};
 
 // Lane -> pixel of a 4 x 8 m-tile.  The hardware serves a ds_read_b128 in the lane groups
 // {0-3, 12-15, 20-27} and {4-11, 16-19, 28-31} (per 32-lane half); giving the first group the
@@ -108,20 +122,20 @@ __device__ __forceinline__ void glds16(const unsigned short* src, unsigned lds_b
 __device__ __forceinline__ unsigned lds_byte_of(const unsigned short* p) {
   return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned short*)p;
 }
-constexpr int GSLOTS = GWR * GWC * 5;                // 16-byte slots of a window (4 data + pad)
-constexpr int GCHUNKS = (GSLOTS + 63) / 64;          // 1-KB DMA chunks per window (49)
-constexpr int GNI = (GCHUNKS + 7) / 8;               // per wave (7)
 constexpr int WCHK = TPB * GWT * 2 / 1024;           // chunks per weight step group (30)
 
 // grid (pixel blocks, kout / 128); block 512.  EPI: 0 plain, 1 + bias (+ ReLU),
 // 2 out = conv * [mask > 0] (the ReLU' of the layer below, for backward-data).
-template <int EPI>
+template <int EPI, int BHv>
 __global__ __launch_bounds__(NTHR, 1) void convg_kernel(const unsigned short* __restrict__ x,
                                                        const unsigned short* __restrict__ packed,
                                                        int B, int H, int W, int cin, int kout,
                                                        unsigned short* __restrict__ out,
                                                        const float* __restrict__ bias, int relu,
                                                        const unsigned short* __restrict__ mask) {
+  using G = GCfg<BHv>;
+  constexpr int BH = G::BH, GWR = G::GWR, GWIN = G::GWIN, NMT = G::NMT, MS = G::MS, NS = G::NS;
+  constexpr int GCHUNKS = G::GCHUNKS, GNI = G::GNI;
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
   unsigned short* win = lds;
   unsigned short* wts = lds + 2 * GWIN;
@@ -167,9 +181,9 @@ __global__ __launch_bounds__(NTHR, 1) void convg_kernel(const unsigned short* __
     }
   };
 
-  f32x16 acc[8];                                      // [m-tile slot 4][n-tile 2]
+  f32x16 acc[MS * NS];                                // [m-tile slot][n-tile]
 #pragma unroll
-  for (int mt = 0; mt < 8; ++mt) acc[mt] = zero16();
+  for (int mt = 0; mt < MS * NS; ++mt) acc[mt] = zero16();
 
   issue_wts(0, 0);
   issue_win(0, 0);
@@ -181,15 +195,15 @@ __global__ __launch_bounds__(NTHR, 1) void convg_kernel(const unsigned short* __
   // (two n-tiles): 8 accumulators = 128 registers, so TWO waves share a SIMD and cover each
   // other's LDS / barrier waits; per k-step 4 A + 2 B fragment reads for 8 MFMAs.
   // lane (r, h): pixel (tile_row(r), tile_col(r)) of an m-tile, channels 8 h .. + 7 of a k-step
-  const int mg = wid >> 1, ng = wid & 1;
-  int aoff[4];
+  const int mg = BH == 12 ? wid >> 1 : wid >> 2, ng = BH == 12 ? wid & 1 : wid & 3;
+  int aoff[MS];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int mt = 4 * mg + j < NMT ? 4 * mg + j : NMT - 1;
+  for (int j = 0; j < MS; ++j) {
+    const int mt = MS * mg + j < NMT ? MS * mg + j : NMT - 1;
     aoff[j] = ((4 * (mt / 5)) * GWC + 8 * (mt % 5)) * GPIX;
   }
   const int lane_a = (tile_row(r) * GWC + tile_col(r)) * GPIX + 8 * h;
-  const int lane_b = (64 * ng + r) * GPIX + 8 * h;
+  const int lane_b = (32 * NS * ng + r) * GPIX + 8 * h;
   // S = 9 * CC steps in groups of three (one tap row of a chunk) per barrier.
   // The DMA of the next group's weights runs under this group; the window of chunk cc + 1 is
   // issued (after the weights) at tap row 0 of chunk cc and may stay in flight across this
@@ -206,8 +220,8 @@ __global__ __launch_bounds__(NTHR, 1) void convg_kernel(const unsigned short* __
     // 2 TPB groups of 8 MFMAs (tap u = g / 2, 16-channel k-step g % 2); the fragments of
     // group g + 1 (4 A + 2 B reads) fly under the MFMAs of group g, also across taps — only
     // the first group after a barrier waits for its operands
-    u32x4 af[2][4], bf[2][2];
-    auto load_group = [&](int g, u32x4 (&a4)[4], u32x4 (&b2)[2]) {
+    u32x4 af[2][MS], bf[2][NS];
+    auto load_group = [&](int g, u32x4 (&a4)[MS], u32x4 (&b2)[NS]) {
       const int u = g >> 1, ks2 = g & 1;
       const int su = s + u;
       const int cc = su / 9, tap = su - 9 * cc;
@@ -215,9 +229,9 @@ __global__ __launch_bounds__(NTHR, 1) void convg_kernel(const unsigned short* __
           win + (cc & 1) * GWIN + lane_a + ((tap / 3) * GWC + tap % 3) * GPIX + 16 * ks2;
       const unsigned short* wbp = wts + (((s / TPB) & 1) * TPB + u) * GWT + lane_b + 16 * ks2;
 #pragma unroll
-      for (int n = 0; n < 2; ++n) b2[n] = *reinterpret_cast<const u32x4*>(wbp + (32 * n) * GPIX);
+      for (int n = 0; n < NS; ++n) b2[n] = *reinterpret_cast<const u32x4*>(wbp + (32 * n) * GPIX);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) a4[j] = *reinterpret_cast<const u32x4*>(wa + aoff[j]);
+      for (int j = 0; j < MS; ++j) a4[j] = *reinterpret_cast<const u32x4*>(wa + aoff[j]);
     };
     load_group(0, af[0], bf[0]);
 #pragma unroll
@@ -225,10 +239,10 @@ __global__ __launch_bounds__(NTHR, 1) void convg_kernel(const unsigned short* __
       if (g + 1 < 2 * TPB) load_group(g + 1, af[(g + 1) & 1], bf[(g + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < MS; ++j)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
-          acc[2 * j + n] = mfma32b(af[g & 1][j], bf[g & 1][n], acc[2 * j + n]);
+        for (int n = 0; n < NS; ++n)
+          acc[NS * j + n] = mfma32b(af[g & 1][j], bf[g & 1][n], acc[NS * j + n]);
     }
     if (!win_issued)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -242,18 +256,18 @@ __global__ __launch_bounds__(NTHR, 1) void convg_kernel(const unsigned short* __
   // epilogue: slot j <-> m-tile 4 mg + j, n <-> channels 64 ng + 32 n ..; accumulator register
   // q <-> pixel acc_row(q, h) of the tile, lane r <-> channel r of the n-tile
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int mt = 4 * mg + j;
+  for (int j = 0; j < MS; ++j) {
+    const int mt = MS * mg + j;
     if (mt >= NMT) break;                             // wave-uniform
     const int mr = mt / 5, mc = mt % 5;
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
-      const float bias_r = EPI == 1 ? bias[NB * nb + 64 * ng + 32 * n + r] : 0.f;
+    for (int n = 0; n < NS; ++n) {
+      const float bias_r = EPI == 1 ? bias[NB * nb + 32 * NS * ng + 32 * n + r] : 0.f;
       const int px = lane >> 1, hf = lane & 1;
       const int oy = y0 + 4 * mr + tile_row(px), ox = x0 + 8 * mc + tile_col(px);
       const bool inside = oy < H && ox < W;
       const int64_t o_off =
-          (((int64_t)b * H + oy) * W + ox) * kout + NB * nb + 64 * ng + 32 * n + 16 * hf;
+          (((int64_t)b * H + oy) * W + ox) * kout + NB * nb + 32 * NS * ng + 32 * n + 16 * hf;
       u32x4 y0v = u32x4{0u, 0u, 0u, 0u}, y1v = y0v;
       if (EPI == 2 && inside) {                          // in flight under the transpose
         y0v = *reinterpret_cast<const u32x4*>(mask + o_off);
@@ -261,7 +275,7 @@ __global__ __launch_bounds__(NTHR, 1) void convg_kernel(const unsigned short* __
       }
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        float v = acc[2 * j + n][q] + bias_r;
+        float v = acc[NS * j + n][q] + bias_r;
         if (EPI == 1 && relu) v = fmaxf(v, 0.f);
         scr[acc_row(q, h) * GSCR_LD + r] = f32_to_bf16(v);
       }
@@ -288,6 +302,17 @@ extern "C" size_t scl_convg_workspace_bytes(int cin, int kout) {
   return scl_round256((size_t)9 * (cin / CCH) * kout * GPIX * sizeof(unsigned short));
 }
 
+static int convg_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, c = 0;
+    n = (hipGetDevice(&dev) == hipSuccess &&
+         hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0)
+            ? c : 256;
+  }
+  return n;
+}
+
 // Same contract as scl_conv3x3_fused / scl_conv3x3_masked (include/scl_hip.h) without the
 // pooled output, for cin % 32 == 0 and kout % 128 == 0.
 static int convg_dispatch(const void* x, const void* w, int64_t w_stride_k, int64_t w_stride_c,
@@ -305,12 +330,12 @@ static int convg_dispatch(const void* x, const void* w, int64_t w_stride_k, int6
   if (!scl_aligned256(workspace) || workspace_bytes < need) return SCL_E_WORKSPACE;
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convg_kernel<0>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kConvgLds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convg_kernel<1>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kConvgLds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convg_kernel<2>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kConvgLds);
+#define SCL_CONVG_ATTR(E, BHV)                                                                 \
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convg_kernel<E, BHV>),              \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)GCfg<BHV>::LDS);
+    SCL_CONVG_ATTR(0, 12) SCL_CONVG_ATTR(1, 12) SCL_CONVG_ATTR(2, 12)
+    SCL_CONVG_ATTR(0, 8) SCL_CONVG_ATTR(1, 8) SCL_CONVG_ATTR(2, 8)
+#undef SCL_CONVG_ATTR
   });
   hipStream_t st = (hipStream_t)stream;
   unsigned short* packed = (unsigned short*)workspace;
@@ -318,20 +343,30 @@ static int convg_dispatch(const void* x, const void* w, int64_t w_stride_k, int6
   SCL_LAUNCH("convg_pack_kernel", convg_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256),
              0, st, (const unsigned short*)w, w_stride_k, w_stride_c, w_stride_h, w_stride_w,
              transposed ? 1 : 0, cin, kout, packed);
-  const dim3 grid(B * ((H + BH - 1) / BH) * ((W + BW - 1) / BW), kout / NB);
+  // block height: 12 rows, or 8 where the 12-row blocks would be too few or pad more
+  const int bx = (W + BW - 1) / BW, kb = kout / NB;
+  const int64_t wg12 = (int64_t)B * ((H + 11) / 12) * bx * kb, wg8 = (int64_t)B * ((H + 7) / 8) * bx * kb;
+  int cus = convg_cus();
+  // rounds of workgroups (one per CU) x rows per block = time in units of a block row
+  const int64_t t12 = ((wg12 + cus - 1) / cus) * 12, t8 = ((wg8 + cus - 1) / cus) * 8;
+  // scl_debug_set_variant(3012 / 3008) pins the block height (tests cover both variants)
+  const bool low = scl_debug_variant == 3012 ? false : scl_debug_variant == 3008 ? true : t8 < t12;
   const int dbgbits = scl_debug_variant / 1000 == 3 ? (scl_debug_variant & 3) << 1 : 0;
-  if (mask)
-    SCL_LAUNCH("convg_kernel", convg_kernel<2>, grid, dim3(NTHR), kConvgLds, st,
-               (const unsigned short*)x, (const unsigned short*)packed, B, H, W, cin, kout,
-               (unsigned short*)out, bias, 0, (const unsigned short*)mask);
-  else if (bias)
-    SCL_LAUNCH("convg_kernel", convg_kernel<1>, grid, dim3(NTHR), kConvgLds, st,
-               (const unsigned short*)x, (const unsigned short*)packed, B, H, W, cin, kout,
-               (unsigned short*)out, bias, relu ? 1 : 0, (const unsigned short*)nullptr);
-  else
-    SCL_LAUNCH("convg_kernel", convg_kernel<0>, grid, dim3(NTHR), kConvgLds, st,
-               (const unsigned short*)x, (const unsigned short*)packed, B, H, W, cin, kout,
-               (unsigned short*)out, bias, dbgbits, (const unsigned short*)nullptr);
+  const dim3 grid((unsigned)((low ? wg8 : wg12) / kb), kb);
+#define SCL_CONVG_LAUNCH(E, BHV, BIAS, RELU, MASK)                                             \
+  SCL_LAUNCH("convg_kernel", (convg_kernel<E, BHV>), grid, dim3(NTHR), GCfg<BHV>::LDS, st,     \
+             (const unsigned short*)x, (const unsigned short*)packed, B, H, W, cin, kout,      \
+             (unsigned short*)out, BIAS, RELU, (const unsigned short*)MASK)
+  if (mask) {
+    if (low) SCL_CONVG_LAUNCH(2, 8, bias, 0, mask); else SCL_CONVG_LAUNCH(2, 12, bias, 0, mask);
+  } else if (bias) {
+    if (low) SCL_CONVG_LAUNCH(1, 8, bias, relu ? 1 : 0, nullptr);
+    else SCL_CONVG_LAUNCH(1, 12, bias, relu ? 1 : 0, nullptr);
+  } else {
+    if (low) SCL_CONVG_LAUNCH(0, 8, bias, dbgbits, nullptr);
+    else SCL_CONVG_LAUNCH(0, 12, bias, dbgbits, nullptr);
+  }
+#undef SCL_CONVG_LAUNCH
   return scl_launch_status();
 }
 

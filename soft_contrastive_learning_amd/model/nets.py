@@ -132,9 +132,10 @@ def _own_conv_kind(x, w, transposed=False):
 
 def _lds_conv_pays(x, transposed=False, fused_tail=False):
     """Measured on MI355X (scripts/conv_layers.py): the LDS-weights kernel beats the library on
-    conv3_x / conv4_x — backward-data 930-1050 vs 550-650 TFLOP/s, forward 870-1030 vs
-    780-940 — but not on maps too small to fill the chip (conv5_x, 30 x 40: 72 pixel blocks)."""
-    return x.shape[2] * x.shape[3] >= 60 * 80
+    conv3_x / conv4_x — backward-data 1000-1130 vs 560-650 TFLOP/s, forward 890-1160 vs
+    780-970 — and, with its 8-row blocks, on the backward-data of conv5_x (30 x 40: 820 vs
+    600); conv5_x forward stays with the library (980 vs 770)."""
+    return x.shape[2] * x.shape[3] >= (30 * 40 if transposed else 60 * 80)
 
 
 def _conv64_ok(x, w, transposed=False):

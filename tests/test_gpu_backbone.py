@@ -230,9 +230,20 @@ def test_own_conv_fused_tails(dev, cin, cout, shape):
     assert float((a.float() - want_a).abs().max()) < 6e-3 * scale
 
 
+@pytest.fixture
+def block_height(request):
+    """Pins the LDS-weights kernel's block height (12 or 8 rows) for one test."""
+    from soft_contrastive_learning_amd import _lib as L
+    lib = L.load()
+    old = lib.scl_debug_set_variant(3000 + request.param)
+    yield request.param
+    lib.scl_debug_set_variant(old)
+
+
+@pytest.mark.parametrize('block_height', [12, 8], indirect=True)
 @pytest.mark.parametrize('cin,cout,shape', [(128, 256, (2, 12, 40)), (256, 256, (1, 30, 40)),
                                             (256, 512, (1, 15, 80)), (512, 512, (1, 7, 23))])
-def test_lds_weight_conv_deeper_layers(dev, cin, cout, shape):
+def test_lds_weight_conv_deeper_layers(dev, cin, cout, shape, block_height):
     """csrc/convg.hip: conv3_x .. conv5_x shapes, forward (+ bias / ReLU) and backward-data."""
     from soft_contrastive_learning_amd.model import nets
     b, h, w = shape
@@ -302,10 +313,11 @@ def test_first_layer_kernel(dev, shape):
     assert float((y.float() - want).abs().max()) < 6e-3 * float(want.abs().max())
 
 
+@pytest.mark.parametrize('block_height', [12, 8], indirect=True)
 @pytest.mark.parametrize('cin,cout,shape', [(64, 64, (2, 16, 40)), (128, 128, (1, 13, 37)),
                                             (128, 64, (1, 9, 33)), (256, 128, (2, 12, 40)),
                                             (512, 256, (1, 15, 80))])
-def test_backward_data_with_relu_mask_in_the_epilogue(dev, cin, cout, shape):
+def test_backward_data_with_relu_mask_in_the_epilogue(dev, cin, cout, shape, block_height):
     """scl_conv3x3_masked / scl_convg_masked: gx * [y > 0] must be the plain kernel's gx with
     the mask applied afterwards, bit for bit (zeros, negative zeros and negatives in y cut)."""
     from soft_contrastive_learning_amd.model import nets
