@@ -344,11 +344,28 @@ __device__ __forceinline__ u32x4 tr_pair(const unsigned short* a0, int step4) {
 // block (input channels 64 cb .., output channels 64 kb ..) over the tiles p, p + P, ...
 // DBG (scl_debug_set_variant(2000 + bits), timing diagnostics only — wrong results): bit 0
 // no operand reads in the product loop, bit 1 no staging after the first tile.
+// Geometry of a variant: TWv = tile width (32 or 8), NKB = 64-channel output blocks per
+// workgroup (1: [64 c] x [64 k], waves = 2 x 2 blocks x 2 pixel halves of a 256-pixel tile;
+// 2: [64 c] x [128 k], waves = 2 x 4 blocks over a whole 128-pixel tile — the x window is
+// fetched once for twice the output channels: 24 % fewer bytes per FLOP, which is what the
+// kernel is bound by once the staging is DMA: 76 KB per 72 MFMAs of every wave).
+template <int TWv, int NKB>
+struct WrwCfg {
+  static constexpr int PIXELS = 256 / NKB;
+  static constexpr int THv = PIXELS / TWv, WCv = TWv + 2, WRv = THv + 2;
+  static constexpr int XCHv = (WRv * WCv + 15) / 16;   // 1-KB chunks per x plane
+  static constexpr int GCHv = PIXELS / 16;             // per gz plane
+  static constexpr int XPL = XCHv * 16 * WPL, GPL = GCHv * 16 * WPL;
+  static constexpr int BUF = 2 * XPL + 2 * NKB * GPL;  // one staged (x window, gz tile) pair
+  static constexpr int CHUNKS = 2 * XCHv + 2 * NKB * GCHv;
+  static constexpr size_t LDS = 2 * (size_t)BUF * sizeof(unsigned short);
+};
+
 // TWv: tile width, 32 (8 x 32 tiles, a step = 16 pixels of a row) or 8 (32 x 8 tiles for
 // narrow maps, a step = two rows of 8): the same 256 pixels, 340-pixel windows and LDS image
 // either way — only the pixel <-> address maps differ; the host takes the shape that pads the
 // map less (W = 80: 96 -> 80 columns; 30 x 40: 32 x 64 -> 32 x 40).
-template <int DBG, int TWv>
+template <int DBG, int TWv, int NKB>
 __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __restrict__ x,
                                                        const unsigned short* __restrict__ gz,
                                                        int B, int H, int W, int C, int K,
@@ -356,13 +373,17 @@ __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __r
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
-  // eight waves, two per SIMD: wave (mt, nt, ph) accumulates block (mt, nt) over the steps
-  // of tile rows 4 ph .. 4 ph + 3; the two pixel halves write separate slabs
-  const int mt = wid & 1, nt = (wid >> 1) & 1, ph = wid >> 2;
+  using Cfg = WrwCfg<TWv, NKB>;
+  constexpr int XCH = Cfg::XCHv, GCH = Cfg::GCHv, XPLANE = Cfg::XPL, GPLANE = Cfg::GPL;
+  constexpr int WBUF = Cfg::BUF, WCHUNKS = Cfg::CHUNKS;
+  // eight waves, two per SIMD.  NKB = 1: wave (mt, nt, ph) accumulates block (mt, nt) over the
+  // steps of pixel half ph of the tile; the two halves write separate slabs.  NKB = 2: wave
+  // (mt, nt of 4) over the whole tile.  Eight steps of 16 pixels per wave and tile either way.
+  const int mt = wid & 1, nt = NKB == 1 ? (wid >> 1) & 1 : wid >> 1, ph = NKB == 1 ? wid >> 2 : 0;
   // transposed-read role of this lane: 16-lane group gq = lane >> 4 covers channels
   // 16 (gq & 1) .. + 15 and pixels 8 (gq >> 1) + q (+ 4); lane 4q + p addresses row q,
   // columns 4p .. 4p + 3
-  constexpr int THv = TH * TW / TWv, WCv = TWv + 2, WRv = THv + 2;
+  constexpr int THv = Cfg::THv, WCv = Cfg::WCv, WRv = Cfg::WRv;
   const int q = (lane >> 2) & 3, pp = lane & 3, gq = lane >> 4;
   const int ch0 = 16 * (gq & 1) + 4 * pp;
   // the lane's pixel inside a step: (row, column) relative to the step's first pixel
@@ -389,10 +410,10 @@ __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __r
       roff[i] = ((pix / WCv) * W + pix % WCv) * C + C64 * blockIdx.y + 8 * piece + 32 * plane;
     } else {
       const int jj = j - 2 * XCH;
-      const int plane = jj >= GCH ? 1 : 0;
+      const int plane = jj / GCH;
       const int pix = 16 * (jj - GCH * plane) + pl;
       rel[i] = j < WCHUNKS ? ((pix / TWv) << 8) | (pix % TWv) : -1;
-      roff[i] = ((pix / TWv) * W + pix % TWv) * K + C64 * blockIdx.z + 8 * piece + 32 * plane;
+      roff[i] = ((pix / TWv) * W + pix % TWv) * K + NKB * C64 * blockIdx.z + 8 * piece + 32 * plane;
     }
   }
   const unsigned short* zeros = reinterpret_cast<const unsigned short*>(zero_block);
@@ -413,7 +434,7 @@ __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __r
         glds16(ok ? x + (xo + roff[i]) : zeros, base + (plane * XPLANE + chunk * 512) * 2);
       } else if (j < WCHUNKS) {
         const int jj = j - 2 * XCH;
-        const int plane = jj >= GCH ? 1 : 0, chunk = jj - GCH * plane;
+        const int plane = jj / GCH, chunk = jj - GCH * plane;
         const int y = ty + (rel[i] >> 8), xx = tx + (rel[i] & 255);
         const bool ok = y < H && xx < W;
         glds16(ok ? gz + (go + roff[i]) : zeros,
@@ -463,9 +484,9 @@ __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __r
     for (int i = 0; i < AHEAD; ++i) af[i] = a_of(i);
     bf[0] = b_of(0);
 #pragma unroll
-    for (int i = 0; i < 9 * TH; ++i) {
-      if (i + AHEAD < 9 * TH) af[(i + AHEAD) % DEPTH] = a_of(i + AHEAD);
-      if (i % 9 == 2 && i / 9 + 1 < TH) bf[(i / 9 + 1) & 1] = b_of(i / 9 + 1);
+    for (int i = 0; i < 9 * 8; ++i) {
+      if (i + AHEAD < 9 * 8) af[(i + AHEAD) % DEPTH] = a_of(i + AHEAD);
+      if (i % 9 == 2 && i / 9 + 1 < 8) bf[(i / 9 + 1) & 1] = b_of(i / 9 + 1);
       __builtin_amdgcn_sched_barrier(0);
       acc[i % 9] = mfma32b(af[i % DEPTH], bf[(i / 9) & 1], acc[i % 9]);
     }
@@ -474,15 +495,17 @@ __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __r
     buf ^= 1;
   }
 
-  // slab[2 p + ph][cb][kb][tap][c][k]: accumulator register qq <-> c = 32 mt + acc_row(qq, h),
-  // lane r <-> k
-  float* out = slabs + (((int64_t)(2 * blockIdx.x + ph) * gridDim.y + blockIdx.y) * gridDim.z +
-                        blockIdx.z) * 9 * C64 * C64;
+  // slab[s][cb][kb][tap][c][k] with 64 x 64 blocks (cb, kb): s = 2 p + ph (NKB = 1) or p, kb =
+  // the workgroup's block or its pair 2 z + nt / 2; accumulator register qq <-> c = 32 mt +
+  // acc_row(qq, h), lane r <-> k
+  const int slab = NKB == 1 ? 2 * blockIdx.x + ph : blockIdx.x;
+  const int kb = NKB == 1 ? blockIdx.z : 2 * blockIdx.z + (nt >> 1);
+  float* out = slabs + (((int64_t)slab * gridDim.y + blockIdx.y) * (NKB * gridDim.z) + kb) * 9 * C64 * C64;
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int qq = 0; qq < 16; ++qq)
-      out[(t * C64 + 32 * mt + acc_row(qq, h)) * C64 + 32 * nt + r] = acc[t][qq];
+      out[(t * C64 + 32 * mt + acc_row(qq, h)) * C64 + 32 * (nt & 1) + r] = acc[t][qq];
 }
 
 // dW element (k, c, kh, kw) = sum over the pixel-split slabs of its (cb, kb) block, written as
@@ -968,40 +991,44 @@ extern "C" int scl_wrw3x3(const void* x, const void* gz, int B, int H, int W, in
   static std::once_flag once;
   static int cus = 256;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wrw64_kernel<0, 32>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWrw64Lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wrw64_kernel<1, 32>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWrw64Lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wrw64_kernel<2, 32>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWrw64Lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wrw64_kernel<3, 32>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWrw64Lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wrw64_kernel<0, 8>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWrw64Lds);
+#define SCL_WRW_ATTR(D, T, N)                                                                  \
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wrw64_kernel<D, T, N>),             \
+                            hipFuncAttributeMaxDynamicSharedMemorySize,                        \
+                            (int)WrwCfg<T, N>::LDS);
+    SCL_WRW_ATTR(0, 32, 1) SCL_WRW_ATTR(1, 32, 1) SCL_WRW_ATTR(2, 32, 1) SCL_WRW_ATTR(3, 32, 1)
+    SCL_WRW_ATTR(0, 8, 1) SCL_WRW_ATTR(0, 32, 2) SCL_WRW_ATTR(0, 8, 2)
+#undef SCL_WRW_ATTR
     cus = conv64_cus();
     if (cus > 1024) cus = 1024;
   });
-  // tile shape: 8 x 32, or 32 x 8 where that pads the map less
-  const int tiles_wide = B * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
-  const int tiles_tall = B * ((H + 31) / 32) * ((W + 7) / 8);
+  // [64 c] x [128 k] blocks wherever the output channels allow (scl_debug_set_variant(2100)
+  // pins the 64 x 64 variant); tile shape: wide, or tall where that pads the map less
   const int dbg = scl_debug_variant / 1000 == 2 ? scl_debug_variant & 3 : 0;
+  const int nkb = (kout % 128 == 0 && dbg == 0 && scl_debug_variant != 2100) ? 2 : 1;
+  const int th_w = nkb == 1 ? 8 : 4, th_t = nkb == 1 ? 32 : 16;
+  const int tiles_wide = B * ((H + th_w - 1) / th_w) * ((W + 31) / 32);
+  const int tiles_tall = B * ((H + th_t - 1) / th_t) * ((W + 7) / 8);
   const bool tall = tiles_tall < tiles_wide && dbg == 0;
   const int tiles = tall ? tiles_tall : tiles_wide;
   const int P = wrw_splits(cin, kout, tiles, cus);
   hipStream_t st = (hipStream_t)stream;
-#define SCL_WRW_LAUNCH(D, T)                                                                   \
-  SCL_LAUNCH("wrw64_kernel", (wrw64_kernel<D, T>), dim3(P, cin / 64, kout / 64), dim3(512),    \
-             kWrw64Lds, st, (const unsigned short*)x, (const unsigned short*)gz, B, H, W, cin, \
-             kout, (float*)workspace)
-  if (tall) SCL_WRW_LAUNCH(0, 8);
-  else if (dbg == 0) SCL_WRW_LAUNCH(0, 32);
-  else if (dbg == 1) SCL_WRW_LAUNCH(1, 32);
-  else if (dbg == 2) SCL_WRW_LAUNCH(2, 32);
-  else SCL_WRW_LAUNCH(3, 32);
+#define SCL_WRW_LAUNCH(D, T, N)                                                                \
+  SCL_LAUNCH("wrw64_kernel", (wrw64_kernel<D, T, N>), dim3(PP, cin / 64, kout / (64 * N)),     \
+             dim3(512), (WrwCfg<T, N>::LDS), st, (const unsigned short*)x,                        \
+             (const unsigned short*)gz, B, H, W, cin, kout, (float*)workspace)
+  int PP = P;
+  if (nkb == 2) {
+    PP = wrw_splits(cin, kout / 2, tiles, cus);
+    if (tall) SCL_WRW_LAUNCH(0, 8, 2); else SCL_WRW_LAUNCH(0, 32, 2);
+  } else if (tall) SCL_WRW_LAUNCH(0, 8, 1);
+  else if (dbg == 0) SCL_WRW_LAUNCH(0, 32, 1);
+  else if (dbg == 1) SCL_WRW_LAUNCH(1, 32, 1);
+  else if (dbg == 2) SCL_WRW_LAUNCH(2, 32, 1);
+  else SCL_WRW_LAUNCH(3, 32, 1);
 #undef SCL_WRW_LAUNCH
   SCL_LAUNCH("wrw64_reduce_kernel", wrw64_reduce_kernel, dim3(9 * 64 * 64 / 64, (cin / 64) * (kout / 64)),
-             dim3(256), 0, st, (const float*)workspace, 2 * P, kout / 64, w_stride_k, w_stride_c,
-             w_stride_h, w_stride_w, (unsigned short*)gw);
+             dim3(256), 0, st, (const float*)workspace, nkb == 1 ? 2 * PP : PP, kout / 64, w_stride_k,
+             w_stride_c, w_stride_h, w_stride_w, (unsigned short*)gw);
   return scl_launch_status();
 }
 
