@@ -33,6 +33,9 @@ def main():
     ap.add_argument('--marker', default='gram_coef_kernel')
     ap.add_argument('--out', default=None)
     ap.add_argument('--note', default='')
+    ap.add_argument('--gaps', type=int, default=0,
+                    help='also print the N largest classes of idle gaps (GPU idle time before a '
+                         'kernel, summed by the kernel that ends the gap), ms per step')
     args = ap.parse_args()
     rows = []
     with open(find_trace(args.trace)) as f:
@@ -70,6 +73,16 @@ def main():
                    ('; ' + args.note) if args.note else ''), '', '', ''])
     for n, (c, t) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
         w.writerow([n, round(c / k, 2), round(t / c / 1e3, 2), round(t / 1e6 / k, 4)])
+    if args.gaps:
+        gaps, last_e = {}, None
+        for s_, e_, n in win:
+            if last_e is not None and s_ > last_e:
+                c, t = gaps.get(n, (0, 0))
+                gaps[n] = (c + 1, t + s_ - last_e)
+            last_e = e_ if last_e is None else max(last_e, e_)
+        print('idle before kernel: count/step, mean us, ms/step')
+        for n, (c, t) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:args.gaps]:
+            print('  %6.1f %8.1f %8.4f  %s' % (c / k, t / c / 1e3, t / 1e6 / k, n[:90]))
     if args.out:
         out.close()
         print('wall %.3f ms/step, busy %.3f ms/step -> %s' % (wall_ms, busy_ms, args.out))

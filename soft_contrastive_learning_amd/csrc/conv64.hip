@@ -194,6 +194,20 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
   for (; tile < ntiles; tile += gridDim.x) {
     const int next = (dbg & 1) ? ntiles : tile + gridDim.x;
     if (next < ntiles) stage_issue(next, buf ^ 1);       // lands under the whole K loop
+    // EPI 3: the tile's mask values are fetched now, under the K loop (an epilogue that waits
+    // for them exposes the HBM latency once per tile row)
+    u32x4 mk[EPI == 3 ? MT : 1][2];
+    if (EPI == 3) {
+      const int b_ = tile / per_img, t2_ = tile % per_img;
+      const int my0 = (t2_ / tiles_x) * TH_ + MT * part, mx = (t2_ % tiles_x) * TW + (lane >> 1);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const bool in_ = my0 + mt < H && mx < W;
+        const int64_t mo = (((int64_t)b_ * H + my0 + mt) * W + mx) * KOUT + 32 * nt + 16 * (lane & 1);
+        mk[mt][0] = in_ ? *reinterpret_cast<const u32x4*>(mask + mo) : u32x4{0u, 0u, 0u, 0u};
+        mk[mt][1] = in_ ? *reinterpret_cast<const u32x4*>(mask + mo + 8) : u32x4{0u, 0u, 0u, 0u};
+      }
+    }
 
     // A fragment of (tile row mt, k-step ks): window pixel (MT part + mt + kh, r + kw),
     // channels 16 (ks % SPT) + 8 h .. + 7
@@ -234,11 +248,7 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
       const int oy = oy0 + mt, ox = ox0 + px;
       const bool inside = oy < H && ox < W;
       const int64_t o_off = (((int64_t)b * H + oy) * W + ox) * KOUT + 32 * nt + 16 * hf;
-      u32x4 y0v = u32x4{0u, 0u, 0u, 0u}, y1v = y0v;
-      if (EPI == 3 && inside) {                          // in flight under the transpose
-        y0v = *reinterpret_cast<const u32x4*>(mask + o_off);
-        y1v = *reinterpret_cast<const u32x4*>(mask + o_off + 8);
-      }
+      const u32x4 y0v = mk[EPI == 3 ? mt : 0][0], y1v = mk[EPI == 3 ? mt : 0][1];
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         float v = acc[mt][q] + add_r;
