@@ -314,12 +314,16 @@ int scl_conv_first(const float* img, const float* avg, const void* w, int64_t w_
 /* Weight AND bias gradient of the first layer in one pass over its gradient map (the backward
  * of model/nets.py:39's conv1_1 + bias): gw[k][c][kh][kw] = sum gz[b,y,x,k] * x0[b,y+kh-1,
  * x+kw-1,c] (bf16 at the given element strides), gb[k] = sum gz[b,y,x,k] (float32 [64]).
- * x0 [B,H,W,3] bf16 (as written by scl_conv_first), gz [B,H,W,64] bf16.  Deterministic. */
+ * x0 [B,H,W,3] bf16 (as written by scl_conv_first), gz [B,H,W,64] bf16.  Deterministic.
+ * davg != NULL also returns the gradient of the trainable mean (model/nets.py:22-24) in closed
+ * form, davg[c] = - sum w[k][c][kh][kw] * (sum of gz where that tap stays inside the image),
+ * from the same pass (w: the layer's bf16 weight at the strides given for gw) — the first
+ * layer's backward-data pass is never needed. */
 size_t scl_conv_first_wrw_workspace_bytes(void);
 int scl_conv_first_wrw(const void* x0, const void* gz, int B, int H, int W, void* gw,
                        int64_t w_stride_k, int64_t w_stride_c, int64_t w_stride_h,
-                       int64_t w_stride_w, float* gb, void* workspace, size_t workspace_bytes,
-                       void* stream);
+                       int64_t w_stride_w, float* gb, const void* w, float* davg, void* workspace,
+                       size_t workspace_bytes, void* stream);
 
 /* Weight gradient of the same layer: gw[k][c][kh][kw] = sum_{b,y,x} gz[b,y,x,k] *
  * x[b, y+kh-1, x+kw-1, c]; x, gz [B,H,W,64] bf16, gw bf16 written at the given element

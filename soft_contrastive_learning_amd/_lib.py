@@ -75,7 +75,7 @@ SIGNATURES = {
     "scl_wrw3x3_workspace_bytes": (_z, [_i, _i]),
     "scl_wrw3x3": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _l, _l, _l, _l, _p, _z, _p]),
     "scl_conv_first_wrw_workspace_bytes": (_z, []),
-    "scl_conv_first_wrw": (_i, [_p, _p, _i, _i, _i, _p, _l, _l, _l, _l, _p, _p, _z, _p]),
+    "scl_conv_first_wrw": (_i, [_p, _p, _i, _i, _i, _p, _l, _l, _l, _l, _p, _p, _p, _p, _z, _p]),
     "scl_conv_first": (_i, [_p, _p, _p, _l, _l, _l, _l, _p, _i, _i, _i, _p, _p, _p]),
     "scl_debug_set_variant": (_i, [_i]),
     "scl_prof_begin": (_i, [_i]),

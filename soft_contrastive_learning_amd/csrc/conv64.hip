@@ -28,14 +28,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int C64 = 64;
 constexpr int TH = 8, TW = 32;                       // output tile
 constexpr int WR = TH + 2, WC = TW + 2;              // halo window
-constexpr int PIX_LD = 72;                           // bf16 per staged pixel (64 + 8 pad = 144 B:
-                                                     // rows 9 slots apart -> conflict-free b128)
-constexpr int WIN = WR * WC * PIX_LD;                // bf16 per window buffer (24,480)
-constexpr int PIECES = WR * WC * 8;                  // 16-byte pieces per window (2720)
-constexpr int NPT = (PIECES + 255) / 256;            // pieces per thread (11)
 constexpr int SCR_LD = 40;                           // bf16 per scratch row (32 ch + 8 pad)
 constexpr int SCR = 32 * SCR_LD;                     // per-wave epilogue scratch (one tile row)
-constexpr size_t kConv64Lds = (2 * (size_t)WIN + 4 * (size_t)SCR) * sizeof(unsigned short);
 
 __device__ __forceinline__ f32x16 mfma32b(u32x4 a, u32x4 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
@@ -330,13 +324,8 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
 // plane, lane -> (pixel lane >> 2, 16-byte piece lane & 3) — the image is lane-linear as the
 // DMA requires.  Out-of-image halo pixels are fetched from a zero block.
 constexpr int WPL = 32;                              // bf16 per pixel and plane
-constexpr int XCH = (WR * WC + 15) / 16;             // 1-KB chunks per x plane (22: 352 pixels)
-constexpr int GCH = TH * TW / 16;                    // per gz plane (16)
-constexpr int XPLANE = XCH * 16 * WPL;
-constexpr int GPLANE = GCH * 16 * WPL;
-constexpr int WBUF = 2 * XPLANE + 2 * GPLANE;        // one staged (x window, gz tile) pair
-constexpr int WCHUNKS = 2 * XCH + 2 * GCH;           // 76 wave-instructions per tile
-constexpr size_t kWrw64Lds = 2 * (size_t)WBUF * sizeof(unsigned short);   // double-buffered
+constexpr int GPLANE = TH * TW * WPL;                // one 32-channel plane of a 256-pixel gz tile
+                                                     // (conv_first_wrw_kernel; wrw64: WrwCfg)
 
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -352,8 +341,8 @@ __device__ __forceinline__ u32x4 tr_pair(const unsigned short* a0, int step4) {
 
 // grid (pixel splits P, C / 64, K / 64): workgroup (p, cb, kb) accumulates the [9][64][64]
 // block (input channels 64 cb .., output channels 64 kb ..) over the tiles p, p + P, ...
-// DBG (scl_debug_set_variant(2000 + bits), timing diagnostics only — wrong results): bit 0
-// no operand reads in the product loop, bit 1 no staging after the first tile.
+// DBG (scl_debug_set_variant(2002), timing diagnostics only — wrong results): 2 = no staging
+// after the first tile.
 // Geometry of a variant: TWv = tile width (32 or 8), NKB = 64-channel output blocks per
 // workgroup (1: [64 c] x [64 k], waves = 2 x 2 blocks x 2 pixel halves of a 256-pixel tile;
 // 2: [64 c] x [128 k], waves = 2 x 4 blocks over a whole 128-pixel tile — the x window is
@@ -480,13 +469,11 @@ __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __r
       const int s_ = i / 9, t = i % 9;
       const int ry = TWv == 32 ? 4 * ph + (s_ >> 1) : 16 * ph + 2 * s_;
       const int cx = TWv == 32 ? 16 * (s_ & 1) : 0;
-      if (DBG & 1) return u32x4{0x3f803f80u + i, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
       return tr_pair(xl + ((ry + t / 3) * WCv + cx + t % 3) * WPL, 4 * WPL);
     };
     auto b_of = [&](int s_) {
       const int ry = TWv == 32 ? 4 * ph + (s_ >> 1) : 16 * ph + 2 * s_;
       const int cx = TWv == 32 ? 16 * (s_ & 1) : 0;
-      if (DBG & 1) return u32x4{0x3f803f80u + s_, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
       return tr_pair(gl + (ry * TWv + cx) * WPL, 4 * WPL);
     };
     u32x4 af[DEPTH], bf[2];
@@ -676,8 +663,10 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
 // as a GEMM over pixels: A = gz^T (64 channels = two m-tiles, read with ds_read_b64_tr_b16
 // from the two LDS-DMA planes of wrw64_kernel), B[p][n] = im2col of x0 gathered from a
 // [10][34][3+1] halo window, n = 3 * tap + c < 27, column 27 = 1.0 (its product is the bias
-// gradient), columns 28 .. 31 zero.  Wave w takes tile rows 2w, 2w + 1; per-workgroup slabs
-// [64][32] float32 are summed in a fixed order by conv_first_wrw_reduce_kernel.
+// gradient), columns 28 .. 31 = the indicators of the image's first / last row and first /
+// last column (their products are the border sums the closed-form gradient of the trainable
+// mean needs, conv_first_davg_kernel).  Wave w takes tile rows 2w, 2w + 1; per-workgroup
+// slabs [64][32] float32 are summed in a fixed order by conv_first_wrw_reduce_kernel.
 constexpr int FW_WIN = WR * WC * F_PIX;               // bf16 per x0 window (1360)
 constexpr int FW_GBUF = 2 * GPLANE;                   // bf16 per staged gz tile (16,384)
 constexpr size_t kFirstWrwLds = (2 * (size_t)FW_GBUF + 2 * (size_t)FW_WIN) * sizeof(unsigned short);
@@ -757,6 +746,8 @@ __global__ __launch_bounds__(256, 2) void conv_first_wrw_kernel(
     }
     const unsigned short* gl = lds + buf * FW_GBUF + pix0 * WPL + ch0;
     const unsigned short* wb = wl + buf * FW_WIN + (kh * WC + kw + 8 * h) * F_PIX + cc;
+    const int t2c = tile % per_img;
+    const int ty = (t2c / tiles_x) * TH, tx = (t2c % tiles_x) * TW;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int s_ = 4 * wid + u, ry = s_ >> 1, cx = 16 * (s_ & 1);
@@ -764,10 +755,23 @@ __global__ __launch_bounds__(256, 2) void conv_first_wrw_kernel(
       const u32x4 a1 = tr_pair(gl + GPLANE + (ry * TW + cx) * WPL, 4 * WPL);
       const unsigned short* wp = wb + (ry * WC + cx) * F_PIX;
       u32x4 bf;
-      bf.x = r < 27 ? (unsigned)wp[0 * F_PIX] | ((unsigned)wp[1 * F_PIX] << 16) : ones;
-      bf.y = r < 27 ? (unsigned)wp[2 * F_PIX] | ((unsigned)wp[3 * F_PIX] << 16) : ones;
-      bf.z = r < 27 ? (unsigned)wp[4 * F_PIX] | ((unsigned)wp[5 * F_PIX] << 16) : ones;
-      bf.w = r < 27 ? (unsigned)wp[6 * F_PIX] | ((unsigned)wp[7 * F_PIX] << 16) : ones;
+      if (r < 27) {
+        bf.x = (unsigned)wp[0 * F_PIX] | ((unsigned)wp[1 * F_PIX] << 16);
+        bf.y = (unsigned)wp[2 * F_PIX] | ((unsigned)wp[3 * F_PIX] << 16);
+        bf.z = (unsigned)wp[4 * F_PIX] | ((unsigned)wp[5 * F_PIX] << 16);
+        bf.w = (unsigned)wp[6 * F_PIX] | ((unsigned)wp[7 * F_PIX] << 16);
+      } else if (r == 27) {
+        bf = u32x4{ones, ones, ones, ones};
+      } else {
+        // border indicators of pixels (ty + ry, tx + cx + 8 h + j), j = 0 .. 7
+        const int y = ty + ry, x0c = tx + cx + 8 * h;
+        const unsigned rowhit = (r == 28 ? y == 0 : r == 29 ? y == H - 1 : false) ? 0x3f80u : 0u;
+        const int xc = r == 30 ? 0 : r == 31 ? W - 1 : -1;        // column whose pixels count
+        unsigned v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (r < 30) ? rowhit : (x0c + j == xc ? 0x3f80u : 0u);
+        bf = u32x4{v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16)};
+      }
       acc[0] = mfma32b(a0, bf, acc[0]);
       acc[1] = mfma32b(a1, bf, acc[1]);
     }
@@ -795,7 +799,7 @@ __global__ __launch_bounds__(256, 2) void conv_first_wrw_kernel(
 // strides; n == 27: bias gradient.  Fixed summation order.
 __global__ __launch_bounds__(256) void conv_first_wrw_reduce_kernel(
     const float* __restrict__ slabs, int nslab, int64_t sk, int64_t sc, int64_t sh, int64_t sw,
-    unsigned short* __restrict__ gw, float* __restrict__ gb) {
+    unsigned short* __restrict__ gw, float* __restrict__ gb, float* __restrict__ aux) {
   __shared__ float red[4][64];
   const int j = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int e = blockIdx.x * 64 + j;
@@ -816,7 +820,51 @@ __global__ __launch_bounds__(256) void conv_first_wrw_reduce_kernel(
       gw[k * sk + c * sc + (tap / 3) * sh + (tap % 3) * sw] = f32_to_bf16(s);
     } else if (n == 27) {
       gb[k] = s;
+    } else {
+      aux[(n - 28) * 64 + k] = s;      // first row, last row, first column, last column sums
     }
+  }
+}
+
+// Gradient of the trainable mean (model/nets.py:22-24) without the first layer's backward-data
+// pass: x0 = img - avg feeds a 3x3 same-padding conv, so
+//   d loss / d avg[c] = - sum_{o,kh,kw} w[o][c][kh][kw] * S[o][kh][kw],
+//   S = (sum of gz over the positions whose tap stays inside the image)
+//     = T[o] - R_kh[o] - C_kw[o] + X_khkw[o]
+// with T the bias gradient, R / C the first or last row / column sums (aux) and X the four
+// corner pixels (read here).  One block of 64 threads, thread = output channel; fixed order.
+__global__ __launch_bounds__(64) void conv_first_davg_kernel(
+    const unsigned short* __restrict__ gz, const unsigned short* __restrict__ w, int64_t sk,
+    int64_t sc, int64_t sh, int64_t sw, const float* __restrict__ gb,
+    const float* __restrict__ aux, int B, int H, int W, float* __restrict__ davg) {
+  __shared__ float part[3][64];
+  const int o = threadIdx.x;
+  float corner[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+  for (int b = 0; b < B; ++b) {
+    const int64_t img = (int64_t)b * H * W;
+    corner[0][0] += bf16_to_f32(gz[(img + 0) * C64 + o]);
+    corner[0][2] += bf16_to_f32(gz[(img + W - 1) * C64 + o]);
+    corner[2][0] += bf16_to_f32(gz[(img + (int64_t)(H - 1) * W) * C64 + o]);
+    corner[2][2] += bf16_to_f32(gz[(img + (int64_t)(H - 1) * W + W - 1) * C64 + o]);
+  }
+  const float rows[3] = {aux[0 * 64 + o], 0.f, aux[1 * 64 + o]};
+  const float cols[3] = {aux[2 * 64 + o], 0.f, aux[3 * 64 + o]};
+  float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const float s_ = gb[o] - rows[kh] - cols[kw] + corner[kh][kw];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[c] += bf16_to_f32(w[o * sk + c * sc + kh * sh + kw * sw]) * s_;
+    }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) part[c][o] = acc[c];
+  __syncthreads();
+  if (o < 3) {
+    float t = 0.f;
+    for (int i = 0; i < 64; ++i) t += part[o][i];
+    davg[o] = -t;
   }
 }
 
@@ -1005,7 +1053,7 @@ extern "C" int scl_wrw3x3(const void* x, const void* gz, int B, int H, int W, in
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wrw64_kernel<D, T, N>),             \
                             hipFuncAttributeMaxDynamicSharedMemorySize,                        \
                             (int)WrwCfg<T, N>::LDS);
-    SCL_WRW_ATTR(0, 32, 1) SCL_WRW_ATTR(1, 32, 1) SCL_WRW_ATTR(2, 32, 1) SCL_WRW_ATTR(3, 32, 1)
+    SCL_WRW_ATTR(0, 32, 1) SCL_WRW_ATTR(2, 32, 1)
     SCL_WRW_ATTR(0, 8, 1) SCL_WRW_ATTR(0, 32, 2) SCL_WRW_ATTR(0, 8, 2)
 #undef SCL_WRW_ATTR
     cus = conv64_cus();
@@ -1032,9 +1080,7 @@ extern "C" int scl_wrw3x3(const void* x, const void* gz, int B, int H, int W, in
     if (tall) SCL_WRW_LAUNCH(0, 8, 2); else SCL_WRW_LAUNCH(0, 32, 2);
   } else if (tall) SCL_WRW_LAUNCH(0, 8, 1);
   else if (dbg == 0) SCL_WRW_LAUNCH(0, 32, 1);
-  else if (dbg == 1) SCL_WRW_LAUNCH(1, 32, 1);
-  else if (dbg == 2) SCL_WRW_LAUNCH(2, 32, 1);
-  else SCL_WRW_LAUNCH(3, 32, 1);
+  else SCL_WRW_LAUNCH(2, 32, 1);
 #undef SCL_WRW_LAUNCH
   SCL_LAUNCH("wrw64_reduce_kernel", wrw64_reduce_kernel, dim3(9 * 64 * 64 / 64, (cin / 64) * (kout / 64)),
              dim3(256), 0, st, (const float*)workspace, nkb == 1 ? 2 * PP : PP, kout / 64, w_stride_k,
@@ -1073,14 +1119,15 @@ extern "C" int scl_conv_first(const float* img, const float* avg, const void* w,
 static int first_wrw_grid(int tiles, int cus) { return tiles < 2 * cus ? tiles : 2 * cus; }
 
 extern "C" size_t scl_conv_first_wrw_workspace_bytes(void) {
-  return scl_round256((size_t)2 * 1024 * 2048 * sizeof(float));      // up to 2048 slabs
+  // up to 2048 slabs [64][32] + the four border-sum rows
+  return scl_round256(((size_t)2 * 1024 * 2048 + 256) * sizeof(float));
 }
 
 extern "C" int scl_conv_first_wrw(const void* x0, const void* gz, int B, int H, int W, void* gw,
                                   int64_t w_stride_k, int64_t w_stride_c, int64_t w_stride_h,
-                                  int64_t w_stride_w, float* gb, void* workspace,
-                                  size_t workspace_bytes, void* stream) {
-  if (!x0 || !gz || !gw || !gb || !workspace) return SCL_E_NULL;
+                                  int64_t w_stride_w, float* gb, const void* w, float* davg,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+  if (!x0 || !gz || !gw || !gb || !workspace || (davg && !w)) return SCL_E_NULL;
   if (B < 1 || H < 1 || W < 1 || (int64_t)B * H * W * 64 >= (int64_t)1 << 31) return SCL_E_SHAPE;
   if ((uintptr_t)gz % 16) return SCL_E_SHAPE;
   if (!scl_aligned256(workspace) || workspace_bytes < scl_conv_first_wrw_workspace_bytes())
@@ -1096,10 +1143,15 @@ extern "C" int scl_conv_first_wrw(const void* x0, const void* gz, int B, int H, 
   const int tiles = B * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
   const int grid = first_wrw_grid(tiles, cus);
   hipStream_t st = (hipStream_t)stream;
+  float* aux = (float*)workspace + (size_t)2 * 1024 * 2048;
   SCL_LAUNCH("conv_first_wrw_kernel", conv_first_wrw_kernel, dim3(grid), dim3(256), kFirstWrwLds,
              st, (const unsigned short*)x0, (const unsigned short*)gz, B, H, W, (float*)workspace);
   SCL_LAUNCH("conv_first_wrw_reduce_kernel", conv_first_wrw_reduce_kernel, dim3(32), dim3(256), 0,
              st, (const float*)workspace, grid, w_stride_k, w_stride_c, w_stride_h, w_stride_w,
-             (unsigned short*)gw, gb);
+             (unsigned short*)gw, gb, aux);
+  if (davg)      // w has the strides of gw (the layer's bf16 weight)
+    SCL_LAUNCH("conv_first_davg_kernel", conv_first_davg_kernel, dim3(1), dim3(64), 0, st,
+               (const unsigned short*)gz, (const unsigned short*)w, w_stride_k, w_stride_c,
+               w_stride_h, w_stride_w, (const float*)gb, (const float*)aux, B, H, W, davg);
   return scl_launch_status();
 }

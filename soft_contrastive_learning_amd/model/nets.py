@@ -444,10 +444,11 @@ def avg_rgb_grad(gz, w, gb):
     return -torch.einsum('ockl,okl->c', w.float(), s)
 
 
-def first_wrw(x0, gz, w_like, gb=None):
+def first_wrw(x0, gz, w_like, gb=None, w=None):
     """conv1_1's weight gradient (bf16, strides of ``w_like``) and bias gradient (float32 [64],
     written into ``gb`` when given) from x0 [B,3,H,W] (NHWC storage) and gz [B,64,H,W]
-    (channels-last): ``scl_conv_first_wrw``."""
+    (channels-last): ``scl_conv_first_wrw``.  With the layer's weight ``w`` the gradient of
+    the trainable mean comes out of the same pass: returns (gw, davg [3])."""
     lib = L.load()
     L.require_device(x0, gz)
     x0 = x0.permute(0, 2, 3, 1).contiguous()
@@ -459,9 +460,18 @@ def first_wrw(x0, gz, w_like, gb=None):
     _work('conv_first_wrw_kernel', 2.0 * b * h * wd * 64 * 28, b * h * wd * (128.0 + 6.0))
     ws = L.workspace(lib.scl_conv_first_wrw_workspace_bytes(), gz.device)
     sk, sc, sh, sw = gw.stride()
+    davg = None
+    if w is not None:
+        if w.stride() != gw.stride() or w.dtype != gw.dtype:
+            w = w.to(gw.dtype).contiguous(memory_format=_CL) if gw.is_contiguous(memory_format=_CL) \
+                else w.to(gw.dtype).contiguous()
+        if w.stride() != gw.stride():
+            raise ValueError("w must have the strides of w_like")
+        davg = torch.empty(3, dtype=torch.float32, device=gz.device)
     L.check(lib.scl_conv_first_wrw(L.ptr(x0), L.ptr(gz), b, h, wd, L.ptr(gw), sk, sc, sh, sw,
-                                   L.ptr(gb), L.ptr(ws), ws.numel(), L.stream_of(gz)))
-    return gw
+                                   L.ptr(gb), L.ptr(w), L.ptr(davg), L.ptr(ws), ws.numel(),
+                                   L.stream_of(gz)))
+    return gw if davg is None else (gw, davg)
 
 
 class _FirstConv(torch.autograd.Function):
@@ -516,12 +526,13 @@ class _FirstConv(torch.autograd.Function):
                                         b * h * wd, c, None if masked else L.ptr(gz), L.ptr(gb),
                                         L.ptr(ws), ws.numel(), L.stream_of(gy)))
         if own_wrw:
-            # weight and bias gradient in one pass over gz (the bias gradient is one more
-            # column of the same product)
-            gw = first_wrw(x0, gz, w, gb)
+            # weight, bias and mean gradient in one pass over gz (the bias gradient and the
+            # border sums of the mean's closed form are five more columns of the same product)
+            gw, davg = first_wrw(x0, gz, w, gb, w)
         else:
             _, gw = _conv3x3_backward(gz, x0, w, False)
-        return None, avg_rgb_grad(gz, w, gb), gw, gb, None, None
+            davg = avg_rgb_grad(gz, w, gb)
+        return None, davg, gw, gb, None, None
 
 
 class _SubMean(torch.autograd.Function):

@@ -402,6 +402,17 @@ def test_first_layer_weight_and_bias_gradient(dev, shape):
     assert float((gb - bf.grad).abs().max() / bf.grad.abs().max()) < 1e-5
     gb2 = torch.empty(64, device=dev)
     assert torch.equal(gw, nets.first_wrw(x0, gz, like, gb2)) and torch.equal(gb, gb2)
+    # the gradient of the trainable mean from the same pass == the closed form in torch ==
+    # minus the spatial sum of the first layer's input gradient
+    wt = (torch.randn(64, 3, 3, 3, generator=g) * 0.1).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    gw3, davg = nets.first_wrw(x0, gz, like, gb2, wt)
+    assert torch.equal(gw3, gw)
+    want = nets.avg_rgb_grad(gz, wt, gb)
+    gx = torch.nn.functional.conv_transpose2d(gz.float(), wt.float(), padding=1)
+    direct = -gx.sum(dim=(0, 2, 3))
+    scale = float(direct.abs().max())
+    assert float((davg - want).abs().max()) < 2e-4 * scale + 1e-3
+    assert float((davg - direct).abs().max()) < 2e-3 * scale + 1e-2
 
 
 @pytest.mark.parametrize('cin,shape', [(64, (2, 16, 40)), (128, (1, 10, 38)), (64, (1, 13, 37))])
