@@ -239,6 +239,10 @@ int scl_vgg_pool_bwd(const void* g, const void* a, const void* z, int dtype, int
  *   transposed 0: out = conv(x, w)                       (forward)
  *              1: out = conv_transpose(x, w) = d loss / d input for x = d loss / d output
  *   workspace scl_conv64_workspace_bytes() bytes (the packed weight image). */
+/* The `transposed` argument of every convolution entry point is a flag word: */
+#define SCL_CONV_TRANSPOSED 1 /* backward-data: out = conv_transpose(x, w)                      */
+#define SCL_W_F32 2           /* w is the float32 master weight (rounded to bf16 while it is    */
+                              /* packed: no separate cast pass); default bf16                   */
 size_t scl_conv64_workspace_bytes(void);
 int scl_conv64(const void* x, const void* w, int64_t w_stride_k, int64_t w_stride_c,
                int64_t w_stride_h, int64_t w_stride_w, int transposed, int B, int H, int W,
@@ -279,9 +283,9 @@ int scl_convg(const void* x, const void* w, int64_t w_stride_k, int64_t w_stride
  * order (on the float32 accumulators), which is all the backward pass needs
  * (scl_vgg_pool_bwd_idx).  Shapes and workspace of scl_conv3x3; forward only. */
 int scl_conv3x3_pool_idx(const void* x, const void* w, int64_t w_stride_k, int64_t w_stride_c,
-                         int64_t w_stride_h, int64_t w_stride_w, int B, int H, int W, int cin,
-                         int kout, const float* bias, void* pooled, void* pool_idx,
-                         void* workspace, size_t workspace_bytes, void* stream);
+                         int64_t w_stride_h, int64_t w_stride_w, int flags /* SCL_W_F32 or 0 */,
+                         int B, int H, int W, int cin, int kout, const float* bias, void* pooled,
+                         void* pool_idx, void* workspace, size_t workspace_bytes, void* stream);
 /* Pool + ReLU backward from that index map: gz [B,H,W,C] = g * [a > 0] at the stored window
  * position, zero elsewhere (and on rows / columns no window covers); bias_grad[c] = sum of
  * g * [a > 0].  Arguments as scl_vgg_pool_bwd with idx in place of z. */
@@ -308,8 +312,9 @@ int scl_convg_masked(const void* x, const void* w, int64_t w_stride_k, int64_t w
  * [64][3][3][3] at the given element strides, bias float32 [64]; x0 [B,H,W,3] bf16 (kept for the
  * weight gradient), y [B,H,W,64] bf16. */
 int scl_conv_first(const float* img, const float* avg, const void* w, int64_t w_stride_k,
-                   int64_t w_stride_c, int64_t w_stride_h, int64_t w_stride_w, const float* bias,
-                   int B, int H, int W, void* x0, void* y, void* stream);
+                   int64_t w_stride_c, int64_t w_stride_h, int64_t w_stride_w,
+                   int w_f32 /* w is float32 instead of bf16 */, const float* bias, int B, int H,
+                   int W, void* x0, void* y, void* stream);
 
 /* Weight AND bias gradient of the first layer in one pass over its gradient map (the backward
  * of model/nets.py:39's conv1_1 + bias): gw[k][c][kh][kw] = sum gz[b,y,x,k] * x0[b,y+kh-1,
@@ -322,7 +327,8 @@ int scl_conv_first(const float* img, const float* avg, const void* w, int64_t w_
 size_t scl_conv_first_wrw_workspace_bytes(void);
 int scl_conv_first_wrw(const void* x0, const void* gz, int B, int H, int W, void* gw,
                        int64_t w_stride_k, int64_t w_stride_c, int64_t w_stride_h,
-                       int64_t w_stride_w, float* gb, const void* w, float* davg, void* workspace,
+                       int64_t w_stride_w, int w_f32 /* gw and w are float32 instead of bf16 */,
+                       float* gb, const void* w, float* davg, void* workspace,
                        size_t workspace_bytes, void* stream);
 
 /* Weight gradient of the same layer: gw[k][c][kh][kw] = sum_{b,y,x} gz[b,y,x,k] *
@@ -340,6 +346,10 @@ size_t scl_wrw3x3_workspace_bytes(int cin, int kout);
 int scl_wrw3x3(const void* x, const void* gz, int B, int H, int W, int cin, int kout, void* gw,
                int64_t w_stride_k, int64_t w_stride_c, int64_t w_stride_h, int64_t w_stride_w,
                void* workspace, size_t workspace_bytes, void* stream);
+/* ... with the gradient written as float32 (gw_f32 != 0) instead of bf16. */
+int scl_wrw3x3_ex(const void* x, const void* gz, int B, int H, int W, int cin, int kout, void* gw,
+                  int64_t w_stride_k, int64_t w_stride_c, int64_t w_stride_h, int64_t w_stride_w,
+                  int gw_f32, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Diagnostics (bench.py's live per-kernel timing; the reference has no counterpart

@@ -20,6 +20,7 @@ TUPLE_TRIPLET, TUPLE_LAZY_TRIPLET, TUPLE_EVIL_TRIPLET = 0, 1, 2
 TUPLE_QUADRUPLET, TUPLE_LAZY_QUADRUPLET, TUPLE_EVIL_QUADRUPLET = 3, 4, 5
 VLAD_D, VLAD_K = 512, 64
 TOPN_SCORE_F32, TOPN_SCORE_BF16X3 = 0, 1
+CONV_TRANSPOSED, W_F32 = 1, 2          # flag word of the convolution entry points
 
 _p = ctypes.c_void_p
 _i = ctypes.c_int
@@ -65,7 +66,8 @@ SIGNATURES = {
     "scl_conv3x3_fused": (_i, [_p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p, _p,
                                _z, _p]),
     "scl_convg_workspace_bytes": (_z, [_i, _i]),
-    "scl_conv3x3_pool_idx": (_i, [_p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _i, _p, _p, _p, _p, _z, _p]),
+    "scl_conv3x3_pool_idx": (_i, [_p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _z,
+                                  _p]),
     "scl_vgg_pool_bwd_idx": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _z, _p]),
     "scl_conv3x3_masked": (_i, [_p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _p, _p, _p, _z, _p]),
     "scl_convg_masked": (_i, [_p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _p, _p, _p, _z, _p]),
@@ -74,9 +76,10 @@ SIGNATURES = {
     "scl_wrw64": (_i, [_p, _p, _i, _i, _i, _p, _l, _l, _l, _l, _p, _z, _p]),
     "scl_wrw3x3_workspace_bytes": (_z, [_i, _i]),
     "scl_wrw3x3": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _l, _l, _l, _l, _p, _z, _p]),
+    "scl_wrw3x3_ex": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _l, _l, _l, _l, _i, _p, _z, _p]),
     "scl_conv_first_wrw_workspace_bytes": (_z, []),
-    "scl_conv_first_wrw": (_i, [_p, _p, _i, _i, _i, _p, _l, _l, _l, _l, _p, _p, _p, _p, _z, _p]),
-    "scl_conv_first": (_i, [_p, _p, _p, _l, _l, _l, _l, _p, _i, _i, _i, _p, _p, _p]),
+    "scl_conv_first_wrw": (_i, [_p, _p, _i, _i, _i, _p, _l, _l, _l, _l, _i, _p, _p, _p, _p, _z, _p]),
+    "scl_conv_first": (_i, [_p, _p, _p, _l, _l, _l, _l, _i, _p, _i, _i, _i, _p, _p, _p]),
     "scl_debug_set_variant": (_i, [_i]),
     "scl_prof_begin": (_i, [_i]),
     "scl_prof_count": (_i, []),

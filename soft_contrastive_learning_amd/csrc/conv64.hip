@@ -90,13 +90,15 @@ struct ConvCfg {
 // Weights -> register image [nt][ks][lane 64][8 bf16].
 //   transposed = 0 (forward):       B[c][k] = w[k][c][kh][kw]
 //   transposed = 1 (backward-data): B[k][c] = w[k][c][2-kh][2-kw]  (contraction over k)
-// w is addressed through its element strides (OIHW logical, any memory format).
+// w is addressed through its element strides (OIHW logical, any memory format); flags =
+// SCL_CONV_TRANSPOSED | SCL_W_F32 (include/scl_hip.h).
 template <int CIN, int KOUT>
-__global__ __launch_bounds__(256) void conv3x3_pack_kernel(const unsigned short* __restrict__ w,
+__global__ __launch_bounds__(256) void conv3x3_pack_kernel(const void* __restrict__ w,
                                                            int64_t sk, int64_t sc, int64_t sh,
-                                                           int64_t sw, int transposed,
+                                                           int64_t sw, int flags,
                                                            unsigned short* __restrict__ packed) {
   using Cfg = ConvCfg<CIN, KOUT>;
+  const int transposed = flags & 1, wf32 = flags & 2;
   const int idx = blockIdx.x * 256 + threadIdx.x;      // over NT * KS * 64 * 8
   if (idx >= Cfg::NT * Cfg::KS * 512) return;
   const int e = idx & 7, lane = (idx >> 3) & 63, ks = (idx >> 9) % Cfg::KS, nt = idx / (Cfg::KS * 512);
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(256) void conv3x3_pack_kernel(const unsigned short*
     off = cout * sk + cin * sc + kh * sh + kw * sw;
   else
     off = cin * sk + cout * sc + (2 - kh) * sh + (2 - kw) * sw;
-  packed[idx] = w[off];
+  packed[idx] = weight_bf16(w, off, wf32);
 }
 
 // grid = number of CUs (persistent); block 256.  EPI (compile-time, so that the plain kernel
@@ -512,7 +514,7 @@ __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __r
 __global__ __launch_bounds__(256) void wrw64_reduce_kernel(const float* __restrict__ slabs,
                                                            int nsplit, int KB, int64_t sk,
                                                            int64_t sc, int64_t sh, int64_t sw,
-                                                           unsigned short* __restrict__ gw) {
+                                                           void* __restrict__ gw, int gw_f32) {
   __shared__ float red[4][64];
   const int j = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int idx = blockIdx.x * 64 + j;                 // over 9 * 64 * 64, k fastest
@@ -531,7 +533,7 @@ __global__ __launch_bounds__(256) void wrw64_reduce_kernel(const float* __restri
   if (g == 0) {
     const float s = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
     const int k = 64 * (blk % KB) + (idx & 63), c = 64 * (blk / KB) + ((idx >> 6) & 63), t = idx >> 12;
-    gw[k * sk + c * sc + (t / 3) * sh + (t % 3) * sw] = f32_to_bf16(s);
+    store_weight_grad(gw, k * sk + c * sc + (t / 3) * sh + (t % 3) * sw, s, gw_f32);
   }
 }
 
@@ -549,7 +551,7 @@ constexpr size_t kFirstLds = ((size_t)F_WIN + 4 * (size_t)SCR) * sizeof(unsigned
 
 __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict__ img,
                                                          const float* __restrict__ avg,
-                                                         const unsigned short* __restrict__ w,
+                                                         const void* __restrict__ w, int w_f32,
                                                          int64_t sk, int64_t sc, int64_t sh,
                                                          int64_t sw, const float* __restrict__ bias,
                                                          int B, int H, int W,
@@ -571,7 +573,9 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
       for (int e = 0; e < 8; ++e) {
         const int k = 16 * ks + 8 * h + e;
         const int tap = k / 3, c = k % 3;
-        v[e] = k < 27 ? w[(32 * nt + r) * sk + c * sc + (tap / 3) * sh + (tap % 3) * sw] : 0;
+        v[e] = k < 27 ? weight_bf16(w, (32 * nt + r) * sk + c * sc + (tap / 3) * sh + (tap % 3) * sw,
+                                    w_f32)
+                      : (unsigned short)0;
       }
       wf[ks][nt] = u32x4{(unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16),
                          (unsigned)v[4] | ((unsigned)v[5] << 16), (unsigned)v[6] | ((unsigned)v[7] << 16)};
@@ -799,7 +803,7 @@ __global__ __launch_bounds__(256, 2) void conv_first_wrw_kernel(
 // strides; n == 27: bias gradient.  Fixed summation order.
 __global__ __launch_bounds__(256) void conv_first_wrw_reduce_kernel(
     const float* __restrict__ slabs, int nslab, int64_t sk, int64_t sc, int64_t sh, int64_t sw,
-    unsigned short* __restrict__ gw, float* __restrict__ gb, float* __restrict__ aux) {
+    void* __restrict__ gw, int w_f32, float* __restrict__ gb, float* __restrict__ aux) {
   __shared__ float red[4][64];
   const int j = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int e = blockIdx.x * 64 + j;
@@ -817,7 +821,7 @@ __global__ __launch_bounds__(256) void conv_first_wrw_reduce_kernel(
     const int k = e >> 5, n = e & 31;
     if (n < 27) {
       const int tap = n / 3, c = n % 3;
-      gw[k * sk + c * sc + (tap / 3) * sh + (tap % 3) * sw] = f32_to_bf16(s);
+      store_weight_grad(gw, k * sk + c * sc + (tap / 3) * sh + (tap % 3) * sw, s, w_f32);
     } else if (n == 27) {
       gb[k] = s;
     } else {
@@ -834,7 +838,7 @@ __global__ __launch_bounds__(256) void conv_first_wrw_reduce_kernel(
 // with T the bias gradient, R / C the first or last row / column sums (aux) and X the four
 // corner pixels (read here).  One block of 64 threads, thread = output channel; fixed order.
 __global__ __launch_bounds__(64) void conv_first_davg_kernel(
-    const unsigned short* __restrict__ gz, const unsigned short* __restrict__ w, int64_t sk,
+    const unsigned short* __restrict__ gz, const void* __restrict__ w, int w_f32, int64_t sk,
     int64_t sc, int64_t sh, int64_t sw, const float* __restrict__ gb,
     const float* __restrict__ aux, int B, int H, int W, float* __restrict__ davg) {
   __shared__ float part[3][64];
@@ -856,7 +860,8 @@ __global__ __launch_bounds__(64) void conv_first_davg_kernel(
     for (int kw = 0; kw < 3; ++kw) {
       const float s_ = gb[o] - rows[kh] - cols[kw] + corner[kh][kw];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) acc[c] += bf16_to_f32(w[o * sk + c * sc + kh * sh + kw * sw]) * s_;
+      for (int c = 0; c < 3; ++c)
+        acc[c] += bf16_to_f32(weight_bf16(w, o * sk + c * sc + kh * sh + kw * sw, w_f32)) * s_;
     }
 #pragma unroll
   for (int c = 0; c < 3; ++c) part[c][o] = acc[c];
@@ -894,8 +899,8 @@ int launch_conv3x3(const void* x, const void* w, int64_t sk, int64_t sc, int64_t
   });
   unsigned short* packed = (unsigned short*)workspace;
   SCL_LAUNCH("conv3x3_pack_kernel", (conv3x3_pack_kernel<CIN, KOUT>),
-             dim3(Cfg::NT * Cfg::KS * 512 / 256), dim3(256), 0, st, (const unsigned short*)w, sk, sc,
-             sh, sw, transposed ? 1 : 0, packed);
+             dim3(Cfg::NT * Cfg::KS * 512 / 256), dim3(256), 0, st, w, sk, sc, sh, sw, transposed,
+             packed);
   const int tiles = B * ((H + Cfg::TH_ - 1) / Cfg::TH_) * ((W + TW - 1) / TW);
   const dim3 grid(tiles < cus ? tiles : cus);
   if (scl_debug_variant / 1000 == 4) relu |= (scl_debug_variant & 3) << 1;
@@ -971,11 +976,11 @@ extern "C" int scl_conv3x3_fused(const void* x, const void* w, int64_t w_stride_
 
 extern "C" int scl_conv3x3_pool_idx(const void* x, const void* w, int64_t w_stride_k,
                                     int64_t w_stride_c, int64_t w_stride_h, int64_t w_stride_w,
-                                    int B, int H, int W, int cin, int kout, const float* bias,
-                                    void* pooled, void* pool_idx, void* workspace,
-                                    size_t workspace_bytes, void* stream) {
+                                    int flags, int B, int H, int W, int cin, int kout,
+                                    const float* bias, void* pooled, void* pool_idx,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
   if (!pool_idx || !pooled || !bias) return SCL_E_NULL;
-  return conv3x3_dispatch(x, w, w_stride_k, w_stride_c, w_stride_h, w_stride_w, 0, B, H, W, cin,
+  return conv3x3_dispatch(x, w, w_stride_k, w_stride_c, w_stride_h, w_stride_w, flags & 2, B, H, W, cin,
                           kout, nullptr, bias, 0, pooled, nullptr, pool_idx, workspace,
                           workspace_bytes, stream);
 }
@@ -1034,10 +1039,10 @@ extern "C" size_t scl_wrw3x3_workspace_bytes(int cin, int kout) {
   return scl_round256(2 * p * blocks * 9 * 64 * 64 * sizeof(float));   // two slabs per workgroup
 }
 
-extern "C" int scl_wrw3x3(const void* x, const void* gz, int B, int H, int W, int cin, int kout,
-                          void* gw, int64_t w_stride_k, int64_t w_stride_c, int64_t w_stride_h,
-                          int64_t w_stride_w, void* workspace, size_t workspace_bytes,
-                          void* stream) {
+extern "C" int scl_wrw3x3_ex(const void* x, const void* gz, int B, int H, int W, int cin, int kout,
+                             void* gw, int64_t w_stride_k, int64_t w_stride_c, int64_t w_stride_h,
+                             int64_t w_stride_w, int gw_f32, void* workspace,
+                             size_t workspace_bytes, void* stream) {
   if (!x || !gz || !gw || !workspace) return SCL_E_NULL;
   const size_t need = scl_wrw3x3_workspace_bytes(cin, kout);
   if (need == 0 || B < 1 || H < 1 || W < 1 || (int64_t)B * H * W > (int64_t)1 << 30)
@@ -1084,8 +1089,16 @@ extern "C" int scl_wrw3x3(const void* x, const void* gz, int B, int H, int W, in
 #undef SCL_WRW_LAUNCH
   SCL_LAUNCH("wrw64_reduce_kernel", wrw64_reduce_kernel, dim3(9 * 64 * 64 / 64, (cin / 64) * (kout / 64)),
              dim3(256), 0, st, (const float*)workspace, nkb == 1 ? 2 * PP : PP, kout / 64, w_stride_k,
-             w_stride_c, w_stride_h, w_stride_w, (unsigned short*)gw);
+             w_stride_c, w_stride_h, w_stride_w, gw, gw_f32 ? 1 : 0);
   return scl_launch_status();
+}
+
+extern "C" int scl_wrw3x3(const void* x, const void* gz, int B, int H, int W, int cin, int kout,
+                          void* gw, int64_t w_stride_k, int64_t w_stride_c, int64_t w_stride_h,
+                          int64_t w_stride_w, void* workspace, size_t workspace_bytes,
+                          void* stream) {
+  return scl_wrw3x3_ex(x, gz, B, H, W, cin, kout, gw, w_stride_k, w_stride_c, w_stride_h,
+                       w_stride_w, 0, workspace, workspace_bytes, stream);
 }
 
 extern "C" size_t scl_wrw64_workspace_bytes(void) { return scl_wrw3x3_workspace_bytes(64, 64); }
@@ -1100,8 +1113,8 @@ extern "C" int scl_wrw64(const void* x, const void* gz, int B, int H, int W, voi
 
 extern "C" int scl_conv_first(const float* img, const float* avg, const void* w, int64_t w_stride_k,
                               int64_t w_stride_c, int64_t w_stride_h, int64_t w_stride_w,
-                              const float* bias, int B, int H, int W, void* x0, void* y,
-                              void* stream) {
+                              int w_f32, const float* bias, int B, int H, int W, void* x0,
+                              void* y, void* stream) {
   if (!img || !avg || !w || !bias || !x0 || !y) return SCL_E_NULL;
   if (B < 1 || H < 1 || W < 1 || (int64_t)B * H * W > (int64_t)1 << 30) return SCL_E_SHAPE;
   if ((uintptr_t)y % 16) return SCL_E_SHAPE;
@@ -1111,7 +1124,7 @@ extern "C" int scl_conv_first(const float* img, const float* avg, const void* w,
   const int tiles = B * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
   const int grid = tiles < 8 * cus ? tiles : 8 * cus;
   SCL_LAUNCH("conv_first_kernel", conv_first_kernel, dim3(grid), dim3(256), kFirstLds,
-             (hipStream_t)stream, img, avg, (const unsigned short*)w, w_stride_k, w_stride_c,
+             (hipStream_t)stream, img, avg, w, w_f32 ? 1 : 0, w_stride_k, w_stride_c,
              w_stride_h, w_stride_w, bias, B, H, W, (unsigned short*)x0, (unsigned short*)y);
   return scl_launch_status();
 }
@@ -1125,8 +1138,9 @@ extern "C" size_t scl_conv_first_wrw_workspace_bytes(void) {
 
 extern "C" int scl_conv_first_wrw(const void* x0, const void* gz, int B, int H, int W, void* gw,
                                   int64_t w_stride_k, int64_t w_stride_c, int64_t w_stride_h,
-                                  int64_t w_stride_w, float* gb, const void* w, float* davg,
-                                  void* workspace, size_t workspace_bytes, void* stream) {
+                                  int64_t w_stride_w, int w_f32, float* gb, const void* w,
+                                  float* davg, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
   if (!x0 || !gz || !gw || !gb || !workspace || (davg && !w)) return SCL_E_NULL;
   if (B < 1 || H < 1 || W < 1 || (int64_t)B * H * W * 64 >= (int64_t)1 << 31) return SCL_E_SHAPE;
   if ((uintptr_t)gz % 16) return SCL_E_SHAPE;
@@ -1148,10 +1162,10 @@ extern "C" int scl_conv_first_wrw(const void* x0, const void* gz, int B, int H, 
              st, (const unsigned short*)x0, (const unsigned short*)gz, B, H, W, (float*)workspace);
   SCL_LAUNCH("conv_first_wrw_reduce_kernel", conv_first_wrw_reduce_kernel, dim3(32), dim3(256), 0,
              st, (const float*)workspace, grid, w_stride_k, w_stride_c, w_stride_h, w_stride_w,
-             (unsigned short*)gw, gb, aux);
+             gw, w_f32 ? 1 : 0, gb, aux);
   if (davg)      // w has the strides of gw (the layer's bf16 weight)
     SCL_LAUNCH("conv_first_davg_kernel", conv_first_davg_kernel, dim3(1), dim3(64), 0, st,
-               (const unsigned short*)gz, (const unsigned short*)w, w_stride_k, w_stride_c,
-               w_stride_h, w_stride_w, (const float*)gb, (const float*)aux, B, H, W, davg);
+               (const unsigned short*)gz, w, w_f32 ? 1 : 0, w_stride_k, w_stride_c, w_stride_h,
+               w_stride_w, (const float*)gb, (const float*)aux, B, H, W, davg);
   return scl_launch_status();
 }

@@ -79,11 +79,12 @@ __device__ __forceinline__ f32x16 mfma32b(u32x4 a, u32x4 b, f32x16 c) {
 // Weights -> [n-block][chunk][tap][k 128][c 32 + 8 pad] bf16: the exact LDS image of a step
 // (10 KB slices in the order the kernel stages them, copied by LDS-DMA as they are).
 // transposed as in conv64.hip.
-__global__ __launch_bounds__(256) void convg_pack_kernel(const unsigned short* __restrict__ w,
+__global__ __launch_bounds__(256) void convg_pack_kernel(const void* __restrict__ w,
                                                          int64_t sk, int64_t sc, int64_t sh,
-                                                         int64_t sw, int transposed, int cin,
+                                                         int64_t sw, int flags, int cin,
                                                          int kout,
                                                          unsigned short* __restrict__ packed) {
+  const int transposed = flags & 1, wf32 = flags & 2;   // SCL_CONV_TRANSPOSED | SCL_W_F32
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t total = (int64_t)9 * (cin / CCH) * kout * GPIX;
   if (idx >= total) return;
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256) void convg_pack_kernel(const unsigned short* _
     off = co * sk + ci * sc + kh * sh + kw * sw;
   else
     off = ci * sk + co * sc + (2 - kh) * sh + (2 - kw) * sw;
-  packed[idx] = w[off];
+  packed[idx] = weight_bf16(w, off, wf32);
 }
 
 __device__ uint4 zero_block[4];                      // never written: zeros
@@ -341,8 +342,7 @@ static int convg_dispatch(const void* x, const void* w, int64_t w_stride_k, int6
   unsigned short* packed = (unsigned short*)workspace;
   const int64_t total = (int64_t)9 * (cin / CCH) * kout * GPIX;
   SCL_LAUNCH("convg_pack_kernel", convg_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256),
-             0, st, (const unsigned short*)w, w_stride_k, w_stride_c, w_stride_h, w_stride_w,
-             transposed ? 1 : 0, cin, kout, packed);
+             0, st, w, w_stride_k, w_stride_c, w_stride_h, w_stride_w, transposed, cin, kout, packed);
   // block height: 12 rows, or 8 where the 12-row blocks would be too few or pad more
   const int bx = (W + BW - 1) / BW, kb = kout / NB;
   const int64_t wg12 = (int64_t)B * ((H + 11) / 12) * bx * kb, wg8 = (int64_t)B * ((H + 7) / 8) * bx * kb;

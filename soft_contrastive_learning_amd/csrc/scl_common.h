@@ -38,6 +38,20 @@ __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
   return __builtin_bit_cast(unsigned short, b);
 }
 
+// Convolution weights come as bf16 or as the float32 master copy (SCL_W_F32 in the flags
+// argument: rounded to bf16 on the way into the packed image, so no separate cast pass);
+// weight gradients go out in the same type.
+__device__ __forceinline__ unsigned short weight_bf16(const void* w, int64_t i, int f32) {
+  return f32 ? f32_to_bf16(static_cast<const float*>(w)[i])
+             : static_cast<const unsigned short*>(w)[i];
+}
+__device__ __forceinline__ void store_weight_grad(void* gw, int64_t i, float v, int f32) {
+  if (f32)
+    static_cast<float*>(gw)[i] = v;
+  else
+    static_cast<unsigned short*>(gw)[i] = f32_to_bf16(v);
+}
+
 // ReLU' on packed bf16: each 16-bit half of g survives where the matching half of y is > 0
 // (sign clear and not zero) and becomes +0 elsewhere — three packed 16-bit integer ops per
 // word (v_pk_max_i16, v_pk_min_i16, v_pk_mul_lo_u16).

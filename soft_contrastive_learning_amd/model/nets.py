@@ -114,10 +114,27 @@ def _work(name, flops, nbytes):
         e[2] += nbytes
 
 
+# The own kernels take the weight as bf16 or as the float32 master parameter (rounded to bf16
+# while it is packed: the 13 per-step cast kernels and their 13 backward casts disappear) and
+# return the weight gradient in the same type.
+_W_DTYPES = (torch.bfloat16, torch.float32)
+
+
+def _wflag(w):
+    return L.W_F32 if w.dtype == torch.float32 else 0
+
+
+def _lib_weight(w, x):
+    """The weight as the library convolution wants it: activation dtype, channels-last."""
+    if w.dtype == x.dtype and w.is_contiguous(memory_format=_CL):
+        return w
+    return w.to(dtype=x.dtype, memory_format=_CL)
+
+
 def _own_conv_kind(x, w, transposed=False):
     """'reg' (weights in registers, csrc/conv64.hip), 'lds' (weights streamed through LDS,
     csrc/convg.hip) or None (library)."""
-    if not (USE_CONV64 and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
+    if not (USE_CONV64 and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype in _W_DTYPES
             and x.dim() == 4 and w.dim() == 4 and tuple(w.shape[2:]) == (3, 3)):
         return None
     cin, kout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
@@ -178,34 +195,36 @@ def conv64(x, w, transposed=False, bias=None, relu=False, pool=False, mask=None)
         ws = L.workspace(lib.scl_conv3x3_workspace_bytes() if own
                          else lib.scl_convg_workspace_bytes(cin, kout), x.device)
         fn = lib.scl_conv3x3_masked if own else lib.scl_convg_masked
-        L.check(fn(L.ptr(x), L.ptr(w), sk, sc, sh, sw, int(bool(transposed)), b, h, wd, cin, kout,
-                   L.ptr(out), L.ptr(mask), L.ptr(ws), ws.numel(), L.stream_of(x)))
+        L.check(fn(L.ptr(x), L.ptr(w), sk, sc, sh, sw, int(bool(transposed)) | _wflag(w), b, h, wd,
+                   cin, kout, L.ptr(out), L.ptr(mask), L.ptr(ws), ws.numel(), L.stream_of(x)))
         return out
     if (cin, kout) not in _OWN_CONV_SHAPES:
         if pool:
             raise ValueError("the fused pooling epilogue exists for the register kernels only")
         ws = L.workspace(lib.scl_convg_workspace_bytes(cin, kout), x.device)
-        L.check(lib.scl_convg(L.ptr(x), L.ptr(w), sk, sc, sh, sw, int(bool(transposed)), b, h, wd,
-                              cin, kout, L.ptr(out), L.ptr(bias), int(bool(relu)), L.ptr(ws),
-                              ws.numel(), L.stream_of(x)))
+        L.check(lib.scl_convg(L.ptr(x), L.ptr(w), sk, sc, sh, sw, int(bool(transposed)) | _wflag(w),
+                              b, h, wd, cin, kout, L.ptr(out), L.ptr(bias), int(bool(relu)),
+                              L.ptr(ws), ws.numel(), L.stream_of(x)))
         return out
     ws = L.workspace(lib.scl_conv3x3_workspace_bytes(), x.device)
-    L.check(lib.scl_conv3x3_fused(L.ptr(x), L.ptr(w), sk, sc, sh, sw, int(bool(transposed)), b, h,
-                                  wd, cin, kout, L.ptr(out), L.ptr(bias), int(bool(relu)),
-                                  L.ptr(pooled), L.ptr(ws), ws.numel(), L.stream_of(x)))
+    L.check(lib.scl_conv3x3_fused(L.ptr(x), L.ptr(w), sk, sc, sh, sw,
+                                  int(bool(transposed)) | _wflag(w), b, h, wd, cin, kout,
+                                  L.ptr(out), L.ptr(bias), int(bool(relu)), L.ptr(pooled),
+                                  L.ptr(ws), ws.numel(), L.stream_of(x)))
     return (out, pooled) if pool else out
 
 
 def _own_wrw_ok(x, gz, w):
     return (USE_CONV64 and USE_WRW and x.is_cuda and x.dtype == torch.bfloat16
-            and gz.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and w.dim() == 4
+            and gz.dtype == torch.bfloat16 and w.dtype in _W_DTYPES and w.dim() == 4
             and tuple(w.shape[2:]) == (3, 3) and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0
             and max(w.shape[0], w.shape[1]) <= 1024)
 
 
 def wrw64(x, gz, w_like):
     """Weight gradient of a 3x3 same-padding convolution whose channel counts are multiples
-    of 64 (``scl_wrw3x3``): bf16 [kout,cin,3,3] with the strides of ``w_like``."""
+    of 64 (``scl_wrw3x3_ex``): [kout,cin,3,3] with the dtype (bf16 or float32) and strides of
+    ``w_like``."""
     lib = L.load()
     L.require_device(x, gz)
     x = x.contiguous(memory_format=_CL)
@@ -216,8 +235,9 @@ def wrw64(x, gz, w_like):
     _work('wrw64_kernel', 2.0 * b * h * wd * cin * kout * 9, 2.0 * b * h * wd * (cin + kout))
     ws = L.workspace(lib.scl_wrw3x3_workspace_bytes(cin, kout), x.device)
     sk, sc, sh, sw = gw.stride()
-    L.check(lib.scl_wrw3x3(L.ptr(x), L.ptr(gz), b, h, wd, cin, kout, L.ptr(gw), sk, sc, sh, sw,
-                           L.ptr(ws), ws.numel(), L.stream_of(x)))
+    L.check(lib.scl_wrw3x3_ex(L.ptr(x), L.ptr(gz), b, h, wd, cin, kout, L.ptr(gw), sk, sc, sh, sw,
+                              int(gw.dtype == torch.float32), L.ptr(ws), ws.numel(),
+                              L.stream_of(x)))
     return gw
 
 
@@ -226,7 +246,8 @@ def _conv3x3(x, w):
     kind = _own_conv_kind(x, w)
     if kind == 'reg' or (kind == 'lds' and _lds_conv_pays(x)):
         return conv64(x, w, False)
-    return torch.ops.aten.convolution(x, w, None, _ONES, _ONES, _ONES, False, [0, 0], 1)
+    return torch.ops.aten.convolution(x, _lib_weight(w, x), None, _ONES, _ONES, _ONES, False,
+                                      [0, 0], 1)
 
 
 def _wrw_pays(x):
@@ -258,6 +279,7 @@ class _GradLink:
 
 USE_MASKED_BWD = os.environ.get('SCL_MASKED_BWD', '1') != '0'
 USE_POOL_IDX = os.environ.get('SCL_POOL_IDX', '1') != '0'
+USE_F32_WEIGHTS = os.environ.get('SCL_F32_WEIGHTS', '1') != '0'
 
 
 def conv_pool_idx(x, w, bias):
@@ -276,7 +298,8 @@ def conv_pool_idx(x, w, bias):
     _work('conv3x3_kernel', 2.0 * b * h * wd * cin * kout * 9,
           b * h * wd * (2.0 * cin + 0.75 * kout))           # in + pooled bf16 / 4 + index / 4
     ws = L.workspace(lib.scl_conv3x3_workspace_bytes(), x.device)
-    L.check(lib.scl_conv3x3_pool_idx(L.ptr(x), L.ptr(w), sk, sc, sh, sw, b, h, wd, cin, kout,
+    L.check(lib.scl_conv3x3_pool_idx(L.ptr(x), L.ptr(w), sk, sc, sh, sw, _wflag(w), b, h, wd, cin,
+                                     kout,
                                      L.ptr(bias.float().contiguous()), L.ptr(a), L.ptr(idx),
                                      L.ptr(ws), ws.numel(), L.stream_of(x)))
     return a, idx
@@ -294,9 +317,10 @@ def _conv3x3_backward(gz, x, w, need_x, link=None):
         link.mark(gx)
         if own_gw:
             return gx, wrw64(x, gz, w)
-        _, gw, _ = torch.ops.aten.convolution_backward(gz, x, w, None, _ONES, _ONES, _ONES, False,
-                                                       [0, 0], 1, [False, True, False])
-        return gx, gw
+        _, gw, _ = torch.ops.aten.convolution_backward(gz, x, _lib_weight(w, gz), None, _ONES,
+                                                       _ONES, _ONES, False, [0, 0], 1,
+                                                       [False, True, False])
+        return gx, gw.to(w.dtype)
     if own_gx and own_gw:
         return (conv64(gz, w, True) if need_x else None), wrw64(x, gz, w)
     if own_gx or own_gw:
@@ -304,14 +328,15 @@ def _conv3x3_backward(gz, x, w, need_x, link=None):
         gw = wrw64(x, gz, w) if own_gw else None
         if (gx is None and need_x) or gw is None:
             lx, lw, _ = torch.ops.aten.convolution_backward(
-                gz, x, w, None, _ONES, _ONES, _ONES, False, [0, 0], 1,
+                gz, x, _lib_weight(w, gz), None, _ONES, _ONES, _ONES, False, [0, 0], 1,
                 [bool(need_x) and gx is None, gw is None, False])
             gx = lx if gx is None else gx
-            gw = lw if gw is None else gw
+            gw = lw.to(w.dtype) if gw is None else gw
         return gx, gw
-    gx, gw, _ = torch.ops.aten.convolution_backward(gz, x, w, None, _ONES, _ONES, _ONES, False,
-                                                    [0, 0], 1, [bool(need_x), True, False])
-    return gx, gw
+    gx, gw, _ = torch.ops.aten.convolution_backward(gz, x, _lib_weight(w, gz), None, _ONES, _ONES,
+                                                    _ONES, False, [0, 0], 1,
+                                                    [bool(need_x), True, False])
+    return gx, gw.to(w.dtype)
 
 
 def _glue_dtype(t):
@@ -445,7 +470,7 @@ def avg_rgb_grad(gz, w, gb):
 
 
 def first_wrw(x0, gz, w_like, gb=None, w=None):
-    """conv1_1's weight gradient (bf16, strides of ``w_like``) and bias gradient (float32 [64],
+    """conv1_1's weight gradient (dtype and strides of ``w_like``: bf16 or float32) and bias gradient (float32 [64],
     written into ``gb`` when given) from x0 [B,3,H,W] (NHWC storage) and gz [B,64,H,W]
     (channels-last): ``scl_conv_first_wrw``.  With the layer's weight ``w`` the gradient of
     the trainable mean comes out of the same pass: returns (gw, davg [3])."""
@@ -469,8 +494,8 @@ def first_wrw(x0, gz, w_like, gb=None, w=None):
             raise ValueError("w must have the strides of w_like")
         davg = torch.empty(3, dtype=torch.float32, device=gz.device)
     L.check(lib.scl_conv_first_wrw(L.ptr(x0), L.ptr(gz), b, h, wd, L.ptr(gw), sk, sc, sh, sw,
-                                   L.ptr(gb), L.ptr(w), L.ptr(davg), L.ptr(ws), ws.numel(),
-                                   L.stream_of(gz)))
+                                   int(gw.dtype == torch.float32), L.ptr(gb), L.ptr(w),
+                                   L.ptr(davg), L.ptr(ws), ws.numel(), L.stream_of(gz)))
     return gw if davg is None else (gw, davg)
 
 
@@ -484,7 +509,7 @@ class _FirstConv(torch.autograd.Function):
         lib = L.load()
         ctx.link_out = link_out
         if (USE_CONV64 and USE_FIRST and dtype == torch.bfloat16 and img_nhwc.is_cuda
-                and img_nhwc.dtype == torch.float32 and w.dtype == torch.bfloat16
+                and img_nhwc.dtype == torch.float32 and w.dtype in _W_DTYPES
                 and tuple(w.shape) == (64, 3, 3, 3)):
             # mean subtraction, cast, convolution, bias and ReLU in one kernel
             img = img_nhwc.contiguous()
@@ -495,7 +520,8 @@ class _FirstConv(torch.autograd.Function):
             sk, sc, sh, sw = w.stride()
             _work('conv_first_kernel', 2.0 * b * h * wd * 27 * 64, b * h * wd * (12.0 + 6.0 + 128.0))
             L.check(lib.scl_conv_first(L.ptr(img), L.ptr(avg.float().contiguous()), L.ptr(w), sk, sc,
-                                       sh, sw, L.ptr(bias.float().contiguous()), b, h, wd,
+                                       sh, sw, int(w.dtype == torch.float32),
+                                       L.ptr(bias.float().contiguous()), b, h, wd,
                                        L.ptr(x0), L.ptr(y), L.stream_of(img)))
             x0 = x0.permute(0, 3, 1, 2)
         else:
@@ -517,7 +543,7 @@ class _FirstConv(torch.autograd.Function):
         ws = L.workspace(lib.scl_vgg_workspace_bytes(c), gy.device)
         masked = ctx.link_out is not None and ctx.link_out.take(gy)
         own_wrw = (USE_CONV64 and USE_FIRST and gy.dtype == torch.bfloat16
-                   and x0.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
+                   and x0.dtype == torch.bfloat16 and w.dtype in _W_DTYPES
                    and tuple(w.shape) == (64, 3, 3, 3))
         gz = gy if masked else torch.empty_like(gy)
         if not (masked and own_wrw):
@@ -626,8 +652,13 @@ class VGG16NetVLAD(torch.nn.Module):
             pool_next = idx + 1 < len(VGG_LAYERS) and VGG_LAYERS[idx + 1] == 'pool'
             w = getattr(self, 'conv%s_kernel' % name)
             bias = getattr(self, 'conv%s_bias' % name)
-            # OIHW master weights -> channels-last (and bf16) operands for MIOpen
-            w = w.to(dtype=dt, memory_format=torch.channels_last)
+            if fuse and dt == torch.bfloat16 and USE_CONV64 and USE_F32_WEIGHTS:
+                # the own kernels read the float32 master weight directly (rounded to bf16 as
+                # it is packed) and return float32 gradients: no cast passes either way
+                pass
+            else:
+                # OIHW master weights -> channels-last (and bf16) operands for MIOpen
+                w = w.to(dtype=dt, memory_format=torch.channels_last)
             if fuse:
                 if x is None:
                     # nets.py:22-24 + conv1_1 + ReLU; no image gradient is ever formed

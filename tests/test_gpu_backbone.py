@@ -304,7 +304,7 @@ def test_first_layer_kernel(dev, shape):
     x0 = torch.empty((b, h, w, 3), dtype=torch.bfloat16, device=dev)
     y = torch.empty((b, 64, h, w), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
     sk, sc, sh, sw = wt.stride()
-    L.check(lib.scl_conv_first(L.ptr(img), L.ptr(avg), L.ptr(wt), sk, sc, sh, sw, L.ptr(bias), b, h, w,
+    L.check(lib.scl_conv_first(L.ptr(img), L.ptr(avg), L.ptr(wt), sk, sc, sh, sw, 0, L.ptr(bias), b, h, w,
                                L.ptr(x0), L.ptr(y), L.stream_of(img)))
     want_x0 = (img - avg).bfloat16()
     assert torch.equal(x0, want_x0)
@@ -452,3 +452,57 @@ def test_pool_index_epilogue_and_its_backward(dev, cin, shape):
         b, cin, 2 * ho, 2 * wo)
     assert torch.equal(gz.float(), want)
     assert float((gb - gg.sum(dim=(0, 2, 3))).abs().max()) < 1e-3 * float(gg.abs().sum(dim=(0, 2, 3)).max())
+
+
+@pytest.mark.parametrize('cin,cout,shape', [(64, 64, (1, 16, 40)), (128, 128, (1, 9, 33)),
+                                            (256, 256, (1, 12, 40)), (128, 256, (1, 30, 40))])
+def test_float32_master_weights_equal_the_bf16_cast(dev, cin, cout, shape):
+    """SCL_W_F32: the kernels round the float32 weight to bf16 while packing — results must be
+    bit-identical to passing the bf16 cast, and the float32 weight gradient must round to the
+    bf16 one."""
+    from soft_contrastive_learning_amd.model import nets
+    b, h, w = shape
+    g = torch.Generator().manual_seed(53)
+    x = torch.randn(b, cin, h, w, generator=g).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(b, cout, h, w, generator=g).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    w32 = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).to(dev)          # contiguous OIHW master
+    w16 = w32.to(dtype=torch.bfloat16, memory_format=torch.channels_last)
+    bias = torch.randn(cout, generator=g).to(dev)
+    assert torch.equal(nets.conv64(x, w32, False), nets.conv64(x, w16, False))
+    assert torch.equal(nets.conv64(x, w32, False, bias=bias, relu=True),
+                       nets.conv64(x, w16, False, bias=bias, relu=True))
+    assert torch.equal(nets.conv64(gy, w32, True), nets.conv64(gy, w16, True))
+    y = torch.relu(torch.randn(b, cin, h, w, generator=g)).to(dev).bfloat16().contiguous(
+        memory_format=torch.channels_last)
+    assert torch.equal(nets.conv64(gy, w32, True, mask=y), nets.conv64(gy, w16, True, mask=y))
+    if cin == cout and cin <= 128:
+        a32, i32 = nets.conv_pool_idx(x, w32, bias)
+        a16, i16 = nets.conv_pool_idx(x, w16, bias)
+        assert torch.equal(a32, a16) and torch.equal(i32, i16)
+    g32 = nets.wrw64(x, gy, w32)
+    g16 = nets.wrw64(x, gy, w16)
+    assert g32.dtype == torch.float32 and g32.stride() == w32.stride()
+    assert torch.equal(g32.to(torch.bfloat16), g16)
+
+
+def test_first_layer_with_float32_master_weights(dev):
+    from soft_contrastive_learning_amd.model import nets
+    g = torch.Generator().manual_seed(59)
+    img = torch.randint(0, 256, (1, 32, 48, 3), generator=g).float().to(dev)
+    avg = torch.tensor([123.68, 116.78, 103.94], device=dev)
+    w32 = (torch.randn(64, 3, 3, 3, generator=g) * 0.1).to(dev)
+    w16 = w32.to(dtype=torch.bfloat16, memory_format=torch.channels_last)
+    bias = torch.randn(64, generator=g).to(dev)
+    gy = torch.randn(1, 64, 32, 48, generator=g).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    outs = []
+    for wt in (w32, w16):
+        a_ = avg.clone().requires_grad_(True)
+        w_ = wt.clone().requires_grad_(True)
+        b_ = bias.clone().requires_grad_(True)
+        y = nets._FirstConv.apply(img, a_, w_, b_, torch.bfloat16, None)
+        y.backward(gy)
+        outs.append((y.detach(), a_.grad, w_.grad, b_.grad))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert outs[0][2].dtype == torch.float32 and torch.equal(outs[0][2].to(torch.bfloat16), outs[1][2])
+    assert torch.equal(outs[0][3], outs[1][3])
+    assert float((outs[0][1] - outs[1][1]).abs().max()) <= 1e-4 * float(outs[1][1].abs().max()) + 1e-5
