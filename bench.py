@@ -188,6 +188,9 @@ def main():
     dmat = np.sqrt(((xy[:, None] - xy[None]) ** 2).sum(2)).astype(np.float32)
     distances = torch.tensor(dmat[None], device=dev)
 
+    if os.environ.get('SCL_GRAD_SINK', '1') != '0':
+        nets.GRAD_SINK = buckets   # conv weight / bias gradients go straight into the flat buffer
+
     def step():
         buckets.zero()
         emb = model(images)

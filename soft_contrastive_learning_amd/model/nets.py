@@ -106,6 +106,34 @@ _OWN_CONV_SHAPES = {(64, 64), (64, 128), (128, 64), (128, 128)}      # (contract
 WORK_LOG = None
 
 
+# The trainer may install a gradient sink (parallel.GradBuckets): an object with view(p) ->
+# the tensor a parameter's gradient must end up in (or None) and done(p).  The backward
+# kernels of the convolution layers then write weight and bias gradients straight into it and
+# return None to autograd — valid because every parameter is used once per step and the sink
+# is zeroed before each backward; it removes a temporary and a `grad += new` pass per
+# parameter.  None (the default): gradients are returned to autograd as usual.
+GRAD_SINK = None
+
+
+def _grad_out(p_like):
+    """Tensor to write a parameter gradient into: the sink's slice, or a fresh one."""
+    if GRAD_SINK is not None:
+        v = GRAD_SINK.view(p_like)
+        if v is not None and v.dtype == p_like.dtype and v.stride() == p_like.stride():
+            return v
+    return torch.empty_like(p_like)
+
+
+def _grad_ret(g, p_like):
+    """What a Function returns to autograd for that gradient: None once it sits in the sink."""
+    if GRAD_SINK is not None and g is not None:
+        v = GRAD_SINK.view(p_like)
+        if v is not None and v.data_ptr() == g.data_ptr():
+            GRAD_SINK.done(p_like)
+            return None
+    return g
+
+
 def _work(name, flops, nbytes):
     if WORK_LOG is not None:
         e = WORK_LOG.setdefault(name, [0, 0.0, 0.0])
@@ -231,7 +259,7 @@ def wrw64(x, gz, w_like):
     gz = gz.contiguous(memory_format=_CL)
     b, cin, h, wd = x.shape
     kout = gz.shape[1]
-    gw = torch.empty_like(w_like)
+    gw = _grad_out(w_like)
     _work('wrw64_kernel', 2.0 * b * h * wd * cin * kout * 9, 2.0 * b * h * wd * (cin + kout))
     ws = L.workspace(lib.scl_wrw3x3_workspace_bytes(cin, kout), x.device)
     sk, sc, sh, sw = gw.stride()
@@ -366,16 +394,17 @@ class _ConvBiasAct(torch.autograd.Function):
             L.check(lib.scl_vgg_bias_act(L.ptr(y), _glue_dtype(y), L.ptr(bias), b * h * wd, c,
                                          int(relu), L.stream_of(y)))
         ctx.relu = relu
-        ctx.save_for_backward(x, w, y if relu else None)
+        ctx.save_for_backward(x, w, y if relu else None, bias)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         lib = L.load()
-        x, w, y = ctx.saved_tensors
+        x, w, y, bias = ctx.saved_tensors
         gy = gy.contiguous(memory_format=_CL)
         b, c, h, wd = gy.shape
-        gb = torch.empty(c, dtype=torch.float32, device=gy.device)
+        gb = _grad_out(bias) if bias.dtype == torch.float32 else torch.empty(
+            c, dtype=torch.float32, device=gy.device)
         ws = L.workspace(lib.scl_vgg_workspace_bytes(c), gy.device)
         # ReLU' already applied by the layer above (its backward-data epilogue)?
         masked = ctx.link_out is not None and ctx.link_out.take(gy)
@@ -387,7 +416,7 @@ class _ConvBiasAct(torch.autograd.Function):
                                     L.ptr(gz) if mask_here else None, L.ptr(gb), L.ptr(ws),
                                     ws.numel(), L.stream_of(gy)))
         gx, gw = _conv3x3_backward(gz, x, w, ctx.needs_input_grad[0], ctx.link_in)
-        return gx, gw, gb, None, None, None
+        return gx, _grad_ret(gw, w), _grad_ret(gb, bias), None, None, None
 
 
 class _ConvBiasPoolReLU(torch.autograd.Function):
@@ -405,7 +434,7 @@ class _ConvBiasPoolReLU(torch.autograd.Function):
             # the full-size convolution output is never written
             a, idx = conv_pool_idx(x, w, bias)
             ctx.by_idx = True
-            ctx.save_for_backward(x, w, idx, a)
+            ctx.save_for_backward(x, w, idx, a, bias)
             return a
         if _own_conv_kind(x, w) == 'reg' and w.shape[0] == w.shape[1]:
             # pooled map from the epilogue (no pooling pass over z)
@@ -418,18 +447,19 @@ class _ConvBiasPoolReLU(torch.autograd.Function):
             _work('vgg_pool_fwd', 0.0, 1.25 * z.numel() * z.element_size())
             L.check(lib.scl_vgg_pool_fwd(L.ptr(z), _glue_dtype(z), L.ptr(bias), b, h, wd, c,
                                          L.ptr(a), L.stream_of(z)))
-        ctx.save_for_backward(x, w, z, a)
+        ctx.save_for_backward(x, w, z, a, bias)
         return a
 
     @staticmethod
     def backward(ctx, ga):
         lib = L.load()
-        x, w, z, a = ctx.saved_tensors
+        x, w, z, a, bias = ctx.saved_tensors
         ga = ga.contiguous(memory_format=_CL)
         b, c = a.shape[0], a.shape[1]
         h, wd = x.shape[2], x.shape[3]
         gz = torch.empty((b, c, h, wd), dtype=a.dtype, device=a.device, memory_format=_CL)
-        gb = torch.empty(c, dtype=torch.float32, device=a.device)
+        gb = _grad_out(bias) if bias.dtype == torch.float32 else torch.empty(
+            c, dtype=torch.float32, device=a.device)
         ws = L.workspace(lib.scl_vgg_workspace_bytes(c), a.device)
         fn = lib.scl_vgg_pool_bwd_idx if ctx.by_idx else lib.scl_vgg_pool_bwd
         # read g, a (1/4 each) and the index bytes (1/8) or z (1); write gz
@@ -438,7 +468,7 @@ class _ConvBiasPoolReLU(torch.autograd.Function):
         L.check(fn(L.ptr(ga), L.ptr(a), L.ptr(z), _glue_dtype(a), b, h, wd, c,
                    L.ptr(gz), L.ptr(gb), L.ptr(ws), ws.numel(), L.stream_of(a)))
         gx, gw = _conv3x3_backward(gz, x, w, ctx.needs_input_grad[0], ctx.link_in)
-        return gx, gw, gb, None
+        return gx, _grad_ret(gw, w), _grad_ret(gb, bias), None
 
 
 def avg_rgb_grad(gz, w, gb):
@@ -479,7 +509,7 @@ def first_wrw(x0, gz, w_like, gb=None, w=None):
     x0 = x0.permute(0, 2, 3, 1).contiguous()
     gz = gz.contiguous(memory_format=_CL)
     b, h, wd, _ = x0.shape
-    gw = torch.empty_like(w_like)
+    gw = _grad_out(w_like)
     if gb is None:
         gb = torch.empty(64, dtype=torch.float32, device=gz.device)
     _work('conv_first_wrw_kernel', 2.0 * b * h * wd * 64 * 28, b * h * wd * (128.0 + 6.0))
@@ -530,16 +560,17 @@ class _FirstConv(torch.autograd.Function):
             b, c, h, wd = y.shape
             L.check(lib.scl_vgg_bias_act(L.ptr(y), _glue_dtype(y), L.ptr(bias), b * h * wd, c, 1,
                                          L.stream_of(y)))
-        ctx.save_for_backward(x0, w, y)
+        ctx.save_for_backward(x0, w, y, bias)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         lib = L.load()
-        x0, w, y = ctx.saved_tensors
+        x0, w, y, bias = ctx.saved_tensors
         gy = gy.contiguous(memory_format=_CL)
         b, c, h, wd = gy.shape
-        gb = torch.empty(c, dtype=torch.float32, device=gy.device)
+        gb = _grad_out(bias) if bias.dtype == torch.float32 else torch.empty(
+            c, dtype=torch.float32, device=gy.device)
         ws = L.workspace(lib.scl_vgg_workspace_bytes(c), gy.device)
         masked = ctx.link_out is not None and ctx.link_out.take(gy)
         own_wrw = (USE_CONV64 and USE_FIRST and gy.dtype == torch.bfloat16
@@ -558,7 +589,7 @@ class _FirstConv(torch.autograd.Function):
         else:
             _, gw = _conv3x3_backward(gz, x0, w, False)
             davg = avg_rgb_grad(gz, w, gb)
-        return None, davg, gw, gb, None, None
+        return None, davg, _grad_ret(gw, w), _grad_ret(gb, bias), None, None
 
 
 class _SubMean(torch.autograd.Function):

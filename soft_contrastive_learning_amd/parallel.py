@@ -128,6 +128,11 @@ class GradBuckets:
         for p in self.params:
             p.register_post_accumulate_grad_hook(self._hook)
         self._remaining = [len(m) for m in self._members]
+        # direct gradient sink (nets.GRAD_SINK): a backward kernel may write a parameter's
+        # gradient straight into its slice of the flat buffer — no temporary, no cast, no
+        # `grad += new` pass — and report it with done(); the bucket logic is the same as for
+        # gradients that arrive through autograd
+        self._by_ptr = {p.data_ptr(): p for p in self.params}
 
     def _close(self, begin, end, members):
         if not hasattr(self, '_members'):
@@ -147,6 +152,19 @@ class GradBuckets:
             b, e = self.buckets[idx]
             self._handles.append(dist.all_reduce(self.flat[b:e], op=dist.ReduceOp.SUM,
                                                  group=self.group, async_op=True))
+
+    def view(self, p_like):
+        """The flat-buffer slice of the parameter that owns p_like's storage, shaped like it
+        (None if p_like is not one of the parameters, e.g. a cast copy)."""
+        p = self._by_ptr.get(p_like.data_ptr())
+        if p is None or p.grad is None or p.shape != p_like.shape or p.dtype != self.flat.dtype:
+            return None
+        return p.grad
+
+    def done(self, p_like):
+        """The gradient of that parameter is final in the flat buffer (written by a kernel
+        enqueued on the current stream): what the post-accumulate hook would have done."""
+        self._hook(self._by_ptr[p_like.data_ptr()])
 
     def zero(self):
         """Zero all gradients in one memset and re-arm the buckets."""

@@ -225,6 +225,7 @@ def main(argv=None):
     model = nets.set_default_model(nets.VGG16NetVLAD(compute_dtype=cdt).to(dev))
     params = list(model.parameters())
     buckets = parallel.GradBuckets(params, group)
+    nets.GRAD_SINK = buckets       # conv weight / bias gradients go straight into the flat buffer
     if flags.optimizer == 'momentum':
         opt = torch.optim.SGD(params, lr=flags.base_lr, momentum=flags.momentum)
     else:
@@ -263,6 +264,7 @@ def main(argv=None):
                     saver.save_part(model, step, opt)                 # :1102
         if rank == 0:
             saver.save_epoch(model, epoch, step, opt)                 # :984
+    nets.GRAD_SINK = None
     if world > 1:
         dist.destroy_process_group()
 

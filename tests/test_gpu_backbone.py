@@ -506,3 +506,31 @@ def test_first_layer_with_float32_master_weights(dev):
     assert outs[0][2].dtype == torch.float32 and torch.equal(outs[0][2].to(torch.bfloat16), outs[1][2])
     assert torch.equal(outs[0][3], outs[1][3])
     assert float((outs[0][1] - outs[1][1]).abs().max()) <= 1e-4 * float(outs[1][1].abs().max()) + 1e-5
+
+
+def test_gradient_sink_gives_the_same_gradients(dev):
+    """nets.GRAD_SINK (parallel.GradBuckets): conv weight / bias gradients written straight
+    into the flat buffer must equal the ones that travel through autograd — bit for bit where
+    every kernel on the way is deterministic (at 480 x 640 all of conv1 .. conv4 are own
+    kernels; the library's conv5_x forward differs in the last bits from run to run)."""
+    from soft_contrastive_learning_amd import parallel
+    from soft_contrastive_learning_amd.model import nets
+    img = torch.randint(0, 256, (1, 480, 640, 3), generator=torch.Generator().manual_seed(61)).float().to(dev)
+    g = torch.randn(1, 30, 40, 512, generator=torch.Generator().manual_seed(62)).to(dev).bfloat16()
+    grads = {}
+    for sink in (False, True):
+        model = nets.VGG16NetVLAD(compute_dtype=torch.bfloat16, seed=9, fused_relu=True).to(dev)
+        buckets = parallel.GradBuckets(list(model.parameters()))
+        nets.GRAD_SINK = buckets if sink else None
+        try:
+            buckets.zero()
+            model.features(img).backward(g)
+        finally:
+            nets.GRAD_SINK = None
+        grads[sink] = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    assert set(grads[True]) == set(grads[False])
+    for n in grads[True]:
+        if n.startswith(('conv1_', 'conv2_', 'conv3_', 'conv4_', 'average_rgb')):
+            assert torch.equal(grads[True][n], grads[False][n]), n
+        else:
+            assert _nrel(grads[True][n], grads[False][n]) < 1e-3, n
