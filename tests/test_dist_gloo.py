@@ -51,6 +51,26 @@ def _reference():
     return float(loss), w1.grad.clone(), w2.grad.clone()
 
 
+class _DirectMatmul(torch.autograd.Function):
+    """y = h @ w whose weight gradient goes straight into the gradient sink (what the HIP
+    weight-gradient kernels do with nets.GRAD_SINK): autograd gets None for it."""
+
+    @staticmethod
+    def forward(ctx, h, w, sink):
+        ctx.save_for_backward(h, w)
+        ctx.sink = sink
+        return h @ w
+
+    @staticmethod
+    def backward(ctx, gy):
+        h, w = ctx.saved_tensors
+        view = ctx.sink.view(w)
+        assert view is not None and view.shape == w.shape
+        view.copy_(h.t() @ gy)
+        ctx.sink.done(w)
+        return gy @ w.t(), None, None
+
+
 def _worker(rank, port, out):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -64,9 +84,13 @@ def _worker(rank, port, out):
         # tiny buckets: every parameter gets its own collective
         buckets = parallel.GradBuckets([p1, p2], bucket_bytes=8)
         assert len(buckets.buckets) == 2
-        for it in range(2):                      # second pass checks zero()/re-arming
-            buckets.zero()
-            local = torch.tanh(xl @ p1) @ p2
+        for it in range(3):                      # second pass checks zero()/re-arming, the
+            buckets.zero()                       # third the direct gradient sink
+            if it < 2:
+                local = torch.tanh(xl @ p1) @ p2
+            else:
+                assert buckets.view(p2.detach().clone()) is None      # not a parameter's storage
+                local = _DirectMatmul.apply(torch.tanh(xl @ p1), p2, buckets)
             full = parallel.all_gather_rows(local)
             assert full.shape == (WORLD * B_LOCAL, E)
             begin, count = parallel.local_rows(B_LOCAL)
