@@ -143,9 +143,16 @@ __global__ __launch_bounds__(NTHR, 1) void convg_kernel(const unsigned short* __
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   unsigned short* scr = lds + wid * GSCR;             // after the K loop only
-  const int nb = blockIdx.y;
+  // XCD-aware order: workgroups are handed to the 8 XCDs round-robin by linear id, and every
+  // 128-channel output block nb of a pixel block reads the same windows — so the kb workgroups
+  // of a pixel block get ids 8 apart (same XCD, same moment): their window fetches meet in
+  // that XCD's L2 instead of going out to the Infinity Cache once per output block.
+  const int kb = kout / NB;
   const int blocks_x = (W + BW - 1) / BW, blocks_y = (H + BH - 1) / BH;
-  const int b = blockIdx.x / (blocks_x * blocks_y), t2 = blockIdx.x % (blocks_x * blocks_y);
+  const int grp = blockIdx.x / (8 * kb), rem = blockIdx.x - grp * 8 * kb;
+  const int nb = rem >> 3, pblk = grp * 8 + (rem & 7);
+  if (pblk >= B * blocks_x * blocks_y) return;          // padding of the last group of 8
+  const int b = pblk / (blocks_x * blocks_y), t2 = pblk % (blocks_x * blocks_y);
   const int y0 = (t2 / blocks_x) * BH, x0 = (t2 % blocks_x) * BW;
   const int CC = cin / CCH, S = 9 * CC;
   // Staging is LDS-DMA.  Weights: the packed image IS the LDS image, 20 chunks of 1 KB per
@@ -352,7 +359,8 @@ static int convg_dispatch(const void* x, const void* w, int64_t w_stride_k, int6
   // scl_debug_set_variant(3012 / 3008) pins the block height (tests cover both variants)
   const bool low = scl_debug_variant == 3012 ? false : scl_debug_variant == 3008 ? true : t8 < t12;
   const int dbgbits = scl_debug_variant / 1000 == 3 ? (scl_debug_variant & 3) << 1 : 0;
-  const dim3 grid((unsigned)((low ? wg8 : wg12) / kb), kb);
+  const int64_t pblocks = (low ? wg8 : wg12) / kb;
+  const dim3 grid((unsigned)(((pblocks + 7) / 8) * 8 * kb));
 #define SCL_CONVG_LAUNCH(E, BHV, BIAS, RELU, MASK)                                             \
   SCL_LAUNCH("convg_kernel", (convg_kernel<E, BHV>), grid, dim3(NTHR), GCfg<BHV>::LDS, st,     \
              (const unsigned short*)x, (const unsigned short*)packed, B, H, W, cin, kout,      \
