@@ -286,6 +286,11 @@ int scl_conv3x3_pool_idx(const void* x, const void* w, int64_t w_stride_k, int64
                          int64_t w_stride_h, int64_t w_stride_w, int flags /* SCL_W_F32 or 0 */,
                          int B, int H, int W, int cin, int kout, const float* bias, void* pooled,
                          void* pool_idx, void* workspace, size_t workspace_bytes, void* stream);
+/* The same for the LDS-weights shapes of scl_convg (conv3_3 / conv4_3); workspace as scl_convg. */
+int scl_convg_pool_idx(const void* x, const void* w, int64_t w_stride_k, int64_t w_stride_c,
+                       int64_t w_stride_h, int64_t w_stride_w, int flags /* SCL_W_F32 or 0 */,
+                       int B, int H, int W, int cin, int kout, const float* bias, void* pooled,
+                       void* pool_idx, void* workspace, size_t workspace_bytes, void* stream);
 /* Pool + ReLU backward from that index map: gz [B,H,W,C] = g * [a > 0] at the stored window
  * position, zero elsewhere (and on rows / columns no window covers); bias_grad[c] = sum of
  * g * [a > 0].  Arguments as scl_vgg_pool_bwd with idx in place of z. */

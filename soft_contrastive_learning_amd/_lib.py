@@ -68,6 +68,8 @@ SIGNATURES = {
     "scl_convg_workspace_bytes": (_z, [_i, _i]),
     "scl_conv3x3_pool_idx": (_i, [_p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _z,
                                   _p]),
+    "scl_convg_pool_idx": (_i, [_p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _z,
+                                _p]),
     "scl_vgg_pool_bwd_idx": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _z, _p]),
     "scl_conv3x3_masked": (_i, [_p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _p, _p, _p, _z, _p]),
     "scl_convg_masked": (_i, [_p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _p, _p, _p, _z, _p]),

@@ -126,14 +126,17 @@ __device__ __forceinline__ unsigned lds_byte_of(const unsigned short* p) {
 constexpr int WCHK = TPB * GWT * 2 / 1024;           // chunks per weight step group (30)
 
 // grid (pixel blocks, kout / 128); block 512.  EPI: 0 plain, 1 + bias (+ ReLU),
-// 2 out = conv * [mask > 0] (the ReLU' of the layer below, for backward-data).
+// 2 out = conv * [mask > 0] (the ReLU' of the layer below, for backward-data),
+// 3 out = relu(maxpool2x2(conv) + bias) [B,H/2,W/2,kout] and pidx = the window position of each
+//   maximum (one byte), no full-size output (conv3_3 / conv4_3 forward).
 template <int EPI, int BHv>
 __global__ __launch_bounds__(NTHR, 1) void convg_kernel(const unsigned short* __restrict__ x,
                                                        const unsigned short* __restrict__ packed,
                                                        int B, int H, int W, int cin, int kout,
                                                        unsigned short* __restrict__ out,
                                                        const float* __restrict__ bias, int relu,
-                                                       const unsigned short* __restrict__ mask) {
+                                                       const unsigned short* __restrict__ mask,
+                                                       unsigned char* __restrict__ pidx) {
   using G = GCfg<BHv>;
   constexpr int BH = G::BH, GWR = G::GWR, GWIN = G::GWIN, NMT = G::NMT, MS = G::MS, NS = G::NS;
   constexpr int GCHUNKS = G::GCHUNKS, GNI = G::GNI;
@@ -263,6 +266,45 @@ __global__ __launch_bounds__(NTHR, 1) void convg_kernel(const unsigned short* __
 
   // epilogue: slot j <-> m-tile 4 mg + j, n <-> channels 64 ng + 32 n ..; accumulator register
   // q <-> pixel acc_row(q, h) of the tile, lane r <-> channel r of the n-tile
+  if (EPI == 3) {
+    // 2x2 pooling in the accumulator layout: with the conflict-free pixel map a window's upper
+    // and lower row sit in the two half-waves (lanes l, l ^ 32) under the SAME register pair
+    // (q, q + 1) — one cross-lane exchange per window; lanes of the first half store.
+    const int PH = H / 2, PW = W / 2;
+#pragma unroll
+    for (int j = 0; j < MS; ++j) {
+      const int mt = MS * mg + j;
+      if (mt >= NMT) break;                           // wave-uniform
+      const int mr = mt / 5, mc = mt % 5;
+#pragma unroll
+      for (int n = 0; n < NS; ++n) {
+        const int ch = NB * nb + 32 * NS * ng + 32 * n + r;
+        const float bias_r = bias[ch];
+#pragma unroll
+        for (int q0 = 0; q0 < 16; q0 += 2) {
+          const float v0 = acc[NS * j + n][q0], v1 = acc[NS * j + n][q0 + 1];
+          const float lm = fmaxf(v0, v1);
+          const int li = v0 >= v1 ? 0 : 1;
+          const float om = __shfl_xor(lm, 32);
+          const int oi = __shfl_xor(li, 32);
+          const int qq = q0 >> 2;
+          const bool upper = (h == 0) == (qq == 0 || qq == 3);
+          const float mu = upper ? lm : om, ml = upper ? om : lm;
+          const int iu = upper ? li : oi, il = upper ? oi : li;
+          const float m = fmaxf(mu, ml);
+          const int k = mu >= ml ? iu : 2 + il;         // first maximum in raster order
+          const int p0 = acc_row(q0, 0);                // the first-half lane's pixel
+          const int py = (y0 + 4 * mr + tile_row(p0)) >> 1, px = (x0 + 8 * mc + tile_col(p0)) >> 1;
+          if (h == 0 && py < PH && px < PW) {
+            const int64_t po = (((int64_t)b * PH + py) * PW + px) * kout + ch;
+            out[po] = f32_to_bf16(fmaxf(m + bias_r, 0.f));
+            pidx[po] = (unsigned char)k;
+          }
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < MS; ++j) {
     const int mt = MS * mg + j;
@@ -326,9 +368,10 @@ static int convg_cus() {
 static int convg_dispatch(const void* x, const void* w, int64_t w_stride_k, int64_t w_stride_c,
                           int64_t w_stride_h, int64_t w_stride_w, int transposed, int B, int H,
                           int W, int cin, int kout, void* out, const float* bias, int relu,
-                          const void* mask, void* workspace, size_t workspace_bytes,
+                          const void* mask, void* pidx, void* workspace, size_t workspace_bytes,
                           void* stream) {
   if (!x || !w || !out || !workspace) return SCL_E_NULL;
+  if (pidx && (!bias || mask)) return SCL_E_NULL;
   if (mask && (bias || ((uintptr_t)mask % 16))) return SCL_E_NULL;
   const size_t need = scl_convg_workspace_bytes(cin, kout);
   if (need == 0 || B < 1 || H < 1 || W < 1 || (int64_t)B * H * W > (int64_t)1 << 30)
@@ -341,8 +384,8 @@ static int convg_dispatch(const void* x, const void* w, int64_t w_stride_k, int6
 #define SCL_CONVG_ATTR(E, BHV)                                                                 \
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convg_kernel<E, BHV>),              \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)GCfg<BHV>::LDS);
-    SCL_CONVG_ATTR(0, 12) SCL_CONVG_ATTR(1, 12) SCL_CONVG_ATTR(2, 12)
-    SCL_CONVG_ATTR(0, 8) SCL_CONVG_ATTR(1, 8) SCL_CONVG_ATTR(2, 8)
+    SCL_CONVG_ATTR(0, 12) SCL_CONVG_ATTR(1, 12) SCL_CONVG_ATTR(2, 12) SCL_CONVG_ATTR(3, 12)
+    SCL_CONVG_ATTR(0, 8) SCL_CONVG_ATTR(1, 8) SCL_CONVG_ATTR(2, 8) SCL_CONVG_ATTR(3, 8)
 #undef SCL_CONVG_ATTR
   });
   hipStream_t st = (hipStream_t)stream;
@@ -364,8 +407,11 @@ static int convg_dispatch(const void* x, const void* w, int64_t w_stride_k, int6
 #define SCL_CONVG_LAUNCH(E, BHV, BIAS, RELU, MASK)                                             \
   SCL_LAUNCH("convg_kernel", (convg_kernel<E, BHV>), grid, dim3(NTHR), GCfg<BHV>::LDS, st,     \
              (const unsigned short*)x, (const unsigned short*)packed, B, H, W, cin, kout,      \
-             (unsigned short*)out, BIAS, RELU, (const unsigned short*)MASK)
-  if (mask) {
+             (unsigned short*)out, BIAS, RELU, (const unsigned short*)MASK,                    \
+             (unsigned char*)pidx)
+  if (pidx) {
+    if (low) SCL_CONVG_LAUNCH(3, 8, bias, 0, nullptr); else SCL_CONVG_LAUNCH(3, 12, bias, 0, nullptr);
+  } else if (mask) {
     if (low) SCL_CONVG_LAUNCH(2, 8, bias, 0, mask); else SCL_CONVG_LAUNCH(2, 12, bias, 0, mask);
   } else if (bias) {
     if (low) SCL_CONVG_LAUNCH(1, 8, bias, relu ? 1 : 0, nullptr);
@@ -383,7 +429,19 @@ extern "C" int scl_convg(const void* x, const void* w, int64_t w_stride_k, int64
                          int W, int cin, int kout, void* out, const float* bias, int relu,
                          void* workspace, size_t workspace_bytes, void* stream) {
   return convg_dispatch(x, w, w_stride_k, w_stride_c, w_stride_h, w_stride_w, transposed, B, H, W,
-                        cin, kout, out, bias, relu, nullptr, workspace, workspace_bytes, stream);
+                        cin, kout, out, bias, relu, nullptr, nullptr, workspace, workspace_bytes,
+                        stream);
+}
+
+extern "C" int scl_convg_pool_idx(const void* x, const void* w, int64_t w_stride_k,
+                                  int64_t w_stride_c, int64_t w_stride_h, int64_t w_stride_w,
+                                  int flags, int B, int H, int W, int cin, int kout,
+                                  const float* bias, void* pooled, void* pool_idx, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  if (!pool_idx || !pooled || !bias) return SCL_E_NULL;
+  return convg_dispatch(x, w, w_stride_k, w_stride_c, w_stride_h, w_stride_w, flags & 2, B, H, W,
+                        cin, kout, pooled, bias, 0, nullptr, pool_idx, workspace, workspace_bytes,
+                        stream);
 }
 
 extern "C" int scl_convg_masked(const void* x, const void* w, int64_t w_stride_k,
@@ -393,5 +451,5 @@ extern "C" int scl_convg_masked(const void* x, const void* w, int64_t w_stride_k
                                 void* stream) {
   if (!mask) return SCL_E_NULL;
   return convg_dispatch(x, w, w_stride_k, w_stride_c, w_stride_h, w_stride_w, transposed, B, H, W,
-                        cin, kout, out, nullptr, 0, mask, workspace, workspace_bytes, stream);
+                        cin, kout, out, nullptr, 0, mask, nullptr, workspace, workspace_bytes, stream);
 }

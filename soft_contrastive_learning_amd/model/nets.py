@@ -323,13 +323,15 @@ def conv_pool_idx(x, w, bias):
     idx = torch.empty((b, kout, h // 2, wd // 2), dtype=torch.uint8, device=x.device,
                       memory_format=_CL)
     sk, sc, sh, sw = w.stride()
-    _work('conv3x3_kernel', 2.0 * b * h * wd * cin * kout * 9,
+    own = (cin, kout) in _OWN_CONV_SHAPES
+    _work('conv3x3_kernel' if own else 'convg_kernel', 2.0 * b * h * wd * cin * kout * 9,
           b * h * wd * (2.0 * cin + 0.75 * kout))           # in + pooled bf16 / 4 + index / 4
-    ws = L.workspace(lib.scl_conv3x3_workspace_bytes(), x.device)
-    L.check(lib.scl_conv3x3_pool_idx(L.ptr(x), L.ptr(w), sk, sc, sh, sw, _wflag(w), b, h, wd, cin,
-                                     kout,
-                                     L.ptr(bias.float().contiguous()), L.ptr(a), L.ptr(idx),
-                                     L.ptr(ws), ws.numel(), L.stream_of(x)))
+    ws = L.workspace(lib.scl_conv3x3_workspace_bytes() if own
+                     else lib.scl_convg_workspace_bytes(cin, kout), x.device)
+    fn = lib.scl_conv3x3_pool_idx if own else lib.scl_convg_pool_idx
+    L.check(fn(L.ptr(x), L.ptr(w), sk, sc, sh, sw, _wflag(w), b, h, wd, cin, kout,
+               L.ptr(bias.float().contiguous()), L.ptr(a), L.ptr(idx), L.ptr(ws), ws.numel(),
+               L.stream_of(x)))
     return a, idx
 
 
@@ -429,8 +431,10 @@ class _ConvBiasPoolReLU(torch.autograd.Function):
         lib = L.load()
         ctx.link_in = link_in
         ctx.by_idx = False
-        if _own_conv_kind(x, w) == 'reg' and w.shape[0] == w.shape[1] and USE_POOL_IDX:
-            # conv1_2 / conv2_2: pooled map and the position of each maximum from the epilogue;
+        kind = _own_conv_kind(x, w)
+        if USE_POOL_IDX and ((kind == 'reg' and w.shape[0] == w.shape[1])
+                             or (kind == 'lds' and _lds_conv_pays(x))):
+            # conv1_2 .. conv4_3: pooled map and the position of each maximum from the epilogue;
             # the full-size convolution output is never written
             a, idx = conv_pool_idx(x, w, bias)
             ctx.by_idx = True
