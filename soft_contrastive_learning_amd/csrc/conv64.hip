@@ -507,33 +507,37 @@ __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __r
       out[(t * C64 + 32 * mt + acc_row(qq, h)) * C64 + 32 * (nt & 1) + r] = acc[t][qq];
 }
 
-// dW element (k, c, kh, kw) = sum over the pixel-split slabs of its (cb, kb) block, written as
-// bf16 at the weight's strides.  grid (9*64*64/64, CB * KB), block 256: thread (j, g) sums the
-// slabs p = g, g + 4, ... of element 64 * blockIdx.x + j; the four partials are combined in a
-// fixed order.
+// dW element (k, c, kh, kw) = sum over the pixel-split slabs of its (cb, kb) block, written
+// at the weight's strides (bf16 or float32).  grid (9*64*64/256, CB * KB), block 256: thread
+// (j, g) sums the slabs p = g, g + 4, ... of the FOUR elements 4 (64 * blockIdx.x + j) .. + 3
+// (16-byte loads); the four partials are combined in a fixed order.
 __global__ __launch_bounds__(256) void wrw64_reduce_kernel(const float* __restrict__ slabs,
                                                            int nsplit, int KB, int64_t sk,
                                                            int64_t sc, int64_t sh, int64_t sw,
                                                            void* __restrict__ gw, int gw_f32) {
-  __shared__ float red[4][64];
+  __shared__ f32x4 red[4][64];
   const int j = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int idx = blockIdx.x * 64 + j;                 // over 9 * 64 * 64, k fastest
+  const int idx = 4 * (blockIdx.x * 64 + j);           // over 9 * 64 * 64, k fastest
   const int blk = blockIdx.y, nblk = gridDim.y;        // blk = cb * KB + kb
   const int64_t stride = (int64_t)nblk * 9 * C64 * C64;
   const float* base = slabs + (int64_t)blk * 9 * C64 * C64 + idx;
-  float s0 = 0.f, s1 = 0.f;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
   int i = g;
   for (; i + 4 < nsplit; i += 8) {
-    s0 += base[(int64_t)i * stride];
-    s1 += base[(int64_t)(i + 4) * stride];
+    s0 += *reinterpret_cast<const f32x4*>(base + (int64_t)i * stride);
+    s1 += *reinterpret_cast<const f32x4*>(base + (int64_t)(i + 4) * stride);
   }
-  if (i < nsplit) s0 += base[(int64_t)i * stride];
+  if (i < nsplit) s0 += *reinterpret_cast<const f32x4*>(base + (int64_t)i * stride);
   red[g][j] = s0 + s1;
   __syncthreads();
   if (g == 0) {
-    const float s = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
-    const int k = 64 * (blk % KB) + (idx & 63), c = 64 * (blk / KB) + ((idx >> 6) & 63), t = idx >> 12;
-    store_weight_grad(gw, k * sk + c * sc + (t / 3) * sh + (t % 3) * sw, s, gw_f32);
+    const f32x4 s = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+    const int c = 64 * (blk / KB) + ((idx >> 6) & 63), t = idx >> 12;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = 64 * (blk % KB) + ((idx + e) & 63);
+      store_weight_grad(gw, k * sk + c * sc + (t / 3) * sh + (t % 3) * sw, s[e], gw_f32);
+    }
   }
 }
 
@@ -1087,7 +1091,7 @@ extern "C" int scl_wrw3x3_ex(const void* x, const void* gz, int B, int H, int W,
   else if (dbg == 0) SCL_WRW_LAUNCH(0, 32, 1);
   else SCL_WRW_LAUNCH(2, 32, 1);
 #undef SCL_WRW_LAUNCH
-  SCL_LAUNCH("wrw64_reduce_kernel", wrw64_reduce_kernel, dim3(9 * 64 * 64 / 64, (cin / 64) * (kout / 64)),
+  SCL_LAUNCH("wrw64_reduce_kernel", wrw64_reduce_kernel, dim3(9 * 64 * 64 / 256, (cin / 64) * (kout / 64)),
              dim3(256), 0, st, (const float*)workspace, nkb == 1 ? 2 * PP : PP, kout / 64, w_stride_k,
              w_stride_c, w_stride_h, w_stride_w, gw, gw_f32 ? 1 : 0);
   return scl_launch_status();
