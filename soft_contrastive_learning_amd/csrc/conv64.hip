@@ -199,9 +199,9 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const bool in_ = my0 + mt < H && mx < W;
-        const int64_t mo = (((int64_t)b_ * H + my0 + mt) * W + mx) * KOUT + 32 * nt + 16 * (lane & 1);
+        const int64_t mo = (((int64_t)b_ * H + my0 + mt) * W + mx) * KOUT + 32 * nt + 8 * (lane & 1);
         mk[mt][0] = in_ ? *reinterpret_cast<const u32x4*>(mask + mo) : u32x4{0u, 0u, 0u, 0u};
-        mk[mt][1] = in_ ? *reinterpret_cast<const u32x4*>(mask + mo + 8) : u32x4{0u, 0u, 0u, 0u};
+        mk[mt][1] = in_ ? *reinterpret_cast<const u32x4*>(mask + mo + 16) : u32x4{0u, 0u, 0u, 0u};
       }
     }
 
@@ -239,11 +239,13 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
     const int oy0 = (t2 / tiles_x) * TH_ + MT * part, ox0 = (t2 % tiles_x) * TW;
 #pragma unroll
     for (int mt = 0; mt < (EPI == 4 ? 0 : MT); ++mt) {
-      // 32 pixels x 64 bytes: lane -> pixel lane >> 1, 32-byte half lane & 1
+      // 32 pixels x 64 bytes in two store instructions: lane -> pixel lane >> 1; instruction i
+      // writes channels 16 i + 8 (lane & 1) .. + 7, so a lane pair covers 32 contiguous bytes
+      // (whole 32-byte sectors — interleaving the two lanes' 16-byte pieces writes half sectors)
       const int px = lane >> 1, hf = lane & 1;
       const int oy = oy0 + mt, ox = ox0 + px;
       const bool inside = oy < H && ox < W;
-      const int64_t o_off = (((int64_t)b * H + oy) * W + ox) * KOUT + 32 * nt + 16 * hf;
+      const int64_t o_off = (((int64_t)b * H + oy) * W + ox) * KOUT + 32 * nt + 8 * hf;
       const u32x4 y0v = mk[EPI == 3 ? mt : 0][0], y1v = mk[EPI == 3 ? mt : 0][1];
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
@@ -252,8 +254,8 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
         scr[acc_row(q, h) * SCR_LD + r] = f32_to_bf16(v);
       }
       __builtin_amdgcn_wave_barrier();
-      u32x4 v0 = *reinterpret_cast<const u32x4*>(scr + px * SCR_LD + 16 * hf);
-      u32x4 v1 = *reinterpret_cast<const u32x4*>(scr + px * SCR_LD + 16 * hf + 8);
+      u32x4 v0 = *reinterpret_cast<const u32x4*>(scr + px * SCR_LD + 8 * hf);
+      u32x4 v1 = *reinterpret_cast<const u32x4*>(scr + px * SCR_LD + 8 * hf + 16);
       __builtin_amdgcn_wave_barrier();
       if (EPI == 3) {
         v0 = relu_mask(v0, y0v);
@@ -261,7 +263,7 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
       }
       if (inside && !(dbg & 2)) {
         *reinterpret_cast<u32x4*>(out + o_off) = v0;
-        *reinterpret_cast<u32x4*>(out + o_off + 8) = v1;
+        *reinterpret_cast<u32x4*>(out + o_off + 16) = v1;
       }
     }
     if (EPI == 2 || EPI == 4) {
@@ -649,14 +651,14 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
               f32_to_bf16(fmaxf((nt ? acc1[q] : acc0[q]) + bb, 0.f));
         __builtin_amdgcn_wave_barrier();
         const int px = lane >> 1, hf = lane & 1;
-        const u32x4 v0 = *reinterpret_cast<const u32x4*>(scr + px * SCR_LD + 16 * hf);
-        const u32x4 v1 = *reinterpret_cast<const u32x4*>(scr + px * SCR_LD + 16 * hf + 8);
+        const u32x4 v0 = *reinterpret_cast<const u32x4*>(scr + px * SCR_LD + 8 * hf);
+        const u32x4 v1 = *reinterpret_cast<const u32x4*>(scr + px * SCR_LD + 8 * hf + 16);
         __builtin_amdgcn_wave_barrier();
         const int ox = tx + px;
-        if (oy < H && ox < W) {
-          unsigned short* o = y + (((int64_t)b * H + oy) * W + ox) * C64 + 32 * nt + 16 * hf;
+        if (oy < H && ox < W) {      // a lane pair writes 32 contiguous bytes per instruction
+          unsigned short* o = y + (((int64_t)b * H + oy) * W + ox) * C64 + 32 * nt + 8 * hf;
           *reinterpret_cast<u32x4*>(o) = v0;
-          *reinterpret_cast<u32x4*>(o + 8) = v1;
+          *reinterpret_cast<u32x4*>(o + 16) = v1;
         }
       }
     }

@@ -317,11 +317,13 @@ __global__ __launch_bounds__(NTHR, 1) void convg_kernel(const unsigned short* __
       const int oy = y0 + 4 * mr + tile_row(px), ox = x0 + 8 * mc + tile_col(px);
       const bool inside = oy < H && ox < W;
       const int64_t o_off =
-          (((int64_t)b * H + oy) * W + ox) * kout + NB * nb + 32 * NS * ng + 32 * n + 16 * hf;
+          (((int64_t)b * H + oy) * W + ox) * kout + NB * nb + 32 * NS * ng + 32 * n + 8 * hf;
+      // instruction i of the two covers channels 16 i + 8 hf .. + 7: a lane pair writes (and
+      // reads the mask as) 32 contiguous bytes — whole sectors
       u32x4 y0v = u32x4{0u, 0u, 0u, 0u}, y1v = y0v;
       if (EPI == 2 && inside) {                          // in flight under the transpose
         y0v = *reinterpret_cast<const u32x4*>(mask + o_off);
-        y1v = *reinterpret_cast<const u32x4*>(mask + o_off + 8);
+        y1v = *reinterpret_cast<const u32x4*>(mask + o_off + 16);
       }
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
@@ -330,8 +332,8 @@ __global__ __launch_bounds__(NTHR, 1) void convg_kernel(const unsigned short* __
         scr[acc_row(q, h) * GSCR_LD + r] = f32_to_bf16(v);
       }
       __builtin_amdgcn_wave_barrier();
-      u32x4 v0 = *reinterpret_cast<const u32x4*>(scr + px * GSCR_LD + 16 * hf);
-      u32x4 v1 = *reinterpret_cast<const u32x4*>(scr + px * GSCR_LD + 16 * hf + 8);
+      u32x4 v0 = *reinterpret_cast<const u32x4*>(scr + px * GSCR_LD + 8 * hf);
+      u32x4 v1 = *reinterpret_cast<const u32x4*>(scr + px * GSCR_LD + 8 * hf + 16);
       __builtin_amdgcn_wave_barrier();
       if (EPI == 2) {
         v0 = relu_mask(v0, y0v);
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(NTHR, 1) void convg_kernel(const unsigned short* __
       }
       if (inside) {
         *reinterpret_cast<u32x4*>(out + o_off) = v0;
-        *reinterpret_cast<u32x4*>(out + o_off + 8) = v1;
+        *reinterpret_cast<u32x4*>(out + o_off + 16) = v1;
       }
     }
   }
