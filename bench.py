@@ -2,9 +2,10 @@
 """Headline benchmark: train-step images/sec, VGG16-NetVLAD + soft contrastive (wms) loss,
 640x480, on N MI355X (BASELINE.json metric; workload = configs[1], per-GPU batch 24).
 
-One step = VGG16 forward (PyTorch-ROCm, bf16 channels-last) -> NetVLAD (HIP) ->
-[all-gather of the embeddings when N > 1] -> wms loss forward+backward (HIP) -> NetVLAD
-backward (HIP) -> VGG backward -> [bucketed gradient all-reduce] -> Adam update.
+One step = VGG16 forward (hand-written HIP convolutions, bf16 channels-last; the library only
+for conv5_x forward) -> NetVLAD (HIP) -> [all-gather of the embeddings when N > 1] -> wms loss
+forward+backward (HIP) -> NetVLAD backward (HIP) -> VGG backward (HIP) -> [bucketed gradient
+all-reduce] -> Adam update.
 Inputs are synthetic and resident in HBM before the timed region.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
@@ -12,8 +13,11 @@ Inputs are synthetic and resident in HBM before the timed region.
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline     live HIP-event timing of the dominant hand-written kernel over the timed
-               steps (scl_prof_* sink in the C library), priced on its governing roofline
+  roofline     live HIP-event timing of the dominant hand-written kernel (scl_prof_* sink in
+               the C library), priced on its governing roofline.  The events bracket every
+               launch and cost ~6 % of a step, so they run over a few extra steps right after
+               the K timed ones (`kernel_timing` says how many; SCL_BENCH_EVENTS_IN_TIMED_REGION=1
+               moves them into the timed region)
   kernels      the same for every hand-written kernel on the path
   cpu_baseline the CPU restatement of the same step timed on the host cores (N=1 only)
 """
@@ -212,13 +216,33 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    nets.WORK_LOG = {}        # algorithmic flops / bytes of the backbone kernels, per call site
-    with _lib.KernelTimer(capacity=256 * max(args.steps, 1)) as kt:
+    # The K timed steps run uninstrumented: bracketing every kernel launch with two HIP events
+    # costs about 6 % of a step (measured: 15.05 vs 14.24 ms), which is instrumentation, not
+    # the path.  Per-kernel durations for `roofline` / `kernels` come from PROF extra steps of
+    # the same process right after the timed region, with the event sink on
+    # (SCL_BENCH_EVENTS_IN_TIMED_REGION=1 puts the sink around the timed steps instead).
+    in_region = os.environ.get('SCL_BENCH_EVENTS_IN_TIMED_REGION') == '1'
+    prof_steps = args.steps if in_region else max(1, min(args.steps, 5))
+    import contextlib
+    if in_region:
+        nets.WORK_LOG = {}
+    with (_lib.KernelTimer(capacity=256 * max(args.steps, 1)) if in_region
+          else contextlib.nullcontext()) as kt:
         t0 = time.perf_counter()
         for _ in range(args.steps):
             loss = step()
         fence()
         elapsed = time.perf_counter() - t0
+    if not in_region:
+        nets.WORK_LOG = {}    # algorithmic flops / bytes of the backbone kernels, per call site
+        with _lib.KernelTimer(capacity=256 * prof_steps) as kt:
+            t1 = time.perf_counter()
+            for _ in range(prof_steps):
+                step()
+            fence()
+            elapsed_prof = time.perf_counter() - t1
+    else:
+        elapsed_prof = elapsed
     work, nets.WORK_LOG = nets.WORK_LOG, None
     loss_val = float(loss.detach())
     if world > 1:
@@ -252,7 +276,7 @@ def main():
                         if d['bound'] == 'mfma' else PEAK_HBM_GBPS,
                         unit='TFLOP/s' if d['bound'] == 'mfma' else 'GB/s',
                         frac=d['frac'], traffic=None, us_per_launch=d['us'],
-                        launches_per_step=d['launches'] / max(args.steps, 1))
+                        launches_per_step=d['launches'] / max(prof_steps, 1))
         roofline = roof(dom) if dom else None
         roofline_head = roof(dom_head) if dom_head else None
         if roofline:
@@ -272,7 +296,7 @@ def main():
                                                 'profiles/r01')
             except (OSError, ValueError, KeyError):
                 pass
-        hip_ms = sum(r['us'] * r['launches'] for r in kernels) / 1e3 / max(args.steps, 1)
+        hip_ms = sum(r['us'] * r['launches'] for r in kernels) / 1e3 / max(prof_steps, 1)
         out = {
             'metric': 'train-step images/sec (VGG16-NetVLAD soft-MS, 640x480)',
             'value': round(gb * args.steps / elapsed, 2),
@@ -291,6 +315,13 @@ def main():
                                    % (b, args.width, args.height, args.dtype),
                        'global_batch': gb, 'locations': n_loc, 'parallelism': 'dp%d' % world,
                        'optimizer': 'adam', 'loss': float('%.6g' % loss_val)},
+            'kernel_timing': {'method': 'HIP events around every launch of the hand-written kernels '
+                                        '(scl_prof sink), on the launch stream',
+                              'steps': prof_steps,
+                              'where': 'timed region' if in_region else
+                              'extra steps right after the timed region (the events cost ~6 % of '
+                              'a step, so the timed steps run without them)',
+                              'ms_per_step_with_events': round(elapsed_prof / prof_steps * 1e3, 3)},
             'roofline': roofline,
             'roofline_netvlad_loss': roofline_head,
             'kernels': kernels,
