@@ -12,15 +12,13 @@ Two on-disk formats carry the same variable NAMES and SHAPES
 
 * ``fmt='tf'`` (default): a TensorFlow bundle ``<stem>.index`` + ``<stem>.data-00000-of-00001``
   (tf_bundle.py) plus the directory's ``checkpoint`` state file — what the reference reads
-  and writes.  The global step is the int64 variable ``Variable`` (the reference's unnamed
+  and writes.  The global step is the int32 variable ``Variable`` (the reference's unnamed
   ``tf.Variable(0)``, cf. the ``Variable:0`` filter in evaluation/inference.py:126); Adam
   slots use TF's names (``<var>/Adam``, ``<var>/Adam_1``, ``beta1_power``, ``beta2_power``).
 * ``fmt='npz'``: one ``<stem>.npz`` with the same keys (``global_step`` instead of
   ``Variable``), handy for tests and quick inspection.
 """
-import glob
 import os
-import re
 
 import numpy as np
 import torch
@@ -98,7 +96,12 @@ def restore_optimizer(model, optimizer, variables):
             st = optimizer.state[p]
             st['exp_avg'] = _from_tf(variables[name + '/Adam'], is_conv, p)
             st['exp_avg_sq'] = _from_tf(variables[name + '/Adam_1'], is_conv, p)
-            st['step'] = torch.tensor(float(steps))
+            # like torch's _init_group: a fused / capturable Adam reads the step on the device
+            # (torch._fused_adam_ hands the kernel its data pointer), the plain one on the host
+            g = next((g for g in optimizer.param_groups if any(q is p for q in g['params'])), {})
+            on_dev = bool(g.get('fused') or g.get('capturable'))
+            st['step'] = torch.tensor(float(steps), dtype=torch.float32,
+                                      device=p.device if on_dev else 'cpu')
             done += 1
         elif name + '/Momentum' in variables and betas is None:
             optimizer.state[p]['momentum_buffer'] = _from_tf(variables[name + '/Momentum'],
@@ -113,7 +116,8 @@ def variables_of(model, global_step=0, optimizer=None, extra=None):
         sd.update(optimizer_slots(model, optimizer))
     for k, v in (extra or {}).items():
         sd[k] = np.asarray(v)
-    sd[GLOBAL_STEP_VAR] = np.asarray(int(global_step), dtype=np.int64)
+    # ops['step'] = tf.Variable(0) (train/train.py:655) is an int32 variable
+    sd[GLOBAL_STEP_VAR] = np.asarray(int(global_step), dtype=np.int32)
     return sd
 
 
@@ -171,16 +175,6 @@ class Saver:
         self.fmt = fmt
         self._kept = {}
 
-    def _stems(self, prefix):
-        pat = prefix + ('-*.index' if self.fmt == 'tf' else '-*.npz')
-        ext = '.index' if self.fmt == 'tf' else '.npz'
-
-        def step_of(stem):
-            m = re.search(r'-(\d+)$', stem)
-            return int(m.group(1)) if m else -1
-        stems = [f[:-len(ext)] for f in glob.glob(os.path.join(self.out_dir, pat))]
-        return sorted(stems, key=step_of)
-
     def _remove(self, stem):
         if self.fmt == 'tf':
             tf_bundle.remove(stem)
@@ -190,11 +184,15 @@ class Saver:
     def _save(self, model, prefix, number, global_step, keep, optimizer):
         stem = os.path.join(self.out_dir, '%s-%d' % (prefix, number))
         out = save(model, stem, global_step, fmt=self.fmt, optimizer=optimizer)
-        stems = self._stems(prefix)
+        # like tf.train.Saver's _last_checkpoints: only what THIS saver wrote, in save order —
+        # files an earlier run left in the directory are never touched
+        stems = self._kept.setdefault(prefix, [])
+        if stem in stems:
+            stems.remove(stem)
+        stems.append(stem)
         if keep > 0:
-            for old in stems[:-keep]:
-                self._remove(old)
-            stems = stems[-keep:]
+            while len(stems) > keep:
+                self._remove(stems.pop(0))
         if self.fmt == 'tf':
             tf_bundle.write_state(self.out_dir, os.path.basename(stem),
                                   [os.path.basename(s) for s in stems])

@@ -69,6 +69,9 @@ def main(argv=None):
     p.add_argument('--images_per_pass', type=int, default=4)
     p.add_argument('--num_images', type=int, default=10, help='synthetic set size')
     flags = p.parse_args(argv)
+    # --reduction pca writes the RAW descriptors, like the reference: "Don't actually do PCA
+    # here - doing it after" (evaluation/inference.py:94-95; its projection branch at :111-116
+    # is unreachable).  The whitening runs in evaluation/top_n.py.
     if flags.vlad_cores != 64 or flags.reduction not in ('none', 'pca'):
         raise SystemExit('only --vlad_cores 64 with --reduction none|pca is on the hot path')
     np.random.seed(42)                                       # inference.py:270-271

@@ -128,6 +128,7 @@ class GradBuckets:
         for p in self.params:
             p.register_post_accumulate_grad_hook(self._hook)
         self._remaining = [len(m) for m in self._members]
+        self._reported = {}
         # direct gradient sink (nets.GRAD_SINK): a backward kernel may write a parameter's
         # gradient straight into its slice of the flat buffer — no temporary, no cast, no
         # `grad += new` pass — and report it with done(); the bucket logic is the same as for
@@ -144,6 +145,24 @@ class GradBuckets:
             self._bucket_of[id(p)] = idx
 
     def _hook(self, p):
+        """Post-accumulate hook (the autograd path)."""
+        self._report(p, False)
+
+    def _report(self, p, via_sink):
+        # The engine runs the post-accumulate hooks of a parameter even when its Function
+        # returned None for it (the sink path, already counted by done()): that follow-up call
+        # is ignored.  Anything else arriving twice before zero() is a second backward pass —
+        # the gradient sink OVERWRITES conv gradients and no further all-reduce would fire, so
+        # refuse instead of silently dropping the first pass / letting the ranks diverge.
+        seen = self._reported.get(id(p))
+        if seen is not None:
+            if seen == 'sink' and not via_sink:
+                self._reported[id(p)] = 'sink+hook'
+                return
+            raise RuntimeError('GradBuckets: a parameter gradient was reported twice before '
+                               'zero(); call zero() before every backward pass (gradient '
+                               'accumulation needs nets.GRAD_SINK = None)')
+        self._reported[id(p)] = 'sink' if via_sink else 'hook'
         if not self.enabled:
             return
         idx = self._bucket_of[id(p)]
@@ -164,12 +183,13 @@ class GradBuckets:
     def done(self, p_like):
         """The gradient of that parameter is final in the flat buffer (written by a kernel
         enqueued on the current stream): what the post-accumulate hook would have done."""
-        self._hook(self._by_ptr[p_like.data_ptr()])
+        self._report(self._by_ptr[p_like.data_ptr()], True)
 
     def zero(self):
         """Zero all gradients in one memset and re-arm the buckets."""
         self.flat.zero_()
         self._remaining = [len(m) for m in self._members]
+        self._reported = {}
         self._handles = []
 
     def finish(self):

@@ -71,7 +71,7 @@ class _DirectMatmul(torch.autograd.Function):
         return gy @ w.t(), None, None
 
 
-def _worker(rank, port, out):
+def _worker(rank, port, out, bucket_bytes=8):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=WORLD)
@@ -82,8 +82,18 @@ def _worker(rank, port, out):
         p1 = torch.nn.Parameter(w1.clone())
         p2 = torch.nn.Parameter(w2.clone())
         # tiny buckets: every parameter gets its own collective
-        buckets = parallel.GradBuckets([p1, p2], bucket_bytes=8)
-        assert len(buckets.buckets) == 2
+        # tiny buckets: every parameter gets its own collective; one large bucket: its
+        # all-reduce must wait for BOTH gradients, also when one arrives through the sink
+        # (the engine still runs that parameter's post-accumulate hook afterwards)
+        holder = {}
+        if bucket_bytes != 8:
+            # runs before GradBuckets' own hook: p1's gradient is the last to arrive, so the
+            # shared bucket's collective must not have been launched yet
+            p1.register_post_accumulate_grad_hook(
+                lambda p: holder.__setitem__('early', len(holder['b']._handles)))
+        buckets = parallel.GradBuckets([p1, p2], bucket_bytes=bucket_bytes)
+        holder['b'] = buckets
+        assert len(buckets.buckets) == (2 if bucket_bytes == 8 else 1)
         for it in range(3):                      # second pass checks zero()/re-arming, the
             buckets.zero()                       # third the direct gradient sink
             if it < 2:
@@ -103,6 +113,7 @@ def _worker(rank, port, out):
             full.register_hook(own_rows_only)    # what `_rows` does inside the HIP backward
             loss = _pair_loss(full)
             loss.backward()
+            assert holder.get('early', 0) == 0, 'all-reduce launched before the bucket was complete'
             buckets.finish()
         out[rank] = (float(loss), p1.grad.clone(), p2.grad.clone())
     finally:
@@ -110,11 +121,12 @@ def _worker(rank, port, out):
 
 
 @pytest.mark.timeout(300)
-def test_dp_gradients_equal_single_process():
+@pytest.mark.parametrize('bucket_bytes', [8, 1 << 20])
+def test_dp_gradients_equal_single_process(bucket_bytes):
     want_loss, g1, g2 = _reference()
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(_free_port(), out), nprocs=WORLD, join=True)
+    mp.spawn(_worker, args=(_free_port(), out, bucket_bytes), nprocs=WORLD, join=True)
     assert sorted(out.keys()) == [0, 1]
     for rank in range(WORLD):
         loss, q1, q2 = out[rank]
@@ -136,6 +148,20 @@ def test_grad_buckets_layout_without_process_group():
     assert ps[0].grad.data_ptr() == gb.flat[9:].data_ptr()          # grads are views
     gb.zero()
     assert float(gb.flat.abs().sum()) == 0.0
+
+
+def test_grad_buckets_refuse_a_second_backward_before_zero():
+    """The gradient sink overwrites conv gradients and the bucket counters would go negative
+    (no all-reduce on the second pass): a second report before zero() must fail loudly."""
+    from soft_contrastive_learning_amd import parallel
+    p = torch.nn.Parameter(torch.ones(3))
+    gb = parallel.GradBuckets([p])
+    (p.sum() * 2).backward()
+    with pytest.raises(RuntimeError, match='reported twice'):
+        (p.sum() * 2).backward()
+    gb.zero()
+    (p.sum() * 3).backward()                       # re-armed
+    assert gb.flat.tolist() == [3.0] * 3
 
 
 def _bruteforce_local(ref, query, n, offset):

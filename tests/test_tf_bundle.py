@@ -175,7 +175,8 @@ def test_model_checkpoint_in_tf_format_with_adam_slots(tmp_path):
     assert entries['vgg16_netvlad_pca/conv1_1/kernel/Adam_1']['shape'] == [3, 3, 3, 64]
     assert entries['vgg16_netvlad_pca/assignment/kernel']['shape'] == [1, 1, 512, 64]
     assert entries['vgg16_netvlad_pca/cluster_centers']['shape'] == [1, 1, 1, 512, 64]
-    assert entries['Variable']['dtype'] == 9 and entries['Variable']['shape'] == []
+    # ops['step'] = tf.Variable(0) is int32 (train/train.py:655): DT_INT32 = 3
+    assert entries['Variable']['dtype'] == 3 and entries['Variable']['shape'] == []
     v = TB.read(stem, names=['beta1_power', 'beta2_power'])
     assert np.isclose(v['beta1_power'], 0.9 ** 4) and np.isclose(v['beta2_power'], 0.999 ** 4)
     assert checkpoint.load(b, stem, optimizer=ob) == 3
@@ -206,3 +207,22 @@ def test_checkpoint_state_file(tmp_path):
     assert TB.latest_checkpoint(d) == os.path.join(d, 'checkpoint-10')
     TB.remove(os.path.join(d, 'checkpoint-10'))
     assert TB.latest_checkpoint(d) is None
+
+
+def test_saver_rotates_only_what_it_wrote_in_save_order(tmp_path):
+    """tf.train.Saver keeps its own _last_checkpoints in save order: a higher-numbered
+    checkpoint left by an earlier run must neither be deleted nor cause the fresh one to be."""
+    d = str(tmp_path)
+    m = nets.VGG16NetVLAD(seed=1)
+    TB.write(os.path.join(d, 'checkpoint-900'), {'w': np.zeros(2, dtype=np.float32)})   # earlier run
+    sv = checkpoint.Saver(d, max_to_keep=1)
+    sv.save_rolling(m, 100)
+    assert TB.exists(os.path.join(d, 'checkpoint-100')) and TB.exists(os.path.join(d, 'checkpoint-900'))
+    assert TB.latest_checkpoint(d) == os.path.join(d, 'checkpoint-100')
+    sv.save_rolling(m, 200)
+    assert not TB.exists(os.path.join(d, 'checkpoint-100'))
+    assert TB.exists(os.path.join(d, 'checkpoint-200')) and TB.exists(os.path.join(d, 'checkpoint-900'))
+    assert TB.latest_checkpoint(d) == os.path.join(d, 'checkpoint-200')
+    sv.save_epoch(m, 0, 200)
+    sv.save_epoch(m, 1, 400)                       # epoch saver keeps everything
+    assert TB.exists(os.path.join(d, 'epoch-checkpoint-0')) and TB.exists(os.path.join(d, 'epoch-checkpoint-1'))
