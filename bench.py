@@ -9,6 +9,7 @@ all-reduce] -> Adam update.
 Inputs are synthetic and resident in HBM before the timed region.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 8 --steps 20 --warmup 5      (starts its own 8 rank processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -63,6 +64,9 @@ def parse():
     ap.add_argument('--fused-relu', type=int, default=1,
                     help='1: fused HIP bias/ReLU/pool glue around the MIOpen convs (csrc/vgg_glue.hip)')
     ap.add_argument('--cpu-images', type=int, default=2, help='images in the CPU-baseline sample')
+    ap.add_argument('--stub-cpu', action='store_true',
+                    help='TEST ONLY: gloo on CPU with a trivial stand-in step; exercises the '
+                         'launcher, the barriers and the max-over-ranks timing, measures nothing')
     return ap.parse_args()
 
 
@@ -157,13 +161,106 @@ def cpu_baseline(args, threads):
                        'NetVLAD/wms autograd twin), no optimizer' % (reps, nb, args.width, args.height))
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without an outer launcher: this process (which has not
+    touched the GPU and never will) starts one fresh child per rank with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* set, relays their output (rank 0 prints the JSON line), and exits
+    non-zero if any rank failed."""
+    import subprocess
+    port = os.environ.get('MASTER_PORT') or str(_free_port())
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1', MASTER_PORT=port)
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                      env=env))
+    codes = [None] * len(procs)
+    try:
+        while any(c is None for c in codes):
+            for i, pr in enumerate(procs):
+                if codes[i] is None:
+                    try:
+                        codes[i] = pr.wait(timeout=0.2)
+                    except subprocess.TimeoutExpired:
+                        pass
+            if any(c not in (None, 0) for c in codes):
+                break                       # one rank died: the others would hang in a collective
+    finally:
+        for pr in procs:                    # exactly the children started above
+            if pr.poll() is None:
+                pr.terminate()
+        for i, pr in enumerate(procs):
+            if codes[i] is None:
+                try:
+                    codes[i] = pr.wait(timeout=30)
+                except subprocess.TimeoutExpired:
+                    pr.kill()
+                    codes[i] = pr.wait()
+    bad = [(i, c) for i, c in enumerate(codes) if c != 0]
+    if bad:
+        sys.stderr.write('bench.py: ranks failed (rank, exit code): %s\n' % bad)
+        raise SystemExit(1)
+    raise SystemExit(0)
+
+
+def stub_main(args, world, rank):
+    """--stub-cpu: the launch / barrier / timing / reporting skeleton of main() on gloo with a
+    trivial step.  Exists so that the N > 1 control flow is testable without a GPU."""
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    w = torch.ones(64, 64)
+
+    def step():
+        y = (w @ w).sum()
+        if world > 1:
+            dist.all_reduce(y)
+        return y
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    if rank == 0:
+        print(json.dumps({'metric': 'STUB (no GPU work; launcher self-test)', 'value': 0.0,
+                          'unit': 'none', 'n_gpus': world, 'steps': args.steps,
+                          'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+                          'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+                          'dtype': 'none', 'data': 'stub',
+                          'config': {'workload': 'stub', 'parallelism': 'dp%d' % world}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        self_launch(args)                       # never returns
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    if args.stub_cpu:
+        return stub_main(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device (no CPU path exists)')
     torch.cuda.set_device(local_rank)

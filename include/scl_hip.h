@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SCL_ABI_VERSION 1
+#define SCL_ABI_VERSION 2
 
 /* error codes (negative = rejected before any launch) */
 #define SCL_OK 0
@@ -204,6 +204,35 @@ size_t scl_topn_l2_ex_workspace_bytes(int R, int Q, int d, int n, int flags);
 int scl_topn_l2_ex(const float* ref, int R, const float* query, int Q, int d, int n,
                    int64_t idx_offset, int64_t* idx_out, double* dist_out, void* workspace,
                    size_t workspace_bytes, int flags, void* stream);
+
+/* The same call with an EXACTNESS CERTIFICATE per query (workspace: the _ex query).  The scan
+ * nominates 32 candidates per query by approximate score and the re-rank orders them exactly;
+ * the lists equal KDTree.query's (evaluation/top-n.py:103-108) whenever no reference outside
+ * the nominated set can reach the n-th exact distance.  That is decided here, not assumed:
+ * every outsider scores >= the nomination threshold tau, so its exact squared distance is
+ * >= tau + |q|^2 - eps, with eps a rigorous bound of |approximate - exact score| for the mode
+ * (float32 or bf16x3 rounding) and the largest reference norm.
+ *   uncertified [Q] bytes: 0 = the emitted list is provably the exact top-n; 1 = cannot be
+ *               proven (near-duplicate references around the n-th neighbour) — resolve those
+ *               queries with scl_topn_exact_filter;
+ *   bound_sq    [Q] float64: n-th smallest exact SQUARED distance among the nominated set,
+ *               an upper bound of the true n-th squared distance.
+ * Both NULL: no certificate (the _ex call). */
+int scl_topn_l2_cert(const float* ref, int R, const float* query, int Q, int d, int n,
+                     int64_t idx_offset, int64_t* idx_out, double* dist_out,
+                     unsigned char* uncertified, double* bound_sq, void* workspace,
+                     size_t workspace_bytes, int flags, void* stream);
+
+/* Exact resolution of uncertified queries: for each listed query, float64 sum (q - r)^2 against
+ * EVERY reference row (d <= 256, d % 4 == 0); rows with squared distance <= bound_sq[query] are
+ * appended (unordered) to that query's candidate list.  The true top-n are the n smallest
+ * (distance, row) pairs of the list.
+ *   qlist [nq] int32 query rows; bound_sq [Q] float64 indexed by query row;
+ *   count [nq] int32 out: candidates found (may exceed cap: then only cap were stored);
+ *   cand_d [nq,cap] float64 squared distances; cand_i [nq,cap] int32 reference rows. */
+int scl_topn_exact_filter(const float* ref, int R, const float* query, int d, const int* qlist,
+                          int nq, const double* bound_sq, int cap, int* count, double* cand_d,
+                          int* cand_i, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * VGG16 backbone glue — the elementwise ops between the convolutions of

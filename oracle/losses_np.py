@@ -296,6 +296,23 @@ def pairwise_squared_distances(features):
     return (r - F32(2.0) * prod + np.transpose(r, (0, 2, 1))).astype(F32)
 
 
+def pairwise_distance_loss(anchor, positives, pairwise_squared_d_dists, d_max_squared,
+                           f_max_squared, distance_loss_name='distance_loss'):
+    """model/losses.py:627-646: all pairs among [anchor | positives] of every tuple; the huber
+    variant is tf.losses.huber_loss(labels=scaled_f, predictions=scaled_d) (argument order as
+    written there), then three nested means."""
+    feats = np.concatenate([_f32(anchor), _f32(positives)], axis=1)
+    sf = (pairwise_squared_distances(feats) / F32(f_max_squared)).astype(F32)
+    sd = (_f32(pairwise_squared_d_dists) / F32(d_max_squared)).astype(F32)
+    if 'huber' in distance_loss_name:
+        sq = _huber(sf, sd)
+    else:
+        sq = ((sf - sd) ** 2).astype(F32)
+    m1 = np.mean(sq, axis=2, dtype=F32)
+    m2 = np.mean(m1, axis=1, dtype=F32)
+    return F32(np.mean(m2, axis=0, dtype=F32))
+
+
 def split_tuples(output, tuples_per_batch, tuple_shape):
     """Trainer glue (train/train.py:654): [T*S,E] -> list of [T,n_i,E]."""
     out = _f32(output).reshape(tuples_per_batch, sum(tuple_shape), -1)

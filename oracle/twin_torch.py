@@ -171,6 +171,17 @@ def distance_tuple_loss(q, pos, neg, other, m1, m2, lam, squared_d_dists, d_max_
     return loss
 
 
+def pairwise_distance_loss(anchor, positives, pairwise_squared_d_dists, d_max_squared,
+                           f_max_squared, huber=False, dtype=torch.float64):
+    """model/losses.py:627-646 (see oracle.losses_np.pairwise_distance_loss)."""
+    f = torch.cat([_t(anchor, dtype), _t(positives, dtype)], dim=1)
+    r = (f * f).sum(dim=2, keepdim=True)
+    sf = (r - 2.0 * f @ f.transpose(1, 2) + r.transpose(1, 2)) / f_max_squared
+    sd = _t(pairwise_squared_d_dists, dtype) / d_max_squared
+    sq = _huber_t(sf, sd) if huber else (sf - sd) ** 2
+    return sq.mean(dim=2).mean(dim=1).mean(dim=0)
+
+
 def netvlad(x, assign_w, centers, pre_l2=True, dtype=torch.float64):
     """x [B,N,D], assign_w [D,K], centers [D,K] -> [B, D*K] (see oracle.netvlad_np)."""
     x, w, c = _t(x, dtype), _t(assign_w, dtype), _t(centers, dtype)

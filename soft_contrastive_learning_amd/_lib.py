@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libscl_hip.so")
 
 # constants of include/scl_hip.h
-ABI_VERSION = 1
+ABI_VERSION = 2
 DT_F32, DT_BF16 = 0, 1
 MASK_WMS_EXP, MASK_WMS_LIN, MASK_WMS_TANH, MASK_LABELS = 0, 1, 2, 3
 SUM_MS, SUM_PLAIN = 0, 1
@@ -54,6 +54,8 @@ SIGNATURES = {
     "scl_topn_l2": (_i, [_p, _i, _p, _i, _i, _i, _l, _p, _p, _p, _z, _p]),
     "scl_topn_l2_ex_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
     "scl_topn_l2_ex": (_i, [_p, _i, _p, _i, _i, _i, _l, _p, _p, _p, _z, _i, _p]),
+    "scl_topn_l2_cert": (_i, [_p, _i, _p, _i, _i, _i, _l, _p, _p, _p, _p, _p, _z, _i, _p]),
+    "scl_topn_exact_filter": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p, _p]),
     "scl_vgg_workspace_bytes": (_z, [_i]),
     "scl_vgg_bias_act": (_i, [_p, _i, _p, _l, _i, _i, _p]),
     "scl_vgg_act_bwd": (_i, [_p, _p, _i, _l, _i, _p, _p, _p, _z, _p]),

@@ -29,22 +29,36 @@ constexpr int KEEP = 32;   // candidates kept per (query, split)
 constexpr int QW = 4;      // waves (32-query tiles) per workgroup
 constexpr int kMaxN = 25;
 
+// grid ceil(R / 64), block 256: wave w takes rows 64 b + 16 w .. + 15.  rmax_bits (optional,
+// zeroed by the caller): max_j ||r_j||^2 as its float bit pattern (non-negative floats order
+// like unsigned integers), one atomic per workgroup — the exactness certificate's norm bound.
 __global__ __launch_bounds__(256) void refnorm_kernel(const float* __restrict__ ref, int R, int d,
-                                                      float* __restrict__ out) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= R) return;
-  const float* p = ref + (int64_t)row * d;
-  float s = 0.f;
-  for (int e = lane * 4; e < d; e += 256) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(p + e);
-    s = fmaf(v[0], v[0], s);
-    s = fmaf(v[1], v[1], s);
-    s = fmaf(v[2], v[2], s);
-    s = fmaf(v[3], v[3], s);
+                                                      float* __restrict__ out,
+                                                      unsigned* __restrict__ rmax_bits) {
+  __shared__ float wmax[4];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float mx = 0.f;
+  for (int t = 0; t < 16; ++t) {
+    const int row = blockIdx.x * 64 + wid * 16 + t;
+    if (row >= R) break;                         // wave-uniform
+    const float* p = ref + (int64_t)row * d;
+    float s = 0.f;
+    for (int e = lane * 4; e < d; e += 256) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(p + e);
+      s = fmaf(v[0], v[0], s);
+      s = fmaf(v[1], v[1], s);
+      s = fmaf(v[2], v[2], s);
+      s = fmaf(v[3], v[3], s);
+    }
+    s = wave_sum(s);
+    if (lane == 0) out[row] = s;
+    mx = fmaxf(mx, s);
   }
-  s = wave_sum(s);
-  if (lane == 0) out[row] = s;
+  if (!rmax_bits) return;
+  if (lane == 0) wmax[wid] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    atomicMax(rmax_bits, __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
 }
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -360,11 +374,15 @@ __global__ __launch_bounds__(256) void topn_rerank_kernel(const float* __restric
                                                           const float* __restrict__ cand_sc,
                                                           const int* __restrict__ cand_ix,
                                                           int64_t* __restrict__ idx_out,
-                                                          double* __restrict__ dist_out) {
+                                                          double* __restrict__ dist_out,
+                                                          const unsigned* __restrict__ rmax_bits,
+                                                          float eps_q, float eps_r,
+                                                          unsigned char* __restrict__ uncertified,
+                                                          double* __restrict__ bound_sq) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int M = splits * KEEP;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int per_wave = 2 * M + KEEP + 2 * KEEP;          // floats (best_d as 2 floats each)
+  const int per_wave = 2 * M + KEEP + 2 * (KEEP + 1) + 2;  // floats (best_d: KEEP + 1 doubles, 8-byte aligned)
   float* sc = lds + wid * per_wave;
   int* ix = reinterpret_cast<int*>(sc + M);
   int* best_ix = ix + M;
@@ -417,6 +435,20 @@ __global__ __launch_bounds__(256) void topn_rerank_kernel(const float* __restric
       }
     }
     tau_key = prefix;                                     // key of the KEEP-th smallest
+  }
+  // Smallest approximate score any reference OUTSIDE the nominated KEEP can have: the merge
+  // threshold when the merge dropped candidates, and the last entry of every full per-split
+  // list (a split only drops what scores no better than its KEEP-th best).
+  float tau_excl = INFINITY;
+  if (uncertified) {
+    if (nvalid > KEEP) {
+      const unsigned bits = (tau_key & 0x80000000u) ? (tau_key ^ 0x80000000u) : ~tau_key;
+      tau_excl = __uint_as_float(bits);
+    }
+#pragma unroll
+    for (int k = 0; k < NE; ++k)
+      if ((lane & (KEEP - 1)) == KEEP - 1 && ei[k] >= 0) tau_excl = fminf(tau_excl, es[k]);
+    tau_excl = wave_min(tau_excl);
   }
   {
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -476,6 +508,78 @@ __global__ __launch_bounds__(256) void topn_rerank_kernel(const float* __restric
       if (rk < n) {
         idx_out[(int64_t)qi * n + rk] = (int64_t)mi + idx_offset;
         dist_out[(int64_t)qi * n + rk] = sqrt(md);
+      }
+      if (rk == n - 1) best_d[KEEP] = md;                 // exact n-th smallest of the nominated
+    }
+  }
+  if (!uncertified) return;
+  // Exactness certificate.  Every reference outside the nominated set has approximate score
+  // >= tau_excl, so its exact squared distance is >= tau_excl + |q|^2 - eps, eps bounding
+  // |approximate - exact score| (rounding of the f32 / bf16x3 contraction and of ||r||^2, as
+  // eps_q |q| Rmax + eps_r Rmax^2 with Rmax = max_j ||r_j||).  If the n-th exact distance of
+  // the nominated set is strictly below that, no outsider can enter (or tie with) the top n.
+  double qq = 0.0;
+  for (int e = lane; e < d; e += 64) {
+    const double v = (double)qp[e];
+    qq = fma(v, v, qq);
+  }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) qq += __shfl_xor(qq, m, 64);
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) {
+    const double dn = best_d[KEEP];
+    const double rmax = sqrt((double)__uint_as_float(*rmax_bits));
+    const double eps = (double)eps_q * sqrt(qq) * rmax + (double)eps_r * rmax * rmax;
+    const bool ok = !(tau_excl < INFINITY) || dn < (double)tau_excl + qq - eps;
+    uncertified[qi] = ok ? 0 : 1;
+    bound_sq[qi] = dn;
+  }
+}
+
+// Exact fallback for the (rare) queries whose certificate failed: float64 sum (q - r)^2 against
+// EVERY reference; the ones within the query's bound (the n-th exact distance of its nominated
+// set, an upper bound of the true n-th distance) are appended to its candidate list.  The host
+// sorts each list by (distance, index).  grid (ceil(R / 1024), nq); block 256: four 16-lane
+// groups per wave, one reference row each per round.
+__global__ __launch_bounds__(256) void topn_exact_filter_kernel(
+    const float* __restrict__ ref, int R, const float* __restrict__ query, int d,
+    const int* __restrict__ qlist, const double* __restrict__ bound_sq, int cap,
+    int* __restrict__ count, double* __restrict__ cand_d, int* __restrict__ cand_i) {
+  const int f = blockIdx.y, qi = qlist[f];
+  const double U = bound_sq[qi];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int grp = lane >> 4, gl = lane & 15;
+  const float* qp = query + (int64_t)qi * d;
+  f32x4 qv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    qv[j] = 4 * gl + 64 * j < d ? *reinterpret_cast<const f32x4*>(qp + 4 * gl + 64 * j)
+                                : f32x4{0.f, 0.f, 0.f, 0.f};
+  const int r0 = blockIdx.x * 1024 + wid * 256;
+  for (int t = 0; t < 64; ++t) {
+    const int ri = r0 + 4 * t + grp;
+    double s = 0.0;
+    if (ri < R) {
+      const float* rp = ref + (int64_t)ri * d;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (4 * gl + 64 * j < d) {
+          const f32x4 rv = *reinterpret_cast<const f32x4*>(rp + 4 * gl + 64 * j);
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) {
+            const double df = (double)qv[j][cc] - (double)rv[cc];
+            s = fma(df, df, s);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) s += __shfl_xor(s, m, 64);
+    if (gl == 0 && ri < R && s <= U) {
+      const int slot = atomicAdd(&count[f], 1);
+      if (slot < cap) {
+        cand_d[(int64_t)f * cap + slot] = s;
+        cand_i[(int64_t)f * cap + slot] = ri;
       }
     }
   }
@@ -552,7 +656,7 @@ extern "C" size_t scl_topn_l2_ex_workspace_bytes(int R, int Q, int d, int n, int
   if (!topn_shape_ok(R, Q, d, n) || (flags & ~SCL_TOPN_SCORE_BF16X3)) return 0;
   const int bf = flags & SCL_TOPN_SCORE_BF16X3;
   const TopnPlan p = topn_plan(R, Q, bf);
-  return scl_round256((size_t)R * sizeof(float)) +
+  return 256 + scl_round256((size_t)R * sizeof(float)) +
          2 * scl_round256((size_t)Q * p.splits * KEEP * sizeof(float)) +
          (bf ? 2 * scl_round256((size_t)R * d * sizeof(unsigned short)) : 0);
 }
@@ -561,10 +665,12 @@ extern "C" size_t scl_topn_l2_workspace_bytes(int R, int Q, int d, int n) {
   return scl_topn_l2_ex_workspace_bytes(R, Q, d, n, 0);
 }
 
-extern "C" int scl_topn_l2_ex(const float* ref, int R, const float* query, int Q, int d, int n,
-                              int64_t idx_offset, int64_t* idx_out, double* dist_out,
-                              void* workspace, size_t workspace_bytes, int flags, void* stream) {
+extern "C" int scl_topn_l2_cert(const float* ref, int R, const float* query, int Q, int d, int n,
+                                int64_t idx_offset, int64_t* idx_out, double* dist_out,
+                                unsigned char* uncertified, double* bound_sq, void* workspace,
+                                size_t workspace_bytes, int flags, void* stream) {
   if (!ref || !query || !idx_out || !dist_out || !workspace) return SCL_E_NULL;
+  if ((uncertified == nullptr) != (bound_sq == nullptr)) return SCL_E_NULL;
   if (!topn_shape_ok(R, Q, d, n)) return SCL_E_SHAPE;
   if (flags & ~SCL_TOPN_SCORE_BF16X3) return SCL_E_KIND;
   if (((uintptr_t)ref % 16) || ((uintptr_t)query % 16)) return SCL_E_SHAPE;
@@ -574,6 +680,8 @@ extern "C" int scl_topn_l2_ex(const float* ref, int R, const float* query, int Q
   const int bf = flags & SCL_TOPN_SCORE_BF16X3;
   const TopnPlan p = topn_plan(R, Q, bf);
   char* base = (char*)workspace;
+  unsigned* rmax_bits = (unsigned*)base;
+  base += 256;
   float* refnorm = (float*)base;
   base += scl_round256((size_t)R * sizeof(float));
   float* cs = (float*)base;
@@ -581,7 +689,12 @@ extern "C" int scl_topn_l2_ex(const float* ref, int R, const float* query, int Q
   int* ci = (int*)base;
   base += scl_round256((size_t)Q * p.splits * KEEP * sizeof(float));
   hipStream_t st = (hipStream_t)stream;
-  SCL_LAUNCH("refnorm_kernel", refnorm_kernel, dim3((R + 3) / 4), dim3(256), 0, st, ref, R, d, refnorm);
+  if (uncertified) {
+    const hipError_t e = hipMemsetAsync(rmax_bits, 0, 16, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  SCL_LAUNCH("refnorm_kernel", refnorm_kernel, dim3((R + 63) / 64), dim3(256), 0, st, ref, R, d,
+             refnorm, uncertified ? rmax_bits : (unsigned*)nullptr);
   const void* scan_ref = ref;
   const void* scan_lo = nullptr;
   if (bf) {
@@ -609,19 +722,38 @@ extern "C" int scl_topn_l2_ex(const float* ref, int R, const float* query, int Q
       default: launch_scan<32, 0>(p, scan_ref, scan_lo, refnorm, R, query, Q, cs, ci, st); break;
     }
   }
+  // |approximate - exact score| <= eps_q |q| Rmax + eps_r Rmax^2 (u = 2^-24; factor 2 of
+  // safety on rigorous worst-case bounds):
+  //   ||r||^2 by f32 FMAs + the final f32 subtraction        (d + 16) u (Rmax^2 + 2 |q| Rmax)
+  //   -2 q.r, f32 MFMA chain of d terms                       2 d u |q| Rmax
+  //   -2 q.r, bf16x3: dropped q_lo.r_lo + split residues      2 * 3 * 2^-18 |q| Rmax
+  //                   + f32 accumulation of 3 d products      2 * 3 d u |q| Rmax
+  const double u = 5.9604644775390625e-8;
+  const double eps_r = 2.0 * (d + 16) * u;
+  const double eps_q = 2.0 * (2.0 * (d + 16) * u +
+                              (bf ? 6.0 / 262144.0 + 6.0 * d * u : 2.0 * d * u));
   const int M = p.splits * KEEP;
-  const size_t lds = (size_t)4 * (2 * M + 3 * KEEP) * sizeof(float);
+  const size_t lds = (size_t)4 * (2 * M + 3 * KEEP + 4) * sizeof(float);
   const dim3 rgrid((Q + 3) / 4);
+#define SCL_RERANK(NE)                                                                           \
+  SCL_LAUNCH("topn_rerank_kernel", topn_rerank_kernel<NE>, rgrid, dim3(256), lds, st, ref, query, \
+             Q, d, p.splits, n, idx_offset, (const float*)cs, (const int*)ci, idx_out, dist_out,  \
+             (const unsigned*)rmax_bits, (float)eps_q, (float)eps_r, uncertified, bound_sq)
   if (M <= 256)
-    SCL_LAUNCH("topn_rerank_kernel", topn_rerank_kernel<4>, rgrid, dim3(256), lds, st, ref, query,
-               Q, d, p.splits, n, idx_offset, (const float*)cs, (const int*)ci, idx_out, dist_out);
+    SCL_RERANK(4);
   else if (M <= 512)
-    SCL_LAUNCH("topn_rerank_kernel", topn_rerank_kernel<8>, rgrid, dim3(256), lds, st, ref, query,
-               Q, d, p.splits, n, idx_offset, (const float*)cs, (const int*)ci, idx_out, dist_out);
+    SCL_RERANK(8);
   else
-    SCL_LAUNCH("topn_rerank_kernel", topn_rerank_kernel<16>, rgrid, dim3(256), lds, st, ref, query,
-               Q, d, p.splits, n, idx_offset, (const float*)cs, (const int*)ci, idx_out, dist_out);
+    SCL_RERANK(16);
+#undef SCL_RERANK
   return scl_launch_status();
+}
+
+extern "C" int scl_topn_l2_ex(const float* ref, int R, const float* query, int Q, int d, int n,
+                              int64_t idx_offset, int64_t* idx_out, double* dist_out,
+                              void* workspace, size_t workspace_bytes, int flags, void* stream) {
+  return scl_topn_l2_cert(ref, R, query, Q, d, n, idx_offset, idx_out, dist_out, nullptr, nullptr,
+                          workspace, workspace_bytes, flags, stream);
 }
 
 extern "C" int scl_topn_l2(const float* ref, int R, const float* query, int Q, int d, int n,
@@ -629,4 +761,18 @@ extern "C" int scl_topn_l2(const float* ref, int R, const float* query, int Q, i
                            size_t workspace_bytes, void* stream) {
   return scl_topn_l2_ex(ref, R, query, Q, d, n, idx_offset, idx_out, dist_out, workspace,
                         workspace_bytes, 0, stream);
+}
+
+extern "C" int scl_topn_exact_filter(const float* ref, int R, const float* query, int d,
+                                     const int* qlist, int nq, const double* bound_sq, int cap,
+                                     int* count, double* cand_d, int* cand_i, void* stream) {
+  if (!ref || !query || !qlist || !bound_sq || !count || !cand_d || !cand_i) return SCL_E_NULL;
+  if (R < 1 || nq < 1 || nq > 65535 || cap < 1 || d < 4 || d > 256 || d % 4) return SCL_E_SHAPE;
+  if (((uintptr_t)ref % 16) || ((uintptr_t)query % 16)) return SCL_E_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  const hipError_t e = hipMemsetAsync(count, 0, (size_t)nq * sizeof(int), st);
+  if (e != hipSuccess) return (int)e;
+  SCL_LAUNCH("topn_exact_filter_kernel", topn_exact_filter_kernel, dim3((R + 1023) / 1024, nq),
+             dim3(256), 0, st, ref, R, query, d, qlist, bound_sq, cap, count, cand_d, cand_i);
+  return scl_launch_status();
 }

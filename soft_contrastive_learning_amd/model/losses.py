@@ -14,6 +14,7 @@ and backward are the hand-written gfx950 kernels behind ``include/scl_hip.h``.
   distance_loss / huber_distance_loss         model/losses.py:225-236
   distance_triplet_loss / distance_quadruplet_loss   model/losses.py:239-307
   _pairwise_squared_distances  model/losses.py:656-661
+  pairwise_distance_loss       model/losses.py:627-646
 The pointnetvlad_cls losses the trainer imports beside them (train/train.py:25)
 live in ``soft_contrastive_learning_amd.pointnetvlad_cls``.
 """
@@ -24,7 +25,7 @@ from .. import _lib as L
 __all__ = ['wms_loss', 'ms_loss', 'ms_det', 'logratio_loss', 'evil_triplet_loss',
            'evil_quadruplet_loss', 'worst_pos_distance', '_pairwise_squared_distances',
            'distance_loss', 'huber_distance_loss', 'distance_triplet_loss',
-           'distance_quadruplet_loss']
+           'distance_quadruplet_loss', 'pairwise_distance_loss']
 
 
 def _as_f32(t):
@@ -411,3 +412,66 @@ def _pairwise_squared_distances(features):
     L.check(lib.scl_pairwise_sqdist(L.ptr(f), t, s, e, L.ptr(out), L.ptr(ws), ws.numel(),
                                     L.stream_of(f)))
     return out
+
+
+class _PairwiseDistanceLoss(torch.autograd.Function):
+    """mean over all (t, i, j) of phi(F_tij / f_max, D_tij / d_max), F = pairwise squared feature
+    distances (``scl_pairwise_sqdist``).  With g = d loss / d F (an [S,S] map per tuple) the
+    feature gradient is 2 (diag(rowsum(g + g^T)) - (g + g^T)) . features — a [S,S] x [S,E]
+    product per tuple, which is what ``scl_gram_loss_bwd`` computes from a coefficient matrix."""
+
+    @staticmethod
+    def forward(ctx, feats, d_dists, d_max_squared, f_max_squared, huber):
+        lib = L.load()
+        L.require_device(feats, d_dists)
+        f = _as_f32(feats).contiguous()
+        t, s, e = f.shape
+        dd = _as_f32(d_dists)
+        if tuple(dd.shape) != (t, s, s):
+            raise ValueError("pairwise_squared_d_dists %s must be [T,1+P,1+P] = %s"
+                             % (tuple(dd.shape), (t, s, s)))
+        sqf = _pairwise_squared_distances(f)
+        sf = sqf / f_max_squared
+        sd = dd / d_max_squared
+        err = sd - sf                                   # huber: predictions - labels
+        if huber:
+            a = err.abs()
+            quad = torch.clamp(a, max=1.0)
+            sq = 0.5 * quad * quad + (a - quad)
+            dphi = -torch.clamp(err, -1.0, 1.0)         # d phi / d sf
+        else:
+            sq = err * err
+            dphi = -2.0 * err
+        loss = sq.mean(dim=2).mean(dim=1).mean(dim=0)
+        g = dphi / (f_max_squared * t * s * s)          # d loss / d F
+        c = g + g.transpose(1, 2)
+        coef = 2.0 * (torch.diag_embed(c.sum(dim=2)) - c)
+        ctx.save_for_backward(f, coef.contiguous())
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        lib = L.load()
+        f, coef = ctx.saved_tensors
+        t, s, e = f.shape
+        g = _as_f32(grad_loss).contiguous()
+        grad = torch.empty_like(f)
+        for k in range(t):
+            L.check(lib.scl_gram_loss_bwd(L.ptr(f[k]), e, s, e, L.ptr(coef[k]), L.ptr(g), 0, s,
+                                          L.ptr(grad[k]), e, L.stream_of(f)))
+        return grad, None, None, None, None
+
+
+def pairwise_distance_loss(anchor, positives, pairwise_squared_d_dists, d_max_squared, f_max_squared,
+                           distance_loss_name='distance_loss'):
+    """model/losses.py:627-646: squared feature distances between ALL pairs of
+    [anchor | positives] against the squared geographic ones (the trainer's 'pairwise'
+    distance tensor [T,1+P,1+P], train/train.py:535-537, 665-667), plain or Huber."""
+    L.require_device(anchor, positives, pairwise_squared_d_dists)
+    if anchor.dim() != 3 or positives.dim() != 3 or anchor.shape[0] != positives.shape[0] \
+            or anchor.shape[2] != positives.shape[2]:
+        raise ValueError("anchor %s / positives %s must be [T,1,E] / [T,P,E]"
+                         % (tuple(anchor.shape), tuple(positives.shape)))
+    feats = torch.cat([_as_f32(anchor), _as_f32(positives)], dim=1)
+    return _PairwiseDistanceLoss.apply(feats, pairwise_squared_d_dists, float(d_max_squared),
+                                       float(f_max_squared), 'huber' in distance_loss_name)

@@ -317,3 +317,28 @@ def test_shape_errors_raise_like_the_reference(dev):
         M.logratio_loss(torch.zeros(1, 1, 8, device=dev), torch.zeros(1, 3, 8, device=dev),
                         torch.zeros(1, 4, 8, device=dev), torch.ones(1, 3, 1, device=dev),
                         torch.ones(1, 4, 1, device=dev))
+
+
+@pytest.mark.parametrize("huber", [False, True])
+@pytest.mark.parametrize("t,p,e", [(1, 12, 32768), (3, 5, 4096)])
+def test_pairwise_distance_loss_and_grad(dev, t, p, e, huber):
+    """model/losses.py:627-646 — the caller of _pairwise_squared_distances: loss vs the float32
+    oracle (1e-4), gradients vs the float64 twin (2e-4 norm-relative)."""
+    from soft_contrastive_learning_amd.model import losses
+    tb = U.tuple_batch(t, p, 0, e, seed=50 + p, scale=0.02)
+    a, pos = tb[:, :1], tb[:, 1:]
+    rng = np.random.default_rng(p)
+    xy = rng.uniform(0, 25, (t, 1 + p, 2))
+    dd = ((xy[:, :, None] - xy[:, None]) ** 2).sum(-1).astype(np.float32)   # squared metres
+    name = 'huber_distance_loss' if huber else 'distance_loss'
+    want = float(O.pairwise_distance_loss(a, pos, dd, 225.0, 2.0, name))
+    at = torch.tensor(a, device=dev, requires_grad=True)
+    pt = torch.tensor(pos, device=dev, requires_grad=True)
+    got = losses.pairwise_distance_loss(at, pt, torch.tensor(dd, device=dev), 225.0, 2.0, name)
+    assert abs(float(got) - want) <= 1e-4 * abs(want) + 1e-8, (float(got), want)
+    got.backward()
+    a64 = torch.tensor(a, dtype=torch.float64, requires_grad=True)
+    p64 = torch.tensor(pos, dtype=torch.float64, requires_grad=True)
+    TT.pairwise_distance_loss(a64, p64, dd, 225.0, 2.0, huber=huber).backward()
+    assert _rel(at.grad.cpu().numpy(), a64.grad.numpy()) < 2e-4
+    assert _rel(pt.grad.cpu().numpy(), p64.grad.numpy()) < 2e-4

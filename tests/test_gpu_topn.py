@@ -88,3 +88,88 @@ def test_topn_bf16x3_on_scaled_and_offset_features(dev):
         np.testing.assert_allclose(got_d.cpu().numpy(), want_d, rtol=1e-12, atol=0)
     with pytest.raises(ValueError):
         retrieval.topn_l2(rt, qt, 25, score='fp8')
+
+
+@pytest.mark.parametrize("score", ['f32', 'bf16x3'])
+def test_topn_certificate_resolves_near_duplicate_clusters(dev, score):
+    """More near-duplicates around a query than the 32 nominated candidates can hold, closer
+    together (1e-6 relative) than either scoring mode resolves: the certificate must flag
+    those queries and the exact pass must reproduce the reference's KDTree lists bit for bit;
+    well-separated queries stay on the fast path."""
+    from soft_contrastive_learning_amd.evaluation import retrieval
+    rng = np.random.default_rng(123)
+    r, q, d, n = 6000, 40, 128, 25
+    ref = rng.standard_normal((r, d)).astype(np.float32)
+    qry = rng.standard_normal((q, d)).astype(np.float32)
+    # cluster A: 48 references within 1e-6 relative of query 3, scattered over the set
+    rows_a = rng.permutation(r)[:48]
+    ref[rows_a] = qry[3] * (1.0 + 1e-6 * rng.standard_normal((48, 1)).astype(np.float32)) \
+        + 1e-6 * rng.standard_normal((48, d)).astype(np.float32)
+    # cluster B: 60 EXACT duplicates of one row near query 7 (ties broken by index)
+    rows_b = np.setdiff1d(rng.permutation(r)[:80], rows_a)[:60]
+    ref[rows_b] = (qry[7] + 0.01 * rng.standard_normal(d)).astype(np.float32)
+    want_d, want_i = TN.topn_kdtree(ref, qry, n)
+    st = {}
+    got_d, got_i = retrieval.topn_l2(torch.tensor(ref, device=dev), torch.tensor(qry, device=dev), n,
+                                     score=score, stats=st)
+    got_i = got_i.cpu().numpy()
+    # exact ties (cluster B) may be listed in any order by the tree: compare as sets there,
+    # then check OUR order is (distance, index)
+    same = got_i == want_i
+    for qi in np.where(~same.all(axis=1))[0]:
+        assert qi == 7, qi
+        assert sorted(got_i[qi]) == sorted(np.sort(rows_b)[:n].tolist())
+        assert list(got_i[qi]) == sorted(got_i[qi])
+    np.testing.assert_array_equal(got_i[3], want_i[3])
+    np.testing.assert_allclose(got_d.cpu().numpy(), want_d, rtol=1e-12, atol=1e-300)
+    assert 2 <= st['uncertified'] <= 6, st        # the two clustered queries (+ at most a few)
+    # without the certificate the fast path alone may return a wrong list for query 3 — which
+    # is exactly why it exists; it must at least never claim more than it checks
+    fast_d, fast_i = retrieval.topn_l2(torch.tensor(ref, device=dev), torch.tensor(qry, device=dev),
+                                       n, score=score, certify=False)
+    ok = np.ones(q, bool)
+    ok[[3, 7]] = False
+    np.testing.assert_array_equal(fast_i.cpu().numpy()[ok], want_i[ok])
+
+
+def test_topn_certificate_is_silent_on_separated_data(dev):
+    from soft_contrastive_learning_amd.evaluation import retrieval
+    ref, qry = U.retrieval_sets(20000, 256, 256)
+    for score in ('f32', 'bf16x3'):
+        st = {}
+        retrieval.topn_l2(torch.tensor(ref, device=dev), torch.tensor(qry, device=dev), 25,
+                          score=score, stats=st)
+        assert st['uncertified'] == 0, (score, st)
+
+
+@pytest.mark.parametrize("score", ['f32', 'bf16x3'])
+def test_config4_full_size_retrieval(dev, score):
+    """BASELINE.json configs[4] at its full single-GPU size: 100 000 references x 10 000
+    queries x 256, n = 25.  Every query against a float64 BLAS brute force (Gram form to pick
+    the 40 best, direct (q - r)^2 form to order them — the tree's own arithmetic), and a
+    500-query subset against the reference's own KDTree.query call
+    (evaluation/top-n.py:103-106).  Index lists bit-exact, distances to 1e-12."""
+    from soft_contrastive_learning_amd.evaluation import retrieval
+    r, q, d, n = 100000, 10000, 256, 25
+    ref, qry = U.retrieval_sets(r, q, d)
+    st = {}
+    got_d, got_i = retrieval.topn_l2(torch.tensor(ref, device=dev), torch.tensor(qry, device=dev), n,
+                                     score=score, stats=st)
+    got_d, got_i = got_d.cpu().numpy(), got_i.cpu().numpy()
+    assert st['uncertified'] <= 5, st           # tie-free Gaussian data: the fast path carries it
+    r64 = ref.astype(np.float64)
+    rn = (r64 ** 2).sum(1)
+    for s in range(0, q, 500):
+        q64 = qry[s:s + 500].astype(np.float64)
+        d2 = rn[None, :] - 2.0 * (q64 @ r64.T)                       # + |q|^2: constant per row
+        part = np.argpartition(d2, 40, axis=1)[:, :40]
+        exact = ((q64[:, None, :] - r64[part]) ** 2).sum(-1)
+        # order by (distance, index)
+        o = np.lexsort((part, exact), axis=1)[:, :n]
+        want_i = np.take_along_axis(part, o, axis=1)
+        want_d = np.sqrt(np.take_along_axis(exact, o, axis=1))
+        np.testing.assert_array_equal(got_i[s:s + 500], want_i)
+        np.testing.assert_allclose(got_d[s:s + 500], want_d, rtol=1e-12, atol=0)
+    kd_d, kd_i = TN.topn_kdtree(ref, qry[:500], n)
+    np.testing.assert_array_equal(got_i[:500], kd_i)
+    np.testing.assert_allclose(got_d[:500], kd_d, rtol=1e-12, atol=0)

@@ -8,6 +8,8 @@ import numpy as np
 import pytest
 import torch
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 from soft_contrastive_learning_amd import checkpoint
 from soft_contrastive_learning_amd.evaluation import inference, top_n
 from soft_contrastive_learning_amd.model import nets
@@ -125,3 +127,26 @@ def test_compute_loss_rejects_losses_outside_the_hot_path():
     flags = T.make_parser().parse_args(['--loss', 'residual_det'])
     with pytest.raises(ValueError):
         T.compute_loss(flags, [1, 12, 12], torch.zeros(25, 8), None)
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no outer launcher must start two rank processes itself
+    and print ONE JSON line with n_gpus 2 (gloo + a stub step here: no GPU in this container);
+    a failing rank must make the parent exit non-zero."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    bench = os.path.join(ROOT, 'bench.py')
+    out = subprocess.run([sys.executable, bench, '--gpus', '2', '--steps', '3', '--warmup', '1',
+                          '--stub-cpu'], env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['steps'] == 3 and rec['data'] == 'stub'
+    # without --stub-cpu the ranks need a HIP device: both fail here, the parent reports it
+    bad = subprocess.run([sys.executable, bench, '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                         env=env, capture_output=True, text=True, timeout=240)
+    assert bad.returncode != 0 and 'ranks failed' in bad.stderr

@@ -262,3 +262,20 @@ def test_k7c_tanh_is_the_eigen_rational_approximation():
     mp, mn = L.wms_masks(d, 0.8, 15.0, 'tanh')
     assert mp[0, 1] == np.float32(2.0 ** -24) and mp[1, 0] == 0.0 and mp[1, 1] == 0.0
     assert mn[1, 1] == 1.0 and mp[0, 0] == 1.0
+
+
+def test_pairwise_distance_loss_kat():
+    """model/losses.py:627-646 by pencil on the reference's own K1 matrices
+    (model/losses.py:708-711): tuple 0 = rows (1,1),(2,2),(3,3) -> squared feature distances
+    [[0,2,8],[2,0,2],[8,2,0]].  With f_max = 2, d_max = 4 and squared geographic distances
+    [[0,4,16],[4,0,4],[16,4,0]]: scaled f = [[0,1,4],[1,0,1],[4,1,0]], scaled d the same ->
+    loss 0.  With d = 0 everywhere: squared differences sum 2 * (1 + 16 + 1) = 36 over 9
+    entries -> 4; Huber (delta 1): 2 * (0.5 + 3.5 + 0.5) = 9 over 9 entries -> 1."""
+    from oracle import losses_np as O
+    f = np.array([[[1.0, 1], [2, 2], [3, 3]]], np.float32)
+    d_same = np.array([[[0, 4, 16], [4, 0, 4], [16, 4, 0]]], np.float32)
+    assert float(O.pairwise_distance_loss(f[:, :1], f[:, 1:], d_same, 4.0, 2.0)) == 0.0
+    zero = np.zeros((1, 3, 3), np.float32)
+    assert float(O.pairwise_distance_loss(f[:, :1], f[:, 1:], zero, 4.0, 2.0)) == 4.0
+    assert float(O.pairwise_distance_loss(f[:, :1], f[:, 1:], zero, 4.0, 2.0,
+                                          'huber_distance_loss')) == 1.0
