@@ -96,8 +96,13 @@ def kernel_models(b, n, gb, x_bytes):
         # [a|ds]·[dU|W]^T then the norm Jacobian; reads x, writes grad_x
         'dx_kernel': dict(flops=4.0 * bn * D * K, bytes=2 * bn * D * x_bytes + bn * K * 8, **b3),
         'wgrad_finish_kernel': dict(flops=4.0 * b * D * K, bytes=b * D * K * 12),
-        # loss: raw Gram (upper-triangular 32x32 tiles), reads E once
+        # loss: raw Gram (upper-triangular tile pairs), reads E once
         'gram_partial_kernel': dict(flops=2.0 * gb * gb * E, bytes=gb * E * 4),
+        'gram16_kernel': dict(flops=2.0 * gb * gb * E, bytes=gb * E * 4),
+        # everything after the Gram for B <= 32, one workgroup
+        'gram_final32_kernel': dict(flops=48.0 * gb * gb, bytes=gb * gb * 16),
+        # slab sums (split-K artefact: priced on the Gram matrix it produces)
+        'gram_reduce_kernel': dict(flops=0.0, bytes=gb * gb * 4),
         'gram_rows_kernel': dict(flops=40.0 * gb * gb, bytes=gb * gb * 16),
         'gram_coef_kernel': dict(flops=8.0 * gb * gb, bytes=gb * gb * 12),
         # grad_E[own rows] = M E: reads E once, writes b rows

@@ -94,6 +94,9 @@ def main():
     ap.add_argument('--topn-refs', type=int, default=100000)
     ap.add_argument('--topn-queries', type=int, default=10000)
     ap.add_argument('--topn-score', default='f32', help="f32, bf16x3 or both (comma list)")
+    ap.add_argument('--loss-batches', default='24,48,96,192')
+    ap.add_argument('--loss-splits', default='',
+                    help='comma list of forced Gram K-split counts for B <= 256 (tuning)')
     ap.add_argument('--topn-splits', default='',
                     help='comma list of forced reference-split counts (tuning; default: planner)')
     args = ap.parse_args()
@@ -105,7 +108,14 @@ def main():
             res['netvlad_bf16_b%d_n1200' % b] = run_netvlad(dev, b, 1200, torch.bfloat16, args.iters)
             res['netvlad_f32_b%d_n1200' % b] = run_netvlad(dev, b, 1200, torch.float32, args.iters)
     if 'loss' in what:
-        res['wms_loss_sweep'] = sum((run_loss(dev, b, args.iters) for b in (24, 48, 96, 192)), [])
+        lb = [int(v) for v in args.loss_batches.split(',')]
+        res['wms_loss_sweep'] = sum((run_loss(dev, b, args.iters) for b in lb), [])
+        for sp in [int(v) for v in args.loss_splits.split(',') if v]:
+            _lib.load().scl_debug_set_variant(100000 * sp)
+            try:
+                res['wms_loss_splits_%d' % sp] = sum((run_loss(dev, b, args.iters) for b in lb), [])
+            finally:
+                _lib.load().scl_debug_set_variant(0)
     if 'topn' in what:
         scores = args.topn_score.split(',')
         for sc in scores:

@@ -439,12 +439,505 @@ __global__ __launch_bounds__(256) void sqdist_finish_kernel(const float* __restr
   }
 }
 
+
+// =======================================================================================
+// Fast path for B <= 256 (the trainer's batches: 24 / 25 rows per GPU, 192 on eight).
+//
+//   gram16_kernel        split-K raw Gram on v_mfma_f32_16x16x4_f32 (exact f32), 16-row tiles,
+//                        upper-triangular tile pairs only.  A workgroup stages its whole
+//                        [B x kchunk] slice of E in LDS with ONE burst of 16-byte loads (a
+//                        single exposed memory latency) and its waves split the work as
+//                        (pair ranges) x (k ranges); fragments are ds_read_b128 from padded
+//                        rows, the k index inside a group of 16 permuted identically on both
+//                        operands so that one 16-byte read feeds four MFMAs.
+//   gram_final32_kernel  B <= 32: ONE workgroup sums the slabs and does everything else —
+//                        norms, masks, mining, row losses, d loss / d S, the loss mean and the
+//                        matrix M — so the forward is two launches (a second launch costs
+//                        less than an in-kernel release / ticket / acquire hand-off).
+//   gram_reduce_kernel   32 < B <= 256: slab sums -> full raw Gram matrix;
+//   gram_rows_wave_kernel  one WAVE per row (lanes across the columns, shuffle reductions)
+//                        instead of one 512-thread workgroup per row.
+//   gram_bwd32_kernel    B <= 32: grad = g M E with a wave per 32 columns (1024 waves).
+// =======================================================================================
+constexpr int kFastB = 256;
+constexpr int kG16 = 16;
+
+__device__ __forceinline__ f32x4 mfma16f(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+struct Gram16Plan {
+  int T;        // 16-row tiles
+  int P;        // tile pairs (upper triangle)
+  int S;        // K-splits = workgroups
+  int kchunk;   // columns per workgroup (multiple of 16)
+  int KS;       // k-ranges among the 4 waves (4, 2 or 1); pair ranges = 4 / KS
+};
+
+inline Gram16Plan make_plan16(int B, int E) {
+  Gram16Plan p;
+  p.T = (B + 15) / 16;
+  p.P = p.T * (p.T + 1) / 2;
+  p.KS = p.P <= 3 ? 4 : (p.P <= 10 ? 2 : 1);
+  // LDS holds [16 T][kchunk + 4] floats (<= 128 KB) and a thread stages <= 48 float4
+  int kc_max = (128 * 1024 / 4) / (16 * p.T) - 4;
+  kc_max = kc_max / 64 * 64;
+  if (kc_max > 512) kc_max = 512;
+  // small batches: fewer, larger splits (the finishing workgroup reads every slab);
+  // large ones: one workgroup per CU
+  int s = B <= 32 ? 64 : 256;
+  int ov = scl_debug_variant / 100000;          // tuning override: splits = ov
+  if (ov > 0) s = ov;
+  int kc = 64;                                   // power of two: staging indices by shifts
+  while (kc < (E + s - 1) / s && 2 * kc <= kc_max) kc *= 2;
+  p.kchunk = kc;
+  p.S = (E + kc - 1) / kc;
+  return p;
+}
+
+// pair index (row-major over the upper triangle of T x T tiles) -> (ti, tj)
+__device__ __forceinline__ void decode_pair16(int pair, int T, int& ti, int& tj) {
+  int i = 0, rem = pair;
+  while (rem >= T - i) {
+    rem -= T - i;
+    ++i;
+  }
+  ti = i;
+  tj = i + rem;
+}
+
+// grid S; block 256; dynamic LDS [16 T][kchunk + 4] floats (reused for the cross-wave sums).
+// slabs: [S][P][256]: accumulator register j of lane l at [l * 4 + j] = Gram entry
+// (row 16 ti + 4 (l >> 4) + j, column 16 tj + (l & 15)).
+template <int PWMAX>
+__global__ __launch_bounds__(256) void gram16_kernel(const float* __restrict__ emb, int64_t ld,
+                                                     int B, int E, int T, int P, int kchunk,
+                                                     int KS, int vec_ok,
+                                                     float* __restrict__ slabs) {
+  extern __shared__ __attribute__((aligned(16))) float g16_lds[];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int i = lane & 15, gq = lane >> 4;
+  const int LD = kchunk + 4;
+  const int Bp = 16 * T;
+  const int k0 = blockIdx.x * kchunk;
+  const int qshift = __ffs(kchunk) - 3;              // log2(float4 per staged row)
+  const int qmask = (1 << qshift) - 1;
+  const int total_q = Bp << qshift;
+
+  // ---- stage the slice: every load is issued before the first LDS write
+  constexpr int RND = 16;
+  for (int base = 0; base < total_q; base += 256 * RND) {
+    f32x4 v[RND];
+#pragma unroll
+    for (int u = 0; u < RND; ++u) {
+      const int q = base + u * 256 + threadIdx.x;
+      const int row = q >> qshift, c4 = q & qmask;
+      const int e = k0 + 4 * c4;
+      v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (q < total_q && row < B) {
+        const float* src = emb + (int64_t)row * ld + e;
+        if (vec_ok && e + 4 <= E) {
+          v[u] = *reinterpret_cast<const f32x4*>(src);
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (e + c < E) v[u][c] = src[c];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < RND; ++u) {
+      const int q = base + u * 256 + threadIdx.x;
+      const int row = q >> qshift, c4 = q & qmask;
+      if (q < total_q) *reinterpret_cast<f32x4*>(&g16_lds[row * LD + 4 * c4]) = v[u];
+    }
+  }
+  __syncthreads();
+
+  // ---- this wave's share: pairs [p_begin, p_end) x 16-column groups [g_begin, g_end)
+  const int PS = 4 / KS;
+  const int kq = wid % KS, pq = wid / KS;
+  const int p_begin = (int)(((long)P * pq) / PS), p_end = (int)(((long)P * (pq + 1)) / PS);
+  const int np = p_end - p_begin;
+  const int G = kchunk / kG16;
+  const int g_begin = (G * kq) / KS, g_end = (G * (kq + 1)) / KS;
+  int ti0, tj0;
+  decode_pair16(p_begin < P ? p_begin : 0, T, ti0, tj0);
+
+  f32x4 acc[PWMAX];
+#pragma unroll
+  for (int lp = 0; lp < PWMAX; ++lp) acc[lp] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // (group, pair) is one flat stream: the fragments of the NEXT step — the next pair of this
+  // group or the first pair of the next group — are read under this step's MFMAs
+  const float* col0 = &g16_lds[i * LD + 4 * gq];
+  f32x4 a = *reinterpret_cast<const f32x4*>(col0 + kG16 * g_begin + 16 * ti0 * LD);
+  f32x4 b = *reinterpret_cast<const f32x4*>(col0 + kG16 * g_begin + 16 * tj0 * LD);
+  for (int g = g_begin; g < g_end; ++g) {
+    const float* col = col0 + kG16 * g;
+    const float* col_next = g + 1 < g_end ? col + kG16 : col;
+    int ti = ti0, tj = tj0;
+#pragma unroll
+    for (int lp = 0; lp < PWMAX; ++lp) {
+      if (lp < np) {
+        const bool last = lp + 1 == np;
+        int tj_n = tj + 1, ti_n = ti;
+        if (tj_n == T) {
+          ti_n = ti + 1;
+          tj_n = ti_n;
+        }
+        ti_n = last ? ti0 : ti_n;
+        tj_n = last ? tj0 : tj_n;
+        const float* cn = last ? col_next : col;
+        const f32x4 a_n = *reinterpret_cast<const f32x4*>(cn + 16 * ti_n * LD);
+        const f32x4 b_n = *reinterpret_cast<const f32x4*>(cn + 16 * tj_n * LD);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[lp] = mfma16f(a[c], b[c], acc[lp]);
+        a = a_n;
+        b = b_n;
+        ti = ti_n;
+        tj = tj_n;
+      }
+    }
+  }
+
+  float* slab = slabs + (int64_t)blockIdx.x * P * 256;
+  if (KS == 1) {
+#pragma unroll
+    for (int lp = 0; lp < PWMAX; ++lp)
+      if (lp < np) *reinterpret_cast<f32x4*>(slab + (int64_t)(p_begin + lp) * 256 + 4 * lane) = acc[lp];
+    return;
+  }
+  // k ranges on different waves: fixed-order sum through LDS (the staged slice is dead)
+  __syncthreads();
+  f32x4* red = reinterpret_cast<f32x4*>(g16_lds);          // [KS][P][64]
+#pragma unroll
+  for (int lp = 0; lp < PWMAX; ++lp)
+    if (lp < np) red[((int64_t)kq * P + p_begin + lp) * 64 + lane] = acc[lp];
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < P * 64; idx += 256) {
+    f32x4 v = red[idx];
+    if (KS == 2) {
+      v += red[P * 64 + idx];
+    } else {
+      const f32x4 v1 = red[P * 64 + idx], v2 = red[2 * P * 64 + idx], v3 = red[3 * P * 64 + idx];
+      v = (v + v1) + (v2 + v3);
+    }
+    *reinterpret_cast<f32x4*>(slab + 4 * (int64_t)idx) = v;
+  }
+}
+
+// ---- pair terms of one (row, column) entry, shared by every finishing kernel --------------
+struct PairEval {
+  float s, mp, mn;   // clamped similarity and the two masks (mp already has the -eye term)
+};
+__device__ __forceinline__ PairEval pair_masks(float gn, float d, int same_label, bool diag,
+                                               const LossParams& lp) {
+  PairEval r;
+  r.s = fmaxf(gn, 0.f);
+  if (lp.mask_kind == SCL_MASK_LABELS) {
+    r.mp = same_label ? 1.f : 0.f;
+    r.mn = same_label ? 0.f : 1.f;
+  } else if (lp.mask_kind == SCL_MASK_WMS_LIN) {
+    r.mp = d < lp.d_beta ? 1.0f - d / lp.d_beta : 0.f;
+    r.mn = d < lp.d_beta ? d / lp.d_beta : 1.f;
+  } else if (lp.mask_kind == SCL_MASK_WMS_TANH) {
+    const float t = eigen_fast_tanh(__fdiv_rn(d, lp.d_beta));
+    r.mp = 1.0f - t;
+    r.mn = t;
+  } else {
+    r.mp = 1.0f / (1.0f + expf(lp.d_alpha * (d - lp.d_beta)));
+    r.mn = 1.0f / (1.0f + expf(lp.d_alpha * (lp.d_beta - d)));
+  }
+  if (diag) r.mp -= 1.0f;   // mask_pos - eye (model/losses.py:22,91)
+  return r;
+}
+
+// One wave evaluates reduction row i.  Lane l holds columns j = l + 64 c (c < C); gn[c] is the
+// normalised Gram entry, d[c] / lab[c] the mask input.  Returns the row loss (all lanes) and
+// fills g[c] = d loss / d S[i, j] (before the 1 / B of the mean is applied by the caller's
+// invB).  Semantics as gram_rows_kernel / model/losses.py:25-58, 94-120.
+template <int C, bool HALF = false>
+__device__ __forceinline__ float wave_row_eval(int i, int B, int lane, const float (&gn)[C],
+                                               const float (&d)[C], const int (&same)[C],
+                                               const LossParams& lp, float invB, float (&g)[C]) {
+  // HALF: `lane` is the column inside a 32-lane half that owns the row; reductions stay in it
+  auto rmax = [](float v) { return HALF ? half_max(v) : wave_max(v); };
+  auto rmin = [](float v) { return HALF ? -half_max(-v) : wave_min(v); };
+  auto rsum = [](float v) { return HALF ? half_sum(v) : wave_sum(v); };
+  PairEval pe[C];
+  float vmaxN = -INFINITY, vmaxP = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int j = lane + 64 * c;
+    pe[c] = pair_masks(gn[c], d[c], same[c], j == i, lp);
+    if (j < B) {
+      vmaxN = fmaxf(vmaxN, pe[c].s * pe[c].mn);
+      vmaxP = fmaxf(vmaxP, pe[c].s * pe[c].mp);
+    }
+  }
+  float max_val = 0.f, min_val = 0.f;
+  if (lp.ms_mining) {
+    max_val = rmax(vmaxN);
+    const float tmp = rmax(vmaxP);
+    float vmin = INFINITY;
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+      if (lane + 64 * c < B) vmin = fminf(vmin, (pe[c].s - tmp) * pe[c].mp);
+    min_val = rmin(vmin) + tmp;
+  }
+  float ps = 0.f, ns = 0.f, pterm[C], nterm[C];
+  bool selp[C], seln[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const float Pm = pe[c].s * pe[c].mp, Nm = pe[c].s * pe[c].mn;
+    float kp = pe[c].mp, kn = pe[c].mn;
+    if (lp.ms_mining) {
+      kp = Pm < max_val + lp.eps ? pe[c].mp : 0.f;
+      kn = Nm > min_val - lp.eps ? pe[c].mn : 0.f;
+    }
+    const bool ok = lane + 64 * c < B;
+    selp[c] = ok && kp > 0.f;
+    seln[c] = ok && kn > 0.f;
+    if (lp.sum_kind == SCL_SUM_PLAIN) {
+      pterm[c] = selp[c] ? Pm : 0.f;
+      nterm[c] = seln[c] ? Nm : 0.f;
+    } else {
+      pterm[c] = selp[c] ? expf(-lp.alpha * (Pm - lp.lamb)) : 0.f;
+      nterm[c] = seln[c] ? expf(lp.beta * (Nm - lp.lamb)) : 0.f;
+    }
+    ps += pterm[c];
+    ns += nterm[c];
+  }
+  ps = rsum(ps);
+  ns = rsum(ns);
+  float rowloss;
+  if (lp.sum_kind == SCL_SUM_PLAIN)
+    rowloss = ns - ps;
+  else
+    rowloss = logf(1.0f + ps) / lp.alpha + logf(1.0f + ns) / lp.beta;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    float v;
+    if (lp.sum_kind == SCL_SUM_PLAIN)
+      v = (seln[c] ? pe[c].mn : 0.f) - (selp[c] ? pe[c].mp : 0.f);
+    else
+      v = nterm[c] / (1.0f + ns) * pe[c].mn - pterm[c] / (1.0f + ps) * pe[c].mp;
+    g[c] = gn[c] >= 0.f ? v * invB : 0.f;
+  }
+  return rowloss;
+}
+
+// B <= 32: the whole finish in one 1024-thread workgroup.
+//   1. G = sum of the S slabs (fixed order), raw Gram in LDS (both triangles)
+//   2. rn_j from the diagonal; 3. one 32-lane HALF-wave per row: masks, mining, row loss,
+//      d loss / d S (all 32 rows in one round);
+//   4. loss mean; M = rn_i rn_j (g_ij + g_ji) - [i == j] rn_i^2 sum_j (g_ij + g_ji) Gn_ij
+// Every global load (slabs, distances / labels) is issued before the first wait.
+__global__ __launch_bounds__(1024) void gram_final32_kernel(
+    const float* __restrict__ slabs, int S, int T, int P, int B,
+    const float* __restrict__ distances, const int64_t* __restrict__ labels, LossParams lp,
+    float* __restrict__ coef, float* __restrict__ loss_out) {
+  __shared__ float Gr[32][33];       // raw Gram, then normalised
+  __shared__ float Gc[32][33];       // d loss / d S
+  __shared__ f32x4 part[4][192];     // partial slab sums
+  __shared__ float rn[32], rowloss[32];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int ri = 2 * wid + (lane >> 5), rj = lane & 31;      // this lane's (row, column)
+  const bool rok = ri < B && rj < B;
+  // mask inputs of entry (ri, rj): in flight under the slab sums
+  float dval = 0.f;
+  int same = 0;
+  if (rok) {
+    if (lp.mask_kind == SCL_MASK_LABELS)
+      same = labels[rj] == labels[ri];
+    else
+      dval = lp.dist_rank3 ? distances[(int64_t)rj * B + ri] : distances[(int64_t)ri * B + rj];
+  }
+  {
+    const int grp = threadIdx.x >> 8, idx = threadIdx.x & 255;
+    constexpr int U = 16;
+    f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+    if (idx < P * 64) {
+      const f32x4* src = reinterpret_cast<const f32x4*>(slabs) + idx;
+      for (int s0 = grp; s0 < S; s0 += 4 * U) {
+        f32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int sidx = s0 + 4 * u;
+          v[u] = sidx < S ? src[(int64_t)sidx * P * 64] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc4 += v[u];
+      }
+      part[grp][idx] = acc4;
+    }
+    __syncthreads();
+    if (threadIdx.x < P * 64) {
+      const f32x4 v = (part[0][idx] + part[1][idx]) + (part[2][idx] + part[3][idx]);
+      const int pair = idx >> 6, l = idx & 63;
+      int ti, tj;
+      decode_pair16(pair, T, ti, tj);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = 16 * ti + 4 * (l >> 4) + j, c = 16 * tj + (l & 15);
+        Gr[r][c] = v[j];
+        if (ti != tj) Gr[c][r] = v[j];
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 32) rn[threadIdx.x] = 1.0f / sqrtf(fmaxf(Gr[threadIdx.x][threadIdx.x], 1e-12f));
+  __syncthreads();
+  // 3. rows: half-wave (wid, lane >> 5) owns row ri
+  const float invB = 1.0f / (float)B;
+  float gnv[1], dv[1], gv[1];
+  int sv[1];
+  gnv[0] = rok ? Gr[ri][rj] * rn[ri] * rn[rj] : 0.f;
+  dv[0] = dval;
+  sv[0] = same;
+  // rows >= B run on zeros (their results are never stored); B is passed as the column count
+  const float rl = wave_row_eval<1, true>(ri, B, rj, gnv, dv, sv, lp, invB, gv);
+  if (rok) Gc[ri][rj] = gv[0];
+  if (rj == 0 && ri < B) rowloss[ri] = rl;
+  __syncthreads();
+  if (wid == 0) {
+    float a = lane < B ? rowloss[lane] : 0.f;
+    a = wave_sum(a);
+    if (lane == 0) *loss_out = a / (float)B;
+  }
+  if (!coef) return;
+  const float gs = rok ? Gc[ri][rj] + Gc[rj][ri] : 0.f;
+  const float c = half_sum(rok ? gs * gnv[0] : 0.f);
+  if (rok) {
+    const float rni = rn[ri];
+    const bool clamped = rni >= 1.0e6f;   // see gram_coef_kernel
+    float m = rni * rn[rj] * gs;
+    if (rj == ri && !clamped) m -= rni * rni * c;
+    coef[(int64_t)ri * B + rj] = m;
+  }
+}
+
+// grid P; block 256: full raw Gram (both triangles) = fixed-order sum of the S slabs of one
+// tile pair.  Wave w adds slabs s = w, w + 4, ...; the four partial sums meet in LDS.
+__global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restrict__ slabs, int S,
+                                                          int T, int P, int B,
+                                                          float* __restrict__ gfull) {
+  __shared__ f32x4 part[4][64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int pair = blockIdx.x;
+  const f32x4* src = reinterpret_cast<const f32x4*>(slabs) + (int64_t)pair * 64 + lane;
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+  int s = wid;
+  for (; s + 12 < S; s += 16) {
+    a0 += src[(int64_t)(s + 0) * P * 64];
+    a1 += src[(int64_t)(s + 4) * P * 64];
+    a2 += src[(int64_t)(s + 8) * P * 64];
+    a3 += src[(int64_t)(s + 12) * P * 64];
+  }
+  for (; s < S; s += 4) a0 += src[(int64_t)s * P * 64];
+  part[wid][lane] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (wid != 0) return;
+  const f32x4 v = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+  int ti, tj;
+  decode_pair16(pair, T, ti, tj);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = 16 * ti + 4 * (lane >> 4) + j, c = 16 * tj + (lane & 15);
+    if (r < B && c < B) {
+      gfull[(int64_t)r * B + c] = v[j];
+      gfull[(int64_t)c * B + r] = v[j];
+    }
+  }
+}
+
+// grid ceil(B / 4); block 256: wave w evaluates reduction row 4 blockIdx.x + w from the full
+// raw Gram matrix.  C = ceil(B / 64) columns per lane.
+template <int C>
+__global__ __launch_bounds__(256) void gram_rows_wave_kernel(
+    const float* __restrict__ gfull, int B, const float* __restrict__ distances,
+    const int64_t* __restrict__ labels, LossParams lp, float* __restrict__ gn_out,
+    float* __restrict__ gc_out, float* __restrict__ rn_out, float* __restrict__ rowloss_out) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int i = blockIdx.x * 4 + wid;
+  if (i >= B) return;                                    // wave-uniform
+  const float rni = 1.0f / sqrtf(fmaxf(gfull[(int64_t)i * B + i], 1e-12f));
+  const int64_t labi = labels ? labels[i] : 0;
+  float gn[C], d[C], g[C];
+  int same[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int j = lane + 64 * c;
+    gn[c] = 0.f;
+    d[c] = 0.f;
+    same[c] = 0;
+    if (j < B) {
+      const float rnj = 1.0f / sqrtf(fmaxf(gfull[(int64_t)j * B + j], 1e-12f));
+      gn[c] = gfull[(int64_t)i * B + j] * rni * rnj;
+      if (lp.mask_kind == SCL_MASK_LABELS)
+        same[c] = labels[j] == labi;
+      else
+        d[c] = lp.dist_rank3 ? distances[(int64_t)j * B + i] : distances[(int64_t)i * B + j];
+    }
+  }
+  const float rl = wave_row_eval<C>(i, B, lane, gn, d, same, lp, 1.0f / (float)B, g);
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int j = lane + 64 * c;
+    if (j < B) {
+      gn_out[(int64_t)i * B + j] = gn[c];
+      gc_out[(int64_t)i * B + j] = g[c];
+    }
+  }
+  if (lane == 0) {
+    rowloss_out[i] = rl;
+    rn_out[i] = rni;
+  }
+}
+
+// B <= 32: grad[r, e] = g * sum_j M[row_begin + r, j] emb[j, e] on v_mfma_f32_32x32x2_f32 with
+// ONE wave per 32 columns (grid E / 128 workgroups of four waves: 1024 waves at E = 32768, so
+// every CU streams; the previous kernel ran 64 workgroups).  All loads of a wave are issued
+// before its first MFMA.
+__global__ __launch_bounds__(256) void gram_bwd32_kernel(const float* __restrict__ emb, int64_t ld,
+                                                         int B, int E,
+                                                         const float* __restrict__ coef,
+                                                         const float* __restrict__ grad_loss,
+                                                         int row_begin, int row_count,
+                                                         float* __restrict__ grad, int64_t ldg) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int e = (blockIdx.x * 4 + wid) * 32 + r;
+  if ((blockIdx.x * 4 + wid) * 32 >= E) return;          // wave-uniform
+  const bool col_ok = e < E;
+  float a[16], b[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int j = 2 * t + h;
+    const bool jok = j < B;
+    a[t] = (jok && r < row_count) ? coef[(int64_t)(row_begin + r) * B + j] : 0.f;
+    b[t] = (jok && col_ok) ? emb[(int64_t)j * ld + e] : 0.f;
+  }
+  f32x16 acc = zero16();
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+    if (2 * t < B) acc = mfma32(a[t], b[t], acc);
+  const float g = grad_loss ? *grad_loss : 1.0f;
+  if (!col_ok) return;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int orow = acc_row(q, h);
+    if (orow < row_count) grad[(int64_t)orow * ldg + e] = g * acc[q];
+  }
+}
+
 struct GramWs {
-  float *slabs, *gn, *gc, *rn, *rowloss;
+  float *slabs, *gn, *gc, *rn, *rowloss, *gfull;
   size_t total;
 };
 
-inline GramWs carve(void* ws, int B, const GramPlan& p, int batch) {
+inline GramWs carve(void* ws, int B, size_t slab_floats) {
   GramWs w;
   char* c = (char*)ws;
   size_t off = 0;
@@ -453,21 +946,45 @@ inline GramWs carve(void* ws, int B, const GramPlan& p, int batch) {
     off += scl_round256(bytes);
     return ptr;
   };
-  w.slabs = take((size_t)batch * p.splits * p.npairs * kTile * kTile * sizeof(float));
+  w.slabs = take(slab_floats * sizeof(float));
   w.gn = take((size_t)B * B * sizeof(float));
   w.gc = take((size_t)B * B * sizeof(float));
   w.rn = take((size_t)B * sizeof(float));
   w.rowloss = take((size_t)B * sizeof(float));
+  w.gfull = take((size_t)B * B * sizeof(float));
   w.total = off;
   return w;
 }
 
+inline size_t slab_floats_for(int B, int E) {
+  if (B <= kFastB) {
+    const Gram16Plan p = make_plan16(B, E);
+    return (size_t)p.S * p.P * 256;
+  }
+  const GramPlan p = make_plan(B, E);
+  return (size_t)p.splits * p.npairs * kTile * kTile;
+}
+
+template <int PWMAX>
+void launch_gram16(const Gram16Plan& p, const float* emb, int64_t ld, int B, int E, int vec_ok,
+                   float* slabs, hipStream_t st) {
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16_kernel<PWMAX>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024);
+  });
+  size_t lds = (size_t)16 * p.T * (p.kchunk + 4) * sizeof(float);
+  const size_t red = p.KS > 1 ? (size_t)p.KS * p.P * 64 * sizeof(f32x4) : 0;
+  if (red > lds) lds = red;
+  SCL_LAUNCH("gram16_kernel", gram16_kernel<PWMAX>, dim3(p.S), dim3(256), lds, st, emb, ld, B, E,
+             p.T, p.P, p.kchunk, p.KS, vec_ok, slabs);
+}
 
 }  // namespace
 
 extern "C" size_t scl_gram_loss_workspace_bytes(int B, int E) {
   if (B < 1 || E < 1 || B > kMaxB) return 0;
-  return carve(nullptr, B, make_plan(B, E), 1).total;
+  return carve(nullptr, B, slab_floats_for(B, E)).total;
 }
 
 extern "C" int scl_gram_loss_fwd(const float* emb, int64_t ld_emb, int B, int E, int mask_kind,
@@ -481,14 +998,11 @@ extern "C" int scl_gram_loss_fwd(const float* emb, int64_t ld_emb, int B, int E,
   if (mask_kind < SCL_MASK_WMS_EXP || mask_kind > SCL_MASK_LABELS) return SCL_E_KIND;
   if (sum_kind != SCL_SUM_MS && sum_kind != SCL_SUM_PLAIN) return SCL_E_KIND;
   if (mask_kind == SCL_MASK_LABELS ? !labels : !distances) return SCL_E_NULL;
-  const GramPlan p = make_plan(B, E);
   if (!scl_aligned256(workspace)) return SCL_E_WORKSPACE;
-  GramWs w = carve(workspace, B, p, 1);
+  GramWs w = carve(workspace, B, slab_floats_for(B, E));
   if (workspace_bytes < w.total) return SCL_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const int vec_ok = (ld_emb % 4 == 0) && ((uintptr_t)emb % 16 == 0);
-  SCL_LAUNCH("gram_partial_kernel", gram_partial_kernel, dim3(p.splits, p.npairs, 1), dim3(256), 0, st, emb,
-                     ld_emb, (int64_t)0, B, E, p.tiles, p.kchunk, vec_ok, w.slabs);
   LossParams lp;
   lp.mask_kind = mask_kind;
   lp.dist_rank3 = dist_rank3 ? 1 : 0;
@@ -500,11 +1014,49 @@ extern "C" int scl_gram_loss_fwd(const float* emb, int64_t ld_emb, int B, int E,
   lp.beta = beta;
   lp.lamb = lamb;
   lp.eps = eps;
-  const int Bp = (B + 63) / 64 * 64;
-  const size_t lds_bytes = ((size_t)rows_part_floats(B) + 5 * (size_t)Bp) * sizeof(float);
-  SCL_LAUNCH("gram_rows_kernel", gram_rows_kernel, dim3(B), dim3(kRowThreads), lds_bytes, st, w.slabs,
-                     p.splits, p.npairs, p.tiles, B, distances, labels, lp, w.gn, w.gc, w.rn,
-                     w.rowloss);
+  if (B <= kFastB) {
+    const Gram16Plan p = make_plan16(B, E);
+    const int pw = (p.P + (4 / p.KS) - 1) / (4 / p.KS);
+    if (pw <= 3)
+      launch_gram16<3>(p, emb, ld_emb, B, E, vec_ok, w.slabs, st);
+    else if (pw <= 5)
+      launch_gram16<5>(p, emb, ld_emb, B, E, vec_ok, w.slabs, st);
+    else if (pw <= 9)
+      launch_gram16<9>(p, emb, ld_emb, B, E, vec_ok, w.slabs, st);
+    else if (pw <= 20)
+      launch_gram16<20>(p, emb, ld_emb, B, E, vec_ok, w.slabs, st);
+    else
+      launch_gram16<34>(p, emb, ld_emb, B, E, vec_ok, w.slabs, st);
+    if (B <= 32) {
+      SCL_LAUNCH("gram_final32_kernel", gram_final32_kernel, dim3(1), dim3(1024), 0, st,
+                 (const float*)w.slabs, p.S, p.T, p.P, B, distances, labels, lp, coef, loss_out);
+      return scl_launch_status();
+    }
+    SCL_LAUNCH("gram_reduce_kernel", gram_reduce_kernel, dim3(p.P), dim3(256), 0, st,
+               (const float*)w.slabs, p.S, p.T, p.P, B, w.gfull);
+    const dim3 rg((B + 3) / 4);
+#define SCL_ROWS(C)                                                                          \
+  SCL_LAUNCH("gram_rows_kernel", gram_rows_wave_kernel<C>, rg, dim3(256), 0, st,             \
+             (const float*)w.gfull, B, distances, labels, lp, w.gn, w.gc, w.rn, w.rowloss)
+    if (B <= 64)
+      SCL_ROWS(1);
+    else if (B <= 128)
+      SCL_ROWS(2);
+    else if (B <= 192)
+      SCL_ROWS(3);
+    else
+      SCL_ROWS(4);
+#undef SCL_ROWS
+  } else {
+    const GramPlan p = make_plan(B, E);
+    SCL_LAUNCH("gram_partial_kernel", gram_partial_kernel, dim3(p.splits, p.npairs, 1), dim3(256),
+               0, st, emb, ld_emb, (int64_t)0, B, E, p.tiles, p.kchunk, vec_ok, w.slabs);
+    const int Bp = (B + 63) / 64 * 64;
+    const size_t lds_bytes = ((size_t)rows_part_floats(B) + 5 * (size_t)Bp) * sizeof(float);
+    SCL_LAUNCH("gram_rows_kernel", gram_rows_kernel, dim3(B), dim3(kRowThreads), lds_bytes, st,
+               w.slabs, p.splits, p.npairs, p.tiles, B, distances, labels, lp, w.gn, w.gc, w.rn,
+               w.rowloss);
+  }
   SCL_LAUNCH("gram_coef_kernel", gram_coef_kernel, dim3(coef ? B : 1), dim3(256), 0, st, w.gn, w.gc, w.rn,
                      w.rowloss, B, coef, loss_out);
   return scl_launch_status();
@@ -516,6 +1068,12 @@ extern "C" int scl_gram_loss_bwd(const float* emb, int64_t ld_emb, int B, int E,
   if (!emb || !coef || !grad_emb) return SCL_E_NULL;
   if (B < 1 || E < 1 || ld_emb < E || ld_grad < E) return SCL_E_SHAPE;
   if (row_begin < 0 || row_count < 1 || row_begin + row_count > B || B > kMaxB) return SCL_E_SHAPE;
+  if (B <= 32) {
+    SCL_LAUNCH("gram_bwd_kernel", gram_bwd32_kernel, dim3((E + 127) / 128), dim3(256), 0,
+               (hipStream_t)stream, emb, ld_emb, B, E, coef, grad_loss, row_begin, row_count,
+               grad_emb, ld_grad);
+    return scl_launch_status();
+  }
   static std::once_flag once;
   std::call_once(once, [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_bwd_kernel),

@@ -67,8 +67,8 @@ def test_baseline_config0_triplet_pipeline_matches_cpu_restatement(dev):
     loss = P.triplet_loss(*parts, 0.5)
     loss.backward()
     err = float((emb.detach().cpu() - torch.from_numpy(want_emb)).abs().max()) / float(np.abs(want_emb).max())
-    assert err < 2e-3                      # MIOpen vs oneDNN convolution algorithms, 13 layers deep
-    assert abs(float(loss) - want) <= 2e-3 * abs(want) + 1e-6, (float(loss), want)
+    assert err < 1e-4                      # north_star tolerance (measured ~1e-6, see test_gpu_config1)
+    assert abs(float(loss) - want) <= 1e-4 * abs(want) + 1e-6, (float(loss), want)
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in gpu_model.parameters())
 
 
@@ -111,7 +111,7 @@ def test_inference_product_is_the_reference_pickle(dev, tmp_path):
     # order: feature i belongs to image i, whatever the batching
     again = inference.extract_features(model, loader, 5, images_per_pass=2)
     for a, b in zip(feats, again):
-        np.testing.assert_allclose(a, b, rtol=2e-3, atol=2e-5)
+        np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-6)
     out = tmp_path / 'set_name.pickle'
     inference.save_pickle(feats, str(out))
     back = pickle.load(open(out, 'rb'))

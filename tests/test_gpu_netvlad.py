@@ -137,7 +137,9 @@ def test_vgg16netvlad_end_to_end_vs_cpu(dev):
         want = NV.netvlad_fused(fmap.reshape(2, -1, 512).numpy(), w, c)
         got = nets.vgg16Netvlad(img.to(dev), model=model.to(dev)).cpu().numpy()
     assert got.shape == (2, 32768)
-    assert _maxrel(got, want) < 2e-3   # backbone conv algorithms differ CPU vs MIOpen
+    # measured on MI355X against a float64 evaluation: HIP 1.8e-7, torch-CPU float32 5.3e-7
+    # (tests/test_gpu_config1.py::test_a1_float32_end_to_end_error_against_float64)
+    assert _maxrel(got, want) < 1e-4
     # grey input is replicated to 3 channels (model/nets.py:15-16)
     grey = img[..., :1].to(dev)
     with torch.no_grad():
