@@ -509,13 +509,18 @@ __device__ __forceinline__ void decode_pair16(int pair, int T, int& ti, int& tj)
 // grid S; block 256; dynamic LDS [16 T][kchunk + 4] floats (reused for the cross-wave sums).
 // slabs: [S][P][256]: accumulator register j of lane l at [l * 4 + j] = Gram entry
 // (row 16 ti + 4 (l >> 4) + j, column 16 tj + (l & 15)).
-template <int PWMAX>
+// FULL: every wave owns exactly PWMAX pairs (no guard in the pair loop).
+template <int PWMAX, bool FULL>
 __global__ __launch_bounds__(256) void gram16_kernel(const float* __restrict__ emb, int64_t ld,
                                                      int B, int E, int T, int P, int kchunk,
                                                      int KS, int vec_ok,
                                                      float* __restrict__ slabs) {
   extern __shared__ __attribute__((aligned(16))) float g16_lds[];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  // the wave index must be PROVABLY wave-uniform: everything derived from it (pair range, k
+  // range) then lives in scalar registers and the pair loop has scalar branches; as a plain
+  // threadIdx expression hipcc treats it as divergent and wraps every step in exec masks and
+  // accumulator copies
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, gq = lane >> 4;
   const int LD = kchunk + 4;
   const int Bp = 16 * T;
@@ -524,24 +529,37 @@ __global__ __launch_bounds__(256) void gram16_kernel(const float* __restrict__ e
   const int qmask = (1 << qshift) - 1;
   const int total_q = Bp << qshift;
 
-  // ---- stage the slice: every load is issued before the first LDS write
+  // ---- stage the slice: every load is issued before the first LDS write.  The common case
+  //      (aligned rows, slice inside E) has NO branch around a load: a guarded load makes hipcc
+  //      wait for each one before issuing the next (16 serial round trips measured here).
   constexpr int RND = 16;
+  const bool fast = vec_ok && k0 + kchunk <= E;
   for (int base = 0; base < total_q; base += 256 * RND) {
     f32x4 v[RND];
+    if (fast) {
 #pragma unroll
-    for (int u = 0; u < RND; ++u) {
-      const int q = base + u * 256 + threadIdx.x;
-      const int row = q >> qshift, c4 = q & qmask;
-      const int e = k0 + 4 * c4;
-      v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (q < total_q && row < B) {
-        const float* src = emb + (int64_t)row * ld + e;
-        if (vec_ok && e + 4 <= E) {
-          v[u] = *reinterpret_cast<const f32x4*>(src);
-        } else {
+      for (int u = 0; u < RND; ++u) {
+        const int q = base + u * 256 + threadIdx.x;
+        int row = q >> qshift;
+        row = row < B ? row : B - 1;                    // padding rows re-read the last row
+        v[u] = *reinterpret_cast<const f32x4*>(emb + (int64_t)row * ld + k0 + 4 * (q & qmask));
+      }
+    } else {
 #pragma unroll
-          for (int c = 0; c < 4; ++c)
-            if (e + c < E) v[u][c] = src[c];
+      for (int u = 0; u < RND; ++u) {
+        const int q = base + u * 256 + threadIdx.x;
+        const int row = q >> qshift, c4 = q & qmask;
+        const int e = k0 + 4 * c4;
+        v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (q < total_q && row < B) {
+          const float* src = emb + (int64_t)row * ld + e;
+          if (vec_ok && e + 4 <= E) {
+            v[u] = *reinterpret_cast<const f32x4*>(src);
+          } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              if (e + c < E) v[u][c] = src[c];
+          }
         }
       }
     }
@@ -549,7 +567,9 @@ __global__ __launch_bounds__(256) void gram16_kernel(const float* __restrict__ e
     for (int u = 0; u < RND; ++u) {
       const int q = base + u * 256 + threadIdx.x;
       const int row = q >> qshift, c4 = q & qmask;
-      if (q < total_q) *reinterpret_cast<f32x4*>(&g16_lds[row * LD + 4 * c4]) = v[u];
+      if (q < total_q)
+        *reinterpret_cast<f32x4*>(&g16_lds[row * LD + 4 * c4]) =
+            row < B ? v[u] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
   __syncthreads();
@@ -579,8 +599,8 @@ __global__ __launch_bounds__(256) void gram16_kernel(const float* __restrict__ e
     int ti = ti0, tj = tj0;
 #pragma unroll
     for (int lp = 0; lp < PWMAX; ++lp) {
-      if (lp < np) {
-        const bool last = lp + 1 == np;
+      if (FULL || lp < np) {
+        const bool last = FULL ? lp + 1 == PWMAX : lp + 1 == np;
         int tj_n = tj + 1, ti_n = ti;
         if (tj_n == T) {
           ti_n = ti + 1;
@@ -605,7 +625,8 @@ __global__ __launch_bounds__(256) void gram16_kernel(const float* __restrict__ e
   if (KS == 1) {
 #pragma unroll
     for (int lp = 0; lp < PWMAX; ++lp)
-      if (lp < np) *reinterpret_cast<f32x4*>(slab + (int64_t)(p_begin + lp) * 256 + 4 * lane) = acc[lp];
+      if (FULL || lp < np)
+        *reinterpret_cast<f32x4*>(slab + (int64_t)(p_begin + lp) * 256 + 4 * lane) = acc[lp];
     return;
   }
   // k ranges on different waves: fixed-order sum through LDS (the staged slice is dead)
@@ -613,7 +634,7 @@ __global__ __launch_bounds__(256) void gram16_kernel(const float* __restrict__ e
   f32x4* red = reinterpret_cast<f32x4*>(g16_lds);          // [KS][P][64]
 #pragma unroll
   for (int lp = 0; lp < PWMAX; ++lp)
-    if (lp < np) red[((int64_t)kq * P + p_begin + lp) * 64 + lane] = acc[lp];
+    if (FULL || lp < np) red[((int64_t)kq * P + p_begin + lp) * 64 + lane] = acc[lp];
   __syncthreads();
   for (int idx = threadIdx.x; idx < P * 64; idx += 256) {
     f32x4 v = red[idx];
@@ -965,18 +986,18 @@ inline size_t slab_floats_for(int B, int E) {
   return (size_t)p.splits * p.npairs * kTile * kTile;
 }
 
-template <int PWMAX>
+template <int PWMAX, bool FULL = false>
 void launch_gram16(const Gram16Plan& p, const float* emb, int64_t ld, int B, int E, int vec_ok,
                    float* slabs, hipStream_t st) {
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16_kernel<PWMAX>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16_kernel<PWMAX, FULL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024);
   });
   size_t lds = (size_t)16 * p.T * (p.kchunk + 4) * sizeof(float);
   const size_t red = p.KS > 1 ? (size_t)p.KS * p.P * 64 * sizeof(f32x4) : 0;
   if (red > lds) lds = red;
-  SCL_LAUNCH("gram16_kernel", gram16_kernel<PWMAX>, dim3(p.S), dim3(256), lds, st, emb, ld, B, E,
+  SCL_LAUNCH("gram16_kernel", (gram16_kernel<PWMAX, FULL>), dim3(p.S), dim3(256), lds, st, emb, ld, B, E,
              p.T, p.P, p.kchunk, p.KS, vec_ok, slabs);
 }
 
@@ -1016,8 +1037,14 @@ extern "C" int scl_gram_loss_fwd(const float* emb, int64_t ld_emb, int B, int E,
   lp.eps = eps;
   if (B <= kFastB) {
     const Gram16Plan p = make_plan16(B, E);
-    const int pw = (p.P + (4 / p.KS) - 1) / (4 / p.KS);
-    if (pw <= 3)
+    const int ps = 4 / p.KS;
+    const int pw = (p.P + ps - 1) / ps;
+    const bool full = p.P % ps == 0;
+    if (pw == 1 && full)
+      launch_gram16<1, true>(p, emb, ld_emb, B, E, vec_ok, w.slabs, st);
+    else if (pw == 3 && full)
+      launch_gram16<3, true>(p, emb, ld_emb, B, E, vec_ok, w.slabs, st);
+    else if (pw <= 3)
       launch_gram16<3>(p, emb, ld_emb, B, E, vec_ok, w.slabs, st);
     else if (pw <= 5)
       launch_gram16<5>(p, emb, ld_emb, B, E, vec_ok, w.slabs, st);
