@@ -388,23 +388,12 @@ __global__ __launch_bounds__(256, 2) void rowtile16_kernel(RowTileArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------
-// rowtile16b_kernel: the same tile for a bf16 feature map on the bf16 matrix cores
-// (v_mfma_f32_16x16x32_bf16).  x is bf16 already; the float32 operand (W^T, or dU^T of the
-// image) arrives split into three bf16 planes o = o1 + o2 + o3 (24 mantissa bits), so every
-// product x * o_p is exact in float32 and x.o = x.o1 + x.o2 + x.o3 differs from the float32
-// contraction only by accumulation order — at 3 x 16 cycles per 16x16x32 step instead of
-// 8 x 32 cycles of 16x16x4 float32 steps, and with no bf16 -> f32 conversion of x at all.
-//   * planes [3][64][512] bf16 (per image for DASSIGN), staged in eight 64-channel chunks,
-//     double-buffered: LDS chunk image [3][64 rows][36 dwords] (32 data + 4 pad: the 16 lanes
-//     of a ds_read_b128 group hit 16 different 16-byte slots);
-//   * lane (i, g) feeds A with the 16 bytes x[n0 + i][32 s + 8 g .. +7] straight from HBM;
-//   * row norms by float32 FMAs on the same registers.
-constexpr int RB_CH = 64;                       // channels per staged chunk
-constexpr int RB_PLANE = K * RT_LD;             // dwords per plane of a chunk (64 x 36)
-constexpr int RB_CHUNK = 3 * RB_PLANE;          // 6912 dwords per buffer
-constexpr size_t kRowTileB3Lds = 2 * (size_t)RB_CHUNK * sizeof(float);   // 55,296 B
-static_assert(kRowTileB3Lds >= 4 * 16 * 68 * sizeof(float), "epilogue scratch must fit");
-
+// bf16 feature maps run on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16).  x is bf16
+// already; the float32 operand (W^T, or dU^T of the image) arrives split into three bf16 planes
+// o = o1 + o2 + o3 (24 mantissa bits), so every product x * o_p is exact in float32 and
+// x.o = x.o1 + x.o2 + x.o3 differs from the float32 contraction only by accumulation order —
+// at 3 x 16 cycles per 16x16x32 step instead of 8 x 32 cycles of 16x16x4 float32 steps, and
+// with no bf16 -> f32 conversion of x at all.  Row norms by float32 FMAs on the same registers.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -413,118 +402,168 @@ __device__ __forceinline__ f32x4 mfma16b(u32x4 a, u32x4 b, f32x4 c) {
                                                  __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// W [512][64] float32 -> planes [3][64][512] bf16 of W^T.  grid 128, block 256.
+// ---------------------------------------------------------------------------------------
+// Operand planes of the bf16x3 row-tile kernel.  The float32 operand O[k = cluster][c = channel]
+// (W^T, or dU^T of an image) is stored as the kernel's LDS images, chunk after chunk:
+//   16-byte unit ((chunk * 3 + plane) * 8 + piece) * 64 + k  =  O_plane[k][64 chunk + 8 piece .. + 7]
+// so a 64-channel chunk (3 planes x 8 pieces x 64 clusters x 16 B = 24 KB) is copied into LDS
+// by LDS-DMA exactly as it lies, and the B fragment of lane (i, g) for k-step s2 and cluster
+// tile kt sits at unit (plane * 8 + 4 s2 + g) * 64 + 16 kt + i: inside every ds_read_b128
+// service group ({0-3, 12-15, 20-27}, ... = each value of i once) the 16 lanes hit 16 different
+// 16-byte slots — conflict-free, no padding.
+constexpr int RC_UNITS = 3 * 8 * 64;                       // 16-byte units per chunk image
+constexpr int RC_IMG = RC_UNITS * 8;                       // bf16 per chunk image (24 KB)
+constexpr size_t kRowTile32bLds = 2 * (size_t)RC_IMG * sizeof(unsigned short);   // 49,152 B
+static_assert(kRowTile32bLds >= 4 * 16 * 68 * sizeof(float), "epilogue scratch must fit");
+
+// W [512][64] float32 -> chunk images of W^T.  grid 16, block 256: thread = (8-channel piece
+// c8, cluster k): eight strided reads (coalesced over k), one 16-byte store per plane.
 __global__ __launch_bounds__(256) void split_w_kernel(const float* __restrict__ w,
                                                       unsigned short* __restrict__ planes) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;  // over D*K, k fastest (coalesced read)
-  if (idx >= D * K) return;
-  unsigned short h1, h2, h3;
-  split3_bf16(w[idx], h1, h2, h3);
-  const int o = (idx % K) * D + idx / K;
-  planes[o] = h1;
-  planes[D * K + o] = h2;
-  planes[2 * D * K + o] = h3;
+  const int idx = blockIdx.x * 256 + threadIdx.x;          // over 64 pieces x 64 clusters
+  if (idx >= (D / 8) * K) return;
+  const int k = idx % K, c8 = idx / K;
+  unsigned short h[3][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) split3_bf16(w[(c8 * 8 + j) * K + k], h[0][j], h[1][j], h[2][j]);
+  const int chunk = c8 >> 3, piece = c8 & 7;
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) {
+    uint4 v;
+    v.x = (unsigned)h[pl][0] | ((unsigned)h[pl][1] << 16);
+    v.y = (unsigned)h[pl][2] | ((unsigned)h[pl][3] << 16);
+    v.z = (unsigned)h[pl][4] | ((unsigned)h[pl][5] << 16);
+    v.w = (unsigned)h[pl][6] | ((unsigned)h[pl][7] << 16);
+    reinterpret_cast<uint4*>(planes)[((chunk * 3 + pl) * 8 + piece) * 64 + k] = v;
+  }
 }
 
-// grid (ceil(ceil(N/16) / 4), B); block 256: wave w owns 16-location tile 4 * blockIdx.x + w.
+// LDS-DMA: 64 lanes x 16 bytes from per-lane global addresses into 1 KB of consecutive LDS at
+// the wave-uniform byte address lds_byte.  Inline asm, so hipcc does not order it against LDS
+// reads of the other buffer; the kernel waits for it itself (s_waitcnt vmcnt).
+__device__ __forceinline__ void nv_glds16(const unsigned short* src, unsigned lds_byte) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(src), "s"(lds_byte)
+      : "memory");
+}
+__device__ __forceinline__ unsigned nv_lds_byte_of(const void* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+
+// rowtile32b_kernel: [32 locations] x [512 channels] x [64 clusters] per wave = two 16-row
+// MFMA tiles that share every B fragment read (24 ds_read_b128 per 48 MFMAs: the LDS read time
+// is half the matrix time; with one tile per wave they were equal and the kernel LDS-bound).
+// grid (ceil(ceil(N / 32) / 4), B); block 256.  Per 64-channel chunk: the operand image arrives
+// by LDS-DMA (6 instructions per wave, no staging registers, no ds_write pass) into the buffer
+// the previous chunk freed, x fragments (16 bytes per lane, MFMA A operands as they are) one
+// chunk ahead in registers; one barrier per chunk.
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void rowtile16b_kernel(RowTileArgs p) {
-  extern __shared__ __attribute__((aligned(16))) float bt_lds[];  // [2][3][64][RT_LD] dwords
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+__global__ __launch_bounds__(256, 2) void rowtile32b_kernel(RowTileArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float bt_lds[];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, g = lane >> 4;
   const int b = blockIdx.y;
-  const int n0 = (blockIdx.x * 4 + wid) * 16;
+  const int n0 = (blockIdx.x * 4 + wid) * 32;
   const bool active = n0 < p.N;          // wave-uniform; idle waves still stage and sync
-  const int n = n0 + i;
-  const bool row_ok = n < p.N;
   const unsigned short* src = p.btp + (int64_t)b * p.btp_stride;
-  const unsigned short* xrow = reinterpret_cast<const unsigned short*>(p.x) +
-                               ((int64_t)b * p.N + (row_ok ? n : 0)) * D + 8 * g;
-
-  // operand staging: 3 planes x 64 rows x 8 sixteen-byte pieces per chunk, 6 per thread
-  u32x4 st[6];
-  auto stage_load = [&](int chunk) {
+  const unsigned lds0 = nv_lds_byte_of(bt_lds);
+  bool row_ok[2];
+  const unsigned short* xrow[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int n = n0 + 16 * t + i;
+    row_ok[t] = n < p.N;
+    xrow[t] = reinterpret_cast<const unsigned short*>(p.x) +
+              ((int64_t)b * p.N + (row_ok[t] ? n : p.N - 1)) * D + 8 * g;
+  }
+  auto stage = [&](int chunk, int buf) {
 #pragma unroll
     for (int v = 0; v < 6; ++v) {
-      const int idx = v * 256 + threadIdx.x;
-      const int plane = idx >> 9, row = (idx >> 3) & 63, c = idx & 7;
-      st[v] = *reinterpret_cast<const u32x4*>(src + (int64_t)plane * D * K + row * D +
-                                              chunk * RB_CH + c * 8);
+      const int piece = v * 4 + wid;                       // 24 one-KB pieces per image
+      nv_glds16(src + (int64_t)chunk * RC_IMG + piece * 512 + lane * 8,
+                lds0 + buf * (RC_IMG * 2) + piece * 1024);
     }
   };
-  auto stage_store = [&](int buf) {
-#pragma unroll
-    for (int v = 0; v < 6; ++v) {
-      const int idx = v * 256 + threadIdx.x;
-      const int plane = idx >> 9, row = (idx >> 3) & 63, c = idx & 7;
-      *reinterpret_cast<u32x4*>(&bt_lds[buf * RB_CHUNK + plane * RB_PLANE + row * RT_LD + 4 * c]) =
-          st[v];
-    }
-  };
-  u32x4 xc[2], xn[2];
+  u32x4 xc[4], xn[4];                                      // [2 t + s2]
   auto x_load = [&](int chunk, u32x4* dst) {
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
-      dst[s2] = *reinterpret_cast<const u32x4*>(xrow + chunk * RB_CH + 32 * s2);
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+        dst[2 * t + s2] = *reinterpret_cast<const u32x4*>(xrow[t] + chunk * 64 + 32 * s2);
   };
 
-  f32x4 acc[4];
+  f32x4 acc[2][4];
 #pragma unroll
-  for (int kt = 0; kt < 4; ++kt) acc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float ss = 0.f;
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) acc[t][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float ss[2] = {0.f, 0.f};
 
-  stage_load(0);
   if (active) x_load(0, xc);
-  stage_store(0);
-  __syncthreads();
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
 #pragma unroll 1
-  for (int c = 0; c < D / RB_CH; ++c) {
-    const bool more = c + 1 < D / RB_CH;
+  for (int c = 0; c < D / 64; ++c) {
+    const bool more = c + 1 < D / 64;
     if (more) {
-      stage_load(c + 1);
       if (active) x_load(c + 1, xn);
+      stage(c + 1, (c + 1) & 1);
     }
     if (active) {
-      const float* wb = &bt_lds[(c & 1) * RB_CHUNK + i * RT_LD + 4 * g];
-      // fragments of the next (k-step, cluster tile) are in flight under this one's MFMAs
+      // B fragment of (plane, k-step s2, cluster tile kt): unit (plane*8 + 4 s2 + g)*64 + 16 kt + i
+      const char* wb = reinterpret_cast<const char*>(bt_lds) + (c & 1) * (RC_IMG * 2) +
+                       (g * 64 + i) * 16;
       u32x4 wv[2][3];
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) wv[0][pl] = *reinterpret_cast<const u32x4*>(wb + pl * RB_PLANE);
+      for (int pl = 0; pl < 3; ++pl)
+        wv[0][pl] = *reinterpret_cast<const u32x4*>(wb + pl * 8 * 64 * 16);
 #pragma unroll
       for (int q = 0; q < 8; ++q) {            // q = 4 * k-step + cluster tile
         const int s2 = q >> 2, kt = q & 3;
-        u32x4 xa = xc[s2];
-        if (!row_ok) xa = u32x4{0u, 0u, 0u, 0u};
         if (q + 1 < 8) {
           const int s3 = (q + 1) >> 2, kt3 = (q + 1) & 3;
 #pragma unroll
           for (int pl = 0; pl < 3; ++pl)
             wv[(q + 1) & 1][pl] = *reinterpret_cast<const u32x4*>(
-                wb + pl * RB_PLANE + kt3 * 16 * RT_LD + 16 * s3);
+                wb + ((pl * 8 + 4 * s3) * 64 + 16 * kt3) * 16);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) acc[kt] = mfma16b(xa, wv[q & 1][pl], acc[kt]);
-        if (MODE == ASSIGN && kt == 0) {
+        for (int t = 0; t < 2; ++t) {
+          u32x4 xa = xc[2 * t + s2];
+          if (!row_ok[t]) xa = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            // (v_dot2c_f32_bf16 measured 2-7 % off on these sums: plain f32 FMAs instead)
-            const float lo = __uint_as_float(xa[e] << 16), hi = __uint_as_float(xa[e] & 0xffff0000u);
-            ss = fmaf(lo, lo, ss);
-            ss = fmaf(hi, hi, ss);
+          for (int pl = 0; pl < 3; ++pl) acc[t][kt] = mfma16b(xa, wv[q & 1][pl], acc[t][kt]);
+          if (MODE == ASSIGN && kt == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float lo = __uint_as_float(xa[e] << 16), hi = __uint_as_float(xa[e] & 0xffff0000u);
+              ss[t] = fmaf(lo, lo, ss[t]);
+              ss[t] = fmaf(hi, hi, ss[t]);
+            }
           }
         }
       }
     }
-    if (more) stage_store((c + 1) & 1);
-    __syncthreads();
+    // the next image has landed (and this wave's x prefetch with it); every wave is done
+    // reading the current one after the barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     if (more) {
-      xc[0] = xn[0];
-      xc[1] = xn[1];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) xc[v] = xn[v];
     }
   }
   if (!active) return;
-  rowtile_epilogue<MODE>(p, acc, ss, bt_lds, b, n0);
+  rowtile_epilogue<MODE>(p, acc[0], ss[0], bt_lds, b, n0);
+  if (n0 + 16 < p.N) rowtile_epilogue<MODE>(p, acc[1], ss[1], bt_lds, b, n0 + 16);
 }
 
 // V_part[b, half, d, k] = sum_{n in half} x[b,n,d] * (coefn[b,n,k] * rn[b,n])
@@ -959,16 +998,16 @@ __global__ __launch_bounds__(256) void bwd_du_kernel(const float* __restrict__ s
     unsigned short h[3][16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) split3_bf16(vals[i], h[0][i], h[1][i], h[2][i]);
-    unsigned short* prow = dplanes + (int64_t)b * 3 * D * K + k * D + blk * 64 + dq * 16;
+    // chunk images (see split_w_kernel): chunk = blk, pieces 2 dq and 2 dq + 1, cluster k
+    uint4* img = reinterpret_cast<uint4*>(dplanes + (int64_t)b * 3 * D * K);
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) {
       unsigned w[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i)
         w[i] = (unsigned)h[pl][2 * i] | ((unsigned)h[pl][2 * i + 1] << 16);
-      uint4* o = reinterpret_cast<uint4*>(prow + (int64_t)pl * D * K);
-      o[0] = make_uint4(w[0], w[1], w[2], w[3]);
-      o[1] = make_uint4(w[4], w[5], w[6], w[7]);
+      img[((blk * 3 + pl) * 8 + 2 * dq) * 64 + k] = make_uint4(w[0], w[1], w[2], w[3]);
+      img[((blk * 3 + pl) * 8 + 2 * dq + 1) * 64 + k] = make_uint4(w[4], w[5], w[6], w[7]);
     }
   }
   if (du2) {
@@ -1417,12 +1456,12 @@ template <int MODE>
 void launch_rowtile_b3(const RowTileArgs& a, hipStream_t st) {
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowtile16b_kernel<MODE>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRowTileB3Lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowtile32b_kernel<MODE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRowTile32bLds);
   });
-  const int tiles16 = (a.N + 15) / 16;
-  SCL_LAUNCH(MODE == ASSIGN ? "rowtile_assign" : "rowtile_dassign", (rowtile16b_kernel<MODE>),
-             dim3((tiles16 + 3) / 4, a.B), dim3(256), kRowTileB3Lds, st, a);
+  const int tiles32 = (a.N + 31) / 32;
+  SCL_LAUNCH(MODE == ASSIGN ? "rowtile_assign" : "rowtile_dassign", (rowtile32b_kernel<MODE>),
+             dim3((tiles32 + 3) / 4, a.B), dim3(256), kRowTile32bLds, st, a);
 }
 inline void launch_aggregate_b3(const char* name, const void* x, const unsigned short* cft,
                                 const float* colpart, int B, int N, int NT, float* part,
@@ -1544,8 +1583,8 @@ extern "C" int scl_netvlad_fwd(const void* x, int x_dtype, const float* assign_w
                        (const float*)assign, (const float*)rnorm, N, w.part, w.colsum);
   } else {
     if (fwd_b3) {
-      SCL_LAUNCH("split_w_kernel", split_w_kernel, dim3(D * K / 256), dim3(256), 0, st, assign_w,
-                 w.wplanes);
+      SCL_LAUNCH("split_w_kernel", split_w_kernel, dim3((D / 8) * K / 256), dim3(256), 0, st,
+                 assign_w, w.wplanes);
       a.btp = w.wplanes;
       a.btp_stride = 0;
       a.cft = w.cft;
