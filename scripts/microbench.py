@@ -94,6 +94,8 @@ def main():
     ap.add_argument('--topn-refs', type=int, default=100000)
     ap.add_argument('--topn-queries', type=int, default=10000)
     ap.add_argument('--topn-score', default='f32', help="f32, bf16x3 or both (comma list)")
+    ap.add_argument('--netvlad-variants', default='',
+                    help='comma list of scl_debug_set_variant values to time besides production')
     ap.add_argument('--loss-batches', default='24,48,96,192')
     ap.add_argument('--loss-splits', default='',
                     help='comma list of forced Gram K-split counts for B <= 256 (tuning)')
@@ -107,6 +109,13 @@ def main():
         for b in [int(v) for v in args.netvlad_batches.split(',')]:
             res['netvlad_bf16_b%d_n1200' % b] = run_netvlad(dev, b, 1200, torch.bfloat16, args.iters)
             res['netvlad_f32_b%d_n1200' % b] = run_netvlad(dev, b, 1200, torch.float32, args.iters)
+            for var in [int(v) for v in args.netvlad_variants.split(',') if v]:
+                _lib.load().scl_debug_set_variant(var)
+                try:
+                    res['netvlad_bf16_b%d_variant_%d' % (b, var)] = run_netvlad(
+                        dev, b, 1200, torch.bfloat16, args.iters)
+                finally:
+                    _lib.load().scl_debug_set_variant(0)
     if 'loss' in what:
         lb = [int(v) for v in args.loss_batches.split(',')]
         res['wms_loss_sweep'] = sum((run_loss(dev, b, args.iters) for b in lb), [])

@@ -60,12 +60,9 @@ struct RowTileArgs {
   const void* x;       // [B,N,512]
   const float* bt;     // ASSIGN: Wt [64][512];  DASSIGN: dUt [B][64][512]
   int64_t bt_stride;   // floats between images (0 for ASSIGN)
-  const unsigned short* btp;   // bf16 input: the same operand as three bf16 planes [3][64][512]
+  const unsigned short* btp;   // bf16 input: the same operand as bf16x3 chunk images (split_w_kernel)
   int64_t btp_stride;          // elements between images (0 for ASSIGN)
-  // bf16 input: operands for aggregate16b_kernel, written by the epilogue (NULL: not wanted)
-  unsigned short* cft;         // [B][NT][3][64][16] bf16 planes of (a or ds) * rn, n fastest
-  float* colpart;              // ASSIGN: [B][NT][64] per-tile sums of a over valid rows
-  int NT;                      // ceil(N / 16)
+  int dbg;                     // timing ablations (scl_debug_set_variant 21 / 22), 0 = production
   int B, N, pre_l2;
   // ASSIGN outputs
   float* assign;       // [B,N,64]
@@ -165,36 +162,15 @@ __device__ __forceinline__ void rowtile_epilogue(const RowTileArgs& p, f32x4 (&a
     __builtin_amdgcn_wave_barrier();
   };
 
-  // (a or ds) * rn of this tile as three bf16 planes [plane][cluster][16 n]: lane (i, g) owns
-  // rows 4g .. 4g+3 of cluster 16 kt + i -> one 8-byte store, 512 contiguous bytes per wave
-  auto put_cft = [&](const float (&v)[4][4], const float (&rrow)[4]) {
-    unsigned short* base = p.cft + ((int64_t)b * p.NT + (n0 >> 4)) * 3 * K * 16;
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      unsigned short h[3][4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float cf = n0 + 4 * g + j < p.N ? v[j][kt] * rrow[j] : 0.f;
-        split3_bf16(cf, h[0][j], h[1][j], h[2][j]);
-      }
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
-        *reinterpret_cast<uint2*>(base + (pl * K + 16 * kt + i) * 16 + 4 * g) =
-            make_uint2((unsigned)h[pl][0] | ((unsigned)h[pl][1] << 16),
-                       (unsigned)h[pl][2] | ((unsigned)h[pl][3] << 16));
-    }
-  };
-
   if (MODE == ASSIGN) {
     ss += __shfl_xor(ss, 16, 64);
     ss += __shfl_xor(ss, 32, 64);
     const float rn = p.pre_l2 ? 1.0f / sqrtf(fmaxf(ss, 1e-12f)) : 1.0f;
     if (g == 0 && row_ok) p.rnorm[(int64_t)b * p.N + n] = rn;
-    float av[4][4], sv[4][4], rrow[4];
+    float av[4][4], sv[4][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float rnr = __shfl(rn, 4 * g + j, 64);
-      rrow[j] = rnr;
       float m = -INFINITY;
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
@@ -212,18 +188,6 @@ __device__ __forceinline__ void rowtile_epilogue(const RowTileArgs& p, f32x4 (&a
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) av[j][kt] *= inv;
     }
-    if (p.cft) {
-      put_cft(av, rrow);
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt) {
-        float cs = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) cs += n0 + 4 * g + j < p.N ? av[j][kt] : 0.f;
-        cs += __shfl_xor(cs, 16, 64);
-        cs += __shfl_xor(cs, 32, 64);
-        if (g == 0) p.colpart[((int64_t)b * p.NT + (n0 >> 4)) * K + 16 * kt + i] = cs;
-      }
-    }
     put_acc_layout(av);
     store_rows(p.assign);
     if (p.logit) {
@@ -234,7 +198,7 @@ __device__ __forceinline__ void rowtile_epilogue(const RowTileArgs& p, f32x4 (&a
     float cd[4];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) cd[kt] = p.cdu[b * K + 16 * kt + i];
-    float a[4][4], lg[4][4], ds[4][4], rrow[4];
+    float a[4][4], lg[4][4], ds[4][4];
     load_rows(p.a_in);
     get_acc_layout(a);
     load_rows(p.logit_in);
@@ -245,7 +209,6 @@ __device__ __forceinline__ void rowtile_epilogue(const RowTileArgs& p, f32x4 (&a
       const bool ok = n0 + row < p.N;
       const int64_t gr = (int64_t)b * p.N + (ok ? n0 + row : 0);
       const float rnr = p.rn_in[gr];
-      rrow[j] = rnr;
       float t[4];
       float dot = 0.f;
 #pragma unroll
@@ -264,7 +227,6 @@ __device__ __forceinline__ void rowtile_epilogue(const RowTileArgs& p, f32x4 (&a
       rd = q16_sum(rd);
       if (ok && i == 0) p.rowdot[gr] = rd;
     }
-    if (p.cft) put_cft(ds, rrow);
     put_acc_layout(ds);
     store_rows(p.ds);
   }
@@ -413,8 +375,6 @@ __device__ __forceinline__ f32x4 mfma16b(u32x4 a, u32x4 b, f32x4 c) {
 // 16-byte slots — conflict-free, no padding.
 constexpr int RC_UNITS = 3 * 8 * 64;                       // 16-byte units per chunk image
 constexpr int RC_IMG = RC_UNITS * 8;                       // bf16 per chunk image (24 KB)
-constexpr size_t kRowTile32bLds = 2 * (size_t)RC_IMG * sizeof(unsigned short);   // 49,152 B
-static_assert(kRowTile32bLds >= 4 * 16 * 68 * sizeof(float), "epilogue scratch must fit");
 
 // W [512][64] float32 -> chunk images of W^T.  grid 16, block 256: thread = (8-channel piece
 // c8, cluster k): eight strided reads (coalesced over k), one 16-byte store per plane.
@@ -454,48 +414,59 @@ __device__ __forceinline__ unsigned nv_lds_byte_of(const void* p) {
   return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
 }
 
-// rowtile32b_kernel: [32 locations] x [512 channels] x [64 clusters] per wave = two 16-row
-// MFMA tiles that share every B fragment read (24 ds_read_b128 per 48 MFMAs: the LDS read time
-// is half the matrix time; with one tile per wave they were equal and the kernel LDS-bound).
-// grid (ceil(ceil(N / 32) / 4), B); block 256.  Per 64-channel chunk: the operand image arrives
-// by LDS-DMA (6 instructions per wave, no staging registers, no ds_write pass) into the buffer
-// the previous chunk freed, x fragments (16 bytes per lane, MFMA A operands as they are) one
-// chunk ahead in registers; one barrier per chunk.
+// rowtile_ring_kernel: [128 locations] x [512 channels] x [64 clusters] per workgroup; a wave
+// owns 32 locations = two 16-row MFMA tiles that share every B fragment read.
+//
+// The kernel is bound by memory latency, not by matrix or LDS time (a compute step of 48 MFMAs
+// is 0.3 us, a loaded HBM round trip 1-2 us), so EVERYTHING it reads arrives by LDS-DMA
+// through one 3-stage ring, two 64-channel stages (80 KB per CU) ahead of the matrix work:
+//   stage = operand chunk image (24 KB, see split_w_kernel) + the workgroup's x slice
+//           [128 locations][64 channels] bf16 (16 KB);
+//   x rows are 128 bytes; 16-byte piece q of row r is stored at position q ^ ((r >> 1) & 7)
+//   (the DMA fetches piece j ^ ((r >> 1) & 7) into position j: the swizzle sits on the source
+//   address, the LDS destination is lane-linear) so the 16 lanes of every ds_read_b128 service
+//   group of an A fragment hit 16 different slots;
+//   one queue, counted waits: s_waitcnt vmcnt(10) leaves the next stage in flight; one
+//   barrier per chunk orders landed stages against readers and frees the stage read last.
+// grid (ceil(N / 128), B); block 256; dynamic LDS 3 x 40 KB (the epilogue scratch reuses it).
+constexpr int RG_STAGE = RC_IMG * 2 + 128 * 128;           // bytes per ring stage (40,960)
+constexpr int RG_NST = 3;
+constexpr size_t kRowTileRingLds = (size_t)RG_NST * RG_STAGE;
+static_assert(kRowTileRingLds >= 4 * 16 * 68 * sizeof(float), "epilogue scratch must fit");
+
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void rowtile32b_kernel(RowTileArgs p) {
+__global__ __launch_bounds__(256, 1) void rowtile_ring_kernel(RowTileArgs p) {
   extern __shared__ __attribute__((aligned(16))) float bt_lds[];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, g = lane >> 4;
   const int b = blockIdx.y;
-  const int n0 = (blockIdx.x * 4 + wid) * 32;
+  const int n0 = blockIdx.x * 128 + wid * 32;
   const bool active = n0 < p.N;          // wave-uniform; idle waves still stage and sync
   const unsigned short* src = p.btp + (int64_t)b * p.btp_stride;
+  const unsigned short* xb = reinterpret_cast<const unsigned short*>(p.x) + (int64_t)b * p.N * D;
   const unsigned lds0 = nv_lds_byte_of(bt_lds);
-  bool row_ok[2];
-  const unsigned short* xrow[2];
+  const bool row_ok[2] = {n0 + i < p.N, n0 + 16 + i < p.N};
+
+  // x DMA of this lane: instruction v covers the wave's rows 8 v .. 8 v + 7, lane = (r, j)
+  const unsigned short* xsrc[4];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int n = n0 + 16 * t + i;
-    row_ok[t] = n < p.N;
-    xrow[t] = reinterpret_cast<const unsigned short*>(p.x) +
-              ((int64_t)b * p.N + (row_ok[t] ? n : p.N - 1)) * D + 8 * g;
+  for (int v = 0; v < 4; ++v) {
+    const int row = 8 * v + (lane >> 3), j = lane & 7;
+    int n = n0 + row;
+    n = n < p.N ? n : p.N - 1;                             // rows past the end re-read the last
+    xsrc[v] = xb + (int64_t)n * D + ((j ^ ((row >> 1) & 7)) << 3);
   }
-  auto stage = [&](int chunk, int buf) {
+  auto stage = [&](int chunk) {
+    const unsigned base = lds0 + (chunk % RG_NST) * RG_STAGE;
 #pragma unroll
     for (int v = 0; v < 6; ++v) {
-      const int piece = v * 4 + wid;                       // 24 one-KB pieces per image
-      nv_glds16(src + (int64_t)chunk * RC_IMG + piece * 512 + lane * 8,
-                lds0 + buf * (RC_IMG * 2) + piece * 1024);
+      const int piece = v * 4 + wid;                       // 24 one-KB pieces per operand image
+      nv_glds16(src + (int64_t)chunk * RC_IMG + piece * 512 + lane * 8, base + piece * 1024);
     }
-  };
-  u32x4 xc[4], xn[4];                                      // [2 t + s2]
-  auto x_load = [&](int chunk, u32x4* dst) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-        dst[2 * t + s2] = *reinterpret_cast<const u32x4*>(xrow[t] + chunk * 64 + 32 * s2);
+    for (int v = 0; v < 4; ++v)
+      nv_glds16(xsrc[v] + chunk * 64, base + RC_IMG * 2 + (wid * 32 + 8 * v) * 128);
   };
 
   f32x4 acc[2][4];
@@ -505,21 +476,34 @@ __global__ __launch_bounds__(256, 2) void rowtile32b_kernel(RowTileArgs p) {
     for (int kt = 0; kt < 4; ++kt) acc[t][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
   float ss[2] = {0.f, 0.f};
 
-  if (active) x_load(0, xc);
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
+  const int nchunks = p.dbg == 22 ? 0 : D / 64;          // 22: epilogue only
+  if (nchunks) {
+    stage(0);
+    stage(1);
+  }
 #pragma unroll 1
-  for (int c = 0; c < D / 64; ++c) {
-    const bool more = c + 1 < D / 64;
-    if (more) {
-      if (active) x_load(c + 1, xn);
-      stage(c + 1, (c + 1) & 1);
-    }
+  for (int c = 0; c < nchunks; ++c) {
+    if (c + 1 < D / 64)
+      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");    // stage c landed, c + 1 in flight
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (c + 2 < D / 64) stage(c + 2);
     if (active) {
+      const char* sb = reinterpret_cast<const char*>(bt_lds) + (c % RG_NST) * RG_STAGE;
       // B fragment of (plane, k-step s2, cluster tile kt): unit (plane*8 + 4 s2 + g)*64 + 16 kt + i
-      const char* wb = reinterpret_cast<const char*>(bt_lds) + (c & 1) * (RC_IMG * 2) +
-                       (g * 64 + i) * 16;
+      const char* wb = sb + (g * 64 + i) * 16;
+      // A fragment of (tile t, k-step s2): row 16 t + i of the wave, piece 4 s2 + g, swizzled
+      const char* xa_base = sb + RC_IMG * 2 + (wid * 32 + i) * 128;
+      const int sw = (i >> 1) & 7;
+      u32x4 xa[2][2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          xa[t][s2] = *reinterpret_cast<const u32x4*>(xa_base + t * 16 * 128 + (((4 * s2 + g) ^ sw) << 4));
+          if (!row_ok[t]) xa[t][s2] = u32x4{0u, 0u, 0u, 0u};
+        }
       u32x4 wv[2][3];
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl)
@@ -537,14 +521,14 @@ __global__ __launch_bounds__(256, 2) void rowtile32b_kernel(RowTileArgs p) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          u32x4 xa = xc[2 * t + s2];
-          if (!row_ok[t]) xa = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl) acc[t][kt] = mfma16b(xa, wv[q & 1][pl], acc[t][kt]);
+          for (int pl = 0; pl < 3; ++pl)
+            acc[t][kt] = mfma16b(xa[t][s2], wv[q & 1][pl], acc[t][kt]);
           if (MODE == ASSIGN && kt == 0) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const float lo = __uint_as_float(xa[e] << 16), hi = __uint_as_float(xa[e] & 0xffff0000u);
+              const unsigned w = xa[t][s2][e];
+              const float lo = __uint_as_float(w << 16), hi = __uint_as_float(w & 0xffff0000u);
               ss[t] = fmaf(lo, lo, ss[t]);
               ss[t] = fmaf(hi, hi, ss[t]);
             }
@@ -552,16 +536,18 @@ __global__ __launch_bounds__(256, 2) void rowtile32b_kernel(RowTileArgs p) {
         }
       }
     }
-    // the next image has landed (and this wave's x prefetch with it); every wave is done
-    // reading the current one after the barrier
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (more) {
-#pragma unroll
-      for (int v = 0; v < 4; ++v) xc[v] = xn[v];
-    }
   }
   if (!active) return;
+  if (p.dbg == 21) {                                       // 21: main loop only
+    float sacc = ss[0] + ss[1];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) sacc += acc[t][kt][0] + acc[t][kt][1] + acc[t][kt][2] + acc[t][kt][3];
+    if (sacc == 1.2345e-7f) p.rnorm[0] = sacc;
+    return;
+  }
+  // stage 0's bytes were last read in chunk 6 and every wave has passed chunk 7's barrier
   rowtile_epilogue<MODE>(p, acc[0], ss[0], bt_lds, b, n0);
   if (n0 + 16 < p.N) rowtile_epilogue<MODE>(p, acc[1], ss[1], bt_lds, b, n0 + 16);
 }
@@ -701,11 +687,14 @@ __global__ __launch_bounds__(256) void aggregate_kernel(const void* __restrict__
 // per-image normalisation state shared by finish (forward) and bwd_prep (backward)
 // ---------------------------------------------------------------------------------------
 // aggregate16b_kernel: V_part[b, split, d, k] = sum_{n in split} x[b,n,d] cf[b,n,k] for a bf16
-// feature map on v_mfma_f32_16x16x32_bf16, cf = (a or ds) * rn as the three bf16 planes the
-// row-tile epilogue wrote ([tile of 16 n][plane][cluster][n], so a B fragment — 8 consecutive
-// n of one cluster — is 16 contiguous bytes).  The contraction runs over n, the SLOW index
-// of x[n][d]: each wave stages its [32 n][64 d] piece of x row-major in LDS and reads the A
-// fragments with ds_read_b64_tr_b16 (4 rows x 16 columns delivered column-major).
+// feature map on v_mfma_f32_16x16x32_bf16, cf = (a or ds) * rn.  The float32 coefficients are
+// read as the row-tile kernel saved them ([n][64] rows) and split into three bf16 planes while
+// they are staged — thread (cluster k, location octet) takes 8 strided values (a wave reads
+// whole 256-byte rows), scales by rn, and writes one 16-byte piece per plane — so no plane
+// copy of them ever goes through HBM (it was 11 MB written and read per pass).
+// The contraction runs over n, the SLOW index of x[n][d]: each wave stages its [32 n][64 d]
+// piece of x row-major in LDS and reads the A fragments with ds_read_b64_tr_b16 (4 rows x 16
+// columns delivered column-major).
 // grid (2 channel halves, NSPLIT, B); block 256: the four waves share a 32-location step
 // (its cf planes are staged once per workgroup) and own 64 channels each, so no cross-wave
 // reduction is needed.  LDS: 2 x ([3][64][40] cf + 4 x [32][72] x) bf16 = 67,584 B.
@@ -719,8 +708,8 @@ constexpr size_t kAgg16bLds = 2 * (size_t)AB_BUF * sizeof(unsigned short);   // 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256, 2) void aggregate16b_kernel(
-    const unsigned short* __restrict__ x, const unsigned short* __restrict__ cft,
-    const float* __restrict__ colpart, int N, int NT, float* __restrict__ part,
+    const unsigned short* __restrict__ x, const float* __restrict__ coefn,
+    const float* __restrict__ rn, int N, float* __restrict__ part,
     float* __restrict__ colsum_part) {
   extern __shared__ __attribute__((aligned(16))) unsigned short ab_lds[];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -732,17 +721,19 @@ __global__ __launch_bounds__(256, 2) void aggregate16b_kernel(
   const int s_begin = split * per;
   const int s_end = s_begin + per < nsteps ? s_begin + per : nsteps;
 
-  // staging registers: 3 sixteen-byte pieces of the cf planes, 4 of the wave's x tile
-  u32x4 st_cf[3], st_x[4];
+  // staging registers: this thread's 8 coefficients (cluster `lane`, locations 8 wid .. + 7
+  // of the step) with their row norms, and 4 sixteen-byte pieces of the wave's x tile
+  float st_a[8], st_r[8];
+  u32x4 st_x[4];
+  const float* cfb_g = coefn + (int64_t)b * N * K + lane;
+  const float* rnb_g = rn + (int64_t)b * N;
   auto stage_load = [&](int s) {
 #pragma unroll
-    for (int v = 0; v < 3; ++v) {
-      const int idx = v * 256 + threadIdx.x;               // 768 pieces: [tile 2][plane 3][k 64][2]
-      const int tl = idx / 384, rem = idx % 384;           // rem = (plane * 64 + k) * 2 + h8
-      const int tile = 2 * s + tl;
-      st_cf[v] = tile < NT ? *reinterpret_cast<const u32x4*>(
-                                 cft + (((int64_t)b * NT + tile) * 3 * K * 16) + rem * 8)
-                           : u32x4{0u, 0u, 0u, 0u};
+    for (int j = 0; j < 8; ++j) {
+      int n = 32 * s + 8 * wid + j;
+      n = n < N ? n : N - 1;                               // masked when it is consumed
+      st_a[j] = cfb_g[(int64_t)n * K];
+      st_r[j] = rnb_g[n];
     }
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -752,15 +743,25 @@ __global__ __launch_bounds__(256, 2) void aggregate16b_kernel(
       st_x[v] = *reinterpret_cast<const u32x4*>(x + ((int64_t)b * N + n) * D + d0 + 8 * (idx & 7));
     }
   };
-  auto stage_store = [&](int buf) {
+  float cs_part = 0.f;                                     // column sum of a (cluster `lane`)
+  auto stage_store = [&](int buf, int s) {
     unsigned short* cfb = ab_lds + buf * AB_BUF;
+    // staged as [plane * 64 + k][32 n (+ pad)]: this thread's piece = locations 8 wid .. + 7
+    unsigned short h[3][8];
 #pragma unroll
-    for (int v = 0; v < 3; ++v) {
-      const int idx = v * 256 + threadIdx.x;
-      const int tl = idx / 384, rem = idx % 384;
-      const int row = rem >> 1, h8 = rem & 1;              // row = plane * 64 + k
-      // staged as [plane * 64 + k][32 n (+ pad)]: tile tl holds n 16 tl .. 16 tl + 15
-      *reinterpret_cast<u32x4*>(cfb + row * AB_CFLD + 16 * tl + 8 * h8) = st_cf[v];
+    for (int j = 0; j < 8; ++j) {
+      const bool ok = 32 * s + 8 * wid + j < N;
+      const float av = ok ? st_a[j] : 0.f;
+      cs_part += av;
+      split3_bf16(av * st_r[j], h[0][j], h[1][j], h[2][j]);
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      u32x4 v;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        v[c] = (unsigned)h[pl][2 * c] | ((unsigned)h[pl][2 * c + 1] << 16);
+      *reinterpret_cast<u32x4*>(cfb + (pl * K + lane) * AB_CFLD + 8 * wid) = v;
     }
     unsigned short* xb = cfb + AB_CF + wid * AB_X;
 #pragma unroll
@@ -776,19 +777,13 @@ __global__ __launch_bounds__(256, 2) void aggregate16b_kernel(
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) acc[mt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // column sums of a over this split's tiles (forward only): wave w takes tiles t0 + w + 4 j;
-  // the loads fly under the main loop, the four partials are combined in a fixed order below
-  float cs_part = 0.f;
+  // column sums of a over this split (forward only) come out of the staging: wave w has
+  // added the locations 8 w .. 8 w + 7 of every step; the four partials meet in LDS below
   const bool want_cs = colsum_part != nullptr && half == 0;
-  if (want_cs) {
-    const int t_end = 2 * s_end < NT ? 2 * s_end : NT;
-    for (int t = 2 * s_begin + wid; t < t_end; t += 4)
-      cs_part += colpart[((int64_t)b * NT + t) * K + lane];
-  }
 
   if (s_begin < s_end) {
     stage_load(s_begin);
-    stage_store(0);
+    stage_store(0, s_begin);
   }
   __syncthreads();
   for (int s = s_begin; s < s_end; ++s) {
@@ -832,7 +827,7 @@ __global__ __launch_bounds__(256, 2) void aggregate16b_kernel(
         for (int pl = 0; pl < 3; ++pl)
           acc[mt][kt] = mfma16b(af[mt], bf[kt & 1][pl], acc[mt][kt]);
     }
-    if (more) stage_store(buf ^ 1);
+    if (more) stage_store(buf ^ 1, s + 1);
     __syncthreads();
   }
 
@@ -1456,23 +1451,24 @@ template <int MODE>
 void launch_rowtile_b3(const RowTileArgs& a, hipStream_t st) {
   static std::once_flag once;
   std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowtile32b_kernel<MODE>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRowTile32bLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowtile_ring_kernel<MODE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRowTileRingLds);
   });
-  const int tiles32 = (a.N + 31) / 32;
-  SCL_LAUNCH(MODE == ASSIGN ? "rowtile_assign" : "rowtile_dassign", (rowtile32b_kernel<MODE>),
-             dim3((tiles32 + 3) / 4, a.B), dim3(256), kRowTile32bLds, st, a);
+  RowTileArgs ad = a;
+  ad.dbg = (scl_debug_variant == 21 || scl_debug_variant == 22) ? scl_debug_variant : 0;
+  SCL_LAUNCH(MODE == ASSIGN ? "rowtile_assign" : "rowtile_dassign", (rowtile_ring_kernel<MODE>),
+             dim3((a.N + 127) / 128, a.B), dim3(256), kRowTileRingLds, st, ad);
 }
-inline void launch_aggregate_b3(const char* name, const void* x, const unsigned short* cft,
-                                const float* colpart, int B, int N, int NT, float* part,
-                                float* colsum, hipStream_t st) {
+inline void launch_aggregate_b3(const char* name, const void* x, const float* coefn,
+                                const float* rn, int B, int N, float* part, float* colsum,
+                                hipStream_t st) {
   static std::once_flag once;
   std::call_once(once, [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aggregate16b_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAgg16bLds);
   });
   SCL_LAUNCH(name, aggregate16b_kernel, dim3(2, NSPLIT, B), dim3(256), kAgg16bLds, st,
-             (const unsigned short*)x, cft, colpart, N, NT, part, colsum);
+             (const unsigned short*)x, coefn, rn, N, part, colsum);
 }
 inline bool use_b3() { return scl_debug_variant < 1 || scl_debug_variant > 8; }
 
@@ -1489,9 +1485,7 @@ struct Carver {
 
 struct FwdWs {
   float *wt, *part, *colsum, *colsq, *vlad, *assign, *rnorm;
-  unsigned short* wplanes;   // [3][64][512] bf16
-  unsigned short* cft;       // [B][NT][3][64][16] bf16
-  float* colpart;            // [B][NT][64]
+  unsigned short* wplanes;   // bf16x3 chunk images of W^T (3 * 64 * 512 bf16)
   size_t total;
 };
 inline FwdWs carve_fwd(void* ws, int B, int N) {
@@ -1505,17 +1499,13 @@ inline FwdWs carve_fwd(void* ws, int B, int N) {
   w.assign = c.take((size_t)B * N * K);
   w.rnorm = c.take((size_t)B * N);
   w.wplanes = (unsigned short*)c.take((size_t)3 * D * K / 2);
-  const size_t nt = (size_t)(N + 15) / 16;
-  w.cft = (unsigned short*)c.take((size_t)B * nt * 3 * K * 16 / 2);
-  w.colpart = c.take((size_t)B * nt * K);
   w.total = c.off;
   return w;
 }
 
 struct BwdWs {
   float *du, *dut, *cdu, *ds, *rowdot, *wpart, *dots;
-  unsigned short* dplanes;   // [B][3][64][512] bf16
-  unsigned short* cft;       // [B][NT][3][64][16] bf16 (ds * rn)
+  unsigned short* dplanes;   // [B] bf16x3 chunk images of dU^T
   unsigned short* du2;       // [B][2][512][64] bf16 planes of dU
   unsigned short* w2;        // [2][512][64] bf16 planes of W
   size_t total;
@@ -1531,7 +1521,6 @@ inline BwdWs carve_bwd(void* ws, int B, int N) {
   w.wpart = c.take((size_t)B * NSPLIT * D * K);
   w.dplanes = (unsigned short*)c.take((size_t)B * 3 * D * K / 2);
   w.dots = c.take((size_t)B * 8 * 4 * K);
-  w.cft = (unsigned short*)c.take((size_t)B * ((size_t)(N + 15) / 16) * 3 * K * 16 / 2);
   w.du2 = (unsigned short*)c.take((size_t)B * 2 * D * K / 2);
   w.w2 = (unsigned short*)c.take((size_t)2 * D * K / 2);
   w.total = c.off;
@@ -1587,11 +1576,9 @@ extern "C" int scl_netvlad_fwd(const void* x, int x_dtype, const float* assign_w
                  assign_w, w.wplanes);
       a.btp = w.wplanes;
       a.btp_stride = 0;
-      a.cft = w.cft;
-      a.colpart = w.colpart;
-      a.NT = (N + 15) / 16;
       launch_rowtile_b3<ASSIGN>(a, st);
-      launch_aggregate_b3("aggregate_kernel", x, w.cft, w.colpart, B, N, a.NT, w.part, w.colsum, st);
+      launch_aggregate_b3("aggregate_kernel", x, (const float*)assign, (const float*)rnorm, B, N,
+                          w.part, w.colsum, st);
     } else {
       launch_rowtile<unsigned short, ASSIGN>(a, st);
       SCL_LAUNCH("aggregate_kernel", aggregate_kernel<unsigned short>, dim3(D / 64, NSPLIT, B), dim3(256), 0, st,
@@ -1660,10 +1647,9 @@ extern "C" int scl_netvlad_bwd(const void* x, int x_dtype, const float* assign_w
     if (b3) {
       a.btp = w.dplanes;
       a.btp_stride = (int64_t)3 * D * K;
-      a.cft = w.cft;
-      a.NT = (N + 15) / 16;
       launch_rowtile_b3<DASSIGN>(a, st);
-      launch_aggregate_b3("aggregate_dw", x, w.cft, nullptr, B, N, a.NT, w.wpart, nullptr, st);
+      launch_aggregate_b3("aggregate_dw", x, (const float*)w.ds, save_rnorm, B, N, w.wpart,
+                          nullptr, st);
     } else {
       launch_rowtile<unsigned short, DASSIGN>(a, st);
       SCL_LAUNCH("aggregate_dw", aggregate_kernel<unsigned short>, dim3(D / 64, NSPLIT, B), dim3(256), 0, st,
