@@ -64,6 +64,11 @@ def parse():
     ap.add_argument('--fused-relu', type=int, default=1,
                     help='1: fused HIP bias/ReLU/pool glue around the MIOpen convs (csrc/vgg_glue.hip)')
     ap.add_argument('--cpu-images', type=int, default=2, help='images in the CPU-baseline sample')
+    ap.add_argument('--graph', type=int, default=0,
+                    help='1: capture one train step (forward, backward, Adam) in a HIP graph after '
+                         'the warm-up and replay it for the timed steps; 0 (default): eager. '
+                         'Measured on MI355X: 14.234 ms per step either way — the host runs ahead '
+                         'of the device, the step is not launch-bound')
     ap.add_argument('--stub-cpu', action='store_true',
                     help='TEST ONLY: gloo on CPU with a trivial stand-in step; exercises the '
                          'launcher, the barriers and the max-over-ranks timing, measures nothing')
@@ -255,6 +260,93 @@ def stub_main(args, world, rank):
         dist.destroy_process_group()
 
 
+def cpu_baseline_kernels(threads):
+    """BASELINE.md §3 / SURVEY §8d: the CPU restatement of the individual hot-path pieces on the
+    host cores, each on a bounded sample — NetVLAD fused and in the reference graph's
+    [N,D,K]-materialising form, the wms loss forward (float32 oracle) and forward+backward
+    (autograd twin) at B = 24 and 192, and the reference's own KDTree query."""
+    from oracle import losses_np as O
+    from oracle import netvlad_np as NV
+    from oracle import topn_np as TN
+    from oracle import twin_torch as TT
+    from tests import util_data as U
+
+    def timeit(fn, budget=3.0, max_reps=20):
+        fn()
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            fn()
+            reps += 1
+            dt = time.perf_counter() - t0
+            if dt > budget or reps >= max_reps:
+                return dt / reps, reps
+
+    out = {'cores': threads, 'kind': 'port'}
+    w, c = U.vlad_params()
+    x4 = U.feature_map(4, 1200, seed=5)
+    t, r = timeit(lambda: NV.netvlad_fused(x4, w, c))
+    out['netvlad_fwd_fused'] = dict(value=round(4 / t, 2), unit='images/sec',
+                                    sample='%d x 4 images x 1200 locations, NumPy two-matmul form' % r)
+    x1 = x4[:1]
+    t, r = timeit(lambda: NV.netvlad_literal(x1, w, c), budget=4.0, max_reps=5)
+    out['netvlad_fwd_tf_style'] = dict(value=round(1 / t, 2), unit='images/sec',
+                                       sample='%d x 1 image: materialises [1200,512,64] like the '
+                                              'reference graph (157 MB per image)' % r)
+
+    def twin_step():
+        xt = torch.tensor(x4[:2], requires_grad=True)
+        TT.netvlad(xt, torch.tensor(w, requires_grad=True), torch.tensor(c, requires_grad=True),
+                   dtype=torch.float32).sum().backward()
+    t, r = timeit(twin_step)
+    out['netvlad_fwd_bwd_twin'] = dict(value=round(2 / t, 2), unit='images/sec',
+                                       sample='%d x 2 images, torch-CPU float32 autograd twin' % r)
+    for bsz in (24, 192):
+        emb = U.embeddings(bsz, E)
+        dm = U.positions_distances(bsz)[None]
+        t, r = timeit(lambda: O.wms_loss(dm, emb, 0.8, 15.0), budget=2.0)
+        out['wms_fwd_b%d' % bsz] = dict(value=round(t * 1e6, 1), unit='us',
+                                        sample='%d calls, float32 NumPy oracle' % r)
+
+        def fb():
+            e = torch.tensor(emb, requires_grad=True)
+            TT.wms_loss(dm, e, 0.8, 15.0, dtype=torch.float32).backward()
+        t, r = timeit(fb, budget=2.0)
+        out['wms_fwd_bwd_b%d' % bsz] = dict(value=round(t * 1e6, 1), unit='us',
+                                            sample='%d calls, torch-CPU float32 autograd twin' % r)
+    ref, qry = U.retrieval_sets(100000, 64, 256)
+    t0 = time.perf_counter()
+    TN.topn_kdtree(ref, qry, 25)
+    dt = time.perf_counter() - t0
+    out['kdtree_100k_refs'] = dict(value=round(64 / dt, 2), unit='queries/sec',
+                                   sample='KDTree(100000 x 256).query(64 queries, k=25) incl. the '
+                                          'build (evaluation/top-n.py:103-106), scikit-learn')
+    return out
+
+
+def loss_b192_line(dev, iters=10):
+    """configs[3]'s loss shape on one GPU: wms forward + backward at B = 192 x 32768 (what every
+    rank of an 8-GPU run evaluates after the all-gather), event-timed per kernel."""
+    from soft_contrastive_learning_amd import _lib
+    from soft_contrastive_learning_amd.model import losses
+    from tests import util_data as U
+    bsz = 192
+    emb = torch.tensor(U.embeddings(bsz, E), device=dev, requires_grad=True)
+    dm = torch.tensor(U.positions_distances(bsz)[None], device=dev)
+    for _ in range(3):
+        losses.wms_loss(dm, emb, 0.8, 15.0).backward()
+    torch.cuda.synchronize()
+    with _lib.KernelTimer(capacity=16 * iters) as kt:
+        for _ in range(iters):
+            losses.wms_loss(dm, emb, 0.8, 15.0).backward()
+        torch.cuda.synchronize()
+    models = kernel_models(bsz, 1200, bsz, 4)
+    rows = [price(k, cnt, ms, models[k]) for k, (cnt, ms) in sorted(kt.summary().items())
+            if k in models]
+    return {'B': bsz, 'E': E, 'kernels': rows,
+            'us_forward_backward': round(sum(r['us'] for r in rows), 1),
+            'note': 'HIP events add ~3 us to each kernel; rocprofv3 trace under profiles/'}
+
+
 def main():
     args = parse()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -284,7 +376,8 @@ def main():
     model = nets.VGG16NetVLAD(compute_dtype=cdt, seed=1234, fused_relu=bool(args.fused_relu)).to(dev)
     params = list(model.parameters())
     buckets = parallel.GradBuckets(params)
-    opt = torch.optim.Adam(params, lr=5e-6, fused=True)     # train/train.py:1270 base_lr; one kernel
+    # train/train.py:1270 base_lr; one fused kernel, step counter on the device (graph-safe)
+    opt = torch.optim.Adam(params, lr=5e-6, fused=True, capturable=bool(args.graph))
 
     # synthetic RobotCar-shaped batch, resident in HBM
     g = torch.Generator().manual_seed(42 + rank)
@@ -318,6 +411,35 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    # One step captured in a HIP graph and replayed: the step is ~125 dependent launches, and
+    # the launch gaps between them cost ~0.3 ms of a 14 ms step when issued one by one.  The
+    # captured work is exactly step(): nothing is skipped, cached or reused between replays
+    # except the allocations.  Falls back to eager launches if the capture is refused.
+    graph = None
+    run = step
+    if args.graph and world == 1 and os.environ.get('SCL_BENCH_EVENTS_IN_TIMED_REGION') != '1':
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step()                                   # allocator warm-up on the side stream
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_loss = step()
+            graph.replay()
+            torch.cuda.synchronize()
+
+            def run():
+                graph.replay()
+                return static_loss
+        except Exception as exc:                         # noqa: BLE001 (report, then go eager)
+            sys.stderr.write('bench.py: HIP graph capture failed (%s: %s); eager launches\n'
+                             % (type(exc).__name__, exc))
+            graph = None
+            run = step
+            torch.cuda.synchronize()
     # The K timed steps run uninstrumented: bracketing every kernel launch with two HIP events
     # costs about 6 % of a step (measured: 15.05 vs 14.24 ms), which is instrumentation, not
     # the path.  Per-kernel durations for `roofline` / `kernels` come from PROF extra steps of
@@ -330,11 +452,15 @@ def main():
         nets.WORK_LOG = {}
     with (_lib.KernelTimer(capacity=256 * max(args.steps, 1)) if in_region
           else contextlib.nullcontext()) as kt:
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            loss = step()
+        evs[0].record()
+        for k in range(args.steps):
+            loss = run()
+            evs[k + 1].record()
         fence()
         elapsed = time.perf_counter() - t0
+    per_step = sorted(evs[k].elapsed_time(evs[k + 1]) for k in range(args.steps))
     if not in_region:
         nets.WORK_LOG = {}    # algorithmic flops / bytes of the backbone kernels, per call site
         with _lib.KernelTimer(capacity=256 * prof_steps) as kt:
@@ -407,6 +533,13 @@ def main():
             'steps': args.steps,
             'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+            'ms_per_step_stats': {'median': round(per_step[len(per_step) // 2], 3),
+                                  'p10': round(per_step[int(0.1 * (len(per_step) - 1))], 3),
+                                  'p90': round(per_step[int(0.9 * (len(per_step) - 1) + 0.5)], 3),
+                                  'min': round(per_step[0], 3), 'max': round(per_step[-1], 3),
+                                  'how': 'device events at the step boundaries of the timed '
+                                         'region (no host synchronisation inside it)'},
+            'hip_graph': graph is not None,
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
@@ -421,16 +554,19 @@ def main():
                                         '(scl_prof sink), on the launch stream',
                               'steps': prof_steps,
                               'where': 'timed region' if in_region else
-                              'extra steps right after the timed region (the events cost ~6 % of '
-                              'a step, so the timed steps run without them)',
+                              'extra eager steps right after the timed region (the events cost '
+                              '~6 % of a step, so the timed steps run without them)',
                               'ms_per_step_with_events': round(elapsed_prof / prof_steps * 1e3, 3)},
             'roofline': roofline,
             'roofline_netvlad_loss': roofline_head,
             'kernels': kernels,
             'hip_path_ms_per_step': round(hip_ms, 3),
         }
+        if world == 1:
+            out['roofline_loss_b192'] = loss_b192_line(dev)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args, torch.get_num_threads())
+            out['cpu_baseline_kernels'] = cpu_baseline_kernels(torch.get_num_threads())
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

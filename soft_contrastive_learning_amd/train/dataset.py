@@ -1,0 +1,77 @@
+"""Pose-tagged image sets for the trainer: the per-epoch CSV lists of the reference
+(``<set>_<epoch:03d>.csv`` with the columns date, folder, t, easting, northing, yaw —
+util/io.py:46-83 ``load_csv``, ``get_xy`` train/train.py:1152-1153) and a synthetic stand-in
+with the same interface for machines without the RobotCar data.
+
+A set exposes what the training loop touches: ``xy`` [M,2] metres, ``yaw`` [M] radians,
+``len``, and ``load_images(indices) -> float32 [n,H,W,3]`` (0..255 RGB, the tensors
+``load_images`` hands to the GPU thread, train/train.py:423-430).
+"""
+import csv
+import os
+
+import numpy as np
+
+
+class CsvImageSet:
+    """One reference CSV + an image root (``img_path``: <root>/<date>/<folder>/<t>.png)."""
+
+    def __init__(self, csv_file, img_root, height=240, ext='.png'):
+        with open(csv_file) as f:
+            rows = list(csv.DictReader(f))
+        need = ('date', 'folder', 't', 'easting', 'northing', 'yaw')
+        if not rows or any(k not in rows[0] for k in need):
+            raise ValueError('%s must have the columns %s' % (csv_file, ', '.join(need)))
+        self.meta = {k: [r[k] for r in rows] for k in rows[0]}
+        self.xy = np.array([[float(e), float(n)] for e, n in
+                            zip(self.meta['easting'], self.meta['northing'])], dtype=float)
+        self.yaw = np.array(self.meta['yaw'], dtype=float)
+        self.img_root, self.height, self.ext = img_root, height, ext
+
+    def __len__(self):
+        return len(self.yaw)
+
+    def path(self, i):
+        return os.path.join(self.img_root, self.meta['date'][i], self.meta['folder'][i],
+                            self.meta['t'][i] + self.ext)
+
+    def load_images(self, indices):
+        from .sampler import load_images_pil
+        return load_images_pil([self.path(int(i)) for i in indices], self.height)
+
+
+class SyntheticImageSet:
+    """A closed loop driven ``laps`` times: poses every ``spacing`` metres with heading along
+    the track, one deterministic image per pose.  An image is a smooth function of the pose
+    (low-frequency pattern indexed by position + per-image noise), so nearby poses look alike
+    and the descriptors carry place information — enough for mining and the localisation
+    evaluation to have something to find."""
+
+    def __init__(self, num, height=64, width=80, spacing=2.0, laps=2, seed=0):
+        self.h, self.w, self.seed = height, width, seed
+        per_lap = max(num // laps, 1)
+        s = (np.arange(num) % per_lap) * spacing                 # arc length along the loop
+        length = per_lap * spacing
+        ang = 2.0 * np.pi * s / length
+        radius = length / (2.0 * np.pi)
+        rng = np.random.default_rng(seed)
+        jitter = rng.normal(0.0, 0.3, size=(num, 2))             # laps do not coincide exactly
+        self.xy = np.stack([radius * np.cos(ang), radius * np.sin(ang)], 1) + jitter
+        self.yaw = (ang + np.pi / 2.0) % (2.0 * np.pi)
+        self._s = s
+        yy, xx = np.mgrid[0:height, 0:width]
+        self._grid = (yy / float(height), xx / float(width))
+
+    def __len__(self):
+        return len(self.yaw)
+
+    def load_images(self, indices):
+        yy, xx = self._grid
+        out = np.empty((len(indices), self.h, self.w, 3), dtype=np.float32)
+        for k, i in enumerate(indices):
+            s = self._s[int(i)]
+            rng = np.random.default_rng(self.seed * 1000003 + int(i))
+            base = [127.5 + 100.0 * np.sin(0.05 * s * (c + 1) + 6.0 * xx * (c + 1) + 3.0 * yy)
+                    for c in range(3)]
+            out[k] = np.clip(np.stack(base, -1) + rng.normal(0.0, 8.0, (self.h, self.w, 3)), 0, 255)
+        return out

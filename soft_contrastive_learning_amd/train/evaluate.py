@@ -1,0 +1,83 @@
+"""In-training evaluation of the reference trainer: the loss on the other region's tuples
+(``get_eval_loss``, train/train.py:1112-1149) and the localisation check
+(``evaluate_localization`` :1156-1193 + ``evaluate_localization_thread`` :360-397): reference
+and query descriptors, the 5 nearest references per query in descriptor space — the
+reference builds ``KDTree(ref_features).query(query_features, k=5)``, here the exact HIP
+top-n — and from their geographic distances the curves the reference plots:
+``top_n[i, j]`` = best distance among the first j + 1 hits, % of queries below a tolerance,
+``AUC@Top1`` over 25 tolerances in [0, rad] and ``%<rad m@Top1`` for rad in 50, 25, 10.
+"""
+import numpy as np
+import torch
+
+from ..evaluation import retrieval
+from ..model import nets
+
+
+def extract_features(model, image_set, indices, images_per_pass):
+    """``extract_features`` (train/train.py:1196-1213): forward-only descriptors of the listed
+    images in list order, in passes of ``images_per_pass`` (the list is padded with image 0 up
+    to a multiple, like the reference's padding arrays) -> float32 [len(indices), E] on the
+    model's device."""
+    dev = next(model.parameters()).device
+    idx = np.asarray(indices, dtype=int)
+    pad = (-len(idx)) % images_per_pass
+    padded = np.concatenate([idx, np.zeros(pad, dtype=int)])
+    outs = []
+    with torch.no_grad():
+        for s in range(0, len(padded), images_per_pass):
+            img = torch.from_numpy(image_set.load_images(padded[s:s + images_per_pass])).to(dev)
+            outs.append(nets.vgg16Netvlad(img, model=model).float())
+    return torch.cat(outs, 0)[:len(idx)]
+
+
+def localization_metrics(top_g_dists, nearest_d_dist=None, radii=(50, 25, 10)):
+    """The summary values of evaluate_localization_thread (train/train.py:363-385).
+    ``top_g_dists`` [Q,k]: geographic distance of every retrieved reference."""
+    import sklearn.metrics
+    g = np.asarray(top_g_dists, dtype=np.float64)
+    top_n = np.minimum.accumulate(g, axis=1)                 # best of the first j + 1 hits
+    out = {}
+    for rad in radii:
+        xs = np.linspace(0, rad, num=25)
+        for n in range(top_n.shape[1]):
+            ys = [float(np.sum(top_n[:, n] < x)) / float(len(top_n)) * 100 for x in xs]
+            if n == 0:
+                out['%dm-auc@Top1' % rad] = float(sklearn.metrics.auc(xs, ys))
+                out['%%<%dm@Top1' % rad] = ys[-1]
+            out['%%<%dm@Top%d' % (rad, n + 1)] = ys[-1]
+        if nearest_d_dist is not None:
+            opt = np.asarray(nearest_d_dist, dtype=np.float64).reshape(-1)
+            out['%%<%dm@Optimum' % rad] = float(np.sum(opt < rad)) / float(len(top_n)) * 100
+    return out
+
+
+def evaluate_localization(model, ref_set, ref_indices, query_set, query_indices, images_per_pass,
+                          k=5):
+    """-> (metrics dict, nearest_latent_indices [Q,k] into ``ref_indices``)."""
+    from sklearn.neighbors import KDTree
+    ref_f = extract_features(model, ref_set, ref_indices, images_per_pass)
+    qry_f = extract_features(model, query_set, query_indices, images_per_pass)
+    k = min(k, len(ref_indices))
+    _, nearest = retrieval.topn_l2(ref_f, qry_f, k)          # KDTree(ref).query(query, k=5)
+    nearest = nearest.cpu().numpy()
+    ref_xy = np.asarray(ref_set.xy)[np.asarray(ref_indices, dtype=int)]
+    qry_xy = np.asarray(query_set.xy)[np.asarray(query_indices, dtype=int)]
+    g = np.linalg.norm(qry_xy[:, None, :] - ref_xy[nearest], axis=2)
+    nearest_d, _ = KDTree(ref_xy).query(qry_xy, k=1)         # the optimum curve (:1184-1185)
+    return localization_metrics(g, nearest_d), nearest
+
+
+def eval_loss(step_loss, sampler, image_set, indices, tuples_per_batch, tuple_shape, device):
+    """``get_eval_loss``: mean loss over the listed anchors' tuples, sampled WITHOUT hard
+    negatives (eval_loss_cpu_thread passes False, :182); batches whose tuple cannot be built
+    are skipped.  ``step_loss(distances, images) -> float``."""
+    losses = []
+    idx = np.asarray(indices, dtype=int)
+    for s in range(0, len(idx) - tuples_per_batch + 1, tuples_per_batch):
+        distances, every = sampler.get_tuple(idx[s:s + tuples_per_batch], tuple_shape, False)
+        if len(every) != tuples_per_batch * sum(tuple_shape):
+            continue
+        images = torch.from_numpy(image_set.load_images(every)).to(device)
+        losses.append(float(step_loss(distances, images)))
+    return (float(np.mean(losses)) if losses else None), len(losses)

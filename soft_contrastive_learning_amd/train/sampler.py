@@ -188,8 +188,11 @@ class InputPipeline:
     every index that reached the device queue (USED_IMAGES, :253-254)."""
 
     def __init__(self, sampler, load_images, tuple_shape, use_hard_negatives=True, depth=2,
-                 workers=1):
+                 workers=1, emit_dropped=False):
         self.sampler, self.load_images, self.tuple_shape = sampler, load_images, tuple_shape
+        # emit_dropped: a dropped batch yields a None item, so that every put() is answered by
+        # exactly one get() (the single-threaded training loop counts on it)
+        self.emit_dropped = emit_dropped
         self.use_hard = use_hard_negatives
         self.cpu_in = queue.Queue()
         self.gpu_in = queue.Queue(maxsize=depth)
@@ -217,6 +220,8 @@ class InputPipeline:
                 else:
                     with self._lock:
                         self.dropped += 1
+                    if self.emit_dropped:
+                        self.gpu_in.put(None, block=True)
             finally:
                 self.cpu_in.task_done()
 

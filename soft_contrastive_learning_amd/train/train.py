@@ -4,13 +4,26 @@ Keeps the reference's flag names and defaults (train/train.py:1226-1312), the lo
 dispatch of ``build_model`` (:585-879), the tuple/batch layout (``[anchor, P positives,
 N negatives(, other negative)]`` per tuple, :502-503, 561, 589-594, 654), the learning-rate
 schedule (:118-121), the optimisers (:865-878) and the three checkpoint cadences
-(:935-937, 1070-1102).  What it does NOT reproduce is dataset-bound: the RobotCar tuple
-sampler, image IO threads, hard-negative mining and PCA threads (out of
-scope; BASELINE configs are synthetic) — ``SyntheticTuples`` stands in for them with the
-same tensors the GPU thread receives (``distances``, ``img``; :263-275).
+(:935-937, 1070-1102).  Two data routes:
+
+* ``--synthetic_dataset M`` or ``--shuffled_root DIR`` (+ ``--img_root``): the reference's
+  epoch loop (``train_one_epoch`` :987-1109) on a pose-tagged image set — anchors go through
+  ``TupleSampler`` -> ``InputPipeline`` (a worker thread samples tuples and loads images while
+  the device trains, :226-260); every ``mining_step`` anchors the descriptors of
+  ``mining_cache_size`` images plus the next anchors are cached for hard-negative mining
+  (``MiningCache``, :1014-1068); every ``eval_step`` anchors a rolling checkpoint is written,
+  the loss on the other region is measured (``get_eval_loss`` :1112-1149) and localisation is
+  evaluated on both regions with the exact HIP top-5 (``evaluate_localization`` :1156-1193);
+  every ``save_step`` a part checkpoint (:1094-1102).
+* default: ``SyntheticTuples`` — random images with the per-loss ``distances`` payload the GPU
+  thread receives (:263-275); what bench.py's workload looks like.
+
+The PCA threads and the eigenvalue / incremental-PCA losses stay out.
 
     python -m soft_contrastive_learning_amd.train.train --loss wms --vlad_cores 64 \
         --reduction none --tuples_per_batch 1 --steps 20
+    python -m soft_contrastive_learning_amd.train.train --loss wms --synthetic_dataset 400 \
+        --height 64 --width 80 --positives_per_tuple 4 --negatives_per_tuple 4
     python -m torch.distributed.run --nproc-per-node 8 -m soft_contrastive_learning_amd.train.train ...
 """
 import argparse
@@ -30,12 +43,18 @@ def make_parser():
     p = argparse.ArgumentParser()
     # output / restore (train/train.py:1233-1238)
     p.add_argument('--checkpoint', default='')
+    p.add_argument('--resume', action='store_true',
+                   help='also restore the optimizer slots and the global step from --checkpoint '
+                        '(the reference only warm-starts the weights, train/train.py:882-905)')
     p.add_argument('--out_root', default='./scl_logs')
     p.add_argument('--out_folder', default='')
     p.add_argument('--max_to_keep', type=int, default=1)
     # tuple size (:1241-1249)
     p.add_argument('--positives_per_tuple', type=int, default=12)
     p.add_argument('--negatives_per_tuple', type=int, default=12)
+    p.add_argument('--hard_negatives_per_tuple', type=int, default=6)
+    p.add_argument('--hard_positives_per_tuple', type=int, default=6)
+    p.add_argument('--mutually_exclusive_negs', type=bool, default=True)
     # loss (:1252-1266)
     p.add_argument('--loss', default='wms')
     p.add_argument('--margin_1', type=float, default=0.1)
@@ -60,9 +79,26 @@ def make_parser():
     # head (:1284-1289); only the NetVLAD / no-reduction path is on the hot path
     p.add_argument('--reduction', default='none')
     p.add_argument('--vlad_cores', default=64, type=int)
-    # cadence (:1299-1300)
+    # hard negative mining (:1288-1293)
+    p.add_argument('--mining_step', type=int, default=250)
+    p.add_argument('--mining_cache_size', type=int, default=1000)
+    # cadence, validation loss and localisation testing (:1296-1300)
     p.add_argument('--eval_step', type=int, default=100)
     p.add_argument('--save_step', type=int, default=500)
+    p.add_argument('--num_eval_queries', type=int, default=50)
+    p.add_argument('--eval_ref_r', default=5, type=int)
+    # data set names (:1303-1307) and locations (:1226-1231)
+    p.add_argument('--local_ref_set', default='train_ref')
+    p.add_argument('--local_query_set', default='train_query')
+    p.add_argument('--other_ref_set', default='test_ref')
+    p.add_argument('--other_query_set', default='test_query')
+    p.add_argument('--train_ref_r', default=1, type=int)
+    p.add_argument('--img_root', default='')
+    p.add_argument('--shuffled_root', default='',
+                   help='directory of the per-epoch lists <set>_<epoch:03d>.csv; empty: synthetic')
+    p.add_argument('--synthetic_dataset', type=int, default=0,
+                   help='M > 0: train on a synthetic pose-tagged set of M images through the '
+                        'sampler / pipeline / mining / evaluation route')
     # synthetic stand-in for the dataset pipeline
     p.add_argument('--steps', type=int, default=10, help='steps per epoch')
     p.add_argument('--height', type=int, default=180)
@@ -201,6 +237,140 @@ class SyntheticTuples:
         return dist_t, img.to(self.dev)
 
 
+def batch_distances(flags, distances, device, world=1, rank_offset=0):
+    """The sampler's per-anchor payloads -> the tensor ``ops['distances']`` holds for the loss
+    (train/train.py:665-691); ms_loss takes the labels of :822-826 instead."""
+    t = flags.tuples_per_batch
+    if flags.loss == 'ms_loss':
+        one = np.concatenate((np.zeros(1 + flags.positives_per_tuple),
+                              np.arange(flags.negatives_per_tuple) + 1))
+        lab = np.concatenate([one + (k + rank_offset) * (flags.negatives_per_tuple + 1)
+                              for k in range(t * world)])
+        return torch.as_tensor(lab).to(device)
+    if distance_type(flags.loss) == 'none':
+        return None
+    return torch.as_tensor(np.asarray(distances, dtype=np.float32)).to(device)
+
+
+def open_sets(flags, epoch):
+    """(local_ref, local_query, other_ref, other_query) image sets of an epoch."""
+    from . import dataset
+    if flags.shuffled_root:
+        def one(name):
+            return dataset.CsvImageSet(os.path.join(flags.shuffled_root,
+                                                    '%s_%03d.csv' % (name, epoch)),
+                                       flags.img_root, flags.height)
+        return (one(flags.local_ref_set), one(flags.local_query_set), one(flags.other_ref_set),
+                one(flags.other_query_set))
+    m = flags.synthetic_dataset
+    local = dataset.SyntheticImageSet(m, flags.height, flags.width, seed=flags.seed)
+    other = dataset.SyntheticImageSet(max(m // 2, 8), flags.height, flags.width,
+                                      seed=flags.seed + 1)
+    return local, local, other, other
+
+
+def train_dataset_epoch(flags, epoch, state, log):
+    """``train_one_epoch`` (train/train.py:987-1109) on this process's device."""
+    from . import evaluate, mining
+    from .sampler import InputPipeline, TupleSampler
+    model, opt, buckets, saver, dev = (state[k] for k in ('model', 'opt', 'buckets', 'saver', 'dev'))
+    tuple_shape = state['tuple_shape']
+    t, s_img = flags.tuples_per_batch, flags.tuples_per_batch * sum(state['tuple_shape'])
+    local_ref, local_query, other_ref, other_query = open_sets(flags, epoch)
+    dtype = distance_type(flags.loss)
+    dtype = dtype if dtype in ('anchor', 'pairwise', 'wms', 'logratio') else 'none'
+    cache = mining.MiningCache()
+
+    def make_sampler(image_set, use_cache):
+        return TupleSampler(image_set.xy, image_set.yaw, flags.positives_per_tuple,
+                            flags.negatives_per_tuple, flags.max_pos_radius, flags.min_neg_radius,
+                            flags.hard_positives_per_tuple, flags.hard_negatives_per_tuple,
+                            flags.mutually_exclusive_negs, dtype, cache if use_cache else None,
+                            flags.mining_cache_size, np.random.RandomState(42 + epoch))
+    sampler = make_sampler(local_ref, True)
+    other_sampler = make_sampler(other_ref, False)
+    pipe = InputPipeline(sampler, local_ref.load_images, tuple_shape, use_hard_negatives=True,
+                         depth=2, emit_dropped=True)
+    anchors = np.random.RandomState(1000 + epoch).permutation(
+        np.arange(0, len(local_ref), max(flags.train_ref_r, 1)))
+    if flags.steps > 0:
+        anchors = anchors[:flags.steps * t]
+    lr = get_learning_rate(epoch, flags)
+    for g in opt.param_groups:
+        g['lr'] = lr
+
+    def loss_of(distances, images):
+        out = nets.vgg16Netvlad(images)
+        return compute_loss(flags, tuple_shape, out, batch_distances(flags, distances, dev))
+
+    def train_on(item):
+        if item is None:
+            return                                              # 'Faulty training batch'
+        distances, images, _ = item
+        buckets.zero()
+        loss = loss_of(distances, torch.from_numpy(images).to(dev))
+        loss.backward()
+        buckets.finish()
+        opt.step()
+        state['step'] += 1
+        rec = {'step': state['step'], 'epoch': epoch, 'loss': float(loss.detach()),
+               'learning_rate': lr}
+        print('Train batch loss: {}'.format(rec['loss']))          # :289
+        log(rec)
+
+    def drain(outstanding):
+        while outstanding:
+            train_on(pipe.get())
+            outstanding -= 1
+        return 0
+
+    outstanding, mining_count = 0, 0
+    try:
+        for step in range(0, len(anchors), t):
+            if step % flags.mining_step == 0:                        # :1014-1068
+                outstanding = drain(outstanding)
+                mining_indices = np.arange(mining_count * flags.mining_cache_size,
+                                           (mining_count + 1) * flags.mining_cache_size) % len(local_ref)
+                to_mine = anchors[step:min(step + flags.mining_step, len(anchors))]
+                mining_indices = np.concatenate([mining_indices, to_mine])
+                feats = evaluate.extract_features(model, local_ref, mining_indices, s_img)
+                cache.update(feats, mining_indices)
+                mining_count += 1
+                log({'step': state['step'], 'event': 'mining_cache', 'images': int(len(mining_indices))})
+            if step % flags.eval_step == 0:                          # :1070-1092
+                outstanding = drain(outstanding)
+                saver.save_rolling(model, state['step'], opt)
+                test_number = state['step'] // flags.eval_step
+                nq = (flags.num_eval_queries // t) * t
+                test_idx = np.arange(test_number * nq, (test_number + 1) * nq) % len(other_ref)
+                with torch.no_grad():
+                    ev, used = evaluate.eval_loss(loss_of, other_sampler, other_ref, test_idx, t,
+                                                  tuple_shape, dev)
+                rec = {'step': state['step'], 'event': 'eval', 'other_region_loss': ev,
+                       'eval_batches': used}
+                for mode, rset, qset in (('other', other_ref, other_query),
+                                         ('local', local_ref, local_query)):
+                    refs = np.arange(0, len(rset), max(flags.eval_ref_r, 1))
+                    q = np.arange(test_number * flags.num_eval_queries,
+                                  (test_number + 1) * flags.num_eval_queries) % len(qset)
+                    metrics, _ = evaluate.evaluate_localization(model, rset, refs, qset, q, s_img)
+                    rec[mode] = metrics
+                print('Other region loss: {}'.format(ev))            # :1144
+                log(rec)
+            if step % flags.save_step == 0:                          # :1094-1102
+                outstanding = drain(outstanding)
+                saver.save_part(model, state['step'], opt)
+            pipe.put(anchors[step:step + t])
+            outstanding += 1
+            if outstanding > 1:                                      # one batch stays in flight
+                train_on(pipe.get())
+                outstanding -= 1
+        drain(outstanding)
+    finally:
+        pipe.close()
+    saver.save_epoch(model, epoch, state['step'], opt)               # :984
+
+
 def main(argv=None):
     flags = make_parser().parse_args(argv)
     if flags.vlad_cores != 64 or flags.reduction != 'none':
@@ -231,12 +401,30 @@ def main(argv=None):
     else:
         opt = torch.optim.Adam(params, lr=flags.base_lr, fused=bool(params) and params[0].is_cuda)
     # restore_weights (:882-905) + the slot variables a tf.train.Saver checkpoint carries
-    step = checkpoint.load(model, flags.checkpoint, optimizer=opt) if flags.checkpoint else 0
+    step = 0
+    if flags.checkpoint:
+        got = checkpoint.load(model, flags.checkpoint, optimizer=opt if flags.resume else None)
+        step = got if flags.resume else 0
     out_dir = os.path.join(flags.out_root, flags.out_folder or flags.loss)
     saver = checkpoint.Saver(out_dir, flags.max_to_keep)
     data = SyntheticTuples(flags, tuple_shape, dev, rank, world)
     log = open(os.path.join(out_dir, 'train_log.txt'), 'a') if rank == 0 and (
         os.makedirs(out_dir, exist_ok=True) or True) else None
+
+    if flags.synthetic_dataset > 0 or flags.shuffled_root:
+        if world > 1:
+            raise SystemExit('the dataset route runs one process (the reference is single-GPU); '
+                             'the data-parallel step is exercised by the default route')
+        state = dict(model=model, opt=opt, buckets=buckets, saver=saver, dev=dev,
+                     tuple_shape=tuple_shape, step=step)
+
+        def write(rec):
+            log.write(json.dumps(rec) + '\n')
+            log.flush()
+        for epoch in range(flags.max_epoch):
+            train_dataset_epoch(flags, epoch, state, write)
+        nets.GRAD_SINK = None
+        return state
 
     for epoch in range(flags.max_epoch):
         lr = get_learning_rate(epoch, flags)

@@ -171,3 +171,72 @@ def test_device_pca_whitening_matches_sklearn_full_solver(dev):
     sign = np.sign(np.sum(got * ref, axis=0))           # sklearn versions differ in svd_flip
     np.testing.assert_allclose(got * sign, ref, rtol=0, atol=2e-3 * np.abs(ref).max())
     assert abs(np.var(pca.transform(x).cpu().numpy(), axis=0, ddof=1) - 1.0).max() < 1e-3
+
+
+def test_trainer_dataset_route_sampling_mining_and_evaluation(dev, tmp_path):
+    """train_one_epoch (train/train.py:987-1109) end to end on a synthetic pose-tagged set:
+    TupleSampler -> InputPipeline -> train steps, a mining-cache refresh every mining_step
+    anchors (hard negatives come from it afterwards), eval loss + localisation on both regions
+    every eval_step, rolling / part / epoch checkpoints."""
+    import json
+    import os
+    from soft_contrastive_learning_amd import tf_bundle
+    from soft_contrastive_learning_amd.train import train as T
+    out = str(tmp_path)
+    state = T.main(['--loss', 'wms', '--synthetic_dataset', '160', '--height', '64', '--width', '80',
+                    '--positives_per_tuple', '3', '--negatives_per_tuple', '3',
+                    '--hard_positives_per_tuple', '1', '--hard_negatives_per_tuple', '2',
+                    '--mining_step', '4', '--mining_cache_size', '40', '--eval_step', '4',
+                    '--save_step', '8', '--num_eval_queries', '8', '--eval_ref_r', '2',
+                    '--steps', '8', '--max_epoch', '1', '--base_lr', '1e-5',
+                    '--out_root', out, '--out_folder', 'run'])
+    recs = [json.loads(l) for l in open(os.path.join(out, 'run', 'train_log.txt'))]
+    steps = [r for r in recs if 'loss' in r]
+    mines = [r for r in recs if r.get('event') == 'mining_cache']
+    evals = [r for r in recs if r.get('event') == 'eval']
+    assert 6 <= len(steps) <= 8 and all(np.isfinite(r['loss']) for r in steps)
+    assert len(mines) == 2 and mines[0]['images'] == 44            # 40 cached + 4 next anchors
+    assert len(evals) == 2
+    for e in evals:
+        assert e['other_region_loss'] is None or np.isfinite(e['other_region_loss'])
+        for mode in ('other', 'local'):
+            m = e[mode]
+            assert 0.0 <= m['%<50m@Top1'] <= m['%<50m@Top5'] <= 100.0
+            assert m['%<10m@Top1'] <= m['%<25m@Top1'] <= m['%<50m@Top1']
+    # the local set retrieves itself: a query image is in the reference list half of the time
+    assert evals[-1]['local']['%<10m@Top1'] >= 50.0
+    d = os.path.join(out, 'run')
+    assert tf_bundle.latest_checkpoint(d) is not None
+    assert tf_bundle.exists(os.path.join(d, 'epoch-checkpoint-0'))
+    assert any(f.startswith('part-checkpoint-') for f in os.listdir(d))
+    assert state['step'] == len(steps)
+
+
+def test_checkpoint_resume_with_fused_adam_on_the_device(dev, tmp_path):
+    """--checkpoint --resume with the trainer's fused Adam: the restored step counter must live
+    on the device (torch._fused_adam_ hands the kernel its pointer); the first update after the
+    restore equals the uninterrupted run bit for bit."""
+    from soft_contrastive_learning_amd import checkpoint
+    from soft_contrastive_learning_amd.model import nets
+    a = nets.VGG16NetVLAD(seed=5).to(dev)
+    b = nets.VGG16NetVLAD(seed=6).to(dev)
+    oa = torch.optim.Adam(a.parameters(), lr=1e-3, fused=True)
+    ob = torch.optim.Adam(b.parameters(), lr=1e-3, fused=True)
+    g = torch.Generator().manual_seed(0)
+    grads = [[torch.randn(p.shape, generator=g) * 1e-2 for p in a.parameters()] for _ in range(4)]
+    for k in range(3):
+        for p, gr in zip(a.parameters(), grads[k]):
+            p.grad = gr.to(dev)
+        oa.step()
+    stem = str(tmp_path / 'checkpoint-3')
+    checkpoint.save(a, stem, global_step=3, optimizer=oa)
+    assert checkpoint.load(b, stem, optimizer=ob) == 3
+    st = ob.state[next(iter(b.parameters()))]['step']
+    assert st.is_cuda and float(st) == 3.0
+    for m, o in ((a, oa), (b, ob)):
+        for p, gr in zip(m.parameters(), grads[3]):
+            p.grad = gr.to(dev)
+        o.step()
+    torch.cuda.synchronize()
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert torch.equal(pa, pb)

@@ -98,3 +98,26 @@ def test_merge_topn_orders_by_distance_then_index():
     i = [torch.tensor([[7, 1]]), torch.tensor([[4, 9]])]
     md, mi = retrieval.merge_topn(d, i, 3)
     assert mi.tolist() == [[4, 7, 9]] and md.tolist() == [[1.0, 1.0, 2.0]]
+
+
+def test_synthetic_image_set_and_localization_metrics():
+    from soft_contrastive_learning_amd.train import dataset, evaluate
+    ds = dataset.SyntheticImageSet(60, height=16, width=20, spacing=2.0, laps=2, seed=3)
+    assert len(ds) == 60 and ds.xy.shape == (60, 2) and ds.yaw.shape == (60,)
+    a, b = ds.load_images([5, 7]), ds.load_images([5])
+    assert a.shape == (2, 16, 20, 3) and a.dtype == np.float32
+    np.testing.assert_array_equal(a[0], b[0])                      # deterministic per index
+    assert 0.0 <= a.min() and a.max() <= 255.0
+    # the two laps pass the same places: pose i and i + 30 are within the jitter
+    assert np.linalg.norm(ds.xy[3] - ds.xy[33]) < 3.0
+    # evaluate_localization_thread's numbers (train/train.py:363-385) on a pencil case:
+    # query 0: hits at 30 m then 5 m; query 1: 60 m twice
+    m = evaluate.localization_metrics([[30.0, 5.0], [60.0, 60.0]], nearest_d_dist=[1.0, 70.0])
+    assert m['%<50m@Top1'] == 50.0 and m['%<50m@Top2'] == 50.0
+    assert m['%<25m@Top1'] == 0.0 and m['%<25m@Top2'] == 50.0      # 5 m only counts from Top-2
+    assert m['%<10m@Top2'] == 50.0 and m['%<50m@Optimum'] == 50.0
+    # AUC@Top1 over 25 tolerances in [0, 50]: query 0 is correct above 30 m -> 50 % there
+    xs = np.linspace(0, 50, 25)
+    ys = [50.0 if x > 30.0 else 0.0 for x in xs]
+    want = float(np.trapz(ys, xs))
+    assert abs(m['50m-auc@Top1'] - want) < 1e-9
