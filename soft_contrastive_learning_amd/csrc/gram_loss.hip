@@ -371,6 +371,72 @@ __global__ __launch_bounds__(256) void gram_coef_kernel(const float* __restrict_
   }
 }
 
+// grad[r, e] = g * sum_j M[row_begin + r, j] emb[j, e] for 32 < B <= 1024 on aligned rows:
+// gram_bwd_kernel without a branch around any load (a guarded load makes hipcc wait for each
+// one before issuing the next) and with the work cut so that every SIMD gets the same number
+// of waves: a wave owns 32 * TILES columns (TILES interleaved accumulator tiles fed by one
+// 4 * TILES-byte load per lane and step), four waves per workgroup.
+// grid (E / (128 * TILES), row tiles); block 256; LDS [32][B | 1] floats (the M tile).
+template <int TILES>
+__global__ __launch_bounds__(256) void gram_bwd_fast_kernel(const float* __restrict__ emb,
+                                                            int64_t ld, int B, int E,
+                                                            const float* __restrict__ coef,
+                                                            const float* __restrict__ grad_loss,
+                                                            int row_begin, int row_count,
+                                                            float* __restrict__ grad, int64_t ldg) {
+  extern __shared__ __attribute__((aligned(16))) float mt[];   // [32][B | 1]
+  typedef float vec_t __attribute__((ext_vector_type(TILES)));
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int ldm = B | 1;
+  for (int idx = threadIdx.x; idx < kTile * B; idx += 256) {
+    const int rr = idx / B, j = idx - rr * B;
+    const int lr = blockIdx.y * kTile + rr;
+    mt[rr * ldm + j] = lr < row_count ? coef[(int64_t)(row_begin + lr) * B + j] : 0.f;
+  }
+  __syncthreads();
+  const int e = (blockIdx.x * 4 + wid) * 32 * TILES + TILES * r;   // this lane's TILES columns
+  f32x16 acc[TILES];
+#pragma unroll
+  for (int t = 0; t < TILES; ++t) acc[t] = zero16();
+  const float* ma = mt + r * ldm + h;
+  const float* eb = emb + (int64_t)h * ld + e;
+  const int steps = B >> 1;                                       // pairs of contraction rows
+  constexpr int U = 8;
+  int s0 = 0;
+  for (; s0 + U <= steps; s0 += U) {
+    vec_t bv[U];
+    float av[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      bv[u] = *reinterpret_cast<const vec_t*>(eb + (int64_t)2 * (s0 + u) * ld);
+      av[u] = ma[2 * (s0 + u)];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int t = 0; t < TILES; ++t) acc[t] = mfma32(av[u], bv[u][t], acc[t]);
+  }
+  for (; 2 * s0 < B; ++s0) {                                      // tail (and an odd last row)
+    const int j = 2 * s0 + h;
+    const bool jok = j < B;
+    const vec_t bvt = *reinterpret_cast<const vec_t*>(emb + (int64_t)(jok ? j : B - 1) * ld + e);
+    const float a = jok ? mt[r * ldm + j] : 0.f;
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) acc[t] = mfma32(a, bvt[t], acc[t]);
+  }
+  const float g = grad_loss ? *grad_loss : 1.0f;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int orow = blockIdx.y * kTile + acc_row(q, h);
+    if (orow >= row_count) continue;
+    vec_t o;
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) o[t] = g * acc[t][q];
+    *reinterpret_cast<vec_t*>(grad + (int64_t)orow * ldg + e) = o;
+  }
+}
+
 // grad[r, e] = g * sum_j M[row_begin + r, j] * emb[j, e].
 // grid (ceil(E/512), row tiles); block 256.  The workgroup's [32 x B] slice of M sits in LDS
 // (odd row stride: conflict-free ds_read_b32); every wave owns 128 columns as 4 accumulator
@@ -646,6 +712,168 @@ __global__ __launch_bounds__(256) void gram16_kernel(const float* __restrict__ e
     }
     *reinterpret_cast<f32x4*>(slab + 4 * (int64_t)idx) = v;
   }
+}
+
+
+// ---------------------------------------------------------------------------------------
+// gram16x6_kernel: the raw Gram for 64 < B <= 256 on the bf16 matrix cores with BOTH operands
+// split into three bf16 planes, e = e1 + e2 + e3 exactly (24 mantissa bits), and the six
+// products whose weight is >= 2^-16 of the leading one:
+//   e.f ~= e1.f1 + e1.f2 + e2.f1 + e1.f3 + e3.f1 + e2.f2     (dropped: 2^-24 relative)
+// every bf16 x bf16 product is exact in float32 and the sum runs in float32, smallest terms
+// first, so the result is float32-equivalent at 6 x 16 cycles per 32-deep step
+// instead of 8 x 32 for the float32 MFMA.  Same decomposition, slab format and finishing
+// kernels as gram16_kernel.
+//   * the workgroup's [B x kchunk] slice of E is loaded ONCE (one burst into registers), split
+//     once — each element of E is split exactly once on the whole chip — and written to LDS
+//     64 columns at a time as plane images [plane][16-byte piece][row]: the fragment of lane
+//     (i, g) for k-step ks and tile t is unit (plane * 8 + 4 ks + g) * Bp + 16 t + i, i.e.
+//     every ds_read_b128 service group hits 16 different slots (conflict-free, no padding);
+//   * A and B fragments are the same thing (rows of E), a pair (ti, tj) costs 3 fragment
+//     reads (tile tj; tile ti is kept while the wave stays in row ti) and 6 MFMAs per k-step.
+// grid S; block 256; dynamic LDS 3 * 8 * Bp * 16 bytes.
+constexpr int kX6Sub = 64;       // columns staged per pass
+
+__device__ __forceinline__ void split3_bf16x(float x, unsigned& h1, unsigned& h2, unsigned& h3) {
+  const unsigned short a = f32_to_bf16(x);
+  const float r1 = x - bf16_to_f32(a);
+  const unsigned short b = f32_to_bf16(r1);
+  h1 = a;
+  h2 = b;
+  h3 = f32_to_bf16(r1 - bf16_to_f32(b));
+}
+typedef unsigned gx_u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 gx_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 mfma16bf(gx_u32x4 a, gx_u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(gx_bf16x8, a),
+                                                 __builtin_bit_cast(gx_bf16x8, b), c, 0, 0, 0);
+}
+
+// DUAL: two accumulation chains per pair (needs 2 x 4 x PWMAX accumulator registers)
+template <int PWMAX, int NSUB, bool DUAL>   // pairs per wave (max), 64-column passes per workgroup
+__global__ __launch_bounds__(256) void gram16x6_kernel(const float* __restrict__ emb, int64_t ld,
+                                                       int B, int E, int T, int P,
+                                                       float* __restrict__ slabs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned x6_lds[];
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, g = lane >> 4;
+  const int Bp = 16 * T;
+  const int k0 = blockIdx.x * (NSUB * kX6Sub);
+  // ---- one burst: thread u-th float4 = row (tid + 256 u) >> 4, columns 4 ((tid + 256 u) & 15)
+  //      of every pass (requires aligned rows and the slice inside E: checked by the host)
+  constexpr int RMAX = 16;                                  // Bp * 16 / 256 <= 16 for Bp <= 256
+  f32x4 v[NSUB][RMAX];
+  const int nq = Bp * 16;
+#pragma unroll
+  for (int sb = 0; sb < NSUB; ++sb)
+#pragma unroll
+    for (int u = 0; u < RMAX; ++u) {
+      const int q = u * 256 + threadIdx.x;                    // no branch around a load:
+      int row = q >> 4;                                        // rows past the end re-read B - 1
+      row = row < B ? row : B - 1;
+      v[sb][u] = *reinterpret_cast<const f32x4*>(emb + (int64_t)row * ld + k0 + sb * kX6Sub + 4 * (q & 15));
+    }
+  // this wave's pairs
+  const int p_begin = (int)(((long)P * wid) / 4), p_end = (int)(((long)P * (wid + 1)) / 4);
+  const int np = p_end - p_begin;
+  int ti0, tj0;
+  decode_pair16(p_begin < P ? p_begin : 0, T, ti0, tj0);
+  // two accumulation chains per pair (three products each): a chain of dependent 16x16x32
+  // MFMAs issues slower than independent ones
+  f32x4 acc[PWMAX], acc2[DUAL ? PWMAX : 1];
+#pragma unroll
+  for (int lp = 0; lp < PWMAX; ++lp) acc[lp] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int lp = 0; lp < (DUAL ? PWMAX : 1); ++lp) acc2[lp] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const gx_u32x4* img = reinterpret_cast<const gx_u32x4*>(x6_lds);
+
+#pragma unroll
+  for (int sb = 0; sb < NSUB; ++sb) {
+    if (sb) __syncthreads();                                // everyone is done with the last pass
+    // split and store: float4 (row, c4) -> planes: unit (plane * 8 + c4 / 2) * Bp + row, half c4 & 1
+#pragma unroll
+    for (int u = 0; u < RMAX; ++u) {
+      const int q = u * 256 + threadIdx.x;
+      if (q < nq) {
+        const int row = q >> 4, c4 = q & 15;
+        unsigned h[3][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float x = row < B ? v[sb][u][c] : 0.f;
+          split3_bf16x(x, h[0][c], h[1][c], h[2][c]);
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          uint2 w2;
+          w2.x = h[pl][0] | (h[pl][1] << 16);
+          w2.y = h[pl][2] | (h[pl][3] << 16);
+          *reinterpret_cast<uint2*>(&x6_lds[(((pl * 8 + (c4 >> 1)) * Bp + row) << 2) + ((c4 & 1) << 1)]) = w2;
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const gx_u32x4* fb = img + (4 * ks + g) * Bp + i;       // + plane * 8 * Bp + 16 * tile
+      int ti = ti0, tj = tj0;
+      gx_u32x4 a[3], b[3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        a[pl] = fb[pl * 8 * Bp + 16 * ti];
+        b[pl] = fb[pl * 8 * Bp + 16 * tj];
+      }
+#pragma unroll
+      for (int lp = 0; lp < PWMAX; ++lp) {
+        if (lp < np) {
+          int tj_n = tj + 1, ti_n = ti;
+          if (tj_n == T) {
+            ti_n = ti + 1 < T ? ti + 1 : ti;
+            tj_n = ti_n;
+          }
+          gx_u32x4 a_n[3], b_n[3];
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+            b_n[pl] = fb[pl * 8 * Bp + 16 * tj_n];
+            a_n[pl] = fb[pl * 8 * Bp + 16 * ti_n];
+          }
+          __builtin_amdgcn_sched_barrier(0);     // next pair's reads fly under these MFMAs
+          if constexpr (DUAL) {
+            f32x4 c = acc[lp], c2 = acc2[lp];
+            c2 = mfma16bf(a[2], b[0], c2);         // chain 2: the small terms
+            c = mfma16bf(a[1], b[0], c);
+            c2 = mfma16bf(a[0], b[2], c2);
+            c = mfma16bf(a[0], b[1], c);
+            c2 = mfma16bf(a[1], b[1], c2);
+            c = mfma16bf(a[0], b[0], c);
+            acc[lp] = c;
+            acc2[lp] = c2;
+          } else {
+            f32x4 c = acc[lp];
+            c = mfma16bf(a[2], b[0], c);
+            c = mfma16bf(a[0], b[2], c);
+            c = mfma16bf(a[1], b[1], c);
+            c = mfma16bf(a[1], b[0], c);
+            c = mfma16bf(a[0], b[1], c);
+            c = mfma16bf(a[0], b[0], c);
+            acc[lp] = c;
+          }
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+            a[pl] = a_n[pl];
+            b[pl] = b_n[pl];
+          }
+          ti = ti_n;
+          tj = tj_n;
+        }
+      }
+    }
+  }
+  float* slab = slabs + (int64_t)blockIdx.x * P * 256;
+#pragma unroll
+  for (int lp = 0; lp < PWMAX; ++lp)
+    if (lp < np)
+      *reinterpret_cast<f32x4*>(slab + (int64_t)(p_begin + lp) * 256 + 4 * lane) =
+          DUAL ? acc[lp] + acc2[DUAL ? lp : 0] : acc[lp];
 }
 
 // ---- pair terms of one (row, column) entry, shared by every finishing kernel --------------
@@ -980,10 +1208,30 @@ inline GramWs carve(void* ws, int B, size_t slab_floats) {
 inline size_t slab_floats_for(int B, int E) {
   if (B <= kFastB) {
     const Gram16Plan p = make_plan16(B, E);
-    return (size_t)p.S * p.P * 256;
+    size_t n = (size_t)p.S * p.P * 256;
+    if (B > 64 && E % 128 == 0 && (size_t)(E / 128) * p.P * 256 > n) n = (size_t)(E / 128) * p.P * 256;
+    return n;
   }
   const GramPlan p = make_plan(B, E);
   return (size_t)p.splits * p.npairs * kTile * kTile;
+}
+
+// bf16x6 route: aligned rows and E a multiple of the 128-column slice
+inline bool use_x6(int B, int E, int64_t ld, const float* emb) {
+  return B > 64 && B <= kFastB && E % 128 == 0 && ld % 4 == 0 && ((uintptr_t)emb % 16) == 0 &&
+         scl_debug_variant != 31;                             // 31: force the float32-MFMA Gram
+}
+template <int PWMAX, bool DUAL>
+void launch_gram16x6(int T, int P, const float* emb, int64_t ld, int B, int E, float* slabs,
+                     hipStream_t st) {
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16x6_kernel<PWMAX, 2, DUAL>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+  });
+  const size_t lds = (size_t)3 * 8 * 16 * T * 16;
+  SCL_LAUNCH("gram16_kernel", (gram16x6_kernel<PWMAX, 2, DUAL>), dim3(E / 128), dim3(256), lds, st, emb,
+             ld, B, E, T, P, slabs);
 }
 
 template <int PWMAX, bool FULL = false>
@@ -1036,11 +1284,19 @@ extern "C" int scl_gram_loss_fwd(const float* emb, int64_t ld_emb, int B, int E,
   lp.lamb = lamb;
   lp.eps = eps;
   if (B <= kFastB) {
-    const Gram16Plan p = make_plan16(B, E);
+    Gram16Plan p = make_plan16(B, E);
     const int ps = 4 / p.KS;
     const int pw = (p.P + ps - 1) / ps;
     const bool full = p.P % ps == 0;
-    if (pw == 1 && full)
+    if (use_x6(B, E, ld_emb, emb)) {
+      p.S = E / 128;                                          // slabs of the bf16x6 kernel
+      if (pw <= 9)
+        launch_gram16x6<9, true>(p.T, p.P, emb, ld_emb, B, E, w.slabs, st);
+      else if (pw <= 20)
+        launch_gram16x6<20, true>(p.T, p.P, emb, ld_emb, B, E, w.slabs, st);
+      else
+        launch_gram16x6<34, false>(p.T, p.P, emb, ld_emb, B, E, w.slabs, st);
+    } else if (pw == 1 && full)
       launch_gram16<1, true>(p, emb, ld_emb, B, E, vec_ok, w.slabs, st);
     else if (pw == 3 && full)
       launch_gram16<3, true>(p, emb, ld_emb, B, E, vec_ok, w.slabs, st);
@@ -1106,7 +1362,33 @@ extern "C" int scl_gram_loss_bwd(const float* emb, int64_t ld_emb, int B, int E,
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_bwd_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(kTile * (kMaxB | 1) * sizeof(float)));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_bwd_fast_kernel<2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(kTile * (kMaxB | 1) * sizeof(float)));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_bwd_fast_kernel<4>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(kTile * (kMaxB | 1) * sizeof(float)));
   });
+  {
+    const bool al = (ld_emb % 4 == 0) && (ld_grad % 4 == 0) && ((uintptr_t)emb % 16 == 0) &&
+                    ((uintptr_t)grad_emb % 16 == 0);
+    const size_t ldsf = (size_t)kTile * (B | 1) * sizeof(float);
+    const int rt = (row_count + kTile - 1) / kTile;
+    // waves per SIMD (1024 SIMDs) with 64- or 128-column waves: take the better balanced cut
+    if (al && E % 512 == 0 && scl_debug_variant != 32) {
+      const long w4 = (long)(E / 128) * rt, w2 = 2 * w4;
+      const long r4 = (w4 + 1023) / 1024 * 2, r2 = (w2 + 1023) / 1024;   // time in 64-column units
+      if (r2 < r4)
+        SCL_LAUNCH("gram_bwd_kernel", gram_bwd_fast_kernel<2>, dim3(E / 256, rt), dim3(256), ldsf,
+                   (hipStream_t)stream, emb, ld_emb, B, E, coef, grad_loss, row_begin, row_count,
+                   grad_emb, ld_grad);
+      else
+        SCL_LAUNCH("gram_bwd_kernel", gram_bwd_fast_kernel<4>, dim3(E / 512, rt), dim3(256), ldsf,
+                   (hipStream_t)stream, emb, ld_emb, B, E, coef, grad_loss, row_begin, row_count,
+                   grad_emb, ld_grad);
+      return scl_launch_status();
+    }
+  }
   const int vec_ok = (ld_emb % 4 == 0) && (ld_grad % 4 == 0) && ((uintptr_t)emb % 16 == 0) &&
                      ((uintptr_t)grad_emb % 16 == 0);
   const size_t lds = (size_t)kTile * (B | 1) * sizeof(float);
