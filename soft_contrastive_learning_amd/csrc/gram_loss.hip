@@ -726,12 +726,15 @@ __global__ __launch_bounds__(256) void gram16_kernel(const float* __restrict__ e
 // kernels as gram16_kernel.
 //   * the workgroup's [B x kchunk] slice of E is loaded ONCE (one burst into registers), split
 //     once — each element of E is split exactly once on the whole chip — and written to LDS
-//     64 columns at a time as plane images [plane][16-byte piece][row]: the fragment of lane
-//     (i, g) for k-step ks and tile t is unit (plane * 8 + 4 ks + g) * Bp + 16 t + i, i.e.
-//     every ds_read_b128 service group hits 16 different slots (conflict-free, no padding);
+//     64 columns at a time as plane images [plane][16-byte piece][row (+ 1 pad)]: the fragment
+//     of lane (i, g) for k-step ks and tile t is unit (plane * 8 + 4 ks + g) * (Bp + 1) + 16 t
+//     + i.  The pad unit per piece keeps the 8-byte staging stores of 16 consecutive lanes
+//     (one row, its 16 column quads = 8 pieces) on 32 different banks — with a piece stride of
+//     Bp units they all fell on the same four (PMC: 2.1 M conflict cycles per launch) — at the
+//     price of one 2-way slot per fragment read;
 //   * A and B fragments are the same thing (rows of E), a pair (ti, tj) costs 3 fragment
 //     reads (tile tj; tile ti is kept while the wave stays in row ti) and 6 MFMAs per k-step.
-// grid S; block 256; dynamic LDS 3 * 8 * Bp * 16 bytes.
+// grid S; block 256; dynamic LDS 3 * 8 * (Bp + 1) * 16 bytes.
 constexpr int kX6Sub = 64;       // columns staged per pass
 
 __device__ __forceinline__ void split3_bf16x(float x, unsigned& h1, unsigned& h2, unsigned& h3) {
@@ -807,20 +810,20 @@ __global__ __launch_bounds__(256) void gram16x6_kernel(const float* __restrict__
           uint2 w2;
           w2.x = h[pl][0] | (h[pl][1] << 16);
           w2.y = h[pl][2] | (h[pl][3] << 16);
-          *reinterpret_cast<uint2*>(&x6_lds[(((pl * 8 + (c4 >> 1)) * Bp + row) << 2) + ((c4 & 1) << 1)]) = w2;
+          *reinterpret_cast<uint2*>(&x6_lds[(((pl * 8 + (c4 >> 1)) * (Bp + 1) + row) << 2) + ((c4 & 1) << 1)]) = w2;
         }
       }
     }
     __syncthreads();
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      const gx_u32x4* fb = img + (4 * ks + g) * Bp + i;       // + plane * 8 * Bp + 16 * tile
+      const gx_u32x4* fb = img + (4 * ks + g) * (Bp + 1) + i;   // + plane * 8 * (Bp + 1) + 16 * tile
       int ti = ti0, tj = tj0;
       gx_u32x4 a[3], b[3];
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) {
-        a[pl] = fb[pl * 8 * Bp + 16 * ti];
-        b[pl] = fb[pl * 8 * Bp + 16 * tj];
+        a[pl] = fb[pl * 8 * (Bp + 1) + 16 * ti];
+        b[pl] = fb[pl * 8 * (Bp + 1) + 16 * tj];
       }
 #pragma unroll
       for (int lp = 0; lp < PWMAX; ++lp) {
@@ -833,8 +836,8 @@ __global__ __launch_bounds__(256) void gram16x6_kernel(const float* __restrict__
           gx_u32x4 a_n[3], b_n[3];
 #pragma unroll
           for (int pl = 0; pl < 3; ++pl) {
-            b_n[pl] = fb[pl * 8 * Bp + 16 * tj_n];
-            a_n[pl] = fb[pl * 8 * Bp + 16 * ti_n];
+            b_n[pl] = fb[pl * 8 * (Bp + 1) + 16 * tj_n];
+            a_n[pl] = fb[pl * 8 * (Bp + 1) + 16 * ti_n];
           }
           __builtin_amdgcn_sched_barrier(0);     // next pair's reads fly under these MFMAs
           if constexpr (DUAL) {
@@ -1229,7 +1232,7 @@ void launch_gram16x6(int T, int P, const float* emb, int64_t ld, int B, int E, f
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16x6_kernel<PWMAX, 2, DUAL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
   });
-  const size_t lds = (size_t)3 * 8 * 16 * T * 16;
+  const size_t lds = (size_t)3 * 8 * (16 * T + 1) * 16;
   SCL_LAUNCH("gram16_kernel", (gram16x6_kernel<PWMAX, 2, DUAL>), dim3(E / 128), dim3(256), lds, st, emb,
              ld, B, E, T, P, slabs);
 }
