@@ -13,9 +13,11 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer into caller-owned memory (HBM); the
- *     library allocates nothing and keeps no global state, so all entry points are
- *     re-entrant (the reference drives one session from three threads,
- *     train/train.py:967-975);
+ *     library allocates nothing and the compute entry points keep no state between calls,
+ *     so they are re-entrant (the reference drives one session from three threads,
+ *     train/train.py:967-975).  Two PROCESS-WIDE diagnostic switches exist and are off by
+ *     default: the ablation selector of scl_debug_set_variant and the timing sink of
+ *     scl_prof_begin / scl_prof_end (see "Diagnostics" at the end);
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and
  *     no entry point synchronises;
  *   - every function returns 0 on success, a negative SCL_E_* code for a rejected
@@ -238,7 +240,9 @@ int scl_topn_exact_filter(const float* ref, int R, const float* query, int d, co
  * VGG16 backbone glue — the elementwise ops between the convolutions of
  * model/nets.py:27-63 (tf.layers.conv2d's bias add, tf.nn.relu,
  * tf.layers.max_pooling2d(2, 2)) and their TF-autodiff backward ops, fused so each
- * activation map is streamed once.  The convolutions stay on PyTorch-ROCm/MIOpen.
+ * activation map is streamed once.  They serve the layers whose convolution runs in the
+ * library (conv5_x forward in bf16, everything in float32 mode); the hand-written
+ * convolutions further down fuse these tails into their epilogues.
  * Activations are channels-last [M = B*H*W, C] (f32 or bf16), C % 8 == 0 and
  * (C / 8) | 256; bias and bias gradients are f32 [C].
  *   scl_vgg_bias_act   y = [relu](y + bias), in place
@@ -397,6 +401,11 @@ int scl_wrw3x3_ex(const void* x, const void* gz, int B, int H, int W, int cin, i
  * the production kernels, any other value makes RESULTS MEANINGLESS.  Returns the old value.
  *   1..7          forward row-tile kernel: bit 0 no epilogue stores, bit 1 no x loads,
  *                 bit 2 no operand staging / barriers
+ *   8             bf16 feature maps through the float32-MFMA NetVLAD kernels
+ *   21 / 22       bf16 row-tile kernel: main loop only / epilogue only
+ *   31 / 32       Gram loss, 64 < B <= 256: float32-MFMA Gram instead of bf16x6 /
+ *                 the older guarded backward kernel
+ *   100000 * s    Gram loss, B <= 256: force s K-splits
  *   100 + s       top-n: force s reference splits (1..32) instead of the planner's choice
  *   1000 * b (+ 100 + s)   top-n scan: b bit 0 no selection, bit 1 no tile staging,
  *                 bit 2 no MFMAs */

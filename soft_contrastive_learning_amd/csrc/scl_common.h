@@ -182,7 +182,7 @@ __device__ __forceinline__ float block_reduce(float v, float* scratch) {
 }
 
 // ---- optional per-kernel timing (bench.py's live roofline measurement) ----------------
-// A thread-local sink set by scl_prof_begin(); when present every launch is bracketed by
+// A process-wide sink set by scl_prof_begin(); when present every launch is bracketed by
 // HIP events on the launch stream.  No sink (the normal case) = plain launches.
 struct SclProfSink {
   int capacity;

@@ -1,10 +1,13 @@
 """Drop-in counterpart of the reference's ``model/nets.py``.
 
 ``vgg16Netvlad(image_batch)`` and ``vgg16(image_batch)`` keep the reference names and
-the NHWC / raw-0..255-RGB input convention (model/nets.py:7-69, :72-131).  The VGG16
-convolutions run on PyTorch-ROCm (MIOpen, channels-last; bf16 optional); the channel L2
-norm + NetVLAD head (model/nets.py:66-67) is one autograd op over the hand-written
-gfx950 kernels of csrc/netvlad.hip.
+the NHWC / raw-0..255-RGB input convention (model/nets.py:7-69, :72-131).  In bf16 mode every
+VGG16 convolution pass except the conv5_x forward runs on the hand-written implicit-GEMM
+kernels of csrc/conv64.hip and csrc/convg.hip (bias / ReLU / max-pool / ReLU' fused into their
+epilogues, float32 master weights read directly, weight gradients written straight into the
+flat gradient buffer); the conv5_x forward and the whole float32 mode use the library
+(MIOpen / CK) with the fused glue passes of csrc/vgg_glue.hip.  The channel L2 norm + NetVLAD
+head (model/nets.py:66-67) is one autograd op over the kernels of csrc/netvlad.hip.
 
 TF1 keeps variables in the graph scope ``vgg16_netvlad_pca``; here they live in a
 ``VGG16NetVLAD`` module.  ``state_dict_tf`` / ``load_state_dict_tf`` expose them under
