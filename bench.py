@@ -69,6 +69,9 @@ def parse():
                          'the warm-up and replay it for the timed steps; 0 (default): eager. '
                          'Measured on MI355X: 14.234 ms per step either way — the host runs ahead '
                          'of the device, the step is not launch-bound')
+    ap.add_argument('--variant', type=int, default=0,
+                    help='DIAGNOSTICS: scl_debug_set_variant value for A/B runs of kernel variants '
+                         'on one box (0 = production; anything else is not a benchmark result)')
     ap.add_argument('--stub-cpu', action='store_true',
                     help='TEST ONLY: gloo on CPU with a trivial stand-in step; exercises the '
                          'launcher, the barriers and the max-over-ranks timing, measures nothing')
@@ -370,6 +373,8 @@ def main():
     from soft_contrastive_learning_amd import _lib, parallel
     from soft_contrastive_learning_amd.model import losses, nets
     _lib.load()
+    if args.variant:
+        _lib.load().scl_debug_set_variant(args.variant)
 
     b, gb = args.batch, args.batch * world
     cdt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
@@ -541,6 +546,7 @@ def main():
                                   'how': 'device events at the step boundaries of the timed '
                                          'region (no host synchronisation inside it)'},
             'hip_graph': graph is not None,
+            'debug_variant': args.variant,
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,

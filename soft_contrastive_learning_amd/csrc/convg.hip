@@ -56,7 +56,7 @@ struct GCfg {
   static constexpr int GNI = (GCHUNKS + 7) / 8;       // per wave
   // two windows + two weight buffers; the epilogue's per-wave scratch reuses the windows
   static constexpr size_t LDS = (2 * (size_t)GWIN + 2 * TPB * (size_t)GWT) * 2;
-  static_assert(8 * GSCR <= 2 * GWIN, "epilogue scratch must fit the window buffers");
+  static_assert(8 * GSCR <= GWIN, "epilogue scratch must fit ONE window buffer");
 };
 
 // Lane -> pixel of a 4 x 8 m-tile.  The hardware serves a ds_read_b128 in the lane groups
@@ -136,7 +136,8 @@ __global__ __launch_bounds__(NTHR, 1) void convg_kernel(const unsigned short* __
                                                        unsigned short* __restrict__ out,
                                                        const float* __restrict__ bias, int relu,
                                                        const unsigned short* __restrict__ mask,
-                                                       unsigned char* __restrict__ pidx) {
+                                                       unsigned char* __restrict__ pidx,
+                                                       int vblocks) {
   using G = GCfg<BHv>;
   constexpr int BH = G::BH, GWR = G::GWR, GWIN = G::GWIN, NMT = G::NMT, MS = G::MS, NS = G::NS;
   constexpr int GCHUNKS = G::GCHUNKS, GNI = G::GNI;
@@ -145,34 +146,47 @@ __global__ __launch_bounds__(NTHR, 1) void convg_kernel(const unsigned short* __
   unsigned short* wts = lds + 2 * GWIN;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
-  unsigned short* scr = lds + wid * GSCR;             // after the K loop only
-  // XCD-aware order: workgroups are handed to the 8 XCDs round-robin by linear id, and every
-  // 128-channel output block nb of a pixel block reads the same windows — so the kb workgroups
-  // of a pixel block get ids 8 apart (same XCD, same moment): their window fetches meet in
-  // that XCD's L2 instead of going out to the Infinity Cache once per output block.
+  // epilogue scratch: window buffer 1 — a tile's last chunk (CC is even) — which is dead after
+  // the K loop; buffer 0 already receives the NEXT tile's first window by then
+  unsigned short* scr = lds + GWIN + wid * GSCR;
+  // PERSISTENT workgroups: block v of the virtual grid goes to workgroup v % gridDim.x.
+  // XCD-aware order of the virtual grid: workgroups are handed to the 8 XCDs round-robin by
+  // linear id, and every 128-channel output block nb of a pixel block reads the same windows —
+  // so the kb blocks of a pixel block get virtual ids 8 apart (same XCD, same moment, gridDim.x
+  // being a multiple of 8 kb): their window fetches meet in that XCD's L2 instead of going out
+  // to the Infinity Cache once per output block.
   const int kb = kout / NB;
   const int blocks_x = (W + BW - 1) / BW, blocks_y = (H + BH - 1) / BH;
-  const int grp = blockIdx.x / (8 * kb), rem = blockIdx.x - grp * 8 * kb;
-  const int nb = rem >> 3, pblk = grp * 8 + (rem & 7);
-  if (pblk >= B * blocks_x * blocks_y) return;          // padding of the last group of 8
-  const int b = pblk / (blocks_x * blocks_y), t2 = pblk % (blocks_x * blocks_y);
-  const int y0 = (t2 / blocks_x) * BH, x0 = (t2 % blocks_x) * BW;
   const int CC = cin / CCH, S = 9 * CC;
-  // Staging is LDS-DMA.  Weights: the packed image IS the LDS image, 20 chunks of 1 KB per
-  // step pair.  Window: lane l of chunk j owns slot 64 j + l = (pixel, piece), piece 4 the
-  // pad (not fetched); where that pixel lies in the image is fixed for the workgroup.
   const int wid_s = __builtin_amdgcn_readfirstlane(wid);
   const unsigned short* zeros = reinterpret_cast<const unsigned short*>(zero_block);
+  const int dbg = relu >> 1;            // timing diagnostics (scl_debug_set_variant(3000 + bits))
+  relu &= 1;
+  // Staging is LDS-DMA.  Weights: the packed image IS the LDS image, 20 chunks of 1 KB per
+  // step pair.  Window: lane l of chunk j owns slot 64 j + l = (pixel, piece), piece 4 the
+  // pad (not fetched); where that pixel lies in the image is fixed for a tile.
+  int nb = 0, b = 0, y0 = 0, x0 = 0;
   int woff[GNI];            // element offset at chunk 0; -1 outside the image; -2 not fetched
+  auto locate = [&](int vb) -> bool {                 // virtual block -> tile; false: padding
+    const int grp = vb / (8 * kb), rem = vb - grp * 8 * kb;
+    const int pblk = grp * 8 + (rem & 7);
+    nb = rem >> 3;
+    if (pblk >= B * blocks_x * blocks_y) return false;
+    b = pblk / (blocks_x * blocks_y);
+    const int t2 = pblk % (blocks_x * blocks_y);
+    y0 = (t2 / blocks_x) * BH;
+    x0 = (t2 % blocks_x) * BW;
 #pragma unroll
-  for (int i = 0; i < GNI; ++i) {
-    const int slot = 64 * (wid_s + 8 * i) + lane;
-    const int pix = slot / 5, piece = slot - 5 * pix;
-    const int y = y0 - 1 + pix / GWC, xx = x0 - 1 + pix % GWC;
-    const bool inimg = y >= 0 && y < H && xx >= 0 && xx < W;
-    woff[i] = (piece == 4 || pix >= GWR * GWC) ? -2
-              : inimg ? ((b * H + y) * W + xx) * cin + 8 * piece : -1;
-  }
+    for (int i = 0; i < GNI; ++i) {
+      const int slot = 64 * (wid_s + 8 * i) + lane;
+      const int pix = slot / 5, piece = slot - 5 * pix;
+      const int y = y0 - 1 + pix / GWC, xx = x0 - 1 + pix % GWC;
+      const bool inimg = y >= 0 && y < H && xx >= 0 && xx < W;
+      woff[i] = (piece == 4 || pix >= GWR * GWC) ? -2
+                : inimg ? ((b * H + y) * W + xx) * cin + 8 * piece : -1;
+    }
+    return true;
+  };
   auto issue_win = [&](int cc, int buf) {
     const unsigned base = lds_byte_of(win) + buf * GWIN * 2;
 #pragma unroll
@@ -191,16 +205,6 @@ __global__ __launch_bounds__(NTHR, 1) void convg_kernel(const unsigned short* __
       if (j < WCHK) glds16(src + j * 512, base + j * 1024);
     }
   };
-
-  f32x16 acc[MS * NS];                                // [m-tile slot][n-tile]
-#pragma unroll
-  for (int mt = 0; mt < MS * NS; ++mt) acc[mt] = zero16();
-
-  issue_wts(0, 0);
-  issue_win(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
   // Wave (mg, ng) of the 8 owns m-tiles 4 mg .. 4 mg + 3 (the block has 15: the last slot of
   // mg = 3 repeats tile 14 and is dropped in the epilogue) and output channels 64 ng .. + 63
   // (two n-tiles): 8 accumulators = 128 registers, so TWO waves share a SIMD and cover each
@@ -215,13 +219,29 @@ __global__ __launch_bounds__(NTHR, 1) void convg_kernel(const unsigned short* __
   }
   const int lane_a = (tile_row(r) * GWC + tile_col(r)) * GPIX + 8 * h;
   const int lane_b = (32 * NS * ng + r) * GPIX + 8 * h;
+
+  bool staged = false;      // the current tile's first weights + window are already in flight
+  for (int vb = blockIdx.x; vb < vblocks; vb += gridDim.x) {
+  if (!staged) {
+    if (!locate(vb)) continue;                          // padding of the last group of 8
+    issue_wts(0, 0);
+    issue_win(0, 0);
+  }
+  staged = false;
+  const int nb_t = nb, b_t = b, y0_t = y0, x0_t = x0;   // this tile (locate() moves on below)
+
+  f32x16 acc[MS * NS];                                // [m-tile slot][n-tile]
+#pragma unroll
+  for (int mt = 0; mt < MS * NS; ++mt) acc[mt] = zero16();
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();        // stage 0 landed; every wave is done with the previous tile's epilogue
+
   // S = 9 * CC steps in groups of three (one tap row of a chunk) per barrier.
   // The DMA of the next group's weights runs under this group; the window of chunk cc + 1 is
   // issued (after the weights) at tap row 0 of chunk cc and may stay in flight across this
   // group's barrier — the DMAs complete in order, so the counted wait below covers the weights
   // and the next group's full wait covers the window, two groups before it is read.
-  const int dbg = relu >> 1;            // timing diagnostics (scl_debug_set_variant(3000 + bits))
-  relu &= 1;
 #pragma unroll 1
   for (int s = 0; s < S; s += TPB) {
     if (s + TPB < S && !(dbg & 1)) issue_wts(s + TPB, ((s / TPB) + 1) & 1);
@@ -264,6 +284,19 @@ __global__ __launch_bounds__(NTHR, 1) void convg_kernel(const unsigned short* __
     __syncthreads();
   }
 
+  // The next tile's first weights and window go out NOW, under this tile's epilogue (with one
+  // workgroup per CU nothing else would cover their latency): every wave is past the K loop's
+  // last barrier, so window buffer 0 and weight buffer 0 are free; the epilogue's scratch lives
+  // in window buffer 1, which the next tile only refills after its first barrier.
+  {
+    const int vn = vb + gridDim.x;
+    if (vn < vblocks && locate(vn)) {
+      issue_wts(0, 0);
+      issue_win(0, 0);
+      staged = true;
+    }
+  }
+
   // epilogue: slot j <-> m-tile 4 mg + j, n <-> channels 64 ng + 32 n ..; accumulator register
   // q <-> pixel acc_row(q, h) of the tile, lane r <-> channel r of the n-tile
   if (EPI == 3) {
@@ -278,7 +311,7 @@ __global__ __launch_bounds__(NTHR, 1) void convg_kernel(const unsigned short* __
       const int mr = mt / 5, mc = mt % 5;
 #pragma unroll
       for (int n = 0; n < NS; ++n) {
-        const int ch = NB * nb + 32 * NS * ng + 32 * n + r;
+        const int ch = NB * nb_t + 32 * NS * ng + 32 * n + r;
         const float bias_r = bias[ch];
 #pragma unroll
         for (int q0 = 0; q0 < 16; q0 += 2) {
@@ -294,17 +327,16 @@ __global__ __launch_bounds__(NTHR, 1) void convg_kernel(const unsigned short* __
           const float m = fmaxf(mu, ml);
           const int k = mu >= ml ? iu : 2 + il;         // first maximum in raster order
           const int p0 = acc_row(q0, 0);                // the first-half lane's pixel
-          const int py = (y0 + 4 * mr + tile_row(p0)) >> 1, px = (x0 + 8 * mc + tile_col(p0)) >> 1;
+          const int py = (y0_t + 4 * mr + tile_row(p0)) >> 1, px = (x0_t + 8 * mc + tile_col(p0)) >> 1;
           if (h == 0 && py < PH && px < PW) {
-            const int64_t po = (((int64_t)b * PH + py) * PW + px) * kout + ch;
+            const int64_t po = (((int64_t)b_t * PH + py) * PW + px) * kout + ch;
             out[po] = f32_to_bf16(fmaxf(m + bias_r, 0.f));
             pidx[po] = (unsigned char)k;
           }
         }
       }
     }
-    return;
-  }
+  } else {
 #pragma unroll
   for (int j = 0; j < MS; ++j) {
     const int mt = MS * mg + j;
@@ -312,12 +344,12 @@ __global__ __launch_bounds__(NTHR, 1) void convg_kernel(const unsigned short* __
     const int mr = mt / 5, mc = mt % 5;
 #pragma unroll
     for (int n = 0; n < NS; ++n) {
-      const float bias_r = EPI == 1 ? bias[NB * nb + 32 * NS * ng + 32 * n + r] : 0.f;
+      const float bias_r = EPI == 1 ? bias[NB * nb_t + 32 * NS * ng + 32 * n + r] : 0.f;
       const int px = lane >> 1, hf = lane & 1;
-      const int oy = y0 + 4 * mr + tile_row(px), ox = x0 + 8 * mc + tile_col(px);
+      const int oy = y0_t + 4 * mr + tile_row(px), ox = x0_t + 8 * mc + tile_col(px);
       const bool inside = oy < H && ox < W;
       const int64_t o_off =
-          (((int64_t)b * H + oy) * W + ox) * kout + NB * nb + 32 * NS * ng + 32 * n + 8 * hf;
+          (((int64_t)b_t * H + oy) * W + ox) * kout + NB * nb_t + 32 * NS * ng + 32 * n + 8 * hf;
       // instruction i of the two covers channels 16 i + 8 hf .. + 7: a lane pair writes (and
       // reads the mask as) 32 contiguous bytes — whole sectors
       u32x4 y0v = u32x4{0u, 0u, 0u, 0u}, y1v = y0v;
@@ -345,6 +377,8 @@ __global__ __launch_bounds__(NTHR, 1) void convg_kernel(const unsigned short* __
       }
     }
   }
+  }   // EPI != 3
+  }   // persistent loop over this workgroup's tiles
 }
 
 }  // namespace
@@ -403,14 +437,23 @@ static int convg_dispatch(const void* x, const void* w, int64_t w_stride_k, int6
   const int64_t t12 = ((wg12 + cus - 1) / cus) * 12, t8 = ((wg8 + cus - 1) / cus) * 8;
   // scl_debug_set_variant(3012 / 3008) pins the block height (tests cover both variants)
   const bool low = scl_debug_variant == 3012 ? false : scl_debug_variant == 3008 ? true : t8 < t12;
-  const int dbgbits = scl_debug_variant / 1000 == 3 ? (scl_debug_variant & 3) << 1 : 0;
+  const int dbgbits = (scl_debug_variant >= 3001 && scl_debug_variant <= 3003) ? (scl_debug_variant & 3) << 1 : 0;
   const int64_t pblocks = (low ? wg8 : wg12) / kb;
-  const dim3 grid((unsigned)(((pblocks + 7) / 8) * 8 * kb));
+  const int vblocks = (int)(((pblocks + 7) / 8) * 8 * kb);      // virtual grid (XCD-aware order)
+  // persistent workgroups: one per CU (160 KB of LDS each), a multiple of 8 kb so that the
+  // virtual blocks that share windows stay 8 apart; scl_debug_set_variant(3100 + g) pins the
+  // grid to g groups of 8 kb (tests: several tiles per workgroup on small shapes)
+  int groups = cus / (8 * kb) > 0 ? cus / (8 * kb) : 1;
+  if (scl_debug_variant >= 3100 && scl_debug_variant < 3200) groups = scl_debug_variant - 3100 + 1;
+  int gsize = groups * 8 * kb;
+  if (gsize > vblocks) gsize = vblocks;
+  if (scl_debug_variant == 3099) gsize = vblocks;               // one tile per workgroup (A/B)
+  const dim3 grid((unsigned)gsize);
 #define SCL_CONVG_LAUNCH(E, BHV, BIAS, RELU, MASK)                                             \
   SCL_LAUNCH("convg_kernel", (convg_kernel<E, BHV>), grid, dim3(NTHR), GCfg<BHV>::LDS, st,     \
              (const unsigned short*)x, (const unsigned short*)packed, B, H, W, cin, kout,      \
              (unsigned short*)out, BIAS, RELU, (const unsigned short*)MASK,                    \
-             (unsigned char*)pidx)
+             (unsigned char*)pidx, vblocks)
   if (pidx) {
     if (low) SCL_CONVG_LAUNCH(3, 8, bias, 0, nullptr); else SCL_CONVG_LAUNCH(3, 12, bias, 0, nullptr);
   } else if (mask) {

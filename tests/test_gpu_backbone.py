@@ -539,3 +539,38 @@ def test_gradient_sink_gives_the_same_gradients(dev):
             assert torch.equal(grads[True][n], grads[False][n]), n
         else:
             assert _nrel(grads[True][n], grads[False][n]) < 1e-3, n
+
+
+def test_lds_weight_conv_persistent_workgroups_equal_one_tile_per_workgroup(dev):
+    """csrc/convg.hip runs persistent workgroups that prefetch the next tile's first stage under
+    the epilogue of the current one.  Every epilogue variant must give bit-identical results
+    with several tiles per workgroup (grid pinned to one group of 8 x kout/128, padding tiles
+    included) and with one tile per workgroup."""
+    from soft_contrastive_learning_amd import _lib as L
+    from soft_contrastive_learning_amd.model import nets
+    lib = L.load()
+    g = torch.Generator().manual_seed(41)
+    b, h, w, cin, cout = 3, 36, 80, 128, 256
+    x = torch.randn(b, cin, h, w, generator=g).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(b, cout, h, w, generator=g).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * 0.03).to(dev).bfloat16().contiguous(
+        memory_format=torch.channels_last)
+    bias = torch.randn(cout, generator=g).to(dev)
+    mask = torch.randn(b, cin, h, w, generator=g).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+
+    def run_all():
+        return (nets.conv64(x, wt, False), nets.conv64(x, wt, False, bias=bias, relu=True),
+                nets.conv64(gy, wt, True), nets.conv64(gy, wt, True, mask=mask),
+                *nets.conv_pool_idx(x, wt, bias))
+    outs = {}
+    for variant in (3099, 3100, 3101, 0):
+        old = lib.scl_debug_set_variant(variant)
+        try:
+            outs[variant] = [t.clone() for t in run_all()]
+        finally:
+            lib.scl_debug_set_variant(old)
+    for variant in (3100, 3101, 0):
+        for a, bb in zip(outs[3099], outs[variant]):
+            assert torch.equal(a, bb), variant
+    z32 = torch.nn.functional.conv2d(x.float(), wt.float(), padding=1)
+    assert float((outs[0][0].float() - z32).abs().max()) < 6e-3 * float(z32.abs().max())
