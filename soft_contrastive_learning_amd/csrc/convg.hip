@@ -415,6 +415,17 @@ static int convg_dispatch(const void* x, const void* w, int64_t w_stride_k, int6
   if (((uintptr_t)x % 16) || ((uintptr_t)out % 16)) return SCL_E_SHAPE;
   if ((int64_t)B * H * W * cin >= (int64_t)1 << 31) return SCL_E_SHAPE;   // 32-bit offsets
   if (!scl_aligned256(workspace) || workspace_bytes < need) return SCL_E_WORKSPACE;
+  // scl_debug_set_variant(4000 + v) pins this (32x32x16) kernel, 5000 + v the 16x16x32 one of
+  // convh.hip, each with the diagnostic variant v of the list below; plain v = the default kernel
+  int dv = scl_debug_variant;
+  bool use_h = SCL_CONVH_DEFAULT;
+  if (dv >= 4000 && dv < 6000) {
+    use_h = dv >= 5000;
+    dv -= use_h ? 5000 : 4000;
+  }
+  if (use_h)
+    return scl_convh_dispatch(x, w, w_stride_k, w_stride_c, w_stride_h, w_stride_w, transposed, B, H,
+                              W, cin, kout, out, bias, relu, mask, pidx, workspace, dv, stream);
   static std::once_flag once;
   std::call_once(once, [] {
 #define SCL_CONVG_ATTR(E, BHV)                                                                 \
@@ -436,18 +447,18 @@ static int convg_dispatch(const void* x, const void* w, int64_t w_stride_k, int6
   // rounds of workgroups (one per CU) x rows per block = time in units of a block row
   const int64_t t12 = ((wg12 + cus - 1) / cus) * 12, t8 = ((wg8 + cus - 1) / cus) * 8;
   // scl_debug_set_variant(3012 / 3008) pins the block height (tests cover both variants)
-  const bool low = scl_debug_variant == 3012 ? false : scl_debug_variant == 3008 ? true : t8 < t12;
-  const int dbgbits = (scl_debug_variant >= 3001 && scl_debug_variant <= 3003) ? (scl_debug_variant & 3) << 1 : 0;
+  const bool low = dv == 3012 ? false : dv == 3008 ? true : t8 < t12;
+  const int dbgbits = (dv >= 3001 && dv <= 3003) ? (dv & 3) << 1 : 0;
   const int64_t pblocks = (low ? wg8 : wg12) / kb;
   const int vblocks = (int)(((pblocks + 7) / 8) * 8 * kb);      // virtual grid (XCD-aware order)
   // persistent workgroups: one per CU (160 KB of LDS each), a multiple of 8 kb so that the
   // virtual blocks that share windows stay 8 apart; scl_debug_set_variant(3100 + g) pins the
   // grid to g groups of 8 kb (tests: several tiles per workgroup on small shapes)
   int groups = cus / (8 * kb) > 0 ? cus / (8 * kb) : 1;
-  if (scl_debug_variant >= 3100 && scl_debug_variant < 3200) groups = scl_debug_variant - 3100 + 1;
+  if (dv >= 3100 && dv < 3200) groups = dv - 3100 + 1;
   int gsize = groups * 8 * kb;
   if (gsize > vblocks) gsize = vblocks;
-  if (scl_debug_variant == 3099) gsize = vblocks;               // one tile per workgroup (A/B)
+  if (dv == 3099) gsize = vblocks;               // one tile per workgroup (A/B)
   const dim3 grid((unsigned)gsize);
 #define SCL_CONVG_LAUNCH(E, BHV, BIAS, RELU, MASK)                                             \
   SCL_LAUNCH("convg_kernel", (convg_kernel<E, BHV>), grid, dim3(NTHR), GCfg<BHV>::LDS, st,     \

@@ -1,0 +1,399 @@
+// The LDS-weights 3x3 convolution of convg.hip on v_mfma_f32_16x16x32_bf16.
+//
+// Same decomposition (workgroup = [12 or 8 rows x 40 cols] of output pixels x 128 output
+// channels, eight waves, K loop over (32-channel chunk, tap) in groups of three behind one
+// barrier, windows and weights by LDS-DMA, persistent workgroups that prefetch the next tile's
+// first stage under the epilogue), but the 16x16x32 shape: at equal FLOP per cycle and equal
+// fragment traffic the chip holds a higher clock on it (bare LDS-fed loop on random operands,
+// scripts/mfma_shape_bf16.hip: 1.68 vs 1.57 PFLOP/s).  What changes with the shape:
+//   * one MFMA k-step = the whole 32-channel chunk of a tap: A fragment of lane (i, g) = the 16
+//     bytes (channels 8 g .. + 7) of pixel i of a 16-pixel m-tile, B fragment = 16 bytes of a
+//     weight row;
+//   * an m-tile is 2 rows x 8 columns.  Lanes 0-3 / 12-15 take the upper row, 4-11 the lower:
+//     with 96-byte window pixels (64 data + 32 pad) and 42-column windows every ds_read_b128
+//     service group ({0-3, 12-15, 20-27}, ...) then hits 16 different 16-byte slots for every
+//     tap and tile column (checked exhaustively); 80-byte pixels admit no such map;
+//   * weights are stored piece-major — unit (piece g * 128 + row) of 16 bytes — so the slot of a
+//     B fragment is the row modulo 16 = the lane's i: conflict-free without padding (8 KB per
+//     step instead of 10), which is what pays for the wider pixels: 2 x 57,344 B of windows +
+//     2 x 3 x 8,192 B of weights = 163,840 B, all of the LDS;
+//   * accumulator register q of lane (c, g') is pixel 4 g' + q, channel c: a 2x2 pooling window
+//     is registers (q, q + 1) of lanes l and l ^ 16 — one cross-lane exchange per window.
+#include <mutex>
+
+#include "scl_common.h"
+
+namespace {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int HBW = 40;                      // output block width
+constexpr int HWC = HBW + 2;                 // window columns
+constexpr int HPIX = 48;                     // bf16 per staged pixel (96 B: 64 data + 32 pad)
+constexpr int HCCH = 32;                     // channels per chunk = one MFMA k-step
+constexpr int HNB = 128;                     // output channels per workgroup
+constexpr int HTPB = 3;                      // (chunk, tap) steps per barrier
+constexpr int HWT = 4 * HNB * 8;             // bf16 per weight step image (8 KB)
+constexpr int HTHR = 512;
+
+template <int BHv>
+struct HCfg {
+  static constexpr int BH = BHv;
+  static constexpr int WR = BH + 2;                          // window rows
+  static constexpr int SLOTS = WR * HWC * 6;                 // 16-byte slots of a window
+  static constexpr int CHUNKS = (SLOTS + 63) / 64;           // 1-KB DMA chunks
+  static constexpr int NI = CHUNKS / 8;                      // per wave (56 / 8, 40 / 8)
+  static_assert(CHUNKS % 8 == 0, "every wave issues the same number of window chunks");
+  static constexpr int WIN = CHUNKS * 512;                   // bf16 per window buffer
+  static constexpr int NMT = BH / 2 * 5;                     // 2 x 8 m-tiles of the block
+  static constexpr int MT = BH == 12 ? 8 : 10;               // m-tiles per wave
+  static constexpr int NT = BH == 12 ? 4 : 2;                // 16-channel n-tiles per wave
+  static constexpr int MH = MT / 2;                          // m-tiles per half step
+  static constexpr int SLD = 16 * NT + 8;                    // epilogue scratch row (bf16)
+  static constexpr size_t LDS = (2 * (size_t)WIN + 2 * HTPB * (size_t)HWT) * 2;
+  static_assert(8 * 16 * SLD <= WIN, "epilogue scratch must fit one window buffer");
+};
+
+// pixel of m-tile row i: lanes 0-3 and 12-15 the upper row, 4-11 the lower (see header)
+__device__ __forceinline__ int ht_row(int i) { return (i >= 4 && i < 12) ? 1 : 0; }
+__device__ __forceinline__ int ht_col(int i) { return i < 4 ? i : i < 8 ? i - 4 : i < 12 ? i - 4 : i - 8; }
+
+__device__ __forceinline__ f32x4 mfma16h(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                 __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// Weights -> [n-block][chunk][tap][piece g][k 128][8 channels] bf16: the LDS image of a step
+// (8 KB), three consecutive steps = one group, copied by LDS-DMA as they lie.
+__global__ __launch_bounds__(256) void convh_pack_kernel(const void* __restrict__ w, int64_t sk,
+                                                         int64_t sc, int64_t sh, int64_t sw,
+                                                         int flags, int cin, int kout,
+                                                         unsigned short* __restrict__ packed) {
+  const int transposed = flags & 1, wf32 = flags & 2;   // SCL_CONV_TRANSPOSED | SCL_W_F32
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)9 * (cin / HCCH) * kout * HCCH;
+  if (idx >= total) return;
+  const int e = idx & 7, k = (idx >> 3) & 127, g = (idx >> 10) & 3;
+  const int64_t rest = idx >> 12;                      // (nb * CC + cc) * 9 + tap
+  const int tap = rest % 9;
+  const int cc = (rest / 9) % (cin / HCCH), nb = rest / 9 / (cin / HCCH);
+  const int kh = tap / 3, kw = tap % 3;
+  const int ci = HCCH * cc + 8 * g + e, co = HNB * nb + k;
+  int64_t off;
+  if (!transposed)
+    off = co * sk + ci * sc + kh * sh + kw * sw;
+  else
+    off = ci * sk + co * sc + (2 - kh) * sh + (2 - kw) * sw;
+  packed[idx] = weight_bf16(w, off, wf32);
+}
+
+__device__ uint4 h_zero_block[4];                      // never written: zeros
+
+__device__ __forceinline__ void hglds16(const unsigned short* src, unsigned lds_byte) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(src), "s"(lds_byte)
+      : "memory");
+}
+__device__ __forceinline__ unsigned h_lds_byte_of(const unsigned short* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned short*)p;
+}
+
+// grid: persistent workgroups over `vblocks` virtual blocks; block 512.  EPI as convg_kernel:
+// 0 plain, 1 + bias (+ ReLU), 2 out = conv * [mask > 0], 3 pooled + window index.
+template <int EPI, int BHv>
+__global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __restrict__ x,
+                                                       const unsigned short* __restrict__ packed,
+                                                       int B, int H, int W, int cin, int kout,
+                                                       unsigned short* __restrict__ out,
+                                                       const float* __restrict__ bias, int relu,
+                                                       const unsigned short* __restrict__ mask,
+                                                       unsigned char* __restrict__ pidx,
+                                                       int vblocks) {
+  using G = HCfg<BHv>;
+  constexpr int BH = G::BH, WR = G::WR, WIN = G::WIN, NMT = G::NMT, MT = G::MT, NT = G::NT;
+  constexpr int MH = G::MH, NI = G::NI, SLD = G::SLD;
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+  unsigned short* win = lds;
+  unsigned short* wts = lds + 2 * WIN;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, g = lane >> 4;
+  unsigned short* scr = lds + WIN + wid * (16 * SLD);   // window buffer 1: dead after the K loop
+  const int kb = kout / HNB;
+  const int blocks_x = (W + HBW - 1) / HBW, blocks_y = (H + BH - 1) / BH;
+  const int CC = cin / HCCH, S = 9 * CC;
+  const unsigned short* zeros = reinterpret_cast<const unsigned short*>(h_zero_block);
+  int nb = 0, b = 0, y0 = 0, x0 = 0;
+  int woff[NI];             // element offset at chunk 0; -1 outside the image; -2 not fetched
+  auto locate = [&](int vb) -> bool {
+    const int grp = vb / (8 * kb), rem = vb - grp * 8 * kb;
+    const int pblk = grp * 8 + (rem & 7);
+    nb = rem >> 3;
+    if (pblk >= B * blocks_x * blocks_y) return false;
+    b = pblk / (blocks_x * blocks_y);
+    const int t2 = pblk % (blocks_x * blocks_y);
+    y0 = (t2 / blocks_x) * BH;
+    x0 = (t2 % blocks_x) * HBW;
+#pragma unroll
+    for (int n = 0; n < NI; ++n) {
+      const int slot = 64 * (wid + 8 * n) + lane;
+      const int pix = slot / 6, piece = slot - 6 * pix;
+      const int y = y0 - 1 + pix / HWC, xx = x0 - 1 + pix % HWC;
+      const bool inimg = y >= 0 && y < H && xx >= 0 && xx < W;
+      woff[n] = (piece >= 4 || pix >= WR * HWC) ? -2
+                : inimg ? ((b * H + y) * W + xx) * cin + 8 * piece : -1;
+    }
+    return true;
+  };
+  auto issue_win = [&](int cc, int buf) {
+    const unsigned base = h_lds_byte_of(win) + buf * WIN * 2;
+#pragma unroll
+    for (int n = 0; n < NI; ++n) {
+      const int j = wid + 8 * n;
+      if (woff[n] != -2) hglds16(woff[n] >= 0 ? x + woff[n] + HCCH * cc : zeros, base + j * 1024);
+    }
+  };
+  auto issue_wts = [&](int s, int buf) {                // three steps = 24 chunks, 3 per wave
+    const unsigned short* src = packed + ((int64_t)nb * S + s) * HWT + lane * 8;
+    const unsigned base = h_lds_byte_of(wts) + buf * HTPB * HWT * 2;
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+      const int j = wid + 8 * n;
+      hglds16(src + j * 512, base + j * 1024);
+    }
+  };
+  // wave (mg, ng): m-tiles MT mg .. + MT - 1 (2 x 8 pixels each, 5 per row pair), channels
+  // 16 NT ng .. + 16 NT - 1
+  const int mg = BH == 12 ? wid >> 1 : wid >> 2, ng = BH == 12 ? wid & 1 : wid & 3;
+  int aoff[MT];
+#pragma unroll
+  for (int j = 0; j < MT; ++j) {
+    const int mt = MT * mg + j < NMT ? MT * mg + j : NMT - 1;
+    aoff[j] = ((2 * (mt / 5)) * HWC + 8 * (mt % 5)) * HPIX;
+  }
+  const int lane_a = (ht_row(i) * HWC + ht_col(i)) * HPIX + 8 * g;
+  const int lane_b = (g * HNB + 16 * NT * ng + i) * 8;
+
+  bool staged = false;
+  for (int vb = blockIdx.x; vb < vblocks; vb += gridDim.x) {
+    if (!staged) {
+      if (!locate(vb)) continue;
+      issue_wts(0, 0);
+      issue_win(0, 0);
+    }
+    staged = false;
+    const int nb_t = nb, b_t = b, y0_t = y0, x0_t = x0;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[j][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+#pragma unroll 1
+    for (int s = 0; s < S; s += HTPB) {
+      if (s + HTPB < S) issue_wts(s + HTPB, ((s / HTPB) + 1) & 1);
+      const int cc0 = s / 9, tap0 = s - 9 * cc0;
+      const bool win_issued = tap0 == 0 && cc0 + 1 < CC;
+      if (win_issued) issue_win(cc0 + 1, (cc0 + 1) & 1);
+      // 2 HTPB half steps (tap u = hs / 2, m-tile half hs % 2): MH A + NT B fragment reads for
+      // MH * NT MFMAs; the fragments of half step hs + 1 fly under the MFMAs of hs
+      u32x4 af[2][MH], bf[2][NT];
+      auto load_half = [&](int hs, u32x4 (&a4)[MH], u32x4 (&b4)[NT]) {
+        const int u = hs >> 1, mh = hs & 1;
+        const int su = s + u;
+        const int cc = su / 9, tap = su - 9 * cc;
+        const unsigned short* wa =
+            win + (cc & 1) * WIN + lane_a + ((tap / 3) * HWC + tap % 3) * HPIX;
+        const unsigned short* wbp = wts + (((s / HTPB) & 1) * HTPB + u) * HWT + lane_b;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) b4[n] = *reinterpret_cast<const u32x4*>(wbp + 16 * n * 8);
+#pragma unroll
+        for (int j = 0; j < MH; ++j) a4[j] = *reinterpret_cast<const u32x4*>(wa + aoff[MH * mh + j]);
+      };
+      load_half(0, af[0], bf[0]);
+#pragma unroll
+      for (int hs = 0; hs < 2 * HTPB; ++hs) {
+        if (hs + 1 < 2 * HTPB) load_half(hs + 1, af[(hs + 1) & 1], bf[(hs + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        const int mh = hs & 1;
+#pragma unroll
+        for (int j = 0; j < MH; ++j)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+            acc[MH * mh + j][n] = mfma16h(af[hs & 1][j], bf[hs & 1][n], acc[MH * mh + j][n]);
+      }
+      if (!win_issued)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+      __syncthreads();
+    }
+
+    // next tile's first stage under this tile's epilogue (see convg.hip)
+    {
+      const int vn = vb + gridDim.x;
+      if (vn < vblocks && locate(vn)) {
+        issue_wts(0, 0);
+        issue_win(0, 0);
+        staged = true;
+      }
+    }
+
+    // epilogue.  Accumulator register q of lane (c = lane & 15, g' = lane >> 4) of tile (j, n):
+    // pixel 4 g' + q of the m-tile (row ht_row, column ht_col), channel 16 n + c of the wave.
+    const int c = i, gq = g;
+    if (EPI == 3) {
+      // registers (0,1) and (2,3) are the two pooling windows of this lane's row quad; the other
+      // row of both windows sits in lane l ^ 16 under the same registers
+      const int PH = H / 2, PW = W / 2;
+      const bool upper = gq == 0 || gq == 3;
+      const int cb = gq < 2 ? 0 : 4;                       // column base of this lane's quad
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        const int mt = MT * mg + j;
+        if (mt >= NMT) break;                              // wave-uniform
+        const int mr = mt / 5, mc = mt % 5;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const int ch = HNB * nb_t + 16 * NT * ng + 16 * n + c;
+          const float bias_r = bias[ch];
+#pragma unroll
+          for (int q0 = 0; q0 < 4; q0 += 2) {
+            const float v0 = acc[j][n][q0], v1 = acc[j][n][q0 + 1];
+            const float lm = fmaxf(v0, v1);
+            const int li = v0 >= v1 ? 0 : 1;
+            const float om = __shfl_xor(lm, 16);
+            const int oi = __shfl_xor(li, 16);
+            const float mu = upper ? lm : om, ml = upper ? om : lm;
+            const int iu = upper ? li : oi, il = upper ? oi : li;
+            const float m = fmaxf(mu, ml);
+            const int k = mu >= ml ? iu : 2 + il;          // first maximum in raster order
+            const int py = (y0_t + 2 * mr) >> 1, px = (x0_t + 8 * mc + cb + q0) >> 1;
+            if (upper && py < PH && px < PW) {
+              const int64_t po = (((int64_t)b_t * PH + py) * PW + px) * kout + ch;
+              out[po] = f32_to_bf16(fmaxf(m + bias_r, 0.f));
+              pidx[po] = (unsigned char)k;
+            }
+          }
+        }
+      }
+    } else {
+      constexpr int PCS = 2 * NT;                          // 16-byte pieces per pixel of the wave
+      constexpr int RR = 16 * PCS / 64;                    // pieces per lane (2 or 1)
+#pragma unroll
+      for (int j = 0; j < MT; ++j) {
+        const int mt = MT * mg + j;
+        if (mt >= NMT) break;                              // wave-uniform
+        const int mr = mt / 5, mc = mt % 5;
+        int64_t o_off[RR];
+        bool inside[RR];
+        u32x4 mk[RR];
+#pragma unroll
+        for (int rr = 0; rr < RR; ++rr) {
+          const int p = lane + 64 * rr, pe = p / PCS, pc = p % PCS;
+          const int oy = y0_t + 2 * mr + ht_row(pe), ox = x0_t + 8 * mc + ht_col(pe);
+          inside[rr] = oy < H && ox < W;
+          o_off[rr] = (((int64_t)b_t * H + oy) * W + ox) * kout + HNB * nb_t + 16 * NT * ng + 8 * pc;
+          mk[rr] = u32x4{0u, 0u, 0u, 0u};
+          if (EPI == 2 && inside[rr]) mk[rr] = *reinterpret_cast<const u32x4*>(mask + o_off[rr]);
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const float bias_r = EPI == 1 ? bias[HNB * nb_t + 16 * NT * ng + 16 * n + c] : 0.f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float v = acc[j][n][q] + bias_r;
+            if (EPI == 1 && relu) v = fmaxf(v, 0.f);
+            scr[(4 * gq + q) * SLD + 16 * n + c] = f32_to_bf16(v);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int rr = 0; rr < RR; ++rr) {
+          const int p = lane + 64 * rr, pe = p / PCS, pc = p % PCS;
+          u32x4 v = *reinterpret_cast<const u32x4*>(scr + pe * SLD + 8 * pc);
+          if (EPI == 2) v = relu_mask(v, mk[rr]);
+          if (inside[rr]) *reinterpret_cast<u32x4*>(out + o_off[rr]) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }   // persistent loop
+}
+
+int convh_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, c = 0;
+    n = (hipGetDevice(&dev) == hipSuccess &&
+         hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0)
+            ? c : 256;
+  }
+  return n;
+}
+
+}  // namespace
+
+// Same contract as convg_dispatch (convg.hip), which validates the arguments and calls this
+// (dv = the diagnostic variant: 3008 / 3012 block height, 3099 one tile per workgroup,
+// 3100 + g grid of g + 1 groups).  The packed weights fit the workspace
+// of scl_convg_workspace_bytes (8 KB per step instead of 10).
+int scl_convh_dispatch(const void* x, const void* w, int64_t w_stride_k, int64_t w_stride_c,
+                       int64_t w_stride_h, int64_t w_stride_w, int flags, int B, int H, int W,
+                       int cin, int kout, void* out, const float* bias, int relu, const void* mask,
+                       void* pidx, void* workspace, int dv, void* stream) {
+  static std::once_flag once;
+  std::call_once(once, [] {
+#define SCL_CONVH_ATTR(E, BHV)                                                                 \
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convh_kernel<E, BHV>),              \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)HCfg<BHV>::LDS);
+    SCL_CONVH_ATTR(0, 12) SCL_CONVH_ATTR(1, 12) SCL_CONVH_ATTR(2, 12) SCL_CONVH_ATTR(3, 12)
+    SCL_CONVH_ATTR(0, 8) SCL_CONVH_ATTR(1, 8) SCL_CONVH_ATTR(2, 8) SCL_CONVH_ATTR(3, 8)
+#undef SCL_CONVH_ATTR
+  });
+  hipStream_t st = (hipStream_t)stream;
+  unsigned short* packed = (unsigned short*)workspace;
+  const int64_t total = (int64_t)9 * (cin / HCCH) * kout * HCCH;
+  SCL_LAUNCH("convg_pack_kernel", convh_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256),
+             0, st, w, w_stride_k, w_stride_c, w_stride_h, w_stride_w, flags, cin, kout, packed);
+  const int bx = (W + HBW - 1) / HBW, kb = kout / HNB;
+  const int64_t wg12 = (int64_t)B * ((H + 11) / 12) * bx * kb, wg8 = (int64_t)B * ((H + 7) / 8) * bx * kb;
+  const int cus = convh_cus();
+  const int64_t t12 = ((wg12 + cus - 1) / cus) * 12, t8 = ((wg8 + cus - 1) / cus) * 8;
+  const bool low = dv == 3012 ? false : dv == 3008 ? true : t8 < t12;
+  const int64_t pblocks = (low ? wg8 : wg12) / kb;
+  const int vblocks = (int)(((pblocks + 7) / 8) * 8 * kb);
+  int groups = cus / (8 * kb) > 0 ? cus / (8 * kb) : 1;
+  if (dv >= 3100 && dv < 3200) groups = dv - 3100 + 1;
+  int gsize = groups * 8 * kb;
+  if (gsize > vblocks) gsize = vblocks;
+  if (dv == 3099) gsize = vblocks;
+  const dim3 grid((unsigned)gsize);
+#define SCL_CONVH_LAUNCH(E, BHV, BIAS, RELU, MASK)                                             \
+  SCL_LAUNCH("convg_kernel", (convh_kernel<E, BHV>), grid, dim3(HTHR), HCfg<BHV>::LDS, st,     \
+             (const unsigned short*)x, (const unsigned short*)packed, B, H, W, cin, kout,      \
+             (unsigned short*)out, BIAS, RELU, (const unsigned short*)MASK,                    \
+             (unsigned char*)pidx, vblocks)
+  if (pidx) {
+    if (low) SCL_CONVH_LAUNCH(3, 8, bias, 0, nullptr); else SCL_CONVH_LAUNCH(3, 12, bias, 0, nullptr);
+  } else if (mask) {
+    if (low) SCL_CONVH_LAUNCH(2, 8, bias, 0, mask); else SCL_CONVH_LAUNCH(2, 12, bias, 0, mask);
+  } else if (bias) {
+    if (low) SCL_CONVH_LAUNCH(1, 8, bias, relu ? 1 : 0, nullptr);
+    else SCL_CONVH_LAUNCH(1, 12, bias, relu ? 1 : 0, nullptr);
+  } else {
+    if (low) SCL_CONVH_LAUNCH(0, 8, bias, 0, nullptr);
+    else SCL_CONVH_LAUNCH(0, 12, bias, 0, nullptr);
+  }
+#undef SCL_CONVH_LAUNCH
+  return scl_launch_status();
+}

@@ -213,6 +213,14 @@ extern SclProfSink* volatile scl_prof_sink;
 // diagnostic kernel variant selector (0 = production kernels); set by scl_debug_set_variant
 extern volatile int scl_debug_variant;
 
+// 3x3 convolution with LDS-resident weights on v_mfma_f32_16x16x32_bf16 (convh.hip); arguments
+// already validated by convg_dispatch (convg.hip)
+#define SCL_CONVH_DEFAULT true
+int scl_convh_dispatch(const void* x, const void* w, int64_t w_stride_k, int64_t w_stride_c,
+                       int64_t w_stride_h, int64_t w_stride_w, int flags, int B, int H, int W,
+                       int cin, int kout, void* out, const float* bias, int relu, const void* mask,
+                       void* pidx, void* workspace, int dv, void* stream);
+
 static inline int scl_launch_status() { return (int)hipGetLastError(); }
 static inline bool scl_aligned256(const void* p) { return (((uintptr_t)p) & 255u) == 0; }
 static inline size_t scl_round256(size_t n) { return (n + 255u) & ~(size_t)255u; }

@@ -230,12 +230,24 @@ def test_own_conv_fused_tails(dev, cin, cout, shape):
     assert float((a.float() - want_a).abs().max()) < 6e-3 * scale
 
 
+@pytest.fixture(params=['mfma32x32x16', 'mfma16x16x32'])
+def lds_kernel(request):
+    """Pins which of the two LDS-weights convolution kernels runs (csrc/convg.hip: 4000 + v,
+    csrc/convh.hip: 5000 + v); yields the variant base for tests that add their own v."""
+    from soft_contrastive_learning_amd import _lib as L
+    lib = L.load()
+    base = 4000 if request.param == 'mfma32x32x16' else 5000
+    old = lib.scl_debug_set_variant(base)
+    yield base
+    lib.scl_debug_set_variant(old)
+
+
 @pytest.fixture
-def block_height(request):
+def block_height(request, lds_kernel):
     """Pins the LDS-weights kernel's block height (12 or 8 rows) for one test."""
     from soft_contrastive_learning_amd import _lib as L
     lib = L.load()
-    old = lib.scl_debug_set_variant(3000 + request.param)
+    old = lib.scl_debug_set_variant(lds_kernel + 3000 + request.param)
     yield request.param
     lib.scl_debug_set_variant(old)
 
@@ -417,7 +429,7 @@ def test_first_layer_weight_and_bias_gradient(dev, shape):
 
 @pytest.mark.parametrize('cin,shape', [(64, (2, 16, 40)), (128, (1, 10, 38)), (64, (1, 13, 37)),
                                        (256, (1, 24, 80)), (512, (1, 13, 37)), (256, (2, 8, 40))])
-def test_pool_index_epilogue_and_its_backward(dev, cin, shape):
+def test_pool_index_epilogue_and_its_backward(dev, cin, shape, lds_kernel):
     """scl_conv3x3_pool_idx + scl_vgg_pool_bwd_idx: pooled map as the fused-tail kernel gives
     it, every stored position points at a maximum of its window, and the backward routes
     g * [a > 0] there (and only there)."""
@@ -461,7 +473,7 @@ def test_pool_index_epilogue_and_its_backward(dev, cin, shape):
 
 @pytest.mark.parametrize('cin,cout,shape', [(64, 64, (1, 16, 40)), (128, 128, (1, 9, 33)),
                                             (256, 256, (1, 12, 40)), (128, 256, (1, 30, 40))])
-def test_float32_master_weights_equal_the_bf16_cast(dev, cin, cout, shape):
+def test_float32_master_weights_equal_the_bf16_cast(dev, cin, cout, shape, lds_kernel):
     """SCL_W_F32: the kernels round the float32 weight to bf16 while packing — results must be
     bit-identical to passing the bf16 cast, and the float32 weight gradient must round to the
     bf16 one."""
@@ -541,8 +553,8 @@ def test_gradient_sink_gives_the_same_gradients(dev):
             assert _nrel(grads[True][n], grads[False][n]) < 1e-3, n
 
 
-def test_lds_weight_conv_persistent_workgroups_equal_one_tile_per_workgroup(dev):
-    """csrc/convg.hip runs persistent workgroups that prefetch the next tile's first stage under
+def test_lds_weight_conv_persistent_workgroups_equal_one_tile_per_workgroup(dev, lds_kernel):
+    """csrc/convg.hip and csrc/convh.hip run persistent workgroups that prefetch the next tile's first stage under
     the epilogue of the current one.  Every epilogue variant must give bit-identical results
     with several tiles per workgroup (grid pinned to one group of 8 x kout/128, padding tiles
     included) and with one tile per workgroup."""
@@ -564,7 +576,7 @@ def test_lds_weight_conv_persistent_workgroups_equal_one_tile_per_workgroup(dev)
                 *nets.conv_pool_idx(x, wt, bias))
     outs = {}
     for variant in (3099, 3100, 3101, 0):
-        old = lib.scl_debug_set_variant(variant)
+        old = lib.scl_debug_set_variant(lds_kernel + variant)
         try:
             outs[variant] = [t.clone() for t in run_all()]
         finally:
