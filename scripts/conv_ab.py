@@ -28,7 +28,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--iters', type=int, default=10)
     ap.add_argument('--batch', type=int, default=24)
-    ap.add_argument('--variants', default='4000,5000')
+    ap.add_argument('--variants', default='40000,50000')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     lib = _lib.load()

@@ -415,13 +415,13 @@ static int convg_dispatch(const void* x, const void* w, int64_t w_stride_k, int6
   if (((uintptr_t)x % 16) || ((uintptr_t)out % 16)) return SCL_E_SHAPE;
   if ((int64_t)B * H * W * cin >= (int64_t)1 << 31) return SCL_E_SHAPE;   // 32-bit offsets
   if (!scl_aligned256(workspace) || workspace_bytes < need) return SCL_E_WORKSPACE;
-  // scl_debug_set_variant(4000 + v) pins this (32x32x16) kernel, 5000 + v the 16x16x32 one of
+  // scl_debug_set_variant(40000 + v) pins this (32x32x16) kernel, 50000 + v the 16x16x32 one of
   // convh.hip, each with the diagnostic variant v of the list below; plain v = the default kernel
   int dv = scl_debug_variant;
   bool use_h = SCL_CONVH_DEFAULT;
-  if (dv >= 4000 && dv < 6000) {
-    use_h = dv >= 5000;
-    dv -= use_h ? 5000 : 4000;
+  if (dv >= 40000 && dv < 60000) {
+    use_h = dv >= 50000;
+    dv -= use_h ? 50000 : 40000;
   }
   if (use_h)
     return scl_convh_dispatch(x, w, w_stride_k, w_stride_c, w_stride_h, w_stride_w, transposed, B, H,

@@ -50,9 +50,7 @@ struct HCfg {
   static constexpr int MT = BH == 12 ? 8 : 10;               // m-tiles per wave
   static constexpr int NT = BH == 12 ? 4 : 2;                // 16-channel n-tiles per wave
   static constexpr int MH = MT / 2;                          // m-tiles per half step
-  static constexpr int SLD = 16 * NT + 8;                    // epilogue scratch row (bf16)
   static constexpr size_t LDS = (2 * (size_t)WIN + 2 * HTPB * (size_t)HWT) * 2;
-  static_assert(8 * 16 * SLD <= WIN, "epilogue scratch must fit one window buffer");
 };
 
 // pixel of m-tile row i: lanes 0-3 and 12-15 the upper row, 4-11 the lower (see header)
@@ -105,6 +103,13 @@ __device__ __forceinline__ unsigned h_lds_byte_of(const unsigned short* p) {
 
 // grid: persistent workgroups over `vblocks` virtual blocks; block 512.  EPI as convg_kernel:
 // 0 plain, 1 + bias (+ ReLU), 2 out = conv * [mask > 0], 3 pooled + window index.
+//
+// EPI 0..2 run the MFMA with the operands swapped (weights as A, pixels as B): accumulator
+// register q of lane (p = lane & 15, g' = lane >> 4) is then pixel p, channel 4 g' + q of the
+// n-tile — four consecutive channels, i.e. 8 bytes of the channels-last output, stored straight
+// from the registers (a 16-pixel store instruction writes 16 whole 32-byte sectors); no LDS
+// transpose, no wave barriers.  EPI 3 keeps pixels as A: register q is pixel 4 g' + q, channel
+// lane & 15, which puts a pooling window into registers (q, q + 1) of lanes l and l ^ 16.
 template <int EPI, int BHv>
 __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __restrict__ x,
                                                        const unsigned short* __restrict__ packed,
@@ -116,19 +121,28 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
                                                        int vblocks) {
   using G = HCfg<BHv>;
   constexpr int BH = G::BH, WR = G::WR, WIN = G::WIN, NMT = G::NMT, MT = G::MT, NT = G::NT;
-  constexpr int MH = G::MH, NI = G::NI, SLD = G::SLD;
+  constexpr int MH = G::MH, NI = G::NI;
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
   unsigned short* win = lds;
   unsigned short* wts = lds + 2 * WIN;
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 15, g = lane >> 4;
-  unsigned short* scr = lds + WIN + wid * (16 * SLD);   // window buffer 1: dead after the K loop
   const int kb = kout / HNB;
   const int blocks_x = (W + HBW - 1) / HBW, blocks_y = (H + BH - 1) / BH;
   const int CC = cin / HCCH, S = 9 * CC;
   const unsigned short* zeros = reinterpret_cast<const unsigned short*>(h_zero_block);
   int nb = 0, b = 0, y0 = 0, x0 = 0;
+  // window slot of (this lane, chunk n): (row << 16) | (col << 8) | piece, -2 = not fetched.
+  // One packed register per chunk, unpacked at every use behind an opaque asm: left to itself
+  // the compiler keeps every derived value live across the K loop and spills.
+  int rel[NI];
+#pragma unroll
+  for (int n = 0; n < NI; ++n) {
+    const int slot = 64 * (wid + 8 * n) + lane;
+    const int pix = slot / 6, piece = slot - 6 * pix;
+    rel[n] = (piece >= 4 || pix >= WR * HWC) ? -2 : ((pix / HWC) << 16) | ((pix % HWC) << 8) | piece;
+  }
   int woff[NI];             // element offset at chunk 0; -1 outside the image; -2 not fetched
   auto locate = [&](int vb) -> bool {
     const int grp = vb / (8 * kb), rem = vb - grp * 8 * kb;
@@ -141,12 +155,11 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
     x0 = (t2 % blocks_x) * HBW;
 #pragma unroll
     for (int n = 0; n < NI; ++n) {
-      const int slot = 64 * (wid + 8 * n) + lane;
-      const int pix = slot / 6, piece = slot - 6 * pix;
-      const int y = y0 - 1 + pix / HWC, xx = x0 - 1 + pix % HWC;
+      int r = rel[n];
+      asm volatile("" : "+v"(r));
+      const int y = y0 - 1 + (r >> 16), xx = x0 - 1 + ((r >> 8) & 255);
       const bool inimg = y >= 0 && y < H && xx >= 0 && xx < W;
-      woff[n] = (piece >= 4 || pix >= WR * HWC) ? -2
-                : inimg ? ((b * H + y) * W + xx) * cin + 8 * piece : -1;
+      woff[n] = r < 0 ? -2 : inimg ? ((b * H + y) * W + xx) * cin + 8 * (r & 255) : -1;
     }
     return true;
   };
@@ -179,6 +192,9 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
   const int lane_a = (ht_row(i) * HWC + ht_col(i)) * HPIX + 8 * g;
   const int lane_b = (g * HNB + 16 * NT * ng + i) * 8;
 
+  const int dbg = relu >> 1;            // timing diagnostics (dv 3020 + bits), results meaningless
+  relu &= 1;
+  const float floor_v = relu ? 0.f : -__builtin_inff();
   bool staged = false;
   for (int vb = blockIdx.x; vb < vblocks; vb += gridDim.x) {
     if (!staged) {
@@ -200,63 +216,112 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
 
 #pragma unroll 1
     for (int s = 0; s < S; s += HTPB) {
-      if (s + HTPB < S) issue_wts(s + HTPB, ((s / HTPB) + 1) & 1);
+      if (s + HTPB < S && !(dbg & 8)) issue_wts(s + HTPB, ((s / HTPB) + 1) & 1);
       const int cc0 = s / 9, tap0 = s - 9 * cc0;
-      const bool win_issued = tap0 == 0 && cc0 + 1 < CC;
+      const bool win_issued = tap0 == 0 && cc0 + 1 < CC && !(dbg & 4);
       if (win_issued) issue_win(cc0 + 1, (cc0 + 1) & 1);
-      // 2 HTPB half steps (tap u = hs / 2, m-tile half hs % 2): MH A + NT B fragment reads for
-      // MH * NT MFMAs; the fragments of half step hs + 1 fly under the MFMAs of hs
+      // 2 HTPB half steps (tap u = hs / 2, m-tile half hs % 2): MH pixel fragments per half
+      // step, NT weight fragments per step, MH * NT MFMAs per half step; the fragments of half
+      // step hs + 1 fly under the MFMAs of hs
       u32x4 af[2][MH], bf[2][NT];
-      auto load_half = [&](int hs, u32x4 (&a4)[MH], u32x4 (&b4)[NT]) {
+      auto load_half = [&](int hs) {
         const int u = hs >> 1, mh = hs & 1;
         const int su = s + u;
         const int cc = su / 9, tap = su - 9 * cc;
         const unsigned short* wa =
             win + (cc & 1) * WIN + lane_a + ((tap / 3) * HWC + tap % 3) * HPIX;
-        const unsigned short* wbp = wts + (((s / HTPB) & 1) * HTPB + u) * HWT + lane_b;
+        if (mh == 0) {
+          const unsigned short* wbp = wts + (((s / HTPB) & 1) * HTPB + u) * HWT + lane_b;
 #pragma unroll
-        for (int n = 0; n < NT; ++n) b4[n] = *reinterpret_cast<const u32x4*>(wbp + 16 * n * 8);
+          for (int n = 0; n < NT; ++n)
+            bf[u & 1][n] = *reinterpret_cast<const u32x4*>(wbp + 16 * n * 8);
+        }
 #pragma unroll
-        for (int j = 0; j < MH; ++j) a4[j] = *reinterpret_cast<const u32x4*>(wa + aoff[MH * mh + j]);
+        for (int j = 0; j < MH; ++j)
+          af[hs & 1][j] = *reinterpret_cast<const u32x4*>(wa + aoff[MH * mh + j]);
       };
-      load_half(0, af[0], bf[0]);
+      load_half(0);
 #pragma unroll
       for (int hs = 0; hs < 2 * HTPB; ++hs) {
-        if (hs + 1 < 2 * HTPB) load_half(hs + 1, af[(hs + 1) & 1], bf[(hs + 1) & 1]);
+        if (hs + 1 < 2 * HTPB) load_half(hs + 1);
         __builtin_amdgcn_sched_barrier(0);
-        const int mh = hs & 1;
+        const int mh = hs & 1, u = hs >> 1;
 #pragma unroll
         for (int j = 0; j < MH; ++j)
 #pragma unroll
           for (int n = 0; n < NT; ++n)
-            acc[MH * mh + j][n] = mfma16h(af[hs & 1][j], bf[hs & 1][n], acc[MH * mh + j][n]);
+            acc[MH * mh + j][n] = EPI == 3 ? mfma16h(af[hs & 1][j], bf[u & 1][n], acc[MH * mh + j][n])
+                                           : mfma16h(bf[u & 1][n], af[hs & 1][j], acc[MH * mh + j][n]);
       }
       if (!win_issued)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
-      __syncthreads();
+      if (!(dbg & 1)) __syncthreads();
+    }
+
+    // (the tile coordinates go through an opaque asm: otherwise every epilogue address is
+    // computed before the K loop and spilled across it)
+    int nb_e = nb_t, b_e = b_t, y0_e = y0_t, x0_e = x0_t;
+    asm volatile("" : "+s"(nb_e), "+s"(b_e), "+s"(y0_e), "+s"(x0_e));
+    // What the epilogue reads from memory is requested first, so that waiting for it does not
+    // wait for the next tile's first stage (issued right after; the counter is in order).
+    const int ch_w = HNB * nb_e + 16 * NT * ng;           // first channel of the wave
+    f32x4 bias4[EPI == 1 ? NT : 1];
+    float bias1[EPI == 3 ? NT : 1];
+    if (EPI == 1) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        bias4[n] = *reinterpret_cast<const f32x4*>(bias + ch_w + 16 * n + 4 * g);
+    }
+    if (EPI == 3) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n) bias1[n] = bias[ch_w + 16 * n + i];
+    }
+    // EPI 0..2: lane (p = i, g') stores channels ch_w + 16 n + 4 g' .. + 3 of pixel p of the
+    // m-tile: element offset = tile part (wave-uniform) + lane part + 16 n
+    const int lane_o = (ht_row(i) * W + ht_col(i)) * kout + 4 * g;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    // EPI 2: the mask words of m-tile j + PD are requested after the stores of m-tile j, the
+    // first PD m-tiles up front (more in flight would not fit the register file next to the
+    // accumulators); the next tile's first stage goes out once every mask load has been issued
+    constexpr int PD = MT / 2;
+    u32x2 mk[EPI == 2 ? MT : 1][EPI == 2 ? NT : 1];
+    auto load_mask = [&](int j) {
+      const int mt = MT * mg + j;
+      const int oy = y0_e + 2 * (mt / 5), ox = x0_e + 8 * (mt % 5);
+      // (every element is assigned: a conditionally assigned one would stay live around the
+      // whole tile loop)
+      const bool inside = mt < NMT && oy + ht_row(i) < H && ox + ht_col(i) < W;
+      const unsigned short* mb = mask + (((int64_t)b_e * H + oy) * W + ox) * kout + ch_w;
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        mk[EPI == 2 ? j : 0][EPI == 2 ? n : 0] =
+            inside ? *reinterpret_cast<const u32x2*>(mb + lane_o + 16 * n) : u32x2{0u, 0u};
+    };
+    if (EPI == 2) {
+#pragma unroll
+      for (int j = 0; j < PD; ++j) load_mask(j);
     }
 
     // next tile's first stage under this tile's epilogue (see convg.hip)
-    {
+    auto stage_next = [&]() {
       const int vn = vb + gridDim.x;
       if (vn < vblocks && locate(vn)) {
         issue_wts(0, 0);
         issue_win(0, 0);
         staged = true;
       }
-    }
+    };
+    if (EPI != 2) stage_next();
 
-    // epilogue.  Accumulator register q of lane (c = lane & 15, g' = lane >> 4) of tile (j, n):
-    // pixel 4 g' + q of the m-tile (row ht_row, column ht_col), channel 16 n + c of the wave.
-    const int c = i, gq = g;
     if (EPI == 3) {
-      // registers (0,1) and (2,3) are the two pooling windows of this lane's row quad; the other
+      // register q of lane (c = i, g' = g): pixel 4 g' + q of the m-tile, channel 16 n + c.
+      // Registers (0,1) and (2,3) are the two pooling windows of this lane's row quad; the other
       // row of both windows sits in lane l ^ 16 under the same registers
       const int PH = H / 2, PW = W / 2;
-      const bool upper = gq == 0 || gq == 3;
-      const int cb = gq < 2 ? 0 : 4;                       // column base of this lane's quad
+      const bool upper = g == 0 || g == 3;
+      const int cb = g < 2 ? 0 : 4;                        // column base of this lane's quad
 #pragma unroll
       for (int j = 0; j < MT; ++j) {
         const int mt = MT * mg + j;
@@ -264,8 +329,7 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
         const int mr = mt / 5, mc = mt % 5;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-          const int ch = HNB * nb_t + 16 * NT * ng + 16 * n + c;
-          const float bias_r = bias[ch];
+          const int ch = ch_w + 16 * n + i;
 #pragma unroll
           for (int q0 = 0; q0 < 4; q0 += 2) {
             const float v0 = acc[j][n][q0], v1 = acc[j][n][q0 + 1];
@@ -277,54 +341,46 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
             const int iu = upper ? li : oi, il = upper ? oi : li;
             const float m = fmaxf(mu, ml);
             const int k = mu >= ml ? iu : 2 + il;          // first maximum in raster order
-            const int py = (y0_t + 2 * mr) >> 1, px = (x0_t + 8 * mc + cb + q0) >> 1;
-            if (upper && py < PH && px < PW) {
-              const int64_t po = (((int64_t)b_t * PH + py) * PW + px) * kout + ch;
-              out[po] = f32_to_bf16(fmaxf(m + bias_r, 0.f));
+            const int py = (y0_e + 2 * mr) >> 1, px = (x0_e + 8 * mc + cb + q0) >> 1;
+            if (upper && py < PH && px < PW && !(dbg & 2)) {
+              const int64_t po = (((int64_t)b_e * PH + py) * PW + px) * kout + ch;
+              out[po] = f32_to_bf16(fmaxf(m + bias1[n], 0.f));
               pidx[po] = (unsigned char)k;
             }
           }
         }
       }
     } else {
-      constexpr int PCS = 2 * NT;                          // 16-byte pieces per pixel of the wave
-      constexpr int RR = 16 * PCS / 64;                    // pieces per lane (2 or 1)
 #pragma unroll
       for (int j = 0; j < MT; ++j) {
         const int mt = MT * mg + j;
-        if (mt >= NMT) break;                              // wave-uniform
-        const int mr = mt / 5, mc = mt % 5;
-        int64_t o_off[RR];
-        bool inside[RR];
-        u32x4 mk[RR];
+        if (mt < NMT) {                                    // wave-uniform
+          const int oy = y0_e + 2 * (mt / 5), ox = x0_e + 8 * (mt % 5);
+          const bool inside = oy + ht_row(i) < H && ox + ht_col(i) < W && !(dbg & 2);
+          unsigned short* ob = out + (((int64_t)b_e * H + oy) * W + ox) * kout + ch_w;
 #pragma unroll
-        for (int rr = 0; rr < RR; ++rr) {
-          const int p = lane + 64 * rr, pe = p / PCS, pc = p % PCS;
-          const int oy = y0_t + 2 * mr + ht_row(pe), ox = x0_t + 8 * mc + ht_col(pe);
-          inside[rr] = oy < H && ox < W;
-          o_off[rr] = (((int64_t)b_t * H + oy) * W + ox) * kout + HNB * nb_t + 16 * NT * ng + 8 * pc;
-          mk[rr] = u32x4{0u, 0u, 0u, 0u};
-          if (EPI == 2 && inside[rr]) mk[rr] = *reinterpret_cast<const u32x4*>(mask + o_off[rr]);
-        }
+          for (int n = 0; n < NT; ++n) {
+            f32x4 v = acc[j][n];
+            if (EPI == 1) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          const float bias_r = EPI == 1 ? bias[HNB * nb_t + 16 * NT * ng + 16 * n + c] : 0.f;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            float v = acc[j][n][q] + bias_r;
-            if (EPI == 1 && relu) v = fmaxf(v, 0.f);
-            scr[(4 * gq + q) * SLD + 16 * n + c] = f32_to_bf16(v);
+              for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q] + bias4[n][q], floor_v);
+            }
+            u32x2 pk;
+            pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+            pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+            if (EPI == 2) {
+              pk.x = relu_mask_word(pk.x, mk[EPI == 2 ? j : 0][EPI == 2 ? n : 0].x);
+              pk.y = relu_mask_word(pk.y, mk[EPI == 2 ? j : 0][EPI == 2 ? n : 0].y);
+            }
+            if (inside) *reinterpret_cast<u32x2*>(ob + lane_o + 16 * n) = pk;
           }
         }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int rr = 0; rr < RR; ++rr) {
-          const int p = lane + 64 * rr, pe = p / PCS, pc = p % PCS;
-          u32x4 v = *reinterpret_cast<const u32x4*>(scr + pe * SLD + 8 * pc);
-          if (EPI == 2) v = relu_mask(v, mk[rr]);
-          if (inside[rr]) *reinterpret_cast<u32x4*>(out + o_off[rr]) = v;
+        if (EPI == 2) {
+          __builtin_amdgcn_sched_barrier(0);               // keep the loads where they are
+          if (j + PD < MT) load_mask(j + PD);
+          if (j + PD == MT - 1) stage_next();
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_wave_barrier();
       }
     }
   }   // persistent loop
@@ -378,18 +434,21 @@ int scl_convh_dispatch(const void* x, const void* w, int64_t w_stride_k, int64_t
   if (gsize > vblocks) gsize = vblocks;
   if (dv == 3099) gsize = vblocks;
   const dim3 grid((unsigned)gsize);
+  // 3020 + bits: 1 no barrier in the K loop, 2 no output stores, 4 no window DMA after the
+  // first chunk, 8 no weight DMA after the first group
+  const int dbgbits = (dv >= 3020 && dv < 3036) ? (dv - 3020) << 1 : 0;
 #define SCL_CONVH_LAUNCH(E, BHV, BIAS, RELU, MASK)                                             \
   SCL_LAUNCH("convg_kernel", (convh_kernel<E, BHV>), grid, dim3(HTHR), HCfg<BHV>::LDS, st,     \
              (const unsigned short*)x, (const unsigned short*)packed, B, H, W, cin, kout,      \
              (unsigned short*)out, BIAS, RELU, (const unsigned short*)MASK,                    \
              (unsigned char*)pidx, vblocks)
   if (pidx) {
-    if (low) SCL_CONVH_LAUNCH(3, 8, bias, 0, nullptr); else SCL_CONVH_LAUNCH(3, 12, bias, 0, nullptr);
+    if (low) SCL_CONVH_LAUNCH(3, 8, bias, dbgbits, nullptr); else SCL_CONVH_LAUNCH(3, 12, bias, dbgbits, nullptr);
   } else if (mask) {
-    if (low) SCL_CONVH_LAUNCH(2, 8, bias, 0, mask); else SCL_CONVH_LAUNCH(2, 12, bias, 0, mask);
+    if (low) SCL_CONVH_LAUNCH(2, 8, bias, dbgbits, mask); else SCL_CONVH_LAUNCH(2, 12, bias, dbgbits, mask);
   } else if (bias) {
-    if (low) SCL_CONVH_LAUNCH(1, 8, bias, relu ? 1 : 0, nullptr);
-    else SCL_CONVH_LAUNCH(1, 12, bias, relu ? 1 : 0, nullptr);
+    if (low) SCL_CONVH_LAUNCH(1, 8, bias, (relu ? 1 : 0) | dbgbits, nullptr);
+    else SCL_CONVH_LAUNCH(1, 12, bias, (relu ? 1 : 0) | dbgbits, nullptr);
   } else {
     if (low) SCL_CONVH_LAUNCH(0, 8, bias, 0, nullptr);
     else SCL_CONVH_LAUNCH(0, 12, bias, 0, nullptr);

@@ -612,8 +612,9 @@ inline TopnPlan topn_plan(int R, int Q, int bf) {
       best = s;
     }
   }
-  if (scl_debug_variant % 1000 >= 100) {   // tuning override (microbench.py --topn-splits)
-    best = scl_debug_variant % 1000 - 100;
+  const int tv = scl_debug_variant < 8000 ? scl_debug_variant : 0;   // larger values: other kernels
+  if (tv % 1000 >= 100) {   // tuning override (microbench.py --topn-splits)
+    best = tv % 1000 - 100;
     if (best > 32) best = 32;
     if (best > max_splits) best = max_splits;
     if (best < 1) best = 1;
@@ -642,7 +643,8 @@ void launch_scan(const TopnPlan& p, const void* ref, const void* ref_lo, const f
   });
   SCL_LAUNCH(BF ? "topn_scan_bf16x3_kernel" : "topn_scan_kernel", (topn_scan_kernel<D8, BF>),
              dim3(p.qtiles, p.splits), dim3(256), scan_lds_bytes(D8 * 8, BF), st, ref, ref_lo,
-             refnorm, R, query, Q, p.refs_per_split, scl_debug_variant / 1000, cs, ci);
+             refnorm, R, query, Q, p.refs_per_split,
+             scl_debug_variant < 8000 ? scl_debug_variant / 1000 : 0, cs, ci);
 }
 
 inline bool topn_shape_ok(int R, int Q, int d, int n) {

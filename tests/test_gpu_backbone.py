@@ -232,11 +232,11 @@ def test_own_conv_fused_tails(dev, cin, cout, shape):
 
 @pytest.fixture(params=['mfma32x32x16', 'mfma16x16x32'])
 def lds_kernel(request):
-    """Pins which of the two LDS-weights convolution kernels runs (csrc/convg.hip: 4000 + v,
-    csrc/convh.hip: 5000 + v); yields the variant base for tests that add their own v."""
+    """Pins which of the two LDS-weights convolution kernels runs (csrc/convg.hip: 40000 + v,
+    csrc/convh.hip: 50000 + v); yields the variant base for tests that add their own v."""
     from soft_contrastive_learning_amd import _lib as L
     lib = L.load()
-    base = 4000 if request.param == 'mfma32x32x16' else 5000
+    base = 40000 if request.param == 'mfma32x32x16' else 50000
     old = lib.scl_debug_set_variant(base)
     yield base
     lib.scl_debug_set_variant(old)
