@@ -423,7 +423,7 @@ static int convg_dispatch(const void* x, const void* w, int64_t w_stride_k, int6
     use_h = dv >= 50000;
     dv -= use_h ? 50000 : 40000;
   }
-  if (use_h)
+  if (use_h && (cin / 64) * 64 == cin)     // convh.hip walks the 32-channel chunks in pairs
     return scl_convh_dispatch(x, w, w_stride_k, w_stride_c, w_stride_h, w_stride_w, transposed, B, H,
                               W, cin, kout, out, bias, relu, mask, pidx, workspace, dv, stream);
   static std::once_flag once;

@@ -1,24 +1,33 @@
 // The LDS-weights 3x3 convolution of convg.hip on v_mfma_f32_16x16x32_bf16.
 //
 // Same decomposition (workgroup = [12 or 8 rows x 40 cols] of output pixels x 128 output
-// channels, eight waves, K loop over (32-channel chunk, tap) in groups of three behind one
-// barrier, windows and weights by LDS-DMA, persistent workgroups that prefetch the next tile's
-// first stage under the epilogue), but the 16x16x32 shape: at equal FLOP per cycle and equal
-// fragment traffic the chip holds a higher clock on it (bare LDS-fed loop on random operands,
-// scripts/mfma_shape_bf16.hip: 1.68 vs 1.57 PFLOP/s).  What changes with the shape:
-//   * one MFMA k-step = the whole 32-channel chunk of a tap: A fragment of lane (i, g) = the 16
-//     bytes (channels 8 g .. + 7) of pixel i of a 16-pixel m-tile, B fragment = 16 bytes of a
-//     weight row;
-//   * an m-tile is 2 rows x 8 columns.  Lanes 0-3 / 12-15 take the upper row, 4-11 the lower:
-//     with 96-byte window pixels (64 data + 32 pad) and 42-column windows every ds_read_b128
-//     service group ({0-3, 12-15, 20-27}, ...) then hits 16 different 16-byte slots for every
-//     tap and tile column (checked exhaustively); 80-byte pixels admit no such map;
-//   * weights are stored piece-major — unit (piece g * 128 + row) of 16 bytes — so the slot of a
-//     B fragment is the row modulo 16 = the lane's i: conflict-free without padding (8 KB per
-//     step instead of 10), which is what pays for the wider pixels: 2 x 57,344 B of windows +
-//     2 x 3 x 8,192 B of weights = 163,840 B, all of the LDS;
-//   * accumulator register q of lane (c, g') is pixel 4 g' + q, channel c: a 2x2 pooling window
-//     is registers (q, q + 1) of lanes l and l ^ 16 — one cross-lane exchange per window.
+// channels, eight waves, K loop over (32-channel chunk, tap) in groups of three, windows and
+// weights by LDS-DMA, persistent workgroups that prefetch the next tile's first stage under the
+// epilogue), rebuilt around what the timing ablations (scripts/conv_ab.py --variants) showed:
+// with every DMA removed the loop runs at the rate of a bare LDS-fed MFMA loop (1.56 of 1.68
+// PFLOP/s), and what the real kernel loses on top of that is the DMA stream (L2 -> LDS runs at
+// 11-13 bytes per cycle and CU with every CU streaming: 43 KB per group against 3,072 MFMA
+// cycles) and the barrier at the end of every group (the first fragment reads of the next group
+// wait behind it with the MFMA pipe idle).  Hence:
+//   * 16x16x32: one MFMA k-step = the whole 32-channel chunk of a tap: a pixel fragment of lane
+//     (i, g) = the 16 bytes (channels 8 g .. + 7) of pixel i of a 16-pixel m-tile, a weight
+//     fragment = 16 bytes of a weight row; the chip also holds a higher clock on this shape
+//     (scripts/mfma_shape_bf16.hip);
+//   * 64-byte window pixels without padding (37.6 KB per window instead of 47 with the 80-byte
+//     pixels of convg.hip): the four 16-byte pieces of pixel (row, col) are stored at piece ^
+//     f(row, col), f = ((col >> 2) & 1) | ((row & 1) << 1) — the DMA applies it on the source
+//     side, its LDS destination stays lane-linear.  An m-tile is 2 rows x 8 columns, lanes 0-3 /
+//     12-15 the upper row, 4-11 the lower; with 42-column windows every ds_read_b128 service
+//     group ({0-3, 12-15, 20-27}, ...) then hits 16 different 16-byte slots for every tap and
+//     tile column (checked exhaustively);
+//   * weights piece-major — unit (piece g * 128 + row) of 16 bytes — so the slot of a weight
+//     fragment is the row modulo 16 = the lane's i: conflict-free without padding, 8 KB per step;
+//   * THREE weight buffers and the barrier in the MIDDLE of a group: before it a wave waits for
+//     its own share of the next group's weights (requested one group earlier), after it the
+//     request for the group after next goes out, and the first fragments of the next group are
+//     read at the end of the current one — no LDS read ever waits behind a barrier.  The next
+//     window travels in two parts after the first two barriers of a chunk;
+//   * LDS: 2 x 40 KB windows + 3 x 24 KB weights = 152 KB (12-row blocks).
 #include <mutex>
 
 #include "scl_common.h"
@@ -30,27 +39,33 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int HBW = 40;                      // output block width
 constexpr int HWC = HBW + 2;                 // window columns
-constexpr int HPIX = 48;                     // bf16 per staged pixel (96 B: 64 data + 32 pad)
+constexpr int HPIX = 32;                     // bf16 per staged pixel (64 B, pieces swizzled)
 constexpr int HCCH = 32;                     // channels per chunk = one MFMA k-step
 constexpr int HNB = 128;                     // output channels per workgroup
-constexpr int HTPB = 3;                      // (chunk, tap) steps per barrier
+constexpr int HTPB = 3;                      // (chunk, tap) steps per group
 constexpr int HWT = 4 * HNB * 8;             // bf16 per weight step image (8 KB)
 constexpr int HTHR = 512;
+constexpr int HX = 1;                        // half step of a group behind whose MFMAs the barrier sits
+                                             // (odd: its pixel and weight fragments are dead by then)
 
 template <int BHv>
 struct HCfg {
   static constexpr int BH = BHv;
   static constexpr int WR = BH + 2;                          // window rows
-  static constexpr int SLOTS = WR * HWC * 6;                 // 16-byte slots of a window
-  static constexpr int CHUNKS = (SLOTS + 63) / 64;           // 1-KB DMA chunks
-  static constexpr int NI = CHUNKS / 8;                      // per wave (56 / 8, 40 / 8)
-  static_assert(CHUNKS % 8 == 0, "every wave issues the same number of window chunks");
-  static constexpr int WIN = CHUNKS * 512;                   // bf16 per window buffer
+  static constexpr int SLOTS = WR * HWC * 4;                 // 16-byte slots of a window
+  static constexpr int NI = (SLOTS + 511) / 512;             // 1-KB DMA chunks per wave: 5 / 4
+  static constexpr int NA = (NI + 1) / 2;                    // ... of them in the first part
+  static constexpr int WIN = NI * 8 * 512;                   // bf16 per window buffer
   static constexpr int NMT = BH / 2 * 5;                     // 2 x 8 m-tiles of the block
   static constexpr int MT = BH == 12 ? 8 : 10;               // m-tiles per wave
   static constexpr int NT = BH == 12 ? 4 : 2;                // 16-channel n-tiles per wave
   static constexpr int MH = MT / 2;                          // m-tiles per half step
-  static constexpr size_t LDS = (2 * (size_t)WIN + 2 * HTPB * (size_t)HWT) * 2;
+  static constexpr size_t LDS = (2 * (size_t)WIN + 3 * HTPB * (size_t)HWT) * 2;
+};
+
+template <int V>
+struct HConst {
+  static constexpr int value = V;
 };
 
 // pixel of m-tile row i: lanes 0-3 and 12-15 the upper row, 4-11 the lower (see header)
@@ -121,7 +136,7 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
                                                        int vblocks) {
   using G = HCfg<BHv>;
   constexpr int BH = G::BH, WR = G::WR, WIN = G::WIN, NMT = G::NMT, MT = G::MT, NT = G::NT;
-  constexpr int MH = G::MH, NI = G::NI;
+  constexpr int MH = G::MH, NI = G::NI, NA = G::NA;
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
   unsigned short* win = lds;
   unsigned short* wts = lds + 2 * WIN;
@@ -130,20 +145,23 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
   const int i = lane & 15, g = lane >> 4;
   const int kb = kout / HNB;
   const int blocks_x = (W + HBW - 1) / HBW, blocks_y = (H + BH - 1) / BH;
-  const int CC = cin / HCCH, S = 9 * CC;
+  const int CC = cin / HCCH, S = 9 * CC;                 // CC is even (host check)
   const unsigned short* zeros = reinterpret_cast<const unsigned short*>(h_zero_block);
   int nb = 0, b = 0, y0 = 0, x0 = 0;
-  // window slot of (this lane, chunk n): (row << 16) | (col << 8) | piece, -2 = not fetched.
-  // One packed register per chunk, unpacked at every use behind an opaque asm: left to itself
-  // the compiler keeps every derived value live across the K loop and spills.
+  // LDS slot 64 (wid + 8 n) + lane of a window = piece `slot & 3` of pixel `slot >> 2`, filled
+  // with the pixel's piece (slot & 3) ^ f(row, col).  One packed register per chunk —
+  // (row << 16) | (col << 8) | source piece, negative past the window (zeros are fetched: every
+  // wave issues the same number of DMAs) — unpacked at every use behind an opaque asm: left to
+  // itself the compiler keeps every derived value live across the K loop and spills.
   int rel[NI];
 #pragma unroll
   for (int n = 0; n < NI; ++n) {
     const int slot = 64 * (wid + 8 * n) + lane;
-    const int pix = slot / 6, piece = slot - 6 * pix;
-    rel[n] = (piece >= 4 || pix >= WR * HWC) ? -2 : ((pix / HWC) << 16) | ((pix % HWC) << 8) | piece;
+    const int pix = slot >> 2, row = pix / HWC, col = pix - row * HWC;
+    const int piece = (slot & 3) ^ (((col >> 2) & 1) | ((row & 1) << 1));
+    rel[n] = pix >= WR * HWC ? -1 : (row << 16) | (col << 8) | piece;
   }
-  int woff[NI];             // element offset at chunk 0; -1 outside the image; -2 not fetched
+  int woff[NI];             // element offset at chunk 0; -1: zeros (outside the image / window)
   auto locate = [&](int vb) -> bool {
     const int grp = vb / (8 * kb), rem = vb - grp * 8 * kb;
     const int pblk = grp * 8 + (rem & 7);
@@ -158,27 +176,31 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
       int r = rel[n];
       asm volatile("" : "+v"(r));
       const int y = y0 - 1 + (r >> 16), xx = x0 - 1 + ((r >> 8) & 255);
-      const bool inimg = y >= 0 && y < H && xx >= 0 && xx < W;
-      woff[n] = r < 0 ? -2 : inimg ? ((b * H + y) * W + xx) * cin + 8 * (r & 255) : -1;
+      const bool inimg = r >= 0 && y >= 0 && y < H && xx >= 0 && xx < W;
+      woff[n] = inimg ? ((b * H + y) * W + xx) * cin + 8 * (r & 255) : -1;
     }
     return true;
   };
-  auto issue_win = [&](int cc, int buf) {
+  auto issue_win = [&](int cc, int buf, int n0, int n1) {
     const unsigned base = h_lds_byte_of(win) + buf * WIN * 2;
 #pragma unroll
-    for (int n = 0; n < NI; ++n) {
-      const int j = wid + 8 * n;
-      if (woff[n] != -2) hglds16(woff[n] >= 0 ? x + woff[n] + HCCH * cc : zeros, base + j * 1024);
-    }
+    for (int n = 0; n < NI; ++n)
+      if (n >= n0 && n < n1)
+        hglds16(woff[n] >= 0 ? x + woff[n] + HCCH * cc : zeros, base + (wid + 8 * n) * 1024);
   };
-  auto issue_wts = [&](int s, int buf) {                // three steps = 24 chunks, 3 per wave
-    const unsigned short* src = packed + ((int64_t)nb * S + s) * HWT + lane * 8;
+  auto issue_wts = [&](int grp, int buf) {              // three steps = 24 chunks, 3 per wave
+    const unsigned short* src = packed + ((int64_t)nb * S + HTPB * grp) * HWT + lane * 8;
     const unsigned base = h_lds_byte_of(wts) + buf * HTPB * HWT * 2;
 #pragma unroll
     for (int n = 0; n < 3; ++n) {
       const int j = wid + 8 * n;
       hglds16(src + j * 512, base + j * 1024);
     }
+  };
+  auto stage_first = [&]() {                            // a tile's first two groups and window
+    issue_wts(0, 0);
+    issue_wts(1, 1);
+    issue_win(0, 0, 0, NI);
   };
   // wave (mg, ng): m-tiles MT mg .. + MT - 1 (2 x 8 pixels each, 5 per row pair), channels
   // 16 NT ng .. + 16 NT - 1
@@ -189,7 +211,16 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
     const int mt = MT * mg + j < NMT ? MT * mg + j : NMT - 1;
     aoff[j] = ((2 * (mt / 5)) * HWC + 8 * (mt % 5)) * HPIX;
   }
-  const int lane_a = (ht_row(i) * HWC + ht_col(i)) * HPIX + 8 * g;
+  // pixel fragment of this lane for tap t = (kh, kw), relative to the m-tile's corner:
+  // lane_a + tap_const(t) + 8 * piece(t), piece(t) = g ^ f(row + kh, col + kw) — the nine
+  // two-bit pieces packed into one register
+  const int lane_a = (ht_row(i) * HWC + ht_col(i)) * HPIX;
+  int pieces = 0;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int r = ht_row(i) + t / 3, c = ht_col(i) + t % 3;
+    pieces |= (g ^ (((c >> 2) & 1) | ((r & 1) << 1))) << (2 * t);
+  }
   const int lane_b = (g * HNB + 16 * NT * ng + i) * 8;
 
   const int dbg = relu >> 1;            // timing diagnostics (dv 3020 + bits), results meaningless
@@ -199,8 +230,7 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
   for (int vb = blockIdx.x; vb < vblocks; vb += gridDim.x) {
     if (!staged) {
       if (!locate(vb)) continue;
-      issue_wts(0, 0);
-      issue_win(0, 0);
+      stage_first();
     }
     staged = false;
     const int nb_t = nb, b_t = b, y0_t = y0, x0_t = x0;
@@ -211,53 +241,79 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
 #pragma unroll
       for (int n = 0; n < NT; ++n) acc[j][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // Half step h = 0 .. 17 of a chunk: tap t = h / 2 (group t / 3 -> weight buffer t / 3), m-tile
+    // half h % 2.  Pixel fragments alternate between af[0] and af[1] by half step, weight
+    // fragments (one set per step) between bf[0] and bf[1] by step; a chunk has nine steps, so
+    // the roles of bf[] flip from chunk to chunk (PAR).
+    u32x4 af[2][MH], bf[2][NT];
+    auto load_half = [&](const unsigned short* wbase, int h, int par) {
+      const int t = h >> 1, mh = h & 1;
+      if (mh == 0) {
+        const unsigned short* wbp = wts + t * HWT + lane_b;    // (t / 3) * HTPB + t % 3 = t
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          bf[(t + par) & 1][n] = *reinterpret_cast<const u32x4*>(wbp + 16 * n * 8);
+      }
+      // (opaque: the compiler would otherwise keep all 9 x MT address sums in registers)
+      int pk = pieces;
+      asm volatile("" : "+v"(pk));
+      const int tb = lane_a + ((pk >> (2 * t)) & 3) * 8;
+#pragma unroll
+      for (int j = 0; j < MH; ++j)
+        af[h & 1][j] = *reinterpret_cast<const u32x4*>(wbase + tb + aoff[MH * mh + j] +
+                                                       ((t / 3) * HWC + t % 3) * HPIX);
+    };
+    // Straight-line on purpose (a data-dependent branch in here costs the accumulators their
+    // registers): the last chunk of a tile requests, and reads ahead, like every other one — the
+    // clamped group / chunk indices make those requests re-fetch what the buffers already hold.
+    const int NG = 3 * CC;
+    auto chunk = [&](int cc, auto par_c) {
+      constexpr int PAR = decltype(par_c)::value;
+      const unsigned short* wcur = win + (cc & 1) * WIN;
+      const unsigned short* wnext = win + ((cc + 1) & 1) * WIN;
+      const int ccn = cc + 1 < CC ? cc + 1 : cc;
+#pragma unroll
+      for (int h = 0; h < 18; ++h) {
+        // the fragments of the next half step fly under the MFMAs of this one
+        if (h + 1 < 18)
+          load_half(wcur, h + 1, PAR);
+        else
+          load_half(wnext, 0, PAR ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const int t = h >> 1, mh = h & 1;
+#pragma unroll
+        for (int j = 0; j < MH; ++j)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+            acc[MH * mh + j][n] =
+                EPI == 3 ? mfma16h(af[h & 1][j], bf[(t + PAR) & 1][n], acc[MH * mh + j][n])
+                         : mfma16h(bf[(t + PAR) & 1][n], af[h & 1][j], acc[MH * mh + j][n]);
+        if (h % 6 == HX) {
+          __builtin_amdgcn_sched_barrier(0);
+          // own share of what the NEXT group reads has landed; the barrier publishes everybody's
+          const int gi = h / 6;
+          if (gi == 1)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA) : "memory");   // first window part may fly on
+          else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          // ... and everybody has left the previous group: its weight buffer takes the group
+          // after next, the other window buffer the next chunk's window (in two parts)
+          const int gn = 3 * cc + gi + 2 < NG ? 3 * cc + gi + 2 : NG - 3 + (gi + 2) % 3;
+          issue_wts(gn, (gi + 2) % 3);
+          if (gi == 0) issue_win(ccn, (cc + 1) & 1, 0, NA);
+          if (gi == 1) issue_win(ccn, (cc + 1) & 1, NA, NI);
+        }
+      }
+    };
+
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-
+    load_half(win, 0, 0);
 #pragma unroll 1
-    for (int s = 0; s < S; s += HTPB) {
-      if (s + HTPB < S && !(dbg & 8)) issue_wts(s + HTPB, ((s / HTPB) + 1) & 1);
-      const int cc0 = s / 9, tap0 = s - 9 * cc0;
-      const bool win_issued = tap0 == 0 && cc0 + 1 < CC && !(dbg & 4);
-      if (win_issued) issue_win(cc0 + 1, (cc0 + 1) & 1);
-      // 2 HTPB half steps (tap u = hs / 2, m-tile half hs % 2): MH pixel fragments per half
-      // step, NT weight fragments per step, MH * NT MFMAs per half step; the fragments of half
-      // step hs + 1 fly under the MFMAs of hs
-      u32x4 af[2][MH], bf[2][NT];
-      auto load_half = [&](int hs) {
-        const int u = hs >> 1, mh = hs & 1;
-        const int su = s + u;
-        const int cc = su / 9, tap = su - 9 * cc;
-        const unsigned short* wa =
-            win + (cc & 1) * WIN + lane_a + ((tap / 3) * HWC + tap % 3) * HPIX;
-        if (mh == 0) {
-          const unsigned short* wbp = wts + (((s / HTPB) & 1) * HTPB + u) * HWT + lane_b;
-#pragma unroll
-          for (int n = 0; n < NT; ++n)
-            bf[u & 1][n] = *reinterpret_cast<const u32x4*>(wbp + 16 * n * 8);
-        }
-#pragma unroll
-        for (int j = 0; j < MH; ++j)
-          af[hs & 1][j] = *reinterpret_cast<const u32x4*>(wa + aoff[MH * mh + j]);
-      };
-      load_half(0);
-#pragma unroll
-      for (int hs = 0; hs < 2 * HTPB; ++hs) {
-        if (hs + 1 < 2 * HTPB) load_half(hs + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        const int mh = hs & 1, u = hs >> 1;
-#pragma unroll
-        for (int j = 0; j < MH; ++j)
-#pragma unroll
-          for (int n = 0; n < NT; ++n)
-            acc[MH * mh + j][n] = EPI == 3 ? mfma16h(af[hs & 1][j], bf[u & 1][n], acc[MH * mh + j][n])
-                                           : mfma16h(bf[u & 1][n], af[hs & 1][j], acc[MH * mh + j][n]);
-      }
-      if (!win_issued)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
-      if (!(dbg & 1)) __syncthreads();
+    for (int cc = 0; cc < CC; cc += 2) {
+      chunk(cc, HConst<0>());
+      chunk(cc + 1, HConst<1>());
     }
 
     // (the tile coordinates go through an opaque asm: otherwise every epilogue address is
@@ -308,8 +364,9 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
     auto stage_next = [&]() {
       const int vn = vb + gridDim.x;
       if (vn < vblocks && locate(vn)) {
-        issue_wts(0, 0);
-        issue_win(0, 0);
+        // (the K loop's last requests target the same buffers)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stage_first();
         staged = true;
       }
     };
@@ -434,9 +491,8 @@ int scl_convh_dispatch(const void* x, const void* w, int64_t w_stride_k, int64_t
   if (gsize > vblocks) gsize = vblocks;
   if (dv == 3099) gsize = vblocks;
   const dim3 grid((unsigned)gsize);
-  // 3020 + bits: 1 no barrier in the K loop, 2 no output stores, 4 no window DMA after the
-  // first chunk, 8 no weight DMA after the first group
-  const int dbgbits = (dv >= 3020 && dv < 3036) ? (dv - 3020) << 1 : 0;
+  // 3020 + bits: 2 no output stores
+  const int dbgbits = (dv >= 3020 && dv < 3024) ? (dv - 3020) << 1 : 0;
 #define SCL_CONVH_LAUNCH(E, BHV, BIAS, RELU, MASK)                                             \
   SCL_LAUNCH("convg_kernel", (convh_kernel<E, BHV>), grid, dim3(HTHR), HCfg<BHV>::LDS, st,     \
              (const unsigned short*)x, (const unsigned short*)packed, B, H, W, cin, kout,      \

@@ -254,7 +254,10 @@ def block_height(request, lds_kernel):
 
 @pytest.mark.parametrize('block_height', [12, 8], indirect=True)
 @pytest.mark.parametrize('cin,cout,shape', [(128, 256, (2, 12, 40)), (256, 256, (1, 30, 40)),
-                                            (256, 512, (1, 15, 80)), (512, 512, (1, 7, 23))])
+                                            (256, 512, (1, 15, 80)), (512, 512, (1, 7, 23)),
+                                            # an odd number of 32-channel chunks: convh.hip walks
+                                            # them in pairs and hands these shapes to convg.hip
+                                            (160, 128, (1, 12, 40))])
 def test_lds_weight_conv_deeper_layers(dev, cin, cout, shape, block_height):
     """csrc/convg.hip: conv3_x .. conv5_x shapes, forward (+ bias / ReLU) and backward-data."""
     from soft_contrastive_learning_amd.model import nets
