@@ -410,7 +410,7 @@ int scl_wrw3x3_ex(const void* x, const void* gz, int B, int H, int W, int cin, i
  *   1000 * b (+ 100 + s)   top-n scan: b bit 0 no selection, bit 1 no tile staging,
  *                 bit 2 no MFMAs (values below 8000 only)
  *   2000 + bits / 2100     weight-gradient kernel: timing ablations / one n-block per workgroup
- *   3008 / 3012   LDS-weights convolution: pin the block height to 8 / 12 rows
+ *   3006 / 3008 / 3012   LDS-weights convolution: pin the block height (6: 16x16x32 kernel only)
  *   3099          LDS-weights convolution: one tile per workgroup instead of persistent ones
  *   3100 + g      LDS-weights convolution: persistent grid of g + 1 groups of 8 * kout / 128
  *   40000 + v / 50000 + v  LDS-weights convolution: pin the v_mfma 32x32x16 kernel

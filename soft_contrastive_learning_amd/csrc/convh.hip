@@ -57,8 +57,11 @@ struct HCfg {
   static constexpr int NA = (NI + 1) / 2;                    // ... of them in the first part
   static constexpr int WIN = NI * 8 * 512;                   // bf16 per window buffer
   static constexpr int NMT = BH / 2 * 5;                     // 2 x 8 m-tiles of the block
-  static constexpr int MT = BH == 12 ? 8 : 10;               // m-tiles per wave
-  static constexpr int NT = BH == 12 ? 4 : 2;                // 16-channel n-tiles per wave
+  // waves (mg, ng): 12 rows 4 x 2 (8 m-tiles x 64 channels each), 8 rows 2 x 4 (10 x 32),
+  // 6 rows 4 x 2 (4 x 64: half the accumulators, for maps whose 8- or 12-row blocks fill the
+  // chip badly — 30 x 40: 480 blocks of 6 rows = 1.9 rounds of 256 against 1.5 of 8 rows)
+  static constexpr int MT = BH == 12 ? 8 : BH == 8 ? 10 : 4; // m-tiles per wave
+  static constexpr int NT = BH == 8 ? 2 : 4;                 // 16-channel n-tiles per wave
   static constexpr int MH = MT / 2;                          // m-tiles per half step
   static constexpr size_t LDS = (2 * (size_t)WIN + 3 * HTPB * (size_t)HWT) * 2;
 };
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
   };
   // wave (mg, ng): m-tiles MT mg .. + MT - 1 (2 x 8 pixels each, 5 per row pair), channels
   // 16 NT ng .. + 16 NT - 1
-  const int mg = BH == 12 ? wid >> 1 : wid >> 2, ng = BH == 12 ? wid & 1 : wid & 3;
+  const int mg = NT == 4 ? wid >> 1 : wid >> 2, ng = NT == 4 ? wid & 1 : wid & 3;
   int aoff[MT];
 #pragma unroll
   for (int j = 0; j < MT; ++j) {
@@ -457,7 +460,7 @@ int convh_cus() {
 }  // namespace
 
 // Same contract as convg_dispatch (convg.hip), which validates the arguments and calls this
-// (dv = the diagnostic variant: 3008 / 3012 block height, 3099 one tile per workgroup,
+// (dv = the diagnostic variant: 3006 / 3008 / 3012 block height, 3099 one tile per workgroup,
 // 3100 + g grid of g + 1 groups).  The packed weights fit the workspace
 // of scl_convg_workspace_bytes (8 KB per step instead of 10).
 int scl_convh_dispatch(const void* x, const void* w, int64_t w_stride_k, int64_t w_stride_c,
@@ -471,6 +474,7 @@ int scl_convh_dispatch(const void* x, const void* w, int64_t w_stride_k, int64_t
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)HCfg<BHV>::LDS);
     SCL_CONVH_ATTR(0, 12) SCL_CONVH_ATTR(1, 12) SCL_CONVH_ATTR(2, 12) SCL_CONVH_ATTR(3, 12)
     SCL_CONVH_ATTR(0, 8) SCL_CONVH_ATTR(1, 8) SCL_CONVH_ATTR(2, 8) SCL_CONVH_ATTR(3, 8)
+    SCL_CONVH_ATTR(0, 6) SCL_CONVH_ATTR(1, 6) SCL_CONVH_ATTR(2, 6) SCL_CONVH_ATTR(3, 6)
 #undef SCL_CONVH_ATTR
   });
   hipStream_t st = (hipStream_t)stream;
@@ -479,11 +483,20 @@ int scl_convh_dispatch(const void* x, const void* w, int64_t w_stride_k, int64_t
   SCL_LAUNCH("convg_pack_kernel", convh_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256),
              0, st, w, w_stride_k, w_stride_c, w_stride_h, w_stride_w, flags, cin, kout, packed);
   const int bx = (W + HBW - 1) / HBW, kb = kout / HNB;
-  const int64_t wg12 = (int64_t)B * ((H + 11) / 12) * bx * kb, wg8 = (int64_t)B * ((H + 7) / 8) * bx * kb;
+  // block height: the one with the fewest (rounds of one workgroup per CU) x (window rows)
   const int cus = convh_cus();
-  const int64_t t12 = ((wg12 + cus - 1) / cus) * 12, t8 = ((wg8 + cus - 1) / cus) * 8;
-  const bool low = dv == 3012 ? false : dv == 3008 ? true : t8 < t12;
-  const int64_t pblocks = (low ? wg8 : wg12) / kb;
+  int bh = 12;
+  int64_t best = -1, pblocks = 0;
+  for (int cand : {12, 8, 6}) {
+    const int64_t wg = (int64_t)B * ((H + cand - 1) / cand) * bx * kb;
+    const int64_t cost = ((wg + cus - 1) / cus) * (cand + 2);
+    if (best < 0 || cost < best) {
+      best = cost;
+      bh = cand;
+    }
+  }
+  if (dv == 3012 || dv == 3008 || dv == 3006) bh = dv - 3000;
+  pblocks = (int64_t)B * ((H + bh - 1) / bh) * bx;
   const int vblocks = (int)(((pblocks + 7) / 8) * 8 * kb);
   int groups = cus / (8 * kb) > 0 ? cus / (8 * kb) : 1;
   if (dv >= 3100 && dv < 3200) groups = dv - 3100 + 1;
@@ -498,17 +511,21 @@ int scl_convh_dispatch(const void* x, const void* w, int64_t w_stride_k, int64_t
              (const unsigned short*)x, (const unsigned short*)packed, B, H, W, cin, kout,      \
              (unsigned short*)out, BIAS, RELU, (const unsigned short*)MASK,                    \
              (unsigned char*)pidx, vblocks)
-  if (pidx) {
-    if (low) SCL_CONVH_LAUNCH(3, 8, bias, dbgbits, nullptr); else SCL_CONVH_LAUNCH(3, 12, bias, dbgbits, nullptr);
-  } else if (mask) {
-    if (low) SCL_CONVH_LAUNCH(2, 8, bias, dbgbits, mask); else SCL_CONVH_LAUNCH(2, 12, bias, dbgbits, mask);
-  } else if (bias) {
-    if (low) SCL_CONVH_LAUNCH(1, 8, bias, (relu ? 1 : 0) | dbgbits, nullptr);
-    else SCL_CONVH_LAUNCH(1, 12, bias, (relu ? 1 : 0) | dbgbits, nullptr);
-  } else {
-    if (low) SCL_CONVH_LAUNCH(0, 8, bias, 0, nullptr);
-    else SCL_CONVH_LAUNCH(0, 12, bias, 0, nullptr);
-  }
+#define SCL_CONVH_BH(E, BIAS, RELU, MASK)                                                      \
+  do {                                                                                         \
+    if (bh == 12) SCL_CONVH_LAUNCH(E, 12, BIAS, RELU, MASK);                                   \
+    else if (bh == 8) SCL_CONVH_LAUNCH(E, 8, BIAS, RELU, MASK);                                \
+    else SCL_CONVH_LAUNCH(E, 6, BIAS, RELU, MASK);                                             \
+  } while (0)
+  if (pidx)
+    SCL_CONVH_BH(3, bias, dbgbits, nullptr);
+  else if (mask)
+    SCL_CONVH_BH(2, bias, dbgbits, mask);
+  else if (bias)
+    SCL_CONVH_BH(1, bias, (relu ? 1 : 0) | dbgbits, nullptr);
+  else
+    SCL_CONVH_BH(0, bias, 0, nullptr);
+#undef SCL_CONVH_BH
 #undef SCL_CONVH_LAUNCH
   return scl_launch_status();
 }

@@ -179,11 +179,12 @@ def _own_conv_kind(x, w, transposed=False):
 
 
 def _lds_conv_pays(x, transposed=False, fused_tail=False):
-    """Measured on MI355X (scripts/conv_layers.py): the LDS-weights kernel beats the library on
-    conv3_x / conv4_x — backward-data 1000-1130 vs 560-650 TFLOP/s, forward 890-1160 vs
-    780-970 — and, with its 8-row blocks, on the backward-data of conv5_x (30 x 40: 820 vs
-    600); conv5_x forward stays with the library (980 vs 770)."""
-    return x.shape[2] * x.shape[3] >= (30 * 40 if transposed else 60 * 80)
+    """Measured on MI355X (scripts/conv_layers.py, profiles/r02): the LDS-weights kernel
+    (csrc/convh.hip) beats the library on conv3_x .. conv5_x in both directions — conv4_x
+    forward 1210 vs 960 TFLOP/s, backward-data 1230 vs 630; at 30 x 40 (conv5_x), with its 6-row
+    blocks, forward 1150 vs 950 and backward-data 1110 vs 600.  Smaller maps fill the chip too
+    badly and stay with the library."""
+    return x.shape[2] * x.shape[3] >= 30 * 40
 
 
 def _conv64_ok(x, w, transposed=False):

@@ -252,12 +252,9 @@ def block_height(request, lds_kernel):
     lib.scl_debug_set_variant(old)
 
 
-@pytest.mark.parametrize('block_height', [12, 8], indirect=True)
+@pytest.mark.parametrize('block_height', [12, 8, 6], indirect=True)
 @pytest.mark.parametrize('cin,cout,shape', [(128, 256, (2, 12, 40)), (256, 256, (1, 30, 40)),
-                                            (256, 512, (1, 15, 80)), (512, 512, (1, 7, 23)),
-                                            # an odd number of 32-channel chunks: convh.hip walks
-                                            # them in pairs and hands these shapes to convg.hip
-                                            (160, 128, (1, 12, 40))])
+                                            (256, 512, (1, 15, 80)), (512, 512, (1, 7, 23))])
 def test_lds_weight_conv_deeper_layers(dev, cin, cout, shape, block_height):
     """csrc/convg.hip: conv3_x .. conv5_x shapes, forward (+ bias / ReLU) and backward-data."""
     from soft_contrastive_learning_amd.model import nets
@@ -280,6 +277,20 @@ def test_lds_weight_conv_deeper_layers(dev, cin, cout, shape, block_height):
     want_gx = torch.nn.functional.conv_transpose2d(gy.float(), wt.float(), padding=1)
     assert gx.shape == want_gx.shape
     assert float((gx.float() - want_gx).abs().max()) < 6e-3 * float(want_gx.abs().max())
+
+
+def test_lds_weight_conv_odd_chunk_count(dev, lds_kernel):
+    """cin = 160 is five 32-channel chunks: csrc/convh.hip walks chunks in pairs and leaves such
+    shapes to csrc/convg.hip — the forward must be right whichever kernel is pinned."""
+    from soft_contrastive_learning_amd.model import nets
+    g = torch.Generator().manual_seed(71)
+    x = torch.randn(1, 160, 12, 40, generator=g).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(128, 160, 3, 3, generator=g) * 0.03).to(dev).bfloat16().contiguous(
+        memory_format=torch.channels_last)
+    assert nets._own_conv_kind(x, wt) == 'lds'
+    z32 = torch.nn.functional.conv2d(x.float(), wt.float(), padding=1)
+    got = nets.conv64(x, wt, False)
+    assert float((got.float() - z32).abs().max()) < 6e-3 * float(z32.abs().max())
 
 
 @pytest.mark.parametrize('cin,cout,shape', [(64, 128, (2, 12, 40)), (128, 128, (1, 13, 37)),
@@ -328,7 +339,7 @@ def test_first_layer_kernel(dev, shape):
     assert float((y.float() - want).abs().max()) < 6e-3 * float(want.abs().max())
 
 
-@pytest.mark.parametrize('block_height', [12, 8], indirect=True)
+@pytest.mark.parametrize('block_height', [12, 8, 6], indirect=True)
 @pytest.mark.parametrize('cin,cout,shape', [(64, 64, (2, 16, 40)), (128, 128, (1, 13, 37)),
                                             (128, 64, (1, 9, 33)), (256, 128, (2, 12, 40)),
                                             (512, 256, (1, 15, 80))])
