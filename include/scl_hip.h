@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SCL_ABI_VERSION 2
+#define SCL_ABI_VERSION 3
 
 /* error codes (negative = rejected before any launch) */
 #define SCL_OK 0
@@ -388,6 +388,14 @@ int scl_wrw3x3(const void* x, const void* gz, int B, int H, int W, int cin, int 
 int scl_wrw3x3_ex(const void* x, const void* gz, int B, int H, int W, int cin, int kout, void* gw,
                   int64_t w_stride_k, int64_t w_stride_c, int64_t w_stride_h, int64_t w_stride_w,
                   int gw_f32, void* workspace, size_t workspace_bytes, void* stream);
+/* ... and the bias gradient grad_bias[k] = sum over pixels of gz[.., k] (float32 [kout], NULL =
+ * not wanted) from the same pass: gz is in LDS for the weight gradient anyway, so the separate
+ * column-sum pass over the gradient map (scl_vgg_act_bwd without a mask) is not needed
+ * (tf.nn.bias_add's gradient under model/nets.py:39-63). */
+int scl_wrw3x3_bias(const void* x, const void* gz, int B, int H, int W, int cin, int kout, void* gw,
+                    int64_t w_stride_k, int64_t w_stride_c, int64_t w_stride_h, int64_t w_stride_w,
+                    int gw_f32, float* grad_bias, void* workspace, size_t workspace_bytes,
+                    void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Diagnostics (bench.py's live per-kernel timing; the reference has no counterpart

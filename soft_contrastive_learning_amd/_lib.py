@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libscl_hip.so")
 
 # constants of include/scl_hip.h
-ABI_VERSION = 2
+ABI_VERSION = 3
 DT_F32, DT_BF16 = 0, 1
 MASK_WMS_EXP, MASK_WMS_LIN, MASK_WMS_TANH, MASK_LABELS = 0, 1, 2, 3
 SUM_MS, SUM_PLAIN = 0, 1
@@ -81,6 +81,7 @@ SIGNATURES = {
     "scl_wrw3x3_workspace_bytes": (_z, [_i, _i]),
     "scl_wrw3x3": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _l, _l, _l, _l, _p, _z, _p]),
     "scl_wrw3x3_ex": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _l, _l, _l, _l, _i, _p, _z, _p]),
+    "scl_wrw3x3_bias": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _l, _l, _l, _l, _i, _p, _p, _z, _p]),
     "scl_conv_first_wrw_workspace_bytes": (_z, []),
     "scl_conv_first_wrw": (_i, [_p, _p, _i, _i, _i, _p, _l, _l, _l, _l, _i, _p, _p, _p, _p, _z, _p]),
     "scl_conv_first": (_i, [_p, _p, _p, _l, _l, _l, _l, _i, _p, _i, _i, _i, _p, _p, _p]),

@@ -372,7 +372,8 @@ template <int DBG, int TWv, int NKB>
 __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __restrict__ x,
                                                        const unsigned short* __restrict__ gz,
                                                        int B, int H, int W, int C, int K,
-                                                       float* __restrict__ slabs) {
+                                                       float* __restrict__ slabs,
+                                                       float* __restrict__ bslabs) {
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -449,6 +450,12 @@ __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __r
   f32x16 acc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = zero16();
+  // Bias gradient on the side: the B fragment of a step is 8 pixels of gz channel r of this
+  // wave's n-tile — summed into one register per lane (v_dot2c_f32_bf16 against (1, 1): four
+  // instructions per nine MFMAs, in every wave so that the loop stays branch-free; only the
+  // waves mt == 0 of the workgroups cb == 0 write theirs out).
+  float bsum = 0.f;
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
   // The wave's 72 (step, tap) products of a tile run as ONE software pipeline: the A operand
   // of product i + 3 is in flight while product i multiplies (an LDS transposed read returns
@@ -490,6 +497,16 @@ __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __r
       if (i % 9 == 2 && i / 9 + 1 < 8) bf[(i / 9 + 1) & 1] = b_of(i / 9 + 1);
       __builtin_amdgcn_sched_barrier(0);
       acc[i % 9] = mfma32b(af[i % DEPTH], bf[(i / 9) & 1], acc[i % 9]);
+      if (i % 9 == 4) {
+        const u32x4 bw = bf[(i / 9) & 1];
+        const bf16x2 one2 = __builtin_bit_cast(bf16x2, 0x3f803f80u);
+        // (element by element: indexing the vector in a loop made hipcc feed word 0 four times)
+        const unsigned w0 = bw.x, w1 = bw.y, w2 = bw.z, w3 = bw.w;
+        bsum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, w0), one2, bsum, false);
+        bsum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, w1), one2, bsum, false);
+        bsum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, w2), one2, bsum, false);
+        bsum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, w3), one2, bsum, false);
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA chunks have landed
     __syncthreads();
@@ -507,6 +524,10 @@ __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __r
 #pragma unroll
     for (int qq = 0; qq < 16; ++qq)
       out[(t * C64 + 32 * mt + acc_row(qq, h)) * C64 + 32 * (nt & 1) + r] = acc[t][qq];
+  // bias partials [slab][K]: the two pixel halves h of a step combined in a fixed order
+  const float bs = bsum + __shfl_xor(bsum, 32);
+  if (bslabs && blockIdx.y == 0 && mt == 0 && h == 0)
+    bslabs[(int64_t)slab * K + C64 * kb + 32 * (nt & 1) + r] = bs;
 }
 
 // dW element (k, c, kh, kw) = sum over the pixel-split slabs of its (cb, kb) block, written
@@ -516,7 +537,9 @@ __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __r
 __global__ __launch_bounds__(256) void wrw64_reduce_kernel(const float* __restrict__ slabs,
                                                            int nsplit, int KB, int64_t sk,
                                                            int64_t sc, int64_t sh, int64_t sw,
-                                                           void* __restrict__ gw, int gw_f32) {
+                                                           void* __restrict__ gw, int gw_f32,
+                                                           const float* __restrict__ bslabs,
+                                                           float* __restrict__ gb) {
   __shared__ f32x4 red[4][64];
   const int j = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int idx = 4 * (blockIdx.x * 64 + j);           // over 9 * 64 * 64, k fastest
@@ -540,6 +563,14 @@ __global__ __launch_bounds__(256) void wrw64_reduce_kernel(const float* __restri
       const int k = 64 * (blk % KB) + ((idx + e) & 63);
       store_weight_grad(gw, k * sk + c * sc + (t / 3) * sh + (t % 3) * sw, s[e], gw_f32);
     }
+  }
+  // bias gradient: the blocks (0, cb = 0, kb) add up the partials of their 64 channels, slab
+  // by slab in index order
+  if (gb && blockIdx.x == 0 && blk / KB == 0 && g == 1) {
+    const int K = 64 * KB, k = 64 * (blk % KB) + j;
+    float acc_b = 0.f;
+    for (int sl = 0; sl < nsplit; ++sl) acc_b += bslabs[(int64_t)sl * K + k];
+    gb[k] = acc_b;
   }
 }
 
@@ -1042,13 +1073,21 @@ extern "C" size_t scl_wrw3x3_workspace_bytes(int cin, int kout) {
   // slabs: at most (1024 CUs rounded up to whole (cb, kb) block sets) x 147,456 B
   const size_t blocks = (size_t)(cin / 64) * (kout / 64);
   const size_t p = (1024 + blocks - 1) / blocks;
-  return scl_round256(2 * p * blocks * 9 * 64 * 64 * sizeof(float));   // two slabs per workgroup
+  // two slabs per workgroup + the bias partials [slab][kout] of scl_wrw3x3_bias
+  return scl_round256(2 * p * blocks * 9 * 64 * 64 * sizeof(float)) +
+         scl_round256((2 * p + 2) * (size_t)kout * sizeof(float));
+}
+static size_t wrw_bias_slab_offset(int cin, int kout) {
+  const size_t blocks = (size_t)(cin / 64) * (kout / 64);
+  const size_t p = (1024 + blocks - 1) / blocks;
+  return scl_round256(2 * p * blocks * 9 * 64 * 64 * sizeof(float));
 }
 
-extern "C" int scl_wrw3x3_ex(const void* x, const void* gz, int B, int H, int W, int cin, int kout,
-                             void* gw, int64_t w_stride_k, int64_t w_stride_c, int64_t w_stride_h,
-                             int64_t w_stride_w, int gw_f32, void* workspace,
-                             size_t workspace_bytes, void* stream) {
+extern "C" int scl_wrw3x3_bias(const void* x, const void* gz, int B, int H, int W, int cin,
+                               int kout, void* gw, int64_t w_stride_k, int64_t w_stride_c,
+                               int64_t w_stride_h, int64_t w_stride_w, int gw_f32,
+                               float* grad_bias, void* workspace, size_t workspace_bytes,
+                               void* stream) {
   if (!x || !gz || !gw || !workspace) return SCL_E_NULL;
   const size_t need = scl_wrw3x3_workspace_bytes(cin, kout);
   if (need == 0 || B < 1 || H < 1 || W < 1 || (int64_t)B * H * W > (int64_t)1 << 30)
@@ -1084,7 +1123,8 @@ extern "C" int scl_wrw3x3_ex(const void* x, const void* gz, int B, int H, int W,
 #define SCL_WRW_LAUNCH(D, T, N)                                                                \
   SCL_LAUNCH("wrw64_kernel", (wrw64_kernel<D, T, N>), dim3(PP, cin / 64, kout / (64 * N)),     \
              dim3(512), (WrwCfg<T, N>::LDS), st, (const unsigned short*)x,                        \
-             (const unsigned short*)gz, B, H, W, cin, kout, (float*)workspace)
+             (const unsigned short*)gz, B, H, W, cin, kout, (float*)workspace, bslabs)
+  float* bslabs = grad_bias ? (float*)((char*)workspace + wrw_bias_slab_offset(cin, kout)) : nullptr;
   int PP = P;
   if (nkb == 2) {
     PP = wrw_splits(cin, kout / 2, tiles, cus);
@@ -1095,8 +1135,16 @@ extern "C" int scl_wrw3x3_ex(const void* x, const void* gz, int B, int H, int W,
 #undef SCL_WRW_LAUNCH
   SCL_LAUNCH("wrw64_reduce_kernel", wrw64_reduce_kernel, dim3(9 * 64 * 64 / 256, (cin / 64) * (kout / 64)),
              dim3(256), 0, st, (const float*)workspace, nkb == 1 ? 2 * PP : PP, kout / 64, w_stride_k,
-             w_stride_c, w_stride_h, w_stride_w, gw, gw_f32 ? 1 : 0);
+             w_stride_c, w_stride_h, w_stride_w, gw, gw_f32 ? 1 : 0, (const float*)bslabs, grad_bias);
   return scl_launch_status();
+}
+
+extern "C" int scl_wrw3x3_ex(const void* x, const void* gz, int B, int H, int W, int cin, int kout,
+                             void* gw, int64_t w_stride_k, int64_t w_stride_c, int64_t w_stride_h,
+                             int64_t w_stride_w, int gw_f32, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+  return scl_wrw3x3_bias(x, gz, B, H, W, cin, kout, gw, w_stride_k, w_stride_c, w_stride_h,
+                         w_stride_w, gw_f32, nullptr, workspace, workspace_bytes, stream);
 }
 
 extern "C" int scl_wrw3x3(const void* x, const void* gz, int B, int H, int W, int cin, int kout,

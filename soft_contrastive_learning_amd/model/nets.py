@@ -253,10 +253,11 @@ def _own_wrw_ok(x, gz, w):
             and max(w.shape[0], w.shape[1]) <= 1024)
 
 
-def wrw64(x, gz, w_like):
+def wrw64(x, gz, w_like, bias_grad=None):
     """Weight gradient of a 3x3 same-padding convolution whose channel counts are multiples
-    of 64 (``scl_wrw3x3_ex``): [kout,cin,3,3] with the dtype (bf16 or float32) and strides of
-    ``w_like``."""
+    of 64 (``scl_wrw3x3_bias``): [kout,cin,3,3] with the dtype (bf16 or float32) and strides of
+    ``w_like``.  ``bias_grad`` (float32 [kout]) receives the column sums of ``gz`` — the bias
+    gradient — from the same pass."""
     lib = L.load()
     L.require_device(x, gz)
     x = x.contiguous(memory_format=_CL)
@@ -267,9 +268,12 @@ def wrw64(x, gz, w_like):
     _work('wrw64_kernel', 2.0 * b * h * wd * cin * kout * 9, 2.0 * b * h * wd * (cin + kout))
     ws = L.workspace(lib.scl_wrw3x3_workspace_bytes(cin, kout), x.device)
     sk, sc, sh, sw = gw.stride()
-    L.check(lib.scl_wrw3x3_ex(L.ptr(x), L.ptr(gz), b, h, wd, cin, kout, L.ptr(gw), sk, sc, sh, sw,
-                              int(gw.dtype == torch.float32), L.ptr(ws), ws.numel(),
-                              L.stream_of(x)))
+    if bias_grad is not None and not (bias_grad.dtype == torch.float32 and bias_grad.is_contiguous()
+                                      and bias_grad.numel() == kout):
+        raise ValueError("bias_grad must be a contiguous float32 vector of kout elements")
+    L.check(lib.scl_wrw3x3_bias(L.ptr(x), L.ptr(gz), b, h, wd, cin, kout, L.ptr(gw), sk, sc, sh, sw,
+                                int(gw.dtype == torch.float32), L.ptr(bias_grad), L.ptr(ws),
+                                ws.numel(), L.stream_of(x)))
     return gw
 
 
@@ -309,6 +313,7 @@ class _GradLink:
         return hit
 
 
+USE_BIAS_IN_WRW = os.environ.get('SCL_BIAS_IN_WRW', '1') != '0'
 USE_MASKED_BWD = os.environ.get('SCL_MASKED_BWD', '1') != '0'
 USE_POOL_IDX = os.environ.get('SCL_POOL_IDX', '1') != '0'
 USE_F32_WEIGHTS = os.environ.get('SCL_F32_WEIGHTS', '1') != '0'
@@ -339,27 +344,34 @@ def conv_pool_idx(x, w, bias):
     return a, idx
 
 
-def _conv3x3_backward(gz, x, w, need_x, link=None):
+def _own_wrw_used(x, gz, w):
+    return _own_wrw_ok(x, gz, w) and _wrw_pays(x)
+
+
+def _conv3x3_backward(gz, x, w, need_x, link=None, gb=None):
     """(gx, gw) of a 3x3 convolution.  With ``link`` (x is a post-ReLU map whose producer
     holds the other end) an own backward-data kernel returns gx * [x > 0] and marks the
-    link."""
+    link.  ``gb`` (only where ``_own_wrw_used``): the weight-gradient kernel also writes the
+    bias gradient there."""
     kind = _own_conv_kind(gz, w, True)
     own_gx = kind == 'reg' or (kind == 'lds' and _lds_conv_pays(gz, True))
-    own_gw = _own_wrw_ok(x, gz, w) and _wrw_pays(x)
+    own_gw = _own_wrw_used(x, gz, w)
+    if gb is not None and not own_gw:
+        raise RuntimeError("bias gradient requested from a weight-gradient pass that is not own")
     if own_gx and need_x and link is not None and USE_MASKED_BWD:
         gx = conv64(gz, w, True, mask=x)
         link.mark(gx)
         if own_gw:
-            return gx, wrw64(x, gz, w)
+            return gx, wrw64(x, gz, w, gb)
         _, gw, _ = torch.ops.aten.convolution_backward(gz, x, _lib_weight(w, gz), None, _ONES,
                                                        _ONES, _ONES, False, [0, 0], 1,
                                                        [False, True, False])
         return gx, gw.to(w.dtype)
     if own_gx and own_gw:
-        return (conv64(gz, w, True) if need_x else None), wrw64(x, gz, w)
+        return (conv64(gz, w, True) if need_x else None), wrw64(x, gz, w, gb)
     if own_gx or own_gw:
         gx = conv64(gz, w, True) if (own_gx and need_x) else None
-        gw = wrw64(x, gz, w) if own_gw else None
+        gw = wrw64(x, gz, w, gb) if own_gw else None
         if (gx is None and need_x) or gw is None:
             lx, lw, _ = torch.ops.aten.convolution_backward(
                 gz, x, _lib_weight(w, gz), None, _ONES, _ONES, _ONES, False, [0, 0], 1,
@@ -416,12 +428,17 @@ class _ConvBiasAct(torch.autograd.Function):
         masked = ctx.link_out is not None and ctx.link_out.take(gy)
         mask_here = ctx.relu and not masked
         gz = torch.empty_like(gy) if mask_here else gy
-        _work('vgg_act_bwd', 0.0, (3.0 if mask_here else 1.0) * gy.numel() * gy.element_size())
-        L.check(lib.scl_vgg_act_bwd(L.ptr(gy), L.ptr(y) if mask_here else None,
-                                    _glue_dtype(gy), b * h * wd, c,
-                                    L.ptr(gz) if mask_here else None, L.ptr(gb), L.ptr(ws),
-                                    ws.numel(), L.stream_of(gy)))
-        gx, gw = _conv3x3_backward(gz, x, w, ctx.needs_input_grad[0], ctx.link_in)
+        # nothing to mask: the bias gradient (column sums of gy) comes out of the own
+        # weight-gradient kernel, which has gy in LDS anyway — no separate pass over the map
+        fold = USE_BIAS_IN_WRW and not mask_here and _own_wrw_used(x, gy, w)
+        if not fold:
+            _work('vgg_act_bwd', 0.0, (3.0 if mask_here else 1.0) * gy.numel() * gy.element_size())
+            L.check(lib.scl_vgg_act_bwd(L.ptr(gy), L.ptr(y) if mask_here else None,
+                                        _glue_dtype(gy), b * h * wd, c,
+                                        L.ptr(gz) if mask_here else None, L.ptr(gb), L.ptr(ws),
+                                        ws.numel(), L.stream_of(gy)))
+        gx, gw = _conv3x3_backward(gz, x, w, ctx.needs_input_grad[0], ctx.link_in,
+                                   gb if fold else None)
         return gx, _grad_ret(gw, w), _grad_ret(gb, bias), None, None, None
 
 

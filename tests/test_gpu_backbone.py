@@ -313,6 +313,14 @@ def test_wrw_other_shapes(dev, cin, cout, shape):
     assert got.shape == wf.grad.shape and got.stride() == like.stride()
     assert float((got.float() - wf.grad).abs().max() / wf.grad.abs().max()) < 6e-3
     assert torch.equal(got, nets.wrw64(x, gz, like))
+    # the bias gradient from the same pass (scl_wrw3x3_bias): column sums of gz in float32
+    gb = torch.full((cout,), 7.0, device=dev)
+    assert torch.equal(nets.wrw64(x, gz, like, gb), got)
+    want_gb = gz.float().sum(dim=(0, 2, 3))
+    assert float((gb - want_gb).abs().max()) < 1e-4 * float(gz.float().abs().sum(dim=(0, 2, 3)).max())
+    gb2 = torch.empty_like(gb)
+    nets.wrw64(x, gz, like, gb2)
+    assert torch.equal(gb, gb2)                          # fixed summation order
 
 
 @pytest.mark.parametrize('shape', [(2, 16, 40), (1, 13, 37), (1, 480, 640)])
@@ -367,8 +375,10 @@ def test_backward_data_with_relu_mask_in_the_epilogue(dev, cin, cout, shape, blo
 
 def test_masked_backward_chain_equals_separate_masking_pass(dev):
     """The hand-off of ReLU' to the layer above (nets._GradLink) must not change a gradient:
-    a three-layer chain of own kernels gives bit-identical results with and without it, and
-    the lower layers really skip their masking pass."""
+    a three-layer chain of own kernels gives bit-identical input and weight gradients with and
+    without it, and the lower layers really skip their masking pass.  The bias gradients of the
+    handed-off layers come out of the weight-gradient kernel instead of the masking pass: the
+    same float32 column sums in another order."""
     from soft_contrastive_learning_amd.model import nets
     g = torch.Generator().manual_seed(41)
     cl = torch.channels_last
@@ -404,8 +414,11 @@ def test_masked_backward_chain_equals_separate_masking_pass(dev):
         nets._GradLink.take = orig
     assert takes == [True, True]
     plain = run(False)
-    for a, b_ in zip(linked, plain):
+    for a, b_ in zip(linked[:4], plain[:4]):
         assert torch.equal(a, b_)
+    for a, b_ in zip(linked[4:], plain[4:]):
+        assert float((a - b_).abs().max()) <= 1e-5 * float(b_.abs().max()) + 1e-6
+    assert torch.equal(linked[6], plain[6])              # pooled layer: same kernel either way
 
 
 @pytest.mark.parametrize('shape', [(2, 16, 40), (1, 13, 37), (2, 120, 160)])
