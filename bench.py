@@ -375,6 +375,7 @@ def main():
     _lib.load()
     if args.variant:
         _lib.load().scl_debug_set_variant(args.variant)
+        nets.USE_PREPACK = False      # a pinned kernel may not read the packed-image layout
 
     b, gb = args.batch, args.batch * world
     cdt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SCL_ABI_VERSION 3
+#define SCL_ABI_VERSION 4
 
 /* error codes (negative = rejected before any launch) */
 #define SCL_OK 0
@@ -274,6 +274,8 @@ int scl_vgg_pool_bwd(const void* g, const void* a, const void* z, int dtype, int
  *   workspace scl_conv64_workspace_bytes() bytes (the packed weight image). */
 /* The `transposed` argument of every convolution entry point is a flag word: */
 #define SCL_CONV_TRANSPOSED 1 /* backward-data: out = conv_transpose(x, w)                      */
+#define SCL_W_PACKED 4        /* w is a packed image written by scl_conv_pack_batch for this     *
+                               * (cin, kout, direction); the strides are ignored                 */
 #define SCL_W_F32 2           /* w is the float32 master weight (rounded to bf16 while it is    */
                               /* packed: no separate cast pass); default bf16                   */
 size_t scl_conv64_workspace_bytes(void);
@@ -396,6 +398,22 @@ int scl_wrw3x3_bias(const void* x, const void* gz, int B, int H, int W, int cin,
                     int64_t w_stride_k, int64_t w_stride_c, int64_t w_stride_h, int64_t w_stride_w,
                     int gw_f32, float* grad_bias, void* workspace, size_t workspace_bytes,
                     void* stream);
+
+/* All packed weight images of a training step in ONE launch (the convolutions above otherwise
+ * each run a 4-10 us packing kernel in front of themselves: 24 per step on the critical
+ * path).  The weights change once per step (train/train.py:877-879), so the caller packs every
+ * (layer, direction) up front and passes the images with SCL_W_PACKED in the flags argument.
+ * jobs is a HOST array; packed buffers are scl_conv_packed_bytes(cin, kout) each (0 = the
+ * shape has no packed form: cin % 64, kout % 128 for the LDS-weights kernels), 256-byte
+ * aligned.  flags per job: SCL_CONV_TRANSPOSED and / or SCL_W_F32. */
+typedef struct SclPackJob {
+  const void* w;
+  int64_t w_stride_k, w_stride_c, w_stride_h, w_stride_w;
+  int flags, cin, kout;      /* cin = contraction channels, kout = output channels of the pass */
+  void* packed;
+} SclPackJob;
+size_t scl_conv_packed_bytes(int cin, int kout);
+int scl_conv_pack_batch(const SclPackJob* jobs, int njobs, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Diagnostics (bench.py's live per-kernel timing; the reference has no counterpart

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libscl_hip.so")
 
 # constants of include/scl_hip.h
-ABI_VERSION = 3
+ABI_VERSION = 4
 DT_F32, DT_BF16 = 0, 1
 MASK_WMS_EXP, MASK_WMS_LIN, MASK_WMS_TANH, MASK_LABELS = 0, 1, 2, 3
 SUM_MS, SUM_PLAIN = 0, 1
@@ -20,7 +20,7 @@ TUPLE_TRIPLET, TUPLE_LAZY_TRIPLET, TUPLE_EVIL_TRIPLET = 0, 1, 2
 TUPLE_QUADRUPLET, TUPLE_LAZY_QUADRUPLET, TUPLE_EVIL_QUADRUPLET = 3, 4, 5
 VLAD_D, VLAD_K = 512, 64
 TOPN_SCORE_F32, TOPN_SCORE_BF16X3 = 0, 1
-CONV_TRANSPOSED, W_F32 = 1, 2          # flag word of the convolution entry points
+CONV_TRANSPOSED, W_F32, W_PACKED = 1, 2, 4   # flag word of the convolution entry points
 
 _p = ctypes.c_void_p
 _i = ctypes.c_int
@@ -28,8 +28,18 @@ _l = ctypes.c_int64
 _f = ctypes.c_float
 _z = ctypes.c_size_t
 
+
+
+class PackJob(ctypes.Structure):
+    """SclPackJob of include/scl_hip.h."""
+    _fields_ = [("w", _p), ("w_stride_k", _l), ("w_stride_c", _l), ("w_stride_h", _l),
+                ("w_stride_w", _l), ("flags", _i), ("cin", _i), ("kout", _i), ("packed", _p)]
+
+
 # name -> (restype, argtypes); every symbol include/scl_hip.h declares
 SIGNATURES = {
+    "scl_conv_packed_bytes": (_z, [_i, _i]),
+    "scl_conv_pack_batch": (_i, [ctypes.POINTER(PackJob), _i, _p]),
     "scl_abi_version": (_i, []),
     "scl_error_string": (ctypes.c_char_p, [_i]),
     "scl_netvlad_fwd_workspace_bytes": (_z, [_i, _i]),

@@ -531,16 +531,19 @@ __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __r
 }
 
 // dW element (k, c, kh, kw) = sum over the pixel-split slabs of its (cb, kb) block, written
-// at the weight's strides (bf16 or float32).  grid (9*64*64/256, CB * KB), block 256: thread
-// (j, g) sums the slabs p = g, g + 4, ... of the FOUR elements 4 (64 * blockIdx.x + j) .. + 3
-// (16-byte loads); the four partials are combined in a fixed order.
-__global__ __launch_bounds__(256) void wrw64_reduce_kernel(const float* __restrict__ slabs,
-                                                           int nsplit, int KB, int64_t sk,
-                                                           int64_t sc, int64_t sh, int64_t sw,
-                                                           void* __restrict__ gw, int gw_f32,
-                                                           const float* __restrict__ bslabs,
-                                                           float* __restrict__ gb) {
-  __shared__ f32x4 red[4][64];
+// at the weight's strides (bf16 or float32).  grid (9*64*64/256, CB * KB), block 64 x RG: thread
+// (j, g) sums the slabs p = g, g + RG, ... of the FOUR elements 4 (64 * blockIdx.x + j) .. + 3
+// (16-byte loads); the RG partials are combined in a fixed order.  RG = 4, or 16 where few
+// (cb, kb) blocks face many slabs (conv1_2 / conv2_1: 256 and 128 slabs for 1 and 2 blocks —
+// with four groups the 37 MB took 75 us).
+template <int RG>
+__global__ __launch_bounds__(64 * RG) void wrw64_reduce_kernel(const float* __restrict__ slabs,
+                                                              int nsplit, int KB, int64_t sk,
+                                                              int64_t sc, int64_t sh, int64_t sw,
+                                                              void* __restrict__ gw, int gw_f32,
+                                                              const float* __restrict__ bslabs,
+                                                              float* __restrict__ gb) {
+  __shared__ f32x4 red[RG][64];
   const int j = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int idx = 4 * (blockIdx.x * 64 + j);           // over 9 * 64 * 64, k fastest
   const int blk = blockIdx.y, nblk = gridDim.y;        // blk = cb * KB + kb
@@ -548,15 +551,17 @@ __global__ __launch_bounds__(256) void wrw64_reduce_kernel(const float* __restri
   const float* base = slabs + (int64_t)blk * 9 * C64 * C64 + idx;
   f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
   int i = g;
-  for (; i + 4 < nsplit; i += 8) {
+  for (; i + RG < nsplit; i += 2 * RG) {
     s0 += *reinterpret_cast<const f32x4*>(base + (int64_t)i * stride);
-    s1 += *reinterpret_cast<const f32x4*>(base + (int64_t)(i + 4) * stride);
+    s1 += *reinterpret_cast<const f32x4*>(base + (int64_t)(i + RG) * stride);
   }
   if (i < nsplit) s0 += *reinterpret_cast<const f32x4*>(base + (int64_t)i * stride);
   red[g][j] = s0 + s1;
   __syncthreads();
   if (g == 0) {
-    const f32x4 s = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+    f32x4 s = red[0][j];
+#pragma unroll
+    for (int q = 1; q < RG; ++q) s += red[q][j];
     const int c = 64 * (blk / KB) + ((idx >> 6) & 63), t = idx >> 12;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -934,10 +939,13 @@ int launch_conv3x3(const void* x, const void* w, int64_t sk, int64_t sc, int64_t
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
     cus = conv64_cus();
   });
-  unsigned short* packed = (unsigned short*)workspace;
-  SCL_LAUNCH("conv3x3_pack_kernel", (conv3x3_pack_kernel<CIN, KOUT>),
-             dim3(Cfg::NT * Cfg::KS * 512 / 256), dim3(256), 0, st, w, sk, sc, sh, sw, transposed,
-             packed);
+  const unsigned short* packed = (const unsigned short*)workspace;
+  if (transposed & SCL_W_PACKED)
+    packed = (const unsigned short*)w;                   // scl_conv_pack_batch wrote it
+  else
+    SCL_LAUNCH("conv3x3_pack_kernel", (conv3x3_pack_kernel<CIN, KOUT>),
+               dim3(Cfg::NT * Cfg::KS * 512 / 256), dim3(256), 0, st, w, sk, sc, sh, sw, transposed,
+               (unsigned short*)workspace);
   const int tiles = B * ((H + Cfg::TH_ - 1) / Cfg::TH_) * ((W + TW - 1) / TW);
   const dim3 grid(tiles < cus ? tiles : cus);
   if (scl_debug_variant / 1000 == 60) relu |= (scl_debug_variant & 3) << 1;
@@ -1017,7 +1025,7 @@ extern "C" int scl_conv3x3_pool_idx(const void* x, const void* w, int64_t w_stri
                                     const float* bias, void* pooled, void* pool_idx,
                                     void* workspace, size_t workspace_bytes, void* stream) {
   if (!pool_idx || !pooled || !bias) return SCL_E_NULL;
-  return conv3x3_dispatch(x, w, w_stride_k, w_stride_c, w_stride_h, w_stride_w, flags & 2, B, H, W, cin,
+  return conv3x3_dispatch(x, w, w_stride_k, w_stride_c, w_stride_h, w_stride_w, flags & 6, B, H, W, cin,
                           kout, nullptr, bias, 0, pooled, nullptr, pool_idx, workspace,
                           workspace_bytes, stream);
 }
@@ -1133,9 +1141,14 @@ extern "C" int scl_wrw3x3_bias(const void* x, const void* gz, int B, int H, int 
   else if (dbg == 0) SCL_WRW_LAUNCH(0, 32, 1);
   else SCL_WRW_LAUNCH(2, 32, 1);
 #undef SCL_WRW_LAUNCH
-  SCL_LAUNCH("wrw64_reduce_kernel", wrw64_reduce_kernel, dim3(9 * 64 * 64 / 256, (cin / 64) * (kout / 64)),
-             dim3(256), 0, st, (const float*)workspace, nkb == 1 ? 2 * PP : PP, kout / 64, w_stride_k,
-             w_stride_c, w_stride_h, w_stride_w, gw, gw_f32 ? 1 : 0, (const float*)bslabs, grad_bias);
+  const int nslab = nkb == 1 ? 2 * PP : PP, nblk = (cin / 64) * (kout / 64);
+#define SCL_WRW_REDUCE(RG)                                                                     \
+  SCL_LAUNCH("wrw64_reduce_kernel", wrw64_reduce_kernel<RG>, dim3(9 * 64 * 64 / 256, nblk),    \
+             dim3(64 * RG), 0, st, (const float*)workspace, nslab, kout / 64, w_stride_k,      \
+             w_stride_c, w_stride_h, w_stride_w, gw, gw_f32 ? 1 : 0, (const float*)bslabs,     \
+             grad_bias)
+  if (nblk <= 4 && nslab >= 32) SCL_WRW_REDUCE(16); else SCL_WRW_REDUCE(4);
+#undef SCL_WRW_REDUCE
   return scl_launch_status();
 }
 

@@ -423,6 +423,8 @@ static int convg_dispatch(const void* x, const void* w, int64_t w_stride_k, int6
     use_h = dv >= 50000;
     dv -= use_h ? 50000 : 40000;
   }
+  if ((transposed & SCL_W_PACKED) && !(use_h && cin % 64 == 0))
+    return SCL_E_KIND;                       // packed images exist in convh.hip's layout only
   if (use_h && (cin / 64) * 64 == cin)     // convh.hip walks the 32-channel chunks in pairs
     return scl_convh_dispatch(x, w, w_stride_k, w_stride_c, w_stride_h, w_stride_w, transposed, B, H,
                               W, cin, kout, out, bias, relu, mask, pidx, workspace, dv, stream);
@@ -495,7 +497,7 @@ extern "C" int scl_convg_pool_idx(const void* x, const void* w, int64_t w_stride
                                   const float* bias, void* pooled, void* pool_idx, void* workspace,
                                   size_t workspace_bytes, void* stream) {
   if (!pool_idx || !pooled || !bias) return SCL_E_NULL;
-  return convg_dispatch(x, w, w_stride_k, w_stride_c, w_stride_h, w_stride_w, flags & 2, B, H, W,
+  return convg_dispatch(x, w, w_stride_k, w_stride_c, w_stride_h, w_stride_w, flags & 6, B, H, W,
                         cin, kout, pooled, bias, 0, nullptr, pool_idx, workspace, workspace_bytes,
                         stream);
 }

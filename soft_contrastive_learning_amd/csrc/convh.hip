@@ -478,10 +478,15 @@ int scl_convh_dispatch(const void* x, const void* w, int64_t w_stride_k, int64_t
 #undef SCL_CONVH_ATTR
   });
   hipStream_t st = (hipStream_t)stream;
-  unsigned short* packed = (unsigned short*)workspace;
-  const int64_t total = (int64_t)9 * (cin / HCCH) * kout * HCCH;
-  SCL_LAUNCH("convg_pack_kernel", convh_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256),
-             0, st, w, w_stride_k, w_stride_c, w_stride_h, w_stride_w, flags, cin, kout, packed);
+  const unsigned short* packed = (const unsigned short*)workspace;
+  if (flags & SCL_W_PACKED) {
+    packed = (const unsigned short*)w;                 // scl_conv_pack_batch wrote it
+  } else {
+    const int64_t total = (int64_t)9 * (cin / HCCH) * kout * HCCH;
+    SCL_LAUNCH("convg_pack_kernel", convh_pack_kernel, dim3((unsigned)((total + 255) / 256)),
+               dim3(256), 0, st, w, w_stride_k, w_stride_c, w_stride_h, w_stride_w, flags, cin, kout,
+               (unsigned short*)workspace);
+  }
   const int bx = (W + HBW - 1) / HBW, kb = kout / HNB;
   // block height: the one with the fewest (rounds of one workgroup per CU) x (window rows)
   const int cus = convh_cus();

@@ -155,6 +155,57 @@ def _wflag(w):
     return L.W_F32 if w.dtype == torch.float32 else 0
 
 
+# ---- packed weight images, all in one launch per step -------------------------------------
+# Each own convolution otherwise packs its weights in a small kernel of its own, 24 of them per
+# training step on the critical path.  prepack() writes every image a step will need with ONE
+# launch (scl_conv_pack_batch); conv64 / conv_pool_idx find them here by (storage address,
+# direction) and a version check, and fall back to packing for themselves on a miss.
+USE_PREPACK = os.environ.get('SCL_PREPACK', '1') != '0'
+_PACKED = {}     # (data_ptr, transposed) -> (weakref to the weight, _version, shape, image)
+
+
+def prepack(weights):
+    """Bring the packed images of ``weights`` (3x3 convolution weights on a HIP device, both
+    directions) up to date; returns the number of images written."""
+    import weakref
+    lib = L.load()
+    jobs, keep = [], []
+    for w in weights:
+        if not (w.is_cuda and w.dtype in _W_DTYPES and w.dim() == 4 and tuple(w.shape[2:]) == (3, 3)):
+            continue
+        for transposed in (False, True):
+            cin, kout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
+            nbytes = lib.scl_conv_packed_bytes(cin, kout)
+            if nbytes == 0:
+                continue
+            key = (w.data_ptr(), transposed)
+            ent = _PACKED.get(key)
+            if ent is not None and ent[0]() is not None and ent[1] == w._version and ent[2] == tuple(w.shape):
+                continue
+            buf = (ent[3] if ent is not None and ent[3].numel() == nbytes and ent[3].device == w.device
+                   else torch.empty(nbytes, dtype=torch.uint8, device=w.device))
+            _PACKED[key] = (weakref.ref(w), w._version, tuple(w.shape), buf)
+            sk, sc, sh, sw = w.stride()
+            jobs.append(L.PackJob(L.ptr(w), sk, sc, sh, sw, int(transposed) | _wflag(w), cin, kout,
+                                  L.ptr(buf)))
+            keep.append(w)
+    if jobs:
+        L.require_device(*keep)
+        arr = (L.PackJob * len(jobs))(*jobs)
+        L.check(lib.scl_conv_pack_batch(arr, len(jobs), L.stream_of(keep[0])))
+    return len(jobs)
+
+
+def _packed_for(w, transposed):
+    """The up-to-date packed image of ``w`` for this direction, or None."""
+    if not USE_PREPACK:
+        return None
+    ent = _PACKED.get((w.data_ptr(), bool(transposed)))
+    if ent is None or ent[0]() is None or ent[1] != w._version or ent[2] != tuple(w.shape):
+        return None
+    return ent[3]
+
+
 def _lib_weight(w, x):
     """The weight as the library convolution wants it: activation dtype, channels-last."""
     if w.dtype == x.dtype and w.is_contiguous(memory_format=_CL):
@@ -217,6 +268,9 @@ def conv64(x, w, transposed=False, bias=None, relu=False, pool=False, mask=None)
     _work('conv3x3_kernel' if (cin, kout) in _OWN_CONV_SHAPES else 'convg_kernel',
           2.0 * px * cin * kout * 9,
           2.0 * px * (cin + kout * (1 + (mask is not None) + 0.25 * bool(pool))))
+    pk = _packed_for(w, transposed)
+    wp = L.ptr(w) if pk is None else L.ptr(pk)            # the weight, or its packed image
+    wflags = (int(bool(transposed)) | _wflag(w)) if pk is None else (int(bool(transposed)) | L.W_PACKED)
     if mask is not None:
         if bias is not None or pool or relu:
             raise ValueError("mask excludes the forward tails (bias / relu / pool)")
@@ -227,20 +281,20 @@ def conv64(x, w, transposed=False, bias=None, relu=False, pool=False, mask=None)
         ws = L.workspace(lib.scl_conv3x3_workspace_bytes() if own
                          else lib.scl_convg_workspace_bytes(cin, kout), x.device)
         fn = lib.scl_conv3x3_masked if own else lib.scl_convg_masked
-        L.check(fn(L.ptr(x), L.ptr(w), sk, sc, sh, sw, int(bool(transposed)) | _wflag(w), b, h, wd,
+        L.check(fn(L.ptr(x), wp, sk, sc, sh, sw, wflags, b, h, wd,
                    cin, kout, L.ptr(out), L.ptr(mask), L.ptr(ws), ws.numel(), L.stream_of(x)))
         return out
     if (cin, kout) not in _OWN_CONV_SHAPES:
         if pool:
             raise ValueError("the fused pooling epilogue exists for the register kernels only")
         ws = L.workspace(lib.scl_convg_workspace_bytes(cin, kout), x.device)
-        L.check(lib.scl_convg(L.ptr(x), L.ptr(w), sk, sc, sh, sw, int(bool(transposed)) | _wflag(w),
+        L.check(lib.scl_convg(L.ptr(x), wp, sk, sc, sh, sw, wflags,
                               b, h, wd, cin, kout, L.ptr(out), L.ptr(bias), int(bool(relu)),
                               L.ptr(ws), ws.numel(), L.stream_of(x)))
         return out
     ws = L.workspace(lib.scl_conv3x3_workspace_bytes(), x.device)
-    L.check(lib.scl_conv3x3_fused(L.ptr(x), L.ptr(w), sk, sc, sh, sw,
-                                  int(bool(transposed)) | _wflag(w), b, h, wd, cin, kout,
+    L.check(lib.scl_conv3x3_fused(L.ptr(x), wp, sk, sc, sh, sw,
+                                  wflags, b, h, wd, cin, kout,
                                   L.ptr(out), L.ptr(bias), int(bool(relu)), L.ptr(pooled),
                                   L.ptr(ws), ws.numel(), L.stream_of(x)))
     return (out, pooled) if pool else out
@@ -338,7 +392,9 @@ def conv_pool_idx(x, w, bias):
     ws = L.workspace(lib.scl_conv3x3_workspace_bytes() if own
                      else lib.scl_convg_workspace_bytes(cin, kout), x.device)
     fn = lib.scl_conv3x3_pool_idx if own else lib.scl_convg_pool_idx
-    L.check(fn(L.ptr(x), L.ptr(w), sk, sc, sh, sw, _wflag(w), b, h, wd, cin, kout,
+    pk = _packed_for(w, False)
+    L.check(fn(L.ptr(x), L.ptr(w) if pk is None else L.ptr(pk), sk, sc, sh, sw,
+               _wflag(w) if pk is None else L.W_PACKED, b, h, wd, cin, kout,
                L.ptr(bias.float().contiguous()), L.ptr(a), L.ptr(idx), L.ptr(ws), ws.numel(),
                L.stream_of(x)))
     return a, idx
@@ -697,6 +753,9 @@ class VGG16NetVLAD(torch.nn.Module):
             x = x.contiguous(memory_format=torch.channels_last)
         skip_pool = False
         link = None        # set while x is the post-ReLU output of the previous conv node
+        if fuse and dt == torch.bfloat16 and USE_CONV64 and USE_F32_WEIGHTS and USE_PREPACK:
+            # every packed weight image of this step (both directions) in one launch
+            prepack([getattr(self, 'conv%s_kernel' % n) for n in self.conv_names])
         for idx, item in enumerate(VGG_LAYERS):
             if item == 'pool':
                 if not skip_pool:

@@ -613,3 +613,45 @@ def test_lds_weight_conv_persistent_workgroups_equal_one_tile_per_workgroup(dev,
             assert torch.equal(a, bb), variant
     z32 = torch.nn.functional.conv2d(x.float(), wt.float(), padding=1)
     assert float((outs[0][0].float() - z32).abs().max()) < 6e-3 * float(z32.abs().max())
+
+
+def test_prepacked_weight_images_equal_self_packing(dev):
+    """nets.prepack (scl_conv_pack_batch: every packed weight image of a step in one launch)
+    + SCL_W_PACKED must give the same bits as each convolution packing for itself — register
+    and LDS-weights kernels, forward (all tails) and backward-data, float32 master and bf16
+    weights — and a weight changed in place must not be served from a stale image."""
+    from soft_contrastive_learning_amd.model import nets
+    g = torch.Generator().manual_seed(83)
+    cl = torch.channels_last
+    cases = [(64, 64, torch.float32), (64, 128, torch.bfloat16), (128, 128, torch.float32),
+             (128, 256, torch.float32), (256, 256, torch.bfloat16), (512, 512, torch.float32)]
+    for cin, cout, wdt in cases:
+        b, h, w = 1, 14, 40
+        x = torch.randn(b, cin, h, w, generator=g).to(dev).bfloat16().contiguous(memory_format=cl)
+        gy = torch.randn(b, cout, h, w, generator=g).to(dev).bfloat16().contiguous(memory_format=cl)
+        wt = (torch.randn(cout, cin, 3, 3, generator=g) * 0.03).to(dev)
+        wt = wt.bfloat16().contiguous(memory_format=cl) if wdt == torch.bfloat16 else wt
+        bias = torch.randn(cout, generator=g).to(dev)
+        mask = torch.randn(b, cin, h, w, generator=g).to(dev).bfloat16().contiguous(memory_format=cl)
+
+        def run_all():
+            outs = [nets.conv64(x, wt, False), nets.conv64(x, wt, False, bias=bias, relu=True),
+                    nets.conv64(gy, wt, True), nets.conv64(gy, wt, True, mask=mask)]
+            if cin == cout:
+                outs += list(nets.conv_pool_idx(x, wt, bias))
+            return [t.clone() for t in outs]
+        nets._PACKED.clear()
+        plain = run_all()
+        assert nets.prepack([wt]) == 2 and nets.prepack([wt]) == 0
+        assert nets._packed_for(wt, False) is not None and nets._packed_for(wt, True) is not None
+        packed = run_all()
+        for a, bb in zip(plain, packed):
+            assert torch.equal(a, bb), (cin, cout, wdt)
+        wt.mul_(0.5)                                       # in place: the images are stale now
+        assert nets._packed_for(wt, False) is None
+        halved = run_all()
+        assert not torch.equal(halved[0], plain[0])
+        assert nets.prepack([wt]) == 2
+        for a, bb in zip(halved, run_all()):
+            assert torch.equal(a, bb), (cin, cout, wdt)
+    nets._PACKED.clear()
