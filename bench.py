@@ -69,6 +69,9 @@ def parse():
                          'the warm-up and replay it for the timed steps; 0 (default): eager. '
                          'Measured on MI355X: 14.234 ms per step either way — the host runs ahead '
                          'of the device, the step is not launch-bound')
+    ap.add_argument('--side-wrw', type=int, default=1,
+                    help='1 (default): weight-gradient kernels on a second HIP stream next to the '
+                         'backward-data kernels; 0: one stream (A/B)')
     ap.add_argument('--variant', type=int, default=0,
                     help='DIAGNOSTICS: scl_debug_set_variant value for A/B runs of kernel variants '
                          'on one box (0 = production; anything else is not a benchmark result)')
@@ -373,6 +376,7 @@ def main():
     from soft_contrastive_learning_amd import _lib, parallel
     from soft_contrastive_learning_amd.model import losses, nets
     _lib.load()
+    nets.USE_SIDE_WRW = bool(args.side_wrw) and nets.USE_SIDE_WRW
     if args.variant:
         _lib.load().scl_debug_set_variant(args.variant)
         nets.USE_PREPACK = False      # a pinned kernel may not read the packed-image layout
@@ -469,12 +473,19 @@ def main():
     per_step = sorted(evs[k].elapsed_time(evs[k + 1]) for k in range(args.steps))
     if not in_region:
         nets.WORK_LOG = {}    # algorithmic flops / bytes of the backbone kernels, per call site
-        with _lib.KernelTimer(capacity=256 * prof_steps) as kt:
-            t1 = time.perf_counter()
-            for _ in range(prof_steps):
-                step()
-            fence()
-            elapsed_prof = time.perf_counter() - t1
+        # one stream here: the timed steps run the weight-gradient kernels on a second stream
+        # next to the backward-data kernels (nets.USE_SIDE_WRW); a duration taken while two
+        # kernels share the CUs belongs to neither, so the instrumented steps serialise them
+        side_wrw, nets.USE_SIDE_WRW = nets.USE_SIDE_WRW, False
+        try:
+            with _lib.KernelTimer(capacity=256 * prof_steps) as kt:
+                t1 = time.perf_counter()
+                for _ in range(prof_steps):
+                    step()
+                fence()
+                elapsed_prof = time.perf_counter() - t1
+        finally:
+            nets.USE_SIDE_WRW = side_wrw
     else:
         elapsed_prof = elapsed
     work, nets.WORK_LOG = nets.WORK_LOG, None
@@ -564,6 +575,10 @@ def main():
                               'where': 'timed region' if in_region else
                               'extra eager steps right after the timed region (the events cost '
                               '~6 % of a step, so the timed steps run without them)',
+                              'streams': 'one (the timed steps run the weight-gradient kernels on a '
+                                         'second stream next to the backward-data kernels; the '
+                                         'instrumented steps serialise them so that a duration '
+                                         'is one kernel alone)' if nets.USE_SIDE_WRW else 'one',
                               'ms_per_step_with_events': round(elapsed_prof / prof_steps * 1e3, 3)},
             'roofline': roofline,
             'roofline_netvlad_loss': roofline_head,

@@ -404,6 +404,34 @@ def _own_wrw_used(x, gz, w):
     return _own_wrw_ok(x, gz, w) and _wrw_pays(x)
 
 
+# Weight gradients on a second stream.  Nothing in the backward chain reads a weight gradient:
+# with the gradient sink it goes straight into the flat buffer, and only the bucket's
+# all-reduce / the optimizer need it.  Run next to the backward-data kernel of the same layer
+# its workgroups fill the CUs that the other kernel's last, partial round leaves idle (both are
+# one-workgroup-per-CU kernels: 960 tiles on 256 CUs is 3.75 rounds).  The sink joins the
+# stream before a collective or the optimizer touches the buffer (GradBuckets.note_stream).
+USE_SIDE_WRW = os.environ.get('SCL_SIDE_WRW', '1') != '0'
+_SIDE = {}
+
+
+def _wrw_maybe_async(x, gz, w, gb):
+    sink = GRAD_SINK
+    if not (USE_SIDE_WRW and sink is not None and hasattr(sink, 'note_stream')
+            and sink.view(w) is not None and sink.view(w).stride() == w.stride()):
+        return wrw64(x, gz, w, gb)
+    dev = x.device
+    side = _SIDE.get(dev)
+    if side is None:
+        side = _SIDE[dev] = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        gw = wrw64(x, gz, w, gb)
+    x.record_stream(side)
+    gz.record_stream(side)
+    sink.note_stream(side)
+    return gw
+
+
 def _conv3x3_backward(gz, x, w, need_x, link=None, gb=None):
     """(gx, gw) of a 3x3 convolution.  With ``link`` (x is a post-ReLU map whose producer
     holds the other end) an own backward-data kernel returns gx * [x > 0] and marks the
@@ -418,13 +446,14 @@ def _conv3x3_backward(gz, x, w, need_x, link=None, gb=None):
         gx = conv64(gz, w, True, mask=x)
         link.mark(gx)
         if own_gw:
-            return gx, wrw64(x, gz, w, gb)
+            return gx, _wrw_maybe_async(x, gz, w, gb)
         _, gw, _ = torch.ops.aten.convolution_backward(gz, x, _lib_weight(w, gz), None, _ONES,
                                                        _ONES, _ONES, False, [0, 0], 1,
                                                        [False, True, False])
         return gx, gw.to(w.dtype)
     if own_gx and own_gw:
-        return (conv64(gz, w, True) if need_x else None), wrw64(x, gz, w, gb)
+        gw = _wrw_maybe_async(x, gz, w, gb)
+        return (conv64(gz, w, True) if need_x else None), gw
     if own_gx or own_gw:
         gx = conv64(gz, w, True) if (own_gx and need_x) else None
         gw = wrw64(x, gz, w, gb) if own_gw else None

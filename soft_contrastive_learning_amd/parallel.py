@@ -134,6 +134,7 @@ class GradBuckets:
         # `grad += new` pass — and report it with done(); the bucket logic is the same as for
         # gradients that arrive through autograd
         self._by_ptr = {p.data_ptr(): p for p in self.params}
+        self._streams = []         # side streams that write into the flat buffer (note_stream)
 
     def _close(self, begin, end, members):
         if not hasattr(self, '_members'):
@@ -169,8 +170,19 @@ class GradBuckets:
         self._remaining[idx] -= 1
         if self._remaining[idx] == 0:
             b, e = self.buckets[idx]
+            self._join_streams()
             self._handles.append(dist.all_reduce(self.flat[b:e], op=dist.ReduceOp.SUM,
                                                  group=self.group, async_op=True))
+
+    def note_stream(self, stream):
+        """A kernel on `stream` (not the current one) writes a gradient into the flat buffer:
+        the stream is joined before a collective reads the buffer and in finish()."""
+        if all(s is not stream for s in self._streams):
+            self._streams.append(stream)
+
+    def _join_streams(self):
+        for s in self._streams:
+            torch.cuda.current_stream(self.flat.device).wait_stream(s)
 
     def view(self, p_like):
         """The flat-buffer slice of the parameter that owns p_like's storage, shaped like it
@@ -197,3 +209,4 @@ class GradBuckets:
         for h in self._handles:
             h.wait()
         self._handles = []
+        self._join_streams()

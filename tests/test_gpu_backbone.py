@@ -655,3 +655,38 @@ def test_prepacked_weight_images_equal_self_packing(dev):
         for a, bb in zip(halved, run_all()):
             assert torch.equal(a, bb), (cin, cout, wdt)
     nets._PACKED.clear()
+
+
+def test_weight_gradients_on_the_second_stream_equal_the_one_stream_run(dev):
+    """nets.USE_SIDE_WRW: with the gradient sink, the weight-gradient kernels run on a second
+    stream next to the backward-data kernels and GradBuckets joins that stream in finish().
+    Same kernels, same inputs: every gradient in the flat buffer must be bit-identical to the
+    one-stream run (the library's conv5_x kernels are not involved at 480 x 640), three times
+    in a row (stale events, early reuse of a gradient map by the allocator)."""
+    from soft_contrastive_learning_amd import parallel
+    from soft_contrastive_learning_amd.model import nets
+    img = torch.randint(0, 256, (2, 480, 640, 3), generator=torch.Generator().manual_seed(91)).float().to(dev)
+    g = torch.randn(2, 30, 40, 512, generator=torch.Generator().manual_seed(92)).to(dev).bfloat16()
+    model = nets.VGG16NetVLAD(compute_dtype=torch.bfloat16, seed=11, fused_relu=True).to(dev)
+    buckets = parallel.GradBuckets(list(model.parameters()))
+    flats = {}
+    old = nets.USE_SIDE_WRW
+    try:
+        for side in (False, True, True, True):
+            nets.USE_SIDE_WRW = side
+            nets.GRAD_SINK = buckets
+            try:
+                buckets.zero()
+                model.features(img).backward(g)
+                buckets.finish()
+            finally:
+                nets.GRAD_SINK = None
+            torch.cuda.synchronize()
+            if side:
+                assert len(buckets._streams) == 1
+                assert torch.equal(buckets.flat, flats[False])
+            else:
+                flats[False] = buckets.flat.clone()
+    finally:
+        nets.USE_SIDE_WRW = old
+    assert float(flats[False].abs().max()) > 0
