@@ -1,17 +1,34 @@
+# Regenerates everything under profiles/rNN from one GPU box (run through gpurun; results land in
+# gpurun_out/rNN and are copied into profiles/rNN by hand).  Usage: bash scripts/collect_profiles.sh r02
 set -x
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02; mkdir -p $O
+RN=${1:-r02}
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$RN; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 python3 $R/bench.py --steps 20 --warmup 5 > $O/bench_n1_default_run.json 2> $O/bench.err
+python3 $R/bench.py --steps 20 --warmup 5 --side-wrw 0 --no-cpu-baseline > $O/bench_n1_one_stream.json 2>> $O/bench.err
+# kernel trace of the default command, and of the one-stream run (the durations of `roofline`
+# are taken with the weight-gradient kernels serialised: compare with the second table)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace1 -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --side-wrw 0 > $O/bench_under_rocprof_one_stream.json 2>/dev/null
+# HBM traffic of the backbone kernels (separate passes per counter, no tracing)
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_bb/fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --side-wrw 0 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_bb/write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --side-wrw 0 > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc_bb/sq -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --side-wrw 0 > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc_nv/sq -- python3 $R/scripts/microbench.py --what netvlad,loss --iters 3 --loss-batches 24,192 > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_nv/fetch -- python3 $R/scripts/microbench.py --what netvlad,loss --iters 3 --loss-batches 24,192 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_nv/write -- python3 $R/scripts/microbench.py --what netvlad,loss --iters 3 --loss-batches 24,192 > /dev/null 2>&1
 cd $R
 python3 scripts/microbench.py --iters 20 --topn-score f32,bf16x3 --json $O/microbench_netvlad_loss_topn.json > $O/microbench.log 2>&1
 python3 scripts/parity_report.py --json $O/parity_report.json > $O/parity.log 2>&1
+python3 scripts/conv_ab.py --rounds 2 > $O/conv_lds_kernels_32x32x16_vs_16x16x32.jsonl 2>/dev/null
+python3 scripts/conv_layers.py > $O/conv_layers_own_vs_library.txt 2>/dev/null
 python3 scripts/trace_summary.py $O/trace --steps 8 --out $O/bench_n1_steady_state_per_step.csv > $O/trace_summary.log 2>&1
+python3 scripts/trace_summary.py $O/trace1 --steps 8 --out $O/bench_n1_one_stream_per_step.csv >> $O/trace_summary.log 2>&1
 python3 scripts/pmc_summary.py $O/pmc_nv --only kernel --out $O/pmc_netvlad_loss_b24_n1200.csv > /dev/null 2>&1
+python3 scripts/pmc_summary.py $O/pmc_bb --only kernel --merge-templates --out $O/pmc_bench_backbone_b24_640x480.csv > /dev/null 2>&1
 python3 scripts/kstats.py $(ls $O/trace/*/*kernel_trace.csv | head -1) > $O/bench_kernel_trace_by_shape.txt
+python3 scripts/kstats.py $(ls $O/trace1/*/*kernel_trace.csv | head -1) > $O/bench_one_stream_kernel_trace_by_shape.txt
 cp $(ls $O/trace/*/*kernel_stats.csv | head -1) $O/bench_n1_kernel_stats_rocprofv3.csv
-rm -rf $O/trace $O/pmc_nv
-tail -3 $O/parity.log; tail -5 $O/trace_summary.log; head -c 600 $O/bench_n1_default_run.json
+cp $(ls $O/trace1/*/*kernel_stats.csv | head -1) $O/bench_n1_one_stream_kernel_stats_rocprofv3.csv
+rm -rf $O/trace $O/trace1 $O/pmc_nv $O/pmc_bb
+tail -3 $O/parity.log; tail -6 $O/trace_summary.log; head -c 600 $O/bench_n1_default_run.json

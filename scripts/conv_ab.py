@@ -4,7 +4,7 @@ csrc/convh.hip on 16x16x32) at the VGG16 layer shapes of the bench (24 x 640 x 4
 
     python scripts/conv_ab.py [--iters 10] [--batch 24]
 
-Per-kernel durations from the library's scl_prof_* sink; both kernels report as convg_kernel.
+Per-kernel durations from the library's scl_prof_* sink.
 """
 import argparse
 import json
@@ -67,7 +67,7 @@ def main():
                     finally:
                         lib.scl_debug_set_variant(0)
                     summ = kt.summary()
-                    kname = 'convg_kernel' if 'convg_kernel' in summ else 'conv3x3_kernel'
+                    kname = next(k for k in ('convh_kernel', 'convg_kernel', 'conv3x3_kernel') if k in summ)
                     us = summ[kname][1] * 1e3
                     row['%d_%s_kernel' % (var, mode)] = kname
                     if rnd > 0:

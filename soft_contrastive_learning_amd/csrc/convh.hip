@@ -483,7 +483,7 @@ int scl_convh_dispatch(const void* x, const void* w, int64_t w_stride_k, int64_t
     packed = (const unsigned short*)w;                 // scl_conv_pack_batch wrote it
   } else {
     const int64_t total = (int64_t)9 * (cin / HCCH) * kout * HCCH;
-    SCL_LAUNCH("convg_pack_kernel", convh_pack_kernel, dim3((unsigned)((total + 255) / 256)),
+    SCL_LAUNCH("convh_pack_kernel", convh_pack_kernel, dim3((unsigned)((total + 255) / 256)),
                dim3(256), 0, st, w, w_stride_k, w_stride_c, w_stride_h, w_stride_w, flags, cin, kout,
                (unsigned short*)workspace);
   }
@@ -512,7 +512,7 @@ int scl_convh_dispatch(const void* x, const void* w, int64_t w_stride_k, int64_t
   // 3020 + bits: 2 no output stores
   const int dbgbits = (dv >= 3020 && dv < 3024) ? (dv - 3020) << 1 : 0;
 #define SCL_CONVH_LAUNCH(E, BHV, BIAS, RELU, MASK)                                             \
-  SCL_LAUNCH("convg_kernel", (convh_kernel<E, BHV>), grid, dim3(HTHR), HCfg<BHV>::LDS, st,     \
+  SCL_LAUNCH("convh_kernel", (convh_kernel<E, BHV>), grid, dim3(HTHR), HCfg<BHV>::LDS, st,     \
              (const unsigned short*)x, (const unsigned short*)packed, B, H, W, cin, kout,      \
              (unsigned short*)out, BIAS, RELU, (const unsigned short*)MASK,                    \
              (unsigned char*)pidx, vblocks)

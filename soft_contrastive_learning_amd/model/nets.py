@@ -137,6 +137,14 @@ def _grad_ret(g, p_like):
     return g
 
 
+def _lds_work(flops, nbytes):
+    """Work of an LDS-weights convolution, under the names of both kernels that may serve it
+    (csrc/convh.hip by default, csrc/convg.hip when pinned or for odd chunk counts): bench.py
+    prices whichever one it timed."""
+    _work('convh_kernel', flops, nbytes)
+    _work('convg_kernel', flops, nbytes)
+
+
 def _work(name, flops, nbytes):
     if WORK_LOG is not None:
         e = WORK_LOG.setdefault(name, [0, 0.0, 0.0])
@@ -265,9 +273,11 @@ def conv64(x, w, transposed=False, bias=None, relu=False, pool=False, mask=None)
         bias = bias.float().contiguous()
     sk, sc, sh, sw = w.stride()
     px = b * h * wd
-    _work('conv3x3_kernel' if (cin, kout) in _OWN_CONV_SHAPES else 'convg_kernel',
-          2.0 * px * cin * kout * 9,
-          2.0 * px * (cin + kout * (1 + (mask is not None) + 0.25 * bool(pool))))
+    if (cin, kout) in _OWN_CONV_SHAPES:
+        _work('conv3x3_kernel', 2.0 * px * cin * kout * 9,
+              2.0 * px * (cin + kout * (1 + (mask is not None) + 0.25 * bool(pool))))
+    else:
+        _lds_work(2.0 * px * cin * kout * 9, 2.0 * px * (cin + kout * (1 + (mask is not None))))
     pk = _packed_for(w, transposed)
     wp = L.ptr(w) if pk is None else L.ptr(pk)            # the weight, or its packed image
     wflags = (int(bool(transposed)) | _wflag(w)) if pk is None else (int(bool(transposed)) | L.W_PACKED)
@@ -387,8 +397,11 @@ def conv_pool_idx(x, w, bias):
                       memory_format=_CL)
     sk, sc, sh, sw = w.stride()
     own = (cin, kout) in _OWN_CONV_SHAPES
-    _work('conv3x3_kernel' if own else 'convg_kernel', 2.0 * b * h * wd * cin * kout * 9,
-          b * h * wd * (2.0 * cin + 0.75 * kout))           # in + pooled bf16 / 4 + index / 4
+    if own:
+        _work('conv3x3_kernel', 2.0 * b * h * wd * cin * kout * 9,
+              b * h * wd * (2.0 * cin + 0.75 * kout))       # in + pooled bf16 / 4 + index / 4
+    else:
+        _lds_work(2.0 * b * h * wd * cin * kout * 9, b * h * wd * (2.0 * cin + 0.75 * kout))
     ws = L.workspace(lib.scl_conv3x3_workspace_bytes() if own
                      else lib.scl_convg_workspace_bytes(cin, kout), x.device)
     fn = lib.scl_conv3x3_pool_idx if own else lib.scl_convg_pool_idx
