@@ -537,9 +537,9 @@ def main():
                         alg = (work[rf['kernel']][2] / work[rf['kernel']][0]
                                if rf['kernel'] in work else models[rf['kernel']]['bytes'])
                         rf['traffic_algorithmic'] = int(alg)
-                        rf['traffic_source'] = ('rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch '
-                                                '(profiles/pmc_traffic.json: backbone r01, '
-                                                'NetVLAD r02)')
+                        rf['traffic_source'] = ('rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch, '
+                                                'L2 misses incl. Infinity-Cache hits '
+                                                '(profiles/pmc_traffic.json, round 2)')
             except (OSError, ValueError, KeyError):
                 pass
         hip_ms = sum(r['us'] * r['launches'] for r in kernels) / 1e3 / max(prof_steps, 1)
