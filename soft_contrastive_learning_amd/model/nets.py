@@ -16,6 +16,7 @@ the reference's checkpoint names and shapes (HWIO kernels, [1,1,512,64] assignme
 """
 import math
 
+import contextlib
 import os
 
 import torch
@@ -250,7 +251,69 @@ def _conv64_ok(x, w, transposed=False):
     return _own_conv_kind(x, w, transposed) is not None
 
 
-def conv64(x, w, transposed=False, bias=None, relu=False, pool=False, mask=None):
+# The forward pass of the backbone as two half-batches on two streams.  Every kernel of the
+# backbone treats images independently, and the one-workgroup-per-CU convolution kernels end in a
+# partial round (960 tiles on 256 CUs = 3.75): with the halves of the batch pipelined on two
+# streams, the next layer's kernel of one half fills the CUs the other half's kernel leaves idle.
+# Autograd sees full-batch tensors and one node per layer as before — only the launches inside a
+# forward are split; VGG16NetVLAD.features opens the window (_FWD_SPLIT) and joins both streams
+# before it returns.  Measured (scripts/fwd_split_probe.py, 24 x 640x480): the forward alone
+# 4.29 -> 3.97 ms, but a whole training step only 12.81 -> 12.70 ms (same-box bench.py A/B:
+# within noise) — the backward pass, whose two streams already fill the chip, gives part of it
+# back.  Hence: on for inference (feature extraction: torch.no_grad), off for training unless
+# SCL_SPLIT_FWD=1; SCL_SPLIT_FWD=0 turns it off everywhere.
+_SPLIT_FWD_ENV = os.environ.get('SCL_SPLIT_FWD', 'infer')
+USE_SPLIT_FWD = None if _SPLIT_FWD_ENV == 'infer' else _SPLIT_FWD_ENV != '0'
+
+
+def _split_fwd_wanted():
+    return (not torch.is_grad_enabled()) if USE_SPLIT_FWD is None else bool(USE_SPLIT_FWD)
+
+
+_FWD_STREAMS = {}
+_FWD_SPLIT = None        # (stream A, stream B) while features() pipelines the halves
+
+
+@contextlib.contextmanager
+def _whole_batch_op():
+    """An op of the forward pass that is NOT split into halves (a library convolution, a glue
+    pass): it runs on the caller's stream, joined with both half-batch streams on either side."""
+    sp = _FWD_SPLIT
+    if sp is None:
+        yield
+        return
+    cur = torch.cuda.current_stream(sp[0].device)
+    cur.wait_stream(sp[0])
+    cur.wait_stream(sp[1])
+    try:
+        yield
+    finally:
+        sp[0].wait_stream(cur)
+        sp[1].wait_stream(cur)
+
+
+_FWD_KEEP = []
+
+
+def _on_half(stream, *tensors):
+    """The tensors are used by kernels on `stream`, not on the stream they were allocated on.
+    Under no_grad an activation would be freed — and its block handed to the next layer's
+    output — while the half-batch streams may still be reading it: keep a reference until
+    features() has joined the streams.  (Tensor.record_stream would do, but it makes the
+    caching allocator defer every reuse behind events: measured 12.9 -> 18 ms per step.)"""
+    _FWD_KEEP.extend(t for t in tensors if t is not None)
+
+
+def _split_halves(b):
+    """[(stream, lo, hi)] of the two half-batches, or None outside a split forward."""
+    sp = _FWD_SPLIT
+    if sp is None or b < 2:
+        return None
+    return [(sp[0], 0, b // 2), (sp[1], b // 2, b)]
+
+
+def conv64(x, w, transposed=False, bias=None, relu=False, pool=False, mask=None, out=None,
+           pooled_out=None):
     """3x3 same-padding convolution on bf16 channels-last activations (``scl_conv3x3_fused``)
     for the shapes of ``_OWN_CONV_SHAPES``; ``transposed`` gives the gradient with respect to
     the input of ``conv(., w)``.  ``bias`` (float32 [kout]) and ``relu`` fuse the layer's tail
@@ -262,15 +325,26 @@ def conv64(x, w, transposed=False, bias=None, relu=False, pool=False, mask=None)
     x = x.contiguous(memory_format=_CL)
     b, _, h, wd = x.shape
     cin, kout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
-    out = torch.empty((b, kout, h, wd), dtype=x.dtype, device=x.device, memory_format=_CL)
-    pooled = None
+    inner = out is not None            # one half of a split forward: no further splitting
+    if out is None:
+        out = torch.empty((b, kout, h, wd), dtype=x.dtype, device=x.device, memory_format=_CL)
+    pooled = pooled_out
     if pool:
         if bias is None:
             raise ValueError("pool=True needs the bias (the pooled map is relu(pool + bias))")
-        pooled = torch.empty((b, kout, h // 2, wd // 2), dtype=x.dtype, device=x.device,
-                             memory_format=_CL)
+        if pooled is None:
+            pooled = torch.empty((b, kout, h // 2, wd // 2), dtype=x.dtype, device=x.device,
+                                 memory_format=_CL)
     if bias is not None:
         bias = bias.float().contiguous()
+    halves = None if (inner or transposed or mask is not None) else _split_halves(b)
+    if halves is not None:
+        for stream, lo, hi in halves:
+            _on_half(stream, x, out, pooled, bias, w)
+            with torch.cuda.stream(stream):
+                conv64(x[lo:hi], w, False, bias, relu, pool, None, out[lo:hi],
+                       pooled[lo:hi] if pool else None)
+        return (out, pooled) if pool else out
     sk, sc, sh, sw = w.stride()
     px = b * h * wd
     if (cin, kout) in _OWN_CONV_SHAPES:
@@ -383,7 +457,7 @@ USE_POOL_IDX = os.environ.get('SCL_POOL_IDX', '1') != '0'
 USE_F32_WEIGHTS = os.environ.get('SCL_F32_WEIGHTS', '1') != '0'
 
 
-def conv_pool_idx(x, w, bias):
+def conv_pool_idx(x, w, bias, out=None):
     """conv -> +bias -> max-pool 2x2 -> ReLU with the pooling in the convolution's epilogue and
     NO full-size output: returns (pooled bf16 [B,K,H/2,W/2], idx uint8 of the same shape: the
     window position of each maximum) — ``scl_conv3x3_pool_idx``."""
@@ -392,9 +466,20 @@ def conv_pool_idx(x, w, bias):
     x = x.contiguous(memory_format=_CL)
     b, cin, h, wd = x.shape
     kout = w.shape[0]
-    a = torch.empty((b, kout, h // 2, wd // 2), dtype=x.dtype, device=x.device, memory_format=_CL)
-    idx = torch.empty((b, kout, h // 2, wd // 2), dtype=torch.uint8, device=x.device,
-                      memory_format=_CL)
+    if out is None:
+        a = torch.empty((b, kout, h // 2, wd // 2), dtype=x.dtype, device=x.device, memory_format=_CL)
+        idx = torch.empty((b, kout, h // 2, wd // 2), dtype=torch.uint8, device=x.device,
+                          memory_format=_CL)
+    else:
+        a, idx = out
+    bias = bias.float().contiguous()
+    halves = _split_halves(b) if out is None else None
+    if halves is not None:
+        for stream, lo, hi in halves:
+            _on_half(stream, x, a, idx, bias, w)
+            with torch.cuda.stream(stream):
+                conv_pool_idx(x[lo:hi], w, bias, (a[lo:hi], idx[lo:hi]))
+        return a, idx
     sk, sc, sh, sw = w.stride()
     own = (cin, kout) in _OWN_CONV_SHAPES
     if own:
@@ -504,11 +589,12 @@ class _ConvBiasAct(torch.autograd.Function):
         if kind == 'reg' or (kind == 'lds' and _lds_conv_pays(x, False, True)):
             y = conv64(x, w, False, bias=bias, relu=relu)         # tail fused in the epilogue
         else:
-            y = _conv3x3(x, w).contiguous(memory_format=_CL)
-            b, c, h, wd = y.shape
-            _work('vgg_bias_act', 0.0, 2.0 * y.numel() * y.element_size())
-            L.check(lib.scl_vgg_bias_act(L.ptr(y), _glue_dtype(y), L.ptr(bias), b * h * wd, c,
-                                         int(relu), L.stream_of(y)))
+            with _whole_batch_op():
+                y = _conv3x3(x, w).contiguous(memory_format=_CL)
+                b, c, h, wd = y.shape
+                _work('vgg_bias_act', 0.0, 2.0 * y.numel() * y.element_size())
+                L.check(lib.scl_vgg_bias_act(L.ptr(y), _glue_dtype(y), L.ptr(bias), b * h * wd, c,
+                                             int(relu), L.stream_of(y)))
         ctx.relu = relu
         ctx.save_for_backward(x, w, y if relu else None, bias)
         return y
@@ -563,13 +649,14 @@ class _ConvBiasPoolReLU(torch.autograd.Function):
             # pooled map from the epilogue (no pooling pass over z)
             z, a = conv64(x, w, False, bias=bias, pool=True)
         else:
-            z = _conv3x3(x, w).contiguous(memory_format=_CL)
-            b, c, h, wd = z.shape
-            a = torch.empty((b, c, h // 2, wd // 2), dtype=z.dtype, device=z.device,
-                            memory_format=_CL)
-            _work('vgg_pool_fwd', 0.0, 1.25 * z.numel() * z.element_size())
-            L.check(lib.scl_vgg_pool_fwd(L.ptr(z), _glue_dtype(z), L.ptr(bias), b, h, wd, c,
-                                         L.ptr(a), L.stream_of(z)))
+            with _whole_batch_op():
+                z = _conv3x3(x, w).contiguous(memory_format=_CL)
+                b, c, h, wd = z.shape
+                a = torch.empty((b, c, h // 2, wd // 2), dtype=z.dtype, device=z.device,
+                                memory_format=_CL)
+                _work('vgg_pool_fwd', 0.0, 1.25 * z.numel() * z.element_size())
+                L.check(lib.scl_vgg_pool_fwd(L.ptr(z), _glue_dtype(z), L.ptr(bias), b, h, wd, c,
+                                             L.ptr(a), L.stream_of(z)))
         ctx.save_for_backward(x, w, z, a, bias)
         return a
 
@@ -671,18 +758,26 @@ class _FirstConv(torch.autograd.Function):
             y = torch.empty((b, 64, h, wd), dtype=torch.bfloat16, device=img.device,
                             memory_format=_CL)
             sk, sc, sh, sw = w.stride()
-            _work('conv_first_kernel', 2.0 * b * h * wd * 27 * 64, b * h * wd * (12.0 + 6.0 + 128.0))
-            L.check(lib.scl_conv_first(L.ptr(img), L.ptr(avg.float().contiguous()), L.ptr(w), sk, sc,
-                                       sh, sw, int(w.dtype == torch.float32),
-                                       L.ptr(bias.float().contiguous()), b, h, wd,
-                                       L.ptr(x0), L.ptr(y), L.stream_of(img)))
+            avg_f, bias_f = avg.float().contiguous(), bias.float().contiguous()
+            y_nhwc = y.permute(0, 2, 3, 1)                    # the storage order, batch-sliceable
+            for stream, lo, hi in (_split_halves(b) or [(None, 0, b)]):
+                if stream is not None:
+                    _on_half(stream, img, x0, y, avg_f, bias_f, w)
+                with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
+                    n = hi - lo
+                    _work('conv_first_kernel', 2.0 * n * h * wd * 27 * 64, n * h * wd * (12.0 + 6.0 + 128.0))
+                    L.check(lib.scl_conv_first(L.ptr(img[lo:hi]), L.ptr(avg_f), L.ptr(w), sk, sc,
+                                               sh, sw, int(w.dtype == torch.float32),
+                                               L.ptr(bias_f), n, h, wd,
+                                               L.ptr(x0[lo:hi]), L.ptr(y_nhwc[lo:hi]), L.stream_of(img)))
             x0 = x0.permute(0, 3, 1, 2)
         else:
-            x0 = (img_nhwc - avg.to(img_nhwc.dtype)).to(dtype).permute(0, 3, 1, 2)
-            y = _conv3x3(x0, w).contiguous(memory_format=_CL)
-            b, c, h, wd = y.shape
-            L.check(lib.scl_vgg_bias_act(L.ptr(y), _glue_dtype(y), L.ptr(bias), b * h * wd, c, 1,
-                                         L.stream_of(y)))
+            with _whole_batch_op():
+                x0 = (img_nhwc - avg.to(img_nhwc.dtype)).to(dtype).permute(0, 3, 1, 2)
+                y = _conv3x3(x0, w).contiguous(memory_format=_CL)
+                b, c, h, wd = y.shape
+                L.check(lib.scl_vgg_bias_act(L.ptr(y), _glue_dtype(y), L.ptr(bias), b * h * wd, c, 1,
+                                             L.stream_of(y)))
         ctx.save_for_backward(x0, w, y, bias)
         return y
 
@@ -793,11 +888,37 @@ class VGG16NetVLAD(torch.nn.Module):
                 x = x.to(dt)
         if x is not None:
             x = x.contiguous(memory_format=torch.channels_last)
-        skip_pool = False
-        link = None        # set while x is the post-ReLU output of the previous conv node
         if fuse and dt == torch.bfloat16 and USE_CONV64 and USE_F32_WEIGHTS and USE_PREPACK:
             # every packed weight image of this step (both directions) in one launch
             prepack([getattr(self, 'conv%s_kernel' % n) for n in self.conv_names])
+        global _FWD_SPLIT
+        split = None
+        if (fuse and dt == torch.bfloat16 and USE_CONV64 and _split_fwd_wanted() and _FWD_SPLIT is None
+                and image_batch.shape[0] >= 2):
+            dev = image_batch.device
+            split = _FWD_STREAMS.get(dev)
+            if split is None:
+                split = _FWD_STREAMS[dev] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+            cur = torch.cuda.current_stream(dev)
+            split[0].wait_stream(cur)
+            split[1].wait_stream(cur)
+            _FWD_SPLIT = split
+        try:
+            x = self._layers(image_batch, x, dt, fuse)
+        finally:
+            if split is not None:
+                _FWD_SPLIT = None
+                cur = torch.cuda.current_stream(image_batch.device)
+                cur.wait_stream(split[0])
+                cur.wait_stream(split[1])
+                # the half-batch streams are done with everything once `cur` passes this point;
+                # blocks freed from here on are reused by `cur` only after it
+                del _FWD_KEEP[:]
+        return x.permute(0, 2, 3, 1)                                      # [B,H',W',512] view
+
+    def _layers(self, image_batch, x, dt, fuse):
+        skip_pool = False
+        link = None        # set while x is the post-ReLU output of the previous conv node
         for idx, item in enumerate(VGG_LAYERS):
             if item == 'pool':
                 if not skip_pool:
@@ -836,7 +957,7 @@ class VGG16NetVLAD(torch.nn.Module):
             x = F.conv2d(x, w, bias, stride=1, padding=1)
             if relu:
                 x = F.relu(x)
-        return x.permute(0, 2, 3, 1)                                      # [B,H',W',512] view
+        return x
 
     def forward(self, image_batch):
         x = self.features(image_batch)

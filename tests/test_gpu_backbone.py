@@ -690,3 +690,44 @@ def test_weight_gradients_on_the_second_stream_equal_the_one_stream_run(dev):
     finally:
         nets.USE_SIDE_WRW = old
     assert float(flats[False].abs().max()) > 0
+
+
+@pytest.mark.parametrize('shape', [(4, 480, 640), (3, 480, 640), (3, 96, 160), (2, 64, 80)])
+def test_half_batches_on_two_streams_equal_the_one_stream_forward(dev, shape):
+    """nets.USE_SPLIT_FWD: features() pipelines the two halves of the batch on two streams (own
+    kernels split, library / glue ops joined around).  Same kernels per image: descriptors and
+    every gradient must be bit-identical to the one-stream run — with autograd and under
+    no_grad (where activations are freed while the half-batch streams may still read them),
+    for an odd batch, and at sizes where the last layers fall back to the library."""
+    from soft_contrastive_learning_amd.model import nets
+    b, h, w = shape
+    img = torch.randint(0, 256, (b, h, w, 3), generator=torch.Generator().manual_seed(101)).float().to(dev)
+    model = nets.VGG16NetVLAD(compute_dtype=torch.bfloat16, seed=13, fused_relu=True).to(dev)
+    g = torch.randn(b, h // 16, w // 16, 512, generator=torch.Generator().manual_seed(102)).to(dev).bfloat16()
+    old = nets.USE_SPLIT_FWD
+    res = {}
+    try:
+        for split in (False, True):
+            nets.USE_SPLIT_FWD = split
+            model.zero_grad(set_to_none=True)
+            y = model.features(img)
+            y.backward(g)
+            with torch.no_grad():
+                outs = [model.features(img).clone() for _ in range(3)]
+            torch.cuda.synchronize()
+            res[split] = (y.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters()
+                                               if p.grad is not None}, outs)
+    finally:
+        nets.USE_SPLIT_FWD = old
+    lib_tail = h * w < 480 * 640       # conv5_x (and more) on the library: not bit-reproducible
+    for o in res[True][2] + [res[True][0]]:
+        if lib_tail:
+            assert _nrel(o.float(), res[False][0].float()) < 2e-2
+        else:
+            assert torch.equal(o, res[False][0])
+    assert set(res[True][1]) == set(res[False][1])
+    for n in res[True][1]:
+        if not lib_tail:
+            assert torch.equal(res[True][1][n], res[False][1][n]), n
+        elif n != 'average_rgb':      # (a sum with heavy cancellation: the library's noise shows)
+            assert _nrel(res[True][1][n], res[False][1][n]) < 0.15, n
