@@ -310,8 +310,10 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
       }
     };
 
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (!(dbg & 1)) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
     load_half(win, 0, 0);
 #pragma unroll 1
     for (int cc = 0; cc < CC; cc += 2) {
@@ -509,7 +511,7 @@ int scl_convh_dispatch(const void* x, const void* w, int64_t w_stride_k, int64_t
   if (gsize > vblocks) gsize = vblocks;
   if (dv == 3099) gsize = vblocks;
   const dim3 grid((unsigned)gsize);
-  // 3020 + bits: 2 no output stores
+  // 3020 + bits: 1 no wait / barrier at the top of a tile, 2 no output stores
   const int dbgbits = (dv >= 3020 && dv < 3024) ? (dv - 3020) << 1 : 0;
 #define SCL_CONVH_LAUNCH(E, BHV, BIAS, RELU, MASK)                                             \
   SCL_LAUNCH("convh_kernel", (convh_kernel<E, BHV>), grid, dim3(HTHR), HCfg<BHV>::LDS, st,     \

@@ -456,7 +456,8 @@ def test_first_layer_weight_and_bias_gradient(dev, shape):
 
 @pytest.mark.parametrize('cin,shape', [(64, (2, 16, 40)), (128, (1, 10, 38)), (64, (1, 13, 37)),
                                        (256, (1, 24, 80)), (512, (1, 13, 37)), (256, (2, 8, 40))])
-def test_pool_index_epilogue_and_its_backward(dev, cin, shape, lds_kernel):
+@pytest.mark.parametrize('block_height', [12, 8, 6], indirect=True)
+def test_pool_index_epilogue_and_its_backward(dev, cin, shape, block_height):
     """scl_conv3x3_pool_idx + scl_vgg_pool_bwd_idx: pooled map as the fused-tail kernel gives
     it, every stored position points at a maximum of its window, and the backward routes
     g * [a > 0] there (and only there)."""
@@ -643,6 +644,13 @@ def test_prepacked_weight_images_equal_self_packing(dev):
         nets._PACKED.clear()
         plain = run_all()
         assert nets.prepack([wt]) == 2 and nets.prepack([wt]) == 0
+        # more jobs than one launch takes (32): the batch entry chunks them
+        many = [(torch.randn(128, 64, 3, 3, generator=g) * 0.03).to(dev) for _ in range(18)]
+        assert nets.prepack(many) == 36
+        ref = nets.conv64(x[:, :64].contiguous(memory_format=cl), many[17], False) if cin >= 64 else None
+        if ref is not None:
+            nets._PACKED.pop((many[17].data_ptr(), False))
+            assert torch.equal(ref, nets.conv64(x[:, :64].contiguous(memory_format=cl), many[17], False))
         assert nets._packed_for(wt, False) is not None and nets._packed_for(wt, True) is not None
         packed = run_all()
         for a, bb in zip(plain, packed):
