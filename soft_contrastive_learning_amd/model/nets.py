@@ -18,6 +18,7 @@ import math
 
 import contextlib
 import os
+import threading
 
 import torch
 import torch.nn.functional as F
@@ -179,6 +180,8 @@ def prepack(weights):
     import weakref
     lib = L.load()
     jobs, keep = [], []
+    for key in [k for k, ent in _PACKED.items() if ent[0]() is None]:
+        del _PACKED[key]                                   # the weight is gone
     for w in weights:
         if not (w.is_cuda and w.dtype in _W_DTYPES and w.dim() == 4 and tuple(w.shape[2:]) == (3, 3)):
             continue
@@ -256,7 +259,7 @@ def _conv64_ok(x, w, transposed=False):
 # partial round (960 tiles on 256 CUs = 3.75): with the halves of the batch pipelined on two
 # streams, the next layer's kernel of one half fills the CUs the other half's kernel leaves idle.
 # Autograd sees full-batch tensors and one node per layer as before — only the launches inside a
-# forward are split; VGG16NetVLAD.features opens the window (_FWD_SPLIT) and joins both streams
+# forward are split; VGG16NetVLAD.features opens the window (_FWD.split) and joins both streams
 # before it returns.  Measured (scripts/fwd_split_probe.py, 24 x 640x480): the forward alone
 # 4.29 -> 3.97 ms, but a whole training step only 12.81 -> 12.70 ms (same-box bench.py A/B:
 # within noise) — the backward pass, whose two streams already fill the chip, gives part of it
@@ -271,14 +274,23 @@ def _split_fwd_wanted():
 
 
 _FWD_STREAMS = {}
-_FWD_SPLIT = None        # (stream A, stream B) while features() pipelines the halves
+
+
+class _FwdState(threading.local):
+    """Per calling thread (the reference drives one session from three threads,
+    train/train.py:967-975): the window features() opens, and what must stay alive in it."""
+    split = None         # (stream A, stream B) while features() pipelines the halves
+    keep = None
+
+
+_FWD = _FwdState()
 
 
 @contextlib.contextmanager
 def _whole_batch_op():
     """An op of the forward pass that is NOT split into halves (a library convolution, a glue
     pass): it runs on the caller's stream, joined with both half-batch streams on either side."""
-    sp = _FWD_SPLIT
+    sp = _FWD.split
     if sp is None:
         yield
         return
@@ -292,21 +304,18 @@ def _whole_batch_op():
         sp[1].wait_stream(cur)
 
 
-_FWD_KEEP = []
-
-
 def _on_half(stream, *tensors):
     """The tensors are used by kernels on `stream`, not on the stream they were allocated on.
     Under no_grad an activation would be freed — and its block handed to the next layer's
     output — while the half-batch streams may still be reading it: keep a reference until
     features() has joined the streams.  (Tensor.record_stream would do, but it makes the
     caching allocator defer every reuse behind events: measured 12.9 -> 18 ms per step.)"""
-    _FWD_KEEP.extend(t for t in tensors if t is not None)
+    _FWD.keep.extend(t for t in tensors if t is not None)
 
 
 def _split_halves(b):
     """[(stream, lo, hi)] of the two half-batches, or None outside a split forward."""
-    sp = _FWD_SPLIT
+    sp = _FWD.split
     if sp is None or b < 2:
         return None
     return [(sp[0], 0, b // 2), (sp[1], b // 2, b)]
@@ -891,9 +900,8 @@ class VGG16NetVLAD(torch.nn.Module):
         if fuse and dt == torch.bfloat16 and USE_CONV64 and USE_F32_WEIGHTS and USE_PREPACK:
             # every packed weight image of this step (both directions) in one launch
             prepack([getattr(self, 'conv%s_kernel' % n) for n in self.conv_names])
-        global _FWD_SPLIT
         split = None
-        if (fuse and dt == torch.bfloat16 and USE_CONV64 and _split_fwd_wanted() and _FWD_SPLIT is None
+        if (fuse and dt == torch.bfloat16 and USE_CONV64 and _split_fwd_wanted() and _FWD.split is None
                 and image_batch.shape[0] >= 2):
             dev = image_batch.device
             split = _FWD_STREAMS.get(dev)
@@ -902,18 +910,18 @@ class VGG16NetVLAD(torch.nn.Module):
             cur = torch.cuda.current_stream(dev)
             split[0].wait_stream(cur)
             split[1].wait_stream(cur)
-            _FWD_SPLIT = split
+            _FWD.split, _FWD.keep = split, []
         try:
             x = self._layers(image_batch, x, dt, fuse)
         finally:
             if split is not None:
-                _FWD_SPLIT = None
+                _FWD.split = None
                 cur = torch.cuda.current_stream(image_batch.device)
                 cur.wait_stream(split[0])
                 cur.wait_stream(split[1])
                 # the half-batch streams are done with everything once `cur` passes this point;
                 # blocks freed from here on are reused by `cur` only after it
-                del _FWD_KEEP[:]
+                _FWD.keep = None
         return x.permute(0, 2, 3, 1)                                      # [B,H',W',512] view
 
     def _layers(self, image_batch, x, dt, fuse):
