@@ -241,8 +241,9 @@ int scl_topn_exact_filter(const float* ref, int R, const float* query, int d, co
  * model/nets.py:27-63 (tf.layers.conv2d's bias add, tf.nn.relu,
  * tf.layers.max_pooling2d(2, 2)) and their TF-autodiff backward ops, fused so each
  * activation map is streamed once.  They serve the layers whose convolution runs in the
- * library (conv5_x forward in bf16, everything in float32 mode); the hand-written
- * convolutions further down fuse these tails into their epilogues.
+ * library (maps below 30 x 40 in bf16, everything in float32 mode) and the few places where a
+ * tail cannot ride on a convolution (the ReLU' under the NetVLAD head, the un-pooling); the
+ * hand-written convolutions further down fuse these tails into their epilogues.
  * Activations are channels-last [M = B*H*W, C] (f32 or bf16), C % 8 == 0 and
  * (C / 8) | 256; bias and bias gradients are f32 [C].
  *   scl_vgg_bias_act   y = [relu](y + bias), in place
@@ -304,8 +305,9 @@ int scl_conv3x3_fused(const void* x, const void* w, int64_t w_stride_k, int64_t 
                       void* pooled, void* workspace, size_t workspace_bytes, void* stream);
 
 /* The deeper layers (conv3_x .. conv5_x: cin % 32 == 0, kout % 128 == 0, up to 1024): weights
- * streamed through LDS, [12 x 40 pixel] x 128-channel workgroup tiles (csrc/convg.hip).
- * Same arguments as scl_conv3x3_fused without the pooled output. */
+ * streamed through LDS, [12 / 8 / 6 x 40 pixel] x 128-channel workgroup tiles — csrc/convh.hip
+ * (v_mfma_f32_16x16x32_bf16; cin % 64 == 0) or csrc/convg.hip (32x32x16; any cin % 32 == 0),
+ * same results bit for bit.  Same arguments as scl_conv3x3_fused without the pooled output. */
 size_t scl_convg_workspace_bytes(int cin, int kout);
 int scl_convg(const void* x, const void* w, int64_t w_stride_k, int64_t w_stride_c,
               int64_t w_stride_h, int64_t w_stride_w, int transposed, int B, int H, int W,
