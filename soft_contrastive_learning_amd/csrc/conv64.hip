@@ -600,6 +600,8 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
                                                          unsigned short* __restrict__ x0,
                                                          unsigned short* __restrict__ y) {
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+  const int dbg = w_f32 >> 4;            // timing diagnostics (scl_debug_set_variant(70000 + bits))
+  w_f32 &= 1;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   unsigned short* scr = lds + F_WIN + wid * SCR;
@@ -638,29 +640,60 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
   const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
   const int per_img = tiles_x * tiles_y;
   const int ntiles = B * per_img;
+  // The image pixels of tile t + 1 are requested before tile t is computed and stored (the
+  // float32 image needs a conversion, so it cannot come by LDS-DMA): a thread owns window
+  // pixels threadIdx.x and threadIdx.x + 256 (340 per window).  Without this the loads of a
+  // tile — 88 MB in all — cost 115 of the kernel's 390 us: nothing else of the workgroup runs
+  // while they are in flight.
+  float pre[2][3];
+  int64_t pre_p[2];        // pixel index, -1: outside the image (zeros) or no such window pixel
+  auto prefetch = [&](int tile) {
+    const int b = tile / per_img, t2 = tile % per_img;
+    const int ty = (t2 / tiles_x) * TH, tx = (t2 % tiles_x) * TW;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int pix = threadIdx.x + 256 * it;
+      const int wy = pix / WC, wx = pix % WC;
+      const int yy = ty - 1 + wy, xx = tx - 1 + wx;
+      pre_p[it] = -1;
+      pre[it][0] = pre[it][1] = pre[it][2] = 0.f;
+      if (pix < WR * WC && tile < ntiles && yy >= 0 && yy < H && xx >= 0 && xx < W && !(dbg & 1)) {
+        const int64_t p = ((int64_t)b * H + yy) * W + xx;
+        pre_p[it] = p;
+        pre[it][0] = img[3 * p];
+        pre[it][1] = img[3 * p + 1];
+        pre[it][2] = img[3 * p + 2];
+      }
+    }
+  };
+  prefetch(blockIdx.x);
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int b = tile / per_img, t2 = tile % per_img;
     const int ty = (t2 / tiles_x) * TH, tx = (t2 % tiles_x) * TW;
     __syncthreads();                                   // previous tile's window is consumed
-    for (int pix = threadIdx.x; pix < WR * WC; pix += 256) {
-      const int wy = pix / WC, wx = pix % WC;
-      const int yy = ty - 1 + wy, xx = tx - 1 + wx;
-      unsigned short v0 = 0, v1 = 0, v2 = 0;
-      if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-        const int64_t p = ((int64_t)b * H + yy) * W + xx;
-        v0 = f32_to_bf16(img[3 * p] - a0);
-        v1 = f32_to_bf16(img[3 * p + 1] - a1);
-        v2 = f32_to_bf16(img[3 * p + 2] - a2);
-        if (wy >= 1 && wy <= TH && wx >= 1 && wx <= TW) {   // interior: this tile owns it
-          x0[3 * p] = v0;
-          x0[3 * p + 1] = v1;
-          x0[3 * p + 2] = v2;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int pix = threadIdx.x + 256 * it;
+      if (pix < WR * WC) {
+        const int wy = pix / WC, wx = pix % WC;
+        unsigned short v0 = 0, v1 = 0, v2 = 0;
+        if (pre_p[it] >= 0) {
+          const int64_t p = pre_p[it];
+          v0 = f32_to_bf16(pre[it][0] - a0);
+          v1 = f32_to_bf16(pre[it][1] - a1);
+          v2 = f32_to_bf16(pre[it][2] - a2);
+          if (wy >= 1 && wy <= TH && wx >= 1 && wx <= TW && !(dbg & 2)) {   // interior: this tile owns it
+            x0[3 * p] = v0;
+            x0[3 * p + 1] = v1;
+            x0[3 * p + 2] = v2;
+          }
         }
+        *reinterpret_cast<uint2*>(lds + pix * F_PIX) =
+            make_uint2((unsigned)v0 | ((unsigned)v1 << 16), (unsigned)v2);
       }
-      *reinterpret_cast<uint2*>(lds + pix * F_PIX) =
-          make_uint2((unsigned)v0 | ((unsigned)v1 << 16), (unsigned)v2);
     }
     __syncthreads();
+    prefetch(tile + gridDim.x);                        // in flight under the MFMAs and stores
 
     // wave w: tile rows 2w, 2w + 1 (two m-tiles of 32 pixels) x both n-tiles
 #pragma unroll
@@ -691,7 +724,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
         const u32x4 v1 = *reinterpret_cast<const u32x4*>(scr + px * SCR_LD + 8 * hf + 16);
         __builtin_amdgcn_wave_barrier();
         const int ox = tx + px;
-        if (oy < H && ox < W) {      // a lane pair writes 32 contiguous bytes per instruction
+        if (oy < H && ox < W && !(dbg & 4)) {      // a lane pair writes 32 contiguous bytes per instruction
           unsigned short* o = y + (((int64_t)b * H + oy) * W + ox) * C64 + 32 * nt + 8 * hf;
           *reinterpret_cast<u32x4*>(o) = v0;
           *reinterpret_cast<u32x4*>(o + 16) = v1;
@@ -1189,9 +1222,13 @@ extern "C" int scl_conv_first(const float* img, const float* avg, const void* w,
   static int cus = 256;
   std::call_once(once, [] { cus = conv64_cus(); });
   const int tiles = B * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+  // (8 workgroups per CU although four are resident at a time: measured 337-348 us against
+  // 351-361 with 4 — the tail is finer)
   const int grid = tiles < 8 * cus ? tiles : 8 * cus;
   SCL_LAUNCH("conv_first_kernel", conv_first_kernel, dim3(grid), dim3(256), kFirstLds,
-             (hipStream_t)stream, img, avg, w, w_f32 ? 1 : 0, w_stride_k, w_stride_c,
+             (hipStream_t)stream, img, avg, w,
+             (w_f32 ? 1 : 0) | (scl_debug_variant / 1000 == 70 ? (scl_debug_variant & 7) << 4 : 0),
+             w_stride_k, w_stride_c,
              w_stride_h, w_stride_w, bias, B, H, W, (unsigned short*)x0, (unsigned short*)y);
   return scl_launch_status();
 }
