@@ -589,7 +589,7 @@ __global__ __launch_bounds__(64 * RG) void wrw64_reduce_kernel(const float* __re
 // writing its 64-channel output, not by this).  x0 is written out for the weight gradient.
 constexpr int F_PIX = 4;                              // bf16 per staged pixel (3 + 1 pad)
 constexpr int F_WIN = WR * WC * F_PIX;                // 1360 bf16
-constexpr size_t kFirstLds = ((size_t)F_WIN + 4 * (size_t)SCR) * sizeof(unsigned short);
+constexpr size_t kFirstLds = ((size_t)F_WIN + 4 * 2 * (size_t)SCR) * sizeof(unsigned short);
 
 __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict__ img,
                                                          const float* __restrict__ avg,
@@ -604,7 +604,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
   w_f32 &= 1;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
-  unsigned short* scr = lds + F_WIN + wid * SCR;
+  unsigned short* scr = lds + F_WIN + wid * 2 * SCR;
 
   // weights: B[k][n], k = 3 * tap + c (k >= 27: zero); lane (j, h) holds k = 16 ks + 8 h + e
   u32x4 wf[2][2];
@@ -711,24 +711,31 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
         acc1 = mfma32b(af, wf[ks][1], acc1);
       }
       const int oy = ty + 2 * wid + mt;
+      // both n-tiles through the scratch (two planes of 32 channels), then whole 128-byte pixels
+      // per store instruction: lane -> (pixel 8 k + lane / 8, 16-byte piece lane % 8) — a store
+      // instruction writes 8 complete lines instead of 32 quarter lines
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
         const float bb = nt ? bias1 : bias0;
 #pragma unroll
         for (int q = 0; q < 16; ++q)
-          scr[acc_row(q, h) * SCR_LD + r] =
+          scr[(32 * nt + acc_row(q, h)) * SCR_LD + r] =
               f32_to_bf16(fmaxf((nt ? acc1[q] : acc0[q]) + bb, 0.f));
-        __builtin_amdgcn_wave_barrier();
-        const int px = lane >> 1, hf = lane & 1;
-        const u32x4 v0 = *reinterpret_cast<const u32x4*>(scr + px * SCR_LD + 8 * hf);
-        const u32x4 v1 = *reinterpret_cast<const u32x4*>(scr + px * SCR_LD + 8 * hf + 16);
-        __builtin_amdgcn_wave_barrier();
-        const int ox = tx + px;
-        if (oy < H && ox < W && !(dbg & 4)) {      // a lane pair writes 32 contiguous bytes per instruction
-          unsigned short* o = y + (((int64_t)b * H + oy) * W + ox) * C64 + 32 * nt + 8 * hf;
-          *reinterpret_cast<u32x4*>(o) = v0;
-          *reinterpret_cast<u32x4*>(o + 16) = v1;
-        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      const int piece = lane & 7;
+      u32x4 vv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int px = 8 * k + (lane >> 3);
+        vv[k] = *reinterpret_cast<const u32x4*>(scr + (32 * (piece >> 2) + px) * SCR_LD + 8 * (piece & 3));
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int ox = tx + 8 * k + (lane >> 3);
+        if (oy < H && ox < W && !(dbg & 4))
+          *reinterpret_cast<u32x4*>(y + (((int64_t)b * H + oy) * W + ox) * C64 + 8 * piece) = vv[k];
       }
     }
   }
