@@ -325,8 +325,23 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
     // computed before the K loop and spilled across it)
     int nb_e = nb_t, b_e = b_t, y0_e = y0_t, x0_e = x0_t;
     asm volatile("" : "+s"(nb_e), "+s"(b_e), "+s"(y0_e), "+s"(x0_e));
-    // What the epilogue reads from memory is requested first, so that waiting for it does not
-    // wait for the next tile's first stage (issued right after; the counter is in order).
+    // Every wave has left the K loop: window buffer 1 (the last chunk's window; the next tile's
+    // first stage goes to buffer 0 and weight buffers 0 / 1) now serves as epilogue scratch.
+    __builtin_amdgcn_s_barrier();
+    // Output through a per-wave LDS transpose so that a store instruction writes WHOLE 128-byte
+    // lines (the 64 channels of the wave for 8 pixels): measured on the first-layer kernel, whose
+    // only problem is its output, 16-byte pieces scattered as quarter lines ran 338-349 us and
+    // whole lines 250-259 — the L2 merges partial lines, but not for free.  The transpose is four
+    // ds_write_b64 and two ds_read_b128 per m-tile (the swapped-operand accumulators hold four
+    // consecutive channels per lane).
+    constexpr int SLD = 16 * NT + 8;                       // bf16 per scratch row (pixel)
+    constexpr int PCS = 2 * NT;                            // 16-byte pieces per pixel of the wave
+    constexpr int RR = 16 * PCS / 64;                      // pieces per lane and m-tile: 2 (or 1)
+    // per wave: 16 pixels x SLD bf16 (+ 16 x (16 NT + 16) index bytes for the pooling epilogue);
+    // waves 0-3 in window buffer 1, waves 4-7 in weight buffer 2 (the last group's: as dead)
+    constexpr int SCRW = 16 * SLD + 8 * (16 * NT + 16);
+    static_assert(4 * SCRW <= WIN && 4 * SCRW <= HTPB * HWT, "epilogue scratch must fit");
+    unsigned short* scr = wid < 4 ? lds + WIN + wid * SCRW : wts + 2 * HTPB * HWT + (wid - 4) * SCRW;
     const int ch_w = HNB * nb_e + 16 * NT * ng;           // first channel of the wave
     f32x4 bias4[EPI == 1 ? NT : 1];
     float bias1[EPI == 3 ? NT : 1];
@@ -339,26 +354,32 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
 #pragma unroll
       for (int n = 0; n < NT; ++n) bias1[n] = bias[ch_w + 16 * n + i];
     }
-    // EPI 0..2: lane (p = i, g') stores channels ch_w + 16 n + 4 g' .. + 3 of pixel p of the
-    // m-tile: element offset = tile part (wave-uniform) + lane part + 16 n
-    const int lane_o = (ht_row(i) * W + ht_col(i)) * kout + 4 * g;
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    // EPI 2: the mask words of m-tile j + PD are requested after the stores of m-tile j, the
+    // piece p = lane + 64 rr of an m-tile: pixel p / PCS (row ht_row, column ht_col), channels
+    // 8 (p % PCS) .. + 7 of the wave; element offset from the m-tile's corner pixel:
+    int piece_o[RR], piece_px[RR];
+#pragma unroll
+    for (int rr = 0; rr < RR; ++rr) {
+      const int pp = lane + 64 * rr;
+      piece_px[rr] = pp / PCS;
+      piece_o[rr] = (ht_row(pp / PCS) * W + ht_col(pp / PCS)) * kout + 8 * (pp % PCS);
+    }
+    // EPI 2: the mask pieces of m-tile j + PD are requested after the stores of m-tile j, the
     // first PD m-tiles up front (more in flight would not fit the register file next to the
     // accumulators); the next tile's first stage goes out once every mask load has been issued
     constexpr int PD = MT / 2;
-    u32x2 mk[EPI == 2 ? MT : 1][EPI == 2 ? NT : 1];
+    u32x4 mk[EPI == 2 ? MT : 1][EPI == 2 ? RR : 1];
     auto load_mask = [&](int j) {
       const int mt = MT * mg + j;
       const int oy = y0_e + 2 * (mt / 5), ox = x0_e + 8 * (mt % 5);
-      // (every element is assigned: a conditionally assigned one would stay live around the
-      // whole tile loop)
-      const bool inside = mt < NMT && oy + ht_row(i) < H && ox + ht_col(i) < W;
       const unsigned short* mb = mask + (((int64_t)b_e * H + oy) * W + ox) * kout + ch_w;
 #pragma unroll
-      for (int n = 0; n < NT; ++n)
-        mk[EPI == 2 ? j : 0][EPI == 2 ? n : 0] =
-            inside ? *reinterpret_cast<const u32x2*>(mb + lane_o + 16 * n) : u32x2{0u, 0u};
+      for (int rr = 0; rr < RR; ++rr) {
+        // (every element is assigned: a conditionally assigned one would stay live around the
+        // whole tile loop)
+        const bool inside = mt < NMT && oy + ht_row(piece_px[rr]) < H && ox + ht_col(piece_px[rr]) < W;
+        mk[EPI == 2 ? j : 0][EPI == 2 ? rr : 0] =
+            inside ? *reinterpret_cast<const u32x4*>(mb + piece_o[rr]) : u32x4{0u, 0u, 0u, 0u};
+      }
     };
     if (EPI == 2) {
 #pragma unroll
@@ -380,45 +401,70 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
     if (EPI == 3) {
       // register q of lane (c = i, g' = g): pixel 4 g' + q of the m-tile, channel 16 n + c.
       // Registers (0,1) and (2,3) are the two pooling windows of this lane's row quad; the other
-      // row of both windows sits in lane l ^ 16 under the same registers
+      // row of both windows sits in lane l ^ 16 under the same registers.  The pooled values and
+      // window indices of FOUR m-tiles (16 pooled pixels x the wave's 64 channels) are gathered
+      // in the scratch and leave as whole lines: 128 bytes of bf16 / 64 bytes of indices per
+      // pooled pixel.
       const int PH = H / 2, PW = W / 2;
       const bool upper = g == 0 || g == 3;
       const int cb = g < 2 ? 0 : 4;                        // column base of this lane's quad
+      unsigned char* scr8 = reinterpret_cast<unsigned char*>(scr + 16 * SLD);   // [16][64 + 16]
+      constexpr int SLD8 = 16 * NT + 16;
 #pragma unroll
-      for (int j = 0; j < MT; ++j) {
-        const int mt = MT * mg + j;
-        if (mt >= NMT) break;                              // wave-uniform
-        const int mr = mt / 5, mc = mt % 5;
+      for (int jb = 0; jb < MT; jb += 4) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          const int ch = ch_w + 16 * n + i;
+        for (int jj = 0; jj < 4; ++jj) {
+          const int j = jb + jj < MT ? jb + jj : MT - 1;   // (MT = 10: the last group is half full)
 #pragma unroll
-          for (int q0 = 0; q0 < 4; q0 += 2) {
-            const float v0 = acc[j][n][q0], v1 = acc[j][n][q0 + 1];
-            const float lm = fmaxf(v0, v1);
-            const int li = v0 >= v1 ? 0 : 1;
-            const float om = __shfl_xor(lm, 16);
-            const int oi = __shfl_xor(li, 16);
-            const float mu = upper ? lm : om, ml = upper ? om : lm;
-            const int iu = upper ? li : oi, il = upper ? oi : li;
-            const float m = fmaxf(mu, ml);
-            const int k = mu >= ml ? iu : 2 + il;          // first maximum in raster order
-            const int py = (y0_e + 2 * mr) >> 1, px = (x0_e + 8 * mc + cb + q0) >> 1;
-            if (upper && py < PH && px < PW && !(dbg & 2)) {
-              const int64_t po = (((int64_t)b_e * PH + py) * PW + px) * kout + ch;
-              out[po] = f32_to_bf16(fmaxf(m + bias1[n], 0.f));
-              pidx[po] = (unsigned char)k;
+          for (int n = 0; n < NT; ++n) {
+#pragma unroll
+            for (int q0 = 0; q0 < 4; q0 += 2) {
+              const float v0 = acc[j][n][q0], v1 = acc[j][n][q0 + 1];
+              const float lm = fmaxf(v0, v1);
+              const int li = v0 >= v1 ? 0 : 1;
+              const float om = __shfl_xor(lm, 16);
+              const int oi = __shfl_xor(li, 16);
+              const float mu = upper ? lm : om, ml = upper ? om : lm;
+              const int iu = upper ? li : oi, il = upper ? oi : li;
+              const float m = fmaxf(mu, ml);
+              const int k = mu >= ml ? iu : 2 + il;        // first maximum in raster order
+              // pooled pixel of the group of four m-tiles: 4 jj + (cb + q0) / 2
+              const int pl = 4 * jj + ((cb + q0) >> 1);
+              if (upper) {
+                scr[pl * SLD + 16 * n + i] = f32_to_bf16(fmaxf(m + bias1[n], 0.f));
+                scr8[pl * SLD8 + 16 * n + i] = (unsigned char)k;
+              }
             }
           }
         }
+        __builtin_amdgcn_wave_barrier();
+        // 16 pooled pixels: values 16 x PCS pieces of 16 bytes, indices 16 x NT pieces
+#pragma unroll
+        for (int rr = 0; rr < RR; ++rr) {
+          const int pp = lane + 64 * rr, pl = pp / PCS, pc = pp % PCS;
+          const int mt = MT * mg + jb + (pl >> 2);
+          const int py = (y0_e >> 1) + mt / 5, px = (x0_e >> 1) + 4 * (mt % 5) + (pl & 3);
+          const u32x4 v = *reinterpret_cast<const u32x4*>(scr + pl * SLD + 8 * pc);
+          if (jb + (pl >> 2) < MT && mt < NMT && py < PH && px < PW && !(dbg & 2))
+            *reinterpret_cast<u32x4*>(out + (((int64_t)b_e * PH + py) * PW + px) * kout + ch_w + 8 * pc) = v;
+        }
+        if (lane < 16 * NT) {
+          const int pl = lane / NT, pc = lane % NT;
+          const int mt = MT * mg + jb + (pl >> 2);
+          const int py = (y0_e >> 1) + mt / 5, px = (x0_e >> 1) + 4 * (mt % 5) + (pl & 3);
+          const u32x4 v = *reinterpret_cast<const u32x4*>(scr8 + pl * SLD8 + 16 * pc);
+          if (jb + (pl >> 2) < MT && mt < NMT && py < PH && px < PW && !(dbg & 2))
+            *reinterpret_cast<u32x4*>(pidx + (((int64_t)b_e * PH + py) * PW + px) * kout + ch_w + 16 * pc) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
       }
     } else {
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
       for (int j = 0; j < MT; ++j) {
         const int mt = MT * mg + j;
         if (mt < NMT) {                                    // wave-uniform
           const int oy = y0_e + 2 * (mt / 5), ox = x0_e + 8 * (mt % 5);
-          const bool inside = oy + ht_row(i) < H && ox + ht_col(i) < W && !(dbg & 2);
           unsigned short* ob = out + (((int64_t)b_e * H + oy) * W + ox) * kout + ch_w;
 #pragma unroll
           for (int n = 0; n < NT; ++n) {
@@ -430,12 +476,17 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
             u32x2 pk;
             pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
             pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-            if (EPI == 2) {
-              pk.x = relu_mask_word(pk.x, mk[EPI == 2 ? j : 0][EPI == 2 ? n : 0].x);
-              pk.y = relu_mask_word(pk.y, mk[EPI == 2 ? j : 0][EPI == 2 ? n : 0].y);
-            }
-            if (inside) *reinterpret_cast<u32x2*>(ob + lane_o + 16 * n) = pk;
+            *reinterpret_cast<u32x2*>(scr + i * SLD + 16 * n + 4 * g) = pk;
           }
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int rr = 0; rr < RR; ++rr) {
+            u32x4 v = *reinterpret_cast<const u32x4*>(scr + piece_px[rr] * SLD + 8 * ((lane + 64 * rr) % PCS));
+            if (EPI == 2) v = relu_mask(v, mk[EPI == 2 ? j : 0][EPI == 2 ? rr : 0]);
+            const bool inside = oy + ht_row(piece_px[rr]) < H && ox + ht_col(piece_px[rr]) < W && !(dbg & 2);
+            if (inside) *reinterpret_cast<u32x4*>(ob + piece_o[rr]) = v;
+          }
+          __builtin_amdgcn_wave_barrier();
         }
         if (EPI == 2) {
           __builtin_amdgcn_sched_barrier(0);               // keep the loads where they are
