@@ -244,8 +244,8 @@ def _own_conv_kind(x, w, transposed=False):
 def _lds_conv_pays(x, transposed=False, fused_tail=False):
     """Measured on MI355X (scripts/conv_layers.py, profiles/r02): the LDS-weights kernel
     (csrc/convh.hip) beats the library on conv3_x .. conv5_x in both directions — conv4_x
-    forward 1235 vs 960 TFLOP/s, backward-data 1250 vs 660; at 30 x 40 (conv5_x), with its 6-row
-    blocks, forward 1050 vs 900 and backward-data 1070 vs 600.  Smaller maps fill the chip too
+    forward 1340 vs 1010 TFLOP/s, backward-data 1370 vs 670; at 30 x 40 (conv5_x), with its 6-row
+    blocks, forward 1070 vs 920 and backward-data 1110 vs 570.  Smaller maps fill the chip too
     badly and stay with the library."""
     return x.shape[2] * x.shape[3] >= 30 * 40
 
