@@ -1,0 +1,109 @@
+"""Two ranks on ONE GPU (gloo carries the collective; both ranks compute on cuda:0): the only
+way to run the data-parallel gradient path with real asynchronous HIP kernels on a one-GPU box.
+
+What is under test (parallel.GradBuckets + nets.GRAD_SINK + nets.USE_SIDE_WRW):
+the weight-gradient kernels write into the flat gradient buffer from a second stream while the
+bucket logic launches the all-reduce of a bucket as soon as its last parameter is reported —
+the collective must see finished gradients.  The all-reduced buffer of each rank has to equal,
+bit for bit, the sum of the two ranks' single-process gradients (a + b of two floats has one
+result), with small buckets (many collectives in flight during backward) and with one bucket.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _images(rank):
+    g = torch.Generator().manual_seed(200 + rank)
+    return torch.randint(0, 256, (1, 480, 640, 3), generator=g).float()
+
+
+def _backbone_params(model):
+    """Only features() runs here: the NetVLAD parameters get no gradient and would keep their
+    bucket from ever completing."""
+    return [p for n, p in model.named_parameters()
+            if not n.startswith(('assignment', 'cluster'))]
+
+
+def _local_grads(rank, dev):
+    """Flat gradient buffer of one rank's batch, no process group."""
+    from soft_contrastive_learning_amd import parallel
+    from soft_contrastive_learning_amd.model import nets
+    model = nets.VGG16NetVLAD(compute_dtype=torch.bfloat16, seed=21, fused_relu=True).to(dev)
+    buckets = parallel.GradBuckets(_backbone_params(model))
+    buckets.enabled = False                # no collective: this rank's own gradients only
+    g = torch.randn(1, 30, 40, 512, generator=torch.Generator().manual_seed(300 + rank)).to(dev).bfloat16()
+    nets.GRAD_SINK = buckets
+    try:
+        buckets.zero()
+        model.features(_images(rank).to(dev)).backward(g)
+        buckets.finish()
+    finally:
+        nets.GRAD_SINK = None
+    torch.cuda.synchronize()
+    return buckets.flat.clone()
+
+
+def _worker(rank, world, port, bucket_bytes, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from soft_contrastive_learning_amd import parallel
+        from soft_contrastive_learning_amd.model import nets
+        dev = torch.device('cuda:0')
+        want = _local_grads(0, dev) + _local_grads(1, dev)
+        model = nets.VGG16NetVLAD(compute_dtype=torch.bfloat16, seed=21, fused_relu=True).to(dev)
+        buckets = parallel.GradBuckets(_backbone_params(model), bucket_bytes=bucket_bytes)
+        assert buckets.enabled and nets.USE_SIDE_WRW
+        g = torch.randn(1, 30, 40, 512, generator=torch.Generator().manual_seed(300 + rank)).to(dev).bfloat16()
+        img = _images(rank).to(dev)
+        nets.GRAD_SINK = buckets
+        try:
+            for _ in range(3):                      # stale events, buffer reuse across steps
+                buckets.zero()
+                model.features(img).backward(g)
+                buckets.finish()
+                torch.cuda.synchronize()
+                same = bool(torch.equal(buckets.flat, want))
+                worst = float((buckets.flat - want).abs().max())
+                if not same:
+                    break
+        finally:
+            nets.GRAD_SINK = None
+        out.put((rank, same, worst, len(buckets.buckets), len(buckets._streams)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('bucket_bytes', [1 << 20, 1 << 30])
+def test_two_ranks_on_one_gpu_all_reduce_finished_gradients(bucket_bytes):
+    if not torch.cuda.is_available():
+        pytest.skip('needs a HIP device')
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, bucket_bytes, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    res = sorted(out.get(timeout=10) for _ in range(2))
+    for rank, same, worst, nb, ns in res:
+        assert ns == 1, 'the weight gradients did not run on the second stream'
+        assert nb >= (8 if bucket_bytes == 1 << 20 else 1)
+        assert same, 'rank %d: all-reduced gradients differ from the sum of the ranks by %g' % (rank, worst)
