@@ -107,3 +107,65 @@ def test_two_ranks_on_one_gpu_all_reduce_finished_gradients(bucket_bytes):
         assert ns == 1, 'the weight gradients did not run on the second stream'
         assert nb >= (8 if bucket_bytes == 1 << 20 else 1)
         assert same, 'rank %d: all-reduced gradients differ from the sum of the ranks by %g' % (rank, worst)
+
+
+def _loss_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import numpy as np
+        from soft_contrastive_learning_amd import parallel
+        from soft_contrastive_learning_amd.evaluation import retrieval
+        from soft_contrastive_learning_amd.model import losses
+        dev = torch.device('cuda:0')
+        b, e = 12, 32768
+        g = torch.Generator().manual_seed(400)
+        emb_all = torch.randn(world * b, e, generator=g)
+        emb_all = (emb_all / emb_all.norm(dim=1, keepdim=True)).to(dev)
+        xy = torch.rand(world * b, 2, generator=g) * 60.0
+        dmat = (xy[:, None] - xy[None]).norm(dim=2)[None].to(dev)
+        # single-process loss and gradient on the whole batch
+        ref = emb_all.clone().requires_grad_(True)
+        loss_ref = losses.wms_loss(dmat, ref, d_alpha=0.8, d_beta=15.0)
+        loss_ref.backward()
+        # this rank's rows through the data-parallel wrapper (all-gather + own-rows backward)
+        mine = emb_all[rank * b:(rank + 1) * b].clone().requires_grad_(True)
+        loss = parallel.wms_loss_dp(dmat, mine, 0.8, 15.0)
+        loss.backward()
+        torch.cuda.synchronize()
+        want = ref.grad[rank * b:(rank + 1) * b]
+        gerr = float((mine.grad - want).abs().max() / want.abs().max())
+        lerr = abs(float(loss) - float(loss_ref)) / abs(float(loss_ref))
+        # sharded retrieval: each rank scans half of the references, lists merged over ranks
+        refs = torch.randn(4096, 256, generator=g).to(dev)
+        qry = torch.randn(64, 256, generator=g).to(dev)
+        half = refs.shape[0] // world
+        d_sh, i_sh = parallel.topn_l2_sharded(refs[rank * half:(rank + 1) * half], qry, 25, rank * half)
+        d_all, i_all = retrieval.topn_l2(refs, qry, 25)
+        out.put((rank, lerr, gerr, bool(torch.equal(i_sh.cpu(), i_all.cpu())),
+                 float((d_sh.cpu() - d_all.cpu()).abs().max())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_loss_and_sharded_retrieval():
+    """parallel.wms_loss_dp (autograd all-gather, the HIP Gram loss on the gathered batch, backward
+    for the rank's own rows) against the single-process loss on the same 24 descriptors: equal loss
+    (<= 1e-6 relative: same kernels, same inputs) and equal gradients for the own rows; and
+    parallel.topn_l2_sharded against retrieval.topn_l2 on the unsharded references: the same index
+    lists."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a HIP device')
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_loss_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    for rank, lerr, gerr, same_idx, derr in sorted(out.get(timeout=10) for _ in range(2)):
+        assert lerr <= 1e-6, (rank, lerr)
+        assert gerr <= 1e-6, (rank, gerr)
+        assert same_idx and derr <= 1e-9, (rank, derr)
