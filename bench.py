@@ -369,12 +369,20 @@ def main():
         return stub_main(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device (no CPU path exists)')
+    # TEST ONLY (SCL_BENCH_ONE_GPU_GLOO=1): every rank on cuda:0 with gloo carrying the
+    # collectives — the whole data-parallel step on a one-GPU box; the timing means nothing
+    one_gpu = os.environ.get('SCL_BENCH_ONE_GPU_GLOO') == '1'
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if one_gpu:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
 
     from soft_contrastive_learning_amd import _lib, parallel
     from soft_contrastive_learning_amd.model import losses, nets

@@ -169,3 +169,28 @@ def test_two_ranks_on_one_gpu_loss_and_sharded_retrieval():
         assert lerr <= 1e-6, (rank, lerr)
         assert gerr <= 1e-6, (rank, gerr)
         assert same_idx and derr <= 1e-9, (rank, derr)
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` end to end on a one-GPU box (SCL_BENCH_ONE_GPU_GLOO=1: both
+    ranks on cuda:0, gloo for the collectives): self-launch, the data-parallel step (all-gather of
+    the embeddings, loss on the global batch of 48, bucketed all-reduce against the second
+    stream), max-over-ranks timing, one JSON line from rank 0.  The timing itself means nothing."""
+    import json
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip('needs a HIP device')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SCL_BENCH_ONE_GPU_GLOO='1')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2',
+                        '--warmup', '1', '--no-cpu-baseline'], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['config']['global_batch'] == 48 and d['scaling'] == 'weak'
+    assert d['value'] > 0 and 0.0 < d['config']['loss'] < 100.0
