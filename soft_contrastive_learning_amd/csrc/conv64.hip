@@ -1104,8 +1104,8 @@ static int conv64_cus() {
   int dev = 0, n = 0;
   if (hipGetDevice(&dev) == hipSuccess &&
       hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-    return n;
-  return 256;
+    return scl_usable_cus(n);
+  return scl_usable_cus(256);
 }
 
 static int wrw_splits(int C, int K, int tiles, int cus) {

@@ -395,6 +395,7 @@ static int convg_cus() {
     n = (hipGetDevice(&dev) == hipSuccess &&
          hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0)
             ? c : 256;
+    n = scl_usable_cus(n);
   }
   return n;
 }

@@ -506,6 +506,7 @@ int convh_cus() {
     n = (hipGetDevice(&dev) == hipSuccess &&
          hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0)
             ? c : 256;
+    n = scl_usable_cus(n);
   }
   return n;
 }

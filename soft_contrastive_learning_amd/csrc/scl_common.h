@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "scl_hip.h"
 
@@ -220,6 +221,20 @@ int scl_convh_dispatch(const void* x, const void* w, int64_t w_stride_k, int64_t
                        int64_t w_stride_h, int64_t w_stride_w, int flags, int B, int H, int W,
                        int cin, int kout, void* out, const float* bias, int relu, const void* mask,
                        void* pidx, void* workspace, int dv, void* stream);
+
+// CUs the persistent convolution grids leave free (SCL_RESERVE_CUS, default 0).  With more than one
+// rank the RCCL kernels need somewhere to run while those grids hold every CU;
+// the knob exists so that this can be measured on a multi-GPU node without a rebuild.
+static inline int scl_usable_cus(int cus) {
+  static int reserve = -1;
+  if (reserve < 0) {
+    const char* e = getenv("SCL_RESERVE_CUS");
+    reserve = e ? atoi(e) : 0;
+    if (reserve < 0) reserve = 0;
+  }
+  const int left = cus - reserve;
+  return left >= 8 ? left : (cus < 8 ? cus : 8);
+}
 
 static inline int scl_launch_status() { return (int)hipGetLastError(); }
 static inline bool scl_aligned256(const void* p) { return (((uintptr_t)p) & 255u) == 0; }
