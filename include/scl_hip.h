@@ -330,7 +330,9 @@ int scl_convg_pool_idx(const void* x, const void* w, int64_t w_stride_k, int64_t
                        void* pool_idx, void* workspace, size_t workspace_bytes, void* stream);
 /* Pool + ReLU backward from that index map: gz [B,H,W,C] = g * [a > 0] at the stored window
  * position, zero elsewhere (and on rows / columns no window covers); bias_grad[c] = sum of
- * g * [a > 0].  Arguments as scl_vgg_pool_bwd with idx in place of z. */
+ * g * [a > 0].  Arguments as scl_vgg_pool_bwd with idx in place of z; a == NULL: g is already
+ * masked (the backward-data kernel of the layer above applied [a > 0] in its epilogue, a being
+ * its own input) and a is not read. */
 int scl_vgg_pool_bwd_idx(const void* g, const void* a, const void* idx, int dtype, int B, int H,
                          int W, int C, void* gz, float* bias_grad, void* workspace,
                          size_t workspace_bytes, void* stream);

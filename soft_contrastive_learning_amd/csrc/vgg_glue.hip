@@ -235,7 +235,12 @@ __global__ __launch_bounds__(kThreads) void pool_bwd_idx_kernel(
     const int64_t base = ((bb * H + 2 * ho) * W + 2 * wo) * C + c8 * 8;
     float gv[8], av[8];
     Vec8<T>::ld(g + i * 8, gv);
-    Vec8<T>::ld(a + i * 8, av);
+    if (a) {
+      Vec8<T>::ld(a + i * 8, av);
+    } else {                                  // g arrives masked (the producer's epilogue did it)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) av[c] = 1.f;
+    }
     const uint2 iw = *reinterpret_cast<const uint2*>(idx + i * 8);
     float o0[8], o1[8], o2[8], o3[8];
 #pragma unroll
@@ -411,8 +416,8 @@ extern "C" int scl_vgg_pool_bwd(const void* g, const void* a, const void* z, int
 extern "C" int scl_vgg_pool_bwd_idx(const void* g, const void* a, const void* idx, int dtype,
                                     int B, int H, int W, int C, void* gz, float* bias_grad,
                                     void* workspace, size_t workspace_bytes, void* stream) {
-  if (!g || !a || !idx || !gz || !bias_grad || !workspace) return SCL_E_NULL;
-  if (B < 1 || H < 2 || W < 2 || !channels_ok(C) || !aligned16(g) || !aligned16(a) ||
+  if (!g || !idx || !gz || !bias_grad || !workspace) return SCL_E_NULL;
+  if (B < 1 || H < 2 || W < 2 || !channels_ok(C) || !aligned16(g) || (a && !aligned16(a)) ||
       (((uintptr_t)idx) & 7u) || !aligned16(gz))
     return SCL_E_SHAPE;
   if (!scl_aligned256(workspace) || workspace_bytes < scl_vgg_workspace_bytes(C))

@@ -533,9 +533,11 @@ def _wrw_maybe_async(x, gz, w, gb):
     side.wait_stream(torch.cuda.current_stream(dev))
     with torch.cuda.stream(side):
         gw = wrw64(x, gz, w, gb)
-    x.record_stream(side)
-    gz.record_stream(side)
-    sink.note_stream(side)
+    # x and gz are read on `side`; they must not go back to the allocator before that stream
+    # is joined.  Tensor.record_stream would say so, but it makes the allocator hold the blocks
+    # behind events and, every few runs, hipMalloc a new one in the middle of a step (one step
+    # of 0.5 s in half of the bench runs): the sink keeps the references until finish() instead.
+    sink.note_stream(side, x, gz)
     return gw
 
 
@@ -641,9 +643,9 @@ class _ConvBiasPoolReLU(torch.autograd.Function):
     conv output (no int64 index tensor) and fuses ReLU' and the bias gradient."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, link_in=None):
+    def forward(ctx, x, w, bias, link_in=None, link_out=None):
         lib = L.load()
-        ctx.link_in = link_in
+        ctx.link_in, ctx.link_out = link_in, link_out
         ctx.by_idx = False
         kind = _own_conv_kind(x, w)
         if USE_POOL_IDX and ((kind == 'reg' and w.shape[0] == w.shape[1])
@@ -681,13 +683,16 @@ class _ConvBiasPoolReLU(torch.autograd.Function):
             c, dtype=torch.float32, device=a.device)
         ws = L.workspace(lib.scl_vgg_workspace_bytes(c), a.device)
         fn = lib.scl_vgg_pool_bwd_idx if ctx.by_idx else lib.scl_vgg_pool_bwd
+        # ReLU' of this layer already applied by the layer above (its backward-data epilogue
+        # masks with its own input, which is this layer's output a)?  Then a is not read.
+        masked = ctx.by_idx and ctx.link_out is not None and ctx.link_out.take(ga)
         # read g, a (1/4 each) and the index bytes (1/8) or z (1); write gz
         _work('vgg_pool_bwd_idx' if ctx.by_idx else 'vgg_pool_bwd', 0.0,
-              (1.625 if ctx.by_idx else 2.5) * gz.numel() * gz.element_size())
-        L.check(fn(L.ptr(ga), L.ptr(a), L.ptr(z), _glue_dtype(a), b, h, wd, c,
+              ((1.375 if masked else 1.625) if ctx.by_idx else 2.5) * gz.numel() * gz.element_size())
+        L.check(fn(L.ptr(ga), None if masked else L.ptr(a), L.ptr(z), _glue_dtype(a), b, h, wd, c,
                    L.ptr(gz), L.ptr(gb), L.ptr(ws), ws.numel(), L.stream_of(a)))
         gx, gw = _conv3x3_backward(gz, x, w, ctx.needs_input_grad[0], ctx.link_in)
-        return gx, _grad_ret(gw, w), _grad_ret(gb, bias), None
+        return gx, _grad_ret(gw, w), _grad_ret(gb, bias), None, None
 
 
 def avg_rgb_grad(gz, w, gb):
@@ -931,8 +936,8 @@ class VGG16NetVLAD(torch.nn.Module):
             if item == 'pool':
                 if not skip_pool:
                     x = F.relu(F.max_pool2d(x, 2, 2))                    # pool, then ReLU
-                skip_pool = False
-                link = None
+                    link = None
+                skip_pool = False                       # (fused conv + pool: its link stays)
                 continue
             name, _, relu = item
             pool_next = idx + 1 < len(VGG_LAYERS) and VGG_LAYERS[idx + 1] == 'pool'
@@ -952,9 +957,12 @@ class VGG16NetVLAD(torch.nn.Module):
                     x = _FirstConv.apply(image_batch, self.average_rgb, w, bias, dt, link)
                 elif pool_next:
                     # conv -> bias -> pool -> ReLU in one elementwise pass (nets.py:40-42)
-                    x = _ConvBiasPoolReLU.apply(x, w, bias, link)
+                    # (the pooled map is post-ReLU too: the next layer's backward-data kernel can
+                    # apply this layer's ReLU' the same way)
+                    pool_link = _GradLink()
+                    x = _ConvBiasPoolReLU.apply(x, w, bias, link, pool_link)
                     skip_pool = True
-                    link = None
+                    link = pool_link
                 else:
                     link_out = _GradLink() if relu else None
                     x = _ConvBiasAct.apply(x, w, bias, relu, link, link_out)

@@ -135,6 +135,7 @@ class GradBuckets:
         # gradients that arrive through autograd
         self._by_ptr = {p.data_ptr(): p for p in self.params}
         self._streams = []         # side streams that write into the flat buffer (note_stream)
+        self._keep = []            # what those streams still read: released once they are joined
 
     def _close(self, begin, end, members):
         if not hasattr(self, '_members'):
@@ -174,11 +175,14 @@ class GradBuckets:
             self._handles.append(dist.all_reduce(self.flat[b:e], op=dist.ReduceOp.SUM,
                                                  group=self.group, async_op=True))
 
-    def note_stream(self, stream):
+    def note_stream(self, stream, *inputs):
         """A kernel on `stream` (not the current one) writes a gradient into the flat buffer:
-        the stream is joined before a collective reads the buffer and in finish()."""
+        the stream is joined before a collective reads the buffer and in finish().  `inputs`
+        (tensors that kernel reads) are kept alive until finish() has joined the stream, so that
+        the caching allocator cannot hand their memory to the current stream early."""
         if all(s is not stream for s in self._streams):
             self._streams.append(stream)
+        self._keep.extend(inputs)
 
     def _join_streams(self):
         for s in self._streams:
@@ -203,6 +207,9 @@ class GradBuckets:
         self._remaining = [len(m) for m in self._members]
         self._reported = {}
         self._handles = []
+        if self._keep:                     # finish() was skipped: join before releasing
+            self._join_streams()
+            self._keep = []
 
     def finish(self):
         """Wait for the collectives launched during backward (call before optimizer.step)."""
@@ -210,3 +217,4 @@ class GradBuckets:
             h.wait()
         self._handles = []
         self._join_streams()
+        self._keep = []
