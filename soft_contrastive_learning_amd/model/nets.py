@@ -174,9 +174,12 @@ USE_PREPACK = os.environ.get('SCL_PREPACK', '1') != '0'
 _PACKED = {}     # (data_ptr, transposed) -> (weakref to the weight, _version, shape, image)
 
 
-def prepack(weights):
+def prepack(weights, force=False):
     """Bring the packed images of ``weights`` (3x3 convolution weights on a HIP device, both
-    directions) up to date; returns the number of images written."""
+    directions) up to date; returns the number of images written.  Without ``force`` an image
+    is rewritten only when the tensor's autograd version moved — which in-place optimizers do
+    NOT guarantee (torch's fused Adam updates the parameters without touching ``_version``), so
+    the model's forward pass forces: one 40 us launch per forward, never a stale weight."""
     import weakref
     lib = L.load()
     jobs, keep = [], []
@@ -192,7 +195,8 @@ def prepack(weights):
                 continue
             key = (w.data_ptr(), transposed)
             ent = _PACKED.get(key)
-            if ent is not None and ent[0]() is not None and ent[1] == w._version and ent[2] == tuple(w.shape):
+            if (not force and ent is not None and ent[0]() is not None and ent[1] == w._version
+                    and ent[2] == tuple(w.shape)):
                 continue
             buf = (ent[3] if ent is not None and ent[3].numel() == nbytes and ent[3].device == w.device
                    else torch.empty(nbytes, dtype=torch.uint8, device=w.device))
@@ -903,8 +907,9 @@ class VGG16NetVLAD(torch.nn.Module):
         if x is not None:
             x = x.contiguous(memory_format=torch.channels_last)
         if fuse and dt == torch.bfloat16 and USE_CONV64 and USE_F32_WEIGHTS and USE_PREPACK:
-            # every packed weight image of this step (both directions) in one launch
-            prepack([getattr(self, 'conv%s_kernel' % n) for n in self.conv_names])
+            # every packed weight image of this step (both directions) in one launch; forced: an
+            # optimizer step in between may not have moved the tensors' versions
+            prepack([getattr(self, 'conv%s_kernel' % n) for n in self.conv_names], force=True)
         split = None
         if (fuse and dt == torch.bfloat16 and USE_CONV64 and _split_fwd_wanted() and _FWD.split is None
                 and image_batch.shape[0] >= 2):

@@ -240,3 +240,35 @@ def test_checkpoint_resume_with_fused_adam_on_the_device(dev, tmp_path):
     torch.cuda.synchronize()
     for pa, pb in zip(a.parameters(), b.parameters()):
         assert torch.equal(pa, pb)
+
+
+def test_fused_adam_steps_reach_the_convolutions(dev):
+    """The packed weight images (nets.prepack) must follow the optimizer: torch's fused Adam
+    updates parameters without moving their autograd version, so a version check alone would
+    serve the FIRST step's weights for ever.  Two models from the same seed, one with the
+    packed-image path and one packing per convolution, must produce the same descriptors after
+    three optimizer steps with a learning rate large enough to matter."""
+    from soft_contrastive_learning_amd import parallel
+    from soft_contrastive_learning_amd.model import nets
+    img = torch.randint(0, 256, (2, 480, 640, 3), generator=torch.Generator().manual_seed(7)).float().to(dev)
+    g = torch.randn(2, 30, 40, 512, generator=torch.Generator().manual_seed(8)).to(dev).bfloat16()
+    outs = {}
+    old = nets.USE_PREPACK
+    try:
+        for use in (False, True):
+            nets.USE_PREPACK = use
+            nets._PACKED.clear()
+            model = nets.VGG16NetVLAD(compute_dtype=torch.bfloat16, seed=5, fused_relu=True).to(dev)
+            opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
+            w0 = model.conv3_1_kernel.detach().clone()
+            for _ in range(3):
+                opt.zero_grad(set_to_none=True)
+                model.features(img).backward(g)
+                opt.step()
+            assert float((model.conv3_1_kernel.detach() - w0).abs().max()) > 1e-3
+            with torch.no_grad():
+                outs[use] = model.features(img).float().clone()
+    finally:
+        nets.USE_PREPACK = old
+        nets._PACKED.clear()
+    assert torch.equal(outs[True], outs[False])
