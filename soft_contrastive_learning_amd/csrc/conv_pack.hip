@@ -12,6 +12,7 @@
 namespace {
 
 constexpr int kMaxJobs = 32;
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
 
 struct PackJobs {
   const void* w[kMaxJobs];
@@ -62,6 +63,54 @@ __global__ __launch_bounds__(256) void conv_pack_batch_kernel(const PackJobs job
   jobs.packed[job][idx] = weight_bf16(jobs.w[job], off, wf32);
 }
 
+// The same images from a contiguous OIHW weight (the float32 master, or a contiguous bf16 copy)
+// through an LDS tile: the gather above reads 4 (or 2) bytes per lane at a stride of 36 (18)
+// bytes and took 255 us per step for the 29 M elements of VGG16 — it runs at every forward pass
+// (prepack forces it: an in-place optimizer need not touch a tensor's version), so it matters.
+// A workgroup takes a [32 output channels] x [32 contraction channels] x 9 taps patch: 32 source
+// rows of 288 contiguous elements in, 1152 units of 16 bytes out, 32 consecutive units (512
+// bytes) per destination run in either layout.
+__global__ __launch_bounds__(256) void conv_pack_tiled_kernel(const PackJobs jobs) {
+  __shared__ unsigned short tile[9][32][40];          // [tap][co][ci + pad]
+  int job = 0;
+  while (job + 1 < jobs.n && (int)blockIdx.x >= jobs.first_block[job + 1]) ++job;
+  const int t = blockIdx.x - jobs.first_block[job];
+  const int cin = jobs.cin[job], flags = jobs.flags[job];
+  const int transposed = flags & 1, wf32 = flags & 2;
+  const int cibn = cin / 32;
+  const int cob = t / cibn, cib = t % cibn;
+  // source rows: forward: output channel co (row stride sk), 288 = (ci, tap) contiguous from
+  // ci0 * 9; transposed: contraction channel ci = source k (row stride sk), 288 = (co, tap)
+  const int64_t sk = jobs.sk[job];
+  const int row0 = transposed ? 32 * cib : 32 * cob, col0 = (transposed ? 32 * cob : 32 * cib) * 9;
+  for (int e = threadIdx.x; e < 32 * 288; e += 256) {
+    const int row = e / 288, col = e - row * 288;
+    const unsigned short v = weight_bf16(jobs.w[job], (row0 + row) * sk + col0 + col, wf32);
+    const int inner = col / 9, tap = col - inner * 9;
+    if (!transposed)
+      tile[tap][row][inner] = v;                      // row = co, inner = ci
+    else
+      tile[8 - tap][inner][row] = v;                  // row = ci, inner = co; taps flipped
+  }
+  __syncthreads();
+  unsigned short* packed = jobs.packed[job];
+  for (int u = threadIdx.x; u < 9 * 4 * 32; u += 256) {
+    const int kl = u & 31, g = (u >> 5) & 3, tap = u >> 7;       // co_local, 8-channel piece
+    const u32x4s v = *reinterpret_cast<const u32x4s*>(&tile[tap][kl][8 * g]);
+    int64_t idx;
+    if (flags & 8) {
+      // conv64.hip: ((nt * KS + ks) * 64 + lane) * 8, ks = tap * SPT + ci / 16, lane = co % 32 + 32 h
+      const int spt = cin / 16, ks = tap * spt + 2 * cib + (g >> 1);
+      idx = (((int64_t)cob * 9 * spt + ks) * 64 + kl + 32 * (g & 1)) * 8;
+    } else {
+      // convh.hip: ((nb * CC + cc) * 9 + tap) * 4096 + (g * 128 + k) * 8
+      const int co = 32 * cob + kl;
+      idx = (((int64_t)(co >> 7) * cibn + cib) * 9 + tap) * 4096 + (g * 128 + (co & 127)) * 8;
+    }
+    *reinterpret_cast<u32x4s*>(packed + idx) = v;
+  }
+}
+
 inline bool reg_shape(int cin, int kout) {
   return (cin == 64 || cin == 128) && (kout == 64 || kout == 128);
 }
@@ -99,8 +148,28 @@ extern "C" int scl_conv_pack_batch(const SclPackJob* jobs, int njobs, void* stre
       blocks += (9 * j.cin * j.kout + 255) / 256;
     }
     pj.first_block[pj.n] = blocks;
-    SCL_LAUNCH("conv_pack_batch_kernel", conv_pack_batch_kernel, dim3((unsigned)blocks), dim3(256), 0,
-               (hipStream_t)stream, pj);
+    // contiguous OIHW sources (the float32 masters): the tiled kernel; anything else: the gather
+    bool tiled = true;
+    for (int i = 0; i < pj.n; ++i) {
+      const SclPackJob& j = jobs[base + i];
+      const int src_c = (j.flags & 1) ? j.kout : j.cin;      // the source tensor's dimension 1
+      tiled = tiled && j.w_stride_w == 1 && j.w_stride_h == 3 && j.w_stride_c == 9 &&
+              j.w_stride_k == (int64_t)9 * src_c && j.cin % 32 == 0 && j.kout % 32 == 0 &&
+              ((uintptr_t)j.packed % 16) == 0;
+    }
+    if (tiled) {
+      int tiles = 0;
+      for (int i = 0; i < pj.n; ++i) {
+        pj.first_block[i] = tiles;
+        tiles += (pj.cin[i] / 32) * (pj.kout[i] / 32);
+      }
+      pj.first_block[pj.n] = tiles;
+      SCL_LAUNCH("conv_pack_batch_kernel", conv_pack_tiled_kernel, dim3((unsigned)tiles), dim3(256), 0,
+                 (hipStream_t)stream, pj);
+    } else {
+      SCL_LAUNCH("conv_pack_batch_kernel", conv_pack_batch_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                 (hipStream_t)stream, pj);
+    }
   }
   return scl_launch_status();
 }
