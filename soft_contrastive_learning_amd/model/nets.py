@@ -248,8 +248,8 @@ def _own_conv_kind(x, w, transposed=False):
 def _lds_conv_pays(x, transposed=False, fused_tail=False):
     """Measured on MI355X (scripts/conv_layers.py, profiles/r02): the LDS-weights kernel
     (csrc/convh.hip) beats the library on conv3_x .. conv5_x in both directions — conv4_x
-    forward 1340 vs 1010 TFLOP/s, backward-data 1370 vs 670; at 30 x 40 (conv5_x), with its 6-row
-    blocks, forward 1070 vs 920 and backward-data 1110 vs 570.  Smaller maps fill the chip too
+    forward 1230-1340 vs 950-1010 TFLOP/s, backward-data 1260-1370 vs 640-670; at 30 x 40 (conv5_x),
+    with its 6-row blocks, forward 1070-1090 vs 910-920 and backward-data 1090-1110 vs 570-600.  Smaller maps fill the chip too
     badly and stay with the library."""
     return x.shape[2] * x.shape[3] >= 30 * 40
 
