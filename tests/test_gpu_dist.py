@@ -118,7 +118,7 @@ def _loss_worker(rank, world, port, out):
         from soft_contrastive_learning_amd.evaluation import retrieval
         from soft_contrastive_learning_amd.model import losses
         dev = torch.device('cuda:0')
-        b, e = 12, 32768
+        b, e = (12 if world == 2 else 24), 32768      # world 8: configs[3], global batch 192
         g = torch.Generator().manual_seed(400)
         emb_all = torch.randn(world * b, e, generator=g)
         emb_all = (emb_all / emb_all.norm(dim=1, keepdim=True)).to(dev)
@@ -148,10 +148,12 @@ def _loss_worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_loss_and_sharded_retrieval():
+@pytest.mark.parametrize('world', [2, 8])
+def test_ranks_on_one_gpu_loss_and_sharded_retrieval(world):
     """parallel.wms_loss_dp (autograd all-gather, the HIP Gram loss on the gathered batch, backward
-    for the rank's own rows) against the single-process loss on the same 24 descriptors: equal loss
-    (<= 1e-6 relative: same kernels, same inputs) and equal gradients for the own rows; and
+    for the rank's own rows) against the single-process loss on the same descriptors: equal loss
+    (<= 1e-6 relative: same kernels, same inputs) and equal gradients for the own rows — with 2
+    ranks of 12 and with 8 ranks of 24 (BASELINE.json configs[3]: global batch 192); and
     parallel.topn_l2_sharded against retrieval.topn_l2 on the unsharded references: the same index
     lists."""
     if not torch.cuda.is_available():
@@ -159,13 +161,13 @@ def test_two_ranks_on_one_gpu_loss_and_sharded_retrieval():
     ctx = mp.get_context('spawn')
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_loss_worker, args=(r, 2, port, out)) for r in range(2)]
+    procs = [ctx.Process(target=_loss_worker, args=(r, world, port, out)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(timeout=600)
         assert p.exitcode == 0
-    for rank, lerr, gerr, same_idx, derr in sorted(out.get(timeout=10) for _ in range(2)):
+    for rank, lerr, gerr, same_idx, derr in sorted(out.get(timeout=10) for _ in range(world)):
         assert lerr <= 1e-6, (rank, lerr)
         assert gerr <= 1e-6, (rank, gerr)
         assert same_idx and derr <= 1e-9, (rank, derr)
