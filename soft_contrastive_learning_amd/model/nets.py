@@ -527,8 +527,14 @@ _SIDE = {}
 
 def _wrw_maybe_async(x, gz, w, gb):
     sink = GRAD_SINK
+
+    def in_sink(t):                  # written where only the sink's consumers will read it
+        flat = sink.flat
+        return flat.data_ptr() <= t.data_ptr() < flat.data_ptr() + flat.numel() * flat.element_size()
     if not (USE_SIDE_WRW and sink is not None and hasattr(sink, 'note_stream')
-            and sink.view(w) is not None and sink.view(w).stride() == w.stride()):
+            and sink.view(w) is not None and sink.view(w).stride() == w.stride()
+            and (gb is None or in_sink(gb))):
+        # (a gradient that goes back to autograd is read on the current stream right away)
         return wrw64(x, gz, w, gb)
     dev = x.device
     side = _SIDE.get(dev)
