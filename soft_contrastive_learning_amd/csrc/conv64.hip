@@ -569,13 +569,23 @@ __global__ __launch_bounds__(64 * RG) void wrw64_reduce_kernel(const float* __re
       store_weight_grad(gw, k * sk + c * sc + (t / 3) * sh + (t % 3) * sw, s[e], gw_f32);
     }
   }
-  // bias gradient: the blocks (0, cb = 0, kb) add up the partials of their 64 channels, slab
-  // by slab in index order
-  if (gb && blockIdx.x == 0 && blk / KB == 0 && g == 1) {
+  // bias gradient: the blocks (0, cb = 0, kb) add up the partials of their 64 channels — slab
+  // groups g, g + RG, ... in parallel, the RG partial sums combined in a fixed order (one wave
+  // walking all slabs alone took 64 us of conv2_1's 70 us reduce: a dependent load per slab)
+  if (gb && blockIdx.x == 0 && blk / KB == 0) {       // block-uniform
     const int K = 64 * KB, k = 64 * (blk % KB) + j;
     float acc_b = 0.f;
-    for (int sl = 0; sl < nsplit; ++sl) acc_b += bslabs[(int64_t)sl * K + k];
-    gb[k] = acc_b;
+#pragma unroll 4
+    for (int sl = g; sl < nsplit; sl += RG) acc_b += bslabs[(int64_t)sl * K + k];
+    __syncthreads();                                   // red[] is free again
+    reinterpret_cast<float*>(red)[g * 64 + j] = acc_b;
+    __syncthreads();
+    if (g == 0) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < RG; ++q) t += reinterpret_cast<float*>(red)[q * 64 + j];
+      gb[k] = t;
+    }
   }
 }
 
