@@ -2,8 +2,8 @@
 """Headline benchmark: train-step images/sec, VGG16-NetVLAD + soft contrastive (wms) loss,
 640x480, on N MI355X (BASELINE.json metric; workload = configs[1], per-GPU batch 24).
 
-One step = VGG16 forward (hand-written HIP convolutions, bf16 channels-last; the library only
-for conv5_x forward) -> NetVLAD (HIP) -> [all-gather of the embeddings when N > 1] -> wms loss
+One step = VGG16 forward (hand-written HIP convolutions for every layer, bf16 channels-last; no
+library convolution is left in the step) -> NetVLAD (HIP) -> [all-gather of the embeddings when N > 1] -> wms loss
 forward+backward (HIP) -> NetVLAD backward (HIP) -> VGG backward (HIP) -> [bucketed gradient
 all-reduce] -> Adam update.
 Inputs are synthetic and resident in HBM before the timed region.

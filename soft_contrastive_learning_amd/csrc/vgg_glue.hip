@@ -1,7 +1,11 @@
 // Elementwise glue of the VGG16 backbone on gfx950 (channels-last activations).
 //
-// The convolutions themselves stay on PyTorch-ROCm / MIOpen (model/nets.py:27-63 use
-// tf.layers.conv2d / max_pooling2d / tf.nn.relu and TF autodiff).  Around them PyTorch
+// The reference's layers are tf.layers.conv2d / max_pooling2d / tf.nn.relu with TF autodiff
+// (model/nets.py:27-63).  In the bf16 step every convolution is an own kernel (conv64.hip,
+// convh.hip, convg.hip) that fuses most of this glue into its epilogue; the passes below serve
+// what is left (the un-pooling by window index, the bias-gradient column sums where no
+// weight-gradient kernel produces them) and the float32 / small-map mode, where the
+// convolutions run in the library.  Around library convolutions PyTorch
 // launches one kernel per elementwise op — bias add, ReLU, max-pool, their backward ops and
 // a per-channel reduction for every bias gradient — and each streams the activation map
 // (up to 943 MB at 24 x 480 x 640 x 64 bf16) through HBM again; pool backward additionally

@@ -29,7 +29,9 @@ def topn_l2(ref, query, n, idx_offset=0, score='f32', certify=True, stats=None):
     cannot prove this for — near-duplicate references around the n-th neighbour — are
     resolved by an exact float64 pass over every reference (``scl_topn_exact_filter``), so the
     index lists are exact with no assumption on the data.  ``stats`` (a dict) receives
-    ``uncertified`` = how many queries took that path."""
+    ``uncertified`` = how many queries took that path.  Descriptors wider than 256 take
+    ``_topn_wide`` (float64 nomination by library GEMM, its own certificate of the same kind;
+    ``score`` does not apply there)."""
     lib = L.load()
     if score not in SCORE_MODES:
         raise ValueError("score must be one of %s, got %r" % (sorted(SCORE_MODES), score))
@@ -44,7 +46,7 @@ def topn_l2(ref, query, n, idx_offset=0, score='f32', certify=True, stats=None):
     if n > MAX_N or n > r or n < 1:
         raise ValueError("n must be in [1, min(%d, R)], got n=%d R=%d" % (MAX_N, n, r))
     if d > 256:
-        return _topn_wide(ref, query, n, idx_offset)
+        return _topn_wide(ref, query, n, idx_offset, certify, stats)
     if d not in (32, 64, 128, 256):
         # zero-padding the feature axis leaves every distance unchanged
         pad = next(c for c in (32, 64, 128, 256) if d <= c)
@@ -107,60 +109,101 @@ def _resolve_exactly(ref, query, n, idx_offset, bad, bound, dist, idx):
             # more than _FILTER_CAP references within the n-th distance (thousands of exact
             # duplicates): plain float64 brute force for that query, in reference chunks
             qi = int(ql[k])
-            qv = query[qi].double()
-            best_d = torch.empty(0, dtype=torch.float64, device=dev)
-            best_i = torch.empty(0, dtype=torch.int64, device=dev)
-            for a in range(0, r, 65536):
-                dd = ((ref[a:a + 65536].double() - qv) ** 2).sum(1)
-                ii = torch.arange(a, a + dd.numel(), device=dev)
-                best_d, best_i = torch.cat([best_d, dd]), torch.cat([best_i, ii])
-                o2 = torch.argsort(best_d, stable=True)[:n]      # index-ascending input: ties by index
-                best_d, best_i = best_d[o2], best_i[o2]
+            best_d, best_i = _brute_force_f64(ref, query[qi], n)
             dist[qi] = best_d.sqrt()
             idx[qi] = best_i + idx_offset
 
 
-_KEEP = 32          # candidates nominated in float32 before the float64 re-rank
+_KEEP = 32          # candidates nominated per query before the exact re-rank
 
 
-def _topn_wide(ref, query, n, idx_offset):
+def _brute_force_f64(ref, qv, n, chunk=65536):
+    """Exact float64 sum((q - r)^2) of one query against every reference, best n by
+    (distance, index): the arithmetic of the tree the reference builds."""
+    dev = ref.device
+    qv = qv.double()
+    best_d = torch.empty(0, dtype=torch.float64, device=dev)
+    best_i = torch.empty(0, dtype=torch.int64, device=dev)
+    step = max(1, min(chunk, (1 << 25) // max(ref.shape[1], 1)))       # <= 256 MB of float64
+    for a in range(0, ref.shape[0], step):
+        dd = ((ref[a:a + step].double() - qv) ** 2).sum(1)
+        ii = torch.arange(a, a + dd.numel(), device=dev)
+        best_d, best_i = torch.cat([best_d, dd]), torch.cat([best_i, ii])
+        o2 = torch.argsort(best_d, stable=True)[:n]          # index-ascending input: ties by index
+        best_d, best_i = best_d[o2], best_i[o2]
+    return best_d, best_i
+
+
+def _topn_wide(ref, query, n, idx_offset, certify=True, stats=None):
     """Descriptors wider than 256 (the in-training localisation check runs the KDTree on the
-    raw 32768-d vectors, train/train.py:1181-1182; evaluation/top-n.py sweeps d up to 4096):
-    blocks of queries x references go through the exact-f32 pairwise-distance kernel
-    (``scl_pairwise_sqdist``), the best 32 per query are kept across blocks and re-ranked in
-    float64 with the direct (q - r)^2 form, like the fused kernel does for d <= 256."""
-    from ..model import losses
+    raw 32768-d vectors, train/train.py:1181-1182; evaluation/top-n.py sweeps d up to 4096).
+
+    Nomination in FLOAT64: s(q, r) = |q|^2 + |r|^2 - 2 q.r with the products from the library's
+    float64 GEMM, blocks of queries x references, the best 32 per query kept across blocks.
+    Those 32 are re-ranked with the direct float64 sum((q - r)^2) — the tree's arithmetic —
+    and ordered by (distance, index).
+
+    Certificate (no assumption on the data): every reference OUTSIDE the nominated set has
+    s >= tau (the largest nominated score), and |s - D| <= eps for the exact squared distance D
+    with eps = 2 (d + 8) 2^-53 (|q| + R_max)^2 — the standard bound gamma_d |x||y| of a
+    length-d float64 inner product in ANY summation order (so it holds for whatever blocking
+    the library GEMM uses; it does not hold for Strassen-type kernels, which rocBLAS's dgemm is
+    not), the same for the two norms, two more roundings for the sums, and a factor 2 of safety.
+    So if the n-th exact distance among the nominated is strictly below tau - eps (inflated by
+    the direct form's own 2 (d + 2) 2^-53 relative error), no outsider can reach it.  Queries
+    that fail the test — exact or 1e-11-near duplicates around the n-th neighbour, or more
+    than 32 references within eps — are resolved by ``_brute_force_f64`` over every reference.
+    ``stats['uncertified']`` counts them."""
     r, d = ref.shape
     q = query.shape[0]
-    qb_max, cap = 512, 4096
-    out_d = torch.empty((q, n), dtype=torch.float64, device=ref.device)
-    out_i = torch.empty((q, n), dtype=torch.int64, device=ref.device)
+    dev = ref.device
+    u = 2.0 ** -53
+    qb_max = 512
+    rb = max(256, min(8192, (1 << 27) // d))                  # <= 1 GB of float64 per ref block
+    out_d = torch.empty((q, n), dtype=torch.float64, device=dev)
+    out_i = torch.empty((q, n), dtype=torch.int64, device=dev)
+    rn_all = torch.cat([(ref[a:a + rb].double() ** 2).sum(1) for a in range(0, r, rb)])
+    r_max = float(rn_all.max().sqrt())
+    uncertified = 0
     for qs in range(0, q, qb_max):
-        qq = query[qs:qs + qb_max]
+        qq = query[qs:qs + qb_max].double()
         qb = qq.shape[0]
+        qn = (qq * qq).sum(1)
         cand_s, cand_i = [], []
-        for rs in range(0, r, cap - qb):
-            rr = ref[rs:rs + cap - qb]
-            d2 = losses._pairwise_squared_distances(torch.cat([qq, rr], 0)[None])[0][:qb, qb:]
+        for rs in range(0, r, rb):
+            rr = ref[rs:rs + rb].double()
+            sc = qn[:, None] + rn_all[None, rs:rs + rb] - 2.0 * (qq @ rr.T)
             k = min(_KEEP, rr.shape[0])
-            s, i = torch.topk(d2, k, dim=1, largest=False)
-            cand_s.append(s)
-            cand_i.append(i + rs)
-        s, i = torch.cat(cand_s, 1), torch.cat(cand_i, 1)
-        k = min(_KEEP, s.shape[1])
-        _, pick = torch.topk(s, k, dim=1, largest=False)
-        cand = torch.gather(i, 1, pick)                                   # [qb, k]
-        exact = torch.empty((qb, k), dtype=torch.float64, device=ref.device)
+            sv, iv = torch.topk(sc, k, dim=1, largest=False)
+            cand_s.append(sv)
+            cand_i.append(iv + rs)
+        sv, iv = torch.cat(cand_s, 1), torch.cat(cand_i, 1)
+        k = min(_KEEP, sv.shape[1])
+        top_s, pick = torch.topk(sv, k, dim=1, largest=False)
+        cand = torch.gather(iv, 1, pick)                                  # [qb, k]
+        exact = torch.empty((qb, k), dtype=torch.float64, device=dev)
         step = max(1, (1 << 25) // (k * d))                               # <= 256 MB of float64
         for a in range(0, qb, step):
-            diff = qq[a:a + step].double()[:, None, :] - ref[cand[a:a + step]].double()
+            diff = qq[a:a + step][:, None, :] - ref[cand[a:a + step]].double()
             exact[a:a + step] = (diff * diff).sum(-1)
         # order by (distance, index): stable sort by index first, then by distance
         o = torch.argsort(cand, dim=1, stable=True)
         exact, cand = torch.gather(exact, 1, o), torch.gather(cand, 1, o)
         o = torch.argsort(exact, dim=1, stable=True)[:, :n]
-        out_d[qs:qs + qb] = torch.gather(exact, 1, o).sqrt()
+        dn = torch.gather(exact, 1, o)
+        out_d[qs:qs + qb] = dn.sqrt()
         out_i[qs:qs + qb] = torch.gather(cand, 1, o) + int(idx_offset)
+        if certify and r > k:                    # (r <= 32: every reference was re-ranked)
+            tau = top_s.max(dim=1).values
+            eps = 2.0 * (d + 8) * u * (qn.sqrt() + r_max) ** 2
+            ok = dn[:, n - 1] * (1.0 + 2.0 * (d + 2) * u) < tau - eps
+            for qi in torch.nonzero(~ok).reshape(-1).tolist():
+                bd, bi = _brute_force_f64(ref, query[qs + qi], n)
+                out_d[qs + qi] = bd.sqrt()
+                out_i[qs + qi] = bi + int(idx_offset)
+                uncertified += 1
+    if stats is not None:
+        stats['uncertified'] = uncertified if certify else None
     return out_d, out_i
 
 

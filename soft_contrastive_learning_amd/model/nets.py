@@ -2,12 +2,13 @@
 
 ``vgg16Netvlad(image_batch)`` and ``vgg16(image_batch)`` keep the reference names and
 the NHWC / raw-0..255-RGB input convention (model/nets.py:7-69, :72-131).  In bf16 mode every
-VGG16 convolution pass except the conv5_x forward runs on the hand-written implicit-GEMM
-kernels of csrc/conv64.hip and csrc/convg.hip (bias / ReLU / max-pool / ReLU' fused into their
-epilogues, float32 master weights read directly, weight gradients written straight into the
-flat gradient buffer); the conv5_x forward and the whole float32 mode use the library
-(MIOpen / CK) with the fused glue passes of csrc/vgg_glue.hip.  The channel L2 norm + NetVLAD
-head (model/nets.py:66-67) is one autograd op over the kernels of csrc/netvlad.hip.
+VGG16 convolution pass (forward, backward-data, weight gradient, every layer) runs on the
+hand-written implicit-GEMM kernels of csrc/conv64.hip, csrc/convh.hip and csrc/convg.hip (bias /
+ReLU / max-pool / ReLU' fused into their epilogues, float32 master weights read directly,
+weight gradients written straight into the flat gradient buffer); only the float32 mode and
+maps below 30x40 use the library (MIOpen / CK) with the fused glue passes of
+csrc/vgg_glue.hip.  The channel L2 norm + NetVLAD head (model/nets.py:66-67) is one autograd op
+over the kernels of csrc/netvlad.hip.
 
 TF1 keeps variables in the graph scope ``vgg16_netvlad_pca``; here they live in a
 ``VGG16NetVLAD`` module.  ``state_dict_tf`` / ``load_state_dict_tf`` expose them under
@@ -171,7 +172,36 @@ def _wflag(w):
 # launch (scl_conv_pack_batch); conv64 / conv_pool_idx find them here by (storage address,
 # direction) and a version check, and fall back to packing for themselves on a miss.
 USE_PREPACK = os.environ.get('SCL_PREPACK', '1') != '0'
-_PACKED = {}     # (data_ptr, transposed) -> (weakref to the weight, _version, shape, image)
+# (data_ptr, transposed, calling thread) -> (weakref to the weight, _version, shape, image).
+# Per THREAD: the reference drives one session from three threads (train/train.py:967-975); the
+# images are rewritten by every forward pass, and a forward on the evaluation thread's stream
+# must not rewrite the images a backward-data kernel of the training thread is reading (nor land
+# its — possibly older — copy of the weights after the training thread's own repack).
+_PACKED = {}
+_PACKED_LOCK = threading.Lock()
+
+
+class _PackSlot(threading.local):
+    """Which thread's images the calling thread reads: its own, except inside a backward pass —
+    autograd runs that on an engine thread, with the slot of the thread that ran the forward
+    (saved in the node by _pack_slot(), restored by _in_slot())."""
+    slot = None
+
+
+_SLOT = _PackSlot()
+
+
+def _pack_slot():
+    return _SLOT.slot if _SLOT.slot is not None else threading.get_ident()
+
+
+@contextlib.contextmanager
+def _in_slot(slot):
+    old, _SLOT.slot = _SLOT.slot, slot
+    try:
+        yield
+    finally:
+        _SLOT.slot = old
 
 
 def prepack(weights, force=False):
@@ -183,24 +213,30 @@ def prepack(weights, force=False):
     import weakref
     lib = L.load()
     jobs, keep = [], []
-    for key in [k for k, ent in _PACKED.items() if ent[0]() is None]:
-        del _PACKED[key]                                   # the weight is gone
+    me = _pack_slot()
+    with _PACKED_LOCK:
+        alive = {t.ident for t in threading.enumerate()}
+        for key in [k for k, ent in _PACKED.items() if ent[0]() is None or k[2] not in alive]:
+            del _PACKED[key]                               # the weight, or the thread, is gone
+    # the backward directions are only ever read by a backward pass
+    directions = (False, True) if torch.is_grad_enabled() else (False,)
     for w in weights:
         if not (w.is_cuda and w.dtype in _W_DTYPES and w.dim() == 4 and tuple(w.shape[2:]) == (3, 3)):
             continue
-        for transposed in (False, True):
+        for transposed in directions:
             cin, kout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
             nbytes = lib.scl_conv_packed_bytes(cin, kout)
             if nbytes == 0:
                 continue
-            key = (w.data_ptr(), transposed)
+            key = (w.data_ptr(), transposed, me)
             ent = _PACKED.get(key)
             if (not force and ent is not None and ent[0]() is not None and ent[1] == w._version
                     and ent[2] == tuple(w.shape)):
                 continue
             buf = (ent[3] if ent is not None and ent[3].numel() == nbytes and ent[3].device == w.device
                    else torch.empty(nbytes, dtype=torch.uint8, device=w.device))
-            _PACKED[key] = (weakref.ref(w), w._version, tuple(w.shape), buf)
+            with _PACKED_LOCK:
+                _PACKED[key] = (weakref.ref(w), w._version, tuple(w.shape), buf)
             sk, sc, sh, sw = w.stride()
             jobs.append(L.PackJob(L.ptr(w), sk, sc, sh, sw, int(transposed) | _wflag(w), cin, kout,
                                   L.ptr(buf)))
@@ -216,7 +252,7 @@ def _packed_for(w, transposed):
     """The up-to-date packed image of ``w`` for this direction, or None."""
     if not USE_PREPACK:
         return None
-    ent = _PACKED.get((w.data_ptr(), bool(transposed)))
+    ent = _PACKED.get((w.data_ptr(), bool(transposed), _pack_slot()))
     if ent is None or ent[0]() is None or ent[1] != w._version or ent[2] != tuple(w.shape):
         return None
     return ent[3]
@@ -301,9 +337,13 @@ def _whole_batch_op():
     cur = torch.cuda.current_stream(sp[0].device)
     cur.wait_stream(sp[0])
     cur.wait_stream(sp[1])
+    # nothing inside splits again: a nested conv64 would otherwise launch its halves on the
+    # half-batch streams while the glue pass that follows reads the result on `cur`
+    _FWD.split = None
     try:
         yield
     finally:
+        _FWD.split = sp
         sp[0].wait_stream(cur)
         sp[1].wait_stream(cur)
 
@@ -606,6 +646,7 @@ class _ConvBiasAct(torch.autograd.Function):
     def forward(ctx, x, w, bias, relu, link_in=None, link_out=None):
         lib = L.load()
         ctx.link_in, ctx.link_out = link_in, (link_out if relu else None)
+        ctx.slot = _pack_slot()
         kind = _own_conv_kind(x, w)
         if kind == 'reg' or (kind == 'lds' and _lds_conv_pays(x, False, True)):
             y = conv64(x, w, False, bias=bias, relu=relu)         # tail fused in the epilogue
@@ -642,8 +683,9 @@ class _ConvBiasAct(torch.autograd.Function):
                                         _glue_dtype(gy), b * h * wd, c,
                                         L.ptr(gz) if mask_here else None, L.ptr(gb), L.ptr(ws),
                                         ws.numel(), L.stream_of(gy)))
-        gx, gw = _conv3x3_backward(gz, x, w, ctx.needs_input_grad[0], ctx.link_in,
-                                   gb if fold else None)
+        with _in_slot(ctx.slot):
+            gx, gw = _conv3x3_backward(gz, x, w, ctx.needs_input_grad[0], ctx.link_in,
+                                       gb if fold else None)
         return gx, _grad_ret(gw, w), _grad_ret(gb, bias), None, None, None
 
 
@@ -657,6 +699,7 @@ class _ConvBiasPoolReLU(torch.autograd.Function):
         lib = L.load()
         ctx.link_in, ctx.link_out = link_in, link_out
         ctx.by_idx = False
+        ctx.slot = _pack_slot()
         kind = _own_conv_kind(x, w)
         if USE_POOL_IDX and ((kind == 'reg' and w.shape[0] == w.shape[1])
                              or (kind == 'lds' and _lds_conv_pays(x))):
@@ -701,7 +744,8 @@ class _ConvBiasPoolReLU(torch.autograd.Function):
               ((1.375 if masked else 1.625) if ctx.by_idx else 2.5) * gz.numel() * gz.element_size())
         L.check(fn(L.ptr(ga), None if masked else L.ptr(a), L.ptr(z), _glue_dtype(a), b, h, wd, c,
                    L.ptr(gz), L.ptr(gb), L.ptr(ws), ws.numel(), L.stream_of(a)))
-        gx, gw = _conv3x3_backward(gz, x, w, ctx.needs_input_grad[0], ctx.link_in)
+        with _in_slot(ctx.slot):
+            gx, gw = _conv3x3_backward(gz, x, w, ctx.needs_input_grad[0], ctx.link_in)
         return gx, _grad_ret(gw, w), _grad_ret(gb, bias), None, None
 
 
@@ -920,9 +964,10 @@ class VGG16NetVLAD(torch.nn.Module):
         if (fuse and dt == torch.bfloat16 and USE_CONV64 and _split_fwd_wanted() and _FWD.split is None
                 and image_batch.shape[0] >= 2):
             dev = image_batch.device
-            split = _FWD_STREAMS.get(dev)
+            key = (dev, threading.get_ident())              # a pair of streams per calling thread
+            split = _FWD_STREAMS.get(key)
             if split is None:
-                split = _FWD_STREAMS[dev] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+                split = _FWD_STREAMS[key] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
             cur = torch.cuda.current_stream(dev)
             split[0].wait_stream(cur)
             split[1].wait_stream(cur)

@@ -203,13 +203,15 @@ class GradBuckets:
 
     def zero(self):
         """Zero all gradients in one memset and re-arm the buckets."""
+        # join first: if finish() was skipped (an exception, a dropped step after backward) side
+        # stream kernels may still be writing gradients into the flat buffer, and their late
+        # writes would survive the memset into the next step
+        self._join_streams()
+        self._keep = []
         self.flat.zero_()
         self._remaining = [len(m) for m in self._members]
         self._reported = {}
         self._handles = []
-        if self._keep:                     # finish() was skipped: join before releasing
-            self._join_streams()
-            self._keep = []
 
     def finish(self):
         """Wait for the collectives launched during backward (call before optimizer.step)."""

@@ -178,6 +178,13 @@ def load_images_pil(paths, height=240):
     return np.stack(out)
 
 
+class _WorkerError:
+    """An exception raised in a pipeline worker, on its way to the consumer."""
+
+    def __init__(self, exc):
+        self.exc = exc
+
+
 class InputPipeline:
     """TRAIN_CPU_IN_QUEUE -> train_cpu_thread -> TRAIN_GPU_IN_QUEUE (train/train.py:226-260).
 
@@ -222,6 +229,11 @@ class InputPipeline:
                         self.dropped += 1
                     if self.emit_dropped:
                         self.gpu_in.put(None, block=True)
+            except BaseException as exc:              # noqa: BLE001 (handed to the consumer)
+                # a failing sampler / image loader (missing or corrupt file) must not leave the
+                # consumer blocked in get() for ever: the exception travels through the queue in
+                # the batch's place and get() re-raises it in the training thread
+                self.gpu_in.put(_WorkerError(exc), block=True)
             finally:
                 self.cpu_in.task_done()
 
@@ -229,8 +241,22 @@ class InputPipeline:
         self.cpu_in.put(list(anchor_indices))
 
     def get(self, timeout=None):
-        item = self.gpu_in.get(timeout=timeout)
+        """Next batch (None for a dropped one with ``emit_dropped``).  Re-raises, in the calling
+        thread, whatever the worker raised while preparing it; with no ``timeout`` the wait
+        still wakes up once a second and fails if every worker thread has died."""
+        while True:
+            try:
+                item = self.gpu_in.get(timeout=1.0 if timeout is None else timeout)
+                break
+            except queue.Empty:
+                if timeout is not None:
+                    raise
+                if not any(t.is_alive() for t in self._threads):
+                    raise RuntimeError('InputPipeline: all worker threads have exited and the '
+                                       'queue is empty')
         self.gpu_in.task_done()
+        if isinstance(item, _WorkerError):
+            raise RuntimeError('InputPipeline worker failed: %r' % (item.exc,)) from item.exc
         return item
 
     def join(self):

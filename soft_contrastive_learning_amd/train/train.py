@@ -295,6 +295,9 @@ def train_dataset_epoch(flags, epoch, state, log):
         np.arange(0, len(local_ref), max(flags.train_ref_r, 1)))
     if flags.steps > 0:
         anchors = anchors[:flags.steps * t]
+    # whole batches only: compute_loss / batch_distances reshape with tuples_per_batch, a short
+    # tail batch would raise at the end of the epoch, before the epoch checkpoint is written
+    anchors = anchors[:(len(anchors) // t) * t]
     lr = get_learning_rate(epoch, flags)
     for g in opt.param_groups:
         g['lr'] = lr
@@ -421,9 +424,11 @@ def main(argv=None):
         def write(rec):
             log.write(json.dumps(rec) + '\n')
             log.flush()
-        for epoch in range(flags.max_epoch):
-            train_dataset_epoch(flags, epoch, state, write)
-        nets.GRAD_SINK = None
+        try:
+            for epoch in range(flags.max_epoch):
+                train_dataset_epoch(flags, epoch, state, write)
+        finally:
+            nets.GRAD_SINK = None        # also after an exception: the sink outlives nothing
         return state
 
     for epoch in range(flags.max_epoch):

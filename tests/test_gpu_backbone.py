@@ -649,7 +649,7 @@ def test_prepacked_weight_images_equal_self_packing(dev):
         assert nets.prepack(many) == 36
         ref = nets.conv64(x[:, :64].contiguous(memory_format=cl), many[17], False) if cin >= 64 else None
         if ref is not None:
-            nets._PACKED.pop((many[17].data_ptr(), False))
+            nets._PACKED.pop((many[17].data_ptr(), False, nets._pack_slot()))
             assert torch.equal(ref, nets.conv64(x[:, :64].contiguous(memory_format=cl), many[17], False))
         assert nets._packed_for(wt, False) is not None and nets._packed_for(wt, True) is not None
         packed = run_all()

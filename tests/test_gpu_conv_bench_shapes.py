@@ -1,0 +1,226 @@
+"""Parity of the convolution kernels AT THE LAUNCH SHAPES OF THE BENCH STEP (configs[1]: 24 images,
+640x480): one test per VGG16 layer (model/nets.py:27-63), batch 24 at the layer's resolution,
+through exactly the dispatch ``VGG16NetVLAD.features`` takes in the timed step — float32 master
+weights, packed weight images written by one ``scl_conv_pack_batch`` launch, persistent grids
+(3.75 tile rounds per workgroup, XCD tile order, next-tile prefetch under the epilogue), the
+pooling epilogue with its one-byte window index, the ReLU' mask in the backward-data epilogue,
+weight AND bias gradient from the weight-gradient kernel on the second stream, written straight
+into the gradient sink (split grids, 16-slab-group reduce).
+
+Reference: float32 ``torch`` convolutions ON THE SAME bf16 INPUTS (bf16-rounded weights,
+activations and incoming gradient), evaluated a few images at a time.  Gate: max-abs error
+<= 6e-3 of the reference's scale — the gate the toy shapes of tests/test_gpu_backbone.py use
+(bf16 output rounding is 2e-3 of a value).  A wrong tile anywhere in the step's launches is an
+O(1) relative error on thousands of elements and fails.
+
+Two decision points are taken FROM the kernel's own output and validated separately, because an
+accumulation-order difference of 1e-6 can legitimately flip them and each flip moves a whole
+gradient term: the ReLU mask [y > 0] (y is checked against the reference), and the position of
+a window's maximum (checked to point at an element within 1e-4 of the reference window's
+maximum).  Given those, every backward pass is LINEAR in its inputs and is compared exactly
+like the forward.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+B = 24
+CL = torch.channels_last
+GATE = 6e-3
+
+# (name, cin, cout, H, W of the layer's input, ReLU directly after, pool after) at 640x480
+LAYERS = [
+    ('1_2', 64, 64, 480, 640, False, True),
+    ('2_1', 64, 128, 240, 320, True, False),
+    ('2_2', 128, 128, 240, 320, False, True),
+    ('3_1', 128, 256, 120, 160, True, False),
+    ('3_2', 256, 256, 120, 160, True, False),
+    ('3_3', 256, 256, 120, 160, False, True),
+    ('4_1', 256, 512, 60, 80, True, False),
+    ('4_2', 512, 512, 60, 80, True, False),
+    ('4_3', 512, 512, 60, 80, False, True),
+    ('5_1', 512, 512, 30, 40, True, False),
+    ('5_2', 512, 512, 30, 40, True, False),
+    ('5_3', 512, 512, 30, 40, False, False),
+]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    torch.backends.cudnn.benchmark = False
+    return torch.device("cuda:0")
+
+
+@pytest.fixture
+def sink():
+    """Installs a gradient sink over the layer's parameters like bench.py / train.py do."""
+    from soft_contrastive_learning_amd import parallel
+    from soft_contrastive_learning_amd.model import nets
+    made = []
+
+    def make(params):
+        b = parallel.GradBuckets(params)
+        nets.GRAD_SINK = b
+        made.append(b)
+        return b
+    yield make
+    nets.GRAD_SINK = None
+
+
+@pytest.fixture
+def takes():
+    """Records whether each _GradLink.take() of the test found the marked buffer."""
+    from soft_contrastive_learning_amd.model import nets
+    hits, orig = [], nets._GradLink.take
+
+    def counting(self, gy):
+        hit = orig(self, gy)
+        hits.append(hit)
+        return hit
+    nets._GradLink.take = counting
+    yield hits
+    nets._GradLink.take = orig
+
+
+def _maxerr(got, want):
+    """max |got - want| / max |want| evaluated in image chunks (float32 copies stay small)."""
+    err, scale = 0.0, 0.0
+    for lo in range(0, got.shape[0], 4):
+        g, w = got[lo:lo + 4].float(), want[lo:lo + 4].float()
+        err = max(err, float((g - w).abs().max()))
+        scale = max(scale, float(w.abs().max()))
+    return err / max(scale, 1e-30), scale
+
+
+def _ref_conv(x, wq, chunk=4):
+    """float32 conv2d of bf16 x with the bf16-rounded weights, as a float32 NCHW tensor."""
+    return torch.cat([F.conv2d(x[lo:lo + chunk].float(), wq, padding=1)
+                      for lo in range(0, x.shape[0], chunk)], 0)
+
+
+def _ref_backward(x, gz, wq, chunk=4):
+    """(gx float32, gw float32) of conv2d(x, wq) for the upstream gradient gz (bf16)."""
+    gx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    gw = torch.zeros(wq.shape, dtype=torch.float64, device=x.device)
+    for lo in range(0, x.shape[0], chunk):
+        g = gz[lo:lo + chunk].float()
+        gx[lo:lo + chunk] = F.conv_transpose2d(g, wq, padding=1)
+        gw += torch.nn.grad.conv2d_weight(x[lo:lo + chunk].float(), wq.shape, g, padding=1).double()
+    return gx, gw.float()
+
+
+@pytest.mark.parametrize('layer', LAYERS, ids=[l[0] for l in LAYERS])
+def test_layer_at_bench_shape(dev, sink, takes, layer):
+    from soft_contrastive_learning_amd.model import nets
+    name, cin, cout, h, w, relu, pool = layer
+    assert nets.USE_PREPACK and nets.USE_SIDE_WRW and nets.USE_POOL_IDX and nets.USE_MASKED_BWD
+    g = torch.Generator().manual_seed(1000 + 17 * cin + cout + h)
+    # a post-ReLU input (about half of it exactly zero, like the step's activations)
+    x = torch.relu(torch.randn(B, cin, h, w, generator=g)).to(dev).bfloat16().contiguous(memory_format=CL)
+    x.requires_grad_(True)
+    wt = torch.nn.Parameter((torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5).to(dev))
+    bias = torch.nn.Parameter((torch.randn(cout, generator=g) * 0.1).to(dev))
+    wq = wt.detach().bfloat16().float()                     # what the packed image holds
+    buckets = sink([wt, bias])
+    assert nets.prepack([wt], force=True) == 2                # both directions, one launch
+    link_in, link_out = nets._GradLink(), nets._GradLink()
+    if pool:
+        y = nets._ConvBiasPoolReLU.apply(x, wt, bias, link_in, link_out)
+    else:
+        y = nets._ConvBiasAct.apply(x, wt, bias, relu, link_in, link_out if relu else None)
+    z32 = _ref_conv(x.detach(), wq) + bias.detach()[None, :, None, None]
+    zscale = float(z32.abs().max())
+    if pool:
+        assert y.grad_fn.by_idx                               # the index epilogue, no full-size z
+        assert tuple(y.shape) == (B, cout, h // 2, w // 2)
+        idx = y.grad_fn.saved_tensors[2]
+        want = torch.relu(F.max_pool2d(z32, 2))
+        err, _ = _maxerr(y.detach(), want)
+        assert err * float(want.abs().max()) < GATE * zscale, (name, 'pooled forward', err)
+        # every stored position points at (numerically) a maximum of its window
+        win = torch.stack([z32[:, :, dy::2, dx::2] for dy in (0, 1) for dx in (0, 1)], -1)
+        assert int(idx.max()) <= 3
+        picked = torch.gather(win, -1, idx.long()[..., None])[..., 0]
+        assert float((win.max(-1).values - picked).max()) <= 1e-4 * zscale, (name, 'pool index')
+        del win, picked
+    else:
+        want = torch.relu(z32) if relu else z32
+        err, _ = _maxerr(y.detach(), want)
+        assert err < GATE, (name, 'forward', err)
+    del z32, want
+
+    # incoming gradient, masked by THIS layer's ReLU' the way the layer above hands it down
+    gy = torch.randn(y.shape, generator=g).to(dev).bfloat16().contiguous(memory_format=CL)
+    if relu or pool:
+        gy = torch.where(y.detach() > 0, gy, torch.zeros_like(gy)).contiguous(memory_format=CL)
+        link_out.mark(gy)
+    buckets.zero()
+    y.backward(gy)
+    buckets.finish()
+    torch.cuda.synchronize()
+    if relu or pool:     # the layer found its gradient already masked: bias gradient from wrw64
+        assert takes == [True], "the layer did not take the masked gradient (autograd copied it?)"
+    assert link_in.ptr is not None                            # ReLU' of the layer below applied
+
+    if pool:   # un-pool by the kernel's own (validated) index: exact routing
+        gz = torch.zeros(B, cout, h, w, dtype=torch.bfloat16, device=dev).contiguous(memory_format=CL)
+        for k in range(4):
+            gz[:, :, (k >> 1)::2, (k & 1)::2] = torch.where(idx == k, gy, torch.zeros_like(gy))
+    else:
+        gz = gy
+    gx_ref, gw_ref = _ref_backward(x.detach(), gz, wq)
+    gx_ref = torch.where(x.detach() > 0, gx_ref, torch.zeros_like(gx_ref))
+    err, _ = _maxerr(x.grad, gx_ref)
+    assert err < GATE, (name, 'masked backward-data', err)
+    assert wt.grad.data_ptr() == buckets.view(wt).data_ptr()  # written into the sink
+    err = float((wt.grad - gw_ref).abs().max() / gw_ref.abs().max())
+    assert err < GATE, (name, 'weight gradient', err)
+    gb_ref = torch.stack([gz[lo:lo + 4].float().sum(dim=(0, 2, 3)) for lo in range(0, B, 4)]).sum(0)
+    gb_scale = float(torch.stack([gz[lo:lo + 4].float().abs().sum(dim=(0, 2, 3))
+                                  for lo in range(0, B, 4)]).sum(0).max())
+    assert float((bias.grad - gb_ref).abs().max()) < 1e-4 * gb_scale, (name, 'bias gradient')
+
+
+def test_first_layer_at_bench_shape(dev, sink, takes):
+    """conv1_1: mean subtraction + cast + convolution + bias + ReLU in one kernel; weight, bias and
+    mean gradient from one pass over the incoming gradient (model/nets.py:22-24, :39)."""
+    from soft_contrastive_learning_amd.model import nets
+    h, w = 480, 640
+    g = torch.Generator().manual_seed(77)
+    img = torch.randint(0, 256, (B, h, w, 3), generator=g).float().to(dev)
+    avg = torch.nn.Parameter(torch.tensor([123.68, 116.78, 103.94], device=dev))
+    wt = torch.nn.Parameter((torch.randn(64, 3, 3, 3, generator=g) * (2.0 / 27) ** 0.5).to(dev))
+    bias = torch.nn.Parameter((torch.randn(64, generator=g) * 0.1).to(dev))
+    wq = wt.detach().bfloat16().float()
+    buckets = sink([avg, wt, bias])
+    link_out = nets._GradLink()
+    y = nets._FirstConv.apply(img, avg, wt, bias, torch.bfloat16, link_out)
+    x0 = (img - avg.detach()).bfloat16().permute(0, 3, 1, 2)
+    want = torch.relu(_ref_conv(x0, wq) + bias.detach()[None, :, None, None])
+    err, _ = _maxerr(y.detach(), want)
+    assert err < GATE, ('forward', err)
+    del want
+    gy = torch.randn(y.shape, generator=g).to(dev).bfloat16().contiguous(memory_format=CL)
+    gy = torch.where(y.detach() > 0, gy, torch.zeros_like(gy)).contiguous(memory_format=CL)
+    link_out.mark(gy)
+    buckets.zero()
+    y.backward(gy)
+    buckets.finish()
+    torch.cuda.synchronize()
+    assert takes == [True]
+    gx_ref, gw_ref = _ref_backward(x0, gy, wq)
+    err = float((wt.grad - gw_ref).abs().max() / gw_ref.abs().max())
+    assert err < GATE, ('weight gradient', err)
+    gb_ref = torch.stack([gy[lo:lo + 4].float().sum(dim=(0, 2, 3)) for lo in range(0, B, 4)]).sum(0)
+    gb_scale = float(torch.stack([gy[lo:lo + 4].float().abs().sum(dim=(0, 2, 3))
+                                  for lo in range(0, B, 4)]).sum(0).max())
+    assert float((bias.grad - gb_ref).abs().max()) < 1e-4 * gb_scale
+    # d loss / d average_rgb = - the spatial sum of the first layer's input gradient (the kernel
+    # takes the closed form of nets.avg_rgb_grad with the same bf16-rounded weights): a sum of
+    # 7.4 M signed terms per channel, compared at 5e-3 of its own magnitude
+    davg_ref = -torch.stack([gx_ref[lo:lo + 4].double().sum(dim=(0, 2, 3)) for lo in range(0, B, 4)]).sum(0)
+    scale = float(davg_ref.abs().max())
+    assert float((avg.grad.double() - davg_ref).abs().max()) < 5e-3 * scale + 1e-2

@@ -162,3 +162,35 @@ def test_input_pipeline_feeds_batches_and_tracks_used_images():
         assert img[:, 0, 0, 0].tolist() == idx.tolist()
     assert pipe.used_images == set(int(i) for g in got for i in g[2])
     assert pipe.dropped == 0
+
+
+def test_input_pipeline_hands_worker_failures_to_the_consumer():
+    """A failing image loader (missing / corrupt file on the dataset route) must surface in the
+    training thread's get() — with emit_dropped the loop counts on one get() per put(), so a
+    worker that died silently left it blocked for ever."""
+    import pytest
+    xy, yaw = route()
+    s = S.TupleSampler(xy, yaw, 3, 4, distance_type='wms', rng=np.random.RandomState(8))
+    calls = []
+
+    def load(indices):
+        calls.append(len(indices))
+        if len(calls) == 2:
+            raise FileNotFoundError('frame 000123.png')
+        return np.zeros((len(indices), 4, 4, 3), np.float32)
+
+    pipe = S.InputPipeline(s, load, [1, 3, 4], use_hard_negatives=False, depth=2, emit_dropped=True)
+    try:
+        for a in (10, 20, 30):
+            pipe.put([a])
+        assert pipe.get(timeout=20) is not None
+        with pytest.raises(RuntimeError, match='000123') as info:
+            pipe.get(timeout=20)
+        assert isinstance(info.value.__cause__, FileNotFoundError)
+        assert pipe.get(timeout=20) is not None            # the worker lives on: one get per put
+        pipe.join()
+    finally:
+        pipe.close()
+    # with every worker gone an un-timed get() fails instead of blocking for ever
+    with pytest.raises(RuntimeError, match='worker threads have exited'):
+        pipe.get()

@@ -51,3 +51,29 @@ def retrieval_sets(r, q, d, seed_r=11, seed_q=12):
     ref = np.random.default_rng(seed_r).standard_normal((r, d)).astype(F32)
     qry = np.random.default_rng(seed_q).standard_normal((q, d)).astype(F32)
     return ref, qry
+
+
+def pose_images(b, h, w, seed=42):
+    """[B,H,W,3] float32 in 0..255 whose CONTENT differs from image to image (oriented
+    sinusoidal textures of image-specific frequency and colour, a few flat rectangles, light
+    noise) — uniform-noise images all have the same statistics and give a random-init VGG16
+    nearly parallel descriptors (cosine > 0.99), which turns every loss gradient into a
+    difference of almost equal terms.  Cheap stand-in for 'pose-correlated' camera frames."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.meshgrid(np.arange(h, dtype=F32) / h, np.arange(w, dtype=F32) / w, indexing='ij')
+    out = np.empty((b, h, w, 3), F32)
+    for i in range(b):
+        img = np.full((h, w, 3), 127.5, F32) + rng.uniform(-60, 60, size=3).astype(F32)
+        for _ in range(3):
+            th = rng.uniform(0, np.pi)
+            fr = rng.uniform(2.0, 60.0)
+            ph = rng.uniform(0, 2 * np.pi)
+            wave = np.sin(2 * np.pi * fr * (np.cos(th) * xx + np.sin(th) * yy) + ph).astype(F32)
+            img += wave[:, :, None] * rng.uniform(-50, 50, size=3).astype(F32)
+        for _ in range(4):
+            y0, x0 = int(rng.integers(0, h - 8)), int(rng.integers(0, w - 8))
+            y1, x1 = int(rng.integers(y0 + 4, h + 1)), int(rng.integers(x0 + 4, w + 1))
+            img[y0:y1, x0:x1] = 0.5 * img[y0:y1, x0:x1] + rng.uniform(0, 128, size=3).astype(F32)
+        img += rng.normal(0, 6.0, size=(h, w, 3)).astype(F32)
+        out[i] = np.clip(np.rint(img), 0, 255)
+    return out
