@@ -15,9 +15,10 @@
  *   - every pointer is a DEVICE pointer into caller-owned memory (HBM); the
  *     library allocates nothing and the compute entry points keep no state between calls,
  *     so they are re-entrant (the reference drives one session from three threads,
- *     train/train.py:967-975).  Two PROCESS-WIDE diagnostic switches exist and are off by
- *     default: the ablation selector of scl_debug_set_variant and the timing sink of
- *     scl_prof_begin / scl_prof_end (see "Diagnostics" at the end);
+ *     train/train.py:967-975).  Three PROCESS-WIDE switches exist, none of which changes a
+ *     result: the ablation selector of scl_debug_set_variant and the timing sink of
+ *     scl_prof_begin / scl_prof_end (diagnostics, off by default) and the number of CUs the
+ *     persistent grids leave free, scl_set_reserve_cus (see "Diagnostics" at the end);
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and
  *     no entry point synchronises;
  *   - every function returns 0 on success, a negative SCL_E_* code for a rejected
@@ -36,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SCL_ABI_VERSION 4
+#define SCL_ABI_VERSION 5
 
 /* error codes (negative = rejected before any launch) */
 #define SCL_OK 0
@@ -449,6 +450,11 @@ int scl_conv_pack_batch(const SclPackJob* jobs, int njobs, void* stream);
  *   60000 + bits  register-weights convolution: bit 0 no window staging after the first
  *                 tile, bit 1 no output stores */
 int scl_debug_set_variant(int variant);
+/* CUs the persistent convolution grids leave free for other kernels (RCCL's, with more than one
+ * rank per node: DESIGN.md section 4).  Default: the environment variable SCL_RESERVE_CUS, or 0.
+ * Process-wide; takes effect at the next launch; returns the previous value; a negative n
+ * re-reads the environment.  Results do not depend on it (fixed-order reductions). */
+int scl_set_reserve_cus(int n);
 int scl_prof_begin(int capacity);
 int scl_prof_count(void);
 int scl_prof_end(float* ms, const char** names, int capacity);

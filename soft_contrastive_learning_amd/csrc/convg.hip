@@ -389,15 +389,14 @@ extern "C" size_t scl_convg_workspace_bytes(int cin, int kout) {
 }
 
 static int convg_cus() {
-  static int n = 0;
+  static int n = 0;                            // the hardware's count; the reserve may change
   if (n == 0) {
     int dev = 0, c = 0;
     n = (hipGetDevice(&dev) == hipSuccess &&
          hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0)
             ? c : 256;
-    n = scl_usable_cus(n);
   }
-  return n;
+  return scl_usable_cus(n);
 }
 
 // Same contract as scl_conv3x3_fused / scl_conv3x3_masked (include/scl_hip.h) without the

@@ -500,15 +500,14 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
 }
 
 int convh_cus() {
-  static int n = 0;
+  static int n = 0;                            // the hardware's count; the reserve may change
   if (n == 0) {
     int dev = 0, c = 0;
     n = (hipGetDevice(&dev) == hipSuccess &&
          hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0)
             ? c : 256;
-    n = scl_usable_cus(n);
   }
-  return n;
+  return scl_usable_cus(n);
 }
 
 }  // namespace

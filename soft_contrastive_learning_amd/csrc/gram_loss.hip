@@ -1233,7 +1233,7 @@ void launch_gram16x6(int T, int P, const float* emb, int64_t ld, int B, int E, f
                               hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
   });
   const size_t lds = (size_t)3 * 8 * (16 * T + 1) * 16;
-  SCL_LAUNCH("gram16_kernel", (gram16x6_kernel<PWMAX, 2, DUAL>), dim3(E / 128), dim3(256), lds, st, emb,
+  SCL_LAUNCH("gram16x6_kernel", (gram16x6_kernel<PWMAX, 2, DUAL>), dim3(E / 128), dim3(256), lds, st, emb,
              ld, B, E, T, P, slabs);
 }
 
@@ -1322,7 +1322,7 @@ extern "C" int scl_gram_loss_fwd(const float* emb, int64_t ld_emb, int B, int E,
                (const float*)w.slabs, p.S, p.T, p.P, B, w.gfull);
     const dim3 rg((B + 3) / 4);
 #define SCL_ROWS(C)                                                                          \
-  SCL_LAUNCH("gram_rows_kernel", gram_rows_wave_kernel<C>, rg, dim3(256), 0, st,             \
+  SCL_LAUNCH("gram_rows_wave_kernel", gram_rows_wave_kernel<C>, rg, dim3(256), 0, st,             \
              (const float*)w.gfull, B, distances, labels, lp, w.gn, w.gc, w.rn, w.rowloss)
     if (B <= 64)
       SCL_ROWS(1);
@@ -1355,7 +1355,7 @@ extern "C" int scl_gram_loss_bwd(const float* emb, int64_t ld_emb, int B, int E,
   if (B < 1 || E < 1 || ld_emb < E || ld_grad < E) return SCL_E_SHAPE;
   if (row_begin < 0 || row_count < 1 || row_begin + row_count > B || B > kMaxB) return SCL_E_SHAPE;
   if (B <= 32) {
-    SCL_LAUNCH("gram_bwd_kernel", gram_bwd32_kernel, dim3((E + 127) / 128), dim3(256), 0,
+    SCL_LAUNCH("gram_bwd32_kernel", gram_bwd32_kernel, dim3((E + 127) / 128), dim3(256), 0,
                (hipStream_t)stream, emb, ld_emb, B, E, coef, grad_loss, row_begin, row_count,
                grad_emb, ld_grad);
     return scl_launch_status();
@@ -1382,11 +1382,11 @@ extern "C" int scl_gram_loss_bwd(const float* emb, int64_t ld_emb, int B, int E,
       const long w4 = (long)(E / 128) * rt, w2 = 2 * w4;
       const long r4 = (w4 + 1023) / 1024 * 2, r2 = (w2 + 1023) / 1024;   // time in 64-column units
       if (r2 < r4)
-        SCL_LAUNCH("gram_bwd_kernel", gram_bwd_fast_kernel<2>, dim3(E / 256, rt), dim3(256), ldsf,
+        SCL_LAUNCH("gram_bwd_fast_kernel<2>", gram_bwd_fast_kernel<2>, dim3(E / 256, rt), dim3(256), ldsf,
                    (hipStream_t)stream, emb, ld_emb, B, E, coef, grad_loss, row_begin, row_count,
                    grad_emb, ld_grad);
       else
-        SCL_LAUNCH("gram_bwd_kernel", gram_bwd_fast_kernel<4>, dim3(E / 512, rt), dim3(256), ldsf,
+        SCL_LAUNCH("gram_bwd_fast_kernel<4>", gram_bwd_fast_kernel<4>, dim3(E / 512, rt), dim3(256), ldsf,
                    (hipStream_t)stream, emb, ld_emb, B, E, coef, grad_loss, row_begin, row_count,
                    grad_emb, ld_grad);
       return scl_launch_status();

@@ -24,6 +24,14 @@ extern "C" int scl_debug_set_variant(int v) {
   return old;
 }
 
+// ---- CUs left free by the persistent convolution grids (scl_usable_cus in scl_common.h) ----
+volatile int scl_reserve_cus = -1;
+extern "C" int scl_set_reserve_cus(int n) {
+  const int old = scl_reserve_cus;
+  scl_reserve_cus = n < 0 ? -1 : n;          // negative: read SCL_RESERVE_CUS again
+  return old < 0 ? 0 : old;
+}
+
 // ---- per-kernel timing sink (diagnostics; see SCL_LAUNCH in scl_common.h) ---------------
 SclProfSink* volatile scl_prof_sink = nullptr;
 

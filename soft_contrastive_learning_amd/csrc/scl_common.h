@@ -222,15 +222,18 @@ int scl_convh_dispatch(const void* x, const void* w, int64_t w_stride_k, int64_t
                        int cin, int kout, void* out, const float* bias, int relu, const void* mask,
                        void* pidx, void* workspace, int dv, void* stream);
 
-// CUs the persistent convolution grids leave free (SCL_RESERVE_CUS, default 0).  With more than one
-// rank the RCCL kernels need somewhere to run while those grids hold every CU;
-// the knob exists so that this can be measured on a multi-GPU node without a rebuild.
+// CUs the persistent convolution grids leave free (SCL_RESERVE_CUS, default 0; or
+// scl_set_reserve_cus).  With more than one rank the RCCL kernels need somewhere to run while
+// those grids hold every CU; the knob exists so that this can be measured
+// on a multi-GPU node without a rebuild — bench.py times a few steps each way in-process.
+extern volatile int scl_reserve_cus;   // -1 until first read from the environment
 static inline int scl_usable_cus(int cus) {
-  static int reserve = -1;
+  int reserve = scl_reserve_cus;
   if (reserve < 0) {
     const char* e = getenv("SCL_RESERVE_CUS");
     reserve = e ? atoi(e) : 0;
     if (reserve < 0) reserve = 0;
+    scl_reserve_cus = reserve;
   }
   const int left = cus - reserve;
   return left >= 8 ? left : (cus < 8 ? cus : 8);

@@ -641,7 +641,7 @@ void launch_scan(const TopnPlan& p, const void* ref, const void* ref_lo, const f
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)scan_lds_bytes(D8 * 8, BF));
   });
-  SCL_LAUNCH(BF ? "topn_scan_bf16x3_kernel" : "topn_scan_kernel", (topn_scan_kernel<D8, BF>),
+  SCL_LAUNCH(BF ? "topn_scan_kernel<BF=1>" : "topn_scan_kernel<BF=0>", (topn_scan_kernel<D8, BF>),
              dim3(p.qtiles, p.splits), dim3(256), scan_lds_bytes(D8 * 8, BF), st, ref, ref_lo,
              refnorm, R, query, Q, p.refs_per_split,
              scl_debug_variant < 8000 ? scl_debug_variant / 1000 : 0, cs, ci);

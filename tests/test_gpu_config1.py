@@ -133,8 +133,8 @@ def test_config1_head_matches_oracle_on_the_hip_conv5_3_map(config1, mode):
 
 
 def test_config1_head_gradient_on_spread_descriptors(dev):
-    """The full-size bf16 step on images whose content differs (tests/util_data.pose_images), so
-    that the 24 descriptors spread out: descriptors and loss within 1e-4 of the oracle on the HIP
+    """The full-size bf16 step on images whose content differs (tests/util_data.pose_images) and
+    sharp VLAD assignments, so that the 24 descriptors spread out: descriptors and loss within 1e-4 of the oracle on the HIP
     conv5_3 map, and d loss / d embeddings within 2e-4 (norm-relative) of the float64 twin — the
     bound tests/test_gpu_losses.py holds on its synthetic embeddings."""
     from soft_contrastive_learning_amd import parallel
@@ -143,6 +143,15 @@ def test_config1_head_gradient_on_spread_descriptors(dev):
     img = torch.tensor(U.pose_images(b, h, w, seed=42), device=dev)
     dmat = U.positions_distances(b, side=200.0, seed=7)
     model = nets.VGG16NetVLAD(compute_dtype=torch.bfloat16, seed=1234).to(dev)
+    # A random-init VGG16 maps ANY image to nearly the same mean direction (|mean xhat| = 0.93,
+    # cosine 0.97-0.99 between images: measured), and with the near-uniform soft-assignment of
+    # random-init VLAD variables every descriptor is that mean + the same centres.  Sharp
+    # assignments and small centres — what a trained NetVLAD has — let the per-cluster residual
+    # sums, which do differ between images, through: median cosine 0.83 instead of 0.99.
+    w, c = U.vlad_params(logit_scale=10.0)
+    with torch.no_grad():
+        model.assignment_kernel.copy_(torch.tensor(w).reshape(1, 1, 512, 64))
+        model.cluster_centers.copy_(torch.tensor(0.1 * c).reshape(1, 1, 1, 512, 64))
     buckets = parallel.GradBuckets(list(model.parameters()))
     nets.GRAD_SINK = buckets
     try:
@@ -161,7 +170,7 @@ def test_config1_head_gradient_on_spread_descriptors(dev):
     off = sim[~np.eye(b, dtype=bool)]
     print('descriptor cosine similarities: min %.3f median %.3f max %.3f'
           % (off.min(), np.median(off), off.max()))
-    assert np.median(off) < 0.97, 'the synthetic images no longer spread the descriptors'
+    assert np.median(off) < 0.9, 'the synthetic images no longer spread the descriptors'
     want_emb = NV.netvlad_fused(fmap.detach().float().cpu().numpy().reshape(b, -1, 512),
                                 model.assignment_kernel.detach().cpu().numpy().reshape(512, 64),
                                 model.cluster_centers.detach().cpu().numpy().reshape(512, 64))
