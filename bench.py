@@ -13,6 +13,8 @@ Inputs are synthetic and resident in HBM before the timed region.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+    python bench.py --workload retrieval --gpus N       (configs[4]: sharded exact top-25)
+
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline     live HIP-event timing of the dominant hand-written kernel (scl_prof_* sink in
                the C library), priced on its governing roofline.  The events bracket every
@@ -21,6 +23,14 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                moves them into the timed region)
   kernels      the same for every hand-written kernel on the path
   cpu_baseline the CPU restatement of the same step timed on the host cores (N=1 only)
+  roofline_netvlad_stage   the NetVLAD head as ONE stage: SURVEY §8(d)'s algorithmic bytes and
+               flops of the forward / backward divided by the SUM of its kernels' durations
+  retrieval    configs[4] on this GPU (N=1): 100 k references x 10 k queries x 256, exact top-25
+               with the certificate, both scoring modes, queries/s and the scan kernel's roofline
+  comm         (N>1) world size as the process group reports it, per-step medians of the
+               embedding all-gather and of the wait behind the last gradient all-reduce, the
+               step time with 0 and 8 CUs left free by the persistent grids
+  switches     every SCL_* environment switch and A/B flag this run was started with
 """
 import argparse
 import json
@@ -78,6 +88,18 @@ def parse():
     ap.add_argument('--variant', type=int, default=0,
                     help='DIAGNOSTICS: scl_debug_set_variant value for A/B runs of kernel variants '
                          'on one box (0 = production; anything else is not a benchmark result)')
+    ap.add_argument('--workload', default='train', choices=['train', 'retrieval'],
+                    help="train (default): the BASELINE metric's train step; retrieval: configs[4], "
+                         "exact L2 top-25 of 10 k queries in 100 k references x 256, the reference "
+                         "set sharded over the ranks (evaluation/top-n.py:103-106)")
+    ap.add_argument('--refs', type=int, default=100000, help='retrieval: references in total')
+    ap.add_argument('--queries', type=int, default=10000, help='retrieval: queries (replicated)')
+    ap.add_argument('--score', default='f32', choices=['f32', 'bf16x3'],
+                    help='retrieval: how candidates are nominated before the float64 re-rank')
+    ap.add_argument('--n1-ref', type=float, default=0.0,
+                    help="N>1: this workload's value measured at --gpus 1 (same box family); the line "
+                         'then carries scaling_efficiency = value / (N * n1_ref)')
+    ap.add_argument('--no-retrieval', action='store_true', help='skip the retrieval object (N=1)')
     ap.add_argument('--stub-cpu', action='store_true',
                     help='TEST ONLY: gloo on CPU with a trivial stand-in step; exercises the '
                          'launcher, the barriers and the max-over-ranks timing, measures nothing')
@@ -113,14 +135,21 @@ def kernel_models(b, n, gb, x_bytes):
         # loss: raw Gram (upper-triangular tile pairs), reads E once
         'gram_partial_kernel': dict(flops=2.0 * gb * gb * E, bytes=gb * E * 4),
         'gram16_kernel': dict(flops=2.0 * gb * gb * E, bytes=gb * E * 4),
+        # 64 < B <= 256: the same Gram from six bf16 plane products (float32-equivalent);
+        # SURVEY §8(d) prices the B = 192 Gram on the float32 MFMA peak
+        'gram16x6_kernel': dict(flops=2.0 * gb * gb * E, bytes=gb * E * 4),
         # everything after the Gram for B <= 32, one workgroup
         'gram_final32_kernel': dict(flops=48.0 * gb * gb, bytes=gb * gb * 16),
         # slab sums (split-K artefact: priced on the Gram matrix it produces)
         'gram_reduce_kernel': dict(flops=0.0, bytes=gb * gb * 4),
         'gram_rows_kernel': dict(flops=40.0 * gb * gb, bytes=gb * gb * 16),
+        'gram_rows_wave_kernel': dict(flops=40.0 * gb * gb, bytes=gb * gb * 16),
         'gram_coef_kernel': dict(flops=8.0 * gb * gb, bytes=gb * gb * 12),
         # grad_E[own rows] = M E: reads E once, writes b rows
         'gram_bwd_kernel': dict(flops=2.0 * b * gb * E, bytes=gb * E * 4 + b * E * 4),
+        'gram_bwd32_kernel': dict(flops=2.0 * b * gb * E, bytes=gb * E * 4 + b * E * 4),
+        'gram_bwd_fast_kernel<2>': dict(flops=2.0 * b * gb * E, bytes=gb * E * 4 + b * E * 4),
+        'gram_bwd_fast_kernel<4>': dict(flops=2.0 * b * gb * E, bytes=gb * E * 4 + b * E * 4),
         'transpose_w_kernel': dict(flops=0.0, bytes=D * K * 8),
         'split_w_kernel': dict(flops=0.0, bytes=D * K * 10),
     }
@@ -332,6 +361,140 @@ def cpu_baseline_kernels(threads):
     return out
 
 
+def price_topn_scan(ms, q, r, d, score):
+    """The scan kernel of csrc/topn.hip on its governing roofline: 2 Q R d algorithmic flops;
+    'f32' runs them on the float32 MFMA (157.3 TF), 'bf16x3' executes THREE bf16 products per
+    algorithmic one on the bf16 matrix cores (2.5 PF dense) — priced on what it executes."""
+    sec = ms * 1e-3
+    alg = 2.0 * q * r * d
+    if score == 'bf16x3':
+        ex = 3.0 * alg / sec / 1e12
+        return dict(bound='mfma', tflops=round(alg / sec / 1e12, 2), executed_tflops=round(ex, 2),
+                    mfma_peak_tflops=PEAK_BF16_TFLOPS, frac=round(ex / PEAK_BF16_TFLOPS, 4))
+    tf = alg / sec / 1e12
+    return dict(bound='mfma', tflops=round(tf, 2), mfma_peak_tflops=PEAK_F32_TFLOPS,
+                frac=round(tf / PEAK_F32_TFLOPS, 4))
+
+
+def retrieval_line(dev, r=100000, q=10000, d=256, n=25, iters=3):
+    """BASELINE.json configs[4] on ONE GPU (evaluation/top-n.py:103-106): exact L2 top-n with the
+    per-query exactness certificate, both scoring modes; whole-call queries/s (inputs resident in
+    HBM, the certificate's host check included) and the scan kernel priced on its roofline."""
+    from soft_contrastive_learning_amd import _lib
+    from soft_contrastive_learning_amd.evaluation import retrieval
+    from tests import util_data as U
+    ref, qry = U.retrieval_sets(r, q, d)
+    rt, qt = torch.tensor(ref, device=dev), torch.tensor(qry, device=dev)
+    out = {'workload': 'configs[4]: %d references x %d queries x %d, exact top-%d, certified' % (r, q, d, n),
+           'refs': r, 'queries': q, 'd': d, 'n': n, 'data': 'synthetic N(0,1), seeds 11 / 12'}
+    for score in ('f32', 'bf16x3'):
+        st = {}
+        retrieval.topn_l2(rt, qt, n, score=score, stats=st)
+        torch.cuda.synchronize()
+        with _lib.KernelTimer(capacity=16 * iters) as kt:
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                retrieval.topn_l2(rt, qt, n, score=score, stats=st)
+            torch.cuda.synchronize()
+            wall = (time.perf_counter() - t0) / iters
+        summ = kt.summary()
+        scan_name = 'topn_scan_kernel<BF=%d>' % (1 if score == 'bf16x3' else 0)
+        row = {'queries_per_sec': round(q / wall, 1), 'ms_per_call': round(wall * 1e3, 3),
+               'uncertified_queries': st.get('uncertified'), 'calls': iters,
+               'kernels_us': {k: round(ms * 1e3, 1) for k, (c, ms) in sorted(summ.items())}}
+        if scan_name in summ:
+            row['scan_kernel'] = dict(kernel=scan_name, us=round(summ[scan_name][1] * 1e3, 1),
+                                      **price_topn_scan(summ[scan_name][1], q, r, d, score))
+        out[score] = row
+    return out
+
+
+def _switches(args):
+    """Everything that can make this run differ from the default one: SCL_* environment
+    switches and the A/B flags of this script."""
+    sw = {k: v for k, v in sorted(os.environ.items()) if k.startswith('SCL_')}
+    for name, default in (('side_wrw', 1), ('split_fwd', 0), ('variant', 0), ('graph', 0),
+                          ('fused_relu', 1), ('miopen_find', 1)):
+        if getattr(args, name) != default:
+            sw['--' + name.replace('_', '-')] = getattr(args, name)
+    return sw
+
+
+def retrieval_main(args, world, rank, dev):
+    """--workload retrieval: configs[4] with the REFERENCE SET SHARDED over the ranks (SURVEY
+    §8e): every rank scans its rows for all (replicated) queries, the [Q, n] candidates are
+    all-gathered and merged.  One step = one call over all queries; strong scaling (the total
+    work is fixed as N grows)."""
+    from soft_contrastive_learning_amd import parallel
+    from soft_contrastive_learning_amd.evaluation import retrieval
+    from tests import util_data as U
+    r, q, d, n = args.refs, args.queries, 256, 25
+    ref, qry = U.retrieval_sets(r, q, d)
+    per = (r + world - 1) // world
+    lo = min(rank * per, r)
+    shard = torch.tensor(ref[lo:lo + per], device=dev)
+    qt = torch.tensor(qry, device=dev)
+    del ref
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(fn, k):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            out = fn()
+        fence()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t)
+        return el, out
+
+    stats = {}
+
+    def step():
+        return parallel.topn_l2_sharded(shard, qt, n, lo, score=args.score)
+
+    def local_only():
+        return retrieval.topn_l2(shard, qt, n, idx_offset=lo, score=args.score, stats=stats)
+
+    for _ in range(args.warmup):
+        step()
+    elapsed, (dd, ii) = timed(step, args.steps)
+    el_local, _ = timed(local_only, args.steps)
+    if rank == 0:
+        out = {
+            'metric': 'retrieval queries/sec (exact L2 top-%d, %d references x %d queries x %d)' % (n, r, q, d),
+            'value': round(q * args.steps / elapsed, 1), 'unit': 'queries/sec', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
+            'scaling': 'strong', 'vs_baseline': None,
+            'dtype': 'f32' if args.score == 'f32' else 'bf16x3 nomination, f64 re-rank',
+            'data': 'synthetic',
+            'config': {'workload': 'configs[4]: exact top-%d, reference set sharded over %d rank(s) '
+                                   '(%d rows each), queries replicated, [Q,n] candidates '
+                                   'all-gathered and merged' % (n, world, per),
+                       'refs': r, 'queries': q, 'd': d, 'n': n, 'score': args.score,
+                       'parallelism': 'ref-shard%d' % world},
+            'local_scan_ms_per_step': round(el_local / args.steps * 1e3, 3),
+            'exchange_and_merge_us_per_step': round((elapsed - el_local) / args.steps * 1e6, 1),
+            'uncertified_queries_local': stats.get('uncertified'),
+            'world_seen': dist.get_world_size() if world > 1 else 1,
+            'checksum_idx': int(ii.sum()),
+            'switches': _switches(args),
+        }
+        if args.n1_ref > 0:
+            out['scaling_efficiency'] = round(out['value'] / (world * args.n1_ref), 4)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def loss_b192_line(dev, iters=10):
     """configs[3]'s loss shape on one GPU: wms forward + backward at B = 192 x 32768 (what every
     rank of an 8-GPU run evaluates after the all-gather), event-timed per kernel."""
@@ -387,6 +550,8 @@ def main():
     from soft_contrastive_learning_amd import _lib, parallel
     from soft_contrastive_learning_amd.model import losses, nets
     _lib.load()
+    if args.workload == 'retrieval':
+        return retrieval_main(args, world, rank, dev)
     nets.USE_SIDE_WRW = bool(args.side_wrw) and nets.USE_SIDE_WRW
     nets.USE_SPLIT_FWD = bool(args.split_fwd)
     if args.variant:
@@ -504,6 +669,52 @@ def main():
         elapsed_prof = elapsed
     work, nets.WORK_LOG = nets.WORK_LOG, None
     loss_val = float(loss.detach())
+
+    def timed_steps(k):
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(k):
+            step()
+        fence()
+        el = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt)
+        return el / k * 1e3
+
+    comm = None
+    if world > 1:
+        # what the first multi-GPU run must be able to explain by itself
+        diag_steps = max(3, min(args.steps, 10))
+        parallel.COMM_LOG = {'allgather': [], 'finish': []}
+        ms_diag = timed_steps(diag_steps)
+        log, parallel.COMM_LOG = parallel.COMM_LOG, None
+
+        def med(pairs):
+            v = sorted(a.elapsed_time(b) * 1e3 for a, b in pairs)
+            return round(v[len(v) // 2], 1) if v else None
+        lib = _lib.load()
+        old_reserve = lib.scl_set_reserve_cus(0)
+        reserve = {}
+        for rv in (0, 8):
+            lib.scl_set_reserve_cus(rv)
+            timed_steps(2)
+            reserve[str(rv)] = round(timed_steps(diag_steps), 3)
+        lib.scl_set_reserve_cus(old_reserve)
+        comm = {'world_seen': dist.get_world_size(), 'backend': dist.get_backend(),
+                'diag_steps': diag_steps, 'ms_per_step_with_comm_events': round(ms_diag, 3),
+                'allgather_us_median': med(log['allgather']),
+                'allgather_bytes_per_rank': b * E * 4,
+                'finish_wait_us_median': med(log['finish']),
+                'allreduce_buckets': len(buckets.buckets),
+                'allreduce_bytes': int(buckets.flat.numel() * 4),
+                'ms_per_step_by_reserved_cus': reserve,
+                'reserved_cus_in_timed_region': old_reserve,
+                'how': 'device events on the compute stream around all_gather_into_tensor and '
+                       'around the waits of GradBuckets.finish() (rank 0, median over the diagnostic '
+                       'steps run after the timed region); step time with scl_set_reserve_cus(0 / 8): '
+                       'same process, max over ranks'}
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -600,8 +811,15 @@ def main():
             'kernels': kernels,
             'hip_path_ms_per_step': round(hip_ms, 3),
         }
+        out['switches'] = _switches(args)
+        if comm is not None:
+            out['comm'] = comm
+        if args.n1_ref > 0:
+            out['scaling_efficiency'] = round(out['value'] / (world * args.n1_ref), 4)
         if world == 1:
             out['roofline_loss_b192'] = loss_b192_line(dev)
+            if not args.no_retrieval:
+                out['retrieval'] = retrieval_line(dev)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args, torch.get_num_threads())
             out['cpu_baseline_kernels'] = cpu_baseline_kernels(torch.get_num_threads())

@@ -18,6 +18,22 @@ box, "gloo" in the CPU tests).  The batch shards by image:
 import torch
 import torch.distributed as dist
 
+# bench.py sets this to {'allgather': [], 'finish': []} for its diagnostic steps: pairs of device
+# events on the compute stream around the embedding all-gather and around the waits of
+# GradBuckets.finish() (how long the step sat behind the last gradient all-reduce).  None: no
+# events are recorded.
+COMM_LOG = None
+
+
+def _comm_events(kind):
+    log = COMM_LOG
+    if log is None or not torch.cuda.is_available():
+        return None
+    pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    log[kind].append(pair)
+    pair[0].record()
+    return pair
+
 
 class _AllGatherRows(torch.autograd.Function):
     """[b,E] per rank -> [world*b,E] on every rank; backward = own rows of the gradient."""
@@ -30,7 +46,10 @@ class _AllGatherRows(torch.autograd.Function):
         local = local.contiguous()
         full = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]),
                            dtype=local.dtype, device=local.device)
+        ev = _comm_events('allgather') if local.is_cuda else None
         dist.all_gather_into_tensor(full, local, group=group)
+        if ev is not None:
+            ev[1].record()
         return full
 
     @staticmethod
@@ -215,8 +234,11 @@ class GradBuckets:
 
     def finish(self):
         """Wait for the collectives launched during backward (call before optimizer.step)."""
+        ev = _comm_events('finish') if (self._handles and self.flat.is_cuda) else None
         for h in self._handles:
             h.wait()
+        if ev is not None:
+            ev[1].record()
         self._handles = []
         self._join_streams()
         self._keep = []

@@ -196,3 +196,42 @@ def test_bench_two_ranks_on_one_gpu():
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['config']['global_batch'] == 48 and d['scaling'] == 'weak'
     assert d['value'] > 0 and 0.0 < d['config']['loss'] < 100.0
+    # the line explains its own communication
+    c = d['comm']
+    assert c['world_seen'] == 2 and c['backend'] == 'gloo'
+    assert c['allgather_us_median'] > 0 and c['finish_wait_us_median'] is not None
+    assert c['allgather_bytes_per_rank'] == 24 * 32768 * 4 and c['allreduce_buckets'] >= 3
+    assert set(c['ms_per_step_by_reserved_cus']) == {'0', '8'}
+    assert all(v > 0 for v in c['ms_per_step_by_reserved_cus'].values())
+    assert d['switches'].get('SCL_BENCH_ONE_GPU_GLOO') == '1'
+    assert 'retrieval' not in d and 'cpu_baseline' not in d          # N = 1 objects
+
+
+def test_bench_retrieval_workload_two_ranks_on_one_gpu():
+    """`python bench.py --workload retrieval --gpus 2` (configs[4], reference set sharded over
+    the ranks) end to end on a one-GPU box, and the same workload at --gpus 1: same index lists
+    (checksum), queries/s reported, exchange time separated from the local scan."""
+    import json
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip('needs a HIP device')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SCL_BENCH_ONE_GPU_GLOO='1')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    recs = {}
+    for gpus in (1, 2):
+        r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--workload', 'retrieval',
+                            '--gpus', str(gpus), '--steps', '2', '--warmup', '1', '--refs', '20000',
+                            '--queries', '1000', '--n1-ref', '1000.0'], env=env, capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+        assert len(lines) == 1
+        recs[gpus] = json.loads(lines[0])
+    for gpus, d in recs.items():
+        assert d['n_gpus'] == gpus and d['unit'] == 'queries/sec' and d['scaling'] == 'strong'
+        assert d['value'] > 0 and d['world_seen'] == gpus and 'scaling_efficiency' in d
+        assert d['config']['refs'] == 20000 and d['config']['parallelism'] == 'ref-shard%d' % gpus
+    assert recs[1]['checksum_idx'] == recs[2]['checksum_idx']
