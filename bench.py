@@ -121,6 +121,22 @@ def kernel_models(b, n, gb, x_bytes):
         # x^T·(a rn); reads x and a once, writes 2 slabs per image
         'aggregate_kernel': dict(flops=2.0 * bn * D * K,
                                  bytes=bn * D * x_bytes + bn * K * 4 + b * 2 * D * K * 4, **b3),
+        # fused soft-assignment + aggregation of one (image, slice): x once; a, logits, rn and
+        # the slices' slabs out (slab count from the launch: ~10 per image at 24 x 1200)
+        'vlad_fwd_kernel<true>': dict(flops=4.0 * bn * D * K,
+                                      bytes=bn * D * x_bytes + bn * K * 8 + bn * 4 + b * 10 * D * K * 4, **b3),
+        'vlad_fwd_kernel<false>': dict(flops=4.0 * bn * D * K,
+                                       bytes=bn * D * x_bytes + b * 10 * D * K * 4, **b3),
+        # fused x.dU + softmax backward + x^T.(ds rn): x, a, logits, rn in; ds, rowdot, slabs out
+        'vlad_bwd_kernel': dict(flops=4.0 * bn * D * K,
+                                bytes=bn * D * x_bytes + bn * K * 12 + bn * 8 + b * 10 * D * K * 4
+                                + b * D * K * 6, **b3),
+        'dx16b_kernel': dict(flops=4.0 * bn * D * K, bytes=2 * bn * D * x_bytes + bn * K * 8, **b3),
+        'vlad_dx_kernel': dict(flops=4.0 * bn * D * K, bytes=2 * bn * D * x_bytes + bn * K * 8, **b3),
+        'vlad_wgrad_partial_kernel': dict(flops=b * 10.0 * D * K, bytes=b * 10 * D * K * 4),
+        'vlad_wgrad_finish_kernel': dict(flops=4.0 * b * D * K, bytes=b * D * K * 4 + 9 * D * K * 4),
+        'vlad_split_w_kernel': dict(flops=0.0, bytes=D * K * 10),
+        'vlad_finish_sum_kernel': dict(flops=6.0 * b * D * K, bytes=b * D * K * 4 * 12),
         'finish_sum_kernel': dict(flops=6.0 * b * D * K, bytes=b * D * K * 4 * 6),
         'finish_norm_kernel': dict(flops=2.0 * b * D * K, bytes=b * D * K * 4 * 2),
         'bwd_dots_kernel': dict(flops=8.0 * b * D * K, bytes=b * D * K * 4 * 2),

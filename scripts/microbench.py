@@ -42,7 +42,8 @@ def run_netvlad(dev, b, n, dtype, iters):
             nets.netvlad(x, wt, ct, True).backward(g)
         torch.cuda.synchronize()
     models = bench.kernel_models(b, n, b, 2 if dtype == torch.bfloat16 else 4)
-    return [bench.price(k, cnt, ms, models[k]) for k, (cnt, ms) in sorted(kt.summary().items())]
+    return [bench.price(k, cnt, ms, models.get(k, dict(flops=0.0, bytes=0.0)))
+            for k, (cnt, ms) in sorted(kt.summary().items())]
 
 
 def run_loss(dev, b, iters):
@@ -56,7 +57,8 @@ def run_loss(dev, b, iters):
             losses.wms_loss(dist, emb, 0.8, 15.0).backward()
         torch.cuda.synchronize()
     models = bench.kernel_models(b, 1200, b, 4)
-    rows = [bench.price(k, cnt, ms, models[k]) for k, (cnt, ms) in sorted(kt.summary().items())]
+    rows = [bench.price(k, cnt, ms, models.get(k, dict(flops=0.0, bytes=0.0)))
+            for k, (cnt, ms) in sorted(kt.summary().items())]
     for r in rows:
         r['B'] = b
     return rows
@@ -77,8 +79,7 @@ def run_topn(dev, r, q, d, n, iters, score='f32'):
     for k, (cnt, ms) in sorted(kt.summary().items()):
         row = dict(kernel=k, launches=cnt, us=round(ms * 1e3, 1))
         if k.startswith('topn_scan'):
-            tf = 2.0 * q * r * d / (ms * 1e-3) / 1e12
-            row.update(bound='mfma', tflops=round(tf, 2), frac=round(tf / bench.PEAK_F32_TFLOPS, 4))
+            row.update(bench.price_topn_scan(ms, q, r, d, score))
         out.append(row)
     out.append(dict(kernel='topn_l2 (whole call)', us=round(wall * 1e6, 1),
                     queries_per_sec=round(q / wall, 1), R=r, Q=q, d=d, n=n, score=score))

@@ -1,0 +1,73 @@
+#!/usr/bin/env python
+"""Where the fused NetVLAD forward kernel (csrc/netvlad.hip, vlad_fwd_kernel) spends its cycles:
+runs it with scl_debug_set_variant(900 + 16 [+ ablation bits]) — wave 0 of every workgroup
+writes shader-clock stamps into the tail of the workspace — and prints the median over
+workgroups of every phase, in cycles.  DIAGNOSTIC ONLY (the stamps perturb the kernel)."""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from soft_contrastive_learning_amd import _lib as L  # noqa: E402
+from tests import util_data as U  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--bits', type=int, default=0, help='ablation bits added to the stamp bit')
+    ap.add_argument('--batch', type=int, default=24)
+    ap.add_argument('--locations', type=int, default=1200)
+    args = ap.parse_args()
+    lib = L.load()
+    dev = torch.device('cuda:0')
+    b, n = args.batch, args.locations
+    x = torch.tensor(U.feature_map(b, n, seed=5), device=dev).bfloat16()
+    w, c = U.vlad_params()
+    wt, ct = torch.tensor(w, device=dev), torch.tensor(c, device=dev)
+    out = torch.empty(b, 32768, device=dev)
+    sa, sl = torch.empty(b, n, 64, device=dev), torch.empty(b, n, 64, device=dev)
+    sr, sv = torch.empty(b, n, device=dev), torch.empty(b, 513, 64, device=dev)
+    ws = L.workspace(lib.scl_netvlad_fwd_workspace_bytes(b, n), dev)
+    steps = (n + 31) // 32
+    per = -(-steps * b // 256)
+    s_cnt = -(-steps // per)
+    nwg = b * s_cnt
+    lib.scl_debug_set_variant(900 + 16 + args.bits)
+    try:
+        for _ in range(3):
+            ws.zero_()
+            L.check(lib.scl_netvlad_fwd(L.ptr(x), L.DT_BF16, L.ptr(wt), L.ptr(ct), b, n, 1, L.ptr(out),
+                                        L.ptr(sa), L.ptr(sl), L.ptr(sr), L.ptr(sv), L.ptr(ws), ws.numel(),
+                                        L.stream_of(x)))
+        torch.cuda.synchronize()
+    finally:
+        lib.scl_debug_set_variant(0)
+    tail = ws[-nwg * 32 * 8:].cpu().numpy().view(np.uint64).reshape(nwg, 32).astype(np.int64)
+    names = {0: 'entry', 1: 'stage DMA issued, W loads issued', 2: 'W + first stages landed', 28: 'loop done',
+             29: 'slab stores issued', 30: 'slab stores complete'}
+    for st in range(4):
+        names.update({4 + 6 * st: 'step %d: stage landed + barrier' % st, 5 + 6 * st: 'step %d: logits done' % st,
+                      6 + 6 * st: 'step %d: softmax exchange barrier' % st,
+                      7 + 6 * st: 'step %d: coefficients written, outputs stored' % st,
+                      8 + 6 * st: 'step %d: aggregation done' % st})
+    t0 = tail[:, 0:1]
+    rel = tail - t0
+    prev = 0
+    print('workgroups %d, start spread (cycles): %d' % (nwg, int(tail[:, 0].max() - tail[:, 0].min())))
+    for k in sorted(names):
+        col = rel[:, k]
+        col = col[tail[:, k] != 0]
+        if col.size == 0:
+            continue
+        med = int(np.median(col))
+        print('%-48s median %7d  (+%6d)   p90 %7d' % (names[k], med, med - prev, int(np.percentile(col, 90))))
+        prev = med
+
+
+if __name__ == '__main__':
+    main()

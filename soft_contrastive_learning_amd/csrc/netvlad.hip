@@ -850,6 +850,719 @@ __global__ __launch_bounds__(256, 2) void aggregate16b_kernel(
   }
 }
 
+// =======================================================================================
+// Fused kernels for bf16 feature maps (round 3): ONE pass over x per direction.
+//
+// vlad_fwd_kernel: soft-assignment AND aggregation of one (image, location slice) per
+// workgroup.  What bounded the two-kernel form (rowtile_ring + aggregate16b) was bytes per CU,
+// not matrix or LDS time: every 128 locations re-streamed the 196 KB operand image of W
+// through the CU's L2 -> LDS path (12-13 B per cycle and CU), and x and the assignments made a
+// second trip for the aggregation.  Here
+//   * W^T lives in REGISTERS for the whole kernel: wave w owns clusters 16 w .. 16 w + 15 as
+//     three bf16 planes (16 k-steps x 3 planes x 4 registers = 192 per lane);
+//   * the partial VLAD of the slice lives in REGISTERS too: V[512 channels][the wave's 16
+//     clusters] = 32 accumulator tiles = 128 per lane (one wave per SIMD, 512-register budget);
+//   * only x moves: 32-location steps through a 3-stage LDS ring filled by LDS-DMA (32 KB per
+//     stage, two stages in flight), each x tile consumed twice while it is in LDS — row-wise
+//     (ds_read_b128) as the B operand of the logits, column-wise (ds_read_b64_tr_b16) as the A
+//     operand of the aggregation.  Unit u(loc, c) = 64 loc + (c ^ (loc & 15)) (c = 16-byte
+//     chunk of the row) makes both kinds of read conflict-free (scripts/lds_conflicts.py); the
+//     swizzle sits on the DMA's source address.
+// The logits run with the operands SWAPPED (S^T = W^T x^T), so a lane holds four consecutive
+// clusters of ONE location: the softmax needs two cross-lane steps instead of four per value, and
+// a / logits leave as 16-byte stores.  Row norms come from the matrix cores as well: x_frag is
+// both operands of one more MFMA per k-step, whose diagonal is sum_d x^2 (bf16 products are
+// exact in float32).  The softmax over the 64 clusters spans the four waves: each wave
+// publishes (max, sum exp) of its 16 clusters per location, ONE barrier, then every wave
+// finishes a = e^(s - m_w) e^(m_w - M) / total.  The coefficients a * rn then go through a
+// per-wave [32 loc][16 cl] x 3-plane LDS image (8-byte writes, transposed reads) to become
+// the B operand of the aggregation — no round trip through HBM, no second read of x.
+// Contraction index k = 8 g + e of the aggregation is location pi(k) of the step (see vf_pi):
+// any permutation works as long as both operands use it, and this one keeps the transposed
+// reads of the x tile conflict-free.
+// Output: a, logits, rn (training), the slice's slab in accumulator order and its column sums
+// of a.  grid (S slices, B images), block 256, one workgroup per CU.
+constexpr int VF_STEP = 32;                       // locations per step
+constexpr int VF_STAGE = VF_STEP * D * 2;         // bytes per x stage (32,768)
+constexpr int VF_NST = 3;
+constexpr int VF_AHEAD = 3;                      // A fragments in flight in the aggregation
+constexpr int VF_CFLD = 48;                       // bytes per coefficient row (16 clusters + pad)
+constexpr int VF_CFPL = VF_STEP * VF_CFLD;        // bytes per plane (1,536)
+constexpr int VF_CF = 3 * VF_CFPL;                // bytes per wave
+constexpr int VF_EXCH = 4 * VF_STEP * 16;         // [wave][location][up to 4 floats]
+constexpr size_t kVladFusedLds = (size_t)VF_NST * VF_STAGE + 4 * VF_CF + VF_EXCH;   // 118,784 B
+
+// location (within the step) of contraction index k = 8 g + e
+__host__ __device__ constexpr int vf_pi(int g, int e) {
+  return 16 * (g >> 1) + 2 * (4 * (g & 1) + (e & 3)) + (e >> 2);
+}
+
+// W [512][64] float32 -> register images of the fused kernels: 16-byte unit
+// ((w * 16 + s) * 3 + plane) * 64 + lane  holds  W_plane[ch 32 s + 8 g + e][cluster 16 w + i],
+// e = 0..7, for lane = 16 g + i: wave w loads its 48 fragments with coalesced 16-byte loads.
+// grid 64, block 64 (block = (w, s)).
+__global__ __launch_bounds__(64) void vlad_split_w_kernel(const float* __restrict__ w,
+                                                          unsigned short* __restrict__ img) {
+  const int lane = threadIdx.x, i = lane & 15, g = lane >> 4;
+  const int wv = blockIdx.x >> 4, s = blockIdx.x & 15;
+  unsigned short h[3][8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    split3_bf16(w[(32 * s + 8 * g + e) * K + 16 * wv + i], h[0][e], h[1][e], h[2][e]);
+#pragma unroll
+  for (int pl = 0; pl < 3; ++pl) {
+    uint4 v;
+    v.x = (unsigned)h[pl][0] | ((unsigned)h[pl][1] << 16);
+    v.y = (unsigned)h[pl][2] | ((unsigned)h[pl][3] << 16);
+    v.z = (unsigned)h[pl][4] | ((unsigned)h[pl][5] << 16);
+    v.w = (unsigned)h[pl][6] | ((unsigned)h[pl][7] << 16);
+    reinterpret_cast<uint4*>(img)[(((wv * 16 + s) * 3 + pl) * 64) + lane] = v;
+  }
+}
+
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+// v + (v of the lane 16 / 32 away): one register swap between 16-lane rows / 32-lane halves
+// (v_permlane16_swap_b32 / v_permlane32_swap_b32) and one add — no trip through the LDS crossbar
+// like ds_bpermute (what __shfl_xor compiles to for these distances).
+__device__ __forceinline__ float vf_pair16(float v, bool want_max) {
+  const unsigned u = __float_as_uint(v);
+  const u32x2 r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const float a = __uint_as_float(r[0]), b = __uint_as_float(r[1]);
+  return want_max ? fmaxf(a, b) : a + b;
+}
+__device__ __forceinline__ float vf_pair32(float v, bool want_max) {
+  const unsigned u = __float_as_uint(v);
+  const u32x2 r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const float a = __uint_as_float(r[0]), b = __uint_as_float(r[1]);
+  return want_max ? fmaxf(a, b) : a + b;
+}
+// sum / max over the four lanes (i, g = 0..3) that share a location
+__device__ __forceinline__ float vf_gsum(float v) { return vf_pair32(vf_pair16(v, false), false); }
+__device__ __forceinline__ float vf_gmax(float v) { return vf_pair32(vf_pair16(v, true), true); }
+
+typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __attribute__((address_space(3))) u32x2 lds_u32x2;
+__device__ __forceinline__ u32x4 vf_ldsr128(unsigned byte) { return *(const lds_u32x4*)(size_t)byte; }
+__device__ __forceinline__ uint2 vf_ldsr_tr(unsigned byte) {
+  const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(size_t)byte);
+  return __builtin_bit_cast(uint2, v);
+}
+__device__ __forceinline__ void vf_ldsw64(unsigned byte, unsigned lo, unsigned hi) {
+  *(lds_u32x2*)(size_t)byte = u32x2{lo, hi};
+}
+// counted wait on the wave's vector-memory queue (immediate operand: a small switch)
+__device__ __forceinline__ void vf_wait_vm(int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+struct VladFwdArgs {
+  const unsigned short* x;      // [B][N][512] bf16
+  const unsigned short* wimg;   // vlad_split_w_kernel's image
+  int N, pre_l2, steps_per_slice;
+  float* assign;                // [B][N][64] or NULL (inference)
+  float* logit;                 // [B][N][64] or NULL
+  float* rnorm;                 // [B][N] or NULL
+  float* slab;                  // [S][B][4 waves][32 tiles][64 lanes][4]
+  float* colsum;                // [S][B][64]
+  int dbg;                      // scl_debug_set_variant(916): in-kernel clock stamps
+                                // (scripts/vlad_stamps.py); 0 in production
+  unsigned long long* stamps;   // [workgroup][32] shader-clock stamps of wave 0 (dbg bit 4)
+  float* trash;                 // 64 x 16 bytes: where the stores of rows past the end go (the
+                                // kernel counts its own vector-memory queue, so every step must
+                                // issue the same number of stores)
+};
+
+template <bool SAVE>
+__global__ __launch_bounds__(256, 1) void vlad_fwd_kernel(VladFwdArgs p) {
+  // 1 KB alignment: the transposed-read addresses are formed by XOR on (stage base + offset)
+  extern __shared__ __attribute__((aligned(1024))) unsigned char vf_lds[];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, g = lane >> 4;
+  // image on blockIdx.x: workgroup b + B * sl, so with B a multiple of 8 all slices of an image
+  // run on one XCD (round-robin placement: speed only) and their slabs meet in one L2
+  const int b = blockIdx.x, sl = blockIdx.y, B = gridDim.x;
+  const int nsteps_img = (p.N + VF_STEP - 1) / VF_STEP;
+  const int st_lo = sl * p.steps_per_slice;
+  const int st_hi = st_lo + p.steps_per_slice < nsteps_img ? st_lo + p.steps_per_slice : nsteps_img;
+  const int nst = st_hi - st_lo;                           // >= 1 by the host's choice of S
+  const unsigned lds0 = nv_lds_byte_of(vf_lds);
+  const unsigned cf0 = lds0 + VF_NST * VF_STAGE + wid * VF_CF;
+  float* exch = reinterpret_cast<float*>(vf_lds + VF_NST * VF_STAGE + 4 * VF_CF);
+  const unsigned short* xb = p.x + (int64_t)b * p.N * D;
+  unsigned long long* stp =
+      (p.dbg & 16) && threadIdx.x == 0 ? p.stamps + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 : nullptr;
+#define VF_STAMP(k)                                         \
+  do {                                                      \
+    if (p.dbg & 16) {                                       \
+      __builtin_amdgcn_sched_barrier(0);                    \
+      if (stp) stp[k] = __builtin_amdgcn_s_memtime();       \
+      __builtin_amdgcn_sched_barrier(0);                    \
+    }                                                       \
+  } while (0)
+  VF_STAMP(0);
+
+  // ---- x stage by LDS-DMA: wave w brings rows w, w + 4, .. of the step; lane l of row r
+  // fetches chunk l ^ (r & 15) into unit 64 r + l (rows past the end re-read the last row)
+  auto stage = [&](int step) {
+    const unsigned base = lds0 + (unsigned)((step - st_lo) % VF_NST) * VF_STAGE;
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+      const int r = wid + 4 * v;
+      int n = VF_STEP * step + r;
+      n = n < p.N ? n : p.N - 1;
+      nv_glds16(xb + (int64_t)n * D + ((lane ^ (r & 15)) << 3), base + r * 1024);
+    }
+  };
+  stage(st_lo);
+  if (nst > 1) stage(st_lo + 1);
+
+  // ---- the wave's slice of W^T: 16 k-steps x 3 planes
+  u32x4 wf[16][3];
+  {
+    const u32x4* src = reinterpret_cast<const u32x4*>(p.wimg) + (int64_t)wid * 16 * 3 * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) wf[s][pl] = src[(s * 3 + pl) * 64];
+  }
+
+  if (p.dbg & 16) {
+    VF_STAMP(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    VF_STAMP(2);
+  }
+  f32x4 accv[32];
+#pragma unroll
+  for (int ct = 0; ct < 32; ++ct) accv[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+
+  // per-lane address parts.  Row fragment of (t, s): unit (16 t + i, 4 s + g):
+  //   byte = 1024 (16 t + i) + 64 (s ^ (i >> 2)) + 16 (g ^ (i & 3));  s ^ ih = (s & ~3) | ((s & 3) ^ ih)
+  unsigned rowoff[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) rowoff[k] = 1024u * i + 64u * (k ^ (i >> 2)) + 16u * (g ^ (i & 3));
+  // Transposed fragment (half h): lane 4 q + p of group g reads 8 bytes at row pi(8 g + 4 h + q),
+  // channels 16 ct + 4 p ..: byte = 1024 row + ((32 Rh + 16 (pb ^ R0) + 8 (p & 1)) ^ 32 ct)
+  float dsel[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) dsel[j] = (g == (i >> 2) && (i & 3) == j) ? 1.0f : 0.0f;
+  const int q = (lane >> 2) & 3, pp = lane & 3;
+  unsigned troff[2], cfoff[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int row = 16 * (g >> 1) + 2 * (4 * (g & 1) + q) + h;     // vf_pi(g, 4 h + q)
+    const int R = row & 15;
+    troff[h] = 1024u * row + 32u * (R >> 1) + 16u * ((pp >> 1) ^ (R & 1)) + 8u * (pp & 1);
+    cfoff[h] = (unsigned)row * VF_CFLD + 8u * pp;
+  }
+
+#pragma unroll 1
+  for (int st = 0; st < nst; ++st) {
+    const int step = st_lo + st;
+    // This stage's DMA must have landed; younger than it in the wave's queue, and allowed to
+    // stay in flight: the next stage's DMA (8) and the previous step's stores (5 when saving).
+    vf_wait_vm((st + 1 < nst ? 8 : 0) + (st >= 1 && SAVE ? 5 : 0));
+    __builtin_amdgcn_s_barrier();         // landed for every wave; the stage read in step - 1 is free
+    if (st < 4) VF_STAMP(4 + 6 * st);
+    const unsigned sb = lds0 + (unsigned)(st % VF_NST) * VF_STAGE;
+
+    // ---- logits (swapped: lane = location, registers = 4 consecutive clusters) + row norms
+    f32x4 accl[2], accn[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      accl[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      accn[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    u32x4 xf[4][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        xf[s][t] = vf_ldsr128(sb + rowoff[s & 3] + 256u * (s >> 2) + 16384u * t);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      if (s + 2 < 16) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          xf[(s + 2) & 3][t] =
+              vf_ldsr128(sb + rowoff[(s + 2) & 3] + 256u * ((s + 2) >> 2) + 16384u * t);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) accl[t] = mfma16b(wf[s][pl], xf[s & 3][t], accl[t]);
+        accn[t] = mfma16b(xf[s & 3][t], xf[s & 3][t], accn[t]);
+      }
+    }
+
+    if (st < 4) VF_STAMP(5 + 6 * st);
+    // ---- softmax over the 64 clusters (this wave: 16 of them), coefficients, outputs
+    float av[2][4], ev[2][4], mloc[2], rnv[2];
+    bool ok[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int n = VF_STEP * step + 16 * t + i;
+      ok[t] = n < p.N;
+      // diagonal of the tile's Gram: row 4 g + j == column i (dsel: 1 on that register, else 0)
+      float d = accn[t][0] * dsel[0] + accn[t][1] * dsel[1] + accn[t][2] * dsel[2] + accn[t][3] * dsel[3];
+      d = vf_gsum(d);
+      rnv[t] = p.pre_l2 ? 1.0f / sqrtf(fmaxf(d, 1e-12f)) : 1.0f;
+      float m = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        ev[t][j] = accl[t][j] * rnv[t];                    // the logit
+        m = fmaxf(m, ev[t][j]);
+      }
+      m = vf_gmax(m);
+      mloc[t] = m;
+      if (SAVE)
+        *reinterpret_cast<f32x4*>(ok[t] ? p.logit + ((int64_t)b * p.N + n) * K + 16 * wid + 4 * g
+                                        : p.trash + 4 * lane) =
+            f32x4{ev[t][0], ev[t][1], ev[t][2], ev[t][3]};
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        ev[t][j] = expf(ev[t][j] - m);
+        sum += ev[t][j];
+      }
+      sum = vf_gsum(sum);
+      if (g == 0) *reinterpret_cast<f32x2*>(exch + (wid * VF_STEP + 16 * t + i) * 2) = f32x2{m, sum};
+    }
+    __builtin_amdgcn_s_barrier();
+    if (st < 4) VF_STAMP(6 + 6 * st);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int n = VF_STEP * step + 16 * t + i;
+      f32x2 ms[4];
+#pragma unroll
+      for (int w2 = 0; w2 < 4; ++w2)
+        ms[w2] = *reinterpret_cast<const f32x2*>(exch + (w2 * VF_STEP + 16 * t + i) * 2);
+      const float M = fmaxf(fmaxf(ms[0][0], ms[1][0]), fmaxf(ms[2][0], ms[3][0]));
+      float tot = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < 4; ++w2) tot += ms[w2][1] * expf(ms[w2][0] - M);
+      const float sc = expf(mloc[t] - M) / tot;
+      unsigned short h[3][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        av[t][j] = ev[t][j] * sc;
+        const float a_ok = ok[t] ? av[t][j] : 0.f;
+        cs[j] += a_ok;
+        split3_bf16(a_ok * rnv[t], h[0][j], h[1][j], h[2][j]);
+      }
+      if (SAVE)
+        *reinterpret_cast<f32x4*>(ok[t] ? p.assign + ((int64_t)b * p.N + n) * K + 16 * wid + 4 * g
+                                        : p.trash + 4 * lane) =
+            f32x4{av[t][0], av[t][1], av[t][2], av[t][3]};
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        vf_ldsw64(cf0 + pl * VF_CFPL + (16 * t + i) * VF_CFLD + 8 * g,
+                  (unsigned)h[pl][0] | ((unsigned)h[pl][1] << 16),
+                  (unsigned)h[pl][2] | ((unsigned)h[pl][3] << 16));
+      }
+    }
+    if (SAVE) {   // rn: wave w writes the step's locations 8 w .. 8 w + 7 (one store per wave)
+      const int t = wid >> 1;
+      const int n = VF_STEP * step + 16 * t + i;
+      const float r = t == 0 ? rnv[0] : rnv[1];
+      const bool mine = g == 0 && (i >> 3) == (wid & 1) && n < p.N;
+      *(mine ? p.rnorm + (int64_t)b * p.N + n : p.trash + 4 * lane) = r;
+    }
+
+    if (st < 4) VF_STAMP(7 + 6 * st);
+    if (st + 2 < nst) stage(step + 2);     // into the stage of step - 1
+
+    // ---- aggregation: V[ch][cl] += sum_loc x[loc][ch] * (a rn)[loc][cl]
+    u32x4 bfr[3];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      const uint2 lo = vf_ldsr_tr(cf0 + pl * VF_CFPL + cfoff[0]);
+      const uint2 hi = vf_ldsr_tr(cf0 + pl * VF_CFPL + cfoff[1]);
+      bfr[pl] = u32x4{lo.x, lo.y, hi.x, hi.y};
+    }
+    const unsigned ta0 = sb + troff[0], ta1 = sb + troff[1];
+    // A fragments VF_AHEAD channel tiles ahead of the matrix work (an LDS round trip is longer
+    // than the three MFMAs of a tile)
+    u32x4 af[4];
+#pragma unroll
+    for (int ct = 0; ct < VF_AHEAD; ++ct) {
+      const uint2 lo = vf_ldsr_tr(ta0 ^ (32u * ct)), hi = vf_ldsr_tr(ta1 ^ (32u * ct));
+      af[ct] = u32x4{lo.x, lo.y, hi.x, hi.y};
+    }
+#pragma unroll
+    for (int ct = 0; ct < 32; ++ct) {
+      if (ct + VF_AHEAD < 32) {
+        const uint2 lo = vf_ldsr_tr(ta0 ^ (32u * (ct + VF_AHEAD))),
+                    hi = vf_ldsr_tr(ta1 ^ (32u * (ct + VF_AHEAD)));
+        af[(ct + VF_AHEAD) & 3] = u32x4{lo.x, lo.y, hi.x, hi.y};
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) accv[ct] = mfma16b(af[ct & 3], bfr[pl], accv[ct]);
+    }
+    if (st < 4) VF_STAMP(8 + 6 * st);
+  }
+  VF_STAMP(28);
+
+  // ---- the slice's slab, in accumulator order, and the column sums of a
+  f32x4* slab = reinterpret_cast<f32x4*>(p.slab) + ((((int64_t)sl * B + b) * 4 + wid) * 32) * 64 + lane;
+#pragma unroll
+  for (int ct = 0; ct < 32; ++ct) slab[ct * 64] = accv[ct];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) cs[j] += __shfl_xor(cs[j], m, 64);
+  }
+  if (i == 0)
+    *reinterpret_cast<f32x4*>(p.colsum + ((int64_t)sl * B + b) * K + 16 * wid + 4 * g) =
+        f32x4{cs[0], cs[1], cs[2], cs[3]};
+  if (p.dbg & 16) {
+    VF_STAMP(29);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    VF_STAMP(30);
+  }
+#undef VF_STAMP
+}
+
+// U = sum of the slices' slabs + C * asum for one 16-channel tile -> vlad[b] (natural [513][64]
+// layout, the saved pre-norm VLAD) and the tile's column sums of squares.  Slabs are in
+// accumulator order: 16-byte unit ((w * 32 + ct) * 64 + lane) = U[16 ct + 4 g + 0..3][16 w + i].
+// grid (B, 32 channel tiles), block 256: thread = (wave w, lane); all S loads of a thread are in
+// flight together (31 MB of slabs at 24 x 1200: a reader with one load at a time took 20 us).
+// Image on blockIdx.x like vlad_fwd_kernel: with B a multiple of 8 an image's slabs are read on
+// the XCD whose L2 they were written through (placement is speed only).
+constexpr int VF_MAXS = 16;
+__global__ __launch_bounds__(256) void vlad_finish_sum_kernel(const float* __restrict__ slab,
+                                                              const float* __restrict__ colsum,
+                                                              const float* __restrict__ centers,
+                                                              int S, float* __restrict__ vlad,
+                                                              float* __restrict__ colsq_part) {
+  const int b = blockIdx.x, ct = blockIdx.y, B = gridDim.x;
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+  const int k = 16 * w + i;
+  const f32x4* src = reinterpret_cast<const f32x4*>(slab) + (((int64_t)b * 4 + w) * 32 + ct) * 64 + lane;
+  const int64_t sstride = (int64_t)B * 4 * 32 * 64;          // units between slices
+  f32x4 u = f32x4{0.f, 0.f, 0.f, 0.f};
+  float asum = 0.f;
+  for (int s0 = 0; s0 < S; s0 += VF_MAXS) {
+    f32x4 v[VF_MAXS];
+    float a[VF_MAXS];
+#pragma unroll
+    for (int s = 0; s < VF_MAXS; ++s) {
+      const bool ok = s0 + s < S;
+      v[s] = ok ? src[(s0 + s) * sstride] : f32x4{0.f, 0.f, 0.f, 0.f};
+      a[s] = ok ? colsum[((int64_t)(s0 + s) * B + b) * K + k] : 0.f;
+    }
+#pragma unroll
+    for (int s = 0; s < VF_MAXS; ++s) {                       // fixed order: bitwise reproducible
+      u += v[s];
+      asum += a[s];
+    }
+  }
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int d = 16 * ct + 4 * g + j;
+    const float v = u[j] + centers[d * K + k] * asum;
+    vlad[((int64_t)b * (D + 1) + d) * K + k] = v;
+    ss = fmaf(v, v, ss);
+  }
+  if (ct == 0 && g == 0) vlad[((int64_t)b * (D + 1) + D) * K + k] = asum;
+  ss = vf_gsum(ss);
+  if (g == 0) colsq_part[((int64_t)b * 32 + ct) * K + k] = ss;
+}
+
+// vlad_bwd_kernel: the backward twin of vlad_fwd_kernel — x.dU[b], the softmax backward and the
+// weight-gradient aggregation x^T.(ds rn) of one (image, location slice) in one pass over x.
+// The image's dU^T sits in registers (bwd_du_kernel writes it as the same register image the
+// forward uses for W^T), the slice's partial dW in the accumulators.  Per location the softmax
+// backward needs sums over all 64 clusters, i.e. over the four waves; every wave publishes four
+// partial sums over its 16 clusters,
+//   P1 = sum a da,  P2 = sum a t,  P3 = sum a da lg,  P4 = sum a lg     (t = xhat.dU, da = t + c.dU)
+// and after ONE barrier   dot = sum P1,   <dxhat, xhat> = sum P2 + sum P3 - dot sum P4
+// (= sum_k a t + ds lg with ds = a (da - dot)).  Outputs: ds, rowdot, the slice's dW slab.
+struct VladBwdArgs {
+  const unsigned short* x;      // [B][N][512] bf16
+  const unsigned short* duimg;  // [B] register images of dU^T (bwd_du_kernel)
+  const float* a;               // [B][N][64] saved assignments
+  const float* lg;              // [B][N][64] saved logits
+  const float* rn;              // [B][N]
+  const float* cdu;             // [B][64]
+  int N, steps_per_slice;
+  float* ds;                    // [B][N][64]
+  float* rowdot;                // [B][N]
+  float* slab;                  // [S][B][4][32][64][4]
+  float* trash;
+};
+
+__global__ __launch_bounds__(256, 1) void vlad_bwd_kernel(VladBwdArgs p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char vf_lds[];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x, sl = blockIdx.y, B = gridDim.x;
+  const int nsteps_img = (p.N + VF_STEP - 1) / VF_STEP;
+  const int st_lo = sl * p.steps_per_slice;
+  const int st_hi = st_lo + p.steps_per_slice < nsteps_img ? st_lo + p.steps_per_slice : nsteps_img;
+  const int nst = st_hi - st_lo;
+  const unsigned lds0 = nv_lds_byte_of(vf_lds);
+  const unsigned cf0 = lds0 + VF_NST * VF_STAGE + wid * VF_CF;
+  float* exch = reinterpret_cast<float*>(vf_lds + VF_NST * VF_STAGE + 4 * VF_CF);   // [wave][loc][4]
+  const unsigned short* xb = p.x + (int64_t)b * p.N * D;
+
+  auto stage = [&](int step) {
+    const unsigned base = lds0 + (unsigned)((step - st_lo) % VF_NST) * VF_STAGE;
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+      const int r = wid + 4 * v;
+      int n = VF_STEP * step + r;
+      n = n < p.N ? n : p.N - 1;
+      nv_glds16(xb + (int64_t)n * D + ((lane ^ (r & 15)) << 3), base + r * 1024);
+    }
+  };
+  stage(st_lo);
+  if (nst > 1) stage(st_lo + 1);
+
+  u32x4 wf[16][3];
+  {
+    const u32x4* src = reinterpret_cast<const u32x4*>(p.duimg) + ((int64_t)b * 4 + wid) * 16 * 3 * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) wf[s][pl] = src[(s * 3 + pl) * 64];
+  }
+  const f32x4 cd = *reinterpret_cast<const f32x4*>(p.cdu + b * K + 16 * wid + 4 * g);
+
+  f32x4 accv[32];
+#pragma unroll
+  for (int ct = 0; ct < 32; ++ct) accv[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  unsigned rowoff[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) rowoff[k] = 1024u * i + 64u * (k ^ (i >> 2)) + 16u * (g ^ (i & 3));
+  const int q = (lane >> 2) & 3, pp = lane & 3;
+  unsigned troff[2], cfoff[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int row = 16 * (g >> 1) + 2 * (4 * (g & 1) + q) + h;
+    const int R = row & 15;
+    troff[h] = 1024u * row + 32u * (R >> 1) + 16u * ((pp >> 1) ^ (R & 1)) + 8u * (pp & 1);
+    cfoff[h] = (unsigned)row * VF_CFLD + 8u * pp;
+  }
+
+#pragma unroll 1
+  for (int st = 0; st < nst; ++st) {
+    const int step = st_lo + st;
+    // younger than this stage's DMA and allowed in flight: the next stage's DMA (8) and the
+    // previous step's three stores (its loads were waited for when they were used)
+    vf_wait_vm((st + 1 < nst ? 8 : 0) + (st >= 1 ? 3 : 0));
+    __builtin_amdgcn_s_barrier();
+    const unsigned sb = lds0 + (unsigned)(st % VF_NST) * VF_STAGE;
+
+    // the step's saved forward values, in flight under the matrix work
+    f32x4 a4[2], l4[2];
+    float rn2[2];
+    bool ok[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int n = VF_STEP * step + 16 * t + i;
+      ok[t] = n < p.N;
+      const int64_t row = (int64_t)b * p.N + (ok[t] ? n : p.N - 1);
+      a4[t] = *reinterpret_cast<const f32x4*>(p.a + row * K + 16 * wid + 4 * g);
+      l4[t] = *reinterpret_cast<const f32x4*>(p.lg + row * K + 16 * wid + 4 * g);
+      rn2[t] = p.rn[row];
+    }
+
+    f32x4 accl[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) accl[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x4 xf[4][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        xf[s][t] = vf_ldsr128(sb + rowoff[s & 3] + 256u * (s >> 2) + 16384u * t);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      if (s + 2 < 16) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          xf[(s + 2) & 3][t] =
+              vf_ldsr128(sb + rowoff[(s + 2) & 3] + 256u * ((s + 2) >> 2) + 16384u * t);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) accl[t] = mfma16b(wf[s][pl], xf[s & 3][t], accl[t]);
+    }
+
+    float tv[2][4], dav[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float p1 = 0.f, p2 = 0.f, p3 = 0.f, p4 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        tv[t][j] = accl[t][j] * rn2[t];                    // xhat . dU
+        dav[t][j] = tv[t][j] + cd[j];
+        const float ad = a4[t][j] * dav[t][j];
+        p1 += ad;
+        p2 = fmaf(a4[t][j], tv[t][j], p2);
+        p3 = fmaf(ad, l4[t][j], p3);
+        p4 = fmaf(a4[t][j], l4[t][j], p4);
+      }
+      p1 = vf_gsum(p1);
+      p2 = vf_gsum(p2);
+      p3 = vf_gsum(p3);
+      p4 = vf_gsum(p4);
+      if (g == 0) *reinterpret_cast<f32x4*>(exch + (wid * VF_STEP + 16 * t + i) * 4) = f32x4{p1, p2, p3, p4};
+    }
+    __builtin_amdgcn_s_barrier();
+    float rd2[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int n = VF_STEP * step + 16 * t + i;
+      f32x4 ps = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int w2 = 0; w2 < 4; ++w2)
+        ps += *reinterpret_cast<const f32x4*>(exch + (w2 * VF_STEP + 16 * t + i) * 4);
+      const float dot = ps[0];
+      rd2[t] = ps[1] + ps[2] - dot * ps[3];
+      float dsv[4];
+      unsigned short h[3][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        dsv[j] = a4[t][j] * (dav[t][j] - dot);
+        split3_bf16(ok[t] ? dsv[j] * rn2[t] : 0.f, h[0][j], h[1][j], h[2][j]);
+      }
+      *reinterpret_cast<f32x4*>(ok[t] ? p.ds + ((int64_t)b * p.N + n) * K + 16 * wid + 4 * g
+                                      : p.trash + 4 * lane) = f32x4{dsv[0], dsv[1], dsv[2], dsv[3]};
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        vf_ldsw64(cf0 + pl * VF_CFPL + (16 * t + i) * VF_CFLD + 8 * g,
+                  (unsigned)h[pl][0] | ((unsigned)h[pl][1] << 16),
+                  (unsigned)h[pl][2] | ((unsigned)h[pl][3] << 16));
+    }
+    {   // rowdot: wave w writes the step's locations 8 w .. 8 w + 7
+      const int t = wid >> 1;
+      const int n = VF_STEP * step + 16 * t + i;
+      const float r = t == 0 ? rd2[0] : rd2[1];
+      const bool mine = g == 0 && (i >> 3) == (wid & 1) && n < p.N;
+      *(mine ? p.rowdot + (int64_t)b * p.N + n : p.trash + 4 * lane) = r;
+    }
+    if (st + 2 < nst) stage(step + 2);
+
+    u32x4 bfr[3];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      const uint2 lo = vf_ldsr_tr(cf0 + pl * VF_CFPL + cfoff[0]);
+      const uint2 hi = vf_ldsr_tr(cf0 + pl * VF_CFPL + cfoff[1]);
+      bfr[pl] = u32x4{lo.x, lo.y, hi.x, hi.y};
+    }
+    const unsigned ta0 = sb + troff[0], ta1 = sb + troff[1];
+    // A fragments VF_AHEAD channel tiles ahead of the matrix work (an LDS round trip is longer
+    // than the three MFMAs of a tile)
+    u32x4 af[4];
+#pragma unroll
+    for (int ct = 0; ct < VF_AHEAD; ++ct) {
+      const uint2 lo = vf_ldsr_tr(ta0 ^ (32u * ct)), hi = vf_ldsr_tr(ta1 ^ (32u * ct));
+      af[ct] = u32x4{lo.x, lo.y, hi.x, hi.y};
+    }
+#pragma unroll
+    for (int ct = 0; ct < 32; ++ct) {
+      if (ct + VF_AHEAD < 32) {
+        const uint2 lo = vf_ldsr_tr(ta0 ^ (32u * (ct + VF_AHEAD))),
+                    hi = vf_ldsr_tr(ta1 ^ (32u * (ct + VF_AHEAD)));
+        af[(ct + VF_AHEAD) & 3] = u32x4{lo.x, lo.y, hi.x, hi.y};
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) accv[ct] = mfma16b(af[ct & 3], bfr[pl], accv[ct]);
+    }
+  }
+
+  f32x4* slab = reinterpret_cast<f32x4*>(p.slab) + ((((int64_t)sl * B + b) * 4 + wid) * 32) * 64 + lane;
+#pragma unroll
+  for (int ct = 0; ct < 32; ++ct) slab[ct * 64] = accv[ct];
+}
+
+// grad_w[d,k] = sum over all (slice, image) slabs, in two levels so that every CU reads its share
+// of the 31 MB: vlad_wgrad_partial_kernel, grid (32 channel tiles, VW_GROUPS), sums one group's
+// slabs (VF_MAXS loads in flight) into partial[group][...]; vlad_wgrad_finish_kernel, grid 32,
+// adds the groups in order and forms grad_c[d,k] = sum_b dU[b,d,k] * asum[b,k].  Fixed orders
+// throughout: bitwise reproducible.  Slabs in accumulator order (see vlad_finish_sum_kernel).
+constexpr int VW_GROUPS = 8;
+__global__ __launch_bounds__(256) void vlad_wgrad_partial_kernel(const float* __restrict__ slab,
+                                                                 int total,
+                                                                 float* __restrict__ partial) {
+  const int ct = blockIdx.x, grp = blockIdx.y;
+  const int per = (total + VW_GROUPS - 1) / VW_GROUPS;
+  const int lo = grp * per, hi = lo + per < total ? lo + per : total;
+  const int64_t unit = ((int64_t)(threadIdx.x >> 6) * 32 + ct) * 64 + (threadIdx.x & 63);
+  const f32x4* src = reinterpret_cast<const f32x4*>(slab) + unit;
+  const int64_t stride = (int64_t)4 * 32 * 64;                // units between (slice, image) slabs
+  f32x4 u = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int s0 = lo; s0 < hi; s0 += VF_MAXS) {
+    f32x4 v[VF_MAXS];
+#pragma unroll
+    for (int s = 0; s < VF_MAXS; ++s)
+      v[s] = s0 + s < hi ? src[(s0 + s) * stride] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < VF_MAXS; ++s) u += v[s];
+  }
+  reinterpret_cast<f32x4*>(partial)[grp * stride + unit] = u;
+}
+
+__global__ __launch_bounds__(256) void vlad_wgrad_finish_kernel(const float* __restrict__ partial,
+                                                                const float* __restrict__ du,
+                                                                const float* __restrict__ save_vlad,
+                                                                int B, float* __restrict__ grad_w,
+                                                                float* __restrict__ grad_c) {
+  const int ct = blockIdx.x;
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+  const int k = 16 * w + i;
+  const int64_t stride = (int64_t)4 * 32 * 64;
+  const f32x4* src = reinterpret_cast<const f32x4*>(partial) + ((int64_t)w * 32 + ct) * 64 + lane;
+  f32x4 v[VW_GROUPS];
+#pragma unroll
+  for (int s = 0; s < VW_GROUPS; ++s) v[s] = src[s * stride];
+  f32x4 u = v[0];
+#pragma unroll
+  for (int s = 1; s < VW_GROUPS; ++s) u += v[s];
+  float gc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int b0 = 0; b0 < B; b0 += 8) {
+    float as8[8], dv[8][4];
+#pragma unroll
+    for (int bb = 0; bb < 8; ++bb) {
+      const int b = b0 + bb < B ? b0 + bb : B - 1;
+      as8[bb] = b0 + bb < B ? save_vlad[((int64_t)b * (D + 1) + D) * K + k] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dv[bb][j] = du[((int64_t)b * D + 16 * ct + 4 * g + j) * K + k];
+    }
+#pragma unroll
+    for (int bb = 0; bb < 8; ++bb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) gc[j] = fmaf(dv[bb][j], as8[bb], gc[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int d = 16 * ct + 4 * g + j;
+    grad_w[d * K + k] = u[j];
+    grad_c[d * K + k] = gc[j];
+  }
+}
+
 // Forward finish in two small launches of 8 x B workgroups (a single workgroup per image
 // left 232 CUs idle and took 3x longer):
 //   finish_sum_kernel   U = slabs + C * asum for one 64-channel block -> vlad[b] (the saved
@@ -888,11 +1601,14 @@ __global__ __launch_bounds__(256) void finish_sum_kernel(const float* __restrict
 
 __global__ __launch_bounds__(256) void finish_norm_kernel(const float* __restrict__ vlad,
                                                           const float* __restrict__ colsq_part,
-                                                          float* __restrict__ out) {
+                                                          int nparts, float* __restrict__ out) {
   const int blk = blockIdx.x, b = blockIdx.y, k = threadIdx.x & 63, dq = threadIdx.x >> 6;
+  float cp[32];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) cp[j] = j < nparts ? colsq_part[((int64_t)b * nparts + j) * K + k] : 0.f;
   float col = 0.f;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) col += colsq_part[((int64_t)b * 8 + j) * K + k];
+  for (int j = 0; j < 32; ++j) col += cp[j];
   // matconvnetNormalize: x / sqrt(sum x^2 + 1e-12), epsilon inside the sqrt
   const float q = 1.0f / sqrtf(col + 1e-12f);
   // every one of the 4 waves holds all 64 columns: a wave sum gives sum_k (q_k^2 col_k)
@@ -953,6 +1669,7 @@ __global__ __launch_bounds__(256) void bwd_du_kernel(const float* __restrict__ s
                                                      float* __restrict__ du,
                                                      float* __restrict__ dut,
                                                      unsigned short* __restrict__ dplanes,
+                                                     unsigned short* __restrict__ duimg,
                                                      unsigned short* __restrict__ du2,
                                                      const float* __restrict__ assign_w,
                                                      unsigned short* __restrict__ w2,
@@ -1003,6 +1720,25 @@ __global__ __launch_bounds__(256) void bwd_du_kernel(const float* __restrict__ s
         w[i] = (unsigned)h[pl][2 * i] | ((unsigned)h[pl][2 * i + 1] << 16);
       img[((blk * 3 + pl) * 8 + 2 * dq) * 64 + k] = make_uint4(w[0], w[1], w[2], w[3]);
       img[((blk * 3 + pl) * 8 + 2 * dq + 1) * 64 + k] = make_uint4(w[4], w[5], w[6], w[7]);
+    }
+  }
+  if (duimg) {
+    // register image of vlad_bwd_kernel (see vlad_split_w_kernel): this thread's 16 channels are
+    // k-step s = 2 blk + (dq >> 1), lane groups g = 2 (dq & 1) and + 1, of wave k >> 4
+    unsigned short h[3][16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) split3_bf16(vals[i], h[0][i], h[1][i], h[2][i]);
+    uint4* img = reinterpret_cast<uint4*>(duimg + (int64_t)b * 3 * D * K);
+    const int wv = k >> 4, ii = k & 15, s = 2 * blk + (dq >> 1);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      unsigned w[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        w[i] = (unsigned)h[pl][2 * i] | ((unsigned)h[pl][2 * i + 1] << 16);
+      const int g0 = 2 * (dq & 1);
+      img[((wv * 16 + s) * 3 + pl) * 64 + 16 * g0 + ii] = make_uint4(w[0], w[1], w[2], w[3]);
+      img[((wv * 16 + s) * 3 + pl) * 64 + 16 * (g0 + 1) + ii] = make_uint4(w[4], w[5], w[6], w[7]);
     }
   }
   if (du2) {
@@ -1379,6 +2115,166 @@ __global__ __launch_bounds__(256, 2) void dx16b_kernel(const unsigned short* __r
   }
 }
 
+// vlad_dx_kernel: grad_x of one (image, location slice) for a bf16 feature map,
+//   dxhat[n, d] = sum_{k<64} a[n,k] dU[b][d,k] + ds[n,k] W[d,k],   grad_x = rn (dxhat - xhat <dxhat, xhat>)
+// with the operand [dU[b] | W] (128 x 512, two bf16 planes: A.B = Ah.Bh + Ah.Bl + Al.Bh, three
+// orders below the bf16 output rounding) RESIDENT IN REGISTERS: wave w owns channels 128 w .. + 127
+// = 8 tiles x 4 k-steps x 2 planes x 4 registers = 256 per lane.  dx16b_kernel re-streamed that
+// 256 KB operand through LDS for every 64 locations (115 MB of L2 -> LDS traffic per launch at
+// 24 x 1200, with 2-way bank conflicts); here it is read once per workgroup.
+// Per 16-location tile: the four waves convert [a | ds] to bf16 high / low fragments
+// cooperatively (wave w = k-step w) into an LDS fragment buffer (lane-linear, conflict-free),
+// one barrier, 96 MFMAs per wave with the operands swapped (lane = location, registers = four
+// consecutive channels), then the wave's [16 loc][128 ch] float32 block goes through a per-wave
+// LDS scratch so that x is loaded and grad_x stored as whole 256-byte row segments.
+// grid (B images, S slices), block 256, one workgroup per CU.
+constexpr int DXV_ABUF = 4 * 2 * 64 * 16;                 // bytes per fragment buffer (8 KB)
+constexpr int DXV_SLD = 128 * 4 + 16;                     // bytes per scratch row (128 f32 + pad)
+constexpr int DXV_SCR = 16 * DXV_SLD;                     // per wave (8,448 B)
+constexpr size_t kVladDxLds = 2 * (size_t)DXV_ABUF + 4 * (size_t)DXV_SCR;   // 50,176 B
+
+struct VladDxArgs {
+  const unsigned short* x;      // [B][N][512] bf16
+  const float* a;               // [B][N][64]
+  const float* ds;              // [B][N][64]
+  const float* rn;              // [B][N]
+  const float* rowdot;          // [B][N]
+  const unsigned short* du2;    // [B][2 planes][512][64] bf16 (bwd_du_kernel)
+  const unsigned short* w2;     // [2 planes][512][64] bf16
+  int N, pre_l2, steps_per_slice;
+  unsigned short* gx;           // [B][N][512] bf16
+};
+
+__global__ __launch_bounds__(256, 1) void vlad_dx_kernel(VladDxArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dxv_lds[];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x, sl = blockIdx.y;
+  const int nsteps_img = (p.N + VF_STEP - 1) / VF_STEP;
+  const int st_lo = sl * p.steps_per_slice;
+  const int st_hi = st_lo + p.steps_per_slice < nsteps_img ? st_lo + p.steps_per_slice : nsteps_img;
+  const int n_lo = VF_STEP * st_lo;
+  const int n_hi = VF_STEP * st_hi < p.N ? VF_STEP * st_hi : p.N;
+  const int ntile = (n_hi - n_lo + 15) / 16;
+  const unsigned lds0 = nv_lds_byte_of(dxv_lds);
+  const unsigned scr0 = lds0 + 2 * DXV_ABUF + wid * DXV_SCR;
+
+  // ---- the wave's operand: bw[nt][s][pl] = [dU | W]_plane[ch 128 w + 16 nt + i][k 32 s + 8 g ..]
+  u32x4 bw[8][4][2];
+  {
+    const unsigned short* dub = p.du2 + (int64_t)b * 2 * D * K;
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+          const unsigned short* src = (s < 2 ? dub : p.w2) +
+                                      ((int64_t)pl * D + 128 * wid + 16 * nt + i) * K + 32 * (s & 1) + 8 * g;
+          bw[nt][s][pl] = *reinterpret_cast<const u32x4*>(src);
+        }
+  }
+
+  // staging role: k-step wid of the tile: [a | ds][n0 + i][32 (wid & 1) + 8 g .. + 7]
+  const float* asrc = (wid < 2 ? p.a : p.ds) + (int64_t)b * p.N * K + 32 * (wid & 1) + 8 * g;
+  auto a_load = [&](int tile, f32x4& v0, f32x4& v1) {
+    int n = n_lo + 16 * tile + i;
+    n = n < n_hi ? n : n_hi - 1;                           // rows past the end: results discarded
+    const float* r = asrc + (int64_t)n * K;
+    v0 = *reinterpret_cast<const f32x4*>(r);
+    v1 = *reinterpret_cast<const f32x4*>(r + 4);
+  };
+  auto a_stage = [&](int buf, const f32x4& v0, const f32x4& v1) {
+    u32x4 hi, lo;
+    split2x8(v0, v1, hi, lo);
+    const unsigned base = lds0 + buf * DXV_ABUF + (wid * 2) * 1024 + lane * 16;
+    *(lds_u32x4*)(size_t)(base) = hi;
+    *(lds_u32x4*)(size_t)(base + 1024) = lo;
+  };
+  // epilogue role: piece p = lane + 64 v of the tile's 256 (location, 8-channel chunk) pieces of
+  // this wave's 128 channels: location (lane >> 4) + 4 v, chunk lane & 15
+  const int el = lane >> 4, ec = lane & 15;
+  const unsigned short* xb = p.x + (int64_t)b * p.N * D + 128 * wid + 8 * ec;
+  unsigned short* gb = p.gx + (int64_t)b * p.N * D + 128 * wid + 8 * ec;
+
+  f32x4 pa0, pa1;
+  a_load(0, pa0, pa1);
+  a_stage(0, pa0, pa1);
+  if (ntile > 1) a_load(1, pa0, pa1);
+  __syncthreads();
+
+#pragma unroll 1
+  for (int tt = 0; tt < ntile; ++tt) {
+    const int n0 = n_lo + 16 * tt;
+    // the epilogue's inputs, in flight under the matrix work
+    u32x4 xr[4];
+    float rn4[4], rd4[4];
+    bool okr[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int n = n0 + el + 4 * v;
+      okr[v] = n < n_hi;
+      const int64_t nn = okr[v] ? n : n_hi - 1;
+      xr[v] = *reinterpret_cast<const u32x4*>(xb + nn * D);
+      rn4[v] = p.pre_l2 ? p.rn[(int64_t)b * p.N + nn] : 1.0f;
+      rd4[v] = p.rowdot[(int64_t)b * p.N + nn];
+    }
+    // A fragments of the tile (B operand of the swapped product): [s][plane]
+    u32x4 af[4][2];
+    {
+      const unsigned base = lds0 + (tt & 1) * DXV_ABUF + lane * 16;
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) af[s][pl] = vf_ldsr128(base + (s * 2 + pl) * 1024);
+    }
+    f32x4 acc[8];
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+      acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        acc[nt] = mfma16b(bw[nt][s][1], af[s][0], acc[nt]);    // Bl . Ah
+        acc[nt] = mfma16b(bw[nt][s][0], af[s][1], acc[nt]);    // Bh . Al
+        acc[nt] = mfma16b(bw[nt][s][0], af[s][0], acc[nt]);    // Bh . Ah
+      }
+    }
+    // next tile's fragments into the other buffer (its last readers finished before the
+    // barrier that ended the previous tile)
+    if (tt + 1 < ntile) {
+      a_stage((tt + 1) & 1, pa0, pa1);
+      if (tt + 2 < ntile) a_load(tt + 2, pa0, pa1);
+    }
+    // ---- transpose through the wave's scratch: lane (i = location, g) holds channels
+    // 16 nt + 4 g .. + 3 -> rows of 128 channels
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+      *(__attribute__((address_space(3))) f32x4*)(size_t)(scr0 + i * DXV_SLD + (16 * nt + 4 * g) * 4) = acc[nt];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const unsigned ra = scr0 + (el + 4 * v) * DXV_SLD + ec * 32;
+      const f32x4 d0 = *(const __attribute__((address_space(3))) f32x4*)(size_t)(ra);
+      const f32x4 d1 = *(const __attribute__((address_space(3))) f32x4*)(size_t)(ra + 16);
+      float out[8] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+      const float rnv = rn4[v];
+      // x * rsqrt(max(ss, eps)): with the clamp active the op is a plain scale (no projection)
+      if (p.pre_l2 && rnv < 1.0e6f) {
+        const float f = rnv * rd4[v];
+        float xv8[8];
+        Elem8<unsigned short>::cvt(xr[v], xv8);
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) out[cc] -= xv8[cc] * f;
+      }
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc) out[cc] *= rnv;
+      if (okr[v]) Elem8<unsigned short>::st(gb + (int64_t)(n0 + el + 4 * v) * D, out);
+    }
+    __syncthreads();       // fragment buffer (tt + 1) & 1 complete; scratch free for the next tile
+  }
+}
+
 // grad_w[d,k] = sum_b sum_s slab[b][s][d,k];  grad_c[d,k] = sum_b dU[b,d,k] * asum[b,k].
 // grid D*K/64, block 256: thread (j, q) sums the images b = q, q + 4, ... of element
 // 64 * blockIdx.x + j; the four partials are combined in a fixed order (512 workgroups
@@ -1483,28 +2379,56 @@ struct Carver {
   }
 };
 
+// Slices of the fused kernels: steps of 32 locations per workgroup so that B * S workgroups
+// cover the chip once (one workgroup per CU, 512 registers per lane).
+struct VladPlan {
+  int steps_per_slice, S;
+};
+inline int vlad_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, c = 0;
+    n = (hipGetDevice(&dev) == hipSuccess &&
+         hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0)
+            ? c : 256;
+  }
+  return n;
+}
+inline VladPlan vlad_plan(int B, int N) {
+  const int nsteps = (N + VF_STEP - 1) / VF_STEP;
+  VladPlan p;
+  p.steps_per_slice = (int)(((int64_t)nsteps * B + vlad_cus() - 1) / vlad_cus());
+  if (p.steps_per_slice < 1) p.steps_per_slice = 1;
+  p.S = (nsteps + p.steps_per_slice - 1) / p.steps_per_slice;
+  return p;
+}
+
 struct FwdWs {
-  float *wt, *part, *colsum, *colsq, *vlad, *assign, *rnorm;
-  unsigned short* wplanes;   // bf16x3 chunk images of W^T (3 * 64 * 512 bf16)
+  float *wt, *part, *colsum, *colsq, *vlad, *assign, *rnorm, *trash;
+  unsigned long long* stamps;   // diagnostics: [B * S][32], the LAST bytes of the workspace
+  unsigned short* wplanes;   // bf16x3 register images of W^T (3 * 64 * 512 bf16)
   size_t total;
 };
 inline FwdWs carve_fwd(void* ws, int B, int N) {
   Carver c(ws);
   FwdWs w;
+  const int S = vlad_plan(B, N).S > NSPLIT ? vlad_plan(B, N).S : NSPLIT;
   w.wt = c.take((size_t)D * K);
-  w.part = c.take((size_t)B * NSPLIT * D * K);
-  w.colsum = c.take((size_t)B * NSPLIT * K);
-  w.colsq = c.take((size_t)B * 8 * K);
+  w.part = c.take((size_t)B * S * D * K);
+  w.colsum = c.take((size_t)B * S * K);
+  w.trash = c.take(256);
+  w.colsq = c.take((size_t)B * 32 * K);
   w.vlad = c.take((size_t)B * (D + 1) * K);
   w.assign = c.take((size_t)B * N * K);
   w.rnorm = c.take((size_t)B * N);
   w.wplanes = (unsigned short*)c.take((size_t)3 * D * K / 2);
+  w.stamps = (unsigned long long*)c.take((size_t)B * S * 32 * 2);
   w.total = c.off;
   return w;
 }
 
 struct BwdWs {
-  float *du, *dut, *cdu, *ds, *rowdot, *wpart, *dots;
+  float *du, *dut, *cdu, *ds, *rowdot, *wpart, *dots, *wpartial, *trash;
   unsigned short* dplanes;   // [B] bf16x3 chunk images of dU^T
   unsigned short* du2;       // [B][2][512][64] bf16 planes of dU
   unsigned short* w2;        // [2][512][64] bf16 planes of W
@@ -1518,7 +2442,10 @@ inline BwdWs carve_bwd(void* ws, int B, int N) {
   w.cdu = c.take((size_t)B * K);
   w.ds = c.take((size_t)B * N * K);
   w.rowdot = c.take((size_t)B * N);
-  w.wpart = c.take((size_t)B * NSPLIT * D * K);
+  const int S = vlad_plan(B, N).S > NSPLIT ? vlad_plan(B, N).S : NSPLIT;
+  w.wpart = c.take((size_t)B * S * D * K);
+  w.wpartial = c.take((size_t)VW_GROUPS * D * K);
+  w.trash = c.take(256);
   w.dplanes = (unsigned short*)c.take((size_t)B * 3 * D * K / 2);
   w.dots = c.take((size_t)B * 8 * 4 * K);
   w.du2 = (unsigned short*)c.take((size_t)B * 2 * D * K / 2);
@@ -1571,7 +2498,47 @@ extern "C" int scl_netvlad_fwd(const void* x, int x_dtype, const float* assign_w
     SCL_LAUNCH("aggregate_kernel", aggregate_kernel<float>, dim3(D / 64, NSPLIT, B), dim3(256), 0, st, x,
                        (const float*)assign, (const float*)rnorm, N, w.part, w.colsum);
   } else {
-    if (fwd_b3) {
+    if (fwd_b3 && scl_debug_variant != 9) {
+      // one pass over x: soft-assignment and aggregation fused (9: the two-kernel form, A/B)
+      static std::once_flag once;
+      std::call_once(once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vlad_fwd_kernel<true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVladFusedLds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vlad_fwd_kernel<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVladFusedLds);
+      });
+      const VladPlan pl = vlad_plan(B, N);
+      SCL_LAUNCH("vlad_split_w_kernel", vlad_split_w_kernel, dim3(64), dim3(64), 0, st, assign_w,
+                 w.wplanes);
+      VladFwdArgs fa{};
+      fa.x = (const unsigned short*)x;
+      fa.wimg = w.wplanes;
+      fa.N = N;
+      fa.pre_l2 = pre_l2 ? 1 : 0;
+      fa.steps_per_slice = pl.steps_per_slice;
+      fa.slab = w.part;
+      fa.colsum = w.colsum;
+      fa.trash = w.trash;
+      fa.dbg = (scl_debug_variant >= 900 && scl_debug_variant < 932) ? scl_debug_variant - 900 : 0;
+      fa.stamps = w.stamps;
+      const bool save = save_assign && save_logit && save_rnorm;
+      if (save) {
+        fa.assign = save_assign;
+        fa.logit = save_logit;
+        fa.rnorm = save_rnorm;
+        SCL_LAUNCH("vlad_fwd_kernel<true>", vlad_fwd_kernel<true>, dim3(B, pl.S), dim3(256),
+                   kVladFusedLds, st, fa);
+      } else {
+        SCL_LAUNCH("vlad_fwd_kernel<false>", vlad_fwd_kernel<false>, dim3(B, pl.S), dim3(256),
+                   kVladFusedLds, st, fa);
+      }
+      float* vlad = save_vlad ? save_vlad : w.vlad;
+      SCL_LAUNCH("vlad_finish_sum_kernel", vlad_finish_sum_kernel, dim3(B, 32), dim3(256), 0, st,
+                 (const float*)w.part, (const float*)w.colsum, centers, pl.S, vlad, w.colsq);
+      SCL_LAUNCH("finish_norm_kernel", finish_norm_kernel, dim3(8, B), dim3(256), 0, st,
+                 (const float*)vlad, (const float*)w.colsq, 32, out);
+      return scl_launch_status();
+    } else if (fwd_b3) {
       SCL_LAUNCH("split_w_kernel", split_w_kernel, dim3((D / 8) * K / 256), dim3(256), 0, st,
                  assign_w, w.wplanes);
       a.btp = w.wplanes;
@@ -1589,7 +2556,7 @@ extern "C" int scl_netvlad_fwd(const void* x, int x_dtype, const float* assign_w
   SCL_LAUNCH("finish_sum_kernel", finish_sum_kernel, dim3(8, B), dim3(256), 0, st,
              (const float*)w.part, (const float*)w.colsum, centers, vlad, w.colsq);
   SCL_LAUNCH("finish_norm_kernel", finish_norm_kernel, dim3(8, B), dim3(256), 0, st,
-             (const float*)vlad, (const float*)w.colsq, out);
+             (const float*)vlad, (const float*)w.colsq, 8, out);
   return scl_launch_status();
 }
 
@@ -1616,12 +2583,64 @@ extern "C" int scl_netvlad_bwd(const void* x, int x_dtype, const float* assign_w
   hipStream_t st = (hipStream_t)stream;
 
   const bool b3 = x_dtype == SCL_DT_BF16 && use_b3();
+  const bool fused = b3 && scl_debug_variant != 9;      // 9: the two-kernel form (A/B)
   SCL_LAUNCH("bwd_dots_kernel", bwd_dots_kernel, dim3(8, B), dim3(256), 0, st, save_vlad, grad_out,
              centers, w.dots);
   SCL_LAUNCH("bwd_du_kernel", bwd_du_kernel, dim3(8, B), dim3(256), 0, st, save_vlad, grad_out,
              (const float*)w.dots, w.du, b3 ? (float*)nullptr : w.dut,
-             b3 ? w.dplanes : (unsigned short*)nullptr,
+             b3 && !fused ? w.dplanes : (unsigned short*)nullptr,
+             fused ? w.dplanes : (unsigned short*)nullptr,
              b3 ? w.du2 : (unsigned short*)nullptr, assign_w, w.w2, w.cdu);
+  if (fused) {
+    static std::once_flag once;
+    std::call_once(once, [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vlad_bwd_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVladFusedLds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vlad_dx_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVladDxLds);
+    });
+    const VladPlan pl = vlad_plan(B, N);
+    VladBwdArgs ba{};
+    ba.x = (const unsigned short*)x;
+    ba.duimg = w.dplanes;
+    ba.a = save_assign;
+    ba.lg = save_logit;
+    ba.rn = save_rnorm;
+    ba.cdu = w.cdu;
+    ba.N = N;
+    ba.steps_per_slice = pl.steps_per_slice;
+    ba.ds = w.ds;
+    ba.rowdot = w.rowdot;
+    ba.slab = w.wpart;
+    ba.trash = w.trash;
+    SCL_LAUNCH("vlad_bwd_kernel", vlad_bwd_kernel, dim3(B, pl.S), dim3(256), kVladFusedLds, st, ba);
+    if (scl_debug_variant == 10) {               // 10: the LDS-streamed grad_x kernel (A/B)
+      const dim3 dxg(((N + 15) / 16 + 3) / 4, B);
+      SCL_LAUNCH("dx16b_kernel", dx16b_kernel, dxg, dim3(256), kDx16bLds, st,
+                 (const unsigned short*)x, save_assign, (const float*)w.ds, save_rnorm,
+                 (const float*)w.rowdot, (const unsigned short*)w.du2, (const unsigned short*)w.w2,
+                 N, pre_l2 ? 1 : 0, (unsigned short*)grad_x);
+    } else {
+      VladDxArgs da{};
+      da.x = (const unsigned short*)x;
+      da.a = save_assign;
+      da.ds = w.ds;
+      da.rn = save_rnorm;
+      da.rowdot = w.rowdot;
+      da.du2 = w.du2;
+      da.w2 = w.w2;
+      da.N = N;
+      da.pre_l2 = pre_l2 ? 1 : 0;
+      da.steps_per_slice = pl.steps_per_slice;
+      da.gx = (unsigned short*)grad_x;
+      SCL_LAUNCH("vlad_dx_kernel", vlad_dx_kernel, dim3(B, pl.S), dim3(256), kVladDxLds, st, da);
+    }
+    SCL_LAUNCH("vlad_wgrad_partial_kernel", vlad_wgrad_partial_kernel, dim3(32, VW_GROUPS), dim3(256),
+               0, st, (const float*)w.wpart, pl.S * B, w.wpartial);
+    SCL_LAUNCH("vlad_wgrad_finish_kernel", vlad_wgrad_finish_kernel, dim3(32), dim3(256), 0, st,
+               (const float*)w.wpartial, (const float*)w.du, save_vlad, B, grad_w, grad_c);
+    return scl_launch_status();
+  }
   RowTileArgs a{};
   a.x = x;
   a.bt = w.dut;
