@@ -54,15 +54,25 @@ __device__ __forceinline__ void split3_bf16(float x, unsigned short& h1, unsigne
   h3 = f32_to_bf16(r1 - bf16_to_f32(h2));
 }
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// float32 x 8 -> packed bf16 high and low halves (v = hi + lo + O(2^-17 |v|))
+__device__ __forceinline__ void split2x8(const f32x4& a, const f32x4& b, u32x4& hi, u32x4& lo) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float v0 = c < 2 ? a[2 * c] : b[2 * c - 4], v1 = c < 2 ? a[2 * c + 1] : b[2 * c - 3];
+    const unsigned short h0 = f32_to_bf16(v0), h1 = f32_to_bf16(v1);
+    hi[c] = (unsigned)h0 | ((unsigned)h1 << 16);
+    lo[c] = (unsigned)f32_to_bf16(v0 - bf16_to_f32(h0)) |
+            ((unsigned)f32_to_bf16(v1 - bf16_to_f32(h1)) << 16);
+  }
+}
+
 enum RowMode { ASSIGN = 0, DASSIGN = 1 };
 
 struct RowTileArgs {
   const void* x;       // [B,N,512]
   const float* bt;     // ASSIGN: Wt [64][512];  DASSIGN: dUt [B][64][512]
   int64_t bt_stride;   // floats between images (0 for ASSIGN)
-  const unsigned short* btp;   // bf16 input: the same operand as bf16x3 chunk images (split_w_kernel)
-  int64_t btp_stride;          // elements between images (0 for ASSIGN)
-  int dbg;                     // timing ablations (scl_debug_set_variant 21 / 22), 0 = production
   int B, N, pre_l2;
   // ASSIGN outputs
   float* assign;       // [B,N,64]
@@ -356,46 +366,11 @@ __global__ __launch_bounds__(256, 2) void rowtile16_kernel(RowTileArgs p) {
 // x.o = x.o1 + x.o2 + x.o3 differs from the float32 contraction only by accumulation order —
 // at 3 x 16 cycles per 16x16x32 step instead of 8 x 32 cycles of 16x16x4 float32 steps, and
 // with no bf16 -> f32 conversion of x at all.  Row norms by float32 FMAs on the same registers.
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ f32x4 mfma16b(u32x4 a, u32x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
                                                  __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-
-// ---------------------------------------------------------------------------------------
-// Operand planes of the bf16x3 row-tile kernel.  The float32 operand O[k = cluster][c = channel]
-// (W^T, or dU^T of an image) is stored as the kernel's LDS images, chunk after chunk:
-//   16-byte unit ((chunk * 3 + plane) * 8 + piece) * 64 + k  =  O_plane[k][64 chunk + 8 piece .. + 7]
-// so a 64-channel chunk (3 planes x 8 pieces x 64 clusters x 16 B = 24 KB) is copied into LDS
-// by LDS-DMA exactly as it lies, and the B fragment of lane (i, g) for k-step s2 and cluster
-// tile kt sits at unit (plane * 8 + 4 s2 + g) * 64 + 16 kt + i: inside every ds_read_b128
-// service group ({0-3, 12-15, 20-27}, ... = each value of i once) the 16 lanes hit 16 different
-// 16-byte slots — conflict-free, no padding.
-constexpr int RC_UNITS = 3 * 8 * 64;                       // 16-byte units per chunk image
-constexpr int RC_IMG = RC_UNITS * 8;                       // bf16 per chunk image (24 KB)
-
-// W [512][64] float32 -> chunk images of W^T.  grid 16, block 256: thread = (8-channel piece
-// c8, cluster k): eight strided reads (coalesced over k), one 16-byte store per plane.
-__global__ __launch_bounds__(256) void split_w_kernel(const float* __restrict__ w,
-                                                      unsigned short* __restrict__ planes) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;          // over 64 pieces x 64 clusters
-  if (idx >= (D / 8) * K) return;
-  const int k = idx % K, c8 = idx / K;
-  unsigned short h[3][8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) split3_bf16(w[(c8 * 8 + j) * K + k], h[0][j], h[1][j], h[2][j]);
-  const int chunk = c8 >> 3, piece = c8 & 7;
-#pragma unroll
-  for (int pl = 0; pl < 3; ++pl) {
-    uint4 v;
-    v.x = (unsigned)h[pl][0] | ((unsigned)h[pl][1] << 16);
-    v.y = (unsigned)h[pl][2] | ((unsigned)h[pl][3] << 16);
-    v.z = (unsigned)h[pl][4] | ((unsigned)h[pl][5] << 16);
-    v.w = (unsigned)h[pl][6] | ((unsigned)h[pl][7] << 16);
-    reinterpret_cast<uint4*>(planes)[((chunk * 3 + pl) * 8 + piece) * 64 + k] = v;
-  }
 }
 
 // LDS-DMA: 64 lanes x 16 bytes from per-lane global addresses into 1 KB of consecutive LDS at
@@ -412,144 +387,6 @@ __device__ __forceinline__ void nv_glds16(const unsigned short* src, unsigned ld
 }
 __device__ __forceinline__ unsigned nv_lds_byte_of(const void* p) {
   return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
-}
-
-// rowtile_ring_kernel: [128 locations] x [512 channels] x [64 clusters] per workgroup; a wave
-// owns 32 locations = two 16-row MFMA tiles that share every B fragment read.
-//
-// The kernel is bound by memory latency, not by matrix or LDS time (a compute step of 48 MFMAs
-// is 0.3 us, a loaded HBM round trip 1-2 us), so EVERYTHING it reads arrives by LDS-DMA
-// through one 3-stage ring, two 64-channel stages (80 KB per CU) ahead of the matrix work:
-//   stage = operand chunk image (24 KB, see split_w_kernel) + the workgroup's x slice
-//           [128 locations][64 channels] bf16 (16 KB);
-//   x rows are 128 bytes; 16-byte piece q of row r is stored at position q ^ ((r >> 1) & 7)
-//   (the DMA fetches piece j ^ ((r >> 1) & 7) into position j: the swizzle sits on the source
-//   address, the LDS destination is lane-linear) so the 16 lanes of every ds_read_b128 service
-//   group of an A fragment hit 16 different slots;
-//   one queue, counted waits: s_waitcnt vmcnt(10) leaves the next stage in flight; one
-//   barrier per chunk orders landed stages against readers and frees the stage read last.
-// grid (ceil(N / 128), B); block 256; dynamic LDS 3 x 40 KB (the epilogue scratch reuses it).
-constexpr int RG_STAGE = RC_IMG * 2 + 128 * 128;           // bytes per ring stage (40,960)
-constexpr int RG_NST = 3;
-constexpr size_t kRowTileRingLds = (size_t)RG_NST * RG_STAGE;
-static_assert(kRowTileRingLds >= 4 * 16 * 68 * sizeof(float), "epilogue scratch must fit");
-
-template <int MODE>
-__global__ __launch_bounds__(256, 1) void rowtile_ring_kernel(RowTileArgs p) {
-  extern __shared__ __attribute__((aligned(16))) float bt_lds[];
-  const int lane = threadIdx.x & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int i = lane & 15, g = lane >> 4;
-  const int b = blockIdx.y;
-  const int n0 = blockIdx.x * 128 + wid * 32;
-  const bool active = n0 < p.N;          // wave-uniform; idle waves still stage and sync
-  const unsigned short* src = p.btp + (int64_t)b * p.btp_stride;
-  const unsigned short* xb = reinterpret_cast<const unsigned short*>(p.x) + (int64_t)b * p.N * D;
-  const unsigned lds0 = nv_lds_byte_of(bt_lds);
-  const bool row_ok[2] = {n0 + i < p.N, n0 + 16 + i < p.N};
-
-  // x DMA of this lane: instruction v covers the wave's rows 8 v .. 8 v + 7, lane = (r, j)
-  const unsigned short* xsrc[4];
-#pragma unroll
-  for (int v = 0; v < 4; ++v) {
-    const int row = 8 * v + (lane >> 3), j = lane & 7;
-    int n = n0 + row;
-    n = n < p.N ? n : p.N - 1;                             // rows past the end re-read the last
-    xsrc[v] = xb + (int64_t)n * D + ((j ^ ((row >> 1) & 7)) << 3);
-  }
-  auto stage = [&](int chunk) {
-    const unsigned base = lds0 + (chunk % RG_NST) * RG_STAGE;
-#pragma unroll
-    for (int v = 0; v < 6; ++v) {
-      const int piece = v * 4 + wid;                       // 24 one-KB pieces per operand image
-      nv_glds16(src + (int64_t)chunk * RC_IMG + piece * 512 + lane * 8, base + piece * 1024);
-    }
-#pragma unroll
-    for (int v = 0; v < 4; ++v)
-      nv_glds16(xsrc[v] + chunk * 64, base + RC_IMG * 2 + (wid * 32 + 8 * v) * 128);
-  };
-
-  f32x4 acc[2][4];
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) acc[t][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float ss[2] = {0.f, 0.f};
-
-  const int nchunks = p.dbg == 22 ? 0 : D / 64;          // 22: epilogue only
-  if (nchunks) {
-    stage(0);
-    stage(1);
-  }
-#pragma unroll 1
-  for (int c = 0; c < nchunks; ++c) {
-    if (c + 1 < D / 64)
-      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");    // stage c landed, c + 1 in flight
-    else
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (c + 2 < D / 64) stage(c + 2);
-    if (active) {
-      const char* sb = reinterpret_cast<const char*>(bt_lds) + (c % RG_NST) * RG_STAGE;
-      // B fragment of (plane, k-step s2, cluster tile kt): unit (plane*8 + 4 s2 + g)*64 + 16 kt + i
-      const char* wb = sb + (g * 64 + i) * 16;
-      // A fragment of (tile t, k-step s2): row 16 t + i of the wave, piece 4 s2 + g, swizzled
-      const char* xa_base = sb + RC_IMG * 2 + (wid * 32 + i) * 128;
-      const int sw = (i >> 1) & 7;
-      u32x4 xa[2][2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          xa[t][s2] = *reinterpret_cast<const u32x4*>(xa_base + t * 16 * 128 + (((4 * s2 + g) ^ sw) << 4));
-          if (!row_ok[t]) xa[t][s2] = u32x4{0u, 0u, 0u, 0u};
-        }
-      u32x4 wv[2][3];
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
-        wv[0][pl] = *reinterpret_cast<const u32x4*>(wb + pl * 8 * 64 * 16);
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {            // q = 4 * k-step + cluster tile
-        const int s2 = q >> 2, kt = q & 3;
-        if (q + 1 < 8) {
-          const int s3 = (q + 1) >> 2, kt3 = (q + 1) & 3;
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl)
-            wv[(q + 1) & 1][pl] = *reinterpret_cast<const u32x4*>(
-                wb + ((pl * 8 + 4 * s3) * 64 + 16 * kt3) * 16);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-#pragma unroll
-          for (int pl = 0; pl < 3; ++pl)
-            acc[t][kt] = mfma16b(xa[t][s2], wv[q & 1][pl], acc[t][kt]);
-          if (MODE == ASSIGN && kt == 0) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const unsigned w = xa[t][s2][e];
-              const float lo = __uint_as_float(w << 16), hi = __uint_as_float(w & 0xffff0000u);
-              ss[t] = fmaf(lo, lo, ss[t]);
-              ss[t] = fmaf(hi, hi, ss[t]);
-            }
-          }
-        }
-      }
-    }
-  }
-  if (!active) return;
-  if (p.dbg == 21) {                                       // 21: main loop only
-    float sacc = ss[0] + ss[1];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt) sacc += acc[t][kt][0] + acc[t][kt][1] + acc[t][kt][2] + acc[t][kt][3];
-    if (sacc == 1.2345e-7f) p.rnorm[0] = sacc;
-    return;
-  }
-  // stage 0's bytes were last read in chunk 6 and every wave has passed chunk 7's barrier
-  rowtile_epilogue<MODE>(p, acc[0], ss[0], bt_lds, b, n0);
-  if (n0 + 16 < p.N) rowtile_epilogue<MODE>(p, acc[1], ss[1], bt_lds, b, n0 + 16);
 }
 
 // V_part[b, half, d, k] = sum_{n in half} x[b,n,d] * (coefn[b,n,k] * rn[b,n])
@@ -684,171 +521,7 @@ __global__ __launch_bounds__(256) void aggregate_kernel(const void* __restrict__
   }
 }
 
-// per-image normalisation state shared by finish (forward) and bwd_prep (backward)
-// ---------------------------------------------------------------------------------------
-// aggregate16b_kernel: V_part[b, split, d, k] = sum_{n in split} x[b,n,d] cf[b,n,k] for a bf16
-// feature map on v_mfma_f32_16x16x32_bf16, cf = (a or ds) * rn.  The float32 coefficients are
-// read as the row-tile kernel saved them ([n][64] rows) and split into three bf16 planes while
-// they are staged — thread (cluster k, location octet) takes 8 strided values (a wave reads
-// whole 256-byte rows), scales by rn, and writes one 16-byte piece per plane — so no plane
-// copy of them ever goes through HBM (it was 11 MB written and read per pass).
-// The contraction runs over n, the SLOW index of x[n][d]: each wave stages its [32 n][64 d]
-// piece of x row-major in LDS and reads the A fragments with ds_read_b64_tr_b16 (4 rows x 16
-// columns delivered column-major).
-// grid (2 channel halves, NSPLIT, B); block 256: the four waves share a 32-location step
-// (its cf planes are staged once per workgroup) and own 64 channels each, so no cross-wave
-// reduction is needed.  LDS: 2 x ([3][64][40] cf + 4 x [32][72] x) bf16 = 67,584 B.
-constexpr int AB_XLD = 72;                                 // bf16 per staged x row (64 + 8 pad)
-constexpr int AB_CFLD = 40;                                // bf16 per staged cf row (32 n + 8 pad:
-                                                           // 16 lanes -> 16 different 16-B slots)
-constexpr int AB_CF = 3 * K * AB_CFLD;                     // bf16 per staged cf step
-constexpr int AB_X = 32 * AB_XLD;                          // bf16 per wave x tile
-constexpr int AB_BUF = AB_CF + 4 * AB_X;                   // bf16 per buffer
-constexpr size_t kAgg16bLds = 2 * (size_t)AB_BUF * sizeof(unsigned short);   // 67,584 B
 typedef short s16x4 __attribute__((ext_vector_type(4)));
-
-__global__ __launch_bounds__(256, 2) void aggregate16b_kernel(
-    const unsigned short* __restrict__ x, const float* __restrict__ coefn,
-    const float* __restrict__ rn, int N, float* __restrict__ part,
-    float* __restrict__ colsum_part) {
-  extern __shared__ __attribute__((aligned(16))) unsigned short ab_lds[];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int i = lane & 15, g = lane >> 4;
-  const int half = blockIdx.x, split = blockIdx.y, b = blockIdx.z;
-  const int d0 = half * 256 + wid * 64;                    // this wave's 64 channels
-  const int nsteps = (N + 31) / 32;
-  const int per = (nsteps + NSPLIT - 1) / NSPLIT;
-  const int s_begin = split * per;
-  const int s_end = s_begin + per < nsteps ? s_begin + per : nsteps;
-
-  // staging registers: this thread's 8 coefficients (cluster `lane`, locations 8 wid .. + 7
-  // of the step) with their row norms, and 4 sixteen-byte pieces of the wave's x tile
-  float st_a[8], st_r[8];
-  u32x4 st_x[4];
-  const float* cfb_g = coefn + (int64_t)b * N * K + lane;
-  const float* rnb_g = rn + (int64_t)b * N;
-  auto stage_load = [&](int s) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      int n = 32 * s + 8 * wid + j;
-      n = n < N ? n : N - 1;                               // masked when it is consumed
-      st_a[j] = cfb_g[(int64_t)n * K];
-      st_r[j] = rnb_g[n];
-    }
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int idx = v * 64 + lane;                       // 256 pieces: [row 32][8]
-      int n = 32 * s + (idx >> 3);
-      if (n >= N) n = N - 1;                               // cf is zero there
-      st_x[v] = *reinterpret_cast<const u32x4*>(x + ((int64_t)b * N + n) * D + d0 + 8 * (idx & 7));
-    }
-  };
-  float cs_part = 0.f;                                     // column sum of a (cluster `lane`)
-  auto stage_store = [&](int buf, int s) {
-    unsigned short* cfb = ab_lds + buf * AB_BUF;
-    // staged as [plane * 64 + k][32 n (+ pad)]: this thread's piece = locations 8 wid .. + 7
-    unsigned short h[3][8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const bool ok = 32 * s + 8 * wid + j < N;
-      const float av = ok ? st_a[j] : 0.f;
-      cs_part += av;
-      split3_bf16(av * st_r[j], h[0][j], h[1][j], h[2][j]);
-    }
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
-      u32x4 v;
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-        v[c] = (unsigned)h[pl][2 * c] | ((unsigned)h[pl][2 * c + 1] << 16);
-      *reinterpret_cast<u32x4*>(cfb + (pl * K + lane) * AB_CFLD + 8 * wid) = v;
-    }
-    unsigned short* xb = cfb + AB_CF + wid * AB_X;
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const int idx = v * 64 + lane;
-      *reinterpret_cast<u32x4*>(xb + (idx >> 3) * AB_XLD + 8 * (idx & 7)) = st_x[v];
-    }
-  };
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) acc[mt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // column sums of a over this split (forward only) come out of the staging: wave w has
-  // added the locations 8 w .. 8 w + 7 of every step; the four partials meet in LDS below
-  const bool want_cs = colsum_part != nullptr && half == 0;
-
-  if (s_begin < s_end) {
-    stage_load(s_begin);
-    stage_store(0, s_begin);
-  }
-  __syncthreads();
-  for (int s = s_begin; s < s_end; ++s) {
-    const int buf = (s - s_begin) & 1;
-    const bool more = s + 1 < s_end;
-    if (more) stage_load(s + 1);
-    const unsigned short* cfb = ab_lds + buf * AB_BUF;
-    const unsigned short* xb = cfb + AB_CF + wid * AB_X;
-    // A fragments: channel 16 mt + i, locations 8g .. 8g+7 of the step (two transposed reads:
-    // lane 4q + p of a 16-lane group addresses row q, columns 4p .. 4p+3 of the 4 x 16 block)
-    u32x4 af[4];
-    {
-      const int q = (lane >> 2) & 3, pp = lane & 3;
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        const unsigned short* a0 = xb + (8 * g + q) * AB_XLD + 16 * mt + 4 * pp;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (s16x4 __attribute__((address_space(3)))*)(a0));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (s16x4 __attribute__((address_space(3)))*)(a0 + 4 * AB_XLD));
-        const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
-        af[mt] = u32x4{l2.x, l2.y, h2.x, h2.y};
-      }
-    }
-    u32x4 bf[2][3];
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
-      bf[0][pl] = *reinterpret_cast<const u32x4*>(cfb + (pl * K + i) * AB_CFLD + 8 * g);
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      if (kt + 1 < 4) {
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          bf[(kt + 1) & 1][pl] = *reinterpret_cast<const u32x4*>(
-              cfb + (pl * K + 16 * (kt + 1) + i) * AB_CFLD + 8 * g);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          acc[mt][kt] = mfma16b(af[mt], bf[kt & 1][pl], acc[mt][kt]);
-    }
-    if (more) stage_store(buf ^ 1, s + 1);
-    __syncthreads();
-  }
-
-  // slab: rows d0 + 16 mt + 4 g + reg, columns 16 kt + i
-  float* out = part + (((int64_t)b * NSPLIT + split) * D + d0) * K;
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg)
-        out[(16 * mt + 4 * g + reg) * K + 16 * kt + i] = acc[mt][kt][reg];
-  if (want_cs) {   // every wave is past the last barrier: the staging buffers are free
-    float* red = reinterpret_cast<float*>(ab_lds);
-    red[wid * K + lane] = cs_part;
-    __syncthreads();
-    if (wid == 0)
-      colsum_part[((int64_t)b * NSPLIT + split) * K + lane] =
-          (red[lane] + red[K + lane]) + (red[2 * K + lane] + red[3 * K + lane]);
-  }
-}
 
 // =======================================================================================
 // Fused kernels for bf16 feature maps (round 3): ONE pass over x per direction.
@@ -885,10 +558,12 @@ __global__ __launch_bounds__(256, 2) void aggregate16b_kernel(
 constexpr int VF_STEP = 32;                       // locations per step
 constexpr int VF_STAGE = VF_STEP * D * 2;         // bytes per x stage (32,768)
 constexpr int VF_NST = 3;
-constexpr int VF_AHEAD = 3;                      // A fragments in flight in the aggregation
+constexpr int VF_AHEAD = 6;                      // A fragments in flight in the aggregation (<= 7)
 constexpr int VF_CFLD = 48;                       // bytes per coefficient row (16 clusters + pad)
+constexpr int VF_NPL = 2;                         // bf16 planes of the float32 operands (W^T, dU^T,
+                                                  // a rn, ds rn): o = o1 + o2 + O(2^-17 |o|); 3 = exact
 constexpr int VF_CFPL = VF_STEP * VF_CFLD;        // bytes per plane (1,536)
-constexpr int VF_CF = 3 * VF_CFPL;                // bytes per wave
+constexpr int VF_CF = VF_NPL * VF_CFPL;           // bytes per wave
 constexpr int VF_EXCH = 4 * VF_STEP * 16;         // [wave][location][up to 4 floats]
 constexpr size_t kVladFusedLds = (size_t)VF_NST * VF_STAGE + 4 * VF_CF + VF_EXCH;   // 118,784 B
 
@@ -898,25 +573,32 @@ __host__ __device__ constexpr int vf_pi(int g, int e) {
 }
 
 // W [512][64] float32 -> register images of the fused kernels: 16-byte unit
-// ((w * 16 + s) * 3 + plane) * 64 + lane  holds  W_plane[ch 32 s + 8 g + e][cluster 16 w + i],
+// ((w * 16 + s) * VF_NPL + plane) * 64 + lane  holds  W_plane[ch 32 s + 8 g + e][cluster 16 w + i],
 // e = 0..7, for lane = 16 g + i: wave w loads its 48 fragments with coalesced 16-byte loads.
-// grid 64, block 64 (block = (w, s)).
+// VF_WREP identical copies, workgroups take copy (slice index) % VF_WREP.  (Tried with 4: every
+// workgroup reads this image in the same order at the same time, but the prologue — 8.3 k cycles
+// for 192 KB + 64 KB of x — did not move: it runs at the CU's L2 -> register rate, 30 B per cycle,
+// not into a hot L2 channel.  Left at 1.)
+// grid (64, VF_WREP), block 64 (block = (w, s)).
+constexpr int VF_WREP = 1;
+constexpr int VF_WIMG = VF_NPL * D * K;           // bf16 elements per copy
 __global__ __launch_bounds__(64) void vlad_split_w_kernel(const float* __restrict__ w,
                                                           unsigned short* __restrict__ img) {
   const int lane = threadIdx.x, i = lane & 15, g = lane >> 4;
   const int wv = blockIdx.x >> 4, s = blockIdx.x & 15;
+  img += (int64_t)blockIdx.y * VF_WIMG;
   unsigned short h[3][8];
 #pragma unroll
   for (int e = 0; e < 8; ++e)
     split3_bf16(w[(32 * s + 8 * g + e) * K + 16 * wv + i], h[0][e], h[1][e], h[2][e]);
 #pragma unroll
-  for (int pl = 0; pl < 3; ++pl) {
+  for (int pl = 0; pl < VF_NPL; ++pl) {
     uint4 v;
     v.x = (unsigned)h[pl][0] | ((unsigned)h[pl][1] << 16);
     v.y = (unsigned)h[pl][2] | ((unsigned)h[pl][3] << 16);
     v.z = (unsigned)h[pl][4] | ((unsigned)h[pl][5] << 16);
     v.w = (unsigned)h[pl][6] | ((unsigned)h[pl][7] << 16);
-    reinterpret_cast<uint4*>(img)[(((wv * 16 + s) * 3 + pl) * 64) + lane] = v;
+    reinterpret_cast<uint4*>(img)[(((wv * 16 + s) * VF_NPL + pl) * 64) + lane] = v;
   }
 }
 
@@ -1027,13 +709,14 @@ __global__ __launch_bounds__(256, 1) void vlad_fwd_kernel(VladFwdArgs p) {
   if (nst > 1) stage(st_lo + 1);
 
   // ---- the wave's slice of W^T: 16 k-steps x 3 planes
-  u32x4 wf[16][3];
+  u32x4 wf[16][VF_NPL];
   {
-    const u32x4* src = reinterpret_cast<const u32x4*>(p.wimg) + (int64_t)wid * 16 * 3 * 64 + lane;
+    const u32x4* src = reinterpret_cast<const u32x4*>(p.wimg + (int64_t)(sl % VF_WREP) * VF_WIMG) +
+                       (int64_t)wid * 16 * VF_NPL * 64 + lane;
 #pragma unroll
     for (int s = 0; s < 16; ++s)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) wf[s][pl] = src[(s * 3 + pl) * 64];
+      for (int pl = 0; pl < VF_NPL; ++pl) wf[s][pl] = src[(s * VF_NPL + pl) * 64];
   }
 
   if (p.dbg & 16) {
@@ -1101,7 +784,7 @@ __global__ __launch_bounds__(256, 1) void vlad_fwd_kernel(VladFwdArgs p) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) accl[t] = mfma16b(wf[s][pl], xf[s & 3][t], accl[t]);
+        for (int pl = 0; pl < VF_NPL; ++pl) accl[t] = mfma16b(wf[s][pl], xf[s & 3][t], accl[t]);
         accn[t] = mfma16b(xf[s & 3][t], xf[s & 3][t], accn[t]);
       }
     }
@@ -1117,7 +800,7 @@ __global__ __launch_bounds__(256, 1) void vlad_fwd_kernel(VladFwdArgs p) {
       // diagonal of the tile's Gram: row 4 g + j == column i (dsel: 1 on that register, else 0)
       float d = accn[t][0] * dsel[0] + accn[t][1] * dsel[1] + accn[t][2] * dsel[2] + accn[t][3] * dsel[3];
       d = vf_gsum(d);
-      rnv[t] = p.pre_l2 ? 1.0f / sqrtf(fmaxf(d, 1e-12f)) : 1.0f;
+      rnv[t] = p.pre_l2 ? rsqrtf(fmaxf(d, 1e-12f)) : 1.0f;
       float m = -INFINITY;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -1133,7 +816,7 @@ __global__ __launch_bounds__(256, 1) void vlad_fwd_kernel(VladFwdArgs p) {
       float sum = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        ev[t][j] = expf(ev[t][j] - m);
+        ev[t][j] = __expf(ev[t][j] - m);
         sum += ev[t][j];
       }
       sum = vf_gsum(sum);
@@ -1151,8 +834,8 @@ __global__ __launch_bounds__(256, 1) void vlad_fwd_kernel(VladFwdArgs p) {
       const float M = fmaxf(fmaxf(ms[0][0], ms[1][0]), fmaxf(ms[2][0], ms[3][0]));
       float tot = 0.f;
 #pragma unroll
-      for (int w2 = 0; w2 < 4; ++w2) tot += ms[w2][1] * expf(ms[w2][0] - M);
-      const float sc = expf(mloc[t] - M) / tot;
+      for (int w2 = 0; w2 < 4; ++w2) tot += ms[w2][1] * __expf(ms[w2][0] - M);
+      const float sc = __fdividef(__expf(mloc[t] - M), tot);
       unsigned short h[3][4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -1166,7 +849,7 @@ __global__ __launch_bounds__(256, 1) void vlad_fwd_kernel(VladFwdArgs p) {
                                         : p.trash + 4 * lane) =
             f32x4{av[t][0], av[t][1], av[t][2], av[t][3]};
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) {
+      for (int pl = 0; pl < VF_NPL; ++pl) {
         vf_ldsw64(cf0 + pl * VF_CFPL + (16 * t + i) * VF_CFLD + 8 * g,
                   (unsigned)h[pl][0] | ((unsigned)h[pl][1] << 16),
                   (unsigned)h[pl][2] | ((unsigned)h[pl][3] << 16));
@@ -1184,32 +867,40 @@ __global__ __launch_bounds__(256, 1) void vlad_fwd_kernel(VladFwdArgs p) {
     if (st + 2 < nst) stage(step + 2);     // into the stage of step - 1
 
     // ---- aggregation: V[ch][cl] += sum_loc x[loc][ch] * (a rn)[loc][cl]
-    u32x4 bfr[3];
+    u32x4 bfr[VF_NPL];
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
+    for (int pl = 0; pl < VF_NPL; ++pl) {
       const uint2 lo = vf_ldsr_tr(cf0 + pl * VF_CFPL + cfoff[0]);
       const uint2 hi = vf_ldsr_tr(cf0 + pl * VF_CFPL + cfoff[1]);
       bfr[pl] = u32x4{lo.x, lo.y, hi.x, hi.y};
     }
-    const unsigned ta0 = sb + troff[0], ta1 = sb + troff[1];
-    // A fragments VF_AHEAD channel tiles ahead of the matrix work (an LDS round trip is longer
-    // than the three MFMAs of a tile)
-    u32x4 af[4];
+    // address of the transposed fragment of channel tile ct: (stage + troff[h]) ^ 32 ct touches
+    // address bits 5..9 only, and (Rh ^ ct) = (ct & 24) | ((ct & 7) ^ Rh): eight per-lane bases
+    // (ct & 7) per half, the rest is an immediate offset — no address arithmetic in the loop
+    unsigned ta[2][8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int c7 = 0; c7 < 8; ++c7) ta[h][c7] = sb + (troff[h] ^ (32u * c7));
+    // A fragments VF_AHEAD channel tiles ahead of the matrix work (an LDS round trip is several
+    // times the MFMAs of a tile)
+    u32x4 af[8];
 #pragma unroll
     for (int ct = 0; ct < VF_AHEAD; ++ct) {
-      const uint2 lo = vf_ldsr_tr(ta0 ^ (32u * ct)), hi = vf_ldsr_tr(ta1 ^ (32u * ct));
+      const uint2 lo = vf_ldsr_tr(ta[0][ct & 7] + 32u * (ct & 24)), hi = vf_ldsr_tr(ta[1][ct & 7] + 32u * (ct & 24));
       af[ct] = u32x4{lo.x, lo.y, hi.x, hi.y};
     }
 #pragma unroll
     for (int ct = 0; ct < 32; ++ct) {
       if (ct + VF_AHEAD < 32) {
-        const uint2 lo = vf_ldsr_tr(ta0 ^ (32u * (ct + VF_AHEAD))),
-                    hi = vf_ldsr_tr(ta1 ^ (32u * (ct + VF_AHEAD)));
-        af[(ct + VF_AHEAD) & 3] = u32x4{lo.x, lo.y, hi.x, hi.y};
+        const int cn = ct + VF_AHEAD;
+        const uint2 lo = vf_ldsr_tr(ta[0][cn & 7] + 32u * (cn & 24)),
+                    hi = vf_ldsr_tr(ta[1][cn & 7] + 32u * (cn & 24));
+        af[cn & 7] = u32x4{lo.x, lo.y, hi.x, hi.y};
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) accv[ct] = mfma16b(af[ct & 3], bfr[pl], accv[ct]);
+      for (int pl = 0; pl < VF_NPL; ++pl) accv[ct] = mfma16b(af[ct & 7], bfr[pl], accv[ct]);
     }
     if (st < 4) VF_STAMP(8 + 6 * st);
   }
@@ -1334,13 +1025,14 @@ __global__ __launch_bounds__(256, 1) void vlad_bwd_kernel(VladBwdArgs p) {
   stage(st_lo);
   if (nst > 1) stage(st_lo + 1);
 
-  u32x4 wf[16][3];
+  u32x4 wf[16][VF_NPL];
   {
-    const u32x4* src = reinterpret_cast<const u32x4*>(p.duimg) + ((int64_t)b * 4 + wid) * 16 * 3 * 64 + lane;
+    const u32x4* src =
+        reinterpret_cast<const u32x4*>(p.duimg) + ((int64_t)b * 4 + wid) * 16 * VF_NPL * 64 + lane;
 #pragma unroll
     for (int s = 0; s < 16; ++s)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) wf[s][pl] = src[(s * 3 + pl) * 64];
+      for (int pl = 0; pl < VF_NPL; ++pl) wf[s][pl] = src[(s * VF_NPL + pl) * 64];
   }
   const f32x4 cd = *reinterpret_cast<const f32x4*>(p.cdu + b * K + 16 * wid + 4 * g);
 
@@ -1405,7 +1097,7 @@ __global__ __launch_bounds__(256, 1) void vlad_bwd_kernel(VladBwdArgs p) {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) accl[t] = mfma16b(wf[s][pl], xf[s & 3][t], accl[t]);
+        for (int pl = 0; pl < VF_NPL; ++pl) accl[t] = mfma16b(wf[s][pl], xf[s & 3][t], accl[t]);
     }
 
     float tv[2][4], dav[2][4];
@@ -1449,7 +1141,7 @@ __global__ __launch_bounds__(256, 1) void vlad_bwd_kernel(VladBwdArgs p) {
       *reinterpret_cast<f32x4*>(ok[t] ? p.ds + ((int64_t)b * p.N + n) * K + 16 * wid + 4 * g
                                       : p.trash + 4 * lane) = f32x4{dsv[0], dsv[1], dsv[2], dsv[3]};
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
+      for (int pl = 0; pl < VF_NPL; ++pl)
         vf_ldsw64(cf0 + pl * VF_CFPL + (16 * t + i) * VF_CFLD + 8 * g,
                   (unsigned)h[pl][0] | ((unsigned)h[pl][1] << 16),
                   (unsigned)h[pl][2] | ((unsigned)h[pl][3] << 16));
@@ -1463,32 +1155,40 @@ __global__ __launch_bounds__(256, 1) void vlad_bwd_kernel(VladBwdArgs p) {
     }
     if (st + 2 < nst) stage(step + 2);
 
-    u32x4 bfr[3];
+    u32x4 bfr[VF_NPL];
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
+    for (int pl = 0; pl < VF_NPL; ++pl) {
       const uint2 lo = vf_ldsr_tr(cf0 + pl * VF_CFPL + cfoff[0]);
       const uint2 hi = vf_ldsr_tr(cf0 + pl * VF_CFPL + cfoff[1]);
       bfr[pl] = u32x4{lo.x, lo.y, hi.x, hi.y};
     }
-    const unsigned ta0 = sb + troff[0], ta1 = sb + troff[1];
-    // A fragments VF_AHEAD channel tiles ahead of the matrix work (an LDS round trip is longer
-    // than the three MFMAs of a tile)
-    u32x4 af[4];
+    // address of the transposed fragment of channel tile ct: (stage + troff[h]) ^ 32 ct touches
+    // address bits 5..9 only, and (Rh ^ ct) = (ct & 24) | ((ct & 7) ^ Rh): eight per-lane bases
+    // (ct & 7) per half, the rest is an immediate offset — no address arithmetic in the loop
+    unsigned ta[2][8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int c7 = 0; c7 < 8; ++c7) ta[h][c7] = sb + (troff[h] ^ (32u * c7));
+    // A fragments VF_AHEAD channel tiles ahead of the matrix work (an LDS round trip is several
+    // times the MFMAs of a tile)
+    u32x4 af[8];
 #pragma unroll
     for (int ct = 0; ct < VF_AHEAD; ++ct) {
-      const uint2 lo = vf_ldsr_tr(ta0 ^ (32u * ct)), hi = vf_ldsr_tr(ta1 ^ (32u * ct));
+      const uint2 lo = vf_ldsr_tr(ta[0][ct & 7] + 32u * (ct & 24)), hi = vf_ldsr_tr(ta[1][ct & 7] + 32u * (ct & 24));
       af[ct] = u32x4{lo.x, lo.y, hi.x, hi.y};
     }
 #pragma unroll
     for (int ct = 0; ct < 32; ++ct) {
       if (ct + VF_AHEAD < 32) {
-        const uint2 lo = vf_ldsr_tr(ta0 ^ (32u * (ct + VF_AHEAD))),
-                    hi = vf_ldsr_tr(ta1 ^ (32u * (ct + VF_AHEAD)));
-        af[(ct + VF_AHEAD) & 3] = u32x4{lo.x, lo.y, hi.x, hi.y};
+        const int cn = ct + VF_AHEAD;
+        const uint2 lo = vf_ldsr_tr(ta[0][cn & 7] + 32u * (cn & 24)),
+                    hi = vf_ldsr_tr(ta[1][cn & 7] + 32u * (cn & 24));
+        af[cn & 7] = u32x4{lo.x, lo.y, hi.x, hi.y};
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) accv[ct] = mfma16b(af[ct & 3], bfr[pl], accv[ct]);
+      for (int pl = 0; pl < VF_NPL; ++pl) accv[ct] = mfma16b(af[ct & 7], bfr[pl], accv[ct]);
     }
   }
 
@@ -1661,19 +1361,28 @@ __global__ __launch_bounds__(256) void bwd_dots_kernel(const float* __restrict__
       (src[k] + src[64 + k]) + (src[128 + k] + src[192 + k]);
 }
 
-// bwd_du_kernel: grid (8, B), block 256: dU of one 64-channel block in both layouts (and as
-// three bf16 planes of dU^T when dplanes != NULL), c.dU from block 0.
+// bwd_du_kernel: grid (8, B), block 256: dU of one 64-channel block as float32 [d][k] (and
+// transposed, for the float32-MFMA row-tile kernel), c.dU from block 0, and for bf16 feature maps
+// the two REGISTER IMAGES the fused kernels load with coalesced 16-byte reads:
+//   duimg  (vlad_bwd_kernel): unit ((w * 16 + s) * VF_NPL + plane) * 64 + lane =
+//          dU_plane[ch 32 s + 8 g + e][cluster 16 w + i] — eight consecutive CHANNELS of a
+//          cluster: what this thread holds in registers;
+//   dximg  (vlad_dx_kernel):  unit (((w * 8 + nt) * 2 + s) * 2 + plane) * 64 + lane =
+//          dU_plane[ch 128 w + 16 nt + i][cluster 32 s + 8 g + e] — eight consecutive CLUSTERS
+//          of a channel: the other orientation, through a [64 ch][64 k] LDS tile;
+//   wdximg (image 0's workgroups): the same image of W, shared by all images.
+constexpr int DU_TLD = 65;                                // floats per tile row (conflict-free columns)
 __global__ __launch_bounds__(256) void bwd_du_kernel(const float* __restrict__ save_vlad,
                                                      const float* __restrict__ grad_out,
                                                      const float* __restrict__ dots,
                                                      float* __restrict__ du,
                                                      float* __restrict__ dut,
-                                                     unsigned short* __restrict__ dplanes,
                                                      unsigned short* __restrict__ duimg,
-                                                     unsigned short* __restrict__ du2,
+                                                     unsigned short* __restrict__ dximg,
                                                      const float* __restrict__ assign_w,
-                                                     unsigned short* __restrict__ w2,
+                                                     unsigned short* __restrict__ wdximg,
                                                      float* __restrict__ cdu) {
+  __shared__ float tile[64 * DU_TLD];
   const int blk = blockIdx.x, b = blockIdx.y, k = threadIdx.x & 63, dq = threadIdx.x >> 6;
   float dot[4];
 #pragma unroll
@@ -1700,65 +1409,60 @@ __global__ __launch_bounds__(256) void bwd_du_kernel(const float* __restrict__ s
     vals[i] = cg * go - cu * u;
     du[((int64_t)b * D + d) * K + k] = vals[i];
   }
+  if (blk == 0 && dq == 0) cdu[b * K + k] = cg * bk - cu * dk;
   if (dut) {   // transposed float32 copy (float32-MFMA row-tile kernel only)
     float* trow = dut + ((int64_t)b * K + k) * D + blk * 64 + dq * 16;
 #pragma unroll
     for (int i = 0; i < 16; i += 4)
       *reinterpret_cast<f32x4*>(trow + i) = f32x4{vals[i], vals[i + 1], vals[i + 2], vals[i + 3]};
   }
-  if (dplanes) {
+  if (!duimg) return;                                      // (uniform over the launch)
+  {
+    // this thread's 16 channels are k-step s = 2 blk + (dq >> 1), lane groups g = 2 (dq & 1) and
+    // + 1, of wave k >> 4
     unsigned short h[3][16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) split3_bf16(vals[i], h[0][i], h[1][i], h[2][i]);
-    // chunk images (see split_w_kernel): chunk = blk, pieces 2 dq and 2 dq + 1, cluster k
-    uint4* img = reinterpret_cast<uint4*>(dplanes + (int64_t)b * 3 * D * K);
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
-      unsigned w[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-        w[i] = (unsigned)h[pl][2 * i] | ((unsigned)h[pl][2 * i + 1] << 16);
-      img[((blk * 3 + pl) * 8 + 2 * dq) * 64 + k] = make_uint4(w[0], w[1], w[2], w[3]);
-      img[((blk * 3 + pl) * 8 + 2 * dq + 1) * 64 + k] = make_uint4(w[4], w[5], w[6], w[7]);
-    }
-  }
-  if (duimg) {
-    // register image of vlad_bwd_kernel (see vlad_split_w_kernel): this thread's 16 channels are
-    // k-step s = 2 blk + (dq >> 1), lane groups g = 2 (dq & 1) and + 1, of wave k >> 4
-    unsigned short h[3][16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) split3_bf16(vals[i], h[0][i], h[1][i], h[2][i]);
-    uint4* img = reinterpret_cast<uint4*>(duimg + (int64_t)b * 3 * D * K);
+    uint4* img = reinterpret_cast<uint4*>(duimg + (int64_t)b * VF_NPL * D * K);
     const int wv = k >> 4, ii = k & 15, s = 2 * blk + (dq >> 1);
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
+    for (int pl = 0; pl < VF_NPL; ++pl) {
       unsigned w[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i)
         w[i] = (unsigned)h[pl][2 * i] | ((unsigned)h[pl][2 * i + 1] << 16);
       const int g0 = 2 * (dq & 1);
-      img[((wv * 16 + s) * 3 + pl) * 64 + 16 * g0 + ii] = make_uint4(w[0], w[1], w[2], w[3]);
-      img[((wv * 16 + s) * 3 + pl) * 64 + 16 * (g0 + 1) + ii] = make_uint4(w[4], w[5], w[6], w[7]);
+      img[((wv * 16 + s) * VF_NPL + pl) * 64 + 16 * g0 + ii] = make_uint4(w[0], w[1], w[2], w[3]);
+      img[((wv * 16 + s) * VF_NPL + pl) * 64 + 16 * (g0 + 1) + ii] = make_uint4(w[4], w[5], w[6], w[7]);
     }
   }
-  if (du2) {
-    // operands of dx16b_kernel: dU[b] and (from image 0's workgroups) W as high / low bf16
-    // planes [plane][d][k]
+  // the other orientation through LDS: tile[channel of the block][cluster]
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int d = blk * 64 + dq * 16 + i;
-      unsigned short h = f32_to_bf16(vals[i]);
-      du2[((int64_t)b * 2 * D + d) * K + k] = h;
-      du2[((int64_t)b * 2 * D + D + d) * K + k] = f32_to_bf16(vals[i] - bf16_to_f32(h));
-      if (b == 0) {
-        const float wv = assign_w[d * K + k];
-        h = f32_to_bf16(wv);
-        w2[d * K + k] = h;
-        w2[(D + d) * K + k] = f32_to_bf16(wv - bf16_to_f32(h));
-      }
+  for (int i = 0; i < 16; ++i) tile[(dq * 16 + i) * DU_TLD + k] = vals[i];
+  __syncthreads();
+  const int wv = blk >> 1;                                  // the block's channels: wave wv, tiles 4 (blk & 1) ..
+#pragma unroll
+  for (int rep = 0; rep < 2; ++rep) {
+    const int u = threadIdx.x + 256 * rep;                  // 512 units: (tile nt', k-step s, lane)
+    const int ntl = u >> 7, s = (u >> 6) & 1, lane = u & 63, i = lane & 15, gq = lane >> 4;
+    const float* row = &tile[(16 * ntl + i) * DU_TLD + 32 * s + 8 * gq];
+    const f32x4 v0{row[0], row[1], row[2], row[3]}, v1{row[4], row[5], row[6], row[7]};
+    u32x4 hi, lo;
+    split2x8(v0, v1, hi, lo);
+    u32x4* img = reinterpret_cast<u32x4*>(dximg) + (int64_t)b * (4 * 8 * 2 * 2 * 64) +
+                 (((wv * 8 + 4 * (blk & 1) + ntl) * 2 + s) * 2) * 64 + lane;
+    img[0] = hi;
+    img[64] = lo;
+    if (b == 0) {                                           // W in the same orientation
+      const float* wr = assign_w + (int64_t)(64 * blk + 16 * ntl + i) * K + 32 * s + 8 * gq;
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr), w1 = *reinterpret_cast<const f32x4*>(wr + 4);
+      split2x8(w0, w1, hi, lo);
+      u32x4* wimg = reinterpret_cast<u32x4*>(wdximg) +
+                    (((wv * 8 + 4 * (blk & 1) + ntl) * 2 + s) * 2) * 64 + lane;
+      wimg[0] = hi;
+      wimg[64] = lo;
     }
   }
-  if (blk == 0 && dq == 0) cdu[b * K + k] = cg * bk - cu * dk;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1951,170 +1655,6 @@ __global__ __launch_bounds__(256, 2) void dx16_kernel(const void* __restrict__ x
   }
 }
 
-// ---------------------------------------------------------------------------------------
-// dx16b_kernel: the same tile for a bf16 feature map on v_mfma_f32_16x16x32_bf16.  grad_x is
-// stored as bf16 (8 mantissa bits), so both operands are taken as TWO bf16 planes and
-// A.B = A_hi.B_hi + A_hi.B_lo + A_lo.B_hi (|error| <= 1.2e-5 of the term magnitudes, three
-// orders below the output rounding): 24 MFMAs of 16 cycles per 32-channel chunk instead of
-// 64 of 32.  A = [a | ds] rows of the tile, split in registers; B = [dU[b] | W] planes
-// [plane][d][k] written by bwd_du_kernel, staged per chunk as [plane][32 d][128 k (+8 pad)].
-constexpr int DXB_LD = 136;                               // bf16 per staged row (128 k + 8 pad)
-constexpr int DXB_CH = 64;                                // channels per staged chunk / barrier
-constexpr int DXB_CHUNK = 2 * DXB_CH * DXB_LD;            // bf16 per buffer (two planes)
-constexpr size_t kDx16bLds = 2 * (size_t)DXB_CHUNK * sizeof(unsigned short) +
-                             4 * (size_t)DX_SCR * sizeof(float);   // 69,632 + 9,216 B
-
-__device__ __forceinline__ void split2x8(const f32x4& a, const f32x4& b, u32x4& hi, u32x4& lo) {
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const float v0 = c < 2 ? a[2 * c] : b[2 * c - 4], v1 = c < 2 ? a[2 * c + 1] : b[2 * c - 3];
-    const unsigned short h0 = f32_to_bf16(v0), h1 = f32_to_bf16(v1);
-    hi[c] = (unsigned)h0 | ((unsigned)h1 << 16);
-    lo[c] = (unsigned)f32_to_bf16(v0 - bf16_to_f32(h0)) |
-            ((unsigned)f32_to_bf16(v1 - bf16_to_f32(h1)) << 16);
-  }
-}
-
-__global__ __launch_bounds__(256, 2) void dx16b_kernel(const unsigned short* __restrict__ xin,
-                                                       const float* __restrict__ a,
-                                                       const float* __restrict__ ds,
-                                                       const float* __restrict__ rn,
-                                                       const float* __restrict__ rowdot,
-                                                       const unsigned short* __restrict__ du2,
-                                                       const unsigned short* __restrict__ w2,
-                                                       int N, int pre_l2,
-                                                       unsigned short* __restrict__ gxo) {
-  extern __shared__ __attribute__((aligned(16))) float dx_lds[];
-  unsigned short* bl = reinterpret_cast<unsigned short*>(dx_lds);
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int i = lane & 15, g = lane >> 4;
-  const int b = blockIdx.y;
-  const int n0 = (blockIdx.x * 4 + wid) * 16;
-  const bool active = n0 < N;
-  float* scr = dx_lds + (2 * DXB_CHUNK) / 2 + wid * DX_SCR;
-  const unsigned short* dub = du2 + (int64_t)b * 2 * D * K;
-
-  // A operand: k-step s (32 of the 128 contraction indices): lane (i, g) holds
-  // [a | ds][n0 + i][32 s + 8 g .. + 7] as packed high and low bf16
-  u32x4 ah[4], al[4];
-  {
-    const bool ok = active && n0 + i < N;
-    const int64_t gr = (int64_t)b * N + (ok ? n0 + i : 0);
-#pragma unroll
-    for (int s2 = 0; s2 < 4; ++s2) {
-      const float* src = (s2 < 2 ? a : ds) + gr * K + 32 * (s2 & 1) + 8 * g;
-      f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
-      if (!ok) v0 = v1 = f32x4{0.f, 0.f, 0.f, 0.f};
-      split2x8(v0, v1, ah[s2], al[s2]);
-    }
-  }
-  // epilogue role of this lane: location row_e, channels 8 seg .. 8 seg + 7 of each chunk
-  const int row_e = lane >> 2, seg = lane & 3;
-  const bool ok_e = active && n0 + row_e < N;
-  const int64_t gr_e = (int64_t)b * N + (ok_e ? n0 + row_e : 0);
-  const float rn_e = pre_l2 ? rn[gr_e] : 1.0f;
-  const float rd_e = rowdot[gr_e];
-  const bool proj = pre_l2 && rn_e < 1.0e6f;
-  const unsigned short* x = xin + gr_e * D + seg * 8;
-  unsigned short* gx = gxo + gr_e * D + seg * 8;
-
-  // staging: 2 planes x 64 channels x 16 sixteen-byte pieces (8 of dU, 8 of W) = 2048 pieces
-  u32x4 st[8];
-  auto stage_load = [&](int chunk) {
-#pragma unroll
-    for (int v = 0; v < 8; ++v) {
-      const int idx = v * 256 + threadIdx.x;
-      const int pl = idx >> 10, dl = (idx >> 4) & 63, c = idx & 15;
-      const unsigned short* src =
-          c < 8 ? dub + ((int64_t)pl * D + chunk * DXB_CH + dl) * K + 8 * c
-                : w2 + ((int64_t)pl * D + chunk * DXB_CH + dl) * K + 8 * (c - 8);
-      st[v] = *reinterpret_cast<const u32x4*>(src);
-    }
-  };
-  auto stage_store = [&](int buf) {
-#pragma unroll
-    for (int v = 0; v < 8; ++v) {
-      const int idx = v * 256 + threadIdx.x;
-      const int pl = idx >> 10, dl = (idx >> 4) & 63, c = idx & 15;
-      *reinterpret_cast<u32x4*>(bl + buf * DXB_CHUNK + (pl * DXB_CH + dl) * DXB_LD + 8 * c) = st[v];
-    }
-  };
-
-  stage_load(0);
-  stage_store(0);
-  __syncthreads();
-#pragma unroll 1
-  for (int c = 0; c < D / DXB_CH; ++c) {
-    const bool more = c + 1 < D / DXB_CH;
-    if (more) stage_load(c + 1);
-    u32x4 xraw2[2] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
-    if (active && proj) {
-      xraw2[0] = *reinterpret_cast<const u32x4*>(x + c * DXB_CH);
-      xraw2[1] = *reinterpret_cast<const u32x4*>(x + c * DXB_CH + DX_CH);
-    }
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {      // two 32-channel blocks per staged chunk
-     const u32x4 xraw = xraw2[sub];
-     if (active) {
-      // B fragment of (channel tile dt, k-step s, plane pl): channel 16 dt + i, k 32 s + 8 g ..
-      const unsigned short* wb =
-          bl + (c & 1) * DXB_CHUNK + (DX_CH * sub + i) * DXB_LD + 8 * g;
-      f32x4 acc[2];
-      acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-      acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-      // fragments of step q + 1 (q = 2 * k-step + channel tile) fly under the MFMAs of step q
-      u32x4 bq[2][2];
-      bq[0][0] = *reinterpret_cast<const u32x4*>(wb);
-      bq[0][1] = *reinterpret_cast<const u32x4*>(wb + DXB_CH * DXB_LD);
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int s2 = q >> 1, dt = q & 1;
-        if (q + 1 < 8) {
-          const int s3 = (q + 1) >> 1, d3 = (q + 1) & 1;
-          bq[(q + 1) & 1][0] =
-              *reinterpret_cast<const u32x4*>(wb + (16 * d3) * DXB_LD + 32 * s3);
-          bq[(q + 1) & 1][1] =
-              *reinterpret_cast<const u32x4*>(wb + (DXB_CH + 16 * d3) * DXB_LD + 32 * s3);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        acc[dt] = mfma16b(ah[s2], bq[q & 1][0], acc[dt]);
-        acc[dt] = mfma16b(ah[s2], bq[q & 1][1], acc[dt]);
-        acc[dt] = mfma16b(al[s2], bq[q & 1][0], acc[dt]);
-      }
-      // transpose the [16 x 32] block: accumulator (row 4g+j, channel 16dt+i) -> rows
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) scr[(4 * g + j) * RT_LD + 16 * dt + i] = acc[dt][j];
-      __builtin_amdgcn_wave_barrier();
-      const f32x4 v0 = *reinterpret_cast<const f32x4*>(&scr[row_e * RT_LD + 8 * seg]);
-      const f32x4 v1 = *reinterpret_cast<const f32x4*>(&scr[row_e * RT_LD + 8 * seg + 4]);
-      __builtin_amdgcn_wave_barrier();
-      if (ok_e) {
-        float out[8];
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-          out[cc] = v0[cc];
-          out[4 + cc] = v1[cc];
-        }
-        if (proj) {
-          const float f = rn_e * rd_e;
-          float xv8[8];
-          Elem8<unsigned short>::cvt(xraw, xv8);
-#pragma unroll
-          for (int cc = 0; cc < 8; ++cc) out[cc] -= xv8[cc] * f;
-        }
-#pragma unroll
-        for (int cc = 0; cc < 8; ++cc) out[cc] *= rn_e;
-        Elem8<unsigned short>::st(gx + c * DXB_CH + DX_CH * sub, out);
-      }
-     }
-    }
-    if (more) stage_store((c + 1) & 1);
-    __syncthreads();
-  }
-}
-
 // vlad_dx_kernel: grad_x of one (image, location slice) for a bf16 feature map,
 //   dxhat[n, d] = sum_{k<64} a[n,k] dU[b][d,k] + ds[n,k] W[d,k],   grad_x = rn (dxhat - xhat <dxhat, xhat>)
 // with the operand [dU[b] | W] (128 x 512, two bf16 planes: A.B = Ah.Bh + Ah.Bl + Al.Bh, three
@@ -2139,8 +1679,8 @@ struct VladDxArgs {
   const float* ds;              // [B][N][64]
   const float* rn;              // [B][N]
   const float* rowdot;          // [B][N]
-  const unsigned short* du2;    // [B][2 planes][512][64] bf16 (bwd_du_kernel)
-  const unsigned short* w2;     // [2 planes][512][64] bf16
+  const unsigned short* dximg;  // [B] register images of dU (bwd_du_kernel)
+  const unsigned short* wdximg; // the same image of W
   int N, pre_l2, steps_per_slice;
   unsigned short* gx;           // [B][N][512] bf16
 };
@@ -2160,20 +1700,19 @@ __global__ __launch_bounds__(256, 1) void vlad_dx_kernel(VladDxArgs p) {
   const unsigned lds0 = nv_lds_byte_of(dxv_lds);
   const unsigned scr0 = lds0 + 2 * DXV_ABUF + wid * DXV_SCR;
 
-  // ---- the wave's operand: bw[nt][s][pl] = [dU | W]_plane[ch 128 w + 16 nt + i][k 32 s + 8 g ..]
+  // ---- the wave's operand: bw[nt][s][pl] = [dU | W]_plane[ch 128 w + 16 nt + i][k 32 s + 8 g ..],
+  // coalesced 16-byte loads from the register images bwd_du_kernel wrote
   u32x4 bw[8][4][2];
   {
-    const unsigned short* dub = p.du2 + (int64_t)b * 2 * D * K;
+    const u32x4* dimg = reinterpret_cast<const u32x4*>(p.dximg) + (int64_t)b * (4 * 8 * 2 * 2 * 64) + lane;
+    const u32x4* wimg = reinterpret_cast<const u32x4*>(p.wdximg) + lane;
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
-          const unsigned short* src = (s < 2 ? dub : p.w2) +
-                                      ((int64_t)pl * D + 128 * wid + 16 * nt + i) * K + 32 * (s & 1) + 8 * g;
-          bw[nt][s][pl] = *reinterpret_cast<const u32x4*>(src);
-        }
+        for (int pl = 0; pl < 2; ++pl)
+          bw[nt][s][pl] = (s < 2 ? dimg : wimg)[(((wid * 8 + nt) * 2 + (s & 1)) * 2 + pl) * 64];
   }
 
   // staging role: k-step wid of the tile: [a | ds][n0 + i][32 (wid & 1) + 8 g .. + 7]
@@ -2198,38 +1737,33 @@ __global__ __launch_bounds__(256, 1) void vlad_dx_kernel(VladDxArgs p) {
   const unsigned short* xb = p.x + (int64_t)b * p.N * D + 128 * wid + 8 * ec;
   unsigned short* gb = p.gx + (int64_t)b * p.N * D + 128 * wid + 8 * ec;
 
-  f32x4 pa0, pa1;
-  a_load(0, pa0, pa1);
-  a_stage(0, pa0, pa1);
-  if (ntile > 1) a_load(1, pa0, pa1);
-  __syncthreads();
-
-#pragma unroll 1
-  for (int tt = 0; tt < ntile; ++tt) {
-    const int n0 = n_lo + 16 * tt;
-    // the epilogue's inputs, in flight under the matrix work
+  // Software pipeline over the 16-location tiles: the matrix work of tile tt and the epilogue of
+  // tile tt - 1 (scratch transpose, projection, stores — vector and LDS instructions only) are
+  // independent and sit in one basic block, so they share the SIMD: an MFMA holds the vector
+  // issue port for 8 of its 16 cycles, the epilogue fits into the other 8.
+  struct EpiIn {
     u32x4 xr[4];
     float rn4[4], rd4[4];
-    bool okr[4];
+    int n0;
+  };
+  auto epi_load = [&](int tt, EpiIn& e) {
+    e.n0 = n_lo + 16 * tt;
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      const int n = n0 + el + 4 * v;
-      okr[v] = n < n_hi;
-      const int64_t nn = okr[v] ? n : n_hi - 1;
-      xr[v] = *reinterpret_cast<const u32x4*>(xb + nn * D);
-      rn4[v] = p.pre_l2 ? p.rn[(int64_t)b * p.N + nn] : 1.0f;
-      rd4[v] = p.rowdot[(int64_t)b * p.N + nn];
+      const int n = e.n0 + el + 4 * v;
+      const int64_t nn = n < n_hi ? n : n_hi - 1;
+      e.xr[v] = *reinterpret_cast<const u32x4*>(xb + nn * D);
+      e.rn4[v] = p.pre_l2 ? p.rn[(int64_t)b * p.N + nn] : 1.0f;
+      e.rd4[v] = p.rowdot[(int64_t)b * p.N + nn];
     }
-    // A fragments of the tile (B operand of the swapped product): [s][plane]
+  };
+  auto tile_mfma = [&](int tt, f32x4 (&acc)[8]) {
     u32x4 af[4][2];
-    {
-      const unsigned base = lds0 + (tt & 1) * DXV_ABUF + lane * 16;
+    const unsigned base = lds0 + (tt & 1) * DXV_ABUF + lane * 16;
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl) af[s][pl] = vf_ldsr128(base + (s * 2 + pl) * 1024);
-    }
-    f32x4 acc[8];
+      for (int pl = 0; pl < 2; ++pl) af[s][pl] = vf_ldsr128(base + (s * 2 + pl) * 1024);
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) {
       acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -2240,39 +1774,63 @@ __global__ __launch_bounds__(256, 1) void vlad_dx_kernel(VladDxArgs p) {
         acc[nt] = mfma16b(bw[nt][s][0], af[s][0], acc[nt]);    // Bh . Ah
       }
     }
-    // next tile's fragments into the other buffer (its last readers finished before the
-    // barrier that ended the previous tile)
-    if (tt + 1 < ntile) {
-      a_stage((tt + 1) & 1, pa0, pa1);
-      if (tt + 2 < ntile) a_load(tt + 2, pa0, pa1);
-    }
-    // ---- transpose through the wave's scratch: lane (i = location, g) holds channels
-    // 16 nt + 4 g .. + 3 -> rows of 128 channels
+  };
+  auto epilogue = [&](const f32x4 (&acc)[8], const EpiIn& e) {
+    // transpose through the wave's scratch: lane (i = location, g) holds channels
+    // 16 nt + 4 g .. + 3 -> rows of 128 channels (LDS serves a wave's accesses in order)
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt)
       *(__attribute__((address_space(3))) f32x4*)(size_t)(scr0 + i * DXV_SLD + (16 * nt + 4 * g) * 4) = acc[nt];
-    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       const unsigned ra = scr0 + (el + 4 * v) * DXV_SLD + ec * 32;
       const f32x4 d0 = *(const __attribute__((address_space(3))) f32x4*)(size_t)(ra);
       const f32x4 d1 = *(const __attribute__((address_space(3))) f32x4*)(size_t)(ra + 16);
       float out[8] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
-      const float rnv = rn4[v];
+      const float rnv = e.rn4[v];
       // x * rsqrt(max(ss, eps)): with the clamp active the op is a plain scale (no projection)
-      if (p.pre_l2 && rnv < 1.0e6f) {
-        const float f = rnv * rd4[v];
-        float xv8[8];
-        Elem8<unsigned short>::cvt(xr[v], xv8);
+      const float f = (p.pre_l2 && rnv < 1.0e6f) ? rnv * e.rd4[v] : 0.f;
+      float xv8[8];
+      Elem8<unsigned short>::cvt(e.xr[v], xv8);
 #pragma unroll
-        for (int cc = 0; cc < 8; ++cc) out[cc] -= xv8[cc] * f;
-      }
-#pragma unroll
-      for (int cc = 0; cc < 8; ++cc) out[cc] *= rnv;
-      if (okr[v]) Elem8<unsigned short>::st(gb + (int64_t)(n0 + el + 4 * v) * D, out);
+      for (int cc = 0; cc < 8; ++cc) out[cc] = (out[cc] - xv8[cc] * f) * rnv;
+      if (e.n0 + el + 4 * v < n_hi) Elem8<unsigned short>::st(gb + (int64_t)(e.n0 + el + 4 * v) * D, out);
     }
-    __syncthreads();       // fragment buffer (tt + 1) & 1 complete; scratch free for the next tile
+  };
+
+  f32x4 pa0, pa1;
+  a_load(0, pa0, pa1);
+  a_stage(0, pa0, pa1);
+  if (ntile > 1) a_load(1, pa0, pa1);
+  __syncthreads();
+
+  f32x4 accp[8];
+  EpiIn ep;
+  epi_load(0, ep);
+  tile_mfma(0, accp);
+  if (ntile > 1) {
+    a_stage(1, pa0, pa1);
+    if (ntile > 2) a_load(2, pa0, pa1);
   }
+  __syncthreads();
+#pragma unroll 1
+  for (int tt = 1; tt < ntile; ++tt) {
+    f32x4 accc[8];
+    EpiIn ec2;
+    epi_load(tt, ec2);
+    tile_mfma(tt, accc);
+    epilogue(accp, ep);
+    // next tile's fragments into the other buffer (its readers finished before the last barrier)
+    if (tt + 1 < ntile) {
+      a_stage((tt + 1) & 1, pa0, pa1);
+      if (tt + 2 < ntile) a_load(tt + 2, pa0, pa1);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) accp[nt] = accc[nt];
+    ep = ec2;
+  }
+  epilogue(accp, ep);
 }
 
 // grad_w[d,k] = sum_b sum_s slab[b][s][d,k];  grad_c[d,k] = sum_b dU[b,d,k] * asum[b,k].
@@ -2308,7 +1866,7 @@ template <typename T, int VAR>
 void launch_variant_one(const RowTileArgs& a, dim3 grid, hipStream_t st) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowtile16_kernel<T, ASSIGN, VAR>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRowTile16Lds);
-  SCL_LAUNCH("rowtile_assign", (rowtile16_kernel<T, ASSIGN, VAR>), grid, dim3(256), kRowTile16Lds,
+  SCL_LAUNCH("rowtile16_kernel<ASSIGN>", (rowtile16_kernel<T, ASSIGN, VAR>), grid, dim3(256), kRowTile16Lds,
              st, a);
 }
 template <typename T>
@@ -2337,36 +1895,13 @@ void launch_rowtile(const RowTileArgs& a, hipStream_t st) {
     launch_rowtile_variant<T>(a, grid, st);
     return;
   }
-  SCL_LAUNCH(MODE == ASSIGN ? "rowtile_assign" : "rowtile_dassign", (rowtile16_kernel<T, MODE>),
+  SCL_LAUNCH(MODE == ASSIGN ? "rowtile16_kernel<ASSIGN>" : "rowtile16_kernel<DASSIGN>", (rowtile16_kernel<T, MODE>),
              grid, dim3(256), kRowTile16Lds, st, a);
 }
 
-// bf16 feature maps: the bf16x3 kernel (scl_debug_set_variant(8) forces the float32-MFMA
-// kernel on them for A/B timing and parity runs)
-template <int MODE>
-void launch_rowtile_b3(const RowTileArgs& a, hipStream_t st) {
-  static std::once_flag once;
-  std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowtile_ring_kernel<MODE>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRowTileRingLds);
-  });
-  RowTileArgs ad = a;
-  ad.dbg = (scl_debug_variant == 21 || scl_debug_variant == 22) ? scl_debug_variant : 0;
-  SCL_LAUNCH(MODE == ASSIGN ? "rowtile_assign" : "rowtile_dassign", (rowtile_ring_kernel<MODE>),
-             dim3((a.N + 127) / 128, a.B), dim3(256), kRowTileRingLds, st, ad);
-}
-inline void launch_aggregate_b3(const char* name, const void* x, const float* coefn,
-                                const float* rn, int B, int N, float* part, float* colsum,
-                                hipStream_t st) {
-  static std::once_flag once;
-  std::call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&aggregate16b_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAgg16bLds);
-  });
-  SCL_LAUNCH(name, aggregate16b_kernel, dim3(2, NSPLIT, B), dim3(256), kAgg16bLds, st,
-             (const unsigned short*)x, coefn, rn, N, part, colsum);
-}
-inline bool use_b3() { return scl_debug_variant < 1 || scl_debug_variant > 8; }
+// bf16 feature maps take the fused kernels; scl_debug_set_variant(1 .. 8) sends them through the
+// float32-MFMA kernels instead (A/B timing and parity runs)
+inline bool use_fused() { return scl_debug_variant < 1 || scl_debug_variant > 8; }
 
 struct Carver {
   char* base;
@@ -2406,7 +1941,7 @@ inline VladPlan vlad_plan(int B, int N) {
 struct FwdWs {
   float *wt, *part, *colsum, *colsq, *vlad, *assign, *rnorm, *trash;
   unsigned long long* stamps;   // diagnostics: [B * S][32], the LAST bytes of the workspace
-  unsigned short* wplanes;   // bf16x3 register images of W^T (3 * 64 * 512 bf16)
+  unsigned short* wplanes;      // register image of W^T (vlad_split_w_kernel)
   size_t total;
 };
 inline FwdWs carve_fwd(void* ws, int B, int N) {
@@ -2421,7 +1956,7 @@ inline FwdWs carve_fwd(void* ws, int B, int N) {
   w.vlad = c.take((size_t)B * (D + 1) * K);
   w.assign = c.take((size_t)B * N * K);
   w.rnorm = c.take((size_t)B * N);
-  w.wplanes = (unsigned short*)c.take((size_t)3 * D * K / 2);
+  w.wplanes = (unsigned short*)c.take((size_t)VF_WREP * VF_WIMG / 2);
   w.stamps = (unsigned long long*)c.take((size_t)B * S * 32 * 2);
   w.total = c.off;
   return w;
@@ -2429,9 +1964,9 @@ inline FwdWs carve_fwd(void* ws, int B, int N) {
 
 struct BwdWs {
   float *du, *dut, *cdu, *ds, *rowdot, *wpart, *dots, *wpartial, *trash;
-  unsigned short* dplanes;   // [B] bf16x3 chunk images of dU^T
-  unsigned short* du2;       // [B][2][512][64] bf16 planes of dU
-  unsigned short* w2;        // [2][512][64] bf16 planes of W
+  unsigned short* duimg;     // [B] register images of dU^T for vlad_bwd_kernel
+  unsigned short* dximg;     // [B] register images of dU for vlad_dx_kernel (2 planes)
+  unsigned short* wdximg;    // the same image of W
   size_t total;
 };
 inline BwdWs carve_bwd(void* ws, int B, int N) {
@@ -2446,10 +1981,10 @@ inline BwdWs carve_bwd(void* ws, int B, int N) {
   w.wpart = c.take((size_t)B * S * D * K);
   w.wpartial = c.take((size_t)VW_GROUPS * D * K);
   w.trash = c.take(256);
-  w.dplanes = (unsigned short*)c.take((size_t)B * 3 * D * K / 2);
   w.dots = c.take((size_t)B * 8 * 4 * K);
-  w.du2 = (unsigned short*)c.take((size_t)B * 2 * D * K / 2);
-  w.w2 = (unsigned short*)c.take((size_t)2 * D * K / 2);
+  w.duimg = (unsigned short*)c.take((size_t)B * VF_NPL * D * K / 2);
+  w.dximg = (unsigned short*)c.take((size_t)B * 2 * D * K / 2);
+  w.wdximg = (unsigned short*)c.take((size_t)2 * D * K / 2);
   w.total = c.off;
   return w;
 }
@@ -2479,10 +2014,49 @@ extern "C" int scl_netvlad_fwd(const void* x, int x_dtype, const float* assign_w
   float* assign = save_assign ? save_assign : w.assign;
   float* rnorm = save_rnorm ? save_rnorm : w.rnorm;
 
-  const bool fwd_b3 = x_dtype == SCL_DT_BF16 && use_b3();
-  if (!fwd_b3)
-    SCL_LAUNCH("transpose_w_kernel", transpose_w_kernel, dim3(D * K / 256), dim3(256), 0, st, assign_w,
-               w.wt);
+  if (x_dtype == SCL_DT_BF16 && use_fused()) {
+    // one pass over x: soft-assignment and aggregation fused
+    static std::once_flag once;
+    std::call_once(once, [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vlad_fwd_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVladFusedLds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vlad_fwd_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVladFusedLds);
+    });
+    const VladPlan pl = vlad_plan(B, N);
+    SCL_LAUNCH("vlad_split_w_kernel", vlad_split_w_kernel, dim3(64, VF_WREP), dim3(64), 0, st,
+               assign_w, w.wplanes);
+    VladFwdArgs fa{};
+    fa.x = (const unsigned short*)x;
+    fa.wimg = w.wplanes;
+    fa.N = N;
+    fa.pre_l2 = pre_l2 ? 1 : 0;
+    fa.steps_per_slice = pl.steps_per_slice;
+    fa.slab = w.part;
+    fa.colsum = w.colsum;
+    fa.trash = w.trash;
+    fa.dbg = scl_debug_variant == 916 ? 16 : 0;           // scripts/vlad_stamps.py
+    fa.stamps = w.stamps;
+    if (save_assign && save_logit && save_rnorm) {
+      fa.assign = save_assign;
+      fa.logit = save_logit;
+      fa.rnorm = save_rnorm;
+      SCL_LAUNCH("vlad_fwd_kernel<true>", vlad_fwd_kernel<true>, dim3(B, pl.S), dim3(256),
+                 kVladFusedLds, st, fa);
+    } else {
+      SCL_LAUNCH("vlad_fwd_kernel<false>", vlad_fwd_kernel<false>, dim3(B, pl.S), dim3(256),
+                 kVladFusedLds, st, fa);
+    }
+    float* vlad = save_vlad ? save_vlad : w.vlad;
+    SCL_LAUNCH("vlad_finish_sum_kernel", vlad_finish_sum_kernel, dim3(B, 32), dim3(256), 0, st,
+               (const float*)w.part, (const float*)w.colsum, centers, pl.S, vlad, w.colsq);
+    SCL_LAUNCH("finish_norm_kernel", finish_norm_kernel, dim3(8, B), dim3(256), 0, st,
+               (const float*)vlad, (const float*)w.colsq, 32, out);
+    return scl_launch_status();
+  }
+  // float32 feature maps (and bf16 ones under scl_debug_set_variant(1 .. 8)): float32-MFMA kernels
+  SCL_LAUNCH("transpose_w_kernel", transpose_w_kernel, dim3(D * K / 256), dim3(256), 0, st, assign_w,
+             w.wt);
   RowTileArgs a{};
   a.x = x;
   a.bt = w.wt;
@@ -2495,62 +2069,12 @@ extern "C" int scl_netvlad_fwd(const void* x, int x_dtype, const float* assign_w
   a.rnorm = rnorm;
   if (x_dtype == SCL_DT_F32) {
     launch_rowtile<float, ASSIGN>(a, st);
-    SCL_LAUNCH("aggregate_kernel", aggregate_kernel<float>, dim3(D / 64, NSPLIT, B), dim3(256), 0, st, x,
-                       (const float*)assign, (const float*)rnorm, N, w.part, w.colsum);
+    SCL_LAUNCH("aggregate_kernel<float>", aggregate_kernel<float>, dim3(D / 64, NSPLIT, B), dim3(256), 0,
+               st, x, (const float*)assign, (const float*)rnorm, N, w.part, w.colsum);
   } else {
-    if (fwd_b3 && scl_debug_variant != 9) {
-      // one pass over x: soft-assignment and aggregation fused (9: the two-kernel form, A/B)
-      static std::once_flag once;
-      std::call_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vlad_fwd_kernel<true>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVladFusedLds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vlad_fwd_kernel<false>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVladFusedLds);
-      });
-      const VladPlan pl = vlad_plan(B, N);
-      SCL_LAUNCH("vlad_split_w_kernel", vlad_split_w_kernel, dim3(64), dim3(64), 0, st, assign_w,
-                 w.wplanes);
-      VladFwdArgs fa{};
-      fa.x = (const unsigned short*)x;
-      fa.wimg = w.wplanes;
-      fa.N = N;
-      fa.pre_l2 = pre_l2 ? 1 : 0;
-      fa.steps_per_slice = pl.steps_per_slice;
-      fa.slab = w.part;
-      fa.colsum = w.colsum;
-      fa.trash = w.trash;
-      fa.dbg = (scl_debug_variant >= 900 && scl_debug_variant < 932) ? scl_debug_variant - 900 : 0;
-      fa.stamps = w.stamps;
-      const bool save = save_assign && save_logit && save_rnorm;
-      if (save) {
-        fa.assign = save_assign;
-        fa.logit = save_logit;
-        fa.rnorm = save_rnorm;
-        SCL_LAUNCH("vlad_fwd_kernel<true>", vlad_fwd_kernel<true>, dim3(B, pl.S), dim3(256),
-                   kVladFusedLds, st, fa);
-      } else {
-        SCL_LAUNCH("vlad_fwd_kernel<false>", vlad_fwd_kernel<false>, dim3(B, pl.S), dim3(256),
-                   kVladFusedLds, st, fa);
-      }
-      float* vlad = save_vlad ? save_vlad : w.vlad;
-      SCL_LAUNCH("vlad_finish_sum_kernel", vlad_finish_sum_kernel, dim3(B, 32), dim3(256), 0, st,
-                 (const float*)w.part, (const float*)w.colsum, centers, pl.S, vlad, w.colsq);
-      SCL_LAUNCH("finish_norm_kernel", finish_norm_kernel, dim3(8, B), dim3(256), 0, st,
-                 (const float*)vlad, (const float*)w.colsq, 32, out);
-      return scl_launch_status();
-    } else if (fwd_b3) {
-      SCL_LAUNCH("split_w_kernel", split_w_kernel, dim3((D / 8) * K / 256), dim3(256), 0, st,
-                 assign_w, w.wplanes);
-      a.btp = w.wplanes;
-      a.btp_stride = 0;
-      launch_rowtile_b3<ASSIGN>(a, st);
-      launch_aggregate_b3("aggregate_kernel", x, (const float*)assign, (const float*)rnorm, B, N,
-                          w.part, w.colsum, st);
-    } else {
-      launch_rowtile<unsigned short, ASSIGN>(a, st);
-      SCL_LAUNCH("aggregate_kernel", aggregate_kernel<unsigned short>, dim3(D / 64, NSPLIT, B), dim3(256), 0, st,
-                         x, (const float*)assign, (const float*)rnorm, N, w.part, w.colsum);
-    }
+    launch_rowtile<unsigned short, ASSIGN>(a, st);
+    SCL_LAUNCH("aggregate_kernel<bf16>", aggregate_kernel<unsigned short>, dim3(D / 64, NSPLIT, B),
+               dim3(256), 0, st, x, (const float*)assign, (const float*)rnorm, N, w.part, w.colsum);
   }
   float* vlad = save_vlad ? save_vlad : w.vlad;
   SCL_LAUNCH("finish_sum_kernel", finish_sum_kernel, dim3(8, B), dim3(256), 0, st,
@@ -2582,15 +2106,12 @@ extern "C" int scl_netvlad_bwd(const void* x, int x_dtype, const float* assign_w
   if (workspace_bytes < w.total) return SCL_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
 
-  const bool b3 = x_dtype == SCL_DT_BF16 && use_b3();
-  const bool fused = b3 && scl_debug_variant != 9;      // 9: the two-kernel form (A/B)
+  const bool fused = x_dtype == SCL_DT_BF16 && use_fused();
   SCL_LAUNCH("bwd_dots_kernel", bwd_dots_kernel, dim3(8, B), dim3(256), 0, st, save_vlad, grad_out,
              centers, w.dots);
   SCL_LAUNCH("bwd_du_kernel", bwd_du_kernel, dim3(8, B), dim3(256), 0, st, save_vlad, grad_out,
-             (const float*)w.dots, w.du, b3 ? (float*)nullptr : w.dut,
-             b3 && !fused ? w.dplanes : (unsigned short*)nullptr,
-             fused ? w.dplanes : (unsigned short*)nullptr,
-             b3 ? w.du2 : (unsigned short*)nullptr, assign_w, w.w2, w.cdu);
+             (const float*)w.dots, w.du, fused ? (float*)nullptr : w.dut,
+             fused ? w.duimg : (unsigned short*)nullptr, w.dximg, assign_w, w.wdximg, w.cdu);
   if (fused) {
     static std::once_flag once;
     std::call_once(once, [] {
@@ -2602,7 +2123,7 @@ extern "C" int scl_netvlad_bwd(const void* x, int x_dtype, const float* assign_w
     const VladPlan pl = vlad_plan(B, N);
     VladBwdArgs ba{};
     ba.x = (const unsigned short*)x;
-    ba.duimg = w.dplanes;
+    ba.duimg = w.duimg;
     ba.a = save_assign;
     ba.lg = save_logit;
     ba.rn = save_rnorm;
@@ -2614,27 +2135,19 @@ extern "C" int scl_netvlad_bwd(const void* x, int x_dtype, const float* assign_w
     ba.slab = w.wpart;
     ba.trash = w.trash;
     SCL_LAUNCH("vlad_bwd_kernel", vlad_bwd_kernel, dim3(B, pl.S), dim3(256), kVladFusedLds, st, ba);
-    if (scl_debug_variant == 10) {               // 10: the LDS-streamed grad_x kernel (A/B)
-      const dim3 dxg(((N + 15) / 16 + 3) / 4, B);
-      SCL_LAUNCH("dx16b_kernel", dx16b_kernel, dxg, dim3(256), kDx16bLds, st,
-                 (const unsigned short*)x, save_assign, (const float*)w.ds, save_rnorm,
-                 (const float*)w.rowdot, (const unsigned short*)w.du2, (const unsigned short*)w.w2,
-                 N, pre_l2 ? 1 : 0, (unsigned short*)grad_x);
-    } else {
-      VladDxArgs da{};
-      da.x = (const unsigned short*)x;
-      da.a = save_assign;
-      da.ds = w.ds;
-      da.rn = save_rnorm;
-      da.rowdot = w.rowdot;
-      da.du2 = w.du2;
-      da.w2 = w.w2;
-      da.N = N;
-      da.pre_l2 = pre_l2 ? 1 : 0;
-      da.steps_per_slice = pl.steps_per_slice;
-      da.gx = (unsigned short*)grad_x;
-      SCL_LAUNCH("vlad_dx_kernel", vlad_dx_kernel, dim3(B, pl.S), dim3(256), kVladDxLds, st, da);
-    }
+    VladDxArgs da{};
+    da.x = (const unsigned short*)x;
+    da.a = save_assign;
+    da.ds = w.ds;
+    da.rn = save_rnorm;
+    da.rowdot = w.rowdot;
+    da.dximg = w.dximg;
+    da.wdximg = w.wdximg;
+    da.N = N;
+    da.pre_l2 = pre_l2 ? 1 : 0;
+    da.steps_per_slice = pl.steps_per_slice;
+    da.gx = (unsigned short*)grad_x;
+    SCL_LAUNCH("vlad_dx_kernel", vlad_dx_kernel, dim3(B, pl.S), dim3(256), kVladDxLds, st, da);
     SCL_LAUNCH("vlad_wgrad_partial_kernel", vlad_wgrad_partial_kernel, dim3(32, VW_GROUPS), dim3(256),
                0, st, (const float*)w.wpart, pl.S * B, w.wpartial);
     SCL_LAUNCH("vlad_wgrad_finish_kernel", vlad_wgrad_finish_kernel, dim3(32), dim3(256), 0, st,
@@ -2657,33 +2170,18 @@ extern "C" int scl_netvlad_bwd(const void* x, int x_dtype, const float* assign_w
   const dim3 dxgrid(((N + 15) / 16 + 3) / 4, B);
   if (x_dtype == SCL_DT_F32) {
     launch_rowtile<float, DASSIGN>(a, st);
-    SCL_LAUNCH("aggregate_dw", aggregate_kernel<float>, dim3(D / 64, NSPLIT, B), dim3(256), 0, st, x,
-                       (const float*)w.ds, save_rnorm, N, w.wpart, (float*)nullptr);
-    SCL_LAUNCH("dx_kernel", dx16_kernel<float>, dxgrid, dim3(256), kDx16Lds, st, x, save_assign,
-                       (const float*)w.ds, save_rnorm, (const float*)w.rowdot,
-                       (const float*)w.du, assign_w, N, pre_l2 ? 1 : 0, grad_x);
+    SCL_LAUNCH("aggregate_kernel<float>", aggregate_kernel<float>, dim3(D / 64, NSPLIT, B), dim3(256), 0,
+               st, x, (const float*)w.ds, save_rnorm, N, w.wpart, (float*)nullptr);
+    SCL_LAUNCH("dx16_kernel<float>", dx16_kernel<float>, dxgrid, dim3(256), kDx16Lds, st, x, save_assign,
+               (const float*)w.ds, save_rnorm, (const float*)w.rowdot, (const float*)w.du, assign_w,
+               N, pre_l2 ? 1 : 0, grad_x);
   } else {
-    if (b3) {
-      a.btp = w.dplanes;
-      a.btp_stride = (int64_t)3 * D * K;
-      launch_rowtile_b3<DASSIGN>(a, st);
-      launch_aggregate_b3("aggregate_dw", x, (const float*)w.ds, save_rnorm, B, N, w.wpart,
-                          nullptr, st);
-    } else {
-      launch_rowtile<unsigned short, DASSIGN>(a, st);
-      SCL_LAUNCH("aggregate_dw", aggregate_kernel<unsigned short>, dim3(D / 64, NSPLIT, B), dim3(256), 0, st,
-                         x, (const float*)w.ds, save_rnorm, N, w.wpart, (float*)nullptr);
-    }
-    if (b3) {
-      SCL_LAUNCH("dx_kernel", dx16b_kernel, dxgrid, dim3(256), kDx16bLds, st,
-                 (const unsigned short*)x, save_assign, (const float*)w.ds, save_rnorm,
-                 (const float*)w.rowdot, (const unsigned short*)w.du2,
-                 (const unsigned short*)w.w2, N, pre_l2 ? 1 : 0, (unsigned short*)grad_x);
-    } else {
-      SCL_LAUNCH("dx_kernel", dx16_kernel<unsigned short>, dxgrid, dim3(256), kDx16Lds, st, x, save_assign,
-                         (const float*)w.ds, save_rnorm, (const float*)w.rowdot,
-                         (const float*)w.du, assign_w, N, pre_l2 ? 1 : 0, grad_x);
-    }
+    launch_rowtile<unsigned short, DASSIGN>(a, st);
+    SCL_LAUNCH("aggregate_kernel<bf16>", aggregate_kernel<unsigned short>, dim3(D / 64, NSPLIT, B),
+               dim3(256), 0, st, x, (const float*)w.ds, save_rnorm, N, w.wpart, (float*)nullptr);
+    SCL_LAUNCH("dx16_kernel<bf16>", dx16_kernel<unsigned short>, dxgrid, dim3(256), kDx16Lds, st, x,
+               save_assign, (const float*)w.ds, save_rnorm, (const float*)w.rowdot,
+               (const float*)w.du, assign_w, N, pre_l2 ? 1 : 0, grad_x);
   }
   SCL_LAUNCH("wgrad_finish_kernel", wgrad_finish_kernel, dim3(D * K / 64), dim3(256), 0, st,
                      (const float*)w.wpart, (const float*)w.du, save_vlad, B, grad_w, grad_c);
