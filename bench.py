@@ -106,48 +106,61 @@ def parse():
     return ap.parse_args()
 
 
-def kernel_models(b, n, gb, x_bytes):
+# kernels of the NetVLAD head, by pass (names = the kernels' own names, as rocprofv3 prints them)
+NETVLAD_FWD = ('vlad_split_w_kernel', 'vlad_fwd_kernel<true>', 'vlad_fwd_kernel<false>',
+               'vlad_finish_sum_kernel', 'finish_norm_kernel', 'transpose_w_kernel',
+               'rowtile16_kernel<ASSIGN>', 'aggregate_kernel<float>', 'aggregate_kernel<bf16>',
+               'finish_sum_kernel')
+NETVLAD_BWD = ('bwd_dots_kernel', 'bwd_du_kernel', 'vlad_bwd_kernel', 'vlad_dx_kernel',
+               'vlad_wgrad_partial_kernel', 'vlad_wgrad_finish_kernel', 'rowtile16_kernel<DASSIGN>',
+               'dx16_kernel<float>', 'dx16_kernel<bf16>', 'wgrad_finish_kernel')
+
+
+def kernel_models(b, n, gb, x_bytes, slices=10):
     """Algorithmic flops / bytes per LAUNCH of each hand-written kernel.
-    b = images on this GPU, n = locations per image, gb = global batch."""
+    b = images on this GPU, n = locations per image, gb = global batch, slices = location slices
+    per image of the fused NetVLAD kernels (10 at 24 x 1200 on 256 CUs)."""
     bn = b * n
-    # bf16 feature maps: the NetVLAD contractions run as three bf16 MFMAs per step (x exact and
-    # the float32 operand split into three bf16 planes; two planes each in the grad_x kernel)
-    # -> priced against the bf16 dense peak with 3x the algorithmic flops executed
-    b3 = dict(peak_tflops=PEAK_BF16_TFLOPS, exec_mult=3.0) if x_bytes == 2 else {}
+    slab = b * slices * D * K * 4
+    # bf16 feature maps: the float32 operands of the NetVLAD contractions are split into bf16
+    # planes (two in the fused assign / aggregate kernels: 2 products per algorithmic one; two
+    # per side in the grad_x kernel: 3 products) -> priced against the bf16 dense peak with the
+    # flops they execute
+    b2 = dict(peak_tflops=PEAK_BF16_TFLOPS, exec_mult=2.0)
+    b3 = dict(peak_tflops=PEAK_BF16_TFLOPS, exec_mult=3.0)
     return {
-        # x·W over all locations; reads x once, writes a (+ logits) and rn
-        'rowtile_assign': dict(flops=2.0 * bn * D * K, bytes=bn * D * x_bytes + bn * K * 8 + bn * 4,
-                               **b3),
-        # x^T·(a rn); reads x and a once, writes 2 slabs per image
-        'aggregate_kernel': dict(flops=2.0 * bn * D * K,
-                                 bytes=bn * D * x_bytes + bn * K * 4 + b * 2 * D * K * 4, **b3),
         # fused soft-assignment + aggregation of one (image, slice): x once; a, logits, rn and
-        # the slices' slabs out (slab count from the launch: ~10 per image at 24 x 1200)
+        # the slices' slabs out
         'vlad_fwd_kernel<true>': dict(flops=4.0 * bn * D * K,
-                                      bytes=bn * D * x_bytes + bn * K * 8 + bn * 4 + b * 10 * D * K * 4, **b3),
-        'vlad_fwd_kernel<false>': dict(flops=4.0 * bn * D * K,
-                                       bytes=bn * D * x_bytes + b * 10 * D * K * 4, **b3),
+                                      bytes=bn * D * 2 + bn * K * 8 + bn * 4 + slab, **b2),
+        'vlad_fwd_kernel<false>': dict(flops=4.0 * bn * D * K, bytes=bn * D * 2 + slab, **b2),
         # fused x.dU + softmax backward + x^T.(ds rn): x, a, logits, rn in; ds, rowdot, slabs out
         'vlad_bwd_kernel': dict(flops=4.0 * bn * D * K,
-                                bytes=bn * D * x_bytes + bn * K * 12 + bn * 8 + b * 10 * D * K * 4
-                                + b * D * K * 6, **b3),
-        'dx16b_kernel': dict(flops=4.0 * bn * D * K, bytes=2 * bn * D * x_bytes + bn * K * 8, **b3),
-        'vlad_dx_kernel': dict(flops=4.0 * bn * D * K, bytes=2 * bn * D * x_bytes + bn * K * 8, **b3),
-        'vlad_wgrad_partial_kernel': dict(flops=b * 10.0 * D * K, bytes=b * 10 * D * K * 4),
+                                bytes=bn * D * 2 + bn * K * 12 + bn * 8 + slab + b * D * K * 4, **b2),
+        # [a|ds].[dU|W]^T then the norm Jacobian: x, a, ds in, grad_x out, the operand once per slice
+        'vlad_dx_kernel': dict(flops=4.0 * bn * D * K,
+                               bytes=4 * bn * D + bn * K * 8 + b * slices * 2 * D * K * 4, **b3),
+        'vlad_wgrad_partial_kernel': dict(flops=b * slices * D * K, bytes=slab),
         'vlad_wgrad_finish_kernel': dict(flops=4.0 * b * D * K, bytes=b * D * K * 4 + 9 * D * K * 4),
-        'vlad_split_w_kernel': dict(flops=0.0, bytes=D * K * 10),
-        'vlad_finish_sum_kernel': dict(flops=6.0 * b * D * K, bytes=b * D * K * 4 * 12),
-        'finish_sum_kernel': dict(flops=6.0 * b * D * K, bytes=b * D * K * 4 * 6),
+        'vlad_split_w_kernel': dict(flops=0.0, bytes=D * K * 8),
+        'vlad_finish_sum_kernel': dict(flops=(slices + 2.0) * b * D * K, bytes=slab + b * D * K * 8),
         'finish_norm_kernel': dict(flops=2.0 * b * D * K, bytes=b * D * K * 4 * 2),
         'bwd_dots_kernel': dict(flops=8.0 * b * D * K, bytes=b * D * K * 4 * 2),
-        'bwd_du_kernel': dict(flops=4.0 * b * D * K, bytes=b * D * K * 4 * 4),
-        'rowtile_dassign': dict(flops=2.0 * bn * D * K,
-                                bytes=bn * D * x_bytes + bn * K * 12 + b * D * K * 4, **b3),
-        'aggregate_dw': dict(flops=2.0 * bn * D * K,
-                             bytes=bn * D * x_bytes + bn * K * 4 + b * 2 * D * K * 4, **b3),
-        # [a|ds]·[dU|W]^T then the norm Jacobian; reads x, writes grad_x
-        'dx_kernel': dict(flops=4.0 * bn * D * K, bytes=2 * bn * D * x_bytes + bn * K * 8, **b3),
+        'bwd_du_kernel': dict(flops=4.0 * b * D * K, bytes=b * D * K * 4 * 5),
+        # float32 feature maps (and the A/B variant 8): float32-MFMA kernels
+        'rowtile16_kernel<ASSIGN>': dict(flops=2.0 * bn * D * K,
+                                         bytes=bn * D * x_bytes + bn * K * 8 + bn * 4),
+        'rowtile16_kernel<DASSIGN>': dict(flops=2.0 * bn * D * K,
+                                          bytes=bn * D * x_bytes + bn * K * 12 + b * D * K * 4),
+        'aggregate_kernel<float>': dict(flops=2.0 * bn * D * K,
+                                        bytes=bn * D * 4 + bn * K * 4 + b * 4 * D * K * 4),
+        'aggregate_kernel<bf16>': dict(flops=2.0 * bn * D * K,
+                                       bytes=bn * D * 2 + bn * K * 4 + b * 4 * D * K * 4),
+        'dx16_kernel<float>': dict(flops=4.0 * bn * D * K, bytes=2 * bn * D * 4 + bn * K * 8),
+        'dx16_kernel<bf16>': dict(flops=4.0 * bn * D * K, bytes=2 * bn * D * 2 + bn * K * 8),
+        'finish_sum_kernel': dict(flops=6.0 * b * D * K, bytes=b * D * K * 4 * 6),
         'wgrad_finish_kernel': dict(flops=4.0 * b * D * K, bytes=b * D * K * 12),
+        'transpose_w_kernel': dict(flops=0.0, bytes=D * K * 8),
         # loss: raw Gram (upper-triangular tile pairs), reads E once
         'gram_partial_kernel': dict(flops=2.0 * gb * gb * E, bytes=gb * E * 4),
         'gram16_kernel': dict(flops=2.0 * gb * gb * E, bytes=gb * E * 4),
@@ -166,9 +179,38 @@ def kernel_models(b, n, gb, x_bytes):
         'gram_bwd32_kernel': dict(flops=2.0 * b * gb * E, bytes=gb * E * 4 + b * E * 4),
         'gram_bwd_fast_kernel<2>': dict(flops=2.0 * b * gb * E, bytes=gb * E * 4 + b * E * 4),
         'gram_bwd_fast_kernel<4>': dict(flops=2.0 * b * gb * E, bytes=gb * E * 4 + b * E * 4),
-        'transpose_w_kernel': dict(flops=0.0, bytes=D * K * 8),
-        'split_w_kernel': dict(flops=0.0, bytes=D * K * 10),
+        'gram_bwd_planes_kernel': dict(flops=2.0 * b * gb * E, bytes=gb * E * 4 + b * E * 4),
     }
+
+
+def netvlad_stage(kernels, b, n, x_bytes, steps):
+    """The NetVLAD head as ONE stage per pass, the way SURVEY §8(d) prices it: algorithmic bytes
+    (forward: x once + the descriptors; backward: x twice + dV) and flops (2 contractions forward,
+    4 backward; on bf16 maps each runs as two bf16 plane products -> executed = 2x, against the
+    bf16 dense peak) over the SUM of its kernels' durations in one step."""
+    bn = b * n
+    out = {}
+    for name, members, nbytes, flops in (
+            ('forward', NETVLAD_FWD, bn * D * x_bytes + b * D * K * 4 + 2 * D * K * 4, 4.0 * bn * D * K),
+            ('backward', NETVLAD_BWD, 2 * bn * D * x_bytes + b * D * K * 4, 8.0 * bn * D * K)):
+        rows = [r for r in kernels if r['kernel'] in members]
+        if not rows:
+            continue
+        us = sum(r['us'] * r['launches'] for r in rows) / max(steps, 1)
+        t_hbm = nbytes / (PEAK_HBM_GBPS * 1e9) * 1e6
+        if x_bytes == 2:
+            t_mfma = 2.0 * flops / (PEAK_BF16_TFLOPS * 1e12) * 1e6
+        else:
+            t_mfma = flops / (PEAK_F32_TFLOPS * 1e12) * 1e6
+        bound_us = max(t_hbm, t_mfma)
+        out[name] = dict(kernels=[r['kernel'] for r in rows],
+                         launches_per_step=round(sum(r['launches'] for r in rows) / max(steps, 1), 2),
+                         us_per_step=round(us, 2), algorithmic_bytes=int(nbytes),
+                         algorithmic_flops=flops, bound='hbm' if t_hbm >= t_mfma else 'mfma',
+                         bound_us=round(bound_us, 2), frac=round(bound_us / us, 4) if us > 0 else None)
+    out['note'] = ('durations = HIP events around every launch (each ~2.5 us above the rocprofv3 '
+                   'duration of the same kernel: profiles/r03)')
+    return out
 
 
 def price(name, launches, mean_ms, model):
@@ -824,6 +866,8 @@ def main():
                               'ms_per_step_with_events': round(elapsed_prof / prof_steps * 1e3, 3)},
             'roofline': roofline,
             'roofline_netvlad_loss': roofline_head,
+            'roofline_netvlad_stage': netvlad_stage(kernels, b, n_loc, 2 if cdt == torch.bfloat16 else 4,
+                                                    prof_steps),
             'kernels': kernels,
             'hip_path_ms_per_step': round(hip_ms, 3),
         }

@@ -432,8 +432,10 @@ int scl_conv_pack_batch(const SclPackJob* jobs, int njobs, void* stream);
  * the production kernels, any other value makes RESULTS MEANINGLESS.  Returns the old value.
  *   1..7          forward row-tile kernel: bit 0 no epilogue stores, bit 1 no x loads,
  *                 bit 2 no operand staging / barriers
- *   8             bf16 feature maps through the float32-MFMA NetVLAD kernels
- *   21 / 22       bf16 row-tile kernel: main loop only / epilogue only
+ *   8             bf16 feature maps through the float32-MFMA NetVLAD kernels (CORRECT results:
+ *                 the A/B partner of the fused bf16 kernels)
+ *   916 / 917     fused NetVLAD kernels (forward / grad_x): wave 0 of every workgroup writes
+ *                 shader-clock stamps into the tail of the workspace (scripts/vlad_stamps.py)
  *   31 / 32       Gram loss, 64 < B <= 256: float32-MFMA Gram instead of bf16x6 /
  *                 the older guarded backward kernel
  *   100000 * s    Gram loss, B <= 256: force s K-splits

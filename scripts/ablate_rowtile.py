@@ -47,7 +47,7 @@ def main():
                     nets.netvlad(x, wt, ct, True)
                     torch.cuda.synchronize()
                 if rnd >= 2:
-                    times[v].append(dict(kt.records)['rowtile_assign'] * 1e3)
+                    times[v].append(dict(kt.records)['rowtile16_kernel<ASSIGN>'] * 1e3)
     finally:
         lib.scl_debug_set_variant(0)
     flops = 2.0 * b * n * 512 * 64

@@ -1,8 +1,8 @@
 #!/usr/bin/env python
-"""Where the fused NetVLAD forward kernel (csrc/netvlad.hip, vlad_fwd_kernel) spends its cycles:
-runs it with scl_debug_set_variant(900 + 16 [+ ablation bits]) — wave 0 of every workgroup
-writes shader-clock stamps into the tail of the workspace — and prints the median over
-workgroups of every phase, in cycles.  DIAGNOSTIC ONLY (the stamps perturb the kernel)."""
+"""Where the fused NetVLAD kernels (csrc/netvlad.hip: vlad_fwd_kernel, vlad_dx_kernel) spend their
+cycles: runs them with scl_debug_set_variant(916 / 917) — wave 0 of every workgroup writes
+shader-clock stamps into the tail of the workspace — and prints the median over workgroups of
+every phase, in cycles.  DIAGNOSTIC ONLY (the stamps perturb the kernel)."""
 import argparse
 import os
 import sys
@@ -19,7 +19,7 @@ from tests import util_data as U  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--bits', type=int, default=0, help='ablation bits added to the stamp bit')
+    ap.add_argument('--kernel', default='fwd', choices=['fwd', 'dx'])
     ap.add_argument('--batch', type=int, default=24)
     ap.add_argument('--locations', type=int, default=1200)
     args = ap.parse_args()
@@ -37,7 +37,7 @@ def main():
     per = -(-steps * b // 256)
     s_cnt = -(-steps // per)
     nwg = b * s_cnt
-    lib.scl_debug_set_variant(900 + 16 + args.bits)
+    lib.scl_debug_set_variant(916 if args.kernel == 'fwd' else 0)
     try:
         for _ in range(3):
             ws.zero_()
@@ -45,16 +45,32 @@ def main():
                                         L.ptr(sa), L.ptr(sl), L.ptr(sr), L.ptr(sv), L.ptr(ws), ws.numel(),
                                         L.stream_of(x)))
         torch.cuda.synchronize()
+        if args.kernel == 'dx':
+            go = torch.randn(b, 32768, device=dev)
+            gx, gw, gc = torch.empty_like(x), torch.empty_like(wt), torch.empty_like(ct)
+            ws = L.workspace(lib.scl_netvlad_bwd_workspace_bytes(b, n), dev)
+            lib.scl_debug_set_variant(917)
+            for _ in range(3):
+                ws.zero_()
+                L.check(lib.scl_netvlad_bwd(L.ptr(x), L.DT_BF16, L.ptr(wt), L.ptr(ct), L.ptr(go), L.ptr(sa),
+                                            L.ptr(sl), L.ptr(sr), L.ptr(sv), b, n, 1, L.ptr(gx), L.ptr(gw),
+                                            L.ptr(gc), L.ptr(ws), ws.numel(), L.stream_of(x)))
+            torch.cuda.synchronize()
     finally:
         lib.scl_debug_set_variant(0)
     tail = ws[-nwg * 32 * 8:].cpu().numpy().view(np.uint64).reshape(nwg, 32).astype(np.int64)
-    names = {0: 'entry', 1: 'stage DMA issued, W loads issued', 2: 'W + first stages landed', 28: 'loop done',
-             29: 'slab stores issued', 30: 'slab stores complete'}
-    for st in range(4):
-        names.update({4 + 6 * st: 'step %d: stage landed + barrier' % st, 5 + 6 * st: 'step %d: logits done' % st,
-                      6 + 6 * st: 'step %d: softmax exchange barrier' % st,
-                      7 + 6 * st: 'step %d: coefficients written, outputs stored' % st,
-                      8 + 6 * st: 'step %d: aggregation done' % st})
+    if args.kernel == 'dx':
+        names = {0: 'entry', 1: 'operand registers loaded', 2: 'tile 0 fragments staged', 13: 'last epilogue issued',
+                 14: 'stores complete'}
+        names.update({3 + t: 'after tile %d (+ epilogue of tile %d)' % (t, t - 1) for t in range(1, 9)})
+    else:
+        names = {0: 'entry', 1: 'stage DMA issued, W loads issued', 2: 'W + first stages landed', 28: 'loop done',
+                 29: 'slab stores issued', 30: 'slab stores complete'}
+        for st in range(4):
+            names.update({4 + 6 * st: 'step %d: stage landed + barrier' % st, 5 + 6 * st: 'step %d: logits done' % st,
+                          6 + 6 * st: 'step %d: softmax exchange barrier' % st,
+                          7 + 6 * st: 'step %d: coefficients written, outputs stored' % st,
+                          8 + 6 * st: 'step %d: aggregation done' % st})
     t0 = tail[:, 0:1]
     rel = tail - t0
     prev = 0

@@ -1683,6 +1683,9 @@ struct VladDxArgs {
   const unsigned short* wdximg; // the same image of W
   int N, pre_l2, steps_per_slice;
   unsigned short* gx;           // [B][N][512] bf16
+  int dbg;                      // scl_debug_set_variant(917): clock stamps (scripts/vlad_stamps.py)
+  unsigned long long* stamps;
+  unsigned short* trash;        // 64 x 16 bytes for the stores of rows past the end
 };
 
 __global__ __launch_bounds__(256, 1) void vlad_dx_kernel(VladDxArgs p) {
@@ -1699,6 +1702,17 @@ __global__ __launch_bounds__(256, 1) void vlad_dx_kernel(VladDxArgs p) {
   const int ntile = (n_hi - n_lo + 15) / 16;
   const unsigned lds0 = nv_lds_byte_of(dxv_lds);
   const unsigned scr0 = lds0 + 2 * DXV_ABUF + wid * DXV_SCR;
+  unsigned long long* stp =
+      p.dbg && threadIdx.x == 0 ? p.stamps + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 : nullptr;
+#define DX_STAMP(k)                                         \
+  do {                                                      \
+    if (p.dbg) {                                            \
+      __builtin_amdgcn_sched_barrier(0);                    \
+      if (stp) stp[k] = __builtin_amdgcn_s_memtime();       \
+      __builtin_amdgcn_sched_barrier(0);                    \
+    }                                                       \
+  } while (0)
+  DX_STAMP(0);
 
   // ---- the wave's operand: bw[nt][s][pl] = [dU | W]_plane[ch 128 w + 16 nt + i][k 32 s + 8 g ..],
   // coalesced 16-byte loads from the register images bwd_du_kernel wrote
@@ -1753,7 +1767,7 @@ __global__ __launch_bounds__(256, 1) void vlad_dx_kernel(VladDxArgs p) {
       const int n = e.n0 + el + 4 * v;
       const int64_t nn = n < n_hi ? n : n_hi - 1;
       e.xr[v] = *reinterpret_cast<const u32x4*>(xb + nn * D);
-      e.rn4[v] = p.pre_l2 ? p.rn[(int64_t)b * p.N + nn] : 1.0f;
+      e.rn4[v] = p.rn[(int64_t)b * p.N + nn];               // (no branch: one basic block per tile)
       e.rd4[v] = p.rowdot[(int64_t)b * p.N + nn];
     }
   };
@@ -1787,22 +1801,29 @@ __global__ __launch_bounds__(256, 1) void vlad_dx_kernel(VladDxArgs p) {
       const f32x4 d0 = *(const __attribute__((address_space(3))) f32x4*)(size_t)(ra);
       const f32x4 d1 = *(const __attribute__((address_space(3))) f32x4*)(size_t)(ra + 16);
       float out[8] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
-      const float rnv = e.rn4[v];
+      const float rnv = p.pre_l2 ? e.rn4[v] : 1.0f;
       // x * rsqrt(max(ss, eps)): with the clamp active the op is a plain scale (no projection)
       const float f = (p.pre_l2 && rnv < 1.0e6f) ? rnv * e.rd4[v] : 0.f;
       float xv8[8];
       Elem8<unsigned short>::cvt(e.xr[v], xv8);
 #pragma unroll
       for (int cc = 0; cc < 8; ++cc) out[cc] = (out[cc] - xv8[cc] * f) * rnv;
-      if (e.n0 + el + 4 * v < n_hi) Elem8<unsigned short>::st(gb + (int64_t)(e.n0 + el + 4 * v) * D, out);
+      // rows past the end go to the trash line: no exec-masked branch inside the tile's block
+      Elem8<unsigned short>::st(e.n0 + el + 4 * v < n_hi ? gb + (int64_t)(e.n0 + el + 4 * v) * D
+                                                         : p.trash + 8 * lane, out);
     }
   };
 
+  if (p.dbg) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DX_STAMP(1);
+  }
   f32x4 pa0, pa1;
   a_load(0, pa0, pa1);
   a_stage(0, pa0, pa1);
   if (ntile > 1) a_load(1, pa0, pa1);
   __syncthreads();
+  DX_STAMP(2);
 
   f32x4 accp[8];
   EpiIn ep;
@@ -1829,8 +1850,15 @@ __global__ __launch_bounds__(256, 1) void vlad_dx_kernel(VladDxArgs p) {
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) accp[nt] = accc[nt];
     ep = ec2;
+    if (tt < 9) DX_STAMP(3 + tt);
   }
   epilogue(accp, ep);
+  if (p.dbg) {
+    DX_STAMP(13);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DX_STAMP(14);
+  }
+#undef DX_STAMP
 }
 
 // grad_w[d,k] = sum_b sum_s slab[b][s][d,k];  grad_c[d,k] = sum_b dU[b,d,k] * asum[b,k].
@@ -1967,6 +1995,7 @@ struct BwdWs {
   unsigned short* duimg;     // [B] register images of dU^T for vlad_bwd_kernel
   unsigned short* dximg;     // [B] register images of dU for vlad_dx_kernel (2 planes)
   unsigned short* wdximg;    // the same image of W
+  unsigned long long* stamps;   // diagnostics: [B * S][32], the LAST bytes of the workspace
   size_t total;
 };
 inline BwdWs carve_bwd(void* ws, int B, int N) {
@@ -1985,6 +2014,7 @@ inline BwdWs carve_bwd(void* ws, int B, int N) {
   w.duimg = (unsigned short*)c.take((size_t)B * VF_NPL * D * K / 2);
   w.dximg = (unsigned short*)c.take((size_t)B * 2 * D * K / 2);
   w.wdximg = (unsigned short*)c.take((size_t)2 * D * K / 2);
+  w.stamps = (unsigned long long*)c.take((size_t)B * S * 32 * 2);
   w.total = c.off;
   return w;
 }
@@ -2147,6 +2177,9 @@ extern "C" int scl_netvlad_bwd(const void* x, int x_dtype, const float* assign_w
     da.pre_l2 = pre_l2 ? 1 : 0;
     da.steps_per_slice = pl.steps_per_slice;
     da.gx = (unsigned short*)grad_x;
+    da.trash = (unsigned short*)w.trash;
+    da.dbg = scl_debug_variant == 917 ? 1 : 0;
+    da.stamps = w.stamps;
     SCL_LAUNCH("vlad_dx_kernel", vlad_dx_kernel, dim3(B, pl.S), dim3(256), kVladDxLds, st, da);
     SCL_LAUNCH("vlad_wgrad_partial_kernel", vlad_wgrad_partial_kernel, dim3(32, VW_GROUPS), dim3(256),
                0, st, (const float*)w.wpart, pl.S * B, w.wpartial);
