@@ -79,9 +79,11 @@ def parse():
                          'the warm-up and replay it for the timed steps; 0 (default): eager. '
                          'Measured on MI355X: 14.234 ms per step either way — the host runs ahead '
                          'of the device, the step is not launch-bound')
-    ap.add_argument('--side-wrw', type=int, default=1,
-                    help='1 (default): weight-gradient kernels on a second HIP stream next to the '
-                         'backward-data kernels; 0: one stream (A/B)')
+    ap.add_argument('--side-wrw', type=int, default=-1,
+                    help='weight-gradient kernels on a second HIP stream next to the backward-data '
+                         'kernels: 1 on, 0 off (A/B), -1 (default) decided on this device during the '
+                         'warm-up by timing 3 steps each way twice (nets.autotune_side_wrw; the '
+                         'setting that wins differs from box to box, the gradients do not)')
     ap.add_argument('--split-fwd', type=int, default=0,
                     help='1: the backbone forward as two half-batches pipelined on two HIP streams '
                          '(measured: forward 4.29 -> 3.97 ms, whole step within noise); 0 (default)')
@@ -471,7 +473,7 @@ def _switches(args):
     """Everything that can make this run differ from the default one: SCL_* environment
     switches and the A/B flags of this script."""
     sw = {k: v for k, v in sorted(os.environ.items()) if k.startswith('SCL_')}
-    for name, default in (('side_wrw', 1), ('split_fwd', 0), ('variant', 0), ('graph', 0),
+    for name, default in (('side_wrw', -1), ('split_fwd', 0), ('variant', 0), ('graph', 0),
                           ('fused_relu', 1), ('miopen_find', 1)):
         if getattr(args, name) != default:
             sw['--' + name.replace('_', '-')] = getattr(args, name)
@@ -554,27 +556,30 @@ def retrieval_main(args, world, rank, dev):
 
 
 def loss_b192_line(dev, iters=10):
-    """configs[3]'s loss shape on one GPU: wms forward + backward at B = 192 x 32768 (what every
-    rank of an 8-GPU run evaluates after the all-gather), event-timed per kernel."""
+    """configs[3]'s loss shape on one GPU, event-timed per kernel: wms forward + backward at
+    B = 192 x 32768.  Two cases: 'all_rows' (a single process owning all 192 rows: every row of
+    d loss / d E) and 'own_rows' — what EVERY RANK of an 8-GPU run evaluates after the all-gather:
+    the full 192 x 192 forward, the backward for its own 24 rows only (parallel.wms_loss_dp)."""
     from soft_contrastive_learning_amd import _lib
     from soft_contrastive_learning_amd.model import losses
     from tests import util_data as U
-    bsz = 192
+    bsz, own = 192, 24
     emb = torch.tensor(U.embeddings(bsz, E), device=dev, requires_grad=True)
     dm = torch.tensor(U.positions_distances(bsz)[None], device=dev)
-    for _ in range(3):
-        losses.wms_loss(dm, emb, 0.8, 15.0).backward()
-    torch.cuda.synchronize()
-    with _lib.KernelTimer(capacity=16 * iters) as kt:
-        for _ in range(iters):
-            losses.wms_loss(dm, emb, 0.8, 15.0).backward()
+    out = {'B': bsz, 'E': E, 'note': 'HIP events add ~2.5 us to each kernel; rocprofv3 trace under profiles/'}
+    for case, rows in (('all_rows', None), ('own_rows', (72, own))):
+        for _ in range(3):
+            losses.wms_loss(dm, emb, 0.8, 15.0, _rows=rows).backward()
         torch.cuda.synchronize()
-    models = kernel_models(bsz, 1200, bsz, 4)
-    rows = [price(k, cnt, ms, models[k]) for k, (cnt, ms) in sorted(kt.summary().items())
-            if k in models]
-    return {'B': bsz, 'E': E, 'kernels': rows,
-            'us_forward_backward': round(sum(r['us'] for r in rows), 1),
-            'note': 'HIP events add ~3 us to each kernel; rocprofv3 trace under profiles/'}
+        with _lib.KernelTimer(capacity=16 * iters) as kt:
+            for _ in range(iters):
+                losses.wms_loss(dm, emb, 0.8, 15.0, _rows=rows).backward()
+            torch.cuda.synchronize()
+        models = kernel_models(bsz if rows is None else own, 1200, bsz, 4)
+        krows = [price(k, cnt, ms, models[k]) for k, (cnt, ms) in sorted(kt.summary().items())
+                 if k in models]
+        out[case] = {'kernels': krows, 'us_forward_backward': round(sum(r['us'] for r in krows), 1)}
+    return out
 
 
 def main():
@@ -610,7 +615,8 @@ def main():
     _lib.load()
     if args.workload == 'retrieval':
         return retrieval_main(args, world, rank, dev)
-    nets.USE_SIDE_WRW = bool(args.side_wrw) and nets.USE_SIDE_WRW
+    if args.side_wrw >= 0:
+        nets.USE_SIDE_WRW = bool(args.side_wrw) and nets.USE_SIDE_WRW
     nets.USE_SPLIT_FWD = bool(args.split_fwd)
     if args.variant:
         _lib.load().scl_debug_set_variant(args.variant)
@@ -656,6 +662,37 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    reserve_choice = None
+    if world > 1 and 'SCL_RESERVE_CUS' not in os.environ:
+        # untimed, part of the warm-up: the persistent convolution grids take every CU, RCCL's
+        # kernels need some — leave 0 or 8 CUs free, whichever gives the
+        # shorter step on THIS node (max over ranks, so every rank decides the same)
+        lib_ = _lib.load()
+        tried = {}
+        for rv in (0, 8):
+            lib_.scl_set_reserve_cus(rv)
+            step()
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                step()
+            fence()
+            tt = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tried[rv] = float(tt) / 3 * 1e3
+        best_rv = min(tried, key=tried.get)
+        lib_.scl_set_reserve_cus(best_rv)
+        reserve_choice = {'chosen': best_rv, 'ms_per_step_tried': {str(k): round(v, 3) for k, v in tried.items()}}
+    side_choice = None
+    if args.side_wrw < 0 and nets.USE_SIDE_WRW and nets.GRAD_SINK is not None:
+        # untimed, part of the warm-up: which setting of the second stream this device prefers
+        side_choice = nets.autotune_side_wrw(step)
+        if world > 1:                       # every rank must run the same schedule
+            flag = torch.tensor([1.0 if side_choice['chosen'] else 0.0], device=dev)
+            dist.all_reduce(flag)
+            nets.USE_SIDE_WRW = bool(flag.item() * 2 >= world)
+            side_choice['chosen'] = nets.USE_SIDE_WRW
+        fence()
     # One step captured in a HIP graph and replayed: the step is ~125 dependent launches, and
     # the launch gaps between them cost ~0.3 ms of a 14 ms step when issued one by one.  The
     # captured work is exactly step(): nothing is skipped, cached or reused between replays
@@ -769,6 +806,7 @@ def main():
                 'allreduce_bytes': int(buckets.flat.numel() * 4),
                 'ms_per_step_by_reserved_cus': reserve,
                 'reserved_cus_in_timed_region': old_reserve,
+                'reserved_cus_warmup_choice': reserve_choice,
                 'how': 'device events on the compute stream around all_gather_into_tensor and '
                        'around the waits of GradBuckets.finish() (rank 0, median over the diagnostic '
                        'steps run after the timed region); step time with scl_set_reserve_cus(0 / 8): '
@@ -872,6 +910,9 @@ def main():
             'hip_path_ms_per_step': round(hip_ms, 3),
         }
         out['switches'] = _switches(args)
+        out['side_stream'] = dict(mode='auto' if args.side_wrw < 0 else 'fixed',
+                                  on=bool(nets.USE_SIDE_WRW), **(
+                                      {k: v for k, v in (side_choice or {}).items() if k != 'chosen'}))
         if comm is not None:
             out['comm'] = comm
         if args.n1_ref > 0:

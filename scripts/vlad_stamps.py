@@ -63,6 +63,8 @@ def main():
         names = {0: 'entry', 1: 'operand registers loaded', 2: 'tile 0 fragments staged', 13: 'last epilogue issued',
                  14: 'stores complete'}
         names.update({3 + t: 'after tile %d (+ epilogue of tile %d)' % (t, t - 1) for t in range(1, 9)})
+        names.update({16: 'tile 2: inputs requested', 17: 'tile 2: MFMAs issued', 18: 'tile 2: epilogue of tile 1 issued',
+                      19: 'tile 2: next fragments staged', 20: 'tile 2: barrier passed'})
     else:
         names = {0: 'entry', 1: 'stage DMA issued, W loads issued', 2: 'W + first stages landed', 28: 'loop done',
                  29: 'slab stores issued', 30: 'slab stores complete'}

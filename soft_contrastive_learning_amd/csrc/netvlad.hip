@@ -1729,14 +1729,19 @@ __global__ __launch_bounds__(256, 1) void vlad_dx_kernel(VladDxArgs p) {
           bw[nt][s][pl] = (s < 2 ? dimg : wimg)[(((wid * 8 + nt) * 2 + (s & 1)) * 2 + pl) * 64];
   }
 
+  // Addresses: wave-uniform 64-bit bases of the slice + 32-bit per-lane byte offsets (the tile
+  // loop is paced by its vector instructions: no 64-bit address arithmetic inside it)
+  const int nrows = n_hi - n_lo;
+  const int64_t row0 = (int64_t)b * p.N + n_lo;
   // staging role: k-step wid of the tile: [a | ds][n0 + i][32 (wid & 1) + 8 g .. + 7]
-  const float* asrc = (wid < 2 ? p.a : p.ds) + (int64_t)b * p.N * K + 32 * (wid & 1) + 8 * g;
+  const char* abase = reinterpret_cast<const char*>((wid < 2 ? p.a : p.ds) + row0 * K);
+  const unsigned acol = (32 * (wid & 1) + 8 * g) * 4;
   auto a_load = [&](int tile, f32x4& v0, f32x4& v1) {
-    int n = n_lo + 16 * tile + i;
-    n = n < n_hi ? n : n_hi - 1;                           // rows past the end: results discarded
-    const float* r = asrc + (int64_t)n * K;
-    v0 = *reinterpret_cast<const f32x4*>(r);
-    v1 = *reinterpret_cast<const f32x4*>(r + 4);
+    int r = 16 * tile + i;
+    r = r < nrows ? r : nrows - 1;                         // rows past the end: results discarded
+    const char* q = abase + ((unsigned)r * (K * 4) + acol);
+    v0 = *reinterpret_cast<const f32x4*>(q);
+    v1 = *reinterpret_cast<const f32x4*>(q + 16);
   };
   auto a_stage = [&](int buf, const f32x4& v0, const f32x4& v1) {
     u32x4 hi, lo;
@@ -1748,8 +1753,11 @@ __global__ __launch_bounds__(256, 1) void vlad_dx_kernel(VladDxArgs p) {
   // epilogue role: piece p = lane + 64 v of the tile's 256 (location, 8-channel chunk) pieces of
   // this wave's 128 channels: location (lane >> 4) + 4 v, chunk lane & 15
   const int el = lane >> 4, ec = lane & 15;
-  const unsigned short* xb = p.x + (int64_t)b * p.N * D + 128 * wid + 8 * ec;
-  unsigned short* gb = p.gx + (int64_t)b * p.N * D + 128 * wid + 8 * ec;
+  const char* xbase = reinterpret_cast<const char*>(p.x + row0 * D);
+  char* gbase = reinterpret_cast<char*>(p.gx + row0 * D);
+  const char* rnbase = reinterpret_cast<const char*>(p.rn + row0);
+  const char* rdbase = reinterpret_cast<const char*>(p.rowdot + row0);
+  const unsigned xcol = (128 * wid + 8 * ec) * 2;
 
   // Software pipeline over the 16-location tiles: the matrix work of tile tt and the epilogue of
   // tile tt - 1 (scratch transpose, projection, stores — vector and LDS instructions only) are
@@ -1758,17 +1766,17 @@ __global__ __launch_bounds__(256, 1) void vlad_dx_kernel(VladDxArgs p) {
   struct EpiIn {
     u32x4 xr[4];
     float rn4[4], rd4[4];
-    int n0;
+    int r0;                                                 // first row of the tile in the slice
   };
   auto epi_load = [&](int tt, EpiIn& e) {
-    e.n0 = n_lo + 16 * tt;
+    e.r0 = 16 * tt;
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      const int n = e.n0 + el + 4 * v;
-      const int64_t nn = n < n_hi ? n : n_hi - 1;
-      e.xr[v] = *reinterpret_cast<const u32x4*>(xb + nn * D);
-      e.rn4[v] = p.rn[(int64_t)b * p.N + nn];               // (no branch: one basic block per tile)
-      e.rd4[v] = p.rowdot[(int64_t)b * p.N + nn];
+      int r = e.r0 + el + 4 * v;
+      r = r < nrows ? r : nrows - 1;
+      e.xr[v] = *reinterpret_cast<const u32x4*>(xbase + ((unsigned)r * (D * 2) + xcol));
+      e.rn4[v] = *reinterpret_cast<const float*>(rnbase + (unsigned)r * 4);   // (no branch: one
+      e.rd4[v] = *reinterpret_cast<const float*>(rdbase + (unsigned)r * 4);   //  basic block per tile)
     }
   };
   auto tile_mfma = [&](int tt, f32x4 (&acc)[8]) {
@@ -1778,17 +1786,27 @@ __global__ __launch_bounds__(256, 1) void vlad_dx_kernel(VladDxArgs p) {
     for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int pl = 0; pl < 2; ++pl) af[s][pl] = vf_ldsr128(base + (s * 2 + pl) * 1024);
+    // The MFMAs are written as asm with the resident operand CONSTRAINED to the accumulator
+    // file ("a"): left to itself hipcc keeps what does not fit into 256 vector registers in
+    // AGPRs as spill slots and copies every fragment back (four v_accvgpr_mov per MFMA: the
+    // vector port, not the matrix pipe, then paces the tile).  hipcc pads no hazards around asm:
+    // the first MFMA of a tile takes C = 0 as an immediate (no vector write in front of it), and
+    // the accumulators are first read one tile later, or behind vlad_mfma_settle().
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) {
-      acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc[nt]) : "a"(bw[nt][0][1]), "v"(af[0][0]));
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[nt]) : "a"(bw[nt][0][0]), "v"(af[0][1]));
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[nt]) : "a"(bw[nt][0][0]), "v"(af[0][0]));
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        acc[nt] = mfma16b(bw[nt][s][1], af[s][0], acc[nt]);    // Bl . Ah
-        acc[nt] = mfma16b(bw[nt][s][0], af[s][1], acc[nt]);    // Bh . Al
-        acc[nt] = mfma16b(bw[nt][s][0], af[s][0], acc[nt]);    // Bh . Ah
+      for (int s = 1; s < 4; ++s) {
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[nt]) : "a"(bw[nt][s][1]), "v"(af[s][0]));   // Bl . Ah
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[nt]) : "a"(bw[nt][s][0]), "v"(af[s][1]));   // Bh . Al
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[nt]) : "a"(bw[nt][s][0]), "v"(af[s][0]));   // Bh . Ah
       }
     }
   };
+  // wait states between the last asm MFMA and the first instruction that reads its result
+  auto vlad_mfma_settle = [] { asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); };
   auto epilogue = [&](const f32x4 (&acc)[8], const EpiIn& e) {
     // transpose through the wave's scratch: lane (i = location, g) holds channels
     // 16 nt + 4 g .. + 3 -> rows of 128 channels (LDS serves a wave's accesses in order)
@@ -1809,8 +1827,9 @@ __global__ __launch_bounds__(256, 1) void vlad_dx_kernel(VladDxArgs p) {
 #pragma unroll
       for (int cc = 0; cc < 8; ++cc) out[cc] = (out[cc] - xv8[cc] * f) * rnv;
       // rows past the end go to the trash line: no exec-masked branch inside the tile's block
-      Elem8<unsigned short>::st(e.n0 + el + 4 * v < n_hi ? gb + (int64_t)(e.n0 + el + 4 * v) * D
-                                                         : p.trash + 8 * lane, out);
+      const int r = e.r0 + el + 4 * v;
+      Elem8<unsigned short>::st(r < nrows ? reinterpret_cast<unsigned short*>(gbase + ((unsigned)r * (D * 2) + xcol))
+                                          : p.trash + 8 * lane, out);
     }
   };
 
@@ -1825,19 +1844,8 @@ __global__ __launch_bounds__(256, 1) void vlad_dx_kernel(VladDxArgs p) {
   __syncthreads();
   DX_STAMP(2);
 
-  f32x4 accp[8];
-  EpiIn ep;
-  epi_load(0, ep);
-  tile_mfma(0, accp);
-  if (ntile > 1) {
-    a_stage(1, pa0, pa1);
-    if (ntile > 2) a_load(2, pa0, pa1);
-  }
-  __syncthreads();
-#pragma unroll 1
-  for (int tt = 1; tt < ntile; ++tt) {
-    f32x4 accc[8];
-    EpiIn ec2;
+  // one tile step: matrix work of tile tt into (accc, ec2), epilogue of tile tt - 1 from (accp, ep)
+  auto tile_step = [&](int tt, f32x4 (&accc)[8], EpiIn& ec2, const f32x4 (&accp)[8], const EpiIn& ep) {
     epi_load(tt, ec2);
     tile_mfma(tt, accc);
     epilogue(accp, ep);
@@ -1846,13 +1854,32 @@ __global__ __launch_bounds__(256, 1) void vlad_dx_kernel(VladDxArgs p) {
       a_stage((tt + 1) & 1, pa0, pa1);
       if (tt + 2 < ntile) a_load(tt + 2, pa0, pa1);
     }
+    vlad_mfma_settle();
     __syncthreads();
-#pragma unroll
-    for (int nt = 0; nt < 8; ++nt) accp[nt] = accc[nt];
-    ep = ec2;
     if (tt < 9) DX_STAMP(3 + tt);
+  };
+  f32x4 acca[8], accb[8];
+  EpiIn ea, eb;
+  epi_load(0, ea);
+  tile_mfma(0, acca);
+  vlad_mfma_settle();
+  if (ntile > 1) {
+    a_stage(1, pa0, pa1);
+    if (ntile > 2) a_load(2, pa0, pa1);
   }
-  epilogue(accp, ep);
+  __syncthreads();
+  int tt = 1;
+#pragma unroll 1
+  for (; tt + 1 < ntile; tt += 2) {                         // ping-pong: no register copies
+    tile_step(tt, accb, eb, acca, ea);
+    tile_step(tt + 1, acca, ea, accb, eb);
+  }
+  if (tt < ntile) {
+    tile_step(tt, accb, eb, acca, ea);
+    epilogue(accb, eb);
+  } else {
+    epilogue(acca, ea);
+  }
   if (p.dbg) {
     DX_STAMP(13);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

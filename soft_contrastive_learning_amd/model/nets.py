@@ -565,6 +565,33 @@ USE_SIDE_WRW = os.environ.get('SCL_SIDE_WRW', '1') != '0'
 _SIDE = {}
 
 
+def autotune_side_wrw(step, steps=3, rounds=2):
+    """Decide USE_SIDE_WRW for THIS device by measurement: ``step()`` (one training step, already
+    warmed up) is timed ``steps`` at a time with the second stream off and on, ``rounds`` times
+    alternating, and the faster setting is kept.  The second stream is worth -4 % of a step on some
+    MI355X boxes and costs +1.4 % on others (profiles/r02/README.md): the clocks the two settings
+    hold differ from device to device, so a fixed default loses on part of the pool.  Gradients are
+    bit-identical either way.  Returns {'chosen': bool, 'ms_on': .., 'ms_off': ..}."""
+    global USE_SIDE_WRW
+    if not torch.cuda.is_available():
+        return {'chosen': USE_SIDE_WRW, 'ms_on': None, 'ms_off': None}
+    best = {True: float('inf'), False: float('inf')}
+    for _ in range(rounds):
+        for mode in (False, True):
+            USE_SIDE_WRW = mode
+            step()                                          # settle into the mode
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(steps):
+                step()
+            e1.record()
+            torch.cuda.synchronize()
+            best[mode] = min(best[mode], e0.elapsed_time(e1) / steps)
+    USE_SIDE_WRW = best[True] <= best[False]
+    return {'chosen': USE_SIDE_WRW, 'ms_on': round(best[True], 3), 'ms_off': round(best[False], 3)}
+
+
 def _wrw_maybe_async(x, gz, w, gb):
     sink = GRAD_SINK
 

@@ -202,6 +202,8 @@ def test_bench_two_ranks_on_one_gpu():
     assert c['allgather_us_median'] > 0 and c['finish_wait_us_median'] is not None
     assert c['allgather_bytes_per_rank'] == 24 * 32768 * 4 and c['allreduce_buckets'] >= 3
     assert set(c['ms_per_step_by_reserved_cus']) == {'0', '8'}
+    assert c['reserved_cus_warmup_choice']['chosen'] in (0, 8)
+    assert c['reserved_cus_in_timed_region'] == c['reserved_cus_warmup_choice']['chosen']
     assert all(v > 0 for v in c['ms_per_step_by_reserved_cus'].values())
     assert d['switches'].get('SCL_BENCH_ONE_GPU_GLOO') == '1'
     assert 'retrieval' not in d and 'cpu_baseline' not in d          # N = 1 objects
