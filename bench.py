@@ -179,6 +179,7 @@ def kernel_models(b, n, gb, x_bytes, slices=10):
         # grad_E[own rows] = M E: reads E once, writes b rows
         'gram_bwd_kernel': dict(flops=2.0 * b * gb * E, bytes=gb * E * 4 + b * E * 4),
         'gram_bwd32_kernel': dict(flops=2.0 * b * gb * E, bytes=gb * E * 4 + b * E * 4),
+        'gram_bwd_fast_kernel<1>': dict(flops=2.0 * b * gb * E, bytes=gb * E * 4 + b * E * 4),
         'gram_bwd_fast_kernel<2>': dict(flops=2.0 * b * gb * E, bytes=gb * E * 4 + b * E * 4),
         'gram_bwd_fast_kernel<4>': dict(flops=2.0 * b * gb * E, bytes=gb * E * 4 + b * E * 4),
         'gram_bwd_planes_kernel': dict(flops=2.0 * b * gb * E, bytes=gb * E * 4 + b * E * 4),

@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256) void gram_bwd_fast_kernel(const float* __restr
   const float* ma = mt + r * ldm + h;
   const float* eb = emb + (int64_t)h * ld + e;
   const int steps = B >> 1;                                       // pairs of contraction rows
-  constexpr int U = 8;
+  constexpr int U = 8;        // (32 for the narrow cut: 19 -> 32 us, the wave count drops)
   int s0 = 0;
   for (; s0 + U <= steps; s0 += U) {
     vec_t bv[U];
@@ -1079,16 +1079,21 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restric
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int pair = blockIdx.x;
   const f32x4* src = reinterpret_cast<const f32x4*>(slabs) + (int64_t)pair * 64 + lane;
-  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
-  int s = wid;
-  for (; s + 12 < S; s += 16) {
-    a0 += src[(int64_t)(s + 0) * P * 64];
-    a1 += src[(int64_t)(s + 4) * P * 64];
-    a2 += src[(int64_t)(s + 8) * P * 64];
-    a3 += src[(int64_t)(s + 12) * P * 64];
+  // sixteen slab loads of a wave in flight at once (the kernel is a latency-bound reader of
+  // S x 1 KB per pair: with four in flight it took 7.7 us for 20 MB), summed in a fixed order
+  constexpr int U = 16;
+  f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+  for (int s0 = wid; s0 < S; s0 += 4 * U) {
+    f32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int sidx = s0 + 4 * u;
+      v[u] = sidx < S ? src[(int64_t)sidx * P * 64] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc4 += v[u];
   }
-  for (; s < S; s += 4) a0 += src[(int64_t)s * P * 64];
-  part[wid][lane] = (a0 + a1) + (a2 + a3);
+  part[wid][lane] = acc4;
   __syncthreads();
   if (wid != 0) return;
   const f32x4 v = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
@@ -1365,6 +1370,9 @@ extern "C" int scl_gram_loss_bwd(const float* emb, int64_t ld_emb, int B, int E,
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_bwd_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(kTile * (kMaxB | 1) * sizeof(float)));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_bwd_fast_kernel<1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(kTile * (kMaxB | 1) * sizeof(float)));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_bwd_fast_kernel<2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(kTile * (kMaxB | 1) * sizeof(float)));
@@ -1377,11 +1385,19 @@ extern "C" int scl_gram_loss_bwd(const float* emb, int64_t ld_emb, int B, int E,
                     ((uintptr_t)grad_emb % 16 == 0);
     const size_t ldsf = (size_t)kTile * (B | 1) * sizeof(float);
     const int rt = (row_count + kTile - 1) / kTile;
-    // waves per SIMD (1024 SIMDs) with 64- or 128-column waves: take the better balanced cut
+    // waves per SIMD (1024 SIMDs) with 32-, 64- or 128-column waves: take the best balanced cut
+    // (ties: the wider wave, which re-reads M less).  A rank of a data-parallel run asks for its
+    // own 24 rows of 192 (parallel.wms_loss_dp): one row tile — 32-column waves are then the only
+    // cut that puts a wave on every SIMD (64-column waves left half the chip idle: 21 us for a
+    // 25 MB read).
     if (al && E % 512 == 0 && scl_debug_variant != 32) {
-      const long w4 = (long)(E / 128) * rt, w2 = 2 * w4;
-      const long r4 = (w4 + 1023) / 1024 * 2, r2 = (w2 + 1023) / 1024;   // time in 64-column units
-      if (r2 < r4)
+      const long w4 = (long)(E / 128) * rt, w2 = 2 * w4, w1 = 4 * w4;
+      const long r4 = (w4 + 1023) / 1024 * 4, r2 = (w2 + 1023) / 1024 * 2, r1 = (w1 + 1023) / 1024;
+      if (r1 < r2 && r1 < r4)
+        SCL_LAUNCH("gram_bwd_fast_kernel<1>", gram_bwd_fast_kernel<1>, dim3(E / 128, rt), dim3(256), ldsf,
+                   (hipStream_t)stream, emb, ld_emb, B, E, coef, grad_loss, row_begin, row_count,
+                   grad_emb, ld_grad);
+      else if (r2 < r4)
         SCL_LAUNCH("gram_bwd_fast_kernel<2>", gram_bwd_fast_kernel<2>, dim3(E / 256, rt), dim3(256), ldsf,
                    (hipStream_t)stream, emb, ld_emb, B, E, coef, grad_loss, row_begin, row_count,
                    grad_emb, ld_grad);
