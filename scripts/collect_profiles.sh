@@ -1,7 +1,7 @@
 # Regenerates everything under profiles/rNN from one GPU box (run through gpurun; results land in
-# gpurun_out/rNN and are copied into profiles/rNN by hand).  Usage: bash scripts/collect_profiles.sh r02
+# gpurun_out/rNN and are copied into profiles/rNN by hand).  Usage: bash scripts/collect_profiles.sh r03
 set -x
-RN=${1:-r02}
+RN=${1:-r03}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$RN; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 python3 $R/bench.py --steps 20 --warmup 5 > $O/bench_n1_default_run.json 2> $O/bench.err
@@ -20,6 +20,12 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_nv/write -- python3 $R/
 cd $R
 python3 scripts/microbench.py --iters 20 --topn-score f32,bf16x3 --json $O/microbench_netvlad_loss_topn.json > $O/microbench.log 2>&1
 python3 scripts/parity_report.py --json $O/parity_report.json > $O/parity.log 2>&1
+python3 bench.py --workload retrieval --steps 5 --warmup 2 > $O/bench_retrieval_n1_f32.json 2>> $O/bench.err
+python3 bench.py --workload retrieval --steps 5 --warmup 2 --score bf16x3 > $O/bench_retrieval_n1_bf16x3.json 2>> $O/bench.err
+python3 scripts/vlad_stamps.py --kernel fwd > $O/vlad_stamps_fwd.txt 2>/dev/null
+python3 scripts/vlad_stamps.py --kernel dx > $O/vlad_stamps_dx.txt 2>/dev/null
+python3 scripts/netvlad_accuracy_probe.py > $O/netvlad_two_plane_accuracy.txt 2>/dev/null
+python3 scripts/lds_conflicts.py > $O/lds_conflicts.txt 2>/dev/null
 python3 scripts/conv_ab.py --rounds 2 > $O/conv_lds_kernels_32x32x16_vs_16x16x32.jsonl 2>/dev/null
 python3 scripts/conv_layers.py > $O/conv_layers_own_vs_library.txt 2>/dev/null
 python3 scripts/trace_summary.py $O/trace --steps 8 --out $O/bench_n1_steady_state_per_step.csv > $O/trace_summary.log 2>&1
