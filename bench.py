@@ -139,9 +139,10 @@ def kernel_models(b, n, gb, x_bytes, slices=10):
         # fused x.dU + softmax backward + x^T.(ds rn): x, a, logits, rn in; ds, rowdot, slabs out
         'vlad_bwd_kernel': dict(flops=4.0 * bn * D * K,
                                 bytes=bn * D * 2 + bn * K * 12 + bn * 8 + slab + b * D * K * 4, **b2),
-        # [a|ds].[dU|W]^T then the norm Jacobian: x, a, ds in, grad_x out, the operand once per slice
+        # [a|ds].[dU|W]^T then the norm Jacobian: x, a, ds in, grad_x out, the operand images (two
+        # bf16 planes of dU per image and of W; the other slices of an image find them in the L2)
         'vlad_dx_kernel': dict(flops=4.0 * bn * D * K,
-                               bytes=4 * bn * D + bn * K * 8 + b * slices * 2 * D * K * 4, **b3),
+                               bytes=4 * bn * D + bn * K * 8 + (b + 1) * D * K * 4, **b3),
         'vlad_wgrad_partial_kernel': dict(flops=b * slices * D * K, bytes=slab),
         'vlad_wgrad_finish_kernel': dict(flops=4.0 * b * D * K, bytes=b * D * K * 4 + 9 * D * K * 4),
         'vlad_split_w_kernel': dict(flops=0.0, bytes=D * K * 8),

@@ -123,7 +123,7 @@ def main():
     w, c = U.vlad_params()
     x = U.feature_map(4, 1200, seed=5)
     g = np.random.default_rng(3).standard_normal((4, 32768)).astype(np.float32)
-    for dt, label in ((torch.float32, 'f32 x (float32 MFMA)'), (torch.bfloat16, 'bf16 x (bf16x3)')):
+    for dt, label in ((torch.float32, 'f32 x (float32 MFMA)'), (torch.bfloat16, 'bf16 x (fused kernels, two bf16 planes)')):
         xin = torch.tensor(x).to(dt).float().numpy()        # what the kernel really sees
         want = NV.netvlad_fused(xin, w, c)
         xt = torch.tensor(xin, device=dev).to(dt).reshape(4, 1, 1200, 512).requires_grad_(True)
