@@ -324,10 +324,10 @@ extern "C" int scl_vgg_bias_act(void* y, int dtype, const float* bias, int64_t M
   const int64_t nvec = M * (C / 8);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == SCL_DT_F32)
-    SCL_LAUNCH("vgg_bias_act", bias_act_kernel<float>, dim3(blocks_for(nvec)), dim3(kThreads), 0,
+    SCL_LAUNCH("bias_act_kernel", bias_act_kernel<float>, dim3(blocks_for(nvec)), dim3(kThreads), 0,
                st, (float*)y, bias, nvec, C / 8, relu);
   else if (dtype == SCL_DT_BF16)
-    SCL_LAUNCH("vgg_bias_act", bias_act_kernel<unsigned short>, dim3(blocks_for(nvec)),
+    SCL_LAUNCH("bias_act_kernel", bias_act_kernel<unsigned short>, dim3(blocks_for(nvec)),
                dim3(kThreads), 0, st, (unsigned short*)y, bias, nvec, C / 8, relu);
   else
     return SCL_E_KIND;
@@ -347,15 +347,15 @@ extern "C" int scl_vgg_act_bwd(const void* g, const void* a, int dtype, int64_t 
   hipStream_t st = (hipStream_t)stream;
   float* partial = (float*)workspace;
   if (dtype == SCL_DT_F32)
-    SCL_LAUNCH("vgg_act_bwd", act_bwd_kernel<float>, dim3(nb), dim3(kThreads), 0, st,
+    SCL_LAUNCH("act_bwd_kernel", act_bwd_kernel<float>, dim3(nb), dim3(kThreads), 0, st,
                (const float*)g, (const float*)a, (float*)gz, nvec, C / 8, C, partial);
   else if (dtype == SCL_DT_BF16)
-    SCL_LAUNCH("vgg_act_bwd", act_bwd_kernel<unsigned short>, dim3(nb), dim3(kThreads), 0, st,
+    SCL_LAUNCH("act_bwd_kernel", act_bwd_kernel<unsigned short>, dim3(nb), dim3(kThreads), 0, st,
                (const unsigned short*)g, (const unsigned short*)a, (unsigned short*)gz, nvec,
                C / 8, C, partial);
   else
     return SCL_E_KIND;
-  SCL_LAUNCH("vgg_colsum", colsum_kernel, dim3((C + 31) / 32), dim3(1024), 0,
+  SCL_LAUNCH("colsum_kernel", colsum_kernel, dim3((C + 31) / 32), dim3(1024), 0,
              st, (const float*)partial, nb, C, bias_grad);
   return scl_launch_status();
 }
@@ -369,10 +369,10 @@ extern "C" int scl_vgg_pool_fwd(const void* z, int dtype, const float* bias, int
   const int64_t nvec = (int64_t)B * Ho * Wo * (C / 8);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == SCL_DT_F32)
-    SCL_LAUNCH("vgg_pool_fwd", pool_fwd_kernel<float>, dim3(blocks_for(nvec)), dim3(kThreads), 0,
+    SCL_LAUNCH("pool_fwd_kernel", pool_fwd_kernel<float>, dim3(blocks_for(nvec)), dim3(kThreads), 0,
                st, (const float*)z, bias, H, W, Ho, Wo, C / 8, nvec, (float*)a);
   else if (dtype == SCL_DT_BF16)
-    SCL_LAUNCH("vgg_pool_fwd", pool_fwd_kernel<unsigned short>, dim3(blocks_for(nvec)),
+    SCL_LAUNCH("pool_fwd_kernel", pool_fwd_kernel<unsigned short>, dim3(blocks_for(nvec)),
                dim3(kThreads), 0, st, (const unsigned short*)z, bias, H, W, Ho, Wo, C / 8, nvec,
                (unsigned short*)a);
   else
@@ -397,22 +397,22 @@ extern "C" int scl_vgg_pool_bwd(const void* g, const void* a, const void* z, int
   const bool border = (H & 1) || (W & 1);
   if (dtype == SCL_DT_F32) {
     if (border)
-      SCL_LAUNCH("vgg_pool_bwd_border", pool_bwd_border_kernel<float>, dim3(kMaxBlocks),
+      SCL_LAUNCH("pool_bwd_border_kernel", pool_bwd_border_kernel<float>, dim3(kMaxBlocks),
                  dim3(kThreads), 0, st, (float*)gz, B, H, W, Ho, Wo, C);
-    SCL_LAUNCH("vgg_pool_bwd", pool_bwd_kernel<float>, dim3(nb), dim3(kThreads), 0, st,
+    SCL_LAUNCH("pool_bwd_kernel", pool_bwd_kernel<float>, dim3(nb), dim3(kThreads), 0, st,
                (const float*)g, (const float*)a, (const float*)z, H, W, Ho, Wo, C / 8, C, nvec,
                (float*)gz, partial);
   } else if (dtype == SCL_DT_BF16) {
     if (border)
-      SCL_LAUNCH("vgg_pool_bwd_border", pool_bwd_border_kernel<unsigned short>, dim3(kMaxBlocks),
+      SCL_LAUNCH("pool_bwd_border_kernel", pool_bwd_border_kernel<unsigned short>, dim3(kMaxBlocks),
                  dim3(kThreads), 0, st, (unsigned short*)gz, B, H, W, Ho, Wo, C);
-    SCL_LAUNCH("vgg_pool_bwd", pool_bwd_kernel<unsigned short>, dim3(nb), dim3(kThreads), 0, st,
+    SCL_LAUNCH("pool_bwd_kernel", pool_bwd_kernel<unsigned short>, dim3(nb), dim3(kThreads), 0, st,
                (const unsigned short*)g, (const unsigned short*)a, (const unsigned short*)z, H, W,
                Ho, Wo, C / 8, C, nvec, (unsigned short*)gz, partial);
   } else {
     return SCL_E_KIND;
   }
-  SCL_LAUNCH("vgg_colsum", colsum_kernel, dim3((C + 31) / 32), dim3(1024), 0,
+  SCL_LAUNCH("colsum_kernel", colsum_kernel, dim3((C + 31) / 32), dim3(1024), 0,
              st, (const float*)partial, nb, C, bias_grad);
   return scl_launch_status();
 }
@@ -434,23 +434,23 @@ extern "C" int scl_vgg_pool_bwd_idx(const void* g, const void* a, const void* id
   const bool border = (H & 1) || (W & 1);
   if (dtype == SCL_DT_F32) {
     if (border)
-      SCL_LAUNCH("vgg_pool_bwd_border", pool_bwd_border_kernel<float>, dim3(kMaxBlocks),
+      SCL_LAUNCH("pool_bwd_border_kernel", pool_bwd_border_kernel<float>, dim3(kMaxBlocks),
                  dim3(kThreads), 0, st, (float*)gz, B, H, W, Ho, Wo, C);
-    SCL_LAUNCH("vgg_pool_bwd_idx", pool_bwd_idx_kernel<float>, dim3(nb), dim3(kThreads), 0, st,
+    SCL_LAUNCH("pool_bwd_idx_kernel", pool_bwd_idx_kernel<float>, dim3(nb), dim3(kThreads), 0, st,
                (const float*)g, (const float*)a, (const unsigned char*)idx, H, W, Ho, Wo, C / 8, C,
                nvec, (float*)gz, partial);
   } else if (dtype == SCL_DT_BF16) {
     if (border)
-      SCL_LAUNCH("vgg_pool_bwd_border", pool_bwd_border_kernel<unsigned short>, dim3(kMaxBlocks),
+      SCL_LAUNCH("pool_bwd_border_kernel", pool_bwd_border_kernel<unsigned short>, dim3(kMaxBlocks),
                  dim3(kThreads), 0, st, (unsigned short*)gz, B, H, W, Ho, Wo, C);
-    SCL_LAUNCH("vgg_pool_bwd_idx", pool_bwd_idx_kernel<unsigned short>, dim3(nb), dim3(kThreads),
+    SCL_LAUNCH("pool_bwd_idx_kernel", pool_bwd_idx_kernel<unsigned short>, dim3(nb), dim3(kThreads),
                0, st, (const unsigned short*)g, (const unsigned short*)a,
                (const unsigned char*)idx, H, W, Ho, Wo, C / 8, C, nvec, (unsigned short*)gz,
                partial);
   } else {
     return SCL_E_KIND;
   }
-  SCL_LAUNCH("vgg_colsum", colsum_kernel, dim3((C + 31) / 32), dim3(1024), 0,
+  SCL_LAUNCH("colsum_kernel", colsum_kernel, dim3((C + 31) / 32), dim3(1024), 0,
              st, (const float*)partial, nb, C, bias_grad);
   return scl_launch_status();
 }

@@ -681,7 +681,7 @@ class _ConvBiasAct(torch.autograd.Function):
             with _whole_batch_op():
                 y = _conv3x3(x, w).contiguous(memory_format=_CL)
                 b, c, h, wd = y.shape
-                _work('vgg_bias_act', 0.0, 2.0 * y.numel() * y.element_size())
+                _work('bias_act_kernel', 0.0, 2.0 * y.numel() * y.element_size())
                 L.check(lib.scl_vgg_bias_act(L.ptr(y), _glue_dtype(y), L.ptr(bias), b * h * wd, c,
                                              int(relu), L.stream_of(y)))
         ctx.relu = relu
@@ -705,7 +705,7 @@ class _ConvBiasAct(torch.autograd.Function):
         # weight-gradient kernel, which has gy in LDS anyway — no separate pass over the map
         fold = USE_BIAS_IN_WRW and not mask_here and _own_wrw_used(x, gy, w)
         if not fold:
-            _work('vgg_act_bwd', 0.0, (3.0 if mask_here else 1.0) * gy.numel() * gy.element_size())
+            _work('act_bwd_kernel', 0.0, (3.0 if mask_here else 1.0) * gy.numel() * gy.element_size())
             L.check(lib.scl_vgg_act_bwd(L.ptr(gy), L.ptr(y) if mask_here else None,
                                         _glue_dtype(gy), b * h * wd, c,
                                         L.ptr(gz) if mask_here else None, L.ptr(gb), L.ptr(ws),
@@ -745,7 +745,7 @@ class _ConvBiasPoolReLU(torch.autograd.Function):
                 b, c, h, wd = z.shape
                 a = torch.empty((b, c, h // 2, wd // 2), dtype=z.dtype, device=z.device,
                                 memory_format=_CL)
-                _work('vgg_pool_fwd', 0.0, 1.25 * z.numel() * z.element_size())
+                _work('pool_fwd_kernel', 0.0, 1.25 * z.numel() * z.element_size())
                 L.check(lib.scl_vgg_pool_fwd(L.ptr(z), _glue_dtype(z), L.ptr(bias), b, h, wd, c,
                                              L.ptr(a), L.stream_of(z)))
         ctx.save_for_backward(x, w, z, a, bias)
@@ -767,7 +767,7 @@ class _ConvBiasPoolReLU(torch.autograd.Function):
         # masks with its own input, which is this layer's output a)?  Then a is not read.
         masked = ctx.by_idx and ctx.link_out is not None and ctx.link_out.take(ga)
         # read g, a (1/4 each) and the index bytes (1/8) or z (1); write gz
-        _work('vgg_pool_bwd_idx' if ctx.by_idx else 'vgg_pool_bwd', 0.0,
+        _work('pool_bwd_idx_kernel' if ctx.by_idx else 'pool_bwd_kernel', 0.0,
               ((1.375 if masked else 1.625) if ctx.by_idx else 2.5) * gz.numel() * gz.element_size())
         L.check(fn(L.ptr(ga), None if masked else L.ptr(a), L.ptr(z), _glue_dtype(a), b, h, wd, c,
                    L.ptr(gz), L.ptr(gb), L.ptr(ws), ws.numel(), L.stream_of(a)))
@@ -891,7 +891,7 @@ class _FirstConv(torch.autograd.Function):
                    and tuple(w.shape) == (64, 3, 3, 3))
         gz = gy if masked else torch.empty_like(gy)
         if not (masked and own_wrw):
-            _work('vgg_act_bwd', 0.0, (1.0 if masked else 3.0) * gy.numel() * gy.element_size())
+            _work('act_bwd_kernel', 0.0, (1.0 if masked else 3.0) * gy.numel() * gy.element_size())
             L.check(lib.scl_vgg_act_bwd(L.ptr(gy), None if masked else L.ptr(y), _glue_dtype(gy),
                                         b * h * wd, c, None if masked else L.ptr(gz), L.ptr(gb),
                                         L.ptr(ws), ws.numel(), L.stream_of(gy)))

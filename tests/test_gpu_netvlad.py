@@ -91,6 +91,37 @@ def test_forward_bf16_feature_map(dev):
     assert _maxrel(got, NV.netvlad_fused(xb, w, c)) < 1e-4
 
 
+@pytest.mark.parametrize("b,n,pre_l2", [(1, 1, True), (2, 31, True), (3, 33, True), (4, 196, True),
+                                        (2, 165, False), (5, 1200, True), (40, 70, True), (2, 2100, True)])
+def test_fused_bf16_kernels_on_ragged_shapes(dev, b, n, pre_l2):
+    """The fused bf16 kernels (vlad_fwd / vlad_bwd / vlad_dx: 32-location steps, slices of an image
+    on different workgroups, the slab sums) at shapes that exercise every edge: a single location,
+    a partial last step, one step per slice, more slices than the slab reader takes in one batch of
+    loads (2100 locations: 66 slices), many images, no channel norm; training mode (saved rows)
+    and inference mode (vlad_fwd_kernel<false>: another instantiation — its float operations may be
+    contracted differently, which moves the two-plane split of a coefficient by one unit, 2^-17)
+    must agree to that level."""
+    x = U.feature_map(b, n, seed=7 * b + n)
+    if not pre_l2:
+        x = x * 0.1
+    xb = torch.tensor(x).to(torch.bfloat16).float().numpy()
+    w, c = U.vlad_params(seed=8, logit_scale=3.0 if pre_l2 else 1.0)
+    g = np.random.default_rng(2).standard_normal((b, 32768)).astype(np.float32)
+    x64 = torch.tensor(xb, dtype=torch.float64, requires_grad=True)
+    w64 = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+    c64 = torch.tensor(c, dtype=torch.float64, requires_grad=True)
+    o64 = TT.netvlad(x64, w64, c64, pre_l2=pre_l2)
+    o64.backward(torch.tensor(g, dtype=torch.float64))
+    out, gx, gw, gc = _run(dev, x, w, c, pre_l2=pre_l2, dtype=torch.bfloat16, grad=g)
+    assert _maxrel(out, NV.netvlad_fused(xb, w, c, pre_l2=pre_l2)) < 1e-4
+    assert _maxrel(out, o64.detach().numpy()) < 1e-4
+    assert _nrel(gx, x64.grad.numpy()) < 6e-3               # grad_x is stored in bf16
+    assert _nrel(gw, w64.grad.numpy()) < 2e-4
+    assert _nrel(gc, c64.grad.numpy()) < 2e-4
+    infer = _run(dev, x, w, c, pre_l2=pre_l2, dtype=torch.bfloat16)
+    assert _maxrel(infer, out) < 2e-5
+
+
 @pytest.mark.parametrize("b,n,pre_l2", [(2, 37, True), (3, 196, True), (2, 64, False), (4, 1200, True)])
 def test_backward_matches_float64_twin(dev, b, n, pre_l2):
     x = U.feature_map(b, n, seed=n)
