@@ -29,6 +29,7 @@
 //   dx16_kernel                [a | ds].[dU | W]^T and the l2-norm Jacobian -> grad_x
 //   wgrad_finish_kernel        sums over the batch -> grad_w, grad_c
 #include <mutex>
+#include <type_traits>
 
 #include "scl_common.h"
 
@@ -1844,16 +1845,94 @@ __global__ __launch_bounds__(256, 1) void vlad_dx_kernel(VladDxArgs p) {
   __syncthreads();
   DX_STAMP(2);
 
-  // one tile step: matrix work of tile tt into (accc, ec2), epilogue of tile tt - 1 from (accp, ep)
+  // One tile step: the matrix work of tile tt into (accc, ec2) and, HAND-INTERLEAVED with it, the
+  // epilogue of tile tt - 1 from (accp, ep), the requests for tile tt + 1's epilogue inputs and
+  // the staging of tile tt + 1's fragments.  A wave issues in order, so vector work only hides
+  // under an MFMA if it stands right behind it in the instruction stream (an MFMA holds the vector
+  // port for 8 of its 16 cycles); hipcc interleaves builtin MFMAs with vector code by itself but
+  // not asm ones, and asm is what keeps the resident operand out of the spill path.  So the step
+  // is written as 32 groups of three MFMAs (one (channel tile, k-step)), each followed by one
+  // slice — about a 32nd — of the vector work; nothing in it branches.
   auto tile_step = [&](int tt, f32x4 (&accc)[8], EpiIn& ec2, const f32x4 (&accp)[8], const EpiIn& ep) {
-    epi_load(tt, ec2);
-    tile_mfma(tt, accc);
-    epilogue(accp, ep);
-    // next tile's fragments into the other buffer (its readers finished before the last barrier)
-    if (tt + 1 < ntile) {
-      a_stage((tt + 1) & 1, pa0, pa1);
-      if (tt + 2 < ntile) a_load(tt + 2, pa0, pa1);
+    u32x4 af[4][2];
+    {
+      const unsigned base = lds0 + (tt & 1) * DXV_ABUF + lane * 16;
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) af[s][pl] = vf_ldsr128(base + (s * 2 + pl) * 1024);
     }
+    f32x4 d0[4], d1[4];
+    float outv[4][8];
+    float rnv[4], fv[4];
+    u32x4 sth, stl;
+    ec2.r0 = 16 * tt;
+    // (macros, not a generic lambda: clang does not capture asm operands inside one)
+#define DX_M0(nt)                                                                                                 \
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(accc[nt]) : "a"(bw[nt][0][1]), "v"(af[0][0]));    \
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(accc[nt]) : "a"(bw[nt][0][0]), "v"(af[0][1]));    \
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(accc[nt]) : "a"(bw[nt][0][0]), "v"(af[0][0]));
+#define DX_MS(nt, sq)                                                                                              \
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(accc[nt]) : "a"(bw[nt][sq][1]), "v"(af[sq][0]));  \
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(accc[nt]) : "a"(bw[nt][sq][0]), "v"(af[sq][1]));  \
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(accc[nt]) : "a"(bw[nt][sq][0]), "v"(af[sq][0]));
+    auto slice = [&](auto gc) {
+      constexpr int G = decltype(gc)::value;
+      if constexpr (G < 4) {
+        // previous tile's accumulators into the wave's scratch: lane (i = location, g) holds
+        // channels 16 nt + 4 g .. + 3 (LDS serves a wave's accesses in order)
+#pragma unroll
+        for (int nt = 2 * G; nt < 2 * G + 2; ++nt)
+          *(__attribute__((address_space(3))) f32x4*)(size_t)(scr0 + i * DXV_SLD + (16 * nt + 4 * g) * 4) = accp[nt];
+      } else if constexpr (G < 8) {
+        // this tile's epilogue inputs (used one step later)
+        constexpr int v = G - 4;
+        int r = ec2.r0 + el + 4 * v;
+        r = r < nrows ? r : nrows - 1;
+        ec2.xr[v] = *reinterpret_cast<const u32x4*>(xbase + ((unsigned)r * (D * 2) + xcol));
+        ec2.rn4[v] = *reinterpret_cast<const float*>(rnbase + (unsigned)r * 4);
+        ec2.rd4[v] = *reinterpret_cast<const float*>(rdbase + (unsigned)r * 4);
+      } else if constexpr (G < 12) {
+        constexpr int v = G - 8;                           // rows of 128 channels back from the scratch
+        const unsigned ra = scr0 + (el + 4 * v) * DXV_SLD + ec * 32;
+        d0[v] = *(const __attribute__((address_space(3))) f32x4*)(size_t)(ra);
+        d1[v] = *(const __attribute__((address_space(3))) f32x4*)(size_t)(ra + 16);
+        rnv[v] = p.pre_l2 ? ep.rn4[v] : 1.0f;
+        // x * rsqrt(max(ss, eps)): with the clamp active the op is a plain scale (no projection)
+        fv[v] = (p.pre_l2 && rnv[v] < 1.0e6f) ? rnv[v] * ep.rd4[v] : 0.f;
+      } else if constexpr (G < 28) {
+        constexpr int v = (G - 12) >> 2, qd = (G - 12) & 3;  // two of the row's eight values
+        const unsigned xw = ep.xr[v][qd];
+        const float x0 = __uint_as_float(xw << 16), x1 = __uint_as_float(xw & 0xffff0000u);
+        const float a0 = qd < 2 ? d0[v][2 * qd] : d1[v][2 * qd - 4];
+        const float a1 = qd < 2 ? d0[v][2 * qd + 1] : d1[v][2 * qd - 3];
+        outv[v][2 * qd] = (a0 - x0 * fv[v]) * rnv[v];
+        outv[v][2 * qd + 1] = (a1 - x1 * fv[v]) * rnv[v];
+        if constexpr (qd == 3) {
+          // rows past the end go to the trash line: no exec-masked branch inside the step
+          const int r = ep.r0 + el + 4 * v;
+          Elem8<unsigned short>::st(r < nrows ? reinterpret_cast<unsigned short*>(gbase + ((unsigned)r * (D * 2) + xcol))
+                                              : p.trash + 8 * lane, outv[v]);
+        }
+      } else if constexpr (G == 28) {
+        split2x8(pa0, pa1, sth, stl);                       // next tile's fragments (k-step wid)
+      } else if constexpr (G == 29) {
+        const unsigned base = lds0 + ((tt + 1) & 1) * DXV_ABUF + (wid * 2) * 1024 + lane * 16;
+        *(lds_u32x4*)(size_t)(base) = sth;
+        *(lds_u32x4*)(size_t)(base + 1024) = stl;
+      } else if constexpr (G == 30) {
+        a_load(tt + 2, pa0, pa1);                           // (rows clamped: harmless past the end)
+      }
+    };
+#define DX_SL(G) slice(std::integral_constant<int, G>{});
+#define DX_NT(nt)                                                                       \
+  DX_M0(nt) DX_SL(4 * nt) DX_MS(nt, 1) DX_SL(4 * nt + 1) DX_MS(nt, 2) DX_SL(4 * nt + 2) \
+  DX_MS(nt, 3) DX_SL(4 * nt + 3)
+    DX_NT(0) DX_NT(1) DX_NT(2) DX_NT(3) DX_NT(4) DX_NT(5) DX_NT(6) DX_NT(7)
+#undef DX_NT
+#undef DX_SL
+#undef DX_MS
+#undef DX_M0
     vlad_mfma_settle();
     __syncthreads();
     if (tt < 9) DX_STAMP(3 + tt);
