@@ -164,7 +164,7 @@ extern "C" int scl_conv_pack_batch(const SclPackJob* jobs, int njobs, void* stre
         tiles += (pj.cin[i] / 32) * (pj.kout[i] / 32);
       }
       pj.first_block[pj.n] = tiles;
-      SCL_LAUNCH("conv_pack_batch_kernel", conv_pack_tiled_kernel, dim3((unsigned)tiles), dim3(256), 0,
+      SCL_LAUNCH("conv_pack_tiled_kernel", conv_pack_tiled_kernel, dim3((unsigned)tiles), dim3(256), 0,
                  (hipStream_t)stream, pj);
     } else {
       SCL_LAUNCH("conv_pack_batch_kernel", conv_pack_batch_kernel, dim3((unsigned)blocks), dim3(256), 0,

@@ -150,3 +150,35 @@ def test_bench_launches_its_own_ranks(tmp_path):
     bad = subprocess.run([sys.executable, bench, '--gpus', '2', '--steps', '1', '--warmup', '0'],
                          env=env, capture_output=True, text=True, timeout=240)
     assert bad.returncode != 0 and 'ranks failed' in bad.stderr
+
+
+def test_profiling_sink_names_are_the_kernel_names():
+    """Every SCL_LAUNCH site reports its kernel under the kernel's OWN name (template arguments may
+    follow), so the rows of bench.py's `kernels` / `roofline*` objects can be looked up in a
+    rocprofv3 trace as they stand; and bench.py prices every NetVLAD / loss kernel the library
+    can launch."""
+    import glob
+    import re
+    names = set()
+    for path in sorted(glob.glob(os.path.join(ROOT, 'soft_contrastive_learning_amd', 'csrc', '*.hip'))):
+        src = open(path).read()
+        for m in re.finditer(r'SCL_LAUNCH\(', src):
+            if '#define' in src[max(0, m.start() - 20):m.start()]:
+                continue                                     # the macro's own definition
+            depth, i = 0, m.end()
+            while not (src[i] == ',' and depth == 0):        # the label expression has no commas
+                depth += (src[i] == '(') - (src[i] == ')')
+                i += 1
+            labels = re.findall(r'"([^"]+)"', src[m.end():i])
+            kernel = re.match(r'[\s\\]*\(?\s*(\w+)', src[i + 1:]).group(1)
+            assert labels, (path, src[m.end():i])
+            for lab in labels:
+                assert re.sub(r'<.*$', '', lab) == kernel, (os.path.basename(path), lab, kernel)
+                names.add(lab)
+    import bench
+    models = bench.kernel_models(24, 1200, 24, 2)
+    head = sorted(n for n in names if re.match(
+        r'(vlad_|gram|finish_|bwd_d|rowtile16|aggregate_kernel|dx16|wgrad_finish)', n))
+    assert len(head) >= 20, head
+    missing = [n for n in head if n not in models]
+    assert not missing, missing
