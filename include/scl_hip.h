@@ -347,6 +347,16 @@ int scl_conv3x3_masked(const void* x, const void* w, int64_t w_stride_k, int64_t
                        int64_t w_stride_h, int64_t w_stride_w, int transposed, int B, int H,
                        int W, int cin, int kout, void* out, const void* mask, void* workspace,
                        size_t workspace_bytes, void* stream);
+/* ... for the layer under a 2x2 max-pooling (cin == kout: 64 or 128): g_pooled [B,H/2,W/2,cin] is
+ * the gradient at the pooled map (ReLU' applied), pool_idx the uint8 window positions of
+ * scl_conv3x3_pool_idx; the kernel un-pools into its LDS window while staging — bit-identical
+ * to scl_vgg_pool_bwd_idx followed by scl_conv3x3_masked, without the full-size gradient in
+ * memory.  flags: SCL_CONV_TRANSPOSED | SCL_W_F32 | SCL_W_PACKED as for scl_conv3x3.  H, W even. */
+int scl_conv3x3_masked_pooled(const void* g_pooled, const void* pool_idx, const void* w,
+                              int64_t w_stride_k, int64_t w_stride_c, int64_t w_stride_h,
+                              int64_t w_stride_w, int flags, int B, int H, int W, int cin,
+                              int kout, void* out, const void* mask, void* workspace,
+                              size_t workspace_bytes, void* stream);
 int scl_convg_masked(const void* x, const void* w, int64_t w_stride_k, int64_t w_stride_c,
                      int64_t w_stride_h, int64_t w_stride_w, int transposed, int B, int H, int W,
                      int cin, int kout, void* out, const void* mask, void* workspace,
@@ -403,6 +413,17 @@ int scl_wrw3x3_bias(const void* x, const void* gz, int B, int H, int W, int cin,
                     int64_t w_stride_k, int64_t w_stride_c, int64_t w_stride_h, int64_t w_stride_w,
                     int gw_f32, float* grad_bias, void* workspace, size_t workspace_bytes,
                     void* stream);
+/* The same for a layer that ends in the 2x2 max-pooling (model/nets.py:40-42, conv1_2 .. conv4_3):
+ * g_pooled [B,H/2,W/2,kout] bf16 is the gradient at the POOLED map (ReLU' applied) and pool_idx
+ * the uint8 window positions scl_conv3x3_pool_idx / scl_convg_pool_idx wrote in the forward
+ * pass.  The full-size gradient (one non-zero per window and channel) is built tile by tile in
+ * LDS and never exists in memory: bit-identical to scl_vgg_pool_bwd_idx followed by
+ * scl_wrw3x3_bias, without that pass's write and this one's read of the full-size map.
+ * H and W even. */
+int scl_wrw3x3_pooled(const void* x, const void* g_pooled, const void* pool_idx, int B, int H,
+                      int W, int cin, int kout, void* gw, int64_t w_stride_k, int64_t w_stride_c,
+                      int64_t w_stride_h, int64_t w_stride_w, int gw_f32, float* grad_bias,
+                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* All packed weight images of a training step in ONE launch (the convolutions above otherwise
  * each run a 4-10 us packing kernel in front of themselves: 24 per step on the critical

@@ -84,6 +84,7 @@ SIGNATURES = {
                                 _p]),
     "scl_vgg_pool_bwd_idx": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _z, _p]),
     "scl_conv3x3_masked": (_i, [_p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _p, _p, _p, _z, _p]),
+    "scl_conv3x3_masked_pooled": (_i, [_p, _p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _p, _p, _p, _z, _p]),
     "scl_convg_masked": (_i, [_p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _p, _p, _p, _z, _p]),
     "scl_convg": (_i, [_p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p, _z, _p]),
     "scl_wrw64_workspace_bytes": (_z, []),
@@ -92,6 +93,7 @@ SIGNATURES = {
     "scl_wrw3x3": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _l, _l, _l, _l, _p, _z, _p]),
     "scl_wrw3x3_ex": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _l, _l, _l, _l, _i, _p, _z, _p]),
     "scl_wrw3x3_bias": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _l, _l, _l, _l, _i, _p, _p, _z, _p]),
+    "scl_wrw3x3_pooled": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _l, _l, _l, _l, _i, _p, _p, _z, _p]),
     "scl_conv_first_wrw_workspace_bytes": (_z, []),
     "scl_conv_first_wrw": (_i, [_p, _p, _i, _i, _i, _p, _l, _l, _l, _l, _i, _p, _p, _p, _p, _z, _p]),
     "scl_conv_first": (_i, [_p, _p, _p, _l, _l, _l, _l, _i, _p, _i, _i, _i, _p, _p, _p]),

@@ -118,7 +118,13 @@ __global__ __launch_bounds__(256) void conv3x3_pack_kernel(const void* __restric
 // keeps its register allocation): 0 plain, 1 + bias (+ ReLU), 2 raw + pooled output,
 // 3 out = conv * [mask > 0] (the ReLU' of the layer below, for backward-data),
 // 4 pooled output + the window position of each maximum (one byte), no full-size output.
-template <int CIN, int KOUT, int EPI>
+//
+// PL = 1 (backward-data of a layer that ends in the 2x2 max-pooling): x is the POOLED gradient
+// [B][H/2][W/2][CIN] and uidx its window positions; the halo window of the full-size gradient is
+// built in LDS by the threads (16 bytes of the pooled map + 8 index bytes per (pooled pixel,
+// 8 channels), loaded when the tile starts, un-pooled and written in slices between the k-steps
+// of the second half of the K loop) — the full-size map is never in memory.  H and W even.
+template <int CIN, int KOUT, int EPI, int PL = 0>
 __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(const unsigned short* __restrict__ x,
                                                          const unsigned short* __restrict__ packed,
                                                          int B, int H, int W,
@@ -126,7 +132,8 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
                                                          const float* __restrict__ bias, int relu,
                                                          unsigned short* __restrict__ pooled,
                                                          const unsigned short* __restrict__ mask,
-                                                         unsigned char* __restrict__ pidx) {
+                                                         unsigned char* __restrict__ pidx,
+                                                         const unsigned char* __restrict__ uidx) {
   using Cfg = ConvCfg<CIN, KOUT>;
   constexpr int TH_ = Cfg::TH_, PIX = Cfg::PIX, WIN_ = Cfg::WIN_, KS = Cfg::KS, MT = Cfg::MT;
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
@@ -179,17 +186,76 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
       }
     }
   };
+  // PL: the window [WR_][34] of the full-size gradient starts at the odd pixel (ty - 1, tx - 1):
+  // it is covered by (TH_ / 2 + 2) x 18 pooling windows, the outer ones with one row / column
+  // inside.  Task (round rd, thread) = (pooled pixel of that grid, 8 channels).
+  constexpr int PWR = TH_ / 2 + 2, PWC = TW / 2 + 2, PPP = Cfg::PPP;
+  constexpr int PNR = PL ? (PWR * PWC * PPP + Cfg::NTHR - 1) / Cfg::NTHR : 1;
+  // The rounds travel in NB batches of PLIVE rounds, one after the other through the same
+  // registers: batch g is loaded at k-step g * SPAN - 1 (the first one when the tile starts) and
+  // written in the last 4 * PLIVE + 2 .. 2 k-steps of its span.  (64, 64): two batches of one round
+  // — six registers live, the kernel sits at the 256 of two waves per SIMD.
+  constexpr int PLIVE = CIN == 64 ? 1 : PNR, NB = PNR / PLIVE, SPAN = KS / NB;
+  static_assert(!PL || (PNR % PLIVE == 0 && 4 * PLIVE + 2 < SPAN), "un-pooling schedule");
+  const int Ho = H >> 1, Wo = W >> 1;
+  u32x4 pg[PLIVE];
+  uint2 pi[PLIVE];
+  const int p_piece = threadIdx.x % PPP;
+  // pooled (row << 8 | column) of this thread's task in round rd, -1: none
+  auto p_rc = [&](int rd) {
+    const int pp = ((int)threadIdx.x + Cfg::NTHR * rd) / PPP;
+    return pp < PWR * PWC ? ((pp / PWC) << 8) | (pp % PWC) : -1;
+  };
+  auto pool_issue = [&](int tile, int g) {
+    const int b = tile / per_img, t2 = tile % per_img;
+    const int py0 = (t2 / tiles_x) * (TH_ / 2) - 1, px0 = (t2 % tiles_x) * (TW / 2) - 1;
+#pragma unroll
+    for (int i = 0; i < PLIVE; ++i) {
+      const int rc = p_rc(g * PLIVE + i);
+      const int py = py0 + (rc >> 8), px = px0 + (rc & 255);
+      const int off = ((b * Ho + py) * Wo + px) * CIN + 8 * p_piece;
+      if (rc >= 0 && (unsigned)py < (unsigned)Ho && (unsigned)px < (unsigned)Wo) {
+        pg[i] = *reinterpret_cast<const u32x4*>(x + off);
+        pi[i] = *reinterpret_cast<const uint2*>(uidx + off);
+      } else {
+        pg[i] = u32x4{0u, 0u, 0u, 0u};
+        pi[i] = uint2{0u, 0u};
+      }
+    }
+  };
+  // slice (round i of batch g, pos): window pixel (2 pr + dy - 1, 2 pc + dx - 1) if inside
+  auto pool_write = [&](int g, int i, int pos, int buf) {
+    const int rc = p_rc(g * PLIVE + i);
+    const int wy = 2 * (rc >> 8) + (pos >> 1) - 1, wx = 2 * (rc & 255) + (pos & 1) - 1;
+    const UnpoolFlags fl = unpool_flags(pi[i].x, pi[i].y);
+    const u32x4 o = unpool8(pg[i], fl, pos);
+    if (rc >= 0 && (unsigned)wy < (unsigned)Cfg::WR_ && (unsigned)wx < (unsigned)WC)
+      *reinterpret_cast<u32x4*>(lds + buf * WIN_ + (wy * WC + wx) * PIX + 8 * p_piece) = o;
+  };
 
   const int dbg = relu >> 1;            // timing diagnostics (scl_debug_set_variant(60000 + bits))
   relu &= 1;
   int tile = blockIdx.x;
-  if (tile < ntiles) stage_issue(tile, 0);
+  if (tile < ntiles) {
+    if (PL) {
+#pragma unroll
+      for (int g = 0; g < NB; ++g) {
+        pool_issue(tile, g);
+#pragma unroll
+        for (int sl = 0; sl < 4 * PLIVE; ++sl) pool_write(g, sl >> 2, sl & 3, 0);
+      }
+    } else {
+      stage_issue(tile, 0);
+    }
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int buf = 0;
   for (; tile < ntiles; tile += gridDim.x) {
     const int next = (dbg & 1) ? ntiles : tile + gridDim.x;
-    if (next < ntiles) stage_issue(next, buf ^ 1);       // lands under the whole K loop
+    if (next < ntiles) {                                 // lands under the whole K loop
+      if (PL) pool_issue(next, 0); else stage_issue(next, buf ^ 1);
+    }
     // EPI 3: the tile's mask values are fetched now, under the K loop (an epilogue that waits
     // for them exposes the HBM latency once per tile row)
     u32x4 mk[EPI == 3 ? MT : 1][2];
@@ -227,6 +293,13 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma32b(af[ks & 1][mt], wf[ks], acc[mt]);
+      if (PL) {
+        // (also after the last tile: stale registers into a buffer nobody reads — no branch)
+        constexpr int W0 = SPAN - 4 * PLIVE - 2;
+        const int g = ks / SPAN, kk = ks % SPAN;
+        if (kk >= W0 && kk < W0 + 4 * PLIVE) pool_write(g, (kk - W0) >> 2, (kk - W0) & 3, buf ^ 1);
+        if (kk == SPAN - 1 && g + 1 < NB && next < ntiles) pool_issue(next, g + 1);
+      }
     }
 
     // this wave's share of the next window has landed (waited for here, before the epilogue's
@@ -368,12 +441,22 @@ struct WrwCfg {
 // narrow maps, a step = two rows of 8): the same 256 pixels, 340-pixel windows and LDS image
 // either way — only the pixel <-> address maps differ; the host takes the shape that pads the
 // map less (W = 80: 96 -> 80 columns; 30 x 40: 32 x 64 -> 32 x 40).
-template <int DBG, int TWv, int NKB>
+//
+// PL = 1: the layer ends in a 2x2 max-pooling, and `gz` is the POOLED gradient [B][H/2][W/2][K]
+// with `pidx` the window position (2 dy + dx) of every maximum (scl_conv3x3_pool_idx): the
+// full-size gradient — one non-zero per window and channel — is never in memory.  Its tile is
+// built in LDS instead: every thread loads 16 bytes of the pooled gradient and their 8 index
+// bytes for the NEXT tile when the tile starts (512 threads = the tile's pooled pixels x planes x
+// pieces exactly), and writes the four 16-byte pixels of the window at the tile's end.  The gz
+// part of the stream shrinks from 2 to 0.75 bytes per element; H and W are even (host check),
+// so a window is inside or outside the image as a whole.
+template <int DBG, int TWv, int NKB, int PL = 0>
 __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __restrict__ x,
                                                        const unsigned short* __restrict__ gz,
                                                        int B, int H, int W, int C, int K,
                                                        float* __restrict__ slabs,
-                                                       float* __restrict__ bslabs) {
+                                                       float* __restrict__ bslabs,
+                                                       const unsigned char* __restrict__ pidx) {
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -436,7 +519,7 @@ __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __r
         const int y = ty - 1 + (rel[i] >> 8), xx = tx - 1 + (rel[i] & 255);
         const bool ok = rel[i] >= 0 && (unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W;
         glds16(ok ? x + (xo + roff[i]) : zeros, base + (plane * XPLANE + chunk * 512) * 2);
-      } else if (j < WCHUNKS) {
+      } else if (j < WCHUNKS && !PL) {
         const int jj = j - 2 * XCH;
         const int plane = jj / GCH, chunk = jj - GCH * plane;
         const int y = ty + (rel[i] >> 8), xx = tx + (rel[i] & 255);
@@ -445,6 +528,33 @@ __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __r
                base + (2 * XPLANE + plane * GPLANE + chunk * 512) * 2);
       }
     }
+  };
+  // PL: this thread's window of the tile = pooled pixel (pr, pc), 8 channels (plane, piece)
+  constexpr int NPC = TWv / 2, NPR = THv / 2;
+  const int p_piece = threadIdx.x & 3, p_pc = (threadIdx.x >> 2) % NPC;
+  const int p_pr = ((threadIdx.x >> 2) / NPC) % NPR, p_plane = (threadIdx.x >> 2) / (NPC * NPR);
+  const int Ho = H >> 1, Wo = W >> 1;
+  u32x4 pg = {0u, 0u, 0u, 0u};
+  uint2 pi = {0u, 0u};
+  auto pool_issue = [&](int tile) {
+    const int b = tile / per_img, t2 = tile % per_img;
+    const int py = (t2 / tiles_x) * NPR + p_pr, px = (t2 % tiles_x) * NPC + p_pc;
+    const int off = ((b * Ho + py) * Wo + px) * K + NKB * C64 * blockIdx.z + 32 * p_plane + 8 * p_piece;
+    if (py < Ho && px < Wo) {
+      pg = *reinterpret_cast<const u32x4*>(gz + off);
+      pi = *reinterpret_cast<const uint2*>(pidx + off);
+    } else {
+      pg = u32x4{0u, 0u, 0u, 0u};
+      pi = uint2{0u, 0u};
+    }
+  };
+  auto pool_write = [&](int buf) {
+    unsigned short* dst = lds + buf * WBUF + 2 * XPLANE + p_plane * GPLANE +
+                          (2 * p_pr * TWv + 2 * p_pc) * WPL + 8 * p_piece;
+    const UnpoolFlags fl = unpool_flags(pi.x, pi.y);
+#pragma unroll
+    for (int pos = 0; pos < 4; ++pos)
+      *reinterpret_cast<u32x4*>(dst + ((pos >> 1) * TWv + (pos & 1)) * WPL) = unpool8(pg, fl, pos);
   };
 
   f32x16 acc[9];
@@ -464,13 +574,22 @@ __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __r
   // of tile n; one barrier per tile (it drains the DMA: hipcc waits vmcnt(0) there).
   constexpr int DEPTH = 4, AHEAD = 3;
   int tile = blockIdx.x;
-  if (tile < ntiles) stage_issue(tile, 0);
+  if (tile < ntiles) {
+    stage_issue(tile, 0);
+    if (PL) {
+      pool_issue(tile);
+      pool_write(0);
+    }
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int buf = 0;
   for (; tile < ntiles; tile += gridDim.x) {
     const int next = (DBG & 2) ? ntiles : tile + gridDim.x;
-    if (next < ntiles) stage_issue(next, buf ^ 1);
+    if (next < ntiles) {
+      stage_issue(next, buf ^ 1);
+      if (PL) pool_issue(next);
+    }
     const unsigned short* xl =
         lds + buf * WBUF + mt * XPLANE + (lrow * WCv + lcol) * WPL + ch0;
     const unsigned short* gl =
@@ -508,6 +627,7 @@ __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __r
         bsum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, w3), one2, bsum, false);
       }
     }
+    if (PL && next < ntiles) pool_write(buf ^ 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA chunks have landed
     __syncthreads();
     buf ^= 1;
@@ -972,7 +1092,8 @@ static int conv64_cus();
 template <int CIN, int KOUT>
 int launch_conv3x3(const void* x, const void* w, int64_t sk, int64_t sc, int64_t sh, int64_t sw,
                    int transposed, int B, int H, int W, void* out, const float* bias, int relu,
-                   void* pooled, const void* mask, void* pidx, void* workspace, hipStream_t st) {
+                   void* pooled, const void* mask, void* pidx, const void* uidx, void* workspace,
+                   hipStream_t st) {
   using Cfg = ConvCfg<CIN, KOUT>;
   static std::once_flag once;
   static int cus = 256;
@@ -987,6 +1108,9 @@ int launch_conv3x3(const void* x, const void* w, int64_t sk, int64_t sc, int64_t
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<CIN, KOUT, 4>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
+    if (CIN == KOUT)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<CIN, CIN, 3, 1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
     cus = conv64_cus();
   });
   const unsigned short* packed = (const unsigned short*)workspace;
@@ -1003,27 +1127,32 @@ int launch_conv3x3(const void* x, const void* w, int64_t sk, int64_t sc, int64_t
     SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 4>), grid, dim3(Cfg::NTHR), Cfg::LDS, st,
                (const unsigned short*)x, (const unsigned short*)packed, B, H, W,
                (unsigned short*)nullptr, bias, relu & ~1, (unsigned short*)pooled,
-               (const unsigned short*)nullptr, (unsigned char*)pidx);
+               (const unsigned short*)nullptr, (unsigned char*)pidx, (const unsigned char*)nullptr);
+  else if (mask && uidx && CIN == KOUT)
+    SCL_LAUNCH("conv3x3_kernel<pooled>", (conv3x3_kernel<CIN, CIN, 3, 1>), grid, dim3(Cfg::NTHR), Cfg::LDS,
+               st, (const unsigned short*)x, (const unsigned short*)packed, B, H, W,
+               (unsigned short*)out, bias, relu & ~1, (unsigned short*)nullptr,
+               (const unsigned short*)mask, (unsigned char*)nullptr, (const unsigned char*)uidx);
   else if (mask)
     SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 3>), grid, dim3(Cfg::NTHR), Cfg::LDS, st,
                (const unsigned short*)x, (const unsigned short*)packed, B, H, W,
                (unsigned short*)out, bias, relu & ~1, (unsigned short*)nullptr,
-               (const unsigned short*)mask, (unsigned char*)nullptr);
+               (const unsigned short*)mask, (unsigned char*)nullptr, (const unsigned char*)nullptr);
   else if (pooled)
     SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 2>), grid, dim3(Cfg::NTHR), Cfg::LDS, st,
                (const unsigned short*)x, (const unsigned short*)packed, B, H, W,
                (unsigned short*)out, bias, relu, (unsigned short*)pooled,
-               (const unsigned short*)nullptr, (unsigned char*)nullptr);
+               (const unsigned short*)nullptr, (unsigned char*)nullptr, (const unsigned char*)nullptr);
   else if (bias)
     SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 1>), grid, dim3(Cfg::NTHR), Cfg::LDS, st,
                (const unsigned short*)x, (const unsigned short*)packed, B, H, W,
                (unsigned short*)out, bias, relu, (unsigned short*)pooled,
-               (const unsigned short*)nullptr, (unsigned char*)nullptr);
+               (const unsigned short*)nullptr, (unsigned char*)nullptr, (const unsigned char*)nullptr);
   else
     SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 0>), grid, dim3(Cfg::NTHR), Cfg::LDS, st,
                (const unsigned short*)x, (const unsigned short*)packed, B, H, W,
                (unsigned short*)out, bias, relu, (unsigned short*)pooled,
-               (const unsigned short*)nullptr, (unsigned char*)nullptr);
+               (const unsigned short*)nullptr, (unsigned char*)nullptr, (const unsigned char*)nullptr);
   return scl_launch_status();
 }
 
@@ -1035,8 +1164,10 @@ static int conv3x3_dispatch(const void* x, const void* w, int64_t w_stride_k, in
                             int64_t w_stride_h, int64_t w_stride_w, int transposed, int B, int H,
                             int W, int cin, int kout, void* out, const float* bias, int relu,
                             void* pooled, const void* mask, void* pidx, void* workspace,
-                            size_t workspace_bytes, void* stream) {
+                            size_t workspace_bytes, void* stream, const void* uidx = nullptr) {
   if (!x || !w || (!out && !pidx) || !workspace) return SCL_E_NULL;
+  // un-pooling window staging: the masked backward-data pass of a cin == kout layer, even H, W
+  if (uidx && (!mask || cin != kout || ((H | W) & 1) || ((uintptr_t)uidx % 8))) return SCL_E_SHAPE;
   if (pidx && (!pooled || !bias || mask || ((uintptr_t)pidx % 8))) return SCL_E_NULL;
   if (mask && (bias || pooled || ((uintptr_t)mask % 16))) return SCL_E_NULL;
   if ((int64_t)B * H * W * cin >= (int64_t)1 << 31) return SCL_E_SHAPE;   // 32-bit element offsets
@@ -1050,7 +1181,7 @@ static int conv3x3_dispatch(const void* x, const void* w, int64_t w_stride_k, in
   if (cin == CI && kout == KO)                                                                 \
     return launch_conv3x3<CI, KO>(x, w, w_stride_k, w_stride_c, w_stride_h, w_stride_w,        \
                                   transposed, B, H, W, out, bias, relu ? 1 : 0, pooled,        \
-                                  mask, pidx, workspace, st);
+                                  mask, pidx, uidx, workspace, st);
   SCL_CONV_CASE(64, 64)
   SCL_CONV_CASE(64, 128)
   SCL_CONV_CASE(128, 64)
@@ -1089,6 +1220,18 @@ extern "C" int scl_conv3x3_masked(const void* x, const void* w, int64_t w_stride
   return conv3x3_dispatch(x, w, w_stride_k, w_stride_c, w_stride_h, w_stride_w, transposed, B, H,
                           W, cin, kout, out, nullptr, 0, nullptr, mask, nullptr, workspace,
                           workspace_bytes, stream);
+}
+
+extern "C" int scl_conv3x3_masked_pooled(const void* g_pooled, const void* pool_idx, const void* w,
+                                         int64_t w_stride_k, int64_t w_stride_c,
+                                         int64_t w_stride_h, int64_t w_stride_w, int flags, int B,
+                                         int H, int W, int cin, int kout, void* out,
+                                         const void* mask, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+  if (!mask || !pool_idx) return SCL_E_NULL;
+  return conv3x3_dispatch(g_pooled, w, w_stride_k, w_stride_c, w_stride_h, w_stride_w, flags, B, H,
+                          W, cin, kout, out, nullptr, 0, nullptr, mask, nullptr, workspace,
+                          workspace_bytes, stream, pool_idx);
 }
 
 extern "C" int scl_conv3x3(const void* x, const void* w, int64_t w_stride_k, int64_t w_stride_c,
@@ -1141,12 +1284,13 @@ static size_t wrw_bias_slab_offset(int cin, int kout) {
   return scl_round256(2 * p * blocks * 9 * 64 * 64 * sizeof(float));
 }
 
-extern "C" int scl_wrw3x3_bias(const void* x, const void* gz, int B, int H, int W, int cin,
-                               int kout, void* gw, int64_t w_stride_k, int64_t w_stride_c,
-                               int64_t w_stride_h, int64_t w_stride_w, int gw_f32,
-                               float* grad_bias, void* workspace, size_t workspace_bytes,
-                               void* stream) {
+// pidx != nullptr: gz is the pooled gradient [B][H/2][W/2][kout], pidx its window positions
+static int wrw3x3_run(const void* x, const void* gz, const unsigned char* pidx, int B, int H, int W,
+                      int cin, int kout, void* gw, int64_t w_stride_k, int64_t w_stride_c,
+                      int64_t w_stride_h, int64_t w_stride_w, int gw_f32, float* grad_bias,
+                      void* workspace, size_t workspace_bytes, void* stream) {
   if (!x || !gz || !gw || !workspace) return SCL_E_NULL;
+  if (pidx && ((H | W) & 1 || (uintptr_t)pidx % 8)) return SCL_E_SHAPE;
   const size_t need = scl_wrw3x3_workspace_bytes(cin, kout);
   if (need == 0 || B < 1 || H < 1 || W < 1 || (int64_t)B * H * W > (int64_t)1 << 30)
     return SCL_E_SHAPE;
@@ -1157,12 +1301,13 @@ extern "C" int scl_wrw3x3_bias(const void* x, const void* gz, int B, int H, int 
   static std::once_flag once;
   static int cus = 256;
   std::call_once(once, [] {
-#define SCL_WRW_ATTR(D, T, N)                                                                  \
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wrw64_kernel<D, T, N>),             \
+#define SCL_WRW_ATTR(D, T, N, PL)                                                              \
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wrw64_kernel<D, T, N, PL>),         \
                             hipFuncAttributeMaxDynamicSharedMemorySize,                        \
                             (int)WrwCfg<T, N>::LDS);
-    SCL_WRW_ATTR(0, 32, 1) SCL_WRW_ATTR(2, 32, 1)
-    SCL_WRW_ATTR(0, 8, 1) SCL_WRW_ATTR(0, 32, 2) SCL_WRW_ATTR(0, 8, 2)
+    SCL_WRW_ATTR(0, 32, 1, 0) SCL_WRW_ATTR(2, 32, 1, 0)
+    SCL_WRW_ATTR(0, 8, 1, 0) SCL_WRW_ATTR(0, 32, 2, 0) SCL_WRW_ATTR(0, 8, 2, 0)
+    SCL_WRW_ATTR(0, 32, 1, 1) SCL_WRW_ATTR(0, 8, 1, 1) SCL_WRW_ATTR(0, 32, 2, 1) SCL_WRW_ATTR(0, 8, 2, 1)
 #undef SCL_WRW_ATTR
     cus = conv64_cus();
     if (cus > 1024) cus = 1024;
@@ -1178,18 +1323,25 @@ extern "C" int scl_wrw3x3_bias(const void* x, const void* gz, int B, int H, int 
   const int tiles = tall ? tiles_tall : tiles_wide;
   const int P = wrw_splits(cin, kout, tiles, cus);
   hipStream_t st = (hipStream_t)stream;
-#define SCL_WRW_LAUNCH(D, T, N)                                                                \
-  SCL_LAUNCH("wrw64_kernel", (wrw64_kernel<D, T, N>), dim3(PP, cin / 64, kout / (64 * N)),     \
-             dim3(512), (WrwCfg<T, N>::LDS), st, (const unsigned short*)x,                        \
-             (const unsigned short*)gz, B, H, W, cin, kout, (float*)workspace, bslabs)
+#define SCL_WRW_LAUNCH(D, T, N, PL)                                                            \
+  SCL_LAUNCH(PL ? "wrw64_kernel<pooled>" : "wrw64_kernel", (wrw64_kernel<D, T, N, PL>),        \
+             dim3(PP, cin / 64, kout / (64 * N)), dim3(512), (WrwCfg<T, N>::LDS), st,          \
+             (const unsigned short*)x, (const unsigned short*)gz, B, H, W, cin, kout,          \
+             (float*)workspace, bslabs, pidx)
   float* bslabs = grad_bias ? (float*)((char*)workspace + wrw_bias_slab_offset(cin, kout)) : nullptr;
   int PP = P;
   if (nkb == 2) {
     PP = wrw_splits(cin, kout / 2, tiles, cus);
-    if (tall) SCL_WRW_LAUNCH(0, 8, 2); else SCL_WRW_LAUNCH(0, 32, 2);
-  } else if (tall) SCL_WRW_LAUNCH(0, 8, 1);
-  else if (dbg == 0) SCL_WRW_LAUNCH(0, 32, 1);
-  else SCL_WRW_LAUNCH(2, 32, 1);
+    if (pidx) {
+      if (tall) SCL_WRW_LAUNCH(0, 8, 2, 1); else SCL_WRW_LAUNCH(0, 32, 2, 1);
+    } else {
+      if (tall) SCL_WRW_LAUNCH(0, 8, 2, 0); else SCL_WRW_LAUNCH(0, 32, 2, 0);
+    }
+  } else if (pidx) {
+    if (tall) SCL_WRW_LAUNCH(0, 8, 1, 1); else SCL_WRW_LAUNCH(0, 32, 1, 1);
+  } else if (tall) SCL_WRW_LAUNCH(0, 8, 1, 0);
+  else if (dbg == 0) SCL_WRW_LAUNCH(0, 32, 1, 0);
+  else SCL_WRW_LAUNCH(2, 32, 1, 0);
 #undef SCL_WRW_LAUNCH
   const int nslab = nkb == 1 ? 2 * PP : PP, nblk = (cin / 64) * (kout / 64);
 #define SCL_WRW_REDUCE(RG)                                                                     \
@@ -1200,6 +1352,26 @@ extern "C" int scl_wrw3x3_bias(const void* x, const void* gz, int B, int H, int 
   if (nblk <= 4 && nslab >= 32) SCL_WRW_REDUCE(16); else SCL_WRW_REDUCE(4);
 #undef SCL_WRW_REDUCE
   return scl_launch_status();
+}
+
+extern "C" int scl_wrw3x3_bias(const void* x, const void* gz, int B, int H, int W, int cin,
+                               int kout, void* gw, int64_t w_stride_k, int64_t w_stride_c,
+                               int64_t w_stride_h, int64_t w_stride_w, int gw_f32,
+                               float* grad_bias, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+  return wrw3x3_run(x, gz, nullptr, B, H, W, cin, kout, gw, w_stride_k, w_stride_c, w_stride_h,
+                    w_stride_w, gw_f32, grad_bias, workspace, workspace_bytes, stream);
+}
+
+extern "C" int scl_wrw3x3_pooled(const void* x, const void* g_pooled, const void* pool_idx, int B,
+                                 int H, int W, int cin, int kout, void* gw, int64_t w_stride_k,
+                                 int64_t w_stride_c, int64_t w_stride_h, int64_t w_stride_w,
+                                 int gw_f32, float* grad_bias, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  if (!pool_idx) return SCL_E_NULL;
+  return wrw3x3_run(x, g_pooled, (const unsigned char*)pool_idx, B, H, W, cin, kout, gw,
+                    w_stride_k, w_stride_c, w_stride_h, w_stride_w, gw_f32, grad_bias, workspace,
+                    workspace_bytes, stream);
 }
 
 extern "C" int scl_wrw3x3_ex(const void* x, const void* gz, int B, int H, int W, int cin, int kout,

@@ -105,6 +105,41 @@ struct Elem<unsigned short> {
   static __device__ __forceinline__ void st(unsigned short* p, float v) { *p = f32_to_bf16(v); }
 };
 
+// Un-pooling of a 2x2 max-pooling gradient in registers.  g = 8 bf16 channels of a POOLED
+// gradient pixel (four words), idx = their 8 window-position bytes (2 dy + dx, values 0..3).
+// UnpoolFlags puts, for each position, a flag into the top bit of every index byte that equals
+// it; unpool8(g, f, pos) is the 16 bytes of the full-size gradient at window position pos: the
+// channels routed there, zero elsewhere.  v_perm_b32's selectors 8..11 replicate bit 15 / 31 of
+// either source word over a byte — (flags << 8, flags) therefore expands to a 16-bit mask per
+// channel with one instruction per output word.
+struct UnpoolFlags {
+  unsigned e[2][4];        // [index word][position]
+};
+__device__ __forceinline__ UnpoolFlags unpool_flags(unsigned i0, unsigned i1) {
+  UnpoolFlags f;
+#pragma unroll
+  for (int hw = 0; hw < 2; ++hw) {
+    const unsigned iw = hw ? i1 : i0;
+    const unsigned b0 = (iw << 7) & 0x80808080u, b1 = (iw << 6) & 0x80808080u;
+    f.e[hw][3] = b0 & b1;
+    f.e[hw][2] = b1 ^ f.e[hw][3];
+    f.e[hw][1] = b0 ^ f.e[hw][3];
+    f.e[hw][0] = (b0 | b1) ^ 0x80808080u;
+  }
+  return f;
+}
+template <typename V4>
+__device__ __forceinline__ V4 unpool8(V4 g, const UnpoolFlags& f, int pos) {
+  V4 o;
+#pragma unroll
+  for (int hw = 0; hw < 2; ++hw) {
+    const unsigned e = f.e[hw][pos], eh = e << 8;
+    o[2 * hw] = g[2 * hw] & __builtin_amdgcn_perm(eh, e, 0x08080a0au);       // channels 0, 1
+    o[2 * hw + 1] = g[2 * hw + 1] & __builtin_amdgcn_perm(eh, e, 0x09090b0bu);   // channels 2, 3
+  }
+  return o;
+}
+
 // Raw (unconverted) vector loads: a prefetch must leave its destination registers untouched
 // until the data is consumed — converting bf16 at load time makes the compiler wait for the
 // load right after issuing it.  ldN returns the memory image, cvtN widens it to f32.

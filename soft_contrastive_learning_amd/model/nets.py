@@ -366,17 +366,27 @@ def _split_halves(b):
 
 
 def conv64(x, w, transposed=False, bias=None, relu=False, pool=False, mask=None, out=None,
-           pooled_out=None):
+           pooled_out=None, pool_idx=None):
     """3x3 same-padding convolution on bf16 channels-last activations (``scl_conv3x3_fused``)
     for the shapes of ``_OWN_CONV_SHAPES``; ``transposed`` gives the gradient with respect to
     the input of ``conv(., w)``.  ``bias`` (float32 [kout]) and ``relu`` fuse the layer's tail
     into the epilogue; ``pool=True`` returns ``(raw conv, relu(maxpool2x2(raw) + bias))``;
     ``mask`` (bf16, the output's shape) multiplies the result by ``[mask > 0]`` — the ReLU' of
-    the layer below fused into a backward-data pass."""
+    the layer below fused into a backward-data pass.  ``pool_idx`` (with ``transposed`` and
+    ``mask``, register kernels with cin == kout): ``x`` is the gradient at the POOLED map and the
+    kernel un-pools it by the forward pass's window positions while staging
+    (``scl_conv3x3_masked_pooled``)."""
     lib = L.load()
-    L.require_device(x, w, bias, mask)
+    L.require_device(x, w, bias, mask, pool_idx)
     x = x.contiguous(memory_format=_CL)
     b, _, h, wd = x.shape
+    if pool_idx is not None:
+        if mask is None or not transposed:
+            raise ValueError("pool_idx goes with the masked backward-data pass")
+        h, wd = mask.shape[2], mask.shape[3]
+        if (h % 2 or wd % 2 or tuple(x.shape[2:]) != (h // 2, wd // 2)
+                or tuple(pool_idx.shape) != tuple(x.shape) or pool_idx.dtype != torch.uint8):
+            raise ValueError("pooled gradient / index must be [B,C,H/2,W/2] (uint8 index), H and W even")
     cin, kout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
     inner = out is not None            # one half of a split forward: no further splitting
     if out is None:
@@ -400,7 +410,9 @@ def conv64(x, w, transposed=False, bias=None, relu=False, pool=False, mask=None,
         return (out, pooled) if pool else out
     sk, sc, sh, sw = w.stride()
     px = b * h * wd
-    if (cin, kout) in _OWN_CONV_SHAPES:
+    if pool_idx is not None:                # pooled gradient bf16 / 4 + index / 4; mask; output
+        _work('conv3x3_kernel<pooled>', 2.0 * px * cin * kout * 9, px * (0.75 * cin + 4.0 * kout))
+    elif (cin, kout) in _OWN_CONV_SHAPES:
         _work('conv3x3_kernel', 2.0 * px * cin * kout * 9,
               2.0 * px * (cin + kout * (1 + (mask is not None) + 0.25 * bool(pool))))
     else:
@@ -415,6 +427,14 @@ def conv64(x, w, transposed=False, bias=None, relu=False, pool=False, mask=None,
             raise ValueError("mask must have the output's shape and dtype")
         mask = mask.contiguous(memory_format=_CL)
         own = (cin, kout) in _OWN_CONV_SHAPES
+        if pool_idx is not None:
+            if not (own and cin == kout):
+                raise ValueError("un-pooling window staging exists for the 64->64 and 128->128 kernels")
+            ws = L.workspace(lib.scl_conv3x3_workspace_bytes(), x.device)
+            L.check(lib.scl_conv3x3_masked_pooled(
+                L.ptr(x), L.ptr(pool_idx.contiguous(memory_format=_CL)), wp, sk, sc, sh, sw, wflags,
+                b, h, wd, cin, kout, L.ptr(out), L.ptr(mask), L.ptr(ws), ws.numel(), L.stream_of(x)))
+            return out
         ws = L.workspace(lib.scl_conv3x3_workspace_bytes() if own
                          else lib.scl_convg_workspace_bytes(cin, kout), x.device)
         fn = lib.scl_conv3x3_masked if own else lib.scl_convg_masked
@@ -444,24 +464,37 @@ def _own_wrw_ok(x, gz, w):
             and max(w.shape[0], w.shape[1]) <= 1024)
 
 
-def wrw64(x, gz, w_like, bias_grad=None):
+def wrw64(x, gz, w_like, bias_grad=None, pool_idx=None):
     """Weight gradient of a 3x3 same-padding convolution whose channel counts are multiples
     of 64 (``scl_wrw3x3_bias``): [kout,cin,3,3] with the dtype (bf16 or float32) and strides of
     ``w_like``.  ``bias_grad`` (float32 [kout]) receives the column sums of ``gz`` — the bias
-    gradient — from the same pass."""
+    gradient — from the same pass.  With ``pool_idx`` (uint8 [B,kout,H/2,W/2], conv_pool_idx's
+    second result) ``gz`` is the gradient at the POOLED map of the same shape and the kernel
+    un-pools it while staging (``scl_wrw3x3_pooled``)."""
     lib = L.load()
-    L.require_device(x, gz)
+    L.require_device(x, gz, pool_idx)
     x = x.contiguous(memory_format=_CL)
     gz = gz.contiguous(memory_format=_CL)
     b, cin, h, wd = x.shape
     kout = gz.shape[1]
     gw = _grad_out(w_like)
-    _work('wrw64_kernel', 2.0 * b * h * wd * cin * kout * 9, 2.0 * b * h * wd * (cin + kout))
     ws = L.workspace(lib.scl_wrw3x3_workspace_bytes(cin, kout), x.device)
     sk, sc, sh, sw = gw.stride()
     if bias_grad is not None and not (bias_grad.dtype == torch.float32 and bias_grad.is_contiguous()
                                       and bias_grad.numel() == kout):
         raise ValueError("bias_grad must be a contiguous float32 vector of kout elements")
+    if pool_idx is not None:
+        if (h % 2 or wd % 2 or tuple(gz.shape) != (b, kout, h // 2, wd // 2)
+                or tuple(pool_idx.shape) != tuple(gz.shape) or pool_idx.dtype != torch.uint8):
+            raise ValueError("pooled gradient / index must be [B,kout,H/2,W/2] (uint8 index), H and W even")
+        pool_idx = pool_idx.contiguous(memory_format=_CL)
+        _work('wrw64_kernel<pooled>', 2.0 * b * h * wd * cin * kout * 9,
+              b * h * wd * (2.0 * cin + 0.75 * kout))
+        L.check(lib.scl_wrw3x3_pooled(L.ptr(x), L.ptr(gz), L.ptr(pool_idx), b, h, wd, cin, kout,
+                                      L.ptr(gw), sk, sc, sh, sw, int(gw.dtype == torch.float32),
+                                      L.ptr(bias_grad), L.ptr(ws), ws.numel(), L.stream_of(x)))
+        return gw
+    _work('wrw64_kernel', 2.0 * b * h * wd * cin * kout * 9, 2.0 * b * h * wd * (cin + kout))
     L.check(lib.scl_wrw3x3_bias(L.ptr(x), L.ptr(gz), b, h, wd, cin, kout, L.ptr(gw), sk, sc, sh, sw,
                                 int(gw.dtype == torch.float32), L.ptr(bias_grad), L.ptr(ws),
                                 ws.numel(), L.stream_of(x)))
@@ -507,6 +540,7 @@ class _GradLink:
 USE_BIAS_IN_WRW = os.environ.get('SCL_BIAS_IN_WRW', '1') != '0'
 USE_MASKED_BWD = os.environ.get('SCL_MASKED_BWD', '1') != '0'
 USE_POOL_IDX = os.environ.get('SCL_POOL_IDX', '1') != '0'
+USE_POOLED_BWD = os.environ.get('SCL_POOLED_BWD', '1') != '0'     # un-pool inside the consumers
 USE_F32_WEIGHTS = os.environ.get('SCL_F32_WEIGHTS', '1') != '0'
 
 
@@ -592,7 +626,7 @@ def autotune_side_wrw(step, steps=3, rounds=2):
     return {'chosen': USE_SIDE_WRW, 'ms_on': round(best[True], 3), 'ms_off': round(best[False], 3)}
 
 
-def _wrw_maybe_async(x, gz, w, gb):
+def _wrw_maybe_async(x, gz, w, gb, pool_idx=None):
     sink = GRAD_SINK
 
     def in_sink(t):                  # written where only the sink's consumers will read it
@@ -602,47 +636,66 @@ def _wrw_maybe_async(x, gz, w, gb):
             and sink.view(w) is not None and sink.view(w).stride() == w.stride()
             and (gb is None or in_sink(gb))):
         # (a gradient that goes back to autograd is read on the current stream right away)
-        return wrw64(x, gz, w, gb)
+        return wrw64(x, gz, w, gb, pool_idx)
     dev = x.device
     side = _SIDE.get(dev)
     if side is None:
         side = _SIDE[dev] = torch.cuda.Stream(device=dev)
     side.wait_stream(torch.cuda.current_stream(dev))
     with torch.cuda.stream(side):
-        gw = wrw64(x, gz, w, gb)
+        gw = wrw64(x, gz, w, gb, pool_idx)
     # x and gz are read on `side`; they must not go back to the allocator before that stream
     # is joined.  Tensor.record_stream would say so, but it makes the allocator hold the blocks
     # behind events and, every few runs, hipMalloc a new one in the middle of a step (one step
     # of 0.5 s in half of the bench runs): the sink keeps the references until finish() instead.
-    sink.note_stream(side, x, gz)
+    sink.note_stream(side, x, gz, *([] if pool_idx is None else [pool_idx]))
     return gw
 
 
-def _conv3x3_backward(gz, x, w, need_x, link=None, gb=None):
+def _conv3x3_backward(gz, x, w, need_x, link=None, gb=None, pooled=None):
     """(gx, gw) of a 3x3 convolution.  With ``link`` (x is a post-ReLU map whose producer
     holds the other end) an own backward-data kernel returns gx * [x > 0] and marks the
     link.  ``gb`` (only where ``_own_wrw_used``): the weight-gradient kernel also writes the
-    bias gradient there."""
-    kind = _own_conv_kind(gz, w, True)
-    own_gx = kind == 'reg' or (kind == 'lds' and _lds_conv_pays(gz, True))
-    own_gw = _own_wrw_used(x, gz, w)
+    bias gradient there.  ``pooled`` = (gradient at the pooled map, window positions) of a layer
+    that ends in the 2x2 max-pooling: the own weight-gradient kernel reads that instead of the
+    full-size ``gz``, and so does the backward-data kernel where it can (then ``gz`` may be
+    None: see ``_pooled_consumers``)."""
+    ga, idx = pooled if pooled is not None else (None, None)
+    g_any = ga if gz is None else gz                      # (channels and dtype are what is looked at)
+    kind = _own_conv_kind(g_any, w, True)
+    own_gx = kind == 'reg' or (kind == 'lds' and _lds_conv_pays(x, True))
+    own_gw = _own_wrw_used(x, g_any, w)
     if gb is not None and not own_gw:
         raise RuntimeError("bias gradient requested from a weight-gradient pass that is not own")
+    if pooled is not None and not own_gw:
+        raise RuntimeError("pooled gradient handed to a weight-gradient pass that is not own")
+
+    def own_wrw():
+        if pooled is not None:
+            return _wrw_maybe_async(x, ga, w, gb, pool_idx=idx)
+        return _wrw_maybe_async(x, gz, w, gb)
     if own_gx and need_x and link is not None and USE_MASKED_BWD:
-        gx = conv64(gz, w, True, mask=x)
+        if gz is None:
+            gx = conv64(ga, w, True, mask=x, pool_idx=idx)
+        else:
+            gx = conv64(gz, w, True, mask=x)
         link.mark(gx)
         if own_gw:
-            return gx, _wrw_maybe_async(x, gz, w, gb)
+            return gx, own_wrw()
         _, gw, _ = torch.ops.aten.convolution_backward(gz, x, _lib_weight(w, gz), None, _ONES,
                                                        _ONES, _ONES, False, [0, 0], 1,
                                                        [False, True, False])
         return gx, gw.to(w.dtype)
+    if gz is None:
+        if need_x:
+            raise RuntimeError("the full-size gradient is needed for this backward-data pass")
+        return None, own_wrw()
     if own_gx and own_gw:
-        gw = _wrw_maybe_async(x, gz, w, gb)
+        gw = own_wrw()
         return (conv64(gz, w, True) if need_x else None), gw
     if own_gx or own_gw:
         gx = conv64(gz, w, True) if (own_gx and need_x) else None
-        gw = wrw64(x, gz, w, gb) if own_gw else None
+        gw = own_wrw() if own_gw else None
         if (gx is None and need_x) or gw is None:
             lx, lw, _ = torch.ops.aten.convolution_backward(
                 gz, x, _lib_weight(w, gz), None, _ONES, _ONES, _ONES, False, [0, 0], 1,
@@ -654,6 +707,20 @@ def _conv3x3_backward(gz, x, w, need_x, link=None, gb=None):
                                                     _ONES, False, [0, 0], 1,
                                                     [bool(need_x), True, False])
     return gx, gw.to(w.dtype)
+
+
+def _pooled_consumers(x, ga, w, need_x, link):
+    """Which consumers of a pooling layer's gradient can un-pool while they stage:
+    (weight gradient, backward-data).  Weight gradient: every own shape (csrc/conv64.hip,
+    wrw64_kernel<.., 1>).  Backward-data: the register kernels with cin == kout — conv1_2 and
+    conv2_2 — in their masked form; conv3_3 / conv4_3 fill their windows by LDS-DMA, which
+    copies bytes as they lie."""
+    h, wd = x.shape[2], x.shape[3]
+    if not (USE_POOLED_BWD and h % 2 == 0 and wd % 2 == 0 and _own_wrw_used(x, ga, w)):
+        return False, False
+    kind = _own_conv_kind(ga, w, True)
+    return True, (not need_x) or (kind == 'reg' and w.shape[0] == w.shape[1]
+                                  and link is not None and USE_MASKED_BWD)
 
 
 def _glue_dtype(t):
@@ -758,21 +825,34 @@ class _ConvBiasPoolReLU(torch.autograd.Function):
         ga = ga.contiguous(memory_format=_CL)
         b, c = a.shape[0], a.shape[1]
         h, wd = x.shape[2], x.shape[3]
-        gz = torch.empty((b, c, h, wd), dtype=a.dtype, device=a.device, memory_format=_CL)
         gb = _grad_out(bias) if bias.dtype == torch.float32 else torch.empty(
             c, dtype=torch.float32, device=a.device)
-        ws = L.workspace(lib.scl_vgg_workspace_bytes(c), a.device)
-        fn = lib.scl_vgg_pool_bwd_idx if ctx.by_idx else lib.scl_vgg_pool_bwd
         # ReLU' of this layer already applied by the layer above (its backward-data epilogue
         # masks with its own input, which is this layer's output a)?  Then a is not read.
         masked = ctx.by_idx and ctx.link_out is not None and ctx.link_out.take(ga)
+        # The full-size gradient has one non-zero per pooling window and channel.  Where both of
+        # its consumers can un-pool while they stage (conv1_2, conv2_2) it is never written: no
+        # un-pooling pass, and the consumers read 0.75 instead of 2 bytes per element; the bias
+        # gradient comes out of the weight-gradient kernel.  Otherwise (conv3_3, conv4_3) the
+        # pass runs for the backward-data kernel and the weight gradient still reads the pooled
+        # form.
+        need_x = ctx.needs_input_grad[0]
+        pool_w, pool_x = _pooled_consumers(x, ga, w, need_x, ctx.link_in) if masked else (False, False)
+        if pool_w and pool_x:
+            with _in_slot(ctx.slot):
+                gx, gw = _conv3x3_backward(None, x, w, need_x, ctx.link_in, gb, pooled=(ga, z))
+            return gx, _grad_ret(gw, w), _grad_ret(gb, bias), None, None
+        gz = torch.empty((b, c, h, wd), dtype=a.dtype, device=a.device, memory_format=_CL)
+        ws = L.workspace(lib.scl_vgg_workspace_bytes(c), a.device)
+        fn = lib.scl_vgg_pool_bwd_idx if ctx.by_idx else lib.scl_vgg_pool_bwd
         # read g, a (1/4 each) and the index bytes (1/8) or z (1); write gz
         _work('pool_bwd_idx_kernel' if ctx.by_idx else 'pool_bwd_kernel', 0.0,
               ((1.375 if masked else 1.625) if ctx.by_idx else 2.5) * gz.numel() * gz.element_size())
         L.check(fn(L.ptr(ga), None if masked else L.ptr(a), L.ptr(z), _glue_dtype(a), b, h, wd, c,
                    L.ptr(gz), L.ptr(gb), L.ptr(ws), ws.numel(), L.stream_of(a)))
         with _in_slot(ctx.slot):
-            gx, gw = _conv3x3_backward(gz, x, w, ctx.needs_input_grad[0], ctx.link_in)
+            gx, gw = _conv3x3_backward(gz, x, w, need_x, ctx.link_in,
+                                       pooled=(ga, z) if pool_w else None)
         return gx, _grad_ret(gw, w), _grad_ret(gb, bias), None, None
 
 

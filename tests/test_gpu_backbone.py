@@ -499,6 +499,72 @@ def test_pool_index_epilogue_and_its_backward(dev, cin, shape, block_height):
     assert float((gb - gg.sum(dim=(0, 2, 3))).abs().max()) < 1e-3 * float(gg.abs().sum(dim=(0, 2, 3)).max())
 
 
+def _unpooled(ga, idx, h, w):
+    """scl_vgg_pool_bwd_idx on an already masked pooled gradient: the full-size map + bias gradient."""
+    from soft_contrastive_learning_amd import _lib as L
+    lib = L.load()
+    b, c = ga.shape[0], ga.shape[1]
+    gz = torch.empty((b, c, h, w), dtype=torch.bfloat16, device=ga.device, memory_format=torch.channels_last)
+    gb = torch.empty(c, device=ga.device)
+    ws = L.workspace(lib.scl_vgg_workspace_bytes(c), ga.device)
+    L.check(lib.scl_vgg_pool_bwd_idx(L.ptr(ga), None, L.ptr(idx), L.DT_BF16, b, h, w, c,
+                                     L.ptr(gz), L.ptr(gb), L.ptr(ws), ws.numel(), L.stream_of(ga)))
+    return gz, gb
+
+
+@pytest.mark.parametrize('cin,cout,shape', [(64, 64, (2, 16, 40)), (64, 64, (1, 10, 38)),
+                                            (128, 128, (1, 14, 70)), (256, 256, (1, 24, 80)),
+                                            (512, 512, (2, 12, 16)), (128, 256, (1, 30, 40)),
+                                            (64, 128, (3, 36, 80))])
+def test_weight_gradient_unpools_the_pooled_gradient_in_staging(dev, cin, cout, shape):
+    """scl_wrw3x3_pooled(x, g_pooled, idx) == scl_wrw3x3_bias(x, un-pooled g) bit for bit (weights
+    and bias gradient): the kernel builds the same LDS tile from a quarter of the bytes."""
+    from soft_contrastive_learning_amd.model import nets
+    b, h, w = shape
+    g = torch.Generator().manual_seed(61)
+    x = torch.randn(b, cin, h, w, generator=g).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    ga = torch.randn(b, cout, h // 2, w // 2, generator=g).to(dev).bfloat16().contiguous(
+        memory_format=torch.channels_last)
+    idx = torch.randint(0, 4, (b, cout, h // 2, w // 2), generator=g, dtype=torch.uint8).to(dev).contiguous(
+        memory_format=torch.channels_last)
+    gz, gb_pass = _unpooled(ga, idx, h, w)
+    for wdtype in (torch.float32, torch.bfloat16):
+        w_like = torch.empty(cout, cin, 3, 3, device=dev, dtype=wdtype)
+        gb0, gb1 = torch.empty(cout, device=dev), torch.empty(cout, device=dev)
+        want = nets.wrw64(x, gz, w_like, gb0)
+        got = nets.wrw64(x, ga, w_like, gb1, pool_idx=idx)
+        assert torch.equal(got, want)
+        assert torch.equal(gb1, gb0)
+    assert float((gb1 - gb_pass).abs().max()) <= 1e-3 * float(gb_pass.abs().max())
+    with pytest.raises(ValueError):
+        nets.wrw64(x, ga[:, :, :-1], w_like, None, pool_idx=idx[:, :, :-1])
+
+
+@pytest.mark.parametrize('c,shape', [(64, (2, 16, 40)), (64, (1, 10, 38)), (64, (3, 36, 80)),
+                                     (64, (1, 2, 2)), (128, (1, 14, 70)), (128, (2, 8, 64)),
+                                     (128, (1, 30, 40))])
+def test_backward_data_unpools_the_pooled_gradient_in_staging(dev, c, shape):
+    """scl_conv3x3_masked_pooled(g_pooled, idx) == scl_conv3x3_masked(un-pooled g) bit for bit:
+    the threads build the same halo window (zero borders, odd window origin) from the pooled map."""
+    from soft_contrastive_learning_amd.model import nets
+    b, h, w = shape
+    g = torch.Generator().manual_seed(67)
+    ga = torch.randn(b, c, h // 2, w // 2, generator=g).to(dev).bfloat16().contiguous(
+        memory_format=torch.channels_last)
+    idx = torch.randint(0, 4, (b, c, h // 2, w // 2), generator=g, dtype=torch.uint8).to(dev).contiguous(
+        memory_format=torch.channels_last)
+    mask = torch.relu(torch.randn(b, c, h, w, generator=g)).to(dev).bfloat16().contiguous(
+        memory_format=torch.channels_last)
+    wt = (torch.randn(c, c, 3, 3, generator=g) * 0.05).to(dev)
+    gz, _ = _unpooled(ga, idx, h, w)
+    want = nets.conv64(gz, wt, True, mask=mask)
+    got = nets.conv64(ga, wt, True, mask=mask, pool_idx=idx)
+    assert torch.equal(got, want)
+    assert float(want.float().abs().max()) > 0
+    with pytest.raises(ValueError):
+        nets.conv64(ga, wt, True, pool_idx=idx)              # un-masked form does not exist
+
+
 @pytest.mark.parametrize('cin,cout,shape', [(64, 64, (1, 16, 40)), (128, 128, (1, 9, 33)),
                                             (256, 256, (1, 12, 40)), (128, 256, (1, 30, 40))])
 def test_float32_master_weights_equal_the_bf16_cast(dev, cin, cout, shape, lds_kernel):
