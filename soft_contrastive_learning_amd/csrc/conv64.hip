@@ -572,7 +572,6 @@ __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __r
   // long after one 32-cycle MFMA), the B operand of the next step while the current one runs.
   // The tiles alternate between two LDS buffers: the DMA of tile n + 1 runs under the whole
   // of tile n; one barrier per tile (it drains the DMA: hipcc waits vmcnt(0) there).
-  constexpr int DEPTH = 4, AHEAD = 3;
   int tile = blockIdx.x;
   if (tile < ntiles) {
     stage_issue(tile, 0);
@@ -594,30 +593,71 @@ __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __r
         lds + buf * WBUF + mt * XPLANE + (lrow * WCv + lcol) * WPL + ch0;
     const unsigned short* gl =
         lds + buf * WBUF + 2 * XPLANE + nt * GPLANE + (lrow * TWv + lcol) * WPL + ch0;
-    // product i = 9 * s + t: step s of this wave's eight (first pixel (ry, cx)), tap t
-    auto a_of = [&](int i) {
-      const int s_ = i / 9, t = i % 9;
-      const int ry = TWv == 32 ? 4 * ph + (s_ >> 1) : 16 * ph + 2 * s_;
-      const int cx = TWv == 32 ? 16 * (s_ & 1) : 0;
-      return tr_pair(xl + ((ry + t / 3) * WCv + cx + t % 3) * WPL, 4 * WPL);
+    // product i = 9 * s + t: step s of this wave's eight (first pixel (ry, cx)), tap t = 3 kh + kw.
+    // A lane's A operand is 8 consecutive pixels of a window row for its channel; the three kw
+    // taps of a row are the same pixels shifted by 0 / 1 / 2 — so ONE fragment of 12 pixels (three
+    // transposed reads: pixels 0-3, 4-7, 8-11 of the lane's block) serves all three: kw = 1 is four
+    // v_alignbit, kw = 2 a renaming of registers.  And a window row serves the kh taps of three
+    // tile rows (wide tiles) / two steps (tall tiles): it is read once and stays in registers.
+    // LDS reads per wave and tile: 36 (52 tall) + 16 for B instead of 144 + 16 — the transposed
+    // reads of nine separate taps kept the LDS pipe busy for more cycles than the MFMAs take.
+    struct XFrag {
+      uint2 lo, hi, ex;
+    };
+    auto x_frag = [&](int wrow, int cx) {
+      const unsigned short* p = xl + (wrow * WCv + cx) * WPL;
+      XFrag f;
+      f.lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                           (s16x4 __attribute__((address_space(3)))*)(p)));
+      f.hi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                           (s16x4 __attribute__((address_space(3)))*)(p + 4 * WPL)));
+      f.ex = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                           (s16x4 __attribute__((address_space(3)))*)(p + 8 * WPL)));
+      return f;
+    };
+    // window row (relative to the wave's first) and column slot of step s_, tap row kh
+    // Wide tiles walk the left 16 columns of the wave's four rows, then the right ones (steps
+    // 0-3, 4-7): three window rows of ONE column half are live at a time.
+    constexpr int NFR = TWv == 32 ? 6 : 18, NFC = TWv == 32 ? 2 : 1;
+    auto f_row = [](int s_, int kh) { return TWv == 32 ? (s_ & 3) + kh : 2 * s_ + kh; };
+    auto f_col = [](int s_) { return TWv == 32 ? (s_ >> 2) : 0; };
+    // is (s_, kh) the first product that touches its fragment?
+    auto f_first = [](int s_, int kh) { return TWv == 32 ? ((s_ & 3) == 0 || kh == 2) : (s_ == 0 || kh >= 1); };
+    const int row_w = TWv == 32 ? 4 * ph : 16 * ph;        // the wave's first window row
+    XFrag fr[NFR][NFC];
+    auto f_load = [&](int i) {                            // the fragment product i (kw = 0) opens
+      const int s_ = i / 9, kh = (i % 9) / 3;
+      fr[f_row(s_, kh)][f_col(s_)] = x_frag(row_w + f_row(s_, kh), 16 * f_col(s_));
     };
     auto b_of = [&](int s_) {
-      const int ry = TWv == 32 ? 4 * ph + (s_ >> 1) : 16 * ph + 2 * s_;
-      const int cx = TWv == 32 ? 16 * (s_ & 1) : 0;
-      return tr_pair(gl + (ry * TWv + cx) * WPL, 4 * WPL);
+      const int ry = TWv == 32 ? 4 * ph + (s_ & 3) : 16 * ph + 2 * s_;
+      return tr_pair(gl + (ry * TWv + 16 * f_col(s_)) * WPL, 4 * WPL);
     };
-    u32x4 af[DEPTH], bf[2];
+    constexpr int LEAD = 6;                                // products between a read and its first use
+    u32x4 bf[2];
 #pragma unroll
-    for (int i = 0; i < AHEAD; ++i) af[i] = a_of(i);
+    for (int i = 0; i < LEAD; i += 3)
+      if (f_first(i / 9, (i % 9) / 3)) f_load(i);
     bf[0] = b_of(0);
 #pragma unroll
     for (int i = 0; i < 9 * 8; ++i) {
-      if (i + AHEAD < 9 * 8) af[(i + AHEAD) % DEPTH] = a_of(i + AHEAD);
-      if (i % 9 == 2 && i / 9 + 1 < 8) bf[(i / 9 + 1) & 1] = b_of(i / 9 + 1);
+      const int s_ = i / 9, kh = (i % 9) / 3, kw = i % 3;
+      if (i + LEAD < 9 * 8 && (i + LEAD) % 3 == 0 && f_first((i + LEAD) / 9, ((i + LEAD) % 9) / 3))
+        f_load(i + LEAD);
+      if (i % 9 == 2 && s_ + 1 < 8) bf[(s_ + 1) & 1] = b_of(s_ + 1);
       __builtin_amdgcn_sched_barrier(0);
-      acc[i % 9] = mfma32b(af[i % DEPTH], bf[(i / 9) & 1], acc[i % 9]);
+      const XFrag& f = fr[f_row(s_, kh)][f_col(s_)];
+      u32x4 a;
+      if (kw == 0)
+        a = u32x4{f.lo.x, f.lo.y, f.hi.x, f.hi.y};
+      else if (kw == 1)
+        a = u32x4{__builtin_amdgcn_alignbit(f.lo.y, f.lo.x, 16), __builtin_amdgcn_alignbit(f.hi.x, f.lo.y, 16),
+                  __builtin_amdgcn_alignbit(f.hi.y, f.hi.x, 16), __builtin_amdgcn_alignbit(f.ex.x, f.hi.y, 16)};
+      else
+        a = u32x4{f.lo.y, f.hi.x, f.hi.y, f.ex.x};
+      acc[i % 9] = mfma32b(a, bf[s_ & 1], acc[i % 9]);
       if (i % 9 == 4) {
-        const u32x4 bw = bf[(i / 9) & 1];
+        const u32x4 bw = bf[s_ & 1];
         const bf16x2 one2 = __builtin_bit_cast(bf16x2, 0x3f803f80u);
         // (element by element: indexing the vector in a loop made hipcc feed word 0 four times)
         const unsigned w0 = bw.x, w1 = bw.y, w2 = bw.z, w3 = bw.w;

@@ -60,6 +60,8 @@ def _local_grads(rank, dev):
 
 def _worker(rank, world, port, bucket_bytes, out):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import faulthandler
+    faulthandler.dump_traceback_later(180, exit=False)      # a hung rank says where
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         from soft_contrastive_learning_amd import parallel
@@ -86,7 +88,25 @@ def _worker(rank, world, port, bucket_bytes, out):
             nets.GRAD_SINK = None
         out.put((rank, same, worst, len(buckets.buckets), len(buckets._streams)))
     finally:
+        faulthandler.cancel_dump_traceback_later()
         dist.destroy_process_group()
+
+
+def _run_ranks(procs, limit=240):
+    """Start the rank processes and wait; a rank that hangs or fails is KILLED before the assert
+    (a live non-daemon child would otherwise keep pytest itself from exiting)."""
+    for p in procs:
+        p.start()
+    try:
+        for p in procs:
+            p.join(timeout=limit)
+        codes = [p.exitcode for p in procs]
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+                p.join(timeout=10)
+    assert codes == [0] * len(procs), 'rank exit codes %s (None = hung, killed)' % (codes,)
 
 
 @pytest.mark.parametrize('bucket_bytes', [1 << 20, 1 << 30])
@@ -97,11 +117,7 @@ def test_two_ranks_on_one_gpu_all_reduce_finished_gradients(bucket_bytes):
     out = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, bucket_bytes, out)) for r in range(2)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(timeout=600)
-        assert p.exitcode == 0
+    _run_ranks(procs)
     res = sorted(out.get(timeout=10) for _ in range(2))
     for rank, same, worst, nb, ns in res:
         assert ns == 1, 'the weight gradients did not run on the second stream'
@@ -162,11 +178,7 @@ def test_ranks_on_one_gpu_loss_and_sharded_retrieval(world):
     out = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_loss_worker, args=(r, world, port, out)) for r in range(world)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(timeout=600)
-        assert p.exitcode == 0
+    _run_ranks(procs)
     for rank, lerr, gerr, same_idx, derr in sorted(out.get(timeout=10) for _ in range(world)):
         assert lerr <= 1e-6, (rank, lerr)
         assert gerr <= 1e-6, (rank, gerr)
