@@ -57,6 +57,18 @@ __device__ __forceinline__ void glds16(const unsigned short* src, unsigned lds_b
 __device__ __forceinline__ unsigned lds_byte_of(const unsigned short* p) {
   return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned short*)p;
 }
+// ... with a wave-uniform base pointer and a 32-bit byte offset per lane: no vector instruction
+// for the address at all
+__device__ __forceinline__ void glds16_s(const unsigned short* base, unsigned off_bytes,
+                                         unsigned lds_byte) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(off_bytes), "s"(base), "s"(lds_byte)
+      : "memory");
+}
 // Generalisation to the other VGG shapes whose weight slice still fits the register file:
 //   (CIN, KOUT) in {(64,64) conv1_2 fwd+bwd, (64,128) conv2_1 fwd, (128,64) conv2_1 bwd,
 //   (128,128) conv2_2 fwd+bwd}.  A wave always owns 32 output channels (KOUT / 32 n-tiles)
@@ -461,6 +473,25 @@ __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __r
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   using Cfg = WrwCfg<TWv, NKB>;
+  // Workgroup -> (pixel split p, input block cb, output block kz).  The 1-D grid is dealt to the
+  // eight XCDs round robin (workgroup L runs on XCD L % 8) and every workgroup is resident at
+  // once.  The n_cb * n_kz workgroups of one p walk the same tiles at the same time — each x
+  // window is read by n_kz of them, each gz tile by n_cb — so they are put on ONE XCD: its L2
+  // then serves all but the first request (33 instead of 13 bytes per cycle and CU into the LDS;
+  // with p on the fast grid axis the siblings sat on different XCDs and every one of them
+  // fetched from the Infinity Cache: the staging stream, 58 KB per tile, was the kernel's bound).
+  const int n_cb = C / C64, n_kz = K / (NKB * C64), n_sib = n_cb * n_kz;
+  const int n_p = gridDim.x / n_sib;
+  int wg_p, wg_sib;
+  if (n_p % 8 == 0) {
+    const int s_ = blockIdx.x >> 3;
+    wg_sib = s_ % n_sib;
+    wg_p = (blockIdx.x & 7) + 8 * (s_ / n_sib);
+  } else {
+    wg_p = blockIdx.x % n_p;
+    wg_sib = blockIdx.x / n_p;
+  }
+  const int wg_cb = wg_sib % n_cb, wg_kz = wg_sib / n_cb;
   constexpr int XCH = Cfg::XCHv, GCH = Cfg::GCHv, XPLANE = Cfg::XPL, GPLANE = Cfg::GPL;
   constexpr int WBUF = Cfg::BUF, WCHUNKS = Cfg::CHUNKS;
   // eight waves, two per SIMD.  NKB = 1: wave (mt, nt, ph) accumulates block (mt, nt) over the
@@ -480,54 +511,80 @@ __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __r
   const int per_img = tiles_x * tiles_y;
   const int ntiles = B * per_img;
 
-  // wave wid issues chunks j = wid, wid + 8, ... of the 76: [x plane 0][x plane 1][gz 0][gz 1].
-  // Which pixel of the window / tile a lane fetches for its i-th chunk does not depend on
-  // the tile: (row << 8 | column) once, -1 for the slack behind the window.
-  constexpr int NI = (WCHUNKS + 7) / 8;
+  // wave wid issues chunks j = wid, wid + 8, ... of the 76: [x plane 0][x plane 1][gz 0][gz 1]
+  // (PL: of the x planes only).  Which pixel of the window / tile a lane fetches for its i-th
+  // chunk does not depend on the tile: (row << 8 | column) once, -1 for the slack behind the
+  // window.  A wave whose last index is past the end issues the last chunk once more (the same
+  // bytes to the same place as the wave that owns it): stage_chunk has no branches, it sits
+  // between the products of the unrolled tile loop.
+  constexpr int NCH = PL ? 2 * XCH : WCHUNKS;
+  constexpr int NI = (NCH + 7) / 8;
   const int wid_s = __builtin_amdgcn_readfirstlane(wid);
   const int pl = lane >> 2, piece = lane & 3;
   int rel[NI], roff[NI];      // roff: element offset from the tile's first (halo) pixel
+  int ldst[NI];               // (wave-uniform) LDS byte offset of the chunk inside a buffer
+  bool is_x[NI];              // (wave-uniform) x window or gz tile
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
-    const int j = wid_s + 8 * i;
+    const int j = wid_s + 8 * i < NCH ? wid_s + 8 * i : NCH - 1;
+    is_x[i] = j < 2 * XCH;
     if (j < 2 * XCH) {
       const int plane = j >= XCH ? 1 : 0;
       const int pix = 16 * (j - XCH * plane) + pl;
       rel[i] = pix < WRv * WCv ? ((pix / WCv) << 8) | (pix % WCv) : -1;
-      roff[i] = ((pix / WCv) * W + pix % WCv) * C + C64 * blockIdx.y + 8 * piece + 32 * plane;
+      // (the slack lanes behind the window point at its first pixel: never read, always mapped)
+      const int pv = pix < WRv * WCv ? pix : 0;
+      roff[i] = ((pv / WCv) * W + pv % WCv) * C + C64 * wg_cb + 8 * piece + 32 * plane;
+      ldst[i] = (plane * XPLANE + (j - XCH * plane) * 512) * 2;
     } else {
       const int jj = j - 2 * XCH;
       const int plane = jj / GCH;
       const int pix = 16 * (jj - GCH * plane) + pl;
-      rel[i] = j < WCHUNKS ? ((pix / TWv) << 8) | (pix % TWv) : -1;
-      roff[i] = ((pix / TWv) * W + pix % TWv) * K + NKB * C64 * blockIdx.z + 8 * piece + 32 * plane;
+      rel[i] = ((pix / TWv) << 8) | (pix % TWv);
+      roff[i] = ((pix / TWv) * W + pix % TWv) * K + NKB * C64 * wg_kz + 8 * piece + 32 * plane;
+      ldst[i] = (2 * XPLANE + plane * GPLANE + (jj - GCH * plane) * 512) * 2;
     }
   }
   const unsigned short* zeros = reinterpret_cast<const unsigned short*>(zero_block);
-  auto stage_issue = [&](int tile, int buf) {
+  // One chunk (i) of a tile's staging; the whole of it = stage_issue.  Inside the tile loop the
+  // chunks go out one at a time between the products (stage_chunk at every fifth): the s_memtime
+  // stamps (scripts/wrw_stamps.py) showed a wave that issues its ten DMA instructions back to back
+  // blocked for 2,100 cycles — the queue in front of the LDS takes them at the rate the data
+  // arrives (58 KB at 13 B per cycle), and the wave's 72 products only started afterwards.
+  struct TilePos {
+    int ty, tx, xo, go;      // first pixel; element offsets of the window's / tile's first pixel
+    bool inner;              // the whole halo window lies inside the image
+  };
+  auto tile_pos = [&](int tile) {
     const int b = tile / per_img, t2 = tile % per_img;
-    const int ty = (t2 / tiles_x) * THv, tx = (t2 % tiles_x) * TWv;
-    const unsigned base = lds_byte_of(lds) + buf * WBUF * 2;
-    // element offsets of the window's / tile's first pixel (< 2^31: host check; the window's
-    // may be negative at the image border — those lanes are masked by `ok`)
-    const int xo = ((b * H + ty - 1) * W + tx - 1) * C, go = ((b * H + ty) * W + tx) * K;
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      const int j = wid_s + 8 * i;                       // wave-uniform
-      if (j < 2 * XCH) {
-        const int plane = j >= XCH ? 1 : 0, chunk = j - XCH * plane;
-        const int y = ty - 1 + (rel[i] >> 8), xx = tx - 1 + (rel[i] & 255);
-        const bool ok = rel[i] >= 0 && (unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W;
-        glds16(ok ? x + (xo + roff[i]) : zeros, base + (plane * XPLANE + chunk * 512) * 2);
-      } else if (j < WCHUNKS && !PL) {
-        const int jj = j - 2 * XCH;
-        const int plane = jj / GCH, chunk = jj - GCH * plane;
-        const int y = ty + (rel[i] >> 8), xx = tx + (rel[i] & 255);
-        const bool ok = y < H && xx < W;
-        glds16(ok ? gz + (go + roff[i]) : zeros,
-               base + (2 * XPLANE + plane * GPLANE + chunk * 512) * 2);
-      }
+    TilePos t;
+    t.ty = (t2 / tiles_x) * THv;
+    t.tx = (t2 % tiles_x) * TWv;
+    // (< 2^31: host check; the window's may be negative at the image border — those lanes are
+    // masked by `ok`)
+    t.xo = ((b * H + t.ty - 1) * W + t.tx - 1) * C;
+    t.go = ((b * H + t.ty) * W + t.tx) * K;
+    t.inner = t.ty >= 1 && t.ty + THv < H && t.tx >= 1 && t.tx + TWv < W;
+    return t;
+  };
+  auto stage_chunk = [&](const TilePos& tp, int buf, int i) __attribute__((always_inline)) {
+    const int ty = tp.ty, tx = tp.tx, xo = tp.xo, go = tp.go;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_byte_of(lds) + buf * WBUF * 2 + ldst[i]);
+    if (tp.inner) {
+      // (wave-uniform) no border in sight: scalar base + the lane's constant offset
+      glds16_s(is_x[i] ? x + xo : gz + go, 2u * (unsigned)roff[i], dst);
+    } else {
+      const int halo = is_x[i] ? 1 : 0;
+      const int y = ty - halo + (rel[i] >> 8), xx = tx - halo + (rel[i] & 255);
+      const bool ok = rel[i] >= 0 && (unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W;
+      const unsigned short* src = (is_x[i] ? x : gz) + ((is_x[i] ? xo : go) + roff[i]);
+      glds16(ok ? src : zeros, dst);
     }
+  };
+  auto stage_issue = [&](int tile, int buf) __attribute__((always_inline)) {
+    const TilePos tp = tile_pos(tile);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) stage_chunk(tp, buf, i);
   };
   // PL: this thread's window of the tile = pooled pixel (pr, pc), 8 channels (plane, piece)
   constexpr int NPC = TWv / 2, NPR = THv / 2;
@@ -539,7 +596,7 @@ __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __r
   auto pool_issue = [&](int tile) {
     const int b = tile / per_img, t2 = tile % per_img;
     const int py = (t2 / tiles_x) * NPR + p_pr, px = (t2 % tiles_x) * NPC + p_pc;
-    const int off = ((b * Ho + py) * Wo + px) * K + NKB * C64 * blockIdx.z + 32 * p_plane + 8 * p_piece;
+    const int off = ((b * Ho + py) * Wo + px) * K + NKB * C64 * wg_kz + 32 * p_plane + 8 * p_piece;
     if (py < Ho && px < Wo) {
       pg = *reinterpret_cast<const u32x4*>(gz + off);
       pi = *reinterpret_cast<const uint2*>(pidx + off);
@@ -572,7 +629,14 @@ __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __r
   // long after one 32-cycle MFMA), the B operand of the next step while the current one runs.
   // The tiles alternate between two LDS buffers: the DMA of tile n + 1 runs under the whole
   // of tile n; one barrier per tile (it drains the DMA: hipcc waits vmcnt(0) there).
-  int tile = blockIdx.x;
+  // DBG & 4 (scl_debug_set_variant(2004), diagnostics): wave 0 of every workgroup writes s_memtime
+  // stamps of its first four tiles to bslabs (no bias partials then): [workgroup][tile][8] —
+  // 0 tile start, 1 staging issued, 2 first step done, 3 fourth step done, 4 last product
+  // issued, 5 own DMA landed, 6 barrier passed.
+  uint64_t stamp[7];
+#define WRW_STAMP(k)                                                   \
+  if (DBG & 4) asm volatile("s_memtime %0" : "=s"(stamp[k])::"memory")
+  int tile = wg_p;
   if (tile < ntiles) {
     stage_issue(tile, 0);
     if (PL) {
@@ -582,13 +646,15 @@ __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __r
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  int buf = 0;
-  for (; tile < ntiles; tile += gridDim.x) {
-    const int next = (DBG & 2) ? ntiles : tile + gridDim.x;
-    if (next < ntiles) {
-      stage_issue(next, buf ^ 1);
-      if (PL) pool_issue(next);
-    }
+  int buf = 0, tcount = 0;
+  for (; tile < ntiles; tile += n_p) {
+    WRW_STAMP(0);
+    const int next = (DBG & 2) ? ntiles : tile + n_p;
+    // (after the last tile the current one is staged again, into the buffer nobody reads: the
+    // product loop stays free of branches)
+    const TilePos stg = tile_pos(next < ntiles ? next : tile);
+    if (PL && next < ntiles) pool_issue(next);
+    WRW_STAMP(1);
     const unsigned short* xl =
         lds + buf * WBUF + mt * XPLANE + (lrow * WCv + lcol) * WPL + ch0;
     const unsigned short* gl =
@@ -634,6 +700,8 @@ __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __r
       return tr_pair(gl + (ry * TWv + 16 * f_col(s_)) * WPL, 4 * WPL);
     };
     constexpr int LEAD = 6;                                // products between a read and its first use
+    constexpr int STG = 5;                                 // products between two staging chunks
+    static_assert(STG * NI <= 9 * 8 - 12, "the last chunk needs time to land");
     u32x4 bf[2];
 #pragma unroll
     for (int i = 0; i < LEAD; i += 3)
@@ -645,6 +713,7 @@ __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __r
       if (i + LEAD < 9 * 8 && (i + LEAD) % 3 == 0 && f_first((i + LEAD) / 9, ((i + LEAD) % 9) / 3))
         f_load(i + LEAD);
       if (i % 9 == 2 && s_ + 1 < 8) bf[(s_ + 1) & 1] = b_of(s_ + 1);
+      if (!(DBG & 2) && i % STG == 0 && i / STG < NI) stage_chunk(stg, buf ^ 1, i / STG);
       __builtin_amdgcn_sched_barrier(0);
       const XFrag& f = fr[f_row(s_, kh)][f_col(s_)];
       u32x4 a;
@@ -656,6 +725,9 @@ __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __r
       else
         a = u32x4{f.lo.y, f.hi.x, f.hi.y, f.ex.x};
       acc[i % 9] = mfma32b(a, bf[s_ & 1], acc[i % 9]);
+      if (i == 8) WRW_STAMP(2);
+      if (i == 35) WRW_STAMP(3);
+      if (i == 71) WRW_STAMP(4);
       if (i % 9 == 4) {
         const u32x4 bw = bf[s_ & 1];
         const bf16x2 one2 = __builtin_bit_cast(bf16x2, 0x3f803f80u);
@@ -669,16 +741,28 @@ __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __r
     }
     if (PL && next < ntiles) pool_write(buf ^ 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA chunks have landed
+    WRW_STAMP(5);
     __syncthreads();
+    WRW_STAMP(6);
+    if (DBG & 4) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (threadIdx.x == 0 && tcount < 4) {
+        uint64_t* o = reinterpret_cast<uint64_t*>(bslabs) + ((int64_t)((int)blockIdx.x) * 4 + tcount) * 8;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) o[k] = stamp[k];
+      }
+      ++tcount;
+    }
     buf ^= 1;
   }
+#undef WRW_STAMP
 
   // slab[s][cb][kb][tap][c][k] with 64 x 64 blocks (cb, kb): s = 2 p + ph (NKB = 1) or p, kb =
   // the workgroup's block or its pair 2 z + nt / 2; accumulator register qq <-> c = 32 mt +
   // acc_row(qq, h), lane r <-> k
-  const int slab = NKB == 1 ? 2 * blockIdx.x + ph : blockIdx.x;
-  const int kb = NKB == 1 ? blockIdx.z : 2 * blockIdx.z + (nt >> 1);
-  float* out = slabs + (((int64_t)slab * gridDim.y + blockIdx.y) * (NKB * gridDim.z) + kb) * 9 * C64 * C64;
+  const int slab = NKB == 1 ? 2 * wg_p + ph : wg_p;
+  const int kb = NKB == 1 ? wg_kz : 2 * wg_kz + (nt >> 1);
+  float* out = slabs + (((int64_t)slab * n_cb + wg_cb) * (NKB * n_kz) + kb) * 9 * C64 * C64;
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -686,7 +770,7 @@ __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __r
       out[(t * C64 + 32 * mt + acc_row(qq, h)) * C64 + 32 * (nt & 1) + r] = acc[t][qq];
   // bias partials [slab][K]: the two pixel halves h of a step combined in a fixed order
   const float bs = bsum + __shfl_xor(bsum, 32);
-  if (bslabs && blockIdx.y == 0 && mt == 0 && h == 0)
+  if (bslabs && !(DBG & 4) && wg_cb == 0 && mt == 0 && h == 0)
     bslabs[(int64_t)slab * K + C64 * kb + 32 * (nt & 1) + r] = bs;
 }
 
@@ -1348,6 +1432,8 @@ static int wrw3x3_run(const void* x, const void* gz, const unsigned char* pidx, 
     SCL_WRW_ATTR(0, 32, 1, 0) SCL_WRW_ATTR(2, 32, 1, 0)
     SCL_WRW_ATTR(0, 8, 1, 0) SCL_WRW_ATTR(0, 32, 2, 0) SCL_WRW_ATTR(0, 8, 2, 0)
     SCL_WRW_ATTR(0, 32, 1, 1) SCL_WRW_ATTR(0, 8, 1, 1) SCL_WRW_ATTR(0, 32, 2, 1) SCL_WRW_ATTR(0, 8, 2, 1)
+    SCL_WRW_ATTR(4, 32, 2, 0) SCL_WRW_ATTR(4, 8, 2, 0) SCL_WRW_ATTR(4, 32, 2, 1) SCL_WRW_ATTR(4, 8, 2, 1)
+    SCL_WRW_ATTR(6, 32, 2, 0) SCL_WRW_ATTR(6, 8, 2, 0)
 #undef SCL_WRW_ATTR
     cus = conv64_cus();
     if (cus > 1024) cus = 1024;
@@ -1355,6 +1441,7 @@ static int wrw3x3_run(const void* x, const void* gz, const unsigned char* pidx, 
   // [64 c] x [128 k] blocks wherever the output channels allow (scl_debug_set_variant(2100)
   // pins the 64 x 64 variant); tile shape: wide, or tall where that pads the map less
   const int dbg = scl_debug_variant / 1000 == 2 ? scl_debug_variant & 3 : 0;
+  const bool stamps = (scl_debug_variant == 2004 || scl_debug_variant == 2006) && kout % 128 == 0;   // (needs >= 64 KB of bias slabs)
   const int nkb = (kout % 128 == 0 && dbg == 0 && scl_debug_variant != 2100) ? 2 : 1;
   const int th_w = nkb == 1 ? 8 : 4, th_t = nkb == 1 ? 32 : 16;
   const int tiles_wide = B * ((H + th_w - 1) / th_w) * ((W + 31) / 32);
@@ -1365,11 +1452,25 @@ static int wrw3x3_run(const void* x, const void* gz, const unsigned char* pidx, 
   hipStream_t st = (hipStream_t)stream;
 #define SCL_WRW_LAUNCH(D, T, N, PL)                                                            \
   SCL_LAUNCH(PL ? "wrw64_kernel<pooled>" : "wrw64_kernel", (wrw64_kernel<D, T, N, PL>),        \
-             dim3(PP, cin / 64, kout / (64 * N)), dim3(512), (WrwCfg<T, N>::LDS), st,          \
+             dim3(PP * (cin / 64) * (kout / (64 * N))), dim3(512), (WrwCfg<T, N>::LDS), st,    \
              (const unsigned short*)x, (const unsigned short*)gz, B, H, W, cin, kout,          \
              (float*)workspace, bslabs, pidx)
   float* bslabs = grad_bias ? (float*)((char*)workspace + wrw_bias_slab_offset(cin, kout)) : nullptr;
   int PP = P;
+  if (stamps) {
+    PP = wrw_splits(cin, kout / 2, tiles, cus);
+    bslabs = (float*)((char*)workspace + wrw_bias_slab_offset(cin, kout));
+    if ((size_t)PP * (cin / 64) * (kout / 128) * 256 > need - wrw_bias_slab_offset(cin, kout))
+      return SCL_E_WORKSPACE;
+    if (scl_debug_variant == 2006) {        // ... without staging after the first tile
+      if (tall) SCL_WRW_LAUNCH(6, 8, 2, 0); else SCL_WRW_LAUNCH(6, 32, 2, 0);
+    } else if (pidx) {
+      if (tall) SCL_WRW_LAUNCH(4, 8, 2, 1); else SCL_WRW_LAUNCH(4, 32, 2, 1);
+    } else {
+      if (tall) SCL_WRW_LAUNCH(4, 8, 2, 0); else SCL_WRW_LAUNCH(4, 32, 2, 0);
+    }
+    return scl_launch_status();
+  }
   if (nkb == 2) {
     PP = wrw_splits(cin, kout / 2, tiles, cus);
     if (pidx) {
