@@ -289,23 +289,34 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
     f32x16 acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = zero16();
-    u32x4 af[2][MT];
+    // The K loop walks (16-channel slice c, window row wr, tap column kw): the fragment of window
+    // pixel row wr at column offset kw is read ONCE and multiplied into every tile row mt that
+    // sees it as tap row kh = wr - mt in 0..2 — (MT + 2) * 3 fragment reads per slice instead of
+    // 9 MT (MT = 2: 12 for 18, MT = 4: 18 for 36, MT = 8: 30 for 72).  Measured: within noise on
+    // conv1_2, -2 % on conv2_2 — the LDS pipe is 25 % busy in this kernel (SQ_LDS_IDX_ACTIVE,
+    // profiles/r03), it was never the bound; kept for the traffic it saves.
+    constexpr int WRW = MT + 2, NST = Cfg::SPT * WRW * 3, RING = 4, AHEAD = 3;
+    auto frag_at = [&](int st) {
+      const int c = st / (WRW * 3), wr = (st / 3) % WRW, kw = st % 3;
+      return *reinterpret_cast<const u32x4*>(wb + (wr * WC + kw) * PIX + 16 * c);
+    };
+    u32x4 af[RING];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-      af[0][mt] = *reinterpret_cast<const u32x4*>(wb + mt * WC * PIX);
+    for (int st = 0; st < AHEAD; ++st) af[st] = frag_at(st);
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      if (ks + 1 < KS) {
-        const int tap = (ks + 1) / Cfg::SPT, kh = tap / 3, kw = tap % 3;
-        const int off = (kh * WC + kw) * PIX + 16 * ((ks + 1) % Cfg::SPT);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          af[(ks + 1) & 1][mt] = *reinterpret_cast<const u32x4*>(wb + mt * WC * PIX + off);
-      }
+    for (int st = 0; st < NST; ++st) {
+      if (st + AHEAD < NST) af[(st + AHEAD) % RING] = frag_at(st + AHEAD);
       __builtin_amdgcn_sched_barrier(0);
+      const int c = st / (WRW * 3), wr = (st / 3) % WRW, kw = st % 3;
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[mt] = mfma32b(af[ks & 1][mt], wf[ks], acc[mt]);
-      if (PL) {
+      for (int mt = 0; mt < MT; ++mt) {
+        const int kh = wr - mt;
+        if (kh >= 0 && kh < 3)
+          acc[mt] = mfma32b(af[st % RING], wf[(3 * kh + kw) * Cfg::SPT + c], acc[mt]);
+      }
+      // the un-pooling slices keep their places on the scale of the KS k-steps
+      const int ks = st * KS / NST;
+      if (PL && (st == 0 || ks != (st - 1) * KS / NST)) {
         // (also after the last tile: stale registers into a buffer nobody reads — no branch)
         constexpr int W0 = SPAN - 4 * PLIVE - 2;
         const int g = ks / SPAN, kk = ks % SPAN;
