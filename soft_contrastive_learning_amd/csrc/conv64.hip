@@ -646,7 +646,7 @@ __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __r
   // issued, 5 own DMA landed, 6 barrier passed.
   uint64_t stamp[7];
 #define WRW_STAMP(k)                                                   \
-  if (DBG & 4) asm volatile("s_memtime %0" : "=s"(stamp[k])::"memory")
+  if (DBG & 4) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp[k])::"memory")
   int tile = wg_p;
   if (tile < ntiles) {
     stage_issue(tile, 0);

@@ -128,7 +128,15 @@ __device__ __forceinline__ unsigned h_lds_byte_of(const unsigned short* p) {
 // from the registers (a 16-pixel store instruction writes 16 whole 32-byte sectors); no LDS
 // transpose, no wave barriers.  EPI 3 keeps pixels as A: register q is pixel 4 g' + q, channel
 // lane & 15, which puts a pooling window into registers (q, q + 1) of lanes l and l ^ 16.
-template <int EPI, int BHv>
+//
+// STAMP (scl_debug_set_variant(53024 + w), <1, 12> only; scripts/convh_stamps.py): wave w of every
+// workgroup writes s_memtime stamps of its second and third tile BEHIND the end of `out` (the
+// caller allocates 2 x 24 x 8 bytes per workgroup more) — slots: 0 tile start, 1 first stage
+// landed + barrier; 2 + 9 (cc & 1) + 3 gi + {0 own share waited for, 1 barrier passed, 2 next
+// requests issued} for the last chunk pair of the tile; 20 K loop left, 21 barrier, 22 epilogue
+// done.  (Each stamp waits for its own result: the compiler does not know that s_memtime writes
+// its registers late, and re-used them — one stamp landed in a pointer.)
+template <int EPI, int BHv, bool STAMP = false>
 __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __restrict__ x,
                                                        const unsigned short* __restrict__ packed,
                                                        int B, int H, int W, int cin, int kout,
@@ -226,11 +234,18 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
   }
   const int lane_b = (g * HNB + 16 * NT * ng + i) * 8;
 
-  const int dbg = relu >> 1;            // timing diagnostics (dv 3020 + bits), results meaningless
+  const int relu_in = relu;
+  const int dbg = STAMP ? 0 : relu >> 1;   // timing diagnostics (dv 3020 + bits), results meaningless
   relu &= 1;
   const float floor_v = relu ? 0.f : -__builtin_inff();
   bool staged = false;
+  uint64_t stamp[STAMP ? 24 : 1];
+  int tcount = 0;
+#define HSTAMP(k)                                                                     \
+  if (STAMP)                                                                          \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp[STAMP ? (k) : 0])::"memory")
   for (int vb = blockIdx.x; vb < vblocks; vb += gridDim.x) {
+    HSTAMP(0);
     if (!staged) {
       if (!locate(vb)) continue;
       stage_first();
@@ -299,13 +314,16 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA) : "memory");   // first window part may fly on
           else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          HSTAMP(2 + 9 * PAR + 3 * (h / 6));
           __builtin_amdgcn_s_barrier();
+          HSTAMP(2 + 9 * PAR + 3 * (h / 6) + 1);
           // ... and everybody has left the previous group: its weight buffer takes the group
           // after next, the other window buffer the next chunk's window (in two parts)
           const int gn = 3 * cc + gi + 2 < NG ? 3 * cc + gi + 2 : NG - 3 + (gi + 2) % 3;
           issue_wts(gn, (gi + 2) % 3);
           if (gi == 0) issue_win(ccn, (cc + 1) & 1, 0, NA);
           if (gi == 1) issue_win(ccn, (cc + 1) & 1, NA, NI);
+          HSTAMP(2 + 9 * PAR + 3 * (h / 6) + 2);
         }
       }
     };
@@ -314,6 +332,7 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
+    HSTAMP(1);
     load_half(win, 0, 0);
 #pragma unroll 1
     for (int cc = 0; cc < CC; cc += 2) {
@@ -327,7 +346,9 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
     asm volatile("" : "+s"(nb_e), "+s"(b_e), "+s"(y0_e), "+s"(x0_e));
     // Every wave has left the K loop: window buffer 1 (the last chunk's window; the next tile's
     // first stage goes to buffer 0 and weight buffers 0 / 1) now serves as epilogue scratch.
+    HSTAMP(20);
     __builtin_amdgcn_s_barrier();
+    HSTAMP(21);
     // Output through a per-wave LDS transpose so that a store instruction writes WHOLE 128-byte
     // lines (the 64 channels of the wave for 8 pixels): measured on the first-layer kernel, whose
     // only problem is its output, 16-byte pieces scattered as quarter lines ran 338-349 us and
@@ -496,7 +517,18 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
         }
       }
     }
+    if (STAMP) {
+      HSTAMP(22);
+      if (threadIdx.x == 64 * ((relu_in >> 4) & 7) && (tcount == 1 || tcount == 2)) {
+        uint64_t* o = reinterpret_cast<uint64_t*>(out + (int64_t)B * H * W * kout) +
+                      (int64_t)(blockIdx.x * 2 + tcount - 1) * 24;
+#pragma unroll
+        for (int k = 0; k < 23; ++k) o[k] = stamp[STAMP ? k : 0];
+      }
+      ++tcount;
+    }
   }   // persistent loop
+#undef HSTAMP
 }
 
 int convh_cus() {
@@ -529,6 +561,8 @@ int scl_convh_dispatch(const void* x, const void* w, int64_t w_stride_k, int64_t
     SCL_CONVH_ATTR(0, 8) SCL_CONVH_ATTR(1, 8) SCL_CONVH_ATTR(2, 8) SCL_CONVH_ATTR(3, 8)
     SCL_CONVH_ATTR(0, 6) SCL_CONVH_ATTR(1, 6) SCL_CONVH_ATTR(2, 6) SCL_CONVH_ATTR(3, 6)
 #undef SCL_CONVH_ATTR
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convh_kernel<1, 12, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)HCfg<12>::LDS);
   });
   hipStream_t st = (hipStream_t)stream;
   const unsigned short* packed = (const unsigned short*)workspace;
@@ -575,6 +609,13 @@ int scl_convh_dispatch(const void* x, const void* w, int64_t w_stride_k, int64_t
     else if (bh == 8) SCL_CONVH_LAUNCH(E, 8, BIAS, RELU, MASK);                                \
     else SCL_CONVH_LAUNCH(E, 6, BIAS, RELU, MASK);                                             \
   } while (0)
+  if (dv >= 3024 && dv < 3032 && bias && !mask && !pidx && bh == 12) {   // stamps of wave dv - 3024
+    SCL_LAUNCH("convh_kernel", (convh_kernel<1, 12, true>), grid, dim3(HTHR), HCfg<12>::LDS, st,
+               (const unsigned short*)x, (const unsigned short*)packed, B, H, W, cin, kout,
+               (unsigned short*)out, bias, (relu ? 1 : 0) | ((dv - 3024) << 4),
+               (const unsigned short*)nullptr, (unsigned char*)nullptr, vblocks);
+    return scl_launch_status();
+  }
   if (pidx)
     SCL_CONVH_BH(3, bias, dbgbits, nullptr);
   else if (mask)
