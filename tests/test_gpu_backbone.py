@@ -565,6 +565,61 @@ def test_backward_data_unpools_the_pooled_gradient_in_staging(dev, c, shape):
         nets.conv64(ga, wt, True, pool_idx=idx)              # un-masked form does not exist
 
 
+@pytest.mark.parametrize('c,shape', [(64, (1, 30, 40)), (64, (2, 32, 48)), (128, (1, 30, 40)), (256, (2, 30, 40)),
+                                     (512, (1, 30, 40))])
+def test_pooling_layer_backward_is_the_same_with_and_without_the_unpooling_pass(dev, c, shape):
+    """SCL_POOLED_BWD: the layer's backward through autograd — input, weight and bias gradient —
+    with the consumers un-pooling while they stage (conv1_2 / conv2_2: no full-size gradient at
+    all; conv3_3 / conv4_3: the weight gradient alone) equals the two-pass form bit for bit (the
+    bias gradient, where another kernel takes it: to summation order)."""
+    from soft_contrastive_learning_amd.model import nets
+    b, h, w = shape
+    g = torch.Generator().manual_seed(71)
+    x0 = torch.relu(torch.randn(b, c, h, w, generator=g)).to(dev).bfloat16().contiguous(
+        memory_format=torch.channels_last)
+    wt0 = (torch.randn(c, c, 3, 3, generator=g) * (2.0 / (9 * c)) ** 0.5).to(dev)
+    b0 = (torch.randn(c, generator=g) * 0.1).to(dev)
+    gy0 = torch.randn(b, c, h // 2, w // 2, generator=g).to(dev).bfloat16().contiguous(
+        memory_format=torch.channels_last)
+    from soft_contrastive_learning_amd import _lib as L
+    results, kernels = [], []
+    keep = nets.USE_POOLED_BWD
+    try:
+        for mode in (True, False):
+            nets.USE_POOLED_BWD = mode
+            x = x0.clone().requires_grad_(True)
+            wt, bias = torch.nn.Parameter(wt0.clone()), torch.nn.Parameter(b0.clone())
+            link_in, link_out = nets._GradLink(), nets._GradLink()
+            y = nets._ConvBiasPoolReLU.apply(x, wt, bias, link_in, link_out)
+            assert y.grad_fn.by_idx
+            gy = torch.where(y.detach() > 0, gy0, torch.zeros_like(gy0)).contiguous(
+                memory_format=torch.channels_last)
+            link_out.mark(gy)                           # "the layer above masked it"
+            with L.KernelTimer(capacity=64) as kt:
+                y.backward(gy)
+                torch.cuda.synchronize()
+            assert link_in.ptr is not None
+            results.append((x.grad.clone(), wt.grad.clone(), bias.grad.clone()))
+            kernels.append(set(kt.summary()))
+    finally:
+        nets.USE_POOLED_BWD = keep
+    # what ran: the pooled weight gradient in the first pass only; no un-pooling pass where the
+    # backward-data kernel un-pools too (the register kernels: 64 and 128 channels)
+    assert 'wrw64_kernel<pooled>' in kernels[0] and 'wrw64_kernel<pooled>' not in kernels[1]
+    assert 'pool_bwd_idx_kernel' in kernels[1]
+    assert ('pool_bwd_idx_kernel' in kernels[0]) == (c > 128)
+    assert ('conv3x3_kernel<pooled>' in kernels[0]) == (c <= 128)
+    (gx0, gw0, gb0), (gx1, gw1, gb1) = results
+    assert torch.equal(gx0, gx1) and torch.equal(gw0, gw1)
+    assert float(gw0.abs().max()) > 0
+    # the bias gradient is the same sum taken by another kernel (the weight-gradient kernel's
+    # side product instead of the un-pooling pass's column sums): another order of additions
+    if c > 128:
+        assert torch.equal(gb0, gb1)
+    else:
+        assert float((gb0 - gb1).abs().max()) <= 2e-5 * float(gy0.float().abs().sum(dim=(0, 2, 3)).max())
+
+
 @pytest.mark.parametrize('cin,cout,shape', [(64, 64, (1, 16, 40)), (128, 128, (1, 9, 33)),
                                             (256, 256, (1, 12, 40)), (128, 256, (1, 30, 40))])
 def test_float32_master_weights_equal_the_bf16_cast(dev, cin, cout, shape, lds_kernel):
