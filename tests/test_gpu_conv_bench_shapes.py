@@ -5,7 +5,9 @@ weights, packed weight images written by one ``scl_conv_pack_batch`` launch, per
 (3.75 tile rounds per workgroup, XCD tile order, next-tile prefetch under the epilogue), the
 pooling epilogue with its one-byte window index, the ReLU' mask in the backward-data epilogue,
 weight AND bias gradient from the weight-gradient kernel on the second stream, written straight
-into the gradient sink (split grids, 16-slab-group reduce).
+into the gradient sink (split grids, 16-slab-group reduce); the pooling layers' backward straight
+from the pooled gradient + window index (conv1_2 / conv2_2: backward-data and weight-gradient
+kernels un-pool while they stage, no full-size gradient; conv3_3 / conv4_3: the weight gradient).
 
 Reference: float32 ``torch`` convolutions ON THE SAME bf16 INPUTS (bf16-rounded weights,
 activations and incoming gradient), evaluated a few images at a time.  Gate: max-abs error
@@ -117,6 +119,7 @@ def test_layer_at_bench_shape(dev, sink, takes, layer):
     from soft_contrastive_learning_amd.model import nets
     name, cin, cout, h, w, relu, pool = layer
     assert nets.USE_PREPACK and nets.USE_SIDE_WRW and nets.USE_POOL_IDX and nets.USE_MASKED_BWD
+    assert nets.USE_POOLED_BWD
     g = torch.Generator().manual_seed(1000 + 17 * cin + cout + h)
     # a post-ReLU input (about half of it exactly zero, like the step's activations)
     x = torch.relu(torch.randn(B, cin, h, w, generator=g)).to(dev).bfloat16().contiguous(memory_format=CL)
