@@ -70,3 +70,33 @@ def test_argument_validation_happens_before_any_launch(lib):
     assert lib.scl_netvlad_fwd(None, 0, None, None, 1, 1, 1, None, None, None, None, None, None, 0,
                                None) == -3
     assert lib.scl_topn_l2(None, 1, None, 1, 64, 1, 0, None, None, None, 0, None) == -3
+
+
+def test_pooled_backward_entry_points_validate_on_the_host(lib):
+    """scl_wrw3x3_pooled / scl_conv3x3_masked_pooled (round 3): NULL operands, odd map sizes and
+    shapes the un-pooling staging does not exist for are refused before any launch."""
+    import ctypes
+    buf = ctypes.create_string_buffer(4096)
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    ws_bytes = lib.scl_wrw3x3_workspace_bytes(64, 64)
+    assert ws_bytes > 0 and lib.scl_wrw3x3_workspace_bytes(48, 64) == 0
+    # NULL index / NULL gradient
+    assert lib.scl_wrw3x3_pooled(p, p, None, 1, 8, 8, 64, 64, p, 576, 9, 3, 1, 1, None, p, ws_bytes,
+                                 None) == -3
+    assert lib.scl_wrw3x3_pooled(p, None, p, 1, 8, 8, 64, 64, p, 576, 9, 3, 1, 1, None, p, ws_bytes,
+                                 None) == -3
+    # channel counts without a kernel (-1 = shape), odd height (a 2x2 window would straddle the edge)
+    assert lib.scl_wrw3x3_pooled(p, p, p, 1, 8, 8, 48, 64, p, 432, 9, 3, 1, 1, None, p, 1 << 20,
+                                 None) == -1
+    assert lib.scl_wrw3x3_pooled(p, p, p, 1, 7, 8, 64, 64, p, 576, 9, 3, 1, 1, None, p, ws_bytes,
+                                 None) == -1
+    cw = lib.scl_conv3x3_workspace_bytes()
+    assert lib.scl_conv3x3_masked_pooled(p, None, p, 576, 9, 3, 1, 1, 1, 8, 8, 64, 64, p, p, p, cw,
+                                         None) == -3
+    assert lib.scl_conv3x3_masked_pooled(p, p, p, 576, 9, 3, 1, 1, 1, 8, 8, 64, 64, p, None, p, cw,
+                                         None) == -3
+    # cin != kout has no un-pooling window staging; odd width
+    assert lib.scl_conv3x3_masked_pooled(p, p, p, 576, 9, 3, 1, 1, 1, 8, 8, 128, 64, p, p, p, cw,
+                                         None) == -1
+    assert lib.scl_conv3x3_masked_pooled(p, p, p, 576, 9, 3, 1, 1, 1, 8, 9, 64, 64, p, p, p, cw,
+                                         None) == -1
