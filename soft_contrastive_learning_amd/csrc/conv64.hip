@@ -1231,7 +1231,6 @@ int launch_conv3x3(const void* x, const void* w, int64_t sk, int64_t sc, int64_t
                    hipStream_t st) {
   using Cfg = ConvCfg<CIN, KOUT>;
   static std::once_flag once;
-  static int cus = 256;
   std::call_once(once, [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<CIN, KOUT, 0>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
@@ -1246,8 +1245,8 @@ int launch_conv3x3(const void* x, const void* w, int64_t sk, int64_t sc, int64_t
     if (CIN == KOUT)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<CIN, CIN, 3, 1>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
-    cus = conv64_cus();
   });
+  const int cus = conv64_cus();
   const unsigned short* packed = (const unsigned short*)workspace;
   if (transposed & SCL_W_PACKED)
     packed = (const unsigned short*)w;                   // scl_conv_pack_batch wrote it
@@ -1388,12 +1387,18 @@ extern "C" int scl_conv64(const void* x, const void* w, int64_t w_stride_k, int6
                      64, 64, out, workspace, workspace_bytes, stream);
 }
 
+// CUs the persistent grids may fill: the hardware's count (asked once), minus the reserve AS IT
+// IS NOW — scl_set_reserve_cus may change between calls (bench.py tries 0 and 8 at N > 1)
 static int conv64_cus() {
-  int dev = 0, n = 0;
-  if (hipGetDevice(&dev) == hipSuccess &&
-      hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-    return scl_usable_cus(n);
-  return scl_usable_cus(256);
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, c = 0;
+    n = (hipGetDevice(&dev) == hipSuccess &&
+         hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0)
+            ? c : 256;
+  }
+  const int u = scl_usable_cus(n);
+  return u > 1024 ? 1024 : u;
 }
 
 static int wrw_splits(int C, int K, int tiles, int cus) {
@@ -1434,7 +1439,6 @@ static int wrw3x3_run(const void* x, const void* gz, const unsigned char* pidx, 
   if (((uintptr_t)x % 16) || ((uintptr_t)gz % 16)) return SCL_E_SHAPE;
   if (!scl_aligned256(workspace) || workspace_bytes < need) return SCL_E_WORKSPACE;
   static std::once_flag once;
-  static int cus = 256;
   std::call_once(once, [] {
 #define SCL_WRW_ATTR(D, T, N, PL)                                                              \
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wrw64_kernel<D, T, N, PL>),         \
@@ -1446,9 +1450,8 @@ static int wrw3x3_run(const void* x, const void* gz, const unsigned char* pidx, 
     SCL_WRW_ATTR(4, 32, 2, 0) SCL_WRW_ATTR(4, 8, 2, 0) SCL_WRW_ATTR(4, 32, 2, 1) SCL_WRW_ATTR(4, 8, 2, 1)
     SCL_WRW_ATTR(6, 32, 2, 0) SCL_WRW_ATTR(6, 8, 2, 0)
 #undef SCL_WRW_ATTR
-    cus = conv64_cus();
-    if (cus > 1024) cus = 1024;
   });
+  const int cus = conv64_cus();
   // [64 c] x [128 k] blocks wherever the output channels allow (scl_debug_set_variant(2100)
   // pins the 64 x 64 variant); tile shape: wide, or tall where that pads the map less
   const int dbg = scl_debug_variant / 1000 == 2 ? scl_debug_variant & 3 : 0;
@@ -1559,9 +1562,7 @@ extern "C" int scl_conv_first(const float* img, const float* avg, const void* w,
   if (!img || !avg || !w || !bias || !x0 || !y) return SCL_E_NULL;
   if (B < 1 || H < 1 || W < 1 || (int64_t)B * H * W > (int64_t)1 << 30) return SCL_E_SHAPE;
   if ((uintptr_t)y % 16) return SCL_E_SHAPE;
-  static std::once_flag once;
-  static int cus = 256;
-  std::call_once(once, [] { cus = conv64_cus(); });
+  const int cus = conv64_cus();
   const int tiles = B * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
   // (8 workgroups per CU although four are resident at a time: measured 337-348 us against
   // 351-361 with 4 — the tail is finer)
@@ -1592,13 +1593,11 @@ extern "C" int scl_conv_first_wrw(const void* x0, const void* gz, int B, int H, 
   if (!scl_aligned256(workspace) || workspace_bytes < scl_conv_first_wrw_workspace_bytes())
     return SCL_E_WORKSPACE;
   static std::once_flag once;
-  static int cus = 256;
   std::call_once(once, [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_first_wrw_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFirstWrwLds);
-    cus = conv64_cus();
-    if (cus > 1024) cus = 1024;
   });
+  const int cus = conv64_cus();
   const int tiles = B * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
   const int grid = first_wrw_grid(tiles, cus);
   hipStream_t st = (hipStream_t)stream;

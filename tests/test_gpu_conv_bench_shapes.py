@@ -114,9 +114,29 @@ def _ref_backward(x, gz, wq, chunk=4):
     return gx, gw.float()
 
 
-@pytest.mark.parametrize('layer', LAYERS, ids=[l[0] for l in LAYERS])
-def test_layer_at_bench_shape(dev, sink, takes, layer):
+@pytest.fixture
+def reserve():
+    """scl_set_reserve_cus(n) for the duration of a test (what bench.py may choose at N > 1: every
+    persistent grid shrinks to 256 - n workgroups, the weight-gradient splits change)."""
+    from soft_contrastive_learning_amd import _lib as L
+    lib = L.load()
+
+    def set_(n):
+        lib.scl_set_reserve_cus(int(n))
+    yield set_
+    lib.scl_set_reserve_cus(0)
+
+
+# (layer, CUs left free): every layer with the whole chip; one layer of every kernel family and
+# resolution again with 8 CUs reserved — 248 workgroups: other tile rounds, weight-gradient pixel
+# splits that are not multiples of 8 (the workgroup -> (split, block) map takes its other branch)
+CASES = [(l, 0) for l in LAYERS] + [(l, 8) for l in LAYERS if l[0] in ('1_2', '2_1', '3_3', '4_2', '5_1')]
+
+
+@pytest.mark.parametrize('layer,free_cus', CASES, ids=['%s%s' % (l[0], '-reserve%d' % r if r else '') for l, r in CASES])
+def test_layer_at_bench_shape(dev, sink, takes, reserve, layer, free_cus):
     from soft_contrastive_learning_amd.model import nets
+    reserve(free_cus)
     name, cin, cout, h, w, relu, pool = layer
     assert nets.USE_PREPACK and nets.USE_SIDE_WRW and nets.USE_POOL_IDX and nets.USE_MASKED_BWD
     assert nets.USE_POOLED_BWD
