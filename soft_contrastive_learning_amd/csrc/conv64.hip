@@ -408,7 +408,8 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
 //   dW[k][c][kh][kw] = sum_{b,y,x} gz[b,y,x,k] * x[b, y+kh-1, x+kw-1, c].
 // The contraction runs over pixels — the SLOW index of both channels-last operands — so both
 // MFMA operands are read with ds_read_b64_tr_b16 out of row-major LDS tiles (the x halo
-// window of conv64_kernel and the gz tile); a tap is again just an address offset.
+// window of conv64_kernel and the gz tile); a tap row is an address offset, the three tap
+// columns of a row are one 12-pixel fragment shifted inside the lane (round 3, see the loop).
 //   * v_mfma_f32_32x32x16_bf16 with M = 32 input channels, N = 32 output channels, 16 pixels
 //     per step; wave (mt, nt) keeps all nine taps of its 32 x 32 block: 144 accumulators;
 //   * persistent grid, one workgroup per CU accumulating over all its tiles, then ONE slab
@@ -422,7 +423,11 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
 // The planes are filled by LDS-DMA (global_load_lds_dwordx4: no staging registers, no
 // ds_write pass, 80 KB in flight per CU): one wave-instruction writes 1 KB = 16 pixels of a
 // plane, lane -> (pixel lane >> 2, 16-byte piece lane & 3) — the image is lane-linear as the
-// DMA requires.  Out-of-image halo pixels are fetched from a zero block.
+// DMA requires.  Out-of-image halo pixels are fetched from a zero block.  Round 3: the DMA
+// instructions of a tile go out one at a time between the products (back to back they parked the
+// wave for 2,100 cycles), with a scalar base + constant lane offset for tiles off the border;
+// the grid is 1-D with the workgroups that share tiles on one XCD; PL = 1 builds the gz tile from
+// the pooled gradient + window index instead.
 constexpr int WPL = 32;                              // bf16 per pixel and plane
 constexpr int GPLANE = TH * TW * WPL;                // one 32-channel plane of a 256-pixel gz tile
                                                      // (conv_first_wrw_kernel; wrw64: WrwCfg)
