@@ -640,8 +640,8 @@ __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __r
   float bsum = 0.f;
   typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
-  // The wave's 72 (step, tap) products of a tile run as ONE software pipeline: the A operand
-  // of product i + 3 is in flight while product i multiplies (an LDS transposed read returns
+  // The wave's 72 (step, tap) products of a tile run as ONE software pipeline: the window-row
+  // fragment a product opens is requested six products earlier (an LDS transposed read returns
   // long after one 32-cycle MFMA), the B operand of the next step while the current one runs.
   // The tiles alternate between two LDS buffers: the DMA of tile n + 1 runs under the whole
   // of tile n; one barrier per tile (it drains the DMA: hipcc waits vmcnt(0) there).
