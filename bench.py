@@ -109,11 +109,13 @@ def parse():
 
 
 # kernels of the NetVLAD head, by pass (names = the kernels' own names, as rocprofv3 prints them)
-NETVLAD_FWD = ('vlad_split_w_kernel', 'vlad_fwd_kernel<true>', 'vlad_fwd_kernel<false>',
-               'vlad_finish_sum_kernel', 'finish_norm_kernel', 'transpose_w_kernel',
+NETVLAD_FWD = ('vlad_split_w_kernel', 'vlad_planes_kernel', 'vlad_fwd_kernel<true>', 'vlad_fwd_kernel<false>',
+               'vlad_fwd8_kernel<true>', 'vlad_fwd8_kernel<false>',
+               'vlad_finish_kernel', 'vlad_finish_sum_kernel', 'finish_norm_kernel', 'transpose_w_kernel',
                'rowtile16_kernel<ASSIGN>', 'aggregate_kernel<float>', 'aggregate_kernel<bf16>',
                'finish_sum_kernel')
-NETVLAD_BWD = ('bwd_dots_kernel', 'bwd_du_kernel', 'vlad_bwd_kernel', 'vlad_dx_kernel',
+NETVLAD_BWD = ('vlad_bwd_prologue_kernel', 'bwd_dots_kernel', 'bwd_du_kernel', 'vlad_bwd_kernel', 'vlad_bwd8_kernel',
+               'vlad_dx_kernel',
                'vlad_wgrad_partial_kernel', 'vlad_wgrad_finish_kernel', 'rowtile16_kernel<DASSIGN>',
                'dx16_kernel<float>', 'dx16_kernel<bf16>', 'wgrad_finish_kernel')
 
@@ -136,13 +138,25 @@ def kernel_models(b, n, gb, x_bytes, slices=10):
         'vlad_fwd_kernel<true>': dict(flops=4.0 * bn * D * K,
                                       bytes=bn * D * 2 + bn * K * 8 + bn * 4 + slab, **b2),
         'vlad_fwd_kernel<false>': dict(flops=4.0 * bn * D * K, bytes=bn * D * 2 + slab, **b2),
+        # round 4: the same two kernels with eight waves per workgroup
+        'vlad_fwd8_kernel<true>': dict(flops=4.0 * bn * D * K,
+                                       bytes=bn * D * 2 + bn * K * 8 + bn * 4 + slab, **b2),
+        'vlad_fwd8_kernel<false>': dict(flops=4.0 * bn * D * K, bytes=bn * D * 2 + slab, **b2),
+        'vlad_bwd8_kernel': dict(flops=4.0 * bn * D * K,
+                                 bytes=bn * D * 2 + bn * K * 12 + bn * 8 + slab + b * D * K * 4, **b2),
         # fused x.dU + softmax backward + x^T.(ds rn): x, a, logits, rn in; ds, rowdot, slabs out
         'vlad_bwd_kernel': dict(flops=4.0 * bn * D * K,
                                 bytes=bn * D * 2 + bn * K * 12 + bn * 8 + slab + b * D * K * 4, **b2),
         # [a|ds].[dU|W]^T then the norm Jacobian: x, a, ds in, grad_x out, the operand images (two
         # bf16 planes of dU per image and of W; the other slices of an image find them in the L2)
+        # (round 4: + the parameter-gradient sums in its tail: every dW slab once, dU once)
         'vlad_dx_kernel': dict(flops=4.0 * bn * D * K,
-                               bytes=4 * bn * D + bn * K * 8 + (b + 1) * D * K * 4, **b3),
+                               bytes=4 * bn * D + bn * K * 8 + (b + 1) * D * K * 4 + slab + b * D * K * 4,
+                               **b3),
+        # round 4: finish_sum + finish_norm, and bwd_dots + bwd_du, as one launch each
+        'vlad_finish_kernel': dict(flops=(slices + 4.0) * b * D * K, bytes=slab + b * D * K * 8),
+        'vlad_bwd_prologue_kernel': dict(flops=12.0 * b * D * K, bytes=b * D * K * 4 * 5),
+        'vlad_planes_kernel': dict(flops=0.0, bytes=D * K * 12),
         'vlad_wgrad_partial_kernel': dict(flops=b * slices * D * K, bytes=slab),
         'vlad_wgrad_finish_kernel': dict(flops=4.0 * b * D * K, bytes=b * D * K * 4 + 9 * D * K * 4),
         'vlad_split_w_kernel': dict(flops=0.0, bytes=D * K * 8),

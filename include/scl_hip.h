@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SCL_ABI_VERSION 5
+#define SCL_ABI_VERSION 6
 
 /* error codes (negative = rejected before any launch) */
 #define SCL_OK 0
@@ -54,6 +54,10 @@ extern "C" {
  * D = 512 VGG16 conv5_3 channels, K = 64 clusters (model/nets.py:67). */
 #define SCL_VLAD_D 512
 #define SCL_VLAD_K 64
+/* rows of 64 floats per image in save_vlad: 512 of the pre-norm VLAD, row 512 = sum_n a[n,:],
+ * row 513 = sync words of the backward pass (zeroed by the forward, zero again when the
+ * backward returns; see scl_netvlad_bwd) */
+#define SCL_VLAD_SAVE_ROWS 514
 
 /* pair-mask kinds of the Gram-matrix loss family */
 #define SCL_MASK_WMS_EXP 0   /* wms_loss wfunction='exp'  (model/losses.py:17-19) */
@@ -87,25 +91,53 @@ const char* scl_error_string(int code);
  * For training the forward also leaves, in caller buffers, what the backward
  * re-uses (pass NULL for all four when only inferring):
  *   save_assign [B,N,64] soft-assignment a;  save_logit [B,N,64] logits;
- *   save_rnorm  [B,N] per-location 1/||x||;  save_vlad  [B,512,64] pre-norm VLAD.
+ *   save_rnorm  [B,N] per-location 1/||x||;  save_vlad  [B,SCL_VLAD_SAVE_ROWS,64].
  * save_assign and save_rnorm double as forward scratch: when NULL they are carved
  * from the workspace.
+ *
+ * w_planes (the _p entries; NULL = build them inside the call, one more launch): the bf16
+ * plane images of assign_w that the fused kernels keep in registers, scl_netvlad_planes_bytes()
+ * bytes, 256-byte aligned, written by scl_netvlad_planes() or — in the same launch as the
+ * packed convolution weights, once per optimizer step — by a SclPackJob with flags =
+ * SCL_PACK_VLAD_W (w = assign_w, cin = 512, kout = 64, strides ignored).  They must be rebuilt
+ * whenever assign_w changes (train/train.py:877-879: once per step).
+ *
+ * Launches for a bf16 map with w_planes given: forward 2 (fused assignment + aggregation; finish),
+ * backward 3 (prologue; fused softmax-backward + dW slabs; grad_x with the parameter-gradient sums in
+ * its tail).  The 8 workgroups of an image inside the finish / prologue kernels exchange one or
+ * two scalars through 8-byte tagged words with a bounded wait and a self-computing fallback: no
+ * result depends on dispatch order or co-residency.
  * ------------------------------------------------------------------------- */
+size_t scl_netvlad_planes_bytes(void);
+int scl_netvlad_planes(const float* assign_w, void* planes, void* stream);
 size_t scl_netvlad_fwd_workspace_bytes(int B, int N);
 int scl_netvlad_fwd(const void* x, int x_dtype, const float* assign_w, const float* centers,
                     int B, int N, int pre_l2, float* out, float* save_assign,
                     float* save_logit, float* save_rnorm, float* save_vlad, void* workspace,
                     size_t workspace_bytes, void* stream);
+int scl_netvlad_fwd_p(const void* x, int x_dtype, const float* assign_w, const float* centers,
+                      const void* w_planes, int B, int N, int pre_l2, float* out,
+                      float* save_assign, float* save_logit, float* save_rnorm, float* save_vlad,
+                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* Backward of the above (TF autodiff of the same graph, train/train.py:877-878).
  *   grad_out [B,32768];  grad_x [B,N,512] in x's dtype;  grad_w, grad_c [512,64]
- *   (sums over the batch, overwritten). */
+ *   (sums over the batch, overwritten).
+ * save_vlad is not const: row 513 of every image carries the exchange words of the prologue
+ * kernel; they are zero on entry (the forward left them so) and zero again on return, so the
+ * same saved tensors can be back-propagated through more than once — but not by two calls
+ * at the same time. */
 size_t scl_netvlad_bwd_workspace_bytes(int B, int N);
 int scl_netvlad_bwd(const void* x, int x_dtype, const float* assign_w, const float* centers,
                     const float* grad_out, const float* save_assign, const float* save_logit,
-                    const float* save_rnorm, const float* save_vlad, int B, int N, int pre_l2,
+                    const float* save_rnorm, float* save_vlad, int B, int N, int pre_l2,
                     void* grad_x, float* grad_w, float* grad_c, void* workspace,
                     size_t workspace_bytes, void* stream);
+int scl_netvlad_bwd_p(const void* x, int x_dtype, const float* assign_w, const float* centers,
+                      const void* w_planes, const float* grad_out, const float* save_assign,
+                      const float* save_logit, const float* save_rnorm, float* save_vlad, int B,
+                      int N, int pre_l2, void* grad_x, float* grad_w, float* grad_c,
+                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Gram-matrix losses — replace wms_loss (model/losses.py:5-60) and
@@ -431,7 +463,9 @@ int scl_wrw3x3_pooled(const void* x, const void* g_pooled, const void* pool_idx,
  * (layer, direction) up front and passes the images with SCL_W_PACKED in the flags argument.
  * jobs is a HOST array; packed buffers are scl_conv_packed_bytes(cin, kout) each (0 = the
  * shape has no packed form: cin % 64, kout % 128 for the LDS-weights kernels), 256-byte
- * aligned.  flags per job: SCL_CONV_TRANSPOSED and / or SCL_W_F32. */
+ * aligned.  flags per job: SCL_CONV_TRANSPOSED and / or SCL_W_F32; or SCL_PACK_VLAD_W alone: the
+ * job writes the NetVLAD plane images of assign_w (see scl_netvlad_fwd_p) instead. */
+#define SCL_PACK_VLAD_W 16
 typedef struct SclPackJob {
   const void* w;
   int64_t w_stride_k, w_stride_c, w_stride_h, w_stride_w;

@@ -19,7 +19,7 @@ from tests import util_data as U  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--kernel', default='fwd', choices=['fwd', 'dx'])
+    ap.add_argument('--kernel', default='fwd', choices=['fwd', 'fwd8', 'dx'])
     ap.add_argument('--batch', type=int, default=24)
     ap.add_argument('--locations', type=int, default=1200)
     args = ap.parse_args()
@@ -31,13 +31,13 @@ def main():
     wt, ct = torch.tensor(w, device=dev), torch.tensor(c, device=dev)
     out = torch.empty(b, 32768, device=dev)
     sa, sl = torch.empty(b, n, 64, device=dev), torch.empty(b, n, 64, device=dev)
-    sr, sv = torch.empty(b, n, device=dev), torch.empty(b, 513, 64, device=dev)
+    sr, sv = torch.empty(b, n, device=dev), torch.empty(b, L.VLAD_SAVE_ROWS, 64, device=dev)
     ws = L.workspace(lib.scl_netvlad_fwd_workspace_bytes(b, n), dev)
     steps = (n + 31) // 32
     per = -(-steps * b // 256)
     s_cnt = -(-steps // per)
     nwg = b * s_cnt
-    lib.scl_debug_set_variant(916 if args.kernel == 'fwd' else 0)
+    lib.scl_debug_set_variant({'fwd': 916, 'fwd8': 918}.get(args.kernel, 0))
     try:
         for _ in range(3):
             ws.zero_()
@@ -65,6 +65,16 @@ def main():
         names.update({3 + t: 'after tile %d (+ epilogue of tile %d)' % (t, t - 1) for t in range(1, 9)})
         names.update({16: 'tile 2: inputs requested', 17: 'tile 2: MFMAs issued', 18: 'tile 2: epilogue of tile 1 issued',
                       19: 'tile 2: next fragments staged', 20: 'tile 2: barrier passed'})
+    elif args.kernel == 'fwd8':
+        names = {0: 'entry', 1: 'stage DMA issued, W loads issued', 28: 'loop done', 29: 'slab stores issued',
+                 30: 'slab stores complete'}
+        for st in range(4):
+            names.update({4 + 6 * st: 'step %d: stage landed + barrier' % st,
+                          5 + 6 * st: 'step %d: partial logits done' % st,
+                          6 + 6 * st: 'step %d: partials exchanged (barrier)' % st,
+                          7 + 6 * st: 'step %d: softmax part 1 + barrier' % st,
+                          8 + 6 * st: 'step %d: coefficients written + barrier' % st,
+                          9 + 6 * st: 'step %d: aggregation done' % st})
     else:
         names = {0: 'entry', 1: 'stage DMA issued, W loads issued', 2: 'W + first stages landed', 28: 'loop done',
                  29: 'slab stores issued', 30: 'slab stores complete'}

@@ -12,15 +12,17 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libscl_hip.so")
 
 # constants of include/scl_hip.h
-ABI_VERSION = 5
+ABI_VERSION = 6
 DT_F32, DT_BF16 = 0, 1
 MASK_WMS_EXP, MASK_WMS_LIN, MASK_WMS_TANH, MASK_LABELS = 0, 1, 2, 3
 SUM_MS, SUM_PLAIN = 0, 1
 TUPLE_TRIPLET, TUPLE_LAZY_TRIPLET, TUPLE_EVIL_TRIPLET = 0, 1, 2
 TUPLE_QUADRUPLET, TUPLE_LAZY_QUADRUPLET, TUPLE_EVIL_QUADRUPLET = 3, 4, 5
 VLAD_D, VLAD_K = 512, 64
+VLAD_SAVE_ROWS = 514      # save_vlad rows per image: U, asum, sync words of the backward pass
 TOPN_SCORE_F32, TOPN_SCORE_BF16X3 = 0, 1
 CONV_TRANSPOSED, W_F32, W_PACKED = 1, 2, 4   # flag word of the convolution entry points
+PACK_VLAD_W = 16           # SclPackJob.flags: the job writes the NetVLAD plane images of assign_w
 
 _p = ctypes.c_void_p
 _i = ctypes.c_int
@@ -44,6 +46,11 @@ SIGNATURES = {
     "scl_error_string": (ctypes.c_char_p, [_i]),
     "scl_netvlad_fwd_workspace_bytes": (_z, [_i, _i]),
     "scl_netvlad_fwd": (_i, [_p, _i, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _z, _p]),
+    "scl_netvlad_planes_bytes": (_z, []),
+    "scl_netvlad_planes": (_i, [_p, _p, _p]),
+    "scl_netvlad_fwd_p": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _z, _p]),
+    "scl_netvlad_bwd_p": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _z,
+                               _p]),
     "scl_netvlad_bwd_workspace_bytes": (_z, [_i, _i]),
     "scl_netvlad_bwd": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _z,
                              _p]),

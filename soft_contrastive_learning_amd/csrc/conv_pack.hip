@@ -8,6 +8,7 @@
 // convolutions with SCL_W_PACKED.  The two layouts are restated here; the parity tests compare
 // a convolution fed this way with the same convolution packing for itself, bit for bit.
 #include "scl_common.h"
+#include "vlad_planes.h"
 
 namespace {
 
@@ -18,7 +19,8 @@ struct PackJobs {
   const void* w[kMaxJobs];
   unsigned short* packed[kMaxJobs];
   int64_t sk[kMaxJobs], sc[kMaxJobs], sh[kMaxJobs], sw[kMaxJobs];
-  int flags[kMaxJobs];       // SCL_CONV_TRANSPOSED | SCL_W_F32 | 8: register-weights layout
+  int flags[kMaxJobs];       // SCL_CONV_TRANSPOSED | SCL_W_F32 | 8: register-weights layout |
+                             // SCL_PACK_VLAD_W: the NetVLAD plane images (vlad_planes.h)
   int cin[kMaxJobs], kout[kMaxJobs];
   int first_block[kMaxJobs + 1];   // prefix sums of 256-element blocks
   int n;
@@ -29,6 +31,11 @@ __global__ __launch_bounds__(256) void conv_pack_batch_kernel(const PackJobs job
   while (job + 1 < jobs.n && (int)blockIdx.x >= jobs.first_block[job + 1]) ++job;
   const int64_t idx = (int64_t)(blockIdx.x - jobs.first_block[job]) * 256 + threadIdx.x;
   const int cin = jobs.cin[job], kout = jobs.kout[job], flags = jobs.flags[job];
+  if (flags & SCL_PACK_VLAD_W) {
+    vlad_planes_wave((const float*)jobs.w[job], jobs.packed[job], jobs.packed[job] + VP_FWD_ELEMS,
+                     (int)(idx >> 6), threadIdx.x & 63);
+    return;
+  }
   const int transposed = flags & 1, wf32 = flags & 2;
   const int64_t total = (int64_t)9 * cin * kout;
   if (idx >= total) return;
@@ -76,6 +83,11 @@ __global__ __launch_bounds__(256) void conv_pack_tiled_kernel(const PackJobs job
   while (job + 1 < jobs.n && (int)blockIdx.x >= jobs.first_block[job + 1]) ++job;
   const int t = blockIdx.x - jobs.first_block[job];
   const int cin = jobs.cin[job], flags = jobs.flags[job];
+  if (flags & SCL_PACK_VLAD_W) {     // (uniform over the workgroup)
+    vlad_planes_wave((const float*)jobs.w[job], jobs.packed[job], jobs.packed[job] + VP_FWD_ELEMS,
+                     4 * t + (threadIdx.x >> 6), threadIdx.x & 63);
+    return;
+  }
   const int transposed = flags & 1, wf32 = flags & 2;
   const int cibn = cin / 32;
   const int cob = t / cibn, cib = t % cibn;
@@ -133,25 +145,33 @@ extern "C" int scl_conv_pack_batch(const SclPackJob* jobs, int njobs, void* stre
     for (int i = 0; i < pj.n; ++i) {
       const SclPackJob& j = jobs[base + i];
       if (!j.w || !j.packed) return SCL_E_NULL;
-      if (scl_conv_packed_bytes(j.cin, j.kout) == 0 || ((uintptr_t)j.packed % 256)) return SCL_E_SHAPE;
-      if (j.flags & ~3) return SCL_E_KIND;
+      const bool vlad = (j.flags & SCL_PACK_VLAD_W) != 0;
+      if (vlad) {      // assign_w [512][64] float32 contiguous -> scl_netvlad_planes_bytes() bytes
+        if (j.flags != SCL_PACK_VLAD_W) return SCL_E_KIND;
+        if (j.cin != SCL_VLAD_D || j.kout != SCL_VLAD_K || ((uintptr_t)j.packed % 256) || ((uintptr_t)j.w % 16))
+          return SCL_E_SHAPE;
+      } else {
+        if (scl_conv_packed_bytes(j.cin, j.kout) == 0 || ((uintptr_t)j.packed % 256)) return SCL_E_SHAPE;
+        if (j.flags & ~3) return SCL_E_KIND;
+      }
       pj.w[i] = j.w;
       pj.packed[i] = (unsigned short*)j.packed;
       pj.sk[i] = j.w_stride_k;
       pj.sc[i] = j.w_stride_c;
       pj.sh[i] = j.w_stride_h;
       pj.sw[i] = j.w_stride_w;
-      pj.flags[i] = j.flags | (reg_shape(j.cin, j.kout) ? 8 : 0);
+      pj.flags[i] = vlad ? j.flags : (j.flags | (reg_shape(j.cin, j.kout) ? 8 : 0));
       pj.cin[i] = j.cin;
       pj.kout[i] = j.kout;
       pj.first_block[i] = blocks;
-      blocks += (9 * j.cin * j.kout + 255) / 256;
+      blocks += vlad ? VP_WAVES / 4 : (9 * j.cin * j.kout + 255) / 256;
     }
     pj.first_block[pj.n] = blocks;
     // contiguous OIHW sources (the float32 masters): the tiled kernel; anything else: the gather
     bool tiled = true;
     for (int i = 0; i < pj.n; ++i) {
       const SclPackJob& j = jobs[base + i];
+      if (j.flags & SCL_PACK_VLAD_W) continue;              // served by either kernel
       const int src_c = (j.flags & 1) ? j.kout : j.cin;      // the source tensor's dimension 1
       tiled = tiled && j.w_stride_w == 1 && j.w_stride_h == 3 && j.w_stride_c == 9 &&
               j.w_stride_k == (int64_t)9 * src_c && j.cin % 32 == 0 && j.kout % 32 == 0 &&
@@ -161,7 +181,7 @@ extern "C" int scl_conv_pack_batch(const SclPackJob* jobs, int njobs, void* stre
       int tiles = 0;
       for (int i = 0; i < pj.n; ++i) {
         pj.first_block[i] = tiles;
-        tiles += (pj.cin[i] / 32) * (pj.kout[i] / 32);
+        tiles += (pj.flags[i] & SCL_PACK_VLAD_W) ? VP_WAVES / 4 : (pj.cin[i] / 32) * (pj.kout[i] / 32);
       }
       pj.first_block[pj.n] = tiles;
       SCL_LAUNCH("conv_pack_tiled_kernel", conv_pack_tiled_kernel, dim3((unsigned)tiles), dim3(256), 0,

@@ -32,40 +32,20 @@
 #include <type_traits>
 
 #include "scl_common.h"
+#include "vlad_planes.h"
 
 namespace {
 
 constexpr int D = SCL_VLAD_D;   // 512
 constexpr int K = SCL_VLAD_K;   // 64
 constexpr int NSPLIT = 4;       // location splits with their own slab in aggregate_kernel
+constexpr int VROWS = SCL_VLAD_SAVE_ROWS;   // rows of save_vlad per image: 512 of U, asum, sync words
 
 // ------------------------------------------------------------------ small kernels
 __global__ __launch_bounds__(256) void transpose_w_kernel(const float* __restrict__ w,
                                                           float* __restrict__ wt) {
   const int idx = blockIdx.x * 256 + threadIdx.x;  // over D*K, k fastest
   if (idx < D * K) wt[(idx % K) * D + idx / K] = w[idx];
-}
-
-// x = h1 + h2 + h3 exactly (up to the float32 subnormal range): three bf16 roundings.
-__device__ __forceinline__ void split3_bf16(float x, unsigned short& h1, unsigned short& h2,
-                                            unsigned short& h3) {
-  h1 = f32_to_bf16(x);
-  const float r1 = x - bf16_to_f32(h1);
-  h2 = f32_to_bf16(r1);
-  h3 = f32_to_bf16(r1 - bf16_to_f32(h2));
-}
-
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-// float32 x 8 -> packed bf16 high and low halves (v = hi + lo + O(2^-17 |v|))
-__device__ __forceinline__ void split2x8(const f32x4& a, const f32x4& b, u32x4& hi, u32x4& lo) {
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const float v0 = c < 2 ? a[2 * c] : b[2 * c - 4], v1 = c < 2 ? a[2 * c + 1] : b[2 * c - 3];
-    const unsigned short h0 = f32_to_bf16(v0), h1 = f32_to_bf16(v1);
-    hi[c] = (unsigned)h0 | ((unsigned)h1 << 16);
-    lo[c] = (unsigned)f32_to_bf16(v0 - bf16_to_f32(h0)) |
-            ((unsigned)f32_to_bf16(v1 - bf16_to_f32(h1)) << 16);
-  }
 }
 
 enum RowMode { ASSIGN = 0, DASSIGN = 1 };
@@ -662,6 +642,7 @@ struct VladFwdArgs {
   float* trash;                 // 64 x 16 bytes: where the stores of rows past the end go (the
                                 // kernel counts its own vector-memory queue, so every step must
                                 // issue the same number of stores)
+  unsigned long long* gran;     // [B][8] granules of vlad_finish_kernel's exchange: zeroed here
 };
 
 template <bool SAVE>
@@ -693,6 +674,8 @@ __global__ __launch_bounds__(256, 1) void vlad_fwd_kernel(VladFwdArgs p) {
     }                                                       \
   } while (0)
   VF_STAMP(0);
+  // (the finish kernel behind this one polls these words: they must be zero when it starts)
+  if (sl == 0 && threadIdx.x < 8) p.gran[b * 8 + threadIdx.x] = 0ull;
 
   // ---- x stage by LDS-DMA: wave w brings rows w, w + 4, .. of the step; lane l of row r
   // fetches chunk l ^ (r & 15) into unit 64 r + l (rows past the end re-read the last row)
@@ -967,10 +950,10 @@ __global__ __launch_bounds__(256) void vlad_finish_sum_kernel(const float* __res
   for (int j = 0; j < 4; ++j) {
     const int d = 16 * ct + 4 * g + j;
     const float v = u[j] + centers[d * K + k] * asum;
-    vlad[((int64_t)b * (D + 1) + d) * K + k] = v;
+    vlad[((int64_t)b * VROWS + d) * K + k] = v;
     ss = fmaf(v, v, ss);
   }
-  if (ct == 0 && g == 0) vlad[((int64_t)b * (D + 1) + D) * K + k] = asum;
+  if (ct == 0 && g == 0) vlad[((int64_t)b * VROWS + D) * K + k] = asum;
   ss = vf_gsum(ss);
   if (g == 0) colsq_part[((int64_t)b * 32 + ct) * K + k] = ss;
 }
@@ -1198,6 +1181,508 @@ __global__ __launch_bounds__(256, 1) void vlad_bwd_kernel(VladBwdArgs p) {
   for (int ct = 0; ct < 32; ++ct) slab[ct * 64] = accv[ct];
 }
 
+// =======================================================================================
+// Round 4: the two fused kernels with EIGHT waves per workgroup (two per SIMD).
+//
+// What the stamps of the four-wave kernels showed (profiles/r03/vlad_stamps_fwd.txt): a 32-location
+// step takes 6.4 k cycles, of which 160 MFMAs x 16 cycles = 2.6 k are matrix work; the rest is the
+// softmax / coefficient arithmetic and its cross-lane and LDS traffic (2.1 k), LDS latency in front
+// of the aggregation's products, and two barriers — all strictly one after the other, because a
+// wave that owns a SIMD alone issues in order: a vector instruction costs it 4 cycles (2 with a
+// second wave on the SIMD) and nothing runs while it waits.  Here wave (w, h) = clusters 16 w .. +15
+// x CHANNEL HALF h:
+//   * registers per wave halve (W^T fragments 64, VLAD accumulators 64), so two waves fit a SIMD:
+//     one wave's LDS round trips, waits and vector work hide behind the other's, and vector
+//     instructions issue at twice the rate;
+//   * the logits are partial sums over the wave's 256 channels: the wave keeps the partial of
+//     location tile t = h and hands the other tile's to its partner (w, 1 - h) through LDS — each
+//     wave then runs the softmax arithmetic of 16 locations instead of 32;
+//   * the row norms (one more MFMA per k-step: the diagonal of x x^T) were computed by all four
+//     waves alike; now wave (w, h) takes k-steps w and w + 4 of its half and the eight partials are
+//     added after the exchange: 4 instead of 32 norm MFMAs per wave and step (136 instead of 160 MFMAs
+//     per SIMD and step);
+//   * aggregation: the wave's 16 channel tiles x its 16 clusters, B operand = the pair's coefficient
+//     image (rows 16 h .. of it written by wave (w, h)).
+// Four barriers per step (stage landed | partials exchanged | (max, sum exp) exchanged |
+// coefficients written) instead of two; x staging, LDS images, slab layout, saved outputs and the
+// W^T register image are the four-wave kernel's (vlad_fwd_kernel), so every consumer is unchanged.
+// scl_debug_set_variant(922) runs the four-wave kernels (same-box A/B).
+constexpr int V8_XL = 8 * 64 * 16;               // partial logits for the partner: [wave][lane] x 16 B
+constexpr int V8_PN = 2 * 16 * 8 * 4;            // norm partials [tile][location][wave]
+constexpr int V8_EXCH = 2 * 4 * 16 * 16;         // [tile][cluster group][location] x up to 4 floats
+constexpr int V8_CS = 4 * 16 * 4;                // column sums of a of the waves h = 1
+constexpr size_t kVlad8Lds = (size_t)VF_NST * VF_STAGE + 4 * VF_CF + V8_XL + V8_PN + V8_EXCH + V8_CS;
+constexpr int V8_AHEAD = 4;                      // A fragments in flight in the aggregation
+
+__device__ __forceinline__ void v8_wait_vm(int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+template <bool SAVE>
+__global__ __launch_bounds__(512) void vlad_fwd8_kernel(VladFwdArgs p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char vf_lds[];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int w = wid & 3, h = wid >> 2;
+  const int i = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x, sl = blockIdx.y, B = gridDim.x;
+  const int nsteps_img = (p.N + VF_STEP - 1) / VF_STEP;
+  const int st_lo = sl * p.steps_per_slice;
+  const int st_hi = st_lo + p.steps_per_slice < nsteps_img ? st_lo + p.steps_per_slice : nsteps_img;
+  const int nst = st_hi - st_lo;                           // >= 1 by the host's choice of S
+  const unsigned lds0 = nv_lds_byte_of(vf_lds);
+  const unsigned cf0 = lds0 + VF_NST * VF_STAGE + w * VF_CF;
+  unsigned char* xl = vf_lds + VF_NST * VF_STAGE + 4 * VF_CF;
+  float* pn = reinterpret_cast<float*>(xl + V8_XL);
+  float* exch = pn + V8_PN / 4;
+  float* csx = exch + V8_EXCH / 4;
+  const unsigned short* xb = p.x + (int64_t)b * p.N * D;
+  unsigned long long* stp =
+      (p.dbg & 16) && threadIdx.x == 0 ? p.stamps + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 : nullptr;
+#define VF_STAMP(k)                                         \
+  do {                                                      \
+    if (p.dbg & 16) {                                       \
+      __builtin_amdgcn_sched_barrier(0);                    \
+      if (stp) stp[k] = __builtin_amdgcn_s_memtime();       \
+      __builtin_amdgcn_sched_barrier(0);                    \
+    }                                                       \
+  } while (0)
+  VF_STAMP(0);
+  // (the finish kernel behind this one polls these words: they must be zero when it starts)
+  if (sl == 0 && threadIdx.x < 8) p.gran[b * 8 + threadIdx.x] = 0ull;
+
+  // ---- x stage by LDS-DMA: wave wid brings rows wid, wid + 8, .. of the step; lane l of row r
+  // fetches chunk l ^ (r & 15) into unit 64 r + l (rows past the end re-read the last row)
+  auto stage = [&](int step) {
+    const unsigned base = lds0 + (unsigned)((step - st_lo) % VF_NST) * VF_STAGE;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int r = wid + 8 * v;
+      int n = VF_STEP * step + r;
+      n = n < p.N ? n : p.N - 1;
+      nv_glds16(xb + (int64_t)n * D + ((lane ^ (r & 15)) << 3), base + r * 1024);
+    }
+  };
+  stage(st_lo);
+  // ---- the wave's slice of W^T: its 8 k-steps (channels 256 h + 32 s ..) x the planes
+  u32x4 wf[8][VF_NPL];
+  {
+    const u32x4* src = reinterpret_cast<const u32x4*>(p.wimg) + (int64_t)(w * 16 + 8 * h) * VF_NPL * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int pl = 0; pl < VF_NPL; ++pl) wf[s][pl] = src[(s * VF_NPL + pl) * 64];
+  }
+  if (nst > 1) stage(st_lo + 1);
+  VF_STAMP(1);
+
+  f32x4 accv[16];
+#pragma unroll
+  for (int ct = 0; ct < 16; ++ct) accv[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+
+  // Row fragment of (tile t, global k-step s' = 8 h + s): unit (16 t + i, 4 s' + g):
+  //   byte = 1024 (16 t + i) + 256 (s' >> 2) + 64 ((s' & 3) ^ (i >> 2)) + 16 (g ^ (i & 3))
+  unsigned rowoff[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) rowoff[k] = 1024u * i + 512u * h + 64u * (k ^ (i >> 2)) + 16u * (g ^ (i & 3));
+  float dsel[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) dsel[j] = (g == (i >> 2) && (i & 3) == j) ? 1.0f : 0.0f;
+  const int q = (lane >> 2) & 3, pp = lane & 3;
+  unsigned troff[2], cfoff[2];
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) {
+    const int row = 16 * (g >> 1) + 2 * (4 * (g & 1) + q) + hh;     // vf_pi(g, 4 hh + q)
+    const int R = row & 15;
+    troff[hh] = 1024u * row + 512u * h + 32u * (R >> 1) + 16u * ((pp >> 1) ^ (R & 1)) + 8u * (pp & 1);
+    cfoff[hh] = (unsigned)row * VF_CFLD + 8u * pp;
+  }
+
+#pragma unroll 1
+  for (int st = 0; st < nst; ++st) {
+    const int step = st_lo + st;
+    // This stage's DMA must have landed; younger in the wave's queue, allowed to stay in flight:
+    // the next stage's DMA (4) and the previous step's three stores (when saving).
+    v8_wait_vm((st + 1 < nst ? 4 : 0) + (st >= 1 && SAVE ? 3 : 0));
+    __builtin_amdgcn_s_barrier();         // landed for every wave; step - 1 is finished everywhere
+    if (st < 4) VF_STAMP(4 + 6 * st);
+    const unsigned sb = lds0 + (unsigned)(st % VF_NST) * VF_STAGE;
+
+    // ---- partial logits over the wave's 256 channels (swapped: lane = location, registers = 4
+    // consecutive clusters) + its share of the row norms
+    f32x4 accl[2], accn[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      accl[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      accn[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    u32x4 xf[4][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        xf[s][t] = vf_ldsr128(sb + rowoff[s & 3] + 256u * (s >> 2) + 16384u * t);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      if (s + 2 < 8) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          xf[(s + 2) & 3][t] =
+              vf_ldsr128(sb + rowoff[(s + 2) & 3] + 256u * ((s + 2) >> 2) + 16384u * t);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int pl = 0; pl < VF_NPL; ++pl) accl[t] = mfma16b(wf[s][pl], xf[s & 3][t], accl[t]);
+      }
+      if ((s & 3) == w) {                                   // (wave-uniform)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) accn[t] = mfma16b(xf[s & 3][t], xf[s & 3][t], accn[t]);
+      }
+    }
+    if (st < 4) VF_STAMP(5 + 6 * st);
+
+    // ---- exchange 1: the other tile's partial logits to the partner, norm partials to everybody
+    *reinterpret_cast<f32x4*>(xl + (wid * 64 + lane) * 16) = h ? accl[0] : accl[1];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      // diagonal of the tile's Gram: row 4 g + j == column i (dsel: 1 on that register, else 0)
+      float d = accn[t][0] * dsel[0] + accn[t][1] * dsel[1] + accn[t][2] * dsel[2] + accn[t][3] * dsel[3];
+      d = vf_gsum(d);
+      if (g == 0) pn[(t * 16 + i) * 8 + wid] = d;
+    }
+    __builtin_amdgcn_s_barrier();
+    if (st < 4) VF_STAMP(6 + 6 * st);
+
+    // ---- the wave's tile (t = h): logits, softmax over the 64 clusters (this wave: 16 of them)
+    const int n = VF_STEP * step + 16 * h + i;
+    const bool ok = n < p.N;
+    float ev[4], av[4], mloc, rnv;
+    {
+      const f32x4 own = h ? accl[1] : accl[0];
+      const f32x4 oth = *reinterpret_cast<const f32x4*>(xl + ((wid ^ 4) * 64 + lane) * 16);
+      const f32x4 lo4 = h ? oth : own, hi4 = h ? own : oth;   // channel halves in a fixed order
+      const f32x4 p0 = *reinterpret_cast<const f32x4*>(pn + (h * 16 + i) * 8);
+      const f32x4 p1 = *reinterpret_cast<const f32x4*>(pn + (h * 16 + i) * 8 + 4);
+      const float d = ((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p1[0] + p1[1]) + (p1[2] + p1[3]));
+      rnv = p.pre_l2 ? rsqrtf(fmaxf(d, 1e-12f)) : 1.0f;
+      float m = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        ev[j] = (lo4[j] + hi4[j]) * rnv;                    // the logit
+        m = fmaxf(m, ev[j]);
+      }
+      m = vf_gmax(m);
+      mloc = m;
+      if (SAVE)
+        *reinterpret_cast<f32x4*>(ok ? p.logit + ((int64_t)b * p.N + n) * K + 16 * w + 4 * g
+                                     : p.trash + 4 * lane) = f32x4{ev[0], ev[1], ev[2], ev[3]};
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        ev[j] = __expf(ev[j] - m);
+        sum += ev[j];
+      }
+      sum = vf_gsum(sum);
+      if (g == 0) *reinterpret_cast<f32x2*>(exch + ((h * 4 + w) * 16 + i) * 2) = f32x2{m, sum};
+    }
+    __builtin_amdgcn_s_barrier();
+    if (st < 4) VF_STAMP(7 + 6 * st);
+    {
+      f32x2 ms[4];
+#pragma unroll
+      for (int w2 = 0; w2 < 4; ++w2)
+        ms[w2] = *reinterpret_cast<const f32x2*>(exch + ((h * 4 + w2) * 16 + i) * 2);
+      const float M = fmaxf(fmaxf(ms[0][0], ms[1][0]), fmaxf(ms[2][0], ms[3][0]));
+      float tot = 0.f;
+#pragma unroll
+      for (int w2 = 0; w2 < 4; ++w2) tot += ms[w2][1] * __expf(ms[w2][0] - M);
+      const float sc = __fdividef(__expf(mloc - M), tot);
+      unsigned short hh[3][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        av[j] = ev[j] * sc;
+        const float a_ok = ok ? av[j] : 0.f;
+        cs[j] += a_ok;
+        split3_bf16(a_ok * rnv, hh[0][j], hh[1][j], hh[2][j]);
+      }
+      if (SAVE)
+        *reinterpret_cast<f32x4*>(ok ? p.assign + ((int64_t)b * p.N + n) * K + 16 * w + 4 * g
+                                     : p.trash + 4 * lane) = f32x4{av[0], av[1], av[2], av[3]};
+#pragma unroll
+      for (int pl = 0; pl < VF_NPL; ++pl) {
+        vf_ldsw64(cf0 + pl * VF_CFPL + (16 * h + i) * VF_CFLD + 8 * g,
+                  (unsigned)hh[pl][0] | ((unsigned)hh[pl][1] << 16),
+                  (unsigned)hh[pl][2] | ((unsigned)hh[pl][3] << 16));
+      }
+      if (SAVE) {   // rn: wave (w, h) writes locations 4 w .. 4 w + 3 of its tile (one store per wave)
+        const bool mine = g == 0 && (i >> 2) == w && ok;
+        *(mine ? p.rnorm + (int64_t)b * p.N + n : p.trash + 4 * lane) = rnv;
+      }
+    }
+    __builtin_amdgcn_s_barrier();          // the pair's coefficient rows are both written
+    if (st < 4) VF_STAMP(8 + 6 * st);
+    if (st + 2 < nst) stage(step + 2);     // into the stage of step - 1
+
+    // ---- aggregation: V[ch][cl] += sum_loc x[loc][ch] * (a rn)[loc][cl], channel tiles 16 h ..
+    u32x4 bfr[VF_NPL];
+#pragma unroll
+    for (int pl = 0; pl < VF_NPL; ++pl) {
+      const uint2 lo = vf_ldsr_tr(cf0 + pl * VF_CFPL + cfoff[0]);
+      const uint2 hi = vf_ldsr_tr(cf0 + pl * VF_CFPL + cfoff[1]);
+      bfr[pl] = u32x4{lo.x, lo.y, hi.x, hi.y};
+    }
+    // address of the transposed fragment of channel tile ct = 16 h + c: (stage + troff[hh]) ^ 32 (c & 7)
+    // + 32 (c & 8) (troff carries the 512 h): XOR touches address bits 5..7 only
+    const unsigned tb0 = sb + troff[0], tb1 = sb + troff[1];
+    u32x4 af[8];
+#pragma unroll
+    for (int c = 0; c < V8_AHEAD; ++c) {
+      const uint2 lo = vf_ldsr_tr((tb0 ^ (32u * (c & 7))) + 32u * (c & 8)),
+                  hi = vf_ldsr_tr((tb1 ^ (32u * (c & 7))) + 32u * (c & 8));
+      af[c] = u32x4{lo.x, lo.y, hi.x, hi.y};
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      if (c + V8_AHEAD < 16) {
+        const int cn = c + V8_AHEAD;
+        const uint2 lo = vf_ldsr_tr((tb0 ^ (32u * (cn & 7))) + 32u * (cn & 8)),
+                    hi = vf_ldsr_tr((tb1 ^ (32u * (cn & 7))) + 32u * (cn & 8));
+        af[cn & 7] = u32x4{lo.x, lo.y, hi.x, hi.y};
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int pl = 0; pl < VF_NPL; ++pl) accv[c] = mfma16b(af[c & 7], bfr[pl], accv[c]);
+    }
+    if (st < 4) VF_STAMP(9 + 6 * st);
+  }
+  VF_STAMP(28);
+
+  // ---- the slice's slab, in accumulator order (unit ((w * 32 + ct) * 64 + lane), ct = 16 h + c),
+  // and the column sums of a (the two tile halves of a cluster group combined through LDS)
+  f32x4* slab =
+      reinterpret_cast<f32x4*>(p.slab) + ((((int64_t)sl * B + b) * 4 + w) * 32 + 16 * h) * 64 + lane;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) slab[c * 64] = accv[c];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) cs[j] += __shfl_xor(cs[j], m, 64);
+  }
+  if (h == 1 && i == 0) *reinterpret_cast<f32x4*>(csx + (w * 4 + g) * 4) = f32x4{cs[0], cs[1], cs[2], cs[3]};
+  __builtin_amdgcn_s_barrier();
+  if (h == 0 && i == 0) {
+    const f32x4 o = *reinterpret_cast<const f32x4*>(csx + (w * 4 + g) * 4);
+    *reinterpret_cast<f32x4*>(p.colsum + ((int64_t)sl * B + b) * K + 16 * w + 4 * g) =
+        f32x4{cs[0] + o[0], cs[1] + o[1], cs[2] + o[2], cs[3] + o[3]};
+  }
+  if (p.dbg & 16) {
+    VF_STAMP(29);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    VF_STAMP(30);
+  }
+#undef VF_STAMP
+}
+
+// vlad_bwd8_kernel: the backward twin with eight waves (see vlad_bwd_kernel for the algebra):
+// wave (w, h) contracts x with the image's dU^T over its channel half, hands the other tile's
+// partial to its partner, runs the softmax backward of its 16 locations (partial sums over its 16
+// clusters exchanged across the four cluster groups) and aggregates its 16 channel tiles of dW.
+__global__ __launch_bounds__(512) void vlad_bwd8_kernel(VladBwdArgs p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char vf_lds[];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int w = wid & 3, h = wid >> 2;
+  const int i = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x, sl = blockIdx.y, B = gridDim.x;
+  const int nsteps_img = (p.N + VF_STEP - 1) / VF_STEP;
+  const int st_lo = sl * p.steps_per_slice;
+  const int st_hi = st_lo + p.steps_per_slice < nsteps_img ? st_lo + p.steps_per_slice : nsteps_img;
+  const int nst = st_hi - st_lo;
+  const unsigned lds0 = nv_lds_byte_of(vf_lds);
+  const unsigned cf0 = lds0 + VF_NST * VF_STAGE + w * VF_CF;
+  unsigned char* xl = vf_lds + VF_NST * VF_STAGE + 4 * VF_CF;
+  float* exch = reinterpret_cast<float*>(xl + V8_XL + V8_PN);     // [tile][cluster group][loc][4]
+  const unsigned short* xb = p.x + (int64_t)b * p.N * D;
+
+  auto stage = [&](int step) {
+    const unsigned base = lds0 + (unsigned)((step - st_lo) % VF_NST) * VF_STAGE;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int r = wid + 8 * v;
+      int n = VF_STEP * step + r;
+      n = n < p.N ? n : p.N - 1;
+      nv_glds16(xb + (int64_t)n * D + ((lane ^ (r & 15)) << 3), base + r * 1024);
+    }
+  };
+  stage(st_lo);
+  u32x4 wf[8][VF_NPL];
+  {
+    const u32x4* src = reinterpret_cast<const u32x4*>(p.duimg) +
+                       (((int64_t)b * 4 + w) * 16 + 8 * h) * VF_NPL * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+      for (int pl = 0; pl < VF_NPL; ++pl) wf[s][pl] = src[(s * VF_NPL + pl) * 64];
+  }
+  const f32x4 cd = *reinterpret_cast<const f32x4*>(p.cdu + b * K + 16 * w + 4 * g);
+  if (nst > 1) stage(st_lo + 1);
+
+  f32x4 accv[16];
+#pragma unroll
+  for (int ct = 0; ct < 16; ++ct) accv[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  unsigned rowoff[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) rowoff[k] = 1024u * i + 512u * h + 64u * (k ^ (i >> 2)) + 16u * (g ^ (i & 3));
+  const int q = (lane >> 2) & 3, pp = lane & 3;
+  unsigned troff[2], cfoff[2];
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) {
+    const int row = 16 * (g >> 1) + 2 * (4 * (g & 1) + q) + hh;
+    const int R = row & 15;
+    troff[hh] = 1024u * row + 512u * h + 32u * (R >> 1) + 16u * ((pp >> 1) ^ (R & 1)) + 8u * (pp & 1);
+    cfoff[hh] = (unsigned)row * VF_CFLD + 8u * pp;
+  }
+
+#pragma unroll 1
+  for (int st = 0; st < nst; ++st) {
+    const int step = st_lo + st;
+    // younger than this stage's DMA and allowed in flight: the next stage's DMA (4) and the
+    // previous step's two stores (its loads were waited for when they were used)
+    v8_wait_vm((st + 1 < nst ? 4 : 0) + (st >= 1 ? 2 : 0));
+    __builtin_amdgcn_s_barrier();
+    const unsigned sb = lds0 + (unsigned)(st % VF_NST) * VF_STAGE;
+
+    // the saved forward values of the wave's tile, in flight under the matrix work
+    const int n = VF_STEP * step + 16 * h + i;
+    const bool ok = n < p.N;
+    const int64_t row = (int64_t)b * p.N + (ok ? n : p.N - 1);
+    const f32x4 a4 = *reinterpret_cast<const f32x4*>(p.a + row * K + 16 * w + 4 * g);
+    const f32x4 l4 = *reinterpret_cast<const f32x4*>(p.lg + row * K + 16 * w + 4 * g);
+    const float rn2 = p.rn[row];
+
+    f32x4 accl[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) accl[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x4 xf[4][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        xf[s][t] = vf_ldsr128(sb + rowoff[s & 3] + 256u * (s >> 2) + 16384u * t);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      if (s + 2 < 8) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          xf[(s + 2) & 3][t] =
+              vf_ldsr128(sb + rowoff[(s + 2) & 3] + 256u * ((s + 2) >> 2) + 16384u * t);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int pl = 0; pl < VF_NPL; ++pl) accl[t] = mfma16b(wf[s][pl], xf[s & 3][t], accl[t]);
+    }
+    *reinterpret_cast<f32x4*>(xl + (wid * 64 + lane) * 16) = h ? accl[0] : accl[1];
+    __builtin_amdgcn_s_barrier();
+
+    float tv[4], dav[4];
+    {
+      const f32x4 own = h ? accl[1] : accl[0];
+      const f32x4 oth = *reinterpret_cast<const f32x4*>(xl + ((wid ^ 4) * 64 + lane) * 16);
+      const f32x4 lo4 = h ? oth : own, hi4 = h ? own : oth;
+      float p1 = 0.f, p2 = 0.f, p3 = 0.f, p4 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        tv[j] = (lo4[j] + hi4[j]) * rn2;                    // xhat . dU
+        dav[j] = tv[j] + cd[j];
+        const float ad = a4[j] * dav[j];
+        p1 += ad;
+        p2 = fmaf(a4[j], tv[j], p2);
+        p3 = fmaf(ad, l4[j], p3);
+        p4 = fmaf(a4[j], l4[j], p4);
+      }
+      p1 = vf_gsum(p1);
+      p2 = vf_gsum(p2);
+      p3 = vf_gsum(p3);
+      p4 = vf_gsum(p4);
+      if (g == 0) *reinterpret_cast<f32x4*>(exch + ((h * 4 + w) * 16 + i) * 4) = f32x4{p1, p2, p3, p4};
+    }
+    __builtin_amdgcn_s_barrier();
+    {
+      f32x4 ps = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int w2 = 0; w2 < 4; ++w2) ps += *reinterpret_cast<const f32x4*>(exch + ((h * 4 + w2) * 16 + i) * 4);
+      const float dot = ps[0];
+      const float rd2 = ps[1] + ps[2] - dot * ps[3];
+      float dsv[4];
+      unsigned short hh[3][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        dsv[j] = a4[j] * (dav[j] - dot);
+        split3_bf16(ok ? dsv[j] * rn2 : 0.f, hh[0][j], hh[1][j], hh[2][j]);
+      }
+      *reinterpret_cast<f32x4*>(ok ? p.ds + ((int64_t)b * p.N + n) * K + 16 * w + 4 * g
+                                   : p.trash + 4 * lane) = f32x4{dsv[0], dsv[1], dsv[2], dsv[3]};
+#pragma unroll
+      for (int pl = 0; pl < VF_NPL; ++pl)
+        vf_ldsw64(cf0 + pl * VF_CFPL + (16 * h + i) * VF_CFLD + 8 * g,
+                  (unsigned)hh[pl][0] | ((unsigned)hh[pl][1] << 16),
+                  (unsigned)hh[pl][2] | ((unsigned)hh[pl][3] << 16));
+      {   // rowdot: wave (w, h) writes locations 4 w .. 4 w + 3 of its tile
+        const bool mine = g == 0 && (i >> 2) == w && ok;
+        *(mine ? p.rowdot + (int64_t)b * p.N + n : p.trash + 4 * lane) = rd2;
+      }
+    }
+    __builtin_amdgcn_s_barrier();
+    if (st + 2 < nst) stage(step + 2);
+
+    u32x4 bfr[VF_NPL];
+#pragma unroll
+    for (int pl = 0; pl < VF_NPL; ++pl) {
+      const uint2 lo = vf_ldsr_tr(cf0 + pl * VF_CFPL + cfoff[0]);
+      const uint2 hi = vf_ldsr_tr(cf0 + pl * VF_CFPL + cfoff[1]);
+      bfr[pl] = u32x4{lo.x, lo.y, hi.x, hi.y};
+    }
+    const unsigned tb0 = sb + troff[0], tb1 = sb + troff[1];
+    u32x4 af[8];
+#pragma unroll
+    for (int c = 0; c < V8_AHEAD; ++c) {
+      const uint2 lo = vf_ldsr_tr((tb0 ^ (32u * (c & 7))) + 32u * (c & 8)),
+                  hi = vf_ldsr_tr((tb1 ^ (32u * (c & 7))) + 32u * (c & 8));
+      af[c] = u32x4{lo.x, lo.y, hi.x, hi.y};
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      if (c + V8_AHEAD < 16) {
+        const int cn = c + V8_AHEAD;
+        const uint2 lo = vf_ldsr_tr((tb0 ^ (32u * (cn & 7))) + 32u * (cn & 8)),
+                    hi = vf_ldsr_tr((tb1 ^ (32u * (cn & 7))) + 32u * (cn & 8));
+        af[cn & 7] = u32x4{lo.x, lo.y, hi.x, hi.y};
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int pl = 0; pl < VF_NPL; ++pl) accv[c] = mfma16b(af[c & 7], bfr[pl], accv[c]);
+    }
+  }
+  f32x4* slab =
+      reinterpret_cast<f32x4*>(p.slab) + ((((int64_t)sl * B + b) * 4 + w) * 32 + 16 * h) * 64 + lane;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) slab[c * 64] = accv[c];
+}
+
 // grad_w[d,k] = sum over all (slice, image) slabs, in two levels so that every CU reads its share
 // of the 31 MB: vlad_wgrad_partial_kernel, grid (32 channel tiles, VW_GROUPS), sums one group's
 // slabs (VF_MAXS loads in flight) into partial[group][...]; vlad_wgrad_finish_kernel, grid 32,
@@ -1247,7 +1732,7 @@ __global__ __launch_bounds__(256) void vlad_wgrad_finish_kernel(const float* __r
 #pragma unroll
     for (int bb = 0; bb < 8; ++bb) {
       const int b = b0 + bb < B ? b0 + bb : B - 1;
-      as8[bb] = b0 + bb < B ? save_vlad[((int64_t)b * (D + 1) + D) * K + k] : 0.f;
+      as8[bb] = b0 + bb < B ? save_vlad[((int64_t)b * VROWS + D) * K + k] : 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) dv[bb][j] = du[((int64_t)b * D + 16 * ct + 4 * g + j) * K + k];
     }
@@ -1261,6 +1746,356 @@ __global__ __launch_bounds__(256) void vlad_wgrad_finish_kernel(const float* __r
     const int d = 16 * ct + 4 * g + j;
     grad_w[d * K + k] = u[j];
     grad_c[d * K + k] = gc[j];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Sibling exchange inside a launch (round 4).  The forward finish and the backward prologue each
+// need, per image, ONE or TWO sums over all 64 clusters (the global norm; <grad_out, Vn>) between
+// two passes over the image's [512][64] block — which used to be a kernel boundary each
+// (finish_sum | finish_norm, bwd_dots | bwd_du: four launches at the 4-6 us floor of a dependent
+// do-almost-nothing kernel).  Both are now ONE kernel of 8 workgroups per image, workgroup c owning
+// the clusters 8 c .. 8 c + 7 of ALL 512 channels, so that every per-cluster quantity is local and
+// only the workgroup's partial of the global scalars travels: an 8-byte {tag = 1, value} granule
+// written by ONE agent-scope (sc1, write-through) store — the data is the flag, no fence on either
+// side (MI355X_MICROARCH.md, hand-off price list, row handoff-1to1; cdna_hip_programming.md
+// Guideline 16 R2).  Wave 0 of each workgroup re-reads the image's granules until all tags are set.
+// The spin is BOUNDED: a workgroup whose siblings are not resident in time computes their scalars
+// itself with the same routine (same instruction sequence, same bits) — correctness never depends on
+// co-residency or dispatch order, only speed does.  Granules are zeroed by the kernel in front
+// (forward: vlad_fwd_kernel, same call) or kept zero between calls (backward: row 513 of save_vlad,
+// zeroed by the forward pass and re-zeroed by the last workgroup of the prologue to leave).
+typedef unsigned long long gran_t;
+typedef __attribute__((address_space(1))) gran_t* gran_gptr;
+typedef __attribute__((address_space(1))) unsigned* u32_gptr;
+__device__ __forceinline__ void gran_put(gran_t* g, float v) {
+  __hip_atomic_store((gran_gptr)g, (1ull << 32) | (gran_t)__float_as_uint(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+// wave-wide (call it from ONE wave): lanes 0 .. n - 1 poll granule `lane` until every tag is set;
+// v = the lane's value.  false after `limit` polls.
+__device__ __forceinline__ bool gran_sweep(gran_t* g, int n, int limit, float& v) {
+  const int lane = threadIdx.x & 63;
+  for (int spins = 0;; ++spins) {
+    const gran_t x = lane < n ? __hip_atomic_load((gran_gptr)g + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                              : (1ull << 32);
+    v = __uint_as_float((unsigned)x);
+    if (__all((unsigned)(x >> 32) == 1u)) return true;
+    if (spins >= limit) return false;
+    __builtin_amdgcn_s_sleep(8);
+  }
+}
+constexpr int kSpinLimit = 20000;          // x (poll + s_sleep 8) ~ several ms: never reached in practice
+// scl_debug_set_variant(921): no patience at all — every workgroup that does not find its siblings'
+// granules at the first poll takes the self-computing path (tests: same bits either way)
+inline int spin_limit() { return scl_debug_variant == 921 ? 0 : kSpinLimit; }
+
+// vlad_finish_kernel: everything behind the fused forward kernel in ONE launch — U = sum of the
+// image's slice slabs + C * asum, the intra-normalisation per cluster, the global normalisation,
+// out = U q g, and the saved pre-norm VLAD (rows 0..511 U, 512 asum, 513 zeroed sync words of the
+// backward prologue).  grid (8 cluster groups, B), block 256: thread (ip = cluster in the group,
+// g, cs) sums the 16-byte slab units of channel tiles ct = cs + 8 r, r = 0..3 (unit ((w * 32 + ct)
+// * 64 + 16 g + i) = U[16 ct + 4 g + 0..3][16 w + i]: a workgroup reads one 128-byte half of every
+// 256-byte row), keeps its 16 values of U in registers across the exchange and writes both outputs
+// from them: U is neither re-read nor does any value make a round trip through memory.
+struct VladFinishArgs {
+  const float* slab;      // [S][B][8192 units][4]
+  const float* colsum;    // [S][B][64]
+  const float* centers;   // [512][64]
+  int S, B;
+  float* vlad;            // [B][VROWS][64]
+  float* out;             // [B][32768]
+  gran_t* gran;           // [B][8], zero on entry
+  int spin_limit;
+};
+
+constexpr int VFIN_NB = 10;                // slices in flight per thread (x 4 units): the kernel is
+                                           // one round trip long, everything it needs must be requested at once
+__global__ __launch_bounds__(256) void vlad_finish_kernel(VladFinishArgs p) {
+  __shared__ float fin_lds[4 * 8 + 8 + 8];   // [wave][ip] partial column sums | siblings' values | flag
+  float* red = fin_lds;
+  float* vals = fin_lds + 32;
+  int* okf = reinterpret_cast<int*>(fin_lds + 40);
+  const int c = blockIdx.x, b = blockIdx.y;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int ip = t & 7, g = (t >> 3) & 3, cs = t >> 5;
+
+  // the cluster group's pass over the slabs: u = its 16 values of U, asum, q of cluster 8 c2 + ip;
+  // returns the group's share of sum_k q_k^2 col_k (the same value in every thread)
+  auto group = [&](int c2, f32x4 (&u)[4], float& asum_out, float& q_out) -> float {
+    const int w = c2 >> 1, k = 8 * c2 + ip;
+    const f32x4* src = reinterpret_cast<const f32x4*>(p.slab) + (int64_t)b * 8192 + (w * 32 + cs) * 64 + 16 * g +
+                       8 * (c2 & 1) + ip;
+    const int64_t sstride = (int64_t)p.B * 8192;               // units between slices
+    f32x4 acc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float asum = 0.f;
+    for (int s0 = 0; s0 < p.S; s0 += VFIN_NB) {
+      f32x4 v[VFIN_NB][4];
+      float a[VFIN_NB];
+#pragma unroll
+      for (int s = 0; s < VFIN_NB; ++s) {                      // branch-free: past the end re-reads
+        const int sc = s0 + s < p.S ? s0 + s : p.S - 1;        // the last slice and drops it
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[s][r] = src[sc * sstride + r * 512];
+        a[s] = p.colsum[((int64_t)sc * p.B + b) * K + k];
+      }
+#pragma unroll
+      for (int s = 0; s < VFIN_NB; ++s) {                      // fixed order: bitwise reproducible
+        const float keep = s0 + s < p.S ? 1.0f : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] += v[s][r] * keep;
+        asum += a[s] * keep;
+      }
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int d = 16 * (cs + 8 * r) + 4 * g + j;
+        u[r][j] = acc[r][j] + p.centers[d * K + k] * asum;
+        ss = fmaf(u[r][j], u[r][j], ss);
+      }
+    // over the 32 threads that share ip: lane bits 3..5, then the four waves
+    ss += __shfl_xor(ss, 8, 64);
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    __syncthreads();
+    if (lane < 8) red[wv * 8 + ip] = ss;
+    __syncthreads();
+    const float col = (red[ip] + red[8 + ip]) + (red[16 + ip] + red[24 + ip]);
+    // matconvnetNormalize: x / sqrt(sum x^2 + 1e-12), epsilon inside the sqrt
+    const float q = 1.0f / sqrtf(col + 1e-12f);
+    float tq = q * q * col;
+    tq += __shfl_xor(tq, 1, 64);
+    tq += __shfl_xor(tq, 2, 64);
+    tq += __shfl_xor(tq, 4, 64);
+    asum_out = asum;
+    q_out = q;
+    return tq;
+  };
+
+  f32x4 u[4];
+  float asum, q;
+  const float mine = group(c, u, asum, q);
+  if (t == 0) gran_put(p.gran + b * 8 + c, mine);
+  if (wv == 0) {
+    float v;
+    const bool ok = gran_sweep(p.gran + b * 8, 8, p.spin_limit, v);
+    if (lane < 8) vals[lane] = v;
+    if (lane == 0) *okf = ok ? 1 : 0;
+  }
+  __syncthreads();
+  if (!*okf) {                                                 // (uniform) siblings not seen in time
+    for (int c2 = 0; c2 < 8; ++c2) {
+      f32x4 u2[4];
+      float a2, q2;
+      const float tv = group(c2, u2, a2, q2);
+      if (t == 0) vals[c2] = tv;
+    }
+    __syncthreads();
+  }
+  float tot = 0.f;
+#pragma unroll
+  for (int c2 = 0; c2 < 8; ++c2) tot += vals[c2];
+  const float gn = 1.0f / sqrtf(tot + 1e-12f);
+  const int k = 8 * c + ip;
+  float* vrow = p.vlad + (int64_t)b * VROWS * K;
+  float* orow = p.out + (int64_t)b * D * K;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int d = 16 * (cs + 8 * r) + 4 * g + j;
+      vrow[d * K + k] = u[r][j];
+      orow[d * K + k] = u[r][j] * q * gn;
+    }
+  if (cs == 0 && g == 0) vrow[D * K + k] = asum;
+  if (c == 0 && t < K) reinterpret_cast<unsigned*>(vrow)[(D + 1) * K + t] = 0u;   // the backward's sync words
+}
+
+// vlad_bwd_prologue_kernel: the gradient through both normalisations (bwd_dots_kernel's comment
+// has the closed form) in ONE launch, 8 workgroups per image, workgroup c = clusters 8 c .. + 7 of
+// all 512 channels: A_k, col_k, Bc_k, Dc_k are local; the two sums over all clusters, tot = sum_k
+// q_k^2 col_k and S1 = sum_k q_k A_k, travel as granules (above).  Thread (ip, r): cluster 8 c + ip,
+// 8-channel chunks r and r + 32; its 16 values of U and grad_out stay in registers for dU.  Outputs as
+// bwd_du_kernel: dU float32 [d][k] (+ transposed for the float32-MFMA kernels), c.dU, and for bf16
+// feature maps the two register images of the fused kernels (duimg straight from the registers —
+// 8 consecutive channels of a cluster are one thread's — dximg through a [512][8] LDS tile).
+struct VladProArgs {
+  float* save_vlad;          // [B][VROWS][64]; row 513: 16 granules + the leave counter (word 32)
+  const float* grad_out;     // [B][32768]
+  const float* centers;
+  float* du;                 // [B][512][64]
+  float* dut;                // [B][64][512] or NULL
+  unsigned short* duimg;     // or NULL
+  unsigned short* dximg;
+  float* cdu;                // [B][64]
+  int spin_limit;
+};
+
+__global__ __launch_bounds__(256) void vlad_bwd_prologue_kernel(VladProArgs p) {
+  __shared__ __attribute__((aligned(16))) float pro_lds[512 * 8 + 4 * 4 * 8 + 16 + 8];
+  float* tile = pro_lds;                       // [512 ch][8 clusters]
+  float* red = pro_lds + 512 * 8;              // [wave][dot][ip]
+  float* vals = red + 4 * 4 * 8;               // the image's 16 granule values
+  int* okf = reinterpret_cast<int*>(vals + 16);
+  const int c = blockIdx.x, b = blockIdx.y;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int ip = t & 7, r = t >> 3;
+  const float* urow = p.save_vlad + (int64_t)b * VROWS * K;
+  const float* grow = p.grad_out + (int64_t)b * D * K;
+  gran_t* gran = reinterpret_cast<gran_t*>(p.save_vlad + ((int64_t)b * VROWS + D + 1) * K);
+  unsigned* leave = reinterpret_cast<unsigned*>(p.save_vlad + ((int64_t)b * VROWS + D + 1) * K) + 32;
+
+  // the four column dots of cluster 8 c2 + ip; (tot, S1) shares of the group (same in every thread)
+  auto group = [&](int c2, float (&uu)[16], float (&gg)[16], float (&dots)[4], float& tq, float& sq) {
+    const int k = 8 * c2 + ip;
+    float cc[16];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int d = 8 * (r + 32 * h) + e;
+        uu[8 * h + e] = urow[d * K + k];
+        gg[8 * h + e] = grow[d * K + k];
+        cc[8 * h + e] = p.centers[d * K + k];
+      }
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      s[0] = fmaf(gg[e], uu[e], s[0]);
+      s[1] = fmaf(uu[e], uu[e], s[1]);
+      s[2] = fmaf(gg[e], cc[e], s[2]);
+      s[3] = fmaf(uu[e], cc[e], s[3]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                             // threads sharing ip: lane bits 3..5
+      s[j] += __shfl_xor(s[j], 8, 64);
+      s[j] += __shfl_xor(s[j], 16, 64);
+      s[j] += __shfl_xor(s[j], 32, 64);
+    }
+    __syncthreads();
+    if (lane < 8) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[(wv * 4 + j) * 8 + ip] = s[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      dots[j] = (red[(0 * 4 + j) * 8 + ip] + red[(1 * 4 + j) * 8 + ip]) +
+                (red[(2 * 4 + j) * 8 + ip] + red[(3 * 4 + j) * 8 + ip]);
+    const float qq = 1.0f / sqrtf(dots[1] + 1e-12f);
+    tq = qq * qq * dots[1];
+    sq = qq * dots[0];
+#pragma unroll
+    for (int m = 1; m < 8; m <<= 1) {
+      tq += __shfl_xor(tq, m, 64);
+      sq += __shfl_xor(sq, m, 64);
+    }
+  };
+
+  float uu[16], gg[16], dots[4], tq, sq;
+  group(c, uu, gg, dots, tq, sq);
+  if (t == 0) {
+    gran_put(gran + 2 * c, tq);
+    gran_put(gran + 2 * c + 1, sq);
+  }
+  if (wv == 0) {
+    float v;
+    const bool ok = gran_sweep(gran, 16, p.spin_limit, v);
+    if (lane < 16) vals[lane] = v;
+    if (lane == 0) *okf = ok ? 1 : 0;
+  }
+  __syncthreads();
+  if (!*okf) {                                                 // (uniform) compute the siblings' shares here
+    for (int c2 = 0; c2 < 8; ++c2) {
+      float u2[16], g2[16], d2[4], t2, s2;
+      group(c2, u2, g2, d2, t2, s2);
+      if (t == 0) {
+        vals[2 * c2] = t2;
+        vals[2 * c2 + 1] = s2;
+      }
+    }
+    __syncthreads();
+  }
+  float tot = 0.f, s1 = 0.f;
+#pragma unroll
+  for (int c2 = 0; c2 < 8; ++c2) {
+    tot += vals[2 * c2];
+    s1 += vals[2 * c2 + 1];
+  }
+  const int k = 8 * c + ip;
+  const float ak = dots[0], col = dots[1], bk = dots[2], dk = dots[3];
+  const float q = 1.0f / sqrtf(col + 1e-12f);
+  const float gn = 1.0f / sqrtf(tot + 1e-12f);
+  const float rr = gn * (q * ak - gn * gn * s1 * q * q * col);
+  const float cu = q * q * (gn * gn * gn * s1 + rr);   // coefficient of U
+  const float cg = q * gn;                             // coefficient of grad_out
+  float vv[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) vv[e] = cg * gg[e] - cu * uu[e];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) p.du[((int64_t)b * D + 8 * (r + 32 * h) + e) * K + k] = vv[8 * h + e];
+  if (r == 0) p.cdu[b * K + k] = cg * bk - cu * dk;
+  if (p.dut) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float* trow = p.dut + ((int64_t)b * K + k) * D + 8 * (r + 32 * h);
+      *reinterpret_cast<f32x4*>(trow) = f32x4{vv[8 * h], vv[8 * h + 1], vv[8 * h + 2], vv[8 * h + 3]};
+      *reinterpret_cast<f32x4*>(trow + 4) = f32x4{vv[8 * h + 4], vv[8 * h + 5], vv[8 * h + 6], vv[8 * h + 7]};
+    }
+  }
+  if (p.duimg) {                                               // (uniform over the launch)
+    // channels 8 ch8 + e of cluster k: unit ((w * 16 + s) * NPL + plane) * 64 + 16 gq + i with
+    // w = k >> 4, i = k & 15, s = ch8 >> 2, gq = ch8 & 3
+    uint4* img = reinterpret_cast<uint4*>(p.duimg + (int64_t)b * VF_NPL * D * K);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int ch8 = r + 32 * h;
+      unsigned short hh[3][8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) split3_bf16(vv[8 * h + e], hh[0][e], hh[1][e], hh[2][e]);
+#pragma unroll
+      for (int pl = 0; pl < VF_NPL; ++pl)
+        img[(((k >> 4) * 16 + (ch8 >> 2)) * VF_NPL + pl) * 64 + 16 * (ch8 & 3) + (k & 15)] =
+            make_uint4((unsigned)hh[pl][0] | ((unsigned)hh[pl][1] << 16), (unsigned)hh[pl][2] | ((unsigned)hh[pl][3] << 16),
+                       (unsigned)hh[pl][4] | ((unsigned)hh[pl][5] << 16), (unsigned)hh[pl][6] | ((unsigned)hh[pl][7] << 16));
+    }
+    // the other orientation: 8 consecutive clusters (= this workgroup's) of one channel
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) tile[(8 * (r + 32 * h) + e) * 8 + ip] = vv[8 * h + e];
+    __syncthreads();
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+      const int ch = t + 256 * rep;
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(tile + ch * 8), v1 = *reinterpret_cast<const f32x4*>(tile + ch * 8 + 4);
+      u32x4 hi, lo;
+      split2x8(v0, v1, hi, lo);
+      // unit (((wv2 * 8 + nt) * 2 + s) * 2 + plane) * 64 + 16 gq + i: channel 128 wv2 + 16 nt + i,
+      // clusters 32 s + 8 gq .. + 7 = 8 c ..
+      u32x4* img = reinterpret_cast<u32x4*>(p.dximg) + (int64_t)b * (4 * 8 * 2 * 2 * 64) +
+                   ((((ch >> 4) * 2 + (c >> 2)) * 2) * 64) + 16 * (c & 3) + (ch & 15);
+      img[0] = hi;
+      img[64] = lo;
+    }
+  }
+  // last workgroup of the image to get here: every sibling has read the granules — zero them for the
+  // next backward pass over the same saved tensors
+  if (t == 0) {
+    const unsigned old = __hip_atomic_fetch_add((u32_gptr)leave, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == 7u) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        __hip_atomic_store((gran_gptr)gran + j, (gran_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store((u32_gptr)leave, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -1289,10 +2124,10 @@ __global__ __launch_bounds__(256) void finish_sum_kernel(const float* __restrict
 #pragma unroll
     for (int s = 0; s < NSPLIT; ++s) p += part[(((int64_t)b * NSPLIT + s) * D + d) * K + k];
     const float u = p + centers[d * K + k] * asum;
-    vlad[((int64_t)b * (D + 1) + d) * K + k] = u;
+    vlad[((int64_t)b * VROWS + d) * K + k] = u;
     ss = fmaf(u, u, ss);
   }
-  if (blk == 0 && dq == 0) vlad[((int64_t)b * (D + 1) + D) * K + k] = asum;
+  if (blk == 0 && dq == 0) vlad[((int64_t)b * VROWS + D) * K + k] = asum;
   colbuf[dq * 64 + k] = ss;
   __syncthreads();
   if (dq == 0)
@@ -1300,10 +2135,12 @@ __global__ __launch_bounds__(256) void finish_sum_kernel(const float* __restrict
         (colbuf[k] + colbuf[64 + k]) + (colbuf[128 + k] + colbuf[192 + k]);
 }
 
-__global__ __launch_bounds__(256) void finish_norm_kernel(const float* __restrict__ vlad,
+__global__ __launch_bounds__(256) void finish_norm_kernel(float* vlad,
                                                           const float* __restrict__ colsq_part,
                                                           int nparts, float* __restrict__ out) {
   const int blk = blockIdx.x, b = blockIdx.y, k = threadIdx.x & 63, dq = threadIdx.x >> 6;
+  // row 513 of the saved VLAD: sync words of the backward prologue, zero between calls
+  if (blk == 0 && dq == 0) reinterpret_cast<unsigned*>(vlad)[((int64_t)b * VROWS + D + 1) * K + k] = 0u;
   float cp[32];
 #pragma unroll
   for (int j = 0; j < 32; ++j) cp[j] = j < nparts ? colsq_part[((int64_t)b * nparts + j) * K + k] : 0.f;
@@ -1318,7 +2155,7 @@ __global__ __launch_bounds__(256) void finish_norm_kernel(const float* __restric
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int d = blk * 64 + dq * 16 + i;
-    out[(int64_t)b * D * K + d * K + k] = vlad[((int64_t)b * (D + 1) + d) * K + k] * q * g;
+    out[(int64_t)b * D * K + d * K + k] = vlad[((int64_t)b * VROWS + d) * K + k] * q * g;
   }
 }
 
@@ -1343,7 +2180,7 @@ __global__ __launch_bounds__(256) void bwd_dots_kernel(const float* __restrict__
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int d = blk * 64 + dq * 16 + i;
-    const float u = save_vlad[((int64_t)b * (D + 1) + d) * K + k];
+    const float u = save_vlad[((int64_t)b * VROWS + d) * K + k];
     const float go = grad_out[(int64_t)b * D * K + d * K + k];
     const float c = centers[d * K + k];
     sa = fmaf(go, u, sa);
@@ -1405,7 +2242,7 @@ __global__ __launch_bounds__(256) void bwd_du_kernel(const float* __restrict__ s
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int d = blk * 64 + dq * 16 + i;
-    const float u = save_vlad[((int64_t)b * (D + 1) + d) * K + k];
+    const float u = save_vlad[((int64_t)b * VROWS + d) * K + k];
     const float go = grad_out[(int64_t)b * D * K + d * K + k];
     vals[i] = cg * go - cu * u;
     du[((int64_t)b * D + d) * K + k] = vals[i];
@@ -1673,6 +2510,7 @@ constexpr int DXV_ABUF = 4 * 2 * 64 * 16;                 // bytes per fragment 
 constexpr int DXV_SLD = 128 * 4 + 16;                     // bytes per scratch row (128 f32 + pad)
 constexpr int DXV_SCR = 16 * DXV_SLD;                     // per wave (8,448 B)
 constexpr size_t kVladDxLds = 2 * (size_t)DXV_ABUF + 4 * (size_t)DXV_SCR;   // 50,176 B
+constexpr int DXV_TAIL_NB = 36;                           // slab loads in flight per thread in the tail
 
 struct VladDxArgs {
   const unsigned short* x;      // [B][N][512] bf16
@@ -1687,6 +2525,14 @@ struct VladDxArgs {
   int dbg;                      // scl_debug_set_variant(917): clock stamps (scripts/vlad_stamps.py)
   unsigned long long* stamps;
   unsigned short* trash;        // 64 x 16 bytes for the stores of rows past the end
+  // tail (wslab != NULL): this workgroup's share of the two parameter gradients
+  const float* wslab;           // [nslab][8192 units][4]: vlad_bwd_kernel's dW slabs (complete: it
+  int nslab;                    //   ran in front of this kernel)
+  const float* du;              // [B][512][64]
+  const float* save_vlad;       // [B][VROWS][64]: row 512 = asum
+  int B;
+  float* grad_w;                // [512][64]
+  float* grad_c;                // [512][64]
 };
 
 __global__ __launch_bounds__(256, 1) void vlad_dx_kernel(VladDxArgs p) {
@@ -1965,6 +2811,76 @@ __global__ __launch_bounds__(256, 1) void vlad_dx_kernel(VladDxArgs p) {
     DX_STAMP(14);
   }
 #undef DX_STAMP
+
+  // ---- tail: the two parameter gradients, spread over the launch.  vlad_bwd_kernel (in front of
+  // this kernel) left one dW slab per (slice, image); grad_w is their sum, grad_c[d,k] = sum_b
+  // dU[b,d,k] asum[b,k].  They were two more launches (partial sums over 8 slab groups, then a
+  // 32-workgroup finish): 10 us at the floor of a dependent kernel for 31 MB of reads.  Here every
+  // workgroup sums a contiguous run of 16-byte units over ALL slabs (threads = units x slab
+  // groups, groups combined through LDS in a fixed order: bitwise reproducible for a given grid).
+  if (p.wslab) {
+    __syncthreads();                                         // the scratch is free
+    const int nwg = gridDim.x * gridDim.y, wg = blockIdx.y * gridDim.x + blockIdx.x;
+    const int tid = threadIdx.x;
+    {
+      const int upw = (8192 + nwg - 1) / nwg;                // units per workgroup
+      const int u_lo = wg * upw, u_hi = u_lo + upw < 8192 ? u_lo + upw : 8192;
+      const int chunk = upw < 256 ? upw : 256;               // units per pass
+      int G = 256 / chunk;                                   // slab groups
+      G = G > 8 ? 8 : G;
+      f32x4* part = reinterpret_cast<f32x4*>(dxv_lds);       // [G][chunk] (<= 256 x 16 B)
+      const int ul = tid % chunk, grp = tid / chunk;
+      for (int u0 = u_lo; u0 < u_hi; u0 += chunk) {
+        const int uidx = u0 + ul;
+        const bool act = grp < G && uidx < u_hi;
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (act) {
+          const f32x4* src = reinterpret_cast<const f32x4*>(p.wslab) + uidx;
+          for (int s0 = grp; s0 < p.nslab; s0 += DXV_TAIL_NB * G) {   // (one round at 24 x 1200: the
+            f32x4 v[DXV_TAIL_NB];                                     //  tail is a round trip long)
+#pragma unroll
+            for (int j = 0; j < DXV_TAIL_NB; ++j) {          // branch-free: past the end re-reads
+              const int sidx = s0 + j * G < p.nslab ? s0 + j * G : p.nslab - 1;
+              v[j] = src[(int64_t)sidx * 8192];
+            }
+#pragma unroll
+            for (int j = 0; j < DXV_TAIL_NB; ++j) acc += v[j] * (s0 + j * G < p.nslab ? 1.0f : 0.0f);
+          }
+          if (grp > 0) part[grp * chunk + ul] = acc;
+        }
+        __syncthreads();
+        if (act && grp == 0) {
+          for (int q2 = 1; q2 < G; ++q2) acc += part[q2 * chunk + ul];
+          // unit ((w * 32 + ct) * 64 + 16 g + i) = dW[16 ct + 4 g + 0..3][16 w + i]
+          const int ww = uidx >> 11, ct = (uidx >> 6) & 31, l2 = uidx & 63;
+          const int kk = 16 * ww + (l2 & 15), d0 = 16 * ct + 4 * (l2 >> 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) p.grad_w[(d0 + j) * K + kk] = acc[j];
+        }
+        __syncthreads();
+      }
+    }
+    {
+      const int epw = (D * K + nwg - 1) / nwg;               // elements of grad_c per workgroup
+      const int e_lo = wg * epw, e_hi = e_lo + epw < D * K ? e_lo + epw : D * K;
+      for (int e = e_lo + tid; e < e_hi; e += 256) {
+        const int kk = e & (K - 1);
+        float gc = 0.f;
+        for (int b0 = 0; b0 < p.B; b0 += 8) {
+          float dv[8], as8[8];
+#pragma unroll
+          for (int bb = 0; bb < 8; ++bb) {
+            const int b2 = b0 + bb < p.B ? b0 + bb : p.B - 1;
+            dv[bb] = p.du[(int64_t)b2 * D * K + e];
+            as8[bb] = b0 + bb < p.B ? p.save_vlad[((int64_t)b2 * VROWS + D) * K + kk] : 0.f;
+          }
+#pragma unroll
+          for (int bb = 0; bb < 8; ++bb) gc = fmaf(dv[bb], as8[bb], gc);
+        }
+        p.grad_c[e] = gc;
+      }
+    }
+  }
 }
 
 // grad_w[d,k] = sum_b sum_s slab[b][s][d,k];  grad_c[d,k] = sum_b dU[b,d,k] * asum[b,k].
@@ -1984,7 +2900,7 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restri
   for (int b = q; b < B; b += 4) {
 #pragma unroll
     for (int s = 0; s < NSPLIT; ++s) gw += wpart[((int64_t)b * NSPLIT + s) * D * K + idx];
-    gc = fmaf(du[(int64_t)b * D * K + idx], save_vlad[((int64_t)b * (D + 1) + D) * K + k], gc);
+    gc = fmaf(du[(int64_t)b * D * K + idx], save_vlad[((int64_t)b * VROWS + D) * K + k], gc);
   }
   red[0][q][j] = gw;
   red[1][q][j] = gc;
@@ -2075,7 +2991,8 @@ inline VladPlan vlad_plan(int B, int N) {
 struct FwdWs {
   float *wt, *part, *colsum, *colsq, *vlad, *assign, *rnorm, *trash;
   unsigned long long* stamps;   // diagnostics: [B * S][32], the LAST bytes of the workspace
-  unsigned short* wplanes;      // register image of W^T (vlad_split_w_kernel)
+  unsigned short* wplanes;      // register images of W when the caller brought none (vlad_planes.h)
+  unsigned long long* gran;     // [B][8] granules of the finish kernel's exchange
   size_t total;
 };
 inline FwdWs carve_fwd(void* ws, int B, int N) {
@@ -2087,10 +3004,11 @@ inline FwdWs carve_fwd(void* ws, int B, int N) {
   w.colsum = c.take((size_t)B * S * K);
   w.trash = c.take(256);
   w.colsq = c.take((size_t)B * 32 * K);
-  w.vlad = c.take((size_t)B * (D + 1) * K);
+  w.vlad = c.take((size_t)B * VROWS * K);
   w.assign = c.take((size_t)B * N * K);
   w.rnorm = c.take((size_t)B * N);
-  w.wplanes = (unsigned short*)c.take((size_t)VF_WREP * VF_WIMG / 2);
+  w.wplanes = (unsigned short*)c.take(VP_BYTES / 4);
+  w.gran = (unsigned long long*)c.take((size_t)B * 8 * 2);
   w.stamps = (unsigned long long*)c.take((size_t)B * S * 32 * 2);
   w.total = c.off;
   return w;
@@ -2119,7 +3037,7 @@ inline BwdWs carve_bwd(void* ws, int B, int N) {
   w.dots = c.take((size_t)B * 8 * 4 * K);
   w.duimg = (unsigned short*)c.take((size_t)B * VF_NPL * D * K / 2);
   w.dximg = (unsigned short*)c.take((size_t)B * 2 * D * K / 2);
-  w.wdximg = (unsigned short*)c.take((size_t)2 * D * K / 2);
+  w.wdximg = (unsigned short*)c.take(VP_BYTES / 4);       // both images of W when the caller brought none
   w.stamps = (unsigned long long*)c.take((size_t)B * S * 32 * 2);
   w.total = c.off;
   return w;
@@ -2134,15 +3052,37 @@ extern "C" size_t scl_netvlad_fwd_workspace_bytes(int B, int N) {
   return carve_fwd(nullptr, B, N).total;
 }
 
-extern "C" int scl_netvlad_fwd(const void* x, int x_dtype, const float* assign_w,
-                               const float* centers, int B, int N, int pre_l2, float* out,
-                               float* save_assign, float* save_logit, float* save_rnorm,
-                               float* save_vlad, void* workspace, size_t workspace_bytes,
-                               void* stream) {
+// scl_debug_set_variant(920): round 3's launch structure (separate plane-split, finish_sum,
+// finish_norm, bwd_dots, bwd_du, wgrad_partial, wgrad_finish kernels) for same-box A/B timing
+inline bool old_launches() { return scl_debug_variant == 920; }
+// scl_debug_set_variant(922): the four-wave fused kernels of round 3 instead of the eight-wave ones
+inline bool four_waves() { return scl_debug_variant == 922 || scl_debug_variant == 920 || scl_debug_variant == 916; }
+
+__global__ __launch_bounds__(256) void vlad_planes_kernel(const float* __restrict__ w,
+                                                          unsigned short* __restrict__ planes) {
+  vlad_planes_wave(w, planes, planes + VP_FWD_ELEMS, 4 * blockIdx.x + (threadIdx.x >> 6), threadIdx.x & 63);
+}
+
+extern "C" size_t scl_netvlad_planes_bytes(void) { return VP_BYTES; }
+
+extern "C" int scl_netvlad_planes(const float* assign_w, void* planes, void* stream) {
+  if (!assign_w || !planes) return SCL_E_NULL;
+  if (!scl_aligned256(planes) || ((uintptr_t)assign_w % 16)) return SCL_E_SHAPE;
+  SCL_LAUNCH("vlad_planes_kernel", vlad_planes_kernel, dim3(VP_WAVES / 4), dim3(256), 0, (hipStream_t)stream,
+             assign_w, (unsigned short*)planes);
+  return scl_launch_status();
+}
+
+extern "C" int scl_netvlad_fwd_p(const void* x, int x_dtype, const float* assign_w,
+                                 const float* centers, const void* w_planes, int B, int N, int pre_l2,
+                                 float* out, float* save_assign, float* save_logit, float* save_rnorm,
+                                 float* save_vlad, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
   if (!x || !assign_w || !centers || !out || !workspace) return SCL_E_NULL;
   if (!shape_ok(B, N)) return SCL_E_SHAPE;
   if (x_dtype != SCL_DT_F32 && x_dtype != SCL_DT_BF16) return SCL_E_KIND;
   if (((uintptr_t)x % 16) != 0) return SCL_E_SHAPE;
+  if (w_planes && !scl_aligned256(w_planes)) return SCL_E_SHAPE;
   if (!scl_aligned256(workspace)) return SCL_E_WORKSPACE;
   FwdWs w = carve_fwd(workspace, B, N);
   if (workspace_bytes < w.total) return SCL_E_WORKSPACE;
@@ -2151,43 +3091,81 @@ extern "C" int scl_netvlad_fwd(const void* x, int x_dtype, const float* assign_w
   float* rnorm = save_rnorm ? save_rnorm : w.rnorm;
 
   if (x_dtype == SCL_DT_BF16 && use_fused()) {
-    // one pass over x: soft-assignment and aggregation fused
+    // one pass over x: soft-assignment and aggregation fused; then ONE finish kernel
     static std::once_flag once;
     std::call_once(once, [] {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vlad_fwd_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVladFusedLds);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vlad_fwd_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVladFusedLds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vlad_fwd8_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVlad8Lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vlad_fwd8_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVlad8Lds);
     });
     const VladPlan pl = vlad_plan(B, N);
-    SCL_LAUNCH("vlad_split_w_kernel", vlad_split_w_kernel, dim3(64, VF_WREP), dim3(64), 0, st,
-               assign_w, w.wplanes);
+    const unsigned short* planes = (const unsigned short*)w_planes;
+    if (!planes || old_launches()) {
+      if (old_launches())
+        SCL_LAUNCH("vlad_split_w_kernel", vlad_split_w_kernel, dim3(64, VF_WREP), dim3(64), 0, st,
+                   assign_w, w.wplanes);
+      else
+        SCL_LAUNCH("vlad_planes_kernel", vlad_planes_kernel, dim3(VP_WAVES / 4), dim3(256), 0, st, assign_w,
+                   w.wplanes);
+      planes = w.wplanes;
+    }
     VladFwdArgs fa{};
     fa.x = (const unsigned short*)x;
-    fa.wimg = w.wplanes;
+    fa.wimg = planes;
     fa.N = N;
     fa.pre_l2 = pre_l2 ? 1 : 0;
     fa.steps_per_slice = pl.steps_per_slice;
     fa.slab = w.part;
     fa.colsum = w.colsum;
     fa.trash = w.trash;
-    fa.dbg = scl_debug_variant == 916 ? 16 : 0;           // scripts/vlad_stamps.py
+    fa.gran = w.gran;
+    fa.dbg = (scl_debug_variant == 916 || scl_debug_variant == 918) ? 16 : 0;   // scripts/vlad_stamps.py
     fa.stamps = w.stamps;
-    if (save_assign && save_logit && save_rnorm) {
+    const bool save = save_assign && save_logit && save_rnorm;
+    if (save) {
       fa.assign = save_assign;
       fa.logit = save_logit;
       fa.rnorm = save_rnorm;
-      SCL_LAUNCH("vlad_fwd_kernel<true>", vlad_fwd_kernel<true>, dim3(B, pl.S), dim3(256),
-                 kVladFusedLds, st, fa);
+    }
+    if (four_waves()) {
+      if (save)
+        SCL_LAUNCH("vlad_fwd_kernel<true>", vlad_fwd_kernel<true>, dim3(B, pl.S), dim3(256),
+                   kVladFusedLds, st, fa);
+      else
+        SCL_LAUNCH("vlad_fwd_kernel<false>", vlad_fwd_kernel<false>, dim3(B, pl.S), dim3(256),
+                   kVladFusedLds, st, fa);
     } else {
-      SCL_LAUNCH("vlad_fwd_kernel<false>", vlad_fwd_kernel<false>, dim3(B, pl.S), dim3(256),
-                 kVladFusedLds, st, fa);
+      if (save)
+        SCL_LAUNCH("vlad_fwd8_kernel<true>", vlad_fwd8_kernel<true>, dim3(B, pl.S), dim3(512), kVlad8Lds,
+                   st, fa);
+      else
+        SCL_LAUNCH("vlad_fwd8_kernel<false>", vlad_fwd8_kernel<false>, dim3(B, pl.S), dim3(512), kVlad8Lds,
+                   st, fa);
     }
     float* vlad = save_vlad ? save_vlad : w.vlad;
-    SCL_LAUNCH("vlad_finish_sum_kernel", vlad_finish_sum_kernel, dim3(B, 32), dim3(256), 0, st,
-               (const float*)w.part, (const float*)w.colsum, centers, pl.S, vlad, w.colsq);
-    SCL_LAUNCH("finish_norm_kernel", finish_norm_kernel, dim3(8, B), dim3(256), 0, st,
-               (const float*)vlad, (const float*)w.colsq, 32, out);
+    if (old_launches()) {
+      SCL_LAUNCH("vlad_finish_sum_kernel", vlad_finish_sum_kernel, dim3(B, 32), dim3(256), 0, st,
+                 (const float*)w.part, (const float*)w.colsum, centers, pl.S, vlad, w.colsq);
+      SCL_LAUNCH("finish_norm_kernel", finish_norm_kernel, dim3(8, B), dim3(256), 0, st, vlad,
+                 (const float*)w.colsq, 32, out);
+      return scl_launch_status();
+    }
+    VladFinishArgs na{};
+    na.slab = w.part;
+    na.colsum = w.colsum;
+    na.centers = centers;
+    na.S = pl.S;
+    na.B = B;
+    na.vlad = vlad;
+    na.out = out;
+    na.gran = w.gran;
+    na.spin_limit = spin_limit();
+    SCL_LAUNCH("vlad_finish_kernel", vlad_finish_kernel, dim3(8, B), dim3(256), 0, st, na);
     return scl_launch_status();
   }
   // float32 feature maps (and bf16 ones under scl_debug_set_variant(1 .. 8)): float32-MFMA kernels
@@ -2215,9 +3193,18 @@ extern "C" int scl_netvlad_fwd(const void* x, int x_dtype, const float* assign_w
   float* vlad = save_vlad ? save_vlad : w.vlad;
   SCL_LAUNCH("finish_sum_kernel", finish_sum_kernel, dim3(8, B), dim3(256), 0, st,
              (const float*)w.part, (const float*)w.colsum, centers, vlad, w.colsq);
-  SCL_LAUNCH("finish_norm_kernel", finish_norm_kernel, dim3(8, B), dim3(256), 0, st,
-             (const float*)vlad, (const float*)w.colsq, 8, out);
+  SCL_LAUNCH("finish_norm_kernel", finish_norm_kernel, dim3(8, B), dim3(256), 0, st, vlad,
+             (const float*)w.colsq, 8, out);
   return scl_launch_status();
+}
+
+extern "C" int scl_netvlad_fwd(const void* x, int x_dtype, const float* assign_w,
+                               const float* centers, int B, int N, int pre_l2, float* out,
+                               float* save_assign, float* save_logit, float* save_rnorm,
+                               float* save_vlad, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+  return scl_netvlad_fwd_p(x, x_dtype, assign_w, centers, nullptr, B, N, pre_l2, out, save_assign,
+                           save_logit, save_rnorm, save_vlad, workspace, workspace_bytes, stream);
 }
 
 extern "C" size_t scl_netvlad_bwd_workspace_bytes(int B, int N) {
@@ -2225,29 +3212,51 @@ extern "C" size_t scl_netvlad_bwd_workspace_bytes(int B, int N) {
   return carve_bwd(nullptr, B, N).total;
 }
 
-extern "C" int scl_netvlad_bwd(const void* x, int x_dtype, const float* assign_w,
-                               const float* centers, const float* grad_out,
-                               const float* save_assign, const float* save_logit,
-                               const float* save_rnorm, const float* save_vlad, int B, int N,
-                               int pre_l2, void* grad_x, float* grad_w, float* grad_c,
-                               void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int scl_netvlad_bwd_p(const void* x, int x_dtype, const float* assign_w,
+                                 const float* centers, const void* w_planes, const float* grad_out,
+                                 const float* save_assign, const float* save_logit,
+                                 const float* save_rnorm, float* save_vlad, int B, int N,
+                                 int pre_l2, void* grad_x, float* grad_w, float* grad_c,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
   if (!x || !assign_w || !centers || !grad_out || !save_assign || !save_logit || !save_rnorm ||
       !save_vlad || !grad_x || !grad_w || !grad_c || !workspace)
     return SCL_E_NULL;
   if (!shape_ok(B, N)) return SCL_E_SHAPE;
   if (x_dtype != SCL_DT_F32 && x_dtype != SCL_DT_BF16) return SCL_E_KIND;
-  if (((uintptr_t)x % 16) != 0) return SCL_E_SHAPE;
+  if (((uintptr_t)x % 16) != 0 || ((uintptr_t)save_vlad % 8) != 0) return SCL_E_SHAPE;
+  if (w_planes && !scl_aligned256(w_planes)) return SCL_E_SHAPE;
   if (!scl_aligned256(workspace)) return SCL_E_WORKSPACE;
   BwdWs w = carve_bwd(workspace, B, N);
   if (workspace_bytes < w.total) return SCL_E_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
 
   const bool fused = x_dtype == SCL_DT_BF16 && use_fused();
-  SCL_LAUNCH("bwd_dots_kernel", bwd_dots_kernel, dim3(8, B), dim3(256), 0, st, save_vlad, grad_out,
-             centers, w.dots);
-  SCL_LAUNCH("bwd_du_kernel", bwd_du_kernel, dim3(8, B), dim3(256), 0, st, save_vlad, grad_out,
-             (const float*)w.dots, w.du, fused ? (float*)nullptr : w.dut,
-             fused ? w.duimg : (unsigned short*)nullptr, w.dximg, assign_w, w.wdximg, w.cdu);
+  const unsigned short* wdx = w_planes ? (const unsigned short*)w_planes + VP_FWD_ELEMS : nullptr;
+  if (old_launches()) {
+    SCL_LAUNCH("bwd_dots_kernel", bwd_dots_kernel, dim3(8, B), dim3(256), 0, st, (const float*)save_vlad,
+               grad_out, centers, w.dots);
+    SCL_LAUNCH("bwd_du_kernel", bwd_du_kernel, dim3(8, B), dim3(256), 0, st, (const float*)save_vlad,
+               grad_out, (const float*)w.dots, w.du, fused ? (float*)nullptr : w.dut,
+               fused ? w.duimg : (unsigned short*)nullptr, w.dximg, assign_w, w.wdximg, w.cdu);
+    wdx = w.wdximg;
+  } else {
+    if (fused && !wdx) {
+      SCL_LAUNCH("vlad_planes_kernel", vlad_planes_kernel, dim3(VP_WAVES / 4), dim3(256), 0, st, assign_w,
+                 w.wdximg);
+      wdx = w.wdximg + VP_FWD_ELEMS;
+    }
+    VladProArgs pa{};
+    pa.save_vlad = save_vlad;
+    pa.grad_out = grad_out;
+    pa.centers = centers;
+    pa.du = w.du;
+    pa.dut = fused ? (float*)nullptr : w.dut;
+    pa.duimg = fused ? w.duimg : (unsigned short*)nullptr;
+    pa.dximg = w.dximg;
+    pa.cdu = w.cdu;
+    pa.spin_limit = spin_limit();
+    SCL_LAUNCH("vlad_bwd_prologue_kernel", vlad_bwd_prologue_kernel, dim3(8, B), dim3(256), 0, st, pa);
+  }
   if (fused) {
     static std::once_flag once;
     std::call_once(once, [] {
@@ -2255,6 +3264,8 @@ extern "C" int scl_netvlad_bwd(const void* x, int x_dtype, const float* assign_w
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVladFusedLds);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vlad_dx_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVladDxLds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vlad_bwd8_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVlad8Lds);
     });
     const VladPlan pl = vlad_plan(B, N);
     VladBwdArgs ba{};
@@ -2270,7 +3281,10 @@ extern "C" int scl_netvlad_bwd(const void* x, int x_dtype, const float* assign_w
     ba.rowdot = w.rowdot;
     ba.slab = w.wpart;
     ba.trash = w.trash;
-    SCL_LAUNCH("vlad_bwd_kernel", vlad_bwd_kernel, dim3(B, pl.S), dim3(256), kVladFusedLds, st, ba);
+    if (four_waves())
+      SCL_LAUNCH("vlad_bwd_kernel", vlad_bwd_kernel, dim3(B, pl.S), dim3(256), kVladFusedLds, st, ba);
+    else
+      SCL_LAUNCH("vlad_bwd8_kernel", vlad_bwd8_kernel, dim3(B, pl.S), dim3(512), kVlad8Lds, st, ba);
     VladDxArgs da{};
     da.x = (const unsigned short*)x;
     da.a = save_assign;
@@ -2278,7 +3292,7 @@ extern "C" int scl_netvlad_bwd(const void* x, int x_dtype, const float* assign_w
     da.rn = save_rnorm;
     da.rowdot = w.rowdot;
     da.dximg = w.dximg;
-    da.wdximg = w.wdximg;
+    da.wdximg = wdx;
     da.N = N;
     da.pre_l2 = pre_l2 ? 1 : 0;
     da.steps_per_slice = pl.steps_per_slice;
@@ -2286,11 +3300,22 @@ extern "C" int scl_netvlad_bwd(const void* x, int x_dtype, const float* assign_w
     da.trash = (unsigned short*)w.trash;
     da.dbg = scl_debug_variant == 917 ? 1 : 0;
     da.stamps = w.stamps;
+    if (!old_launches()) {               // the parameter gradients ride in the tail of this launch
+      da.wslab = w.wpart;
+      da.nslab = pl.S * B;
+      da.du = w.du;
+      da.save_vlad = save_vlad;
+      da.B = B;
+      da.grad_w = grad_w;
+      da.grad_c = grad_c;
+    }
     SCL_LAUNCH("vlad_dx_kernel", vlad_dx_kernel, dim3(B, pl.S), dim3(256), kVladDxLds, st, da);
-    SCL_LAUNCH("vlad_wgrad_partial_kernel", vlad_wgrad_partial_kernel, dim3(32, VW_GROUPS), dim3(256),
-               0, st, (const float*)w.wpart, pl.S * B, w.wpartial);
-    SCL_LAUNCH("vlad_wgrad_finish_kernel", vlad_wgrad_finish_kernel, dim3(32), dim3(256), 0, st,
-               (const float*)w.wpartial, (const float*)w.du, save_vlad, B, grad_w, grad_c);
+    if (old_launches()) {
+      SCL_LAUNCH("vlad_wgrad_partial_kernel", vlad_wgrad_partial_kernel, dim3(32, VW_GROUPS), dim3(256),
+                 0, st, (const float*)w.wpart, pl.S * B, w.wpartial);
+      SCL_LAUNCH("vlad_wgrad_finish_kernel", vlad_wgrad_finish_kernel, dim3(32), dim3(256), 0, st,
+                 (const float*)w.wpartial, (const float*)w.du, (const float*)save_vlad, B, grad_w, grad_c);
+    }
     return scl_launch_status();
   }
   RowTileArgs a{};
@@ -2325,4 +3350,15 @@ extern "C" int scl_netvlad_bwd(const void* x, int x_dtype, const float* assign_w
   SCL_LAUNCH("wgrad_finish_kernel", wgrad_finish_kernel, dim3(D * K / 64), dim3(256), 0, st,
                      (const float*)w.wpart, (const float*)w.du, save_vlad, B, grad_w, grad_c);
   return scl_launch_status();
+}
+
+extern "C" int scl_netvlad_bwd(const void* x, int x_dtype, const float* assign_w,
+                               const float* centers, const float* grad_out,
+                               const float* save_assign, const float* save_logit,
+                               const float* save_rnorm, float* save_vlad, int B, int N,
+                               int pre_l2, void* grad_x, float* grad_w, float* grad_c,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+  return scl_netvlad_bwd_p(x, x_dtype, assign_w, centers, nullptr, grad_out, save_assign, save_logit,
+                           save_rnorm, save_vlad, B, N, pre_l2, grad_x, grad_w, grad_c, workspace,
+                           workspace_bytes, stream);
 }

@@ -67,29 +67,34 @@ class _NetVLADFn(torch.autograd.Function):
             sa = torch.empty((b, n, L.VLAD_K), dtype=torch.float32, device=dev)
             sl = torch.empty((b, n, L.VLAD_K), dtype=torch.float32, device=dev)
             sr = torch.empty((b, n), dtype=torch.float32, device=dev)
-            sv = torch.empty((b, L.VLAD_D + 1, L.VLAD_K), dtype=torch.float32, device=dev)
+            sv = torch.empty((b, L.VLAD_SAVE_ROWS, L.VLAD_K), dtype=torch.float32, device=dev)
         ws = L.workspace(lib.scl_netvlad_fwd_workspace_bytes(b, n), dev)
-        L.check(lib.scl_netvlad_fwd(L.ptr(x), dt, L.ptr(w), L.ptr(c), b, n, int(bool(pre_l2)),
-                                    L.ptr(out), L.ptr(sa), L.ptr(sl), L.ptr(sr), L.ptr(sv),
-                                    L.ptr(ws), ws.numel(), L.stream_of(x)))
+        # the plane images of the assignment weights: written by prepack() in the launch that packs
+        # the convolution weights (once per step); without them the call builds its own
+        planes = _vlad_planes_for(w) if dt == L.DT_BF16 else None
+        L.check(lib.scl_netvlad_fwd_p(L.ptr(x), dt, L.ptr(w), L.ptr(c), L.ptr(planes), b, n,
+                                      int(bool(pre_l2)), L.ptr(out), L.ptr(sa), L.ptr(sl), L.ptr(sr),
+                                      L.ptr(sv), L.ptr(ws), ws.numel(), L.stream_of(x)))
         if train:
             ctx.save_for_backward(x, w, c, sa, sl, sr, sv)
-            ctx.meta = (dt, b, n, int(bool(pre_l2)), assign_w.shape, centers.shape)
+            ctx.meta = (dt, b, n, int(bool(pre_l2)), assign_w.shape, centers.shape, planes)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         lib = L.load()
         x, w, c, sa, sl, sr, sv = ctx.saved_tensors
-        dt, b, n, pre_l2, w_shape, c_shape = ctx.meta
+        dt, b, n, pre_l2, w_shape, c_shape, planes = ctx.meta
         go = grad_out.float().contiguous()
         gx = torch.empty_like(x)
         gw = torch.empty_like(w)
         gc = torch.empty_like(c)
         ws = L.workspace(lib.scl_netvlad_bwd_workspace_bytes(b, n), x.device)
-        L.check(lib.scl_netvlad_bwd(L.ptr(x), dt, L.ptr(w), L.ptr(c), L.ptr(go), L.ptr(sa),
-                                    L.ptr(sl), L.ptr(sr), L.ptr(sv), b, n, pre_l2, L.ptr(gx),
-                                    L.ptr(gw), L.ptr(gc), L.ptr(ws), ws.numel(), L.stream_of(x)))
+        # (the forward's plane images: the weights it saw are the ones this gradient is for)
+        L.check(lib.scl_netvlad_bwd_p(L.ptr(x), dt, L.ptr(w), L.ptr(c), L.ptr(planes), L.ptr(go),
+                                      L.ptr(sa), L.ptr(sl), L.ptr(sr), L.ptr(sv), b, n, pre_l2,
+                                      L.ptr(gx), L.ptr(gw), L.ptr(gc), L.ptr(ws), ws.numel(),
+                                      L.stream_of(x)))
         return gx, gw.reshape(w_shape), gc.reshape(c_shape), None
 
 
@@ -204,16 +209,31 @@ def _in_slot(slot):
         _SLOT.slot = old
 
 
-def prepack(weights, force=False):
+def prepack(weights, force=False, vlad_w=None):
     """Bring the packed images of ``weights`` (3x3 convolution weights on a HIP device, both
     directions) up to date; returns the number of images written.  Without ``force`` an image
     is rewritten only when the tensor's autograd version moved — which in-place optimizers do
     NOT guarantee (torch's fused Adam updates the parameters without touching ``_version``), so
-    the model's forward pass forces: one 40 us launch per forward, never a stale weight."""
+    the model's forward pass forces: one 40 us launch per forward, never a stale weight.
+    ``vlad_w``: the NetVLAD assignment weights (float32, contiguous, 512 * 64 elements): their bf16
+    plane images ride in the same launch (SCL_PACK_VLAD_W) and are found by _vlad_planes_for()."""
     import weakref
     lib = L.load()
     jobs, keep = [], []
     me = _pack_slot()
+
+    def slot_buffer(key, w, nbytes):
+        """The image buffer registered under ``key`` (None = up to date, nothing to write)."""
+        with _PACKED_LOCK:
+            ent = _PACKED.get(key)
+            if (not force and ent is not None and ent[0]() is not None and ent[1] == w._version
+                    and ent[2] == tuple(w.shape)):
+                return None
+            buf = (ent[3] if ent is not None and ent[3].numel() == nbytes and ent[3].device == w.device
+                   else torch.empty(nbytes, dtype=torch.uint8, device=w.device))
+            _PACKED[key] = (weakref.ref(w), w._version, tuple(w.shape), buf)
+            return buf
+
     with _PACKED_LOCK:
         alive = {t.ident for t in threading.enumerate()}
         for key in [k for k, ent in _PACKED.items() if ent[0]() is None or k[2] not in alive]:
@@ -228,19 +248,19 @@ def prepack(weights, force=False):
             nbytes = lib.scl_conv_packed_bytes(cin, kout)
             if nbytes == 0:
                 continue
-            key = (w.data_ptr(), transposed, me)
-            ent = _PACKED.get(key)
-            if (not force and ent is not None and ent[0]() is not None and ent[1] == w._version
-                    and ent[2] == tuple(w.shape)):
+            buf = slot_buffer((w.data_ptr(), transposed, me), w, nbytes)
+            if buf is None:
                 continue
-            buf = (ent[3] if ent is not None and ent[3].numel() == nbytes and ent[3].device == w.device
-                   else torch.empty(nbytes, dtype=torch.uint8, device=w.device))
-            with _PACKED_LOCK:
-                _PACKED[key] = (weakref.ref(w), w._version, tuple(w.shape), buf)
             sk, sc, sh, sw = w.stride()
             jobs.append(L.PackJob(L.ptr(w), sk, sc, sh, sw, int(transposed) | _wflag(w), cin, kout,
                                   L.ptr(buf)))
             keep.append(w)
+    if (vlad_w is not None and vlad_w.is_cuda and vlad_w.dtype == torch.float32 and vlad_w.is_contiguous()
+            and vlad_w.numel() == L.VLAD_D * L.VLAD_K):
+        buf = slot_buffer((vlad_w.data_ptr(), 'vlad', me), vlad_w, lib.scl_netvlad_planes_bytes())
+        if buf is not None:
+            jobs.append(L.PackJob(L.ptr(vlad_w), 0, 0, 0, 0, L.PACK_VLAD_W, L.VLAD_D, L.VLAD_K, L.ptr(buf)))
+            keep.append(vlad_w)
     if jobs:
         L.require_device(*keep)
         arr = (L.PackJob * len(jobs))(*jobs)
@@ -248,11 +268,24 @@ def prepack(weights, force=False):
     return len(jobs)
 
 
+def _vlad_planes_for(w):
+    """The up-to-date plane images of the assignment weights ``w`` ([512, 64] float32 view of the
+    parameter) written by prepack() on this thread, or None (the call then builds its own)."""
+    if not USE_PREPACK:
+        return None
+    with _PACKED_LOCK:
+        ent = _PACKED.get((w.data_ptr(), 'vlad', _pack_slot()))
+    if ent is None or ent[0]() is None or ent[1] != w._version or ent[3].device != w.device:
+        return None
+    return ent[3]
+
+
 def _packed_for(w, transposed):
     """The up-to-date packed image of ``w`` for this direction, or None."""
     if not USE_PREPACK:
         return None
-    ent = _PACKED.get((w.data_ptr(), bool(transposed), _pack_slot()))
+    with _PACKED_LOCK:
+        ent = _PACKED.get((w.data_ptr(), bool(transposed), _pack_slot()))
     if ent is None or ent[0]() is None or ent[1] != w._version or ent[2] != tuple(w.shape):
         return None
     return ent[3]
@@ -1066,7 +1099,9 @@ class VGG16NetVLAD(torch.nn.Module):
         if fuse and dt == torch.bfloat16 and USE_CONV64 and USE_F32_WEIGHTS and USE_PREPACK:
             # every packed weight image of this step (both directions) in one launch; forced: an
             # optimizer step in between may not have moved the tensors' versions
-            prepack([getattr(self, 'conv%s_kernel' % n) for n in self.conv_names], force=True)
+            # (+ the plane images of the NetVLAD assignment weights: the same launch)
+            prepack([getattr(self, 'conv%s_kernel' % n) for n in self.conv_names], force=True,
+                    vlad_w=self.assignment_kernel)
         split = None
         if (fuse and dt == torch.bfloat16 and USE_CONV64 and _split_fwd_wanted() and _FWD.split is None
                 and image_batch.shape[0] >= 2):

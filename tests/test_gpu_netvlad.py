@@ -177,3 +177,94 @@ def test_vgg16netvlad_end_to_end_vs_cpu(dev):
         g1 = nets.vgg16Netvlad(grey, model=model)
         g3 = nets.vgg16Netvlad(grey.expand(-1, -1, -1, 3).contiguous(), model=model)
     assert _maxrel(g1.cpu().numpy(), g3.cpu().numpy()) < 1e-5   # MIOpen may pick another solver
+
+
+# ---- round 4: two launches forward, three backward ---------------------------------------------
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def _run_variant(dev, variant, x, w, c, g, dtype=torch.bfloat16, planes=False):
+    """_run under scl_debug_set_variant(variant); planes=True: the assignment weights' plane images
+    come from prepack() (the weight-packing launch) instead of a launch inside the call."""
+    from soft_contrastive_learning_amd import _lib as L
+    from soft_contrastive_learning_amd.model import nets
+    b, n, d = x.shape
+    xt = torch.tensor(x, device=dev).to(dtype).reshape(b, 1, n, d).requires_grad_(True)
+    wt = torch.tensor(w, device=dev).reshape(1, 1, d, -1).requires_grad_(True)
+    ct = torch.tensor(c, device=dev).reshape(1, 1, 1, d, -1).requires_grad_(True)
+    L.load().scl_debug_set_variant(variant)
+    try:
+        if planes:
+            wd = wt.detach()                                  # (the registry holds a weak reference)
+            assert nets.prepack([], force=True, vlad_w=wd) == 1
+            assert nets._vlad_planes_for(wd.reshape(512, 64)) is not None
+        out = nets.netvlad(xt, wt, ct, True)
+        out.backward(torch.tensor(g, device=dev))
+        torch.cuda.synchronize()
+    finally:
+        L.load().scl_debug_set_variant(0)
+    return (out.detach().cpu().numpy(), xt.grad.float().cpu().numpy().reshape(b, n, d),
+            wt.grad.cpu().numpy().reshape(d, -1), ct.grad.cpu().numpy().reshape(d, -1))
+
+
+@pytest.mark.parametrize("b,n", [(1, 1), (3, 33), (5, 1200), (24, 1200), (40, 70)])
+def test_sibling_exchange_and_self_computing_path_give_the_same_bits(dev, b, n):
+    """vlad_finish_kernel / vlad_bwd_prologue_kernel: the 8 workgroups of an image exchange their
+    shares of the global sums through tagged words with a bounded wait.  Variant 921 sets the
+    patience to zero, so that workgroups compute their siblings' shares themselves: every output
+    must be bit-identical (same routine, same order), i.e. no result depends on co-residency."""
+    x = U.feature_map(b, n, seed=11 * b + n)
+    w, c = U.vlad_params(seed=8, logit_scale=3.0)
+    g = np.random.default_rng(5).standard_normal((b, 32768)).astype(np.float32)
+    ref = _run_variant(dev, 0, x, w, c, g)
+    alone = _run_variant(dev, 921, x, w, c, g)
+    for r, a in zip(ref, alone):
+        assert np.array_equal(_bits(r), _bits(a))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_new_launch_structure_agrees_with_round_3s(dev, dtype):
+    """scl_debug_set_variant(920) runs round 3's ten launches (separate plane split, finish_sum,
+    finish_norm, bwd_dots, bwd_du, wgrad_partial, wgrad_finish); the merged kernels add the same
+    numbers in another order."""
+    b, n = 24, 1200
+    x = U.feature_map(b, n, seed=3)
+    w, c = U.vlad_params(seed=8, logit_scale=3.0)
+    g = np.random.default_rng(6).standard_normal((b, 32768)).astype(np.float32)
+    new = _run_variant(dev, 0, x, w, c, g, dtype=dtype)
+    old = _run_variant(dev, 920, x, w, c, g, dtype=dtype)
+    assert _maxrel(new[0], old[0]) < 5e-6
+    assert _nrel(new[1], old[1]) < (2e-3 if dtype == torch.bfloat16 else 5e-6)   # bf16 storage of grad_x
+    assert _nrel(new[2], old[2]) < 5e-6
+    assert _nrel(new[3], old[3]) < 5e-6
+
+
+def test_plane_images_from_the_packing_launch(dev):
+    """The assignment weights' plane images written by scl_conv_pack_batch (SCL_PACK_VLAD_W, the
+    launch that packs the convolution weights) are the ones the call would build for itself."""
+    x = U.feature_map(4, 300, seed=21)
+    w, c = U.vlad_params(seed=9, logit_scale=3.0)
+    g = np.random.default_rng(7).standard_normal((4, 32768)).astype(np.float32)
+    own = _run_variant(dev, 0, x, w, c, g)
+    pre = _run_variant(dev, 0, x, w, c, g, planes=True)
+    for r, a in zip(own, pre):
+        assert np.array_equal(_bits(r), _bits(a))
+
+
+def test_backward_twice_over_the_same_saved_tensors(dev):
+    """Row 513 of save_vlad carries the prologue's exchange words: zero on entry, zero again on
+    return — a second backward pass over the same graph sees what the first one saw."""
+    from soft_contrastive_learning_amd.model import nets
+    b, n = 6, 500
+    x = U.feature_map(b, n, seed=2)
+    w, c = U.vlad_params(seed=8, logit_scale=3.0)
+    xt = torch.tensor(x, device=dev).bfloat16().reshape(b, 1, n, 512).requires_grad_(True)
+    wt = torch.tensor(w, device=dev).reshape(1, 1, 512, 64).requires_grad_(True)
+    ct = torch.tensor(c, device=dev).reshape(1, 1, 1, 512, 64).requires_grad_(True)
+    go = torch.randn(b, 32768, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    out = nets.netvlad(xt, wt, ct, True)
+    g1 = torch.autograd.grad(out, (xt, wt, ct), go, retain_graph=True)
+    g2 = torch.autograd.grad(out, (xt, wt, ct), go)
+    for a, bb in zip(g1, g2):
+        assert torch.equal(a, bb)
