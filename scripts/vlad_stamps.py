@@ -68,13 +68,13 @@ def main():
     elif args.kernel == 'fwd8':
         names = {0: 'entry', 1: 'stage DMA issued, W loads issued', 28: 'loop done', 29: 'slab stores issued',
                  30: 'slab stores complete'}
+        names.update({2: 'stage 0 + W landed, barrier', 3: 'partial logits of step 0 + barrier', 28: 'last aggregation + slab stores issued'})
         for st in range(4):
-            names.update({4 + 6 * st: 'step %d: stage landed + barrier' % st,
-                          5 + 6 * st: 'step %d: partial logits done' % st,
-                          6 + 6 * st: 'step %d: partials exchanged (barrier)' % st,
-                          7 + 6 * st: 'step %d: softmax part 1 + barrier' % st,
-                          8 + 6 * st: 'step %d: coefficients written + barrier' % st,
-                          9 + 6 * st: 'step %d: aggregation done' % st})
+            names.update({4 + 6 * st: 'step %d: block P starts' % st,
+                          5 + 6 * st: 'step %d: P done (aggregation of step %d || softmax part 1)' % (st, st - 1),
+                          6 + 6 * st: 'step %d: stage wait + barrier' % st,
+                          7 + 6 * st: 'step %d: Q done (DMA issue, logits of step %d || softmax part 2)' % (st, st + 1),
+                          8 + 6 * st: 'step %d: barrier' % st})
     else:
         names = {0: 'entry', 1: 'stage DMA issued, W loads issued', 2: 'W + first stages landed', 28: 'loop done',
                  29: 'slab stores issued', 30: 'slab stores complete'}

@@ -366,6 +366,22 @@ __device__ __forceinline__ void nv_glds16(const unsigned short* src, unsigned ld
       : "v"(src), "s"(lds_byte)
       : "memory");
 }
+// The same with a wave-uniform 64-bit base (SGPR pair) and a 32-bit per-lane byte offset: the
+// eight-wave kernels have no registers to spare for per-lane 64-bit row addresses (hipcc hoisted
+// four of them out of the step loop, spilled two, and put the reload — an s_waitcnt vmcnt(0) —
+// between two DMA instructions: every stage then waited out a full memory latency twice).
+// The lane's offset 16 (lane ^ cx) is formed inside the asm block (two vector instructions): kept
+// as a value it is one more candidate for that spill.
+__device__ __forceinline__ void nv_glds16s(const unsigned short* sbase, unsigned lane, unsigned cx, unsigned lds_byte) {
+  unsigned keep, voff;
+  asm volatile(
+      "v_xor_b32 %1, %3, %2\n\tv_lshlrev_b32 %1, 4, %1\n\t"
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep), "=&v"(voff)
+      : "v"(lane), "s"(cx), "s"(sbase), "s"(lds_byte)
+      : "memory");
+}
 __device__ __forceinline__ unsigned nv_lds_byte_of(const void* p) {
   return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
 }
@@ -1217,16 +1233,30 @@ constexpr int V8_AHEAD = 4;                      // A fragments in flight in the
 __device__ __forceinline__ void v8_wait_vm(int n) {
   switch (n) {
     case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
     case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
     case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
     case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
     case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
     case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
 }
 
-template <bool SAVE>
+// STAMPS: the diagnostic instance (scripts/vlad_stamps.py, scl_debug_set_variant(918)); the production
+// instances carry no stamp code.
+//
+// Tried on top of this and NOT kept (second half of round 4, profiles/r04/vlad_stamps_fwd8_pipelined.txt):
+// a software pipeline over the steps — aggregation of step i - 1 with the first half of step i's softmax
+// chain hand-interleaved into it, partial logits of step i + 1 with the second half, two barriers per
+// step instead of four.  Blocks measured 1.8 k + 2.6 k cycles against 1.0 k + 1.25 k for the bare matrix
+// phases and 1.2 k + 0.8 k for the bare chains: vector and matrix instructions of a SIMD's two waves
+// ADD (what scripts/mfma_valu_overlap.hip showed in round 1 for two waves of different workgroups
+// holds inside a workgroup too), and the extra live state (256 registers per wave) cost spills; the
+// kernel came out 0.9 us SLOWER than this one.  What pays on this chip is fewer vector instructions
+// and fewer barrier intervals, not overlap.
+template <bool SAVE, bool STAMPS = false>
 __global__ __launch_bounds__(512) void vlad_fwd8_kernel(VladFwdArgs p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char vf_lds[];
   const int lane = threadIdx.x & 63;
@@ -1245,15 +1275,14 @@ __global__ __launch_bounds__(512) void vlad_fwd8_kernel(VladFwdArgs p) {
   float* exch = pn + V8_PN / 4;
   float* csx = exch + V8_EXCH / 4;
   const unsigned short* xb = p.x + (int64_t)b * p.N * D;
-  unsigned long long* stp =
-      (p.dbg & 16) && threadIdx.x == 0 ? p.stamps + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 : nullptr;
-#define VF_STAMP(k)                                         \
-  do {                                                      \
-    if (p.dbg & 16) {                                       \
-      __builtin_amdgcn_sched_barrier(0);                    \
-      if (stp) stp[k] = __builtin_amdgcn_s_memtime();       \
-      __builtin_amdgcn_sched_barrier(0);                    \
-    }                                                       \
+#define VF_STAMP(k)                                                                              \
+  do {                                                                                           \
+    if constexpr (STAMPS) {                                                                      \
+      __builtin_amdgcn_sched_barrier(0);                                                         \
+      if (threadIdx.x == 0)                                                                      \
+        p.stamps[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 + (k)] = __builtin_amdgcn_s_memtime(); \
+      __builtin_amdgcn_sched_barrier(0);                                                         \
+    }                                                                                            \
   } while (0)
   VF_STAMP(0);
   // (the finish kernel behind this one polls these words: they must be zero when it starts)
@@ -1265,10 +1294,10 @@ __global__ __launch_bounds__(512) void vlad_fwd8_kernel(VladFwdArgs p) {
     const unsigned base = lds0 + (unsigned)((step - st_lo) % VF_NST) * VF_STAGE;
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      const int r = wid + 8 * v;
+      const int r = wid + 8 * v;                           // (wave-uniform: the row base is scalar)
       int n = VF_STEP * step + r;
       n = n < p.N ? n : p.N - 1;
-      nv_glds16(xb + (int64_t)n * D + ((lane ^ (r & 15)) << 3), base + r * 1024);
+      nv_glds16s(xb + (int64_t)n * D, (unsigned)lane, (unsigned)(r & 15), base + r * 1024);
     }
   };
   stage(st_lo);
@@ -1288,6 +1317,10 @@ __global__ __launch_bounds__(512) void vlad_fwd8_kernel(VladFwdArgs p) {
 #pragma unroll
   for (int ct = 0; ct < 16; ++ct) accv[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
   float cs[4] = {0.f, 0.f, 0.f, 0.f};
+  // wave-uniform bases of the image's saved rows + 32-bit per-lane offsets
+  float* const lg_img = SAVE ? p.logit + (int64_t)b * p.N * K : nullptr;
+  float* const as_img = SAVE ? p.assign + (int64_t)b * p.N * K : nullptr;
+  float* const rn_img = SAVE ? p.rnorm + (int64_t)b * p.N : nullptr;
 
   // Row fragment of (tile t, global k-step s' = 8 h + s): unit (16 t + i, 4 s' + g):
   //   byte = 1024 (16 t + i) + 256 (s' >> 2) + 64 ((s' & 3) ^ (i >> 2)) + 16 (g ^ (i & 3))
@@ -1365,8 +1398,12 @@ __global__ __launch_bounds__(512) void vlad_fwd8_kernel(VladFwdArgs p) {
     if (st < 4) VF_STAMP(6 + 6 * st);
 
     // ---- the wave's tile (t = h): logits, softmax over the 64 clusters (this wave: 16 of them)
-    const int n = VF_STEP * step + 16 * h + i;
-    const bool ok = n < p.N;
+    // Locations past the end of the image are copies of its last one (the stage re-reads that row):
+    // their saved rows are stored over it with the same values — one destination, and every step
+    // issues the same stores (the kernel counts its own vector-memory queue).
+    const int nraw = VF_STEP * step + 16 * h + i;
+    const bool ok = nraw < p.N;
+    const unsigned n = ok ? nraw : p.N - 1;
     float ev[4], av[4], mloc, rnv;
     {
       const f32x4 own = h ? accl[1] : accl[0];
@@ -1384,9 +1421,7 @@ __global__ __launch_bounds__(512) void vlad_fwd8_kernel(VladFwdArgs p) {
       }
       m = vf_gmax(m);
       mloc = m;
-      if (SAVE)
-        *reinterpret_cast<f32x4*>(ok ? p.logit + ((int64_t)b * p.N + n) * K + 16 * w + 4 * g
-                                     : p.trash + 4 * lane) = f32x4{ev[0], ev[1], ev[2], ev[3]};
+      if (SAVE) *reinterpret_cast<f32x4*>(lg_img + (n * K + 16 * w + 4 * g)) = f32x4{ev[0], ev[1], ev[2], ev[3]};
       float sum = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -1416,9 +1451,7 @@ __global__ __launch_bounds__(512) void vlad_fwd8_kernel(VladFwdArgs p) {
         cs[j] += a_ok;
         split3_bf16(a_ok * rnv, hh[0][j], hh[1][j], hh[2][j]);
       }
-      if (SAVE)
-        *reinterpret_cast<f32x4*>(ok ? p.assign + ((int64_t)b * p.N + n) * K + 16 * w + 4 * g
-                                     : p.trash + 4 * lane) = f32x4{av[0], av[1], av[2], av[3]};
+      if (SAVE) *reinterpret_cast<f32x4*>(as_img + (n * K + 16 * w + 4 * g)) = f32x4{av[0], av[1], av[2], av[3]};
 #pragma unroll
       for (int pl = 0; pl < VF_NPL; ++pl) {
         vf_ldsw64(cf0 + pl * VF_CFPL + (16 * h + i) * VF_CFLD + 8 * g,
@@ -1426,8 +1459,7 @@ __global__ __launch_bounds__(512) void vlad_fwd8_kernel(VladFwdArgs p) {
                   (unsigned)hh[pl][2] | ((unsigned)hh[pl][3] << 16));
       }
       if (SAVE) {   // rn: wave (w, h) writes locations 4 w .. 4 w + 3 of its tile (one store per wave)
-        const bool mine = g == 0 && (i >> 2) == w && ok;
-        *(mine ? p.rnorm + (int64_t)b * p.N + n : p.trash + 4 * lane) = rnv;
+        if (g == 0 && (i >> 2) == w) rn_img[n] = rnv;
       }
     }
     __builtin_amdgcn_s_barrier();          // the pair's coefficient rows are both written
@@ -1486,7 +1518,7 @@ __global__ __launch_bounds__(512) void vlad_fwd8_kernel(VladFwdArgs p) {
     *reinterpret_cast<f32x4*>(p.colsum + ((int64_t)sl * B + b) * K + 16 * w + 4 * g) =
         f32x4{cs[0] + o[0], cs[1] + o[1], cs[2] + o[2], cs[3] + o[3]};
   }
-  if (p.dbg & 16) {
+  if constexpr (STAMPS) {
     VF_STAMP(29);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     VF_STAMP(30);
@@ -1519,10 +1551,10 @@ __global__ __launch_bounds__(512) void vlad_bwd8_kernel(VladBwdArgs p) {
     const unsigned base = lds0 + (unsigned)((step - st_lo) % VF_NST) * VF_STAGE;
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      const int r = wid + 8 * v;
+      const int r = wid + 8 * v;                           // (wave-uniform: the row base is scalar)
       int n = VF_STEP * step + r;
       n = n < p.N ? n : p.N - 1;
-      nv_glds16(xb + (int64_t)n * D + ((lane ^ (r & 15)) << 3), base + r * 1024);
+      nv_glds16s(xb + (int64_t)n * D, (unsigned)lane, (unsigned)(r & 15), base + r * 1024);
     }
   };
   stage(st_lo);
@@ -1831,6 +1863,15 @@ __global__ __launch_bounds__(256) void vlad_finish_kernel(VladFinishArgs p) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
     float asum = 0.f;
+    // The kernel is ONE memory round trip long if everything a thread needs is requested before
+    // anything is consumed (left to itself hipcc keeps ~10 loads in flight and waits between them:
+    // four round trips for the 40 slab units): the centres first, then the slabs, then a scheduling
+    // fence.
+    float cen[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) cen[r][j] = p.centers[(16 * (cs + 8 * r) + 4 * g + j) * K + k];
     for (int s0 = 0; s0 < p.S; s0 += VFIN_NB) {
       f32x4 v[VFIN_NB][4];
       float a[VFIN_NB];
@@ -1841,6 +1882,7 @@ __global__ __launch_bounds__(256) void vlad_finish_kernel(VladFinishArgs p) {
         for (int r = 0; r < 4; ++r) v[s][r] = src[sc * sstride + r * 512];
         a[s] = p.colsum[((int64_t)sc * p.B + b) * K + k];
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < VFIN_NB; ++s) {                      // fixed order: bitwise reproducible
         const float keep = s0 + s < p.S ? 1.0f : 0.0f;
@@ -1854,8 +1896,7 @@ __global__ __launch_bounds__(256) void vlad_finish_kernel(VladFinishArgs p) {
     for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int d = 16 * (cs + 8 * r) + 4 * g + j;
-        u[r][j] = acc[r][j] + p.centers[d * K + k] * asum;
+        u[r][j] = acc[r][j] + cen[r][j] * asum;
         ss = fmaf(u[r][j], u[r][j], ss);
       }
     // over the 32 threads that share ip: lane bits 3..5, then the four waves
@@ -1963,6 +2004,7 @@ __global__ __launch_bounds__(256) void vlad_bwd_prologue_kernel(VladProArgs p) {
         gg[8 * h + e] = grow[d * K + k];
         cc[8 * h + e] = p.centers[d * K + k];
       }
+    __builtin_amdgcn_sched_barrier(0);                        // all 48 loads requested before the first use
     float s[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -2843,6 +2885,7 @@ __global__ __launch_bounds__(256, 1) void vlad_dx_kernel(VladDxArgs p) {
               const int sidx = s0 + j * G < p.nslab ? s0 + j * G : p.nslab - 1;
               v[j] = src[(int64_t)sidx * 8192];
             }
+            __builtin_amdgcn_sched_barrier(0);               // every load requested before the first add
 #pragma unroll
             for (int j = 0; j < DXV_TAIL_NB; ++j) acc += v[j] * (s0 + j * G < p.nslab ? 1.0f : 0.0f);
           }
@@ -2866,16 +2909,17 @@ __global__ __launch_bounds__(256, 1) void vlad_dx_kernel(VladDxArgs p) {
       for (int e = e_lo + tid; e < e_hi; e += 256) {
         const int kk = e & (K - 1);
         float gc = 0.f;
-        for (int b0 = 0; b0 < p.B; b0 += 8) {
-          float dv[8], as8[8];
+        for (int b0 = 0; b0 < p.B; b0 += 24) {               // (24 images: one round trip)
+          float dv[24], as8[24];
 #pragma unroll
-          for (int bb = 0; bb < 8; ++bb) {
+          for (int bb = 0; bb < 24; ++bb) {
             const int b2 = b0 + bb < p.B ? b0 + bb : p.B - 1;
             dv[bb] = p.du[(int64_t)b2 * D * K + e];
-            as8[bb] = b0 + bb < p.B ? p.save_vlad[((int64_t)b2 * VROWS + D) * K + kk] : 0.f;
+            as8[bb] = p.save_vlad[((int64_t)b2 * VROWS + D) * K + kk];
           }
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int bb = 0; bb < 8; ++bb) gc = fmaf(dv[bb], as8[bb], gc);
+          for (int bb = 0; bb < 24; ++bb) gc = fmaf(dv[bb], b0 + bb < p.B ? as8[bb] : 0.f, gc);
         }
         p.grad_c[e] = gc;
       }
@@ -3102,6 +3146,8 @@ extern "C" int scl_netvlad_fwd_p(const void* x, int x_dtype, const float* assign
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVlad8Lds);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vlad_fwd8_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVlad8Lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vlad_fwd8_kernel<true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVlad8Lds);
     });
     const VladPlan pl = vlad_plan(B, N);
     const unsigned short* planes = (const unsigned short*)w_planes;
@@ -3140,7 +3186,10 @@ extern "C" int scl_netvlad_fwd_p(const void* x, int x_dtype, const float* assign
         SCL_LAUNCH("vlad_fwd_kernel<false>", vlad_fwd_kernel<false>, dim3(B, pl.S), dim3(256),
                    kVladFusedLds, st, fa);
     } else {
-      if (save)
+      if (save && scl_debug_variant == 918)
+        SCL_LAUNCH("vlad_fwd8_kernel<true, true>", (vlad_fwd8_kernel<true, true>), dim3(B, pl.S), dim3(512),
+                   kVlad8Lds, st, fa);
+      else if (save)
         SCL_LAUNCH("vlad_fwd8_kernel<true>", vlad_fwd8_kernel<true>, dim3(B, pl.S), dim3(512), kVlad8Lds,
                    st, fa);
       else
