@@ -42,8 +42,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# MIOpen's find step (torch.backends.cudnn.benchmark) would otherwise also time its naive
-# reference solvers — seconds per call at this size — during warm-up.
+# (--dtype f32 only: the float32 mode runs library convolutions, and MIOpen's find step would
+# otherwise also time its naive reference solvers — seconds per call at this size)
 for _k in ('FWD', 'BWD', 'WRW'):
     os.environ.setdefault('MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_' + _k, '0')
 
@@ -70,9 +70,12 @@ def parse():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'], help='backbone dtype')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--miopen-find', type=int, default=1,
-                    help='1: let MIOpen benchmark its solvers per conv shape during warm-up')
+                    help='--dtype f32 only (the float32 mode runs library convolutions): 1 lets MIOpen '
+                         'benchmark its solvers per shape during the warm-up.  The bf16 step has no '
+                         'library convolution')
     ap.add_argument('--fused-relu', type=int, default=1,
-                    help='1: fused HIP bias/ReLU/pool glue around the MIOpen convs (csrc/vgg_glue.hip)')
+                    help='1 (default): bias / ReLU / pooling in the convolution epilogues and fused HIP '
+                         'passes (csrc/vgg_glue.hip); 0: the plain PyTorch composition (A/B only)')
     ap.add_argument('--cpu-images', type=int, default=2, help='images in the CPU-baseline sample')
     ap.add_argument('--graph', type=int, default=0,
                     help='1: capture one train step (forward, backward, Adam) in a HIP graph after '
@@ -102,6 +105,7 @@ def parse():
                     help="N>1: this workload's value measured at --gpus 1 (same box family); the line "
                          'then carries scaling_efficiency = value / (N * n1_ref)')
     ap.add_argument('--no-retrieval', action='store_true', help='skip the retrieval object (N=1)')
+    ap.add_argument('--no-batch-sweep', action='store_true', help='skip the batch_sweep object (N=1)')
     ap.add_argument('--stub-cpu', action='store_true',
                     help='TEST ONLY: gloo on CPU with a trivial stand-in step; exercises the '
                          'launcher, the barriers and the max-over-ranks timing, measures nothing')
@@ -142,6 +146,8 @@ def kernel_models(b, n, gb, x_bytes, slices=10):
         'vlad_fwd8_kernel<true>': dict(flops=4.0 * bn * D * K,
                                        bytes=bn * D * 2 + bn * K * 8 + bn * 4 + slab, **b2),
         'vlad_fwd8_kernel<false>': dict(flops=4.0 * bn * D * K, bytes=bn * D * 2 + slab, **b2),
+        'vlad_fwd8_kernel<stamps>': dict(flops=4.0 * bn * D * K,
+                                         bytes=bn * D * 2 + bn * K * 8 + bn * 4 + slab, **b2),
         'vlad_bwd8_kernel': dict(flops=4.0 * bn * D * K,
                                  bytes=bn * D * 2 + bn * K * 12 + bn * 8 + slab + b * D * K * 4, **b2),
         # fused x.dU + softmax backward + x^T.(ds rn): x, a, logits, rn in; ds, rowdot, slabs out
@@ -226,12 +232,41 @@ def netvlad_stage(kernels, b, n, x_bytes, steps):
                          us_per_step=round(us, 2), algorithmic_bytes=int(nbytes),
                          algorithmic_flops=flops, bound='hbm' if t_hbm >= t_mfma else 'mfma',
                          bound_us=round(bound_us, 2), frac=round(bound_us / us, 4) if us > 0 else None)
-    out['note'] = ('durations = HIP events around every launch (each ~2.5 us above the rocprofv3 '
-                   'duration of the same kernel: profiles/r03)')
+    out['note'] = ('durations = HIP events around every launch minus the bracket measured on the empty '
+                   'kernel in this process (bracket_us in kernel_timing); rocprofv3 trace of the same '
+                   'command: profiles/r04')
     return out
 
 
+# Device time of the library's empty kernel (scl_null_kernel, 256 x 256 threads) as rocprofv3
+# reports it on MI355X (profiles/r04/null_kernel_bracket.txt).  bracket_us() measures the same
+# launch through the event bracket in this process; the difference is what the bracket adds to
+# every kernel, and price() takes it off (`us` = corrected, `us_events` = as measured).
+NULL_KERNEL_DEVICE_US = 3.5
+BRACKET_US = 0.0
+
+
+def bracket_us(dev, n=100):
+    """HIP-event bracket overhead per launch on this device, measured on the empty kernel."""
+    from soft_contrastive_learning_amd import _lib
+    lib = _lib.load()
+    x = torch.zeros(1 << 16, device=dev)
+    st = _lib.stream_of(x)
+    for _ in range(10):
+        lib.scl_prof_null(st)
+    torch.cuda.synchronize()
+    with _lib.KernelTimer(capacity=2 * n) as kt:
+        for _ in range(n):
+            x.add_(1.0)                       # a kernel in front, as inside a step
+            lib.scl_prof_null(st)
+        torch.cuda.synchronize()
+    us = sorted(t * 1e3 for name, t in kt.records if name == 'scl_null_kernel')
+    return max(0.0, us[len(us) // 2] - NULL_KERNEL_DEVICE_US) if us else 0.0
+
+
 def price(name, launches, mean_ms, model):
+    events_ms = mean_ms
+    mean_ms = max(mean_ms - BRACKET_US * 1e-3, 0.2 * mean_ms)
     sec = mean_ms * 1e-3
     tf = model['flops'] / sec / 1e12 if sec > 0 else 0.0
     gbs = model['bytes'] / sec / 1e9 if sec > 0 else 0.0
@@ -243,6 +278,8 @@ def price(name, launches, mean_ms, model):
     frac = mult * tf / peak_tf if bound == 'mfma' else gbs / PEAK_HBM_GBPS
     out = dict(kernel=name, launches=launches, us=round(mean_ms * 1e3, 2), bound=bound,
                tflops=round(tf, 2), gbps=round(gbs, 1), frac=round(frac, 4))
+    if BRACKET_US:
+        out['us_events'] = round(events_ms * 1e3, 2)
     if mult != 1.0:      # bf16x3 kernels: flops executed on the bf16 matrix cores
         out.update(executed_tflops=round(mult * tf, 2), mfma_peak_tflops=peak_tf)
     return out
@@ -582,7 +619,8 @@ def loss_b192_line(dev, iters=10):
     bsz, own = 192, 24
     emb = torch.tensor(U.embeddings(bsz, E), device=dev, requires_grad=True)
     dm = torch.tensor(U.positions_distances(bsz)[None], device=dev)
-    out = {'B': bsz, 'E': E, 'note': 'HIP events add ~2.5 us to each kernel; rocprofv3 trace under profiles/'}
+    out = {'B': bsz, 'E': E, 'note': 'event-bracketed, bracket subtracted (kernel_timing.bracket_us); '
+                                    'rocprofv3 trace under profiles/'}
     for case, rows in (('all_rows', None), ('own_rows', (72, own))):
         for _ in range(3):
             losses.wms_loss(dm, emb, 0.8, 15.0, _rows=rows).backward()
@@ -595,6 +633,71 @@ def loss_b192_line(dev, iters=10):
         krows = [price(k, cnt, ms, models[k]) for k, (cnt, ms) in sorted(kt.summary().items())
                  if k in models]
         out[case] = {'kernels': krows, 'us_forward_backward': round(sum(r['us'] for r in krows), 1)}
+    return out
+
+
+def batch_sweep(dev, iters=5):
+    """the kernels of the head over the batch, kernel-only, a few launches
+    each, right after the timed region.  NetVLAD (bf16 map, 1200 locations, plane images from the
+    packing launch) forward / backward at b = 24 / 48 / 96 images per GPU: launches, corrected
+    microseconds, fraction of the stage's governing bound (netvlad_stage).  wms loss at B = 24 /
+    48 / 96 / 192 x 32768: forward and backward against max(HBM, float32-MFMA) of SURVEY 8(d)."""
+    from soft_contrastive_learning_amd import _lib
+    from soft_contrastive_learning_amd.model import losses, nets
+    from tests import util_data as U
+    out = {'netvlad': [], 'wms_loss': [],
+           'how': 'event-bracketed launches minus the bracket (kernel_timing.bracket_us), %d iterations '
+                  'per size; bound = max(algorithmic bytes / 8 TB/s, executed flops / MFMA peak)' % iters}
+    w, c = U.vlad_params()
+    wt = torch.tensor(w, device=dev).reshape(1, 1, D, K).requires_grad_(True)
+    ct = torch.tensor(c, device=dev).reshape(1, 1, 1, D, K).requires_grad_(True)
+    wd = wt.detach()
+    gen = torch.Generator(device=dev).manual_seed(5)
+    for b in (24, 48, 96):
+        x = torch.randn(b, 1, 1200, D, device=dev, generator=gen).bfloat16().requires_grad_(True)
+        g = torch.randn(b, E, device=dev, generator=gen)
+        nets.prepack([], force=True, vlad_w=wd)
+        for _ in range(2):
+            nets.netvlad(x, wt, ct, True).backward(g)
+        torch.cuda.synchronize()
+        with _lib.KernelTimer(capacity=16 * iters) as kt:
+            for _ in range(iters):
+                nets.netvlad(x, wt, ct, True).backward(g)
+            torch.cuda.synchronize()
+        steps = (1200 + 31) // 32
+        per = -(-steps * b // 256)
+        models = kernel_models(b, 1200, b, 2, slices=-(-steps // per))
+        rows = [price(k, cnt, ms, models[k]) for k, (cnt, ms) in sorted(kt.summary().items()) if k in models]
+        st = netvlad_stage(rows, b, 1200, 2, iters)
+        ent = {'images': b}
+        for ps in ('forward', 'backward'):
+            if ps in st:
+                ent[ps] = {k: st[ps][k] for k in ('launches_per_step', 'us_per_step', 'bound', 'bound_us', 'frac')}
+                ent[ps]['us_per_image'] = round(st[ps]['us_per_step'] / b, 3)
+        out['netvlad'].append(ent)
+        del x, g
+    for bsz in (24, 48, 96, 192):
+        emb = torch.tensor(U.embeddings(bsz, E), device=dev, requires_grad=True)
+        dm = torch.tensor(U.positions_distances(bsz)[None], device=dev)
+        for _ in range(2):
+            losses.wms_loss(dm, emb, 0.8, 15.0).backward()
+        torch.cuda.synchronize()
+        with _lib.KernelTimer(capacity=16 * iters) as kt:
+            for _ in range(iters):
+                losses.wms_loss(dm, emb, 0.8, 15.0).backward()
+            torch.cuda.synchronize()
+        models = kernel_models(bsz, 1200, bsz, 4)
+        rows = [price(k, cnt, ms, models[k]) for k, (cnt, ms) in sorted(kt.summary().items()) if k in models]
+        fwd = [r for r in rows if not r['kernel'].startswith('gram_bwd')]
+        bwd = [r for r in rows if r['kernel'].startswith('gram_bwd')]
+        bound = max(bsz * E * 4 / (PEAK_HBM_GBPS * 1e9), 2.0 * bsz * bsz * E / (PEAK_F32_TFLOPS * 1e12)) * 1e6
+        ent = {'B': bsz, 'bound_us_each_pass': round(bound, 2)}
+        for name, rs in (('forward', fwd), ('backward', bwd)):
+            us = sum(r['us'] * r['launches'] for r in rs) / iters
+            ent[name] = {'launches': round(sum(r['launches'] for r in rs) / iters, 2), 'us': round(us, 2),
+                         'frac': round(bound / us, 4) if us > 0 else None,
+                         'kernels': [r['kernel'] for r in rs]}
+        out['wms_loss'].append(ent)
     return out
 
 
@@ -617,7 +720,8 @@ def main():
     if one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    torch.backends.cudnn.benchmark = bool(args.miopen_find)
+    if args.dtype == 'f32':      # the bf16 step runs no library convolution
+        torch.backends.cudnn.benchmark = bool(args.miopen_find)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -780,6 +884,8 @@ def main():
         elapsed_prof = elapsed
     work, nets.WORK_LOG = nets.WORK_LOG, None
     loss_val = float(loss.detach())
+    global BRACKET_US
+    BRACKET_US = bracket_us(dev) if rank == 0 else 0.0
 
     def timed_steps(k):
         fence()
@@ -876,7 +982,7 @@ def main():
                         rf['traffic_algorithmic'] = int(alg)
                         rf['traffic_source'] = ('rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch, '
                                                 'L2 misses incl. Infinity-Cache hits '
-                                                '(profiles/pmc_traffic.json, round 2)')
+                                                '(profiles/pmc_traffic.json: %s)' % pmc.get('source', '?'))
             except (OSError, ValueError, KeyError):
                 pass
         hip_ms = sum(r['us'] * r['launches'] for r in kernels) / 1e3 / max(prof_steps, 1)
@@ -917,7 +1023,13 @@ def main():
                                          'instrumented steps serialise them so that a duration '
                                          'is one kernel alone)'
                               if (nets.USE_SIDE_WRW or bool(nets.USE_SPLIT_FWD)) else 'one',
-                              'ms_per_step_with_events': round(elapsed_prof / prof_steps * 1e3, 3)},
+                              'ms_per_step_with_events': round(elapsed_prof / prof_steps * 1e3, 3),
+                              'bracket_us': round(BRACKET_US, 2),
+                              'bracket_how': 'event duration of the empty kernel (scl_prof_null) in this '
+                                             'process minus its device time (%.1f us, rocprofv3: '
+                                             'profiles/r04/null_kernel_bracket.txt); subtracted from '
+                                             'every `us` below, `us_events` is the raw figure'
+                                             % NULL_KERNEL_DEVICE_US},
             'roofline': roofline,
             'roofline_netvlad_loss': roofline_head,
             'roofline_netvlad_stage': netvlad_stage(kernels, b, n_loc, 2 if cdt == torch.bfloat16 else 4,
@@ -933,6 +1045,8 @@ def main():
             out['comm'] = comm
         if args.n1_ref > 0:
             out['scaling_efficiency'] = round(out['value'] / (world * args.n1_ref), 4)
+        if world == 1 and not args.no_batch_sweep:
+            out['batch_sweep'] = batch_sweep(dev)
         if world == 1:
             out['roofline_loss_b192'] = loss_b192_line(dev)
             if not args.no_retrieval:

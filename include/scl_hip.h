@@ -15,10 +15,12 @@
  *   - every pointer is a DEVICE pointer into caller-owned memory (HBM); the
  *     library allocates nothing and the compute entry points keep no state between calls,
  *     so they are re-entrant (the reference drives one session from three threads,
- *     train/train.py:967-975).  Three PROCESS-WIDE switches exist, none of which changes a
- *     result: the ablation selector of scl_debug_set_variant and the timing sink of
- *     scl_prof_begin / scl_prof_end (diagnostics, off by default) and the number of CUs the
- *     persistent grids leave free, scl_set_reserve_cus (see "Diagnostics" at the end);
+ *     train/train.py:967-975).  Three PROCESS-WIDE switches exist: the timing sink of
+ *     scl_prof_begin / scl_prof_end (changes no result), the number of CUs the persistent grids
+ *     leave free, scl_set_reserve_cus (deterministic for a fixed value; weight gradients differ in
+ *     rounding between values), and the ablation selector of scl_debug_set_variant (diagnostics,
+ *     0 by default: several values give MEANINGLESS results by design; see "Diagnostics" at the
+ *     end);
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and
  *     no entry point synchronises;
  *   - every function returns 0 on success, a negative SCL_E_* code for a rejected
@@ -510,11 +512,20 @@ int scl_debug_set_variant(int variant);
 /* CUs the persistent convolution grids leave free for other kernels (RCCL's, with more than one
  * rank per node: DESIGN.md section 4).  Default: the environment variable SCL_RESERVE_CUS, or 0.
  * Process-wide; takes effect at the next launch; returns the previous value; a negative n
- * re-reads the environment.  Results do not depend on it (fixed-order reductions). */
+ * re-reads the environment.  Results are deterministic for a fixed value (fixed-order reductions);
+ * between values the weight and bias gradients differ in ROUNDING: the weight-gradient kernels cut
+ * the pixels into one slab per usable CU, so the number of partial sums — and the order in which
+ * they are added — follows the setting.  Record the value next to anything that must be
+ * reproduced bit for bit (bench.py prints it in `switches`; checkpoints carry it in their
+ * metadata).  The fused NetVLAD kernels (csrc/netvlad.hip) do not honour it: their grids are
+ * one workgroup per (image, location slice). */
 int scl_set_reserve_cus(int n);
 int scl_prof_begin(int capacity);
 int scl_prof_count(void);
 int scl_prof_end(float* ms, const char** names, int capacity);
+/* Launches an empty kernel (256 x 256 threads) through the same bracket: its event duration minus
+ * its device time is what the bracket adds to every kernel (bench.py's correction). */
+int scl_prof_null(void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Host utility for the checkpoint bundle reader / writer (tf_bundle.py; the reference

@@ -109,6 +109,7 @@ SIGNATURES = {
     "scl_prof_begin": (_i, [_i]),
     "scl_prof_count": (_i, []),
     "scl_prof_end": (_i, [_p, _p, _i]),
+    "scl_prof_null": (_i, [_p]),
     "scl_crc32c": (ctypes.c_uint, [ctypes.c_uint, _p, _z]),
 }
 

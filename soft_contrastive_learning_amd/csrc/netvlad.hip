@@ -3187,7 +3187,7 @@ extern "C" int scl_netvlad_fwd_p(const void* x, int x_dtype, const float* assign
                    kVladFusedLds, st, fa);
     } else {
       if (save && scl_debug_variant == 918)
-        SCL_LAUNCH("vlad_fwd8_kernel<true, true>", (vlad_fwd8_kernel<true, true>), dim3(B, pl.S), dim3(512),
+        SCL_LAUNCH("vlad_fwd8_kernel<stamps>", (vlad_fwd8_kernel<true, true>), dim3(B, pl.S), dim3(512),
                    kVlad8Lds, st, fa);
       else if (save)
         SCL_LAUNCH("vlad_fwd8_kernel<true>", vlad_fwd8_kernel<true>, dim3(B, pl.S), dim3(512), kVlad8Lds,

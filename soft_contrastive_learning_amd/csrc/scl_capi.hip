@@ -85,6 +85,18 @@ extern "C" int scl_prof_end(float* ms, const char** names, int capacity) {
   return n;
 }
 
+// A kernel that does nothing, launched like every other kernel of the library (256 workgroups of
+// 256 threads): what the event bracket of SCL_LAUNCH measures beyond a kernel's own duration is
+// the bracket of THIS launch minus its device time (rocprofv3: profiles/r04/null_kernel_bracket.txt).
+// bench.py subtracts that from every event-bracketed duration it reports.
+__global__ void scl_null_kernel(int* p) {
+  if (p && threadIdx.x == 0 && blockIdx.x == 0x7fffffff) *p = 0;
+}
+extern "C" int scl_prof_null(void* stream) {
+  SCL_LAUNCH("scl_null_kernel", scl_null_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, (int*)nullptr);
+  return scl_launch_status();
+}
+
 // ---- CRC-32C for checkpoint bundles (host only; slice-by-8 tables) ------------------------
 namespace {
 struct Crc32cTables {

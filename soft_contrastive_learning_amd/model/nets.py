@@ -1107,9 +1107,15 @@ class VGG16NetVLAD(torch.nn.Module):
                 and image_batch.shape[0] >= 2):
             dev = image_batch.device
             key = (dev, threading.get_ident())              # a pair of streams per calling thread
-            split = _FWD_STREAMS.get(key)
-            if split is None:
-                split = _FWD_STREAMS[key] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+            with _PACKED_LOCK:
+                split = _FWD_STREAMS.get(key)
+                if split is None:
+                    # (streams of threads that have ended are dropped here: short-lived
+                    # evaluation threads would otherwise leak a pair each)
+                    alive = {t.ident for t in threading.enumerate()}
+                    for k in [k for k in _FWD_STREAMS if k[1] not in alive]:
+                        del _FWD_STREAMS[k]
+                    split = _FWD_STREAMS[key] = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
             cur = torch.cuda.current_stream(dev)
             split[0].wait_stream(cur)
             split[1].wait_stream(cur)

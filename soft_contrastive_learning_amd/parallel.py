@@ -222,15 +222,18 @@ class GradBuckets:
 
     def zero(self):
         """Zero all gradients in one memset and re-arm the buckets."""
-        # join first: if finish() was skipped (an exception, a dropped step after backward) side
-        # stream kernels may still be writing gradients into the flat buffer, and their late
-        # writes would survive the memset into the next step
+        # If finish() was skipped (an exception, a dropped step after backward) two things may
+        # still be touching the flat buffer: all-reduces launched from the abandoned backward pass
+        # (their late result would land in the next step's gradients) and side-stream kernels
+        # writing weight gradients.  Wait for both before the memset.
+        for h in self._handles:
+            h.wait()
+        self._handles = []
         self._join_streams()
         self._keep = []
         self.flat.zero_()
         self._remaining = [len(m) for m in self._members]
         self._reported = {}
-        self._handles = []
 
     def finish(self):
         """Wait for the collectives launched during backward (call before optimizer.step)."""

@@ -127,9 +127,16 @@ def test_config1_head_matches_oracle_on_the_hip_conv5_3_map(config1, mode):
     assert _maxrel(r['emb'], want_emb) < 1e-4
     want_loss = float(O.wms_loss(config1['dmat'][None], want_emb, 0.8, 15.0))
     assert abs(r['loss'] - want_loss) <= 1e-4 * abs(want_loss), (r['loss'], want_loss)
-    # (d loss / d embeddings: test_config1_head_gradient_on_spread_descriptors — the uniform-noise
-    # images of this fixture give 24 nearly parallel descriptors, on which every gradient row
-    # M_i . E is a difference of almost equal terms and no tight bound is meaningful)
+    # d loss / d embeddings against the float64 twin on the oracle's descriptors, at the DEFAULT
+    # initialisation — the regime bench.py runs.  The uniform-noise images of this fixture give 24
+    # nearly parallel descriptors (all similarities > 0.99), so every gradient row M_i . E is a
+    # difference of nearly equal terms: the float32 error, ~1e-7 of sum_j |M_ij| |E_j|, is amplified
+    # by that cancellation (measured 2.3e-4 norm-relative on MI355X), hence the looser bound here;
+    # test_config1_head_gradient_on_spread_descriptors holds 2e-4 on descriptors that spread out.
+    if 'gemb' in r:
+        e64 = torch.tensor(want_emb, dtype=torch.float64, requires_grad=True)
+        TT.wms_loss(config1['dmat'][None], e64, 0.8, 15.0).backward()
+        assert _nrel(r['gemb'], e64.grad.numpy()) < 1e-3
 
 
 def test_config1_head_gradient_on_spread_descriptors(dev):
