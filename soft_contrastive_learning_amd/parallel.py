@@ -84,6 +84,48 @@ def ms_loss_dp(labels, local_embeddings, group=None, **kw):
     return losses.ms_loss(labels, full, _rows=rows, **kw)
 
 
+class _MeanOverRanks(torch.autograd.Function):
+    """Scalar mean over this rank's tuples -> mean over the tuples of ALL ranks (every rank holds
+    the same number of tuples); backward: d global / d local = 1 / world on every rank."""
+
+    @staticmethod
+    def forward(ctx, local, group):
+        ctx.world = dist.get_world_size(group)
+        total = local.detach().clone()
+        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+        return total / ctx.world
+
+    @staticmethod
+    def backward(ctx, grad):
+        return grad / ctx.world, None
+
+
+def tuple_loss_dp(local_loss, group=None):
+    """The per-tuple losses (triplet / quadruplet families, log-ratio, the distance-term losses:
+    a mean over tuples of terms that each involve one tuple only) shard BY TUPLE (SURVEY section
+    8e): every rank evaluates the loss of its own tuples with the HIP kernels, this makes the scalar
+    the mean over all ranks' tuples — the single-process loss on the concatenated batch — and
+    scales the local gradient by 1 / world; ``GradBuckets`` then SUMS the parameter gradients.
+    No embedding travels: the only collectives are this scalar and the gradient buckets."""
+    return _MeanOverRanks.apply(local_loss, group)
+
+
+def all_gather_ragged(local, group=None):
+    """Rows of every rank, concatenated in rank order, for row counts that may differ by rank
+    (mining-cache descriptors, image indices): padded to the longest, gathered, trimmed."""
+    world = dist.get_world_size(group)
+    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c) for c in counts]
+    longest = max(counts)
+    pad = torch.zeros((longest,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    return torch.cat([p[:c] for p, c in zip(parts, counts)], 0)
+
+
 def topn_l2_sharded(ref_shard, query, n, shard_offset, group=None, score='f32', local_fn=None):
     """Retrieval with the reference set sharded over ranks: every rank scans
     its own rows ``[shard_offset, shard_offset + len(ref_shard))`` for all (replicated)

@@ -156,6 +156,9 @@ def compute_loss(flags, tuple_shape, output, distances, local_rows=None, group=N
             return parallel.wms_loss_dp(distances, output, flags.alpha, flags.beta, group=group,
                                         wfunction=flags.wfunction, sumfunction=flags.sumfunction)
         return parallel.ms_loss_dp(distances, output, group=group, ms_mining=flags.msmining)
+    if group is not None and loss in SUPPORTED_LOSSES:
+        # per-tuple losses shard by tuple: the local mean, then the mean over ranks
+        return parallel.tuple_loss_dp(compute_loss(flags, tuple_shape, output, distances), group)
     outs = torch.split(output.reshape(t, s, -1), tuple_shape, dim=1)       # :654
     if loss == 'triplet':
         return pointnetvlad_cls.triplet_loss(outs[0], outs[1], outs[2], flags.margin_1)
@@ -214,17 +217,19 @@ class SyntheticTuples:
         dtype = distance_type(f.loss)
         gb = t * s * self.world
         xy = self.rng.uniform(0.0, 200.0, size=(gb, 2))         # same on every rank
+        mine = slice(self.rank * t, (self.rank + 1) * t)        # per-tuple payloads: this rank's tuples
         if dtype == 'wms':
             # sklearn pairwise_distances(all, all, 'euclidean') (:557-563), rank-3 [T,S,S]
             d = np.sqrt(((xy[:, None] - xy[None]) ** 2).sum(2)).astype(np.float32)[None]
         elif dtype == 'anchor':
             # squared metres anchor -> positives inside max_pos_radius (:529-533), [T,P]
             d = self.rng.uniform(0.0, f.max_pos_radius ** 2,
-                                 (t, f.positives_per_tuple)).astype(np.float32)
+                                 (t * self.world, f.positives_per_tuple)).astype(np.float32)[mine]
         elif dtype == 'logratio':
             p, n = f.positives_per_tuple, f.negatives_per_tuple      # squared metres (:569-571)
-            d = np.concatenate([self.rng.uniform(1, 15 ** 2, (t, p)),
-                                self.rng.uniform(15 ** 2, 200 ** 2, (t, n))], 1).astype(np.float32)
+            d = np.concatenate([self.rng.uniform(1, 15 ** 2, (t * self.world, p)),
+                                self.rng.uniform(15 ** 2, 200 ** 2, (t * self.world, n))],
+                               1).astype(np.float32)[mine]
         elif f.loss == 'ms_loss':
             # labels built in build_model (:822-826), globally unique across ranks
             p = f.positives_per_tuple
@@ -270,10 +275,23 @@ def open_sets(flags, epoch):
 
 
 def train_dataset_epoch(flags, epoch, state, log):
-    """``train_one_epoch`` (train/train.py:987-1109) on this process's device."""
+    """``train_one_epoch`` (train/train.py:987-1109) on this process's device.
+
+    With more than one rank (``state['group']``; new work, the reference is single-GPU) a step takes
+    ``tuples_per_batch`` anchors PER RANK: rank r trains on anchors [r t, (r + 1) t) of every
+    block of world * t, with its own sampler stream (seeded by (epoch, rank)); a batch dropped on
+    one rank ('Faulty training batch') is dropped on all of them (one MIN all-reduce of a flag per
+    step), the per-tuple losses become the mean over all ranks' tuples (parallel.tuple_loss_dp),
+    the pairwise losses take the gathered batch (for wms the ranks exchange the image indices and
+    build the full distance matrix from the poses every rank holds), the mining cache is
+    extracted in shards and all-gathered, and rank 0 alone logs and writes checkpoints; the
+    evaluations run on every rank alike (no collective inside them)."""
     from . import evaluate, mining
     from .sampler import InputPipeline, TupleSampler
     model, opt, buckets, saver, dev = (state[k] for k in ('model', 'opt', 'buckets', 'saver', 'dev'))
+    group = state.get('group')
+    world = dist.get_world_size(group) if group is not None else 1
+    rank = dist.get_rank(group) if group is not None else 0
     tuple_shape = state['tuple_shape']
     t, s_img = flags.tuples_per_batch, flags.tuples_per_batch * sum(state['tuple_shape'])
     local_ref, local_query, other_ref, other_query = open_sets(flags, epoch)
@@ -286,7 +304,9 @@ def train_dataset_epoch(flags, epoch, state, log):
                             flags.negatives_per_tuple, flags.max_pos_radius, flags.min_neg_radius,
                             flags.hard_positives_per_tuple, flags.hard_negatives_per_tuple,
                             flags.mutually_exclusive_negs, dtype, cache if use_cache else None,
-                            flags.mining_cache_size, np.random.RandomState(42 + epoch))
+                            flags.mining_cache_size,
+                            np.random.RandomState(42 + epoch if world == 1 or not use_cache
+                                                  else [42 + epoch, rank]))
     sampler = make_sampler(local_ref, True)
     other_sampler = make_sampler(other_ref, False)
     pipe = InputPipeline(sampler, local_ref.load_images, tuple_shape, use_hard_negatives=True,
@@ -294,32 +314,57 @@ def train_dataset_epoch(flags, epoch, state, log):
     anchors = np.random.RandomState(1000 + epoch).permutation(
         np.arange(0, len(local_ref), max(flags.train_ref_r, 1)))
     if flags.steps > 0:
-        anchors = anchors[:flags.steps * t]
+        anchors = anchors[:flags.steps * t * world]           # --steps = batches per rank
     # whole batches only: compute_loss / batch_distances reshape with tuples_per_batch, a short
     # tail batch would raise at the end of the epoch, before the epoch checkpoint is written
-    anchors = anchors[:(len(anchors) // t) * t]
+    anchors = anchors[:(len(anchors) // (t * world)) * (t * world)]
     lr = get_learning_rate(epoch, flags)
     for g in opt.param_groups:
         g['lr'] = lr
 
     def loss_of(distances, images):
+        """Single-process loss (the evaluation on the other region: every rank alike)."""
         out = nets.vgg16Netvlad(images)
         return compute_loss(flags, tuple_shape, out, batch_distances(flags, distances, dev))
 
+    def train_loss(distances, images, indices):
+        out = nets.vgg16Netvlad(images)
+        if group is None:
+            return compute_loss(flags, tuple_shape, out, batch_distances(flags, distances, dev))
+        if flags.loss == 'wms':
+            # the global batch's pairwise geographic distances (train/train.py:557-563) from the
+            # poses of ALL ranks' images: the indices travel, every rank holds the poses
+            idx_all = parallel.all_gather_ragged(
+                torch.as_tensor(np.asarray(indices, dtype=np.int64), device=dev), group).cpu().numpy()
+            xy = np.asarray(local_ref.xy, dtype=np.float64)[idx_all]
+            dmat = np.sqrt(((xy[:, None] - xy[None]) ** 2).sum(2)).astype(np.float32)[None]
+            payload = torch.as_tensor(dmat).to(dev)
+        elif flags.loss == 'ms_loss':
+            payload = batch_distances(flags, distances, dev, world=world)   # globally unique labels
+        else:
+            payload = batch_distances(flags, distances, dev)
+        return compute_loss(flags, tuple_shape, out, payload, group=group)
+
     def train_on(item):
-        if item is None:
+        have = 0 if item is None else 1
+        if group is not None:                                   # a batch dropped anywhere is dropped everywhere
+            flag = torch.tensor([have], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            have = int(flag)
+        if not have:
             return                                              # 'Faulty training batch'
-        distances, images, _ = item
+        distances, images, indices = item
         buckets.zero()
-        loss = loss_of(distances, torch.from_numpy(images).to(dev))
+        loss = train_loss(distances, torch.from_numpy(images).to(dev), indices)
         loss.backward()
         buckets.finish()
         opt.step()
         state['step'] += 1
         rec = {'step': state['step'], 'epoch': epoch, 'loss': float(loss.detach()),
                'learning_rate': lr}
-        print('Train batch loss: {}'.format(rec['loss']))          # :289
-        log(rec)
+        if rank == 0:
+            print('Train batch loss: {}'.format(rec['loss']))      # :289
+            log(rec)
 
     def drain(outstanding):
         while outstanding:
@@ -329,20 +374,34 @@ def train_dataset_epoch(flags, epoch, state, log):
 
     outstanding, mining_count = 0, 0
     try:
-        for step in range(0, len(anchors), t):
-            if step % flags.mining_step == 0:                        # :1014-1068
+        stride = t * world
+
+        def due(every):
+            """The reference's `step % every == 0` (one rank); with several ranks a step covers
+            `stride` anchors and the cadence fires when a multiple lies inside it."""
+            return step % every == 0 if world == 1 else step % every < stride
+        for step in range(0, len(anchors), stride):
+            if due(flags.mining_step):                               # :1014-1068
                 outstanding = drain(outstanding)
                 mining_indices = np.arange(mining_count * flags.mining_cache_size,
                                            (mining_count + 1) * flags.mining_cache_size) % len(local_ref)
                 to_mine = anchors[step:min(step + flags.mining_step, len(anchors))]
                 mining_indices = np.concatenate([mining_indices, to_mine])
-                feats = evaluate.extract_features(model, local_ref, mining_indices, s_img)
+                if group is None:
+                    feats = evaluate.extract_features(model, local_ref, mining_indices, s_img)
+                else:                        # each rank embeds a contiguous share, rank order = list order
+                    share = np.array_split(mining_indices, world)[rank]
+                    feats = parallel.all_gather_ragged(
+                        evaluate.extract_features(model, local_ref, share, s_img)
+                        if len(share) else torch.zeros((0, 32768), device=dev), group)
                 cache.update(feats, mining_indices)
                 mining_count += 1
-                log({'step': state['step'], 'event': 'mining_cache', 'images': int(len(mining_indices))})
-            if step % flags.eval_step == 0:                          # :1070-1092
+                if rank == 0:
+                    log({'step': state['step'], 'event': 'mining_cache', 'images': int(len(mining_indices))})
+            if due(flags.eval_step):                                 # :1070-1092
                 outstanding = drain(outstanding)
-                saver.save_rolling(model, state['step'], opt)
+                if rank == 0:
+                    saver.save_rolling(model, state['step'], opt)
                 test_number = state['step'] // flags.eval_step
                 nq = (flags.num_eval_queries // t) * t
                 test_idx = np.arange(test_number * nq, (test_number + 1) * nq) % len(other_ref)
@@ -358,12 +417,14 @@ def train_dataset_epoch(flags, epoch, state, log):
                                   (test_number + 1) * flags.num_eval_queries) % len(qset)
                     metrics, _ = evaluate.evaluate_localization(model, rset, refs, qset, q, s_img)
                     rec[mode] = metrics
-                print('Other region loss: {}'.format(ev))            # :1144
-                log(rec)
-            if step % flags.save_step == 0:                          # :1094-1102
+                if rank == 0:
+                    print('Other region loss: {}'.format(ev))        # :1144
+                    log(rec)
+            if due(flags.save_step):                                 # :1094-1102
                 outstanding = drain(outstanding)
-                saver.save_part(model, state['step'], opt)
-            pipe.put(anchors[step:step + t])
+                if rank == 0:
+                    saver.save_part(model, state['step'], opt)
+            pipe.put(anchors[step + rank * t:step + (rank + 1) * t])
             outstanding += 1
             if outstanding > 1:                                      # one batch stays in flight
                 train_on(pipe.get())
@@ -371,7 +432,8 @@ def train_dataset_epoch(flags, epoch, state, log):
         drain(outstanding)
     finally:
         pipe.close()
-    saver.save_epoch(model, epoch, state['step'], opt)               # :984
+    if rank == 0:
+        saver.save_epoch(model, epoch, state['step'], opt)           # :984
 
 
 def main(argv=None):
@@ -381,15 +443,21 @@ def main(argv=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # TEST ONLY (SCL_TRAIN_ONE_GPU_GLOO=1): every rank on cuda:0 with gloo carrying the collectives —
+    # the data-parallel routes on a one-GPU box (tests/test_gpu_dist.py)
+    one_gpu = os.environ.get('SCL_TRAIN_ONE_GPU_GLOO') == '1'
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     group = None
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if one_gpu:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
         group = dist.group.WORLD
-        if flags.loss not in ('wms', 'ms_loss'):
-            raise SystemExit('data-parallel training shards the pairwise losses (wms, ms_loss)')
 
     np.random.seed(42)                                    # train/train.py:1463-1464
     tuple_shape = tuple_shape_for(flags.loss, flags.positives_per_tuple,
@@ -415,15 +483,13 @@ def main(argv=None):
         os.makedirs(out_dir, exist_ok=True) or True) else None
 
     if flags.synthetic_dataset > 0 or flags.shuffled_root:
-        if world > 1:
-            raise SystemExit('the dataset route runs one process (the reference is single-GPU); '
-                             'the data-parallel step is exercised by the default route')
         state = dict(model=model, opt=opt, buckets=buckets, saver=saver, dev=dev,
-                     tuple_shape=tuple_shape, step=step)
+                     tuple_shape=tuple_shape, step=step, group=group)
 
         def write(rec):
-            log.write(json.dumps(rec) + '\n')
-            log.flush()
+            if log is not None:
+                log.write(json.dumps(rec) + '\n')
+                log.flush()
         try:
             for epoch in range(flags.max_epoch):
                 train_dataset_epoch(flags, epoch, state, write)

@@ -207,3 +207,91 @@ def test_sharded_retrieval_equals_single_process():
         d, i = res[rank]
         assert torch.equal(i, want_i)
         assert torch.allclose(d, want_d, rtol=0, atol=0)
+
+
+# ---- per-tuple losses shard by tuple ------------------------------------------
+def _tuple_batch(seed=3):
+    """Two tuples (one per rank) of [anchor, 3 positives, 3 negatives, other] in E = 16."""
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(WORLD, 8, 6, generator=gen, dtype=torch.float64)
+    w = torch.randn(6, 16, generator=gen, dtype=torch.float64)
+    return x, w
+
+
+def _tuple_losses(out, kind):
+    """The float64 autograd twins of the per-tuple losses on out [T, 8, E] (oracle = test infrastructure)."""
+    from oracle import twin_torch as TT
+    q, pos, neg, oth = out[:, :1], out[:, 1:4], out[:, 4:7], out[:, 7:]
+    if kind == 'triplet':
+        return TT.triplet_loss(q, pos, neg, 0.5)
+    if kind == 'lazy_quadruplet':
+        return TT.lazy_quadruplet_loss(q, pos, neg, oth, 0.5, 0.2)
+    sp = torch.tensor([[1.0], [4.0], [9.0]], dtype=torch.float64)[None]
+    sn = torch.tensor([[400.0], [900.0], [2500.0]], dtype=torch.float64)[None]
+    # the log-ratio loss takes one tuple per call (the reference's broadcasting, SURVEY A8): the
+    # mean over tuples of the per-tuple values is what a batch of T = 1 calls gives
+    return torch.stack([TT.logratio_loss(q[k:k + 1], pos[k:k + 1], neg[k:k + 1], sp, sn)
+                        for k in range(out.shape[0])]).mean()
+
+
+def _tuple_worker(rank, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=WORLD)
+    try:
+        from soft_contrastive_learning_amd import parallel
+        x, w = _tuple_batch()
+        res = {}
+        for kind in ('triplet', 'lazy_quadruplet', 'logratio'):
+            p = torch.nn.Parameter(w.clone())
+            buckets = parallel.GradBuckets([p])
+            buckets.zero()
+            local = _tuple_losses(torch.tanh(x[rank:rank + 1] @ p), kind)
+            loss = parallel.tuple_loss_dp(local)
+            loss.backward()
+            buckets.finish()
+            res[kind] = (float(loss), p.grad.clone())
+        out[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_tuple_losses_shard_by_tuple():
+    """parallel.tuple_loss_dp: the loss of a rank's own tuples -> the mean over all ranks' tuples,
+    local gradients scaled by 1 / world and SUMMED by GradBuckets == the single-process loss and
+    gradient on the concatenated batch, for triplet, lazy_quadruplet and logratio."""
+    x, w = _tuple_batch()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_tuple_worker, args=(_free_port(), out), nprocs=WORLD, join=True)
+    for kind in ('triplet', 'lazy_quadruplet', 'logratio'):
+        p = w.clone().requires_grad_(True)
+        want = _tuple_losses(torch.tanh(x @ p), kind)
+        want.backward()
+        for rank in range(WORLD):
+            loss, grad = out[rank][kind]
+            assert abs(loss - float(want)) < 1e-12, (kind, rank)
+            torch.testing.assert_close(grad, p.grad, rtol=1e-10, atol=1e-12)
+
+
+def _ragged_worker(rank, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=WORLD)
+    try:
+        from soft_contrastive_learning_amd import parallel
+        rows = torch.arange(10, dtype=torch.float32).reshape(5, 2)
+        share = rows[:3] if rank == 0 else rows[3:]
+        out[rank] = parallel.all_gather_ragged(share)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_all_gather_ragged_concatenates_in_rank_order():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_ragged_worker, args=(_free_port(), out), nprocs=WORLD, join=True)
+    for rank in range(WORLD):
+        assert torch.equal(out[rank], torch.arange(10, dtype=torch.float32).reshape(5, 2))

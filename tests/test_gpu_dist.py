@@ -10,7 +10,9 @@ result), with small buckets (many collectives in flight during backward) and wit
 """
 import os
 import socket
+import sys
 
+import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
@@ -249,3 +251,106 @@ def test_bench_retrieval_workload_two_ranks_on_one_gpu():
         assert d['value'] > 0 and d['world_seen'] == gpus and 'scaling_efficiency' in d
         assert d['config']['refs'] == 20000 and d['config']['parallelism'] == 'ref-shard%d' % gpus
     assert recs[1]['checksum_idx'] == recs[2]['checksum_idx']
+
+
+# ---- per-tuple losses and the dataset route with several ranks ---------------
+def _tuple_dp_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import argparse
+        from soft_contrastive_learning_amd.train import train as T
+        dev = torch.device('cuda:0')
+        g = torch.Generator().manual_seed(77)
+        res = []
+        for loss_name in ('triplet', 'lazy_quadruplet', 'logratio', 'huber_distance_triplet'):
+            flags = T.make_parser().parse_args(['--loss', loss_name, '--positives_per_tuple', '3',
+                                                '--negatives_per_tuple', '3', '--tuples_per_batch', '1'])
+            shape = T.tuple_shape_for(loss_name, 3, 3)
+            s = sum(shape)
+            emb_all = torch.randn(world * s, 4096, generator=g)
+            emb_all = (emb_all / emb_all.norm(dim=1, keepdim=True)).to(dev)
+            if T.distance_type(loss_name) == 'logratio':
+                pay = torch.rand(world, 6, generator=g) * 50.0 + 1.0
+            elif T.distance_type(loss_name) == 'anchor':
+                pay = torch.rand(world, 3, generator=g) * 200.0
+            else:
+                pay = None
+            # single process on the concatenated batch (T = world tuples); the log-ratio loss takes
+            # one tuple per call, so its single-process value is the mean of the calls
+            ref = emb_all.clone().requires_grad_(True)
+            if loss_name == 'logratio':
+                parts = [T.compute_loss(flags, shape, ref[k * s:(k + 1) * s], pay[k:k + 1].to(dev))
+                         for k in range(world)]
+                want = torch.stack(parts).mean()
+            else:
+                fl2 = argparse.Namespace(**dict(vars(flags), tuples_per_batch=world))
+                want = T.compute_loss(fl2, shape, ref, None if pay is None else pay.to(dev))
+            want.backward()
+            mine = emb_all[rank * s:(rank + 1) * s].clone().requires_grad_(True)
+            got = T.compute_loss(flags, shape, mine, None if pay is None else pay[rank:rank + 1].to(dev),
+                                 group=dist.group.WORLD)
+            got.backward()
+            torch.cuda.synchronize()
+            wg = ref.grad[rank * s:(rank + 1) * s]
+            res.append((loss_name, abs(float(got) - float(want)) / max(abs(float(want)), 1e-30),
+                        float((mine.grad - wg).abs().max() / wg.abs().max().clamp_min(1e-30))))
+        out.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tuple_losses_two_ranks_on_one_gpu():
+    """train.compute_loss with a process group for the per-tuple losses (HIP kernels on the rank's own
+    tuple, parallel.tuple_loss_dp for the mean over ranks) against the single-process loss on the
+    concatenated batch: same value, and own-tuple gradients equal to the single-process rows."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a HIP device')
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tuple_dp_worker, args=(r, 2, port, out)) for r in range(2)]
+    _run_ranks(procs)
+    for rank, res in sorted(out.get(timeout=10) for _ in range(2)):
+        for name, lerr, gerr in res:
+            assert lerr <= 1e-6, (rank, name, lerr)
+            assert gerr <= 1e-5, (rank, name, gerr)
+
+
+@pytest.mark.parametrize('loss_name', ['wms', 'lazy_quadruplet'])
+def test_dataset_route_two_ranks_on_one_gpu(loss_name, tmp_path):
+    """`train.py --synthetic_dataset` with two ranks (both on cuda:0, gloo): sampler -> pipeline ->
+    step with the gathered batch (wms: image indices exchanged, distances from the shared poses) or the
+    tuple-sharded loss, sharded mining-cache refresh, evaluation on every rank, rank 0 writing the log
+    and the checkpoints — runs to the end and logs finite losses."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a HIP device')
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), SCL_TRAIN_ONE_GPU_GLOO='1', PYTHONPATH=root)
+        procs.append(subprocess.Popen(
+            [sys.executable, '-m', 'soft_contrastive_learning_amd.train.train', '--loss', loss_name,
+             '--synthetic_dataset', '120', '--height', '64', '--width', '80', '--positives_per_tuple', '3',
+             '--negatives_per_tuple', '3', '--hard_negatives_per_tuple', '1', '--hard_positives_per_tuple', '1',
+             '--steps', '6', '--max_epoch', '1', '--mining_step', '4', '--mining_cache_size', '16',
+             '--eval_step', '4', '--save_step', '4', '--num_eval_queries', '4', '--dtype', 'bf16',
+             '--out_root', str(tmp_path)], env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    for pr in procs:
+        try:
+            o, _ = pr.communicate(timeout=400)
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            o, _ = pr.communicate()
+        outs.append(o.decode(errors='replace'))
+    assert all(pr.returncode == 0 for pr in procs), outs
+    recs = [json.loads(line) for line in open(os.path.join(str(tmp_path), loss_name, 'train_log.txt'))]
+    losses = [r['loss'] for r in recs if 'loss' in r]
+    assert len(losses) >= 4 and all(np.isfinite(losses)), recs
+    assert any(r.get('event') == 'mining_cache' for r in recs)
+    assert any(r.get('event') == 'eval' for r in recs)
