@@ -519,6 +519,35 @@ def retrieval_line(dev, r=100000, q=10000, d=256, n=25, iters=3):
             row['scan_kernel'] = dict(kernel=scan_name, us=round(summ[scan_name][1] * 1e3, 1),
                                       **price_topn_scan(summ[scan_name][1], q, r, d, score))
         out[score] = row
+    # the in-training localisation check (train/train.py:1181-1182): the raw 32768-wide descriptors,
+    # 5 nearest of a few thousand references for a few dozen queries — nomination from the inner
+    # products of topn_dots_kernel (float32 matrix instructions in chunks of 256, float64 across)
+    gen = torch.Generator(device=dev).manual_seed(13)
+    rw, qw, dw, nw = 2000, 50, E, 5
+    refw = torch.randn(rw, dw, device=dev, generator=gen)
+    refw = refw / refw.norm(dim=1, keepdim=True)
+    qryw = refw[torch.randperm(rw, device=dev, generator=gen)[:qw]] + 0.05 * torch.randn(
+        qw, dw, device=dev, generator=gen) / dw ** 0.5
+    st = {}
+    retrieval.topn_l2(refw, qryw, nw, stats=st)
+    torch.cuda.synchronize()
+    with _lib.KernelTimer(capacity=64) as kt:
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            retrieval.topn_l2(refw, qryw, nw, stats=st)
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / iters
+    summ = kt.summary()
+    dots_ms = summ.get('topn_dots_kernel', (0, 0.0))[1]
+    out['localisation_width'] = {
+        'workload': 'train/train.py:1181-1182 shape: %d references x %d queries x %d (unit-norm), exact top-%d, '
+                    'certified' % (rw, qw, dw, nw),
+        'queries_per_sec': round(qw / wall, 1), 'ms_per_call': round(wall * 1e3, 3),
+        'uncertified_queries': st.get('uncertified'),
+        'dots_kernel': dict(kernel='topn_dots_kernel', us=round(max(dots_ms * 1e3 - BRACKET_US, 0.0), 1),
+                            tflops=round(2.0 * rw * qw * dw / max(dots_ms * 1e-3 - BRACKET_US * 1e-6, 1e-9) / 1e12, 2),
+                            peak_tflops=PEAK_F32_TFLOPS,
+                            note='64 x 64 tiles x 16 feature-axis splits = 512 workgroups at this shape')}
     return out
 
 

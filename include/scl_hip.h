@@ -271,6 +271,18 @@ int scl_topn_exact_filter(const float* ref, int R, const float* query, int d, co
                           int nq, const double* bound_sq, int cap, int* count, double* cand_d,
                           int* cand_i, void* stream);
 
+/* Inner products of a block of queries with a block of references for descriptors of ANY width
+ * (the in-training localisation check on the raw 32768-wide descriptors, train/train.py:1181-1182;
+ * evaluation/top-n.py's sweep over d): out [splits,Q,R] float64; summed over the splits (by the
+ * caller, in float64), out[q,r] = sum over chunks of 256 features of the chunk's float32-FMA
+ * chain, the chunks added in float64, so that |sum - q.r| <= 1.53e-5 |q||r| + 2^-53 (d / 256 + 1)
+ * |q.r| for every d (the bound the caller's exactness certificate uses;
+ * evaluation/retrieval._topn_wide).  splits >= 1 cuts the feature axis into runs of whole chunks
+ * (one grid layer each: small query / reference blocks then still fill the chip); no split may be
+ * empty: splits <= ceil(d / 256) and (splits - 1) * ceil(ceil(d / 256) / splits) < ceil(d / 256). */
+int scl_topn_dots(const float* ref, int R, const float* query, int Q, int d, int splits, double* out,
+                  void* stream);
+
 /* ------------------------------------------------------------------------- *
  * VGG16 backbone glue — the elementwise ops between the convolutions of
  * model/nets.py:27-63 (tf.layers.conv2d's bias add, tf.nn.relu,

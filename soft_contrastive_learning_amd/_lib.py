@@ -73,6 +73,7 @@ SIGNATURES = {
     "scl_topn_l2_ex": (_i, [_p, _i, _p, _i, _i, _i, _l, _p, _p, _p, _z, _i, _p]),
     "scl_topn_l2_cert": (_i, [_p, _i, _p, _i, _i, _i, _l, _p, _p, _p, _p, _p, _z, _i, _p]),
     "scl_topn_exact_filter": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p, _p]),
+    "scl_topn_dots": (_i, [_p, _i, _p, _i, _i, _i, _p, _p]),
     "scl_vgg_workspace_bytes": (_z, [_i]),
     "scl_vgg_bias_act": (_i, [_p, _i, _p, _l, _i, _i, _p]),
     "scl_vgg_act_bwd": (_i, [_p, _p, _i, _l, _i, _p, _p, _p, _z, _p]),

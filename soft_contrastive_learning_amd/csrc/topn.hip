@@ -778,3 +778,104 @@ extern "C" int scl_topn_exact_filter(const float* ref, int R, const float* query
              dim3(256), 0, st, ref, R, query, d, qlist, bound_sq, cap, count, cand_d, cand_i);
   return scl_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------
+// topn_dots_kernel: the inner products q.r of a block of queries with a block of references for
+// descriptors of ANY width (round 4: the in-training localisation check runs on the raw
+// 32768-wide descriptors, train/train.py:1181-1182; evaluation/top-n.py sweeps d up to 4096).
+// The nomination of evaluation/retrieval._topn_wide used the library's float64 GEMM here.
+//
+// Arithmetic chosen for a WIDTH-INDEPENDENT error bound: inside a chunk of 256 features the
+// products run on the float32 matrix cores (v_mfma_f32_32x32x2_f32: a k-ordered chain of fused
+// multiply-adds, one rounding each), the chunk sums are added in float64.  For any summation
+// order of a length-k chain |fl(x.y) - x.y| <= gamma_k |x||y|, gamma_k = k u / (1 - k u), u =
+// 2^-24; summed over chunks (Cauchy-Schwarz) the float32 part is <= gamma_256 |q||r| = 1.53e-5
+// |q||r| whatever d is, the float64 part 2^-53 (d / 256 + 1) relative.  retrieval._topn_wide turns
+// that into its per-query certificate.
+// grid (ceil(R / 64), ceil(Q / 64)), block 256: wave w = 32 queries x 32 references of the 64 x 64
+// tile; both operand tiles staged through LDS 128 features at a time (rows of 129 floats: the
+// 32 lanes of a fragment read hit 32 banks).
+constexpr int DT_CH = 128, DT_LD = DT_CH + 1, DT_CHUNK = 256;
+constexpr size_t kDotsLds = 2 * (size_t)64 * DT_LD * sizeof(float);
+
+// blockIdx.z = split of the feature axis (whole chunks of 256 each): its partial sums go to
+// out[z][Q][R]; the caller adds the splits in float64 (a few dozen queries against a few thousand
+// references are 32 tiles: without the split the launch leaves 7/8 of the chip idle).
+__global__ __launch_bounds__(256) void topn_dots_kernel(const float* __restrict__ ref, int R,
+                                                        const float* __restrict__ qry, int Q, int d,
+                                                        int chunks_per_split, double* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float dt_lds[];
+  float* qs = dt_lds;
+  float* rs = dt_lds + 64 * DT_LD;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int r0 = blockIdx.x * 64, q0 = blockIdx.y * 64;
+  const int qi = (wid >> 1) * 32, rj = (wid & 1) * 32;
+  const bool vec = (d & 3) == 0 && (((uintptr_t)ref | (uintptr_t)qry) & 15) == 0;
+  double acc64[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) acc64[k] = 0.0;
+  const int d_lo = blockIdx.z * chunks_per_split * DT_CHUNK;
+  const int d_hi = d_lo + chunks_per_split * DT_CHUNK < d ? d_lo + chunks_per_split * DT_CHUNK : d;
+  out += (int64_t)blockIdx.z * Q * R;
+  for (int c0 = d_lo; c0 < d_hi; c0 += DT_CHUNK) {
+    f32x16 acc = zero16();
+    const int c1 = c0 + DT_CHUNK < d_hi ? c0 + DT_CHUNK : d_hi;
+    for (int s0 = c0; s0 < c1; s0 += DT_CH) {
+      __syncthreads();
+      // stage [64 rows][128 features] of both operands (zeros past the matrix / the chunk)
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int row = (threadIdx.x >> 5) + 8 * it, col = (threadIdx.x & 31) * 4;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const float* src = m ? ref : qry;
+          const int grow = (m ? r0 : q0) + row, nrows = m ? R : Q;
+          float v[4] = {0.f, 0.f, 0.f, 0.f};
+          if (grow < nrows) {
+            const float* p = src + (int64_t)grow * d + s0 + col;
+            if (vec && s0 + col + 4 <= c1) {
+              const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+              v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (s0 + col + e < c1) v[e] = p[e];
+            }
+          }
+          float* dst = (m ? rs : qs) + row * DT_LD + col;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dst[e] = v[e];
+        }
+      }
+      __syncthreads();
+      const float* qa = qs + (qi + (lane & 31)) * DT_LD + (lane >> 5);
+      const float* rb = rs + (rj + (lane & 31)) * DT_LD + (lane >> 5);
+#pragma unroll 16
+      for (int k = 0; k < DT_CH; k += 2) acc = mfma32(qa[k], rb[k], acc);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc64[k] += (double)acc[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int q = q0 + qi + acc_row(k, lane >> 5), r = r0 + rj + (lane & 31);
+    if (q < Q && r < R) out[(int64_t)q * R + r] = acc64[k];
+  }
+}
+
+extern "C" int scl_topn_dots(const float* ref, int R, const float* query, int Q, int d, int splits,
+                             double* out, void* stream) {
+  if (!ref || !query || !out) return SCL_E_NULL;
+  if (R < 1 || Q < 1 || d < 1 || splits < 1 || splits > 65535) return SCL_E_SHAPE;
+  const int chunks = (d + DT_CHUNK - 1) / DT_CHUNK;
+  const int per = (chunks + splits - 1) / splits;
+  if ((int64_t)(splits - 1) * per >= chunks && splits > 1) return SCL_E_SHAPE;   // an empty split
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&topn_dots_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDotsLds);
+  });
+  SCL_LAUNCH("topn_dots_kernel", topn_dots_kernel, dim3((R + 63) / 64, (Q + 63) / 64, splits), dim3(256),
+             kDotsLds, (hipStream_t)stream, ref, R, query, Q, d, per, out);
+  return scl_launch_status();
+}

@@ -30,8 +30,8 @@ def topn_l2(ref, query, n, idx_offset=0, score='f32', certify=True, stats=None):
     resolved by an exact float64 pass over every reference (``scl_topn_exact_filter``), so the
     index lists are exact with no assumption on the data.  ``stats`` (a dict) receives
     ``uncertified`` = how many queries took that path.  Descriptors wider than 256 take
-    ``_topn_wide`` (float64 nomination by library GEMM, its own certificate of the same kind;
-    ``score`` does not apply there)."""
+    ``_topn_wide`` (nomination from the inner products of ``scl_topn_dots``, its own certificate
+    of the same kind; ``score`` does not apply there)."""
     lib = L.load()
     if score not in SCORE_MODES:
         raise ValueError("score must be one of %s, got %r" % (sorted(SCORE_MODES), score))
@@ -46,7 +46,7 @@ def topn_l2(ref, query, n, idx_offset=0, score='f32', certify=True, stats=None):
     if n > MAX_N or n > r or n < 1:
         raise ValueError("n must be in [1, min(%d, R)], got n=%d R=%d" % (MAX_N, n, r))
     if d > 256:
-        return _topn_wide(ref, query, n, idx_offset, certify, stats)
+        return _topn_wide(ref.contiguous(), query.contiguous(), n, idx_offset, certify, stats)
     if d not in (32, 64, 128, 256):
         # zero-padding the feature axis leaves every distance unchanged
         pad = next(c for c in (32, 64, 128, 256) if d <= c)
@@ -134,46 +134,70 @@ def _brute_force_f64(ref, qv, n, chunk=65536):
     return best_d, best_i
 
 
-def _topn_wide(ref, query, n, idx_offset, certify=True, stats=None):
+def _topn_wide(ref, query, n, idx_offset, certify=True, stats=None, dots_fn=None):
     """Descriptors wider than 256 (the in-training localisation check runs the KDTree on the
     raw 32768-d vectors, train/train.py:1181-1182; evaluation/top-n.py sweeps d up to 4096).
 
-    Nomination in FLOAT64: s(q, r) = |q|^2 + |r|^2 - 2 q.r with the products from the library's
-    float64 GEMM, blocks of queries x references, the best 32 per query kept across blocks.
-    Those 32 are re-ranked with the direct float64 sum((q - r)^2) — the tree's arithmetic —
-    and ordered by (distance, index).
+    Nomination: s(q, r) = |q|^2 + |r|^2 - 2 q.r with the inner products from the library's own
+    kernel ``scl_topn_dots`` (csrc/topn.hip: float32 matrix instructions inside chunks of 256
+    features, float64 across chunks; round 3 used the float64 library GEMM here), norms in
+    float64, blocks of queries x references, the best 32 per query kept across blocks.  Those 32
+    are re-ranked with the direct float64 sum((q - r)^2) — the tree's arithmetic — and ordered
+    by (distance, index).
 
     Certificate (no assumption on the data): every reference OUTSIDE the nominated set has
-    s >= tau (the largest nominated score), and |s - D| <= eps for the exact squared distance D
-    with eps = 2 (d + 8) 2^-53 (|q| + R_max)^2 — the standard bound gamma_d |x||y| of a
-    length-d float64 inner product in ANY summation order (so it holds for whatever blocking
-    the library GEMM uses; it does not hold for Strassen-type kernels, which rocBLAS's dgemm is
-    not), the same for the two norms, two more roundings for the sums, and a factor 2 of safety.
-    So if the n-th exact distance among the nominated is strictly below tau - eps (inflated by
-    the direct form's own 2 (d + 2) 2^-53 relative error), no outsider can reach it.  Queries
-    that fail the test — exact or 1e-11-near duplicates around the n-th neighbour, or more
-    than 32 references within eps — are resolved by ``_brute_force_f64`` over every reference.
-    ``stats['uncertified']`` counts them."""
+    s >= tau (the largest nominated score), and |s - D| <= eps for the exact squared distance D,
+    with eps = 2 [2 gamma |q| R_max + (d + 8) 2^-53 (|q| + R_max)^2]: gamma = 256 u / (1 - 256 u),
+    u = 2^-24, bounds a 256-long float32 FMA chain in ANY order, chunks combine by Cauchy-Schwarz
+    (so the bound does not grow with d), the second term covers the float64 chunk sums, the two
+    norms and the final additions, and the leading 2 is safety.  So if the n-th exact distance
+    among the nominated is strictly below tau - eps (inflated by the direct form's own
+    2 (d + 2) 2^-53 relative error), no outsider can reach it.  Queries that fail the test — near
+    duplicates around the n-th neighbour within eps (6e-5 in squared distance for unit
+    descriptors), or more than 32 references that close — are resolved by ``_brute_force_f64``
+    over every reference.  ``stats['uncertified']`` counts them.
+
+    ``dots_fn(ref_block, query_block) -> [Q, R] float64`` replaces the HIP kernel in the CPU
+    tests of the logic around it (tests/test_retrieval_wide.py: the same chunked arithmetic in
+    NumPy); the product path has no such argument and no CPU fallback."""
+    lib = L.load() if dots_fn is None else None
     r, d = ref.shape
     q = query.shape[0]
     dev = ref.device
     u = 2.0 ** -53
+    g32 = 256.0 * 2.0 ** -24 / (1.0 - 256.0 * 2.0 ** -24)
     qb_max = 512
-    rb = max(256, min(8192, (1 << 27) // d))                  # <= 1 GB of float64 per ref block
+    rb = 8192
     out_d = torch.empty((q, n), dtype=torch.float64, device=dev)
     out_i = torch.empty((q, n), dtype=torch.int64, device=dev)
-    rn_all = torch.cat([(ref[a:a + rb].double() ** 2).sum(1) for a in range(0, r, rb)])
+    sb = max(256, (1 << 27) // d)                             # <= 1 GB of float64 per norm block
+    rn_all = torch.cat([(ref[a:a + sb].double() ** 2).sum(1) for a in range(0, r, sb)])
     r_max = float(rn_all.max().sqrt())
     uncertified = 0
+    # feature-axis splits: enough grid layers to put a workgroup on every CU for small blocks
+    chunks = -(-d // 256)
+    tiles = -(-min(q, qb_max) // 64) * -(-min(r, rb) // 64)
+    splits = max(1, min(chunks, 16, 512 // max(tiles, 1)))
+    while splits > 1 and (splits - 1) * -(-chunks // splits) >= chunks:
+        splits -= 1
+    dots = torch.empty(splits * min(q, qb_max) * min(r, rb), dtype=torch.float64, device=dev)
     for qs in range(0, q, qb_max):
-        qq = query[qs:qs + qb_max].double()
-        qb = qq.shape[0]
-        qn = (qq * qq).sum(1)
+        qblk = query[qs:qs + qb_max]
+        qb = qblk.shape[0]
+        qn = torch.cat([(qblk[a:a + sb].double() ** 2).sum(1) for a in range(0, qb, sb)])
         cand_s, cand_i = [], []
         for rs in range(0, r, rb):
-            rr = ref[rs:rs + rb].double()
-            sc = qn[:, None] + rn_all[None, rs:rs + rb] - 2.0 * (qq @ rr.T)
-            k = min(_KEEP, rr.shape[0])
+            rblk = ref[rs:rs + rb]
+            nr = rblk.shape[0]
+            if dots_fn is None:
+                dv = dots[:splits * qb * nr].view(splits, qb, nr)
+                L.check(lib.scl_topn_dots(L.ptr(rblk), nr, L.ptr(qblk), qb, d, splits, L.ptr(dv),
+                                          L.stream_of(ref)))
+                dv = dv.sum(0) if splits > 1 else dv[0]
+            else:
+                dv = dots_fn(rblk, qblk)
+            sc = qn[:, None] + rn_all[None, rs:rs + nr] - 2.0 * dv
+            k = min(_KEEP, nr)
             sv, iv = torch.topk(sc, k, dim=1, largest=False)
             cand_s.append(sv)
             cand_i.append(iv + rs)
@@ -184,7 +208,7 @@ def _topn_wide(ref, query, n, idx_offset, certify=True, stats=None):
         exact = torch.empty((qb, k), dtype=torch.float64, device=dev)
         step = max(1, (1 << 25) // (k * d))                               # <= 256 MB of float64
         for a in range(0, qb, step):
-            diff = qq[a:a + step][:, None, :] - ref[cand[a:a + step]].double()
+            diff = qblk[a:a + step].double()[:, None, :] - ref[cand[a:a + step]].double()
             exact[a:a + step] = (diff * diff).sum(-1)
         # order by (distance, index): stable sort by index first, then by distance
         o = torch.argsort(cand, dim=1, stable=True)
@@ -195,7 +219,8 @@ def _topn_wide(ref, query, n, idx_offset, certify=True, stats=None):
         out_i[qs:qs + qb] = torch.gather(cand, 1, o) + int(idx_offset)
         if certify and r > k:                    # (r <= 32: every reference was re-ranked)
             tau = top_s.max(dim=1).values
-            eps = 2.0 * (d + 8) * u * (qn.sqrt() + r_max) ** 2
+            qnorm = qn.sqrt()
+            eps = 2.0 * (2.0 * g32 * qnorm * r_max + (d + 8) * u * (qnorm + r_max) ** 2)
             ok = dn[:, n - 1] * (1.0 + 2.0 * (d + 2) * u) < tau - eps
             for qi in torch.nonzero(~ok).reshape(-1).tolist():
                 bd, bi = _brute_force_f64(ref, query[qs + qi], n)

@@ -1,7 +1,10 @@
 """The d > 256 retrieval path (evaluation/retrieval._topn_wide: the in-training localisation
 check on raw 32768-d descriptors, train/train.py:1181-1182, and top-n.py's d sweep above 256):
-float64 nomination + a PROVEN certificate + exact fallback.  The path is plain torch above a
-library GEMM, so its logic is tested on the CPU here and at d = 32768 on the GPU.
+nomination from the inner products of the library's own kernel (scl_topn_dots: float32 matrix
+instructions inside chunks of 256 features, float64 across them) + a PROVEN certificate + exact
+fallback.  The logic around the kernel is tested on the CPU with a NumPy stand-in of the same
+chunked arithmetic (oracle side: test infrastructure), the kernel itself at d = 300 / 320 / 32768 on
+the GPU.
 
 The adversarial set: more references than the 32 nominated candidates can hold whose exact
 squared distances to a query differ by ~1e-14 relative — below what the float64 Gram form
@@ -55,15 +58,26 @@ def check_against_tree(got_d, got_i, ref, qry, n, dup_rows, dup_query=5):
     np.testing.assert_allclose(got_d, want_d, rtol=1e-12, atol=1e-300)
 
 
+def chunked_dots(rblk, qblk):
+    """What scl_topn_dots computes, in NumPy: float32 products and sums inside chunks of 256
+    features, the chunk sums added in float64 (the summation order inside a chunk differs from the
+    kernel's; the certificate's bound holds for any order)."""
+    r32, q32 = rblk.numpy().astype(np.float32), qblk.numpy().astype(np.float32)
+    out = np.zeros((q32.shape[0], r32.shape[0]), np.float64)
+    for c in range(0, r32.shape[1], 256):
+        out += (q32[:, c:c + 256] @ r32[:, c:c + 256].T).astype(np.float64)
+    return torch.from_numpy(out)
+
+
 def test_wide_path_certificate_on_cpu():
     from soft_contrastive_learning_amd.evaluation import retrieval
     ref, qry, rows, dup_rows = adversarial_sets(400, 12, 300, 44, seed=5)
     st = {}
-    d, i = retrieval._topn_wide(torch.tensor(ref), torch.tensor(qry), 25, 0, True, st)
+    d, i = retrieval._topn_wide(torch.tensor(ref), torch.tensor(qry), 25, 0, True, st, dots_fn=chunked_dots)
     check_against_tree(d.numpy(), i.numpy(), ref, qry, 25, dup_rows)
     assert 2 <= st['uncertified'] <= 4, st              # the two adversarial queries
     # the nomination alone does get the adversarial query wrong here (or the test is too easy)
-    d0, i0 = retrieval._topn_wide(torch.tensor(ref), torch.tensor(qry), 25, 0, False, st)
+    d0, i0 = retrieval._topn_wide(torch.tensor(ref), torch.tensor(qry), 25, 0, False, st, dots_fn=chunked_dots)
     assert st['uncertified'] is None
     _, want_i = TN.topn_kdtree(ref, qry, 25)
     ok = np.ones(len(qry), bool)
@@ -77,13 +91,13 @@ def test_wide_path_separated_data_stays_certified_on_cpu():
     ref = rng.standard_normal((700, 320)).astype(np.float32)
     qry = rng.standard_normal((30, 320)).astype(np.float32)
     st = {}
-    d, i = retrieval._topn_wide(torch.tensor(ref), torch.tensor(qry), 5, 100, True, st)
+    d, i = retrieval._topn_wide(torch.tensor(ref), torch.tensor(qry), 5, 100, True, st, dots_fn=chunked_dots)
     want_d, want_i = TN.topn_kdtree(ref, qry, 5)
     np.testing.assert_array_equal(i.numpy(), want_i + 100)
     np.testing.assert_allclose(d.numpy(), want_d, rtol=1e-12)
     assert st['uncertified'] == 0
     # fewer references than candidates: everything is re-ranked, nothing to certify
-    d, i = retrieval._topn_wide(torch.tensor(ref[:20]), torch.tensor(qry), 5, 0, True, st)
+    d, i = retrieval._topn_wide(torch.tensor(ref[:20]), torch.tensor(qry), 5, 0, True, st, dots_fn=chunked_dots)
     np.testing.assert_array_equal(i.numpy(), TN.topn_kdtree(ref[:20], qry, 5)[1])
     assert st['uncertified'] == 0
 
@@ -98,4 +112,41 @@ def test_wide_path_certificate_at_the_localisation_width():
     st = {}
     d, i = retrieval.topn_l2(torch.tensor(ref, device=dev), torch.tensor(qry, device=dev), 5, stats=st)
     check_against_tree(d.cpu().numpy(), i.cpu().numpy(), ref, qry, 5, dup_rows)
+    assert 2 <= st['uncertified'] <= 4, st
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("r,q,d", [(400, 12, 300), (700, 30, 320), (3000, 70, 1025), (200, 3, 4096)])
+def test_wide_dots_kernel_within_its_stated_bound(r, q, d):
+    """scl_topn_dots against float64 inner products: |error| <= gamma_256 |q||r| (+ the float64
+    chunk sums) — the bound _topn_wide's certificate is built on — at widths that are not
+    multiples of the chunk or of the 16-byte loads, and tiles that are not full."""
+    from soft_contrastive_learning_amd import _lib as L
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(d)
+    ref = rng.standard_normal((r, d)).astype(np.float32)
+    qry = rng.standard_normal((q, d)).astype(np.float32)
+    splits = 1 if d < 1024 else 3
+    out = torch.empty((splits, q, r), dtype=torch.float64, device=dev)
+    rt, qt = torch.tensor(ref, device=dev), torch.tensor(qry, device=dev)
+    L.check(L.load().scl_topn_dots(L.ptr(rt), r, L.ptr(qt), q, d, splits, L.ptr(out), L.stream_of(rt)))
+    out = out.sum(0)
+    want = qry.astype(np.float64) @ ref.astype(np.float64).T
+    g32 = 256 * 2.0 ** -24 / (1 - 256 * 2.0 ** -24)
+    bound = g32 * np.linalg.norm(qry.astype(np.float64), axis=1)[:, None] * np.linalg.norm(
+        ref.astype(np.float64), axis=1)[None] + 2.0 ** -50 * np.abs(want)
+    err = np.abs(out.cpu().numpy() - want)
+    assert (err <= bound).all(), float((err / bound).max())
+    # typical error sits two orders below the worst-case bound
+    assert float((err / bound).max()) < 0.2
+
+
+@pytest.mark.gpu
+def test_wide_path_on_the_gpu_at_the_cpu_test_shapes():
+    from soft_contrastive_learning_amd.evaluation import retrieval
+    dev = torch.device('cuda:0')
+    ref, qry, rows, dup_rows = adversarial_sets(400, 12, 300, 44, seed=5)
+    st = {}
+    d, i = retrieval.topn_l2(torch.tensor(ref, device=dev), torch.tensor(qry, device=dev), 25, stats=st)
+    check_against_tree(d.cpu().numpy(), i.cpu().numpy(), ref, qry, 25, dup_rows)
     assert 2 <= st['uncertified'] <= 4, st
