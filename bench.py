@@ -187,6 +187,8 @@ def kernel_models(b, n, gb, x_bytes, slices=10):
         # loss: raw Gram (upper-triangular tile pairs), reads E once
         'gram_partial_kernel': dict(flops=2.0 * gb * gb * E, bytes=gb * E * 4),
         'gram16_kernel': dict(flops=2.0 * gb * gb * E, bytes=gb * E * 4),
+        # round 4, B <= 32: the finish rides in the Gram kernel's last workgroup (one launch)
+        'gram16_fused_kernel': dict(flops=2.0 * gb * gb * E + 48.0 * gb * gb, bytes=gb * E * 4),
         # 64 < B <= 256: the same Gram from six bf16 plane products (float32-equivalent);
         # SURVEY §8(d) prices the B = 192 Gram on the float32 MFMA peak
         'gram16x6_kernel': dict(flops=2.0 * gb * gb * E, bytes=gb * E * 4),

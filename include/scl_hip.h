@@ -161,6 +161,17 @@ int scl_gram_loss_fwd(const float* emb, int64_t ld_emb, int B, int E, int mask_k
                       const int64_t* labels, float alpha, float beta, float lamb, float eps,
                       int ms_mining, int sum_kind, float* loss_out, float* coef,
                       void* workspace, size_t workspace_bytes, void* stream);
+/* The same with a SYNC BLOCK (B <= 32: the forward is then ONE launch — the Gram kernel, whose last
+ * workgroup to arrive runs the finish — instead of two).  sync_words: at least 4 bytes of device
+ * memory that are ZERO when the call is enqueued and that no other call in flight uses; the
+ * library leaves them zero, so one zero-initialised block per (device, stream) serves every
+ * call.  NULL, or B > 32: exactly scl_gram_loss_fwd.  The results are bit-identical either way
+ * (same sums in the same order). */
+int scl_gram_loss_fwd_s(const float* emb, int64_t ld_emb, int B, int E, int mask_kind,
+                        const float* distances, int dist_rank3, float d_alpha, float d_beta,
+                        const int64_t* labels, float alpha, float beta, float lamb, float eps,
+                        int ms_mining, int sum_kind, float* loss_out, float* coef, void* workspace,
+                        size_t workspace_bytes, void* sync_words, void* stream);
 
 /* grad_emb[r, :] = (*grad_loss) * sum_j coef[row_begin + r, j] * emb[j, :]
  * for r in [0, row_count): a data-parallel rank asks only for its own rows.

@@ -57,6 +57,8 @@ SIGNATURES = {
     "scl_gram_loss_workspace_bytes": (_z, [_i, _i]),
     "scl_gram_loss_fwd": (_i, [_p, _l, _i, _i, _i, _p, _i, _f, _f, _p, _f, _f, _f, _f, _i, _i, _p,
                                _p, _p, _z, _p]),
+    "scl_gram_loss_fwd_s": (_i, [_p, _l, _i, _i, _i, _p, _i, _f, _f, _p, _f, _f, _f, _f, _i, _i, _p,
+                                 _p, _p, _z, _p, _p]),
     "scl_gram_loss_bwd": (_i, [_p, _l, _i, _i, _p, _p, _i, _i, _p, _l, _p]),
     "scl_pairwise_sqdist_workspace_bytes": (_z, [_i, _i, _i]),
     "scl_pairwise_sqdist": (_i, [_p, _i, _i, _i, _p, _p, _z, _p]),
@@ -168,6 +170,27 @@ def ptr(t):
 
 def stream_of(t):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+_SYNC = {}
+_SYNC_LOCK = __import__('threading').Lock()
+
+
+def sync_words(device):
+    """The zero-initialised sync block of the calling thread's current stream on ``device`` (64
+    bytes; scl_gram_loss_fwd_s: zero on entry, zero on return).  One per (device, stream, thread):
+    two calls that could be in flight at once never share one."""
+    import threading
+    key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream,
+           threading.get_ident())
+    with _SYNC_LOCK:
+        t = _SYNC.get(key)
+        if t is None:
+            alive = {th.ident for th in threading.enumerate()}
+            for k in [k for k in _SYNC if k[2] not in alive]:
+                del _SYNC[k]
+            t = _SYNC[key] = torch.zeros(64, dtype=torch.uint8, device=device)
+    return t
 
 
 def workspace(nbytes, device):

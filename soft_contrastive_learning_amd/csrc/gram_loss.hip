@@ -576,11 +576,41 @@ __device__ __forceinline__ void decode_pair16(int pair, int T, int& ti, int& tj)
 // slabs: [S][P][256]: accumulator register j of lane l at [l * 4 + j] = Gram entry
 // (row 16 ti + 4 (l >> 4) + j, column 16 tj + (l & 15)).
 // FULL: every wave owns exactly PWMAX pairs (no guard in the pair loop).
-template <int PWMAX, bool FULL>
-__global__ __launch_bounds__(256) void gram16_kernel(const float* __restrict__ emb, int64_t ld,
-                                                     int B, int E, int T, int P, int kchunk,
-                                                     int KS, int vec_ok,
-                                                     float* __restrict__ slabs) {
+// write-through (sc1) 16-byte store / L1-bypassing (sc1) load: the hand-off of the fused finish
+// (MI355X_MICROARCH.md, "Valid forms": every handed-off byte stored sc1 and drained before ONE lane's
+// agent-scope ticket add, every load of them sc1 behind the last ticket holder's add — no release,
+// no acquire).
+__device__ __forceinline__ void st_sc1_x4(float* p, f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+// (the loads go through the buffer-load builtin with aux = 16 = sc1, so that hipcc tracks their
+// destinations: an asm load's destination register is unprotected until the wait, and a copy
+// hipcc placed right behind one read stale bits — found as a launch failure)
+__device__ __forceinline__ f32x4 ld_sc1_x4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 16));
+}
+
+// Arguments of the finish that rides in the LAST workgroup of gram16_kernel to arrive (B <= 32,
+// round 4): what gram_final32_kernel takes, plus the arrival counter.
+struct FinalArgs {
+  unsigned* counter;          // one word of the caller's sync block: zero on entry, zero on return
+  const float* distances;
+  const int64_t* labels;
+  LossParams lp;
+  float* coef;
+  float* loss_out;
+};
+template <int NT>
+__device__ void final32_body(float* lds, const float* slabs, int S, int T, int P, int B,
+                             const FinalArgs& fa);
+
+// FUSE (gram16_fused_kernel, 1024 threads): the first four waves run the Gram exactly as the
+// 256-thread kernel does, the other twelve only keep its barriers company until the finish, which
+// (in the last workgroup to arrive) wants sixteen waves: a half-wave per row, all rows at once.
+template <int PWMAX, bool FULL, bool FUSE>
+__device__ __forceinline__ void gram16_body(const float* __restrict__ emb, int64_t ld, int B, int E, int T,
+                                            int P, int kchunk, int KS, int vec_ok,
+                                            float* __restrict__ slabs, const FinalArgs& fa) {
   extern __shared__ __attribute__((aligned(16))) float g16_lds[];
   // the wave index must be PROVABLY wave-uniform: everything derived from it (pair range, k
   // range) then lives in scalar registers and the pair loop has scalar branches; as a plain
@@ -595,6 +625,16 @@ __global__ __launch_bounds__(256) void gram16_kernel(const float* __restrict__ e
   const int qmask = (1 << qshift) - 1;
   const int total_q = Bp << qshift;
 
+  // (FUSE: waves 4..15 only match the barriers of the Gram part: one behind the staging, two more
+  // around the cross-wave sums when the k ranges are split)
+  const bool worker = !FUSE || wid < 4;                       // (wid is a scalar: a scalar branch)
+  if (!worker) {
+    __syncthreads();
+    if (KS != 1) {
+      __syncthreads();
+      __syncthreads();
+    }
+  } else {
   // ---- stage the slice: every load is issued before the first LDS write.  The common case
   //      (aligned rows, slice inside E) has NO branch around a load: a guarded load makes hipcc
   //      wait for each one before issuing the next (16 serial round trips measured here).
@@ -691,27 +731,75 @@ __global__ __launch_bounds__(256) void gram16_kernel(const float* __restrict__ e
   if (KS == 1) {
 #pragma unroll
     for (int lp = 0; lp < PWMAX; ++lp)
-      if (FULL || lp < np)
-        *reinterpret_cast<f32x4*>(slab + (int64_t)(p_begin + lp) * 256 + 4 * lane) = acc[lp];
-    return;
-  }
-  // k ranges on different waves: fixed-order sum through LDS (the staged slice is dead)
-  __syncthreads();
-  f32x4* red = reinterpret_cast<f32x4*>(g16_lds);          // [KS][P][64]
+      if (FULL || lp < np) {
+        if (FUSE)
+          st_sc1_x4(slab + (int64_t)(p_begin + lp) * 256 + 4 * lane, acc[lp]);
+        else
+          *reinterpret_cast<f32x4*>(slab + (int64_t)(p_begin + lp) * 256 + 4 * lane) = acc[lp];
+      }
+    if (!FUSE) return;
+  } else {
+    // k ranges on different waves: fixed-order sum through LDS (the staged slice is dead)
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(g16_lds);          // [KS][P][64]
 #pragma unroll
-  for (int lp = 0; lp < PWMAX; ++lp)
-    if (FULL || lp < np) red[((int64_t)kq * P + p_begin + lp) * 64 + lane] = acc[lp];
-  __syncthreads();
-  for (int idx = threadIdx.x; idx < P * 64; idx += 256) {
-    f32x4 v = red[idx];
-    if (KS == 2) {
-      v += red[P * 64 + idx];
-    } else {
-      const f32x4 v1 = red[P * 64 + idx], v2 = red[2 * P * 64 + idx], v3 = red[3 * P * 64 + idx];
-      v = (v + v1) + (v2 + v3);
+    for (int lp = 0; lp < PWMAX; ++lp)
+      if (FULL || lp < np) red[((int64_t)kq * P + p_begin + lp) * 64 + lane] = acc[lp];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < P * 64; idx += 256) {
+      f32x4 v = red[idx];
+      if (KS == 2) {
+        v += red[P * 64 + idx];
+      } else {
+        const f32x4 v1 = red[P * 64 + idx], v2 = red[2 * P * 64 + idx], v3 = red[3 * P * 64 + idx];
+        v = (v + v1) + (v2 + v3);
+      }
+      if (FUSE)
+        st_sc1_x4(slab + 4 * (int64_t)idx, v);
+      else
+        *reinterpret_cast<f32x4*>(slab + 4 * (int64_t)idx) = v;
     }
-    *reinterpret_cast<f32x4*>(slab + 4 * (int64_t)idx) = v;
   }
+  }
+  if constexpr (FUSE) {
+    // ---- the workgroup whose slab arrives last finishes the loss (round 4: the forward at B <= 32
+    // was this kernel + a one-workgroup finish kernel, each at the floor of a dependent launch).
+    // Write-through slab stores -> every wave drains its stores -> barrier -> lane 0 draws a ticket
+    // (agent-scope add).  The last ticket holder puts the counter back to zero (nobody touches it
+    // afterwards: the caller's word is zero again when the call returns) and runs the finish on
+    // all slabs with L1-bypassing loads — the same fixed-order sums as gram_final32_kernel: same
+    // bits.  (A first version with plain stores, a release fence per workgroup and an acquire in
+    // the last one took 20 us against 14 for the two launches: the fences cost more than a launch.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(g16_lds);
+    if (threadIdx.x == 0) {
+      const unsigned old = __hip_atomic_fetch_add(fa.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = old == gridDim.x - 1;
+      if (last) __hip_atomic_store(fa.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *flag = last;
+    }
+    __syncthreads();
+    const int last = *flag;
+    __syncthreads();
+    if (!last) return;
+    final32_body<1024>(g16_lds, slabs, gridDim.x, T, P, B, fa);
+  }
+}
+
+template <int PWMAX, bool FULL>
+__global__ __launch_bounds__(256) void gram16_kernel(const float* __restrict__ emb, int64_t ld,
+                                                     int B, int E, int T, int P, int kchunk,
+                                                     int KS, int vec_ok,
+                                                     float* __restrict__ slabs) {
+  gram16_body<PWMAX, FULL, false>(emb, ld, B, E, T, P, kchunk, KS, vec_ok, slabs, FinalArgs{});
+}
+template <int PWMAX, bool FULL>
+__global__ __launch_bounds__(1024) void gram16_fused_kernel(const float* __restrict__ emb, int64_t ld,
+                                                            int B, int E, int T, int P, int kchunk,
+                                                            int KS, int vec_ok,
+                                                            float* __restrict__ slabs, FinalArgs fa) {
+  gram16_body<PWMAX, FULL, true>(emb, ld, B, E, T, P, kchunk, KS, vec_ok, slabs, fa);
 }
 
 
@@ -1070,6 +1158,95 @@ __global__ __launch_bounds__(1024) void gram_final32_kernel(
   }
 }
 
+// The finish of gram_final32_kernel as a device function for the 1024 threads of the last gram16
+// workgroup: the same sums in the same order (four slab groups s = g, g + 4, .. added in batches
+// of 16, then (g0 + g1) + (g2 + g3)), the same row evaluation (a half-wave per row, all rows at
+// once).  Slabs come in through L1-bypassing loads (see st_sc1_x4).  LDS (>= 24 KB of the caller's
+// dynamic block): Gr[32][33] | Gc[32][33] | rn[32] | rowloss[32] | part[4][192] x 16 B.
+template <int NT>
+__device__ void final32_body(float* lds, const float* slabs, int S, int T, int P, int B,
+                             const FinalArgs& fa) {
+  static_assert(NT == 1024, "a half-wave per row");
+  float(*Gr)[33] = reinterpret_cast<float(*)[33]>(lds);
+  float(*Gc)[33] = reinterpret_cast<float(*)[33]>(lds + 32 * 33);
+  float* rn = lds + 2 * 32 * 33;
+  float* rowloss = rn + 32;
+  f32x4* part = reinterpret_cast<f32x4*>(lds + 2 * 32 * 33 + 64);       // [4][192]
+  const LossParams& lp = fa.lp;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int ri = 2 * wid + (lane >> 5), rj = lane & 31;      // this lane's (row, column)
+  const bool rok = ri < B && rj < B;
+  float dval = 0.f;
+  int same = 0;
+  if (rok) {
+    if (lp.mask_kind == SCL_MASK_LABELS)
+      same = fa.labels[rj] == fa.labels[ri];
+    else
+      dval = lp.dist_rank3 ? fa.distances[(int64_t)rj * B + ri] : fa.distances[(int64_t)ri * B + rj];
+  }
+  {
+    const int grp = threadIdx.x >> 8, idx = threadIdx.x & 255;
+    constexpr int U = 16;
+    f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+    if (idx < P * 64) {
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(slabs), 0, S * P * 1024, 0x00020000);
+      for (int s0 = grp; s0 < S; s0 += 4 * U) {
+        f32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {                          // (branch-free: clamped, masked below)
+          const int sidx = s0 + 4 * u < S ? s0 + 4 * u : S - 1;
+          v[u] = ld_sc1_x4(rsrc, (unsigned)((sidx * P * 64 + idx) * 16));
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc4 += s0 + 4 * u < S ? v[u] : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      part[grp * 192 + idx] = acc4;
+    }
+    __syncthreads();
+    if (threadIdx.x < P * 64) {
+      const f32x4 v = (part[idx] + part[192 + idx]) + (part[2 * 192 + idx] + part[3 * 192 + idx]);
+      const int pair = idx >> 6, l = idx & 63;
+      int ti, tj;
+      decode_pair16(pair, T, ti, tj);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = 16 * ti + 4 * (l >> 4) + j, c = 16 * tj + (l & 15);
+        Gr[r][c] = v[j];
+        if (ti != tj) Gr[c][r] = v[j];
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 32) rn[threadIdx.x] = 1.0f / sqrtf(fmaxf(Gr[threadIdx.x][threadIdx.x], 1e-12f));
+  __syncthreads();
+  const float invB = 1.0f / (float)B;
+  float gnv[1], dv[1], gv[1];
+  int sv[1];
+  gnv[0] = rok ? Gr[ri][rj] * rn[ri] * rn[rj] : 0.f;
+  dv[0] = dval;
+  sv[0] = same;
+  const float rl = wave_row_eval<1, true>(ri, B, rj, gnv, dv, sv, lp, invB, gv);
+  if (rok) Gc[ri][rj] = gv[0];
+  if (rj == 0 && ri < B) rowloss[ri] = rl;
+  __syncthreads();
+  if (wid == 0) {
+    float a = lane < B ? rowloss[lane] : 0.f;
+    a = wave_sum(a);
+    if (lane == 0) *fa.loss_out = a / (float)B;
+  }
+  if (!fa.coef) return;
+  const float gs = rok ? Gc[ri][rj] + Gc[rj][ri] : 0.f;
+  const float c = half_sum(rok ? gs * gnv[0] : 0.f);
+  if (rok) {
+    const float rni = rn[ri];
+    const bool clamped = rni >= 1.0e6f;   // see gram_coef_kernel
+    float m = rni * rn[rj] * gs;
+    if (rj == ri && !clamped) m -= rni * rni * c;
+    fa.coef[(int64_t)ri * B + rj] = m;
+  }
+}
+
 // grid P; block 256: full raw Gram (both triangles) = fixed-order sum of the S slabs of one
 // tile pair.  Wave w adds slabs s = w, w + 4, ...; the four partial sums meet in LDS.
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restrict__ slabs, int S,
@@ -1256,6 +1433,22 @@ void launch_gram16(const Gram16Plan& p, const float* emb, int64_t ld, int B, int
   SCL_LAUNCH("gram16_kernel", (gram16_kernel<PWMAX, FULL>), dim3(p.S), dim3(256), lds, st, emb, ld, B, E,
              p.T, p.P, p.kchunk, p.KS, vec_ok, slabs);
 }
+// B <= 32 with the finish inside: the last workgroup to arrive runs it
+template <int PWMAX, bool FULL>
+void launch_gram16_fused(const Gram16Plan& p, const float* emb, int64_t ld, int B, int E, int vec_ok,
+                         float* slabs, const FinalArgs& fa, hipStream_t st) {
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16_fused_kernel<PWMAX, FULL>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024);
+  });
+  size_t lds = (size_t)16 * p.T * (p.kchunk + 4) * sizeof(float);
+  const size_t red = p.KS > 1 ? (size_t)p.KS * p.P * 64 * sizeof(f32x4) : 0;
+  if (red > lds) lds = red;
+  if (lds < 24 * 1024) lds = 24 * 1024;                       // final32_body's tables
+  SCL_LAUNCH("gram16_fused_kernel", (gram16_fused_kernel<PWMAX, FULL>), dim3(p.S), dim3(1024), lds, st,
+             emb, ld, B, E, p.T, p.P, p.kchunk, p.KS, vec_ok, slabs, fa);
+}
 
 }  // namespace
 
@@ -1270,7 +1463,19 @@ extern "C" int scl_gram_loss_fwd(const float* emb, int64_t ld_emb, int B, int E,
                                  float lamb, float eps, int ms_mining, int sum_kind,
                                  float* loss_out, float* coef, void* workspace,
                                  size_t workspace_bytes, void* stream) {
+  return scl_gram_loss_fwd_s(emb, ld_emb, B, E, mask_kind, distances, dist_rank3, d_alpha, d_beta, labels,
+                             alpha, beta, lamb, eps, ms_mining, sum_kind, loss_out, coef, workspace,
+                             workspace_bytes, nullptr, stream);
+}
+
+extern "C" int scl_gram_loss_fwd_s(const float* emb, int64_t ld_emb, int B, int E, int mask_kind,
+                                   const float* distances, int dist_rank3, float d_alpha,
+                                   float d_beta, const int64_t* labels, float alpha, float beta,
+                                   float lamb, float eps, int ms_mining, int sum_kind,
+                                   float* loss_out, float* coef, void* workspace,
+                                   size_t workspace_bytes, void* sync_words, void* stream) {
   if (!emb || !loss_out || !workspace) return SCL_E_NULL;
+  if (sync_words && ((uintptr_t)sync_words % 4)) return SCL_E_SHAPE;
   if (B < 1 || E < 1 || B > kMaxB || ld_emb < E) return SCL_E_SHAPE;
   if (mask_kind < SCL_MASK_WMS_EXP || mask_kind > SCL_MASK_LABELS) return SCL_E_KIND;
   if (sum_kind != SCL_SUM_MS && sum_kind != SCL_SUM_PLAIN) return SCL_E_KIND;
@@ -1304,6 +1509,20 @@ extern "C" int scl_gram_loss_fwd(const float* emb, int64_t ld_emb, int B, int E,
         launch_gram16x6<20, true>(p.T, p.P, emb, ld_emb, B, E, w.slabs, st);
       else
         launch_gram16x6<34, false>(p.T, p.P, emb, ld_emb, B, E, w.slabs, st);
+    } else if (B <= 32 && sync_words && full && (pw == 1 || pw == 3) && scl_debug_variant != 32) {
+      // (32: the two-launch forward, for A/B)  one launch: the Gram and, in its last workgroup, the finish
+      FinalArgs fa;
+      fa.counter = (unsigned*)sync_words;
+      fa.distances = distances;
+      fa.labels = labels;
+      fa.lp = lp;
+      fa.coef = coef;
+      fa.loss_out = loss_out;
+      if (pw == 1)
+        launch_gram16_fused<1, true>(p, emb, ld_emb, B, E, vec_ok, w.slabs, fa, st);
+      else
+        launch_gram16_fused<3, true>(p, emb, ld_emb, B, E, vec_ok, w.slabs, fa, st);
+      return scl_launch_status();
     } else if (pw == 1 && full)
       launch_gram16<1, true>(p, emb, ld_emb, B, E, vec_ok, w.slabs, st);
     else if (pw == 3 && full)

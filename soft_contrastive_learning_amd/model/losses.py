@@ -54,11 +54,14 @@ class _GramLoss(torch.autograd.Function):
         if nbytes == 0:
             raise ValueError("unsupported batch / embedding size B=%d E=%d" % (b, e))
         ws = L.workspace(nbytes, emb.device)
-        L.check(lib.scl_gram_loss_fwd(
+        # B <= 32: with the stream's zeroed sync block the forward is one launch (the finish runs in
+        # the Gram kernel's last workgroup)
+        sync = L.sync_words(emb.device) if b <= 32 else None
+        L.check(lib.scl_gram_loss_fwd_s(
             L.ptr(emb), emb.stride(0), b, e, cfg['mask_kind'], L.ptr(distances),
             cfg['dist_rank3'], cfg['d_alpha'], cfg['d_beta'], L.ptr(labels), cfg['alpha'],
             cfg['beta'], cfg['lamb'], cfg['eps'], int(bool(cfg['ms_mining'])), cfg['sum_kind'],
-            L.ptr(loss), L.ptr(coef), L.ptr(ws), ws.numel(), L.stream_of(emb)))
+            L.ptr(loss), L.ptr(coef), L.ptr(ws), ws.numel(), L.ptr(sync), L.stream_of(emb)))
         ctx.rows = cfg.get('rows')
         if need_grad:
             ctx.save_for_backward(emb, coef)

@@ -342,3 +342,41 @@ def test_pairwise_distance_loss_and_grad(dev, t, p, e, huber):
     TT.pairwise_distance_loss(a64, p64, dd, 225.0, 2.0, huber=huber).backward()
     assert _rel(at.grad.cpu().numpy(), a64.grad.numpy()) < 2e-4
     assert _rel(pt.grad.cpu().numpy(), p64.grad.numpy()) < 2e-4
+
+
+# ---- round 4: the B <= 32 forward in one launch ---------------------------------------------------
+@pytest.mark.parametrize("b,e", [(2, 64), (7, 200), (16, 4096), (24, 32768), (25, 32768), (32, 32768)])
+@pytest.mark.parametrize("kind", ["wms_exp", "wms_tanh_plain", "ms"])
+def test_fused_finish_gives_the_bits_of_the_two_launch_forward(dev, b, e, kind):
+    """scl_gram_loss_fwd_s with the stream's sync block: the Gram kernel's last workgroup runs the
+    finish (same sums, same order).  scl_debug_set_variant(32) = the two-launch forward: loss and
+    d loss / d embeddings must be bit-identical, and the sync block must be zero afterwards."""
+    from soft_contrastive_learning_amd import _lib as L
+    from soft_contrastive_learning_amd.model import losses
+    emb = torch.tensor(U.embeddings(b, e), device=dev)
+    dm = torch.tensor(U.positions_distances(b)[None], device=dev)
+    lab = torch.tensor(np.arange(b) // 3, device=dev)
+
+    def run(variant):
+        x = emb.clone().requires_grad_(True)
+        L.load().scl_debug_set_variant(variant)
+        try:
+            if kind == "wms_exp":
+                loss = losses.wms_loss(dm, x, 0.8, 15.0)
+            elif kind == "wms_tanh_plain":
+                loss = losses.wms_loss(dm, x, 0.8, 15.0, wfunction='tanh', sumfunction='plain')
+            else:
+                loss = losses.ms_loss(lab, x)
+            loss.backward()
+            torch.cuda.synchronize()
+        finally:
+            L.load().scl_debug_set_variant(0)
+        return loss.detach().cpu().numpy(), x.grad.cpu().numpy()
+    l1, g1 = run(0)
+    l2, g2 = run(32)
+    assert l1.view(np.uint32) == l2.view(np.uint32)
+    assert np.array_equal(g1.view(np.uint32), g2.view(np.uint32))
+    assert int(L.sync_words(dev).sum()) == 0
+    for _ in range(20):                                       # the counter keeps returning to zero
+        l3, _ = run(0)
+        assert l3.view(np.uint32) == l1.view(np.uint32)
