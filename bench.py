@@ -206,6 +206,7 @@ def kernel_models(b, n, gb, x_bytes, slices=10):
         'gram_bwd_fast_kernel<2>': dict(flops=2.0 * b * gb * E, bytes=gb * E * 4 + b * E * 4),
         'gram_bwd_fast_kernel<4>': dict(flops=2.0 * b * gb * E, bytes=gb * E * 4 + b * E * 4),
         'gram_bwd_planes_kernel': dict(flops=2.0 * b * gb * E, bytes=gb * E * 4 + b * E * 4),
+        'gram_bwd_rows_kernel': dict(flops=2.0 * b * gb * E, bytes=gb * E * 4 + b * E * 4),
     }
 
 

@@ -1,29 +1,35 @@
 # Regenerates everything under profiles/rNN from one GPU box (run through gpurun; results land in
 # gpurun_out/rNN and are copied into profiles/rNN by hand).  Usage: bash scripts/collect_profiles.sh r03
 set -x
-RN=${1:-r03}
+RN=${1:-r04}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$RN; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 python3 $R/bench.py --steps 20 --warmup 5 > $O/bench_n1_default_run.json 2> $O/bench.err
 python3 $R/bench.py --steps 20 --warmup 5 --side-wrw 0 --no-cpu-baseline > $O/bench_n1_one_stream.json 2>> $O/bench.err
 # kernel trace of the default command, and of the one-stream run (the durations of `roofline`
 # are taken with the weight-gradient kernels serialised: compare with the second table)
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_under_rocprof.json 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace1 -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --side-wrw 0 > $O/bench_under_rocprof_one_stream.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-batch-sweep --no-retrieval > $O/bench_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace1 -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-batch-sweep --no-retrieval --side-wrw 0 > $O/bench_under_rocprof_one_stream.json 2>/dev/null
 # HBM traffic of the backbone kernels (separate passes per counter, no tracing)
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_bb/fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --side-wrw 0 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_bb/write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --side-wrw 0 > /dev/null 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc_bb/sq -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --side-wrw 0 > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_bb/fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-batch-sweep --no-retrieval --side-wrw 0 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_bb/write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-batch-sweep --no-retrieval --side-wrw 0 > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc_bb/sq -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-batch-sweep --no-retrieval --side-wrw 0 > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc_nv/sq -- python3 $R/scripts/microbench.py --what netvlad,loss --iters 3 --loss-batches 24,192 > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_nv/fetch -- python3 $R/scripts/microbench.py --what netvlad,loss --iters 3 --loss-batches 24,192 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_nv/write -- python3 $R/scripts/microbench.py --what netvlad,loss --iters 3 --loss-batches 24,192 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_nv -- python3 $R/scripts/microbench.py --what netvlad,loss --iters 20 --loss-batches 24,192 --netvlad-variants 920 > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc_tn/sq -- python3 $R/scripts/microbench.py --what topn --iters 20 --topn-score f32,bf16x3 > /dev/null 2>&1
 cd $R
-python3 scripts/microbench.py --iters 20 --topn-score f32,bf16x3 --json $O/microbench_netvlad_loss_topn.json > $O/microbench.log 2>&1
+cp $(ls $O/trace_nv/*/*kernel_stats.csv | head -1) $O/microbench_netvlad_loss_kernel_stats_rocprofv3.csv
+python3 scripts/pmc_summary.py $O/pmc_tn --only kernel --out $O/pmc_topn_sq_counters.csv > /dev/null 2>&1
+python3 scripts/microbench.py --iters 20 --topn-score f32,bf16x3 --topn-splits 1106,2106,4106 --json $O/microbench_netvlad_loss_topn.json > $O/microbench.log 2>&1
 python3 scripts/parity_report.py --json $O/parity_report.json > $O/parity.log 2>&1
 python3 bench.py --workload retrieval --steps 5 --warmup 2 > $O/bench_retrieval_n1_f32.json 2>> $O/bench.err
 python3 bench.py --workload retrieval --steps 5 --warmup 2 --score bf16x3 > $O/bench_retrieval_n1_bf16x3.json 2>> $O/bench.err
 python3 scripts/vlad_stamps.py --kernel fwd > $O/vlad_stamps_fwd.txt 2>/dev/null
+python3 scripts/vlad_stamps.py --kernel fwd8 > $O/vlad_stamps_fwd8.txt 2>/dev/null
 python3 scripts/vlad_stamps.py --kernel dx > $O/vlad_stamps_dx.txt 2>/dev/null
+python3 scripts/null_bracket.py > $O/null_bracket_events.txt 2>/dev/null
 python3 scripts/netvlad_accuracy_probe.py > $O/netvlad_two_plane_accuracy.txt 2>/dev/null
 python3 scripts/lds_conflicts.py > $O/lds_conflicts.txt 2>/dev/null
 python3 scripts/conv_ab.py --rounds 2 > $O/conv_lds_kernels_32x32x16_vs_16x16x32.jsonl 2>/dev/null
@@ -36,5 +42,5 @@ python3 scripts/kstats.py $(ls $O/trace/*/*kernel_trace.csv | head -1) > $O/benc
 python3 scripts/kstats.py $(ls $O/trace1/*/*kernel_trace.csv | head -1) > $O/bench_one_stream_kernel_trace_by_shape.txt
 cp $(ls $O/trace/*/*kernel_stats.csv | head -1) $O/bench_n1_kernel_stats_rocprofv3.csv
 cp $(ls $O/trace1/*/*kernel_stats.csv | head -1) $O/bench_n1_one_stream_kernel_stats_rocprofv3.csv
-rm -rf $O/trace $O/trace1 $O/pmc_nv $O/pmc_bb
+rm -rf $O/trace $O/trace1 $O/pmc_nv $O/pmc_bb $O/trace_nv $O/pmc_tn
 tail -3 $O/parity.log; tail -6 $O/trace_summary.log; head -c 600 $O/bench_n1_default_run.json

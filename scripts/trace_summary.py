@@ -5,7 +5,7 @@
     python scripts/trace_summary.py gpurun_out/trace --steps 4 --out profiles/rNN/....csv
 
 The window is the last ``--steps`` periods of a kernel that runs exactly once per step
-(default: gram_final32_kernel, the B <= 32 loss finish), so warm-up, MIOpen's find step and the
+(default: gram16_fused_kernel, the B <= 32 loss forward), so warm-up, MIOpen's find step and the
 CPU-baseline leg are excluded.  Reports, per kernel: launches per step, mean duration and
 milliseconds per step; plus the window's wall time and GPU-busy time (union of kernel
 intervals) per step.
@@ -30,7 +30,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('trace')
     ap.add_argument('--steps', type=int, default=4)
-    ap.add_argument('--marker', default='gram_final32_kernel')
+    ap.add_argument('--marker', default='gram16_fused_kernel')
     ap.add_argument('--out', default=None)
     ap.add_argument('--note', default='')
     ap.add_argument('--gaps', type=int, default=0,

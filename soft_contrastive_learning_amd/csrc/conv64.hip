@@ -247,6 +247,8 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
 
   const int dbg = relu >> 1;            // timing diagnostics (scl_debug_set_variant(60000 + bits))
   relu &= 1;
+  // (experiment, 60004: static priority for the younger half of an eight-wave workgroup)
+  if ((dbg & 4) && (threadIdx.x >> 6) >= 4) __builtin_amdgcn_s_setprio(1);
   int tile = blockIdx.x;
   if (tile < ntiles) {
     if (PL) {
@@ -1261,7 +1263,7 @@ int launch_conv3x3(const void* x, const void* w, int64_t sk, int64_t sc, int64_t
                (unsigned short*)workspace);
   const int tiles = B * ((H + Cfg::TH_ - 1) / Cfg::TH_) * ((W + TW - 1) / TW);
   const dim3 grid(tiles < cus ? tiles : cus);
-  if (scl_debug_variant / 1000 == 60) relu |= (scl_debug_variant & 3) << 1;
+  if (scl_debug_variant / 1000 == 60) relu |= (scl_debug_variant & 7) << 1;   // bit 2: setprio experiment
   if (pidx)
     SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 4>), grid, dim3(Cfg::NTHR), Cfg::LDS, st,
                (const unsigned short*)x, (const unsigned short*)packed, B, H, W,

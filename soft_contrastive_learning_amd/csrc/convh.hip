@@ -239,6 +239,9 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
   relu &= 1;
   const float floor_v = relu ? 0.f : -__builtin_inff();
   bool staged = false;
+  // (experiment, dv 3040: static priority for the younger half — MI355X_MICROARCH.md, two waves
+  // per SIMD, item 4)
+  if (!STAMP && (dbg & 4) && wid >= 4) __builtin_amdgcn_s_setprio(1);
   uint64_t stamp[STAMP ? 24 : 1];
   int tcount = 0;
 #define HSTAMP(k)                                                                     \
@@ -597,7 +600,8 @@ int scl_convh_dispatch(const void* x, const void* w, int64_t w_stride_k, int64_t
   if (dv == 3099) gsize = vblocks;
   const dim3 grid((unsigned)gsize);
   // 3020 + bits: 1 no wait / barrier at the top of a tile, 2 no output stores
-  const int dbgbits = (dv >= 3020 && dv < 3024) ? (dv - 3020) << 1 : 0;
+  // 3040: EXPERIMENT (correct results): s_setprio 1 for waves 4..7 before the tile loop
+  const int dbgbits = (dv >= 3020 && dv < 3024) ? (dv - 3020) << 1 : (dv == 3040 ? 4 << 1 : 0);
 #define SCL_CONVH_LAUNCH(E, BHV, BIAS, RELU, MASK)                                             \
   SCL_LAUNCH("convh_kernel", (convh_kernel<E, BHV>), grid, dim3(HTHR), HCfg<BHV>::LDS, st,     \
              (const unsigned short*)x, (const unsigned short*)packed, B, H, W, cin, kout,      \

@@ -437,6 +437,74 @@ __global__ __launch_bounds__(256) void gram_bwd_fast_kernel(const float* __restr
   }
 }
 
+// gram_bwd_rows_kernel (round 4): the backward for ONE row tile (<= 32 rows) — what every rank of a
+// data-parallel run asks for after the all-gather (its own 24 rows of the 192, parallel.wms_loss_dp).
+// That is a 25 MB read of E for 19 MFLOP per KB: a stream, and gram_bwd_fast_kernel<1> ran it with
+// 4-byte loads per lane (32-column waves were the only cut that put a wave on every SIMD).  Here
+// a workgroup owns 128 columns and its four waves split the CONTRACTION rows: every lane loads 16
+// bytes per step (a half-wave reads 512 contiguous bytes of an embedding row), twelve steps in
+// flight, and the four partial [32 x 128] tiles meet in LDS in a fixed order.
+// grid E / 128, block 256; LDS [32][B | 1] (M tile) + [4][32][132] floats.
+constexpr int GBR_LD = 132;
+__global__ __launch_bounds__(256) void gram_bwd_rows_kernel(const float* __restrict__ emb, int64_t ld,
+                                                            int B, int E, const float* __restrict__ coef,
+                                                            const float* __restrict__ grad_loss,
+                                                            int row_begin, int row_count,
+                                                            float* __restrict__ grad, int64_t ldg) {
+  extern __shared__ __attribute__((aligned(16))) float mt[];   // [32][B | 1] | part[4][32][GBR_LD]
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int ldm = B | 1;
+  float* part = mt + ((kTile * ldm + 3) & ~3);
+  for (int idx = threadIdx.x; idx < kTile * B; idx += 256) {
+    const int rr = idx / B, j = idx - rr * B;
+    mt[rr * ldm + j] = rr < row_count ? coef[(int64_t)(row_begin + rr) * B + j] : 0.f;
+  }
+  __syncthreads();
+  const int e = blockIdx.x * 128 + 4 * r;                        // this lane's four columns
+  f32x16 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = zero16();
+  const int steps = (B + 1) >> 1;                                // pairs of contraction rows
+  const int per = (steps + 3) >> 2;
+  const int s_lo = wid * per, s_hi = s_lo + per < steps ? s_lo + per : steps;
+  constexpr int U = 12;
+  for (int s0 = s_lo; s0 < s_hi; s0 += U) {
+    f32x4 bv[U];
+    float av[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {                                // branch-free: clamped rows, zero weight
+      const int j = 2 * (s0 + u) + h;
+      const bool ok = s0 + u < s_hi && j < B;
+      bv[u] = *reinterpret_cast<const f32x4*>(emb + (int64_t)(ok ? j : B - 1) * ld + e);
+      av[u] = ok ? mt[r * ldm + j] : 0.f;
+    }
+    __builtin_amdgcn_sched_barrier(0);                           // every load requested before the products
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = mfma32(av[u], bv[u][t], acc[t]);
+  }
+  // partial tile of this wave: element (row acc_row(q, h), column 4 r + t)
+  float* mine = part + wid * kTile * GBR_LD;
+#pragma unroll
+  for (int q = 0; q < 16; ++q)
+    *reinterpret_cast<f32x4*>(mine + acc_row(q, h) * GBR_LD + 4 * r) =
+        f32x4{acc[0][q], acc[1][q], acc[2][q], acc[3][q]};
+  __syncthreads();
+  const float g = grad_loss ? *grad_loss : 1.0f;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int unit = it * 256 + threadIdx.x, row = unit >> 5, c4 = unit & 31;
+    const float* p0 = part + row * GBR_LD + 4 * c4;
+    const f32x4 v = (*reinterpret_cast<const f32x4*>(p0) + *reinterpret_cast<const f32x4*>(p0 + kTile * GBR_LD)) +
+                    (*reinterpret_cast<const f32x4*>(p0 + 2 * kTile * GBR_LD) +
+                     *reinterpret_cast<const f32x4*>(p0 + 3 * kTile * GBR_LD));
+    if (row < row_count)
+      *reinterpret_cast<f32x4*>(grad + (int64_t)row * ldg + blockIdx.x * 128 + 4 * c4) = v * g;
+  }
+}
+
 // grad[r, e] = g * sum_j M[row_begin + r, j] * emb[j, e].
 // grid (ceil(E/512), row tiles); block 256.  The workgroup's [32 x B] slice of M sits in LDS
 // (odd row stride: conflict-free ds_read_b32); every wave owns 128 columns as 4 accumulator
@@ -1609,6 +1677,19 @@ extern "C" int scl_gram_loss_bwd(const float* emb, int64_t ld_emb, int B, int E,
     // own 24 rows of 192 (parallel.wms_loss_dp): one row tile — 32-column waves are then the only
     // cut that puts a wave on every SIMD (64-column waves left half the chip idle: 21 us for a
     // 25 MB read).
+    if (al && rt == 1 && E % 128 == 0 && B >= 64 && B <= 512 && scl_debug_variant != 32 &&
+        scl_debug_variant != 33) {                            // (33: the 32-column waves, for A/B)
+      static std::once_flag once_rows;
+      std::call_once(once_rows, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_bwd_rows_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+      });
+      const size_t lds_rows = ((size_t)((kTile * (B | 1) + 3) & ~3) + 4 * kTile * GBR_LD) * sizeof(float);
+      SCL_LAUNCH("gram_bwd_rows_kernel", gram_bwd_rows_kernel, dim3(E / 128), dim3(256), lds_rows,
+                 (hipStream_t)stream, emb, ld_emb, B, E, coef, grad_loss, row_begin, row_count, grad_emb,
+                 ld_grad);
+      return scl_launch_status();
+    }
     if (al && E % 512 == 0 && scl_debug_variant != 32) {
       const long w4 = (long)(E / 128) * rt, w2 = 2 * w4, w1 = 4 * w4;
       const long r4 = (w4 + 1023) / 1024 * 4, r2 = (w2 + 1023) / 1024 * 2, r1 = (w1 + 1023) / 1024;
