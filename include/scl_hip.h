@@ -514,10 +514,16 @@ int scl_conv_pack_batch(const SclPackJob* jobs, int njobs, void* stream);
  *                 bit 2 no operand staging / barriers
  *   8             bf16 feature maps through the float32-MFMA NetVLAD kernels (CORRECT results:
  *                 the A/B partner of the fused bf16 kernels)
- *   916 / 917     fused NetVLAD kernels (forward / grad_x): wave 0 of every workgroup writes
- *                 shader-clock stamps into the tail of the workspace (scripts/vlad_stamps.py)
- *   31 / 32       Gram loss, 64 < B <= 256: float32-MFMA Gram instead of bf16x6 /
- *                 the older guarded backward kernel
+ *   916 / 917 / 918   fused NetVLAD kernels (four-wave forward / grad_x / eight-wave forward):
+ *                 wave 0 of every workgroup writes shader-clock stamps into the tail of the
+ *                 workspace (scripts/vlad_stamps.py)
+ *   920 / 922     NetVLAD head with round 3's launch structure and four-wave kernels / the
+ *                 four-wave kernels in round 4's structure (CORRECT results: A/B partners)
+ *   921           sibling exchange of the NetVLAD finish / backward prologue: wait limit 0, every
+ *                 workgroup takes the self-computing path (CORRECT, bit-identical results)
+ *   31            Gram loss, 64 < B <= 256: float32-MFMA Gram instead of bf16x6
+ *   32 / 33       Gram loss: the two-launch forward at B <= 32 and the older guarded backward /
+ *                 the 32-column backward of the own rows (CORRECT results: A/B partners)
  *   100000 * s    Gram loss, B <= 256: force s K-splits
  *   100 + s       top-n: force s reference splits (1..32) instead of the planner's choice
  *   1000 * b (+ 100 + s)   top-n scan: b bit 0 no selection, bit 1 no tile staging,
@@ -530,7 +536,9 @@ int scl_conv_pack_batch(const SclPackJob* jobs, int njobs, void* stream);
  *                 (csrc/convg.hip) / the 16x16x32 kernel (csrc/convh.hip, the default), with
  *                 v = 0 or one of the 3xxx values above — these two give CORRECT results
  *   60000 + bits  register-weights convolution: bit 0 no window staging after the first
- *                 tile, bit 1 no output stores */
+ *                 tile, bit 1 no output stores, bit 2 (and 53040 for the LDS-weights kernel)
+ *                 static wave priorities around the MFMA runs (CORRECT results; measured without
+ *                 effect, scripts/setprio_ab.sh) */
 int scl_debug_set_variant(int variant);
 /* CUs the persistent convolution grids leave free for other kernels (RCCL's, with more than one
  * rank per node: DESIGN.md section 4).  Default: the environment variable SCL_RESERVE_CUS, or 0.
