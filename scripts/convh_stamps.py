@@ -25,6 +25,8 @@ def main():
     ap.add_argument('--layer', default='4_2')
     ap.add_argument('--batch', type=int, default=24)
     ap.add_argument('--wave', type=int, default=0, help='which of the eight waves writes the stamps')
+    ap.add_argument('--cut', default='2x4', choices=['2x4', '4x2'],
+                    help='wave grid of the 12-row block: 2x4 (15 m-tiles x 32 channels per wave, the default since round 4) or 4x2 (8 x 64)')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     lib = L.load()
@@ -43,7 +45,7 @@ def main():
     store = torch.zeros(n + nwg * 2 * 24 * 4, dtype=torch.bfloat16, device=dev)    # + room for the stamps
     out = store.as_strided((b, cout, h, w), (h * w * cout, 1, w * cout, cout))
     assert out.is_contiguous(memory_format=cl)
-    lib.scl_debug_set_variant(53024 + args.wave)
+    lib.scl_debug_set_variant((53024 if args.cut == '2x4' else 53032) + args.wave)
     try:
         nets.conv64(x, wt, False, bias=bias, relu=True, out=out)
         torch.cuda.synchronize()

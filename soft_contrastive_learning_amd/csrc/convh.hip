@@ -48,9 +48,10 @@ constexpr int HTHR = 512;
 constexpr int HX = 1;                        // half step of a group behind whose MFMAs the barrier sits
                                              // (odd: its pixel and weight fragments are dead by then)
 
+// BHv = block rows, or 24 = 12 rows cut 2 x 4 (below)
 template <int BHv>
 struct HCfg {
-  static constexpr int BH = BHv;
+  static constexpr int BH = BHv == 24 ? 12 : BHv;
   static constexpr int WR = BH + 2;                          // window rows
   static constexpr int SLOTS = WR * HWC * 4;                 // 16-byte slots of a window
   static constexpr int NI = (SLOTS + 511) / 512;             // 1-KB DMA chunks per wave: 5 / 4
@@ -60,9 +61,14 @@ struct HCfg {
   // waves (mg, ng): 12 rows 4 x 2 (8 m-tiles x 64 channels each), 8 rows 2 x 4 (10 x 32),
   // 6 rows 4 x 2 (4 x 64: half the accumulators, for maps whose 8- or 12-row blocks fill the
   // chip badly — 30 x 40: 480 blocks of 6 rows = 1.9 rounds of 256 against 1.5 of 8 rows)
-  static constexpr int MT = BH == 12 ? 8 : BH == 8 ? 10 : 4; // m-tiles per wave
-  static constexpr int NT = BH == 8 ? 2 : 4;                 // 16-channel n-tiles per wave
-  static constexpr int MH = MT / 2;                          // m-tiles per half step
+  // 24: 12 rows 2 x 4 (15 x 32 — three whole row pairs per wave group: all 30 m-tiles of the
+  // block are computed once (4 x 8 = 32 slots recompute two), and m-tile j sits at a compile-time
+  // offset from the group's first, see REG in the kernel; a tap runs in three sub-steps of a row
+  // pair each)
+  static constexpr int MT = BHv == 24 ? 15 : BH == 12 ? 8 : BH == 8 ? 10 : 4;   // m-tiles per wave
+  static constexpr int NT = (BHv == 24 || BH == 8) ? 2 : 4;  // 16-channel n-tiles per wave
+  static constexpr int SPT = BHv == 24 ? 3 : 2;              // sub-steps per tap
+  static constexpr int MH = MT / SPT;                        // m-tiles per sub-step
   static constexpr size_t LDS = (2 * (size_t)WIN + 3 * HTPB * (size_t)HWT) * 2;
 };
 
@@ -147,7 +153,8 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
                                                        int vblocks) {
   using G = HCfg<BHv>;
   constexpr int BH = G::BH, WR = G::WR, WIN = G::WIN, NMT = G::NMT, MT = G::MT, NT = G::NT;
-  constexpr int MH = G::MH, NI = G::NI, NA = G::NA;
+  constexpr int MH = G::MH, NI = G::NI, NA = G::NA, SPT = G::SPT;
+  constexpr int HS = 9 * SPT;                  // sub-steps per chunk; odd: the roles of af[] flip too
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
   unsigned short* win = lds;
   unsigned short* wts = lds + 2 * WIN;
@@ -216,6 +223,9 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
   // wave (mg, ng): m-tiles MT mg .. + MT - 1 (2 x 8 pixels each, 5 per row pair), channels
   // 16 NT ng .. + 16 NT - 1
   const int mg = NT == 4 ? wid >> 1 : wid >> 2, ng = NT == 4 ? wid & 1 : wid & 3;
+  // REG: a wave group's m-tiles are whole row pairs — m-tile j sits at a compile-time offset from
+  // the group's first one, which rides in the ds_read's offset field (no address add per read)
+  constexpr bool REG = MT % 5 == 0;
   int aoff[MT];
 #pragma unroll
   for (int j = 0; j < MT; ++j) {
@@ -225,7 +235,7 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
   // pixel fragment of this lane for tap t = (kh, kw), relative to the m-tile's corner:
   // lane_a + tap_const(t) + 8 * piece(t), piece(t) = g ^ f(row + kh, col + kw) — the nine
   // two-bit pieces packed into one register
-  const int lane_a = (ht_row(i) * HWC + ht_col(i)) * HPIX;
+  const int lane_a = (ht_row(i) * HWC + ht_col(i)) * HPIX + (REG ? 2 * (MT / 5) * mg * HWC * HPIX : 0);
   int pieces = 0;
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
@@ -267,8 +277,8 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
     // fragments (one set per step) between bf[0] and bf[1] by step; a chunk has nine steps, so
     // the roles of bf[] flip from chunk to chunk (PAR).
     u32x4 af[2][MH], bf[2][NT];
-    auto load_half = [&](const unsigned short* wbase, int h, int par) {
-      const int t = h >> 1, mh = h & 1;
+    auto load_half = [&](const unsigned short* wbase, int h, int par, int apar) {
+      const int t = h / SPT, mh = h % SPT;
       if (mh == 0) {
         const unsigned short* wbp = wts + t * HWT + lane_b;    // (t / 3) * HTPB + t % 3 = t
 #pragma unroll
@@ -281,8 +291,10 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
       const int tb = lane_a + ((pk >> (2 * t)) & 3) * 8;
 #pragma unroll
       for (int j = 0; j < MH; ++j)
-        af[h & 1][j] = *reinterpret_cast<const u32x4*>(wbase + tb + aoff[MH * mh + j] +
-                                                       ((t / 3) * HWC + t % 3) * HPIX);
+        af[(h + apar) & 1][j] = *reinterpret_cast<const u32x4*>(
+            wbase + tb +
+            (REG ? (2 * ((MH * mh + j) / 5) * HWC + 8 * ((MH * mh + j) % 5)) * HPIX : aoff[MH * mh + j]) +
+            ((t / 3) * HWC + t % 3) * HPIX);
     };
     // Straight-line on purpose (a data-dependent branch in here costs the accumulators their
     // registers): the last chunk of a tile requests, and reads ahead, like every other one — the
@@ -290,43 +302,44 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
     const int NG = 3 * CC;
     auto chunk = [&](int cc, auto par_c) {
       constexpr int PAR = decltype(par_c)::value;
+      constexpr int APAR = PAR * (HS & 1);
       const unsigned short* wcur = win + (cc & 1) * WIN;
       const unsigned short* wnext = win + ((cc + 1) & 1) * WIN;
       const int ccn = cc + 1 < CC ? cc + 1 : cc;
 #pragma unroll
-      for (int h = 0; h < 18; ++h) {
-        // the fragments of the next half step fly under the MFMAs of this one
-        if (h + 1 < 18)
-          load_half(wcur, h + 1, PAR);
+      for (int h = 0; h < HS; ++h) {
+        // the fragments of the next sub-step fly under the MFMAs of this one
+        if (h + 1 < HS)
+          load_half(wcur, h + 1, PAR, APAR);
         else
-          load_half(wnext, 0, PAR ^ 1);
+          load_half(wnext, 0, PAR ^ 1, APAR ^ (HS & 1));
         __builtin_amdgcn_sched_barrier(0);
-        const int t = h >> 1, mh = h & 1;
+        const int t = h / SPT, mh = h % SPT;
 #pragma unroll
         for (int j = 0; j < MH; ++j)
 #pragma unroll
           for (int n = 0; n < NT; ++n)
             acc[MH * mh + j][n] =
-                EPI == 3 ? mfma16h(af[h & 1][j], bf[(t + PAR) & 1][n], acc[MH * mh + j][n])
-                         : mfma16h(bf[(t + PAR) & 1][n], af[h & 1][j], acc[MH * mh + j][n]);
-        if (h % 6 == HX) {
+                EPI == 3 ? mfma16h(af[(h + APAR) & 1][j], bf[(t + PAR) & 1][n], acc[MH * mh + j][n])
+                         : mfma16h(bf[(t + PAR) & 1][n], af[(h + APAR) & 1][j], acc[MH * mh + j][n]);
+        if (h % (3 * SPT) == HX) {
           __builtin_amdgcn_sched_barrier(0);
           // own share of what the NEXT group reads has landed; the barrier publishes everybody's
-          const int gi = h / 6;
+          const int gi = h / (3 * SPT);
           if (gi == 1)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA) : "memory");   // first window part may fly on
           else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          HSTAMP(2 + 9 * PAR + 3 * (h / 6));
+          HSTAMP(2 + 9 * PAR + 3 * gi);
           __builtin_amdgcn_s_barrier();
-          HSTAMP(2 + 9 * PAR + 3 * (h / 6) + 1);
+          HSTAMP(2 + 9 * PAR + 3 * gi + 1);
           // ... and everybody has left the previous group: its weight buffer takes the group
           // after next, the other window buffer the next chunk's window (in two parts)
           const int gn = 3 * cc + gi + 2 < NG ? 3 * cc + gi + 2 : NG - 3 + (gi + 2) % 3;
           issue_wts(gn, (gi + 2) % 3);
           if (gi == 0) issue_win(ccn, (cc + 1) & 1, 0, NA);
           if (gi == 1) issue_win(ccn, (cc + 1) & 1, NA, NI);
-          HSTAMP(2 + 9 * PAR + 3 * (h / 6) + 2);
+          HSTAMP(2 + 9 * PAR + 3 * gi + 2);
         }
       }
     };
@@ -336,7 +349,7 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
       __syncthreads();
     }
     HSTAMP(1);
-    load_half(win, 0, 0);
+    load_half(win, 0, 0, 0);
 #pragma unroll 1
     for (int cc = 0; cc < CC; cc += 2) {
       chunk(cc, HConst<0>());
@@ -561,11 +574,14 @@ int scl_convh_dispatch(const void* x, const void* w, int64_t w_stride_k, int64_t
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convh_kernel<E, BHV>),              \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)HCfg<BHV>::LDS);
     SCL_CONVH_ATTR(0, 12) SCL_CONVH_ATTR(1, 12) SCL_CONVH_ATTR(2, 12) SCL_CONVH_ATTR(3, 12)
+    SCL_CONVH_ATTR(0, 24) SCL_CONVH_ATTR(1, 24) SCL_CONVH_ATTR(2, 24) SCL_CONVH_ATTR(3, 24)
     SCL_CONVH_ATTR(0, 8) SCL_CONVH_ATTR(1, 8) SCL_CONVH_ATTR(2, 8) SCL_CONVH_ATTR(3, 8)
     SCL_CONVH_ATTR(0, 6) SCL_CONVH_ATTR(1, 6) SCL_CONVH_ATTR(2, 6) SCL_CONVH_ATTR(3, 6)
 #undef SCL_CONVH_ATTR
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convh_kernel<1, 12, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)HCfg<12>::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convh_kernel<1, 24, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)HCfg<24>::LDS);
   });
   hipStream_t st = (hipStream_t)stream;
   const unsigned short* packed = (const unsigned short*)workspace;
@@ -591,6 +607,8 @@ int scl_convh_dispatch(const void* x, const void* w, int64_t w_stride_k, int64_t
     }
   }
   if (dv == 3012 || dv == 3008 || dv == 3006) bh = dv - 3000;
+  if (dv == 3013) bh = 12;
+  const bool cut2x4 = dv != 3012;      // 12 rows: 2 x 4 waves (HCfg<24>); 3012 pins the 4 x 2 cut, 3013 this one
   pblocks = (int64_t)B * ((H + bh - 1) / bh) * bx;
   const int vblocks = (int)(((pblocks + 7) / 8) * 8 * kb);
   int groups = cus / (8 * kb) > 0 ? cus / (8 * kb) : 1;
@@ -609,15 +627,23 @@ int scl_convh_dispatch(const void* x, const void* w, int64_t w_stride_k, int64_t
              (unsigned char*)pidx, vblocks)
 #define SCL_CONVH_BH(E, BIAS, RELU, MASK)                                                      \
   do {                                                                                         \
-    if (bh == 12) SCL_CONVH_LAUNCH(E, 12, BIAS, RELU, MASK);                                   \
+    if (bh == 12 && cut2x4) SCL_CONVH_LAUNCH(E, 24, BIAS, RELU, MASK);                         \
+    else if (bh == 12) SCL_CONVH_LAUNCH(E, 12, BIAS, RELU, MASK);                              \
     else if (bh == 8) SCL_CONVH_LAUNCH(E, 8, BIAS, RELU, MASK);                                \
     else SCL_CONVH_LAUNCH(E, 6, BIAS, RELU, MASK);                                             \
   } while (0)
-  if (dv >= 3024 && dv < 3032 && bias && !mask && !pidx && bh == 12) {   // stamps of wave dv - 3024
-    SCL_LAUNCH("convh_kernel", (convh_kernel<1, 12, true>), grid, dim3(HTHR), HCfg<12>::LDS, st,
-               (const unsigned short*)x, (const unsigned short*)packed, B, H, W, cin, kout,
-               (unsigned short*)out, bias, (relu ? 1 : 0) | ((dv - 3024) << 4),
-               (const unsigned short*)nullptr, (unsigned char*)nullptr, vblocks);
+  // stamps of wave dv - 3024 (2 x 4 cut) / dv - 3032 (4 x 2 cut)
+  if (dv >= 3024 && dv < 3040 && bias && !mask && !pidx && bh == 12) {
+    if (dv < 3032)
+      SCL_LAUNCH("convh_kernel", (convh_kernel<1, 24, true>), grid, dim3(HTHR), HCfg<24>::LDS, st,
+                 (const unsigned short*)x, (const unsigned short*)packed, B, H, W, cin, kout,
+                 (unsigned short*)out, bias, (relu ? 1 : 0) | ((dv - 3024) << 4),
+                 (const unsigned short*)nullptr, (unsigned char*)nullptr, vblocks);
+    else
+      SCL_LAUNCH("convh_kernel", (convh_kernel<1, 12, true>), grid, dim3(HTHR), HCfg<12>::LDS, st,
+                 (const unsigned short*)x, (const unsigned short*)packed, B, H, W, cin, kout,
+                 (unsigned short*)out, bias, (relu ? 1 : 0) | ((dv - 3032) << 4),
+                 (const unsigned short*)nullptr, (unsigned char*)nullptr, vblocks);
     return scl_launch_status();
   }
   if (pidx)

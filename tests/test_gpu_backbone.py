@@ -252,7 +252,7 @@ def block_height(request, lds_kernel):
     lib.scl_debug_set_variant(old)
 
 
-@pytest.mark.parametrize('block_height', [12, 8, 6], indirect=True)
+@pytest.mark.parametrize('block_height', [12, 13, 8, 6], indirect=True)
 @pytest.mark.parametrize('cin,cout,shape', [(128, 256, (2, 12, 40)), (256, 256, (1, 30, 40)),
                                             (256, 512, (1, 15, 80)), (512, 512, (1, 7, 23))])
 def test_lds_weight_conv_deeper_layers(dev, cin, cout, shape, block_height):
@@ -347,7 +347,7 @@ def test_first_layer_kernel(dev, shape):
     assert float((y.float() - want).abs().max()) < 6e-3 * float(want.abs().max())
 
 
-@pytest.mark.parametrize('block_height', [12, 8, 6], indirect=True)
+@pytest.mark.parametrize('block_height', [12, 13, 8, 6], indirect=True)
 @pytest.mark.parametrize('cin,cout,shape', [(64, 64, (2, 16, 40)), (128, 128, (1, 13, 37)),
                                             (128, 64, (1, 9, 33)), (256, 128, (2, 12, 40)),
                                             (512, 256, (1, 15, 80))])
@@ -456,7 +456,7 @@ def test_first_layer_weight_and_bias_gradient(dev, shape):
 
 @pytest.mark.parametrize('cin,shape', [(64, (2, 16, 40)), (128, (1, 10, 38)), (64, (1, 13, 37)),
                                        (256, (1, 24, 80)), (512, (1, 13, 37)), (256, (2, 8, 40))])
-@pytest.mark.parametrize('block_height', [12, 8, 6], indirect=True)
+@pytest.mark.parametrize('block_height', [12, 13, 8, 6], indirect=True)
 def test_pool_index_epilogue_and_its_backward(dev, cin, shape, block_height):
     """scl_conv3x3_pool_idx + scl_vgg_pool_bwd_idx: pooled map as the fused-tail kernel gives
     it, every stored position points at a maximum of its window, and the backward routes
