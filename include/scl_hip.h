@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SCL_ABI_VERSION 6
+#define SCL_ABI_VERSION 7
 
 /* error codes (negative = rejected before any launch) */
 #define SCL_OK 0
@@ -427,6 +427,22 @@ int scl_conv_first(const float* img, const float* avg, const void* w, int64_t w_
                    int64_t w_stride_c, int64_t w_stride_h, int64_t w_stride_w,
                    int w_f32 /* w is float32 instead of bf16 */, const float* bias, int B, int H,
                    int W, void* x0, void* y, void* stream);
+
+/* The first TWO layers of the forward pass in one kernel (model/nets.py:22-24, 39-42; round 4):
+ * what scl_conv_first followed by scl_conv3x3_pool_idx(64 -> 64) compute, value for value —
+ * x0 and y1 = relu(conv1_1 + bias1) as above (both are written: the backward pass reads them),
+ * pooled [B,H/2,W/2,64] bf16 = relu(maxpool2x2(conv1_2(y1)) + bias2) and pool_idx (uint8, same
+ * shape: the window position 2 dy + dx of each maximum) — but a tile's halo window of y1 is
+ * computed into LDS from the image instead of read back from memory.  w1 as in scl_conv_first;
+ * w2 logical [64][64][3][3] at its element strides with w2_flags = SCL_W_F32 or 0, or the image
+ * scl_conv_pack_batch wrote (SCL_W_PACKED); workspace >= scl_conv3x3_workspace_bytes(). */
+int scl_conv_first_pool_idx(const float* img, const float* avg, const void* w1,
+                            int64_t w1_stride_k, int64_t w1_stride_c, int64_t w1_stride_h,
+                            int64_t w1_stride_w, int w1_f32, const float* bias1, const void* w2,
+                            int64_t w2_stride_k, int64_t w2_stride_c, int64_t w2_stride_h,
+                            int64_t w2_stride_w, int w2_flags, const float* bias2, int B, int H,
+                            int W, void* x0, void* y1, void* pooled, void* pool_idx,
+                            void* workspace, size_t workspace_bytes, void* stream);
 
 /* Weight AND bias gradient of the first layer in one pass over its gradient map (the backward
  * of model/nets.py:39's conv1_1 + bias): gw[k][c][kh][kw] = sum gz[b,y,x,k] * x0[b,y+kh-1,

@@ -1015,6 +1015,258 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
 
 
 // ---------------------------------------------------------------------------------------
+// conv12_kernel: conv1_1 and conv1_2 of the forward pass in ONE kernel (model/nets.py:22-24,
+// 39-42): image -> x0 = bf16(img - average_rgb) -> y1 = relu(conv1_1(x0) + b1) -> pooled =
+// relu(maxpool2x2(conv1_2(y1)) + b2) + the window index.  conv1_2's forward is bound by reading
+// its 944 MB input with 1.33 x halo amplification; here a tile's
+// [10][34] halo window of y1 is COMPUTED into LDS from a [12][36] window of the image (44 more
+// MFMAs per tile next to conv1_2's 576) instead of fetched, and y1 — which the backward pass
+// needs (weight gradient of conv1_2, ReLU' of conv1_1) — is written once from that window
+// (interior pixels only: every y1 pixel has exactly one owner).  Replaces conv_first_kernel +
+// conv3x3_kernel<64, 64, 4>: 1.25 GB less read per step, one launch less.
+//
+// The arithmetic is that of the two kernels it replaces, value for value: conv1_1 with the
+// same K order (k = 3 tap + c, two k-steps), float32 bias, ReLU, bf16 rounding (the MFMA's
+// operands are swapped — weights as A — so that a lane holds four consecutive channels of a
+// pixel: products and summation order do not change); conv1_2 with the register-resident
+// weight slices, K-loop order and pooled epilogue of conv3x3_kernel.  tests/test_gpu_backbone.py
+// compares x0, y1, pooled map and index bit for bit with the two-kernel path.
+//
+// Per tile and workgroup (512 threads): [S2] waves 0..7 take the 11 32-pixel groups of the y1
+// window: im2col gather from the image window, 4 MFMAs, bias / ReLU / zero outside the image
+// (conv1_2's padding is zero in y1, not conv1_1 of a padded image), 8-byte LDS writes;
+// barrier; [S3] the interior of the window leaves as whole 128-byte pixels; the next tile's
+// image pixels (requested one tile earlier) go into the image window; conv1_2's K loop and
+// pooled epilogue; barrier.  One window buffer: nothing is staged under the K loop.
+constexpr int IWR = TH + 4, IWC = TW + 4;            // image window of a tile: 12 x 36 pixels
+constexpr int C12_IW = IWR * IWC * F_PIX;            // bf16 (1728)
+constexpr int C12_W1 = 2 * 2 * 64 * 8;               // conv1_1 fragments [k-step][ch tile][lane][8]
+constexpr int C12_PT = (WR * WC + 31) / 32;          // 32-pixel groups of the y1 window: 11
+constexpr size_t kConv12Lds =
+    ((size_t)ConvCfg<64, 64>::WIN_ + C12_IW + C12_W1 + 128 + 8 * (size_t)SCR) * sizeof(unsigned short);
+
+__global__ __launch_bounds__(512, 1) void conv12_kernel(
+    const float* __restrict__ img, const float* __restrict__ avg, const void* __restrict__ w1,
+    int w1_f32, int64_t sk, int64_t sc, int64_t sh, int64_t sw, const float* __restrict__ b1,
+    const unsigned short* __restrict__ packed2, const float* __restrict__ b2, int B, int H, int W,
+    unsigned short* __restrict__ x0, unsigned short* __restrict__ y1,
+    unsigned short* __restrict__ pooled, unsigned char* __restrict__ pidx) {
+  using Cfg = ConvCfg<64, 64>;
+  constexpr int PIX = Cfg::PIX, WIN_ = Cfg::WIN_, KS = Cfg::KS, MT = Cfg::MT;
+  static_assert(MT == 2 && Cfg::NTHR == 512, "conv12_kernel is conv3x3_kernel<64, 64>'s geometry");
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+  unsigned short* win = lds;
+  unsigned short* iw = lds + WIN_;
+  unsigned short* w1i = iw + C12_IW;
+  float* b1s = reinterpret_cast<float*>(w1i + C12_W1);
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int nt = wid % Cfg::NT, part = wid / Cfg::NT;
+  unsigned short* scr = w1i + C12_W1 + 128 + wid * SCR;
+  const float bias_r = b2[32 * nt + r];
+
+  // conv1_2: the wave's weight slice, KS fragments of 16 bytes per lane
+  u32x4 wf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+    wf[ks] = *reinterpret_cast<const u32x4*>(packed2 + (((int64_t)nt * KS + ks) * 64 + lane) * 8);
+
+  // conv1_1: fragment (k-step ks, channel tile ct) of lane (j, hh) = channel 32 ct + j,
+  // k = 16 ks + 8 hh + e = 3 tap + c (k >= 27: zero) — conv_first_kernel's wf[ks][nt]
+  if (threadIdx.x < 256) {
+    const int ks = threadIdx.x >> 7, ct = (threadIdx.x >> 6) & 1, hh = (threadIdx.x >> 5) & 1;
+    const int j = threadIdx.x & 31;
+    unsigned short v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = 16 * ks + 8 * hh + e;
+      const int tap = k / 3, c = k % 3;
+      v[e] = k < 27 ? weight_bf16(w1, (32 * ct + j) * sk + c * sc + (tap / 3) * sh + (tap % 3) * sw, w1_f32)
+                    : (unsigned short)0;
+    }
+    *reinterpret_cast<u32x4*>(w1i + threadIdx.x * 8) =
+        u32x4{(unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16),
+              (unsigned)v[4] | ((unsigned)v[5] << 16), (unsigned)v[6] | ((unsigned)v[7] << 16)};
+  }
+  if (threadIdx.x < 64) b1s[threadIdx.x] = b1[threadIdx.x];
+  const float a0 = avg[0], a1 = avg[1], a2 = avg[2];
+
+  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+  const int per_img = tiles_x * tiles_y;
+  const int ntiles = B * per_img;
+
+  // image window: thread t < 432 owns pixel (t / 36, t % 36) of the [12][36] window, whose origin
+  // is the tile's corner minus (2, 2); its float32 values travel one tile ahead in registers
+  const int iwy = (int)threadIdx.x / IWC, iwx = (int)threadIdx.x % IWC;
+  const bool iw_owner = threadIdx.x < IWR * IWC;
+  const bool iw_interior = iwy >= 2 && iwy < 2 + TH && iwx >= 2 && iwx < 2 + TW;
+  float pre0 = 0.f, pre1 = 0.f, pre2 = 0.f;
+  int64_t pre_p = -1;
+  auto prefetch = [&](int t) {
+    pre_p = -1;
+    pre0 = pre1 = pre2 = 0.f;
+    if (t < ntiles && iw_owner) {
+      const int b = t / per_img, t2 = t % per_img;
+      const int yy = (t2 / tiles_x) * TH - 2 + iwy, xx = (t2 % tiles_x) * TW - 2 + iwx;
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+        const int64_t p = ((int64_t)b * H + yy) * W + xx;
+        pre_p = p;
+        pre0 = img[3 * p];
+        pre1 = img[3 * p + 1];
+        pre2 = img[3 * p + 2];
+      }
+    }
+  };
+  auto write_iw = [&]() {
+    if (iw_owner) {
+      unsigned short v0 = 0, v1 = 0, v2 = 0;
+      if (pre_p >= 0) {
+        v0 = f32_to_bf16(pre0 - a0);
+        v1 = f32_to_bf16(pre1 - a1);
+        v2 = f32_to_bf16(pre2 - a2);
+        if (iw_interior) {                               // this tile owns the pixel
+          x0[3 * pre_p] = v0;
+          x0[3 * pre_p + 1] = v1;
+          x0[3 * pre_p + 2] = v2;
+        }
+      }
+      *reinterpret_cast<uint2*>(iw + threadIdx.x * F_PIX) =
+          make_uint2((unsigned)v0 | ((unsigned)v1 << 16), (unsigned)v2);
+    }
+  };
+  // gather offset (bf16 units from the lane's window pixel) of contraction index k
+  auto goff_of = [](int k) {
+    const int tap = k < 27 ? k / 3 : 0, c = k < 27 ? k % 3 : 3;      // the pad slot holds zero
+    return ((tap / 3) * IWC + tap % 3) * F_PIX + c;
+  };
+
+  int tile = blockIdx.x;
+  prefetch(tile);
+  write_iw();
+  prefetch(tile + gridDim.x);
+  __syncthreads();
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int b = tile / per_img, t2 = tile % per_img;
+    const int ty = (t2 / tiles_x) * TH, tx = (t2 % tiles_x) * TW;
+
+    // [S2] y1 window: group pt = window pixels 32 pt .. + 31 (row-major over [10][34])
+    for (int pt = wid; pt < C12_PT; pt += 8) {
+      const int pix = 32 * pt + r;
+      const bool live = pix < WR * WC;
+      const int pc = live ? pix : WR * WC - 1;
+      const int wy = pc / WC, wx = pc % WC;
+      const unsigned short* base = iw + (wy * IWC + wx) * F_PIX;
+      f32x16 acc0 = zero16(), acc1 = zero16();
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        unsigned short v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = base[h ? goff_of(16 * ks + 8 + e) : goff_of(16 * ks + e)];
+        const u32x4 af = u32x4{(unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16),
+                               (unsigned)v[4] | ((unsigned)v[5] << 16), (unsigned)v[6] | ((unsigned)v[7] << 16)};
+        const u32x4 wa0 = *reinterpret_cast<const u32x4*>(w1i + ((ks * 2 + 0) * 64 + lane) * 8);
+        const u32x4 wa1 = *reinterpret_cast<const u32x4*>(w1i + ((ks * 2 + 1) * 64 + lane) * 8);
+        acc0 = mfma32b(wa0, af, acc0);
+        acc1 = mfma32b(wa1, af, acc1);
+      }
+      // register q of lane (pixel r, half h) = channel 32 ct + acc_row(q, h): four consecutive
+      // channels per register quad
+      const int yy = ty - 1 + wy, xx = tx - 1 + wx;
+      const bool inimg = live && yy >= 0 && yy < H && xx >= 0 && xx < W;
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(b1s + 32 * ct + 8 * j + 4 * h);
+          unsigned short o[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float a = ct ? acc1[4 * j + i] : acc0[4 * j + i];
+            o[i] = f32_to_bf16(fmaxf(a + bb[i], 0.f));
+          }
+          uint2 pk = make_uint2((unsigned)o[0] | ((unsigned)o[1] << 16), (unsigned)o[2] | ((unsigned)o[3] << 16));
+          if (!inimg) pk = make_uint2(0u, 0u);           // conv1_2 pads y1 with zeros
+          if (live) *reinterpret_cast<uint2*>(win + pix * PIX + 32 * ct + 8 * j + 4 * h) = pk;
+        }
+    }
+    __syncthreads();
+
+    // [S3] the tile's own 8 x 32 pixels of y1: 16-byte piece id -> (pixel id / 8, piece id % 8),
+    // eight lanes write one 128-byte pixel
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int id = (int)threadIdx.x + 512 * k;
+      const int px = id >> 3, piece = id & 7;
+      const int py = px / TW, pxx = px % TW;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(win + ((py + 1) * WC + pxx + 1) * PIX + 8 * piece);
+      const int oy = ty + py, ox = tx + pxx;
+      if (oy < H && ox < W)
+        *reinterpret_cast<u32x4*>(y1 + (((int64_t)b * H + oy) * W + ox) * C64 + 8 * piece) = v;
+    }
+    // the next tile's image window (its pixels were requested a tile ago), then the request for
+    // the tile after it
+    write_iw();
+    prefetch(tile + 2 * gridDim.x);
+
+    // conv1_2: K loop and pooled epilogue of conv3x3_kernel<64, 64, 4>
+    const unsigned short* wb = win + ((MT * part) * WC + r) * PIX + 8 * h;
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = zero16();
+    constexpr int WRW = MT + 2, NST = Cfg::SPT * WRW * 3, RING = 4, AHEAD = 3;
+    auto frag_at = [&](int st) {
+      const int c = st / (WRW * 3), wr = (st / 3) % WRW, kw = st % 3;
+      return *reinterpret_cast<const u32x4*>(wb + (wr * WC + kw) * PIX + 16 * c);
+    };
+    u32x4 af[RING];
+#pragma unroll
+    for (int st = 0; st < AHEAD; ++st) af[st] = frag_at(st);
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+      if (st + AHEAD < NST) af[(st + AHEAD) % RING] = frag_at(st + AHEAD);
+      __builtin_amdgcn_sched_barrier(0);
+      const int c = st / (WRW * 3), wr = (st / 3) % WRW, kw = st % 3;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int kh = wr - mt;
+        if (kh >= 0 && kh < 3)
+          acc[mt] = mfma32b(af[st % RING], wf[(3 * kh + kw) * Cfg::SPT + c], acc[mt]);
+      }
+    }
+
+    const int oy0 = ty + MT * part, ox0 = tx;
+    const int PH2 = H / 2, PW2 = W / 2;
+    unsigned char* scr8 = reinterpret_cast<unsigned char*>(scr + 16 * SCR_LD);   // [16][32]
+#pragma unroll
+    for (int q = 0; q < 16; q += 2) {
+      const float m0 = fmaxf(acc[0][q], acc[0][q + 1]);
+      const float m1 = fmaxf(acc[1][q], acc[1][q + 1]);
+      const float m = fmaxf(m0, m1);
+      scr[(acc_row(q, h) >> 1) * SCR_LD + r] = f32_to_bf16(fmaxf(m + bias_r, 0.f));
+      // first maximum in raster order (0,0), (0,1), (1,0), (1,1)
+      const int k = acc[0][q] == m ? 0 : acc[0][q + 1] == m ? 1 : acc[1][q] == m ? 2 : 3;
+      scr8[(acc_row(q, h) >> 1) * 32 + r] = (unsigned char)k;
+    }
+    __builtin_amdgcn_wave_barrier();
+    {
+      // 16 pooled pixels x 64 bytes: lane -> pixel lane >> 2, 16-byte quarter lane & 3
+      const int px = lane >> 2, qu = lane & 3;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(scr + px * SCR_LD + 8 * qu);
+      const uint2 kv = *reinterpret_cast<const uint2*>(scr8 + px * 32 + 8 * qu);
+      __builtin_amdgcn_wave_barrier();
+      const int py = oy0 >> 1, pxg = (ox0 >> 1) + px;
+      if (py < PH2 && pxg < PW2) {
+        const int64_t po = (((int64_t)b * PH2 + py) * PW2 + pxg) * C64 + 32 * nt + 8 * qu;
+        *reinterpret_cast<u32x4*>(pooled + po) = v;
+        *reinterpret_cast<uint2*>(pidx + po) = kv;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------
 // conv_first_wrw_kernel: weight AND bias gradient of the first layer in ONE pass over its
 // 64-channel gradient map (the layer's only large operand: 944 MB at 24 x 480 x 640),
 //   gw[k][c][kh][kw] = sum_p gz[p][k] * x0[p + (kh-1, kw-1)][c],     gb[k] = sum_p gz[p][k],
@@ -1579,6 +1831,46 @@ extern "C" int scl_conv_first(const float* img, const float* avg, const void* w,
              (w_f32 ? 1 : 0) | (scl_debug_variant / 1000 == 70 ? (scl_debug_variant & 7) << 4 : 0),
              w_stride_k, w_stride_c,
              w_stride_h, w_stride_w, bias, B, H, W, (unsigned short*)x0, (unsigned short*)y);
+  return scl_launch_status();
+}
+
+extern "C" int scl_conv_first_pool_idx(const float* img, const float* avg, const void* w1,
+                                       int64_t w1_stride_k, int64_t w1_stride_c,
+                                       int64_t w1_stride_h, int64_t w1_stride_w, int w1_f32,
+                                       const float* bias1, const void* w2, int64_t w2_stride_k,
+                                       int64_t w2_stride_c, int64_t w2_stride_h,
+                                       int64_t w2_stride_w, int w2_flags, const float* bias2, int B,
+                                       int H, int W, void* x0, void* y1, void* pooled,
+                                       void* pool_idx, void* workspace, size_t workspace_bytes,
+                                       void* stream) {
+  if (!img || !avg || !w1 || !bias1 || !w2 || !bias2 || !x0 || !y1 || !pooled || !pool_idx ||
+      !workspace)
+    return SCL_E_NULL;
+  if (B < 1 || H < 1 || W < 1 || (int64_t)B * H * W * 64 >= (int64_t)1 << 31) return SCL_E_SHAPE;
+  if (((uintptr_t)y1 % 16) || ((uintptr_t)pooled % 16) || ((uintptr_t)pool_idx % 8)) return SCL_E_SHAPE;
+  if (w2_flags & SCL_CONV_TRANSPOSED) return SCL_E_SHAPE;
+  if (!scl_aligned256(workspace) || workspace_bytes < scl_conv3x3_workspace_bytes())
+    return SCL_E_WORKSPACE;
+  using Cfg = ConvCfg<64, 64>;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv12_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kConv12Lds);
+  });
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned short* packed = (const unsigned short*)workspace;
+  if (w2_flags & SCL_W_PACKED)
+    packed = (const unsigned short*)w2;                  // scl_conv_pack_batch wrote it
+  else
+    SCL_LAUNCH("conv3x3_pack_kernel", (conv3x3_pack_kernel<64, 64>),
+               dim3(Cfg::NT * Cfg::KS * 512 / 256), dim3(256), 0, st, w2, w2_stride_k, w2_stride_c,
+               w2_stride_h, w2_stride_w, w2_flags & SCL_W_F32, (unsigned short*)workspace);
+  const int cus = conv64_cus();
+  const int tiles = B * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+  SCL_LAUNCH("conv12_kernel", conv12_kernel, dim3(tiles < cus ? tiles : cus), dim3(512), kConv12Lds,
+             st, img, avg, w1, w1_f32 ? 1 : 0, w1_stride_k, w1_stride_c, w1_stride_h, w1_stride_w,
+             bias1, packed, bias2, B, H, W, (unsigned short*)x0, (unsigned short*)y1,
+             (unsigned short*)pooled, (unsigned char*)pool_idx);
   return scl_launch_status();
 }
 

@@ -556,10 +556,12 @@ class _GradLink:
     next, takes it and skips its own masking pass.  Anything else (a copied or re-accumulated
     gradient, a library backward) leaves the link empty and the lower layer masks itself —
     masking twice would be harmless, skipping it is only done on this exact buffer."""
-    __slots__ = ('ptr',)
+    __slots__ = ('ptr', 'fused')
 
     def __init__(self):
         self.ptr = None
+        self.fused = None      # (data_ptr of y1, pooled map, window index): conv1_2's forward
+                               # results, computed by the kernel that produced y1 (_FirstConv)
 
     def mark(self, gx):
         self.ptr = gx.data_ptr()
@@ -575,6 +577,12 @@ USE_MASKED_BWD = os.environ.get('SCL_MASKED_BWD', '1') != '0'
 USE_POOL_IDX = os.environ.get('SCL_POOL_IDX', '1') != '0'
 USE_POOLED_BWD = os.environ.get('SCL_POOLED_BWD', '1') != '0'     # un-pool inside the consumers
 USE_F32_WEIGHTS = os.environ.get('SCL_F32_WEIGHTS', '1') != '0'
+# conv1_1 and conv1_2 of the forward pass in one kernel (scl_conv_first_pool_idx): bit-identical
+# to the two-kernel path and 1.25 GB less read per step, but SLOWER as built (776 against 243 + 480
+# us on one box, profiles/r04/first_block_one_kernel_vs_two.txt): conv1_2's kernel sits at 256
+# registers with two waves per SIMD, so the first layer's products, gathers and bias / ReLU /
+# rounding run in a phase of their own in front of the K loop instead of under it.  Off by default.
+USE_FUSED12 = os.environ.get('SCL_FUSED12', '0') != '0'
 
 
 def conv_pool_idx(x, w, bias, out=None):
@@ -827,6 +835,16 @@ class _ConvBiasPoolReLU(torch.autograd.Function):
         ctx.link_in, ctx.link_out = link_in, link_out
         ctx.by_idx = False
         ctx.slot = _pack_slot()
+        fused = link_in.fused if link_in is not None else None
+        if fused is not None:
+            link_in.fused = None
+            if fused[0] == x.data_ptr() and fused[3] is w and fused[4] is bias:
+                # conv1_2: the kernel that wrote x (= y1) computed this layer's forward as well
+                a, idx = fused[1], fused[2]
+                ctx.by_idx = True
+                ctx.save_for_backward(x, w, idx, a, bias)
+                return a
+            raise RuntimeError("fused conv1_1 + conv1_2 results do not belong to this layer")
         kind = _own_conv_kind(x, w)
         if USE_POOL_IDX and ((kind == 'reg' and w.shape[0] == w.shape[1])
                              or (kind == 'lds' and _lds_conv_pays(x))):
@@ -953,7 +971,7 @@ class _FirstConv(torch.autograd.Function):
     the closed form of ``avg_rgb_grad`` — so conv1_1's bwd-data pass is never run."""
 
     @staticmethod
-    def forward(ctx, img_nhwc, avg, w, bias, dtype, link_out=None):
+    def forward(ctx, img_nhwc, avg, w, bias, dtype, link_out=None, w2=None, bias2=None):
         lib = L.load()
         ctx.link_out = link_out
         if (USE_CONV64 and USE_FIRST and dtype == torch.bfloat16 and img_nhwc.is_cuda
@@ -968,16 +986,47 @@ class _FirstConv(torch.autograd.Function):
             sk, sc, sh, sw = w.stride()
             avg_f, bias_f = avg.float().contiguous(), bias.float().contiguous()
             y_nhwc = y.permute(0, 2, 3, 1)                    # the storage order, batch-sliceable
+            # ... and, when the caller hands over conv1_2's parameters, that layer's forward too
+            # (pooled map + window index): its halo windows of y are computed, not read back
+            fuse2 = (USE_FUSED12 and USE_POOL_IDX and w2 is not None and bias2 is not None
+                     and link_out is not None and tuple(w2.shape) == (64, 64, 3, 3)
+                     and w2.dtype in _W_DTYPES and h % 2 == 0 and wd % 2 == 0
+                     and b * h * wd * 64 < 2 ** 31)
+            if fuse2:
+                a = torch.empty((b, 64, h // 2, wd // 2), dtype=torch.bfloat16, device=img.device,
+                                memory_format=_CL)
+                idx = torch.empty((b, 64, h // 2, wd // 2), dtype=torch.uint8, device=img.device,
+                                  memory_format=_CL)
+                a_nhwc, idx_nhwc = a.permute(0, 2, 3, 1), idx.permute(0, 2, 3, 1)
+                bias2_f = bias2.float().contiguous()
+                pk2 = _packed_for(w2, False)
+                ws = L.workspace(lib.scl_conv3x3_workspace_bytes(), img.device)
+                s2 = w2.stride()
             for stream, lo, hi in (_split_halves(b) or [(None, 0, b)]):
                 if stream is not None:
                     _on_half(stream, img, x0, y, avg_f, bias_f, w)
+                    if fuse2:
+                        _on_half(stream, a, idx, bias2_f, w2)
                 with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
                     n = hi - lo
+                    if fuse2:
+                        _work('conv12_kernel', 2.0 * n * h * wd * (27 * 64 + 64 * 64 * 9),
+                              n * h * wd * (12.0 + 6.0 + 128.0 + 0.75 * 64))
+                        L.check(lib.scl_conv_first_pool_idx(
+                            L.ptr(img[lo:hi]), L.ptr(avg_f), L.ptr(w), sk, sc, sh, sw,
+                            int(w.dtype == torch.float32), L.ptr(bias_f),
+                            L.ptr(w2) if pk2 is None else L.ptr(pk2), s2[0], s2[1], s2[2], s2[3],
+                            _wflag(w2) if pk2 is None else L.W_PACKED, L.ptr(bias2_f), n, h, wd,
+                            L.ptr(x0[lo:hi]), L.ptr(y_nhwc[lo:hi]), L.ptr(a_nhwc[lo:hi]),
+                            L.ptr(idx_nhwc[lo:hi]), L.ptr(ws), ws.numel(), L.stream_of(img)))
+                        continue
                     _work('conv_first_kernel', 2.0 * n * h * wd * 27 * 64, n * h * wd * (12.0 + 6.0 + 128.0))
                     L.check(lib.scl_conv_first(L.ptr(img[lo:hi]), L.ptr(avg_f), L.ptr(w), sk, sc,
                                                sh, sw, int(w.dtype == torch.float32),
                                                L.ptr(bias_f), n, h, wd,
                                                L.ptr(x0[lo:hi]), L.ptr(y_nhwc[lo:hi]), L.stream_of(img)))
+            if fuse2:
+                link_out.fused = (y.data_ptr(), a, idx, w2, bias2)
             x0 = x0.permute(0, 3, 1, 2)
         else:
             with _whole_batch_op():
@@ -1015,7 +1064,7 @@ class _FirstConv(torch.autograd.Function):
         else:
             _, gw = _conv3x3_backward(gz, x0, w, False)
             davg = avg_rgb_grad(gz, w, gb)
-        return None, davg, _grad_ret(gw, w), _grad_ret(gb, bias), None, None
+        return None, davg, _grad_ret(gw, w), _grad_ret(gb, bias), None, None, None, None
 
 
 class _SubMean(torch.autograd.Function):
@@ -1158,7 +1207,15 @@ class VGG16NetVLAD(torch.nn.Module):
                 if x is None:
                     # nets.py:22-24 + conv1_1 + ReLU; no image gradient is ever formed
                     link = _GradLink()
-                    x = _FirstConv.apply(image_batch, self.average_rgb, w, bias, dt, link)
+                    nxt = VGG_LAYERS[idx + 1] if idx + 2 < len(VGG_LAYERS) else None
+                    if (nxt is not None and nxt != 'pool' and VGG_LAYERS[idx + 2] == 'pool'
+                            and USE_F32_WEIGHTS):
+                        # conv1_2 ends in the pooling: its forward rides in the first layer's kernel
+                        x = _FirstConv.apply(image_batch, self.average_rgb, w, bias, dt, link,
+                                             getattr(self, 'conv%s_kernel' % nxt[0]),
+                                             getattr(self, 'conv%s_bias' % nxt[0]))
+                    else:
+                        x = _FirstConv.apply(image_batch, self.average_rgb, w, bias, dt, link)
                 elif pool_next:
                     # conv -> bias -> pool -> ReLU in one elementwise pass (nets.py:40-42)
                     # (the pooled map is post-ReLU too: the next layer's backward-data kernel can

@@ -347,6 +347,84 @@ def test_first_layer_kernel(dev, shape):
     assert float((y.float() - want).abs().max()) < 6e-3 * float(want.abs().max())
 
 
+@pytest.mark.parametrize('shape', [(2, 16, 64), (1, 14, 38), (3, 40, 96), (1, 480, 640)])
+@pytest.mark.parametrize('w_f32', [False, True])
+def test_first_two_layers_in_one_kernel(dev, shape, w_f32):
+    """scl_conv_first_pool_idx (conv1_1 + conv1_2 forward, the y1 halo windows computed in LDS)
+    against scl_conv_first followed by scl_conv3x3_pool_idx: x0, y1, pooled map and window index
+    bit for bit — ragged tiles, image borders, bf16 and float32 master weights."""
+    from soft_contrastive_learning_amd import _lib as L
+    b, h, w = shape
+    lib = L.load()
+    g = torch.Generator().manual_seed(131)
+    img = torch.randint(0, 256, (b, h, w, 3), generator=g).float().to(dev)
+    avg = torch.tensor([123.68, 116.78, 103.94], device=dev)
+    cl = torch.channels_last
+    w1 = (torch.randn(64, 3, 3, 3, generator=g) * 0.1).to(dev)
+    w2 = (torch.randn(64, 64, 3, 3, generator=g) * 0.05).to(dev)
+    if not w_f32:
+        w1 = w1.bfloat16().contiguous(memory_format=cl)
+        w2 = w2.bfloat16().contiguous(memory_format=cl)
+    b1 = torch.randn(64, generator=g).to(dev)
+    b2 = torch.randn(64, generator=g).to(dev)
+    ws = L.workspace(lib.scl_conv3x3_workspace_bytes(), dev)
+
+    def outputs():
+        return (torch.full((b, h, w, 3), 7, dtype=torch.bfloat16, device=dev),
+                torch.full((b, h, w, 64), 7, dtype=torch.bfloat16, device=dev),
+                torch.full((b, h // 2, w // 2, 64), 7, dtype=torch.bfloat16, device=dev),
+                torch.full((b, h // 2, w // 2, 64), 9, dtype=torch.uint8, device=dev))
+
+    s1, s2 = w1.stride(), w2.stride()
+    f2 = L.W_F32 if w_f32 else 0
+    x0, y1, a, idx = outputs()
+    L.check(lib.scl_conv_first(L.ptr(img), L.ptr(avg), L.ptr(w1), *s1, int(w_f32), L.ptr(b1), b, h, w,
+                               L.ptr(x0), L.ptr(y1), L.stream_of(img)))
+    L.check(lib.scl_conv3x3_pool_idx(L.ptr(y1), L.ptr(w2), *s2, f2, b, h, w, 64, 64, L.ptr(b2),
+                                     L.ptr(a), L.ptr(idx), L.ptr(ws), ws.numel(), L.stream_of(img)))
+    fx0, fy1, fa, fidx = outputs()
+    L.check(lib.scl_conv_first_pool_idx(L.ptr(img), L.ptr(avg), L.ptr(w1), *s1, int(w_f32), L.ptr(b1),
+                                        L.ptr(w2), *s2, f2, L.ptr(b2), b, h, w, L.ptr(fx0), L.ptr(fy1),
+                                        L.ptr(fa), L.ptr(fidx), L.ptr(ws), ws.numel(), L.stream_of(img)))
+    torch.cuda.synchronize()
+    assert torch.equal(fx0, x0)
+    assert torch.equal(fy1, y1)
+    assert torch.equal(fa, a)
+    assert torch.equal(fidx, idx)
+    # and the pair against float32 torch (the fused kernel is not only equal to its sibling)
+    want_y1 = torch.relu(torch.nn.functional.conv2d(x0.float().permute(0, 3, 1, 2), w1.float(), padding=1)
+                         + b1[None, :, None, None])
+    assert float((fy1.float().permute(0, 3, 1, 2) - want_y1).abs().max()) < 6e-3 * float(want_y1.abs().max())
+    z = torch.nn.functional.conv2d(fy1.float().permute(0, 3, 1, 2), w2.bfloat16().float(), padding=1)
+    want_a = torch.relu(torch.nn.functional.max_pool2d(z, 2) + b2[None, :, None, None])
+    assert float((fa.float().permute(0, 3, 1, 2) - want_a).abs().max()) < 6e-3 * float(want_a.abs().max() + 1)
+
+
+def test_model_with_and_without_the_fused_first_block(dev):
+    """nets.USE_FUSED12: features and every gradient of a backbone step are bit-identical with the
+    first two layers in one kernel and in two."""
+    from soft_contrastive_learning_amd.model import nets
+    # (at 480 x 640 every layer runs on the library's own, deterministic kernels)
+    img = torch.randint(0, 256, (2, 480, 640, 3), generator=torch.Generator().manual_seed(71)).float().to(dev)
+    g = torch.randn(2, 30, 40, 512, generator=torch.Generator().manual_seed(72)).to(dev).bfloat16()
+    res = {}
+    old = nets.USE_FUSED12
+    try:
+        for fused in (False, True):
+            nets.USE_FUSED12 = fused
+            model = nets.VGG16NetVLAD(compute_dtype=torch.bfloat16, seed=9, fused_relu=True).to(dev)
+            f = model.features(img)
+            f.backward(g)
+            res[fused] = (f.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters()
+                                               if p.grad is not None})
+    finally:
+        nets.USE_FUSED12 = old
+    assert torch.equal(res[True][0], res[False][0])
+    assert set(res[True][1]) == set(res[False][1])
+    for n in res[True][1]:
+        assert torch.equal(res[True][1][n], res[False][1][n]), n
+
+
 @pytest.mark.parametrize('block_height', [12, 13, 8, 6], indirect=True)
 @pytest.mark.parametrize('cin,cout,shape', [(64, 64, (2, 16, 40)), (128, 128, (1, 13, 37)),
                                             (128, 64, (1, 9, 33)), (256, 128, (2, 12, 40)),
