@@ -304,39 +304,45 @@ __global__ __launch_bounds__(256, 2) void topn_scan_kernel(const void* __restric
 #pragma unroll
       for (int q = 0; q < 16; ++q) tq[q] = my_tau[acc_row(q, h)];
     } else if (!(dbg & 1)) {
+      // Register q of the two half-waves holds two DIFFERENT queries (rows acc_row(q, 0) and
+      // acc_row(q, 1)) against the tile's 32 references, and an insertion needs 32 lanes (one per
+      // list entry): each half-wave inserts its own row's candidates, both at once (round 4; one
+      // candidate per step for the whole wave before).  Per list the order of insertion —
+      // ascending reference index — is unchanged, and so is every list.
       bool any = false;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const float sc = rnj - 2.0f * acc[q];
-        unsigned long long m = __ballot(sc < tq[q]);
-        while (m) {
-          const int L = __ffsll((long long)m) - 1;
-          m &= m - 1;
-          any = true;
-          const int row = acc_row(q, L >> 5);
-          const float s = __shfl(sc, L, 64);
-          const int id = r_begin + t * 32 + (L & 31);
-          // sorted insertion by the whole wave: lanes 0..31 mirror the list entries
-          float* ls = my_sc + row * KEEP;
-          int* li = my_ix + row * KEEP;
-          const int e = lane & (KEEP - 1);
+        const unsigned long long m = __ballot(sc < tq[q]);
+        unsigned mh = h ? (unsigned)(m >> 32) : (unsigned)m;    // this half's candidates
+        if (m) any = true;
+        const int row = acc_row(q, h);
+        float* ls = my_sc + row * KEEP;
+        int* li = my_ix + row * KEEP;
+        const int e = lane & (KEEP - 1);
+        while (__ballot(mh != 0)) {
+          const bool act = mh != 0;
+          const int L = act ? __ffs((int)mh) - 1 : 0;
+          mh &= mh - 1;
+          const float s = __shfl(sc, 32 * h + L, 64);
+          const int id = r_begin + t * 32 + L;
+          // sorted insertion by the half-wave: its 32 lanes mirror the list entries
           const float cs = ls[e];
           const int ci = li[e];
           const bool before = (cs < s) || (cs == s && ci < id);
-          const int pos = __popcll(__ballot(before) & 0xffffffffull);
-          if (pos < KEEP) {
-            const float ps = __shfl_up(cs, 1, 64);
-            const int pi = __shfl_up(ci, 1, 64);
-            const float ns = e < pos ? cs : (e == pos ? s : ps);
-            const int ni = e < pos ? ci : (e == pos ? id : pi);
-            __builtin_amdgcn_wave_barrier();
-            if (lane < KEEP) {
-              ls[e] = ns;
-              li[e] = ni;
-              if (e == KEEP - 1) my_tau[row] = ns;
-            }
-            __builtin_amdgcn_wave_barrier();
+          const unsigned long long bb = __ballot(before);
+          const int pos = __popc(h ? (unsigned)(bb >> 32) : (unsigned)bb);
+          const float ps = __shfl_up(cs, 1, 64);           // (entry 0 never takes its neighbour's)
+          const int pi = __shfl_up(ci, 1, 64);
+          const float ns = e < pos ? cs : (e == pos ? s : ps);
+          const int ni = e < pos ? ci : (e == pos ? id : pi);
+          __builtin_amdgcn_wave_barrier();
+          if (act && pos < KEEP) {
+            ls[e] = ns;
+            li[e] = ni;
+            if (e == KEEP - 1) my_tau[row] = ns;
           }
+          __builtin_amdgcn_wave_barrier();
         }
       }
       if (any) {
