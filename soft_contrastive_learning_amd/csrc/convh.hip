@@ -247,7 +247,7 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
   const int relu_in = relu;
   const int dbg = STAMP ? 0 : relu >> 1;   // timing diagnostics (dv 3020 + bits), results meaningless
   relu &= 1;
-  const float floor_v = relu ? 0.f : -__builtin_inff();
+  const short relu_floor = relu ? (short)0 : (short)-32768;   // packed ReLU: max with 0, or with the least int16
   bool staged = false;
   // (experiment, dv 3040: static priority for the younger half — MI355X_MICROARCH.md, two waves
   // per SIMD, item 4)
@@ -497,22 +497,28 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
       }
     } else {
       typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      // the tile's corner pixel, this wave's channels; a tile that lies inside the image whole
+      // (every tile of the bench shapes) stores without the per-lane border tests
+      unsigned short* out_tile = out + (((int64_t)b_e * H + y0_e) * W + x0_e) * kout + ch_w;
+      const bool full_tile = y0_e + BH <= H && x0_e + HBW <= W && !(dbg & 2);
 #pragma unroll
       for (int j = 0; j < MT; ++j) {
         const int mt = MT * mg + j;
         if (mt < NMT) {                                    // wave-uniform
           const int oy = y0_e + 2 * (mt / 5), ox = x0_e + 8 * (mt % 5);
-          unsigned short* ob = out + (((int64_t)b_e * H + oy) * W + ox) * kout + ch_w;
+          unsigned short* ob = out_tile + ((2 * (mt / 5)) * W + 8 * (mt % 5)) * kout;
 #pragma unroll
           for (int n = 0; n < NT; ++n) {
             f32x4 v = acc[j][n];
+            if (EPI == 1) v += bias4[n];                   // (packed adds)
+            // (scalars, not elements of pk: a bit cast of a vector ELEMENT read element 0 for
+            // both halves — hipcc 7.2)
+            unsigned p0 = pack2_bf16(v[0], v[1]), p1 = pack2_bf16(v[2], v[3]);
             if (EPI == 1) {
-#pragma unroll
-              for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q] + bias4[n][q], floor_v);
+              p0 = max2_i16(p0, relu_floor);               // ReLU on the rounded pairs, or the identity
+              p1 = max2_i16(p1, relu_floor);
             }
-            u32x2 pk;
-            pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-            pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+            const u32x2 pk = {p0, p1};
             *reinterpret_cast<u32x2*>(scr + i * SLD + 16 * n + 4 * g) = pk;
           }
           __builtin_amdgcn_wave_barrier();
@@ -520,8 +526,12 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
           for (int rr = 0; rr < RR; ++rr) {
             u32x4 v = *reinterpret_cast<const u32x4*>(scr + piece_px[rr] * SLD + 8 * ((lane + 64 * rr) % PCS));
             if (EPI == 2) v = relu_mask(v, mk[EPI == 2 ? j : 0][EPI == 2 ? rr : 0]);
-            const bool inside = oy + ht_row(piece_px[rr]) < H && ox + ht_col(piece_px[rr]) < W && !(dbg & 2);
-            if (inside) *reinterpret_cast<u32x4*>(ob + piece_o[rr]) = v;
+            if (full_tile) {                               // (wave-uniform: no per-lane test)
+              *reinterpret_cast<u32x4*>(ob + piece_o[rr]) = v;
+            } else {
+              const bool inside = oy + ht_row(piece_px[rr]) < H && ox + ht_col(piece_px[rr]) < W && !(dbg & 2);
+              if (inside) *reinterpret_cast<u32x4*>(ob + piece_o[rr]) = v;
+            }
           }
           __builtin_amdgcn_wave_barrier();
         }

@@ -39,6 +39,25 @@ __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
   return __builtin_bit_cast(unsigned short, b);
 }
 
+// two values at once: one v_cvt_pk_bf16_f32 instead of two conversions + a shift + an or
+// (a in the low half); the same rounding
+__device__ __forceinline__ unsigned pack2_bf16(float a, float b) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+
+// max of both bf16 halves of a word with `floor16` AS 16-BIT INTEGERS (one v_pk_max_i16): with
+// floor16 = 0 that is ReLU on the rounded pair — a bf16 is negative exactly when it is as an
+// integer, rounding keeps the sign, so max(round(v), 0) = round(max(v, 0)), -0 -> +0 (a NaN with
+// the sign bit clear stays) — and with the least int16 the identity
+__device__ __forceinline__ unsigned max2_i16(unsigned w, short floor16) {
+  typedef short s16x2_t __attribute__((ext_vector_type(2)));
+  const s16x2_t a = __builtin_bit_cast(s16x2_t, w), z = {floor16, floor16};
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(a, z));
+}
+
 // Convolution weights come as bf16 or as the float32 master copy (SCL_W_F32 in the flags
 // argument: rounded to bf16 on the way into the packed image, so no separate cast pass);
 // weight gradients go out in the same type.
