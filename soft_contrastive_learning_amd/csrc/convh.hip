@@ -154,6 +154,7 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
   using G = HCfg<BHv>;
   constexpr int BH = G::BH, WR = G::WR, WIN = G::WIN, NMT = G::NMT, MT = G::MT, NT = G::NT;
   constexpr int MH = G::MH, NI = G::NI, NA = G::NA, SPT = G::SPT;
+  constexpr bool WEAVE = BHv == 24;
   constexpr int HS = 9 * SPT;                  // sub-steps per chunk; odd: the roles of af[] flip too
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
   unsigned short* win = lds;
@@ -214,6 +215,12 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
       const int j = wid + 8 * n;
       hglds16(src + j * 512, base + j * 1024);
     }
+  };
+  auto issue_wts_one = [&](int grp, int buf, int n) {   // one of a wave's three chunks of a group
+    const unsigned short* src = packed + ((int64_t)nb * S + HTPB * grp) * HWT + lane * 8;
+    const unsigned base = h_lds_byte_of(wts) + buf * HTPB * HWT * 2;
+    const int j = wid + 8 * n;
+    hglds16(src + j * 512, base + j * 1024);
   };
   auto stage_first = [&]() {                            // a tile's first two groups and window
     issue_wts(0, 0);
@@ -306,6 +313,18 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
       const unsigned short* wcur = win + (cc & 1) * WIN;
       const unsigned short* wnext = win + ((cc + 1) & 1) * WIN;
       const int ccn = cc + 1 < CC ? cc + 1 : cc;
+      // request k = 0 .. 5 of the group behind barrier gi: the three weight chunks, then the
+      // window chunks of that barrier's part
+      auto issue_op = [&](int gi, int k) {
+        if (k < 3) {
+          const int gn = 3 * cc + gi + 2 < NG ? 3 * cc + gi + 2 : NG - 3 + (gi + 2) % 3;
+          issue_wts_one(gn, (gi + 2) % 3, k);
+        } else {
+          const int n = (gi == 0 ? 0 : NA) + k - 3;
+          if (gi == 0 && n < NA) issue_win(ccn, (cc + 1) & 1, n, n + 1);
+          if (gi == 1 && n < NI) issue_win(ccn, (cc + 1) & 1, n, n + 1);
+        }
+      };
 #pragma unroll
       for (int h = 0; h < HS; ++h) {
         // the fragments of the next sub-step fly under the MFMAs of this one
@@ -315,13 +334,23 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
           load_half(wnext, 0, PAR ^ 1, APAR ^ (HS & 1));
         __builtin_amdgcn_sched_barrier(0);
         const int t = h / SPT, mh = h % SPT;
+        // WEAVE: the requests that follow a barrier go out BETWEEN the products of the next
+        // sub-step (one behind every m-tile's products) instead of in one block in front of them
+        const bool after_barrier = WEAVE && (h % (3 * SPT) == HX + 1);   // (compile-time once unrolled)
 #pragma unroll
-        for (int j = 0; j < MH; ++j)
+        for (int j = 0; j < MH; ++j) {
 #pragma unroll
           for (int n = 0; n < NT; ++n)
             acc[MH * mh + j][n] =
                 EPI == 3 ? mfma16h(af[(h + APAR) & 1][j], bf[(t + PAR) & 1][n], acc[MH * mh + j][n])
                          : mfma16h(bf[(t + PAR) & 1][n], af[(h + APAR) & 1][j], acc[MH * mh + j][n]);
+          if (after_barrier) {
+            __builtin_amdgcn_sched_barrier(0);
+            issue_op(h / (3 * SPT), j);
+            if (j == MH - 1) issue_op(h / (3 * SPT), MH);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
         if (h % (3 * SPT) == HX) {
           __builtin_amdgcn_sched_barrier(0);
           // own share of what the NEXT group reads has landed; the barrier publishes everybody's
@@ -335,10 +364,12 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
           HSTAMP(2 + 9 * PAR + 3 * gi + 1);
           // ... and everybody has left the previous group: its weight buffer takes the group
           // after next, the other window buffer the next chunk's window (in two parts)
-          const int gn = 3 * cc + gi + 2 < NG ? 3 * cc + gi + 2 : NG - 3 + (gi + 2) % 3;
-          issue_wts(gn, (gi + 2) % 3);
-          if (gi == 0) issue_win(ccn, (cc + 1) & 1, 0, NA);
-          if (gi == 1) issue_win(ccn, (cc + 1) & 1, NA, NI);
+          if (!WEAVE) {
+            const int gn = 3 * cc + gi + 2 < NG ? 3 * cc + gi + 2 : NG - 3 + (gi + 2) % 3;
+            issue_wts(gn, (gi + 2) % 3);
+            if (gi == 0) issue_win(ccn, (cc + 1) & 1, 0, NA);
+            if (gi == 1) issue_win(ccn, (cc + 1) & 1, NA, NI);
+          }
           HSTAMP(2 + 9 * PAR + 3 * gi + 2);
         }
       }
