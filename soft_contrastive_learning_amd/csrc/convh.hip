@@ -154,7 +154,7 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
   using G = HCfg<BHv>;
   constexpr int BH = G::BH, WR = G::WR, WIN = G::WIN, NMT = G::NMT, MT = G::MT, NT = G::NT;
   constexpr int MH = G::MH, NI = G::NI, NA = G::NA, SPT = G::SPT;
-  constexpr bool WEAVE = BHv == 24;
+  constexpr bool WEAVE = BHv == 24 || BHv == 6 || BHv == 8;
   constexpr int HS = 9 * SPT;                  // sub-steps per chunk; odd: the roles of af[] flip too
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
   unsigned short* win = lds;
@@ -346,8 +346,8 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
                          : mfma16h(bf[(t + PAR) & 1][n], af[(h + APAR) & 1][j], acc[MH * mh + j][n]);
           if (after_barrier) {
             __builtin_amdgcn_sched_barrier(0);
-            issue_op(h / (3 * SPT), j);
-            if (j == MH - 1) issue_op(h / (3 * SPT), MH);
+#pragma unroll
+            for (int k = j * 6 / MH; k < (j + 1) * 6 / MH; ++k) issue_op(h / (3 * SPT), k);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
