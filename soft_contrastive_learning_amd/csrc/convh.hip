@@ -284,6 +284,7 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
     // fragments (one set per step) between bf[0] and bf[1] by step; a chunk has nine steps, so
     // the roles of bf[] flip from chunk to chunk (PAR).
     u32x4 af[2][MH], bf[2][NT];
+    int tb = 0;            // the lane's fragment offset for the tap in flight (set at its first sub-step)
     auto load_half = [&](const unsigned short* wbase, int h, int par, int apar) {
       const int t = h / SPT, mh = h % SPT;
       if (mh == 0) {
@@ -291,11 +292,12 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
 #pragma unroll
         for (int n = 0; n < NT; ++n)
           bf[(t + par) & 1][n] = *reinterpret_cast<const u32x4*>(wbp + 16 * n * 8);
+        // once per tap (it was once per sub-step: four vector instructions each)
+        // (opaque: the compiler would otherwise keep all 9 x MT address sums in registers)
+        int pk = pieces;
+        asm volatile("" : "+v"(pk));
+        tb = lane_a + ((pk >> (2 * t)) & 3) * 8;
       }
-      // (opaque: the compiler would otherwise keep all 9 x MT address sums in registers)
-      int pk = pieces;
-      asm volatile("" : "+v"(pk));
-      const int tb = lane_a + ((pk >> (2 * t)) & 3) * 8;
 #pragma unroll
       for (int j = 0; j < MH; ++j)
         af[(h + apar) & 1][j] = *reinterpret_cast<const u32x4*>(
