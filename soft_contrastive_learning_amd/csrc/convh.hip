@@ -142,7 +142,9 @@ __device__ __forceinline__ unsigned h_lds_byte_of(const unsigned short* p) {
 // requests issued} for the last chunk pair of the tile; 20 K loop left, 21 barrier, 22 epilogue
 // done.  (Each stamp waits for its own result: the compiler does not know that s_memtime writes
 // its registers late, and re-used them — one stamp landed in a pointer.)
-template <int EPI, int BHv, bool STAMP = false>
+// FULL: H and W are multiples of the block — no tile crosses the image's lower or right border, the
+// epilogue carries no border code at all (every bench shape).
+template <int EPI, int BHv, bool STAMP = false, bool FULL = false>
 __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __restrict__ x,
                                                        const unsigned short* __restrict__ packed,
                                                        int B, int H, int W, int cin, int kout,
@@ -233,6 +235,7 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
   // REG: a wave group's m-tiles are whole row pairs — m-tile j sits at a compile-time offset from
   // the group's first one, which rides in the ds_read's offset field (no address add per read)
   constexpr bool REG = MT % 5 == 0;
+  constexpr bool ALLT = NMT % MT == 0;         // every m-tile slot of every wave group is a real m-tile
   int aoff[MT];
 #pragma unroll
   for (int j = 0; j < MT; ++j) {
@@ -438,17 +441,28 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
     // accumulators); the next tile's first stage goes out once every mask load has been issued
     constexpr int PD = MT / 2;
     u32x4 mk[EPI == 2 ? MT : 1][EPI == 2 ? RR : 1];
+    // the tile's corner pixel, this wave's channels (element offset into out / mask); a tile that
+    // lies inside the image whole (every tile of the bench shapes) loads and stores without the
+    // per-lane border tests
+    const int64_t tile_off = (((int64_t)b_e * H + y0_e) * W + x0_e) * kout + ch_w;
+    const bool full_tile = FULL ? !(dbg & 2) : (y0_e + BH <= H && x0_e + HBW <= W && !(dbg & 2));
     auto load_mask = [&](int j) {
       const int mt = MT * mg + j;
       const int oy = y0_e + 2 * (mt / 5), ox = x0_e + 8 * (mt % 5);
-      const unsigned short* mb = mask + (((int64_t)b_e * H + oy) * W + ox) * kout + ch_w;
+      const unsigned short* mb = mask + tile_off + ((2 * (mt / 5)) * W + 8 * (mt % 5)) * kout;
 #pragma unroll
       for (int rr = 0; rr < RR; ++rr) {
         // (every element is assigned: a conditionally assigned one would stay live around the
         // whole tile loop)
-        const bool inside = mt < NMT && oy + ht_row(piece_px[rr]) < H && ox + ht_col(piece_px[rr]) < W;
-        mk[EPI == 2 ? j : 0][EPI == 2 ? rr : 0] =
-            inside ? *reinterpret_cast<const u32x4*>(mb + piece_o[rr]) : u32x4{0u, 0u, 0u, 0u};
+        if (FULL ? (ALLT || mt < NMT) : (full_tile && mt < NMT)) {   // wave-uniform
+          mk[EPI == 2 ? j : 0][EPI == 2 ? rr : 0] = *reinterpret_cast<const u32x4*>(mb + piece_o[rr]);
+        } else if (FULL) {
+          mk[EPI == 2 ? j : 0][EPI == 2 ? rr : 0] = u32x4{0u, 0u, 0u, 0u};
+        } else {
+          const bool inside = mt < NMT && oy + ht_row(piece_px[rr]) < H && ox + ht_col(piece_px[rr]) < W;
+          mk[EPI == 2 ? j : 0][EPI == 2 ? rr : 0] =
+              inside ? *reinterpret_cast<const u32x4*>(mb + piece_o[rr]) : u32x4{0u, 0u, 0u, 0u};
+        }
       }
     };
     if (EPI == 2) {
@@ -530,14 +544,11 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
       }
     } else {
       typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-      // the tile's corner pixel, this wave's channels; a tile that lies inside the image whole
-      // (every tile of the bench shapes) stores without the per-lane border tests
-      unsigned short* out_tile = out + (((int64_t)b_e * H + y0_e) * W + x0_e) * kout + ch_w;
-      const bool full_tile = y0_e + BH <= H && x0_e + HBW <= W && !(dbg & 2);
+      unsigned short* out_tile = out + tile_off;
 #pragma unroll
       for (int j = 0; j < MT; ++j) {
         const int mt = MT * mg + j;
-        if (mt < NMT) {                                    // wave-uniform
+        if (ALLT || mt < NMT) {                            // wave-uniform
           const int oy = y0_e + 2 * (mt / 5), ox = x0_e + 8 * (mt % 5);
           unsigned short* ob = out_tile + ((2 * (mt / 5)) * W + 8 * (mt % 5)) * kout;
 #pragma unroll
@@ -561,7 +572,7 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
             if (EPI == 2) v = relu_mask(v, mk[EPI == 2 ? j : 0][EPI == 2 ? rr : 0]);
             if (full_tile) {                               // (wave-uniform: no per-lane test)
               *reinterpret_cast<u32x4*>(ob + piece_o[rr]) = v;
-            } else {
+            } else if (!FULL) {
               const bool inside = oy + ht_row(piece_px[rr]) < H && ox + ht_col(piece_px[rr]) < W && !(dbg & 2);
               if (inside) *reinterpret_cast<u32x4*>(ob + piece_o[rr]) = v;
             }
@@ -615,6 +626,8 @@ int scl_convh_dispatch(const void* x, const void* w, int64_t w_stride_k, int64_t
   std::call_once(once, [] {
 #define SCL_CONVH_ATTR(E, BHV)                                                                 \
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convh_kernel<E, BHV>),              \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)HCfg<BHV>::LDS);  \
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convh_kernel<E, BHV, false, true>), \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)HCfg<BHV>::LDS);
     SCL_CONVH_ATTR(0, 12) SCL_CONVH_ATTR(1, 12) SCL_CONVH_ATTR(2, 12) SCL_CONVH_ATTR(3, 12)
     SCL_CONVH_ATTR(0, 24) SCL_CONVH_ATTR(1, 24) SCL_CONVH_ATTR(2, 24) SCL_CONVH_ATTR(3, 24)
@@ -663,11 +676,18 @@ int scl_convh_dispatch(const void* x, const void* w, int64_t w_stride_k, int64_t
   // 3020 + bits: 1 no wait / barrier at the top of a tile, 2 no output stores
   // 3040: EXPERIMENT (correct results): s_setprio 1 for waves 4..7 before the tile loop
   const int dbgbits = (dv >= 3020 && dv < 3024) ? (dv - 3020) << 1 : (dv == 3040 ? 4 << 1 : 0);
-#define SCL_CONVH_LAUNCH(E, BHV, BIAS, RELU, MASK)                                             \
-  SCL_LAUNCH("convh_kernel", (convh_kernel<E, BHV>), grid, dim3(HTHR), HCfg<BHV>::LDS, st,     \
-             (const unsigned short*)x, (const unsigned short*)packed, B, H, W, cin, kout,      \
-             (unsigned short*)out, BIAS, RELU, (const unsigned short*)MASK,                    \
+#define SCL_CONVH_LAUNCH_F(E, BHV, FULLV, BIAS, RELU, MASK)                                   \
+  SCL_LAUNCH("convh_kernel", (convh_kernel<E, BHV, false, FULLV>), grid, dim3(HTHR),           \
+             HCfg<BHV>::LDS, st, (const unsigned short*)x, (const unsigned short*)packed, B, H, \
+             W, cin, kout, (unsigned short*)out, BIAS, RELU, (const unsigned short*)MASK,      \
              (unsigned char*)pidx, vblocks)
+#define SCL_CONVH_LAUNCH(E, BHV, BIAS, RELU, MASK)                                             \
+  do {                                                                                         \
+    if (E != 3 && H % HCfg<BHV>::BH == 0 && W % HBW == 0)                                      \
+      SCL_CONVH_LAUNCH_F(E, BHV, true, BIAS, RELU, MASK);                                      \
+    else                                                                                       \
+      SCL_CONVH_LAUNCH_F(E, BHV, false, BIAS, RELU, MASK);                                     \
+  } while (0)
 #define SCL_CONVH_BH(E, BIAS, RELU, MASK)                                                      \
   do {                                                                                         \
     if (bh == 12 && cut2x4) SCL_CONVH_LAUNCH(E, 24, BIAS, RELU, MASK);                         \
@@ -699,5 +719,6 @@ int scl_convh_dispatch(const void* x, const void* w, int64_t w_stride_k, int64_t
     SCL_CONVH_BH(0, bias, 0, nullptr);
 #undef SCL_CONVH_BH
 #undef SCL_CONVH_LAUNCH
+#undef SCL_CONVH_LAUNCH_F
   return scl_launch_status();
 }
