@@ -157,7 +157,18 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
   //   pooled == NULL: out = acc (+ bias) (ReLU if relu)            conv + bias + activation
   //   pooled != NULL: out = acc raw, pooled = relu(max2x2(acc) + bias)   conv + pool + ReLU
   const float bias_r = (EPI == 1 || EPI == 2 || EPI == 4) ? bias[32 * nt + r] : 0.f;
-  const float add_r = EPI == 1 ? bias_r : 0.f;
+  // SWAP (the epilogues without pooling): the MFMA runs with the operands swapped — weights as A,
+  // pixels as B; products and summation order do not change — so that accumulator register q of
+  // lane (pixel r, half h) is channel acc_row(q, h) of the wave's 32: four consecutive channels
+  // per register quad, i.e. two packed conversions and one 8-byte LDS write instead of four
+  // conversions and four 2-byte writes.  The pooled epilogues keep pixels as A (their 2 x 2
+  // windows are register pairs of one lane).
+  constexpr bool SWAP = EPI == 0 || EPI == 1 || EPI == 3;
+  f32x4 bias_q[4];                     // SWAP + bias: channels 8 j + 4 h .. + 3 of the n-tile
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    bias_q[j] = (SWAP && EPI == 1) ? *reinterpret_cast<const f32x4*>(bias + 32 * nt + 8 * j + 4 * h)
+                                   : f32x4{0.f, 0.f, 0.f, 0.f};
 
   // the wave's weight slice: KS fragments of 16 bytes per lane
   u32x4 wf[KS];
@@ -247,6 +258,7 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
 
   const int dbg = relu >> 1;            // timing diagnostics (scl_debug_set_variant(60000 + bits))
   relu &= 1;
+  const short relu_floor = relu ? (short)0 : (short)-32768;   // packed ReLU: max with 0, or with the least int16
   // (experiment, 60004: static priority for the younger half of an eight-wave workgroup)
   if ((dbg & 4) && (threadIdx.x >> 6) >= 4) __builtin_amdgcn_s_setprio(1);
   int tile = blockIdx.x;
@@ -314,7 +326,8 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
       for (int mt = 0; mt < MT; ++mt) {
         const int kh = wr - mt;
         if (kh >= 0 && kh < 3)
-          acc[mt] = mfma32b(af[st % RING], wf[(3 * kh + kw) * Cfg::SPT + c], acc[mt]);
+          acc[mt] = SWAP ? mfma32b(wf[(3 * kh + kw) * Cfg::SPT + c], af[st % RING], acc[mt])
+                         : mfma32b(af[st % RING], wf[(3 * kh + kw) * Cfg::SPT + c], acc[mt]);
       }
       // the un-pooling slices keep their places on the scale of the KS k-steps
       const int ks = st * KS / NST;
@@ -345,11 +358,21 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
       const bool inside = oy < H && ox < W;
       const int64_t o_off = (((int64_t)b * H + oy) * W + ox) * KOUT + 32 * nt + 8 * hf;
       const u32x4 y0v = mk[EPI == 3 ? mt : 0][0], y1v = mk[EPI == 3 ? mt : 0][1];
+      if (SWAP) {
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        float v = acc[mt][q] + add_r;
-        if (EPI == 1 && relu) v = fmaxf(v, 0.f);
-        scr[acc_row(q, h) * SCR_LD + r] = f32_to_bf16(v);
+        for (int j = 0; j < 4; ++j) {
+          f32x4 v = {acc[mt][4 * j], acc[mt][4 * j + 1], acc[mt][4 * j + 2], acc[mt][4 * j + 3]};
+          if (EPI == 1) v += bias_q[j];
+          unsigned p0 = pack2_bf16(v[0], v[1]), p1 = pack2_bf16(v[2], v[3]);
+          if (EPI == 1) {                                  // ReLU on the rounded pairs, or the identity
+            p0 = max2_i16(p0, relu_floor);
+            p1 = max2_i16(p1, relu_floor);
+          }
+          *reinterpret_cast<uint2*>(scr + r * SCR_LD + 8 * j + 4 * h) = make_uint2(p0, p1);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) scr[acc_row(q, h) * SCR_LD + r] = f32_to_bf16(acc[mt][q]);   // (EPI 2: raw)
       }
       __builtin_amdgcn_wave_barrier();
       u32x4 v0 = *reinterpret_cast<const u32x4*>(scr + px * SCR_LD + 8 * hf);
