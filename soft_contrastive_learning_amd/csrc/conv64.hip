@@ -136,9 +136,7 @@ __global__ __launch_bounds__(256) void conv3x3_pack_kernel(const void* __restric
 // built in LDS by the threads (16 bytes of the pooled map + 8 index bytes per (pooled pixel,
 // 8 channels), loaded when the tile starts, un-pooled and written in slices between the k-steps
 // of the second half of the K loop) — the full-size map is never in memory.  H and W even.
-// FULL: H and W are multiples of the tile — no output tile crosses the image's lower or right
-// border: the epilogue's stores and mask loads carry no per-lane border tests (every bench shape).
-template <int CIN, int KOUT, int EPI, int PL = 0, bool FULL = false>
+template <int CIN, int KOUT, int EPI, int PL = 0>
 __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(const unsigned short* __restrict__ x,
                                                          const unsigned short* __restrict__ packed,
                                                          int B, int H, int W,
@@ -292,7 +290,7 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
       const int my0 = (t2_ / tiles_x) * TH_ + MT * part, mx = (t2_ % tiles_x) * TW + (lane >> 1);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        const bool in_ = FULL || (my0 + mt < H && mx < W);
+        const bool in_ = my0 + mt < H && mx < W;
         const int64_t mo = (((int64_t)b_ * H + my0 + mt) * W + mx) * KOUT + 32 * nt + 8 * (lane & 1);
         mk[mt][0] = in_ ? *reinterpret_cast<const u32x4*>(mask + mo) : u32x4{0u, 0u, 0u, 0u};
         mk[mt][1] = in_ ? *reinterpret_cast<const u32x4*>(mask + mo + 16) : u32x4{0u, 0u, 0u, 0u};
@@ -357,7 +355,7 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
       // (whole 32-byte sectors — interleaving the two lanes' 16-byte pieces writes half sectors)
       const int px = lane >> 1, hf = lane & 1;
       const int oy = oy0 + mt, ox = ox0 + px;
-      const bool inside = FULL || (oy < H && ox < W);
+      const bool inside = oy < H && ox < W;
       const int64_t o_off = (((int64_t)b * H + oy) * W + ox) * KOUT + 32 * nt + 8 * hf;
       const u32x4 y0v = mk[EPI == 3 ? mt : 0][0], y1v = mk[EPI == 3 ? mt : 0][1];
       if (SWAP) {
@@ -384,7 +382,7 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
         v0 = relu_mask(v0, y0v);
         v1 = relu_mask(v1, y1v);
       }
-      if (FULL || (inside && !(dbg & 2))) {
+      if (inside && !(dbg & 2)) {
         *reinterpret_cast<u32x4*>(out + o_off) = v0;
         *reinterpret_cast<u32x4*>(out + o_off + 16) = v1;
       }
@@ -417,7 +415,7 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
         if (EPI == 4) kv = *reinterpret_cast<const uint2*>(scr8 + px * 32 + 8 * qu);
         __builtin_amdgcn_wave_barrier();
         const int py = (oy0 >> 1) + mp, pxg = (ox0 >> 1) + px;
-        if (FULL || (py < PH2 && pxg < PW2)) {
+        if (py < PH2 && pxg < PW2) {
           const int64_t po = (((int64_t)b * PH2 + py) * PW2 + pxg) * KOUT + 32 * nt + 8 * qu;
           *reinterpret_cast<u32x4*>(pooled + po) = v;
           if (EPI == 4) *reinterpret_cast<uint2*>(pidx + po) = kv;
@@ -1526,18 +1524,9 @@ int launch_conv3x3(const void* x, const void* w, int64_t sk, int64_t sc, int64_t
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<CIN, KOUT, 4>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
-    if (CIN == KOUT) {
+    if (CIN == KOUT)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<CIN, CIN, 3, 1>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<CIN, CIN, 3, 1, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
-    }
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<CIN, KOUT, 1, 0, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<CIN, KOUT, 3, 0, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<CIN, KOUT, 4, 0, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
   });
   const int cus = conv64_cus();
   const unsigned short* packed = (const unsigned short*)workspace;
@@ -1550,34 +1539,16 @@ int launch_conv3x3(const void* x, const void* w, int64_t sk, int64_t sc, int64_t
   const int tiles = B * ((H + Cfg::TH_ - 1) / Cfg::TH_) * ((W + TW - 1) / TW);
   const dim3 grid(tiles < cus ? tiles : cus);
   if (scl_debug_variant / 1000 == 60) relu |= (scl_debug_variant & 7) << 1;   // bit 2: setprio experiment
-  // (the passes of the training step have a FULL form for shapes that tile exactly; the timing
-  // ablations run the general one)
-  const bool full = H % Cfg::TH_ == 0 && W % TW == 0 && !(relu >> 1);
-  if (pidx && full)
-    SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 4, 0, true>), grid, dim3(Cfg::NTHR), Cfg::LDS, st,
-               (const unsigned short*)x, (const unsigned short*)packed, B, H, W,
-               (unsigned short*)nullptr, bias, relu & ~1, (unsigned short*)pooled,
-               (const unsigned short*)nullptr, (unsigned char*)pidx, (const unsigned char*)nullptr);
-  else if (pidx)
+  if (pidx)
     SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 4>), grid, dim3(Cfg::NTHR), Cfg::LDS, st,
                (const unsigned short*)x, (const unsigned short*)packed, B, H, W,
                (unsigned short*)nullptr, bias, relu & ~1, (unsigned short*)pooled,
                (const unsigned short*)nullptr, (unsigned char*)pidx, (const unsigned char*)nullptr);
-  else if (mask && uidx && CIN == KOUT && full)
-    SCL_LAUNCH("conv3x3_kernel<pooled>", (conv3x3_kernel<CIN, CIN, 3, 1, true>), grid, dim3(Cfg::NTHR), Cfg::LDS,
-               st, (const unsigned short*)x, (const unsigned short*)packed, B, H, W,
-               (unsigned short*)out, bias, relu & ~1, (unsigned short*)nullptr,
-               (const unsigned short*)mask, (unsigned char*)nullptr, (const unsigned char*)uidx);
   else if (mask && uidx && CIN == KOUT)
     SCL_LAUNCH("conv3x3_kernel<pooled>", (conv3x3_kernel<CIN, CIN, 3, 1>), grid, dim3(Cfg::NTHR), Cfg::LDS,
                st, (const unsigned short*)x, (const unsigned short*)packed, B, H, W,
                (unsigned short*)out, bias, relu & ~1, (unsigned short*)nullptr,
                (const unsigned short*)mask, (unsigned char*)nullptr, (const unsigned char*)uidx);
-  else if (mask && full)
-    SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 3, 0, true>), grid, dim3(Cfg::NTHR), Cfg::LDS, st,
-               (const unsigned short*)x, (const unsigned short*)packed, B, H, W,
-               (unsigned short*)out, bias, relu & ~1, (unsigned short*)nullptr,
-               (const unsigned short*)mask, (unsigned char*)nullptr, (const unsigned char*)nullptr);
   else if (mask)
     SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 3>), grid, dim3(Cfg::NTHR), Cfg::LDS, st,
                (const unsigned short*)x, (const unsigned short*)packed, B, H, W,
@@ -1585,11 +1556,6 @@ int launch_conv3x3(const void* x, const void* w, int64_t sk, int64_t sc, int64_t
                (const unsigned short*)mask, (unsigned char*)nullptr, (const unsigned char*)nullptr);
   else if (pooled)
     SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 2>), grid, dim3(Cfg::NTHR), Cfg::LDS, st,
-               (const unsigned short*)x, (const unsigned short*)packed, B, H, W,
-               (unsigned short*)out, bias, relu, (unsigned short*)pooled,
-               (const unsigned short*)nullptr, (unsigned char*)nullptr, (const unsigned char*)nullptr);
-  else if (bias && full)
-    SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 1, 0, true>), grid, dim3(Cfg::NTHR), Cfg::LDS, st,
                (const unsigned short*)x, (const unsigned short*)packed, B, H, W,
                (unsigned short*)out, bias, relu, (unsigned short*)pooled,
                (const unsigned short*)nullptr, (unsigned char*)nullptr, (const unsigned char*)nullptr);
