@@ -24,7 +24,7 @@ LAYERS = {'3_2': (256, 256, 120, 160), '4_2': (512, 512, 60, 80), '5_2': (512, 5
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--layer', default='4_2')
-    ap.add_argument('--pass', dest='which', default='fwd', choices=['fwd', 'bwd'])
+    ap.add_argument('--pass', dest='which', default='fwd', choices=['fwd', 'bwd', 'pool'])
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--batch', type=int, default=24)
     ap.add_argument('--rounds', type=int, default=4)
@@ -46,6 +46,8 @@ def main():
     def run():
         if args.which == 'fwd':
             nets.conv64(x, wt, False, bias=bias, relu=True, out=out)
+        elif args.which == 'pool':
+            nets.conv_pool_idx(x, wt, bias)          # forward with the pooled + window index epilogue
         else:
             nets.conv64(gz, wt, True, mask=x, out=gx)
 

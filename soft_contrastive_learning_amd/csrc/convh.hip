@@ -529,7 +529,7 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
           const int mt = MT * mg + jb + (pl >> 2);
           const int py = (y0_e >> 1) + mt / 5, px = (x0_e >> 1) + 4 * (mt % 5) + (pl & 3);
           const u32x4 v = *reinterpret_cast<const u32x4*>(scr + pl * SLD + 8 * pc);
-          if (jb + (pl >> 2) < MT && mt < NMT && py < PH && px < PW && !(dbg & 2))
+          if (jb + (pl >> 2) < MT && (FULL ? (ALLT || mt < NMT) : (mt < NMT && py < PH && px < PW && !(dbg & 2))))
             *reinterpret_cast<u32x4*>(out + (((int64_t)b_e * PH + py) * PW + px) * kout + ch_w + 8 * pc) = v;
         }
         if (lane < 16 * NT) {
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
           const int mt = MT * mg + jb + (pl >> 2);
           const int py = (y0_e >> 1) + mt / 5, px = (x0_e >> 1) + 4 * (mt % 5) + (pl & 3);
           const u32x4 v = *reinterpret_cast<const u32x4*>(scr8 + pl * SLD8 + 16 * pc);
-          if (jb + (pl >> 2) < MT && mt < NMT && py < PH && px < PW && !(dbg & 2))
+          if (jb + (pl >> 2) < MT && (FULL ? (ALLT || mt < NMT) : (mt < NMT && py < PH && px < PW && !(dbg & 2))))
             *reinterpret_cast<u32x4*>(pidx + (((int64_t)b_e * PH + py) * PW + px) * kout + ch_w + 16 * pc) = v;
         }
         __builtin_amdgcn_wave_barrier();
@@ -683,7 +683,7 @@ int scl_convh_dispatch(const void* x, const void* w, int64_t w_stride_k, int64_t
              (unsigned char*)pidx, vblocks)
 #define SCL_CONVH_LAUNCH(E, BHV, BIAS, RELU, MASK)                                             \
   do {                                                                                         \
-    if (E != 3 && H % HCfg<BHV>::BH == 0 && W % HBW == 0)                                      \
+    if (H % HCfg<BHV>::BH == 0 && W % HBW == 0)                                                \
       SCL_CONVH_LAUNCH_F(E, BHV, true, BIAS, RELU, MASK);                                      \
     else                                                                                       \
       SCL_CONVH_LAUNCH_F(E, BHV, false, BIAS, RELU, MASK);                                     \
