@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SCL_ABI_VERSION 7
+#define SCL_ABI_VERSION 8
 
 /* error codes (negative = rejected before any launch) */
 #define SCL_OK 0
@@ -563,10 +563,12 @@ int scl_debug_set_variant(int variant);
  * between values the weight and bias gradients differ in ROUNDING: the weight-gradient kernels cut
  * the pixels into one slab per usable CU, so the number of partial sums — and the order in which
  * they are added — follows the setting.  Record the value next to anything that must be
- * reproduced bit for bit (bench.py prints it in `switches`; checkpoints carry it in their
- * metadata).  The fused NetVLAD kernels (csrc/netvlad.hip) do not honour it: their grids are
+ * reproduced bit for bit (bench.py prints it in `switches`; the trainer's checkpoints carry it as
+ * the int32 variable `scl/reserve_cus`).  The fused NetVLAD kernels (csrc/netvlad.hip) do not honour it: their grids are
  * one workgroup per (image, location slice). */
 int scl_set_reserve_cus(int n);
+/* The value in force (the environment variable is resolved on the way); changes nothing. */
+int scl_get_reserve_cus(void);
 int scl_prof_begin(int capacity);
 int scl_prof_count(void);
 int scl_prof_end(float* ms, const char** names, int capacity);

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libscl_hip.so")
 
 # constants of include/scl_hip.h
-ABI_VERSION = 7
+ABI_VERSION = 8
 DT_F32, DT_BF16 = 0, 1
 MASK_WMS_EXP, MASK_WMS_LIN, MASK_WMS_TANH, MASK_LABELS = 0, 1, 2, 3
 SUM_MS, SUM_PLAIN = 0, 1
@@ -111,6 +111,7 @@ SIGNATURES = {
                                      _i, _i, _i, _p, _p, _p, _p, _p, _z, _p]),
     "scl_debug_set_variant": (_i, [_i]),
     "scl_set_reserve_cus": (_i, [_i]),
+    "scl_get_reserve_cus": (_i, []),
     "scl_prof_begin": (_i, [_i]),
     "scl_prof_count": (_i, []),
     "scl_prof_end": (_i, [_p, _p, _i]),

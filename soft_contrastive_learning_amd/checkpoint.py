@@ -121,6 +121,21 @@ def variables_of(model, global_step=0, optimizer=None, extra=None):
     return sd
 
 
+RESERVE_CUS_VAR = 'scl/reserve_cus'
+
+
+def run_switches():
+    """What a bit-for-bit reproduction of the run needs besides the variables: the CUs the
+    persistent convolution grids leave free (include/scl_hip.h, scl_set_reserve_cus: the weight
+    and bias gradients differ in rounding between values).  An int32 variable next to
+    ``global_step``; restoring ignores it (only float variables under the scope are taken).  Empty
+    where the HIP library is not in use."""
+    if not torch.cuda.is_available():
+        return {}
+    from . import _lib
+    return {RESERVE_CUS_VAR: np.asarray(int(_lib.load().scl_get_reserve_cus()), dtype=np.int32)}
+
+
 def save(model, path_stem, global_step=0, extra=None, fmt='tf', optimizer=None):
     """Write one checkpoint; returns its prefix (tf) or file name (npz)."""
     sd = variables_of(model, global_step, optimizer, extra)
@@ -183,7 +198,7 @@ class Saver:
 
     def _save(self, model, prefix, number, global_step, keep, optimizer):
         stem = os.path.join(self.out_dir, '%s-%d' % (prefix, number))
-        out = save(model, stem, global_step, fmt=self.fmt, optimizer=optimizer)
+        out = save(model, stem, global_step, fmt=self.fmt, optimizer=optimizer, extra=run_switches())
         # like tf.train.Saver's _last_checkpoints: only what THIS saver wrote, in save order —
         # files an earlier run left in the directory are never touched
         stems = self._kept.setdefault(prefix, [])

@@ -32,6 +32,11 @@ extern "C" int scl_set_reserve_cus(int n) {
   return old < 0 ? 0 : old;
 }
 
+extern "C" int scl_get_reserve_cus(void) {
+  (void)scl_usable_cus(256);                  // resolves the environment variable if nobody has yet
+  return scl_reserve_cus < 0 ? 0 : scl_reserve_cus;
+}
+
 // ---- per-kernel timing sink (diagnostics; see SCL_LAUNCH in scl_common.h) ---------------
 SclProfSink* volatile scl_prof_sink = nullptr;
 

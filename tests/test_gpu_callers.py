@@ -242,6 +242,30 @@ def test_checkpoint_resume_with_fused_adam_on_the_device(dev, tmp_path):
         assert torch.equal(pa, pb)
 
 
+def test_saver_records_the_reserved_cus(dev, tmp_path):
+    """scl_set_reserve_cus changes the rounding of the weight gradients: the trainer's checkpoints
+    carry the value in force (int32 variable scl/reserve_cus); restoring ignores it."""
+    from soft_contrastive_learning_amd import _lib as L
+    from soft_contrastive_learning_amd import checkpoint
+    from soft_contrastive_learning_amd.model import nets
+    lib = L.load()
+    a = nets.VGG16NetVLAD(seed=5).to(dev)
+    old = lib.scl_set_reserve_cus(8)
+    try:
+        assert lib.scl_get_reserve_cus() == 8
+        sv = checkpoint.Saver(str(tmp_path), max_to_keep=1)
+        stem = sv.save_rolling(a, 11)
+    finally:
+        lib.scl_set_reserve_cus(old)
+    assert lib.scl_get_reserve_cus() == old
+    sd = checkpoint.read_variables(stem)
+    assert int(sd[checkpoint.RESERVE_CUS_VAR]) == 8 and sd[checkpoint.RESERVE_CUS_VAR].dtype.kind == 'i'
+    b = nets.VGG16NetVLAD(seed=6).to(dev)
+    assert checkpoint.load(b, stem) == 11
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert torch.equal(pa, pb)
+
+
 def test_fused_adam_steps_reach_the_convolutions(dev):
     """The packed weight images (nets.prepack) must follow the optimizer: torch's fused Adam
     updates parameters without moving their autograd version, so a version check alone would
