@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SCL_ABI_VERSION 8
+#define SCL_ABI_VERSION 9
 
 /* error codes (negative = rejected before any launch) */
 #define SCL_OK 0
@@ -179,6 +179,15 @@ int scl_gram_loss_fwd_s(const float* emb, int64_t ld_emb, int B, int E, int mask
 int scl_gram_loss_bwd(const float* emb, int64_t ld_emb, int B, int E, const float* coef,
                       const float* grad_loss, int row_begin, int row_count, float* grad_emb,
                       int64_t ld_grad, void* stream);
+/* The same with a workspace (>= scl_gram_loss_bwd_workspace_bytes(B, row_count), 256-byte
+ * aligned; ABI 9): for 64 < B <= 256, at least 128 rows and E % 128 == 0 both operands run as
+ * three bf16 planes on the bf16 matrix cores (six products: float32-equivalent, like the Gram of
+ * the forward) — the many-row case of a single-process run at B = 192; every other shape, and a
+ * NULL workspace, take scl_gram_loss_bwd's kernels. */
+size_t scl_gram_loss_bwd_workspace_bytes(int B, int row_count);
+int scl_gram_loss_bwd_w(const float* emb, int64_t ld_emb, int B, int E, const float* coef,
+                        const float* grad_loss, int row_begin, int row_count, float* grad_emb,
+                        int64_t ld_grad, void* workspace, size_t workspace_bytes, void* stream);
 
 /* _pairwise_squared_distances (model/losses.py:656-661): [T,S,E] -> [T,S,S]. */
 size_t scl_pairwise_sqdist_workspace_bytes(int T, int S, int E);
@@ -538,8 +547,9 @@ int scl_conv_pack_batch(const SclPackJob* jobs, int njobs, void* stream);
  *   921           sibling exchange of the NetVLAD finish / backward prologue: wait limit 0, every
  *                 workgroup takes the self-computing path (CORRECT, bit-identical results)
  *   31            Gram loss, 64 < B <= 256: float32-MFMA Gram instead of bf16x6
- *   32 / 33       Gram loss: the two-launch forward at B <= 32 and the older guarded backward /
- *                 the 32-column backward of the own rows (CORRECT results: A/B partners)
+ *   32 / 33 / 34  Gram loss: the two-launch forward at B <= 32 and the older guarded backward /
+ *                 the 32-column backward of the own rows / the float32-MFMA backward where the
+ *                 bf16-plane one would run (CORRECT results: A/B partners)
  *   100000 * s    Gram loss, B <= 256: force s K-splits
  *   100 + s       top-n: force s reference splits (1..32) instead of the planner's choice
  *   1000 * b (+ 100 + s)   top-n scan: b bit 0 no selection, bit 1 no tile staging,

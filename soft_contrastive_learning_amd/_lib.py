@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libscl_hip.so")
 
 # constants of include/scl_hip.h
-ABI_VERSION = 8
+ABI_VERSION = 9
 DT_F32, DT_BF16 = 0, 1
 MASK_WMS_EXP, MASK_WMS_LIN, MASK_WMS_TANH, MASK_LABELS = 0, 1, 2, 3
 SUM_MS, SUM_PLAIN = 0, 1
@@ -60,6 +60,8 @@ SIGNATURES = {
     "scl_gram_loss_fwd_s": (_i, [_p, _l, _i, _i, _i, _p, _i, _f, _f, _p, _f, _f, _f, _f, _i, _i, _p,
                                  _p, _p, _z, _p, _p]),
     "scl_gram_loss_bwd": (_i, [_p, _l, _i, _i, _p, _p, _i, _i, _p, _l, _p]),
+    "scl_gram_loss_bwd_workspace_bytes": (_z, [_i, _i]),
+    "scl_gram_loss_bwd_w": (_i, [_p, _l, _i, _i, _p, _p, _i, _i, _p, _l, _p, _z, _p]),
     "scl_pairwise_sqdist_workspace_bytes": (_z, [_i, _i, _i]),
     "scl_pairwise_sqdist": (_i, [_p, _i, _i, _i, _p, _p, _z, _p]),
     "scl_tuple_loss_fwd": (_i, [_i, _p, _l, _p, _l, _p, _l, _p, _l, _i, _i, _i, _i, _f, _f, _p, _p,

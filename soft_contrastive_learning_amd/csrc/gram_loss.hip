@@ -1640,6 +1640,161 @@ extern "C" int scl_gram_loss_fwd_s(const float* emb, int64_t ld_emb, int B, int 
   return scl_launch_status();
 }
 
+// ---------------------------------------------------------------------------------------
+// gram_bwd_planes_kernel (round 4): grad[r, :] = g * sum_j M[row_begin + r, j] E[j, :] for MANY rows
+// (a single-process run at B = 192 asks for all of them) with BOTH operands as three bf16 planes
+// and the six products M1E1 + M1E2 + M2E1 + M1E3 + M3E1 + M2E2 on v_mfma_f32_16x16x32_bf16 —
+// float32-equivalent like gram16x6 (what is dropped is 2^-24 relative), at 2.7 x the rate of the
+// float32 MFMA the older kernels use (gram_bwd_fast_kernel<2>: 40 us at B = 192 = 0.39 of that
+// pipe's peak).  Workgroup = 64 columns of E x ALL the rows: the E tile [B][64] is split once into
+// pipe's peak).  The M planes of a k-step (32 contraction rows) come from a pre-split image
+// (gram_coef_planes_kernel: fragment rows of 80 bytes, copied as they lie); see the kernel below.
+constexpr int GBP_LDM = 40;      // bf16 per row of a k-step's M planes (32 + 8 pad = 80 bytes)
+
+// coef rows [row_begin, row_begin + R) -> img[plane 3][k-step KS][row Rp][GBP_LDM], zero padded
+__global__ __launch_bounds__(256) void gram_coef_planes_kernel(const float* __restrict__ coef, int B,
+                                                               int row_begin, int R, int Rp, int KS,
+                                                               unsigned short* __restrict__ img) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= Rp * KS * GBP_LDM) return;
+  const int c = idx % GBP_LDM, ks = (idx / GBP_LDM) % KS, r = idx / (GBP_LDM * KS);
+  const int j = 32 * ks + c;
+  const float v = (c < 32 && r < R && j < B) ? coef[(int64_t)(row_begin + r) * B + j] : 0.f;
+  unsigned h1, h2, h3;
+  split3_bf16x(v, h1, h2, h3);
+  const int64_t o = ((int64_t)ks * Rp + r) * GBP_LDM + c, plane = (int64_t)KS * Rp * GBP_LDM;
+  img[o] = (unsigned short)h1;
+  img[plane + o] = (unsigned short)h2;
+  img[2 * plane + o] = (unsigned short)h3;
+}
+
+// grid E / 128; block 512; dynamic LDS max(3 (Rp GBP_LDM + 32 GBP_LDE) * 2, Rp * GBP_LDO * 4) bytes,
+// Rp = 16 NRT (a multiple of 32).  Workgroup = 128 columns x ALL the rows, k-step by k-step: the M
+// planes [Rp][32] of the step come from the pre-split image as they lie, the E slab [32][128] is
+// split into its planes on the way into LDS; both are requested into registers one k-step ahead.
+// Wave w = columns 16 w .. + 15: two transposed reads per plane give its E^T fragments, then one
+// ds_read_b128 per plane and row tile and six MFMAs (two chains of three) per row tile.
+// (The first version kept the whole E tile of 64 columns in LDS and re-read the M planes per
+// 64 columns: 166 MB of L2 -> LDS traffic at B = 192, 34 us — slower than the prepass saved.)
+constexpr int GBP_LDE = 144;     // bf16 per row of an E slab plane in LDS (128 + 16 pad = 288 bytes)
+constexpr int GBP_LDO = 132;     // floats per staged output row (128 + 4 pad)
+template <int NRT>
+__global__ __launch_bounds__(512) void gram_bwd_planes_kernel(const float* __restrict__ emb, int64_t ld,
+                                                              int B, int Bp, int E,
+                                                              const unsigned short* __restrict__ img,
+                                                              const float* __restrict__ grad_loss,
+                                                              int R, float* __restrict__ grad,
+                                                              int64_t ldg) {
+  constexpr int Rp = 16 * NRT;
+  constexpr int NPC = (3 * Rp * 5 + 511) / 512;       // 16-byte pieces of a k-step's M planes per thread
+  extern __shared__ __attribute__((aligned(16))) unsigned short gbp_lds[];
+  unsigned short* mp = gbp_lds;                       // [3][Rp][GBP_LDM]
+  unsigned short* ep = gbp_lds + 3 * Rp * GBP_LDM;    // [3][32][GBP_LDE]
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ii = lane & 15, g_ = lane >> 4, q_ = (lane >> 2) & 3, p_ = lane & 3;
+  const int e0 = blockIdx.x * 128;
+  const int KS = Bp >> 5;
+  gx_u32x4 pre[NPC];                 // (a clang vector: an array of HIP's uint4 structs went to scratch)
+  f32x4 ev[2];
+  auto request = [&](int ks) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < NPC; ++k) {
+      const int idx = threadIdx.x + 512 * k;
+      const int pl = idx / (Rp * 5), rem = idx - pl * Rp * 5;
+      const int ic = idx < 3 * Rp * 5 ? idx : 0;
+      const int plc = ic / (Rp * 5), remc = ic - plc * Rp * 5;
+      pre[k] = *reinterpret_cast<const gx_u32x4*>(img + ((int64_t)(plc * KS + ks) * Rp) * GBP_LDM + remc * 8);
+      (void)pl; (void)rem;
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {                      // E slab: 32 rows x 32 float4
+      const int idx = threadIdx.x + 512 * k, jj = idx >> 5, c4 = idx & 31;
+      const int j = 32 * ks + jj, jc = j < B ? j : B - 1;
+      ev[k] = *reinterpret_cast<const f32x4*>(emb + (int64_t)jc * ld + e0 + 4 * c4);
+      if (j >= B) ev[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto publish = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < NPC; ++k) {
+      const int idx = threadIdx.x + 512 * k;
+      const int pl = idx / (Rp * 5), rem = idx - pl * Rp * 5;
+      if (idx < 3 * Rp * 5) *reinterpret_cast<gx_u32x4*>(mp + pl * Rp * GBP_LDM + rem * 8) = pre[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int idx = threadIdx.x + 512 * k, jj = idx >> 5, c4 = idx & 31;
+      unsigned h[3][4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) split3_bf16x(ev[k][c], h[0][c], h[1][c], h[2][c]);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        *reinterpret_cast<uint2*>(ep + (pl * 32 + jj) * GBP_LDE + 4 * c4) =
+            make_uint2(h[pl][0] | (h[pl][1] << 16), h[pl][2] | (h[pl][3] << 16));
+    }
+  };
+  request(0);
+  f32x4 acc0[NRT], acc1[NRT];
+#pragma unroll
+  for (int t = 0; t < NRT; ++t) acc0[t] = acc1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  typedef short gbp_s16x4 __attribute__((ext_vector_type(4)));
+  for (int ks = 0; ks < KS; ++ks) {
+    __syncthreads();                                   // the previous k-step's fragments are read
+    publish();
+    __syncthreads();
+    if (ks + 1 < KS) request(ks + 1);                  // lands under this k-step's products
+    // E^T fragments of the wave's 16 columns: lane (group g, 4 q + p) addresses slab row
+    // 8 g + 4 half + q, columns 16 w + 4 p .. + 3; lane (g, i) receives column i of the four rows —
+    // k index 8 g + 4 half + q, the natural order of the A fragment's 16 bytes
+    gx_u32x4 bfr[3];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      const unsigned short* pb = ep + (pl * 32 + 8 * g_ + q_) * GBP_LDE + 16 * wid + 4 * p_;
+      const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                                     (gbp_s16x4 __attribute__((address_space(3)))*)(pb)));
+      const uint2 hi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                                     (gbp_s16x4 __attribute__((address_space(3)))*)(pb + 4 * GBP_LDE)));
+      bfr[pl] = gx_u32x4{lo.x, lo.y, hi.x, hi.y};
+    }
+#pragma unroll
+    for (int t = 0; t < NRT; ++t) {
+      gx_u32x4 a[3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        a[pl] = *reinterpret_cast<const gx_u32x4*>(mp + (pl * Rp + 16 * t + ii) * GBP_LDM + 8 * g_);
+      acc0[t] = mfma16bf(a[1], bfr[1], acc0[t]);       // small terms first, two chains
+      acc1[t] = mfma16bf(a[0], bfr[2], acc1[t]);
+      acc0[t] = mfma16bf(a[2], bfr[0], acc0[t]);
+      acc1[t] = mfma16bf(a[0], bfr[1], acc1[t]);
+      acc0[t] = mfma16bf(a[1], bfr[0], acc0[t]);
+      acc1[t] = mfma16bf(a[0], bfr[0], acc1[t]);
+    }
+  }
+  // register q of lane (column i, group g) = row 16 t + 4 g + q.  The tile leaves through LDS so
+  // that a store instruction writes whole 512-byte row segments.
+  const float g = grad_loss ? *grad_loss : 1.0f;
+  float* ob = reinterpret_cast<float*>(gbp_lds);
+  __syncthreads();                                     // every wave is done with the planes
+#pragma unroll
+  for (int t = 0; t < NRT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      ob[(16 * t + 4 * g_ + q) * GBP_LDO + 16 * wid + ii] = g * (acc0[t][q] + acc1[t][q]);
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < Rp * 32; idx += 512) {
+    const int row = idx >> 5, pc = idx & 31;
+    if (row < R)
+      *reinterpret_cast<f32x4*>(grad + (int64_t)row * ldg + e0 + 4 * pc) =
+          *reinterpret_cast<const f32x4*>(ob + row * GBP_LDO + 4 * pc);
+  }
+}
+
+extern "C" size_t scl_gram_loss_bwd_workspace_bytes(int B, int row_count) {
+  if (B < 1 || row_count < 1) return 0;
+  const int Bp = (B + 31) & ~31, Rp = (row_count + 31) & ~31;
+  return scl_round256((size_t)3 * (Bp / 32) * Rp * GBP_LDM * sizeof(unsigned short));
+}
+
 extern "C" int scl_gram_loss_bwd(const float* emb, int64_t ld_emb, int B, int E, const float* coef,
                                  const float* grad_loss, int row_begin, int row_count,
                                  float* grad_emb, int64_t ld_grad, void* stream) {
@@ -1715,6 +1870,56 @@ extern "C" int scl_gram_loss_bwd(const float* emb, int64_t ld_emb, int B, int E,
   SCL_LAUNCH("gram_bwd_kernel", gram_bwd_kernel, grid, dim3(256), lds, (hipStream_t)stream, emb,
              ld_emb, B, E, coef, grad_loss, row_begin, row_count, vec_ok, grad_emb, ld_grad);
   return scl_launch_status();
+}
+
+extern "C" int scl_gram_loss_bwd_w(const float* emb, int64_t ld_emb, int B, int E, const float* coef,
+                                   const float* grad_loss, int row_begin, int row_count,
+                                   float* grad_emb, int64_t ld_grad, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+  if (!emb || !coef || !grad_emb) return SCL_E_NULL;
+  if (B < 1 || E < 1 || ld_emb < E || ld_grad < E) return SCL_E_SHAPE;
+  if (row_begin < 0 || row_count < 1 || row_begin + row_count > B || B > kMaxB) return SCL_E_SHAPE;
+  const int Bp = (B + 31) & ~31, Rp = (row_count + 31) & ~31;
+  const size_t lds_k = ((size_t)3 * Rp * GBP_LDM + (size_t)3 * 32 * GBP_LDE) * sizeof(unsigned short);
+  const size_t lds_o = (size_t)Rp * GBP_LDO * sizeof(float);
+  const size_t lds = lds_k > lds_o ? lds_k : lds_o;
+  const bool al = (ld_emb % 4 == 0) && ((uintptr_t)emb % 16 == 0) && (ld_grad % 4 == 0) &&
+                  ((uintptr_t)grad_emb % 16 == 0);
+  // many rows (>= 128: with fewer the pre-split launch costs what the kernel saves — B = 96, all
+  // rows: 13.8 + 6.3 us against 17.5) on the bf16 planes; one row tile (a data-parallel rank's own
+  // rows) stays with gram_bwd_rows_kernel, everything else with the float32-MFMA kernels
+  if (workspace && scl_aligned256(workspace) && B > 64 && B <= 256 && row_count >= 128 && E % 128 == 0 &&
+      al && lds <= 160 * 1024 && workspace_bytes >= scl_gram_loss_bwd_workspace_bytes(B, row_count) &&
+      scl_debug_variant != 32 && scl_debug_variant != 34) {      // (34: the float32-MFMA kernels, for A/B)
+    hipStream_t st = (hipStream_t)stream;
+    const int KS = Bp / 32;
+    unsigned short* img = (unsigned short*)workspace;
+    SCL_LAUNCH("gram_coef_planes_kernel", gram_coef_planes_kernel,
+               dim3((unsigned)((Rp * KS * GBP_LDM + 255) / 256)), dim3(256), 0, st, coef, B, row_begin,
+               row_count, Rp, KS, img);
+#define SCL_GBP_CASE(N)                                                                          \
+  if (Rp / 16 == N) {                                                                            \
+    static std::once_flag once##N;                                                               \
+    std::call_once(once##N, [] {                                                                 \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_bwd_planes_kernel<N>),       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);         \
+    });                                                                                          \
+    SCL_LAUNCH("gram_bwd_planes_kernel", gram_bwd_planes_kernel<N>, dim3(E / 128), dim3(512), lds, \
+               st, emb, ld_emb, B, Bp, E, (const unsigned short*)img, grad_loss, row_count,      \
+               grad_emb, ld_grad);                                                               \
+    return scl_launch_status();                                                                  \
+  }
+    SCL_GBP_CASE(4)
+    SCL_GBP_CASE(6)
+    SCL_GBP_CASE(8)
+    SCL_GBP_CASE(10)
+    SCL_GBP_CASE(12)
+    SCL_GBP_CASE(14)
+    SCL_GBP_CASE(16)
+#undef SCL_GBP_CASE
+  }
+  return scl_gram_loss_bwd(emb, ld_emb, B, E, coef, grad_loss, row_begin, row_count, grad_emb, ld_grad,
+                           stream);
 }
 
 extern "C" size_t scl_pairwise_sqdist_workspace_bytes(int T, int S, int E) {

@@ -81,9 +81,11 @@ class _GramLoss(torch.autograd.Function):
             # a data-parallel rank only needs its own rows; the rest stay zero
             grad = torch.zeros((b, e), dtype=torch.float32, device=emb.device)
             target = grad[row_begin:row_begin + row_count]
-        L.check(lib.scl_gram_loss_bwd(L.ptr(emb), emb.stride(0), b, e, L.ptr(coef), L.ptr(g),
-                                      row_begin, row_count, L.ptr(target), grad.stride(0),
-                                      L.stream_of(emb)))
+        # (with a workspace the many-row case runs on bf16 planes: scl_gram_loss_bwd_w)
+        ws = L.workspace(lib.scl_gram_loss_bwd_workspace_bytes(b, row_count), emb.device)
+        L.check(lib.scl_gram_loss_bwd_w(L.ptr(emb), emb.stride(0), b, e, L.ptr(coef), L.ptr(g),
+                                        row_begin, row_count, L.ptr(target), grad.stride(0),
+                                        L.ptr(ws), ws.numel(), L.stream_of(emb)))
         return grad, None, None, None
 
 

@@ -41,7 +41,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_abi_version_and_error_strings(lib):
-    assert lib.scl_abi_version() == 8
+    assert lib.scl_abi_version() == 9
     assert lib.scl_error_string(0) == b"ok"
     assert b"shape" in lib.scl_error_string(-1)
     assert b"NULL" in lib.scl_error_string(-3)

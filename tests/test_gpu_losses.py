@@ -380,3 +380,38 @@ def test_fused_finish_gives_the_bits_of_the_two_launch_forward(dev, b, e, kind):
     for _ in range(20):                                       # the counter keeps returning to zero
         l3, _ = run(0)
         assert l3.view(np.uint32) == l1.view(np.uint32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('b,row_begin,row_count,e', [(192, 0, 192, 4096), (96, 0, 96, 2048), (200, 40, 100, 1024),
+                                                    (256, 0, 200, 1024), (256, 0, 256, 512), (130, 7, 33, 640), (192, 0, 192, 448), (160, 16, 130, 256)])
+def test_gram_backward_on_bf16_planes(dev, b, row_begin, row_count, e):
+    """scl_gram_loss_bwd_w: grad = g M E for many rows on three bf16 planes per operand (six
+    products) against float64, and against the float32-MFMA kernels it replaces (variant 34) —
+    float32-equivalent: both within 2e-6 of the float64 result relative to its largest entry."""
+    from soft_contrastive_learning_amd import _lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(b * 1000 + e)
+    emb = torch.randn(b, e, generator=g).to(dev)
+    coef = (torch.randn(b, b, generator=g) * torch.rand(b, b, generator=g).pow(4)).to(dev)
+    gl = torch.tensor([0.37], device=dev)
+    want = 0.37 * (coef.double()[row_begin:row_begin + row_count] @ emb.double())
+    ws = L.workspace(lib.scl_gram_loss_bwd_workspace_bytes(b, row_count), dev)
+    outs = {}
+    for variant in (0, 34):
+        out = torch.full((row_count, e), 7.0, device=dev)
+        old = lib.scl_debug_set_variant(variant)
+        try:
+            with L.KernelTimer(capacity=16) as kt:
+                L.check(lib.scl_gram_loss_bwd_w(L.ptr(emb), e, b, e, L.ptr(coef), L.ptr(gl), row_begin,
+                                                row_count, L.ptr(out), e, L.ptr(ws), ws.numel(),
+                                                L.stream_of(emb)))
+                torch.cuda.synchronize()
+        finally:
+            lib.scl_debug_set_variant(old)
+        outs[variant] = (out, set(kt.summary()))
+        err = float((out.double() - want).abs().max() / want.abs().max())
+        assert err < 2e-6, (variant, err)
+    planes = 'gram_bwd_planes_kernel' in outs[0][1]
+    assert planes == (64 < b <= 256 and row_count >= 128 and e % 128 == 0), outs[0][1]
+    assert 'gram_bwd_planes_kernel' not in outs[34][1]
