@@ -208,7 +208,6 @@ def kernel_models(b, n, gb, x_bytes, slices=10):
         # M E on three bf16 planes each: six products executed on the bf16 matrix cores
         'gram_bwd_planes_kernel': dict(flops=2.0 * b * gb * E, bytes=gb * E * 4 + b * E * 4,
                                        exec_mult=6.0, peak_tflops=PEAK_BF16_TFLOPS),
-        'gram_coef_planes_kernel': dict(flops=12.0 * b * gb, bytes=b * gb * 10),
         'gram_bwd_rows_kernel': dict(flops=2.0 * b * gb * E, bytes=gb * E * 4 + b * E * 4),
     }
 

@@ -179,11 +179,11 @@ int scl_gram_loss_fwd_s(const float* emb, int64_t ld_emb, int B, int E, int mask
 int scl_gram_loss_bwd(const float* emb, int64_t ld_emb, int B, int E, const float* coef,
                       const float* grad_loss, int row_begin, int row_count, float* grad_emb,
                       int64_t ld_grad, void* stream);
-/* The same with a workspace (>= scl_gram_loss_bwd_workspace_bytes(B, row_count), 256-byte
- * aligned; ABI 9): for 64 < B <= 256, at least 128 rows and E % 128 == 0 both operands run as
- * three bf16 planes on the bf16 matrix cores (six products: float32-equivalent, like the Gram of
- * the forward) — the many-row case of a single-process run at B = 192; every other shape, and a
- * NULL workspace, take scl_gram_loss_bwd's kernels. */
+/* (ABI 9) For 64 < B <= 256 with B % 4 == 0, at least 96 rows and E % 128 == 0 (16-byte aligned
+ * operands) scl_gram_loss_bwd runs both operands as three bf16 planes on the bf16 matrix cores
+ * (six products: float32-equivalent, like the Gram of the forward) — the many-row case of a
+ * single-process run at B = 192.  scl_gram_loss_bwd_w is the same call with a workspace argument
+ * that an earlier form of that path needed; the workspace may be NULL. */
 size_t scl_gram_loss_bwd_workspace_bytes(int B, int row_count);
 int scl_gram_loss_bwd_w(const float* emb, int64_t ld_emb, int B, int E, const float* coef,
                         const float* grad_loss, int row_begin, int row_count, float* grad_emb,

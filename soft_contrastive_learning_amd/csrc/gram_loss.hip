@@ -1647,26 +1647,8 @@ extern "C" int scl_gram_loss_fwd_s(const float* emb, int64_t ld_emb, int B, int 
 // float32-equivalent like gram16x6 (what is dropped is 2^-24 relative), at 2.7 x the rate of the
 // float32 MFMA the older kernels use (gram_bwd_fast_kernel<2>: 40 us at B = 192 = 0.39 of that
 // pipe's peak).  Workgroup = 64 columns of E x ALL the rows: the E tile [B][64] is split once into
-// pipe's peak).  The M planes of a k-step (32 contraction rows) come from a pre-split image
-// (gram_coef_planes_kernel: fragment rows of 80 bytes, copied as they lie); see the kernel below.
+// pipe's peak); see the kernel below.
 constexpr int GBP_LDM = 40;      // bf16 per row of a k-step's M planes (32 + 8 pad = 80 bytes)
-
-// coef rows [row_begin, row_begin + R) -> img[plane 3][k-step KS][row Rp][GBP_LDM], zero padded
-__global__ __launch_bounds__(256) void gram_coef_planes_kernel(const float* __restrict__ coef, int B,
-                                                               int row_begin, int R, int Rp, int KS,
-                                                               unsigned short* __restrict__ img) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= Rp * KS * GBP_LDM) return;
-  const int c = idx % GBP_LDM, ks = (idx / GBP_LDM) % KS, r = idx / (GBP_LDM * KS);
-  const int j = 32 * ks + c;
-  const float v = (c < 32 && r < R && j < B) ? coef[(int64_t)(row_begin + r) * B + j] : 0.f;
-  unsigned h1, h2, h3;
-  split3_bf16x(v, h1, h2, h3);
-  const int64_t o = ((int64_t)ks * Rp + r) * GBP_LDM + c, plane = (int64_t)KS * Rp * GBP_LDM;
-  img[o] = (unsigned short)h1;
-  img[plane + o] = (unsigned short)h2;
-  img[2 * plane + o] = (unsigned short)h3;
-}
 
 // grid E / 128; block 512; dynamic LDS max(3 (Rp GBP_LDM + 32 GBP_LDE) * 2, Rp * GBP_LDO * 4) bytes,
 // Rp = 16 NRT (a multiple of 32).  Workgroup = 128 columns x ALL the rows, k-step by k-step: the M
@@ -1681,12 +1663,13 @@ constexpr int GBP_LDO = 132;     // floats per staged output row (128 + 4 pad)
 template <int NRT>
 __global__ __launch_bounds__(512) void gram_bwd_planes_kernel(const float* __restrict__ emb, int64_t ld,
                                                               int B, int Bp, int E,
-                                                              const unsigned short* __restrict__ img,
+                                                              const float* __restrict__ coef,
+                                                              int row_begin,
                                                               const float* __restrict__ grad_loss,
                                                               int R, float* __restrict__ grad,
                                                               int64_t ldg) {
   constexpr int Rp = 16 * NRT;
-  constexpr int NPC = (3 * Rp * 5 + 511) / 512;       // 16-byte pieces of a k-step's M planes per thread
+  constexpr int NPC = (Rp * 8 + 511) / 512;           // float4 pieces of a k-step's M rows per thread
   extern __shared__ __attribute__((aligned(16))) unsigned short gbp_lds[];
   unsigned short* mp = gbp_lds;                       // [3][Rp][GBP_LDM]
   unsigned short* ep = gbp_lds + 3 * Rp * GBP_LDM;    // [3][32][GBP_LDE]
@@ -1694,17 +1677,16 @@ __global__ __launch_bounds__(512) void gram_bwd_planes_kernel(const float* __res
   const int ii = lane & 15, g_ = lane >> 4, q_ = (lane >> 2) & 3, p_ = lane & 3;
   const int e0 = blockIdx.x * 128;
   const int KS = Bp >> 5;
-  gx_u32x4 pre[NPC];                 // (a clang vector: an array of HIP's uint4 structs went to scratch)
+  f32x4 pre[NPC];                    // (clang vectors: an array of HIP's uint4 structs went to scratch)
   f32x4 ev[2];
   auto request = [&](int ks) __attribute__((always_inline)) {
 #pragma unroll
-    for (int k = 0; k < NPC; ++k) {
-      const int idx = threadIdx.x + 512 * k;
-      const int pl = idx / (Rp * 5), rem = idx - pl * Rp * 5;
-      const int ic = idx < 3 * Rp * 5 ? idx : 0;
-      const int plc = ic / (Rp * 5), remc = ic - plc * Rp * 5;
-      pre[k] = *reinterpret_cast<const gx_u32x4*>(img + ((int64_t)(plc * KS + ks) * Rp) * GBP_LDM + remc * 8);
-      (void)pl; (void)rem;
+    for (int k = 0; k < NPC; ++k) {                    // M rows [Rp][32] of the k-step, float4 pieces
+      const int idx = threadIdx.x + 512 * k, r = idx >> 3, c4 = idx & 7;
+      const int j = 32 * ks + 4 * c4;                  // (B % 4 == 0: a piece is inside or outside)
+      const bool in_ = r < R && j < B;
+      pre[k] = *reinterpret_cast<const f32x4*>(coef + (int64_t)(row_begin + (in_ ? r : 0)) * B + (in_ ? j : 0));
+      if (!in_) pre[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {                      // E slab: 32 rows x 32 float4
@@ -1717,9 +1699,16 @@ __global__ __launch_bounds__(512) void gram_bwd_planes_kernel(const float* __res
   auto publish = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < NPC; ++k) {
-      const int idx = threadIdx.x + 512 * k;
-      const int pl = idx / (Rp * 5), rem = idx - pl * Rp * 5;
-      if (idx < 3 * Rp * 5) *reinterpret_cast<gx_u32x4*>(mp + pl * Rp * GBP_LDM + rem * 8) = pre[k];
+      const int idx = threadIdx.x + 512 * k, r = idx >> 3, c4 = idx & 7;
+      unsigned h[3][4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) split3_bf16x(pre[k][c], h[0][c], h[1][c], h[2][c]);
+      if (r < Rp) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          *reinterpret_cast<uint2*>(mp + (pl * Rp + r) * GBP_LDM + 4 * c4) =
+              make_uint2(h[pl][0] | (h[pl][1] << 16), h[pl][2] | (h[pl][3] << 16));
+      }
     }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -1790,9 +1779,9 @@ __global__ __launch_bounds__(512) void gram_bwd_planes_kernel(const float* __res
 }
 
 extern "C" size_t scl_gram_loss_bwd_workspace_bytes(int B, int row_count) {
-  if (B < 1 || row_count < 1) return 0;
-  const int Bp = (B + 31) & ~31, Rp = (row_count + 31) & ~31;
-  return scl_round256((size_t)3 * (Bp / 32) * Rp * GBP_LDM * sizeof(unsigned short));
+  (void)B;
+  (void)row_count;
+  return 256;                                   // (no workspace is needed any more: kept for the ABI)
 }
 
 extern "C" int scl_gram_loss_bwd(const float* emb, int64_t ld_emb, int B, int E, const float* coef,
@@ -1806,6 +1795,40 @@ extern "C" int scl_gram_loss_bwd(const float* emb, int64_t ld_emb, int B, int E,
                (hipStream_t)stream, emb, ld_emb, B, E, coef, grad_loss, row_begin, row_count,
                grad_emb, ld_grad);
     return scl_launch_status();
+  }
+  {
+    // many rows (>= 128; a single-process run at B = 192) on bf16 planes; one row tile (a
+    // data-parallel rank's own rows) stays with gram_bwd_rows_kernel, everything else with the
+    // float32-MFMA kernels
+    const int Bp = (B + 31) & ~31, Rp = (row_count + 31) & ~31;
+    const size_t lds_k = ((size_t)3 * Rp * GBP_LDM + (size_t)3 * 32 * GBP_LDE) * sizeof(unsigned short);
+    const size_t lds_o = (size_t)Rp * GBP_LDO * sizeof(float);
+    const size_t lds = lds_k > lds_o ? lds_k : lds_o;
+    const bool al = (ld_emb % 4 == 0) && ((uintptr_t)emb % 16 == 0) && (ld_grad % 4 == 0) &&
+                    ((uintptr_t)grad_emb % 16 == 0) && ((uintptr_t)coef % 16 == 0) && B % 4 == 0;
+    if (B > 64 && B <= 256 && row_count >= 96 && E % 128 == 0 && al && lds <= 160 * 1024 &&
+        scl_debug_variant != 32 && scl_debug_variant != 34) {      // (34: the float32-MFMA kernels, for A/B)
+      hipStream_t st = (hipStream_t)stream;
+#define SCL_GBP_CASE(N)                                                                          \
+  if (Rp / 16 == N) {                                                                            \
+    static std::once_flag once##N;                                                               \
+    std::call_once(once##N, [] {                                                                 \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_bwd_planes_kernel<N>),       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);         \
+    });                                                                                          \
+    SCL_LAUNCH("gram_bwd_planes_kernel", gram_bwd_planes_kernel<N>, dim3(E / 128), dim3(512), lds, \
+               st, emb, ld_emb, B, Bp, E, coef, row_begin, grad_loss, row_count, grad_emb,       \
+               ld_grad);                                                                         \
+    return scl_launch_status();                                                                  \
+  }
+      SCL_GBP_CASE(6)
+      SCL_GBP_CASE(8)
+      SCL_GBP_CASE(10)
+      SCL_GBP_CASE(12)
+      SCL_GBP_CASE(14)
+      SCL_GBP_CASE(16)
+#undef SCL_GBP_CASE
+    }
   }
   static std::once_flag once;
   std::call_once(once, [] {
@@ -1876,48 +1899,8 @@ extern "C" int scl_gram_loss_bwd_w(const float* emb, int64_t ld_emb, int B, int 
                                    const float* grad_loss, int row_begin, int row_count,
                                    float* grad_emb, int64_t ld_grad, void* workspace,
                                    size_t workspace_bytes, void* stream) {
-  if (!emb || !coef || !grad_emb) return SCL_E_NULL;
-  if (B < 1 || E < 1 || ld_emb < E || ld_grad < E) return SCL_E_SHAPE;
-  if (row_begin < 0 || row_count < 1 || row_begin + row_count > B || B > kMaxB) return SCL_E_SHAPE;
-  const int Bp = (B + 31) & ~31, Rp = (row_count + 31) & ~31;
-  const size_t lds_k = ((size_t)3 * Rp * GBP_LDM + (size_t)3 * 32 * GBP_LDE) * sizeof(unsigned short);
-  const size_t lds_o = (size_t)Rp * GBP_LDO * sizeof(float);
-  const size_t lds = lds_k > lds_o ? lds_k : lds_o;
-  const bool al = (ld_emb % 4 == 0) && ((uintptr_t)emb % 16 == 0) && (ld_grad % 4 == 0) &&
-                  ((uintptr_t)grad_emb % 16 == 0);
-  // many rows (>= 128: with fewer the pre-split launch costs what the kernel saves — B = 96, all
-  // rows: 13.8 + 6.3 us against 17.5) on the bf16 planes; one row tile (a data-parallel rank's own
-  // rows) stays with gram_bwd_rows_kernel, everything else with the float32-MFMA kernels
-  if (workspace && scl_aligned256(workspace) && B > 64 && B <= 256 && row_count >= 128 && E % 128 == 0 &&
-      al && lds <= 160 * 1024 && workspace_bytes >= scl_gram_loss_bwd_workspace_bytes(B, row_count) &&
-      scl_debug_variant != 32 && scl_debug_variant != 34) {      // (34: the float32-MFMA kernels, for A/B)
-    hipStream_t st = (hipStream_t)stream;
-    const int KS = Bp / 32;
-    unsigned short* img = (unsigned short*)workspace;
-    SCL_LAUNCH("gram_coef_planes_kernel", gram_coef_planes_kernel,
-               dim3((unsigned)((Rp * KS * GBP_LDM + 255) / 256)), dim3(256), 0, st, coef, B, row_begin,
-               row_count, Rp, KS, img);
-#define SCL_GBP_CASE(N)                                                                          \
-  if (Rp / 16 == N) {                                                                            \
-    static std::once_flag once##N;                                                               \
-    std::call_once(once##N, [] {                                                                 \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_bwd_planes_kernel<N>),       \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);         \
-    });                                                                                          \
-    SCL_LAUNCH("gram_bwd_planes_kernel", gram_bwd_planes_kernel<N>, dim3(E / 128), dim3(512), lds, \
-               st, emb, ld_emb, B, Bp, E, (const unsigned short*)img, grad_loss, row_count,      \
-               grad_emb, ld_grad);                                                               \
-    return scl_launch_status();                                                                  \
-  }
-    SCL_GBP_CASE(4)
-    SCL_GBP_CASE(6)
-    SCL_GBP_CASE(8)
-    SCL_GBP_CASE(10)
-    SCL_GBP_CASE(12)
-    SCL_GBP_CASE(14)
-    SCL_GBP_CASE(16)
-#undef SCL_GBP_CASE
-  }
+  (void)workspace;                              // (an earlier form pre-split M into it; not needed)
+  (void)workspace_bytes;
   return scl_gram_loss_bwd(emb, ld_emb, B, E, coef, grad_loss, row_begin, row_count, grad_emb, ld_grad,
                            stream);
 }

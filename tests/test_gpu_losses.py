@@ -413,5 +413,5 @@ def test_gram_backward_on_bf16_planes(dev, b, row_begin, row_count, e):
         err = float((out.double() - want).abs().max() / want.abs().max())
         assert err < 2e-6, (variant, err)
     planes = 'gram_bwd_planes_kernel' in outs[0][1]
-    assert planes == (64 < b <= 256 and row_count >= 128 and e % 128 == 0), outs[0][1]
+    assert planes == (64 < b <= 256 and b % 4 == 0 and row_count >= 96 and e % 128 == 0), outs[0][1]
     assert 'gram_bwd_planes_kernel' not in outs[34][1]
