@@ -1652,12 +1652,12 @@ constexpr int GBP_LDM = 40;      // bf16 per row of a k-step's M planes (32 + 8 
 
 // grid E / 128; block 512; dynamic LDS max(3 (Rp GBP_LDM + 32 GBP_LDE) * 2, Rp * GBP_LDO * 4) bytes,
 // Rp = 16 NRT (a multiple of 32).  Workgroup = 128 columns x ALL the rows, k-step by k-step: the M
-// planes [Rp][32] of the step come from the pre-split image as they lie, the E slab [32][128] is
-// split into its planes on the way into LDS; both are requested into registers one k-step ahead.
-// Wave w = columns 16 w .. + 15: two transposed reads per plane give its E^T fragments, then one
-// ds_read_b128 per plane and row tile and six MFMAs (two chains of three) per row tile.
-// (The first version kept the whole E tile of 64 columns in LDS and re-read the M planes per
-// 64 columns: 166 MB of L2 -> LDS traffic at B = 192, 34 us — slower than the prepass saved.)
+// rows [Rp][32] of the step and the E slab [32][128] are split into their planes on the way into
+// LDS; both are requested into registers one k-step ahead.  Wave w = columns 16 w .. + 15: two
+// transposed reads per plane give its E^T fragments, then one ds_read_b128 per plane and row tile
+// and six MFMAs (two chains of three) per row tile.  (Versions on the way — 64-column workgroups
+// with the whole E tile in LDS, a pre-split image of M from a launch of its own, two k-steps per
+// stage: DESIGN.md section 5, Round 4.)
 constexpr int GBP_LDE = 144;     // bf16 per row of an E slab plane in LDS (128 + 16 pad = 288 bytes)
 constexpr int GBP_LDO = 132;     // floats per staged output row (128 + 4 pad)
 template <int NRT>
