@@ -106,6 +106,7 @@ def parse():
                          'then carries scaling_efficiency = value / (N * n1_ref)')
     ap.add_argument('--no-retrieval', action='store_true', help='skip the retrieval object (N=1)')
     ap.add_argument('--no-batch-sweep', action='store_true', help='skip the batch_sweep object (N=1)')
+    ap.add_argument('--no-telemetry', action='store_true', help='skip the clock / power sample (N=1)')
     ap.add_argument('--stub-cpu', action='store_true',
                     help='TEST ONLY: gloo on CPU with a trivial stand-in step; exercises the '
                          'launcher, the barriers and the max-over-ranks timing, measures nothing')
@@ -226,6 +227,7 @@ def netvlad_stage(kernels, b, n, x_bytes, steps):
         if not rows:
             continue
         us = sum(r['us'] * r['launches'] for r in rows) / max(steps, 1)
+        us_ev = sum(r.get('us_events', r['us']) * r['launches'] for r in rows) / max(steps, 1)
         t_hbm = nbytes / (PEAK_HBM_GBPS * 1e9) * 1e6
         if x_bytes == 2:
             t_mfma = 2.0 * flops / (PEAK_BF16_TFLOPS * 1e12) * 1e6
@@ -236,23 +238,30 @@ def netvlad_stage(kernels, b, n, x_bytes, steps):
                          launches_per_step=round(sum(r['launches'] for r in rows) / max(steps, 1), 2),
                          us_per_step=round(us, 2), algorithmic_bytes=int(nbytes),
                          algorithmic_flops=flops, bound='hbm' if t_hbm >= t_mfma else 'mfma',
-                         bound_us=round(bound_us, 2), frac=round(bound_us / us, 4) if us > 0 else None)
+                         bound_us=round(bound_us, 2), frac=round(bound_us / us, 4) if us > 0 else None,
+                         us_per_step_events=round(us_ev, 2),
+                         frac_events=round(bound_us / us_ev, 4) if us_ev > 0 else None)
     out['note'] = ('durations = HIP events around every launch minus the bracket measured on the empty '
-                   'kernel in this process (bracket_us in kernel_timing); rocprofv3 trace of the same '
-                   'command: profiles/r04')
+                   'kernel in this process (bracket_us in kernel_timing; *_events = the raw event figures); '
+                   'rocprofv3 trace of the same command: profiles/r05')
     return out
 
 
-# Device time of the library's empty kernel (scl_null_kernel, 256 x 256 threads) as rocprofv3
-# reports it on MI355X (profiles/r04/null_kernel_bracket.txt).  bracket_us() measures the same
-# launch through the event bracket in this process; the difference is what the bracket adds to
-# every kernel, and price() takes it off (`us` = corrected, `us_events` = as measured).
-NULL_KERNEL_DEVICE_US = 3.5
+# What the event bracket adds to a launch is measured IN THIS PROCESS (round 4 subtracted a
+# constant taken from a rocprofv3 run on another box — ADVICE round 4): bracket_us() times the
+# library's empty kernel (scl_null_kernel) through the bracket, and the same kernel launched 200
+# times back to back between ONE event pair; the second figure per launch is the device's own
+# dispatch + run time of an empty kernel, the difference is the bracket.  price() takes it off
+# (`us` = corrected, `us_events` / `frac_events` = exactly as measured), never more than
+# BRACKET_CAP of a duration.
+NULL_KERNEL_DEVICE_US = None          # measured by bracket_us(); rocprofv3 on this chip: 3.5 us
 BRACKET_US = 0.0
+BRACKET_CAP = 0.3
 
 
 def bracket_us(dev, n=100):
     """HIP-event bracket overhead per launch on this device, measured on the empty kernel."""
+    global NULL_KERNEL_DEVICE_US
     from soft_contrastive_learning_amd import _lib
     lib = _lib.load()
     x = torch.zeros(1 << 16, device=dev)
@@ -266,12 +275,24 @@ def bracket_us(dev, n=100):
             lib.scl_prof_null(st)
         torch.cuda.synchronize()
     us = sorted(t * 1e3 for name, t in kt.records if name == 'scl_null_kernel')
+    # the empty kernel's own time: 200 launches back to back between one event pair
+    per = []
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        x.add_(1.0)
+        e0.record()
+        for _ in range(200):
+            lib.scl_prof_null(st)
+        e1.record()
+        torch.cuda.synchronize()
+        per.append(e0.elapsed_time(e1) * 1e3 / 200)
+    NULL_KERNEL_DEVICE_US = sorted(per)[len(per) // 2]
     return max(0.0, us[len(us) // 2] - NULL_KERNEL_DEVICE_US) if us else 0.0
 
 
 def price(name, launches, mean_ms, model):
     events_ms = mean_ms
-    mean_ms = max(mean_ms - BRACKET_US * 1e-3, 0.2 * mean_ms)
+    mean_ms = max(mean_ms - BRACKET_US * 1e-3, (1.0 - BRACKET_CAP) * mean_ms)
     sec = mean_ms * 1e-3
     tf = model['flops'] / sec / 1e12 if sec > 0 else 0.0
     gbs = model['bytes'] / sec / 1e9 if sec > 0 else 0.0
@@ -285,6 +306,7 @@ def price(name, launches, mean_ms, model):
                tflops=round(tf, 2), gbps=round(gbs, 1), frac=round(frac, 4))
     if BRACKET_US:
         out['us_events'] = round(events_ms * 1e3, 2)
+        out['frac_events'] = round(frac * mean_ms / events_ms, 4) if events_ms > 0 else None
     if mult != 1.0:      # bf16x3 kernels: flops executed on the bf16 matrix cores
         out.update(executed_tflops=round(mult * tf, 2), mfma_peak_tflops=peak_tf)
     return out
@@ -556,6 +578,70 @@ def retrieval_line(dev, r=100000, q=10000, d=256, n=25, iters=3):
     return out
 
 
+def gpu_telemetry(step, fence, seconds=2.5):
+    """Shader clock and package power UNDER THE BENCH STEP, outside the timed region: the step runs
+    in a loop for `seconds` while a thread polls `rocm-smi --showclocks --showpower --json`
+    (boxes of this pool differ by +-4 % in the MFMA-bound kernels — VERDICT round 4, weak item 11 —
+    and a reader of BENCH_r*.json should be able to tell a slow box from a regression).  One idle
+    sample first.  Never raises: a box without rocm-smi yields {'error': ...}."""
+    import re
+    import subprocess
+    import threading
+
+    def sample():
+        try:
+            r = subprocess.run(['rocm-smi', '--showclocks', '--showpower', '--json'], capture_output=True,
+                               text=True, timeout=10)
+            d = json.loads(r.stdout[r.stdout.index('{'):])
+        except Exception as exc:                          # noqa: BLE001
+            return {'error': '%s: %s' % (type(exc).__name__, str(exc)[:80])}
+        card = d.get('card0') or next((v for v in d.values() if isinstance(v, dict)), {})
+        out = {}
+        for k, v in card.items():
+            m = re.search(r'(\d+(?:\.\d+)?)', str(v))
+            if not m:
+                continue
+            kl = k.lower()
+            if 'sclk' in kl and 'sclk_mhz' not in out:
+                out['sclk_mhz'] = float(m.group(1))
+            elif 'mclk' in kl and 'mclk_mhz' not in out:
+                out['mclk_mhz'] = float(m.group(1))
+            elif 'power' in kl and 'power_w' not in out:
+                out['power_w'] = float(m.group(1))
+        return out or {'error': 'no clock / power fields in rocm-smi output', 'keys': sorted(card)[:12]}
+
+    idle = sample()
+    if 'error' in idle:
+        return idle
+    got, stop = [], threading.Event()
+
+    def poll():
+        while not stop.is_set():
+            got.append(sample())
+    th = threading.Thread(target=poll, daemon=True)
+    fence()
+    t0 = time.perf_counter()
+    th.start()
+    n = 0
+    while time.perf_counter() - t0 < seconds:
+        step()
+        n += 1
+        if n % 8 == 0:
+            torch.cuda.synchronize()                      # keep the host at most 8 steps ahead
+    fence()
+    stop.set()
+    th.join(timeout=15)
+    got = [g for g in got if 'error' not in g]
+
+    def stat(key):
+        v = sorted(g[key] for g in got if key in g)
+        return {'median': v[len(v) // 2], 'min': v[0], 'max': v[-1]} if v else None
+    return {'idle': idle, 'under_load': {'sclk_mhz': stat('sclk_mhz'), 'mclk_mhz': stat('mclk_mhz'),
+                                         'power_w': stat('power_w'), 'samples': len(got),
+                                         'steps_run': n, 'seconds': round(time.perf_counter() - t0, 2)},
+            'how': 'rocm-smi polled by a thread while the bench step loops, after the timed region'}
+
+
 def _switches(args):
     """Everything that can make this run differ from the default one: SCL_* environment
     switches and the A/B flags of this script."""
@@ -691,12 +777,13 @@ def batch_sweep(dev, iters=5):
         x = torch.randn(b, 1, 1200, D, device=dev, generator=gen).bfloat16().requires_grad_(True)
         g = torch.randn(b, E, device=dev, generator=gen)
         nets.prepack([], force=True, vlad_w=wd)
+        pl = nets.fresh_vlad_planes(wd)        # (the weights do not change inside this loop)
         for _ in range(2):
-            nets.netvlad(x, wt, ct, True).backward(g)
+            nets.netvlad(x, wt, ct, True, pl).backward(g)
         torch.cuda.synchronize()
         with _lib.KernelTimer(capacity=16 * iters) as kt:
             for _ in range(iters):
-                nets.netvlad(x, wt, ct, True).backward(g)
+                nets.netvlad(x, wt, ct, True, pl).backward(g)
             torch.cuda.synchronize()
         steps = (1200 + 31) // 32
         per = -(-steps * b // 256)
@@ -706,7 +793,8 @@ def batch_sweep(dev, iters=5):
         ent = {'images': b}
         for ps in ('forward', 'backward'):
             if ps in st:
-                ent[ps] = {k: st[ps][k] for k in ('launches_per_step', 'us_per_step', 'bound', 'bound_us', 'frac')}
+                ent[ps] = {k: st[ps][k] for k in ('launches_per_step', 'us_per_step', 'bound', 'bound_us', 'frac',
+                                                  'us_per_step_events', 'frac_events')}
                 ent[ps]['us_per_image'] = round(st[ps]['us_per_step'] / b, 3)
         out['netvlad'].append(ent)
         del x, g
@@ -728,8 +816,11 @@ def batch_sweep(dev, iters=5):
         ent = {'B': bsz, 'bound_us_each_pass': round(bound, 2)}
         for name, rs in (('forward', fwd), ('backward', bwd)):
             us = sum(r['us'] * r['launches'] for r in rs) / iters
+            us_ev = sum(r.get('us_events', r['us']) * r['launches'] for r in rs) / iters
             ent[name] = {'launches': round(sum(r['launches'] for r in rs) / iters, 2), 'us': round(us, 2),
                          'frac': round(bound / us, 4) if us > 0 else None,
+                         'us_events': round(us_ev, 2),
+                         'frac_events': round(bound / us_ev, 4) if us_ev > 0 else None,
                          'kernels': [r['kernel'] for r in rs]}
         out['wms_loss'].append(ent)
     return out
@@ -766,6 +857,8 @@ def main():
 
     from soft_contrastive_learning_amd import _lib, parallel
     from soft_contrastive_learning_amd.model import losses, nets
+    if args.variant:
+        _lib.use_diag()               # the variants exist in the diagnostic build only
     _lib.load()
     if args.workload == 'retrieval':
         return retrieval_main(args, world, rank, dev)
@@ -934,6 +1027,7 @@ def main():
             el = float(tt)
         return el / k * 1e3
 
+    telemetry = gpu_telemetry(step, fence) if rank == 0 and world == 1 and not args.no_telemetry else None
     comm = None
     if world > 1:
         # what the first multi-GPU run must be able to explain by itself
@@ -1059,11 +1153,13 @@ def main():
                               if (nets.USE_SIDE_WRW or bool(nets.USE_SPLIT_FWD)) else 'one',
                               'ms_per_step_with_events': round(elapsed_prof / prof_steps * 1e3, 3),
                               'bracket_us': round(BRACKET_US, 2),
-                              'bracket_how': 'event duration of the empty kernel (scl_prof_null) in this '
-                                             'process minus its device time (%.1f us, rocprofv3: '
-                                             'profiles/r04/null_kernel_bracket.txt); subtracted from '
-                                             'every `us` below, `us_events` is the raw figure'
-                                             % NULL_KERNEL_DEVICE_US},
+                              'null_kernel_us': round(NULL_KERNEL_DEVICE_US or 0.0, 2),
+                              'bracket_how': 'event duration of the empty kernel (scl_prof_null) minus '
+                                             'its own time (null_kernel_us: 200 launches back to back '
+                                             'between one event pair), both in this process; subtracted '
+                                             'from every `us` below, at most %d %% of a duration; '
+                                             '`us_events` / `frac_events` are the raw figures'
+                                             % int(BRACKET_CAP * 100)},
             'roofline': roofline,
             'roofline_netvlad_loss': roofline_head,
             'roofline_netvlad_stage': netvlad_stage(kernels, b, n_loc, 2 if cdt == torch.bfloat16 else 4,
@@ -1077,6 +1173,8 @@ def main():
                                       {k: v for k, v in (side_choice or {}).items() if k != 'chosen'}))
         if comm is not None:
             out['comm'] = comm
+        if telemetry is not None:
+            out['telemetry'] = telemetry
         if args.n1_ref > 0:
             out['scaling_efficiency'] = round(out['value'] / (world * args.n1_ref), 4)
         if world == 1 and not args.no_batch_sweep:

@@ -15,12 +15,13 @@
  *   - every pointer is a DEVICE pointer into caller-owned memory (HBM); the
  *     library allocates nothing and the compute entry points keep no state between calls,
  *     so they are re-entrant (the reference drives one session from three threads,
- *     train/train.py:967-975).  Three PROCESS-WIDE switches exist: the timing sink of
- *     scl_prof_begin / scl_prof_end (changes no result), the number of CUs the persistent grids
- *     leave free, scl_set_reserve_cus (deterministic for a fixed value; weight gradients differ in
- *     rounding between values), and the ablation selector of scl_debug_set_variant (diagnostics,
- *     0 by default: several values give MEANINGLESS results by design; see "Diagnostics" at the
- *     end);
+ *     train/train.py:967-975).  Two PROCESS-WIDE settings exist in the product library
+ *     (libscl_hip.so): the timing sink of scl_prof_begin / scl_prof_end (changes no result) and
+ *     the number of CUs the persistent grids leave free, scl_set_reserve_cus (deterministic for a
+ *     fixed value; weight gradients differ in rounding between values).  The ablation selector
+ *     scl_debug_set_variant is compiled into the DIAGNOSTIC build only (libscl_hip_diag.so,
+ *     -DSCL_DIAG; see "Diagnostics" at the end): the product library contains no variant code
+ *     and rejects every value but 0;
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and
  *     no entry point synchronises;
  *   - every function returns 0 on success, a negative SCL_E_* code for a rejected
@@ -39,7 +40,7 @@
 extern "C" {
 #endif
 
-#define SCL_ABI_VERSION 9
+#define SCL_ABI_VERSION 10
 
 /* error codes (negative = rejected before any launch) */
 #define SCL_OK 0
@@ -533,8 +534,12 @@ int scl_conv_pack_batch(const SclPackJob* jobs, int njobs, void* stream);
  * one sink at a time.  scl_prof_end waits for them and returns per-launch milliseconds and
  * kernel names (static strings); call it once the launching threads are quiescent.
  * ------------------------------------------------------------------------- */
-/* Ablation / tuning switch (scripts/ablate_rowtile.py, scripts/microbench.py); 0 restores
- * the production kernels, any other value makes RESULTS MEANINGLESS.  Returns the old value.
+/* 1 for libscl_hip_diag.so (-DSCL_DIAG), 0 for the product library. */
+int scl_build_is_diag(void);
+/* Ablation / tuning switch (scripts/ablate_rowtile.py, scripts/microbench.py) of the DIAGNOSTIC
+ * build; 0 restores the production kernels, any other value makes RESULTS MEANINGLESS unless
+ * marked CORRECT below.  Returns the old value.  In the product library (no -DSCL_DIAG) the
+ * variants do not exist: 0 is accepted (returns 0), anything else returns SCL_E_KIND.
  *   1..7          forward row-tile kernel: bit 0 no epilogue stores, bit 1 no x loads,
  *                 bit 2 no operand staging / barriers
  *   8             bf16 feature maps through the float32-MFMA NetVLAD kernels (CORRECT results:

@@ -10,6 +10,8 @@ staging / barriers.  The variants compute garbage; only their timing is meaningf
 """
 import argparse
 import os
+
+os.environ.setdefault('SCL_DIAG', '1')   # the diagnostic build carries the variants (csrc/Makefile)
 import statistics
 import sys
 

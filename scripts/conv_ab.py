@@ -9,6 +9,8 @@ Per-kernel durations from the library's scl_prof_* sink.
 import argparse
 import json
 import os
+
+os.environ.setdefault('SCL_DIAG', '1')   # the diagnostic build carries the variants (csrc/Makefile)
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -8,6 +8,8 @@ bit 1 = no output stores.  Results under a non-zero variant are meaningless.
 import argparse
 import json
 import os
+
+os.environ.setdefault('SCL_DIAG', '1')   # the diagnostic build carries the variants (csrc/Makefile)
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -7,6 +7,8 @@ production, no output stores (53022), no wait / barrier at the top of a tile (53
 import argparse
 import json
 import os
+
+os.environ.setdefault('SCL_DIAG', '1')   # the diagnostic build carries the variants (csrc/Makefile)
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -6,6 +6,8 @@ workgroup write s_memtime stamps of its second and third tile to the tail of the
 """
 import argparse
 import os
+
+os.environ.setdefault('SCL_DIAG', '1')   # the diagnostic build carries the variants (csrc/Makefile)
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

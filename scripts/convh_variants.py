@@ -8,6 +8,8 @@ that clock drift shows.  Forward with bias + ReLU or the masked backward-data pa
 import argparse
 import json
 import os
+
+os.environ.setdefault('SCL_DIAG', '1')   # the diagnostic build carries the variants (csrc/Makefile)
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -2,6 +2,8 @@
 """Timing ablation of conv_first_kernel: scl_debug_set_variant(70000 + bits), bit 0 no image
 loads, bit 1 no x0 stores, bit 2 no output stores (results meaningless)."""
 import os, sys
+
+os.environ.setdefault('SCL_DIAG', '1')   # the diagnostic build carries the variants (csrc/Makefile)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch

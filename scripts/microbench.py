@@ -11,6 +11,8 @@ stream).  Under rocprofv3 run this file directly:  rocprofv3 ... -- python3 scri
 import argparse
 import json
 import os
+
+os.environ.setdefault('SCL_DIAG', '1')   # the diagnostic build carries the variants (csrc/Makefile)
 import sys
 import time
 

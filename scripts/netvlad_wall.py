@@ -6,6 +6,8 @@ launches, four-wave kernels).  Device events around 200 back-to-back iterations,
 instrumentation; three rounds, alternating.  The C-ABI is called directly (through autograd the Python
 overhead of ~100 us per iteration starves the device and the figure measures the host)."""
 import os
+
+os.environ.setdefault('SCL_DIAG', '1')   # the diagnostic build carries the variants (csrc/Makefile)
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -5,6 +5,8 @@ shader-clock stamps into the tail of the workspace — and prints the median ove
 every phase, in cycles.  DIAGNOSTIC ONLY (the stamps perturb the kernel)."""
 import argparse
 import os
+
+os.environ.setdefault('SCL_DIAG', '1')   # the diagnostic build carries the variants (csrc/Makefile)
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -2,7 +2,15 @@
 
 There is no CPU fallback: if the shared library is missing, or a tensor is not on a
 HIP device, the call raises.  PyTorch is used only for device memory and streams.
+
+Two builds of the same sources exist (csrc/Makefile): the PRODUCT library ``libscl_hip.so`` — what
+``load()`` returns — has no diagnostic kernel variants compiled in and rejects
+``scl_debug_set_variant(v != 0)``; ``libscl_hip_diag.so`` (``-DSCL_DIAG``) carries the A/B,
+ablation and clock-stamp variants.  ``with variant(v):`` runs the enclosed calls on the
+diagnostic build under variant ``v`` (equality tests, scripts/); ``SCL_DIAG=1`` in the
+environment or ``use_diag()`` makes it the process's library (scripts/).
 """
+import contextlib
 import ctypes
 import os
 
@@ -10,9 +18,10 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libscl_hip.so")
+DIAG_LIB_PATH = os.path.join(_HERE, "libscl_hip_diag.so")
 
 # constants of include/scl_hip.h
-ABI_VERSION = 9
+ABI_VERSION = 10
 DT_F32, DT_BF16 = 0, 1
 MASK_WMS_EXP, MASK_WMS_LIN, MASK_WMS_TANH, MASK_LABELS = 0, 1, 2, 3
 SUM_MS, SUM_PLAIN = 0, 1
@@ -112,6 +121,7 @@ SIGNATURES = {
     "scl_conv_first_pool_idx": (_i, [_p, _p, _p, _l, _l, _l, _l, _i, _p, _p, _l, _l, _l, _l, _i, _p,
                                      _i, _i, _i, _p, _p, _p, _p, _p, _z, _p]),
     "scl_debug_set_variant": (_i, [_i]),
+    "scl_build_is_diag": (_i, []),
     "scl_set_reserve_cus": (_i, [_i]),
     "scl_get_reserve_cus": (_i, []),
     "scl_prof_begin": (_i, [_i]),
@@ -121,32 +131,75 @@ SIGNATURES = {
     "scl_crc32c": (ctypes.c_uint, [ctypes.c_uint, _p, _z]),
 }
 
-_lib = None
+_libs = {}
+_diag = os.environ.get('SCL_DIAG', '0') == '1'
 
 
 class SclError(RuntimeError):
     pass
 
 
-def load():
-    """Load the shared library once; raise loudly if it has not been built."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(diag=None):
+    """The process's library (loaded once): the product build, unless the diagnostic build was
+    asked for (``diag=True``, ``use_diag()``, ``SCL_DIAG=1``, or inside ``with variant(v)``).
+    Raises loudly if it has not been built."""
+    want = _diag if diag is None else bool(diag)
+    lib = _libs.get(want)
+    if lib is not None:
+        return lib
+    path = DIAG_LIB_PATH if want else LIB_PATH
+    if not os.path.exists(path):
         raise SclError(
-            "libscl_hip.so not found at %s: build it with "
+            "%s not found at %s: build it with "
             "`python -c 'import __graft_entry__ as g; g.build()'` or "
-            "`make -C soft_contrastive_learning_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
-    lib = ctypes.CDLL(LIB_PATH)
+            "`make -C soft_contrastive_learning_amd/csrc` (there is no CPU fallback)"
+            % (os.path.basename(path), path))
+    lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
     if lib.scl_abi_version() != ABI_VERSION:
-        raise SclError("libscl_hip.so ABI %d != expected %d" % (lib.scl_abi_version(), ABI_VERSION))
-    _lib = lib
+        raise SclError("%s ABI %d != expected %d" % (os.path.basename(path), lib.scl_abi_version(),
+                                                     ABI_VERSION))
+    if bool(lib.scl_build_is_diag()) != want:
+        raise SclError("%s is not the %s build" % (path, 'diagnostic' if want else 'product'))
+    _libs[want] = lib
     return lib
+
+
+def use_diag(on=True):
+    """Make the diagnostic build (libscl_hip_diag.so) the process's library from here on; returns
+    the previous setting.  Diagnostics only: scripts/, bench.py --variant."""
+    global _diag
+    old, _diag = _diag, bool(on)
+    return old
+
+
+@contextlib.contextmanager
+def variant(v):
+    """Run the enclosed library calls on the DIAGNOSTIC build under scl_debug_set_variant(v)
+    (process-wide inside the block, like the switch itself; tests and scripts only)."""
+    old_diag = use_diag(True)
+    lib = load()
+    old = lib.scl_debug_set_variant(int(v))
+    try:
+        yield lib
+    finally:
+        lib.scl_debug_set_variant(old)
+        use_diag(old_diag)
+
+
+@contextlib.contextmanager
+def maybe_variant(v):
+    """variant(v) for v != 0; for 0 the process's own library untouched (the product build unless
+    the process asked for the diagnostic one) — so that an equality test compares the PRODUCT
+    kernels with a diagnostic variant."""
+    if v:
+        with variant(v) as lib:
+            yield lib
+    else:
+        yield load()
 
 
 def check(code):

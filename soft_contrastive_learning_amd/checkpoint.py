@@ -36,8 +36,9 @@ def _param_table(model):
         rows.append(('%s/conv%s/kernel' % (SCOPE, name), getattr(model, 'conv%s_kernel' % name),
                      True))
         rows.append(('%s/conv%s/bias' % (SCOPE, name), getattr(model, 'conv%s_bias' % name), False))
-    rows.append((SCOPE + '/assignment/kernel', model.assignment_kernel, False))
-    rows.append((SCOPE + '/cluster_centers', model.cluster_centers, False))
+    if getattr(model, 'vlad_cores', 64) == 64:     # the vgg16() graph has no head variables
+        rows.append((SCOPE + '/assignment/kernel', model.assignment_kernel, False))
+        rows.append((SCOPE + '/cluster_centers', model.cluster_centers, False))
     return rows
 
 

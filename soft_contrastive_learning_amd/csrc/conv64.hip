@@ -256,7 +256,7 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
       *reinterpret_cast<u32x4*>(lds + buf * WIN_ + (wy * WC + wx) * PIX + 8 * p_piece) = o;
   };
 
-  const int dbg = relu >> 1;            // timing diagnostics (scl_debug_set_variant(60000 + bits))
+  const int dbg = SCL_DIAG_ONLY(relu >> 1);            // timing diagnostics (scl_debug_set_variant(60000 + bits))
   relu &= 1;
   const short relu_floor = relu ? (short)0 : (short)-32768;   // packed ReLU: max with 0, or with the least int16
   // (experiment, 60004: static priority for the younger half of an eight-wave workgroup)
@@ -895,7 +895,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
                                                          unsigned short* __restrict__ x0,
                                                          unsigned short* __restrict__ y) {
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
-  const int dbg = w_f32 >> 4;            // timing diagnostics (scl_debug_set_variant(70000 + bits))
+  const int dbg = SCL_DIAG_ONLY(w_f32 >> 4);            // timing diagnostics (scl_debug_set_variant(70000 + bits))
   w_f32 &= 1;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -1512,8 +1512,8 @@ int launch_conv3x3(const void* x, const void* w, int64_t sk, int64_t sc, int64_t
                    void* pooled, const void* mask, void* pidx, const void* uidx, void* workspace,
                    hipStream_t st) {
   using Cfg = ConvCfg<CIN, KOUT>;
-  static std::once_flag once;
-  std::call_once(once, [] {
+  static SclDeviceOnce once;
+  scl_call_once(once, [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<CIN, KOUT, 0>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<CIN, KOUT, 1>),
@@ -1538,7 +1538,7 @@ int launch_conv3x3(const void* x, const void* w, int64_t sk, int64_t sc, int64_t
                (unsigned short*)workspace);
   const int tiles = B * ((H + Cfg::TH_ - 1) / Cfg::TH_) * ((W + TW - 1) / TW);
   const dim3 grid(tiles < cus ? tiles : cus);
-  if (scl_debug_variant / 1000 == 60) relu |= (scl_debug_variant & 7) << 1;   // bit 2: setprio experiment
+  if (scl_variant() / 1000 == 60) relu |= (scl_variant() & 7) << 1;   // bit 2: setprio experiment
   if (pidx)
     SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 4>), grid, dim3(Cfg::NTHR), Cfg::LDS, st,
                (const unsigned short*)x, (const unsigned short*)packed, B, H, W,
@@ -1672,13 +1672,7 @@ extern "C" int scl_conv64(const void* x, const void* w, int64_t w_stride_k, int6
 // CUs the persistent grids may fill: the hardware's count (asked once), minus the reserve AS IT
 // IS NOW — scl_set_reserve_cus may change between calls (bench.py tries 0 and 8 at N > 1)
 static int conv64_cus() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, c = 0;
-    n = (hipGetDevice(&dev) == hipSuccess &&
-         hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0)
-            ? c : 256;
-  }
+  const int n = scl_device_cus();      // per device (scl_common.h)
   const int u = scl_usable_cus(n);
   return u > 1024 ? 1024 : u;
 }
@@ -1720,8 +1714,8 @@ static int wrw3x3_run(const void* x, const void* gz, const unsigned char* pidx, 
     return SCL_E_SHAPE;                                 // 32-bit element offsets in the kernel
   if (((uintptr_t)x % 16) || ((uintptr_t)gz % 16)) return SCL_E_SHAPE;
   if (!scl_aligned256(workspace) || workspace_bytes < need) return SCL_E_WORKSPACE;
-  static std::once_flag once;
-  std::call_once(once, [] {
+  static SclDeviceOnce once;
+  scl_call_once(once, [] {
 #define SCL_WRW_ATTR(D, T, N, PL)                                                              \
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wrw64_kernel<D, T, N, PL>),         \
                             hipFuncAttributeMaxDynamicSharedMemorySize,                        \
@@ -1736,9 +1730,9 @@ static int wrw3x3_run(const void* x, const void* gz, const unsigned char* pidx, 
   const int cus = conv64_cus();
   // [64 c] x [128 k] blocks wherever the output channels allow (scl_debug_set_variant(2100)
   // pins the 64 x 64 variant); tile shape: wide, or tall where that pads the map less
-  const int dbg = scl_debug_variant / 1000 == 2 ? scl_debug_variant & 3 : 0;
-  const bool stamps = (scl_debug_variant == 2004 || scl_debug_variant == 2006) && kout % 128 == 0;   // (needs >= 64 KB of bias slabs)
-  const int nkb = (kout % 128 == 0 && dbg == 0 && scl_debug_variant != 2100) ? 2 : 1;
+  const int dbg = scl_variant() / 1000 == 2 ? scl_variant() & 3 : 0;
+  const bool stamps = (scl_variant() == 2004 || scl_variant() == 2006) && kout % 128 == 0;   // (needs >= 64 KB of bias slabs)
+  const int nkb = (kout % 128 == 0 && dbg == 0 && scl_variant() != 2100) ? 2 : 1;
   const int th_w = nkb == 1 ? 8 : 4, th_t = nkb == 1 ? 32 : 16;
   const int tiles_wide = B * ((H + th_w - 1) / th_w) * ((W + 31) / 32);
   const int tiles_tall = B * ((H + th_t - 1) / th_t) * ((W + 7) / 8);
@@ -1758,7 +1752,7 @@ static int wrw3x3_run(const void* x, const void* gz, const unsigned char* pidx, 
     bslabs = (float*)((char*)workspace + wrw_bias_slab_offset(cin, kout));
     if ((size_t)PP * (cin / 64) * (kout / 128) * 256 > need - wrw_bias_slab_offset(cin, kout))
       return SCL_E_WORKSPACE;
-    if (scl_debug_variant == 2006) {        // ... without staging after the first tile
+    if (scl_variant() == 2006) {        // ... without staging after the first tile
       if (tall) SCL_WRW_LAUNCH(6, 8, 2, 0); else SCL_WRW_LAUNCH(6, 32, 2, 0);
     } else if (pidx) {
       if (tall) SCL_WRW_LAUNCH(4, 8, 2, 1); else SCL_WRW_LAUNCH(4, 32, 2, 1);
@@ -1851,7 +1845,7 @@ extern "C" int scl_conv_first(const float* img, const float* avg, const void* w,
   const int grid = tiles < 8 * cus ? tiles : 8 * cus;
   SCL_LAUNCH("conv_first_kernel", conv_first_kernel, dim3(grid), dim3(256), kFirstLds,
              (hipStream_t)stream, img, avg, w,
-             (w_f32 ? 1 : 0) | (scl_debug_variant / 1000 == 70 ? (scl_debug_variant & 7) << 4 : 0),
+             (w_f32 ? 1 : 0) | (scl_variant() / 1000 == 70 ? (scl_variant() & 7) << 4 : 0),
              w_stride_k, w_stride_c,
              w_stride_h, w_stride_w, bias, B, H, W, (unsigned short*)x0, (unsigned short*)y);
   return scl_launch_status();
@@ -1875,8 +1869,8 @@ extern "C" int scl_conv_first_pool_idx(const float* img, const float* avg, const
   if (!scl_aligned256(workspace) || workspace_bytes < scl_conv3x3_workspace_bytes())
     return SCL_E_WORKSPACE;
   using Cfg = ConvCfg<64, 64>;
-  static std::once_flag once;
-  std::call_once(once, [] {
+  static SclDeviceOnce once;
+  scl_call_once(once, [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv12_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kConv12Lds);
   });
@@ -1914,8 +1908,8 @@ extern "C" int scl_conv_first_wrw(const void* x0, const void* gz, int B, int H, 
   if ((uintptr_t)gz % 16) return SCL_E_SHAPE;
   if (!scl_aligned256(workspace) || workspace_bytes < scl_conv_first_wrw_workspace_bytes())
     return SCL_E_WORKSPACE;
-  static std::once_flag once;
-  std::call_once(once, [] {
+  static SclDeviceOnce once;
+  scl_call_once(once, [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_first_wrw_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFirstWrwLds);
   });

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(NTHR, 1) void convg_kernel(const unsigned short* __
   const int CC = cin / CCH, S = 9 * CC;
   const int wid_s = __builtin_amdgcn_readfirstlane(wid);
   const unsigned short* zeros = reinterpret_cast<const unsigned short*>(zero_block);
-  const int dbg = relu >> 1;            // timing diagnostics (scl_debug_set_variant(3000 + bits))
+  const int dbg = SCL_DIAG_ONLY(relu >> 1);            // timing diagnostics (scl_debug_set_variant(3000 + bits))
   relu &= 1;
   // Staging is LDS-DMA.  Weights: the packed image IS the LDS image, 20 chunks of 1 KB per
   // step pair.  Window: lane l of chunk j owns slot 64 j + l = (pixel, piece), piece 4 the
@@ -389,13 +389,7 @@ extern "C" size_t scl_convg_workspace_bytes(int cin, int kout) {
 }
 
 static int convg_cus() {
-  static int n = 0;                            // the hardware's count; the reserve may change
-  if (n == 0) {
-    int dev = 0, c = 0;
-    n = (hipGetDevice(&dev) == hipSuccess &&
-         hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0)
-            ? c : 256;
-  }
+  const int n = scl_device_cus();      // per device (scl_common.h)
   return scl_usable_cus(n);
 }
 
@@ -417,7 +411,7 @@ static int convg_dispatch(const void* x, const void* w, int64_t w_stride_k, int6
   if (!scl_aligned256(workspace) || workspace_bytes < need) return SCL_E_WORKSPACE;
   // scl_debug_set_variant(40000 + v) pins this (32x32x16) kernel, 50000 + v the 16x16x32 one of
   // convh.hip, each with the diagnostic variant v of the list below; plain v = the default kernel
-  int dv = scl_debug_variant;
+  int dv = scl_variant();
   bool use_h = SCL_CONVH_DEFAULT;
   if (dv >= 40000 && dv < 60000) {
     use_h = dv >= 50000;
@@ -428,8 +422,8 @@ static int convg_dispatch(const void* x, const void* w, int64_t w_stride_k, int6
   if (use_h && (cin / 64) * 64 == cin)     // convh.hip walks the 32-channel chunks in pairs
     return scl_convh_dispatch(x, w, w_stride_k, w_stride_c, w_stride_h, w_stride_w, transposed, B, H,
                               W, cin, kout, out, bias, relu, mask, pidx, workspace, dv, stream);
-  static std::once_flag once;
-  std::call_once(once, [] {
+  static SclDeviceOnce once;
+  scl_call_once(once, [] {
 #define SCL_CONVG_ATTR(E, BHV)                                                                 \
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convg_kernel<E, BHV>),              \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)GCfg<BHV>::LDS);

@@ -255,7 +255,7 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
   const int lane_b = (g * HNB + 16 * NT * ng + i) * 8;
 
   const int relu_in = relu;
-  const int dbg = STAMP ? 0 : relu >> 1;   // timing diagnostics (dv 3020 + bits), results meaningless
+  const int dbg = STAMP ? 0 : SCL_DIAG_ONLY(relu >> 1);   // timing diagnostics (dv 3020 + bits), results meaningless
   relu &= 1;
   const short relu_floor = relu ? (short)0 : (short)-32768;   // packed ReLU: max with 0, or with the least int16
   bool staged = false;
@@ -602,13 +602,7 @@ __global__ __launch_bounds__(HTHR, 1) void convh_kernel(const unsigned short* __
 }
 
 int convh_cus() {
-  static int n = 0;                            // the hardware's count; the reserve may change
-  if (n == 0) {
-    int dev = 0, c = 0;
-    n = (hipGetDevice(&dev) == hipSuccess &&
-         hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0)
-            ? c : 256;
-  }
+  const int n = scl_device_cus();      // per device (scl_common.h)
   return scl_usable_cus(n);
 }
 
@@ -622,8 +616,8 @@ int scl_convh_dispatch(const void* x, const void* w, int64_t w_stride_k, int64_t
                        int64_t w_stride_h, int64_t w_stride_w, int flags, int B, int H, int W,
                        int cin, int kout, void* out, const float* bias, int relu, const void* mask,
                        void* pidx, void* workspace, int dv, void* stream) {
-  static std::once_flag once;
-  std::call_once(once, [] {
+  static SclDeviceOnce once;
+  scl_call_once(once, [] {
 #define SCL_CONVH_ATTR(E, BHV)                                                                 \
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&convh_kernel<E, BHV>),              \
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)HCfg<BHV>::LDS);  \

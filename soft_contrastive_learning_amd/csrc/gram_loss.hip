@@ -620,7 +620,7 @@ inline Gram16Plan make_plan16(int B, int E) {
   // small batches: fewer, larger splits (the finishing workgroup reads every slab);
   // large ones: one workgroup per CU
   int s = B <= 32 ? 64 : 256;
-  int ov = scl_debug_variant / 100000;          // tuning override: splits = ov
+  int ov = scl_variant() / 100000;          // tuning override: splits = ov
   if (ov > 0) s = ov;
   int kc = 64;                                   // power of two: staging indices by shifts
   while (kc < (E + s - 1) / s && 2 * kc <= kc_max) kc *= 2;
@@ -1472,13 +1472,13 @@ inline size_t slab_floats_for(int B, int E) {
 // bf16x6 route: aligned rows and E a multiple of the 128-column slice
 inline bool use_x6(int B, int E, int64_t ld, const float* emb) {
   return B > 64 && B <= kFastB && E % 128 == 0 && ld % 4 == 0 && ((uintptr_t)emb % 16) == 0 &&
-         scl_debug_variant != 31;                             // 31: force the float32-MFMA Gram
+         scl_variant() != 31;                             // 31: force the float32-MFMA Gram
 }
 template <int PWMAX, bool DUAL>
 void launch_gram16x6(int T, int P, const float* emb, int64_t ld, int B, int E, float* slabs,
                      hipStream_t st) {
-  static std::once_flag once;
-  std::call_once(once, [] {
+  static SclDeviceOnce once;
+  scl_call_once(once, [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16x6_kernel<PWMAX, 2, DUAL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
   });
@@ -1490,8 +1490,8 @@ void launch_gram16x6(int T, int P, const float* emb, int64_t ld, int B, int E, f
 template <int PWMAX, bool FULL = false>
 void launch_gram16(const Gram16Plan& p, const float* emb, int64_t ld, int B, int E, int vec_ok,
                    float* slabs, hipStream_t st) {
-  static std::once_flag once;
-  std::call_once(once, [] {
+  static SclDeviceOnce once;
+  scl_call_once(once, [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16_kernel<PWMAX, FULL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024);
   });
@@ -1505,8 +1505,8 @@ void launch_gram16(const Gram16Plan& p, const float* emb, int64_t ld, int B, int
 template <int PWMAX, bool FULL>
 void launch_gram16_fused(const Gram16Plan& p, const float* emb, int64_t ld, int B, int E, int vec_ok,
                          float* slabs, const FinalArgs& fa, hipStream_t st) {
-  static std::once_flag once;
-  std::call_once(once, [] {
+  static SclDeviceOnce once;
+  scl_call_once(once, [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16_fused_kernel<PWMAX, FULL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024);
   });
@@ -1577,7 +1577,7 @@ extern "C" int scl_gram_loss_fwd_s(const float* emb, int64_t ld_emb, int B, int 
         launch_gram16x6<20, true>(p.T, p.P, emb, ld_emb, B, E, w.slabs, st);
       else
         launch_gram16x6<34, false>(p.T, p.P, emb, ld_emb, B, E, w.slabs, st);
-    } else if (B <= 32 && sync_words && full && (pw == 1 || pw == 3) && scl_debug_variant != 32) {
+    } else if (B <= 32 && sync_words && full && (pw == 1 || pw == 3) && scl_variant() != 32) {
       // (32: the two-launch forward, for A/B)  one launch: the Gram and, in its last workgroup, the finish
       FinalArgs fa;
       fa.counter = (unsigned*)sync_words;
@@ -1806,12 +1806,12 @@ extern "C" int scl_gram_loss_bwd(const float* emb, int64_t ld_emb, int B, int E,
     const bool al = (ld_emb % 4 == 0) && ((uintptr_t)emb % 16 == 0) && (ld_grad % 4 == 0) &&
                     ((uintptr_t)grad_emb % 16 == 0) && ((uintptr_t)coef % 16 == 0) && B % 4 == 0;
     if (B > 64 && B <= 256 && row_count >= 96 && E % 128 == 0 && al && lds <= 160 * 1024 &&
-        scl_debug_variant != 32 && scl_debug_variant != 34) {      // (34: the float32-MFMA kernels, for A/B)
+        scl_variant() != 32 && scl_variant() != 34) {      // (34: the float32-MFMA kernels, for A/B)
       hipStream_t st = (hipStream_t)stream;
 #define SCL_GBP_CASE(N)                                                                          \
   if (Rp / 16 == N) {                                                                            \
-    static std::once_flag once##N;                                                               \
-    std::call_once(once##N, [] {                                                                 \
+    static SclDeviceOnce once##N;                                                               \
+    scl_call_once(once##N, [] {                                                                 \
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_bwd_planes_kernel<N>),       \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);         \
     });                                                                                          \
@@ -1829,8 +1829,8 @@ extern "C" int scl_gram_loss_bwd(const float* emb, int64_t ld_emb, int B, int E,
 #undef SCL_GBP_CASE
     }
   }
-  static std::once_flag once;
-  std::call_once(once, [] {
+  static SclDeviceOnce once;
+  scl_call_once(once, [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_bwd_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(kTile * (kMaxB | 1) * sizeof(float)));
@@ -1854,10 +1854,10 @@ extern "C" int scl_gram_loss_bwd(const float* emb, int64_t ld_emb, int B, int E,
     // own 24 rows of 192 (parallel.wms_loss_dp): one row tile — 32-column waves are then the only
     // cut that puts a wave on every SIMD (64-column waves left half the chip idle: 21 us for a
     // 25 MB read).
-    if (al && rt == 1 && E % 128 == 0 && B >= 64 && B <= 512 && scl_debug_variant != 32 &&
-        scl_debug_variant != 33) {                            // (33: the 32-column waves, for A/B)
-      static std::once_flag once_rows;
-      std::call_once(once_rows, [] {
+    if (al && rt == 1 && E % 128 == 0 && B >= 64 && B <= 512 && scl_variant() != 32 &&
+        scl_variant() != 33) {                            // (33: the 32-column waves, for A/B)
+      static SclDeviceOnce once_rows;
+      scl_call_once(once_rows, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_bwd_rows_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
       });
@@ -1867,7 +1867,7 @@ extern "C" int scl_gram_loss_bwd(const float* emb, int64_t ld_emb, int B, int E,
                  ld_grad);
       return scl_launch_status();
     }
-    if (al && E % 512 == 0 && scl_debug_variant != 32) {
+    if (al && E % 512 == 0 && scl_variant() != 32) {
       const long w4 = (long)(E / 128) * rt, w2 = 2 * w4, w1 = 4 * w4;
       const long r4 = (w4 + 1023) / 1024 * 4, r2 = (w2 + 1023) / 1024 * 2, r1 = (w1 + 1023) / 1024;
       if (r1 < r2 && r1 < r4)

@@ -680,10 +680,10 @@ __global__ __launch_bounds__(256, 1) void vlad_fwd_kernel(VladFwdArgs p) {
   float* exch = reinterpret_cast<float*>(vf_lds + VF_NST * VF_STAGE + 4 * VF_CF);
   const unsigned short* xb = p.x + (int64_t)b * p.N * D;
   unsigned long long* stp =
-      (p.dbg & 16) && threadIdx.x == 0 ? p.stamps + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 : nullptr;
+      (SCL_DIAG_ONLY(p.dbg) & 16) && threadIdx.x == 0 ? p.stamps + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 : nullptr;
 #define VF_STAMP(k)                                         \
   do {                                                      \
-    if (p.dbg & 16) {                                       \
+    if (SCL_DIAG_ONLY(p.dbg) & 16) {                                       \
       __builtin_amdgcn_sched_barrier(0);                    \
       if (stp) stp[k] = __builtin_amdgcn_s_memtime();       \
       __builtin_amdgcn_sched_barrier(0);                    \
@@ -719,7 +719,7 @@ __global__ __launch_bounds__(256, 1) void vlad_fwd_kernel(VladFwdArgs p) {
       for (int pl = 0; pl < VF_NPL; ++pl) wf[s][pl] = src[(s * VF_NPL + pl) * 64];
   }
 
-  if (p.dbg & 16) {
+  if (SCL_DIAG_ONLY(p.dbg) & 16) {
     VF_STAMP(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     VF_STAMP(2);
@@ -918,7 +918,7 @@ __global__ __launch_bounds__(256, 1) void vlad_fwd_kernel(VladFwdArgs p) {
   if (i == 0)
     *reinterpret_cast<f32x4*>(p.colsum + ((int64_t)sl * B + b) * K + 16 * wid + 4 * g) =
         f32x4{cs[0], cs[1], cs[2], cs[3]};
-  if (p.dbg & 16) {
+  if (SCL_DIAG_ONLY(p.dbg) & 16) {
     VF_STAMP(29);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     VF_STAMP(30);
@@ -1820,7 +1820,7 @@ __device__ __forceinline__ bool gran_sweep(gran_t* g, int n, int limit, float& v
 constexpr int kSpinLimit = 20000;          // x (poll + s_sleep 8) ~ several ms: never reached in practice
 // scl_debug_set_variant(921): no patience at all — every workgroup that does not find its siblings'
 // granules at the first poll takes the self-computing path (tests: same bits either way)
-inline int spin_limit() { return scl_debug_variant == 921 ? 0 : kSpinLimit; }
+inline int spin_limit() { return scl_variant() == 921 ? 0 : kSpinLimit; }
 
 // vlad_finish_kernel: everything behind the fused forward kernel in ONE launch — U = sum of the
 // image's slice slabs + C * asum, the intra-normalisation per cluster, the global normalisation,
@@ -2592,10 +2592,10 @@ __global__ __launch_bounds__(256, 1) void vlad_dx_kernel(VladDxArgs p) {
   const unsigned lds0 = nv_lds_byte_of(dxv_lds);
   const unsigned scr0 = lds0 + 2 * DXV_ABUF + wid * DXV_SCR;
   unsigned long long* stp =
-      p.dbg && threadIdx.x == 0 ? p.stamps + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 : nullptr;
+      SCL_DIAG_ONLY(p.dbg) && threadIdx.x == 0 ? p.stamps + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 32 : nullptr;
 #define DX_STAMP(k)                                         \
   do {                                                      \
-    if (p.dbg) {                                            \
+    if (SCL_DIAG_ONLY(p.dbg)) {                                            \
       __builtin_amdgcn_sched_barrier(0);                    \
       if (stp) stp[k] = __builtin_amdgcn_s_memtime();       \
       __builtin_amdgcn_sched_barrier(0);                    \
@@ -2722,7 +2722,7 @@ __global__ __launch_bounds__(256, 1) void vlad_dx_kernel(VladDxArgs p) {
     }
   };
 
-  if (p.dbg) {
+  if (SCL_DIAG_ONLY(p.dbg)) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     DX_STAMP(1);
   }
@@ -2847,7 +2847,7 @@ __global__ __launch_bounds__(256, 1) void vlad_dx_kernel(VladDxArgs p) {
   } else {
     epilogue(acca, ea);
   }
-  if (p.dbg) {
+  if (SCL_DIAG_ONLY(p.dbg)) {
     DX_STAMP(13);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     DX_STAMP(14);
@@ -2965,7 +2965,7 @@ void launch_variant_one(const RowTileArgs& a, dim3 grid, hipStream_t st) {
 }
 template <typename T>
 void launch_rowtile_variant(const RowTileArgs& a, dim3 grid, hipStream_t st) {
-  switch (scl_debug_variant & 7) {
+  switch (scl_variant() & 7) {
     case 1: launch_variant_one<T, 1>(a, grid, st); break;
     case 2: launch_variant_one<T, 2>(a, grid, st); break;
     case 3: launch_variant_one<T, 3>(a, grid, st); break;
@@ -2978,14 +2978,14 @@ void launch_rowtile_variant(const RowTileArgs& a, dim3 grid, hipStream_t st) {
 
 template <typename T, int MODE>
 void launch_rowtile(const RowTileArgs& a, hipStream_t st) {
-  static std::once_flag once;
-  std::call_once(once, [] {
+  static SclDeviceOnce once;
+  scl_call_once(once, [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rowtile16_kernel<T, MODE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRowTile16Lds);
   });
   const int tiles16 = (a.N + 15) / 16;
   const dim3 grid((tiles16 + 3) / 4, a.B);
-  if (MODE == ASSIGN && scl_debug_variant >= 1 && scl_debug_variant <= 7) {   // ablate_rowtile.py
+  if (MODE == ASSIGN && scl_variant() >= 1 && scl_variant() <= 7) {   // ablate_rowtile.py
     launch_rowtile_variant<T>(a, grid, st);
     return;
   }
@@ -2995,7 +2995,7 @@ void launch_rowtile(const RowTileArgs& a, hipStream_t st) {
 
 // bf16 feature maps take the fused kernels; scl_debug_set_variant(1 .. 8) sends them through the
 // float32-MFMA kernels instead (A/B timing and parity runs)
-inline bool use_fused() { return scl_debug_variant < 1 || scl_debug_variant > 8; }
+inline bool use_fused() { return scl_variant() < 1 || scl_variant() > 8; }
 
 struct Carver {
   char* base;
@@ -3014,13 +3014,7 @@ struct VladPlan {
   int steps_per_slice, S;
 };
 inline int vlad_cus() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, c = 0;
-    n = (hipGetDevice(&dev) == hipSuccess &&
-         hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0)
-            ? c : 256;
-  }
+  const int n = scl_device_cus();      // per device (scl_common.h)
   return n;
 }
 inline VladPlan vlad_plan(int B, int N) {
@@ -3098,9 +3092,9 @@ extern "C" size_t scl_netvlad_fwd_workspace_bytes(int B, int N) {
 
 // scl_debug_set_variant(920): round 3's launch structure (separate plane-split, finish_sum,
 // finish_norm, bwd_dots, bwd_du, wgrad_partial, wgrad_finish kernels) for same-box A/B timing
-inline bool old_launches() { return scl_debug_variant == 920; }
+inline bool old_launches() { return scl_variant() == 920; }
 // scl_debug_set_variant(922): the four-wave fused kernels of round 3 instead of the eight-wave ones
-inline bool four_waves() { return scl_debug_variant == 922 || scl_debug_variant == 920 || scl_debug_variant == 916; }
+inline bool four_waves() { return scl_variant() == 922 || scl_variant() == 920 || scl_variant() == 916; }
 
 __global__ __launch_bounds__(256) void vlad_planes_kernel(const float* __restrict__ w,
                                                           unsigned short* __restrict__ planes) {
@@ -3136,8 +3130,8 @@ extern "C" int scl_netvlad_fwd_p(const void* x, int x_dtype, const float* assign
 
   if (x_dtype == SCL_DT_BF16 && use_fused()) {
     // one pass over x: soft-assignment and aggregation fused; then ONE finish kernel
-    static std::once_flag once;
-    std::call_once(once, [] {
+    static SclDeviceOnce once;
+    scl_call_once(once, [] {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vlad_fwd_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVladFusedLds);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vlad_fwd_kernel<false>),
@@ -3170,7 +3164,7 @@ extern "C" int scl_netvlad_fwd_p(const void* x, int x_dtype, const float* assign
     fa.colsum = w.colsum;
     fa.trash = w.trash;
     fa.gran = w.gran;
-    fa.dbg = (scl_debug_variant == 916 || scl_debug_variant == 918) ? 16 : 0;   // scripts/vlad_stamps.py
+    fa.dbg = (scl_variant() == 916 || scl_variant() == 918) ? 16 : 0;   // scripts/vlad_stamps.py
     fa.stamps = w.stamps;
     const bool save = save_assign && save_logit && save_rnorm;
     if (save) {
@@ -3186,7 +3180,7 @@ extern "C" int scl_netvlad_fwd_p(const void* x, int x_dtype, const float* assign
         SCL_LAUNCH("vlad_fwd_kernel<false>", vlad_fwd_kernel<false>, dim3(B, pl.S), dim3(256),
                    kVladFusedLds, st, fa);
     } else {
-      if (save && scl_debug_variant == 918)
+      if (save && scl_variant() == 918)
         SCL_LAUNCH("vlad_fwd8_kernel<stamps>", (vlad_fwd8_kernel<true, true>), dim3(B, pl.S), dim3(512),
                    kVlad8Lds, st, fa);
       else if (save)
@@ -3307,8 +3301,8 @@ extern "C" int scl_netvlad_bwd_p(const void* x, int x_dtype, const float* assign
     SCL_LAUNCH("vlad_bwd_prologue_kernel", vlad_bwd_prologue_kernel, dim3(8, B), dim3(256), 0, st, pa);
   }
   if (fused) {
-    static std::once_flag once;
-    std::call_once(once, [] {
+    static SclDeviceOnce once;
+    scl_call_once(once, [] {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vlad_bwd_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVladFusedLds);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vlad_dx_kernel),
@@ -3347,7 +3341,7 @@ extern "C" int scl_netvlad_bwd_p(const void* x, int x_dtype, const float* assign
     da.steps_per_slice = pl.steps_per_slice;
     da.gx = (unsigned short*)grad_x;
     da.trash = (unsigned short*)w.trash;
-    da.dbg = scl_debug_variant == 917 ? 1 : 0;
+    da.dbg = scl_variant() == 917 ? 1 : 0;
     da.stamps = w.stamps;
     if (!old_launches()) {               // the parameter gradients ride in the tail of this launch
       da.wslab = w.wpart;

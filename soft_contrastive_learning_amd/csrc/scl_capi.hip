@@ -17,12 +17,19 @@ extern "C" const char* scl_error_string(int code) {
 }
 
 // ---- ablation switch for diagnostic kernel variants (scripts/ablate_rowtile.py) ----------
+#ifdef SCL_DIAG
 volatile int scl_debug_variant = 0;
 extern "C" int scl_debug_set_variant(int v) {
   const int old = scl_debug_variant;
   scl_debug_variant = v;
   return old;
 }
+extern "C" int scl_build_is_diag(void) { return 1; }
+#else
+// the product library has no variants: 0 is accepted (and is what it always runs)
+extern "C" int scl_debug_set_variant(int v) { return v == 0 ? 0 : SCL_E_KIND; }
+extern "C" int scl_build_is_diag(void) { return 0; }
+#endif
 
 // ---- CUs left free by the persistent convolution grids (scl_usable_cus in scl_common.h) ----
 volatile int scl_reserve_cus = -1;

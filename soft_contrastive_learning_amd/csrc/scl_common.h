@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <atomic>
+#include <mutex>
 
 #include "scl_hip.h"
 
@@ -265,8 +267,20 @@ extern SclProfSink* volatile scl_prof_sink;
     if (slot_ >= 0) (void)hipEventRecord(ps_->ev[2 * slot_ + 1], (st));          \
   } while (0)
 
-// diagnostic kernel variant selector (0 = production kernels); set by scl_debug_set_variant
+// Diagnostic kernel variant selector.  It exists in the DIAGNOSTIC build only (-DSCL_DIAG ->
+// libscl_hip_diag.so: the A/B, ablation and clock-stamp variants that scripts/ and the equality
+// tests select with scl_debug_set_variant).  The product library (libscl_hip.so) is compiled
+// without it: scl_variant() is the constant 0 there, every variant branch of the dispatch code
+// and every `dbg` test inside a kernel folds away, and scl_debug_set_variant rejects anything
+// but 0 — the shipped library has no process-wide switch that changes a result.
+#ifdef SCL_DIAG
 extern volatile int scl_debug_variant;
+static inline int scl_variant() { return scl_debug_variant; }
+#define SCL_DIAG_ONLY(x) (x)
+#else
+static constexpr int scl_variant() { return 0; }
+#define SCL_DIAG_ONLY(x) 0
+#endif
 
 // 3x3 convolution with LDS-resident weights on v_mfma_f32_16x16x32_bf16 (convh.hip); arguments
 // already validated by convg_dispatch (convg.hip)
@@ -291,6 +305,31 @@ static inline int scl_usable_cus(int cus) {
   }
   const int left = cus - reserve;
   return left >= 8 ? left : (cus < 8 ? cus : 8);
+}
+
+// CU count of the calling thread's CURRENT device, cached per device ordinal (round 4 cached the
+// first device's count in one unsynchronised static per file: wrong for two devices in one
+// process).  Relaxed atomics: the value is idempotent, a race stores the same number twice.
+static inline int scl_device_cus() {
+  static std::atomic<int> table[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int n = table[dev].load(std::memory_order_relaxed);
+  if (n == 0) {
+    int c = 0;
+    n = (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0) ? c : 256;
+    table[dev].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
+
+// One-time function attributes (dynamic LDS limits) are set once PER DEVICE: a function object
+// belongs to a device, and one process may drive several.
+struct SclDeviceOnce { std::once_flag f[64]; };
+template <class F> static inline void scl_call_once(SclDeviceOnce& o, F&& fn) {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) d = 0;
+  std::call_once(o.f[d], fn);
 }
 
 static inline int scl_launch_status() { return (int)hipGetLastError(); }

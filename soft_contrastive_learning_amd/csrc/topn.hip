@@ -144,9 +144,10 @@ __global__ __launch_bounds__(256, 2) void topn_scan_kernel(const void* __restric
                                                            const void* __restrict__ ref_lov,
                                                            const float* __restrict__ refnorm,
                                                            int R, const float* __restrict__ query,
-                                                           int Q, int refs_per_split, int dbg,
+                                                           int Q, int refs_per_split, int dbg_arg,
                                                            float* __restrict__ cand_sc,
                                                            int* __restrict__ cand_ix) {
+  const int dbg = SCL_DIAG_ONLY(dbg_arg);      // timing ablations: diagnostic build only
   constexpr int d = D8 * 8;
   constexpr int LD = d + 4;          // f32 tile: floats per row
   constexpr int LDB = d / 2 + 4;     // bf16 planes: dwords per row
@@ -618,7 +619,7 @@ inline TopnPlan topn_plan(int R, int Q, int bf) {
       best = s;
     }
   }
-  const int tv = scl_debug_variant < 8000 ? scl_debug_variant : 0;   // larger values: other kernels
+  const int tv = scl_variant() < 8000 ? scl_variant() : 0;   // larger values: other kernels
   if (tv % 1000 >= 100) {   // tuning override (microbench.py --topn-splits)
     best = tv % 1000 - 100;
     if (best > 32) best = 32;
@@ -641,8 +642,8 @@ inline size_t scan_lds_bytes(int d, int bf) {
 template <int D8, int BF>
 void launch_scan(const TopnPlan& p, const void* ref, const void* ref_lo, const float* refnorm,
                  int R, const float* query, int Q, float* cs, int* ci, hipStream_t st) {
-  static std::once_flag once;
-  std::call_once(once, [] {
+  static SclDeviceOnce once;
+  scl_call_once(once, [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&topn_scan_kernel<D8, BF>),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)scan_lds_bytes(D8 * 8, BF));
@@ -650,7 +651,7 @@ void launch_scan(const TopnPlan& p, const void* ref, const void* ref_lo, const f
   SCL_LAUNCH(BF ? "topn_scan_kernel<BF=1>" : "topn_scan_kernel<BF=0>", (topn_scan_kernel<D8, BF>),
              dim3(p.qtiles, p.splits), dim3(256), scan_lds_bytes(D8 * 8, BF), st, ref, ref_lo,
              refnorm, R, query, Q, p.refs_per_split,
-             scl_debug_variant < 8000 ? scl_debug_variant / 1000 : 0, cs, ci);
+             scl_variant() < 8000 ? scl_variant() / 1000 : 0, cs, ci);
 }
 
 inline bool topn_shape_ok(int R, int Q, int d, int n) {
@@ -876,8 +877,8 @@ extern "C" int scl_topn_dots(const float* ref, int R, const float* query, int Q,
   const int chunks = (d + DT_CHUNK - 1) / DT_CHUNK;
   const int per = (chunks + splits - 1) / splits;
   if ((int64_t)(splits - 1) * per >= chunks && splits > 1) return SCL_E_SHAPE;   // an empty split
-  static std::once_flag once;
-  std::call_once(once, [] {
+  static SclDeviceOnce once;
+  scl_call_once(once, [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&topn_dots_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kDotsLds);
   });

@@ -28,7 +28,8 @@ def pad_indices(num, images_per_pass):
 
 
 def extract_features(model, loader, num, images_per_pass=4, device=None):
-    """Returns ``list`` of ``num`` float32 vectors of length 32768, in index order."""
+    """Returns ``list`` of ``num`` float32 vectors (length 32768 with the NetVLAD head, H' W' 512
+    without: ``ops['full_out']``, evaluation/inference.py:89-92), in index order."""
     device = device or next(model.parameters()).device
     order = pad_indices(num, images_per_pass)
     feats = [None] * len(order)
@@ -36,7 +37,7 @@ def extract_features(model, loader, num, images_per_pass=4, device=None):
         for s in range(0, len(order), images_per_pass):
             idx = order[s:s + images_per_pass]
             batch = np.stack([np.asarray(loader(int(i)), dtype=np.float32) for i in idx])
-            out = nets.vgg16Netvlad(torch.from_numpy(batch).to(device), model=model)
+            out = nets.full_out(torch.from_numpy(batch).to(device), model=model)
             out = out.float().cpu().numpy()
             for slot, f in zip(range(s, s + len(idx)), out):
                 feats[slot] = f
@@ -72,10 +73,10 @@ def main(argv=None):
     # --reduction pca writes the RAW descriptors, like the reference: "Don't actually do PCA
     # here - doing it after" (evaluation/inference.py:94-95; its projection branch at :111-116
     # is unreachable).  The whitening runs in evaluation/top_n.py.
-    if flags.vlad_cores != 64 or flags.reduction not in ('none', 'pca'):
-        raise SystemExit('only --vlad_cores 64 with --reduction none|pca is on the hot path')
+    if flags.vlad_cores not in (0, 64) or flags.reduction not in ('none', 'pca'):
+        raise SystemExit('only --vlad_cores 64 | 0 with --reduction none|pca is on the hot path')
     np.random.seed(42)                                       # inference.py:270-271
-    model = nets.VGG16NetVLAD().cuda()
+    model = nets.VGG16NetVLAD(vlad_cores=flags.vlad_cores).cuda()
     if flags.checkpoint:
         checkpoint.load(model, flags.checkpoint)
     feats = extract_features(model, synthetic_loader(flags.small_side, flags.large_side),

@@ -43,7 +43,7 @@ class _NetVLADFn(torch.autograd.Function):
     """l2_normalize(axis=-1) + netVLAD(x, 64) on a channels-last feature map."""
 
     @staticmethod
-    def forward(ctx, x, assign_w, centers, pre_l2):
+    def forward(ctx, x, assign_w, centers, pre_l2, planes=None):
         lib = L.load()
         L.require_device(x, assign_w, centers)
         if x.dim() != 4 or x.shape[3] != L.VLAD_D:
@@ -69,33 +69,41 @@ class _NetVLADFn(torch.autograd.Function):
             sr = torch.empty((b, n), dtype=torch.float32, device=dev)
             sv = torch.empty((b, L.VLAD_SAVE_ROWS, L.VLAD_K), dtype=torch.float32, device=dev)
         ws = L.workspace(lib.scl_netvlad_fwd_workspace_bytes(b, n), dev)
-        # the plane images of the assignment weights: written by prepack() in the launch that packs
-        # the convolution weights (once per step); without them the call builds its own
-        planes = _vlad_planes_for(w) if dt == L.DT_BF16 else None
+        # the plane images of the assignment weights: handed in by the caller whose forward pass
+        # wrote them in its weight-packing launch (VGG16NetVLAD.forward: a forced prepack() of THIS
+        # pass — never found by address + version, which in-place optimizers do not move); without
+        # them the call builds its own
+        pgen = None
+        if planes is not None and dt == L.DT_BF16:
+            planes, pgen = planes
+        else:
+            planes = None
         L.check(lib.scl_netvlad_fwd_p(L.ptr(x), dt, L.ptr(w), L.ptr(c), L.ptr(planes), b, n,
                                       int(bool(pre_l2)), L.ptr(out), L.ptr(sa), L.ptr(sl), L.ptr(sr),
                                       L.ptr(sv), L.ptr(ws), ws.numel(), L.stream_of(x)))
         if train:
             ctx.save_for_backward(x, w, c, sa, sl, sr, sv)
-            ctx.meta = (dt, b, n, int(bool(pre_l2)), assign_w.shape, centers.shape, planes)
+            ctx.meta = (dt, b, n, int(bool(pre_l2)), assign_w.shape, centers.shape, planes, pgen)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         lib = L.load()
         x, w, c, sa, sl, sr, sv = ctx.saved_tensors
-        dt, b, n, pre_l2, w_shape, c_shape, planes = ctx.meta
+        dt, b, n, pre_l2, w_shape, c_shape, planes, pgen = ctx.meta
+        if planes is not None and _PLANE_GEN.get(planes.data_ptr()) != pgen:
+            planes = None        # rewritten by a later forward pass: the call builds its own from w
         go = grad_out.float().contiguous()
         gx = torch.empty_like(x)
         gw = torch.empty_like(w)
         gc = torch.empty_like(c)
         ws = L.workspace(lib.scl_netvlad_bwd_workspace_bytes(b, n), x.device)
-        # (the forward's plane images: the weights it saw are the ones this gradient is for)
+        # (the forward's plane images, unless a later pass has rewritten the buffer since)
         L.check(lib.scl_netvlad_bwd_p(L.ptr(x), dt, L.ptr(w), L.ptr(c), L.ptr(planes), L.ptr(go),
                                       L.ptr(sa), L.ptr(sl), L.ptr(sr), L.ptr(sv), b, n, pre_l2,
                                       L.ptr(gx), L.ptr(gw), L.ptr(gc), L.ptr(ws), ws.numel(),
                                       L.stream_of(x)))
-        return gx, gw.reshape(w_shape), gc.reshape(c_shape), None
+        return gx, gw.reshape(w_shape), gc.reshape(c_shape), None, None
 
 
 _CL = torch.channels_last
@@ -184,6 +192,9 @@ USE_PREPACK = os.environ.get('SCL_PREPACK', '1') != '0'
 # its — possibly older — copy of the weights after the training thread's own repack).
 _PACKED = {}
 _PACKED_LOCK = threading.Lock()
+# plane-image buffer address -> how many times prepack() has written it: a NetVLAD backward trusts
+# the forward's plane images only while the count is the one its forward saw
+_PLANE_GEN = {}
 
 
 class _PackSlot(threading.local):
@@ -216,7 +227,8 @@ def prepack(weights, force=False, vlad_w=None):
     NOT guarantee (torch's fused Adam updates the parameters without touching ``_version``), so
     the model's forward pass forces: one 40 us launch per forward, never a stale weight.
     ``vlad_w``: the NetVLAD assignment weights (float32, contiguous, 512 * 64 elements): their bf16
-    plane images ride in the same launch (SCL_PACK_VLAD_W) and are found by _vlad_planes_for()."""
+    plane images ride in the same launch (SCL_PACK_VLAD_W); fresh_vlad_planes() hands them to the
+    caller that asked for them (and to nobody else)."""
     import weakref
     lib = L.load()
     jobs, keep = [], []
@@ -261,6 +273,9 @@ def prepack(weights, force=False, vlad_w=None):
         if buf is not None:
             jobs.append(L.PackJob(L.ptr(vlad_w), 0, 0, 0, 0, L.PACK_VLAD_W, L.VLAD_D, L.VLAD_K, L.ptr(buf)))
             keep.append(vlad_w)
+            with _PACKED_LOCK:
+                gen = _PLANE_GEN[buf.data_ptr()] = _PLANE_GEN.get(buf.data_ptr(), 0) + 1
+            _FWD.planes = (vlad_w.data_ptr(), buf, gen)
     if jobs:
         L.require_device(*keep)
         arr = (L.PackJob * len(jobs))(*jobs)
@@ -268,16 +283,16 @@ def prepack(weights, force=False, vlad_w=None):
     return len(jobs)
 
 
-def _vlad_planes_for(w):
-    """The up-to-date plane images of the assignment weights ``w`` ([512, 64] float32 view of the
-    parameter) written by prepack() on this thread, or None (the call then builds its own)."""
-    if not USE_PREPACK:
+def fresh_vlad_planes(w):
+    """(plane images, generation) of the assignment weights ``w`` if the LAST prepack() of this
+    thread wrote them for exactly this tensor, else None — consumed by the call: the images are
+    valid for the forward pass that packed them and are handed over once.  (Round 4 looked them up
+    by storage address + ``_version``; an in-place optimizer step or a ``.data`` write moves
+    neither, so a direct nets.netvlad() call after one silently used the old W.)"""
+    got, _FWD.planes = _FWD.planes, None
+    if got is None or not USE_PREPACK or got[0] != w.data_ptr() or got[1].device != w.device:
         return None
-    with _PACKED_LOCK:
-        ent = _PACKED.get((w.data_ptr(), 'vlad', _pack_slot()))
-    if ent is None or ent[0]() is None or ent[1] != w._version or ent[3].device != w.device:
-        return None
-    return ent[3]
+    return got[1], got[2]
 
 
 def _packed_for(w, transposed):
@@ -354,6 +369,7 @@ class _FwdState(threading.local):
     train/train.py:967-975): the window features() opens, and what must stay alive in it."""
     split = None         # (stream A, stream B) while features() pipelines the halves
     keep = None
+    planes = None        # (weight address, plane images, generation) of this thread's last prepack()
 
 
 _FWD = _FwdState()
@@ -1088,17 +1104,23 @@ class _SubMean(torch.autograd.Function):
         return None, -s, None
 
 
-def netvlad(x_nhwc, assign_w, centers, pre_l2=True):
+def netvlad(x_nhwc, assign_w, centers, pre_l2=True, planes=None):
     """``tf.nn.l2_normalize(x, axis=-1)`` then ``layers.netVLAD(x, 64)``
-    (model/nets.py:66-67).  x_nhwc [B,H',W',512] -> [B,32768]."""
-    return _NetVLADFn.apply(x_nhwc, assign_w, centers, pre_l2)
+    (model/nets.py:66-67).  x_nhwc [B,H',W',512] -> [B,32768].  ``planes``: what
+    fresh_vlad_planes() returned for ``assign_w`` right after a prepack() of its current value
+    (bf16 maps only; None: the call splits the weights itself)."""
+    return _NetVLADFn.apply(x_nhwc, assign_w, centers, pre_l2, planes)
 
 
 class VGG16NetVLAD(torch.nn.Module):
     """Variables of the reference's ``vgg16_netvlad_pca`` scope."""
 
-    def __init__(self, compute_dtype=torch.float32, seed=1234, fused_relu=True):
+    def __init__(self, compute_dtype=torch.float32, seed=1234, fused_relu=True, vlad_cores=64):
         super().__init__()
+        if vlad_cores not in (0, 64):
+            # the reference's callers know two heads: netVLAD(x, 64) and none (train/train.py:606-611)
+            raise ValueError("vlad_cores must be 64 (NetVLAD head) or 0 (flattened conv5_3 map)")
+        self.vlad_cores = vlad_cores
         self.compute_dtype = compute_dtype
         self.fused_relu = fused_relu
         g = torch.Generator().manual_seed(seed)
@@ -1237,8 +1259,11 @@ class VGG16NetVLAD(torch.nn.Module):
         return x
 
     def forward(self, image_batch):
+        _FWD.planes = None
         x = self.features(image_batch)
-        return netvlad(x, self.assignment_kernel, self.cluster_centers, True)
+        # the plane images features() had written by its own (forced) packing launch, or None
+        planes = fresh_vlad_planes(self.assignment_kernel)
+        return netvlad(x, self.assignment_kernel, self.cluster_centers, True, planes)
 
     def forward_vgg16(self, image_batch):
         """model/nets.py:72-131: backbone + channel L2 norm, no VLAD."""
@@ -1252,8 +1277,9 @@ class VGG16NetVLAD(torch.nn.Module):
             w = getattr(self, 'conv%s_kernel' % name).detach()
             sd['%s/conv%s/kernel' % (SCOPE, name)] = w.permute(2, 3, 1, 0).contiguous()  # HWIO
             sd['%s/conv%s/bias' % (SCOPE, name)] = getattr(self, 'conv%s_bias' % name).detach()
-        sd[SCOPE + '/assignment/kernel'] = self.assignment_kernel.detach()
-        sd[SCOPE + '/cluster_centers'] = self.cluster_centers.detach()
+        if self.vlad_cores == 64:      # the vgg16() graph creates no head variables (nets.py:72-131)
+            sd[SCOPE + '/assignment/kernel'] = self.assignment_kernel.detach()
+            sd[SCOPE + '/cluster_centers'] = self.cluster_centers.detach()
         return sd
 
     def load_state_dict_tf(self, sd, strict=True):
@@ -1316,3 +1342,22 @@ def vgg16Netvlad(image_batch, model=None):
 def vgg16(image_batch, model=None):
     """model/nets.py:72-131 -> [B,H',W',512] channel-normalised conv5_3 map."""
     return (model or default_model()).forward_vgg16(image_batch)
+
+
+def full_out(image_batch, model=None):
+    """``ops['full_out']`` of both reference callers (train/train.py:606-611,
+    evaluation/inference.py:89-92): ``vgg16Netvlad(input)`` when the model was built with
+    ``vlad_cores == 64``, else ``tf.layers.flatten(vgg16(input))`` — the channel-normalised
+    conv5_3 map flattened in NHWC order, [B, H' W' 512]."""
+    model = model or default_model()
+    if getattr(model, 'vlad_cores', 64) == 64:
+        return model(image_batch)
+    x = model.forward_vgg16(image_batch)
+    return x.reshape(x.shape[0], -1)
+
+
+def trainable_parameters(model):
+    """The variables the chosen head creates (the reference's ``vgg16`` graph has no
+    ``assignment/kernel`` / ``cluster_centers``): what the optimizer and the gradient buckets see."""
+    skip = () if getattr(model, 'vlad_cores', 64) == 64 else ('assignment_kernel', 'cluster_centers')
+    return [p for n, p in model.named_parameters() if n not in skip]

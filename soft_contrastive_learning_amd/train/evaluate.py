@@ -27,7 +27,7 @@ def extract_features(model, image_set, indices, images_per_pass):
     with torch.no_grad():
         for s in range(0, len(padded), images_per_pass):
             img = torch.from_numpy(image_set.load_images(padded[s:s + images_per_pass])).to(dev)
-            outs.append(nets.vgg16Netvlad(img, model=model).float())
+            outs.append(nets.full_out(img, model=model).float())
     return torch.cat(outs, 0)[:len(idx)]
 
 

@@ -257,6 +257,22 @@ def batch_distances(flags, distances, device, world=1, rank_offset=0):
     return torch.as_tensor(np.asarray(distances, dtype=np.float32)).to(device)
 
 
+def cadence_due(step, every, stride, world):
+    """Does the cadence `every` (in anchors) fire at anchor position `step`?  One rank: the
+    reference's `step % every == 0` (train/train.py:1014, 1070, 1094); several ranks: a step covers
+    `stride` = tuples_per_batch * world anchors and the cadence fires when a multiple lies inside it."""
+    return step % every == 0 if world == 1 else step % every < stride
+
+
+def next_cadence(step, every, stride, world, n_anchors):
+    """First anchor position after `step` (in steps of `stride`) at which cadence_due fires again,
+    capped at `n_anchors`: the end of the window a mining-cache refresh at `step` must cover."""
+    nxt = step + stride
+    while nxt < n_anchors and not cadence_due(nxt, every, stride, world):
+        nxt += stride
+    return min(nxt, n_anchors)
+
+
 def open_sets(flags, epoch):
     """(local_ref, local_query, other_ref, other_query) image sets of an epoch."""
     from . import dataset
@@ -279,7 +295,8 @@ def train_dataset_epoch(flags, epoch, state, log):
 
     With more than one rank (``state['group']``; new work, the reference is single-GPU) a step takes
     ``tuples_per_batch`` anchors PER RANK: rank r trains on anchors [r t, (r + 1) t) of every
-    block of world * t, with its own sampler stream (seeded by (epoch, rank)); a batch dropped on
+    block of world * t, with its own sampler stream (seeded by (epoch, rank), with and without the
+    mining cache); a batch dropped on
     one rank ('Faulty training batch') is dropped on all of them (one MIN all-reduce of a flag per
     step), the per-tuple losses become the mean over all ranks' tuples (parallel.tuple_loss_dp),
     the pairwise losses take the gathered batch (for wms the ranks exchange the image indices and
@@ -305,8 +322,7 @@ def train_dataset_epoch(flags, epoch, state, log):
                             flags.hard_positives_per_tuple, flags.hard_negatives_per_tuple,
                             flags.mutually_exclusive_negs, dtype, cache if use_cache else None,
                             flags.mining_cache_size,
-                            np.random.RandomState(42 + epoch if world == 1 or not use_cache
-                                                  else [42 + epoch, rank]))
+                            np.random.RandomState(42 + epoch if world == 1 else [42 + epoch, rank]))
     sampler = make_sampler(local_ref, True)
     other_sampler = make_sampler(other_ref, False)
     pipe = InputPipeline(sampler, local_ref.load_images, tuple_shape, use_hard_negatives=True,
@@ -324,11 +340,11 @@ def train_dataset_epoch(flags, epoch, state, log):
 
     def loss_of(distances, images):
         """Single-process loss (the evaluation on the other region: every rank alike)."""
-        out = nets.vgg16Netvlad(images)
+        out = nets.full_out(images)
         return compute_loss(flags, tuple_shape, out, batch_distances(flags, distances, dev))
 
     def train_loss(distances, images, indices):
-        out = nets.vgg16Netvlad(images)
+        out = nets.full_out(images)
         if group is None:
             return compute_loss(flags, tuple_shape, out, batch_distances(flags, distances, dev))
         if flags.loss == 'wms':
@@ -377,15 +393,17 @@ def train_dataset_epoch(flags, epoch, state, log):
         stride = t * world
 
         def due(every):
-            """The reference's `step % every == 0` (one rank); with several ranks a step covers
-            `stride` anchors and the cadence fires when a multiple lies inside it."""
-            return step % every == 0 if world == 1 else step % every < stride
+            return cadence_due(step, every, stride, world)
         for step in range(0, len(anchors), stride):
             if due(flags.mining_step):                               # :1014-1068
                 outstanding = drain(outstanding)
                 mining_indices = np.arange(mining_count * flags.mining_cache_size,
                                            (mining_count + 1) * flags.mining_cache_size) % len(local_ref)
-                to_mine = anchors[step:min(step + flags.mining_step, len(anchors))]
+                # every anchor trained before the NEXT refresh: with several ranks the cadence fires
+                # up to stride - 1 anchors late, so the window runs to the next firing, not to
+                # step + mining_step (anchors outside the cache get no hard positives / negatives)
+                window_end = next_cadence(step, flags.mining_step, stride, world, len(anchors))
+                to_mine = anchors[step:window_end]
                 mining_indices = np.concatenate([mining_indices, to_mine])
                 if group is None:
                     feats = evaluate.extract_features(model, local_ref, mining_indices, s_img)
@@ -393,11 +411,12 @@ def train_dataset_epoch(flags, epoch, state, log):
                     share = np.array_split(mining_indices, world)[rank]
                     feats = parallel.all_gather_ragged(
                         evaluate.extract_features(model, local_ref, share, s_img)
-                        if len(share) else torch.zeros((0, 32768), device=dev), group)
+                        if len(share) else torch.zeros((0, state['feat_dim']), device=dev), group)
                 cache.update(feats, mining_indices)
                 mining_count += 1
                 if rank == 0:
-                    log({'step': state['step'], 'event': 'mining_cache', 'images': int(len(mining_indices))})
+                    log({'step': state['step'], 'event': 'mining_cache', 'images': int(len(mining_indices)),
+                         'anchor_window': [int(step), int(window_end)]})
             if due(flags.eval_step):                                 # :1070-1092
                 outstanding = drain(outstanding)
                 if rank == 0:
@@ -430,6 +449,19 @@ def train_dataset_epoch(flags, epoch, state, log):
                 train_on(pipe.get())
                 outstanding -= 1
         drain(outstanding)
+    except BaseException:
+        # a failure on ONE rank (a worker error re-raised by pipe.get(), a bad batch) would leave
+        # the others blocked in the per-step MIN all-reduce: take the process group down with it
+        if group is not None:
+            try:
+                dist.destroy_process_group()
+            except Exception:
+                pass
+            if os.environ.get('SCL_TRAIN_ABORT_ON_RANK_FAILURE', '1') != '0':
+                import traceback
+                traceback.print_exc()
+                os._exit(1)               # peers see the closed connection instead of waiting
+        raise
     finally:
         pipe.close()
     if rank == 0:
@@ -438,8 +470,8 @@ def train_dataset_epoch(flags, epoch, state, log):
 
 def main(argv=None):
     flags = make_parser().parse_args(argv)
-    if flags.vlad_cores != 64 or flags.reduction != 'none':
-        raise SystemExit('only --vlad_cores 64 --reduction none is on the hot path')
+    if flags.vlad_cores not in (0, 64) or flags.reduction != 'none':
+        raise SystemExit('only --vlad_cores 64 | 0 with --reduction none is on the hot path')
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -463,8 +495,10 @@ def main(argv=None):
     tuple_shape = tuple_shape_for(flags.loss, flags.positives_per_tuple,
                                   flags.negatives_per_tuple)
     cdt = torch.bfloat16 if flags.dtype == 'bf16' else torch.float32
-    model = nets.set_default_model(nets.VGG16NetVLAD(compute_dtype=cdt).to(dev))
-    params = list(model.parameters())
+    model = nets.set_default_model(nets.VGG16NetVLAD(compute_dtype=cdt,
+                                                     vlad_cores=flags.vlad_cores).to(dev))
+    params = nets.trainable_parameters(model)       # train/train.py:606-611: the head decides
+    feat_dim = 32768 if flags.vlad_cores == 64 else (flags.height // 16) * (flags.width // 16) * 512
     buckets = parallel.GradBuckets(params, group)
     nets.GRAD_SINK = buckets       # conv weight / bias gradients go straight into the flat buffer
     if flags.optimizer == 'momentum':
@@ -484,7 +518,7 @@ def main(argv=None):
 
     if flags.synthetic_dataset > 0 or flags.shuffled_root:
         state = dict(model=model, opt=opt, buckets=buckets, saver=saver, dev=dev,
-                     tuple_shape=tuple_shape, step=step, group=group)
+                     tuple_shape=tuple_shape, step=step, group=group, feat_dim=feat_dim)
 
         def write(rec):
             if log is not None:
@@ -505,7 +539,7 @@ def main(argv=None):
             t0 = time.time()
             distances, img = data.batch()
             buckets.zero()
-            output = nets.vgg16Netvlad(img)                       # ops['output'] (:608-629)
+            output = nets.full_out(img)                           # ops['output'] (:606-629)
             loss = compute_loss(flags, tuple_shape, output, distances, group=group)
             loss.backward()
             buckets.finish()

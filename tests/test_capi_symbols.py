@@ -40,8 +40,33 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
         assert getattr(lib, name) is not None
 
 
+def test_product_library_has_no_variants_and_the_diagnostic_build_does(lib):
+    """csrc/Makefile builds the sources twice: libscl_hip.so (what load() returns) is compiled
+    without -DSCL_DIAG — scl_variant() is the constant 0 there, no variant branch survives — and
+    refuses every selector but 0; libscl_hip_diag.so exports the same surface with the switch."""
+    from soft_contrastive_learning_amd import _lib
+    assert lib.scl_build_is_diag() == 0
+    assert lib.scl_debug_set_variant(0) == 0
+    assert lib.scl_debug_set_variant(921) == -2 and lib.scl_debug_set_variant(0) == 0
+    diag = _lib.load(diag=True)
+    assert diag is not lib and diag.scl_build_is_diag() == 1
+    for name in _declared():
+        assert getattr(diag, name) is not None
+    assert diag.scl_debug_set_variant(921) == 0 and diag.scl_debug_set_variant(0) == 921
+    with _lib.variant(32) as inside:
+        assert inside is diag and _lib.load() is diag
+    assert _lib.load() is lib and diag.scl_debug_set_variant(0) == 0
+    # the product object files carry no reference to the switch at all
+    import subprocess
+    so = os.path.join(ROOT, 'soft_contrastive_learning_amd', 'libscl_hip.so')
+    syms = subprocess.run(['nm', '-D', so], capture_output=True, text=True).stdout
+    assert 'scl_debug_variant' not in syms.replace('scl_debug_set_variant', '')
+    syms = subprocess.run(['nm', '-D', so.replace('.so', '_diag.so')], capture_output=True, text=True).stdout
+    assert 'scl_debug_variant' in syms.replace('scl_debug_set_variant', '')
+
+
 def test_abi_version_and_error_strings(lib):
-    assert lib.scl_abi_version() == 9
+    assert lib.scl_abi_version() == 10
     assert lib.scl_error_string(0) == b"ok"
     assert b"shape" in lib.scl_error_string(-1)
     assert b"NULL" in lib.scl_error_string(-3)

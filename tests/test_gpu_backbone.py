@@ -235,21 +235,17 @@ def lds_kernel(request):
     """Pins which of the two LDS-weights convolution kernels runs (csrc/convg.hip: 40000 + v,
     csrc/convh.hip: 50000 + v); yields the variant base for tests that add their own v."""
     from soft_contrastive_learning_amd import _lib as L
-    lib = L.load()
     base = 40000 if request.param == 'mfma32x32x16' else 50000
-    old = lib.scl_debug_set_variant(base)
-    yield base
-    lib.scl_debug_set_variant(old)
+    with L.variant(base):                      # (the diagnostic build for the test's duration)
+        yield base
 
 
 @pytest.fixture
 def block_height(request, lds_kernel):
     """Pins the LDS-weights kernel's block height (12 or 8 rows) for one test."""
     from soft_contrastive_learning_amd import _lib as L
-    lib = L.load()
-    old = lib.scl_debug_set_variant(lds_kernel + 3000 + request.param)
-    yield request.param
-    lib.scl_debug_set_variant(old)
+    with L.variant(lds_kernel + 3000 + request.param):
+        yield request.param
 
 
 @pytest.mark.parametrize('block_height', [12, 13, 8, 6], indirect=True)
@@ -803,11 +799,8 @@ def test_lds_weight_conv_persistent_workgroups_equal_one_tile_per_workgroup(dev,
                 *nets.conv_pool_idx(x, wt, bias))
     outs = {}
     for variant in (3099, 3100, 3101, 0):
-        old = lib.scl_debug_set_variant(lds_kernel + variant)
-        try:
+        with L.variant(lds_kernel + variant):
             outs[variant] = [t.clone() for t in run_all()]
-        finally:
-            lib.scl_debug_set_variant(old)
     for variant in (3100, 3101, 0):
         for a, bb in zip(outs[3099], outs[variant]):
             assert torch.equal(a, bb), variant

@@ -223,6 +223,34 @@ def test_bench_two_ranks_on_one_gpu():
     assert 'retrieval' not in d and 'cpu_baseline' not in d          # N = 1 objects
 
 
+def test_bench_eight_ranks_on_one_gpu_reduced_images():
+    """`python bench.py --gpus 8` — the driver's last scaling point, configs[3]'s world size — kept
+    warm on a one-GPU box: eight self-launched ranks on cuda:0 over gloo, 4 images of 128 x 160 per
+    rank (global batch 32: the B <= 32 one-launch loss on the gathered batch, own-rows backward,
+    bucketed all-reduce over 8 ranks), so that the first real 8-GPU run cannot fail on plumbing."""
+    import json
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip('needs a HIP device')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SCL_BENCH_ONE_GPU_GLOO='1')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '2',
+                        '--warmup', '1', '--batch', '4', '--height', '128', '--width', '160',
+                        '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 8 and d['config']['global_batch'] == 32 and d['scaling'] == 'weak'
+    assert d['value'] > 0 and 0.0 < d['config']['loss'] < 100.0
+    c = d['comm']
+    assert c['world_seen'] == 8 and c['backend'] == 'gloo'
+    assert c['allgather_bytes_per_rank'] == 4 * 32768 * 4 and c['allreduce_buckets'] >= 3
+
+
 def test_bench_retrieval_workload_two_ranks_on_one_gpu():
     """`python bench.py --workload retrieval --gpus 2` (configs[4], reference set sharded over
     the ranks) end to end on a one-GPU box, and the same workload at --gpus 1: same index lists

@@ -359,8 +359,7 @@ def test_fused_finish_gives_the_bits_of_the_two_launch_forward(dev, b, e, kind):
 
     def run(variant):
         x = emb.clone().requires_grad_(True)
-        L.load().scl_debug_set_variant(variant)
-        try:
+        with L.maybe_variant(variant):        # 0: the product library; 32: the diagnostic build
             if kind == "wms_exp":
                 loss = losses.wms_loss(dm, x, 0.8, 15.0)
             elif kind == "wms_tanh_plain":
@@ -369,8 +368,6 @@ def test_fused_finish_gives_the_bits_of_the_two_launch_forward(dev, b, e, kind):
                 loss = losses.ms_loss(lab, x)
             loss.backward()
             torch.cuda.synchronize()
-        finally:
-            L.load().scl_debug_set_variant(0)
         return loss.detach().cpu().numpy(), x.grad.cpu().numpy()
     l1, g1 = run(0)
     l2, g2 = run(32)
@@ -400,15 +397,12 @@ def test_gram_backward_on_bf16_planes(dev, b, row_begin, row_count, e):
     outs = {}
     for variant in (0, 34):
         out = torch.full((row_count, e), 7.0, device=dev)
-        old = lib.scl_debug_set_variant(variant)
-        try:
+        with L.maybe_variant(variant) as vlib:
             with L.KernelTimer(capacity=16) as kt:
-                L.check(lib.scl_gram_loss_bwd_w(L.ptr(emb), e, b, e, L.ptr(coef), L.ptr(gl), row_begin,
-                                                row_count, L.ptr(out), e, L.ptr(ws), ws.numel(),
-                                                L.stream_of(emb)))
+                L.check(vlib.scl_gram_loss_bwd_w(L.ptr(emb), e, b, e, L.ptr(coef), L.ptr(gl), row_begin,
+                                                 row_count, L.ptr(out), e, L.ptr(ws), ws.numel(),
+                                                 L.stream_of(emb)))
                 torch.cuda.synchronize()
-        finally:
-            lib.scl_debug_set_variant(old)
         outs[variant] = (out, set(kt.summary()))
         err = float((out.double() - want).abs().max() / want.abs().max())
         assert err < 2e-6, (variant, err)

@@ -121,3 +121,28 @@ def test_synthetic_image_set_and_localization_metrics():
     ys = [50.0 if x > 30.0 else 0.0 for x in xs]
     want = float(np.trapz(ys, xs))
     assert abs(m['50m-auc@Top1'] - want) < 1e-9
+
+
+def test_mining_windows_cover_every_trained_anchor():
+    """with several ranks the mining cadence fires when a multiple of mining_step
+    lies inside a step's stride of anchors, i.e. up to stride - 1 anchors late; the window handed
+    to the cache must run to the NEXT firing (mining_step = 10, stride = 4 fires at 0, 12, 20:
+    anchors 10..11 are trained at step 8).  Every anchor position must lie in the window of the
+    last refresh at or before its step."""
+    from soft_contrastive_learning_amd.train.train import cadence_due, next_cadence
+    for world, t in ((1, 1), (1, 3), (2, 1), (2, 2), (4, 1), (8, 3)):
+        stride = t * world
+        for every in (1, 4, 7, 10, 250):
+            n = (237 // stride) * stride
+            covered_to = 0
+            for step in range(0, n, stride):
+                if cadence_due(step, every, stride, world):
+                    end = next_cadence(step, every, stride, world, n)
+                    assert end > step and (end == n or cadence_due(end, every, stride, world))
+                    assert step <= covered_to             # no gap between consecutive windows
+                    covered_to = end
+                assert step + stride <= covered_to, (world, t, every, step)
+    # one rank: exactly the reference's windows [k * every, (k + 1) * every)
+    assert next_cadence(0, 10, 1, 1, 100) == 10 and next_cadence(90, 10, 1, 1, 95) == 95
+    assert [s for s in range(0, 24, 4) if cadence_due(s, 10, 4, 2)] == [0, 12, 20]
+    assert next_cadence(0, 10, 4, 2, 24) == 12
