@@ -1,0 +1,112 @@
+#!/usr/bin/env python
+"""Does the bf16 path TRAIN like the float32 path?  (every GPU test
+is single-step, and single-step bf16-vs-f32 gradient agreement in the lower layers is 0.7-0.95
+cosine.)  Runs the trainer's dataset route — sampler -> pipeline -> mining cache -> step ->
+evaluation, the reference loop train/train.py:987-1109 — twice on the synthetic pose-tagged set
+(image content is a smooth function of the pose), same seed, once `--dtype bf16`, once `--dtype
+f32`, and compares what a trainer cares about: the loss curve (smoothed), the loss on the other
+region and the localisation metrics of train/evaluate.py at every evaluation point.
+
+    python scripts/train_dtype_ab.py [--steps 300] [--height 128 --width 160] [--json out.json]
+
+Prints one JSON object: per dtype the smoothed loss curve (means over windows of 25 steps), the
+evaluation records, seconds; and the comparison (relative gap of the window means, final metrics).
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def run(dtype, args, out_root):
+    import torch
+    from soft_contrastive_learning_amd.model import nets
+    from soft_contrastive_learning_amd.train import train as T
+    torch.manual_seed(0)
+    epochs = max(1, -(-args.steps // args.steps_per_epoch))
+    argv = ['--loss', args.loss, '--synthetic_dataset', str(args.images), '--height', str(args.height),
+            '--width', str(args.width), '--positives_per_tuple', str(args.positives),
+            '--negatives_per_tuple', str(args.negatives), '--hard_negatives_per_tuple', '2',
+            '--hard_positives_per_tuple', '2', '--steps', str(args.steps_per_epoch),
+            '--max_epoch', str(epochs), '--mining_step', str(args.mining_step),
+            '--mining_cache_size', str(args.mining_cache), '--eval_step', str(args.eval_step),
+            '--save_step', '100000', '--num_eval_queries', str(args.eval_queries), '--eval_ref_r', '1',
+            '--base_lr', str(args.lr), '--lr_down_factor', '1.0', '--max_pos_radius', '6',
+            '--min_neg_radius', '12', '--alpha', '0.8', '--beta', '8', '--dtype', dtype, '--seed', '42',
+            '--out_root', out_root, '--out_folder', dtype]
+    t0 = time.time()
+    T.main(argv)
+    torch.cuda.synchronize()
+    sec = time.time() - t0
+    nets.set_default_model(None)
+    recs = [json.loads(l) for l in open(os.path.join(out_root, dtype, 'train_log.txt'))]
+    losses = [r['loss'] for r in recs if 'loss' in r]
+    evals = [r for r in recs if r.get('event') == 'eval']
+    return dict(dtype=dtype, steps=len(losses), seconds=round(sec, 1), losses=losses, evals=evals)
+
+
+def windows(v, w):
+    return [sum(v[i:i + w]) / len(v[i:i + w]) for i in range(0, len(v) - w + 1, w)]
+
+
+def compare(a, b, w=25):
+    """a = bf16 run, b = f32 run."""
+    wa, wb = windows(a['losses'], w), windows(b['losses'], w)
+    n = min(len(wa), len(wb))
+    gaps = [abs(wa[i] - wb[i]) / max(abs(wb[i]), 1e-12) for i in range(n)]
+    out = dict(window=w, bf16_window_means=[round(x, 5) for x in wa[:n]],
+               f32_window_means=[round(x, 5) for x in wb[:n]],
+               max_relative_gap_of_window_means=round(max(gaps), 4) if gaps else None,
+               loss_drop_bf16=round(wa[0] - wa[n - 1], 5) if n else None,
+               loss_drop_f32=round(wb[0] - wb[n - 1], 5) if n else None)
+    keys = ('10m-auc@Top1', '%<10m@Top1', '%<10m@Top5', '%<25m@Top1')
+    ev = []
+    for ea, eb in zip(a['evals'], b['evals']):
+        row = dict(step=ea['step'], other_region_loss=(ea.get('other_region_loss'), eb.get('other_region_loss')))
+        for mode in ('local', 'other'):
+            for k in keys:
+                if mode in ea and k in ea[mode]:
+                    row['%s %s' % (mode, k)] = (round(ea[mode][k], 2), round(eb[mode][k], 2))
+        ev.append(row)
+    out['evaluations_bf16_vs_f32'] = ev
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--steps', type=int, default=300)
+    ap.add_argument('--steps_per_epoch', type=int, default=150)
+    ap.add_argument('--images', type=int, default=360)
+    ap.add_argument('--height', type=int, default=128)
+    ap.add_argument('--width', type=int, default=160)
+    ap.add_argument('--positives', type=int, default=4)
+    ap.add_argument('--negatives', type=int, default=4)
+    ap.add_argument('--loss', default='wms')
+    ap.add_argument('--lr', type=float, default=2e-5)
+    ap.add_argument('--mining_step', type=int, default=50)
+    ap.add_argument('--mining_cache', type=int, default=60)
+    ap.add_argument('--eval_step', type=int, default=50)
+    ap.add_argument('--eval_queries', type=int, default=40)
+    ap.add_argument('--json', default='')
+    ap.add_argument('--dtypes', default='bf16,f32')
+    args = ap.parse_args()
+    with tempfile.TemporaryDirectory() as tmp:
+        runs = {d: run(d, args, tmp) for d in args.dtypes.split(',')}
+    out = dict(config=vars(args), runs={d: {k: v for k, v in r.items() if k != 'losses'} for d, r in runs.items()})
+    if 'bf16' in runs and 'f32' in runs:
+        out['comparison'] = compare(runs['bf16'], runs['f32'])
+    text = json.dumps(out)
+    print(text)
+    if args.json:
+        with open(args.json, 'w') as f:
+            f.write(text + '\n')
+    return out
+
+
+if __name__ == '__main__':
+    main()

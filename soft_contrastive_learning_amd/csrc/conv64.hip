@@ -69,6 +69,31 @@ __device__ __forceinline__ void glds16_s(const unsigned short* base, unsigned of
       : "v"(off_bytes), "s"(base), "s"(lds_byte)
       : "memory");
 }
+// LDS-DMA through a BUFFER RESOURCE (buffer_load_dwordx4 ... offen lds): the same 1-KB copy, with
+// the hardware's bounds check on every lane's byte offset — an offset at or beyond num_records,
+// or a negative one (it wraps to > 2^31), delivers ZEROS (scripts/buffer_lds_probe.hip).  With one
+// resource per image the rows of a halo window that lie above or below the image need no per-lane
+// test, no zero block and no select: one v_add per chunk instead of ~11 vector instructions.
+// rsrc: {base lo, base hi (stride 0), num_records in bytes, 0x00020000}, wave-uniform.
+__device__ __forceinline__ void blds16(u32x4 rsrc, unsigned voff_bytes, unsigned lds_byte) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff_bytes), "s"(rsrc), "s"(lds_byte)
+      : "memory");
+}
+__device__ __forceinline__ u32x4 image_rsrc(const unsigned short* base, int64_t first_elem, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)(base + first_elem);
+  return u32x4{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a),
+               (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu)),
+               (unsigned)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000u};
+}
+// Round 5: wrw64_kernel takes the buffer path for tiles whose window columns lie inside the image
+// (DBG & 8 = the round-4 staging, for A/B in the diagnostic build).
+constexpr bool kWrwBufPath = true;
+
 // Generalisation to the other VGG shapes whose weight slice still fits the register file:
 //   (CIN, KOUT) in {(64,64) conv1_2 fwd+bwd, (64,128) conv2_1 fwd, (128,64) conv2_1 bwd,
 //   (128,128) conv2_2 fwd+bwd}.  A wave always owns 32 output channels (KOUT / 32 n-tiles)
@@ -594,7 +619,9 @@ __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __r
   // arrives (58 KB at 13 B per cycle), and the wave's 72 products only started afterwards.
   struct TilePos {
     int ty, tx, xo, go;      // first pixel; element offsets of the window's / tile's first pixel
-    bool inner;              // the whole halo window lies inside the image
+    int mode;                // 0: the whole halo window lies inside the image; 1: its COLUMNS do
+                             // (rows may not): the buffer path; 2: per-lane border tests
+    int b, xi, gi;           // image; the same offsets relative to the image's first element
   };
   auto tile_pos = [&](int tile) {
     const int b = tile / per_img, t2 = tile % per_img;
@@ -605,15 +632,27 @@ __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __r
     // masked by `ok`)
     t.xo = ((b * H + t.ty - 1) * W + t.tx - 1) * C;
     t.go = ((b * H + t.ty) * W + t.tx) * K;
-    t.inner = t.ty >= 1 && t.ty + THv < H && t.tx >= 1 && t.tx + TWv < W;
+    const bool colin = t.tx >= 1 && t.tx + TWv < W;
+    // (one scalar: as two bools hipcc rebuilt them as lane masks at every chunk)
+    t.mode = __builtin_amdgcn_readfirstlane(
+        colin && t.ty >= 1 && t.ty + THv < H ? 0 : (colin && kWrwBufPath && !(DBG & 8) ? 1 : 2));
+    t.b = b;
+    t.xi = ((t.ty - 1) * W + t.tx - 1) * C;      // (negative in the first tile row)
+    t.gi = (t.ty * W + t.tx) * K;
     return t;
   };
   auto stage_chunk = [&](const TilePos& tp, int buf, int i) __attribute__((always_inline)) {
     const int ty = tp.ty, tx = tp.tx, xo = tp.xo, go = tp.go;
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds_byte_of(lds) + buf * WBUF * 2 + ldst[i]);
-    if (tp.inner) {
+    if (tp.mode == 0) {
       // (wave-uniform) no border in sight: scalar base + the lane's constant offset
       glds16_s(is_x[i] ? x + xo : gz + go, 2u * (unsigned)roff[i], dst);
+    } else if (tp.mode == 1) {
+      // (wave-uniform) rows above / below the image: the resource of image b bounds every lane's
+      // offset; a negative one wraps and is out of range too — zeros, like the zero block's
+      const u32x4 rs = is_x[i] ? image_rsrc(x, (int64_t)tp.b * H * W * C, (unsigned)(H * W * C) * 2u)
+                               : image_rsrc(gz, (int64_t)tp.b * H * W * K, (unsigned)(H * W * K) * 2u);
+      blds16(rs, 2u * (unsigned)((is_x[i] ? tp.xi : tp.gi) + roff[i]), dst);
     } else {
       const int halo = is_x[i] ? 1 : 0;
       const int y = ty - halo + (rel[i] >> 8), xx = tx - halo + (rel[i] & 255);
@@ -1725,6 +1764,9 @@ static int wrw3x3_run(const void* x, const void* gz, const unsigned char* pidx, 
     SCL_WRW_ATTR(0, 32, 1, 1) SCL_WRW_ATTR(0, 8, 1, 1) SCL_WRW_ATTR(0, 32, 2, 1) SCL_WRW_ATTR(0, 8, 2, 1)
     SCL_WRW_ATTR(4, 32, 2, 0) SCL_WRW_ATTR(4, 8, 2, 0) SCL_WRW_ATTR(4, 32, 2, 1) SCL_WRW_ATTR(4, 8, 2, 1)
     SCL_WRW_ATTR(6, 32, 2, 0) SCL_WRW_ATTR(6, 8, 2, 0)
+#ifdef SCL_DIAG
+    SCL_WRW_ATTR(8, 32, 2, 0) SCL_WRW_ATTR(8, 8, 2, 0) SCL_WRW_ATTR(8, 32, 2, 1) SCL_WRW_ATTR(8, 8, 2, 1)
+#endif
 #undef SCL_WRW_ATTR
   });
   const int cus = conv64_cus();
@@ -1761,6 +1803,16 @@ static int wrw3x3_run(const void* x, const void* gz, const unsigned char* pidx, 
     }
     return scl_launch_status();
   }
+#ifdef SCL_DIAG
+  if (nkb == 2 && scl_variant() == 2200) {     // round 4's staging (no buffer path): A/B partner, CORRECT results
+    PP = wrw_splits(cin, kout / 2, tiles, cus);
+    if (pidx) {
+      if (tall) SCL_WRW_LAUNCH(8, 8, 2, 1); else SCL_WRW_LAUNCH(8, 32, 2, 1);
+    } else {
+      if (tall) SCL_WRW_LAUNCH(8, 8, 2, 0); else SCL_WRW_LAUNCH(8, 32, 2, 0);
+    }
+  } else
+#endif
   if (nkb == 2) {
     PP = wrw_splits(cin, kout / 2, tiles, cus);
     if (pidx) {
