@@ -22,6 +22,8 @@ from soft_contrastive_learning_amd.model import nets  # noqa: E402
 LAYERS = [('1_1', 3, 64, 1), ('1_2', 64, 64, 1), ('2_1', 64, 128, 2), ('2_2', 128, 128, 2),
           ('3_1', 128, 256, 4), ('3_2', 256, 256, 4), ('4_1', 256, 512, 8), ('4_2', 512, 512, 8),
           ('5_1', 512, 512, 16)]
+# (the reference's own training resolution, train/train.py:423-428: --height 180 --width 240
+# --batch 25 -> conv4 maps 22 x 30, conv5 11 x 15; configs[0]: --height 224 --width 224 --batch 4)
 if os.environ.get('SCL_LAYERS'):
     LAYERS = [l for l in LAYERS if l[0] in os.environ['SCL_LAYERS'].split(',')]
 ONES = [1, 1]

@@ -38,7 +38,7 @@ def run(dtype, args, out_root):
             '--save_step', '100000', '--num_eval_queries', str(args.eval_queries), '--eval_ref_r', '1',
             '--base_lr', str(args.lr), '--lr_down_factor', '1.0', '--max_pos_radius', '6',
             '--min_neg_radius', '12', '--alpha', '0.8', '--beta', '8', '--dtype', dtype, '--seed', '42',
-            '--out_root', out_root, '--out_folder', dtype]
+            '--synthetic_distractor', str(args.distractor), '--out_root', out_root, '--out_folder', dtype]
     t0 = time.time()
     T.main(argv)
     torch.cuda.synchronize()
@@ -87,7 +87,8 @@ def main():
     ap.add_argument('--positives', type=int, default=4)
     ap.add_argument('--negatives', type=int, default=4)
     ap.add_argument('--loss', default='wms')
-    ap.add_argument('--lr', type=float, default=2e-5)
+    ap.add_argument('--lr', type=float, default=1e-4)
+    ap.add_argument('--distractor', type=float, default=0.7)
     ap.add_argument('--mining_step', type=int, default=50)
     ap.add_argument('--mining_cache', type=int, default=60)
     ap.add_argument('--eval_step', type=int, default=50)

@@ -9,7 +9,7 @@ import torch
 
 from .. import _lib as L
 
-MAX_N = 25
+MAX_N = 25          # what ONE kernel pass returns per query (32 nominated, 25 certified: csrc/topn.hip)
 
 
 SCORE_MODES = {'f32': L.TOPN_SCORE_F32, 'bf16x3': L.TOPN_SCORE_BF16X3}
@@ -43,10 +43,13 @@ def topn_l2(ref, query, n, idx_offset=0, score='f32', certify=True, stats=None):
                                                                      tuple(query.shape)))
     r, d = ref.shape
     q = query.shape[0]
-    if n > MAX_N or n > r or n < 1:
-        raise ValueError("n must be in [1, min(%d, R)], got n=%d R=%d" % (MAX_N, n, r))
+    if n > r or n < 1:
+        raise ValueError("n must be in [1, R], got n=%d R=%d" % (n, r))
     if d > 256:
         return _topn_wide(ref.contiguous(), query.contiguous(), n, idx_offset, certify, stats)
+    if n > MAX_N:
+        # evaluation/top-n.py:135 leaves --N free; one kernel pass certifies 25 per query
+        return _topn_many(ref, query, n, idx_offset, score, stats)
     if d not in (32, 64, 128, 256):
         # zero-padding the feature axis leaves every distance unchanged
         pad = next(c for c in (32, 64, 128, 256) if d <= c)
@@ -114,7 +117,75 @@ def _resolve_exactly(ref, query, n, idx_offset, bad, bound, dist, idx):
             idx[qi] = best_i + idx_offset
 
 
-_KEEP = 32          # candidates nominated per query before the exact re-rank
+def _topn_many(ref, query, n, idx_offset=0, score='f32', stats=None):
+    """Exact top-n for n > 25 (``KDTree.query(k=N)`` with the reference's free ``--N``,
+    evaluation/top-n.py:103-108, 135) from the exact, certified top-25 primitive.
+
+    The references are dealt into S interleaved shards (``ref[s::S]``: neighbours that are
+    adjacent in list order — consecutive frames of a traverse — spread over all shards); every
+    shard returns its exact top-25 per query; the merged pool, ordered by (distance, index), gives
+    the candidate n-th distance D_n.  A shard whose 25th distance is STRICTLY beyond D_n cannot
+    hold anything else within D_n, so its contribution is complete.  For the (query, shard) pairs
+    where that fails — more than 25 of the query's n nearest fell into one shard, or ties at D_n —
+    the shard is split in two and those queries alone are asked again, until every pair is
+    certified (a shard of <= 25 references returns all of them).  Exact for any data; the expected
+    case (S chosen so that a shard holds ~n/S << 25 of the top n) is one pass and no refinement.
+    ``stats['refined']`` counts the (query, shard) pairs that needed a split."""
+    dev = ref.device
+    r = ref.shape[0]
+    q = query.shape[0]
+    shards = max(2, -(-n // 10))                      # expected share of the top n per shard: <= 10
+    inf = float('inf')
+    pool_d = torch.full((q, 0), inf, dtype=torch.float64, device=dev)
+    pool_i = torch.zeros((q, 0), dtype=torch.int64, device=dev)
+    refined = 0
+    # work list: (reference rows of the shard as a LongTensor of positions, query rows or None = all)
+    work = [(torch.arange(s, r, shards, device=dev), None) for s in range(shards)]
+    passes = []                                      # (positions, query rows, dists, local idx)
+    while work:
+        pos, qrows = work.pop()
+        sub = ref[pos].contiguous()
+        qq = query if qrows is None else query[qrows].contiguous()
+        k = min(MAX_N, sub.shape[0])
+        dd, ii = topn_l2(sub, qq, k, 0, score)
+        passes.append((pos, qrows, dd, pos[ii]))
+        # fold into the pool: rows of the asked queries only
+        rows = torch.arange(q, device=dev) if qrows is None else qrows
+        add_d = torch.full((q, k), inf, dtype=torch.float64, device=dev)
+        add_i = torch.full((q, k), 2 ** 62, dtype=torch.int64, device=dev)
+        add_d[rows], add_i[rows] = dd, pos[ii]
+        pool_d, pool_i = torch.cat([pool_d, add_d], 1), torch.cat([pool_i, add_i], 1)
+        if work:
+            continue
+        # every outstanding pass is in: merge by (distance, index), drop what a refined shard
+        # returned a second time (same index: its parent already gave it), then the candidate
+        # n-th distance per query and the test
+        o = torch.argsort(pool_i, dim=1, stable=True)
+        pd, pi = torch.gather(pool_d, 1, o), torch.gather(pool_i, 1, o)
+        dup = torch.zeros_like(pi, dtype=torch.bool)
+        dup[:, 1:] = pi[:, 1:] == pi[:, :-1]
+        pd = pd.masked_fill(dup, inf)
+        o = torch.argsort(pd, dim=1, stable=True)
+        pd, pi = torch.gather(pd, 1, o), torch.gather(pi, 1, o)
+        keep = min(pd.shape[1], 4 * n)
+        pool_d, pool_i = pd[:, :keep].contiguous(), pi[:, :keep].contiguous()
+        d_n = pool_d[:, n - 1]
+        for pos, qrows, dd, _ in passes:
+            if pos.numel() <= MAX_N:
+                continue                              # the shard returned all it has
+            rows = torch.arange(q, device=dev) if qrows is None else qrows
+            bad = rows[~(dd[:, -1] > d_n[rows])]
+            if bad.numel():
+                refined += int(bad.numel())
+                work.append((pos[0::2], bad))
+                work.append((pos[1::2], bad))
+        passes = []
+    if stats is not None:
+        stats['refined'] = refined
+    return pool_d[:, :n].contiguous(), (pool_i[:, :n] + int(idx_offset)).contiguous()
+
+
+_KEEP = 32          # candidates nominated per query before the exact re-rank (wide path: >= n + 8)
 
 
 def _brute_force_f64(ref, qv, n, chunk=65536):
@@ -164,6 +235,7 @@ def _topn_wide(ref, query, n, idx_offset, certify=True, stats=None, dots_fn=None
     r, d = ref.shape
     q = query.shape[0]
     dev = ref.device
+    keep = max(_KEEP, n + 8)                  # n > 25 (evaluation/top-n.py:135): nominate more
     u = 2.0 ** -53
     g32 = 256.0 * 2.0 ** -24 / (1.0 - 256.0 * 2.0 ** -24)
     qb_max = 512
@@ -197,12 +269,12 @@ def _topn_wide(ref, query, n, idx_offset, certify=True, stats=None, dots_fn=None
             else:
                 dv = dots_fn(rblk, qblk)
             sc = qn[:, None] + rn_all[None, rs:rs + nr] - 2.0 * dv
-            k = min(_KEEP, nr)
+            k = min(keep, nr)
             sv, iv = torch.topk(sc, k, dim=1, largest=False)
             cand_s.append(sv)
             cand_i.append(iv + rs)
         sv, iv = torch.cat(cand_s, 1), torch.cat(cand_i, 1)
-        k = min(_KEEP, sv.shape[1])
+        k = min(keep, sv.shape[1])
         top_s, pick = torch.topk(sv, k, dim=1, largest=False)
         cand = torch.gather(iv, 1, pick)                                  # [qb, k]
         exact = torch.empty((qb, k), dtype=torch.float64, device=dev)
@@ -217,7 +289,7 @@ def _topn_wide(ref, query, n, idx_offset, certify=True, stats=None, dots_fn=None
         dn = torch.gather(exact, 1, o)
         out_d[qs:qs + qb] = dn.sqrt()
         out_i[qs:qs + qb] = torch.gather(cand, 1, o) + int(idx_offset)
-        if certify and r > k:                    # (r <= 32: every reference was re-ranked)
+        if certify and r > k:                    # (r <= keep: every reference was re-ranked)
             tau = top_s.max(dim=1).values
             qnorm = qn.sqrt()
             eps = 2.0 * (2.0 * g32 * qnorm * r_max + (d + 8) * u * (qnorm + r_max) ** 2)

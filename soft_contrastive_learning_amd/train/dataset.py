@@ -47,8 +47,14 @@ class SyntheticImageSet:
     and the descriptors carry place information — enough for mining and the localisation
     evaluation to have something to find."""
 
-    def __init__(self, num, height=64, width=80, spacing=2.0, laps=2, seed=0):
+    def __init__(self, num, height=64, width=80, spacing=2.0, laps=2, seed=0, distractor=0.0):
+        """``distractor`` in [0, 1): share of an image's contrast taken by a per-IMAGE pattern that
+        says nothing about the place (random orientation, frequency and phase — "illumination"),
+        with the per-pixel noise raised in step: 0 (the default) leaves a set that untrained
+        descriptors already localise perfectly; 0.7 one on which training has something to learn
+        (scripts/train_dtype_ab.py, tests/test_gpu_training.py)."""
         self.h, self.w, self.seed = height, width, seed
+        self.distractor = float(distractor)
         per_lap = max(num // laps, 1)
         s = (np.arange(num) % per_lap) * spacing                 # arc length along the loop
         length = per_lap * spacing
@@ -71,7 +77,15 @@ class SyntheticImageSet:
         for k, i in enumerate(indices):
             s = self._s[int(i)]
             rng = np.random.default_rng(self.seed * 1000003 + int(i))
-            base = [127.5 + 100.0 * np.sin(0.05 * s * (c + 1) + 6.0 * xx * (c + 1) + 3.0 * yy)
+            a = 1.0 - self.distractor
+            base = [127.5 + 100.0 * a * np.sin(0.05 * s * (c + 1) + 6.0 * xx * (c + 1) + 3.0 * yy)
                     for c in range(3)]
-            out[k] = np.clip(np.stack(base, -1) + rng.normal(0.0, 8.0, (self.h, self.w, 3)), 0, 255)
+            img = np.stack(base, -1)
+            sigma = 8.0
+            if self.distractor > 0.0:
+                fx, fy = rng.uniform(-9.0, 9.0, 2)
+                ph, tint = rng.uniform(0.0, 2.0 * np.pi), rng.uniform(0.5, 1.0, 3)
+                img = img + (100.0 * self.distractor * np.sin(fx * xx + fy * yy + ph))[..., None] * tint
+                sigma = 8.0 + 24.0 * self.distractor
+            out[k] = np.clip(img + rng.normal(0.0, sigma, (self.h, self.w, 3)), 0, 255)
         return out

@@ -99,6 +99,8 @@ def make_parser():
     p.add_argument('--synthetic_dataset', type=int, default=0,
                    help='M > 0: train on a synthetic pose-tagged set of M images through the '
                         'sampler / pipeline / mining / evaluation route')
+    p.add_argument('--synthetic_distractor', type=float, default=0.0,
+                   help='synthetic set: share of the image contrast that is place-independent')
     # synthetic stand-in for the dataset pipeline
     p.add_argument('--steps', type=int, default=10, help='steps per epoch')
     p.add_argument('--height', type=int, default=180)
@@ -284,9 +286,10 @@ def open_sets(flags, epoch):
         return (one(flags.local_ref_set), one(flags.local_query_set), one(flags.other_ref_set),
                 one(flags.other_query_set))
     m = flags.synthetic_dataset
-    local = dataset.SyntheticImageSet(m, flags.height, flags.width, seed=flags.seed)
+    local = dataset.SyntheticImageSet(m, flags.height, flags.width, seed=flags.seed,
+                                      distractor=flags.synthetic_distractor)
     other = dataset.SyntheticImageSet(max(m // 2, 8), flags.height, flags.width,
-                                      seed=flags.seed + 1)
+                                      seed=flags.seed + 1, distractor=flags.synthetic_distractor)
     return local, local, other, other
 
 

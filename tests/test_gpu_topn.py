@@ -173,3 +173,29 @@ def test_config4_full_size_retrieval(dev, score):
     kd_d, kd_i = TN.topn_kdtree(ref, qry[:500], n)
     np.testing.assert_array_equal(got_i[:500], kd_i)
     np.testing.assert_allclose(got_d[:500], kd_d, rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("score", ['f32', 'bf16x3'])
+@pytest.mark.parametrize("r,q,d,n", [(5000, 300, 256, 50), (20000, 64, 128, 100), (2000, 50, 300, 60),
+                                     (60, 9, 64, 40)])
+def test_topn_above_25_matches_kdtree(dev, r, q, d, n, score):
+    """--N above 25 (evaluation/top-n.py:135 leaves it free): exact lists from the certified
+    top-25 kernel through interleaved shards + per-query refinement (retrieval._topn_many; the
+    d = 300 case takes the wide path with a longer nomination list).  Bit-exact index lists
+    against the reference's own KDTree.query call, incl. a query whose 90 nearest references all
+    sit in ONE shard (consecutive multiples of the shard count)."""
+    from soft_contrastive_learning_amd.evaluation import retrieval
+    ref, qry = U.retrieval_sets(r, q, d)
+    if r >= 2000:
+        shards = max(2, -(-n // 10))
+        rows = np.arange(0, 90 * shards, shards)
+        rng = np.random.default_rng(1)
+        ref[rows] = qry[2] + (1e-2 * rng.standard_normal((90, d))).astype(np.float32)
+    st = {}
+    got_d, got_i = retrieval.topn_l2(torch.tensor(ref, device=dev), torch.tensor(qry, device=dev), n,
+                                     idx_offset=11, score=score, stats=st)
+    want_d, want_i = TN.topn_kdtree(ref, qry, n)
+    np.testing.assert_array_equal(got_i.cpu().numpy() - 11, want_i)
+    np.testing.assert_allclose(got_d.cpu().numpy(), want_d, rtol=1e-12, atol=0)
+    if r >= 2000 and d <= 256:
+        assert st['refined'] >= 1

@@ -150,3 +150,41 @@ def test_wide_path_on_the_gpu_at_the_cpu_test_shapes():
     d, i = retrieval.topn_l2(torch.tensor(ref, device=dev), torch.tensor(qry, device=dev), 25, stats=st)
     check_against_tree(d.cpu().numpy(), i.cpu().numpy(), ref, qry, 25, dup_rows)
     assert 2 <= st['uncertified'] <= 4, st
+
+
+# ---- n > 25 (evaluation/top-n.py:135 leaves --N free): retrieval._topn_many --------------------
+def _exact_topk_cpu(ref, query, k, idx_offset=0, score='f32', certify=True, stats=None):
+    """CPU stand-in of the certified top-25 primitive (float64 direct form, (distance, index)
+    order) for the logic test of the layer above it: test infrastructure, never the product."""
+    r64, q64 = ref.double(), query.double()
+    d = ((q64[:, None, :] - r64[None]) ** 2).sum(-1)
+    idx = torch.arange(ref.shape[0])[None].expand_as(d)
+    o = torch.argsort(d, dim=1, stable=True)[:, :k]              # stable: ties by index
+    return torch.gather(d, 1, o).sqrt(), torch.gather(idx, 1, o) + idx_offset
+
+
+@pytest.mark.parametrize("n", [26, 50, 100])
+def test_topn_many_is_exact_from_the_top25_primitive(monkeypatch, n):
+    """Interleaved shards + per-(query, shard) certification + splitting: index lists equal the
+    reference's KDTree.query(k=N) on tie-free data AND on a set where one query's 80 nearest
+    references are consecutive multiples of the shard count (all in ONE shard: the refinement
+    must run), incl. exact duplicates (ties go by index, like the kernel's order)."""
+    from soft_contrastive_learning_amd.evaluation import retrieval
+    monkeypatch.setattr(retrieval, 'topn_l2', _exact_topk_cpu)
+    rng = np.random.default_rng(n)
+    r, q, d = 1500, 40, 24
+    ref = rng.standard_normal((r, d)).astype(np.float32)
+    qry = rng.standard_normal((q, d)).astype(np.float32)
+    shards = max(2, -(-n // 10))
+    rows = np.arange(0, 80 * shards, shards)                    # every one in shard 0
+    ref[rows] = qry[3] + 1e-3 * rng.standard_normal((80, d)).astype(np.float32)
+    ref[rows[5]] = ref[rows[4]]                                  # exact duplicates: a tie
+    ref[rows[7]] = ref[rows[4]]
+    st = {}
+    got_d, got_i = retrieval._topn_many(torch.tensor(ref), torch.tensor(qry), n, 7, 'f32', st)
+    want_d, want_i = _exact_topk_cpu(torch.tensor(ref), torch.tensor(qry), n, 7)
+    assert torch.equal(got_i, want_i)
+    np.testing.assert_allclose(got_d.numpy(), want_d.numpy(), rtol=1e-12)
+    assert st['refined'] >= 1                                    # query 3 overflowed its shard
+    kd_d, kd_i = TN.topn_kdtree(ref, qry[10:20], n)              # tie-free queries: the tree itself
+    np.testing.assert_array_equal(got_i[10:20].numpy() - 7, kd_i)
