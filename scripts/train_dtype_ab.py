@@ -35,7 +35,7 @@ def run(dtype, args, out_root):
             '--hard_positives_per_tuple', '2', '--steps', str(args.steps_per_epoch),
             '--max_epoch', str(epochs), '--mining_step', str(args.mining_step),
             '--mining_cache_size', str(args.mining_cache), '--eval_step', str(args.eval_step),
-            '--save_step', '100000', '--num_eval_queries', str(args.eval_queries), '--eval_ref_r', '1',
+            '--save_step', '100000', '--num_eval_queries', str(args.eval_queries), '--eval_ref_r', '2',
             '--base_lr', str(args.lr), '--lr_down_factor', '1.0', '--max_pos_radius', '6',
             '--min_neg_radius', '12', '--alpha', '0.8', '--beta', '8', '--dtype', dtype, '--seed', '42',
             '--synthetic_distractor', str(args.distractor), '--out_root', out_root, '--out_folder', dtype]
@@ -64,7 +64,7 @@ def compare(a, b, w=25):
                max_relative_gap_of_window_means=round(max(gaps), 4) if gaps else None,
                loss_drop_bf16=round(wa[0] - wa[n - 1], 5) if n else None,
                loss_drop_f32=round(wb[0] - wb[n - 1], 5) if n else None)
-    keys = ('10m-auc@Top1', '%<10m@Top1', '%<10m@Top5', '%<25m@Top1')
+    keys = ('10m-auc@Top1', '%<10m@Top1', '%<10m@Top5', '%<25m@Top1', '%<10m@Optimum')
     ev = []
     for ea, eb in zip(a['evals'], b['evals']):
         row = dict(step=ea['step'], other_region_loss=(ea.get('other_region_loss'), eb.get('other_region_loss')))

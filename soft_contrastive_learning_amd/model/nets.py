@@ -329,13 +329,23 @@ def _own_conv_kind(x, w, transposed=False):
     return None
 
 
-def _lds_conv_pays(x, transposed=False, fused_tail=False):
-    """Measured on MI355X (scripts/conv_layers.py, profiles/r02): the LDS-weights kernel
-    (csrc/convh.hip) beats the library on conv3_x .. conv5_x in both directions — conv4_x
-    forward 1230-1340 vs 950-1010 TFLOP/s, backward-data 1260-1370 vs 640-670; at 30 x 40 (conv5_x),
-    with its 6-row blocks, forward 1070-1090 vs 910-920 and backward-data 1090-1110 vs 570-600.  Smaller maps fill the chip too
-    badly and stay with the library."""
-    return x.shape[2] * x.shape[3] >= 30 * 40
+def _lds_conv_pays(x, transposed=False, fused_tail=False, kout=512):
+    """Own LDS-weights kernel (csrc/convh.hip) or the library?  Measured on MI355X
+    (scripts/conv_layers.py; profiles/r02 for the bench shapes, profiles/r05/conv_layers_*.txt for
+    the small maps): what decides is how many workgroup tiles ([8 rows x 40 px] x 128 output
+    channels) the launch has for the chip's 256 CUs, not the map size —
+      * 24 x 30x40 (conv5_x of the bench step, 384 tiles): own 1070-1110 vs 910 / 570-600 TFLOP/s;
+      * 25 x 22x30 and 25 x 11x15 (conv4_x / conv5_x at the reference's own training resolution,
+        240 x 180, train/train.py:423-428; 1200 / 200 tiles): forward 61-104 vs 67-120 us and
+        67 vs 64 us, backward-data 64-103 vs 131-188 and 67 vs 88 us;
+      * 24 x 14x14 (192 tiles): forward 72 vs 65 us, backward-data 71 vs 88;
+      * 4 x 28x28 / 4 x 14x14 (configs[0]; 64 / 32 tiles): forward 59 vs 49 and 58 vs 36 us — the
+        library wins when most CUs would get no tile at all; backward-data 60 vs 67 / 58 vs 39.
+    Round 4 gated on the map size (>= 30 x 40) and so handed conv4_x / conv5_x of the reference's
+    real training shape to the library: 39 % of its convolution FLOPs."""
+    b, _, h, w = x.shape
+    tiles = b * -(-h // 8) * -(-w // 40) * max(int(kout) // 128, 1)
+    return tiles >= (48 if transposed else 192)
 
 
 def _conv64_ok(x, w, transposed=False):
@@ -553,7 +563,7 @@ def wrw64(x, gz, w_like, bias_grad=None, pool_idx=None):
 def _conv3x3(x, w):
     """3x3 / stride 1 / same-padding convolution without bias (MIOpen, or conv64)."""
     kind = _own_conv_kind(x, w)
-    if kind == 'reg' or (kind == 'lds' and _lds_conv_pays(x)):
+    if kind == 'reg' or (kind == 'lds' and _lds_conv_pays(x, kout=w.shape[0])):
         return conv64(x, w, False)
     return torch.ops.aten.convolution(x, _lib_weight(w, x), None, _ONES, _ONES, _ONES, False,
                                       [0, 0], 1)
@@ -561,8 +571,13 @@ def _conv3x3(x, w):
 
 def _wrw_pays(x):
     """scripts/conv_layers.py: own 850-1070 vs library 370-750 TFLOP/s on conv1_2 .. conv4_x,
-    900 vs 600 at 30 x 40 (conv5_x) with the 32 x 8 tile shape for narrow maps."""
-    return x.shape[2] * x.shape[3] >= 30 * 40
+    900 vs 600 at 30 x 40 (conv5_x) with the 32 x 8 tile shape for narrow maps.  Round 5
+    (profiles/r05/conv_layers_*.txt): by pixel tiles of the launch, not by map size — 25 x 11x15
+    (50 tiles of 128 pixels) own 69 vs 83 us, 24 x 14x14 (48) 64 vs 82, 4 x 28x28 (28) 44-56 vs
+    42-62, 4 x 14x14 (8 tiles) 44 vs 27: the library below 32 tiles."""
+    b, _, h, w = x.shape
+    tiles = b * min(-(-h // 16) * -(-w // 8), -(-h // 4) * -(-w // 32))
+    return tiles >= 32
 
 
 class _GradLink:
@@ -720,7 +735,7 @@ def _conv3x3_backward(gz, x, w, need_x, link=None, gb=None, pooled=None):
     ga, idx = pooled if pooled is not None else (None, None)
     g_any = ga if gz is None else gz                      # (channels and dtype are what is looked at)
     kind = _own_conv_kind(g_any, w, True)
-    own_gx = kind == 'reg' or (kind == 'lds' and _lds_conv_pays(x, True))
+    own_gx = kind == 'reg' or (kind == 'lds' and _lds_conv_pays(x, True, kout=w.shape[1]))
     own_gw = _own_wrw_used(x, g_any, w)
     if gb is not None and not own_gw:
         raise RuntimeError("bias gradient requested from a weight-gradient pass that is not own")
@@ -799,7 +814,7 @@ class _ConvBiasAct(torch.autograd.Function):
         ctx.link_in, ctx.link_out = link_in, (link_out if relu else None)
         ctx.slot = _pack_slot()
         kind = _own_conv_kind(x, w)
-        if kind == 'reg' or (kind == 'lds' and _lds_conv_pays(x, False, True)):
+        if kind == 'reg' or (kind == 'lds' and _lds_conv_pays(x, False, True, kout=w.shape[0])):
             y = conv64(x, w, False, bias=bias, relu=relu)         # tail fused in the epilogue
         else:
             with _whole_batch_op():
@@ -863,7 +878,7 @@ class _ConvBiasPoolReLU(torch.autograd.Function):
             raise RuntimeError("fused conv1_1 + conv1_2 results do not belong to this layer")
         kind = _own_conv_kind(x, w)
         if USE_POOL_IDX and ((kind == 'reg' and w.shape[0] == w.shape[1])
-                             or (kind == 'lds' and _lds_conv_pays(x))):
+                             or (kind == 'lds' and _lds_conv_pays(x, kout=w.shape[0]))):
             # conv1_2 .. conv4_3: pooled map and the position of each maximum from the epilogue;
             # the full-size convolution output is never written
             a, idx = conv_pool_idx(x, w, bias)

@@ -286,10 +286,16 @@ def open_sets(flags, epoch):
         return (one(flags.local_ref_set), one(flags.local_query_set), one(flags.other_ref_set),
                 one(flags.other_query_set))
     m = flags.synthetic_dataset
-    local = dataset.SyntheticImageSet(m, flags.height, flags.width, seed=flags.seed,
-                                      distractor=flags.synthetic_distractor)
-    other = dataset.SyntheticImageSet(max(m // 2, 8), flags.height, flags.width,
-                                      seed=flags.seed + 1, distractor=flags.synthetic_distractor)
+    dis = flags.synthetic_distractor
+
+    def make(num, seed):
+        return dataset.SyntheticImageSet(num, flags.height, flags.width, seed=seed, distractor=dis)
+    local, other = make(m, flags.seed), make(max(m // 2, 8), flags.seed + 1)
+    if dis > 0.0:
+        # queries from ANOTHER traverse of the same track (own jitter, noise and distractors), like
+        # the reference's query sets: with the references themselves as queries every nearest
+        # descriptor is the query's own and the localisation check says 100 % whatever the weights
+        return local, make(m, flags.seed + 100), other, make(max(m // 2, 8), flags.seed + 101)
     return local, local, other, other
 
 

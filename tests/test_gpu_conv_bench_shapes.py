@@ -188,12 +188,38 @@ def reserve():
 # splits that are not multiples of 8 (the workgroup -> (split, block) map takes its other branch)
 CASES = [(l, 0) for l in LAYERS] + [(l, 8) for l in LAYERS if l[0] in ('1_2', '2_1', '3_3', '4_2', '5_1')]
 
+# Round 5: the LDS-weights layers at the launch shapes of the reference's OWN training resolution
+# (240 x 180, 25 images per batch: train/train.py:423-428, util/cv.py:7-9 -> conv4_x maps 22 x 30,
+# conv5_x 11 x 15) and of configs[0]'s image size at a full batch (224 x 224 -> 28 x 28 / 14 x 14):
+# the tile-count rule of nets._lds_conv_pays / _wrw_pays sends them to the own kernels (round 4's
+# map-size gate handed them to the library).  Maps narrower than a 40-pixel tile, fewer rows than
+# a block, more images than tile rounds.
+SMALL = [(('4_1', 256, 512, 22, 30, True, False), 25), (('4_2', 512, 512, 22, 30, True, False), 25),
+         (('4_3', 512, 512, 22, 30, False, True), 25), (('5_1', 512, 512, 11, 15, True, False), 25),
+         (('5_3', 512, 512, 11, 15, False, False), 25), (('4_2', 512, 512, 28, 28, True, False), 24),
+         (('4_3', 512, 512, 28, 28, False, True), 24), (('5_2', 512, 512, 14, 14, True, False), 24)]
+
+
+@pytest.mark.parametrize('layer,batch', SMALL, ids=['%s-%dx%dx%d' % (l[0], b, l[3], l[4]) for l, b in SMALL])
+def test_layer_at_small_map_launch_shapes(dev, sink, takes, reserve, layer, batch):
+    from soft_contrastive_learning_amd.model import nets
+    x_like = torch.empty(batch, layer[1], layer[3], layer[4], device='meta')
+    assert nets._lds_conv_pays(x_like, False, kout=layer[2]) and nets._lds_conv_pays(x_like, True, kout=layer[1])
+    assert nets._wrw_pays(x_like)
+    _layer_case(dev, sink, takes, reserve, layer, 0, batch)
+
 
 @pytest.mark.parametrize('layer,free_cus', CASES, ids=['%s%s' % (l[0], '-reserve%d' % r if r else '') for l, r in CASES])
 def test_layer_at_bench_shape(dev, sink, takes, reserve, layer, free_cus):
+    _layer_case(dev, sink, takes, reserve, layer, free_cus, B)
+
+
+def _layer_case(dev, sink, takes, reserve, layer, free_cus, B):
     from soft_contrastive_learning_amd.model import nets
     reserve(free_cus)
     name, cin, cout, h, w, relu, pool = layer
+    if B != 24 or h * w < 1200:
+        name = '%s@%dx%dx%d' % (name, B, h, w)
     assert nets.USE_PREPACK and nets.USE_SIDE_WRW and nets.USE_POOL_IDX and nets.USE_MASKED_BWD
     assert nets.USE_POOLED_BWD
     g = torch.Generator().manual_seed(1000 + 17 * cin + cout + h)
