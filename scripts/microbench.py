@@ -100,6 +100,8 @@ def main():
     ap.add_argument('--netvlad-variants', default='',
                     help='comma list of scl_debug_set_variant values to time besides production')
     ap.add_argument('--loss-batches', default='24,48,96,192')
+    ap.add_argument('--loss-variants', default='',
+                    help='comma list of scl_debug_set_variant values for the loss sweep (35 = multi-launch forward)')
     ap.add_argument('--loss-splits', default='',
                     help='comma list of forced Gram K-split counts for B <= 256 (tuning)')
     ap.add_argument('--topn-splits', default='',
@@ -122,6 +124,12 @@ def main():
     if 'loss' in what:
         lb = [int(v) for v in args.loss_batches.split(',')]
         res['wms_loss_sweep'] = sum((run_loss(dev, b, args.iters) for b in lb), [])
+        for var in [int(v) for v in args.loss_variants.split(',') if v]:
+            _lib.load().scl_debug_set_variant(var)
+            try:
+                res['wms_loss_variant_%d' % var] = sum((run_loss(dev, b, args.iters) for b in lb), [])
+            finally:
+                _lib.load().scl_debug_set_variant(0)
         for sp in [int(v) for v in args.loss_splits.split(',') if v]:
             _lib.load().scl_debug_set_variant(100000 * sp)
             try:

@@ -671,6 +671,9 @@ struct FinalArgs {
 template <int NT>
 __device__ void final32_body(float* lds, const float* slabs, int S, int T, int P, int B,
                              const FinalArgs& fa);
+template <int NT>
+__device__ void final64_body(float* lds, const float* slabs, int S, int T, int P, int B,
+                             const FinalArgs& fa);
 
 // FUSE (gram16_fused_kernel, 1024 threads): the first four waves run the Gram exactly as the
 // 256-thread kernel does, the other twelve only keep its barriers company until the finish, which
@@ -694,7 +697,10 @@ __device__ __forceinline__ void gram16_body(const float* __restrict__ emb, int64
   const int total_q = Bp << qshift;
 
   // (FUSE: waves 4..15 only match the barriers of the Gram part: one behind the staging, two more
-  // around the cross-wave sums when the k ranges are split)
+  // around the cross-wave sums when the k ranges are split.  The barriers of the two branches sit
+  // at DIFFERENT program points: valid because s_barrier on this hardware counts arrivals of the
+  // workgroup's waves — it does not require them to arrive at the same instruction — and both
+  // branches execute the same NUMBER of barriers, 1 or 3, chosen by the uniform KS.)
   const bool worker = !FUSE || wid < 4;                       // (wid is a scalar: a scalar branch)
   if (!worker) {
     __syncthreads();
@@ -833,9 +839,9 @@ __device__ __forceinline__ void gram16_body(const float* __restrict__ emb, int64
     // ---- the workgroup whose slab arrives last finishes the loss (round 4: the forward at B <= 32
     // was this kernel + a one-workgroup finish kernel, each at the floor of a dependent launch).
     // Write-through slab stores -> every wave drains its stores -> barrier -> lane 0 draws a ticket
-    // (agent-scope add).  The last ticket holder puts the counter back to zero (nobody touches it
-    // afterwards: the caller's word is zero again when the call returns) and runs the finish on
-    // all slabs with L1-bypassing loads — the same fixed-order sums as gram_final32_kernel: same
+    // (agent-scope add).  The last ticket holder runs the finish on all slabs with L1-bypassing loads
+    // and puts the counter back to zero behind it (the caller's word is zero again when the call
+    // returns) — the same fixed-order sums as gram_final32_kernel: same
     // bits.  (A first version with plain stores, a release fence per workgroup and an acquire in
     // the last one took 20 us against 14 for the two launches: the fences cost more than a launch.)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -843,15 +849,28 @@ __device__ __forceinline__ void gram16_body(const float* __restrict__ emb, int64
     int* flag = reinterpret_cast<int*>(g16_lds);
     if (threadIdx.x == 0) {
       const unsigned old = __hip_atomic_fetch_add(fa.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int last = old == gridDim.x - 1;
-      if (last) __hip_atomic_store(fa.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      *flag = last;
+      *flag = old == gridDim.x - 1;
     }
     __syncthreads();
     const int last = *flag;
     __syncthreads();
     if (!last) return;
-    final32_body<1024>(g16_lds, slabs, gridDim.x, T, P, B, fa);
+    if (B <= 32)
+      final32_body<1024>(g16_lds, slabs, gridDim.x, T, P, B, fa);
+    else
+      final64_body<1024>(g16_lds, slabs, gridDim.x, T, P, B, fa);
+    // The word goes back to zero at the END of the finish, and is checked first: under the contract
+    // (zero on entry) every workgroup has drawn its ticket by now and nobody resets, so it reads
+    // exactly gridDim.x.  Anything else means the caller's word was not zero on entry and this
+    // workgroup took itself for the last one too early: the loss becomes NaN —
+    // loud, not a plausible number from half the slabs — and the reset heals the block for the
+    // next call (round 4 reset at the ticket, which left a wrong word wrong for ever).
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned seen = __hip_atomic_load(fa.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (seen != gridDim.x) *fa.loss_out = __builtin_nanf("");
+      __hip_atomic_store(fa.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -1315,6 +1334,119 @@ __device__ void final32_body(float* lds, const float* slabs, int S, int T, int P
   }
 }
 
+// Round 5: the same for 32 < B <= 64 — what gram_reduce_kernel + gram_rows_wave_kernel<1> +
+// gram_coef_kernel do in three launches behind gram16_kernel, by the 1024 threads of the last gram16
+// workgroup to arrive, with the SAME sums in the SAME order (same bits):
+//   1. per tile pair, four waves add the slabs w, w + 4, .. in batches of 16 and combine as
+//      (p0 + p1) + (p2 + p3) — sixteen waves take four pairs at a time;
+//   2. a wave per row: normalised entries, masks, mining, row loss, d loss / d S (wave_row_eval<1>);
+//   3. loss mean and M = coef, a wave per row (gram_coef_kernel's block_reduce over 256 threads of
+//      which only the first 64 hold a term: the wave sum, then three additions of zero).
+// LDS (>= 67 KB of the caller's dynamic block): G | GN | GC [64][65] | rn[64] | rowloss[64] |
+// part[16][64] x 16 B.
+constexpr int kFinal64Lds = (3 * 64 * 65 + 128) * 4 + 16 * 64 * 16;
+template <int NT>
+__device__ void final64_body(float* lds, const float* slabs, int S, int T, int P, int B,
+                             const FinalArgs& fa) {
+  static_assert(NT == 1024, "sixteen waves");
+  constexpr int LD = 65;
+  float* G = lds;
+  float* GN = G + 64 * LD;
+  float* GC = GN + 64 * LD;
+  float* rn = GC + 64 * LD;
+  float* rowloss = rn + 64;
+  f32x4* part = reinterpret_cast<f32x4*>(rowloss + 64);
+  const LossParams& lp = fa.lp;
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  {
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(slabs), 0, S * P * 1024, 0x00020000);
+    const int w = wid & 3, pg = wid >> 2;
+    constexpr int U = 16;
+    for (int p0 = 0; p0 < P; p0 += 4) {
+      const int pair = p0 + pg;
+      f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+      if (pair < P) {
+        for (int s0 = w; s0 < S; s0 += 4 * U) {
+          f32x4 v[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {                        // (branch-free: clamped, masked below)
+            const int sidx = s0 + 4 * u < S ? s0 + 4 * u : S - 1;
+            v[u] = ld_sc1_x4(rsrc, (unsigned)(((sidx * P + pair) * 64 + lane) * 16));
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) acc4 += s0 + 4 * u < S ? v[u] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      part[wid * 64 + lane] = acc4;
+      __syncthreads();
+      if (w == 0 && pair < P) {
+        const f32x4 v = (part[(4 * pg) * 64 + lane] + part[(4 * pg + 1) * 64 + lane]) +
+                        (part[(4 * pg + 2) * 64 + lane] + part[(4 * pg + 3) * 64 + lane]);
+        int ti, tj;
+        decode_pair16(pair, T, ti, tj);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = 16 * ti + 4 * (lane >> 4) + j, c = 16 * tj + (lane & 15);
+          G[r * LD + c] = v[j];
+          G[c * LD + r] = v[j];
+        }
+      }
+      __syncthreads();
+    }
+  }
+  const float invB = 1.0f / (float)B;
+  for (int i = wid; i < B; i += 16) {                          // (wave-uniform)
+    const float rni = 1.0f / sqrtf(fmaxf(G[i * LD + i], 1e-12f));
+    const int j = lane;
+    float gn[1] = {0.f}, d[1] = {0.f}, g[1];
+    int same[1] = {0};
+    if (j < B) {
+      const float rnj = 1.0f / sqrtf(fmaxf(G[j * LD + j], 1e-12f));
+      gn[0] = G[i * LD + j] * rni * rnj;
+      if (lp.mask_kind == SCL_MASK_LABELS)
+        same[0] = fa.labels[j] == fa.labels[i];
+      else
+        d[0] = lp.dist_rank3 ? fa.distances[(int64_t)j * B + i] : fa.distances[(int64_t)i * B + j];
+    }
+    const float rl = wave_row_eval<1>(i, B, lane, gn, d, same, lp, invB, g);
+    if (j < B) {
+      GN[i * LD + j] = gn[0];
+      GC[i * LD + j] = g[0];
+    }
+    if (lane == 0) {
+      rowloss[i] = rl;
+      rn[i] = rni;
+    }
+  }
+  __syncthreads();
+  if (wid == 0) {
+    float a = 0.f;
+    if (lane < B) a += rowloss[lane];
+    a = wave_sum(a);
+    a = ((a + 0.f) + 0.f) + 0.f;                               // gram_coef_kernel's empty waves
+    if (lane == 0) *fa.loss_out = a / (float)B;
+  }
+  if (!fa.coef) return;
+  for (int i = wid; i < B; i += 16) {
+    const int j = lane;
+    float gs = 0.f, c = 0.f;
+    if (j < B) {
+      gs = GC[i * LD + j] + GC[j * LD + i];
+      c += gs * GN[i * LD + j];
+    }
+    c = wave_sum(c);
+    c = ((c + 0.f) + 0.f) + 0.f;
+    const float rni = rn[i];
+    const bool clamped = rni >= 1.0e6f;                        // see gram_coef_kernel
+    if (j < B) {
+      float m = rni * rn[j] * gs;
+      if (j == i && !clamped) m -= rni * rni * c;
+      fa.coef[(int64_t)i * B + j] = m;
+    }
+  }
+}
+
 // grid P; block 256: full raw Gram (both triangles) = fixed-order sum of the S slabs of one
 // tile pair.  Wave w adds slabs s = w, w + 4, ...; the four partial sums meet in LDS.
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restrict__ slabs, int S,
@@ -1514,6 +1646,7 @@ void launch_gram16_fused(const Gram16Plan& p, const float* emb, int64_t ld, int 
   const size_t red = p.KS > 1 ? (size_t)p.KS * p.P * 64 * sizeof(f32x4) : 0;
   if (red > lds) lds = red;
   if (lds < 24 * 1024) lds = 24 * 1024;                       // final32_body's tables
+  if (B > 32 && lds < (size_t)kFinal64Lds) lds = kFinal64Lds; // final64_body's
   SCL_LAUNCH("gram16_fused_kernel", (gram16_fused_kernel<PWMAX, FULL>), dim3(p.S), dim3(1024), lds, st,
              emb, ld, B, E, p.T, p.P, p.kchunk, p.KS, vec_ok, slabs, fa);
 }
@@ -1577,7 +1710,8 @@ extern "C" int scl_gram_loss_fwd_s(const float* emb, int64_t ld_emb, int B, int 
         launch_gram16x6<20, true>(p.T, p.P, emb, ld_emb, B, E, w.slabs, st);
       else
         launch_gram16x6<34, false>(p.T, p.P, emb, ld_emb, B, E, w.slabs, st);
-    } else if (B <= 32 && sync_words && full && (pw == 1 || pw == 3) && scl_variant() != 32) {
+    } else if (B <= 64 && sync_words && full && (pw == 1 || pw == 3 || pw == 5) && scl_variant() != 32 &&
+               scl_variant() != 35) {     // (35: the multi-launch forward alone, the backward untouched)
       // (32: the two-launch forward, for A/B)  one launch: the Gram and, in its last workgroup, the finish
       FinalArgs fa;
       fa.counter = (unsigned*)sync_words;
@@ -1588,8 +1722,10 @@ extern "C" int scl_gram_loss_fwd_s(const float* emb, int64_t ld_emb, int B, int 
       fa.loss_out = loss_out;
       if (pw == 1)
         launch_gram16_fused<1, true>(p, emb, ld_emb, B, E, vec_ok, w.slabs, fa, st);
-      else
+      else if (pw == 3)
         launch_gram16_fused<3, true>(p, emb, ld_emb, B, E, vec_ok, w.slabs, fa, st);
+      else
+        launch_gram16_fused<5, true>(p, emb, ld_emb, B, E, vec_ok, w.slabs, fa, st);
       return scl_launch_status();
     } else if (pw == 1 && full)
       launch_gram16<1, true>(p, emb, ld_emb, B, E, vec_ok, w.slabs, st);

@@ -344,13 +344,37 @@ def test_pairwise_distance_loss_and_grad(dev, t, p, e, huber):
     assert _rel(pt.grad.cpu().numpy(), p64.grad.numpy()) < 2e-4
 
 
+def test_fused_finish_with_a_dirty_sync_word_is_loud_and_heals(dev):
+    """the one-launch forward relies on the caller's sync word being zero on entry.
+    A word left non-zero (a contract violation) makes a middle workgroup take itself for the last:
+    the call cannot be repaired, but it must not return a plausible number from half the slabs —
+    the loss comes out NaN — and the word is zero again afterwards, so the NEXT call is sound."""
+    from soft_contrastive_learning_amd import _lib as L
+    from soft_contrastive_learning_amd.model import losses
+    b, e = 24, 32768
+    emb = torch.tensor(U.embeddings(b, e), device=dev)
+    dm = torch.tensor(U.positions_distances(b)[None], device=dev)
+    good = float(losses.wms_loss(dm, emb, 0.8, 15.0))
+    word = L.sync_words(dev)
+    assert int(word.view(torch.int32)[0]) == 0                # left zero by the call above
+    word.view(torch.int32)[0] = 3                             # the violation
+    bad = float(losses.wms_loss(dm, emb, 0.8, 15.0))
+    torch.cuda.synchronize()
+    assert np.isnan(bad)
+    assert int(word.view(torch.int32)[0]) == 0                # healed
+    assert float(losses.wms_loss(dm, emb, 0.8, 15.0)) == good
+
+
 # ---- round 4: the B <= 32 forward in one launch ---------------------------------------------------
-@pytest.mark.parametrize("b,e", [(2, 64), (7, 200), (16, 4096), (24, 32768), (25, 32768), (32, 32768)])
+@pytest.mark.parametrize("b,e", [(2, 64), (7, 200), (16, 4096), (24, 32768), (25, 32768), (32, 32768),
+                                 (33, 32768), (40, 4096), (48, 32768), (49, 32768), (56, 200), (64, 32768)])
 @pytest.mark.parametrize("kind", ["wms_exp", "wms_tanh_plain", "ms"])
 def test_fused_finish_gives_the_bits_of_the_two_launch_forward(dev, b, e, kind):
     """scl_gram_loss_fwd_s with the stream's sync block: the Gram kernel's last workgroup runs the
     finish (same sums, same order).  scl_debug_set_variant(32) = the two-launch forward: loss and
-    d loss / d embeddings must be bit-identical, and the sync block must be zero afterwards."""
+    d loss / d embeddings must be bit-identical, and the sync block must be zero afterwards.
+    Round 5: 32 < B <= 64 as well (final64_body against gram_reduce + gram_rows_wave + gram_coef:
+    variant 35 = that four-launch forward with the backward left alone)."""
     from soft_contrastive_learning_amd import _lib as L
     from soft_contrastive_learning_amd.model import losses
     emb = torch.tensor(U.embeddings(b, e), device=dev)
@@ -370,7 +394,7 @@ def test_fused_finish_gives_the_bits_of_the_two_launch_forward(dev, b, e, kind):
             torch.cuda.synchronize()
         return loss.detach().cpu().numpy(), x.grad.cpu().numpy()
     l1, g1 = run(0)
-    l2, g2 = run(32)
+    l2, g2 = run(32 if b <= 32 else 35)
     assert l1.view(np.uint32) == l2.view(np.uint32)
     assert np.array_equal(g1.view(np.uint32), g2.view(np.uint32))
     assert int(L.sync_words(dev).sum()) == 0
