@@ -244,6 +244,55 @@ def netvlad_stage(kernels, b, n, x_bytes, steps):
     out['note'] = ('durations = HIP events around every launch minus the bracket measured on the empty '
                    'kernel in this process (bracket_us in kernel_timing; *_events = the raw event figures); '
                    'rocprofv3 trace of the same command: profiles/r05')
+    if x_bytes == 2:
+        out['floor'] = netvlad_floor(b, n, out)
+    return out
+
+
+# What one CU streams from beyond its L2 with every CU streaming, measured on this chip by
+# scripts/dma_line_probe.hip (profiles/r02: 12.7-13.7 B per cycle and CU from the Infinity Cache,
+# 10.7 from HBM, at the 2.1 GHz the chip holds under load) — the rate the fused NetVLAD kernels'
+# workgroups are bound by: bytes PER WORKGROUP, not bytes per chip, because 24 images on 256 CUs
+# mean ten partial VLADs per image.
+CU_STREAM_B_PER_CLK = 13.0
+CU_CLOCK_GHZ = 2.1
+
+
+def netvlad_floor(b, n, stage):
+    """The floor of the NetVLAD head UNDER ITS DECOMPOSITION (one workgroup per CU and (image, slice
+    of locations); W^T / dU^T as register fragments; one [512][64] float32 partial per workgroup):
+    bytes each workgroup must move / the measured per-CU stream rate, per launch, never below the
+    empty-kernel time.  SURVEY 8(d)'s HBM bound (`bound_us`) prices the bytes as if they were spread
+    over the whole chip once — unreachable at 24 images, where a workgroup re-reads the 128 KB
+    operand image and writes a 128 KB partial for 123 KB of x.  Reported next to the measured time:
+    how much of it the decomposition explains, and how much is left to the kernels."""
+    steps = -(-n // 32)
+    per = -(-steps * b // 256)
+    slices = -(-steps // per)
+    loc = per * 32
+    kb = 1024.0
+    x = loc * D * 2 / kb
+    frag = 2 * D * K * 2 / kb                   # two bf16 planes of a [512][64] operand: 128 KB
+    slab = D * K * 4 / kb                       # a float32 partial: 128 KB
+    rows = loc * K * 4 / kb                     # one saved [loc][64] float32 array
+    rate = CU_STREAM_B_PER_CLK * CU_CLOCK_GHZ * 1e3          # bytes per microsecond and CU
+    null_us = NULL_KERNEL_DEVICE_US or 3.4
+    launches = {
+        'forward': {'vlad_fwd8_kernel': x + frag + 2 * rows + slab,
+                    'vlad_finish_kernel': slices * slab / 8 + 2 * slab / 8},
+        'backward': {'vlad_bwd_prologue_kernel': 3 * slab / 8 + 2 * frag / 8,
+                     'vlad_bwd8_kernel': x + frag + 2 * rows + rows + slab,
+                     'vlad_dx_kernel': 2 * x + 2 * rows + 2 * frag + b * slices * slab / (b * slices)},
+    }
+    out = {'per_cu_rate_bytes_per_us': round(rate, 1), 'workgroups': b * slices, 'slices_per_image': slices,
+           'how': 'sum over the launches of max(empty-kernel time, KB per workgroup / per-CU stream rate); '
+                  'KB per workgroup: x slice + operand fragments + saved rows + the float32 partial'}
+    for ps, ks in launches.items():
+        us = sum(max(null_us, v * kb / rate) for v in ks.values())
+        ent = {'kb_per_workgroup': {k: round(v, 1) for k, v in ks.items()}, 'floor_us': round(us, 2)}
+        if ps in stage and stage[ps].get('us_per_step'):
+            ent['floor_over_measured'] = round(us / stage[ps]['us_per_step'], 3)
+        out[ps] = ent
     return out
 
 

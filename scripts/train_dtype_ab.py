@@ -77,7 +77,7 @@ def compare(a, b, w=25):
     return out
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--steps', type=int, default=300)
     ap.add_argument('--steps_per_epoch', type=int, default=150)
@@ -95,7 +95,7 @@ def main():
     ap.add_argument('--eval_queries', type=int, default=40)
     ap.add_argument('--json', default='')
     ap.add_argument('--dtypes', default='bf16,f32')
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     with tempfile.TemporaryDirectory() as tmp:
         runs = {d: run(d, args, tmp) for d in args.dtypes.split(',')}
     out = dict(config=vars(args), runs={d: {k: v for k, v in r.items() if k != 'losses'} for d, r in runs.items()})

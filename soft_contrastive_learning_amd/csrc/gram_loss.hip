@@ -613,13 +613,15 @@ inline Gram16Plan make_plan16(int B, int E) {
   p.T = (B + 15) / 16;
   p.P = p.T * (p.T + 1) / 2;
   p.KS = p.P <= 3 ? 4 : (p.P <= 10 ? 2 : 1);
-  // LDS holds [16 T][kchunk + 4] floats (<= 128 KB) and a thread stages <= 48 float4
-  int kc_max = (128 * 1024 / 4) / (16 * p.T) - 4;
+  // LDS holds [16 T][kchunk + 4] floats (<= 132 KB, the kernels' dynamic limit: [64][516] floats
+  // is the largest) and a thread stages <= 48 float4
+  int kc_max = (132 * 1024 / 4) / (16 * p.T) - 4;
   kc_max = kc_max / 64 * 64;
   if (kc_max > 512) kc_max = 512;
-  // small batches: fewer, larger splits (the finishing workgroup reads every slab);
-  // large ones: one workgroup per CU
-  int s = B <= 32 ? 64 : 256;
+  // small batches: fewer, larger splits (the finishing workgroup reads every slab: at 256 splits
+  // the one-launch forward of B = 48 spent 29 us reading 1.5 MB of them — round 5, 64 splits up to
+  // B = 64); large ones: one workgroup per CU
+  int s = B <= 64 ? 64 : 256;
   int ov = scl_variant() / 100000;          // tuning override: splits = ov
   if (ov > 0) s = ov;
   int kc = 64;                                   // power of two: staging indices by shifts
