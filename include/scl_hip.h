@@ -555,8 +555,8 @@ int scl_build_is_diag(void);
  *   32 / 33 / 34  Gram loss: the two-launch forward at B <= 32 and the older guarded backward /
  *                 the 32-column backward of the own rows / the float32-MFMA backward where the
  *                 bf16-plane one would run (CORRECT results: A/B partners)
- *   35            Gram loss: the multi-launch forward at B <= 64 with the backward untouched
- *                 (CORRECT results: the bit-equality partner of the one-launch forward)
+ *   36            Gram loss: the one-launch forward for 32 < B <= 64 as well (CORRECT, bit-identical
+ *                 to the four launches of the product path; measured slower)
  *   2200          weight-gradient kernel: round 4's staging without the buffer-resource path
  *                 (CORRECT results: A/B partner)
  *   100000 * s    Gram loss, B <= 256: force s K-splits

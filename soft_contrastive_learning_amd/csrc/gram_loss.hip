@@ -618,10 +618,10 @@ inline Gram16Plan make_plan16(int B, int E) {
   int kc_max = (132 * 1024 / 4) / (16 * p.T) - 4;
   kc_max = kc_max / 64 * 64;
   if (kc_max > 512) kc_max = 512;
-  // small batches: fewer, larger splits (the finishing workgroup reads every slab: at 256 splits
-  // the one-launch forward of B = 48 spent 29 us reading 1.5 MB of them — round 5, 64 splits up to
-  // B = 64); large ones: one workgroup per CU
-  int s = B <= 64 ? 64 : 256;
+  // small batches: fewer, larger splits (the finishing workgroup reads every slab); large ones:
+  // one workgroup per CU.  (Round 5 measured 64 splits up to B = 64 for a one-launch forward there:
+  // the Gram on 64 CUs takes 11.7 / 18.3 us at B = 48 / 64 against 7.8 / 9.7 on 256 — not kept.)
+  int s = B <= 32 ? 64 : 256;
   int ov = scl_variant() / 100000;          // tuning override: splits = ov
   if (ov > 0) s = ov;
   int kc = 64;                                   // power of two: staging indices by shifts
@@ -1712,8 +1712,12 @@ extern "C" int scl_gram_loss_fwd_s(const float* emb, int64_t ld_emb, int B, int 
         launch_gram16x6<20, true>(p.T, p.P, emb, ld_emb, B, E, w.slabs, st);
       else
         launch_gram16x6<34, false>(p.T, p.P, emb, ld_emb, B, E, w.slabs, st);
-    } else if (B <= 64 && sync_words && full && (pw == 1 || pw == 3 || pw == 5) && scl_variant() != 32 &&
-               scl_variant() != 35) {     // (35: the multi-launch forward alone, the backward untouched)
+    } else if ((B <= 32 || (B <= 64 && scl_variant() == 36)) && sync_words && full &&
+               (pw == 1 || pw == 3 || pw == 5) && scl_variant() != 32) {
+      // (32: the two-launch forward, for A/B.  36: the one-launch forward for 32 < B <= 64 as well —
+      // final64_body; bit-identical to the four launches and SLOWER, so not the product path: in
+      // device time 24.8 us against 17.0 at B = 48 — one workgroup reads every slab and walks 48 rows
+      // where three small kernels use the chip; profiles/r05/loss_one_launch_above_32.txt)
       // (32: the two-launch forward, for A/B)  one launch: the Gram and, in its last workgroup, the finish
       FinalArgs fa;
       fa.counter = (unsigned*)sync_words;

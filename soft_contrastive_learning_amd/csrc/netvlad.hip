@@ -1839,7 +1839,6 @@ struct VladFinishArgs {
   float* out;             // [B][32768]
   gran_t* gran;           // [B][8], zero on entry
   int spin_limit;
-  int by_image;
 };
 
 constexpr int VFIN_NB = 10;                // slices in flight per thread (x 4 units): the kernel is
@@ -1849,9 +1848,11 @@ __global__ __launch_bounds__(256) void vlad_finish_kernel(VladFinishArgs p) {
   float* red = fin_lds;
   float* vals = fin_lds + 32;
   int* okf = reinterpret_cast<int*>(fin_lds + 40);
-  // (p.by_image: grid (B, 8) instead of (8, B) — the eight workgroups of an image then run on the
-  // XCD whose workgroups wrote its slabs when B % 8 == 0; A/B, scl_debug_set_variant(923))
-  const int c = p.by_image ? blockIdx.y : blockIdx.x, b = p.by_image ? blockIdx.x : blockIdx.y;
+  // (Round 5 measured the transposed grid (B, 8) — the eight workgroups of an image on the XCD whose
+  // workgroups wrote its slabs when B % 8 == 0: 12.7 -> 11.7 us at 24 images, and 14 MILLISECONDS at
+  // 96, where an image's siblings are dispatched 96 workgroups apart and every exchange runs into
+  // its spin limit.  Siblings must be neighbours in dispatch order: cluster group on x.)
+  const int c = blockIdx.x, b = blockIdx.y;
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int ip = t & 7, g = (t >> 3) & 3, cs = t >> 5;
 
@@ -3022,14 +3023,12 @@ inline int vlad_cus() {
 }
 inline VladPlan vlad_plan(int B, int N) {
   const int nsteps = (N + VF_STEP - 1) / VF_STEP;
-  const int cus = vlad_cus();
   VladPlan p;
-  // As many slices per image as keep B * S workgroups within ONE round of the chip (round 4 cut by
-  // total steps / CUs, which at 96 images gave 3 slices = 288 workgroups on 256 CUs: a second round
-  // for the last 32 — 23 step times and three partial VLADs per image where 2 slices take 19 and two).
-  int smax = B <= cus ? cus / B : 1;
-  if (smax > nsteps) smax = nsteps;
-  p.steps_per_slice = (nsteps + smax - 1) / smax;
+  // (Round 5 tried "as many slices as keep B * S within ONE round of the chip" — 96 images: 2 slices
+  // of 19 steps instead of 3 of 15 / 15 / 8, two partial VLADs per image instead of three.  Measured
+  // equal to 2 % slower: the 32 workgroups of the short third slices start when the first short ones
+  // end and finish with the long ones, so the cut by total steps / CUs was already balanced.)
+  p.steps_per_slice = (int)(((int64_t)nsteps * B + vlad_cus() - 1) / vlad_cus());
   if (p.steps_per_slice < 1) p.steps_per_slice = 1;
   p.S = (nsteps + p.steps_per_slice - 1) / p.steps_per_slice;
   return p;
@@ -3217,9 +3216,7 @@ extern "C" int scl_netvlad_fwd_p(const void* x, int x_dtype, const float* assign
     na.out = out;
     na.gran = w.gran;
     na.spin_limit = spin_limit();
-    na.by_image = scl_variant() == 923 ? 1 : 0;
-    SCL_LAUNCH("vlad_finish_kernel", vlad_finish_kernel, na.by_image ? dim3(B, 8) : dim3(8, B), dim3(256), 0, st,
-               na);
+    SCL_LAUNCH("vlad_finish_kernel", vlad_finish_kernel, dim3(8, B), dim3(256), 0, st, na);
     return scl_launch_status();
   }
   // float32 feature maps (and bf16 ones under scl_debug_set_variant(1 .. 8)): float32-MFMA kernels
