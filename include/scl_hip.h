@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define SCL_ABI_VERSION 10
+#define SCL_ABI_VERSION 11
 
 /* error codes (negative = rejected before any launch) */
 #define SCL_OK 0
@@ -468,6 +468,26 @@ int scl_conv_first_wrw(const void* x0, const void* gz, int B, int H, int W, void
                        int64_t w_stride_w, int w_f32 /* gw and w are float32 instead of bf16 */,
                        float* gb, const void* w, float* davg, void* workspace,
                        size_t workspace_bytes, void* stream);
+
+/* conv1_2's backward-data pass and the first layer's parameter gradients in ONE launch (round 5,
+ * ABI 11; train/train.py:877-878's gradient of model/nets.py:39-42): the gradient at conv1_1's
+ * pre-activation, gz1 = conv_transpose(unpool(g_pooled, pool_idx), w2) * [mask > 0] — 944 MB at
+ * 24 x 640x480 — has ONE consumer, scl_conv_first_wrw (conv1_1's input is the image: no
+ * backward-data pass below it), so it is never written: every [8 x 32]-pixel tile of it is
+ * multiplied with the im2col of x0 while it sits in LDS, and gw1 / gb1 / davg come out exactly as
+ * scl_conv_first_wrw(x0, gz1, ...) defines them (other summation order: float32 rounding differs).
+ * g_pooled [B,H/2,W/2,64] bf16 + pool_idx (uint8, same shape: scl_conv3x3_pool_idx's), w2 logical
+ * [64][64][3][3] at its element strides (flags: SCL_W_F32, or SCL_W_PACKED for the
+ * backward-direction image of scl_conv_pack_batch), mask [B,H,W,64] bf16 = conv1_1's output, x0
+ * [B,H,W,3] bf16; gw1 / gb1 / w1 / davg as in scl_conv_first_wrw.  H and W even, B <= 8192.
+ * workspace >= scl_conv3x3_workspace_bytes(), fw_workspace >= scl_conv_first_wrw_workspace_bytes().
+ * Deterministic for a fixed scl_set_reserve_cus value (one slab per workgroup, fixed-order sums). */
+int scl_conv3x3_masked_pooled_first_wrw(
+    const void* g_pooled, const void* pool_idx, const void* w2, int64_t w2_stride_k, int64_t w2_stride_c,
+    int64_t w2_stride_h, int64_t w2_stride_w, int flags, int B, int H, int W, const void* mask,
+    const void* x0, void* gw1, int64_t w1_stride_k, int64_t w1_stride_c, int64_t w1_stride_h,
+    int64_t w1_stride_w, int w1_f32, float* gb1, const void* w1, float* davg, void* workspace,
+    size_t workspace_bytes, void* fw_workspace, size_t fw_workspace_bytes, void* stream);
 
 /* Weight gradient of the same layer: gw[k][c][kh][kw] = sum_{b,y,x} gz[b,y,x,k] *
  * x[b, y+kh-1, x+kw-1, c]; x, gz [B,H,W,64] bf16, gw bf16 written at the given element

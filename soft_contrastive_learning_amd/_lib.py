@@ -21,7 +21,7 @@ LIB_PATH = os.path.join(_HERE, "libscl_hip.so")
 DIAG_LIB_PATH = os.path.join(_HERE, "libscl_hip_diag.so")
 
 # constants of include/scl_hip.h
-ABI_VERSION = 10
+ABI_VERSION = 11
 DT_F32, DT_BF16 = 0, 1
 MASK_WMS_EXP, MASK_WMS_LIN, MASK_WMS_TANH, MASK_LABELS = 0, 1, 2, 3
 SUM_MS, SUM_PLAIN = 0, 1
@@ -120,6 +120,8 @@ SIGNATURES = {
     "scl_conv_first": (_i, [_p, _p, _p, _l, _l, _l, _l, _i, _p, _i, _i, _i, _p, _p, _p]),
     "scl_conv_first_pool_idx": (_i, [_p, _p, _p, _l, _l, _l, _l, _i, _p, _p, _l, _l, _l, _l, _i, _p,
                                      _i, _i, _i, _p, _p, _p, _p, _p, _z, _p]),
+    "scl_conv3x3_masked_pooled_first_wrw": (_i, [_p, _p, _p, _l, _l, _l, _l, _i, _i, _i, _i, _p, _p, _p, _l,
+                                                 _l, _l, _l, _i, _p, _p, _p, _p, _z, _p, _z, _p]),
     "scl_debug_set_variant": (_i, [_i]),
     "scl_build_is_diag": (_i, []),
     "scl_set_reserve_cus": (_i, [_i]),

@@ -36,6 +36,22 @@ __device__ __forceinline__ f32x16 mfma32b(u32x4 a, u32x4 b, f32x16 c) {
                                                  __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+typedef float f32x4_ __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4_ mfma16b(u32x4 a, u32x4 b, f32x4_ c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                 __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+typedef short s16x4_ __attribute__((ext_vector_type(4)));
+// two transposed reads (ds_read_b64_tr_b16), `step4` elements apart: 8 consecutive rows of one column
+__device__ __forceinline__ u32x4 tr_pair_early(const unsigned short* a0, int step4) {
+  const s16x4_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (s16x4_ __attribute__((address_space(3)))*)(a0));
+  const s16x4_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (s16x4_ __attribute__((address_space(3)))*)(a0 + step4));
+  const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+  return u32x4{l2.x, l2.y, h2.x, h2.y};
+}
+
 // LDS-DMA staging (global_load_lds_dwordx4): one wave-instruction copies 64 x 16 bytes from
 // per-lane global addresses to 1 KB of CONSECUTIVE LDS — no staging registers, no ds_write
 // pass, many more bytes in flight per CU.  Out-of-image halo pixels read a zero block.
@@ -161,7 +177,27 @@ __global__ __launch_bounds__(256) void conv3x3_pack_kernel(const void* __restric
 // built in LDS by the threads (16 bytes of the pooled map + 8 index bytes per (pooled pixel,
 // 8 channels), loaded when the tile starts, un-pooled and written in slices between the k-steps
 // of the second half of the K loop) — the full-size map is never in memory.  H and W even.
-template <int CIN, int KOUT, int EPI, int PL = 0>
+//
+// FW = 1 (round 5; with EPI 3, PL 1 and (64, 64) only: conv1_2's backward-data pass): the masked
+// result — the gradient at conv1_1's pre-activation, 944 MB at 24 x 640x480 — is NOT written.  Its
+// only consumer is the first layer's weight / bias / mean gradient (conv1_1 has no backward-data
+// pass: its input is the image), a GEMM over pixels with 27 + 5 columns per pixel
+// (conv_first_wrw_kernel, below): that product runs HERE, on the tile while it is in LDS —
+//   * after the K loop and one more barrier the tile's window buffer is dead; the epilogue puts the
+//     masked bf16 tile there as two 32-channel planes [256 px][32 ch] (the layout of the
+//     weight-gradient kernels: transposed reads give 8 pixels of a channel per lane);
+//   * wave (cg = wid & 3, phf = wid >> 2) multiplies channels 16 cg .. + 15 of pixel half phf
+//     (tile rows 4 phf .. + 3) with the im2col columns of the x0 window ([10][34][3 + 1] bf16, its
+//     own small double-buffered LDS area): v_mfma_f32_16x16x32_bf16, four k-steps x two column
+//     halves; column 27 = 1 (bias gradient), 28 .. 31 = first / last row / column indicators (the
+//     border sums of the mean gradient's closed form) exactly as in conv_first_wrw_kernel;
+//   * the partial [16 ch][32 cols] of a wave lives in LDS between tiles (8 KB... 2 KB per wave:
+//     the kernel has no registers to spare), one slab [64][32] per workgroup at the end,
+//     conv_first_wrw_reduce_kernel sums the slabs as before; the four corner pixels of every image
+//     (the davg kernel's X term) go to a compact side buffer.
+// `pooled` carries x0 and `pidx` the float32 slab / corner workspace in this mode (EPI 3 uses
+// neither); saves the 944 MB store here and the 944 MB read + 217 us of conv_first_wrw_kernel.
+template <int CIN, int KOUT, int EPI, int PL = 0, int FW = 0>
 __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(const unsigned short* __restrict__ x,
                                                          const unsigned short* __restrict__ packed,
                                                          int B, int H, int W,
@@ -178,6 +214,13 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
   const int r = lane & 31, h = lane >> 5;
   const int nt = wid % Cfg::NT, part = wid / Cfg::NT;
   unsigned short* scr = lds + 2 * WIN_ + wid * SCR;
+  // FW: [8 waves][2 halves][64 lanes][4] float32 partials | two x0 windows [10][34][4] bf16
+  static_assert(!FW || (CIN == 64 && KOUT == 64 && EPI == 3 && PL == 1), "FW: conv1_2 backward-data only");
+  constexpr int FWPL = 32, FGPL = TH * TW * FWPL, FXW = WR * WC * 4;
+  float* dwl = reinterpret_cast<float*>(lds + 2 * WIN_ + Cfg::WAVES * SCR);
+  unsigned short* xwl = reinterpret_cast<unsigned short*>(dwl + Cfg::WAVES * 512);
+  const unsigned short* fx0 = reinterpret_cast<const unsigned short*>(pooled);
+  float* fslabs = reinterpret_cast<float*>(pidx);
   // epilogue fusions (lane r <-> output channel 32 nt + r):
   //   pooled == NULL: out = acc (+ bias) (ReLU if relu)            conv + bias + activation
   //   pooled != NULL: out = acc raw, pooled = relu(max2x2(acc) + bias)   conv + pool + ReLU
@@ -286,7 +329,44 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
   const short relu_floor = relu ? (short)0 : (short)-32768;   // packed ReLU: max with 0, or with the least int16
   // (experiment, 60004: static priority for the younger half of an eight-wave workgroup)
   if ((dbg & 4) && (threadIdx.x >> 6) >= 4) __builtin_amdgcn_s_setprio(1);
+  // FW: this thread's two elements of a tile's x0 window (340 pixels x 3 channels)
+  unsigned short xreg[FW ? 2 : 1];
+  // (thread index through an opaque copy per call: its quotients by 3 and 34 must not be hoisted
+  // out of the tile loop — the K loop has no register for them)
+  auto xwin_load = [&](int tile_) {
+    const int b_ = tile_ / per_img, t2_ = tile_ % per_img;
+    const int ty_ = (t2_ / tiles_x) * TH_, tx_ = (t2_ % tiles_x) * TW;
+    int tid2 = threadIdx.x;
+    asm volatile("" : "+v"(tid2));
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const int idx = v * Cfg::NTHR + tid2;
+      const int pix = idx / 3, c = idx - 3 * pix;
+      const int y = ty_ - 1 + pix / WC, xx = tx_ - 1 + pix % WC;
+      const bool ok = idx < 3 * WR * WC && y >= 0 && y < H && xx >= 0 && xx < W;
+      xreg[v] = ok ? fx0[(((int64_t)b_ * H + y) * W + xx) * 3 + c] : (unsigned short)0;
+    }
+  };
+  auto xwin_store = [&](int par) {
+    int tid2 = threadIdx.x;
+    asm volatile("" : "+v"(tid2));
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const int idx = v * Cfg::NTHR + tid2;
+      const int pix = idx / 3, c = idx - 3 * pix;
+      if (idx < 3 * WR * WC) xwl[par * FXW + pix * 4 + c] = xreg[v];
+    }
+  };
   int tile = blockIdx.x;
+  if (FW) {
+    *reinterpret_cast<f32x4_*>(dwl + wid * 512 + lane * 4) = f32x4_{0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4_*>(dwl + wid * 512 + 256 + lane * 4) = f32x4_{0.f, 0.f, 0.f, 0.f};
+    if (tile < ntiles) {
+      xwin_load(tile);
+      xwin_store(0);
+    }
+  }
+  int xpar = 0;
   if (tile < ntiles) {
     if (PL) {
 #pragma unroll
@@ -368,6 +448,13 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
     // this wave's share of the next window has landed (waited for here, before the epilogue's
     // own stores join the queue); the barrier below publishes it
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (FW) {
+      __syncthreads();             // every wave is done with the window: its buffer takes the tile
+      // the next tile's x0 window: requested here, where the K loop's registers are free (held
+      // across the K loop its two values cost eleven scratch accesses per tile), stored behind the
+      // products below
+      if (next < ntiles) xwin_load(next);
+    }
 
     // epilogue: tile row MT part + mt, accumulator register q <-> column acc_row(q, h),
     // lane r <-> output channel 32 nt + r
@@ -407,10 +494,73 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
         v0 = relu_mask(v0, y0v);
         v1 = relu_mask(v1, y1v);
       }
-      if (inside && !(dbg & 2)) {
+      if (FW) {
+        // (outside the image the mask was loaded as zero: v0 = v1 = 0 there already)
+        unsigned short* gzp = lds + buf * WIN_ + nt * FGPL + ((MT * part + mt) * TW + px) * FWPL + 8 * hf;
+        *reinterpret_cast<u32x4*>(gzp) = v0;
+        *reinterpret_cast<u32x4*>(gzp + 16) = v1;
+        // the four corner pixels of the image: what conv_first_davg_kernel reads of this map
+        const bool cy0 = oy == 0, cy1 = oy == H - 1, cx0 = ox == 0, cx1 = ox == W - 1;
+        if ((cy0 || cy1) && (cx0 || cx1)) {
+          unsigned short* cp = reinterpret_cast<unsigned short*>(fslabs + (size_t)1536 * 2048) +
+                               ((int64_t)b * 4 + (cy1 ? 2 : 0) + (cx1 ? 1 : 0)) * C64 + 32 * nt + 8 * hf;
+          *reinterpret_cast<u32x4*>(cp) = v0;
+          *reinterpret_cast<u32x4*>(cp + 16) = v1;
+        }
+      } else if (inside && !(dbg & 2)) {
         *reinterpret_cast<u32x4*>(out + o_off) = v0;
         *reinterpret_cast<u32x4*>(out + o_off + 16) = v1;
       }
+    }
+    if (FW) {
+      __syncthreads();             // the whole masked tile is in LDS
+      // (the lane's roles are re-derived per tile from opaque copies: hoisted out of the tile loop
+      // they stay live across the K loop, which has no register left — scratch reloads there)
+      int lane2 = lane, wid2 = wid;
+      asm volatile("" : "+v"(lane2), "+v"(wid2));
+      const int cg = wid2 & 3, phf = wid2 >> 2;
+      const int li = lane2 & 15, lg = lane2 >> 4, q4 = (lane2 >> 2) & 3, p4 = lane2 & 3;
+      const unsigned short* ga = lds + buf * WIN_ + (cg >> 1) * FGPL +
+                                 ((4 * phf) * TW + 8 * lg + q4) * FWPL + 16 * (cg & 1) + 4 * p4;
+      f32x4_ dacc[2];
+      dacc[0] = *reinterpret_cast<const f32x4_*>(dwl + wid2 * 512 + lane2 * 4);
+      dacc[1] = *reinterpret_cast<const f32x4_*>(dwl + wid2 * 512 + 256 + lane2 * 4);
+      const unsigned short* xw = xwl + xpar * FXW;
+      const int ty_ = oy0 - MT * part, tx_ = ox0;
+      // column n = 16 nh + li of the im2col matrix: tap (kh, kw), channel c; n >= 27: 1 | border flags
+      int woff[2];
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh) {
+        const int n = 16 * nh + li, nc = n < 27 ? n : 26;
+        const int tap = nc / 3, c = nc - 3 * tap;
+        woff[nh] = ((tap / 3) * WC + tap % 3 + 8 * lg) * 4 + c;
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int row = 4 * phf + ks;                                    // tile row of this k-step
+        const u32x4 a = tr_pair_early(ga + ks * TW * FWPL, 4 * FWPL);
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) {
+          const unsigned short* wp = xw + row * WC * 4 + woff[nh];
+          unsigned e[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) e[j] = wp[4 * j];
+          if (nh == 1) {
+            const int y = ty_ + row, xb = tx_ + 8 * lg;
+            const bool rowflag = li == 11 || (li == 12 && y == 0) || (li == 13 && y == H - 1);
+            const int colx = li == 14 ? 0 : (li == 15 ? W - 1 : -1);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (li >= 11) e[j] = (rowflag || xb + j == colx) ? 0x3f80u : 0u;
+          }
+          const u32x4 bfr = {e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
+          dacc[nh] = mfma16b(a, bfr, dacc[nh]);
+        }
+      }
+      *reinterpret_cast<f32x4_*>(dwl + wid2 * 512 + lane2 * 4) = dacc[0];
+      *reinterpret_cast<f32x4_*>(dwl + wid2 * 512 + 256 + lane2 * 4) = dacc[1];
+      if (next < ntiles) xwin_store(xpar ^ 1);
+      xpar ^= 1;
     }
     if (EPI == 2 || EPI == 4) {
       // 2x2 / stride 2 max-pool of the raw outputs, lane-local: rows mt, mt + 1 are two
@@ -450,6 +600,16 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
 
     __syncthreads();
     buf ^= 1;
+  }
+  if (FW) {
+    // slab [64 ch][32 cols] of the workgroup = pixel half 0 + pixel half 1, element e = ch * 32 + col
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2048; e += Cfg::NTHR) {
+      const int k = e >> 5, n = e & 31;
+      const int cg = k >> 4, i = k & 15, ln = 16 * (i >> 2) + (n & 15);
+      const int o = ((n >> 4) * 64 + ln) * 4 + (i & 3);
+      fslabs[(int64_t)blockIdx.x * 2048 + e] = dwl[cg * 512 + o] + dwl[(cg + 4) * 512 + o];
+    }
   }
 }
 
@@ -1508,11 +1668,20 @@ __global__ __launch_bounds__(256) void conv_first_wrw_reduce_kernel(
 __global__ __launch_bounds__(64) void conv_first_davg_kernel(
     const unsigned short* __restrict__ gz, const void* __restrict__ w, int w_f32, int64_t sk,
     int64_t sc, int64_t sh, int64_t sw, const float* __restrict__ gb,
-    const float* __restrict__ aux, int B, int H, int W, float* __restrict__ davg) {
+    const float* __restrict__ aux, int B, int H, int W, float* __restrict__ davg, int compact) {
   __shared__ float part[3][64];
   const int o = threadIdx.x;
   float corner[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
   for (int b = 0; b < B; ++b) {
+    if (compact) {           // gz = [B][4 corners: (0,0) (0,W-1) (H-1,0) (H-1,W-1)][64] — the fused
+                             // conv1_2 backward's side buffer (H, W >= 2 there: four distinct pixels)
+      const unsigned short* c4 = gz + (int64_t)b * 4 * C64 + o;
+      corner[0][0] += bf16_to_f32(c4[0 * C64]);
+      corner[0][2] += bf16_to_f32(c4[1 * C64]);
+      corner[2][0] += bf16_to_f32(c4[2 * C64]);
+      corner[2][2] += bf16_to_f32(c4[3 * C64]);
+      continue;
+    }
     const int64_t img = (int64_t)b * H * W;
     corner[0][0] += bf16_to_f32(gz[(img + 0) * C64 + o]);
     corner[0][2] += bf16_to_f32(gz[(img + W - 1) * C64 + o]);
@@ -1978,6 +2147,62 @@ extern "C" int scl_conv_first_wrw(const void* x0, const void* gz, int B, int H, 
   if (davg)      // w has the strides of gw (the layer's bf16 weight)
     SCL_LAUNCH("conv_first_davg_kernel", conv_first_davg_kernel, dim3(1), dim3(64), 0, st,
                (const unsigned short*)gz, w, w_f32 ? 1 : 0, w_stride_k, w_stride_c, w_stride_h,
-               w_stride_w, (const float*)gb, (const float*)aux, B, H, W, davg);
+               w_stride_w, (const float*)gb, (const float*)aux, B, H, W, davg, 0);
+  return scl_launch_status();
+}
+
+// conv1_2's backward-data pass WITHOUT its output, the first layer's weight / bias / mean gradient
+// out of the same launch (conv3x3_kernel<64, 64, 3, 1, FW = 1>; then the two small kernels of
+// scl_conv_first_wrw).  g_pooled / pool_idx / w2 / mask as scl_conv3x3_masked_pooled (64 -> 64
+// channels, H and W even); x0 / gw1 / gb1 / w1 / davg / fw_workspace as scl_conv_first_wrw.
+extern "C" int scl_conv3x3_masked_pooled_first_wrw(
+    const void* g_pooled, const void* pool_idx, const void* w2, int64_t w2_stride_k, int64_t w2_stride_c,
+    int64_t w2_stride_h, int64_t w2_stride_w, int flags, int B, int H, int W, const void* mask,
+    const void* x0, void* gw1, int64_t w1_stride_k, int64_t w1_stride_c, int64_t w1_stride_h,
+    int64_t w1_stride_w, int w1_f32, float* gb1, const void* w1, float* davg, void* workspace,
+    size_t workspace_bytes, void* fw_workspace, size_t fw_workspace_bytes, void* stream) {
+  if (!g_pooled || !pool_idx || !w2 || !mask || !x0 || !gw1 || !gb1 || !workspace || !fw_workspace ||
+      (davg && !w1))
+    return SCL_E_NULL;
+  if (B < 1 || B > 8192 || H < 2 || W < 2 || ((H | W) & 1) ||
+      (int64_t)B * H * W * 64 >= (int64_t)1 << 31)
+    return SCL_E_SHAPE;
+  if (((uintptr_t)g_pooled % 16) || ((uintptr_t)mask % 16) || ((uintptr_t)pool_idx % 8)) return SCL_E_SHAPE;
+  if (!scl_aligned256(workspace) || workspace_bytes < scl_conv3x3_workspace_bytes()) return SCL_E_WORKSPACE;
+  if (!scl_aligned256(fw_workspace) || fw_workspace_bytes < scl_conv_first_wrw_workspace_bytes())
+    return SCL_E_WORKSPACE;
+  using Cfg = ConvCfg<64, 64>;
+  constexpr size_t kLds = Cfg::LDS + (size_t)Cfg::WAVES * 512 * sizeof(float) +
+                          2 * (size_t)WR * WC * 4 * sizeof(unsigned short);
+  static SclDeviceOnce once;
+  scl_call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<64, 64, 3, 1, 1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
+  });
+  hipStream_t st = (hipStream_t)stream;
+  const int cus = conv64_cus();
+  const unsigned short* packed = (const unsigned short*)workspace;
+  const int transposed = (flags & (SCL_W_F32 | SCL_W_PACKED)) | SCL_CONV_TRANSPOSED;
+  if (flags & SCL_W_PACKED)
+    packed = (const unsigned short*)w2;
+  else
+    SCL_LAUNCH("conv3x3_pack_kernel", (conv3x3_pack_kernel<64, 64>), dim3(Cfg::NT * Cfg::KS * 512 / 256),
+               dim3(256), 0, st, w2, w2_stride_k, w2_stride_c, w2_stride_h, w2_stride_w, transposed,
+               (unsigned short*)workspace);
+  const int tiles = B * ((H + Cfg::TH_ - 1) / Cfg::TH_) * ((W + TW - 1) / TW);
+  const int grid = tiles < cus ? tiles : cus;
+  float* aux = (float*)fw_workspace + (size_t)2 * 1024 * 2048;
+  const unsigned short* corners = (const unsigned short*)((float*)fw_workspace + (size_t)1536 * 2048);
+  SCL_LAUNCH("conv3x3_kernel<pooled,first_wrw>", (conv3x3_kernel<64, 64, 3, 1, 1>), dim3(grid),
+             dim3(Cfg::NTHR), kLds, st, (const unsigned short*)g_pooled, packed, B, H, W,
+             (unsigned short*)nullptr, (const float*)nullptr, 0, (unsigned short*)x0,
+             (const unsigned short*)mask, (unsigned char*)fw_workspace, (const unsigned char*)pool_idx);
+  SCL_LAUNCH("conv_first_wrw_reduce_kernel", conv_first_wrw_reduce_kernel, dim3(32), dim3(256), 0,
+             st, (const float*)fw_workspace, grid, w1_stride_k, w1_stride_c, w1_stride_h, w1_stride_w,
+             gw1, w1_f32 ? 1 : 0, gb1, aux);
+  if (davg)
+    SCL_LAUNCH("conv_first_davg_kernel", conv_first_davg_kernel, dim3(1), dim3(64), 0, st, corners, w1,
+               w1_f32 ? 1 : 0, w1_stride_k, w1_stride_c, w1_stride_h, w1_stride_w, (const float*)gb1,
+               (const float*)aux, B, H, W, davg, 1);
   return scl_launch_status();
 }

@@ -592,12 +592,16 @@ class _GradLink:
     next, takes it and skips its own masking pass.  Anything else (a copied or re-accumulated
     gradient, a library backward) leaves the link empty and the lower layer masks itself —
     masking twice would be harmless, skipping it is only done on this exact buffer."""
-    __slots__ = ('ptr', 'fused')
+    __slots__ = ('ptr', 'fused', 'first', 'first_done')
 
     def __init__(self):
         self.ptr = None
         self.fused = None      # (data_ptr of y1, pooled map, window index): conv1_2's forward
                                # results, computed by the kernel that produced y1 (_FirstConv)
+        self.first = None      # (x0, w1, bias1, avg): set by _FirstConv.forward — the layer above may
+                               # compute conv1_1's weight / bias / mean gradient in its own
+                               # backward-data kernel instead of writing the gradient map
+        self.first_done = None  # (gw1, gb1, davg) once it has
 
     def mark(self, gx):
         self.ptr = gx.data_ptr()
@@ -613,6 +617,10 @@ USE_MASKED_BWD = os.environ.get('SCL_MASKED_BWD', '1') != '0'
 USE_POOL_IDX = os.environ.get('SCL_POOL_IDX', '1') != '0'
 USE_POOLED_BWD = os.environ.get('SCL_POOLED_BWD', '1') != '0'     # un-pool inside the consumers
 USE_F32_WEIGHTS = os.environ.get('SCL_F32_WEIGHTS', '1') != '0'
+# Round 5: conv1_2's backward-data kernel keeps its output tile in LDS and multiplies it with the
+# im2col of x0 right there (scl_conv3x3_masked_pooled_first_wrw): the 944 MB gradient map at
+# conv1_1's pre-activation is neither written nor read, conv_first_wrw_kernel is not launched.
+USE_FUSED_FIRST_WRW = os.environ.get('SCL_FUSED_FIRST_WRW', '1') != '0'
 # conv1_1 and conv1_2 of the forward pass in one kernel (scl_conv_first_pool_idx): bit-identical
 # to the two-kernel path and 1.25 GB less read per step, but SLOWER as built (776 against 243 + 480
 # us on one box, profiles/r04/first_block_one_kernel_vs_two.txt): conv1_2's kernel sits at 256
@@ -729,6 +737,43 @@ def _wrw_maybe_async(x, gz, w, gb, pool_idx=None):
     return gw
 
 
+def _masked_pooled_first_wrw(ga, idx, w2, y1, first):
+    """conv1_2's backward-data pass fused with conv1_1's parameter gradients
+    (``scl_conv3x3_masked_pooled_first_wrw``): ga / idx = gradient at the pooled map and window
+    positions, w2 = conv1_2's weight, y1 = conv1_1's output (the ReLU' mask), ``first`` = (x0, w1,
+    bias1) from _FirstConv.forward.  Returns (gw1, gb1, davg), written where the gradient sink
+    wants them."""
+    lib = L.load()
+    x0, w1, bias1 = first
+    L.require_device(ga, idx, w2, y1, x0, w1)
+    ga = ga.contiguous(memory_format=_CL)
+    idx = idx.contiguous(memory_format=_CL)
+    y1 = y1.contiguous(memory_format=_CL)
+    b, _, h, wd = y1.shape
+    gw1 = _grad_out(w1)
+    gb1 = _grad_out(bias1) if bias1.dtype == torch.float32 else torch.empty(
+        64, dtype=torch.float32, device=y1.device)
+    davg = torch.empty(3, dtype=torch.float32, device=y1.device)
+    w1c = w1
+    if w1c.stride() != gw1.stride() or w1c.dtype != gw1.dtype:
+        w1c = w1.to(gw1.dtype).contiguous(memory_format=_CL) if gw1.is_contiguous(memory_format=_CL) \
+            else w1.to(gw1.dtype).contiguous()
+    pk = _packed_for(w2, True)
+    wp = L.ptr(w2) if pk is None else L.ptr(pk)
+    wflags = _wflag(w2) if pk is None else L.W_PACKED
+    s2 = w2.stride()
+    s1 = gw1.stride()
+    ws = L.workspace(lib.scl_conv3x3_workspace_bytes(), y1.device)
+    fws = L.workspace(lib.scl_conv_first_wrw_workspace_bytes(), y1.device)
+    px = b * h * wd
+    _work('conv3x3_kernel<pooled,first_wrw>', 2.0 * px * (64 * 64 * 9 + 64 * 28), px * (0.75 * 64 + 2.0 * 64 + 6.0))
+    L.check(lib.scl_conv3x3_masked_pooled_first_wrw(
+        L.ptr(ga), L.ptr(idx), wp, s2[0], s2[1], s2[2], s2[3], wflags, b, h, wd, L.ptr(y1), L.ptr(x0),
+        L.ptr(gw1), s1[0], s1[1], s1[2], s1[3], int(gw1.dtype == torch.float32), L.ptr(gb1), L.ptr(w1c),
+        L.ptr(davg), L.ptr(ws), ws.numel(), L.ptr(fws), fws.numel(), L.stream_of(y1)))
+    return gw1, gb1, davg
+
+
 def _conv3x3_backward(gz, x, w, need_x, link=None, gb=None, pooled=None):
     """(gx, gw) of a 3x3 convolution.  With ``link`` (x is a post-ReLU map whose producer
     holds the other end) an own backward-data kernel returns gx * [x > 0] and marks the
@@ -752,6 +797,16 @@ def _conv3x3_backward(gz, x, w, need_x, link=None, gb=None, pooled=None):
             return _wrw_maybe_async(x, ga, w, gb, pool_idx=idx)
         return _wrw_maybe_async(x, gz, w, gb)
     if own_gx and need_x and link is not None and USE_MASKED_BWD:
+        if (gz is None and USE_FUSED_FIRST_WRW and link.first is not None and own_gw
+                and tuple(w.shape) == (64, 64, 3, 3) and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0):
+            # x is conv1_1's output: its gradient map has ONE consumer, the first layer's weight /
+            # bias / mean gradient — computed here, the map itself never exists.  What autograd
+            # carries down is an UNINITIALISED tensor of its shape that _FirstConv.backward must
+            # recognise (same hand-off as the ReLU' mark) and never read.
+            gx = torch.empty_like(x)
+            link.first_done = _masked_pooled_first_wrw(ga, idx, w, x, link.first)
+            link.mark(gx)
+            return gx, own_wrw()
         if gz is None:
             gx = conv64(ga, w, True, mask=x, pool_idx=idx)
         else:
@@ -1063,6 +1118,8 @@ class _FirstConv(torch.autograd.Function):
                                                L.ptr(x0[lo:hi]), L.ptr(y_nhwc[lo:hi]), L.stream_of(img)))
             if fuse2:
                 link_out.fused = (y.data_ptr(), a, idx, w2, bias2)
+            if link_out is not None and b * h * wd * 64 < 2 ** 31 and b <= 8192:
+                link_out.first = (x0, w, bias)            # (x0 in its [B,H,W,3] storage order)
             x0 = x0.permute(0, 3, 1, 2)
         else:
             with _whole_batch_op():
@@ -1083,7 +1140,18 @@ class _FirstConv(torch.autograd.Function):
         gb = _grad_out(bias) if bias.dtype == torch.float32 else torch.empty(
             c, dtype=torch.float32, device=gy.device)
         ws = L.workspace(lib.scl_vgg_workspace_bytes(c), gy.device)
+        done = ctx.link_out.first_done if ctx.link_out is not None else None
         masked = ctx.link_out is not None and ctx.link_out.take(gy)
+        if done is not None:
+            ctx.link_out.first_done = None
+            if not masked:
+                # the layer above skipped the gradient map (it lives in LDS tiles only) and what
+                # arrived here is not the placeholder it handed down: nothing valid to fall back on
+                raise RuntimeError("fused first-layer gradients: the placeholder gradient was replaced on "
+                                   "its way down (a hook or a second consumer of conv1_1's output?); "
+                                   "set SCL_FUSED_FIRST_WRW=0")
+            gw, gb, davg = done
+            return None, davg, _grad_ret(gw, w), _grad_ret(gb, bias), None, None, None, None
         own_wrw = (USE_CONV64 and USE_FIRST and gy.dtype == torch.bfloat16
                    and x0.dtype == torch.bfloat16 and w.dtype in _W_DTYPES
                    and tuple(w.shape) == (64, 3, 3, 3))

@@ -931,3 +931,96 @@ def test_half_batches_on_two_streams_equal_the_one_stream_forward(dev, shape):
             assert torch.equal(res[True][1][n], res[False][1][n]), n
         elif n != 'average_rgb':      # (a sum with heavy cancellation: the library's noise shows)
             assert _nrel(res[True][1][n], res[False][1][n]) < 0.15, n
+
+
+# ---- round 5: conv1_2's backward-data pass computes conv1_1's parameter gradients -------------------
+def _first_block_grads(dev, img, seed, fused):
+    """conv1_1 -> ReLU -> conv1_2 -> pool -> ReLU as the model builds it; backward from a fixed
+    gradient at the pooled map.  Returns (gw1, gb1, davg, gw2, gb2)."""
+    from soft_contrastive_learning_amd import parallel
+    from soft_contrastive_learning_amd.model import nets
+    g = torch.Generator().manual_seed(seed)
+    avg = torch.nn.Parameter(torch.tensor([123.68, 116.78, 103.94], device=dev))
+    w1 = torch.nn.Parameter((torch.randn(64, 3, 3, 3, generator=g) * (2.0 / 27) ** 0.5).to(dev))
+    b1 = torch.nn.Parameter((torch.randn(64, generator=g) * 0.1).to(dev))
+    w2 = torch.nn.Parameter((torch.randn(64, 64, 3, 3, generator=g) * (2.0 / 576) ** 0.5).to(dev))
+    b2 = torch.nn.Parameter((torch.randn(64, generator=g) * 0.1).to(dev))
+    params = [avg, w1, b1, w2, b2]
+    buckets = parallel.GradBuckets(params)
+    old = nets.USE_FUSED_FIRST_WRW
+    nets.USE_FUSED_FIRST_WRW = fused
+    nets.GRAD_SINK = buckets
+    try:
+        assert nets.prepack([w2], force=True) == 2
+        l1, l2 = nets._GradLink(), nets._GradLink()
+        y1 = nets._FirstConv.apply(img, avg, w1, b1, torch.bfloat16, l1)
+        a = nets._ConvBiasPoolReLU.apply(y1, w2, b2, l1, l2)
+        ga = torch.randn(a.shape, generator=g).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+        ga = torch.where(a.detach() > 0, ga, torch.zeros_like(ga)).contiguous(memory_format=torch.channels_last)
+        l2.mark(ga)
+        buckets.zero()
+        a.backward(ga)
+        buckets.finish()
+        torch.cuda.synchronize()
+    finally:
+        nets.GRAD_SINK = None
+        nets.USE_FUSED_FIRST_WRW = old
+    return [p.grad.detach().clone() for p in (w1, b1, avg, w2, b2)]
+
+
+@pytest.mark.parametrize('shape', [(24, 480, 640), (3, 36, 70), (2, 8, 32), (5, 180, 240), (1, 2, 2)])
+def test_first_layer_gradients_from_conv1_2_backward_kernel(dev, shape):
+    """scl_conv3x3_masked_pooled_first_wrw: conv1_2's backward-data kernel keeps the masked tile of
+    the gradient at conv1_1's pre-activation in LDS and multiplies it with the im2col of x0 right
+    there (weight, bias and the five columns of the mean gradient's closed form); the 944 MB map
+    is neither written nor read.  Against the two-kernel path (scl_conv3x3_masked_pooled +
+    scl_conv_first_wrw, validated against float32 torch in test_gpu_conv_bench_shapes.py) at the
+    bench launch shape and at ragged ones (partial tiles, one tile, the reference's 240 x 180, a
+    2 x 2 image whose four pixels are all corners): the same sums in another order."""
+    b, h, w = shape
+    img = torch.randint(0, 256, (b, h, w, 3), generator=torch.Generator().manual_seed(5)).float().to(dev)
+    two = _first_block_grads(dev, img, 17, False)
+    one = _first_block_grads(dev, img, 17, True)
+    names = ('conv1_1 weight', 'conv1_1 bias', 'average_rgb', 'conv1_2 weight', 'conv1_2 bias')
+    for n, a, bb in zip(names, one, two):
+        if n.startswith('conv1_2'):
+            assert torch.equal(a, bb), n                     # untouched by the fusion
+            continue
+        rel = float((a.double() - bb.double()).norm() / bb.double().norm().clamp_min(1e-30))
+        assert rel < (2e-5 if n != 'average_rgb' else 2e-4), (n, rel, shape)
+        assert float((a - bb).abs().max()) <= 1e-4 * float(bb.abs().max()) + 1e-6, (n, shape)
+
+
+def test_model_gradients_with_and_without_the_fused_first_layer_gradients(dev):
+    """The whole backbone step with nets.USE_FUSED_FIRST_WRW on and off: every other gradient
+    bit-identical, conv1_1's and the mean's within float32 summation-order noise."""
+    from soft_contrastive_learning_amd import parallel
+    from soft_contrastive_learning_amd.model import nets
+    img = torch.randint(0, 256, (2, 480, 640, 3), generator=torch.Generator().manual_seed(81)).float().to(dev)
+    g = torch.randn(2, 30, 40, 512, generator=torch.Generator().manual_seed(82)).to(dev).bfloat16()
+    grads = {}
+    old = nets.USE_FUSED_FIRST_WRW
+    try:
+        for fused in (False, True):
+            nets.USE_FUSED_FIRST_WRW = fused
+            model = nets.VGG16NetVLAD(compute_dtype=torch.bfloat16, seed=13, fused_relu=True).to(dev)
+            buckets = parallel.GradBuckets(list(model.parameters()))
+            nets.GRAD_SINK = buckets
+            try:
+                buckets.zero()
+                model.features(img).backward(g)
+                buckets.finish()
+            finally:
+                nets.GRAD_SINK = None
+            torch.cuda.synchronize()
+            grads[fused] = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    finally:
+        nets.USE_FUSED_FIRST_WRW = old
+    assert set(grads[True]) == set(grads[False])
+    for n in grads[True]:
+        a, bb = grads[True][n], grads[False][n]
+        if n in ('conv1_1_kernel', 'conv1_1_bias', 'average_rgb'):
+            rel = float((a.double() - bb.double()).norm() / bb.double().norm())
+            assert rel < 2e-4, (n, rel)
+        else:
+            assert torch.equal(a, bb), n
