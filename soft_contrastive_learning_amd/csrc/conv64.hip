@@ -186,15 +186,19 @@ __global__ __launch_bounds__(256) void conv3x3_pack_kernel(const void* __restric
 //   * after the K loop and one more barrier the tile's window buffer is dead; the epilogue puts the
 //     masked bf16 tile there as two 32-channel planes [256 px][32 ch] (the layout of the
 //     weight-gradient kernels: transposed reads give 8 pixels of a channel per lane);
-//   * wave (cg = wid & 3, phf = wid >> 2) multiplies channels 16 cg .. + 15 of pixel half phf
-//     (tile rows 4 phf .. + 3) with the im2col columns of the x0 window ([10][34][3 + 1] bf16, its
-//     own small double-buffered LDS area): v_mfma_f32_16x16x32_bf16, four k-steps x two column
-//     halves; column 27 = 1 (bias gradient), 28 .. 31 = first / last row / column indicators (the
-//     border sums of the mean gradient's closed form) exactly as in conv_first_wrw_kernel;
-//   * the partial [16 ch][32 cols] of a wave lives in LDS between tiles (8 KB... 2 KB per wave:
-//     the kernel has no registers to spare), one slab [64][32] per workgroup at the end,
-//     conv_first_wrw_reduce_kernel sums the slabs as before; the four corner pixels of every image
-//     (the davg kernel's X term) go to a compact side buffer.
+//   * the im2col matrix of the tile's x0 window ([10][34][3 + 1] bf16, its own small double-buffered
+//     LDS area) is built ONCE per tile, by all 512 threads, into the epilogue scratch (dead by then)
+//     as ready B operands [16 steps][32 columns][16 pixels]: column 27 = 1 (bias gradient), 28 .. 31
+//     = first / last row / column indicators (the border sums of the mean gradient's closed form)
+//     exactly as in conv_first_wrw_kernel.  (A first version let every wave gather its own operands
+//     for v_mfma_f32_16x16x32_bf16 — 512 two-byte gather instructions per tile: 792 us for the
+//     kernel against 505 + 216 for the two it replaces);
+//   * wave (mt = wid & 1, pq = wid >> 1) multiplies channels 32 mt .. + 31 of tile rows 2 pq, 2 pq + 1
+//     (four steps of 16 pixels) on v_mfma_f32_32x32x16_bf16 — one transposed read pair and one
+//     ds_read_b128 per product; its partial [32 ch][32 cols] (16 registers) lives in LDS between
+//     tiles (4 KB per wave: the kernel has no registers to spare), one slab [64][32] per workgroup
+//     at the end, conv_first_wrw_reduce_kernel sums the slabs as before; the four corner pixels of
+//     every image (the davg kernel's X term) go to a compact side buffer.
 // `pooled` carries x0 and `pidx` the float32 slab / corner workspace in this mode (EPI 3 uses
 // neither); saves the 944 MB store here and the 944 MB read + 217 us of conv_first_wrw_kernel.
 template <int CIN, int KOUT, int EPI, int PL = 0, int FW = 0>
@@ -218,7 +222,8 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
   static_assert(!FW || (CIN == 64 && KOUT == 64 && EPI == 3 && PL == 1), "FW: conv1_2 backward-data only");
   constexpr int FWPL = 32, FGPL = TH * TW * FWPL, FXW = WR * WC * 4;
   float* dwl = reinterpret_cast<float*>(lds + 2 * WIN_ + Cfg::WAVES * SCR);
-  unsigned short* xwl = reinterpret_cast<unsigned short*>(dwl + Cfg::WAVES * 512);
+  unsigned short* xwl = reinterpret_cast<unsigned short*>(dwl + Cfg::WAVES * 1024);
+  unsigned short* imc = lds + 2 * WIN_;     // im2col tile [16][32][16] bf16 = 16 KB of the 20 KB scratch
   const unsigned short* fx0 = reinterpret_cast<const unsigned short*>(pooled);
   float* fslabs = reinterpret_cast<float*>(pidx);
   // epilogue fusions (lane r <-> output channel 32 nt + r):
@@ -293,8 +298,13 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
   uint2 pi[PLIVE];
   const int p_piece = threadIdx.x % PPP;
   // pooled (row << 8 | column) of this thread's task in round rd, -1: none
+  // (FW: re-derived at every use from an opaque copy of the thread index — kept across the K loop
+  // these per-thread constants were what the fused kernel spilled, and every scratch reload waits
+  // vmcnt(0), i.e. for the next tile's pooled gradient, in the middle of the products)
   auto p_rc = [&](int rd) {
-    const int pp = ((int)threadIdx.x + Cfg::NTHR * rd) / PPP;
+    int tid_ = threadIdx.x;
+    if (FW) asm volatile("" : "+v"(tid_));
+    const int pp = (tid_ + Cfg::NTHR * rd) / PPP;
     return pp < PWR * PWC ? ((pp / PWC) << 8) | (pp % PWC) : -1;
   };
   auto pool_issue = [&](int tile, int g) {
@@ -330,7 +340,7 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
   // (experiment, 60004: static priority for the younger half of an eight-wave workgroup)
   if ((dbg & 4) && (threadIdx.x >> 6) >= 4) __builtin_amdgcn_s_setprio(1);
   // FW: this thread's two elements of a tile's x0 window (340 pixels x 3 channels)
-  unsigned short xreg[FW ? 2 : 1];
+  unsigned xreg = 0u;                  // (both elements in ONE register: it lives across the K loop)
   // (thread index through an opaque copy per call: its quotients by 3 and 34 must not be hoisted
   // out of the tile loop — the K loop has no register for them)
   auto xwin_load = [&](int tile_) {
@@ -344,7 +354,8 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
       const int pix = idx / 3, c = idx - 3 * pix;
       const int y = ty_ - 1 + pix / WC, xx = tx_ - 1 + pix % WC;
       const bool ok = idx < 3 * WR * WC && y >= 0 && y < H && xx >= 0 && xx < W;
-      xreg[v] = ok ? fx0[(((int64_t)b_ * H + y) * W + xx) * 3 + c] : (unsigned short)0;
+      const unsigned e = ok ? (unsigned)fx0[(((int64_t)b_ * H + y) * W + xx) * 3 + c] : 0u;
+      xreg = v == 0 ? e : (xreg | (e << 16));
     }
   };
   auto xwin_store = [&](int par) {
@@ -354,13 +365,14 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
     for (int v = 0; v < 2; ++v) {
       const int idx = v * Cfg::NTHR + tid2;
       const int pix = idx / 3, c = idx - 3 * pix;
-      if (idx < 3 * WR * WC) xwl[par * FXW + pix * 4 + c] = xreg[v];
+      if (idx < 3 * WR * WC) xwl[par * FXW + pix * 4 + c] = (unsigned short)(v == 0 ? xreg & 0xffffu : xreg >> 16);
     }
   };
   int tile = blockIdx.x;
   if (FW) {
-    *reinterpret_cast<f32x4_*>(dwl + wid * 512 + lane * 4) = f32x4_{0.f, 0.f, 0.f, 0.f};
-    *reinterpret_cast<f32x4_*>(dwl + wid * 512 + 256 + lane * 4) = f32x4_{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+      *reinterpret_cast<f32x4_*>(dwl + wid * 1024 + v * 256 + lane * 4) = f32x4_{0.f, 0.f, 0.f, 0.f};
     if (tile < ntiles) {
       xwin_load(tile);
       xwin_store(0);
@@ -450,9 +462,9 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (FW) {
       __syncthreads();             // every wave is done with the window: its buffer takes the tile
-      // the next tile's x0 window: requested here, where the K loop's registers are free (held
-      // across the K loop its two values cost eleven scratch accesses per tile), stored behind the
-      // products below
+      // the next tile's x0 window: requested here, stored behind the products below.  (Requested
+      // at the top of the tile instead — its one register alive across the K loop — the kernel
+      // measured 844 us against 765: profiles/r05/first_wrw_fused_notes.txt)
       if (next < ntiles) xwin_load(next);
     }
 
@@ -494,7 +506,9 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
         v0 = relu_mask(v0, y0v);
         v1 = relu_mask(v1, y1v);
       }
-      if (FW) {
+      if (FW && (dbg & 32)) {
+        // (timing ablation, scl_debug_set_variant(61032): the tile is not written to LDS)
+      } else if (FW) {
         // (outside the image the mask was loaded as zero: v0 = v1 = 0 there already)
         unsigned short* gzp = lds + buf * WIN_ + nt * FGPL + ((MT * part + mt) * TW + px) * FWPL + 8 * hf;
         *reinterpret_cast<u32x4*>(gzp) = v0;
@@ -513,52 +527,64 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
       }
     }
     if (FW) {
-      __syncthreads();             // the whole masked tile is in LDS
-      // (the lane's roles are re-derived per tile from opaque copies: hoisted out of the tile loop
-      // they stay live across the K loop, which has no register left — scratch reloads there)
-      int lane2 = lane, wid2 = wid;
-      asm volatile("" : "+v"(lane2), "+v"(wid2));
-      const int cg = wid2 & 3, phf = wid2 >> 2;
-      const int li = lane2 & 15, lg = lane2 >> 4, q4 = (lane2 >> 2) & 3, p4 = lane2 & 3;
-      const unsigned short* ga = lds + buf * WIN_ + (cg >> 1) * FGPL +
-                                 ((4 * phf) * TW + 8 * lg + q4) * FWPL + 16 * (cg & 1) + 4 * p4;
-      f32x4_ dacc[2];
-      dacc[0] = *reinterpret_cast<const f32x4_*>(dwl + wid2 * 512 + lane2 * 4);
-      dacc[1] = *reinterpret_cast<const f32x4_*>(dwl + wid2 * 512 + 256 + lane2 * 4);
+      __syncthreads();             // the whole masked tile is in LDS; the epilogue scratch is dead
+      // (the thread's / lane's roles are re-derived per tile from opaque copies: hoisted out of
+      // the tile loop they stay live across the K loop, which has no register left)
+      int tid2 = threadIdx.x;
+      asm volatile("" : "+v"(tid2));
       const unsigned short* xw = xwl + xpar * FXW;
       const int ty_ = oy0 - MT * part, tx_ = ox0;
-      // column n = 16 nh + li of the im2col matrix: tap (kh, kw), channel c; n >= 27: 1 | border flags
-      int woff[2];
+      // 1. im2col: unit u = (step s, column n, pixel half hh) = 8 pixels of one column, two per thread
+      // (dbg & 8 / & 16, scl_debug_set_variant(61008 / 61016): timing ablations without this pass /
+      // without the products)
 #pragma unroll
-      for (int nh = 0; nh < 2; ++nh) {
-        const int n = 16 * nh + li, nc = n < 27 ? n : 26;
-        const int tap = nc / 3, c = nc - 3 * tap;
-        woff[nh] = ((tap / 3) * WC + tap % 3 + 8 * lg) * 4 + c;
-      }
+      for (int v = 0; v < ((dbg & 8) ? 0 : 2); ++v) {
+        const int u = v * Cfg::NTHR + tid2;                   // 0 .. 1023
+        const int hh = u & 1, n = (u >> 1) & 31, s_ = u >> 6;
+        const int row = s_ >> 1, col0 = 16 * (s_ & 1) + 8 * hh;   // first pixel of the unit
+        const int nc = n < 27 ? n : 26, tap = nc / 3, c = nc - 3 * tap;
+        const unsigned short* wp = xw + ((row + tap / 3) * WC + col0 + tap % 3) * 4 + c;
+        unsigned e[8];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int row = 4 * phf + ks;                                    // tile row of this k-step
-        const u32x4 a = tr_pair_early(ga + ks * TW * FWPL, 4 * FWPL);
+        for (int j = 0; j < 8; ++j) e[j] = wp[4 * j];
+        if (n >= 27) {
+          const int y = ty_ + row, xb = tx_ + col0;
+          const bool rowflag = n == 27 || (n == 28 && y == 0) || (n == 29 && y == H - 1);
+          const int colx = n == 30 ? 0 : (n == 31 ? W - 1 : -1);
 #pragma unroll
-        for (int nh = 0; nh < 2; ++nh) {
-          const unsigned short* wp = xw + row * WC * 4 + woff[nh];
-          unsigned e[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) e[j] = wp[4 * j];
-          if (nh == 1) {
-            const int y = ty_ + row, xb = tx_ + 8 * lg;
-            const bool rowflag = li == 11 || (li == 12 && y == 0) || (li == 13 && y == H - 1);
-            const int colx = li == 14 ? 0 : (li == 15 ? W - 1 : -1);
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-              if (li >= 11) e[j] = (rowflag || xb + j == colx) ? 0x3f80u : 0u;
-          }
-          const u32x4 bfr = {e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
-          dacc[nh] = mfma16b(a, bfr, dacc[nh]);
+          for (int j = 0; j < 8; ++j) e[j] = (rowflag || xb + j == colx) ? 0x3f80u : 0u;
         }
+        *reinterpret_cast<u32x4*>(imc + (s_ * 32 + n) * 16 + 8 * hh) =
+            u32x4{e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
       }
-      *reinterpret_cast<f32x4_*>(dwl + wid2 * 512 + lane2 * 4) = dacc[0];
-      *reinterpret_cast<f32x4_*>(dwl + wid2 * 512 + 256 + lane2 * 4) = dacc[1];
+      __syncthreads();
+      // 2. the products: wave (mt, pq), steps 4 pq .. 4 pq + 3
+      int lane2 = lane, wid2 = wid;
+      asm volatile("" : "+v"(lane2), "+v"(wid2));
+      const int mt_ = wid2 & 1, pq = wid2 >> 1;
+      const int r2 = lane2 & 31, h2 = lane2 >> 5;
+      const int q4 = (lane2 >> 2) & 3, p4 = lane2 & 3, gq = lane2 >> 4;
+      // A (gz^T): the lane addresses pixel 8 (gq >> 1) + q4 of the step, channels 16 (gq & 1) + 4 p4 ..
+      const unsigned short* ga = lds + buf * WIN_ + mt_ * FGPL + (8 * (gq >> 1) + q4) * FWPL +
+                                 16 * (gq & 1) + 4 * p4;
+      f32x16 dacc;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const f32x4_ t = *reinterpret_cast<const f32x4_*>(dwl + wid2 * 1024 + v * 256 + lane2 * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dacc[4 * v + j] = t[j];
+      }
+#pragma unroll
+      for (int u = 0; u < ((dbg & 16) ? 0 : 4); ++u) {
+        const int s_ = 4 * pq + u;                                   // 16 pixels: row s_ / 2, half s_ & 1
+        const u32x4 a = tr_pair_early(ga + s_ * 16 * FWPL, 4 * FWPL);
+        const u32x4 bfr = *reinterpret_cast<const u32x4*>(imc + (s_ * 32 + r2) * 16 + 8 * h2);
+        dacc = mfma32b(a, bfr, dacc);
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        *reinterpret_cast<f32x4_*>(dwl + wid2 * 1024 + v * 256 + lane2 * 4) =
+            f32x4_{dacc[4 * v], dacc[4 * v + 1], dacc[4 * v + 2], dacc[4 * v + 3]};
       if (next < ntiles) xwin_store(xpar ^ 1);
       xpar ^= 1;
     }
@@ -602,14 +628,20 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
     buf ^= 1;
   }
   if (FW) {
-    // slab [64 ch][32 cols] of the workgroup = pixel half 0 + pixel half 1, element e = ch * 32 + col
+    // slab [64 ch][32 cols] of the workgroup = the four pixel quarters in a fixed order; the
+    // partials pass through the (free) window buffers as [pq][64][32]
     __syncthreads();
-    for (int e = threadIdx.x; e < 2048; e += Cfg::NTHR) {
-      const int k = e >> 5, n = e & 31;
-      const int cg = k >> 4, i = k & 15, ln = 16 * (i >> 2) + (n & 15);
-      const int o = ((n >> 4) * 64 + ln) * 4 + (i & 3);
-      fslabs[(int64_t)blockIdx.x * 2048 + e] = dwl[cg * 512 + o] + dwl[(cg + 4) * 512 + o];
+    float* red = reinterpret_cast<float*>(lds);
+    const int mt_ = wid & 1, pq = wid >> 1;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const f32x4_ t = *reinterpret_cast<const f32x4_*>(dwl + wid * 1024 + v * 256 + lane * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[(pq * 64 + 32 * mt_ + acc_row(4 * v + j, h)) * 32 + r] = t[j];
     }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2048; e += Cfg::NTHR)
+      fslabs[(int64_t)blockIdx.x * 2048 + e] = (red[e] + red[2048 + e]) + (red[4096 + e] + red[6144 + e]);
   }
 }
 
@@ -2172,7 +2204,7 @@ extern "C" int scl_conv3x3_masked_pooled_first_wrw(
   if (!scl_aligned256(fw_workspace) || fw_workspace_bytes < scl_conv_first_wrw_workspace_bytes())
     return SCL_E_WORKSPACE;
   using Cfg = ConvCfg<64, 64>;
-  constexpr size_t kLds = Cfg::LDS + (size_t)Cfg::WAVES * 512 * sizeof(float) +
+  constexpr size_t kLds = Cfg::LDS + (size_t)Cfg::WAVES * 1024 * sizeof(float) +
                           2 * (size_t)WR * WC * 4 * sizeof(unsigned short);
   static SclDeviceOnce once;
   scl_call_once(once, [] {
@@ -2195,8 +2227,10 @@ extern "C" int scl_conv3x3_masked_pooled_first_wrw(
   const unsigned short* corners = (const unsigned short*)((float*)fw_workspace + (size_t)1536 * 2048);
   SCL_LAUNCH("conv3x3_kernel<pooled,first_wrw>", (conv3x3_kernel<64, 64, 3, 1, 1>), dim3(grid),
              dim3(Cfg::NTHR), kLds, st, (const unsigned short*)g_pooled, packed, B, H, W,
-             (unsigned short*)nullptr, (const float*)nullptr, 0, (unsigned short*)x0,
-             (const unsigned short*)mask, (unsigned char*)fw_workspace, (const unsigned char*)pool_idx);
+             (unsigned short*)nullptr, (const float*)nullptr,
+             scl_variant() / 1000 == 61 ? (scl_variant() & 63) << 1 : 0,       // timing ablations (diagnostic build)
+             (unsigned short*)x0, (const unsigned short*)mask, (unsigned char*)fw_workspace,
+             (const unsigned char*)pool_idx);
   SCL_LAUNCH("conv_first_wrw_reduce_kernel", conv_first_wrw_reduce_kernel, dim3(32), dim3(256), 0,
              st, (const float*)fw_workspace, grid, w1_stride_k, w1_stride_c, w1_stride_h, w1_stride_w,
              gw1, w1_f32 ? 1 : 0, gb1, aux);

@@ -968,7 +968,7 @@ def _first_block_grads(dev, img, seed, fused):
     return [p.grad.detach().clone() for p in (w1, b1, avg, w2, b2)]
 
 
-@pytest.mark.parametrize('shape', [(24, 480, 640), (3, 36, 70), (2, 8, 32), (5, 180, 240), (1, 2, 2)])
+@pytest.mark.parametrize('shape', [(24, 480, 640), (3, 36, 70), (2, 32, 64), (5, 180, 240), (40, 2, 2)])
 def test_first_layer_gradients_from_conv1_2_backward_kernel(dev, shape):
     """scl_conv3x3_masked_pooled_first_wrw: conv1_2's backward-data kernel keeps the masked tile of
     the gradient at conv1_1's pre-activation in LDS and multiplies it with the im2col of x0 right
@@ -976,7 +976,8 @@ def test_first_layer_gradients_from_conv1_2_backward_kernel(dev, shape):
     is neither written nor read.  Against the two-kernel path (scl_conv3x3_masked_pooled +
     scl_conv_first_wrw, validated against float32 torch in test_gpu_conv_bench_shapes.py) at the
     bench launch shape and at ragged ones (partial tiles, one tile, the reference's 240 x 180, a
-    2 x 2 image whose four pixels are all corners): the same sums in another order."""
+    2 x 2 image whose four pixels are all corners — 40 of them, so that the own weight-gradient
+    kernel and with it the fused path is taken): the same sums in another order."""
     b, h, w = shape
     img = torch.randint(0, 256, (b, h, w, 3), generator=torch.Generator().manual_seed(5)).float().to(dev)
     two = _first_block_grads(dev, img, 17, False)

@@ -331,3 +331,60 @@ def test_first_layer_at_bench_shape(dev, sink, takes):
     davg_ref = -torch.stack([gx_ref[lo:lo + 4].double().sum(dim=(0, 2, 3)) for lo in range(0, B, 4)]).sum(0)
     scale = float(davg_ref.abs().max())
     assert float((avg.grad.double() - davg_ref).abs().max()) < 5e-3 * scale + 1e-2
+
+
+def test_first_block_backward_at_bench_shape(dev, sink, takes):
+    """Round 5: conv1_2's backward-data kernel computes conv1_1's weight / bias / mean gradient on
+    its LDS tile (scl_conv3x3_masked_pooled_first_wrw; the 944 MB gradient map at conv1_1's
+    pre-activation is never written).  The chain conv1_1 -> ReLU -> conv1_2 -> pool -> ReLU as the
+    model builds it, 24 x 640x480, against float32 torch on the same bf16 operands: the kernel's own
+    y1 (validated in test_first_layer_at_bench_shape) as conv1_2's input and ReLU' mask, its own
+    window index (validated in test_layer_at_bench_shape[1_2]) for the un-pooling, the gradient at
+    conv1_1's pre-activation rounded to bf16 where the kernel rounds it."""
+    from soft_contrastive_learning_amd.model import nets
+    assert nets.USE_FUSED_FIRST_WRW
+    h, w = 480, 640
+    g = torch.Generator().manual_seed(177)
+    img = torch.randint(0, 256, (B, h, w, 3), generator=g).float().to(dev)
+    avg = torch.nn.Parameter(torch.tensor([123.68, 116.78, 103.94], device=dev))
+    w1 = torch.nn.Parameter((torch.randn(64, 3, 3, 3, generator=g) * (2.0 / 27) ** 0.5).to(dev))
+    b1 = torch.nn.Parameter((torch.randn(64, generator=g) * 0.1).to(dev))
+    w2 = torch.nn.Parameter((torch.randn(64, 64, 3, 3, generator=g) * (2.0 / 576) ** 0.5).to(dev))
+    b2 = torch.nn.Parameter((torch.randn(64, generator=g) * 0.1).to(dev))
+    w1q, w2q = w1.detach().bfloat16().float(), w2.detach().bfloat16().float()
+    buckets = sink([avg, w1, b1, w2, b2])
+    assert nets.prepack([w2], force=True) == 2
+    l1, l2 = nets._GradLink(), nets._GradLink()
+    y1 = nets._FirstConv.apply(img, avg, w1, b1, torch.bfloat16, l1)
+    a = nets._ConvBiasPoolReLU.apply(y1, w2, b2, l1, l2)
+    assert a.grad_fn.by_idx and l1.first is not None
+    idx = a.grad_fn.saved_tensors[2]
+    ga = torch.randn(a.shape, generator=g).to(dev).bfloat16().contiguous(memory_format=CL)
+    ga = torch.where(a.detach() > 0, ga, torch.zeros_like(ga)).contiguous(memory_format=CL)
+    l2.mark(ga)
+    buckets.zero()
+    a.backward(ga)
+    buckets.finish()
+    torch.cuda.synchronize()
+    assert takes == [True, True]                    # both layers took what the layer above handed down
+    x0 = (img - avg.detach()).bfloat16().permute(0, 3, 1, 2)
+    gw1 = torch.zeros(w1.shape, dtype=torch.float64, device=dev)
+    gb1 = torch.zeros(64, dtype=torch.float64, device=dev)
+    davg = torch.zeros(3, dtype=torch.float64, device=dev)
+    gb1_abs = torch.zeros(64, dtype=torch.float64, device=dev)
+    for lo in range(0, B, 2):
+        sl = slice(lo, lo + 2)
+        gz2 = torch.zeros(2, 64, h, w, dtype=torch.float32, device=dev)
+        for k in range(4):
+            gz2[:, :, (k >> 1)::2, (k & 1)::2] = torch.where(idx[sl] == k, ga[sl], torch.zeros_like(ga[sl])).float()
+        gz1 = F.conv_transpose2d(gz2, w2q, padding=1)
+        gz1 = torch.where(y1.detach()[sl] > 0, gz1, torch.zeros_like(gz1)).bfloat16().float()
+        gw1 += torch.nn.grad.conv2d_weight(x0[sl].float(), w1q.shape, gz1, padding=1).double()
+        gb1 += gz1.double().sum(dim=(0, 2, 3))
+        gb1_abs += gz1.double().abs().sum(dim=(0, 2, 3))
+        davg -= F.conv_transpose2d(gz1, w1q, padding=1).double().sum(dim=(0, 2, 3))
+        del gz2, gz1
+    err = _rel_f32(w1.grad, gw1.float(), '1_1 weight gradient out of the conv1_2 backward kernel', gate=2e-3)
+    assert err < GATE, err
+    assert float((b1.grad.double() - gb1).abs().max()) < 2e-4 * float(gb1_abs.max())
+    assert float((avg.grad.double() - davg).abs().max()) < 5e-3 * float(davg.abs().max()) + 1e-2
