@@ -38,6 +38,7 @@ def main():
     ap.add_argument('--batch', type=int, default=24)
     ap.add_argument('--height', type=int, default=480)
     ap.add_argument('--width', type=int, default=640)
+    ap.add_argument('--stamps', action='store_true', help='in-kernel clock stamps of waves 0 and 7 (variant 61064 + 128 w)')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     lib = L.load()
@@ -67,6 +68,46 @@ def main():
         finally:
             lib.scl_debug_set_variant(0)
         print('variant %5d  %-26s %.1f us' % (var, what, t))
+    if args.stamps:
+        for wave in (0, 7):
+            print_stamps(stamps(lib, ga, idx, w2, y1, x0, w1, wave), wave)
+
+
+def stamps(lib, ga, idx, w2, y1, x0, w1, wave):
+    """One fused launch under variant 61064 + 128 * wave; returns the [workgroups][4 tiles][10] stamps."""
+    dev = y1.device
+    b, _, h, w = y1.shape
+    gw1 = torch.empty(64, 3, 3, 3, device=dev)
+    gb1 = torch.empty(64, device=dev)
+    davg = torch.empty(3, device=dev)
+    ws = L.workspace(lib.scl_conv3x3_workspace_bytes(), dev)
+    fws = torch.zeros(lib.scl_conv_first_wrw_workspace_bytes(), dtype=torch.uint8, device=dev)
+    s2, s1 = w2.stride(), gw1.stride()
+    lib.scl_debug_set_variant(61064 + 128 * wave)
+    try:
+        L.check(lib.scl_conv3x3_masked_pooled_first_wrw(
+            L.ptr(ga), L.ptr(idx), L.ptr(w2), s2[0], s2[1], s2[2], s2[3], L.W_F32, b, h, w, L.ptr(y1), L.ptr(x0),
+            L.ptr(gw1), s1[0], s1[1], s1[2], s1[3], 1, L.ptr(gb1), L.ptr(w1), L.ptr(davg), L.ptr(ws),
+            ws.numel(), L.ptr(fws), fws.numel(), L.stream_of(y1)))
+        torch.cuda.synchronize()
+    finally:
+        lib.scl_debug_set_variant(0)
+    st = fws.view(torch.int64)[1024 * 2048 // 2:1024 * 2048 // 2 + 256 * 4 * 12].view(256, 4, 12)[:, :, :10]
+    return st.cpu().numpy()
+
+
+def print_stamps(st, wave):
+    import numpy as np
+    names = ['K loop', 'own loads landed', 'barrier 1', 'epilogue rows -> LDS', 'barrier 2', 'im2col',
+             'barrier 3', 'products + partial + x0 store', 'barrier 4']
+    ok = st[:, :, 0] > 0
+    d = np.diff(st.astype(np.int64), axis=2)                    # [wg][tile][9]
+    tile = (st[:, :, 9] - st[:, :, 0])
+    print('wave %d: cycles per interval, median over %d (workgroup, tile) samples (tiles 2..5 of each workgroup)'
+          % (wave, int(ok.sum())))
+    for k, n in enumerate(names):
+        print('  %-32s %8.0f' % (n, float(np.median(d[:, :, k][ok]))))
+    print('  %-32s %8.0f' % ('whole tile', float(np.median(tile[ok]))))
 
 
 if __name__ == '__main__':

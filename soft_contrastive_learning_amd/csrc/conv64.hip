@@ -340,7 +340,8 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
   // (experiment, 60004: static priority for the younger half of an eight-wave workgroup)
   if ((dbg & 4) && (threadIdx.x >> 6) >= 4) __builtin_amdgcn_s_setprio(1);
   // FW: this thread's two elements of a tile's x0 window (340 pixels x 3 channels)
-  unsigned xreg = 0u;                  // (both elements in ONE register: it lives across the K loop)
+  unsigned short xreg[FW ? 2 : 1];     // (two registers, written by the loads and by nothing else: packed into
+                                       // one the shift / or had to wait for the load right behind it)
   // (thread index through an opaque copy per call: its quotients by 3 and 34 must not be hoisted
   // out of the tile loop — the K loop has no register for them)
   auto xwin_load = [&](int tile_) {
@@ -354,8 +355,7 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
       const int pix = idx / 3, c = idx - 3 * pix;
       const int y = ty_ - 1 + pix / WC, xx = tx_ - 1 + pix % WC;
       const bool ok = idx < 3 * WR * WC && y >= 0 && y < H && xx >= 0 && xx < W;
-      const unsigned e = ok ? (unsigned)fx0[(((int64_t)b_ * H + y) * W + xx) * 3 + c] : 0u;
-      xreg = v == 0 ? e : (xreg | (e << 16));
+      xreg[v] = ok ? fx0[(((int64_t)b_ * H + y) * W + xx) * 3 + c] : (unsigned short)0;
     }
   };
   auto xwin_store = [&](int par) {
@@ -365,7 +365,7 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
     for (int v = 0; v < 2; ++v) {
       const int idx = v * Cfg::NTHR + tid2;
       const int pix = idx / 3, c = idx - 3 * pix;
-      if (idx < 3 * WR * WC) xwl[par * FXW + pix * 4 + c] = (unsigned short)(v == 0 ? xreg & 0xffffu : xreg >> 16);
+      if (idx < 3 * WR * WC) xwl[par * FXW + pix * 4 + c] = xreg[v];
     }
   };
   int tile = blockIdx.x;
@@ -379,6 +379,16 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
     }
   }
   int xpar = 0;
+  // dbg & 64 (scl_debug_set_variant(61064), FW only): wave `dbg >> 7` of every workgroup writes
+  // s_memtime stamps of its tiles 2 .. 5 behind the slabs ([workgroup][tile][12] at float offset
+  // 1024 * 2048 of the workspace): 0 tile start, 1 K loop done, 2 own loads landed, 3 barrier 1
+  // passed, 4 epilogue rows in LDS, 5 barrier 2, 6 im2col built, 7 barrier 3, 8 products done,
+  // 9 barrier 4 (scripts/first_wrw_fused_ablate.py --stamps)
+  uint64_t fstamp[10];
+  int ftile = 0;
+#define FW_STAMP(k)                                                                     \
+  if (FW && (dbg & 64))                                                                 \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(fstamp[k])::"memory")
   if (tile < ntiles) {
     if (PL) {
 #pragma unroll
@@ -395,6 +405,7 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
   __syncthreads();
   int buf = 0;
   for (; tile < ntiles; tile += gridDim.x) {
+    FW_STAMP(0);
     const int next = (dbg & 1) ? ntiles : tile + gridDim.x;
     if (next < ntiles) {                                 // lands under the whole K loop
       if (PL) pool_issue(next, 0); else stage_issue(next, buf ^ 1);
@@ -459,9 +470,12 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
 
     // this wave's share of the next window has landed (waited for here, before the epilogue's
     // own stores join the queue); the barrier below publishes it
+    FW_STAMP(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    FW_STAMP(2);
     if (FW) {
       __syncthreads();             // every wave is done with the window: its buffer takes the tile
+      FW_STAMP(3);
       // the next tile's x0 window: requested here, stored behind the products below.  (Requested
       // at the top of the tile instead — its one register alive across the K loop — the kernel
       // measured 844 us against 765: profiles/r05/first_wrw_fused_notes.txt)
@@ -527,7 +541,9 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
       }
     }
     if (FW) {
+      FW_STAMP(4);
       __syncthreads();             // the whole masked tile is in LDS; the epilogue scratch is dead
+      FW_STAMP(5);
       // (the thread's / lane's roles are re-derived per tile from opaque copies: hoisted out of
       // the tile loop they stay live across the K loop, which has no register left)
       int tid2 = threadIdx.x;
@@ -557,7 +573,9 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
         *reinterpret_cast<u32x4*>(imc + (s_ * 32 + n) * 16 + 8 * hh) =
             u32x4{e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16)};
       }
+      FW_STAMP(6);
       __syncthreads();
+      FW_STAMP(7);
       // 2. the products: wave (mt, pq), steps 4 pq .. 4 pq + 3
       int lane2 = lane, wid2 = wid;
       asm volatile("" : "+v"(lane2), "+v"(wid2));
@@ -587,6 +605,7 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
             f32x4_{dacc[4 * v], dacc[4 * v + 1], dacc[4 * v + 2], dacc[4 * v + 3]};
       if (next < ntiles) xwin_store(xpar ^ 1);
       xpar ^= 1;
+      FW_STAMP(8);
     }
     if (EPI == 2 || EPI == 4) {
       // 2x2 / stride 2 max-pool of the raw outputs, lane-local: rows mt, mt + 1 are two
@@ -625,8 +644,19 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
     }
 
     __syncthreads();
+    if (FW && (dbg & 64)) {
+      FW_STAMP(9);
+      if ((int)threadIdx.x == 64 * (dbg >> 7) && ftile >= 2 && ftile < 6) {
+        uint64_t* o = reinterpret_cast<uint64_t*>(fslabs + (size_t)1024 * 2048) +
+                      ((int64_t)blockIdx.x * 4 + (ftile - 2)) * 12;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) o[k] = fstamp[k];
+      }
+      ++ftile;
+    }
     buf ^= 1;
   }
+#undef FW_STAMP
   if (FW) {
     // slab [64 ch][32 cols] of the workgroup = the four pixel quarters in a fixed order; the
     // partials pass through the (free) window buffers as [pq][64][32]
@@ -2228,7 +2258,7 @@ extern "C" int scl_conv3x3_masked_pooled_first_wrw(
   SCL_LAUNCH("conv3x3_kernel<pooled,first_wrw>", (conv3x3_kernel<64, 64, 3, 1, 1>), dim3(grid),
              dim3(Cfg::NTHR), kLds, st, (const unsigned short*)g_pooled, packed, B, H, W,
              (unsigned short*)nullptr, (const float*)nullptr,
-             scl_variant() / 1000 == 61 ? (scl_variant() & 63) << 1 : 0,       // timing ablations (diagnostic build)
+             scl_variant() / 1000 == 61 ? (scl_variant() % 1000) << 1 : 0,     // timing ablations / stamps (diagnostic build)
              (unsigned short*)x0, (const unsigned short*)mask, (unsigned char*)fw_workspace,
              (const unsigned char*)pool_idx);
   SCL_LAUNCH("conv_first_wrw_reduce_kernel", conv_first_wrw_reduce_kernel, dim3(32), dim3(256), 0,
