@@ -988,6 +988,11 @@ def main():
             dist.all_reduce(flag)
             nets.USE_SIDE_WRW = bool(flag.item() * 2 >= world)
             side_choice['chosen'] = nets.USE_SIDE_WRW
+            if nets._FFW_ENV == 'auto':      # (and the fused first-layer gradients, which go with it)
+                flag = torch.tensor([1.0 if side_choice.get('fused_first_wrw') else 0.0], device=dev)
+                dist.all_reduce(flag)
+                nets.USE_FUSED_FIRST_WRW = nets.USE_SIDE_WRW and bool(flag.item() * 2 >= world)
+                side_choice['fused_first_wrw'] = nets.USE_FUSED_FIRST_WRW
         fence()
     # One step captured in a HIP graph and replayed: the step is ~125 dependent launches, and
     # the launch gaps between them cost ~0.3 ms of a 14 ms step when issued one by one.  The

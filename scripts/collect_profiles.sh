@@ -1,7 +1,7 @@
 # Regenerates everything under profiles/rNN from one GPU box (run through gpurun; results land in
 # gpurun_out/rNN and are copied into profiles/rNN by hand).  Usage: bash scripts/collect_profiles.sh r03
 set -x
-RN=${1:-r04}
+RN=${1:-r05}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$RN; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 python3 $R/bench.py --steps 20 --warmup 5 > $O/bench_n1_default_run.json 2> $O/bench.err
@@ -34,6 +34,10 @@ python3 scripts/netvlad_accuracy_probe.py > $O/netvlad_two_plane_accuracy.txt 2>
 python3 scripts/lds_conflicts.py > $O/lds_conflicts.txt 2>/dev/null
 python3 scripts/conv_ab.py --rounds 2 > $O/conv_lds_kernels_32x32x16_vs_16x16x32.jsonl 2>/dev/null
 python3 scripts/conv_layers.py > $O/conv_layers_own_vs_library.txt 2>/dev/null
+# round 5: wrw64 staging A/B, the fused first-layer gradients (ablations + stamps, step A/B)
+python3 scripts/wrw_ab.py --variants 0,2200 --rounds 2 > $O/wrw64_buffer_path_vs_round4_staging_same_box.txt 2>/dev/null
+python3 scripts/first_wrw_fused_ablate.py --stamps > $O/first_wrw_fused_ablations_and_stamps.txt 2>/dev/null
+bash scripts/env_ab.sh SCL_FUSED_FIRST_WRW 2 > $O/fused_first_wrw_step_ab.txt 2>/dev/null
 python3 scripts/trace_summary.py $O/trace --steps 8 --out $O/bench_n1_steady_state_per_step.csv > $O/trace_summary.log 2>&1
 python3 scripts/trace_summary.py $O/trace1 --steps 8 --out $O/bench_n1_one_stream_per_step.csv >> $O/trace_summary.log 2>&1
 python3 scripts/pmc_summary.py $O/pmc_nv --only kernel --out $O/pmc_netvlad_loss_b24_n1200.csv > /dev/null 2>&1

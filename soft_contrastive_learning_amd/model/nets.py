@@ -620,7 +620,17 @@ USE_F32_WEIGHTS = os.environ.get('SCL_F32_WEIGHTS', '1') != '0'
 # Round 5: conv1_2's backward-data kernel keeps its output tile in LDS and multiplies it with the
 # im2col of x0 right there (scl_conv3x3_masked_pooled_first_wrw): the 944 MB gradient map at
 # conv1_1's pre-activation is neither written nor read, conv_first_wrw_kernel is not launched.
-USE_FUSED_FIRST_WRW = os.environ.get('SCL_FUSED_FIRST_WRW', '1') != '0'
+# As a kernel it is slower than the two it replaces; the step gains where the weight-gradient
+# kernels run on the second stream next to it (they no longer compete with 1.9 GB of traffic):
+# 'auto' (default) = with the second stream (autotune_side_wrw decides both per device), 1 / 0 pin it.
+_FFW_ENV = os.environ.get('SCL_FUSED_FIRST_WRW', 'auto')
+USE_FUSED_FIRST_WRW = None if _FFW_ENV == 'auto' else _FFW_ENV != '0'
+
+
+def _fused_first_wrw_wanted():
+    if USE_FUSED_FIRST_WRW is None:
+        return bool(USE_SIDE_WRW) and GRAD_SINK is not None
+    return bool(USE_FUSED_FIRST_WRW)
 # conv1_1 and conv1_2 of the forward pass in one kernel (scl_conv_first_pool_idx): bit-identical
 # to the two-kernel path and 1.25 GB less read per step, but SLOWER as built (776 against 243 + 480
 # us on one box, profiles/r04/first_block_one_kernel_vs_two.txt): conv1_2's kernel sits at 256
@@ -691,13 +701,20 @@ def autotune_side_wrw(step, steps=3, rounds=2):
     MI355X boxes and costs +1.4 % on others (profiles/r02/README.md): the clocks the two settings
     hold differ from device to device, so a fixed default loses on part of the pool.  Gradients are
     bit-identical either way.  Returns {'chosen': bool, 'ms_on': .., 'ms_off': ..}."""
-    global USE_SIDE_WRW
+    global USE_SIDE_WRW, USE_FUSED_FIRST_WRW
     if not torch.cuda.is_available():
         return {'chosen': USE_SIDE_WRW, 'ms_on': None, 'ms_off': None}
-    best = {True: float('inf'), False: float('inf')}
+    # Round 5: the fused first-layer gradients (USE_FUSED_FIRST_WRW) pay only next to the second
+    # stream; unless pinned by SCL_FUSED_FIRST_WRW the three settings (one stream / two streams /
+    # two streams + fused) are timed together and the fastest kept.
+    fused_free = _FFW_ENV == 'auto'
+    settings = [(False, False), (True, False)] + ([(True, True)] if fused_free else [])
+    if not fused_free:
+        settings = [(False, bool(USE_FUSED_FIRST_WRW)), (True, bool(USE_FUSED_FIRST_WRW))]
+    best = {st: float('inf') for st in settings}
     for _ in range(rounds):
-        for mode in (False, True):
-            USE_SIDE_WRW = mode
+        for st in settings:
+            USE_SIDE_WRW, USE_FUSED_FIRST_WRW = st
             step()                                          # settle into the mode
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -706,9 +723,16 @@ def autotune_side_wrw(step, steps=3, rounds=2):
                 step()
             e1.record()
             torch.cuda.synchronize()
-            best[mode] = min(best[mode], e0.elapsed_time(e1) / steps)
-    USE_SIDE_WRW = best[True] <= best[False]
-    return {'chosen': USE_SIDE_WRW, 'ms_on': round(best[True], 3), 'ms_off': round(best[False], 3)}
+            best[st] = min(best[st], e0.elapsed_time(e1) / steps)
+    pick = min(settings, key=lambda st: (best[st], st))
+    USE_SIDE_WRW, USE_FUSED_FIRST_WRW = pick
+    on = min(best[st] for st in settings if st[0])
+    out = {'chosen': USE_SIDE_WRW, 'ms_on': round(on, 3), 'ms_off': round(best[settings[0]], 3),
+           'fused_first_wrw': bool(USE_FUSED_FIRST_WRW)}
+    if fused_free:
+        out['ms_on_fused_first_wrw'] = round(best[(True, True)], 3)
+        out['ms_on_two_kernels'] = round(best[(True, False)], 3)
+    return out
 
 
 def _wrw_maybe_async(x, gz, w, gb, pool_idx=None):
@@ -797,7 +821,7 @@ def _conv3x3_backward(gz, x, w, need_x, link=None, gb=None, pooled=None):
             return _wrw_maybe_async(x, ga, w, gb, pool_idx=idx)
         return _wrw_maybe_async(x, gz, w, gb)
     if own_gx and need_x and link is not None and USE_MASKED_BWD:
-        if (gz is None and USE_FUSED_FIRST_WRW and link.first is not None and own_gw
+        if (gz is None and _fused_first_wrw_wanted() and link.first is not None and own_gw
                 and tuple(w.shape) == (64, 64, 3, 3) and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0):
             # x is conv1_1's output: its gradient map has ONE consumer, the first layer's weight /
             # bias / mean gradient — computed here, the map itself never exists.  What autograd

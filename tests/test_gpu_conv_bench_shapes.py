@@ -342,7 +342,7 @@ def test_first_block_backward_at_bench_shape(dev, sink, takes):
     window index (validated in test_layer_at_bench_shape[1_2]) for the un-pooling, the gradient at
     conv1_1's pre-activation rounded to bf16 where the kernel rounds it."""
     from soft_contrastive_learning_amd.model import nets
-    assert nets.USE_FUSED_FIRST_WRW
+    assert nets.USE_FUSED_FIRST_WRW is None and nets.USE_SIDE_WRW     # 'auto': on with the sink + second stream
     h, w = 480, 640
     g = torch.Generator().manual_seed(177)
     img = torch.randint(0, 256, (B, h, w, 3), generator=g).float().to(dev)
