@@ -1081,7 +1081,13 @@ def main():
             el = float(tt)
         return el / k * 1e3
 
-    telemetry = gpu_telemetry(step, fence) if rank == 0 and world == 1 and not args.no_telemetry else None
+    # (not under rocprofv3: its preloaded library initialises the GPU in every child process, and
+    # rocm-smi's `#!/usr/bin/env python3` hop is then an exec after GPU initialisation, which the
+    # GPU boxes of this pool refuse)
+    profiled = 'rocprof' in os.environ.get('LD_PRELOAD', '').lower() or any(
+        k.startswith(('ROCPROF', 'ROCPROFILER')) for k in os.environ)
+    telemetry = (gpu_telemetry(step, fence)
+                 if rank == 0 and world == 1 and not args.no_telemetry and not profiled else None)
     comm = None
     if world > 1:
         # what the first multi-GPU run must be able to explain by itself

@@ -8,12 +8,12 @@ python3 $R/bench.py --steps 20 --warmup 5 > $O/bench_n1_default_run.json 2> $O/b
 python3 $R/bench.py --steps 20 --warmup 5 --side-wrw 0 --no-cpu-baseline > $O/bench_n1_one_stream.json 2>> $O/bench.err
 # kernel trace of the default command, and of the one-stream run (the durations of `roofline`
 # are taken with the weight-gradient kernels serialised: compare with the second table)
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-batch-sweep --no-retrieval > $O/bench_under_rocprof.json 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace1 -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-batch-sweep --no-retrieval --side-wrw 0 > $O/bench_under_rocprof_one_stream.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-batch-sweep --no-retrieval --no-telemetry > $O/bench_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace1 -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-batch-sweep --no-retrieval --no-telemetry --side-wrw 0 > $O/bench_under_rocprof_one_stream.json 2>/dev/null
 # HBM traffic of the backbone kernels (separate passes per counter, no tracing)
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_bb/fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-batch-sweep --no-retrieval --side-wrw 0 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_bb/write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-batch-sweep --no-retrieval --side-wrw 0 > /dev/null 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc_bb/sq -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-batch-sweep --no-retrieval --side-wrw 0 > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_bb/fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-batch-sweep --no-retrieval --no-telemetry --side-wrw 0 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_bb/write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-batch-sweep --no-retrieval --no-telemetry --side-wrw 0 > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc_bb/sq -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-batch-sweep --no-retrieval --no-telemetry --side-wrw 0 > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc_nv/sq -- python3 $R/scripts/microbench.py --what netvlad,loss --iters 3 --loss-batches 24,192 > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_nv/fetch -- python3 $R/scripts/microbench.py --what netvlad,loss --iters 3 --loss-batches 24,192 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_nv/write -- python3 $R/scripts/microbench.py --what netvlad,loss --iters 3 --loss-batches 24,192 > /dev/null 2>&1
