@@ -339,6 +339,45 @@ def bracket_us(dev, n=100):
     return max(0.0, us[len(us) // 2] - NULL_KERNEL_DEVICE_US) if us else 0.0
 
 
+def sustained_mfma(dev, launches=8, iters=2000):
+    """What this device sustains on a bare LDS-fed bf16 MFMA loop (csrc/calibrate.hip,
+    scl_calibrate_mfma_bf16: one 512-thread workgroup per CU, [128 x 64] accumulators per wave, no
+    global traffic, random operands), timed here — right after the steps, chip warm — with one event
+    pair around `launches` back-to-back launches of ~1.4 ms each.  The datasheet figure `roofline`
+    is priced against assumes 2.4 GHz; under the 1.3-1.4 kW cap the matrix cores run at 2.0-2.2 GHz,
+    and boxes differ: this is the ceiling of THIS box in THIS run."""
+    import ctypes
+    from soft_contrastive_learning_amd import _lib
+    lib = _lib.load()
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    ops = (torch.rand(32768, device=dev) * 2 - 1).to(torch.bfloat16)           # 64 KB
+    sink = torch.zeros(cus, device=dev, dtype=torch.float32)
+    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    out = {}
+    for shape, key in ((32, 'tflops_32x32x16'), (16, 'tflops_16x16x32')):
+        def go():
+            rc = lib.scl_calibrate_mfma_bf16(shape, cus, iters, ctypes.c_void_p(ops.data_ptr()),
+                                             ctypes.c_void_p(sink.data_ptr()), st)
+            if rc != 0:
+                raise RuntimeError('scl_calibrate_mfma_bf16: %d' % rc)
+        for _ in range(3):
+            go()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(launches):
+            go()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        ms = e0.elapsed_time(e1) / launches
+        out[key] = round(lib.scl_calibrate_mfma_bf16_flops(cus, iters) / (ms * 1e-3) / 1e12, 1)
+    out['workgroups'] = cus
+    out['ms_per_launch'] = round(ms, 3)
+    out['how'] = ('bare bf16 MFMA loop fed from LDS (scl_calibrate_mfma_bf16: 512 threads per CU, random '
+                  'operands, no global traffic), %d launches back to back between one event pair, in this '
+                  'process right after the steps' % launches)
+    return out
+
+
 def price(name, launches, mean_ms, model):
     events_ms = mean_ms
     mean_ms = max(mean_ms - BRACKET_US * 1e-3, (1.0 - BRACKET_CAP) * mean_ms)
@@ -1173,6 +1212,15 @@ def main():
                                                 '(profiles/pmc_traffic.json: %s)' % pmc.get('source', '?'))
             except (OSError, ValueError, KeyError):
                 pass
+        if roofline and roofline['bound'] == 'mfma' and roofline['kernel'] in work:
+            try:
+                sus = sustained_mfma(dev)
+                top = max(sus['tflops_32x32x16'], sus['tflops_16x16x32'])
+                sus['frac_of_sustained'] = round(roofline['achieved'] / top, 4)
+                sus['sustained_over_peak'] = round(top / roofline['peak'], 4)
+                roofline['sustained'] = sus
+            except (RuntimeError, AttributeError) as e:
+                roofline['sustained'] = {'error': str(e)}
         hip_ms = sum(r['us'] * r['launches'] for r in kernels) / 1e3 / max(prof_steps, 1)
         out = {
             'metric': 'train-step images/sec (VGG16-NetVLAD soft-MS, 640x480)',

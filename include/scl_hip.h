@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define SCL_ABI_VERSION 11
+#define SCL_ABI_VERSION 12
 
 /* error codes (negative = rejected before any launch) */
 #define SCL_OK 0
@@ -554,6 +554,17 @@ int scl_conv_pack_batch(const SclPackJob* jobs, int njobs, void* stream);
  * one sink at a time.  scl_prof_end waits for them and returns per-launch milliseconds and
  * kernel names (static strings); call it once the launching threads are quiescent.
  * ------------------------------------------------------------------------- */
+/* Device calibration (csrc/calibrate.hip): a bare bf16 MFMA loop — `workgroups` workgroups of 512
+ * threads, each wave a [128 x 64] accumulator block fed from LDS, `iters` 32-deep k-steps, no global
+ * traffic — on `shape` = 32 (v_mfma_f32_32x32x16_bf16) or 16 (v_mfma_f32_16x16x32_bf16).
+ * `operands`: 64 KB of bf16 values (16-byte aligned; random values: zeros draw less power and
+ * over-state what the device sustains); `sink`: `workgroups` floats (one checksum each).  No
+ * counterpart in the reference: bench.py times it beside the convolution kernels so that the
+ * datasheet peak its `roofline` is priced against comes with what this device, at its power cap,
+ * sustains (`roofline.sustained`).  scl_calibrate_mfma_bf16_flops = the FLOPs one launch executes. */
+int scl_calibrate_mfma_bf16(int shape, int workgroups, int iters, const void* operands, float* sink,
+                            void* stream);
+double scl_calibrate_mfma_bf16_flops(int workgroups, int iters);
 /* 1 for libscl_hip_diag.so (-DSCL_DIAG), 0 for the product library. */
 int scl_build_is_diag(void);
 /* Ablation / tuning switch (scripts/ablate_rowtile.py, scripts/microbench.py) of the DIAGNOSTIC
@@ -579,6 +590,8 @@ int scl_build_is_diag(void);
  *                 to the four launches of the product path; measured slower)
  *   2200          weight-gradient kernel: round 4's staging without the buffer-resource path
  *                 (CORRECT results: A/B partner)
+ *   2300          weight-gradient kernel: every 32x32x16 product issued as two 16x16x32 MFMAs on the
+ *                 same registers (timing only: would the other MFMA shape pay here?  It does not)
  *   100000 * s    Gram loss, B <= 256: force s K-splits
  *   100 + s       top-n: force s reference splits (1..32) instead of the planner's choice
  *   1000 * b (+ 100 + s)   top-n scan: b bit 0 no selection, bit 1 no tile staging,

@@ -98,8 +98,8 @@ def stamps(lib, ga, idx, w2, y1, x0, w1, wave):
 
 def print_stamps(st, wave):
     import numpy as np
-    names = ['K loop', 'own loads landed', 'barrier 1', 'epilogue rows -> LDS', 'barrier 2', 'im2col',
-             'barrier 3', 'products + partial + x0 store', 'barrier 4']
+    names = ['K loop (im2col inside)', 'own loads landed', 'barrier 1', 'masked rows -> LDS planes', 'barrier 2',
+             '(empty)', '(empty)', 'products + partial + x0 store', 'barrier 3']
     ok = st[:, :, 0] > 0
     d = np.diff(st.astype(np.int64), axis=2)                    # [wg][tile][9]
     tile = (st[:, :, 9] - st[:, :, 0])

@@ -21,7 +21,7 @@ LIB_PATH = os.path.join(_HERE, "libscl_hip.so")
 DIAG_LIB_PATH = os.path.join(_HERE, "libscl_hip_diag.so")
 
 # constants of include/scl_hip.h
-ABI_VERSION = 11
+ABI_VERSION = 12
 DT_F32, DT_BF16 = 0, 1
 MASK_WMS_EXP, MASK_WMS_LIN, MASK_WMS_TANH, MASK_LABELS = 0, 1, 2, 3
 SUM_MS, SUM_PLAIN = 0, 1
@@ -124,6 +124,8 @@ SIGNATURES = {
                                                  _l, _l, _l, _i, _p, _p, _p, _p, _z, _p, _z, _p]),
     "scl_debug_set_variant": (_i, [_i]),
     "scl_build_is_diag": (_i, []),
+    "scl_calibrate_mfma_bf16": (_i, [_i, _i, _i, _p, _p, _p]),
+    "scl_calibrate_mfma_bf16_flops": (ctypes.c_double, [_i, _i]),
     "scl_set_reserve_cus": (_i, [_i]),
     "scl_get_reserve_cus": (_i, []),
     "scl_prof_begin": (_i, [_i]),

@@ -1026,7 +1026,20 @@ __global__ __launch_bounds__(512, 1) void wrw64_kernel(const unsigned short* __r
                   __builtin_amdgcn_alignbit(f.hi.y, f.hi.x, 16), __builtin_amdgcn_alignbit(f.ex.x, f.hi.y, 16)};
       else
         a = u32x4{f.lo.y, f.hi.x, f.hi.y, f.ex.x};
-      acc[i % 9] = mfma32b(a, bf[s_ & 1], acc[i % 9]);
+      if constexpr ((DBG & 16) != 0) {
+        // timing ablation (RESULTS MEANINGLESS): the same FLOPs, operand registers and accumulator
+        // registers on v_mfma_f32_16x16x32_bf16 — what would the other MFMA shape be worth here?
+        f32x16& c_ = acc[i % 9];
+        const int o_ = 8 * (i & 1);
+        f32x4_ q0 = {c_[o_], c_[o_ + 1], c_[o_ + 2], c_[o_ + 3]};
+        f32x4_ q1 = {c_[o_ + 4], c_[o_ + 5], c_[o_ + 6], c_[o_ + 7]};
+        q0 = mfma16b(a, bf[s_ & 1], q0);
+        q1 = mfma16b(a, bf[s_ & 1], q1);
+        c_[o_] = q0[0]; c_[o_ + 1] = q0[1]; c_[o_ + 2] = q0[2]; c_[o_ + 3] = q0[3];
+        c_[o_ + 4] = q1[0]; c_[o_ + 5] = q1[1]; c_[o_ + 6] = q1[2]; c_[o_ + 7] = q1[3];
+      } else {
+        acc[i % 9] = mfma32b(a, bf[s_ & 1], acc[i % 9]);
+      }
       if (i == 8) WRW_STAMP(2);
       if (i == 35) WRW_STAMP(3);
       if (i == 71) WRW_STAMP(4);
@@ -1997,6 +2010,7 @@ static int wrw3x3_run(const void* x, const void* gz, const unsigned char* pidx, 
     SCL_WRW_ATTR(6, 32, 2, 0) SCL_WRW_ATTR(6, 8, 2, 0)
 #ifdef SCL_DIAG
     SCL_WRW_ATTR(8, 32, 2, 0) SCL_WRW_ATTR(8, 8, 2, 0) SCL_WRW_ATTR(8, 32, 2, 1) SCL_WRW_ATTR(8, 8, 2, 1)
+    SCL_WRW_ATTR(16, 32, 2, 0) SCL_WRW_ATTR(16, 8, 2, 0) SCL_WRW_ATTR(16, 32, 2, 1) SCL_WRW_ATTR(16, 8, 2, 1)
 #endif
 #undef SCL_WRW_ATTR
   });
@@ -2041,6 +2055,13 @@ static int wrw3x3_run(const void* x, const void* gz, const unsigned char* pidx, 
       if (tall) SCL_WRW_LAUNCH(8, 8, 2, 1); else SCL_WRW_LAUNCH(8, 32, 2, 1);
     } else {
       if (tall) SCL_WRW_LAUNCH(8, 8, 2, 0); else SCL_WRW_LAUNCH(8, 32, 2, 0);
+    }
+  } else if (nkb == 2 && scl_variant() == 2300) {   // 16x16x32 timing ablation: RESULTS MEANINGLESS
+    PP = wrw_splits(cin, kout / 2, tiles, cus);
+    if (pidx) {
+      if (tall) SCL_WRW_LAUNCH(16, 8, 2, 1); else SCL_WRW_LAUNCH(16, 32, 2, 1);
+    } else {
+      if (tall) SCL_WRW_LAUNCH(16, 8, 2, 0); else SCL_WRW_LAUNCH(16, 32, 2, 0);
     }
   } else
 #endif
@@ -2255,7 +2276,7 @@ extern "C" int scl_conv3x3_masked_pooled_first_wrw(
   const int grid = tiles < cus ? tiles : cus;
   float* aux = (float*)fw_workspace + (size_t)2 * 1024 * 2048;
   const unsigned short* corners = (const unsigned short*)((float*)fw_workspace + (size_t)1536 * 2048);
-  SCL_LAUNCH("conv3x3_kernel<pooled,first_wrw>", (conv3x3_kernel<64, 64, 3, 1, 1>), dim3(grid),
+  SCL_LAUNCH("conv3x3_kernel<pooled+first_wrw>", (conv3x3_kernel<64, 64, 3, 1, 1>), dim3(grid),
              dim3(Cfg::NTHR), kLds, st, (const unsigned short*)g_pooled, packed, B, H, W,
              (unsigned short*)nullptr, (const float*)nullptr,
              scl_variant() / 1000 == 61 ? (scl_variant() % 1000) << 1 : 0,     // timing ablations / stamps (diagnostic build)

@@ -790,7 +790,7 @@ def _masked_pooled_first_wrw(ga, idx, w2, y1, first):
     ws = L.workspace(lib.scl_conv3x3_workspace_bytes(), y1.device)
     fws = L.workspace(lib.scl_conv_first_wrw_workspace_bytes(), y1.device)
     px = b * h * wd
-    _work('conv3x3_kernel<pooled,first_wrw>', 2.0 * px * (64 * 64 * 9 + 64 * 28), px * (0.75 * 64 + 2.0 * 64 + 6.0))
+    _work('conv3x3_kernel<pooled+first_wrw>', 2.0 * px * (64 * 64 * 9 + 64 * 28), px * (0.75 * 64 + 2.0 * 64 + 6.0))
     L.check(lib.scl_conv3x3_masked_pooled_first_wrw(
         L.ptr(ga), L.ptr(idx), wp, s2[0], s2[1], s2[2], s2[3], wflags, b, h, wd, L.ptr(y1), L.ptr(x0),
         L.ptr(gw1), s1[0], s1[1], s1[2], s1[3], int(gw1.dtype == torch.float32), L.ptr(gb1), L.ptr(w1c),

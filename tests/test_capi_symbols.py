@@ -66,7 +66,7 @@ def test_product_library_has_no_variants_and_the_diagnostic_build_does(lib):
 
 
 def test_abi_version_and_error_strings(lib):
-    assert lib.scl_abi_version() == 11
+    assert lib.scl_abi_version() == 12
     assert lib.scl_error_string(0) == b"ok"
     assert b"shape" in lib.scl_error_string(-1)
     assert b"NULL" in lib.scl_error_string(-3)
