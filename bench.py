@@ -963,7 +963,10 @@ def main():
     params = list(model.parameters())
     buckets = parallel.GradBuckets(params)
     # train/train.py:1270 base_lr; one fused kernel, step counter on the device (graph-safe)
-    opt = torch.optim.Adam(params, lr=5e-6, fused=True, capturable=bool(args.graph))
+    # tf.train.AdamOptimizer (train/train.py:870): torch's fused kernel with TF's epsilon placement
+    # (train/optim.py; under --graph the captured step keeps the eps of the capture)
+    from soft_contrastive_learning_amd.train.optim import TFAdam
+    opt = TFAdam(params, lr=5e-6, fused=True, capturable=bool(args.graph))
 
     # synthetic RobotCar-shaped batch, resident in HBM
     g = torch.Generator().manual_seed(42 + rank)

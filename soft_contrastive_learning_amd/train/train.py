@@ -37,6 +37,7 @@ import torch.distributed as dist
 
 from .. import checkpoint, parallel, pointnetvlad_cls
 from ..model import losses, nets
+from .optim import make_optimizer
 
 
 def make_parser():
@@ -510,10 +511,9 @@ def main(argv=None):
     feat_dim = 32768 if flags.vlad_cores == 64 else (flags.height // 16) * (flags.width // 16) * 512
     buckets = parallel.GradBuckets(params, group)
     nets.GRAD_SINK = buckets       # conv weight / bias gradients go straight into the flat buffer
-    if flags.optimizer == 'momentum':
-        opt = torch.optim.SGD(params, lr=flags.base_lr, momentum=flags.momentum)
-    else:
-        opt = torch.optim.Adam(params, lr=flags.base_lr, fused=bool(params) and params[0].is_cuda)
+    # train/train.py:865-870: MomentumOptimizer / AdamOptimizer — TF's Adam (epsilon outside the bias
+    # correction), not torch's: train/optim.py
+    opt = make_optimizer(flags.optimizer, params, flags.base_lr, flags.momentum)
     # restore_weights (:882-905) + the slot variables a tf.train.Saver checkpoint carries
     step = 0
     if flags.checkpoint:

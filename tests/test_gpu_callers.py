@@ -275,10 +275,12 @@ def test_checkpoint_resume_with_fused_adam_on_the_device(dev, tmp_path):
     from soft_contrastive_learning_amd.model import nets
     a = nets.VGG16NetVLAD(seed=5).to(dev)
     b = nets.VGG16NetVLAD(seed=6).to(dev)
-    oa = torch.optim.Adam(a.parameters(), lr=1e-3, fused=True)
-    ob = torch.optim.Adam(b.parameters(), lr=1e-3, fused=True)
+    from soft_contrastive_learning_amd.train.optim import TFAdam
+    oa = TFAdam(a.parameters(), lr=1e-3, fused=True)
+    ob = TFAdam(b.parameters(), lr=1e-3, fused=True)
     g = torch.Generator().manual_seed(0)
-    grads = [[torch.randn(p.shape, generator=g) * 1e-2 for p in a.parameters()] for _ in range(4)]
+    # gradients around epsilon / sqrt(1 - beta2^t): the step count decides the size of the update
+    grads = [[torch.randn(p.shape, generator=g) * 1e-7 for p in a.parameters()] for _ in range(4)]
     for k in range(3):
         for p, gr in zip(a.parameters(), grads[k]):
             p.grad = gr.to(dev)
@@ -293,8 +295,36 @@ def test_checkpoint_resume_with_fused_adam_on_the_device(dev, tmp_path):
             p.grad = gr.to(dev)
         o.step()
     torch.cuda.synchronize()
+    assert oa._t == ob._t == 4
     for pa, pb in zip(a.parameters(), b.parameters()):
         assert torch.equal(pa, pb)
+
+
+def test_fused_tf_adam_on_the_device_against_the_oracle(dev):
+    """A13 (train/train.py:870): the trainer's optimiser — torch's fused Adam kernel fed TF's
+    step-dependent epsilon (train/optim.py) — against oracle/adam_np.py's float32 restatement of
+    tf.train.AdamOptimizer over 40 steps of gradients spanning 1e-9 .. 1e-2."""
+    import numpy as np
+    from oracle import adam_np
+    from soft_contrastive_learning_amd.train.optim import TFAdam
+    rng = np.random.RandomState(11)
+    shapes = [(64, 3, 3, 3), (512, 64), (3,)]
+    lr = 5e-6
+    init = [rng.randn(*s).astype(np.float32) * 0.05 for s in shapes]
+    ref = [a.copy() for a in init]
+    st = adam_np.TFAdamState(shapes)
+    params = [torch.nn.Parameter(torch.from_numpy(a.copy()).to(dev)) for a in init]
+    opt = TFAdam(params, lr=lr, fused=True)
+    for _ in range(40):
+        gs = [(10.0 ** rng.uniform(-9, -2, s) * rng.choice([-1.0, 1.0], s)).astype(np.float32) for s in shapes]
+        adam_np.tf_adam_step(ref, gs, st, lr)
+        for p, g_ in zip(params, gs):
+            p.grad = torch.from_numpy(g_).to(dev)
+        opt.step()
+    for a0, r, p in zip(init, ref, params):
+        moved = np.abs(r - a0).max()
+        assert moved > 5 * lr
+        assert np.abs(p.detach().cpu().numpy() - r).max() < 5e-4 * moved
 
 
 def test_saver_records_the_reserved_cus(dev, tmp_path):

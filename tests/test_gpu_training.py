@@ -9,8 +9,8 @@ since round 5 every bf16 convolution is an own kernel — once `--dtype bf16`, o
 every image and queries from another traverse (an untrained net localises 30 % of them).
 
 Stated bands (measured: scripts/train_dtype_ab.py, profiles/r05/train_bf16_vs_f32_240x180.json —
-window means within 0.1 %, loss drop 0.0185 / 0.0197 over 200 steps, other-region %<25m@Top1
-32.5 -> 75 / 67.5):
+with the trainer's TensorFlow-form Adam (train/optim.py): window means within 0.08 %, loss drop
+0.0196 / 0.0176 over 200 steps, other-region %<25m@Top1 32.5 -> 70 / 60):
   * means of the training loss over windows of 25 steps: bf16 within 1 % of f32, every window;
   * the loss falls in both runs, by amounts within a factor of two of each other;
   * the localisation metric of train/evaluate.py on the OTHER region (%<25m@Top1) improves in both
