@@ -20,7 +20,10 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                the C library), priced on its governing roofline.  The events bracket every
                launch and cost ~6 % of a step, so they run over a few extra steps right after
                the K timed ones (`kernel_timing` says how many; SCL_BENCH_EVENTS_IN_TIMED_REGION=1
-               moves them into the timed region)
+               moves them into the timed region).  `roofline.sustained` (N=1): what THIS device
+               sustains on a bare LDS-fed bf16 MFMA loop at its power cap, timed in this process
+               (scl_calibrate_mfma_bf16) — `frac` is against the datasheet peak, `frac_of_sustained`
+               against that
   kernels      the same for every hand-written kernel on the path
   cpu_baseline the CPU restatement of the same step timed on the host cores (N=1 only)
   roofline_netvlad_stage   the NetVLAD head as ONE stage: SURVEY §8(d)'s algorithmic bytes and
@@ -1215,7 +1218,7 @@ def main():
                                                 '(profiles/pmc_traffic.json: %s)' % pmc.get('source', '?'))
             except (OSError, ValueError, KeyError):
                 pass
-        if roofline and roofline['bound'] == 'mfma' and roofline['kernel'] in work:
+        if world == 1 and roofline and roofline['bound'] == 'mfma' and roofline['kernel'] in work:
             try:
                 sus = sustained_mfma(dev)
                 top = max(sus['tflops_32x32x16'], sus['tflops_16x16x32'])
