@@ -9,6 +9,8 @@ twin for gradients) of the reference's hot-path arithmetic:
                                                         -> ``oracle.netvlad_np``
   * ``pointnetvlad_cls`` tuple losses                  -> ``oracle.losses_np``
   * ``evaluation/top-n.py:103-108`` exact L2 top-N      -> ``oracle.topn_np``
+  * ``tf.train.AdamOptimizer`` / ``MomentumOptimizer`` (train/train.py:865-878)
+                                                        -> ``oracle.adam_np``
 
 Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
 ``bench.py`` may import it, and only as the checker / the timed CPU baseline.  The
@@ -26,5 +28,7 @@ Third-party algorithms restated from their published sources:
   netvlad_tf  (github.com/uzh-rpg/netvlad_tf_open, python/netvlad_tf/layers.py,
                no version pinned by the reference),
   pointnetvlad (github.com/mikacuy/pointnetvlad, pointnetvlad_cls.py, no version
-               pinned by the reference).
+               pinned by the reference),
+  tensorflow   (==1.10.0, README.md:9: python/training/adam.py + the ApplyAdam /
+               ApplyMomentum kernels of core/kernels/training_ops.cc).
 """
