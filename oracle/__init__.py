@@ -29,6 +29,6 @@ Third-party algorithms restated from their published sources:
                no version pinned by the reference),
   pointnetvlad (github.com/mikacuy/pointnetvlad, pointnetvlad_cls.py, no version
                pinned by the reference),
-  tensorflow   (==1.10.0, README.md:9: python/training/adam.py + the ApplyAdam /
+  tensorflow   (==1.10.0, README.md:6: python/training/adam.py + the ApplyAdam /
                ApplyMomentum kernels of core/kernels/training_ops.cc).
 """

@@ -2,7 +2,7 @@
 
 `tf.train.AdamOptimizer(learning_rate)` — train/train.py:870, with TensorFlow's defaults
 beta1 = 0.9, beta2 = 0.999, epsilon = 1e-8 — is third-party code absent from /root/reference:
-tensorflow==1.10.0 (README.md:9).  Its published algorithm (python/training/adam.py docstring and
+TensorFlow 1.10.0 (README.md:6: "tested using").  Its published algorithm (python/training/adam.py docstring and
 the ApplyAdam kernel, core/kernels/training_ops.cc, non-Nesterov branch), restated in float32:
 
     beta1_power, beta2_power : float32 variables, initialised to beta1, beta2, multiplied by

@@ -1,6 +1,6 @@
 """The reference's optimisers (train/train.py:865-878) on torch's fused kernels.
 
-`tf.train.AdamOptimizer(learning_rate)` (train/train.py:870; tensorflow==1.10.0, README.md:9 —
+`tf.train.AdamOptimizer(learning_rate)` (train/train.py:870; tensorflow==1.10.0, README.md:6 —
 kernel ApplyAdam, non-Nesterov) updates
 
     lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t)
