@@ -6,8 +6,13 @@ copies of image 0 up to a multiple of ``images_per_pass`` (:172-175), batches go
 padding rows are dropped (:186-191) and the product is a pickle holding a ``list`` of
 ``np.ndarray(32768,) float32`` in list order (:192).
 
-Image decoding / resizing (cv2, util/cv.py) is dataset-bound and out of scope; callers
-hand in a loader ``index -> np.ndarray[H,W,3] uint8/float`` (a synthetic one is provided).
+Images: ``--csv_root/<set>.csv`` with a ``path`` column relative to ``--img_root``
+(evaluation/inference.py:168-170), decoded and sized by ``load_images``' rules (:52-72; util/cv.py,
+util/io.py restated in ``soft_contrastive_learning_amd/util``): 'oxs' sets read ``.jpg`` instead of
+``.png``, 'achen' sets are portrait (cover ``large_side x small_side``), with the NetVLAD head the
+longer side becomes ``large_side`` unless ``--rescale`` is off, without it the frame is brought to
+``small_side x large_side``.  Six loader threads feed the device (:155-160).  ``--set synthetic``:
+random images, no files.
 """
 import argparse
 import os
@@ -27,21 +32,53 @@ def pad_indices(num, images_per_pass):
     return np.concatenate((np.arange(num), np.array(padding, dtype=int))).astype(int)
 
 
-def extract_features(model, loader, num, images_per_pass=4, device=None):
+def extract_features(model, loader, num, images_per_pass=4, device=None, loader_threads=6):
     """Returns ``list`` of ``num`` float32 vectors (length 32768 with the NetVLAD head, H' W' 512
-    without: ``ops['full_out']``, evaluation/inference.py:89-92), in index order."""
+    without: ``ops['full_out']``, evaluation/inference.py:89-92), in index order.  ``loader`` is
+    called from ``loader_threads`` threads (cpu_thread, :28-38), one batch ahead of the device."""
+    from concurrent.futures import ThreadPoolExecutor
     device = device or next(model.parameters()).device
     order = pad_indices(num, images_per_pass)
     feats = [None] * len(order)
-    with torch.no_grad():
-        for s in range(0, len(order), images_per_pass):
-            idx = order[s:s + images_per_pass]
-            batch = np.stack([np.asarray(loader(int(i)), dtype=np.float32) for i in idx])
+    starts = list(range(0, len(order), images_per_pass))
+
+    def load_batch(s):
+        idx = order[s:s + images_per_pass]
+        return np.stack([np.asarray(loader(int(i)), dtype=np.float32) for i in idx])
+    with torch.no_grad(), ThreadPoolExecutor(max_workers=max(int(loader_threads), 1)) as pool:
+        ahead = max(int(loader_threads), 1)
+        pending = [pool.submit(load_batch, s) for s in starts[:ahead]]
+        for k, s in enumerate(starts):
+            batch = pending.pop(0).result()
+            if k + ahead < len(starts):
+                pending.append(pool.submit(load_batch, starts[k + ahead]))
             out = nets.full_out(torch.from_numpy(batch).to(device), model=model)
             out = out.float().cpu().numpy()
-            for slot, f in zip(range(s, s + len(idx)), out):
+            for slot, f in zip(range(s, s + len(out)), out):
                 feats[slot] = f
     return feats[:num]
+
+
+def csv_loader(set_name, csv_root, img_root, vlad_cores=64, rescale=True, small_side=180, large_side=240):
+    """(loader, num) over ``<csv_root>/<set>.csv`` (column ``path``): evaluation/inference.py:52-72,
+    168-170."""
+    from ..util import cv, io
+    meta = io.load_csv(os.path.join(csv_root, '{}.csv'.format(set_name)))
+    if not isinstance(meta, dict) or 'path' not in meta:
+        raise ValueError('%s.csv needs a "path" column and at least one row' % set_name)
+    paths = list(meta['path'])
+
+    def load(i):
+        rel = paths[i]
+        if 'oxs' in set_name:
+            rel = rel.replace('.png', '.jpg')
+        img = io.load_img(os.path.join(img_root, rel))
+        if 'achen' in set_name:
+            return cv.standard_size(img, h=large_side, w=small_side)           # portrait images
+        if vlad_cores > 0:
+            return cv.resize_img(img, large_side) if rescale else img
+        return cv.standard_size(img, h=small_side, w=large_side)
+    return load, len(paths)
 
 
 def save_pickle(data, out_file):
@@ -59,8 +96,12 @@ def synthetic_loader(height, width, seed=42):
 def main(argv=None):
     p = argparse.ArgumentParser()
     # flag names of evaluation/inference.py:204-230
+    p.add_argument('--rescale', default=True,
+                   type=lambda v: str(v).lower() not in ('0', 'false', 'no', ''))
     p.add_argument('--small_side', default=180, type=int)
     p.add_argument('--large_side', default=240, type=int)
+    p.add_argument('--img_root', default='')
+    p.add_argument('--csv_root', default='')
     p.add_argument('--set', default='synthetic')
     p.add_argument('--checkpoint', default='')
     p.add_argument('--out_name', default='scl_amd')
@@ -79,8 +120,12 @@ def main(argv=None):
     model = nets.VGG16NetVLAD(vlad_cores=flags.vlad_cores).cuda()
     if flags.checkpoint:
         checkpoint.load(model, flags.checkpoint)
-    feats = extract_features(model, synthetic_loader(flags.small_side, flags.large_side),
-                             flags.num_images, flags.images_per_pass)
+    if flags.set == 'synthetic' and not flags.csv_root:
+        loader, num = synthetic_loader(flags.small_side, flags.large_side), flags.num_images
+    else:
+        loader, num = csv_loader(flags.set, flags.csv_root, flags.img_root, flags.vlad_cores,
+                                 flags.rescale, flags.small_side, flags.large_side)
+    feats = extract_features(model, loader, num, flags.images_per_pass)
     os.makedirs(flags.out_root, exist_ok=True)
     out = os.path.join(flags.out_root, '{}_{}.pickle'.format(flags.set, flags.out_name))
     save_pickle(feats, out)

@@ -14,9 +14,14 @@ import numpy as np
 
 
 class CsvImageSet:
-    """One reference CSV + an image root (``img_path``: <root>/<date>/<folder>/<t>.png)."""
+    """One reference CSV + an image root.  File of row i (``img_path``, train/train.py:124-128):
+    ``<root>/<date>_stereo_centre_<folder:02d>/<t>.png``.  Images (``load_images``,
+    train/train.py:423-430): with the NetVLAD head the longer side is brought to ``max_side`` = 240
+    (``resize_img``), without it the image is scaled to cover ``standard`` = (180, 240) and
+    centre-cropped (``standard_size``) — both with OpenCV's un-filtered bilinear resampling,
+    restated in util/cv.py."""
 
-    def __init__(self, csv_file, img_root, height=240, ext='.png'):
+    def __init__(self, csv_file, img_root, vlad_cores=64, max_side=240, standard=(180, 240), ext='.png'):
         with open(csv_file) as f:
             rows = list(csv.DictReader(f))
         need = ('date', 'folder', 't', 'easting', 'northing', 'yaw')
@@ -26,18 +31,28 @@ class CsvImageSet:
         self.xy = np.array([[float(e), float(n)] for e, n in
                             zip(self.meta['easting'], self.meta['northing'])], dtype=float)
         self.yaw = np.array(self.meta['yaw'], dtype=float)
-        self.img_root, self.height, self.ext = img_root, height, ext
+        self.img_root, self.ext = img_root, ext
+        self.vlad_cores, self.max_side, self.standard = vlad_cores, max_side, tuple(standard)
 
     def __len__(self):
         return len(self.yaw)
 
     def path(self, i):
-        return os.path.join(self.img_root, self.meta['date'][i], self.meta['folder'][i],
-                            self.meta['t'][i] + self.ext)
+        return os.path.join(self.img_root,
+                            '{}_stereo_centre_{:02d}'.format(self.meta['date'][i], int(self.meta['folder'][i])),
+                            '{}{}'.format(self.meta['t'][i], self.ext))
+
+    def load_image(self, i):
+        from ..util import cv, io
+        img = io.load_img(self.path(int(i)))
+        if self.vlad_cores > 0:
+            return cv.resize_img(img, self.max_side)
+        return cv.standard_size(img, h=self.standard[0], w=self.standard[1])
 
     def load_images(self, indices):
-        from .sampler import load_images_pil
-        return load_images_pil([self.path(int(i)) for i in indices], self.height)
+        """float32 [n,H,W,3], 0..255 RGB (all images of a batch must come out the same size, as
+        in the reference, whose feed would fail otherwise)."""
+        return np.stack([self.load_image(i) for i in indices]).astype(np.float32)
 
 
 class SyntheticImageSet:

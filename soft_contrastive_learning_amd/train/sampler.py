@@ -165,19 +165,6 @@ class TupleSampler:
         return distances, np.asarray(every, dtype=int)
 
 
-def load_images_pil(paths, height=240):
-    """load_images (train/train.py:423-430) for files on disk: RGB, resized to ``height`` rows
-    keeping the aspect ratio, float32 0..255 NHWC."""
-    from PIL import Image
-    out = []
-    for p in paths:
-        with Image.open(p) as im:
-            im = im.convert('RGB')
-            w = max(int(round(im.width * height / float(im.height))), 1)
-            out.append(np.asarray(im.resize((w, height), Image.BILINEAR), dtype=np.float32))
-    return np.stack(out)
-
-
 class _WorkerError:
     """An exception raised in a pipeline worker, on its way to the consumer."""
 

@@ -281,9 +281,12 @@ def open_sets(flags, epoch):
     from . import dataset
     if flags.shuffled_root:
         def one(name):
+            # (image size: the reference's fixed rule, train/train.py:423-430 — longer side 240 with
+            # the NetVLAD head, 180 x 240 cover-and-crop without; --height / --width are the
+            # synthetic set's)
             return dataset.CsvImageSet(os.path.join(flags.shuffled_root,
                                                     '%s_%03d.csv' % (name, epoch)),
-                                       flags.img_root, flags.height)
+                                       flags.img_root, vlad_cores=flags.vlad_cores)
         return (one(flags.local_ref_set), one(flags.local_query_set), one(flags.other_ref_set),
                 one(flags.other_query_set))
     m = flags.synthetic_dataset

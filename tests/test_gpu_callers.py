@@ -118,6 +118,45 @@ def test_inference_product_is_the_reference_pickle(dev, tmp_path):
     assert isinstance(back, list) and len(back) == 5
 
 
+def test_inference_over_a_csv_image_list(dev, tmp_path):
+    """evaluation/inference.py:52-72, 168-192 on files: <csv_root>/<set>.csv (column `path`) under
+    --img_root, the loader rules per set name, the pickle <out_root>/<set>_<out_name>.pickle."""
+    import os
+    from soft_contrastive_learning_amd.evaluation import inference
+    from soft_contrastive_learning_amd.util import cv, io
+    rng = np.random.RandomState(4)
+    img_root, csv_root, out_root = tmp_path / 'img', tmp_path / 'lists', tmp_path / 'out'
+    (img_root / 'a').mkdir(parents=True)
+    csv_root.mkdir()
+    frames, paths = [], []
+    for i in range(5):
+        f = rng.randint(0, 256, (120, 160, 3)).astype(np.uint8)
+        io.save_img(f, img_root / 'a' / ('%d.png' % i))
+        frames.append(f)
+        paths.append('a/%d.png' % i)
+    io.save_csv({'path': paths}, str(csv_root / 'cmu_ref.csv'))
+    loader, num = inference.csv_loader('cmu_ref', str(csv_root), str(img_root))
+    assert num == 5 and np.array_equal(loader(3), cv.resize_img(frames[3], 240))      # 180 x 240
+    raw, _ = inference.csv_loader('cmu_ref', str(csv_root), str(img_root), rescale=False)
+    assert np.array_equal(raw(1), frames[1])
+    flat, _ = inference.csv_loader('cmu_ref', str(csv_root), str(img_root), vlad_cores=0)
+    assert flat(0).shape == (180, 240, 3)
+    io.save_csv({'path': paths}, str(csv_root / 'achen_q.csv'))
+    port, _ = inference.csv_loader('achen_q', str(csv_root), str(img_root))
+    assert port(0).shape == (240, 180, 3)                                            # portrait
+    inference.main(['--set', 'cmu_ref', '--csv_root', str(csv_root), '--img_root', str(img_root),
+                    '--out_root', str(out_root), '--out_name', 'm', '--images_per_pass', '4'])
+    feats = pickle.load(open(os.path.join(str(out_root), 'cmu_ref_m.pickle'), 'rb'))
+    assert isinstance(feats, list) and len(feats) == 5
+    assert all(f.shape == (32768,) and f.dtype == np.float32 for f in feats)
+    # feature i belongs to row i of the list (padding rows dropped): against a one-image pass
+    from soft_contrastive_learning_amd.model import nets
+    model = nets.VGG16NetVLAD().to(dev)
+    one = inference.extract_features(model, loader, 5, images_per_pass=1)
+    for a, b in zip(feats, one):
+        np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-6)
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_callers_without_the_vlad_head(dev, tmp_path, dtype):
     """--vlad_cores 0 (train/train.py:606-611, evaluation/inference.py:89-92): both callers take
@@ -265,6 +304,49 @@ def test_trainer_dataset_route_sampling_mining_and_evaluation(dev, tmp_path):
     assert tf_bundle.exists(os.path.join(d, 'epoch-checkpoint-0'))
     assert any(f.startswith('part-checkpoint-') for f in os.listdir(d))
     assert state['step'] == len(steps)
+
+
+def test_trainer_on_csv_lists_and_png_frames_in_the_reference_layout(dev, tmp_path):
+    """The same route on FILES: per-epoch lists <set>_<epoch:03d>.csv (util/io.py:46-83) and frames
+    <img_root>/<date>_stereo_centre_<folder:02d>/<t>.png (train/train.py:124-128), loaded with the
+    reference's geometry (longer side -> 240, un-filtered bilinear: util/cv.py) — what a user of the
+    reference points --shuffled_root / --img_root at."""
+    import json
+    import os
+    from soft_contrastive_learning_amd.train import dataset, train as T
+    from soft_contrastive_learning_amd.util import io
+    img_root, lists, out = str(tmp_path / 'img'), tmp_path / 'lists', str(tmp_path / 'out')
+    lists.mkdir()
+    for name, num, seed, folder in (('train_ref', 96, 1, 1), ('train_query', 96, 2, 2),
+                                    ('test_ref', 48, 3, 3), ('test_query', 48, 4, 4)):
+        syn = dataset.SyntheticImageSet(num, 96, 128, seed=1 if 'train' in name else 3, distractor=0.3)
+        if 'query' in name:                                   # another traverse of the same track
+            syn = dataset.SyntheticImageSet(num, 96, 128, seed=(1 if 'train' in name else 3) + 100,
+                                            distractor=0.3)
+        frames = syn.load_images(np.arange(num)).clip(0, 255).astype(np.uint8)
+        d = os.path.join(img_root, '2015-01-01-00-00-00_stereo_centre_{:02d}'.format(folder))
+        os.makedirs(d)
+        cols = dict(date=['2015-01-01-00-00-00'] * num, folder=[folder] * num, t=[1000 + i for i in range(num)],
+                    easting=[float(v) for v in syn.xy[:, 0]], northing=[float(v) for v in syn.xy[:, 1]],
+                    yaw=[float(v) for v in syn.yaw])
+        for i in range(num):
+            io.save_img(frames[i], os.path.join(d, '%d.png' % (1000 + i)))
+        io.save_csv(cols, str(lists / ('%s_000.csv' % name)))
+    state = T.main(['--loss', 'wms', '--shuffled_root', str(lists), '--img_root', img_root,
+                    '--positives_per_tuple', '3', '--negatives_per_tuple', '3',
+                    '--hard_positives_per_tuple', '1', '--hard_negatives_per_tuple', '2',
+                    '--mining_step', '3', '--mining_cache_size', '24', '--eval_step', '3',
+                    '--save_step', '100', '--num_eval_queries', '6', '--eval_ref_r', '2',
+                    '--steps', '4', '--max_epoch', '1', '--base_lr', '1e-5', '--dtype', 'bf16',
+                    '--out_root', out, '--out_folder', 'run'])
+    recs = [json.loads(l) for l in open(os.path.join(out, 'run', 'train_log.txt'))]
+    steps = [r for r in recs if 'loss' in r]
+    assert 3 <= len(steps) <= 4 and all(np.isfinite(r['loss']) for r in steps)
+    assert state['step'] == len(steps)
+    assert any(r.get('event') == 'eval' for r in recs)
+    # the frames went through the reference's loader: 96 x 128 -> 180 x 240
+    one = dataset.CsvImageSet(str(lists / 'train_ref_000.csv'), img_root).load_images([0])
+    assert one.shape == (1, 180, 240, 3)
 
 
 def test_checkpoint_resume_with_fused_adam_on_the_device(dev, tmp_path):
