@@ -758,16 +758,22 @@ def test_gradient_sink_gives_the_same_gradients(dev):
     img = torch.randint(0, 256, (1, 480, 640, 3), generator=torch.Generator().manual_seed(61)).float().to(dev)
     g = torch.randn(1, 30, 40, 512, generator=torch.Generator().manual_seed(62)).to(dev).bfloat16()
     grads = {}
-    for sink in (False, True):
-        model = nets.VGG16NetVLAD(compute_dtype=torch.bfloat16, seed=9, fused_relu=True).to(dev)
-        buckets = parallel.GradBuckets(list(model.parameters()))
-        nets.GRAD_SINK = buckets if sink else None
-        try:
-            buckets.zero()
-            model.features(img).backward(g)
-        finally:
-            nets.GRAD_SINK = None
-        grads[sink] = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    # (the fused first-layer gradients follow the sink + second stream by default and sum conv1_1's
+    # gradients in another order: pinned off here, compared on their own further down)
+    old_ffw, nets.USE_FUSED_FIRST_WRW = nets.USE_FUSED_FIRST_WRW, False
+    try:
+        for sink in (False, True):
+            model = nets.VGG16NetVLAD(compute_dtype=torch.bfloat16, seed=9, fused_relu=True).to(dev)
+            buckets = parallel.GradBuckets(list(model.parameters()))
+            nets.GRAD_SINK = buckets if sink else None
+            try:
+                buckets.zero()
+                model.features(img).backward(g)
+            finally:
+                nets.GRAD_SINK = None
+            grads[sink] = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    finally:
+        nets.USE_FUSED_FIRST_WRW = old_ffw
     assert set(grads[True]) == set(grads[False])
     for n in grads[True]:
         if n.startswith(('conv1_', 'conv2_', 'conv3_', 'conv4_', 'average_rgb')):
@@ -871,6 +877,7 @@ def test_weight_gradients_on_the_second_stream_equal_the_one_stream_run(dev):
     buckets = parallel.GradBuckets(list(model.parameters()))
     flats = {}
     old = nets.USE_SIDE_WRW
+    old_ffw, nets.USE_FUSED_FIRST_WRW = nets.USE_FUSED_FIRST_WRW, False      # (as above)
     try:
         for side in (False, True, True, True):
             nets.USE_SIDE_WRW = side
@@ -889,6 +896,7 @@ def test_weight_gradients_on_the_second_stream_equal_the_one_stream_run(dev):
                 flats[False] = buckets.flat.clone()
     finally:
         nets.USE_SIDE_WRW = old
+        nets.USE_FUSED_FIRST_WRW = old_ffw
     assert float(flats[False].abs().max()) > 0
 
 
