@@ -21,16 +21,20 @@ class CsvImageSet:
     centre-cropped (``standard_size``) — both with OpenCV's un-filtered bilinear resampling,
     restated in util/cv.py."""
 
-    def __init__(self, csv_file, img_root, vlad_cores=64, max_side=240, standard=(180, 240), ext='.png'):
+    def __init__(self, csv_file, img_root, vlad_cores=64, max_side=240, standard=(180, 240), ext='.png',
+                 need_yaw=True):
         with open(csv_file) as f:
             rows = list(csv.DictReader(f))
-        need = ('date', 'folder', 't', 'easting', 'northing', 'yaw')
+        need = ('date', 'folder', 't', 'easting', 'northing') + (('yaw',) if need_yaw else ())
         if not rows or any(k not in rows[0] for k in need):
             raise ValueError('%s must have the columns %s' % (csv_file, ', '.join(need)))
         self.meta = {k: [r[k] for r in rows] for k in rows[0]}
         self.xy = np.array([[float(e), float(n)] for e, n in
                             zip(self.meta['easting'], self.meta['northing'])], dtype=float)
-        self.yaw = np.array(self.meta['yaw'], dtype=float)
+        # (the localisation reference lists, train/train.py:1158-1167, are read for t / easting /
+        # northing only)
+        self.yaw = (np.array(self.meta['yaw'], dtype=float) if 'yaw' in self.meta
+                    else np.zeros(len(rows), dtype=float))
         self.img_root, self.ext = img_root, ext
         self.vlad_cores, self.max_side, self.standard = vlad_cores, max_side, tuple(standard)
 

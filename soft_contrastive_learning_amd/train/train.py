@@ -95,6 +95,13 @@ def make_parser():
     p.add_argument('--other_query_set', default='test_query')
     p.add_argument('--train_ref_r', default=1, type=int)
     p.add_argument('--img_root', default='')
+    p.add_argument('--anchor_root', default='',
+                   help='directory of the anchor lists <local_ref_set>_<train_ref_r>_<epoch:03d>.csv '
+                        '(column idx; train/train.py:1007-1009); empty: a seeded permutation of '
+                        'every train_ref_r-th image')
+    p.add_argument('--loc_ref_root', default='',
+                   help='directory of the localisation reference lists <ref_set>_<eval_ref_r>.csv '
+                        '(train/train.py:1158); empty: every eval_ref_r-th image of the set')
     p.add_argument('--shuffled_root', default='',
                    help='directory of the per-epoch lists <set>_<epoch:03d>.csv; empty: synthetic')
     p.add_argument('--synthetic_dataset', type=int, default=0,
@@ -276,6 +283,15 @@ def next_cadence(step, every, stride, world, n_anchors):
     return min(nxt, n_anchors)
 
 
+def loc_ref_set(flags, ref_set_name):
+    """The thinned reference list the localisation check runs against:
+    <loc_ref_root>/<ref_set>_<eval_ref_r>.csv (train/train.py:1158)."""
+    from . import dataset
+    return dataset.CsvImageSet(os.path.join(flags.loc_ref_root,
+                                            '{}_{}.csv'.format(ref_set_name, flags.eval_ref_r)),
+                               flags.img_root, vlad_cores=flags.vlad_cores, need_yaw=False)
+
+
 def open_sets(flags, epoch):
     """(local_ref, local_query, other_ref, other_query) image sets of an epoch."""
     from . import dataset
@@ -340,8 +356,16 @@ def train_dataset_epoch(flags, epoch, state, log):
     other_sampler = make_sampler(other_ref, False)
     pipe = InputPipeline(sampler, local_ref.load_images, tuple_shape, use_hard_negatives=True,
                          depth=2, emit_dropped=True)
-    anchors = np.random.RandomState(1000 + epoch).permutation(
-        np.arange(0, len(local_ref), max(flags.train_ref_r, 1)))
+    if flags.anchor_root:                                     # train/train.py:1007-1009
+        from ..util import io
+        anchors = np.array(io.load_csv(os.path.join(
+            flags.anchor_root, '{}_{}_{:03d}.csv'.format(flags.local_ref_set, flags.train_ref_r, epoch)))['idx'],
+            dtype=int)
+        if len(anchors) and (anchors.min() < 0 or anchors.max() >= len(local_ref)):
+            raise ValueError('anchor list of epoch %d points outside %s' % (epoch, flags.local_ref_set))
+    else:
+        anchors = np.random.RandomState(1000 + epoch).permutation(
+            np.arange(0, len(local_ref), max(flags.train_ref_r, 1)))
     if flags.steps > 0:
         anchors = anchors[:flags.steps * t * world]           # --steps = batches per rank
     # whole batches only: compute_loss / batch_distances reshape with tuples_per_batch, a short
@@ -350,6 +374,10 @@ def train_dataset_epoch(flags, epoch, state, log):
     lr = get_learning_rate(epoch, flags)
     for g in opt.param_groups:
         g['lr'] = lr
+    if rank == 0:
+        log({'event': 'epoch', 'epoch': epoch, 'anchors': int(len(anchors)),
+             'anchor_source': 'list' if flags.anchor_root else 'permutation',
+             'first_anchors': [int(a) for a in anchors[:4]], 'learning_rate': lr})
 
     def loss_of(distances, images):
         """Single-process loss (the evaluation on the other region: every rank alike)."""
@@ -442,9 +470,13 @@ def train_dataset_epoch(flags, epoch, state, log):
                                                   tuple_shape, dev)
                 rec = {'step': state['step'], 'event': 'eval', 'other_region_loss': ev,
                        'eval_batches': used}
-                for mode, rset, qset in (('other', other_ref, other_query),
-                                         ('local', local_ref, local_query)):
-                    refs = np.arange(0, len(rset), max(flags.eval_ref_r, 1))
+                for mode, rset, qset, rname in (('other', other_ref, other_query, flags.other_ref_set),
+                                                ('local', local_ref, local_query, flags.local_ref_set)):
+                    if flags.loc_ref_root and flags.shuffled_root:     # train/train.py:1158-1167
+                        rset = loc_ref_set(flags, rname)
+                        refs = np.arange(len(rset))
+                    else:
+                        refs = np.arange(0, len(rset), max(flags.eval_ref_r, 1))
                     q = np.arange(test_number * flags.num_eval_queries,
                                   (test_number + 1) * flags.num_eval_queries) % len(qset)
                     metrics, _ = evaluate.evaluate_localization(model, rset, refs, qset, q, s_img)

@@ -332,7 +332,15 @@ def test_trainer_on_csv_lists_and_png_frames_in_the_reference_layout(dev, tmp_pa
         for i in range(num):
             io.save_img(frames[i], os.path.join(d, '%d.png' % (1000 + i)))
         io.save_csv(cols, str(lists / ('%s_000.csv' % name)))
+        if 'ref' in name:       # the thinned localisation references (no yaw column) ...
+            keep = list(range(0, num, 2))
+            io.save_csv({k: [cols[k][i] for i in keep] for k in cols if k != 'yaw'},
+                        str(lists / ('%s_2.csv' % name)))
+    # ... and the epoch's anchor list (train/train.py:1007-1009)
+    order = np.random.RandomState(5).permutation(96)
+    io.save_csv({'idx': [int(v) for v in order]}, str(lists / 'train_ref_1_000.csv'))
     state = T.main(['--loss', 'wms', '--shuffled_root', str(lists), '--img_root', img_root,
+                    '--anchor_root', str(lists), '--loc_ref_root', str(lists),
                     '--positives_per_tuple', '3', '--negatives_per_tuple', '3',
                     '--hard_positives_per_tuple', '1', '--hard_negatives_per_tuple', '2',
                     '--mining_step', '3', '--mining_cache_size', '24', '--eval_step', '3',
@@ -344,6 +352,8 @@ def test_trainer_on_csv_lists_and_png_frames_in_the_reference_layout(dev, tmp_pa
     assert 3 <= len(steps) <= 4 and all(np.isfinite(r['loss']) for r in steps)
     assert state['step'] == len(steps)
     assert any(r.get('event') == 'eval' for r in recs)
+    ep = [r for r in recs if r.get('event') == 'epoch'][0]
+    assert ep['anchor_source'] == 'list' and ep['first_anchors'] == [int(v) for v in order[:4]]
     # the frames went through the reference's loader: 96 x 128 -> 180 x 240
     one = dataset.CsvImageSet(str(lists / 'train_ref_000.csv'), img_root).load_images([0])
     assert one.shape == (1, 180, 240, 3)
