@@ -46,7 +46,11 @@ def get_top_n(pca_f, full_ref_f, full_query_f, full_ref_xy, full_query_xy, n=25,
     from sklearn.metrics import pairwise_distances
     full_xy_dists = pairwise_distances(full_query_xy, full_ref_xy, metric='euclidean')
     pca_ref_f, pca_query_f = whiten(pca_f, [full_ref_f, full_query_f], d, device, pca_backend)
+    return retrieve(pca_ref_f, pca_query_f, full_xy_dists, full_ref_xy, n, l)
 
+
+def retrieve(pca_ref_f, pca_query_f, full_xy_dists, full_ref_xy, n, l):
+    """evaluation/top-n.py:91-119 for one thinning distance l on whitened features."""
     ref_idx = thin_reference(np.asarray(full_ref_xy), l)
     if len(ref_idx) < n:
         return None
@@ -71,3 +75,73 @@ def recall_at(top_g_dists, thresholds, n=1):
     threshold (train/train.py:363-376; evaluation/roc.py:213-216 uses n=1)."""
     g = np.asarray(top_g_dists, dtype=np.float64)[:, :n].min(axis=1)
     return np.array([np.mean(g < x) for x in thresholds])
+
+
+def get_xy(meta):
+    """evaluation/top-n.py's use of util.io.load_csv columns (train/train.py:1152-1153)."""
+    return np.array([[e, n] for e, n in zip(meta['easting'], meta['northing'])], dtype=float)
+
+
+def out_pickle_path(out_root, query_lv_pickle, l, d):
+    """evaluation/top-n.py:43-45, 83-86: <out_root>/l<l>_dim<d>/<query pickle name without dots>.pickle."""
+    import os
+    name = ''.join(os.path.basename(query_lv_pickle).split('.')[:-1])
+    return os.path.join(out_root, 'l{}_dim{}'.format(l, d), '{}.pickle'.format(name))
+
+
+def main(argv=None):
+    """The script (evaluation/top-n.py:23-119, flags :126-139): descriptor pickles of
+    evaluation/inference.py + the sets' CSV lists (easting / northing) in, one pickle per
+    (thinning distance l, PCA dimension d) out; finished outputs are skipped.  The reference picks
+    its sweeps from checkpoint names (:25-39: L = 0, 0.3, 1, 5 and D = 64 .. 4096 for its 'obm'
+    models, else L = 0, D = 256); here they are the flags --L / --D with the latter as defaults."""
+    import argparse
+    import os
+    from sklearn.metrics import pairwise_distances
+    from ..util import io
+    p = argparse.ArgumentParser()
+    p.add_argument('--pca_lv_pickle', required=True)
+    p.add_argument('--query_lv_pickle', required=True)
+    p.add_argument('--ref_lv_pickle', required=True)
+    p.add_argument('--query_csv', required=True)
+    p.add_argument('--ref_csv', required=True)
+    p.add_argument('--N', default=25, type=int)
+    p.add_argument('--out_root', default='./scl_top_n')
+    p.add_argument('--L', default='0.0', help='comma-separated thinning distances in metres')
+    p.add_argument('--D', default='256', help='comma-separated PCA dimensions')
+    p.add_argument('--pca_backend', default='device', choices=['device', 'sklearn'])
+    flags = p.parse_args(argv)
+    ls = [float(v) for v in flags.L.split(',')]
+    ds = [int(v) for v in flags.D.split(',')]
+    todo = [(l, d) for l in ls for d in ds
+            if not os.path.exists(out_pickle_path(flags.out_root, flags.query_lv_pickle, l, d))]
+    if not todo:
+        print('Skipping complete {}'.format(flags.query_lv_pickle))
+        return []
+    full_ref_xy = get_xy(io.load_csv(flags.ref_csv))
+    full_query_xy = get_xy(io.load_csv(flags.query_csv))
+    pca_f = np.array(io.load_pickle(flags.pca_lv_pickle))
+    full_ref_f = np.array(io.load_pickle(flags.ref_lv_pickle))
+    full_query_f = np.array(io.load_pickle(flags.query_lv_pickle))
+    full_xy_dists = pairwise_distances(full_query_xy, full_ref_xy, metric='euclidean')
+    written = []
+    for d in ds:
+        if not any(dd == d for _, dd in todo):
+            continue
+        pca_ref_f, pca_query_f = whiten(pca_f, [full_ref_f, full_query_f], d, 'cuda', flags.pca_backend)
+        for l in ls:
+            out = out_pickle_path(flags.out_root, flags.query_lv_pickle, l, d)
+            if os.path.exists(out):
+                print('{} already exists. Skipping.'.format(out))
+                continue
+            payload = retrieve(pca_ref_f, pca_query_f, full_xy_dists, full_ref_xy, flags.N, l)
+            if payload is None:                               # fewer than N references left (:96-97)
+                continue
+            os.makedirs(os.path.dirname(out), exist_ok=True)
+            io.save_pickle(payload, out)
+            written.append(out)
+    return written
+
+
+if __name__ == '__main__':
+    main()

@@ -246,6 +246,43 @@ def test_top_n_harness_matches_the_reference_pipeline(dev):
     np.testing.assert_allclose(dev_out[2], top_f, rtol=2e-4)
 
 
+def test_top_n_script_files_in_files_out(dev, tmp_path):
+    """evaluation/top-n.py as a script (flags :126-139): descriptor pickles + CSV lists in,
+    <out_root>/l<l>_dim<d>/<query pickle name>.pickle out for every (l, d) of the sweep, finished
+    outputs skipped, thinning that leaves fewer than N references writes nothing."""
+    import os
+    from soft_contrastive_learning_amd.evaluation import top_n
+    from soft_contrastive_learning_amd.util import io
+    rng = np.random.default_rng(15)
+    feats = {k: [v for v in rng.standard_normal((n, 96)).astype(np.float32)]
+             for k, n in (('pca', 300), ('ref', 200), ('query', 30))}
+    for k, v in feats.items():
+        io.save_pickle(v, str(tmp_path / ('oxford_%s_m.v1.pickle' % k)))     # a list of vectors, a dot in the name
+    ref_xy = np.cumsum(rng.uniform(0.2, 1.5, size=(200, 2)), axis=0)
+    qry_xy = rng.uniform(0, 150, size=(30, 2))
+    for name, xy in (('ref', ref_xy), ('query', qry_xy)):
+        io.save_csv({'path': ['x/%d.png' % i for i in range(len(xy))], 'easting': list(xy[:, 0]),
+                     'northing': list(xy[:, 1])}, str(tmp_path / ('%s.csv' % name)))
+    argv = ['--pca_lv_pickle', str(tmp_path / 'oxford_pca_m.v1.pickle'),
+            '--query_lv_pickle', str(tmp_path / 'oxford_query_m.v1.pickle'),
+            '--ref_lv_pickle', str(tmp_path / 'oxford_ref_m.v1.pickle'),
+            '--query_csv', str(tmp_path / 'query.csv'), '--ref_csv', str(tmp_path / 'ref.csv'),
+            '--N', '25', '--out_root', str(tmp_path / 'out'), '--L', '0.0,1.0,500.0', '--D', '32,64']
+    written = top_n.main(argv)
+    want = [os.path.join(str(tmp_path / 'out'), 'l%s_dim%d' % (l, d), 'oxford_query_mv1.pickle')
+            for d in (32, 64) for l in ('0.0', '1.0')]                      # l = 500 m leaves one reference
+    assert sorted(written) == sorted(want) and all(os.path.exists(w) for w in want)
+    assert not os.path.exists(os.path.join(str(tmp_path / 'out'), 'l500.0_dim32'))
+    top_i, top_g, top_f, gt_i, gt_g, ref_idx = io.load_pickle(want[1])      # l = 1.0, d = 32
+    direct = top_n.get_top_n(np.array(feats['pca']), np.array(feats['ref']), np.array(feats['query']),
+                             ref_xy, qry_xy, n=25, d=32, l=1.0)
+    np.testing.assert_array_equal(np.asarray(top_i), np.asarray(direct[0]))
+    assert ref_idx == direct[5] and len(top_i) == 30 and len(top_i[0]) == 25
+    # a second run: the four outputs exist, the 500 m ones are attempted again and skipped again
+    assert top_n.main(argv) == []
+    assert top_n.main(argv[:-4] + ['--L', '0.0', '--D', '32']) == []          # "Skipping complete"
+
+
 def test_device_pca_whitening_matches_sklearn_full_solver(dev):
     from sklearn.decomposition import PCA
     from soft_contrastive_learning_amd.evaluation.pca import PCAWhitening
