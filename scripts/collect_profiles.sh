@@ -23,14 +23,14 @@ cd $R
 cp $(ls $O/trace_nv/*/*kernel_stats.csv | head -1) $O/microbench_netvlad_loss_kernel_stats_rocprofv3.csv
 python3 scripts/pmc_summary.py $O/pmc_tn --only kernel --out $O/pmc_topn_sq_counters.csv > /dev/null 2>&1
 python3 scripts/microbench.py --iters 20 --topn-score f32,bf16x3 --topn-splits 1106,2106,4106 --json $O/microbench_netvlad_loss_topn.json > $O/microbench.log 2>&1
-python3 scripts/parity_report.py --json $O/parity_report.json > $O/parity.log 2>&1
+python3 tests/tools/parity_report.py --json $O/parity_report.json > $O/parity.log 2>&1
 python3 bench.py --workload retrieval --steps 5 --warmup 2 > $O/bench_retrieval_n1_f32.json 2>> $O/bench.err
 python3 bench.py --workload retrieval --steps 5 --warmup 2 --score bf16x3 > $O/bench_retrieval_n1_bf16x3.json 2>> $O/bench.err
 python3 scripts/vlad_stamps.py --kernel fwd > $O/vlad_stamps_fwd.txt 2>/dev/null
 python3 scripts/vlad_stamps.py --kernel fwd8 > $O/vlad_stamps_fwd8.txt 2>/dev/null
 python3 scripts/vlad_stamps.py --kernel dx > $O/vlad_stamps_dx.txt 2>/dev/null
 python3 scripts/null_bracket.py > $O/null_bracket_events.txt 2>/dev/null
-python3 scripts/netvlad_accuracy_probe.py > $O/netvlad_two_plane_accuracy.txt 2>/dev/null
+python3 tests/tools/netvlad_accuracy_probe.py > $O/netvlad_two_plane_accuracy.txt 2>/dev/null
 python3 scripts/lds_conflicts.py > $O/lds_conflicts.txt 2>/dev/null
 python3 scripts/conv_ab.py --rounds 2 > $O/conv_lds_kernels_32x32x16_vs_16x16x32.jsonl 2>/dev/null
 python3 scripts/conv_layers.py > $O/conv_layers_own_vs_library.txt 2>/dev/null

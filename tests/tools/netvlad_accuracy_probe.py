@@ -3,7 +3,8 @@
 float32 operand as bf16 high + low, 2^-17 relative) cost in accuracy, at the bench shape: the
 descriptors and all three gradients against the float64 autograd twin on the same bf16-rounded
 feature map.  Gates (tests/test_gpu_config1.py): 1e-4, 2e-4, 2e-4, 2.5e-3."""
-import sys; sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import netvlad_np as NV, twin_torch as TT
 from soft_contrastive_learning_amd.model import nets

@@ -2,7 +2,7 @@
 """Measured parity of the HIP path against the CPU oracle, as numbers (the tests assert the
 same comparisons against fixed tolerances; this prints / stores what was actually reached).
 
-    python scripts/parity_report.py [--json profiles/rNN/parity_report.json]
+    python tests/tools/parity_report.py [--json profiles/rNN/parity_report.json]
 
 Rows: relative loss error vs the float32 NumPy oracle (north_star gate: 1e-4), norm-relative
 gradient error vs the float64 autograd twin, descriptor error of the NetVLAD head for both
@@ -14,7 +14,7 @@ import json
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
