@@ -6,3 +6,29 @@ gfx950 kernels behind the C-ABI of ``include/scl_hip.h``).  Importing the packag
 not load the library; the first op does, and raises if it was never built.
 """
 __version__ = "0.1.0"
+
+
+def install_as_learnlarge():
+    """Make the reference's own import lines resolve to this backend: its scripts import
+    ``learnlarge.model.nets``, ``learnlarge.model.losses``, ``learnlarge.util.cv`` / ``.io``
+    (train/train.py:15-25, evaluation/inference.py:11-16) and ``pointnetvlad_cls``.  Registers
+    those names in ``sys.modules`` (a ``learnlarge`` package that is really installed is left
+    alone and the call raises) and returns the alias package."""
+    import importlib
+    import sys
+    import types
+    if 'learnlarge' in sys.modules and not getattr(sys.modules['learnlarge'], '_scl_alias', False):
+        raise RuntimeError("a real 'learnlarge' package is already imported")
+    names = {'model': 'model', 'model.nets': 'model.nets', 'model.losses': 'model.losses',
+             'util': 'util', 'util.cv': 'util.cv', 'util.io': 'util.io'}
+    pkg = types.ModuleType('learnlarge')
+    pkg._scl_alias = True
+    pkg.__path__ = []                                   # a package: `import learnlarge.model.nets`
+    sys.modules['learnlarge'] = pkg
+    for alias, real in names.items():
+        mod = importlib.import_module(__name__ + '.' + real)
+        sys.modules['learnlarge.' + alias] = mod
+        parent, _, leaf = alias.rpartition('.')
+        setattr(sys.modules['learnlarge' + ('.' + parent if parent else '')], leaf, mod)
+    sys.modules['pointnetvlad_cls'] = importlib.import_module(__name__ + '.pointnetvlad_cls')
+    return pkg

@@ -146,3 +146,29 @@ def test_mining_windows_cover_every_trained_anchor():
     assert next_cadence(0, 10, 1, 1, 100) == 10 and next_cadence(90, 10, 1, 1, 95) == 95
     assert [s for s in range(0, 24, 4) if cadence_due(s, 10, 4, 2)] == [0, 12, 20]
     assert next_cadence(0, 10, 4, 2, 24) == 12
+
+
+def test_reference_import_lines_resolve_to_this_backend():
+    """after install_as_learnlarge() the reference's own import
+    statements (train/train.py:15-25, evaluation/inference.py:11-16) bind to this package."""
+    import sys
+    import soft_contrastive_learning_amd as scl
+    saved = {k: sys.modules.get(k) for k in list(sys.modules) if k == 'learnlarge' or k.startswith('learnlarge.')
+             or k == 'pointnetvlad_cls'}
+    try:
+        scl.install_as_learnlarge()
+        from learnlarge.model.nets import vgg16Netvlad, vgg16                # noqa: F401
+        from learnlarge.model.losses import wms_loss, ms_loss, logratio_loss   # noqa: F401
+        from learnlarge.util.cv import resize_img, standard_size              # noqa: F401
+        from learnlarge.util.io import load_img, load_csv, save_pickle        # noqa: F401
+        import learnlarge.model.nets as n2
+        from pointnetvlad_cls import lazy_quadruplet_loss, triplet_loss       # noqa: F401
+        from soft_contrastive_learning_amd.model import nets
+        assert n2 is nets and vgg16Netvlad is nets.vgg16Netvlad
+        scl.install_as_learnlarge()                                           # idempotent
+    finally:
+        for k in [k for k in sys.modules if k == 'learnlarge' or k.startswith('learnlarge.') or k == 'pointnetvlad_cls']:
+            del sys.modules[k]
+        for k, v in saved.items():
+            if v is not None:
+                sys.modules[k] = v
