@@ -77,11 +77,6 @@ def recall_at(top_g_dists, thresholds, n=1):
     return np.array([np.mean(g < x) for x in thresholds])
 
 
-def get_xy(meta):
-    """evaluation/top-n.py's use of util.io.load_csv columns (train/train.py:1152-1153)."""
-    return np.array([[e, n] for e, n in zip(meta['easting'], meta['northing'])], dtype=float)
-
-
 def out_pickle_path(out_root, query_lv_pickle, l, d):
     """evaluation/top-n.py:43-45, 83-86: <out_root>/l<l>_dim<d>/<query pickle name without dots>.pickle."""
     import os
@@ -99,6 +94,7 @@ def main(argv=None):
     import os
     from sklearn.metrics import pairwise_distances
     from ..util import io
+    from ..util.meta import get_xy
     p = argparse.ArgumentParser()
     p.add_argument('--pca_lv_pickle', required=True)
     p.add_argument('--query_lv_pickle', required=True)

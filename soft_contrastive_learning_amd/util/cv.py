@@ -51,15 +51,21 @@ def _axis(dn, sn, inv_scale, zero_outside):
     return s0, s1, w0, w1
 
 
-def resize_linear(img, fx, fy):
-    """``cv2.resize(img, (0, 0), fx=fx, fy=fy)`` for a uint8 image [H,W] or [H,W,C]."""
+def resize_linear(img, fx=None, fy=None, dsize=None):
+    """``cv2.resize(img, (0, 0), fx=fx, fy=fy)`` — or ``cv2.resize(img, dsize)`` with ``dsize`` =
+    (width, height), where the sampling scale is the ratio of the sizes — for a uint8 image [H,W] or
+    [H,W,C]."""
     img = np.asarray(img)
     if img.dtype != np.uint8 or img.ndim not in (2, 3):
         raise ValueError("resize_linear takes a uint8 image [H,W] or [H,W,C]")
     flat = img.ndim == 2
     src = img[:, :, None] if flat else img
     sh, sw = src.shape[:2]
-    dw, dh = int(np.rint(sw * float(fx))), int(np.rint(sh * float(fy)))
+    if dsize is not None:
+        dw, dh = int(dsize[0]), int(dsize[1])
+        fx, fy = dw / float(sw), dh / float(sh)
+    else:
+        dw, dh = int(np.rint(sw * float(fx))), int(np.rint(sh * float(fy)))
     if dw < 1 or dh < 1:
         raise ValueError("resize_linear: empty destination (%d x %d)" % (dw, dh))
     x0, x1, a0, a1 = _axis(dw, sw, float(fx), True)
@@ -87,3 +93,26 @@ def standard_size(img, h=180, w=240):
     top = math.floor((img.shape[0] - h) / 2.0)
     left = math.floor((img.shape[1] - w) / 2.0)
     return img[top:top + h, left:left + w, :]
+
+
+def merge_images(left_image, right_image):
+    """util/cv.py:30-34: the right image scaled to the left one's height, side by side (the example
+    pictures of the localisation check, train/train.py:400-420)."""
+    right = resize_linear(right_image, dsize=(right_image.shape[1] * left_image.shape[0] // right_image.shape[0],
+                                              left_image.shape[0]))
+    return np.concatenate((left_image, right), axis=1)
+
+
+def put_text(text, image, scale=1, color=(0, 255, 0)):
+    """util/cv.py:23-27: a caption at the lower-left anchor (10, 35).  The reference draws OpenCV's
+    Hershey glyphs; this draws PIL's default font — the pictures are for people, no number depends
+    on them."""
+    from PIL import Image, ImageDraw, ImageFont
+    im = Image.fromarray(np.asarray(image, dtype=np.uint8))
+    try:
+        font = ImageFont.load_default(size=int(round(28 * scale)))
+    except TypeError:                                        # older Pillow: fixed-size bitmap font
+        font = ImageFont.load_default()
+    draw = ImageDraw.Draw(im)
+    draw.text((10, 35), str(text), fill=tuple(int(c) for c in color), font=font, anchor='ls')
+    return np.asarray(im)

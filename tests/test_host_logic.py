@@ -153,21 +153,24 @@ def test_reference_import_lines_resolve_to_this_backend():
     statements (train/train.py:15-25, evaluation/inference.py:11-16) bind to this package."""
     import sys
     import soft_contrastive_learning_amd as scl
-    saved = {k: sys.modules.get(k) for k in list(sys.modules) if k == 'learnlarge' or k.startswith('learnlarge.')
-             or k == 'pointnetvlad_cls'}
+    def mine(k):
+        return k.split('.')[0] in ('learnlarge', 'pointnetvlad', 'pointnetvlad_cls')
+    saved = {k: sys.modules.get(k) for k in list(sys.modules) if mine(k)}
     try:
         scl.install_as_learnlarge()
         from learnlarge.model.nets import vgg16Netvlad, vgg16                # noqa: F401
         from learnlarge.model.losses import wms_loss, ms_loss, logratio_loss   # noqa: F401
-        from learnlarge.util.cv import resize_img, standard_size              # noqa: F401
-        from learnlarge.util.io import load_img, load_csv, save_pickle        # noqa: F401
+        from learnlarge.util.cv import put_text, merge_images, resize_img, standard_size   # noqa: F401
+        from learnlarge.util.meta import get_xy                              # noqa: F401
+        from pointnetvlad.pointnetvlad_cls import quadruplet_loss, lazy_triplet_loss   # noqa: F401
+        from learnlarge.util.io import load_img, load_csv, save_img, save_pickle, save_csv, load_pickle   # noqa: F401
         import learnlarge.model.nets as n2
         from pointnetvlad_cls import lazy_quadruplet_loss, triplet_loss       # noqa: F401
         from soft_contrastive_learning_amd.model import nets
         assert n2 is nets and vgg16Netvlad is nets.vgg16Netvlad
         scl.install_as_learnlarge()                                           # idempotent
     finally:
-        for k in [k for k in sys.modules if k == 'learnlarge' or k.startswith('learnlarge.') or k == 'pointnetvlad_cls']:
+        for k in [k for k in sys.modules if mine(k)]:
             del sys.modules[k]
         for k, v in saved.items():
             if v is not None:

@@ -107,3 +107,18 @@ def test_image_and_list_files(tmp_path):
     assert io.load_csv(tmp_path / 's.csv') == {'k': ['3'], 'm': ['z']}
     io.save_pickle([np.arange(3)], tmp_path / 'p.pickle')
     assert np.array_equal(io.load_pickle(tmp_path / 'p.pickle')[0], np.arange(3))
+
+
+def test_example_picture_helpers():
+    """util/cv.py:23-34 (the localisation check's example pictures, train/train.py:400-420)."""
+    rng = np.random.RandomState(6)
+    left = rng.randint(0, 256, (180, 240, 3)).astype(np.uint8)
+    right = rng.randint(0, 256, (90, 160, 3)).astype(np.uint8)
+    both = cv.merge_images(left, right)
+    assert both.shape == (180, 240 + 320, 3) and np.array_equal(both[:, :240], left)
+    assert np.array_equal(both[:, 240:], cv.resize_linear(right, dsize=(320, 180)))
+    assert np.array_equal(cv.resize_linear(right, dsize=(320, 180)), cv.resize_linear(right, 2.0, 2.0))
+    noted = cv.put_text('Top 1: 3.2', left.copy())
+    assert noted.shape == left.shape and (noted != left).any()
+    changed = np.argwhere((noted != left).any(axis=2))
+    assert changed[:, 0].max() <= 45 and changed[:, 1].min() >= 5       # around the anchor (10, 35)
