@@ -46,6 +46,11 @@ class CsvImageSet:
                             '{}_stereo_centre_{:02d}'.format(self.meta['date'][i], int(self.meta['folder'][i])),
                             '{}{}'.format(self.meta['t'][i], self.ext))
 
+    def load_raw(self, i):
+        """The frame as it lies on disk (the example pictures of the localisation check)."""
+        from ..util import io
+        return io.load_img(self.path(int(i)))
+
     def load_image(self, i):
         from ..util import cv, io
         img = io.load_img(self.path(int(i)))
@@ -89,6 +94,9 @@ class SyntheticImageSet:
 
     def __len__(self):
         return len(self.yaw)
+
+    def load_raw(self, i):
+        return self.load_images([int(i)])[0].clip(0, 255).astype(np.uint8)
 
     def load_images(self, indices):
         yy, xx = self._grid

@@ -81,3 +81,31 @@ def eval_loss(step_loss, sampler, image_set, indices, tuples_per_batch, tuple_sh
         images = torch.from_numpy(image_set.load_images(every)).to(device)
         losses.append(float(step_loss(distances, images)))
     return (float(np.mean(losses)) if losses else None), len(losses)
+
+
+def save_example_pictures(out_dir, mode, out_name, query_set, query_indices, ref_set, ref_indices,
+                          nearest, rng=None, count=10):
+    """The visual examples of the localisation check (train/train.py:400-420): for ``count`` random
+    queries the query frame, the retrieved frame and the geographically nearest reference frame side
+    by side, captioned with their distances, as ``<out_dir>/<mode>_<out_name>/<query file name>``.
+    ``nearest`` [Q,k]: the retrieval result of ``evaluate_localization`` (indices into
+    ``ref_indices``).  Returns the folder."""
+    import os
+    from sklearn.neighbors import KDTree
+    from ..util import cv, io
+    rng = rng or np.random
+    q_idx, r_idx = np.asarray(query_indices, dtype=int), np.asarray(ref_indices, dtype=int)
+    ref_xy, qry_xy = np.asarray(ref_set.xy)[r_idx], np.asarray(query_set.xy)[q_idx]
+    nearest = np.asarray(nearest, dtype=int)
+    d_top = np.linalg.norm(qry_xy - ref_xy[nearest[:, 0]], axis=1)
+    d_opt, i_opt = KDTree(ref_xy).query(qry_xy, k=1)
+    folder = os.path.join(out_dir, mode + '_' + out_name)
+    os.makedirs(folder, exist_ok=True)
+    for q in rng.choice(len(q_idx), min(count, len(q_idx)), replace=False):
+        query = cv.put_text('Query', query_set.load_raw(q_idx[q]))
+        got = cv.put_text('Retrieved {}'.format(d_top[q]), ref_set.load_raw(r_idx[nearest[q, 0]]))
+        best = cv.put_text('Optimal {}'.format(d_opt[q][0]), ref_set.load_raw(r_idx[i_opt[q][0]]))
+        merged = cv.merge_images(cv.merge_images(query, got), best)
+        name = os.path.basename(query_set.path(q_idx[q])) if hasattr(query_set, 'path') else '%d.png' % q_idx[q]
+        io.save_img(merged, os.path.join(folder, name))
+    return folder

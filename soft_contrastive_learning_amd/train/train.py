@@ -104,6 +104,9 @@ def make_parser():
                         '(train/train.py:1158); empty: every eval_ref_r-th image of the set')
     p.add_argument('--shuffled_root', default='',
                    help='directory of the per-epoch lists <set>_<epoch:03d>.csv; empty: synthetic')
+    p.add_argument('--save_examples', type=int, default=-1,
+                   help='example pictures of every localisation check (train/train.py:400-420): '
+                        '1 / 0; -1 = with --shuffled_root only')
     p.add_argument('--synthetic_dataset', type=int, default=0,
                    help='M > 0: train on a synthetic pose-tagged set of M images through the '
                         'sampler / pipeline / mining / evaluation route')
@@ -479,8 +482,13 @@ def train_dataset_epoch(flags, epoch, state, log):
                         refs = np.arange(0, len(rset), max(flags.eval_ref_r, 1))
                     q = np.arange(test_number * flags.num_eval_queries,
                                   (test_number + 1) * flags.num_eval_queries) % len(qset)
-                    metrics, _ = evaluate.evaluate_localization(model, rset, refs, qset, q, s_img)
+                    metrics, nearest = evaluate.evaluate_localization(model, rset, refs, qset, q, s_img)
                     rec[mode] = metrics
+                    want = flags.save_examples if flags.save_examples >= 0 else bool(flags.shuffled_root)
+                    if want and rank == 0:                           # :1079-1080, 400-420
+                        out_name = '{:02d}_checkpoint-{}'.format(epoch, state['step'])
+                        evaluate.save_example_pictures(saver.out_dir, mode, out_name, qset, q, rset, refs,
+                                                       nearest)
                 if rank == 0:
                     print('Other region loss: {}'.format(ev))        # :1144
                     log(rec)

@@ -43,3 +43,27 @@ def test_csv_set_paths_and_geometry(tmp_path):
     (lists / 'bad.csv').write_text('date,folder\n1,2\n')
     with pytest.raises(ValueError):
         dataset.CsvImageSet(str(lists / 'bad.csv'), root)
+
+
+def test_example_pictures_of_the_localisation_check(tmp_path):
+    """train/train.py:400-420: query | retrieved | optimal, captioned, one file per chosen query."""
+    from soft_contrastive_learning_amd.train import evaluate
+    root, lists = str(tmp_path / 'img'), tmp_path / 'lists'
+    lists.mkdir()
+    write_set(root, str(lists / 'ref_000.csv'), 8, size=(48, 64), folder=1, seed=1)
+    write_set(root, str(lists / 'qry_000.csv'), 6, size=(48, 64), folder=2, seed=2, t0=1500000000000000)
+    refs = dataset.CsvImageSet(str(lists / 'ref_000.csv'), root)
+    qrys = dataset.CsvImageSet(str(lists / 'qry_000.csv'), root)
+    ref_idx, q_idx = np.arange(0, 8, 2), np.array([1, 3, 4])
+    nearest = np.array([[0, 1], [3, 2], [1, 0]])
+    folder = evaluate.save_example_pictures(str(tmp_path / 'out'), 'other', '00_checkpoint-4', qrys, q_idx,
+                                            refs, ref_idx, nearest, rng=np.random.RandomState(0), count=2)
+    files = sorted(os.listdir(folder))
+    assert folder.endswith(os.path.join('out', 'other_00_checkpoint-4')) and len(files) == 2
+    assert all(f in {os.path.basename(qrys.path(i)) for i in q_idx} for f in files)
+    pic = io.load_img(os.path.join(folder, files[0]))
+    assert pic.shape == (48, 3 * 64, 3)
+    syn = dataset.SyntheticImageSet(12, 32, 40, seed=3)
+    folder = evaluate.save_example_pictures(str(tmp_path / 'out'), 'local', 's', syn, [0, 5], syn, [1, 2, 3],
+                                            np.array([[2], [0]]), rng=np.random.RandomState(1))
+    assert sorted(os.listdir(folder)) == ['0.png', '5.png']
