@@ -104,6 +104,9 @@ def make_parser():
                         '(train/train.py:1158); empty: every eval_ref_r-th image of the set')
     p.add_argument('--shuffled_root', default='',
                    help='directory of the per-epoch lists <set>_<epoch:03d>.csv; empty: synthetic')
+    p.add_argument('--tensorboard', type=int, default=1,
+                   help='TensorBoard event files <out>/local and <out>/other with the reference\'s tags '
+                        '(train/train.py:304, 380-397, 929-932, 1139-1147)')
     p.add_argument('--save_examples', type=int, default=-1,
                    help='example pictures of every localisation check (train/train.py:400-420): '
                         '1 / 0; -1 = with --shuffled_root only')
@@ -568,6 +571,30 @@ def main(argv=None):
     log = open(os.path.join(out_dir, 'train_log.txt'), 'a') if rank == 0 and (
         os.makedirs(out_dir, exist_ok=True) or True) else None
 
+    # writers['local'] / writers['other'] (train/train.py:929-932): the training loss and learning
+    # rate of every step and the training region's localisation numbers / the other region's loss and
+    # localisation numbers, as TensorBoard event files (tf_events.py)
+    boards = None
+    if rank == 0 and flags.tensorboard:
+        from .. import tf_events
+        boards = {m: tf_events.SummaryWriter(os.path.join(out_dir, m)) for m in ('local', 'other')}
+
+    def to_boards(rec):
+        if boards is None:
+            return
+        if 'loss' in rec and 'event' not in rec:                                  # :304
+            boards['local'].add_scalars({'loss': rec['loss'], 'learning_rate': rec['learning_rate']},
+                                        rec['step'])
+        elif rec.get('event') == 'eval':
+            if rec.get('other_region_loss') is not None:                           # :1145-1147
+                boards['other'].add_scalars({'loss': rec['other_region_loss']}, rec['step'])
+            for mode in ('other', 'local'):                                        # :380-397
+                vals = {k: v for k, v in (rec.get(mode) or {}).items() if isinstance(v, (int, float))}
+                if vals:
+                    boards[mode].add_scalars(vals, rec['step'])
+            for b in boards.values():
+                b.flush()
+
     if flags.synthetic_dataset > 0 or flags.shuffled_root:
         state = dict(model=model, opt=opt, buckets=buckets, saver=saver, dev=dev,
                      tuple_shape=tuple_shape, step=step, group=group, feat_dim=feat_dim)
@@ -576,11 +603,14 @@ def main(argv=None):
             if log is not None:
                 log.write(json.dumps(rec) + '\n')
                 log.flush()
+            to_boards(rec)
         try:
             for epoch in range(flags.max_epoch):
                 train_dataset_epoch(flags, epoch, state, write)
         finally:
             nets.GRAD_SINK = None        # also after an exception: the sink outlives nothing
+            for b in (boards or {}).values():
+                b.close()
         return state
 
     for epoch in range(flags.max_epoch):
@@ -603,6 +633,7 @@ def main(argv=None):
                 print('Train batch loss: {}'.format(rec['loss']))   # :289
                 log.write(json.dumps(rec) + '\n')
                 log.flush()
+                to_boards(rec)
                 if step % flags.eval_step == 0:
                     saver.save_rolling(model, step, opt)              # :1079
                 if step % flags.save_step == 0:
@@ -610,6 +641,8 @@ def main(argv=None):
         if rank == 0:
             saver.save_epoch(model, epoch, step, opt)                 # :984
     nets.GRAD_SINK = None
+    for b in (boards or {}).values():
+        b.close()
     if world > 1:
         dist.destroy_process_group()
 

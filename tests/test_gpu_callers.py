@@ -337,6 +337,15 @@ def test_trainer_dataset_route_sampling_mining_and_evaluation(dev, tmp_path):
     # the local set retrieves itself: a query image is in the reference list half of the time
     assert evals[-1]['local']['%<10m@Top1'] >= 50.0
     d = os.path.join(out, 'run')
+    # the two TensorBoard writers of the reference (train/train.py:929-932) with its tags
+    from soft_contrastive_learning_amd import tf_events
+    ev = {m: tf_events.read_events(os.path.join(d, m, os.listdir(os.path.join(d, m))[0])) for m in ('local', 'other')}
+    assert ev['local'][0][2] == 'brain.Event:2'
+    train_ev = [e for e in ev['local'] if 'learning_rate' in e[3]]
+    assert [e[1] for e in train_ev] == [r['step'] for r in steps]
+    assert abs(train_ev[0][3]['loss'] - steps[0]['loss']) < 1e-6 * abs(steps[0]['loss'])
+    assert any('%<25m@Top1' in e[3] and '25m-auc@Top1' in e[3] for e in ev['local'])
+    assert any('%<50m@Top1' in e[3] for e in ev['other'])
     assert tf_bundle.latest_checkpoint(d) is not None
     assert tf_bundle.exists(os.path.join(d, 'epoch-checkpoint-0'))
     assert any(f.startswith('part-checkpoint-') for f in os.listdir(d))
