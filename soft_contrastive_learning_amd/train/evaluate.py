@@ -53,7 +53,7 @@ def localization_metrics(top_g_dists, nearest_d_dist=None, radii=(50, 25, 10)):
 
 
 def evaluate_localization(model, ref_set, ref_indices, query_set, query_indices, images_per_pass,
-                          k=5):
+                          k=5, plots=None):
     """-> (metrics dict, nearest_latent_indices [Q,k] into ``ref_indices``)."""
     from sklearn.neighbors import KDTree
     ref_f = extract_features(model, ref_set, ref_indices, images_per_pass)
@@ -65,6 +65,8 @@ def evaluate_localization(model, ref_set, ref_indices, query_set, query_indices,
     qry_xy = np.asarray(query_set.xy)[np.asarray(query_indices, dtype=int)]
     g = np.linalg.norm(qry_xy[:, None, :] - ref_xy[nearest], axis=2)
     nearest_d, _ = KDTree(ref_xy).query(qry_xy, k=1)         # the optimum curve (:1184-1185)
+    if plots is not None:                                    # (out_dir, mode, out_name): the three PDFs
+        save_localization_plots(plots[0], plots[1], plots[2], g, nearest_d)
     return localization_metrics(g, nearest_d), nearest
 
 
@@ -109,3 +111,44 @@ def save_example_pictures(out_dir, mode, out_name, query_set, query_indices, ref
         name = os.path.basename(query_set.path(q_idx[q])) if hasattr(query_set, 'path') else '%d.png' % q_idx[q]
         io.save_img(merged, os.path.join(folder, name))
     return folder
+
+
+def save_localization_plots(out_dir, mode, out_name, top_g_dists, nearest_d_dist, radii=(50, 25, 10)):
+    """The three PDFs of a localisation check (train/train.py:368-396):
+    ``<out_dir>/<mode>_<out_name>_<rad>.pdf`` — % of queries localised within a tolerance, one curve
+    per Top-1 .. Top-k plus the optimum, AUC@Top1 and %<rad m@Top1 written into the plot.  Returns
+    the paths; [] when matplotlib is not importable."""
+    import os
+    try:
+        import matplotlib
+        matplotlib.use('Agg')
+        import matplotlib.pyplot as plt
+    except ImportError:
+        return []
+    import sklearn.metrics
+    g = np.asarray(top_g_dists, dtype=np.float64)
+    top_n = np.minimum.accumulate(g, axis=1)
+    opt = np.asarray(nearest_d_dist, dtype=np.float64).reshape(-1)
+    os.makedirs(out_dir, exist_ok=True)
+    paths = []
+    for rad in radii:
+        fig = plt.figure()
+        xs = np.linspace(0, rad, num=25)
+        for n in range(top_n.shape[1]):
+            ys = [float(np.sum(top_n[:, n] < x)) / float(len(top_n)) * 100 for x in xs]
+            plt.plot(xs, ys)
+            if n == 0:
+                plt.text(0.5 * float(rad), 8, 'AUC@Top1={:7.2f}'.format(sklearn.metrics.auc(xs, ys)))
+                plt.text(0.5 * float(rad), 2, '%<{}m@Top1={:7.2f}'.format(rad, ys[-1]))
+        plt.plot(xs, [float(np.sum(opt < x)) / float(len(top_n)) * 100 for x in xs])
+        plt.legend(['Top-%d' % (n + 1) for n in range(top_n.shape[1])] + ['Optimum'])
+        plt.ylabel('Correctly localized')
+        plt.xlabel('Tolerance [m]')
+        plt.xlim(0, rad)
+        plt.title(os.path.basename(os.path.dirname(out_dir)) + '\n' + os.path.basename(out_dir) + '\n' +
+                  mode + ' ' + out_name)
+        path = os.path.join(out_dir, mode + '_' + out_name + '_{}.pdf'.format(rad))
+        plt.savefig(path)
+        plt.close(fig)
+        paths.append(path)
+    return paths

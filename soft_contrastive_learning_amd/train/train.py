@@ -108,7 +108,7 @@ def make_parser():
                    help='TensorBoard event files <out>/local and <out>/other with the reference\'s tags '
                         '(train/train.py:304, 380-397, 929-932, 1139-1147)')
     p.add_argument('--save_examples', type=int, default=-1,
-                   help='example pictures of every localisation check (train/train.py:400-420): '
+                   help='curve PDFs and example pictures of every localisation check (train/train.py:368-420): '
                         '1 / 0; -1 = with --shuffled_root only')
     p.add_argument('--synthetic_dataset', type=int, default=0,
                    help='M > 0: train on a synthetic pose-tagged set of M images through the '
@@ -485,11 +485,14 @@ def train_dataset_epoch(flags, epoch, state, log):
                         refs = np.arange(0, len(rset), max(flags.eval_ref_r, 1))
                     q = np.arange(test_number * flags.num_eval_queries,
                                   (test_number + 1) * flags.num_eval_queries) % len(qset)
-                    metrics, nearest = evaluate.evaluate_localization(model, rset, refs, qset, q, s_img)
+                    want = (flags.save_examples if flags.save_examples >= 0 else bool(flags.shuffled_root)) \
+                        and rank == 0
+                    out_name = '{:02d}_checkpoint-{}'.format(epoch, state['step'])   # :1079-1080
+                    metrics, nearest = evaluate.evaluate_localization(
+                        model, rset, refs, qset, q, s_img,
+                        plots=(saver.out_dir, mode, out_name) if want else None)    # :368-396
                     rec[mode] = metrics
-                    want = flags.save_examples if flags.save_examples >= 0 else bool(flags.shuffled_root)
-                    if want and rank == 0:                           # :1079-1080, 400-420
-                        out_name = '{:02d}_checkpoint-{}'.format(epoch, state['step'])
+                    if want:                                         # :400-420
                         evaluate.save_example_pictures(saver.out_dir, mode, out_name, qset, q, rset, refs,
                                                        nearest)
                 if rank == 0:

@@ -67,3 +67,14 @@ def test_example_pictures_of_the_localisation_check(tmp_path):
     folder = evaluate.save_example_pictures(str(tmp_path / 'out'), 'local', 's', syn, [0, 5], syn, [1, 2, 3],
                                             np.array([[2], [0]]), rng=np.random.RandomState(1))
     assert sorted(os.listdir(folder)) == ['0.png', '5.png']
+
+
+def test_localisation_plots(tmp_path):
+    """train/train.py:368-396: <mode>_<out_name>_<rad>.pdf for rad in 50, 25, 10."""
+    from soft_contrastive_learning_amd.train import evaluate
+    rng = np.random.RandomState(4)
+    g = rng.uniform(0, 60, size=(20, 5))
+    paths = evaluate.save_localization_plots(str(tmp_path / 'run'), 'local', '00_checkpoint-100', g,
+                                             rng.uniform(0, 5, size=(20, 1)))
+    assert [os.path.basename(p) for p in paths] == ['local_00_checkpoint-100_%d.pdf' % r for r in (50, 25, 10)]
+    assert all(open(p, 'rb').read(5) == b'%PDF-' for p in paths)

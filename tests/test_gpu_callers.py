@@ -401,8 +401,11 @@ def test_trainer_on_csv_lists_and_png_frames_in_the_reference_layout(dev, tmp_pa
     ep = [r for r in recs if r.get('event') == 'epoch'][0]
     assert ep['anchor_source'] == 'list' and ep['first_anchors'] == [int(v) for v in order[:4]]
     # example pictures of both localisation checks (train/train.py:400-420), six queries each
-    shots = [d for d in os.listdir(os.path.join(out, 'run')) if d.startswith(('other_00_checkpoint-', 'local_00_checkpoint-'))]
+    shots = [d for d in os.listdir(os.path.join(out, 'run')) if d.startswith(('other_00_checkpoint-', 'local_00_checkpoint-'))
+             and os.path.isdir(os.path.join(out, 'run', d))]
     assert len(shots) >= 2 and all(len(os.listdir(os.path.join(out, 'run', d))) == 6 for d in shots)
+    pdfs = [f for f in os.listdir(os.path.join(out, 'run')) if f.endswith('.pdf')]
+    assert len(pdfs) >= 6 and any(f.startswith('other_00_checkpoint-') and f.endswith('_25.pdf') for f in pdfs)
     # the frames went through the reference's loader: 96 x 128 -> 180 x 240
     one = dataset.CsvImageSet(str(lists / 'train_ref_000.csv'), img_root).load_images([0])
     assert one.shape == (1, 180, 240, 3)
