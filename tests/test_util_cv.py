@@ -122,3 +122,25 @@ def test_example_picture_helpers():
     assert noted.shape == left.shape and (noted != left).any()
     changed = np.argwhere((noted != left).any(axis=2))
     assert changed[:, 0].max() <= 45 and changed[:, 1].min() >= 5       # around the anchor (10, 35)
+
+
+def test_resampler_properties():
+    """Size-independent properties of the restated resampler: outputs stay inside the range of the
+    inputs they mix; mirroring commutes with resizing whenever the destination size is exact
+    (W fx integral: the sample points are then symmetric about the image centre and the two
+    fixed-point weights swap roles)."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=40, deadline=None)
+    @given(st.integers(1, 6), st.integers(1, 6), st.integers(1, 5), st.integers(1, 5), st.integers(0, 2 ** 31 - 1))
+    def check(ph, pw, qh, qw, seed):
+        rng = np.random.RandomState(seed)
+        sh, sw = 4 * qh * rng.randint(1, 4), 4 * qw * rng.randint(1, 4)
+        img = rng.randint(0, 256, (sh, sw, 3)).astype(np.uint8)
+        fy, fx = ph / float(qh), pw / float(qw)                  # sh fy and sw fx are integers
+        out = cv.resize_linear(img, fx, fy)
+        assert out.shape == (sh * ph // qh, sw * pw // qw, 3)
+        assert out.min() >= img.min() and out.max() <= img.max()
+        assert np.array_equal(cv.resize_linear(img[:, ::-1].copy(), fx, fy), out[:, ::-1])
+        assert np.array_equal(cv.resize_linear(img[::-1].copy(), fx, fy), out[::-1])
+    check()
