@@ -88,7 +88,7 @@ def parse():
     ap.add_argument('--side-wrw', type=int, default=-1,
                     help='weight-gradient kernels on a second HIP stream next to the backward-data '
                          'kernels: 1 on, 0 off (A/B), -1 (default) decided on this device during the '
-                         'warm-up by timing 3 steps each way twice (nets.autotune_side_wrw; the '
+                         'warm-up, at steady state, by timing 5 steps per setting three times (nets.autotune_side_wrw; the '
                          'setting that wins differs from box to box, the gradients do not)')
     ap.add_argument('--split-fwd', type=int, default=0,
                     help='1: the backbone forward as two half-batches pipelined on two HIP streams '
@@ -1026,8 +1026,16 @@ def main():
         reserve_choice = {'chosen': best_rv, 'ms_per_step_tried': {str(k): round(v, 3) for k, v in tried.items()}}
     side_choice = None
     if args.side_wrw < 0 and nets.USE_SIDE_WRW and nets.GRAD_SINK is not None:
-        # untimed, part of the warm-up: which setting of the second stream this device prefers
-        side_choice = nets.autotune_side_wrw(step)
+        # untimed, part of the warm-up: which setting of the second stream this device prefers.
+        # Decided in the regime the timed steps run in: a chip that has just started is cooler and
+        # clocks higher than after a quarter of a second under load (the first collections of round 5
+        # chose on 3-step bursts from cold: 11.38 ms in the warm-up, 11.60 in the timed region), so
+        # the device is brought to its steady state first and every setting gets 3 x 5 steps.
+        for _ in range(24):
+            step()
+        fence()
+        side_choice = nets.autotune_side_wrw(step, steps=5, rounds=3)
+        side_choice['settle_steps'] = 24
         if world > 1:                       # every rank must run the same schedule
             flag = torch.tensor([1.0 if side_choice['chosen'] else 0.0], device=dev)
             dist.all_reduce(flag)
