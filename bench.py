@@ -1009,18 +1009,22 @@ def main():
         # kernels need some — leave 0 or 8 CUs free, whichever gives the
         # shorter step on THIS node (max over ranks, so every rank decides the same)
         lib_ = _lib.load()
-        tried = {}
-        for rv in (0, 8):
-            lib_.scl_set_reserve_cus(rv)
+        for _ in range(24):                  # (at steady state, like the second-stream choice below)
             step()
-            fence()
-            t1 = time.perf_counter()
-            for _ in range(3):
+        fence()
+        tried = {0: float('inf'), 8: float('inf')}
+        for _ in range(2):
+            for rv in (0, 8):
+                lib_.scl_set_reserve_cus(rv)
                 step()
-            fence()
-            tt = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            tried[rv] = float(tt) / 3 * 1e3
+                fence()
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    step()
+                fence()
+                tt = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                tried[rv] = min(tried[rv], float(tt) / 5 * 1e3)
         best_rv = min(tried, key=tried.get)
         lib_.scl_set_reserve_cus(best_rv)
         reserve_choice = {'chosen': best_rv, 'ms_per_step_tried': {str(k): round(v, 3) for k, v in tried.items()}}
@@ -1031,9 +1035,10 @@ def main():
         # clocks higher than after a quarter of a second under load (the first collections of round 5
         # chose on 3-step bursts from cold: 11.38 ms in the warm-up, 11.60 in the timed region), so
         # the device is brought to its steady state first and every setting gets 3 x 5 steps.
-        for _ in range(24):
-            step()
-        fence()
+        if reserve_choice is None:          # (else the device is at its steady state already)
+            for _ in range(24):
+                step()
+            fence()
         side_choice = nets.autotune_side_wrw(step, steps=5, rounds=3)
         side_choice['settle_steps'] = 24
         if world > 1:                       # every rank must run the same schedule
