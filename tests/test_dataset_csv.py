@@ -40,6 +40,9 @@ def test_csv_set_paths_and_geometry(tmp_path):
     got = flat.load_images([1])
     assert got.shape == (1, 180, 240, 3)
     assert np.array_equal(got[0], cv.standard_size(frames[1], 180, 240).astype(np.float32))
+    serial = dataset.CsvImageSet(str(lists / 'train_ref_000.csv'), root, loader_threads=1)
+    pooled = dataset.CsvImageSet(str(lists / 'train_ref_000.csv'), root, loader_threads=4)
+    assert np.array_equal(serial.load_images([4, 1, 1, 0, 2]), pooled.load_images([4, 1, 1, 0, 2]))
     (lists / 'bad.csv').write_text('date,folder\n1,2\n')
     with pytest.raises(ValueError):
         dataset.CsvImageSet(str(lists / 'bad.csv'), root)
