@@ -13,6 +13,34 @@ import os
 import numpy as np
 
 
+def load_frame(path, vlad_cores=64, max_side=240, standard=(180, 240)):
+    """One frame as the network sees it (train/train.py:423-430) — a module-level function so that a
+    process pool can run it."""
+    from ..util import cv, io
+    img = io.load_img(path)
+    if vlad_cores > 0:
+        return cv.resize_img(img, max_side)
+    return cv.standard_size(img, h=standard[0], w=standard[1])
+
+
+def make_loader_pool(processes):
+    """A pool of worker PROCESSES for CsvImageSet(pool=...): PNG decoding scales with cores only
+    across processes.  Must be created before the process initialises the GPU (workers are spawned,
+    i.e. exec'd — and they never touch the device); returns None when that is too late or
+    ``processes`` < 1, and the sets fall back to their thread pools."""
+    import multiprocessing
+    from concurrent.futures import ProcessPoolExecutor
+    if processes < 1:
+        return None
+    try:
+        import torch
+        if torch.cuda.is_initialized():
+            return None
+    except ImportError:
+        pass
+    return ProcessPoolExecutor(max_workers=int(processes), mp_context=multiprocessing.get_context('spawn'))
+
+
 class CsvImageSet:
     """One reference CSV + an image root.  File of row i (``img_path``, train/train.py:124-128):
     ``<root>/<date>_stereo_centre_<folder:02d>/<t>.png``.  Images (``load_images``,
@@ -22,7 +50,7 @@ class CsvImageSet:
     restated in util/cv.py."""
 
     def __init__(self, csv_file, img_root, vlad_cores=64, max_side=240, standard=(180, 240), ext='.png',
-                 need_yaw=True, loader_threads=None):
+                 need_yaw=True, loader_threads=None, pool=None):
         with open(csv_file) as f:
             rows = list(csv.DictReader(f))
         need = ('date', 'folder', 't', 'easting', 'northing') + (('yaw',) if need_yaw else ())
@@ -43,6 +71,7 @@ class CsvImageSet:
         self.loader_threads = (min(16, os.cpu_count() or 1) if loader_threads is None
                                else max(int(loader_threads), 1))
         self._pool = None
+        self._procs = pool               # make_loader_pool(...): worker processes, shared by the sets
 
     def __len__(self):
         return len(self.yaw)
@@ -58,17 +87,17 @@ class CsvImageSet:
         return io.load_img(self.path(int(i)))
 
     def load_image(self, i):
-        from ..util import cv, io
-        img = io.load_img(self.path(int(i)))
-        if self.vlad_cores > 0:
-            return cv.resize_img(img, self.max_side)
-        return cv.standard_size(img, h=self.standard[0], w=self.standard[1])
+        return load_frame(self.path(int(i)), self.vlad_cores, self.max_side, self.standard)
 
     def load_images(self, indices):
         """float32 [n,H,W,3], 0..255 RGB (all images of a batch must come out the same size, as
         in the reference, whose feed would fail otherwise)."""
         indices = [int(i) for i in indices]
-        if self.loader_threads > 1 and len(indices) > 1:
+        if self._procs is not None and len(indices) > 1:
+            n = len(indices)
+            frames = list(self._procs.map(load_frame, [self.path(i) for i in indices], [self.vlad_cores] * n,
+                                          [self.max_side] * n, [self.standard] * n))
+        elif self.loader_threads > 1 and len(indices) > 1:
             if self._pool is None:
                 from concurrent.futures import ThreadPoolExecutor
                 self._pool = ThreadPoolExecutor(max_workers=self.loader_threads)

@@ -104,6 +104,9 @@ def make_parser():
                         '(train/train.py:1158); empty: every eval_ref_r-th image of the set')
     p.add_argument('--shuffled_root', default='',
                    help='directory of the per-epoch lists <set>_<epoch:03d>.csv; empty: synthetic')
+    p.add_argument('--loader_processes', type=int, default=0,
+                   help='worker processes decoding the frames of --shuffled_root sets (0: threads only). '
+                        'Created before the device is initialised; ignored when it already is')
     p.add_argument('--tensorboard', type=int, default=1,
                    help='TensorBoard event files <out>/local and <out>/other with the reference\'s tags '
                         '(train/train.py:304, 380-397, 929-932, 1139-1147)')
@@ -308,7 +311,8 @@ def open_sets(flags, epoch):
             # synthetic set's)
             return dataset.CsvImageSet(os.path.join(flags.shuffled_root,
                                                     '%s_%03d.csv' % (name, epoch)),
-                                       flags.img_root, vlad_cores=flags.vlad_cores)
+                                       flags.img_root, vlad_cores=flags.vlad_cores,
+                                       pool=getattr(flags, 'loader_pool', None))
         return (one(flags.local_ref_set), one(flags.local_query_set), one(flags.other_ref_set),
                 one(flags.other_query_set))
     m = flags.synthetic_dataset
@@ -539,6 +543,11 @@ def main(argv=None):
     one_gpu = os.environ.get('SCL_TRAIN_ONE_GPU_GLOO') == '1'
     if one_gpu:
         local_rank = 0
+    # worker processes for the image files: spawned BEFORE anything touches the device
+    flags.loader_pool = None
+    if flags.shuffled_root and flags.loader_processes > 0:
+        from . import dataset
+        flags.loader_pool = dataset.make_loader_pool(flags.loader_processes)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     group = None
@@ -614,6 +623,8 @@ def main(argv=None):
             nets.GRAD_SINK = None        # also after an exception: the sink outlives nothing
             for b in (boards or {}).values():
                 b.close()
+            if flags.loader_pool is not None:
+                flags.loader_pool.shutdown()
         return state
 
     for epoch in range(flags.max_epoch):

@@ -43,6 +43,14 @@ def test_csv_set_paths_and_geometry(tmp_path):
     serial = dataset.CsvImageSet(str(lists / 'train_ref_000.csv'), root, loader_threads=1)
     pooled = dataset.CsvImageSet(str(lists / 'train_ref_000.csv'), root, loader_threads=4)
     assert np.array_equal(serial.load_images([4, 1, 1, 0, 2]), pooled.load_images([4, 1, 1, 0, 2]))
+    procs = dataset.make_loader_pool(2)                     # (no device in this process: a real pool)
+    if procs is not None:
+        try:
+            forked = dataset.CsvImageSet(str(lists / 'train_ref_000.csv'), root, pool=procs)
+            assert np.array_equal(serial.load_images([4, 1, 1, 0, 2]), forked.load_images([4, 1, 1, 0, 2]))
+        finally:
+            procs.shutdown()
+    assert dataset.make_loader_pool(0) is None
     (lists / 'bad.csv').write_text('date,folder\n1,2\n')
     with pytest.raises(ValueError):
         dataset.CsvImageSet(str(lists / 'bad.csv'), root)
