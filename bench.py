@@ -110,6 +110,13 @@ def parse():
     ap.add_argument('--no-retrieval', action='store_true', help='skip the retrieval object (N=1)')
     ap.add_argument('--no-batch-sweep', action='store_true', help='skip the batch_sweep object (N=1)')
     ap.add_argument('--no-telemetry', action='store_true', help='skip the clock / power sample (N=1)')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='--gpus 1 only: form a ONE-rank RCCL ("nccl") process group and run the '
+                         'data-parallel step through it (embedding all-gather, own-rows backward, '
+                         'bucketed asynchronous gradient all-reduce) — the collective path on one GPU')
+    ap.add_argument('--dist-timeout', type=float, default=300.0,
+                    help='seconds: rendezvous and every collective (a missing rank fails the job '
+                         'after this long instead of hanging it)')
     ap.add_argument('--stub-cpu', action='store_true',
                     help='TEST ONLY: gloo on CPU with a trivial stand-in step; exercises the '
                          'launcher, the barriers and the max-over-ranks timing, measures nothing')
@@ -494,8 +501,8 @@ def stub_main(args, world, rank):
     """--stub-cpu: the launch / barrier / timing / reporting skeleton of main() on gloo with a
     trivial step.  Exists so that the N > 1 control flow is testable without a GPU."""
     if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('gloo', rank=rank, world_size=world)
+        from soft_contrastive_learning_amd import parallel
+        parallel.init_process_group(backend='gloo', timeout_s=args.dist_timeout)
     w = torch.ones(64, 64)
 
     def step():
@@ -738,13 +745,13 @@ def _switches(args):
     switches and the A/B flags of this script."""
     sw = {k: v for k, v in sorted(os.environ.items()) if k.startswith('SCL_')}
     for name, default in (('side_wrw', -1), ('split_fwd', 0), ('variant', 0), ('graph', 0),
-                          ('fused_relu', 1), ('miopen_find', 1)):
+                          ('fused_relu', 1), ('miopen_find', 1), ('force_dist', False)):
         if getattr(args, name) != default:
             sw['--' + name.replace('_', '-')] = getattr(args, name)
     return sw
 
 
-def retrieval_main(args, world, rank, dev):
+def retrieval_main(args, world, rank, dev, dp=False):
     """--workload retrieval: configs[4] with the REFERENCE SET SHARDED over the ranks (SURVEY
     §8e): every rank scans its rows for all (replicated) queries, the [Q, n] candidates are
     all-gathered and merged.  One step = one call over all queries; strong scaling (the total
@@ -762,7 +769,7 @@ def retrieval_main(args, world, rank, dev):
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -773,7 +780,7 @@ def retrieval_main(args, world, rank, dev):
             out = fn()
         fence()
         el = time.perf_counter() - t0
-        if world > 1:
+        if dp:
             t = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t)
@@ -782,7 +789,7 @@ def retrieval_main(args, world, rank, dev):
     stats = {}
 
     def step():
-        return parallel.topn_l2_sharded(shard, qt, n, lo, score=args.score)
+        return parallel.topn_l2_sharded(shard, qt, n, lo, score=args.score, force_exchange=dp)
 
     def local_only():
         return retrieval.topn_l2(shard, qt, n, idx_offset=lo, score=args.score, stats=stats)
@@ -808,14 +815,15 @@ def retrieval_main(args, world, rank, dev):
             'local_scan_ms_per_step': round(el_local / args.steps * 1e3, 3),
             'exchange_and_merge_us_per_step': round((elapsed - el_local) / args.steps * 1e6, 1),
             'uncertified_queries_local': stats.get('uncertified'),
-            'world_seen': dist.get_world_size() if world > 1 else 1,
+            'world_seen': dist.get_world_size() if dp else 1,
+            'backend': dist.get_backend() if dp else None,
             'checksum_idx': int(ii.sum()),
             'switches': _switches(args),
         }
         if args.n1_ref > 0:
             out['scaling_efficiency'] = round(out['value'] / (world * args.n1_ref), 4)
         print(json.dumps(out))
-    if world > 1:
+    if dp:
         dist.destroy_process_group()
 
 
@@ -939,20 +947,30 @@ def main():
     if args.dtype == 'f32':      # the bf16 step runs no library convolution
         torch.backends.cudnn.benchmark = bool(args.miopen_find)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if one_gpu:
-            dist.init_process_group('gloo')
-        else:
-            dist.init_process_group('nccl', device_id=dev)
+    from soft_contrastive_learning_amd import _lib, parallel
+    if args.force_dist and world != 1:
+        raise SystemExit('--force-dist is the one-rank form of the collective path: use --gpus 1')
+    # dp: the step runs through the process group (world > 1, or the one-rank group of --force-dist)
+    dp = world > 1 or args.force_dist
+    if dp:
+        parallel.init_process_group(dev, backend='gloo' if one_gpu else 'nccl',
+                                    timeout_s=args.dist_timeout, force_single=args.force_dist)
+    try:
+        return _main_body(args, world, rank, dev, dp)
+    except BaseException as exc:
+        if dp and not (isinstance(exc, SystemExit) and exc.code in (0, None)):
+            parallel.abort_rank(1)      # never leave the peers waiting in a collective
+        raise
 
+
+def _main_body(args, world, rank, dev, dp):
     from soft_contrastive_learning_amd import _lib, parallel
     from soft_contrastive_learning_amd.model import losses, nets
     if args.variant:
         _lib.use_diag()               # the variants exist in the diagnostic build only
     _lib.load()
     if args.workload == 'retrieval':
-        return retrieval_main(args, world, rank, dev)
+        return retrieval_main(args, world, rank, dev, dp)
     if args.side_wrw >= 0:
         nets.USE_SIDE_WRW = bool(args.side_wrw) and nets.USE_SIDE_WRW
     nets.USE_SPLIT_FWD = bool(args.split_fwd)
@@ -964,7 +982,7 @@ def main():
     cdt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
     model = nets.VGG16NetVLAD(compute_dtype=cdt, seed=1234, fused_relu=bool(args.fused_relu)).to(dev)
     params = list(model.parameters())
-    buckets = parallel.GradBuckets(params)
+    buckets = parallel.GradBuckets(params, force_collectives=args.force_dist)
     # train/train.py:1270 base_lr; one fused kernel, step counter on the device (graph-safe)
     # tf.train.AdamOptimizer (train/train.py:870): torch's fused kernel with TF's epsilon placement
     # (train/optim.py; under --graph the captured step keeps the eps of the capture)
@@ -985,7 +1003,7 @@ def main():
     def step():
         buckets.zero()
         emb = model(images)
-        if world > 1:
+        if dp:
             loss = parallel.wms_loss_dp(distances, emb, 0.8, 15.0)
         else:
             loss = losses.wms_loss(distances, emb, d_alpha=0.8, d_beta=15.0)
@@ -996,7 +1014,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -1004,7 +1022,7 @@ def main():
         step()
     fence()
     reserve_choice = None
-    if world > 1 and 'SCL_RESERVE_CUS' not in os.environ:
+    if dp and 'SCL_RESERVE_CUS' not in os.environ:
         # untimed, part of the warm-up: the persistent convolution grids take every CU, RCCL's
         # kernels need some — leave 0 or 8 CUs free, whichever gives the
         # shorter step on THIS node (max over ranks, so every rank decides the same)
@@ -1041,7 +1059,7 @@ def main():
             fence()
         side_choice = nets.autotune_side_wrw(step, steps=5, rounds=3)
         side_choice['settle_steps'] = 24
-        if world > 1:                       # every rank must run the same schedule
+        if dp:                              # every rank must run the same schedule
             flag = torch.tensor([1.0 if side_choice['chosen'] else 0.0], device=dev)
             dist.all_reduce(flag)
             nets.USE_SIDE_WRW = bool(flag.item() * 2 >= world)
@@ -1058,7 +1076,7 @@ def main():
     # except the allocations.  Falls back to eager launches if the capture is refused.
     graph = None
     run = step
-    if args.graph and world == 1 and os.environ.get('SCL_BENCH_EVENTS_IN_TIMED_REGION') != '1':
+    if args.graph and not dp and os.environ.get('SCL_BENCH_EVENTS_IN_TIMED_REGION') != '1':
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -1133,7 +1151,7 @@ def main():
             step()
         fence()
         el = time.perf_counter() - t1
-        if world > 1:
+        if dp:
             tt = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt)
@@ -1147,7 +1165,7 @@ def main():
     telemetry = (gpu_telemetry(step, fence)
                  if rank == 0 and world == 1 and not args.no_telemetry and not profiled else None)
     comm = None
-    if world > 1:
+    if dp:
         # what the first multi-GPU run must be able to explain by itself
         diag_steps = max(3, min(args.steps, 10))
         parallel.COMM_LOG = {'allgather': [], 'finish': []}
@@ -1179,7 +1197,7 @@ def main():
                        'around the waits of GradBuckets.finish() (rank 0, median over the diagnostic '
                        'steps run after the timed region); step time with scl_set_reserve_cus(0 / 8): '
                        'same process, max over ranks'}
-    if world > 1:
+    if dp:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
@@ -1314,7 +1332,7 @@ def main():
             out['cpu_baseline'] = cpu_baseline(args, torch.get_num_threads())
             out['cpu_baseline_kernels'] = cpu_baseline_kernels(torch.get_num_threads())
         print(json.dumps(out))
-    if world > 1:
+    if dp:
         dist.destroy_process_group()
 
 

@@ -15,8 +15,66 @@ box, "gloo" in the CPU tests).  The batch shards by image:
      through its own images only), in buckets launched as soon as their gradients are
      final so the collective overlaps the rest of the VGG backward.
 """
+import datetime
+import os
+import sys
+
 import torch
 import torch.distributed as dist
+
+
+def init_process_group(dev=None, backend='nccl', timeout_s=None, force_single=False):
+    """Join the job's process group (RANK / WORLD_SIZE / MASTER_* from the launcher's environment)
+    and return it, or None for a single process that was not asked to form one.
+
+    * ``backend`` "nccl" IS RCCL on this platform; the communicator is bound to ``dev`` at
+      creation (``device_id``), so the first collective does not have to guess the device.
+    * ``timeout_s`` (default ``SCL_DIST_TIMEOUT_S`` or 300): rendezvous AND every collective.  A
+      rank that never arrives makes the others fail after that long (the watchdog aborts the
+      communicator and the process exits non-zero) instead of sitting in a kernel until the
+      launcher's own limit.
+    * ``force_single``: with WORLD_SIZE 1 still create a one-rank group, so that the whole
+      collective path (communicator creation, the collectives' own stream and events, the
+      asynchronous work handles of GradBuckets) runs on a one-GPU box."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world == 1 and not force_single:
+        return None
+    if timeout_s is None:
+        timeout_s = float(os.environ.get('SCL_DIST_TIMEOUT_S', '300'))
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    if world == 1:
+        os.environ.setdefault('MASTER_PORT', str(_free_port()))
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+    kw = dict(timeout=datetime.timedelta(seconds=timeout_s))
+    if backend == 'nccl':
+        kw['device_id'] = dev
+    dist.init_process_group(backend, **kw)
+    return dist.group.WORLD
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def abort_rank(code=1):
+    """A rank failed: print the traceback of the exception being handled and leave at once.  No
+    destroy_process_group() — with RCCL that can block behind this rank's own outstanding
+    collectives while the peers wait in theirs, which is the hang this exists to avoid; the peers
+    see the closed connection (or their collective timeout) and fail too."""
+    import traceback
+    traceback.print_exc()
+    sys.stderr.flush()
+    sys.stdout.flush()
+    os._exit(code)
+
+
+# launch a bucket's all-reduce from the weight-gradient stream (GradBuckets._launch); 0: join that
+# stream into the compute stream first, as rounds 3-5 did
+ON_SIDE_STREAM = os.environ.get('SCL_BUCKETS_ON_SIDE', '1') != '0'
 
 # bench.py sets this to {'allgather': [], 'finish': []} for its diagnostic steps: pairs of device
 # events on the compute stream around the embedding all-gather and around the waits of
@@ -112,12 +170,28 @@ def tuple_loss_dp(local_loss, group=None):
 
 def all_gather_ragged(local, group=None):
     """Rows of every rank, concatenated in rank order, for row counts that may differ by rank
-    (mining-cache descriptors, image indices): padded to the longest, gathered, trimmed."""
+    (mining-cache descriptors, image indices): padded to the longest, gathered, trimmed.  A rank
+    with NO rows need not know the row width (a [0, anything] tensor will do): widths travel with
+    the counts and an empty rank adopts the others'."""
     world = dist.get_world_size(group)
-    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    width = 1
+    for d in local.shape[1:]:
+        width *= int(d)
+    n = torch.tensor([local.shape[0], width if local.shape[0] else 0], dtype=torch.int64,
+                     device=local.device)
     counts = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(counts, n, group=group)
-    counts = [int(c) for c in counts]
+    widths = {int(c[1]) for c in counts if int(c[0])}
+    counts = [int(c[0]) for c in counts]
+    if len(widths) > 1:
+        raise ValueError('all_gather_ragged: ranks disagree on the row width: %s' % sorted(widths))
+    if not widths:                                  # nobody has rows
+        return local[:0]
+    if local.shape[0] == 0 and width != next(iter(widths)):
+        if local.dim() != 2:
+            raise ValueError('all_gather_ragged: an empty rank of rank-%d rows must match the row '
+                             'shape of the others' % local.dim())
+        local = local.new_zeros((0, next(iter(widths))))
     longest = max(counts)
     pad = torch.zeros((longest,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[:local.shape[0]] = local
@@ -126,20 +200,21 @@ def all_gather_ragged(local, group=None):
     return torch.cat([p[:c] for p, c in zip(parts, counts)], 0)
 
 
-def topn_l2_sharded(ref_shard, query, n, shard_offset, group=None, score='f32', local_fn=None):
+def topn_l2_sharded(ref_shard, query, n, shard_offset, group=None, score='f32', local_fn=None,
+                    force_exchange=False):
     """Retrieval with the reference set sharded over ranks: every rank scans
     its own rows ``[shard_offset, shard_offset + len(ref_shard))`` for all (replicated)
     queries, the [Q, n] (distance, index) candidates are all-gathered (Q * n * 16 bytes per
     rank) and merged by (distance, index) — the same lists on every rank as the single-device
     call on the concatenated reference set.  ``local_fn`` replaces the HIP kernel in the
-    CPU tests of the exchange."""
+    CPU tests of the exchange; ``force_exchange`` runs the all-gather + merge in a one-rank group."""
     from .evaluation import retrieval
     if local_fn is None:
         d, i = retrieval.topn_l2(ref_shard, query, n, idx_offset=shard_offset, score=score)
     else:
         d, i = local_fn(ref_shard, query, n, shard_offset)
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-    if world == 1:
+    if world == 1 and not (force_exchange and dist.is_initialized()):
         return d, i
     ds = [torch.empty_like(d) for _ in range(world)]
     idx = [torch.empty_like(i) for _ in range(world)]
@@ -159,7 +234,9 @@ class GradBuckets:
     on the point-to-point xGMI fabric and small enough to hide under the conv backward.
     """
 
-    def __init__(self, params, group=None, bucket_bytes=16 << 20):
+    def __init__(self, params, group=None, bucket_bytes=16 << 20, force_collectives=False):
+        """``force_collectives``: launch the bucket all-reduces in a ONE-rank group too (a sum over
+        one rank: the gradients come back unchanged) — the asynchronous path on a one-GPU box."""
         self.params = [p for p in params if p.requires_grad]
         self.group = group
         total = sum(p.numel() for p in self.params)
@@ -185,9 +262,8 @@ class GradBuckets:
         if members:
             self._close(begin, off, members)
         self.enabled = dist.is_available() and dist.is_initialized() and \
-            dist.get_world_size(group) > 1
-        for p in self.params:
-            p.register_post_accumulate_grad_hook(self._hook)
+            (dist.get_world_size(group) > 1 or force_collectives)
+        self._hook_handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
         self._remaining = [len(m) for m in self._members]
         self._reported = {}
         # direct gradient sink (nets.GRAD_SINK): a backward kernel may write a parameter's
@@ -232,9 +308,26 @@ class GradBuckets:
         self._remaining[idx] -= 1
         if self._remaining[idx] == 0:
             b, e = self.buckets[idx]
+            self._handles.append(self._launch(self.flat[b:e]))
+
+    def _launch(self, part):
+        """Start the all-reduce of one bucket.  The collective orders itself after the stream that
+        is current when it is called.  With weight gradients on a side stream that stream is made
+        current for the call (after it has been ordered behind the compute stream's position,
+        which every weight-gradient launch does anyway): the collective then waits for exactly the
+        kernels that write the bucket, and the COMPUTE stream never waits for the side stream at a
+        bucket boundary — it only meets the collectives again in finish().  Joining the side stream
+        into the compute stream here instead (rounds 3-5) stalled the backward-data chain behind the
+        weight-gradient kernels four times per step."""
+        if not self._streams or not ON_SIDE_STREAM:
             self._join_streams()
-            self._handles.append(dist.all_reduce(self.flat[b:e], op=dist.ReduceOp.SUM,
-                                                 group=self.group, async_op=True))
+            return dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        side = self._streams[0]
+        side.wait_stream(torch.cuda.current_stream(self.flat.device))
+        for other in self._streams[1:]:
+            side.wait_stream(other)
+        with torch.cuda.stream(side):
+            return dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def note_stream(self, stream, *inputs):
         """A kernel on `stream` (not the current one) writes a gradient into the flat buffer:
@@ -276,6 +369,16 @@ class GradBuckets:
         self.flat.zero_()
         self._remaining = [len(m) for m in self._members]
         self._reported = {}
+
+    def close(self):
+        """Detach from the parameters (hooks removed, .grad views dropped): a second GradBuckets
+        over the same parameters must not find this one still reporting."""
+        self.zero()
+        for h in self._hook_handles:
+            h.remove()
+        self._hook_handles = []
+        for p in self.params:
+            p.grad = None
 
     def finish(self):
         """Wait for the collectives launched during backward (call before optimizer.step)."""

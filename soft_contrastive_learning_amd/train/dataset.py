@@ -23,13 +23,63 @@ def load_frame(path, vlad_cores=64, max_side=240, standard=(180, 240)):
     return cv.standard_size(img, h=standard[0], w=standard[1])
 
 
+def _worker_hello(delay):
+    """First task of every loader process: stay busy long enough for the pool to start them all."""
+    import time
+    time.sleep(delay)
+    return os.getpid()
+
+
+class LoaderPool:
+    """Worker PROCESSES for CsvImageSet(pool=...): PNG decoding scales with cores only across
+    processes.  Every worker is started (spawned, i.e. exec'd) INSIDE the constructor — the executor
+    would otherwise create them lazily on the first ``map``, after the trainer has initialised the
+    GPU, and an exec from a process that holds the device is what this pool of machines forbids.
+    The executor never starts a process later (it only adds one when it has fewer than
+    ``max_workers``, and a dead worker breaks it instead of being replaced); once broken, ``map``
+    returns None for good and the sets use their thread pools."""
+
+    def __init__(self, processes):
+        import multiprocessing
+        from concurrent.futures import ProcessPoolExecutor
+        self.processes = int(processes)
+        self._ex = ProcessPoolExecutor(max_workers=self.processes,
+                                       mp_context=multiprocessing.get_context('spawn'))
+        # a submit() adds a process while none is idle: `processes` tasks that keep their worker busy
+        # bring up all of them (repeat if an early worker finished and took a second task)
+        pids = set()
+        for _ in range(8):
+            futs = [self._ex.submit(_worker_hello, 0.5) for _ in range(self.processes)]
+            pids.update(f.result() for f in futs)
+            if len(self._ex._processes) >= self.processes:
+                break
+        if len(self._ex._processes) != self.processes:
+            self._ex.shutdown(cancel_futures=True)
+            raise RuntimeError('loader pool: %d of %d worker processes started'
+                               % (len(self._ex._processes), self.processes))
+        self.pids = sorted(p.pid for p in self._ex._processes.values())
+        self.broken = False
+
+    def map(self, fn, *iterables):
+        """list(map(fn, ...)) on the workers, or None when the pool is (now) unusable."""
+        from concurrent.futures.process import BrokenProcessPool
+        if self.broken:
+            return None
+        try:
+            return list(self._ex.map(fn, *iterables))
+        except (BrokenProcessPool, RuntimeError):     # a worker died / the pool was shut down
+            self.broken = True
+            return None
+
+    def shutdown(self):
+        self.broken = True
+        self._ex.shutdown(cancel_futures=True)
+
+
 def make_loader_pool(processes):
-    """A pool of worker PROCESSES for CsvImageSet(pool=...): PNG decoding scales with cores only
-    across processes.  Must be created before the process initialises the GPU (workers are spawned,
-    i.e. exec'd — and they never touch the device); returns None when that is too late or
-    ``processes`` < 1, and the sets fall back to their thread pools."""
-    import multiprocessing
-    from concurrent.futures import ProcessPoolExecutor
+    """LoaderPool(processes), all workers running on return.  Must be called before the process
+    initialises the GPU; returns None when that is too late or ``processes`` < 1, and the sets fall
+    back to their thread pools."""
     if processes < 1:
         return None
     try:
@@ -38,7 +88,7 @@ def make_loader_pool(processes):
             return None
     except ImportError:
         pass
-    return ProcessPoolExecutor(max_workers=int(processes), mp_context=multiprocessing.get_context('spawn'))
+    return LoaderPool(processes)
 
 
 class CsvImageSet:
@@ -93,10 +143,13 @@ class CsvImageSet:
         """float32 [n,H,W,3], 0..255 RGB (all images of a batch must come out the same size, as
         in the reference, whose feed would fail otherwise)."""
         indices = [int(i) for i in indices]
+        frames = None
         if self._procs is not None and len(indices) > 1:
             n = len(indices)
-            frames = list(self._procs.map(load_frame, [self.path(i) for i in indices], [self.vlad_cores] * n,
-                                          [self.max_side] * n, [self.standard] * n))
+            frames = self._procs.map(load_frame, [self.path(i) for i in indices], [self.vlad_cores] * n,
+                                     [self.max_side] * n, [self.standard] * n)     # None: pool broken
+        if frames is not None:
+            pass
         elif self.loader_threads > 1 and len(indices) > 1:
             if self._pool is None:
                 from concurrent.futures import ThreadPoolExecutor

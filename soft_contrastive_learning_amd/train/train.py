@@ -107,6 +107,11 @@ def make_parser():
     p.add_argument('--loader_processes', type=int, default=0,
                    help='worker processes decoding the frames of --shuffled_root sets (0: threads only). '
                         'Created before the device is initialised; ignored when it already is')
+    p.add_argument('--force_dist', type=int, default=0,
+                   help='single process only: form a ONE-rank RCCL process group and take the data-parallel '
+                        'routes through it (the collective path on a one-GPU box)')
+    p.add_argument('--dist_timeout', type=float, default=300.0,
+                   help='seconds: rendezvous and every collective')
     p.add_argument('--tensorboard', type=int, default=1,
                    help='TensorBoard event files <out>/local and <out>/other with the reference\'s tags '
                         '(train/train.py:304, 380-397, 929-932, 1139-1147)')
@@ -462,7 +467,7 @@ def train_dataset_epoch(flags, epoch, state, log):
                     share = np.array_split(mining_indices, world)[rank]
                     feats = parallel.all_gather_ragged(
                         evaluate.extract_features(model, local_ref, share, s_img)
-                        if len(share) else torch.zeros((0, state['feat_dim']), device=dev), group)
+                        if len(share) else torch.zeros((0, 0), device=dev), group)   # (width: from the others)
                 cache.update(feats, mining_indices)
                 mining_count += 1
                 if rank == 0:
@@ -512,18 +517,21 @@ def train_dataset_epoch(flags, epoch, state, log):
                 train_on(pipe.get())
                 outstanding -= 1
         drain(outstanding)
-    except BaseException:
+    except Exception:
         # a failure on ONE rank (a worker error re-raised by pipe.get(), a bad batch) would leave
         # the others blocked in the per-step MIN all-reduce: take the process group down with it
-        if group is not None:
+        # (no destroy_process_group() first: with RCCL it can block behind this rank's outstanding
+        # collectives while the peers wait in theirs — a hang is not an exception)
+        if group is not None and os.environ.get('SCL_TRAIN_ABORT_ON_RANK_FAILURE', '1') != '0':
             try:
-                dist.destroy_process_group()
+                pipe.close()
+                if getattr(flags, 'loader_pool', None) is not None:
+                    flags.loader_pool.shutdown()
+                for b in (state.get('boards') or {}).values():
+                    b.close()
             except Exception:
                 pass
-            if os.environ.get('SCL_TRAIN_ABORT_ON_RANK_FAILURE', '1') != '0':
-                import traceback
-                traceback.print_exc()
-                os._exit(1)               # peers see the closed connection instead of waiting
+            parallel.abort_rank(1)        # peers see the closed connection instead of waiting
         raise
     finally:
         pipe.close()
@@ -550,14 +558,10 @@ def main(argv=None):
         flags.loader_pool = dataset.make_loader_pool(flags.loader_processes)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    group = None
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if one_gpu:
-            dist.init_process_group('gloo')
-        else:
-            dist.init_process_group('nccl', device_id=dev)
-        group = dist.group.WORLD
+    if flags.force_dist and world != 1:
+        raise SystemExit('--force_dist is the one-rank form of the collective path')
+    group = parallel.init_process_group(dev, backend='gloo' if one_gpu else 'nccl',
+                                        timeout_s=flags.dist_timeout, force_single=bool(flags.force_dist))
 
     np.random.seed(42)                                    # train/train.py:1463-1464
     tuple_shape = tuple_shape_for(flags.loss, flags.positives_per_tuple,
@@ -566,8 +570,7 @@ def main(argv=None):
     model = nets.set_default_model(nets.VGG16NetVLAD(compute_dtype=cdt,
                                                      vlad_cores=flags.vlad_cores).to(dev))
     params = nets.trainable_parameters(model)       # train/train.py:606-611: the head decides
-    feat_dim = 32768 if flags.vlad_cores == 64 else (flags.height // 16) * (flags.width // 16) * 512
-    buckets = parallel.GradBuckets(params, group)
+    buckets = parallel.GradBuckets(params, group, force_collectives=bool(flags.force_dist))
     nets.GRAD_SINK = buckets       # conv weight / bias gradients go straight into the flat buffer
     # train/train.py:865-870: MomentumOptimizer / AdamOptimizer — TF's Adam (epsilon outside the bias
     # correction), not torch's: train/optim.py
@@ -609,7 +612,7 @@ def main(argv=None):
 
     if flags.synthetic_dataset > 0 or flags.shuffled_root:
         state = dict(model=model, opt=opt, buckets=buckets, saver=saver, dev=dev,
-                     tuple_shape=tuple_shape, step=step, group=group, feat_dim=feat_dim)
+                     tuple_shape=tuple_shape, step=step, group=group, boards=boards)
 
         def write(rec):
             if log is not None:
@@ -657,7 +660,7 @@ def main(argv=None):
     nets.GRAD_SINK = None
     for b in (boards or {}).values():
         b.close()
-    if world > 1:
+    if group is not None:
         dist.destroy_process_group()
 
 

@@ -56,6 +56,33 @@ def test_csv_set_paths_and_geometry(tmp_path):
         dataset.CsvImageSet(str(lists / 'bad.csv'), root)
 
 
+def test_loader_pool_workers_run_before_the_first_load_and_are_never_replaced(tmp_path):
+    """The workers must exist when make_loader_pool returns (the trainer initialises the GPU right
+    after it: a process started later would be an exec from a process that holds the device), the
+    first load_images() must start none, and a pool that lost a worker falls back to the threads
+    instead of starting a replacement."""
+    import signal
+    root, lists = str(tmp_path / 'img'), tmp_path / 'lists'
+    lists.mkdir()
+    write_set(root, str(lists / 'train_ref_000.csv'), 4, size=(96, 128))
+    procs = dataset.make_loader_pool(3)
+    try:
+        assert len(procs.pids) == 3
+        for pid in procs.pids:
+            os.kill(pid, 0)                                  # alive now, before any load_images()
+        s = dataset.CsvImageSet(str(lists / 'train_ref_000.csv'), root, pool=procs)
+        serial = dataset.CsvImageSet(str(lists / 'train_ref_000.csv'), root, loader_threads=1)
+        want = serial.load_images([0, 1, 2, 3])
+        assert np.array_equal(s.load_images([0, 1, 2, 3]), want)
+        assert sorted(p.pid for p in procs._ex._processes.values()) == procs.pids   # the same three
+        os.kill(procs.pids[0], signal.SIGKILL)               # a worker dies
+        assert np.array_equal(s.load_images([0, 1, 2, 3]), want)                    # threads took over
+        assert procs.broken
+        assert np.array_equal(s.load_images([3, 2]), want[[3, 2]])
+    finally:
+        procs.shutdown()
+
+
 def test_example_pictures_of_the_localisation_check(tmp_path):
     """train/train.py:400-420: query | retrieved | optimal, captioned, one file per chosen query."""
     from soft_contrastive_learning_amd.train import evaluate

@@ -284,6 +284,9 @@ def _ragged_worker(rank, port, out):
         rows = torch.arange(10, dtype=torch.float32).reshape(5, 2)
         share = rows[:3] if rank == 0 else rows[3:]
         out[rank] = parallel.all_gather_ragged(share)
+        # a rank with no rows that does not know the row width (the mining share of a short list)
+        out[10 + rank] = parallel.all_gather_ragged(rows if rank == 1 else torch.zeros((0, 0)))
+        out[20 + rank] = parallel.all_gather_ragged(torch.zeros((0, 7))).shape
     finally:
         dist.destroy_process_group()
 
@@ -295,3 +298,76 @@ def test_all_gather_ragged_concatenates_in_rank_order():
     mp.spawn(_ragged_worker, args=(_free_port(), out), nprocs=WORLD, join=True)
     for rank in range(WORLD):
         assert torch.equal(out[rank], torch.arange(10, dtype=torch.float32).reshape(5, 2))
+        assert torch.equal(out[10 + rank], torch.arange(10, dtype=torch.float32).reshape(5, 2))
+        assert tuple(out[20 + rank]) == (0, 7)
+
+
+# ---- a missing or silent rank fails the job after the timeout instead of hanging it ---------------
+_TIMEOUT_RANK = r"""
+import os, sys, time
+sys.path.insert(0, %r)
+import torch
+import torch.distributed as dist
+from soft_contrastive_learning_amd import parallel
+mode = sys.argv[1]
+group = parallel.init_process_group(backend='gloo', timeout_s=4.0)
+if mode == 'silent':              # joined, then never calls the collective
+    time.sleep(120)
+    sys.exit(0)
+try:
+    t = torch.ones(4)
+    dist.all_reduce(t, group=group)
+    print('all_reduce returned', flush=True)
+except Exception:
+    parallel.abort_rank(3)
+"""
+
+
+def _rank_proc(mode, rank, world, port):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+               MASTER_PORT=str(port))
+    return subprocess.Popen([sys.executable, '-c', _TIMEOUT_RANK % root, mode], env=env,
+                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+
+
+@pytest.mark.timeout(300)
+def test_rendezvous_times_out_when_a_rank_never_arrives():
+    """parallel.init_process_group(timeout_s=4) with WORLD_SIZE 2 and only rank 0 present: the
+    process fails (non-zero) within the timeout's order of magnitude — it does not wait for the
+    launcher's limit."""
+    import time
+    t0 = time.time()
+    pr = _rank_proc('wait', 0, 2, _free_port())
+    try:
+        out, _ = pr.communicate(timeout=120)
+    finally:
+        if pr.poll() is None:
+            pr.kill()
+    assert pr.returncode not in (0, None), out.decode(errors='replace')[-800:]
+    assert time.time() - t0 < 90
+
+
+@pytest.mark.timeout(300)
+def test_collective_times_out_and_the_rank_leaves_nonzero():
+    """Rank 1 joins the group and then never calls the collective: rank 0's all-reduce raises after
+    the group's timeout and parallel.abort_rank() ends the process with the given code, traceback
+    printed, no destroy_process_group()."""
+    import time
+    port = _free_port()
+    silent = _rank_proc('silent', 1, 2, port)
+    active = _rank_proc('reduce', 0, 2, port)
+    t0 = time.time()
+    try:
+        out, _ = active.communicate(timeout=150)
+    finally:
+        for pr in (active, silent):
+            if pr.poll() is None:
+                pr.kill()
+        silent.communicate()
+    text = out.decode(errors='replace')
+    assert active.returncode == 3, text[-1500:]
+    assert 'Traceback' in text and 'all_reduce returned' not in text
+    assert time.time() - t0 < 120
