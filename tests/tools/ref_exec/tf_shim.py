@@ -1,0 +1,345 @@
+"""A NumPy stand-in for the ~35 TensorFlow 1.x ops that ``/root/reference/model/losses.py`` calls
+at lines 5-135 (wms / evil_triplet / ms / logratio), 139-185 (ms_det), 197-250 (evil_quadruplet,
+worst_pos_distance, distance / huber_distance losses), 627-646 (pairwise_distance_loss) and
+656-700 (helpers) — so that the reference's OWN source text can be executed in the build
+container, where TensorFlow 1.10 does not exist, and its outputs frozen as fixtures
+(tests/tools/ref_exec/make_golden_ref.py -> tests/golden/golden_ref_v1.json).
+
+TEST TOOLING, BUILD CONTAINER ONLY.  Neither this file's consumer (the reference) nor anything it
+produces at run time travels to the GPU box; only the JSON does.
+
+What this does and does not buy.  By the task's rules a stand-in library pins nothing formally:
+parity stays "unpinned".  What changes is the trust surface.  Before: "a 300-line hand
+transcription of losses.py is faithful".  Now: "each op below means what TensorFlow 1.10 means
+by it" — every rank, axis, broadcast, transpose and tile of the reference's text is executed as
+written, by the reference's own statements, not re-read by the builder.  Eager evaluation in
+float32, one NumPy call per TF op, TF's static-shape API (``get_shape()``) on every tensor, and
+TF's STRICTER shape rules enforced where NumPy would silently broadcast (``tf.where`` operands of
+one shape, ``tf.matmul`` without batch broadcasting, ``tf.tile`` multiples of the tensor's rank).
+
+Known places where float32 results can differ from TensorFlow's in the last bits (none is a
+semantic difference): ``matmul`` / ``reduce_*`` accumulation order (Eigen vs NumPy pairwise),
+``exp`` / ``log`` (Eigen's vectorised polynomials vs NumPy's), ``rsqrt`` inside l2_normalize, and
+``tanh`` — TF 1.10 evaluates float32 tanh with Eigen's rational approximation, which this shim can
+imitate (``TANH = 'eigen'``, the polynomial recalled in oracle/losses_np.py) or replace by
+``np.tanh`` (``TANH = 'numpy'``); the fixture generator records both.
+"""
+import builtins
+import contextlib
+import types
+
+import numpy as np
+
+F32 = np.float32
+float32 = np.float32
+float64 = np.float64
+int32 = np.int32
+int64 = np.int64
+bool_ = np.bool_
+
+TANH = 'eigen'            # 'eigen' | 'numpy' (see the module docstring)
+CALLS = {}                # op name -> number of calls (the generator prints the ops a case used)
+
+
+class Dimension(int):
+    """tf.Dimension: usable as an int (the reference writes ``int(num_neg)``)."""
+    @property
+    def value(self):
+        return int(self)
+
+
+class TensorShape(tuple):
+    def as_list(self):
+        return [int(d) for d in self]
+
+    def __getitem__(self, i):
+        got = tuple.__getitem__(self, i)
+        return TensorShape(got) if isinstance(i, builtins.slice) else Dimension(got)
+
+    @property
+    def ndims(self):
+        return len(self)
+
+
+class Tensor(np.ndarray):
+    """An eager value with the static-shape API of tf.Tensor."""
+
+    def get_shape(self):
+        return TensorShape(Dimension(d) for d in self.shape)
+
+    def __array_finalize__(self, obj):
+        pass
+
+
+def _t(x, dtype=None):
+    """convert_to_tensor: Python floats become float32 (TF's default float), ints int32."""
+    if isinstance(x, Tensor) and (dtype is None or x.dtype == dtype):
+        return x
+    a = np.asarray(x)
+    if dtype is None:
+        if a.dtype == np.float64 and not isinstance(x, np.ndarray):
+            dtype = F32
+        elif a.dtype == np.int64 and not isinstance(x, np.ndarray):
+            dtype = np.int32
+        else:
+            dtype = a.dtype
+    return np.asarray(a, dtype=dtype, order='C').view(Tensor)
+
+
+def _count(name):
+    CALLS[name] = CALLS.get(name, 0) + 1
+
+
+def _same_float(a, b, op):
+    """TF refuses mixed dtypes in a binary op; Python scalars take the tensor's dtype."""
+    ta = isinstance(a, np.ndarray)
+    tb = isinstance(b, np.ndarray)
+    if ta and tb:
+        if a.dtype != b.dtype:
+            raise TypeError('%s: dtypes %s and %s do not match (TensorFlow does not promote)'
+                            % (op, a.dtype, b.dtype))
+        return _t(a), _t(b)
+    if ta:
+        return _t(a), _t(np.asarray(b, dtype=a.dtype))
+    if tb:
+        return _t(np.asarray(a, dtype=b.dtype)), _t(b)
+    return _t(a), _t(b)
+
+
+def _binary(name, fn):
+    def op(x, y, name_=None):
+        _count(name)
+        a, b = _same_float(x, y, name)
+        with np.errstate(over='ignore', divide='ignore', invalid='ignore'):
+            return _t(fn(a.view(np.ndarray), b.view(np.ndarray)))
+    op.__name__ = name
+    return op
+
+
+add = _binary('add', np.add)
+subtract = _binary('subtract', np.subtract)
+multiply = _binary('multiply', np.multiply)
+divide = _binary('divide', np.divide)
+div = _binary('div', np.divide)                    # float operands: true division
+maximum = _binary('maximum', np.maximum)
+minimum = _binary('minimum', np.minimum)
+equal = _binary('equal', np.equal)
+squared_difference = _binary('squared_difference', lambda a, b: (a - b) * (a - b))
+
+
+def _unary(name, fn):
+    def op(x, name_=None):
+        _count(name)
+        a = _t(x)
+        with np.errstate(over='ignore', divide='ignore', invalid='ignore'):
+            return _t(fn(a.view(np.ndarray)).astype(a.dtype, copy=False))
+    op.__name__ = name
+    return op
+
+
+exp = _unary('exp', np.exp)
+log = _unary('log', np.log)
+logical_not = _unary('logical_not', np.logical_not)
+zeros_like = _unary('zeros_like', np.zeros_like)
+ones_like = _unary('ones_like', np.ones_like)
+
+
+def _eigen_fast_tanh_f32(x):
+    """Eigen 3.3.90 generic_fast_tanh_float (RECALLED — the same restatement as
+    oracle/losses_np.py:eigen_fast_tanh_f32): clamp to +-9, 13th / 6th degree rational."""
+    x = np.maximum(F32(-9.0), np.minimum(F32(9.0), x.astype(F32)))
+    a = [F32(v) for v in (4.89352455891786e-03, 6.37261928875436e-04, 1.48572235717979e-05,
+                          5.12229709037114e-08, -8.60467152213735e-11, 2.00018790482477e-13,
+                          -2.76076847742355e-16)]
+    b = [F32(v) for v in (4.89352518554385e-03, 2.26843463243900e-03, 1.18534705686654e-04,
+                          1.19825839466702e-06)]
+    x2 = x * x
+    p = x2 * a[6] + a[5]
+    for c in (a[4], a[3], a[2], a[1], a[0]):
+        p = x2 * p + c
+    p = x * p
+    q = x2 * b[3] + b[2]
+    q = x2 * q + b[1]
+    q = x2 * q + b[0]
+    return (p / q).astype(F32)
+
+
+def tanh(x, name=None):
+    _count('tanh')
+    a = _t(x)
+    if TANH == 'eigen' and a.dtype == F32:
+        return _t(_eigen_fast_tanh_f32(a.view(np.ndarray)))
+    return _t(np.tanh(a.view(np.ndarray)).astype(a.dtype))
+
+
+def cast(x, dtype, name=None):
+    _count('cast')
+    return _t(np.asarray(x).astype(dtype))
+
+
+def constant(value, dtype=None, shape=None, name=None):
+    _count('constant')
+    a = _t(value, dtype)
+    return a if shape is None else _t(np.broadcast_to(a, shape).copy())
+
+
+def eye(num_rows, num_columns=None, dtype=F32, name=None):
+    _count('eye')
+    return _t(np.eye(int(num_rows), None if num_columns is None else int(num_columns), dtype=dtype))
+
+
+def zeros(shape, dtype=F32, name=None):
+    _count('zeros')
+    return _t(np.zeros([int(d) for d in shape], dtype=dtype))
+
+
+def ones(shape, dtype=F32, name=None):
+    _count('ones')
+    return _t(np.ones([int(d) for d in shape], dtype=dtype))
+
+
+def fill(dims, value, name=None):
+    _count('fill')
+    v = _t(value)
+    return _t(np.full([int(d) for d in dims], v, dtype=v.dtype))
+
+
+def where(condition, x=None, y=None, name=None):
+    """TF 1.10 Select: x and y of ONE shape; condition of that shape (or a vector over dim 0)."""
+    _count('where')
+    if x is None or y is None:
+        raise NotImplementedError('tf.where(condition) alone is not used by the reference')
+    c, a, b = np.asarray(condition), _t(x), _t(y)
+    if c.dtype != np.bool_:
+        raise TypeError('where: condition must be bool')
+    if a.shape != b.shape or a.dtype != b.dtype:
+        raise ValueError('where: x %s %s and y %s %s must match' % (a.shape, a.dtype, b.shape, b.dtype))
+    if c.shape != a.shape and not (c.ndim == 1 and c.shape[0] == a.shape[0]):
+        raise ValueError('where: condition %s does not match x %s (Select does not broadcast)'
+                         % (c.shape, a.shape))
+    if c.shape != a.shape:
+        c = c.reshape((-1,) + (1,) * (a.ndim - 1))
+    return _t(np.where(c, a.view(np.ndarray), b.view(np.ndarray)))
+
+
+def matmul(a, b, transpose_a=False, transpose_b=False, name=None):
+    """No batch broadcasting in TF 1.10: equal ranks >= 2 and equal leading dimensions."""
+    _count('matmul')
+    a, b = _same_float(a, b, 'matmul')
+    if a.ndim < 2 or a.ndim != b.ndim or a.shape[:-2] != b.shape[:-2]:
+        raise ValueError('matmul: shapes %s and %s' % (a.shape, b.shape))
+    x = np.swapaxes(a.view(np.ndarray), -1, -2) if transpose_a else a.view(np.ndarray)
+    y = np.swapaxes(b.view(np.ndarray), -1, -2) if transpose_b else b.view(np.ndarray)
+    return _t(np.matmul(x, y))
+
+
+def einsum(equation, *inputs):
+    _count('einsum')
+    return _t(np.einsum(equation, *[_t(i).view(np.ndarray) for i in inputs]))
+
+
+def transpose(a, perm=None, name=None):
+    """perm None = reverse ALL dimensions (the logratio quirk)."""
+    _count('transpose')
+    return _t(np.transpose(_t(a).view(np.ndarray), perm))
+
+
+def tile(input, multiples, name=None):       # noqa: A002 (TensorFlow's argument name)
+    _count('tile')
+    a = _t(input)
+    m = [int(v) for v in multiples]
+    if len(m) != a.ndim:
+        raise ValueError('tile: %d multiples for a rank-%d tensor' % (len(m), a.ndim))
+    return _t(np.tile(a.view(np.ndarray), m))
+
+
+def reshape(tensor, shape, name=None):
+    _count('reshape')
+    return _t(np.reshape(_t(tensor).view(np.ndarray), [int(d) for d in shape]))
+
+
+def concat(values, axis, name=None):
+    _count('concat')
+    return _t(np.concatenate([_t(v).view(np.ndarray) for v in values], axis=int(axis)))
+
+
+def _reduce(name, fn):
+    def op(input_tensor, axis=None, keepdims=False, name_=None, keep_dims=None):
+        _count(name)
+        a = _t(input_tensor).view(np.ndarray)
+        kd = bool(keepdims if keep_dims is None else keep_dims)
+        if name in ('reduce_sum', 'reduce_mean'):
+            return _t(np.asarray(fn(a, axis=axis, keepdims=kd, dtype=a.dtype)))
+        return _t(np.asarray(fn(a, axis=axis, keepdims=kd)))
+    op.__name__ = name
+    return op
+
+
+reduce_sum = _reduce('reduce_sum', np.sum)
+reduce_mean = _reduce('reduce_mean', np.mean)
+reduce_max = _reduce('reduce_max', np.max)
+reduce_min = _reduce('reduce_min', np.min)
+
+
+@contextlib.contextmanager
+def name_scope(name, default_name=None, values=None):
+    yield name
+
+
+def _l2_normalize(x, axis=None, epsilon=1e-12, name=None, dim=None):
+    """x * rsqrt(max(sum(x^2, axis), epsilon))   (python/ops/nn_impl.py)."""
+    _count('nn.l2_normalize')
+    a = _t(x).view(np.ndarray)
+    ax = axis if axis is not None else dim
+    sq = np.sum(a * a, axis=ax, keepdims=True, dtype=a.dtype)
+    inv = (a.dtype.type(1.0) / np.sqrt(np.maximum(sq, a.dtype.type(epsilon)))).astype(a.dtype)
+    return _t(a * inv)
+
+
+nn = types.SimpleNamespace(l2_normalize=_l2_normalize)
+
+
+class _Reduction:
+    NONE = 'none'
+    SUM = 'weighted_sum'
+    MEAN = 'weighted_mean'
+    SUM_BY_NONZERO_WEIGHTS = 'weighted_sum_by_nonzero_weights'
+
+
+def _huber_loss(labels, predictions, weights=1.0, delta=1.0, scope=None, loss_collection=None,
+                reduction=_Reduction.SUM_BY_NONZERO_WEIGHTS):
+    """python/ops/losses/losses_impl.py (RECALLED): error = predictions - labels;
+    quadratic = min(|error|, delta); linear = |error| - quadratic;
+    0.5 * quadratic^2 + delta * linear; default reduction with weights 1.0 = the mean."""
+    _count('losses.huber_loss')
+    lab, pred = _same_float(labels, predictions, 'huber_loss')
+    err = pred.view(np.ndarray) - lab.view(np.ndarray)
+    abs_err = np.abs(err)
+    quad = np.minimum(abs_err, err.dtype.type(delta))
+    lin = abs_err - quad
+    out = err.dtype.type(0.5) * quad * quad + err.dtype.type(delta) * lin
+    if reduction == _Reduction.NONE:
+        return _t(out)
+    if reduction == _Reduction.SUM:
+        return _t(np.asarray(np.sum(out, dtype=out.dtype)))
+    return _t(np.asarray(np.sum(out, dtype=out.dtype) / out.dtype.type(out.size)))
+
+
+losses = types.SimpleNamespace(huber_loss=_huber_loss, Reduction=_Reduction)
+
+
+def _unsupported(name):
+    def op(*a, **k):
+        raise NotImplementedError('tf.%s is outside the hot path (SURVEY.md section 2: OUT OF SCOPE)' % name)
+    return op
+
+
+linalg = types.SimpleNamespace(svd=_unsupported('linalg.svd'), eigh=_unsupported('linalg.eigh'),
+                               trace=_unsupported('linalg.trace'))
+slice = _unsupported('slice')        # noqa: A001
+
+
+class Session:
+    """The reference's __main__ smoke prints through a session (model/losses.py:712-714)."""
+    def run(self, fetches):
+        return np.asarray(fetches)
