@@ -167,7 +167,10 @@ int scl_gram_loss_fwd(const float* emb, int64_t ld_emb, int B, int E, int mask_k
  * memory that are ZERO when the call is enqueued and that no other call in flight uses; the
  * library leaves them zero, so one zero-initialised block per (device, stream) serves every
  * call.  NULL, or B > 32: exactly scl_gram_loss_fwd.  The results are bit-identical either way
- * (same sums in the same order). */
+ * (same sums in the same order).  (Diagnostic build only: with 8 bytes of 8-byte-aligned sync block
+ * scl_debug_set_variant(41) runs 32 < B <= 208 as ONE persistent kernel with grid barriers —
+ * bit-identical, deadlock-free by a bounded spin + repair path, and slower than the four launches:
+ * profiles/r06/loss_one_launch_persistent.txt.) */
 int scl_gram_loss_fwd_s(const float* emb, int64_t ld_emb, int B, int E, int mask_kind,
                         const float* distances, int dist_rank3, float d_alpha, float d_beta,
                         const int64_t* labels, float alpha, float beta, float lamb, float eps,

@@ -680,7 +680,9 @@ __device__ void final64_body(float* lds, const float* slabs, int S, int T, int P
 // FUSE (gram16_fused_kernel, 1024 threads): the first four waves run the Gram exactly as the
 // 256-thread kernel does, the other twelve only keep its barriers company until the finish, which
 // (in the last workgroup to arrive) wants sixteen waves: a half-wave per row, all rows at once.
-template <int PWMAX, bool FULL, bool FUSE>
+// PERSIST (gram16_persist_kernel, round 6): write-through slab stores and no early return — the
+// caller continues with persist_tail.
+template <int PWMAX, bool FULL, bool FUSE, bool PERSIST = false>
 __device__ __forceinline__ void gram16_body(const float* __restrict__ emb, int64_t ld, int B, int E, int T,
                                             int P, int kchunk, int KS, int vec_ok,
                                             float* __restrict__ slabs, const FinalArgs& fa) {
@@ -808,12 +810,12 @@ __device__ __forceinline__ void gram16_body(const float* __restrict__ emb, int64
 #pragma unroll
     for (int lp = 0; lp < PWMAX; ++lp)
       if (FULL || lp < np) {
-        if (FUSE)
+        if (FUSE || PERSIST)
           st_sc1_x4(slab + (int64_t)(p_begin + lp) * 256 + 4 * lane, acc[lp]);
         else
           *reinterpret_cast<f32x4*>(slab + (int64_t)(p_begin + lp) * 256 + 4 * lane) = acc[lp];
       }
-    if (!FUSE) return;
+    if (!FUSE && !PERSIST) return;
   } else {
     // k ranges on different waves: fixed-order sum through LDS (the staged slice is dead)
     __syncthreads();
@@ -830,7 +832,7 @@ __device__ __forceinline__ void gram16_body(const float* __restrict__ emb, int64
         const f32x4 v1 = red[P * 64 + idx], v2 = red[2 * P * 64 + idx], v3 = red[3 * P * 64 + idx];
         v = (v + v1) + (v2 + v3);
       }
-      if (FUSE)
+      if (FUSE || PERSIST)
         st_sc1_x4(slab + 4 * (int64_t)idx, v);
       else
         *reinterpret_cast<f32x4*>(slab + 4 * (int64_t)idx) = v;
@@ -1391,7 +1393,7 @@ __device__ void final64_body(float* lds, const float* slabs, int S, int T, int P
         for (int j = 0; j < 4; ++j) {
           const int r = 16 * ti + 4 * (lane >> 4) + j, c = 16 * tj + (lane & 15);
           G[r * LD + c] = v[j];
-          G[c * LD + r] = v[j];
+          if (ti != tj) G[c * LD + r] = v[j];
         }
       }
       __syncthreads();
@@ -1482,8 +1484,11 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const float* __restric
   for (int j = 0; j < 4; ++j) {
     const int r = 16 * ti + 4 * (lane >> 4) + j, c = 16 * tj + (lane & 15);
     if (r < B && c < B) {
+      // (diagonal tiles hold both (r, c) and (c, r) themselves: each is written by its owner only —
+      // the bf16x6 Gram adds the cross products of the two in a different order, so the two need
+      // not agree in the last bit, and which of two stores lands last must not decide a result)
       gfull[(int64_t)r * B + c] = v[j];
-      gfull[(int64_t)c * B + r] = v[j];
+      if (ti != tj) gfull[(int64_t)c * B + r] = v[j];
     }
   }
 }
@@ -1568,8 +1573,555 @@ __global__ __launch_bounds__(256) void gram_bwd32_kernel(const float* __restrict
   }
 }
 
+// =======================================================================================
+// Round 6: the forward for 32 < B <= 208 as ONE launch (was four: Gram | slab sums | rows | M).
+//
+//   gram16x6p_body   the bf16x6 Gram of gram16x6_kernel with BOTH 64-column passes of the
+//                    workgroup's slice resident in LDS (2 x 3 planes x 8 pieces x (Bp + 1) x 16 B =
+//                    145 KB at B = 192) and the PAIR loop outermost: a pair's 24 MFMAs (2 passes x 2
+//                    k-steps x 6 products, the same products in the same order into the same two
+//                    chains: same bits) finish it, and its 1 KB of slab goes out while the next
+//                    pair's MFMAs run — the 78 KB of slab per workgroup used to leave in one tail
+//                    burst after the last MFMA (store-issue-bound, ~4 us of a 22 us kernel).
+//   persist_tail     behind a grid barrier: phase 2, the slab sums, spread over EVERY workgroup
+//                    (item = one 16-byte unit of a pair tile; workgroup w owns items [N w / W, N (w +
+//                    1) / W), its four waves are gram_reduce_kernel's four chains s = w, w + 4, ..:
+//                    the same sums in the same order); barrier; phase 3, a wave per row
+//                    (wave_row_eval, as gram_rows_wave_kernel); barrier; phase 4, a workgroup per row
+//                    of M (as gram_coef_kernel).  Same bits as the four launches.
+//
+// Cross-workgroup visibility (MI355X_MICROARCH.md, "Valid forms", first row of the table): every
+// handed-off byte is stored sc1 (write-through), every storing wave drains its stores, a workgroup
+// barrier, ONE lane's agent-scope add to the arrival counter; consumers poll the counter with an
+// sc1 load, join a workgroup barrier and read every handed-off byte with sc1 loads.  No fence.
+//
+// The barrier SPINS, so the grid must be co-resident: the host only takes this path with at most
+// one workgroup per CU of the device.  Correctness still never depends on it: the spin is bounded
+// (a few ms), a workgroup that runs out of patience raises the ABORT bit, every workgroup that sees
+// it leaves at once, and the LAST workgroup to leave the kernel — by then every slab is complete —
+// runs phases 2-4 alone with the same routines (partition 0 of 1: the same sums in the same order,
+// the same bits).  That is what happens when two such kernels from two streams each hold part of
+// the chip, or when another kernel holds CUs for longer than the limit.
+// sync words (8-byte aligned, zero on entry, zero on return): [0] arrivals | ABORT bit, [1] leavers.
+// =======================================================================================
+#ifdef SCL_DIAG
+typedef __attribute__((address_space(1))) unsigned* u32_gptr_t;
+constexpr unsigned kAbortBit = 0x80000000u;
+constexpr int kPersistSpinLimit = 20000;        // x (poll + s_sleep) ~ 5-10 ms
+
+struct PersistArgs {
+  unsigned* sync;
+  const float* distances;
+  const int64_t* labels;
+  LossParams lp;
+  const float* slabs;        // [S][P][256]
+  float* gsum;               // [P][256] summed pair tiles
+  float *gn, *gc, *rn, *rowloss;
+  float* coef;
+  float* loss_out;
+  int S, T, P, B;
+  int spin_limit;
+  unsigned long long* stamps;   // diagnostics (scl_debug_set_variant(40), scripts/loss_stamps.py):
+                                // [workgroup][16] shader-clock stamps of thread 0; null otherwise
+};
+#define PSTAMP(a, k)                                                                         \
+  do {                                                                                       \
+    if (SCL_DIAG_ONLY((a).stamps != nullptr) && threadIdx.x == 0)                            \
+      (a).stamps[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime();                      \
+  } while (0)
+
+__device__ __forceinline__ void st_sc1_f32(float* p, float v) {
+  __hip_atomic_store((__attribute__((address_space(1))) float*)p, v, __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_sc1_f32(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, byte_off, 0, 16));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+
+// Arrive at the grid barrier number `phase` (1, 2, 3) and wait for the others.  false: aborted.
+// flag: one LDS word.  Every wave's stores are drained before the arrival is counted.
+__device__ __forceinline__ bool persist_barrier(unsigned* sync, unsigned target, int limit, int* flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int ok = 0;
+    for (int spins = 0;; ++spins) {
+      const unsigned x = __hip_atomic_load((u32_gptr_t)sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (x & kAbortBit) break;
+      if (x >= target) {
+        ok = 1;
+        break;
+      }
+      if (spins >= limit) {
+        __hip_atomic_fetch_or(sync, kAbortBit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(4);
+    }
+    *flag = ok;
+  }
+  __syncthreads();
+  const int ok = *flag;
+  __syncthreads();
+  return ok != 0;
+}
+
+// entry (r, c) of the summed Gram: tile (min, max) of the upper triangle, lane 16 (row >> 2) + col,
+// register row & 3 (gram16 / gram16x6 accumulator layout).  Diagonal tiles are read directly, as
+// gram_reduce_kernel writes them.
+__device__ __forceinline__ unsigned gsum_offset(int r, int c, int T) {
+  int tr = r >> 4, tc = c >> 4, rr = r & 15, cc = c & 15;
+  if (tr > tc) {
+    const int t = tr;
+    tr = tc;
+    tc = t;
+    const int q = rr;
+    rr = cc;
+    cc = q;
+  }
+  const int pair = tr * T - tr * (tr - 1) / 2 + (tc - tr);
+  return (unsigned)(((pair * 64 + 16 * (rr >> 2) + cc) * 4 + (rr & 3)) * 4);
+}
+
+// phase 2: partition w of W.  lds: [4][64] f32x4.
+__device__ __forceinline__ void persist_reduce(const PersistArgs& a, int w, int W, f32x4* part) {
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int N = 64 * a.P;
+  const int lo = (int)(((long)N * w) / W), hi = (int)(((long)N * (w + 1)) / W);
+  const __amdgpu_buffer_rsrc_t rsrc = rsrc_of(a.slabs, (unsigned)((size_t)a.S * a.P * 1024));
+  constexpr int U = 16;                                        // gram_reduce_kernel's batches
+  for (int base = lo; base < hi; base += 64) {
+    const int item = base + lane < hi ? base + lane : hi - 1;   // (idle lanes re-read the last item)
+    f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+    for (int s0 = wid; s0 < a.S; s0 += 4 * U) {
+      f32x4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {                            // (branch-free: clamped, masked below)
+        const int sidx = s0 + 4 * u < a.S ? s0 + 4 * u : a.S - 1;
+        v[u] = ld_sc1_x4(rsrc, (unsigned)((sidx * a.P * 64 + item) * 16));
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc4 += s0 + 4 * u < a.S ? v[u] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    part[wid * 64 + lane] = acc4;
+    __syncthreads();
+    if (wid == 0 && base + lane < hi) {
+      const f32x4 v = (part[lane] + part[64 + lane]) + (part[128 + lane] + part[192 + lane]);
+      st_sc1_x4(a.gsum + (int64_t)(base + lane) * 4, v);
+    }
+    __syncthreads();
+  }
+}
+
+// phase 3: rows i = w + W wid, + 4 W, ..: one wave per row, as gram_rows_wave_kernel<C>.
+template <int C>
+__device__ __forceinline__ void persist_rows(const PersistArgs& a, int w, int W) {
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int B = a.B;
+  const __amdgpu_buffer_rsrc_t gs = rsrc_of(a.gsum, (unsigned)(a.P * 1024));
+  const LossParams& lp = a.lp;
+  for (int i = w + W * wid; i < B; i += 4 * W) {               // (wave-uniform)
+    const float gii = ld_sc1_f32(gs, gsum_offset(i, i, a.T));
+    float gij[C], gjj[C], d[C], gn[C], g[C];
+    int same[C];
+    const int64_t labi = a.labels ? a.labels[i] : 0;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int j = lane + 64 * c;
+      const int jj = j < B ? j : B - 1;                        // (clamped: no branch around a load)
+      gij[c] = ld_sc1_f32(gs, gsum_offset(i, jj, a.T));
+      gjj[c] = ld_sc1_f32(gs, gsum_offset(jj, jj, a.T));
+      d[c] = 0.f;
+      same[c] = 0;
+      if (j < B) {
+        if (lp.mask_kind == SCL_MASK_LABELS)
+          same[c] = a.labels[j] == labi;
+        else
+          d[c] = lp.dist_rank3 ? a.distances[(int64_t)j * B + i] : a.distances[(int64_t)i * B + j];
+      }
+    }
+    const float rni = 1.0f / sqrtf(fmaxf(gii, 1e-12f));
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int j = lane + 64 * c;
+      const float rnj = 1.0f / sqrtf(fmaxf(gjj[c], 1e-12f));
+      gn[c] = j < B ? gij[c] * rni * rnj : 0.f;
+    }
+    const float rl = wave_row_eval<C>(i, B, lane, gn, d, same, lp, 1.0f / (float)B, g);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int j = lane + 64 * c;
+      if (j < B) {
+        st_sc1_f32(a.gn + (int64_t)i * B + j, gn[c]);
+        st_sc1_f32(a.gc + (int64_t)i * B + j, g[c]);
+      }
+    }
+    if (lane == 0) {
+      st_sc1_f32(a.rowloss + i, rl);
+      st_sc1_f32(a.rn + i, rni);
+    }
+  }
+}
+
+// phase 4: rows i = w, w + W, ..: the whole workgroup per row, as gram_coef_kernel (B <= 256:
+// thread j holds column j).  scratch: 32 floats.
+__device__ __forceinline__ void persist_coef(const PersistArgs& a, int w, int W, float* scratch) {
+  const int B = a.B, j = threadIdx.x;
+  const __amdgpu_buffer_rsrc_t rgn = rsrc_of(a.gn, (unsigned)(B * B * 4)), rgc = rsrc_of(a.gc, (unsigned)(B * B * 4)),
+                               rrn = rsrc_of(a.rn, (unsigned)(B * 4)), rrl = rsrc_of(a.rowloss, (unsigned)(B * 4));
+  const int jj = j < B ? j : B - 1;
+  if (w == 0) {
+    float s = j < B ? ld_sc1_f32(rrl, (unsigned)(jj * 4)) : 0.f;
+    s = block_reduce<0>(s, scratch);
+    if (threadIdx.x == 0) *a.loss_out = s / (float)B;
+  }
+  if (!a.coef) return;
+  const float rnj = ld_sc1_f32(rrn, (unsigned)(jj * 4));
+  for (int i = w; i < B; i += W) {
+    const float gs = ld_sc1_f32(rgc, (unsigned)((i * B + jj) * 4)) + ld_sc1_f32(rgc, (unsigned)((jj * B + i) * 4));
+    float c = j < B ? gs * ld_sc1_f32(rgn, (unsigned)((i * B + jj) * 4)) : 0.f;
+    c = block_reduce<0>(c, scratch);
+    const float rni = ld_sc1_f32(rrn, (unsigned)(i * 4));
+    const bool clamped = rni >= 1.0e6f;                        // see gram_coef_kernel
+    if (j < B) {
+      float m = rni * rnj * gs;
+      if (j == i && !clamped) m -= rni * rni * c;
+      a.coef[(int64_t)i * B + j] = m;
+    }
+    __syncthreads();                                           // scratch is reused by the next row
+  }
+}
+
+__device__ __forceinline__ void persist_rows_any(const PersistArgs& a, int w, int W) {
+  if (a.B <= 64)
+    persist_rows<1>(a, w, W);
+  else if (a.B <= 128)
+    persist_rows<2>(a, w, W);
+  else if (a.B <= 192)
+    persist_rows<3>(a, w, W);
+  else
+    persist_rows<4>(a, w, W);
+}
+
+// Everything behind the Gram phase of a 256-thread workgroup.  lds: >= 4.5 KB, dead Gram data.
+// One loop body serves both the normal run (partition blockIdx of gridDim, grid barriers between
+// the phases) and the repair run of the last workgroup out (partition 0 of 1, its own barriers).
+__device__ __forceinline__ void persist_tail(const PersistArgs& a, float* lds) {
+  f32x4* part = reinterpret_cast<f32x4*>(lds);                 // [4][64]
+  float* scratch = lds + 1024;                                 // [32]
+  int* flag = reinterpret_cast<int*>(lds + 1024 + 32);
+  int W = gridDim.x, w = blockIdx.x;
+  bool solo = false;
+  for (;;) {
+    auto barrier = [&](unsigned k) -> bool {
+      if (solo) {                                              // own stores -> own sc1 loads
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        return true;
+      }
+      return persist_barrier(a.sync, k * gridDim.x, a.spin_limit, flag);
+    };
+    PSTAMP(a, 2);
+    bool ok = barrier(1u);
+    PSTAMP(a, 3);
+    if (ok) {
+      persist_reduce(a, w, W, part);
+      PSTAMP(a, 4);
+      ok = barrier(2u);
+      PSTAMP(a, 5);
+    }
+    if (ok) {
+      persist_rows_any(a, w, W);
+      PSTAMP(a, 6);
+      ok = barrier(3u);
+      PSTAMP(a, 7);
+    }
+    if (ok) persist_coef(a, w, W, scratch);
+    PSTAMP(a, 8);
+    if (solo) break;
+    // ---- leave.  The last workgroup out repairs an aborted run; it puts the words back to zero.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned left = __hip_atomic_fetch_add(a.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int role = 0;
+      if (left == gridDim.x - 1) {
+        const unsigned x = __hip_atomic_load((u32_gptr_t)a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        role = (x & kAbortBit) ? 2 : 1;
+      }
+      *flag = role;
+    }
+    __syncthreads();
+    const int role = *flag;
+    __syncthreads();
+    if (role == 0) return;
+    if (role == 1) break;
+    solo = true;                                               // every slab is complete by now
+    w = 0;
+    W = 1;
+  }
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(a.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(a.sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+#endif   // SCL_DIAG (the persistent tail)
+
+// grid E / 128; block 256; dynamic LDS 2 * 3 * 8 * (Bp + 1) * 16 bytes (Bp = 16 T <= 208).
+// gram16x6_kernel's products in gram16x6_kernel's order (same bits per pair), scheduled differently:
+//   * STRIPS: a wave walks strips of TWO tile rows (r0, r0 + 1) from the diagonal to the right; a
+//     step = one tile column tj = the pairs (r0, tj) and (r0 + 1, tj).  The A fragments of both rows
+//     stay in registers along the strip and one read of the B fragments feeds two pairs: ~6.5
+//     fragment reads per pair and k-step instead of ~14 — the pair loop was bound by the LDS read
+//     rate (stamps, round 6: 18.5 k cycles for 7.7 k cycles of MFMA), not by the matrix pipe.
+//     The flat list of steps is cut into four ranges of (almost) equal pair counts, one per wave.
+//   * TWO PASSES, the second finishing pair by pair: pass 0 (columns 0..63 of the slice) runs while
+//     the loads of pass 1 are still in flight and keeps every pair's partial sums in registers;
+//     pass 1 runs step-outermost, so a step's pairs are complete after its 24 MFMAs and their 2 KB
+//     of slab leave while the next step computes (the 78 KB per workgroup used to go out in one
+//     burst behind the last MFMA: store-issue-bound).
+// DUAL as gram16x6_kernel (two accumulation chains per pair; the host picks it by the same rule).
+// SMAX: steps per wave (T <= 12: 11; T = 13: 13).  SC1: write-through slab stores.
+template <bool DUAL>
+__device__ __forceinline__ void x6_pair_mfmas(const gx_u32x4 (&A)[3], const gx_u32x4 (&Bf)[3], f32x4& c,
+                                              f32x4& c2) {
+  if constexpr (DUAL) {
+    c2 = mfma16bf(A[2], Bf[0], c2);         // chain 2: the small terms
+    c = mfma16bf(A[1], Bf[0], c);
+    c2 = mfma16bf(A[0], Bf[2], c2);
+    c = mfma16bf(A[0], Bf[1], c);
+    c2 = mfma16bf(A[1], Bf[1], c2);
+    c = mfma16bf(A[0], Bf[0], c);
+  } else {
+    c = mfma16bf(A[2], Bf[0], c);
+    c = mfma16bf(A[0], Bf[2], c);
+    c = mfma16bf(A[1], Bf[1], c);
+    c = mfma16bf(A[1], Bf[0], c);
+    c = mfma16bf(A[0], Bf[1], c);
+    c = mfma16bf(A[0], Bf[0], c);
+  }
+}
+
+template <bool DUAL, int SMAX, bool SC1>
+__device__ __forceinline__ void gram16x6p_body(const float* __restrict__ emb, int64_t ld, int B, int T, int P,
+                                               float* __restrict__ slabs,
+                                               unsigned long long* stamps = nullptr) {
+  extern __shared__ __attribute__((aligned(16))) unsigned x6p_lds[];
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, g = lane >> 4;
+  const int Bp = 16 * T;
+  const int IMG = 3 * 8 * (Bp + 1);                            // 16-byte units per pass image
+  const int k0 = blockIdx.x * (2 * kX6Sub);
+  constexpr int RMAX = 13;                                     // Bp * 16 / 256 <= 13 for Bp <= 208
+  f32x4 v[2][RMAX];
+  const int nq = Bp * 16;
+#pragma unroll
+  for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+    for (int u = 0; u < RMAX; ++u) {
+      const int q = u * 256 + threadIdx.x;                     // no branch around a load:
+      int row = q >> 4;                                        // rows past the end re-read B - 1
+      row = row < B ? row : B - 1;
+      v[sb][u] = *reinterpret_cast<const f32x4*>(emb + (int64_t)row * ld + k0 + sb * kX6Sub + 4 * (q & 15));
+    }
+  // ---- this wave's range of steps (scalar work under the loads): steps in strip-major order, a
+  //      step belongs to the wave whose pair range [P w / 4, P (w + 1) / 4) holds its first pair
+  int s_first = 0, tj_first = 0, nsteps = 0;
+  {
+    const int lo = (int)(((long)P * wid) / 4), hi = (int)(((long)P * (wid + 1)) / 4);
+    int c = 0;
+    for (int st = 0; 2 * st < T; ++st) {
+      const int r0 = 2 * st;
+      for (int tj = r0; tj < T; ++tj) {
+        if (c >= lo && c < hi) {
+          if (nsteps == 0) {
+            s_first = st;
+            tj_first = tj;
+          }
+          ++nsteps;
+        }
+        c += (r0 + 1 < T && tj >= r0 + 1) ? 2 : 1;
+      }
+    }
+  }
+  auto split_store = [&](int sb) {
+#pragma unroll
+    for (int u = 0; u < RMAX; ++u) {
+      const int q = u * 256 + threadIdx.x;
+      if (q < nq) {
+        const int row = q >> 4, c4 = q & 15;
+        unsigned h[3][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float x = row < B ? v[sb][u][c] : 0.f;
+          split3_bf16x(x, h[0][c], h[1][c], h[2][c]);
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          uint2 w2;
+          w2.x = h[pl][0] | (h[pl][1] << 16);
+          w2.y = h[pl][2] | (h[pl][3] << 16);
+          *reinterpret_cast<uint2*>(
+              &x6p_lds[((sb * IMG + (pl * 8 + (c4 >> 1)) * (Bp + 1) + row) << 2) + ((c4 & 1) << 1)]) = w2;
+        }
+      }
+    }
+  };
+  const gx_u32x4* img = reinterpret_cast<const gx_u32x4*>(x6p_lds) + g * (Bp + 1) + i;
+  // fragment (pass sb, k-step ks, plane pl, tile t) = img[sb * IMG + (pl * 8 + 4 * ks) * (Bp + 1) + 16 * t]
+  auto frag3 = [&](gx_u32x4 (&f)[3], int sb, int ks, int tile) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) f[pl] = img[sb * IMG + (pl * 8 + 4 * ks) * (Bp + 1) + 16 * tile];
+  };
+  auto next_step = [&](int st, int tj, int& st_n, int& tj_n) {
+    st_n = st;
+    tj_n = tj + 1;
+    if (tj_n == T) {
+      st_n = 2 * (st + 1) < T ? st + 1 : st;                   // (past the end: stay, harmless re-read)
+      tj_n = 2 * st_n;
+    }
+  };
+  f32x4 acc[2 * SMAX], acc2[DUAL ? 2 * SMAX : 1];
+#pragma unroll
+  for (int q = 0; q < 2 * SMAX; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < (DUAL ? 2 * SMAX : 1); ++q) acc2[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- pass 0: columns 0..63, k-step outermost, every pair's sums stay in registers
+  split_store(0);
+  __syncthreads();
+  if (SCL_DIAG_ONLY(stamps != nullptr) && threadIdx.x == 0)
+    stamps[blockIdx.x * 16 + 1] = __builtin_amdgcn_s_memtime();
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    int st = s_first, tj = tj_first;
+    gx_u32x4 a0[3], a1[3], b[3];
+    frag3(a0, 0, ks, 2 * st);
+    frag3(a1, 0, ks, 2 * st + 1 < T ? 2 * st + 1 : 2 * st);
+    frag3(b, 0, ks, tj);
+#pragma unroll
+    for (int ls = 0; ls < SMAX; ++ls) {
+      if (ls < nsteps) {
+        int st_n, tj_n;
+        next_step(st, tj, st_n, tj_n);
+        gx_u32x4 b_n[3];
+        frag3(b_n, 0, ks, tj_n);
+        __builtin_amdgcn_sched_barrier(0);       // the next step's reads fly under these MFMAs
+        x6_pair_mfmas<DUAL>(a0, b, acc[2 * ls], acc2[DUAL ? 2 * ls : 0]);
+        if (2 * st + 1 < T && tj >= 2 * st + 1)
+          x6_pair_mfmas<DUAL>(a1, b, acc[2 * ls + 1], acc2[DUAL ? 2 * ls + 1 : 0]);
+        if (st_n != st) {                        // (wave-uniform: the next strip)
+          frag3(a0, 0, ks, 2 * st_n);
+          frag3(a1, 0, ks, 2 * st_n + 1 < T ? 2 * st_n + 1 : 2 * st_n);
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) b[pl] = b_n[pl];
+        st = st_n;
+        tj = tj_n;
+      }
+    }
+  }
+  // ---- pass 1: columns 64..127, step outermost: a step's pairs are final after its MFMAs
+  split_store(1);
+  __syncthreads();
+  if (SCL_DIAG_ONLY(stamps != nullptr) && threadIdx.x == 0)
+    stamps[blockIdx.x * 16 + 9] = __builtin_amdgcn_s_memtime();
+  float* slab = slabs + (int64_t)blockIdx.x * P * 256;
+  {
+    int st = s_first, tj = tj_first;
+    gx_u32x4 a0[2][3], a1[2][3], b[2][3];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      frag3(a0[ks], 1, ks, 2 * st);
+      frag3(a1[ks], 1, ks, 2 * st + 1 < T ? 2 * st + 1 : 2 * st);
+      frag3(b[ks], 1, ks, tj);
+    }
+#pragma unroll
+    for (int ls = 0; ls < SMAX; ++ls) {
+      if (ls < nsteps) {
+        int st_n, tj_n;
+        next_step(st, tj, st_n, tj_n);
+        gx_u32x4 b_n[2][3];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) frag3(b_n[ks], 1, ks, tj_n);
+        __builtin_amdgcn_sched_barrier(0);
+        const bool two = 2 * st + 1 < T && tj >= 2 * st + 1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          x6_pair_mfmas<DUAL>(a0[ks], b[ks], acc[2 * ls], acc2[DUAL ? 2 * ls : 0]);
+          if (two) x6_pair_mfmas<DUAL>(a1[ks], b[ks], acc[2 * ls + 1], acc2[DUAL ? 2 * ls + 1 : 0]);
+        }
+        {
+          const int r0 = 2 * st;
+          const int pair = r0 * T - r0 * (r0 - 1) / 2 + (tj - r0);
+          const f32x4 out = DUAL ? acc[2 * ls] + acc2[DUAL ? 2 * ls : 0] : acc[2 * ls];
+          if (SC1)
+            st_sc1_x4(slab + (int64_t)pair * 256 + 4 * lane, out);
+          else
+            *reinterpret_cast<f32x4*>(slab + (int64_t)pair * 256 + 4 * lane) = out;
+        }
+        if (two) {
+          const int r1 = 2 * st + 1;
+          const int pair = r1 * T - r1 * (r1 - 1) / 2 + (tj - r1);
+          const f32x4 out = DUAL ? acc[2 * ls + 1] + acc2[DUAL ? 2 * ls + 1 : 0] : acc[2 * ls + 1];
+          if (SC1)
+            st_sc1_x4(slab + (int64_t)pair * 256 + 4 * lane, out);
+          else
+            *reinterpret_cast<f32x4*>(slab + (int64_t)pair * 256 + 4 * lane) = out;
+        }
+        if (st_n != st) {
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            frag3(a0[ks], 1, ks, 2 * st_n);
+            frag3(a1[ks], 1, ks, 2 * st_n + 1 < T ? 2 * st_n + 1 : 2 * st_n);
+          }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) b[ks][pl] = b_n[ks][pl];
+        st = st_n;
+        tj = tj_n;
+      }
+    }
+  }
+}
+
+template <bool DUAL, int SMAX>
+__global__ __launch_bounds__(256) void gram16x6p_kernel(const float* __restrict__ emb, int64_t ld, int B,
+                                                        int T, int P, float* __restrict__ slabs) {
+  gram16x6p_body<DUAL, SMAX, false>(emb, ld, B, T, P, slabs);
+}
+#ifdef SCL_DIAG
+template <bool DUAL, int SMAX>
+__global__ __launch_bounds__(256) void gram16x6_persist_kernel(const float* __restrict__ emb, int64_t ld,
+                                                               float* __restrict__ slabs, PersistArgs pa) {
+  extern __shared__ __attribute__((aligned(16))) unsigned x6p_lds[];
+  PSTAMP(pa, 0);
+  gram16x6p_body<DUAL, SMAX, true>(emb, ld, pa.B, pa.T, pa.P, slabs, SCL_DIAG_ONLY(pa.stamps));
+  persist_tail(pa, reinterpret_cast<float*>(x6p_lds));
+}
+
+// 32 < B <= 64: the exact-float32 Gram of gram16_kernel in front of the same tail.
+template <int PWMAX, bool FULL>
+__global__ __launch_bounds__(256) void gram16_persist_kernel(const float* __restrict__ emb, int64_t ld,
+                                                             int E, int kchunk, int KS, int vec_ok,
+                                                             float* __restrict__ slabs, PersistArgs pa) {
+  extern __shared__ __attribute__((aligned(16))) float g16_lds[];
+  PSTAMP(pa, 0);
+  gram16_body<PWMAX, FULL, false, true>(emb, ld, pa.B, E, pa.T, pa.P, kchunk, KS, vec_ok, slabs, FinalArgs{});
+  persist_tail(pa, g16_lds);
+}
+#endif   // SCL_DIAG
+
 struct GramWs {
-  float *slabs, *gn, *gc, *rn, *rowloss, *gfull;
+  float *slabs, *gn, *gc, *rn, *rowloss, *gfull, *gsum;
+  unsigned long long* stamps;   // diagnostic build: [256][16], the LAST bytes of the workspace
   size_t total;
 };
 
@@ -1588,6 +2140,12 @@ inline GramWs carve(void* ws, int B, size_t slab_floats) {
   w.rn = take((size_t)B * sizeof(float));
   w.rowloss = take((size_t)B * sizeof(float));
   w.gfull = take((size_t)B * B * sizeof(float));
+  const size_t t16 = (size_t)(B + 15) / 16;
+  w.gsum = take(t16 * (t16 + 1) / 2 * 256 * sizeof(float));    // summed pair tiles (one-launch forward)
+  w.stamps = nullptr;
+#ifdef SCL_DIAG
+  w.stamps = (unsigned long long*)take(256 * 16 * sizeof(unsigned long long));
+#endif
   w.total = off;
   return w;
 }
@@ -1653,6 +2211,50 @@ void launch_gram16_fused(const Gram16Plan& p, const float* emb, int64_t ld, int 
              emb, ld, B, E, p.T, p.P, p.kchunk, p.KS, vec_ok, slabs, fa);
 }
 
+#ifdef SCL_DIAG
+template <bool DUAL, int SMAX>
+void launch_x6_persist(const float* emb, int64_t ld, int E, float* slabs, const PersistArgs& pa,
+                       hipStream_t st) {
+  static SclDeviceOnce once;
+  scl_call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16x6_persist_kernel<DUAL, SMAX>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  });
+  const size_t lds = (size_t)2 * 3 * 8 * (16 * pa.T + 1) * 16;
+  SCL_LAUNCH("gram16x6_persist_kernel", (gram16x6_persist_kernel<DUAL, SMAX>), dim3(E / 128), dim3(256), lds, st,
+             emb, ld, slabs, pa);
+}
+#endif
+template <bool DUAL, int SMAX>
+void launch_x6p(const float* emb, int64_t ld, int B, int E, int T, int P, float* slabs, hipStream_t st) {
+  static SclDeviceOnce once;
+  scl_call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16x6p_kernel<DUAL, SMAX>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  });
+  const size_t lds = (size_t)2 * 3 * 8 * (16 * T + 1) * 16;
+  SCL_LAUNCH("gram16x6p_kernel", (gram16x6p_kernel<DUAL, SMAX>), dim3(E / 128), dim3(256), lds, st, emb, ld, B, T,
+             P, slabs);
+}
+#ifdef SCL_DIAG
+template <int PWMAX, bool FULL>
+void launch_gram16_persist(const Gram16Plan& p, const float* emb, int64_t ld, int E, int vec_ok,
+                           float* slabs, const PersistArgs& pa, hipStream_t st) {
+  static SclDeviceOnce once;
+  scl_call_once(once, [] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gram16_persist_kernel<PWMAX, FULL>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024);
+  });
+  size_t lds = (size_t)16 * p.T * (p.kchunk + 4) * sizeof(float);
+  const size_t red = p.KS > 1 ? (size_t)p.KS * p.P * 64 * sizeof(f32x4) : 0;
+  if (red > lds) lds = red;
+  if (lds < 8 * 1024) lds = 8 * 1024;                         // persist_tail's tables
+  SCL_LAUNCH("gram16_persist_kernel", (gram16_persist_kernel<PWMAX, FULL>), dim3(p.S), dim3(256), lds, st,
+             emb, ld, E, p.kchunk, p.KS, vec_ok, slabs, pa);
+}
+#endif
+constexpr int kX6pMaxRows = 208;     // both passes of the slice in LDS: 2 * 3 * 8 * (Bp + 1) * 16 B <= 160 KB
+
 }  // namespace
 
 extern "C" size_t scl_gram_loss_workspace_bytes(int B, int E) {
@@ -1704,13 +2306,71 @@ extern "C" int scl_gram_loss_fwd_s(const float* emb, int64_t ld_emb, int B, int 
     const int ps = 4 / p.KS;
     const int pw = (p.P + ps - 1) / ps;
     const bool full = p.P % ps == 0;
-    if (use_x6(B, E, ld_emb, emb)) {
+    // ---- round 6.  Product path for 64 < B <= 208: the strip-scheduled Gram kernel (gram16x6p_kernel)
+    // in front of the three finishing launches.  The ONE-launch persistent form (persist_tail) was
+    // built, is bit-identical and deadlock-free, and is SLOWER (B = 192: 52 us against 35; stamps in
+    // profiles/r06/loss_one_launch_persistent.txt: three grid barriers at 6-10 us each with their
+    // imbalance, and phases whose latency chains cost what the small kernels cost): it lives in the
+    // diagnostic build only — scl_debug_set_variant(41), + 39 no patience (repair path), 40 stamps.
+    // 37 = round 5's four launches (the old Gram kernel).
+    const bool x6 = use_x6(B, E, ld_emb, emb);
+    const bool x6p = x6 && 16 * p.T <= kX6pMaxRows;
+#ifdef SCL_DIAG
+    const int grid = x6 ? E / 128 : p.S;
+    const int pv = scl_variant();
+    if (B > 32 && sync_words && ((uintptr_t)sync_words % 8) == 0 && (x6p || (!x6 && B <= 64)) &&
+        grid <= scl_device_cus() && (pv == 39 || pv == 40 || pv == 41)) {
+      PersistArgs pa;
+      pa.sync = (unsigned*)sync_words;
+      pa.distances = distances;
+      pa.labels = labels;
+      pa.lp = lp;
+      pa.slabs = w.slabs;
+      pa.gsum = w.gsum;
+      pa.gn = w.gn;
+      pa.gc = w.gc;
+      pa.rn = w.rn;
+      pa.rowloss = w.rowloss;
+      pa.coef = coef;
+      pa.loss_out = loss_out;
+      pa.S = grid;
+      pa.T = p.T;
+      pa.P = p.P;
+      pa.B = B;
+      pa.spin_limit = scl_variant() == 39 ? 0 : kPersistSpinLimit;   // 39: no patience (the repair path)
+      pa.stamps = scl_variant() == 40 ? w.stamps : nullptr;          // 40: clock stamps
+      bool launched = true;
+      if (x6p) {
+        if ((p.P + 3) / 4 <= 20)
+          launch_x6_persist<true, 11>(emb, ld_emb, E, w.slabs, pa, st);
+        else
+          launch_x6_persist<false, 13>(emb, ld_emb, E, w.slabs, pa, st);
+      } else if (pw == 3 && full)
+        launch_gram16_persist<3, true>(p, emb, ld_emb, E, vec_ok, w.slabs, pa, st);
+      else if (pw <= 3)
+        launch_gram16_persist<3, false>(p, emb, ld_emb, E, vec_ok, w.slabs, pa, st);
+      else if (pw <= 5)
+        launch_gram16_persist<5, false>(p, emb, ld_emb, E, vec_ok, w.slabs, pa, st);
+      else
+        launched = false;
+      if (launched) return scl_launch_status();
+    }
+#endif
+    if (x6p && scl_variant() != 37) {
+      p.S = E / 128;
+      if ((p.P + 3) / 4 <= 20)
+        launch_x6p<true, 11>(emb, ld_emb, B, E, p.T, p.P, w.slabs, st);
+      else
+        launch_x6p<false, 13>(emb, ld_emb, B, E, p.T, p.P, w.slabs, st);
+    } else if (use_x6(B, E, ld_emb, emb)) {
       p.S = E / 128;                                          // slabs of the bf16x6 kernel
+#ifdef SCL_DIAG                                               // (B <= 208 arrives here under variant 37 only)
       if (pw <= 9)
         launch_gram16x6<9, true>(p.T, p.P, emb, ld_emb, B, E, w.slabs, st);
       else if (pw <= 20)
         launch_gram16x6<20, true>(p.T, p.P, emb, ld_emb, B, E, w.slabs, st);
       else
+#endif
         launch_gram16x6<34, false>(p.T, p.P, emb, ld_emb, B, E, w.slabs, st);
     } else if ((B <= 32 || (B <= 64 && scl_variant() == 36)) && sync_words && full &&
                (pw == 1 || pw == 3 || pw == 5) && scl_variant() != 32) {

@@ -54,10 +54,10 @@ class _GramLoss(torch.autograd.Function):
         if nbytes == 0:
             raise ValueError("unsupported batch / embedding size B=%d E=%d" % (b, e))
         ws = L.workspace(nbytes, emb.device)
-        # B <= 32: with the stream's zeroed sync block the forward is one launch (the finish runs in
-        # the Gram kernel's last workgroup).  The library takes the block up to B = 64; above 32 the
-        # one-launch form exists (scl_debug_set_variant(36), bit-identical) but measured slower
-        sync = L.sync_words(emb.device) if b <= 64 else None
+        # With the stream's zeroed sync block the forward is ONE launch: B <= 32 the finish runs in the
+        # Gram kernel's last workgroup; 32 < B <= 208 a persistent kernel with grid barriers between
+        # its phases (csrc/gram_loss.hip, persist_tail).  Bit-identical to the multi-launch forms.
+        sync = L.sync_words(emb.device) if b <= 256 else None
         L.check(lib.scl_gram_loss_fwd_s(
             L.ptr(emb), emb.stride(0), b, e, cfg['mask_kind'], L.ptr(distances),
             cfg['dist_rank3'], cfg['d_alpha'], cfg['d_beta'], L.ptr(labels), cfg['alpha'],

@@ -404,6 +404,94 @@ def test_fused_finish_gives_the_bits_of_the_two_launch_forward(dev, b, e, kind):
         assert l3.view(np.uint32) == l1.view(np.uint32)
 
 
+# ---- round 6: the strip-scheduled Gram kernel; the one-launch persistent forward (diagnostic) ------
+@pytest.mark.parametrize("b,e", [(33, 32768), (48, 32768), (64, 32768), (64, 4096), (65, 32768), (100, 4096),
+                                 (130, 32768), (160, 2048), (192, 32768), (192, 8192), (200, 32768),
+                                 (208, 32768), (209, 32768), (256, 32768)])
+@pytest.mark.parametrize("kind", ["wms_exp", "wms_tanh_plain", "ms"])
+def test_forward_above_32_gives_the_bits_of_round_5_in_every_form(dev, b, e, kind):
+    """Three forms of the forward for 32 < B <= 256, loss and d loss / d embeddings bit-identical:
+      0   the product path: 64 < B <= 208 the strip-scheduled Gram kernel (gram16x6p_kernel: two tile
+          rows per strip, second pass finishing pair by pair) + the three finishing launches;
+      37  round 5's four launches (gram16x6_kernel / gram16_kernel in front);
+      41  ONE persistent kernel (the Gram, then slab sums / rows / M behind grid barriers; B <= 208) —
+          built, measured slower, kept in the diagnostic build (profiles/r06) — and 39, the same with
+          no patience at the barriers: the run aborts and the last workgroup out redoes the phases
+          alone (the repair path that makes the spinning kernel safe without co-residency).
+    The sync block is zero after every form."""
+    from soft_contrastive_learning_amd import _lib as L
+    from soft_contrastive_learning_amd.model import losses
+    emb = torch.tensor(U.embeddings(b, e), device=dev)
+    dm = torch.tensor(U.positions_distances(b)[None], device=dev)
+    lab = torch.tensor(np.arange(b) // 3, device=dev)
+
+    def run(variant):
+        x = emb.clone().requires_grad_(True)
+        with L.maybe_variant(variant):
+            with L.KernelTimer(capacity=64) as kt:
+                if kind == "wms_exp":
+                    loss = losses.wms_loss(dm, x, 0.8, 15.0)
+                elif kind == "wms_tanh_plain":
+                    loss = losses.wms_loss(dm, x, 0.8, 15.0, wfunction='tanh', sumfunction='plain')
+                else:
+                    loss = losses.ms_loss(lab, x)
+                torch.cuda.synchronize()
+            names = set(kt.summary())
+            loss.backward()
+            torch.cuda.synchronize()
+            assert int(L.sync_words(dev).sum()) == 0
+        return loss.detach().cpu().numpy(), x.grad.cpu().numpy(), names
+    l0, g0, n0 = run(0)
+    l1, g1, n1 = run(37)
+    persistent = {'gram16x6_persist_kernel', 'gram16_persist_kernel'}
+    assert ('gram16x6p_kernel' in n0) == (64 < b <= 208 and e % 128 == 0), n0
+    assert 'gram16x6p_kernel' not in n1 and 'gram_reduce_kernel' in n1 and not ((n0 | n1) & persistent)
+    assert np.isfinite(l0) and l0.view(np.uint32) == l1.view(np.uint32), (l0, l1)
+    assert np.array_equal(g0.view(np.uint32), g1.view(np.uint32))
+    if b <= 208:
+        for v in (41, 39):
+            l2, g2, n2 = run(v)
+            assert n2 <= persistent and len(n2) == 1, (v, n2)
+            assert l2.view(np.uint32) == l0.view(np.uint32), v
+            assert np.array_equal(g2.view(np.uint32), g0.view(np.uint32)), v
+
+
+def test_two_streams_of_persistent_forwards_do_not_deadlock(dev):
+    """(Diagnostic variant 41.)  Two threads, each on its own stream with its own sync block, launch
+    the persistent B = 192 forward back to back: 2 x 256 workgroups of 145 KB LDS cannot all be
+    resident, so whenever the two grids split the chip between them both spin — the bounded spin +
+    repair path must bring every call home with the bits of an undisturbed call."""
+    import threading
+    from soft_contrastive_learning_amd import _lib as L
+    from soft_contrastive_learning_amd.model import losses
+    b, e, reps = 192, 32768, 150
+    emb = torch.tensor(U.embeddings(b, e), device=dev)
+    dm = torch.tensor(U.positions_distances(b)[None], device=dev)
+    want = losses.wms_loss(dm, emb, 0.8, 15.0).cpu().numpy()
+    torch.cuda.synchronize()
+    out, errs = {}, []
+
+    def work(k):
+        try:
+            st = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st):
+                vals = [losses.wms_loss(dm, emb, 0.8, 15.0) for _ in range(reps)]
+                st.synchronize()
+            out[k] = torch.stack(vals).cpu().numpy()
+        except Exception as ex:                                # noqa: BLE001 (reported below)
+            errs.append(ex)
+    with L.variant(41):
+        ths = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join(timeout=300)
+        assert not any(t.is_alive() for t in ths), 'a stream of persistent forwards did not finish'
+    assert not errs, errs
+    for k in range(2):
+        assert np.array_equal(out[k].view(np.uint32), np.broadcast_to(want.view(np.uint32), (reps,))), k
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('b,row_begin,row_count,e', [(192, 0, 192, 4096), (96, 0, 96, 2048), (200, 40, 100, 1024),
                                                     (256, 0, 200, 1024), (256, 0, 256, 512), (130, 7, 33, 640), (192, 0, 192, 448), (160, 16, 130, 256)])
