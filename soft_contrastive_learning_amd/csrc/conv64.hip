@@ -116,9 +116,16 @@ constexpr bool kWrwBufPath = true;
 // and, when KOUT = 64, one half of the tile's rows; its weights are 9 * CIN / 16 fragments =
 // 144 (CIN = 64) or 288 (CIN = 128) VGPRs.  CIN = 128 uses 4-row tiles so that two halo
 // windows fit LDS.
-template <int CIN, int KOUT>
+// GEO = 1 (round 6, (64, 64) only): 4-row tiles and FOUR waves per workgroup, so that TWO workgroups
+// share a CU (2 x 69 KB of LDS, 256 registers per lane as before).  The two waves of a SIMD then
+// belong to different workgroups: no barrier ties them together, so one runs its epilogue (matrix
+// pipe idle) while the other is in its K loop — with eight waves in one workgroup the tile barrier
+// phase-locked them (both in the K loop, then both in the epilogue: 8,100 cycles per tile against
+// 4,608 of MFMA issue).
+template <int CIN, int KOUT, int GEO = 0>
 struct ConvCfg {
-  static constexpr int TH_ = CIN == 64 ? 8 : 4;
+  static_assert(GEO == 0 || (CIN == 64 && KOUT == 64), "GEO 1 is conv1_2's geometry");
+  static constexpr int TH_ = (CIN == 64 && GEO == 0) ? 8 : 4;
   static constexpr int WR_ = TH_ + 2;
   static constexpr int PIX = CIN + 8;                  // bf16 per staged pixel
   static constexpr int WIN_ = WR_ * WC * PIX;          // bf16 per window buffer
@@ -126,7 +133,7 @@ struct ConvCfg {
   static constexpr int PIECES_ = WR_ * WC * PPP;
   // (64, 64) runs eight waves (two per SIMD: 144 weight + 32 accumulator registers fit 256),
   // the other shapes four (their register budget needs occupancy 1)
-  static constexpr int WAVES = (CIN == 64 && KOUT == 64) ? 8 : 4;
+  static constexpr int WAVES = (CIN == 64 && KOUT == 64 && GEO == 0) ? 8 : 4;
   static constexpr int NTHR = 64 * WAVES;
   static constexpr int SPP = PPP + 1;                  // 16-byte slots per staged pixel (+ pad)
   static constexpr int CHUNKS = (WR_ * WC * SPP + 63) / 64;   // 1-KB DMA chunks per window
@@ -201,8 +208,8 @@ __global__ __launch_bounds__(256) void conv3x3_pack_kernel(const void* __restric
 //     every image (the davg kernel's X term) go to a compact side buffer.
 // `pooled` carries x0 and `pidx` the float32 slab / corner workspace in this mode (EPI 3 uses
 // neither); saves the 944 MB store here and the 944 MB read + 217 us of conv_first_wrw_kernel.
-template <int CIN, int KOUT, int EPI, int PL = 0, int FW = 0>
-__global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(const unsigned short* __restrict__ x,
+template <int CIN, int KOUT, int EPI, int PL = 0, int FW = 0, int GEO = 0>
+__global__ __launch_bounds__((ConvCfg<CIN, KOUT, GEO>::NTHR), (GEO ? 2 : 1)) void conv3x3_kernel(const unsigned short* __restrict__ x,
                                                          const unsigned short* __restrict__ packed,
                                                          int B, int H, int W,
                                                          unsigned short* __restrict__ out,
@@ -211,8 +218,9 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
                                                          const unsigned short* __restrict__ mask,
                                                          unsigned char* __restrict__ pidx,
                                                          const unsigned char* __restrict__ uidx) {
-  using Cfg = ConvCfg<CIN, KOUT>;
+  using Cfg = ConvCfg<CIN, KOUT, GEO>;
   constexpr int TH_ = Cfg::TH_, PIX = Cfg::PIX, WIN_ = Cfg::WIN_, KS = Cfg::KS, MT = Cfg::MT;
+  static_assert(!FW || GEO == 0, "the fused first-layer gradients are written for the 8-row tile");
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -303,7 +311,7 @@ __global__ __launch_bounds__((ConvCfg<CIN, KOUT>::NTHR), 1) void conv3x3_kernel(
   // vmcnt(0), i.e. for the next tile's pooled gradient, in the middle of the products)
   auto p_rc = [&](int rd) {
     int tid_ = threadIdx.x;
-    if (FW) asm volatile("" : "+v"(tid_));
+    if (FW || GEO) asm volatile("" : "+v"(tid_));
     const int pp = (tid_ + Cfg::NTHR * rd) / PPP;
     return pp < PWR * PWC ? ((pp / PWC) << 8) | (pp % PWC) : -1;
   };
@@ -1789,29 +1797,47 @@ __global__ __launch_bounds__(64) void conv_first_davg_kernel(
 
 static int conv64_cus();
 
-template <int CIN, int KOUT>
+// conv1_2 with two 4-wave workgroups per CU (ConvCfg GEO 1) — DIAGNOSTIC BUILD, SCL_CONV64_TWO_WG=1.
+// Round 6 measured it (scripts/conv12_geo_ab.py, profiles/r06/conv12_two_workgroups_per_cu.txt):
+// bit-identical, forward 488 -> 478 us, backward-data with the un-pooling window 555 -> 686 us,
+// bias + ReLU forward 510 -> 510.  Taking the tile barrier out from between the two waves of a
+// SIMD does not speed the K loop up: the 8,100 cycles per tile are not the phase lock DESIGN.md
+// section 7 suspected, so the product keeps the one 8-wave workgroup.
+static bool conv64_two_wg() {
+#ifdef SCL_DIAG
+  static const bool on = [] {
+    const char* e = getenv("SCL_CONV64_TWO_WG");
+    return e && e[0] == '1';
+  }();
+  return on;
+#else
+  return false;
+#endif
+}
+
+template <int CIN, int KOUT, int GEO = 0>
 int launch_conv3x3(const void* x, const void* w, int64_t sk, int64_t sc, int64_t sh, int64_t sw,
                    int transposed, int B, int H, int W, void* out, const float* bias, int relu,
                    void* pooled, const void* mask, void* pidx, const void* uidx, void* workspace,
                    hipStream_t st) {
-  using Cfg = ConvCfg<CIN, KOUT>;
+  using Cfg = ConvCfg<CIN, KOUT, GEO>;
   static SclDeviceOnce once;
   scl_call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<CIN, KOUT, 0>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<CIN, KOUT, 0, 0, 0, GEO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<CIN, KOUT, 1>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<CIN, KOUT, 1, 0, 0, GEO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<CIN, KOUT, 2>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<CIN, KOUT, 2, 0, 0, GEO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<CIN, KOUT, 3>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<CIN, KOUT, 3, 0, 0, GEO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<CIN, KOUT, 4>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<CIN, KOUT, 4, 0, 0, GEO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
     if (CIN == KOUT)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<CIN, CIN, 3, 1>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<CIN, CIN, 3, 1, 0, GEO>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)Cfg::LDS);
   });
-  const int cus = conv64_cus();
+  const int cus = conv64_cus() * (GEO ? 2 : 1);
   const unsigned short* packed = (const unsigned short*)workspace;
   if (transposed & SCL_W_PACKED)
     packed = (const unsigned short*)w;                   // scl_conv_pack_batch wrote it
@@ -1823,32 +1849,32 @@ int launch_conv3x3(const void* x, const void* w, int64_t sk, int64_t sc, int64_t
   const dim3 grid(tiles < cus ? tiles : cus);
   if (scl_variant() / 1000 == 60) relu |= (scl_variant() & 7) << 1;   // bit 2: setprio experiment
   if (pidx)
-    SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 4>), grid, dim3(Cfg::NTHR), Cfg::LDS, st,
+    SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 4, 0, 0, GEO>), grid, dim3(Cfg::NTHR), Cfg::LDS, st,
                (const unsigned short*)x, (const unsigned short*)packed, B, H, W,
                (unsigned short*)nullptr, bias, relu & ~1, (unsigned short*)pooled,
                (const unsigned short*)nullptr, (unsigned char*)pidx, (const unsigned char*)nullptr);
   else if (mask && uidx && CIN == KOUT)
-    SCL_LAUNCH("conv3x3_kernel<pooled>", (conv3x3_kernel<CIN, CIN, 3, 1>), grid, dim3(Cfg::NTHR), Cfg::LDS,
+    SCL_LAUNCH("conv3x3_kernel<pooled>", (conv3x3_kernel<CIN, CIN, 3, 1, 0, GEO>), grid, dim3(Cfg::NTHR), Cfg::LDS,
                st, (const unsigned short*)x, (const unsigned short*)packed, B, H, W,
                (unsigned short*)out, bias, relu & ~1, (unsigned short*)nullptr,
                (const unsigned short*)mask, (unsigned char*)nullptr, (const unsigned char*)uidx);
   else if (mask)
-    SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 3>), grid, dim3(Cfg::NTHR), Cfg::LDS, st,
+    SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 3, 0, 0, GEO>), grid, dim3(Cfg::NTHR), Cfg::LDS, st,
                (const unsigned short*)x, (const unsigned short*)packed, B, H, W,
                (unsigned short*)out, bias, relu & ~1, (unsigned short*)nullptr,
                (const unsigned short*)mask, (unsigned char*)nullptr, (const unsigned char*)nullptr);
   else if (pooled)
-    SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 2>), grid, dim3(Cfg::NTHR), Cfg::LDS, st,
+    SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 2, 0, 0, GEO>), grid, dim3(Cfg::NTHR), Cfg::LDS, st,
                (const unsigned short*)x, (const unsigned short*)packed, B, H, W,
                (unsigned short*)out, bias, relu, (unsigned short*)pooled,
                (const unsigned short*)nullptr, (unsigned char*)nullptr, (const unsigned char*)nullptr);
   else if (bias)
-    SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 1>), grid, dim3(Cfg::NTHR), Cfg::LDS, st,
+    SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 1, 0, 0, GEO>), grid, dim3(Cfg::NTHR), Cfg::LDS, st,
                (const unsigned short*)x, (const unsigned short*)packed, B, H, W,
                (unsigned short*)out, bias, relu, (unsigned short*)pooled,
                (const unsigned short*)nullptr, (unsigned char*)nullptr, (const unsigned char*)nullptr);
   else
-    SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 0>), grid, dim3(Cfg::NTHR), Cfg::LDS, st,
+    SCL_LAUNCH("conv3x3_kernel", (conv3x3_kernel<CIN, KOUT, 0, 0, 0, GEO>), grid, dim3(Cfg::NTHR), Cfg::LDS, st,
                (const unsigned short*)x, (const unsigned short*)packed, B, H, W,
                (unsigned short*)out, bias, relu, (unsigned short*)pooled,
                (const unsigned short*)nullptr, (unsigned char*)nullptr, (const unsigned char*)nullptr);
@@ -1881,6 +1907,11 @@ static int conv3x3_dispatch(const void* x, const void* w, int64_t w_stride_k, in
     return launch_conv3x3<CI, KO>(x, w, w_stride_k, w_stride_c, w_stride_h, w_stride_w,        \
                                   transposed, B, H, W, out, bias, relu ? 1 : 0, pooled,        \
                                   mask, pidx, uidx, workspace, st);
+#ifdef SCL_DIAG
+  if (cin == 64 && kout == 64 && conv64_two_wg())
+    return launch_conv3x3<64, 64, 1>(x, w, w_stride_k, w_stride_c, w_stride_h, w_stride_w, transposed, B, H,
+                                     W, out, bias, relu ? 1 : 0, pooled, mask, pidx, uidx, workspace, st);
+#endif
   SCL_CONV_CASE(64, 64)
   SCL_CONV_CASE(64, 128)
   SCL_CONV_CASE(128, 64)
