@@ -125,7 +125,7 @@ def parse():
 
 # kernels of the NetVLAD head, by pass (names = the kernels' own names, as rocprofv3 prints them)
 NETVLAD_FWD = ('vlad_split_w_kernel', 'vlad_planes_kernel', 'vlad_fwd_kernel<true>', 'vlad_fwd_kernel<false>',
-               'vlad_fwd8_kernel<true>', 'vlad_fwd8_kernel<false>',
+               'vlad_fwd8_kernel<true>', 'vlad_fwd8_kernel<false>', 'vlad_fwd8_kernel<finish>',
                'vlad_finish_kernel', 'vlad_finish_sum_kernel', 'finish_norm_kernel', 'transpose_w_kernel',
                'rowtile16_kernel<ASSIGN>', 'aggregate_kernel<float>', 'aggregate_kernel<bf16>',
                'finish_sum_kernel')
@@ -153,14 +153,18 @@ def kernel_models(b, n, gb, x_bytes, slices=10):
         'vlad_fwd_kernel<true>': dict(flops=4.0 * bn * D * K,
                                       bytes=bn * D * 2 + bn * K * 8 + bn * 4 + slab, **b2),
         'vlad_fwd_kernel<false>': dict(flops=4.0 * bn * D * K, bytes=bn * D * 2 + slab, **b2),
-        # round 4: the same two kernels with eight waves per workgroup
+        # round 4: the same two kernels with eight waves per workgroup (round 6: the logits are no
+        # longer saved — a and rn only — and the backward pass reads a, not a + logits)
         'vlad_fwd8_kernel<true>': dict(flops=4.0 * bn * D * K,
-                                       bytes=bn * D * 2 + bn * K * 8 + bn * 4 + slab, **b2),
+                                       bytes=bn * D * 2 + bn * K * 4 + bn * 4 + slab, **b2),
         'vlad_fwd8_kernel<false>': dict(flops=4.0 * bn * D * K, bytes=bn * D * 2 + slab, **b2),
         'vlad_fwd8_kernel<stamps>': dict(flops=4.0 * bn * D * K,
-                                         bytes=bn * D * 2 + bn * K * 8 + bn * 4 + slab, **b2),
+                                         bytes=bn * D * 2 + bn * K * 4 + bn * 4 + slab, **b2),
+        # round 6, inference at >= 144 images: one workgroup per image, the finish in its tail
+        'vlad_fwd8_kernel<finish>': dict(flops=4.0 * bn * D * K + 4.0 * b * D * K,
+                                         bytes=bn * D * 2 + b * D * K * 4 + 2 * D * K * 4, **b2),
         'vlad_bwd8_kernel': dict(flops=4.0 * bn * D * K,
-                                 bytes=bn * D * 2 + bn * K * 12 + bn * 8 + slab + b * D * K * 4, **b2),
+                                 bytes=bn * D * 2 + bn * K * 8 + bn * 8 + slab + b * D * K * 4, **b2),
         # fused x.dU + softmax backward + x^T.(ds rn): x, a, logits, rn in; ds, rowdot, slabs out
         'vlad_bwd_kernel': dict(flops=4.0 * bn * D * K,
                                 bytes=bn * D * 2 + bn * K * 12 + bn * 8 + slab + b * D * K * 4, **b2),
@@ -203,6 +207,8 @@ def kernel_models(b, n, gb, x_bytes, slices=10):
         # 64 < B <= 256: the same Gram from six bf16 plane products (float32-equivalent);
         # SURVEY §8(d) prices the B = 192 Gram on the float32 MFMA peak
         'gram16x6_kernel': dict(flops=2.0 * gb * gb * E, bytes=gb * E * 4),
+        # round 6: the same products, strip-scheduled (64 < B <= 208)
+        'gram16x6p_kernel': dict(flops=2.0 * gb * gb * E, bytes=gb * E * 4),
         # everything after the Gram for B <= 32, one workgroup
         'gram_final32_kernel': dict(flops=48.0 * gb * gb, bytes=gb * gb * 16),
         # slab sums (split-K artefact: priced on the Gram matrix it produces)
@@ -288,10 +294,10 @@ def netvlad_floor(b, n, stage):
     rate = CU_STREAM_B_PER_CLK * CU_CLOCK_GHZ * 1e3          # bytes per microsecond and CU
     null_us = NULL_KERNEL_DEVICE_US or 3.4
     launches = {
-        'forward': {'vlad_fwd8_kernel': x + frag + 2 * rows + slab,
+        'forward': {'vlad_fwd8_kernel': x + frag + rows + slab,
                     'vlad_finish_kernel': slices * slab / 8 + 2 * slab / 8},
         'backward': {'vlad_bwd_prologue_kernel': 3 * slab / 8 + 2 * frag / 8,
-                     'vlad_bwd8_kernel': x + frag + 2 * rows + rows + slab,
+                     'vlad_bwd8_kernel': x + frag + rows + rows + slab,
                      'vlad_dx_kernel': 2 * x + 2 * rows + 2 * frag + b * slices * slab / (b * slices)},
     }
     out = {'per_cu_rate_bytes_per_us': round(rate, 1), 'workgroups': b * slices, 'slices_per_image': slices,
@@ -897,6 +903,32 @@ def batch_sweep(dev, iters=5):
                 ent[ps]['us_per_image'] = round(st[ps]['us_per_step'] / b, 3)
         out['netvlad'].append(ent)
         del x, g
+    # inference (evaluation/inference.py at large images_per_pass): nothing saved; from 144 images on
+    # one workgroup per image with the finish in its tail (one launch)
+    out['netvlad_inference'] = []
+    for b in (96, 256):
+        x = torch.randn(b, 1, 1200, D, device=dev, generator=gen).bfloat16()
+        nets.prepack([], force=True, vlad_w=wd)
+        pl = nets.fresh_vlad_planes(wd)
+        with torch.no_grad():
+            for _ in range(2):
+                nets.netvlad(x, wd, ct.detach(), True, pl)
+            torch.cuda.synchronize()
+            with _lib.KernelTimer(capacity=16 * iters) as kt:
+                for _ in range(iters):
+                    nets.netvlad(x, wd, ct.detach(), True, pl)
+                torch.cuda.synchronize()
+        steps = (1200 + 31) // 32
+        per = -(-steps * b // 256)
+        models = kernel_models(b, 1200, b, 2, slices=-(-steps // per))
+        rows = [price(k, cnt, ms, models[k]) for k, (cnt, ms) in sorted(kt.summary().items()) if k in models]
+        us = sum(r['us'] * r['launches'] for r in rows) / iters
+        bound = (b * 1200 * D * 2 + b * D * K * 4 + 2 * D * K * 4) / (PEAK_HBM_GBPS * 1e9) * 1e6
+        out['netvlad_inference'].append({'images': b, 'kernels': [r['kernel'] for r in rows],
+                                         'us': round(us, 2), 'bound': 'hbm', 'bound_us': round(bound, 2),
+                                         'frac': round(bound / us, 4) if us > 0 else None,
+                                         'us_per_image': round(us / b, 3)})
+        del x
     for bsz in (24, 48, 96, 192):
         emb = torch.tensor(U.embeddings(bsz, E), device=dev, requires_grad=True)
         dm = torch.tensor(U.positions_distances(bsz)[None], device=dev)

@@ -93,7 +93,9 @@ const char* scl_error_string(int code);
  *   out      [B, 32768]   index d*64 + k, unit L2 norm
  * For training the forward also leaves, in caller buffers, what the backward
  * re-uses (pass NULL for all four when only inferring):
- *   save_assign [B,N,64] soft-assignment a;  save_logit [B,N,64] logits;
+ *   save_assign [B,N,64] soft-assignment a;  save_logit [B,N,64] logits (float32 feature maps
+ *   only: the bf16 kernels neither write nor read it since round 6 — their backward pass takes
+ *   log a, which differs from the logit by a per-location constant that cancels — pass NULL);
  *   save_rnorm  [B,N] per-location 1/||x||;  save_vlad  [B,SCL_VLAD_SAVE_ROWS,64].
  * save_assign and save_rnorm double as forward scratch: when NULL they are carved
  * from the workspace.

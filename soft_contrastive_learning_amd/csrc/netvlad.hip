@@ -659,6 +659,10 @@ struct VladFwdArgs {
                                 // kernel counts its own vector-memory queue, so every step must
                                 // issue the same number of stores)
   unsigned long long* gran;     // [B][8] granules of vlad_finish_kernel's exchange: zeroed here
+  // Round 6, inference with ONE workgroup per image (S == 1, nothing saved): the finish runs in the
+  // tail of vlad_fwd8_kernel<false, false, true> — no slab, no second launch.  Else NULL.
+  const float* fin_centers;     // [512][64]
+  float* fin_out;               // [B][32768]
 };
 
 template <bool SAVE>
@@ -1256,8 +1260,9 @@ __device__ __forceinline__ void v8_wait_vm(int n) {
 // holds inside a workgroup too), and the extra live state (256 registers per wave) cost spills; the
 // kernel came out 0.9 us SLOWER than this one.  What pays on this chip is fewer vector instructions
 // and fewer barrier intervals, not overlap.
-template <bool SAVE, bool STAMPS = false>
+template <bool SAVE, bool STAMPS = false, bool FIN = false>
 __global__ __launch_bounds__(512) void vlad_fwd8_kernel(VladFwdArgs p) {
+  static_assert(!FIN || !SAVE, "the fused finish is the inference path");
   extern __shared__ __attribute__((aligned(1024))) unsigned char vf_lds[];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1318,7 +1323,6 @@ __global__ __launch_bounds__(512) void vlad_fwd8_kernel(VladFwdArgs p) {
   for (int ct = 0; ct < 16; ++ct) accv[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
   float cs[4] = {0.f, 0.f, 0.f, 0.f};
   // wave-uniform bases of the image's saved rows + 32-bit per-lane offsets
-  float* const lg_img = SAVE ? p.logit + (int64_t)b * p.N * K : nullptr;
   float* const as_img = SAVE ? p.assign + (int64_t)b * p.N * K : nullptr;
   float* const rn_img = SAVE ? p.rnorm + (int64_t)b * p.N : nullptr;
 
@@ -1344,8 +1348,9 @@ __global__ __launch_bounds__(512) void vlad_fwd8_kernel(VladFwdArgs p) {
   for (int st = 0; st < nst; ++st) {
     const int step = st_lo + st;
     // This stage's DMA must have landed; younger in the wave's queue, allowed to stay in flight:
-    // the next stage's DMA (4) and the previous step's three stores (when saving).
-    v8_wait_vm((st + 1 < nst ? 4 : 0) + (st >= 1 && SAVE ? 3 : 0));
+    // the next stage's DMA (4) and the previous step's two stores (when saving: assignments and
+    // row norms; round 6: the logits are no longer saved — the backward pass takes log a instead).
+    v8_wait_vm((st + 1 < nst ? 4 : 0) + (st >= 1 && SAVE ? 2 : 0));
     __builtin_amdgcn_s_barrier();         // landed for every wave; step - 1 is finished everywhere
     if (st < 4) VF_STAMP(4 + 6 * st);
     const unsigned sb = lds0 + (unsigned)(st % VF_NST) * VF_STAGE;
@@ -1421,7 +1426,6 @@ __global__ __launch_bounds__(512) void vlad_fwd8_kernel(VladFwdArgs p) {
       }
       m = vf_gmax(m);
       mloc = m;
-      if (SAVE) *reinterpret_cast<f32x4*>(lg_img + (n * K + 16 * w + 4 * g)) = f32x4{ev[0], ev[1], ev[2], ev[3]};
       float sum = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -1500,17 +1504,62 @@ __global__ __launch_bounds__(512) void vlad_fwd8_kernel(VladFwdArgs p) {
   }
   VF_STAMP(28);
 
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) cs[j] += __shfl_xor(cs[j], m, 64);
+  }
+  if constexpr (FIN) {
+    // ---- the finish of vlad_finish_kernel on the accumulators (this workgroup holds the whole
+    // image): lane (i, g) of wave (w, h) owns cluster k = 16 w + i, channels 16 (16 h + c) + 4 g + j.
+    //   U = V + C * asum;  col_k = sum_d U^2;  q_k = 1 / sqrt(col_k + 1e-12);
+    //   tot = sum_k q_k^2 col_k;  out = U q_k / sqrt(tot + 1e-12)
+    // (the sums run in another order than the finish kernel's: same values to rounding).
+    float* fl = reinterpret_cast<float*>(vf_lds);              // the x stages are dead
+    float* f_as = fl;                                          // [2][64] column sums of a by h
+    float* f_sq = fl + 128;                                    // [2][64] sum U^2 by channel half
+    float* f_tq = fl + 256;                                    // [4]     q^2 col by cluster group
+    __builtin_amdgcn_s_barrier();                              // every wave is done with the stages
+    if (i == 0) *reinterpret_cast<f32x4*>(f_as + h * 64 + 16 * w + 4 * g) = f32x4{cs[0], cs[1], cs[2], cs[3]};
+    __builtin_amdgcn_s_barrier();
+    const int k = 16 * w + i;
+    const float asum = f_as[k] + f_as[64 + k];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float u = accv[c][j] + p.fin_centers[(16 * (16 * h + c) + 4 * g + j) * K + k] * asum;
+        accv[c][j] = u;
+        ss = fmaf(u, u, ss);
+      }
+    }
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    if (g == 0) f_sq[h * 64 + k] = ss;
+    __builtin_amdgcn_s_barrier();
+    const float col = f_sq[k] + f_sq[64 + k];
+    const float q = 1.0f / sqrtf(col + 1e-12f);
+    float tq = q * q * col;
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) tq += __shfl_xor(tq, m, 64);
+    if (h == 0 && lane == 0) f_tq[w] = tq;
+    __builtin_amdgcn_s_barrier();
+    const float tot = (f_tq[0] + f_tq[1]) + (f_tq[2] + f_tq[3]);
+    const float sc = q * (1.0f / sqrtf(tot + 1e-12f));
+    float* orow = p.fin_out + (int64_t)b * D * K + k;
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) orow[(16 * (16 * h + c) + 4 * g + j) * K] = accv[c][j] * sc;
+    return;
+  }
   // ---- the slice's slab, in accumulator order (unit ((w * 32 + ct) * 64 + lane), ct = 16 h + c),
   // and the column sums of a (the two tile halves of a cluster group combined through LDS)
   f32x4* slab =
       reinterpret_cast<f32x4*>(p.slab) + ((((int64_t)sl * B + b) * 4 + w) * 32 + 16 * h) * 64 + lane;
 #pragma unroll
   for (int c = 0; c < 16; ++c) slab[c * 64] = accv[c];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-#pragma unroll
-    for (int m = 1; m < 16; m <<= 1) cs[j] += __shfl_xor(cs[j], m, 64);
-  }
   if (h == 1 && i == 0) *reinterpret_cast<f32x4*>(csx + (w * 4 + g) * 4) = f32x4{cs[0], cs[1], cs[2], cs[3]};
   __builtin_amdgcn_s_barrier();
   if (h == 0 && i == 0) {
@@ -1601,7 +1650,6 @@ __global__ __launch_bounds__(512) void vlad_bwd8_kernel(VladBwdArgs p) {
     const bool ok = n < p.N;
     const int64_t row = (int64_t)b * p.N + (ok ? n : p.N - 1);
     const f32x4 a4 = *reinterpret_cast<const f32x4*>(p.a + row * K + 16 * w + 4 * g);
-    const f32x4 l4 = *reinterpret_cast<const f32x4*>(p.lg + row * K + 16 * w + 4 * g);
     const float rn2 = p.rn[row];
 
     f32x4 accl[2];
@@ -1629,6 +1677,15 @@ __global__ __launch_bounds__(512) void vlad_bwd8_kernel(VladBwdArgs p) {
     }
     *reinterpret_cast<f32x4*>(xl + (wid * 64 + lane) * 16) = h ? accl[0] : accl[1];
     __builtin_amdgcn_s_barrier();
+
+    // Round 6: the logits are not saved.  They enter the backward pass only through the row-norm
+    // term sum_k ds_k l_k with sum_k ds_k = 0, so any l_k + const serves: l_k = log a_k (the logit
+    // minus the location's log-sum-exp).  What the constant would have contributed is
+    // lse * dot * (1 - sum_k a_k), i.e. rounding-level.  a_k == 0 (underflow) carries ds_k == 0:
+    // its term is dropped instead of becoming 0 * -inf.
+    f32x4 l4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) l4[j] = a4[j] > 1.0e-37f ? __logf(a4[j]) : 0.f;
 
     float tv[4], dav[4];
     {
@@ -3021,6 +3078,16 @@ inline int vlad_cus() {
   const int n = scl_device_cus();      // per device (scl_common.h)
   return n;
 }
+// images from which inference takes one workgroup per image with the fused finish (SCL_VLAD_FIN_IMAGES;
+// measured, profiles/r06/netvlad_inference_sweep.txt)
+inline int vlad_fin_images() {
+  static const int n = [] {
+    const char* e = getenv("SCL_VLAD_FIN_IMAGES");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 144;
+  }();
+  return n;
+}
 inline VladPlan vlad_plan(int B, int N) {
   const int nsteps = (N + VF_STEP - 1) / VF_STEP;
   VladPlan p;
@@ -3150,8 +3217,20 @@ extern "C" int scl_netvlad_fwd_p(const void* x, int x_dtype, const float* assign
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVlad8Lds);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vlad_fwd8_kernel<true, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVlad8Lds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vlad_fwd8_kernel<false, false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVlad8Lds);
     });
-    const VladPlan pl = vlad_plan(B, N);
+    VladPlan pl = vlad_plan(B, N);
+    // Inference (nothing saved) at many images: ONE workgroup per image with the finish in its tail —
+    // no partial VLADs written and re-read, one launch (evaluation/inference.py at large
+    // images_per_pass).  From kVladFinImages images on; below that the slices keep the chip full.
+    const bool fin = !save_assign && !save_rnorm && !save_vlad && !four_waves() && !old_launches() &&
+                     (B >= vlad_fin_images() || scl_variant() == 924) &&    // 924: at any batch size (tests)
+                     scl_variant() != 923;                                   // 923: the two launches, for A/B
+    if (fin) {
+      pl.steps_per_slice = (N + VF_STEP - 1) / VF_STEP;
+      pl.S = 1;
+    }
     const unsigned short* planes = (const unsigned short*)w_planes;
     if (!planes || old_launches()) {
       if (old_launches())
@@ -3174,11 +3253,20 @@ extern "C" int scl_netvlad_fwd_p(const void* x, int x_dtype, const float* assign
     fa.gran = w.gran;
     fa.dbg = (scl_variant() == 916 || scl_variant() == 918) ? 16 : 0;   // scripts/vlad_stamps.py
     fa.stamps = w.stamps;
-    const bool save = save_assign && save_logit && save_rnorm;
+    // (round 6: the eight-wave kernels neither write nor read logits — save_logit may be NULL; the
+    // four-wave kernels of the diagnostic build still do)
+    const bool save = save_assign && save_rnorm && (save_logit || !four_waves());
     if (save) {
       fa.assign = save_assign;
       fa.logit = save_logit;
       fa.rnorm = save_rnorm;
+    }
+    if (fin) {
+      fa.fin_centers = centers;
+      fa.fin_out = out;
+      SCL_LAUNCH("vlad_fwd8_kernel<finish>", (vlad_fwd8_kernel<false, false, true>), dim3(B, 1), dim3(512),
+                 kVlad8Lds, st, fa);
+      return scl_launch_status();
     }
     if (four_waves()) {
       if (save)
@@ -3269,11 +3357,13 @@ extern "C" int scl_netvlad_bwd_p(const void* x, int x_dtype, const float* assign
                                  const float* save_rnorm, float* save_vlad, int B, int N,
                                  int pre_l2, void* grad_x, float* grad_w, float* grad_c,
                                  void* workspace, size_t workspace_bytes, void* stream) {
-  if (!x || !assign_w || !centers || !grad_out || !save_assign || !save_logit || !save_rnorm ||
+  if (!x || !assign_w || !centers || !grad_out || !save_assign || !save_rnorm ||
       !save_vlad || !grad_x || !grad_w || !grad_c || !workspace)
     return SCL_E_NULL;
   if (!shape_ok(B, N)) return SCL_E_SHAPE;
   if (x_dtype != SCL_DT_F32 && x_dtype != SCL_DT_BF16) return SCL_E_KIND;
+  // the saved logits: float32 feature maps and the four-wave kernels of the diagnostic build only
+  if (!save_logit && !(x_dtype == SCL_DT_BF16 && use_fused() && !four_waves())) return SCL_E_NULL;
   if (((uintptr_t)x % 16) != 0 || ((uintptr_t)save_vlad % 8) != 0) return SCL_E_SHAPE;
   if (w_planes && !scl_aligned256(w_planes)) return SCL_E_SHAPE;
   if (!scl_aligned256(workspace)) return SCL_E_WORKSPACE;

@@ -239,6 +239,46 @@ def test_new_launch_structure_agrees_with_round_3s(dev, dtype):
     assert _nrel(new[3], old[3]) < 5e-6
 
 
+@pytest.mark.parametrize("b,n", [(1, 1), (3, 33), (7, 165), (5, 1200), (200, 165), (192, 1200)])
+def test_inference_with_the_finish_in_the_forward_kernel(dev, b, n):
+    """Round 6: inference (nothing saved) at >= 144 images runs ONE workgroup per image with the
+    finish in the tail of vlad_fwd8_kernel — no partial VLADs, one launch.  Against the two launches
+    (diagnostic variant 923; 924 forces the one-launch form at any batch size): the same descriptors
+    to float32 rounding (the column and global norms are summed in another order), unit norm, and
+    against the oracle where it is small enough to run."""
+    from soft_contrastive_learning_amd import _lib as L
+    from soft_contrastive_learning_amd.model import nets
+    from oracle import netvlad_np
+    x = U.feature_map(b, n, seed=7 * b + n)
+    w, c = U.vlad_params(seed=8, logit_scale=3.0)
+    xt = torch.tensor(x, device=dev).bfloat16().reshape(b, 1, n, 512)
+    wt, ct = torch.tensor(w, device=dev), torch.tensor(c, device=dev)
+
+    def run(variant):
+        with L.variant(variant):
+            with L.KernelTimer(capacity=16) as kt:
+                with torch.no_grad():
+                    out = nets.netvlad(xt, wt, ct, True)
+                torch.cuda.synchronize()
+        return out.cpu().numpy(), set(kt.summary())
+    two, n2 = run(923)
+    one, n1 = run(924)
+    assert 'vlad_finish_kernel' in n2 and 'vlad_fwd8_kernel<finish>' not in n2, n2
+    assert n1 == {'vlad_fwd8_kernel<finish>'} or n1 == {'vlad_fwd8_kernel<finish>', 'vlad_planes_kernel'}, n1
+    assert np.abs(one - two).max() <= 2e-6 * np.abs(two).max()
+    np.testing.assert_allclose(np.linalg.norm(one.astype(np.float64), axis=1), 1.0, atol=1e-5)
+    if b >= 144:                                              # the product picks it by itself there
+        with L.KernelTimer(capacity=16) as kt:
+            with torch.no_grad():
+                auto = nets.netvlad(xt, wt, ct, True)
+            torch.cuda.synchronize()
+        assert 'vlad_fwd8_kernel<finish>' in set(kt.summary())
+        assert np.array_equal(auto.cpu().numpy(), one)
+    if b * n <= 6000:
+        want = netvlad_np.netvlad_fused(xt.float().cpu().numpy().reshape(b, n, 512), w, c)
+        assert np.abs(one - want).max() <= 1e-4 * np.abs(want).max()
+
+
 def test_plane_images_from_the_packing_launch(dev):
     """The assignment weights' plane images written by scl_conv_pack_batch (SCL_PACK_VLAD_W, the
     launch that packs the convolution weights) are the ones the call would build for itself."""
