@@ -642,13 +642,22 @@ def retrieval_line(dev, r=100000, q=10000, d=256, n=25, iters=3):
             torch.cuda.synchronize()
             wall = (time.perf_counter() - t0) / iters
         summ = kt.summary()
-        scan_name = 'topn_scan_kernel<BF=%d>' % (1 if score == 'bf16x3' else 0)
+        # round 6: the threshold scan (its 1/16 pre-pass is priced with it: 17/16 of the products)
+        bfn = 1 if score == 'bf16x3' else 0
+        scan_name = 'topn_scan_kernel<BF=%d,tau>' % bfn
+        pre_name = 'topn_scan_kernel<BF=%d,pre>' % bfn
+        if scan_name not in summ:
+            scan_name, pre_name = 'topn_scan_kernel<BF=%d>' % bfn, None
         row = {'queries_per_sec': round(q / wall, 1), 'ms_per_call': round(wall * 1e3, 3),
                'uncertified_queries': st.get('uncertified'), 'calls': iters,
                'kernels_us': {k: round(ms * 1e3, 1) for k, (c, ms) in sorted(summ.items())}}
         if scan_name in summ:
             row['scan_kernel'] = dict(kernel=scan_name, us=round(summ[scan_name][1] * 1e3, 1),
                                       **price_topn_scan(summ[scan_name][1], q, r, d, score))
+            if pre_name in summ:
+                both = summ[scan_name][1] + summ[pre_name][1]
+                row['scan_with_prepass'] = dict(us=round(both * 1e3, 1),
+                                                **price_topn_scan(both, q, r * 17.0 / 16.0, d, score))
         out[score] = row
     # the in-training localisation check (train/train.py:1181-1182): the raw 32768-wide descriptors,
     # 5 nearest of a few thousand references for a few dozen queries — nomination from the inner

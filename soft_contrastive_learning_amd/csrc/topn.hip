@@ -139,14 +139,36 @@ __device__ __forceinline__ void sort_list(float* sc, int* ix, int lane) {
 // 2^-17 split residue, |error| <= 1.2e-5 |q||r|).  `ref` then points at the high plane and
 // `ref_lo` at the low plane written by ref_split_kernel; the LDS tile holds both planes with
 // rows of d/2 + 4 dwords.  The float64 re-rank still reads the float32 rows.
-template <int D8, int BF>
+//
+// Round 6 — SEL = 1, the THRESHOLD scan: every query comes with a score threshold tau_q that at
+// least KEEP references are known to meet (the KEEP-th best score of a pre-pass over every 16th
+// reference tile, topn_tau_kernel).  The scan then keeps no lists at all: a score <= tau_q is
+// APPENDED to the query's candidate buffer [Q][cap] (one atomic add per (query, tile) that has any;
+// ~16 KEEP = 512 of R references qualify per query whatever R is) and the re-rank selects the best
+// KEEP of them.  The nominated set is the same as with the lists — the KEEP best scores of the whole
+// reference set all lie at or below tau_q — so the certificate and the emitted lists do not change;
+// what goes is the sorted insertion (~32 ln(tiles) per query and split at ~240 cycles each: as long
+// as the products in the bf16x3 mode) and 64 KB of list LDS per workgroup.  A query whose buffer
+// overflows is handed to the exact fallback like an uncertified one.
+// SEL = 2, the PRE-PASS that produces tau_q: over a 1 / kTauStride sample of the tiles every lane
+// keeps, per query row, the TWO smallest scores of its own reference column (3 vector ops per
+// score, no cross-lane work, no lists): 64 scores of 64 DIFFERENT references per (query, split);
+// topn_tau_kernel takes the KEEP-th smallest of the splits' union.
+// Interleaved splits (refs_per_split == 0; SEL 1 and 2): split s takes the tiles s, s + S, s + 2 S,
+// .. (x tile_stride), so that every split sees the whole reference set thinly — references in
+// driving order put a query's neighbours in consecutive tiles, which contiguous splits would all
+// hand to one workgroup's buffers.
+template <int D8, int BF, int SEL = 0>
 __global__ __launch_bounds__(256, 2) void topn_scan_kernel(const void* __restrict__ refv,
                                                            const void* __restrict__ ref_lov,
                                                            const float* __restrict__ refnorm,
                                                            int R, const float* __restrict__ query,
                                                            int Q, int refs_per_split, int dbg_arg,
                                                            float* __restrict__ cand_sc,
-                                                           int* __restrict__ cand_ix) {
+                                                           int* __restrict__ cand_ix, int tile_stride,
+                                                           const float* __restrict__ tau_q,
+                                                           int* __restrict__ cand_cnt, int cap,
+                                                           int tile_first) {
   const int dbg = SCL_DIAG_ONLY(dbg_arg);      // timing ablations: diagnostic build only
   constexpr int d = D8 * 8;
   constexpr int LD = d + 4;          // f32 tile: floats per row
@@ -157,18 +179,20 @@ __global__ __launch_bounds__(256, 2) void topn_scan_kernel(const void* __restric
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* tile = lds;                                   // TILE_DW
   float* refn = tile + TILE_DW;                        // 32
-  float* lsc = refn + 32;                              // QW * 32 * KEEP
+  float* lsc = refn + 32;                              // QW * 32 * KEEP      (SEL 0 only)
   int* lix = reinterpret_cast<int*>(lsc + QW * 32 * KEEP);
-  float* tau = reinterpret_cast<float*>(lix + QW * 32 * KEEP);   // QW * 32
+  float* tau = SEL == 0 ? reinterpret_cast<float*>(lix + QW * 32 * KEEP) : refn + 32;   // QW * 32
 
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int q0 = (blockIdx.x * QW + wid) * 32;
   const int split = blockIdx.y;
-  const int r_begin = split * refs_per_split;
-  int r_end = r_begin + refs_per_split;
+  // contiguous splits (refs_per_split > 0) or interleaved ones: first tile split * tile_first,
+  // then every tile_stride-th
+  const int r_begin = refs_per_split > 0 ? split * refs_per_split : split * tile_first * 32;
+  int r_end = refs_per_split > 0 ? r_begin + refs_per_split : R;
   if (r_end > R) r_end = R;
-  const int ntiles = (r_end - r_begin + 31) / 32;
+  const int ntiles = r_begin < r_end ? ((r_end - r_begin + 31) / 32 + tile_stride - 1) / tile_stride : 0;
 
   // query fragments.  f32: lane (r, h) keeps q[q0 + r][8t + 4h .. +3] for every t.
   // bf16x3: q[q0 + r][16u + 8h .. +7] split into packed high / low parts for every k-step u.
@@ -204,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void topn_scan_kernel(const void* __restric
   f32x4 stage[V4];
   float stage_n = 0.f;
   auto stage_load = [&](int t) {
-    const int rb = r_begin + t * 32;
+    const int rb = r_begin + t * 32 * tile_stride;
 #pragma unroll
     for (int v = 0; v < V4; ++v) {
       const int idx = v * 256 + threadIdx.x;
@@ -241,9 +265,23 @@ __global__ __launch_bounds__(256, 2) void topn_scan_kernel(const void* __restric
     stage_store();
   }
   __syncthreads();
-  float tq[16];
+  float tq[SEL == 0 ? 16 : 1];
 #pragma unroll
-  for (int q = 0; q < 16; ++q) tq[q] = INFINITY;
+  for (int q = 0; q < (SEL == 0 ? 16 : 1); ++q) tq[q] = INFINITY;
+  // SEL 1: the rows' thresholds live in LDS (16 more registers would spill), their candidate
+  // counters in registers: row acc_row(q, h) belongs to this half-wave alone — no atomics
+  int cntv[SEL == 1 ? 16 : 1];
+  float m1[SEL == 2 ? 16 : 1], m2[SEL == 2 ? 16 : 1];
+  if constexpr (SEL == 1) {
+    if (lane < 32) my_tau[lane] = q0 + lane < Q ? tau_q[q0 + lane] : -INFINITY;   // (rows past the end: nothing)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) cntv[q] = 0;
+    __builtin_amdgcn_wave_barrier();
+  }
+  if constexpr (SEL == 2) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) m1[q] = m2[q] = INFINITY;
+  }
 
   for (int t = 0; t < ntiles; ++t) {
     if (t + 1 < ntiles && !(dbg & 2)) stage_load(t + 1);
@@ -286,11 +324,42 @@ __global__ __launch_bounds__(256, 2) void topn_scan_kernel(const void* __restric
       }
     }
     const float rnj = refn[r];
-    const int ridx = r_begin + t * 32 + r;
+    const int ridx = r_begin + t * 32 * tile_stride + r;
     __syncthreads();                       // every wave is done reading the tile
     if (t + 1 < ntiles && !(dbg & 2)) stage_store();   // refill it under the selection below
 
-    if (t == 0) {
+    if constexpr (SEL == 1) {
+      // threshold scan: half-wave h holds row acc_row(q, h) of register q against the tile's 32
+      // references; the qualifying ones take consecutive slots of the row's region [split][cap]
+      if (!(dbg & 1)) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const float sc = rnj - 2.0f * acc[q];
+          const bool hit = sc <= my_tau[acc_row(q, h)];
+          const unsigned long long m = __ballot(hit);
+          if (m) {                                             // (wave-uniform, rare)
+            const unsigned mh = h ? (unsigned)(m >> 32) : (unsigned)m;
+            const int slot = cntv[q] + __popc(mh & ((1u << r) - 1u));
+            cntv[q] += __popc(mh);
+            if (hit && slot < cap) {
+              const int qrow = q0 + acc_row(q, h);
+              const int64_t o = ((int64_t)qrow * gridDim.y + split) * cap + slot;
+              cand_sc[o] = sc;
+              cand_ix[o] = ridx;
+            }
+          }
+        }
+      }
+    } else if constexpr (SEL == 2) {
+      // pre-pass: the two smallest scores of this lane's reference column, per row
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float sc = rnj - 2.0f * acc[q];
+        const float t2 = fmaxf(m1[q], sc);
+        m1[q] = fminf(m1[q], sc);
+        m2[q] = fminf(m2[q], t2);
+      }
+    } else if (t == 0) {
       // first tile of the split: every list takes the 32 scores as they are, then sorts
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
@@ -326,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void topn_scan_kernel(const void* __restric
           const int L = act ? __ffs((int)mh) - 1 : 0;
           mh &= mh - 1;
           const float s = __shfl(sc, 32 * h + L, 64);
-          const int id = r_begin + t * 32 + L;
+          const int id = r_begin + t * 32 * tile_stride + L;
           // sorted insertion by the half-wave: its 32 lanes mirror the list entries
           const float cs = ls[e];
           const int ci = li[e];
@@ -354,6 +423,30 @@ __global__ __launch_bounds__(256, 2) void topn_scan_kernel(const void* __restric
     __syncthreads();                       // refilled tile visible to everyone
   }
 
+  if constexpr (SEL == 1) {
+    // the rows' candidate counts: lane r == 0 of each half holds them
+    if (r == 0) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int qrow = q0 + acc_row(q, h);
+        if (qrow < Q) cand_cnt[(int64_t)qrow * gridDim.y + split] = cntv[q];
+      }
+    }
+    return;
+  }
+  if constexpr (SEL == 2) {
+    // [Q][splits][64]: the row's two smallest per reference column (+inf where the split had no tile)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int qrow = q0 + acc_row(q, h);
+      if (qrow < Q) {
+        float* o = cand_sc + ((int64_t)qrow * gridDim.y + split) * 64;
+        o[r] = m1[q];
+        o[32 + r] = m2[q];
+      }
+    }
+    return;
+  }
   // hand-off: [Q][splits][KEEP], already sorted; +inf scores mark empty slots
   for (int row = 0; row < 32; ++row) {
     const int qrow = q0 + row;
@@ -366,6 +459,43 @@ __global__ __launch_bounds__(256, 2) void topn_scan_kernel(const void* __restric
   }
 }
 
+// tau_q = the KEEP-th smallest of the pre-pass values [Q][S][64] (S <= 8: 8 per lane), one wave per
+// query, radix select on the order-preserving integer image of the scores.  Every value is the
+// score of a different reference, so at least KEEP references score <= tau_q; +inf entries (no
+// tile) lose, and tau_q = +inf when fewer than KEEP values exist (everything is appended then: the
+// buffers overflow and the exact pass takes the query).
+__global__ __launch_bounds__(256) void topn_tau_kernel(const float* __restrict__ pre, int Q, int S,
+                                                       float* __restrict__ tau_out) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int qi = blockIdx.x * 4 + wid;
+  if (qi >= Q) return;                                     // wave-uniform
+  const int M = S * 64;
+  unsigned key[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int e = k * 64 + lane;
+    const float v = e < M ? pre[(int64_t)qi * M + e] : INFINITY;
+    const unsigned bits = __float_as_uint(v);
+    key[k] = bits ^ ((bits >> 31) ? 0xffffffffu : 0x80000000u);
+  }
+  unsigned prefix = 0;
+  int need = KEEP;
+  for (int bit = 31; bit >= 0; --bit) {
+    const unsigned hi_mask = bit == 31 ? 0u : (0xffffffffu << (bit + 1));
+    int c0 = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) c0 += ((key[k] & hi_mask) == (prefix & hi_mask)) && !((key[k] >> bit) & 1u);
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) c0 += __shfl_xor(c0, m, 64);
+    if (need > c0) {
+      need -= c0;
+      prefix |= 1u << bit;
+    }
+  }
+  const unsigned bits = (prefix & 0x80000000u) ? (prefix ^ 0x80000000u) : ~prefix;
+  if (lane == 0) tau_out[qi] = __uint_as_float(bits);
+}
+
 // One WAVE per query (4 queries per workgroup).  Per-wave LDS: sc[M] | ix[M] | best_ix[KEEP]
 // | best_d[KEEP] with M = splits * KEEP.  NE = entries per lane (M <= 64 * NE).
 //   stage 1  best KEEP of the M per-split candidates by f32 score (rank counting)
@@ -373,7 +503,10 @@ __global__ __launch_bounds__(256, 2) void topn_scan_kernel(const void* __restric
 //            candidates at a time and all loads of a round are issued before any reduction,
 //            so the 32 scattered reference rows are fetched with 4-8 rows in flight
 //   stage 3  order by (distance, index), emit the first n
-template <int NE>
+// APPEND (round 6): the candidates are the threshold scan's regions [Q][splits][cap] with
+// cnt[q][split] entries each, in no particular order; what lies outside the nominated KEEP is
+// either a dropped candidate (>= the KEEP-th best score) or was never appended (> tau_q).
+template <int NE, bool APPEND = false>
 __global__ __launch_bounds__(256) void topn_rerank_kernel(const float* __restrict__ ref,
                                                           const float* __restrict__ query, int Q,
                                                           int d, int splits, int n,
@@ -385,25 +518,63 @@ __global__ __launch_bounds__(256) void topn_rerank_kernel(const float* __restric
                                                           const unsigned* __restrict__ rmax_bits,
                                                           float eps_q, float eps_r,
                                                           unsigned char* __restrict__ uncertified,
-                                                          double* __restrict__ bound_sq) {
+                                                          double* __restrict__ bound_sq,
+                                                          const int* __restrict__ cand_cnt = nullptr,
+                                                          const float* __restrict__ tau_q = nullptr,
+                                                          int cap = 0) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int M = splits * KEEP;
+  // APPEND: the regions are mostly empty (16 KEEP candidates expected in splits x cap slots): the
+  // wave works on the COMPACTED list of at most M = 64 NE entries — position p belongs to the split
+  // whose running count covers it (binary search over the splits' prefix sums in LDS), so every
+  // lane's NE loads are independent and only occupied slots are read
+  const int M = APPEND ? 64 * NE : splits * KEEP;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int per_wave = 2 * M + KEEP + 2 * (KEEP + 1) + 2;  // floats (best_d: KEEP + 1 doubles, 8-byte aligned)
+  const int per_wave = 2 * M + KEEP + 2 * (KEEP + 1) + 2 + 66;  // floats (best_d: KEEP + 1 doubles, 8-byte aligned)
   float* sc = lds + wid * per_wave;
   int* ix = reinterpret_cast<int*>(sc + M);
   int* best_ix = ix + M;
   double* best_d = reinterpret_cast<double*>(best_ix + KEEP);
+  int* pre_off = reinterpret_cast<int*>(best_d + KEEP + 1);     // [65] exclusive prefix sums (APPEND)
   const int qi = blockIdx.x * 4 + wid;
   if (qi >= Q) return;                                   // wave-uniform; no block barriers below
 
   float es[NE];
   int ei[NE];
+  bool overflow = false;
+  int total = M;
+  if constexpr (APPEND) {                                  // (splits <= 64)
+    const int craw = lane < splits ? cand_cnt[(int64_t)qi * splits + lane] : 0;
+    overflow = craw > cap;
+    const int c = craw < cap ? craw : cap;
+    int incl = c;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+      const int o = __shfl_up(incl, m, 64);
+      if (lane >= m) incl += o;
+    }
+    pre_off[lane + 1] = incl;
+    if (lane == 0) pre_off[0] = 0;
+    total = __shfl(incl, 63, 64);
+    overflow = __any(overflow) || total > M;               // (more candidates than the compact list holds)
+    __builtin_amdgcn_wave_barrier();
+  }
 #pragma unroll
   for (int k = 0; k < NE; ++k) {
     const int e = k * 64 + lane;
-    es[k] = e < M ? cand_sc[(int64_t)qi * M + e] : INFINITY;
-    ei[k] = e < M ? cand_ix[(int64_t)qi * M + e] : -1;
+    bool valid = e < M;
+    int64_t src = (int64_t)qi * M + e;
+    if constexpr (APPEND) {
+      valid = e < total && e < M;
+      int lo = 0, hi = splits;                             // largest s with pre_off[s] <= e
+#pragma unroll
+      for (int it = 0; it < 7; ++it) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (mid <= splits && pre_off[mid < 64 ? mid : 64] <= e) lo = mid; else hi = mid - 1;
+      }
+      src = ((int64_t)qi * splits + lo) * cap + (e - pre_off[lo]);
+    }
+    es[k] = valid ? cand_sc[src] : INFINITY;
+    ei[k] = valid ? cand_ix[src] : -1;
     if (e < M) {
       sc[e] = es[k];
       ix[e] = ei[k];
@@ -452,9 +623,13 @@ __global__ __launch_bounds__(256) void topn_rerank_kernel(const float* __restric
       const unsigned bits = (tau_key & 0x80000000u) ? (tau_key ^ 0x80000000u) : ~tau_key;
       tau_excl = __uint_as_float(bits);
     }
+    if constexpr (APPEND) {
+      tau_excl = fminf(tau_excl, tau_q[qi]);                // never appended: score > tau_q
+    } else {
 #pragma unroll
-    for (int k = 0; k < NE; ++k)
-      if ((lane & (KEEP - 1)) == KEEP - 1 && ei[k] >= 0) tau_excl = fminf(tau_excl, es[k]);
+      for (int k = 0; k < NE; ++k)
+        if ((lane & (KEEP - 1)) == KEEP - 1 && ei[k] >= 0) tau_excl = fminf(tau_excl, es[k]);
+    }
     tau_excl = wave_min(tau_excl);
   }
   {
@@ -537,7 +712,8 @@ __global__ __launch_bounds__(256) void topn_rerank_kernel(const float* __restric
     const double dn = best_d[KEEP];
     const double rmax = sqrt((double)__uint_as_float(*rmax_bits));
     const double eps = (double)eps_q * sqrt(qq) * rmax + (double)eps_r * rmax * rmax;
-    const bool ok = !(tau_excl < INFINITY) || dn < (double)tau_excl + qq - eps;
+    bool ok = !(tau_excl < INFINITY) || dn < (double)tau_excl + qq - eps;
+    if (APPEND && overflow) ok = false;                     // a region overflowed: candidates lost
     uncertified[qi] = ok ? 0 : 1;
     bound_sq[qi] = dn;
   }
@@ -634,24 +810,89 @@ inline TopnPlan topn_plan(int R, int Q, int bf) {
   return p;
 }
 
-inline size_t scan_lds_bytes(int d, int bf) {
+inline size_t scan_lds_bytes(int d, int bf, int sel = 0) {
   const size_t tile = bf ? (size_t)2 * 32 * (d / 2 + 4) : (size_t)32 * (d + 4);
-  return (tile + 32 + (size_t)QW * 32 * KEEP * 2 + QW * 32) * sizeof(float);
+  return (tile + 32 + (sel ? 0 : (size_t)QW * 32 * KEEP * 2) + QW * 32) * sizeof(float);
 }
 
-template <int D8, int BF>
+// The threshold scheme (SEL = 1 scan behind the SEL = 2 pre-pass over every kTauStride-th tile).
+constexpr int kTauStride = 16;        // the pre-pass scores 1 / 16 of the references
+constexpr int kTauCapSplit = 128;     // candidate slots per (query, split): ~16 KEEP = 512 candidates per query
+constexpr int kTauSplits = 32;        // are expected over the 32 interleaved splits (16 each, sd 4) when the
+                                      // references come in random order; in DRIVING order a query's
+                                      // neighbours are one run of consecutive tiles, of which the strided
+                                      // pre-pass sees one in sixteen — counts then vary by a factor of 2-3
+constexpr int kTauCompact = 1024;     // candidates the re-rank takes per query (more: the exact pass)
+constexpr int kTauMinRefs = 32768;    // below: the sorted-list scan
+struct TauPlan {
+  int qtiles, pre_splits, main_splits;
+};
+inline TauPlan tau_plan(int R, int Q) {
+  TauPlan t;
+  t.qtiles = (Q + 32 * QW - 1) / (32 * QW);
+  const int tiles = (R + 31) / 32;
+  const int sampled = (tiles + kTauStride - 1) / kTauStride;
+  // pre-pass: interleaved splits (<= 8: topn_tau_kernel keeps 8 values per lane) that fill the chip
+  // once, each with >= 8 sampled tiles
+  int sp = (512 + t.qtiles - 1) / t.qtiles;
+  if (sp > 8) sp = 8;
+  if (sp > sampled / 8) sp = sampled / 8;
+  t.pre_splits = sp < 1 ? 1 : sp;
+  t.main_splits = kTauSplits < tiles ? kTauSplits : tiles;
+  return t;
+}
+inline bool use_tau(int R, bool certified, int bf) {
+  // Both score modes (configs[4], 100k x 10k x 256, same box: bf16x3 2.78 -> 2.00 ms, float32 5.75 ->
+  // 5.00 ms per call; profiles/r06/topn_threshold_scan.txt).
+  // 8100: the sorted-list scan, for A/B; 9000 + bits: the same with the timing ablations `bits`
+  (void)bf;
+  if (scl_variant() == 8100 || scl_variant() / 1000 == 9) return false;
+  return certified && R >= kTauMinRefs;
+}
+
+template <int D8, int BF, int SEL = 0>
 void launch_scan(const TopnPlan& p, const void* ref, const void* ref_lo, const float* refnorm,
-                 int R, const float* query, int Q, float* cs, int* ci, hipStream_t st) {
+                 int R, const float* query, int Q, float* cs, int* ci, hipStream_t st,
+                 int tile_stride = 1, const float* tau = nullptr, int* cnt = nullptr, int cap = 0,
+                 int tile_first = 0) {
   static SclDeviceOnce once;
   scl_call_once(once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&topn_scan_kernel<D8, BF>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&topn_scan_kernel<D8, BF, SEL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)scan_lds_bytes(D8 * 8, BF));
+                              (int)scan_lds_bytes(D8 * 8, BF, SEL));
   });
-  SCL_LAUNCH(BF ? "topn_scan_kernel<BF=1>" : "topn_scan_kernel<BF=0>", (topn_scan_kernel<D8, BF>),
-             dim3(p.qtiles, p.splits), dim3(256), scan_lds_bytes(D8 * 8, BF), st, ref, ref_lo,
-             refnorm, R, query, Q, p.refs_per_split,
-             scl_variant() < 8000 ? scl_variant() / 1000 : 0, cs, ci);
+  const char* name = SEL == 1   ? (BF ? "topn_scan_kernel<BF=1,tau>" : "topn_scan_kernel<BF=0,tau>")
+                     : SEL == 2 ? (BF ? "topn_scan_kernel<BF=1,pre>" : "topn_scan_kernel<BF=0,pre>")
+                                : (BF ? "topn_scan_kernel<BF=1>" : "topn_scan_kernel<BF=0>");
+  SCL_LAUNCH(name, (topn_scan_kernel<D8, BF, SEL>), dim3(p.qtiles, p.splits), dim3(256),
+             scan_lds_bytes(D8 * 8, BF, SEL), st, ref, ref_lo, refnorm, R, query, Q, p.refs_per_split,
+             scl_variant() < 8000 ? scl_variant() / 1000 : (scl_variant() / 1000 == 9 ? scl_variant() % 1000 : 0),
+             cs, ci, tile_stride, tau, cnt, cap, tile_first);
+}
+template <int SEL>
+void launch_scan_d(int d, int bf, const TopnPlan& p, const void* ref, const void* ref_lo,
+                   const float* refnorm, int R, const float* query, int Q, float* cs, int* ci,
+                   hipStream_t st, int tile_stride = 1, const float* tau = nullptr, int* cnt = nullptr,
+                   int cap = 0, int tile_first = 0) {
+#define SCL_SCAN(D8, BF)                                                                                  \
+  launch_scan<D8, BF, SEL>(p, ref, ref_lo, refnorm, R, query, Q, cs, ci, st, tile_stride, tau, cnt, cap, \
+                           tile_first)
+  if (bf) {
+    switch (d) {
+      case 32: SCL_SCAN(4, 1); break;
+      case 64: SCL_SCAN(8, 1); break;
+      case 128: SCL_SCAN(16, 1); break;
+      default: SCL_SCAN(32, 1); break;
+    }
+  } else {
+    switch (d) {
+      case 32: SCL_SCAN(4, 0); break;
+      case 64: SCL_SCAN(8, 0); break;
+      case 128: SCL_SCAN(16, 0); break;
+      default: SCL_SCAN(32, 0); break;
+    }
+  }
+#undef SCL_SCAN
 }
 
 inline bool topn_shape_ok(int R, int Q, int d, int n) {
@@ -665,8 +906,16 @@ extern "C" size_t scl_topn_l2_ex_workspace_bytes(int R, int Q, int d, int n, int
   if (!topn_shape_ok(R, Q, d, n) || (flags & ~SCL_TOPN_SCORE_BF16X3)) return 0;
   const int bf = flags & SCL_TOPN_SCORE_BF16X3;
   const TopnPlan p = topn_plan(R, Q, bf);
-  return 256 + scl_round256((size_t)R * sizeof(float)) +
-         2 * scl_round256((size_t)Q * p.splits * KEEP * sizeof(float)) +
+  size_t lists = 2 * scl_round256((size_t)Q * p.splits * KEEP * sizeof(float));
+  if (R >= kTauMinRefs) {             // the threshold scheme's buffers (whichever is larger serves both)
+    const TauPlan t = tau_plan(R, Q);
+    const size_t tau_bytes = scl_round256((size_t)Q * t.pre_splits * 64 * sizeof(float)) +
+                             2 * scl_round256((size_t)Q * t.main_splits * kTauCapSplit * sizeof(float)) +
+                             scl_round256((size_t)Q * sizeof(float)) +
+                             scl_round256((size_t)Q * t.main_splits * sizeof(int));
+    if (tau_bytes > lists) lists = tau_bytes;
+  }
+  return 256 + scl_round256((size_t)R * sizeof(float)) + lists +
          (bf ? 2 * scl_round256((size_t)R * d * sizeof(unsigned short)) : 0);
 }
 
@@ -693,11 +942,37 @@ extern "C" int scl_topn_l2_cert(const float* ref, int R, const float* query, int
   base += 256;
   float* refnorm = (float*)base;
   base += scl_round256((size_t)R * sizeof(float));
-  float* cs = (float*)base;
-  base += scl_round256((size_t)Q * p.splits * KEEP * sizeof(float));
-  int* ci = (int*)base;
-  base += scl_round256((size_t)Q * p.splits * KEEP * sizeof(float));
   hipStream_t st = (hipStream_t)stream;
+  const bool tau_mode = use_tau(R, uncertified != nullptr, bf);
+  const TauPlan tp = tau_mode ? tau_plan(R, Q) : TauPlan{};
+  // sorted-list scan: cs / ci [Q][splits][KEEP].  threshold scheme: pre-pass values [Q][S'][64],
+  // candidate regions [Q][S][kTauCapSplit] x 2, tau [Q], counts [Q][S]
+  float *cs, *pre = nullptr, *tau = nullptr;
+  int *ci, *cnt = nullptr;
+  if (tau_mode) {
+    pre = (float*)base;
+    base += scl_round256((size_t)Q * tp.pre_splits * 64 * sizeof(float));
+    cs = (float*)base;
+    base += scl_round256((size_t)Q * tp.main_splits * kTauCapSplit * sizeof(float));
+    ci = (int*)base;
+    base += scl_round256((size_t)Q * tp.main_splits * kTauCapSplit * sizeof(float));
+    tau = (float*)base;
+    base += scl_round256((size_t)Q * sizeof(float));
+    cnt = (int*)base;
+    base += scl_round256((size_t)Q * tp.main_splits * sizeof(int));
+  } else {
+    cs = (float*)base;
+    base += scl_round256((size_t)Q * p.splits * KEEP * sizeof(float));
+    ci = (int*)base;
+    base += scl_round256((size_t)Q * p.splits * KEEP * sizeof(float));
+  }
+  // (the bf16 planes lie behind whichever of the two layouts is larger)
+  {
+    const size_t used = (size_t)(base - (char*)workspace);
+    const size_t planes = bf ? 2 * scl_round256((size_t)R * d * sizeof(unsigned short)) : 0;
+    base = (char*)workspace + (scl_topn_l2_ex_workspace_bytes(R, Q, d, n, flags) - planes);
+    if ((size_t)(base - (char*)workspace) < used) return SCL_E_WORKSPACE;
+  }
   if (uncertified) {
     const hipError_t e = hipMemsetAsync(rmax_bits, 0, 16, st);
     if (e != hipSuccess) return (int)e;
@@ -716,20 +991,21 @@ extern "C" int scl_topn_l2_cert(const float* ref, int R, const float* query, int
     scan_ref = hi;
     scan_lo = lo;
   }
-  if (bf) {
-    switch (d) {
-      case 32: launch_scan<4, 1>(p, scan_ref, scan_lo, refnorm, R, query, Q, cs, ci, st); break;
-      case 64: launch_scan<8, 1>(p, scan_ref, scan_lo, refnorm, R, query, Q, cs, ci, st); break;
-      case 128: launch_scan<16, 1>(p, scan_ref, scan_lo, refnorm, R, query, Q, cs, ci, st); break;
-      default: launch_scan<32, 1>(p, scan_ref, scan_lo, refnorm, R, query, Q, cs, ci, st); break;
-    }
+  if (tau_mode) {
+    // pre-pass over every kTauStride-th tile (interleaved splits) -> tau_q -> threshold scan
+    TopnPlan pp;
+    pp.qtiles = tp.qtiles;
+    pp.refs_per_split = 0;                                   // interleaved
+    pp.splits = tp.pre_splits;
+    launch_scan_d<2>(d, bf, pp, scan_ref, scan_lo, refnorm, R, query, Q, pre, (int*)nullptr, st,
+                     kTauStride * tp.pre_splits, nullptr, nullptr, 0, kTauStride);
+    SCL_LAUNCH("topn_tau_kernel", topn_tau_kernel, dim3((Q + 3) / 4), dim3(256), 0, st, (const float*)pre, Q,
+               tp.pre_splits, tau);
+    pp.splits = tp.main_splits;
+    launch_scan_d<1>(d, bf, pp, scan_ref, scan_lo, refnorm, R, query, Q, cs, ci, st, tp.main_splits, tau, cnt,
+                     kTauCapSplit, 1);
   } else {
-    switch (d) {
-      case 32: launch_scan<4, 0>(p, scan_ref, scan_lo, refnorm, R, query, Q, cs, ci, st); break;
-      case 64: launch_scan<8, 0>(p, scan_ref, scan_lo, refnorm, R, query, Q, cs, ci, st); break;
-      case 128: launch_scan<16, 0>(p, scan_ref, scan_lo, refnorm, R, query, Q, cs, ci, st); break;
-      default: launch_scan<32, 0>(p, scan_ref, scan_lo, refnorm, R, query, Q, cs, ci, st); break;
-    }
+    launch_scan_d<0>(d, bf, p, scan_ref, scan_lo, refnorm, R, query, Q, cs, ci, st);
   }
   // |approximate - exact score| <= eps_q |q| Rmax + eps_r Rmax^2 (u = 2^-24; factor 2 of
   // safety on rigorous worst-case bounds):
@@ -741,9 +1017,21 @@ extern "C" int scl_topn_l2_cert(const float* ref, int R, const float* query, int
   const double eps_r = 2.0 * (d + 16) * u;
   const double eps_q = 2.0 * (2.0 * (d + 16) * u +
                               (bf ? 6.0 / 262144.0 + 6.0 * d * u : 2.0 * d * u));
-  const int M = p.splits * KEEP;
-  const size_t lds = (size_t)4 * (2 * M + 3 * KEEP + 4) * sizeof(float);
+  const int M = tau_mode ? kTauCompact : p.splits * KEEP;
+  const size_t lds = (size_t)4 * (2 * M + 3 * KEEP + 4 + 66) * sizeof(float);
   const dim3 rgrid((Q + 3) / 4);
+  if (tau_mode) {
+    static SclDeviceOnce once;
+    scl_call_once(once, [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&topn_rerank_kernel<kTauCompact / 64, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    });
+    SCL_LAUNCH("topn_rerank_kernel<append>", (topn_rerank_kernel<kTauCompact / 64, true>), rgrid, dim3(256), lds, st, ref,
+               query, Q, d, tp.main_splits, n, idx_offset, (const float*)cs, (const int*)ci, idx_out, dist_out,
+               (const unsigned*)rmax_bits, (float)eps_q, (float)eps_r, uncertified, bound_sq,
+               (const int*)cnt, (const float*)tau, kTauCapSplit);
+    return scl_launch_status();
+  }
 #define SCL_RERANK(NE)                                                                           \
   SCL_LAUNCH("topn_rerank_kernel", topn_rerank_kernel<NE>, rgrid, dim3(256), lds, st, ref, query, \
              Q, d, p.splits, n, idx_offset, (const float*)cs, (const int*)ci, idx_out, dist_out,  \

@@ -199,3 +199,72 @@ def test_topn_above_25_matches_kdtree(dev, r, q, d, n, score):
     np.testing.assert_allclose(got_d.cpu().numpy(), want_d, rtol=1e-12, atol=0)
     if r >= 2000 and d <= 256:
         assert st['refined'] >= 1
+
+
+# ---- round 6: the threshold scan (pre-pass over every 16th tile -> tau_q -> append, no lists) -----
+@pytest.mark.parametrize("score", ['f32', 'bf16x3'])
+@pytest.mark.parametrize("r,q,d,n", [(32768, 70, 64, 25), (40000, 257, 256, 25), (100003, 130, 128, 7)])
+def test_threshold_scan_gives_the_lists_of_the_sorted_list_scan(dev, r, q, d, n, score):
+    """From 32768 references on, the certified call scores a 1/16 sample first (topn_scan_kernel<..,pre>: the two smallest scores per reference
+    column and query), takes the 32nd smallest of those per query as a threshold and appends what
+    meets it (topn_scan_kernel<..,tau>); the nominated 32 are the same references as with the sorted
+    lists (variant 8100), so index lists and float64 distances are identical — and equal to the
+    KD-tree's."""
+    from soft_contrastive_learning_amd import _lib as L
+    from soft_contrastive_learning_amd.evaluation import retrieval
+    ref, qry = U.retrieval_sets(r, q, d)
+    rt, qt = torch.tensor(ref, device=dev), torch.tensor(qry, device=dev)
+    st = {}
+    with L.KernelTimer(capacity=64) as kt:
+        d0, i0 = retrieval.topn_l2(rt, qt, n, score=score, stats=st)
+        torch.cuda.synchronize()
+    names = set(kt.summary())
+    assert any(k.endswith(',tau>') for k in names) and any(k.endswith(',pre>') for k in names) \
+        and 'topn_tau_kernel' in names, names
+    assert st.get('uncertified') == 0, st
+    with L.variant(8100):
+        with L.KernelTimer(capacity=64) as kt:
+            d1, i1 = retrieval.topn_l2(rt, qt, n, score=score)
+            torch.cuda.synchronize()
+        assert not any(k.endswith(',tau>') for k in kt.summary())
+    assert torch.equal(i0, i1) and torch.equal(d0, d1)
+    want_d, want_i = TN.topn_kdtree(ref, qry, n)
+    np.testing.assert_array_equal(i0.cpu().numpy(), want_i)
+    np.testing.assert_allclose(d0.cpu().numpy(), want_d, rtol=1e-12, atol=0)
+
+
+def test_threshold_scan_on_trajectory_ordered_references_and_buffer_overflow(dev):
+    """References in DRIVING order (consecutive rows are neighbouring places — the order of the
+    reference's CSV lists): a query's near references sit in a few consecutive tiles, most of which
+    the strided pre-pass skips.  Plus queries with more than 1024 references inside their threshold
+    (a dense cluster the sample barely touches): their candidate buffers overflow, the call flags
+    them and the exact pass resolves them.  Lists equal to the brute force either way."""
+    from soft_contrastive_learning_amd.evaluation import retrieval
+    rng = np.random.default_rng(5)
+    r, q, d, n = 60000, 96, 64, 25
+    t = np.linspace(0.0, 400.0, r)
+    path = np.stack([np.sin(0.05 * t * (k + 1) / 8.0 + k) for k in range(d)], 1)     # a smooth curve in R^d
+    ref = (path + 0.01 * rng.standard_normal((r, d))).astype(np.float32)
+    at = rng.integers(0, r, q)
+    qry = (path[at] + 0.01 * rng.standard_normal((q, d))).astype(np.float32)
+    # queries 0..3: 3000 near-identical references in ONE run of rows that starts on a sampled tile
+    # boundary + 32 (so the pre-pass sees only every 16th tile of it)
+    for k in range(4):
+        lo = 512 * (10 + 17 * k) + 32
+        ref[lo:lo + 3000] = (qry[k] + 1e-3 * rng.standard_normal((3000, d))).astype(np.float32)
+    want_d, want_i = TN.topn_bruteforce(ref, qry, n, chunk=8)
+    st = {}
+    got_d, got_i = retrieval.topn_l2(torch.tensor(ref, device=dev), torch.tensor(qry, device=dev), n, stats=st,
+                                     score='bf16x3')
+    np.testing.assert_array_equal(got_i.cpu().numpy(), want_i)
+    np.testing.assert_allclose(got_d.cpu().numpy(), want_d, rtol=1e-10, atol=0)
+    # how many queries the sorted-list scan hands to the exact pass on this set (dense runs of
+    # near-equidistant references fail the certificate by themselves): the threshold scheme may add
+    # the four overflowing ones, not more
+    from soft_contrastive_learning_amd import _lib as L
+    st_old = {}
+    with L.variant(8100):
+        retrieval.topn_l2(torch.tensor(ref, device=dev), torch.tensor(qry, device=dev), n, stats=st_old,
+                          score='bf16x3')
+    print('uncertified: threshold scheme %d, sorted lists %d' % (st['uncertified'], st_old['uncertified']))
+    assert 4 <= st['uncertified'] <= st_old['uncertified'] + 4, (st, st_old)
