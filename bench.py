@@ -209,6 +209,9 @@ def kernel_models(b, n, gb, x_bytes, slices=10):
         'gram16x6_kernel': dict(flops=2.0 * gb * gb * E, bytes=gb * E * 4),
         # round 6: the same products, strip-scheduled (64 < B <= 208)
         'gram16x6p_kernel': dict(flops=2.0 * gb * gb * E, bytes=gb * E * 4),
+        # (diagnostic build, scl_debug_set_variant(41): the whole forward as one persistent launch)
+        'gram16x6_persist_kernel': dict(flops=2.0 * gb * gb * E + 48.0 * gb * gb, bytes=gb * E * 4),
+        'gram16_persist_kernel': dict(flops=2.0 * gb * gb * E + 48.0 * gb * gb, bytes=gb * E * 4),
         # everything after the Gram for B <= 32, one workgroup
         'gram_final32_kernel': dict(flops=48.0 * gb * gb, bytes=gb * gb * 16),
         # slab sums (split-K artefact: priced on the Gram matrix it produces)

@@ -579,6 +579,7 @@ __host__ __device__ constexpr int vf_pi(int g, int e) {
 // grid (64, VF_WREP), block 64 (block = (w, s)).
 constexpr int VF_WREP = 1;
 constexpr int VF_WIMG = VF_NPL * D * K;           // bf16 elements per copy
+#ifdef SCL_DIAG   // superseded: reachable through scl_debug_set_variant only (A/B, parity runs)
 __global__ __launch_bounds__(64) void vlad_split_w_kernel(const float* __restrict__ w,
                                                           unsigned short* __restrict__ img) {
   const int lane = threadIdx.x, i = lane & 15, g = lane >> 4;
@@ -598,6 +599,7 @@ __global__ __launch_bounds__(64) void vlad_split_w_kernel(const float* __restric
     reinterpret_cast<uint4*>(img)[(((wv * 16 + s) * VF_NPL + pl) * 64) + lane] = v;
   }
 }
+#endif   // SCL_DIAG
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // v + (v of the lane 16 / 32 away): one register swap between 16-lane rows / 32-lane halves
@@ -665,6 +667,7 @@ struct VladFwdArgs {
   float* fin_out;               // [B][32768]
 };
 
+#ifdef SCL_DIAG   // superseded: reachable through scl_debug_set_variant only (A/B, parity runs)
 template <bool SAVE>
 __global__ __launch_bounds__(256, 1) void vlad_fwd_kernel(VladFwdArgs p) {
   // 1 KB alignment: the transposed-read addresses are formed by XOR on (stage base + offset)
@@ -929,6 +932,7 @@ __global__ __launch_bounds__(256, 1) void vlad_fwd_kernel(VladFwdArgs p) {
   }
 #undef VF_STAMP
 }
+#endif   // SCL_DIAG
 
 // U = sum of the slices' slabs + C * asum for one 16-channel tile -> vlad[b] (natural [513][64]
 // layout, the saved pre-norm VLAD) and the tile's column sums of squares.  Slabs are in
@@ -938,6 +942,7 @@ __global__ __launch_bounds__(256, 1) void vlad_fwd_kernel(VladFwdArgs p) {
 // Image on blockIdx.x like vlad_fwd_kernel: with B a multiple of 8 an image's slabs are read on
 // the XCD whose L2 they were written through (placement is speed only).
 constexpr int VF_MAXS = 16;
+#ifdef SCL_DIAG   // superseded: reachable through scl_debug_set_variant only (A/B, parity runs)
 __global__ __launch_bounds__(256) void vlad_finish_sum_kernel(const float* __restrict__ slab,
                                                               const float* __restrict__ colsum,
                                                               const float* __restrict__ centers,
@@ -977,6 +982,7 @@ __global__ __launch_bounds__(256) void vlad_finish_sum_kernel(const float* __res
   ss = vf_gsum(ss);
   if (g == 0) colsq_part[((int64_t)b * 32 + ct) * K + k] = ss;
 }
+#endif   // SCL_DIAG
 
 // vlad_bwd_kernel: the backward twin of vlad_fwd_kernel — x.dU[b], the softmax backward and the
 // weight-gradient aggregation x^T.(ds rn) of one (image, location slice) in one pass over x.
@@ -1001,6 +1007,7 @@ struct VladBwdArgs {
   float* trash;
 };
 
+#ifdef SCL_DIAG   // superseded: reachable through scl_debug_set_variant only (A/B, parity runs)
 __global__ __launch_bounds__(256, 1) void vlad_bwd_kernel(VladBwdArgs p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char vf_lds[];
   const int lane = threadIdx.x & 63;
@@ -1200,6 +1207,7 @@ __global__ __launch_bounds__(256, 1) void vlad_bwd_kernel(VladBwdArgs p) {
 #pragma unroll
   for (int ct = 0; ct < 32; ++ct) slab[ct * 64] = accv[ct];
 }
+#endif   // SCL_DIAG
 
 // =======================================================================================
 // Round 4: the two fused kernels with EIGHT waves per workgroup (two per SIMD).
@@ -1778,6 +1786,7 @@ __global__ __launch_bounds__(512) void vlad_bwd8_kernel(VladBwdArgs p) {
 // adds the groups in order and forms grad_c[d,k] = sum_b dU[b,d,k] * asum[b,k].  Fixed orders
 // throughout: bitwise reproducible.  Slabs in accumulator order (see vlad_finish_sum_kernel).
 constexpr int VW_GROUPS = 8;
+#ifdef SCL_DIAG   // superseded: reachable through scl_debug_set_variant only (A/B, parity runs)
 __global__ __launch_bounds__(256) void vlad_wgrad_partial_kernel(const float* __restrict__ slab,
                                                                  int total,
                                                                  float* __restrict__ partial) {
@@ -1798,7 +1807,9 @@ __global__ __launch_bounds__(256) void vlad_wgrad_partial_kernel(const float* __
   }
   reinterpret_cast<f32x4*>(partial)[grp * stride + unit] = u;
 }
+#endif   // SCL_DIAG
 
+#ifdef SCL_DIAG   // superseded: reachable through scl_debug_set_variant only (A/B, parity runs)
 __global__ __launch_bounds__(256) void vlad_wgrad_finish_kernel(const float* __restrict__ partial,
                                                                 const float* __restrict__ du,
                                                                 const float* __restrict__ save_vlad,
@@ -1837,6 +1848,7 @@ __global__ __launch_bounds__(256) void vlad_wgrad_finish_kernel(const float* __r
     grad_c[d * K + k] = gc[j];
   }
 }
+#endif   // SCL_DIAG
 
 // ---------------------------------------------------------------------------------------
 // Sibling exchange inside a launch (round 4).  The forward finish and the backward prologue each
@@ -2273,6 +2285,7 @@ __global__ __launch_bounds__(256) void finish_norm_kernel(float* vlad,
 //   c.dU_k = q_k g Bc_k - q_k^2 (g^3 S1 + r_k) Dc_k
 // bwd_dots_kernel: grid (8, B), block 256 (k = t & 63, dq = t >> 6): the four partial dots of
 // one 64-channel block -> dots[b][blk][4][64].
+#ifdef SCL_DIAG   // superseded: reachable through scl_debug_set_variant only (A/B, parity runs)
 __global__ __launch_bounds__(256) void bwd_dots_kernel(const float* __restrict__ save_vlad,
                                                        const float* __restrict__ grad_out,
                                                        const float* __restrict__ centers,
@@ -2301,6 +2314,7 @@ __global__ __launch_bounds__(256) void bwd_dots_kernel(const float* __restrict__
   dots[(((int64_t)b * 8 + blk) * 4 + dq) * K + k] =
       (src[k] + src[64 + k]) + (src[128 + k] + src[192 + k]);
 }
+#endif   // SCL_DIAG
 
 // bwd_du_kernel: grid (8, B), block 256: dU of one 64-channel block as float32 [d][k] (and
 // transposed, for the float32-MFMA row-tile kernel), c.dU from block 0, and for bf16 feature maps
@@ -2313,6 +2327,7 @@ __global__ __launch_bounds__(256) void bwd_dots_kernel(const float* __restrict__
 //          of a channel: the other orientation, through a [64 ch][64 k] LDS tile;
 //   wdximg (image 0's workgroups): the same image of W, shared by all images.
 constexpr int DU_TLD = 65;                                // floats per tile row (conflict-free columns)
+#ifdef SCL_DIAG   // superseded: reachable through scl_debug_set_variant only (A/B, parity runs)
 __global__ __launch_bounds__(256) void bwd_du_kernel(const float* __restrict__ save_vlad,
                                                      const float* __restrict__ grad_out,
                                                      const float* __restrict__ dots,
@@ -2405,6 +2420,7 @@ __global__ __launch_bounds__(256) void bwd_du_kernel(const float* __restrict__ s
     }
   }
 }
+#endif   // SCL_DIAG
 
 // ---------------------------------------------------------------------------------------
 // dx16_kernel: grad_x on 16-location tiles (v_mfma_f32_16x16x4_f32), 2-3 workgroups per CU.
@@ -3207,15 +3223,17 @@ extern "C" int scl_netvlad_fwd_p(const void* x, int x_dtype, const float* assign
     // one pass over x: soft-assignment and aggregation fused; then ONE finish kernel
     static SclDeviceOnce once;
     scl_call_once(once, [] {
+#ifdef SCL_DIAG
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vlad_fwd_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVladFusedLds);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vlad_fwd_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVladFusedLds);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vlad_fwd8_kernel<true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVlad8Lds);
+#endif
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vlad_fwd8_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVlad8Lds);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vlad_fwd8_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVlad8Lds);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vlad_fwd8_kernel<true, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVlad8Lds);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vlad_fwd8_kernel<false, false, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVlad8Lds);
@@ -3233,10 +3251,12 @@ extern "C" int scl_netvlad_fwd_p(const void* x, int x_dtype, const float* assign
     }
     const unsigned short* planes = (const unsigned short*)w_planes;
     if (!planes || old_launches()) {
+#ifdef SCL_DIAG
       if (old_launches())
         SCL_LAUNCH("vlad_split_w_kernel", vlad_split_w_kernel, dim3(64, VF_WREP), dim3(64), 0, st,
                    assign_w, w.wplanes);
       else
+#endif
         SCL_LAUNCH("vlad_planes_kernel", vlad_planes_kernel, dim3(VP_WAVES / 4), dim3(256), 0, st, assign_w,
                    w.wplanes);
       planes = w.wplanes;
@@ -3268,6 +3288,7 @@ extern "C" int scl_netvlad_fwd_p(const void* x, int x_dtype, const float* assign
                  kVlad8Lds, st, fa);
       return scl_launch_status();
     }
+#ifdef SCL_DIAG
     if (four_waves()) {
       if (save)
         SCL_LAUNCH("vlad_fwd_kernel<true>", vlad_fwd_kernel<true>, dim3(B, pl.S), dim3(256),
@@ -3275,11 +3296,13 @@ extern "C" int scl_netvlad_fwd_p(const void* x, int x_dtype, const float* assign
       else
         SCL_LAUNCH("vlad_fwd_kernel<false>", vlad_fwd_kernel<false>, dim3(B, pl.S), dim3(256),
                    kVladFusedLds, st, fa);
-    } else {
-      if (save && scl_variant() == 918)
-        SCL_LAUNCH("vlad_fwd8_kernel<stamps>", (vlad_fwd8_kernel<true, true>), dim3(B, pl.S), dim3(512),
-                   kVlad8Lds, st, fa);
-      else if (save)
+    } else if (save && scl_variant() == 918) {
+      SCL_LAUNCH("vlad_fwd8_kernel<stamps>", (vlad_fwd8_kernel<true, true>), dim3(B, pl.S), dim3(512),
+                 kVlad8Lds, st, fa);
+    } else
+#endif
+    {
+      if (save)
         SCL_LAUNCH("vlad_fwd8_kernel<true>", vlad_fwd8_kernel<true>, dim3(B, pl.S), dim3(512), kVlad8Lds,
                    st, fa);
       else
@@ -3287,6 +3310,7 @@ extern "C" int scl_netvlad_fwd_p(const void* x, int x_dtype, const float* assign
                    st, fa);
     }
     float* vlad = save_vlad ? save_vlad : w.vlad;
+#ifdef SCL_DIAG
     if (old_launches()) {
       SCL_LAUNCH("vlad_finish_sum_kernel", vlad_finish_sum_kernel, dim3(B, 32), dim3(256), 0, st,
                  (const float*)w.part, (const float*)w.colsum, centers, pl.S, vlad, w.colsq);
@@ -3294,6 +3318,7 @@ extern "C" int scl_netvlad_fwd_p(const void* x, int x_dtype, const float* assign
                  (const float*)w.colsq, 32, out);
       return scl_launch_status();
     }
+#endif
     VladFinishArgs na{};
     na.slab = w.part;
     na.colsum = w.colsum;
@@ -3373,6 +3398,7 @@ extern "C" int scl_netvlad_bwd_p(const void* x, int x_dtype, const float* assign
 
   const bool fused = x_dtype == SCL_DT_BF16 && use_fused();
   const unsigned short* wdx = w_planes ? (const unsigned short*)w_planes + VP_FWD_ELEMS : nullptr;
+#ifdef SCL_DIAG
   if (old_launches()) {
     SCL_LAUNCH("bwd_dots_kernel", bwd_dots_kernel, dim3(8, B), dim3(256), 0, st, (const float*)save_vlad,
                grad_out, centers, w.dots);
@@ -3380,7 +3406,9 @@ extern "C" int scl_netvlad_bwd_p(const void* x, int x_dtype, const float* assign
                grad_out, (const float*)w.dots, w.du, fused ? (float*)nullptr : w.dut,
                fused ? w.duimg : (unsigned short*)nullptr, w.dximg, assign_w, w.wdximg, w.cdu);
     wdx = w.wdximg;
-  } else {
+  } else
+#endif
+  {
     if (fused && !wdx) {
       SCL_LAUNCH("vlad_planes_kernel", vlad_planes_kernel, dim3(VP_WAVES / 4), dim3(256), 0, st, assign_w,
                  w.wdximg);
@@ -3401,8 +3429,10 @@ extern "C" int scl_netvlad_bwd_p(const void* x, int x_dtype, const float* assign
   if (fused) {
     static SclDeviceOnce once;
     scl_call_once(once, [] {
+#ifdef SCL_DIAG
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vlad_bwd_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVladFusedLds);
+#endif
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vlad_dx_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kVladDxLds);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vlad_bwd8_kernel),
@@ -3422,9 +3452,11 @@ extern "C" int scl_netvlad_bwd_p(const void* x, int x_dtype, const float* assign
     ba.rowdot = w.rowdot;
     ba.slab = w.wpart;
     ba.trash = w.trash;
+#ifdef SCL_DIAG
     if (four_waves())
       SCL_LAUNCH("vlad_bwd_kernel", vlad_bwd_kernel, dim3(B, pl.S), dim3(256), kVladFusedLds, st, ba);
     else
+#endif
       SCL_LAUNCH("vlad_bwd8_kernel", vlad_bwd8_kernel, dim3(B, pl.S), dim3(512), kVlad8Lds, st, ba);
     VladDxArgs da{};
     da.x = (const unsigned short*)x;
@@ -3451,12 +3483,14 @@ extern "C" int scl_netvlad_bwd_p(const void* x, int x_dtype, const float* assign
       da.grad_c = grad_c;
     }
     SCL_LAUNCH("vlad_dx_kernel", vlad_dx_kernel, dim3(B, pl.S), dim3(256), kVladDxLds, st, da);
+#ifdef SCL_DIAG
     if (old_launches()) {
       SCL_LAUNCH("vlad_wgrad_partial_kernel", vlad_wgrad_partial_kernel, dim3(32, VW_GROUPS), dim3(256),
                  0, st, (const float*)w.wpart, pl.S * B, w.wpartial);
       SCL_LAUNCH("vlad_wgrad_finish_kernel", vlad_wgrad_finish_kernel, dim3(32), dim3(256), 0, st,
                  (const float*)w.wpartial, (const float*)w.du, (const float*)save_vlad, B, grad_w, grad_c);
     }
+#endif
     return scl_launch_status();
   }
   RowTileArgs a{};

@@ -861,10 +861,10 @@ void launch_scan(const TopnPlan& p, const void* ref, const void* ref_lo, const f
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)scan_lds_bytes(D8 * 8, BF, SEL));
   });
-  const char* name = SEL == 1   ? (BF ? "topn_scan_kernel<BF=1,tau>" : "topn_scan_kernel<BF=0,tau>")
-                     : SEL == 2 ? (BF ? "topn_scan_kernel<BF=1,pre>" : "topn_scan_kernel<BF=0,pre>")
-                                : (BF ? "topn_scan_kernel<BF=1>" : "topn_scan_kernel<BF=0>");
-  SCL_LAUNCH(name, (topn_scan_kernel<D8, BF, SEL>), dim3(p.qtiles, p.splits), dim3(256),
+  SCL_LAUNCH(SEL == 1   ? (BF ? "topn_scan_kernel<BF=1,tau>" : "topn_scan_kernel<BF=0,tau>")
+             : SEL == 2 ? (BF ? "topn_scan_kernel<BF=1,pre>" : "topn_scan_kernel<BF=0,pre>")
+                        : (BF ? "topn_scan_kernel<BF=1>" : "topn_scan_kernel<BF=0>"),
+             (topn_scan_kernel<D8, BF, SEL>), dim3(p.qtiles, p.splits), dim3(256),
              scan_lds_bytes(D8 * 8, BF, SEL), st, ref, ref_lo, refnorm, R, query, Q, p.refs_per_split,
              scl_variant() < 8000 ? scl_variant() / 1000 : (scl_variant() / 1000 == 9 ? scl_variant() % 1000 : 0),
              cs, ci, tile_stride, tau, cnt, cap, tile_first);
