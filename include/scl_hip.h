@@ -165,10 +165,11 @@ int scl_gram_loss_fwd(const float* emb, int64_t ld_emb, int B, int E, int mask_k
                       int ms_mining, int sum_kind, float* loss_out, float* coef,
                       void* workspace, size_t workspace_bytes, void* stream);
 /* The same with a SYNC BLOCK (B <= 32: the forward is then ONE launch — the Gram kernel, whose last
- * workgroup to arrive runs the finish — instead of two).  sync_words: at least 4 bytes of device
+ * workgroup to arrive runs the finish — instead of two).  sync_words: at least 12 bytes of device
  * memory that are ZERO when the call is enqueued and that no other call in flight uses; the
  * library leaves them zero, so one zero-initialised block per (device, stream) serves every
- * call.  NULL, or B > 32: exactly scl_gram_loss_fwd.  The results are bit-identical either way
+ * call.  A block that was not zero on entry cannot be repaired: the library then sets word 2 for
+ * good and every call on the block returns a NaN loss until the caller zeroes it.  NULL, or B > 32: exactly scl_gram_loss_fwd.  The results are bit-identical either way
  * (same sums in the same order).  (Diagnostic build only: with 8 bytes of 8-byte-aligned sync block
  * scl_debug_set_variant(41) runs 32 < B <= 208 as ONE persistent kernel with grid barriers —
  * bit-identical, deadlock-free by a bounded spin + repair path, and slower than the four launches:

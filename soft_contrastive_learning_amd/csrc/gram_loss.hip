@@ -854,6 +854,9 @@ __device__ __forceinline__ void gram16_body(const float* __restrict__ emb, int64
     if (threadIdx.x == 0) {
       const unsigned old = __hip_atomic_fetch_add(fa.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       *flag = old == gridDim.x - 1;
+      // a ticket past the grid size: the word was not zero on entry (see below) — word 2 of the
+      // block records it for good
+      if (old >= gridDim.x) __hip_atomic_store(fa.counter + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     const int last = *flag;
@@ -863,16 +866,20 @@ __device__ __forceinline__ void gram16_body(const float* __restrict__ emb, int64
       final32_body<1024>(g16_lds, slabs, gridDim.x, T, P, B, fa);
     else
       final64_body<1024>(g16_lds, slabs, gridDim.x, T, P, B, fa);
-    // The word goes back to zero at the END of the finish, and is checked first: under the contract
-    // (zero on entry) every workgroup has drawn its ticket by now and nobody resets, so it reads
-    // exactly gridDim.x.  Anything else means the caller's word was not zero on entry and this
-    // workgroup took itself for the last one too early: the loss becomes NaN —
-    // loud, not a plausible number from half the slabs — and the reset heals the block for the
-    // next call (round 4 reset at the ticket, which left a wrong word wrong for ever).
+    // The word goes back to zero at the END of the finish.  Under the contract (zero on entry) every
+    // workgroup has drawn its ticket by now, so it reads exactly gridDim.x.  A word that was NOT zero
+    // on entry (an aborted earlier launch, a caller's bug) makes a middle workgroup take itself for
+    // the last one: that cannot be repaired and — ADVICE rounds 4 and 5 — cannot be detected here
+    // with certainty either (the late workgroups may not have drawn their tickets yet when this
+    // check runs).  What is certain: each of them draws a ticket >= gridDim.x and sets the STICKY
+    // error word (word 2 of the block), and leaves word 0 non-zero again behind this reset.  So the
+    // violating call returns NaN if it can see the damage and every later call on the block returns
+    // NaN until the host zeroes the block: loud, and not "healed" by the library.
     __syncthreads();
     if (threadIdx.x == 0) {
       const unsigned seen = __hip_atomic_load(fa.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (seen != gridDim.x) *fa.loss_out = __builtin_nanf("");
+      const unsigned sticky = __hip_atomic_load(fa.counter + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (seen != gridDim.x || sticky != 0u) *fa.loss_out = __builtin_nanf("");
       __hip_atomic_store(fa.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }

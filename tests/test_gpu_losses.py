@@ -344,11 +344,12 @@ def test_pairwise_distance_loss_and_grad(dev, t, p, e, huber):
     assert _rel(pt.grad.cpu().numpy(), p64.grad.numpy()) < 2e-4
 
 
-def test_fused_finish_with_a_dirty_sync_word_is_loud_and_heals(dev):
-    """the one-launch forward relies on the caller's sync word being zero on entry.
-    A word left non-zero (a contract violation) makes a middle workgroup take itself for the last:
-    the call cannot be repaired, but it must not return a plausible number from half the slabs —
-    the loss comes out NaN — and the word is zero again afterwards, so the NEXT call is sound."""
+def test_fused_finish_with_a_dirty_sync_word_is_loud_until_the_host_clears_it(dev):
+    """ADVICE rounds 4 and 5: the one-launch forward relies on the caller's sync word being zero on
+    entry.  A word left non-zero (a contract violation) makes a middle workgroup take itself for the
+    last: the call cannot be repaired and must not pass for sound.  The workgroups that draw a ticket
+    past the grid size set a STICKY error word: this call and every later one on the block return
+    NaN until the host zeroes the block — the library does not pretend to heal it."""
     from soft_contrastive_learning_amd import _lib as L
     from soft_contrastive_learning_amd.model import losses
     b, e = 24, 32768
@@ -358,11 +359,14 @@ def test_fused_finish_with_a_dirty_sync_word_is_loud_and_heals(dev):
     word = L.sync_words(dev)
     assert int(word.view(torch.int32)[0]) == 0                # left zero by the call above
     word.view(torch.int32)[0] = 3                             # the violation
-    bad = float(losses.wms_loss(dm, emb, 0.8, 15.0))
+    losses.wms_loss(dm, emb, 0.8, 15.0)
     torch.cuda.synchronize()
-    assert np.isnan(bad)
-    assert int(word.view(torch.int32)[0]) == 0                # healed
+    assert int(word.view(torch.int32)[2]) == 1                # recorded for good
+    for _ in range(3):                                        # ... and loud from here on
+        assert np.isnan(float(losses.wms_loss(dm, emb, 0.8, 15.0)))
+    word.zero_()                                              # the host's repair
     assert float(losses.wms_loss(dm, emb, 0.8, 15.0)) == good
+    assert int(word.view(torch.int32).abs().sum()) == 0
 
 
 # ---- round 4: the B <= 32 forward in one launch ---------------------------------------------------
