@@ -12,8 +12,12 @@ def load_img(in_file):
     from PIL import Image, ImageOps
     with Image.open(str(in_file)) as im:
         im = ImageOps.exif_transpose(im)
-        if im.mode in ('I;16', 'I;16B', 'I'):               # imread scales 16-bit files down to 8
-            im = im.point(lambda v: v / 256.0).convert('L')
+        if im.mode in ('I;16', 'I;16B', 'I;16L', 'I'):
+            # imread without IMREAD_ANYDEPTH hands 16-bit files back as 8-bit: the high byte (recalled,
+            # not checked against OpenCV here: no cv2 in the image).  Through NumPy — Image.point with a
+            # function is not defined for the 16-bit modes in every Pillow version.
+            hi = (np.asarray(im).astype(np.int64) >> 8).clip(0, 255).astype(np.uint8)
+            return np.repeat(hi[:, :, None], 3, axis=2)
         return np.asarray(im.convert('RGB'), dtype=np.uint8)
 
 

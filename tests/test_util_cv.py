@@ -144,3 +144,35 @@ def test_resampler_properties():
         assert np.array_equal(cv.resize_linear(img[:, ::-1].copy(), fx, fy), out[:, ::-1])
         assert np.array_equal(cv.resize_linear(img[::-1].copy(), fx, fy), out[::-1])
     check()
+
+
+def test_sixteen_bit_png_loads_as_its_high_byte(tmp_path):
+    """the 16-bit branch of load_img was untested (and Image.point with a function is
+    not defined for 'I;16' in every Pillow version): a 16-bit grey PNG comes back as three equal
+    8-bit channels holding the high byte."""
+    from PIL import Image
+    from soft_contrastive_learning_amd.util import io
+    arr = (np.arange(6 * 8, dtype=np.uint32).reshape(6, 8) * 1367 % 65536).astype(np.uint16)
+    path = tmp_path / 'deep.png'
+    Image.fromarray(arr).save(str(path))
+    with Image.open(str(path)) as im:
+        assert im.mode.startswith('I')
+    got = io.load_img(path)
+    assert got.shape == (6, 8, 3) and got.dtype == np.uint8
+    for c in range(3):
+        assert np.array_equal(got[:, :, c], (arr >> 8).astype(np.uint8))
+
+
+def test_resampler_against_opencv_when_it_is_there():
+    """Optional (skipped here: no cv2 in the image): util.cv.resize_img / standard_size restate
+    OpenCV's 8-bit INTER_LINEAR from memory; where cv2 exists the two must agree bit for bit on a
+    RobotCar-sized frame — the maximum deviation is what a first cv2 user should record."""
+    cv2 = pytest.importorskip('cv2')
+    from soft_contrastive_learning_amd.util import cv
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, size=(960, 1280, 3), dtype=np.uint8)
+    for max_side in (240, 640):
+        want = cv2.resize(img, (max_side, max_side * 960 // 1280), interpolation=cv2.INTER_LINEAR)
+        got = cv.resize_img(img, max_side)
+        assert got.shape == want.shape
+        assert int(np.abs(got.astype(int) - want.astype(int)).max()) == 0
