@@ -104,6 +104,23 @@ __global__ __launch_bounds__(256) void ref_split_kernel(const float* __restrict_
   lo[i] = l;
 }
 
+// LDS-DMA (global_load_lds_dwordx4): one wave instruction copies 64 x 16 bytes from a wave-uniform base
+// + per-lane byte offsets straight into 1 KB of consecutive LDS — no staging registers, no ds_write pass.
+// Inline asm so that hipcc does not order it against the reads of the other buffer; the kernel waits
+// vmcnt(0) itself before the barrier that hands the buffer over (csrc/conv64.hip has the same helper).
+__device__ __forceinline__ void tn_glds16(const void* base, unsigned off_bytes, unsigned lds_byte) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(off_bytes), "s"(base), "s"(lds_byte)
+      : "memory");
+}
+__device__ __forceinline__ unsigned tn_lds_byte_of(const void* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+
 // Rank-count sort of one query's KEEP-entry list by one wave (entry e = lane & 31):
 // afterwards the list is ascending by (score, index).
 __device__ __forceinline__ void sort_list(float* sc, int* ix, int lane) {
@@ -177,11 +194,24 @@ __global__ __launch_bounds__(256, 2) void topn_scan_kernel(const void* __restric
   constexpr int TILE_DW = BF ? 2 * 32 * LDB : 32 * LD;
   const float* ref = reinterpret_cast<const float*>(refv);
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* tile = lds;                                   // TILE_DW
+  // SEL 1 / 2 (no lists in LDS): the tile arrives by LDS-DMA into one of TWO unpadded, XOR-swizzled
+  // buffers (16-byte slot s of row r lies at slot s ^ (r & (SLOTS - 1)): the 32 rows a fragment read
+  // touches fall on different banks without row padding, which a lane-linear DMA cannot write) — no
+  // staging registers (the register-staged form spilled), no store pass, one barrier per tile.  Same
+  // box, configs[4]: bf16x3 scan 1585 -> 1455-1475 us, float32 4851-4887 -> 4700-4727 us.  (Two
+  // buffers with REGISTER staging had measured slower: profiles/r06/topn_threshold_scan.txt.)
+  // SEL 0 keeps the padded single buffer (its lists fill the LDS).
+  constexpr bool DMA = SEL != 0;
+  constexpr int ROWB = BF ? d * 2 : d * 4;             // bytes per row (per plane)
+  constexpr int SLOTS = ROWB / 16;                     // 16-byte slots per row
+  constexpr int PLANE_B = 32 * ROWB;                   // bytes per plane image of a tile
+  constexpr int DMA_TILE_DW = (BF ? 2 : 1) * PLANE_B / 4;
+  constexpr int BUF_DW = (DMA ? DMA_TILE_DW : TILE_DW) + 32;   // + refn[32]
+  float* tile = lds;                                   // (SEL 0) TILE_DW | refn
   float* refn = tile + TILE_DW;                        // 32
-  float* lsc = refn + 32;                              // QW * 32 * KEEP      (SEL 0 only)
+  float* lsc = lds + (DMA ? 2 : 1) * BUF_DW;           // QW * 32 * KEEP      (SEL 0 only)
   int* lix = reinterpret_cast<int*>(lsc + QW * 32 * KEEP);
-  float* tau = SEL == 0 ? reinterpret_cast<float*>(lix + QW * 32 * KEEP) : refn + 32;   // QW * 32
+  float* tau = SEL == 0 ? reinterpret_cast<float*>(lix + QW * 32 * KEEP) : lsc;   // QW * 32
 
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -260,9 +290,46 @@ __global__ __launch_bounds__(256, 2) void topn_scan_kernel(const void* __restric
     if (threadIdx.x < 32) refn[threadIdx.x] = stage_n;
   };
 
+  // DMA path: chunk c of a plane image = its bytes [1024 c, 1024 c + 1024); lane l owns byte 1024 c +
+  // 16 l = (row, physical slot) and fetches the row's LOGICAL slot phys ^ (row & (SLOTS - 1)).  Rows
+  // past the end of the split re-read its last row (their norm is +inf: they never qualify).
+  constexpr int NCH = PLANE_B / 1024, NCHT = (BF ? 2 : 1) * NCH;      // chunks per plane / per tile
+  const int wid_s = __builtin_amdgcn_readfirstlane(wid);
+  auto dma_issue = [&](int t) {
+    const int rb = r_begin + t * 32 * tile_stride;
+    const int last = r_end - 1 - rb < 31 ? r_end - 1 - rb : 31;       // last valid row of the tile
+    const unsigned dst0 = tn_lds_byte_of(lds) + (unsigned)(t & 1) * (BUF_DW * 4);
+#pragma unroll
+    for (int k = 0; k < (NCHT + QW - 1) / QW; ++k) {
+      const int c = wid_s + QW * k;                                   // (wave-uniform)
+      if (c < NCHT) {
+        const int pl = c / NCH, cc = c % NCH;
+        const int o = 1024 * cc + 16 * lane;
+        int row = o / ROWB;
+        const int phys = (o % ROWB) / 16;
+        const int logical = phys ^ (row & (SLOTS - 1));
+        row = row < last ? row : last;
+        const char* base = reinterpret_cast<const char*>(BF && pl ? ref_lov : refv) + (int64_t)rb * ROWB;
+        tn_glds16(base, (unsigned)(row * ROWB + logical * 16), dst0 + (unsigned)(pl * PLANE_B + 1024 * cc));
+      }
+    }
+    if (threadIdx.x < 32) {
+      const int rr = rb + threadIdx.x;
+      stage_n = rr < r_end ? refnorm[rr] : INFINITY;
+    }
+  };
+  auto dma_publish = [&](int t) {      // own chunks landed; the norms of tile t into its buffer
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x < 32) lds[(t & 1) * BUF_DW + DMA_TILE_DW + threadIdx.x] = stage_n;
+  };
   if (ntiles > 0) {
-    stage_load(0);
-    stage_store();
+    if constexpr (DMA) {
+      dma_issue(0);
+      dma_publish(0);
+    } else {
+      stage_load(0);
+      stage_store();
+    }
   }
   __syncthreads();
   float tq[SEL == 0 ? 16 : 1];
@@ -284,22 +351,36 @@ __global__ __launch_bounds__(256, 2) void topn_scan_kernel(const void* __restric
   }
 
   for (int t = 0; t < ntiles; ++t) {
-    if (t + 1 < ntiles && !(dbg & 2)) stage_load(t + 1);
+    if (t + 1 < ntiles && !(dbg & 2)) {
+      if constexpr (DMA) dma_issue(t + 1); else stage_load(t + 1);
+    }
     f32x16 acc = zero16();
+    // DMA buffers: row r starts at byte r * ROWB; the lane's slot 2 u + h lies at (2 u) ^ cm
+    const char* dbuf = reinterpret_cast<const char*>(lds) + (t & 1) * (BUF_DW * 4);
+    const int cm = h ^ (r & (SLOTS - 1));
     if constexpr (BF) {
       // planes: hi rows at tile[row * LDB], lo rows at tile[(32 + row) * LDB]; lane (r, h) reads
       // the 16 bytes of reference row r holding elements 16u + 8h .. +7
       const float* bh = &tile[r * LDB + 4 * h];
       const float* bl = bh + 32 * LDB;
+      const char* dh = dbuf + r * ROWB;
+      auto rd_h = [&](int u) {
+        return DMA ? *reinterpret_cast<const u32x4*>(dh + 16 * ((2 * u) ^ cm))
+                   : *reinterpret_cast<const u32x4*>(bh + 8 * u);
+      };
+      auto rd_l = [&](int u) {
+        return DMA ? *reinterpret_cast<const u32x4*>(dh + PLANE_B + 16 * ((2 * u) ^ cm))
+                   : *reinterpret_cast<const u32x4*>(bl + 8 * u);
+      };
       u32x4 vh[2], vl[2];
-      vh[0] = *reinterpret_cast<const u32x4*>(bh);
-      vl[0] = *reinterpret_cast<const u32x4*>(bl);
+      vh[0] = rd_h(0);
+      vl[0] = rd_l(0);
       if (!(dbg & 4)) {
 #pragma unroll
         for (int u = 0; u < KS; ++u) {
           if (u + 1 < KS) {
-            vh[(u + 1) & 1] = *reinterpret_cast<const u32x4*>(bh + 8 * (u + 1));
-            vl[(u + 1) & 1] = *reinterpret_cast<const u32x4*>(bl + 8 * (u + 1));
+            vh[(u + 1) & 1] = rd_h(u + 1);
+            vl[(u + 1) & 1] = rd_l(u + 1);
           }
           __builtin_amdgcn_sched_barrier(0);
           acc = mfma_bf16(qh[u], vh[u & 1], acc);
@@ -309,24 +390,31 @@ __global__ __launch_bounds__(256, 2) void topn_scan_kernel(const void* __restric
       }
     } else {
       const float* bp = &tile[r * LD + 4 * h];
+      const char* dp = dbuf + r * ROWB;
+      auto rd = [&](int u) {
+        return DMA ? *reinterpret_cast<const f32x4*>(dp + 16 * ((2 * u) ^ cm))
+                   : *reinterpret_cast<const f32x4*>(bp + 8 * u);
+      };
       // reference fragments run two steps ahead of the MFMAs in a 3-deep register ring
       f32x4 bv[3];
-      bv[0] = *reinterpret_cast<const f32x4*>(bp);
-      if (D8 > 1) bv[1] = *reinterpret_cast<const f32x4*>(bp + 8);
+      bv[0] = rd(0);
+      if (D8 > 1) bv[1] = rd(1);
       if (!(dbg & 4)) {
 #pragma unroll
         for (int u = 0; u < D8; ++u) {
-          if (u + 2 < D8) bv[(u + 2) % 3] = *reinterpret_cast<const f32x4*>(bp + 8 * (u + 2));
+          if (u + 2 < D8) bv[(u + 2) % 3] = rd(u + 2);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int c = 0; c < 4; ++c) acc = mfma32(qf[u][c], bv[u % 3][c], acc);
         }
       }
     }
-    const float rnj = refn[r];
+    const float rnj = DMA ? lds[(t & 1) * BUF_DW + DMA_TILE_DW + r] : refn[r];
     const int ridx = r_begin + t * 32 * tile_stride + r;
-    __syncthreads();                       // every wave is done reading the tile
-    if (t + 1 < ntiles && !(dbg & 2)) stage_store();   // refill it under the selection below
+    if constexpr (!DMA) {
+      __syncthreads();                     // every wave is done reading the tile
+      if (t + 1 < ntiles && !(dbg & 2)) stage_store();   // refill it under the selection below
+    }
 
     if constexpr (SEL == 1) {
       // threshold scan: half-wave h holds row acc_row(q, h) of register q against the tile's 32
@@ -420,7 +508,10 @@ __global__ __launch_bounds__(256, 2) void topn_scan_kernel(const void* __restric
         for (int q = 0; q < 16; ++q) tq[q] = my_tau[acc_row(q, h)];
       }
     }
-    __syncthreads();                       // refilled tile visible to everyone
+    if constexpr (DMA) {
+      if (t + 1 < ntiles && !(dbg & 2)) dma_publish(t + 1);
+    }
+    __syncthreads();                       // the next tile visible to everyone (DMA: and this one free)
   }
 
   if constexpr (SEL == 1) {
@@ -812,6 +903,8 @@ inline TopnPlan topn_plan(int R, int Q, int bf) {
 
 inline size_t scan_lds_bytes(int d, int bf, int sel = 0) {
   const size_t tile = bf ? (size_t)2 * 32 * (d / 2 + 4) : (size_t)32 * (d + 4);
+  if (sel)   // two unpadded DMA buffers (+ norms) and the thresholds
+    return (2 * ((size_t)(bf ? 2 : 1) * 32 * (bf ? d / 2 : d) + 32) + QW * 32) * sizeof(float);
   return (tile + 32 + (sel ? 0 : (size_t)QW * 32 * KEEP * 2) + QW * 32) * sizeof(float);
 }
 
