@@ -32,6 +32,12 @@ by the reference (README.md:10-11).  The oracle is therefore pinned only by
       transpose and tile in wms / ms / ms_det / logratio / evil_* / distance / pairwise losses is
       now the reference's statement, not the builder's reading of it.  oracle.losses_np agrees
       with those numbers to 1e-5, the HIP path to 1e-4 (tests/test_golden_ref.py).
+      The same for model/nets.py (make_golden_ref_nets.py -> golden_ref_nets_v1.json,
+      tests/test_golden_ref_nets.py): `vgg16` executed as written on eight more stand-ins
+      (layers.conv2d / max_pooling2d, nn.conv2d / relu, get_variable, variable_scope), and the
+      tensor + cluster count `vgg16Netvlad` hands to a RECORDING stand-in of layers.netVLAD — the
+      backbone's layer list, paddings, variable names and the head's call site are the
+      reference's statements; the head itself stays recalled (table below).
 
 Still RECALLED (no source in /root/reference, nothing here can execute them) — what the first
 person with TensorFlow 1.10 at hand should run:

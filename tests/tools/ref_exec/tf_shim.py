@@ -1,4 +1,5 @@
 """A NumPy stand-in for the ~35 TensorFlow 1.x ops that ``/root/reference/model/losses.py`` calls
+(and, further down, the eight graph-building calls of ``model/nets.py:7-131``) — losses.py
 at lines 5-135 (wms / evil_triplet / ms / logratio), 139-185 (ms_det), 197-250 (evil_quadruplet,
 worst_pos_distance, distance / huber_distance losses), 627-646 (pairwise_distance_loss) and
 656-700 (helpers) — so that the reference's OWN source text can be executed in the build
@@ -296,7 +297,116 @@ def _l2_normalize(x, axis=None, epsilon=1e-12, name=None, dim=None):
     return _t(a * inv)
 
 
-nn = types.SimpleNamespace(l2_normalize=_l2_normalize)
+# ---------------------------------------------------------------------------------------------
+# The ops model/nets.py:7-131 calls (graph builders in TensorFlow; eager here).  Variables come
+# from VARIABLES, keyed by their full TensorFlow name ('vgg16_netvlad_pca/conv1_1/kernel', ...):
+# the generator fills it before it calls the reference's function, the way a restored checkpoint
+# would (train/train.py:882-905).  A name the dictionary lacks is an error, never an initialiser.
+VARIABLES = {}
+CREATED = []              # full names in creation order (the generator records them)
+_SCOPES = []
+
+
+@contextlib.contextmanager
+def variable_scope(name, reuse=None):
+    _count('variable_scope')
+    _SCOPES.append(name)
+    try:
+        yield
+    finally:
+        _SCOPES.pop()
+
+
+def _variable(full, shape, dtype):
+    if full not in VARIABLES:
+        raise KeyError('variable %r was not supplied (tf_shim.VARIABLES)' % full)
+    v = np.asarray(VARIABLES[full])
+    if shape is not None and tuple(v.shape) != tuple(shape):
+        raise ValueError('variable %s: shape %s, the graph asks for %s' % (full, v.shape, tuple(shape)))
+    if dtype is not None and v.dtype != np.dtype(dtype):
+        raise TypeError('variable %s: dtype %s, the graph asks for %s' % (full, v.dtype, np.dtype(dtype)))
+    CREATED.append(full)
+    return _t(v)
+
+
+def get_variable(name, shape=None, dtype=None, initializer=None, trainable=True):
+    _count('get_variable')
+    if isinstance(shape, (int, np.integer)):
+        shape = (int(shape),)
+    return _variable('/'.join(_SCOPES + [name]), shape, dtype)
+
+
+def _conv2d_nhwc(x, w, stride, padding):
+    """NHWC input, HWIO filter, cross-correlation (TensorFlow's conv2d); 'SAME' with stride 1 pads
+    (k - 1) // 2 before and k // 2 after; products and sums in float64, one rounding to float32."""
+    kh, kw, cin, cout = w.shape
+    if x.shape[3] != cin:
+        raise ValueError('conv2d: input has %d channels, filter %d' % (x.shape[3], cin))
+    if stride != 1:
+        raise NotImplementedError('conv2d stride %r' % (stride,))
+    pad = padding.upper()
+    if pad == 'SAME':
+        x = np.pad(x, ((0, 0), ((kh - 1) // 2, kh // 2), ((kw - 1) // 2, kw // 2), (0, 0)))
+    elif pad != 'VALID':
+        raise ValueError('conv2d padding %r' % padding)
+    b, h, wd, _ = x.shape
+    ho, wo = h - kh + 1, wd - kw + 1
+    out = np.zeros((b, ho, wo, cout), np.float64)
+    w64 = w.astype(np.float64)
+    x64 = x.astype(np.float64)
+    for dy in range(kh):
+        for dx in range(kw):
+            out += x64[:, dy:dy + ho, dx:dx + wo, :] @ w64[dy, dx]
+    return out
+
+
+def _nn_conv2d(input, filter, strides, padding, name=None):          # noqa: A002
+    _count('nn.conv2d')
+    x = _t(input)
+    if len(strides) != 4 or any(float(s) != 1.0 for s in strides):
+        raise NotImplementedError('nn.conv2d strides %r' % (strides,))
+    w = np.asarray(filter, dtype=x.dtype)            # a NumPy filter takes the input's dtype
+    return _t(_conv2d_nhwc(x.view(np.ndarray), w, 1, padding).astype(x.dtype))
+
+
+def _relu(features, name=None):
+    _count('nn.relu')
+    x = _t(features)
+    return _t(np.maximum(x.view(np.ndarray), x.dtype.type(0)))
+
+
+def _layers_conv2d(inputs, filters, kernel_size, strides=(1, 1), padding='valid', activation=None,
+                   use_bias=True, name=None):
+    """tf.layers.conv2d: variables '<scope>/<name>/kernel' [kh,kw,in,filters] and '<name>/bias'."""
+    _count('layers.conv2d')
+    x = _t(inputs)
+    if name is None:
+        raise NotImplementedError('layers.conv2d without a name (auto-numbered scopes)')
+    kh, kw = (kernel_size, kernel_size) if isinstance(kernel_size, int) else tuple(kernel_size)
+    st = strides if isinstance(strides, int) else strides[0]
+    scope = '/'.join(_SCOPES + [name])
+    w = _variable(scope + '/kernel', (kh, kw, x.shape[3], filters), x.dtype)
+    y = _conv2d_nhwc(x.view(np.ndarray), w.view(np.ndarray), st, padding)
+    if use_bias:
+        y = y + _variable(scope + '/bias', (filters,), x.dtype).view(np.ndarray).astype(np.float64)
+    y = _t(y.astype(x.dtype))
+    return activation(y) if activation is not None else y
+
+
+def _layers_max_pooling2d(inputs, pool_size, strides, padding='valid', name=None):
+    """'valid' (the default, and what nets.py:37 gets): windows that do not fit are dropped."""
+    _count('layers.max_pooling2d')
+    x = _t(inputs).view(np.ndarray)
+    if padding.lower() != 'valid' or pool_size != strides or isinstance(pool_size, (tuple, list)):
+        raise NotImplementedError('max_pooling2d(%r, %r, %r)' % (pool_size, strides, padding))
+    k = int(pool_size)
+    b, h, w, c = x.shape
+    x = x[:, :h // k * k, :w // k * k, :].reshape(b, h // k, k, w // k, k, c)
+    return _t(x.max(axis=(2, 4)))
+
+
+nn = types.SimpleNamespace(l2_normalize=_l2_normalize, conv2d=_nn_conv2d, relu=_relu)
+layers = types.SimpleNamespace(conv2d=_layers_conv2d, max_pooling2d=_layers_max_pooling2d)
 
 
 class _Reduction:

@@ -77,3 +77,20 @@ def pose_images(b, h, w, seed=42):
         img += rng.normal(0, 6.0, size=(h, w, 3)).astype(F32)
         out[i] = np.clip(np.rint(img), 0, 255)
     return out
+
+
+VGG_CONVS = (('1_1', 3, 64), ('1_2', 64, 64), ('2_1', 64, 128), ('2_2', 128, 128), ('3_1', 128, 256),
+             ('3_2', 256, 256), ('3_3', 256, 256), ('4_1', 256, 512), ('4_2', 512, 512), ('4_3', 512, 512),
+             ('5_1', 512, 512), ('5_2', 512, 512), ('5_3', 512, 512))
+
+
+def vgg_variables(seed=77, scope='vgg16_netvlad_pca'):
+    """The backbone's variables by TensorFlow name, in the checkpoint layout (kernels [3,3,in,out],
+    model/nets.py:12-63): He-scaled kernels, biases of a size that matters, a mean image."""
+    rng = np.random.default_rng(seed)
+    sd = {scope + '/average_rgb': np.array([123.68, 116.78, 103.94], F32) + rng.uniform(-2, 2, 3).astype(F32)}
+    for name, cin, cout in VGG_CONVS:
+        sd['%s/conv%s/kernel' % (scope, name)] = (
+            rng.standard_normal((3, 3, cin, cout)) * np.sqrt(2.0 / (9 * cin))).astype(F32)
+        sd['%s/conv%s/bias' % (scope, name)] = (rng.standard_normal(cout) * 0.1).astype(F32)
+    return sd
