@@ -23,6 +23,7 @@ import types
 
 import numpy as np
 
+sys.dont_write_bytecode = True          # nothing may be written under /root/reference (no __pycache__)
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(HERE)))
 sys.path.insert(0, ROOT)

@@ -94,3 +94,33 @@ def vgg_variables(seed=77, scope='vgg16_netvlad_pca'):
             rng.standard_normal((3, 3, cin, cout)) * np.sqrt(2.0 / (9 * cin))).astype(F32)
         sd['%s/conv%s/bias' % (scope, name)] = (rng.standard_normal(cout) * 0.1).astype(F32)
     return sd
+
+
+def retrieval_dataset(seed=5, n_pca=640, n_ref=900, n_query=120, e=288, rank=24):
+    """A small place-recognition data set for evaluation/top-n.py: a reference traverse (steps of
+    0.2-3 m along a wandering path), queries near random reference poses, and descriptors that are
+    a smooth function of the pose (random Fourier features through a rank-`rank` map) plus noise —
+    so that whitening has a real spectrum to equalise and neighbours in feature space are mostly
+    neighbours on the ground.  e = 288 with 640 PCA rows and d = 256 makes scikit-learn's 'auto'
+    solver the exact one (randomized is picked only when d < 0.8 * min(shape))."""
+    rng = np.random.default_rng(seed)
+
+    def path(n, start):
+        head = np.cumsum(rng.normal(0.0, 0.08, n))
+        step = rng.uniform(0.2, 3.0, n)
+        return start + np.cumsum(np.stack([step * np.cos(head), step * np.sin(head)], 1), axis=0)
+
+    ref_xy = path(n_ref, np.array([620000.0, 5700000.0]))
+    pca_xy = path(n_pca, ref_xy[n_ref // 3] + 40.0)
+    query_xy = ref_xy[rng.integers(0, n_ref, n_query)] + rng.normal(0.0, 2.0, (n_query, 2))
+    freq = rng.normal(0.0, 1.0 / 15.0, (2, 4 * rank))
+    phase = rng.uniform(0.0, 2 * np.pi, 4 * rank)
+    mix = rng.standard_normal((4 * rank, e)) * (np.arange(4 * rank)[:, None] % rank + 1.0) ** -0.7
+
+    def feats(xy):
+        f = np.cos((xy - ref_xy[0]) @ freq + phase) @ mix / np.sqrt(4 * rank)
+        f = f + rng.standard_normal(f.shape) * 0.05
+        return (f / np.linalg.norm(f, axis=1, keepdims=True)).astype(F32)
+
+    return {'pca_f': feats(pca_xy), 'ref_f': feats(ref_xy), 'query_f': feats(query_xy),
+            'ref_xy': ref_xy, 'query_xy': query_xy}
