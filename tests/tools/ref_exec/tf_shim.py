@@ -268,7 +268,7 @@ def _reduce(name, fn):
     def op(input_tensor, axis=None, keepdims=False, name_=None, keep_dims=None):
         _count(name)
         a = _t(input_tensor).view(np.ndarray)
-        kd = bool(keepdims if keep_dims is None else keep_dims)
+        kd = builtins.bool(keepdims if keep_dims is None else keep_dims)
         if name in ('reduce_sum', 'reduce_mean'):
             return _t(np.asarray(fn(a, axis=axis, keepdims=kd, dtype=a.dtype)))
         return _t(np.asarray(fn(a, axis=axis, keepdims=kd)))
@@ -447,6 +447,101 @@ def _unsupported(name):
 linalg = types.SimpleNamespace(svd=_unsupported('linalg.svd'), eigh=_unsupported('linalg.eigh'),
                                trace=_unsupported('linalg.trace'))
 slice = _unsupported('slice')        # noqa: A001
+
+
+# ---------------------------------------------------------------------------------------------
+# What build_model() of train/train.py:585-879 calls around the losses.  Placeholders are EAGER:
+# each takes the next entry of FEEDS whose dtype and static shape fit (None = any extent), so the
+# function's own reshape / split / label statements run on real values as it builds its `ops`.
+FEEDS = []
+
+
+def placeholder(dtype, shape=None, name=None):
+    _count('placeholder')
+    want = np.dtype(dtype)
+    for pos, val in enumerate(FEEDS):
+        v = np.asarray(val)
+        if v.dtype != want:
+            continue
+        if shape is not None:
+            shp = tuple(shape)
+            if len(shp) != v.ndim or any(d is not None and int(d) != e for d, e in zip(shp, v.shape)):
+                continue
+        del FEEDS[pos]
+        return _t(v)
+    raise LookupError('no fed value left for placeholder(%s, shape=%r)' % (want, shape))
+
+
+def placeholder_with_default(input, shape, name=None):         # noqa: A002
+    _count('placeholder_with_default')
+    return _t(input)
+
+
+def no_op(name=None):
+    return None
+
+
+def split(value, num_or_size_splits, axis=0, num=None, name=None):
+    _count('split')
+    v = _t(value)
+    if isinstance(num_or_size_splits, (int, np.integer)):
+        if v.shape[axis] % num_or_size_splits:
+            raise ValueError('split: %d does not divide axis of %d' % (num_or_size_splits, v.shape[axis]))
+        return [_t(p) for p in np.split(v.view(np.ndarray), num_or_size_splits, axis=axis)]
+    sizes = [int(x) for x in num_or_size_splits]
+    if builtins.sum(sizes) != v.shape[axis]:
+        raise ValueError('split: sizes %r do not add up to %d' % (sizes, v.shape[axis]))
+    return [_t(p) for p in np.split(v.view(np.ndarray), np.cumsum(sizes)[:-1], axis=axis)]
+
+
+class Variable:
+    def __init__(self, initial_value, trainable=True, name=None):
+        self.value = initial_value
+
+
+class _Optimizer:
+    made = []
+
+    def __init__(self, learning_rate, **kw):
+        self.learning_rate, self.kw = learning_rate, kw
+        _Optimizer.made.append(self)
+
+    def minimize(self, loss, global_step=None, var_list=None):
+        _count('train.minimize')
+        return ('train_op', type(self).__name__)
+
+
+class _Adam(_Optimizer):
+    pass
+
+
+class _Momentum(_Optimizer):
+    pass
+
+
+train = types.SimpleNamespace(AdamOptimizer=_Adam, MomentumOptimizer=_Momentum, made=_Optimizer.made)
+SUMMARIES = {}
+summary = types.SimpleNamespace(scalar=lambda name, tensor: SUMMARIES.__setitem__(name, tensor))
+GraphKeys = types.SimpleNamespace(UPDATE_OPS='update_ops')
+
+
+def get_collection(key, scope=None):
+    return []
+
+
+@contextlib.contextmanager
+def control_dependencies(control_inputs):
+    yield
+
+
+def _layers_flatten(inputs, name=None):
+    _count('layers.flatten')
+    x = _t(inputs)
+    return _t(x.view(np.ndarray).reshape(x.shape[0], -1))
+
+
+layers.flatten = _layers_flatten
+globals()['bool'] = np.bool_             # tf.bool (kept out of a plain assignment: the name is a builtin)
 
 
 class Session:
