@@ -24,11 +24,9 @@ oracle/losses_np.py — cases that reach them say ``uses_recalled_pointnetvlad``
 around them only.
 """
 import ast
-import importlib.util
 import json
 import os
 import sys
-import types
 
 import numpy as np
 
@@ -39,52 +37,11 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
 
 import tf_shim  # noqa: E402
-from oracle import losses_np as O  # noqa: E402
+from ref_trainer import TRAIN, install_names, load_trainer  # noqa: E402
 from tests import util_data as U  # noqa: E402
 
-REF_ROOT = '/root/reference'
-TRAIN = os.path.join(REF_ROOT, 'train', 'train.py')
 OUT = os.path.join(ROOT, 'tests', 'golden', 'golden_ref_trainer_v1.json')
 F32 = np.float32
-
-
-def install_names():
-    sys.modules['tensorflow'] = tf_shim
-    pkg = types.ModuleType('learnlarge')
-    pkg.__path__ = [REF_ROOT]
-    sys.modules['learnlarge'] = pkg
-    sys.modules['cv2'] = types.ModuleType('cv2')
-    nv, nvl = types.ModuleType('netvlad_tf'), types.ModuleType('netvlad_tf.layers')
-    nv.layers = nvl                                    # imported by model/nets.py; the embedder is not run
-    sys.modules['netvlad_tf'], sys.modules['netvlad_tf.layers'] = nv, nvl
-    pn = types.ModuleType('pointnetvlad_cls')
-    for name in ('triplet_loss', 'lazy_triplet_loss', 'quadruplet_loss', 'lazy_quadruplet_loss'):
-        fn = getattr(O, name)
-        setattr(pn, name, (lambda f: lambda *a: tf_shim._t(np.asarray(
-            f(*[np.asarray(x) for x in a]), dtype=F32)))(fn))
-    pn.best_pos_distance = lambda q, p: tf_shim._t(O.best_pos_distance(np.asarray(q), np.asarray(p)))
-    outer = types.ModuleType('pointnetvlad')
-    outer.pointnetvlad_cls = pn
-    sys.modules['pointnetvlad'] = outer
-    sys.modules['pointnetvlad.pointnetvlad_cls'] = pn
-    sys.modules['pointnetvlad_cls'] = pn
-    import learnlarge.util.helper as helper            # the reference's own module
-    helper.debugging = lambda: False
-    helper.location = lambda: 'here'
-    helper.srv_root = helper.fs_root
-    skl = types.ModuleType('learnlarge.model.incremental_skl')
-    skl.skl_init = skl.single_skl_increment = skl.multiple_skl_increments = None
-    sys.modules['learnlarge.model.incremental_skl'] = skl
-    mac = types.ModuleType('learnlarge.model.mac')
-    mac.spp = None
-    sys.modules['learnlarge.model.mac'] = mac
-
-
-def load_trainer():
-    spec = importlib.util.spec_from_file_location('reference_train_train', TRAIN)
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    return mod
 
 
 def main_block_chain(first_string):

@@ -124,3 +124,18 @@ def retrieval_dataset(seed=5, n_pca=640, n_ref=900, n_query=120, e=288, rank=24)
 
     return {'pca_f': feats(pca_xy), 'ref_f': feats(ref_xy), 'query_f': feats(query_xy),
             'ref_xy': ref_xy, 'query_xy': query_xy}
+
+
+def sampler_dataset(seed=3, n=360, laps=2):
+    """Poses for the tuple sampler (train/train.py:433-582): `laps` passes of a closed course with
+    2-3 m between frames, lateral noise, heading from the direction of travel — every frame has
+    positives within 15 m and 30 degrees of heading (other laps, neighbours), and frames on the far
+    side of the course to draw negatives from.  -> xy [n,2] float64, yaw [n] float64."""
+    rng = np.random.default_rng(seed)
+    per = n // laps
+    ang = np.concatenate([np.linspace(0.0, 2 * np.pi, per, endpoint=False) + rng.normal(0, 0.002, per)
+                          for _ in range(laps)] + [np.zeros(n - per * laps)])
+    rad = 2.5 * per / (2 * np.pi)
+    xy = np.stack([rad * np.cos(ang) * 1.4, rad * np.sin(ang)], 1) + rng.normal(0.0, 0.6, (n, 2))
+    yaw = np.arctan2(np.cos(ang), -1.4 * np.sin(ang)) + rng.normal(0.0, 0.05, n)
+    return xy + np.array([620000.0, 5700000.0]), yaw
