@@ -17,7 +17,8 @@ Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
 product package ``soft_contrastive_learning_amd`` never imports it and has no CPU
 fallback: it raises if the HIP library is missing.
 
-PARITY UNPINNED.  The reference ships no tests and no golden vectors for this path,
+PARITY UNPINNED for the losses, the network and the optimiser (retrieval and the tuple sampler: see
+(d)).  The reference ships no tests and no golden vectors for this path,
 TensorFlow 1.10 / netvlad_tf / pointnetvlad are not importable in the build
 container, and the two third-party modules are neither vendored nor version-pinned
 by the reference (README.md:10-11).  The oracle is therefore pinned only by
@@ -38,6 +39,21 @@ by the reference (README.md:10-11).  The oracle is therefore pinned only by
       tensor + cluster count `vgg16Netvlad` hands to a RECORDING stand-in of layers.netVLAD — the
       backbone's layer list, paddings, variable names and the head's call site are the
       reference's statements; the head itself stays recalled (table below).
+      And for train/train.py's build_model() (:585-879; make_golden_ref_trainer.py ->
+      golden_ref_trainer_v1.json): eager placeholders, the embedder replaced by the fed
+      descriptors — the trainer's reshape / split / label / distance-split glue and which flag
+      reaches which loss call are the reference's statements (tests/test_golden_ref_trainer.py).
+  (d) since round 6, and PINNED for the two rows they cover, because these ran the reference's own
+      code on the REAL libraries it computes with (NumPy, scikit-learn 1.7.2 — no stand-in on the
+      executed path; the generators list the import-only names they had to supply):
+        * evaluation/top-n.py run as __main__ on a synthetic traverse -> golden_ref_topn_v1.json:
+          PCA whitening, the thinning loop (index 0 twice at l = 0), KDTree top-25, ground truth,
+          index translation, pickle layout and file name.  oracle.topn_np reproduces its lists and
+          distances (1e-6), the package's script its pickle (tests/test_golden_ref_topn.py).
+        * get_tuple() of train/train.py:433-582 run under np.random.seed -> golden_ref_sampler_v1.json:
+          tuples, per-loss distance payloads, mining-cache walk.  The package's sampler returns the
+          same images, bit-identical payloads and leaves the stream where the reference does
+          (tests/test_golden_ref_sampler.py).
 
 Still RECALLED (no source in /root/reference, nothing here can execute them) — what the first
 person with TensorFlow 1.10 at hand should run:
