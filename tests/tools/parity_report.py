@@ -6,7 +6,8 @@ same comparisons against fixed tolerances; this prints / stores what was actuall
 
 Rows: relative loss error vs the float32 NumPy oracle (north_star gate: 1e-4), norm-relative
 gradient error vs the float64 autograd twin, descriptor error of the NetVLAD head for both
-input dtypes, and index-list equality of the retrieval against scikit-learn's KDTree.
+input dtypes, index-list equality of the retrieval against scikit-learn's KDTree, and the worst
+errors against the fixtures made by executing / running the reference's own files (golden_ref_*).
 Needs an MI355X; uses oracle/ as the checker only.
 """
 import argparse
@@ -150,6 +151,60 @@ def main():
         add('top-25 of 40000 x 500 x 256, score=%s' % score,
             index_lists_equal=bool(np.array_equal(i.cpu().numpy(), want_i)),
             dist_maxrel_vs_kdtree=float(np.abs(d.cpu().numpy() - want_d).max() / want_d.max()))
+
+    # ---- against the fixtures made by executing / running the reference's own files ---------
+    # (tests/golden/golden_ref_*.json; tests/tools/ref_exec/ made them in the build container)
+    import tests.test_golden_ref as GR
+    import tests.test_golden_ref_nets as GN
+    import tests.test_golden_ref_topn as GT
+    import tests.test_golden_ref_trainer as GTR
+    from soft_contrastive_learning_amd.train import train as T
+    worst, worst_name = 0.0, ''
+    for c in GR.BY_KIND['wms']:
+        emb, dist = GR._wms_inputs(c)
+        got = M.wms_loss(torch.tensor(dist, device=dev), torch.tensor(emb, device=dev), 0.8, 15.0, **c['kw'])
+        if rel(got, c['loss']) > worst:
+            worst, worst_name = rel(got, c['loss']), c['name']
+    add('EXECUTED reference losses.py: wms_loss, %d cases' % len(GR.BY_KIND['wms']),
+        worst_loss_rel=worst, worst_case=worst_name)
+    worst, worst_name = 0.0, ''
+    for c in GTR.CASES:
+        f, emb, dist = GTR._inputs(c)
+        shape = T.tuple_shape_for(c['loss'], f.positives_per_tuple, f.negatives_per_tuple)
+        got = T.compute_loss(f, shape, torch.from_numpy(emb).to(dev), T.batch_distances(f, dist, dev))
+        if rel(got, c['loss_value']) > worst:
+            worst, worst_name = rel(got, c['loss_value']), c['name']
+    add("EXECUTED reference train.py build_model(): trainer's loss, %d configurations" % len(GTR.CASES),
+        worst_loss_rel=worst, worst_case=worst_name)
+    for dt, label in ((torch.float32, 'f32'), (torch.bfloat16, 'bf16')):
+        worst = 0.0
+        for c in GN.CASES:
+            want = GN._expected(c)
+            with torch.no_grad():
+                got = GN._model(c, dt).to(dev).forward_vgg16(torch.from_numpy(GN._images(c)).to(dev))
+            worst = max(worst, float(np.abs(got.float().cpu().numpy() - want).max() / np.abs(want).max()))
+        add('EXECUTED reference nets.py: vgg16 maps, %d cases, %s maps' % (len(GN.CASES), label),
+            worst_maxrel=worst)
+    import tempfile
+    ds, want = GT._dataset(), GT._want()
+    with tempfile.TemporaryDirectory() as tmp:
+        from soft_contrastive_learning_amd.evaluation import top_n
+        from soft_contrastive_learning_amd.util import io as sio
+        argv = ['--N', str(GT.C['N']), '--out_root', os.path.join(tmp, 'top_n')]
+        for name, xy in (('ref', ds['ref_xy']), ('query', ds['query_xy'])):
+            path = os.path.join(tmp, 'set_%s.csv' % name)
+            sio.save_csv({'easting': [repr(float(v)) for v in xy[:, 0]],
+                          'northing': [repr(float(v)) for v in xy[:, 1]]}, path)
+            argv += ['--%s_csv' % name, path]
+        for name in ('pca', 'ref', 'query'):
+            path = os.path.join(tmp, 'set_%s.v1.pickle' % name)
+            sio.save_pickle([row for row in ds[name + '_f']], path)
+            argv += ['--%s_lv_pickle' % name, path]
+        top_i, _, top_f, gt_i, _, _ = sio.load_pickle(top_n.main(argv)[0])
+    add("RUN of the reference's evaluation/top-n.py (real scikit-learn): the script's pickle",
+        index_lists_equal=bool(np.array_equal(np.asarray(top_i), want['top_i'])),
+        dist_maxrel=float(np.abs(np.asarray(top_f) - want['top_f']).max() / want['top_f'].max()),
+        ground_truth_equal=bool(np.array_equal(np.asarray(gt_i), want['gt_i'])))
 
     if args.json:
         with open(args.json, 'w') as f:
