@@ -54,6 +54,11 @@ by the reference (README.md:10-11).  The oracle is therefore pinned only by
           tuples, per-loss distance payloads, mining-cache walk.  The package's sampler returns the
           same images, bit-identical payloads and leaves the stream where the reference does
           (tests/test_golden_ref_sampler.py).
+        * evaluate_localization_thread() of train/train.py:360-420 run on a synthetic retrieval result
+          (real sklearn.metrics.auc and matplotlib; the OpenCV picture helpers replaced by array
+          stand-ins) -> golden_ref_localization_v1.json: the six summary values per check and the
+          PDF names.  The package's localization_metrics gives the same numbers to 1e-12
+          (tests/test_golden_ref_localization.py).
 
 Still RECALLED (no source in /root/reference, nothing here can execute them) — what the first
 person with TensorFlow 1.10 at hand should run:

@@ -544,6 +544,19 @@ layers.flatten = _layers_flatten
 globals()['bool'] = np.bool_             # tf.bool (kept out of a plain assignment: the name is a builtin)
 
 
+class _SummaryValues(list):
+    def add(self, tag=None, simple_value=None):
+        self.append((tag, simple_value))
+
+
+class Summary:
+    """tf.Summary as evaluate_localization_thread uses it (train/train.py:362, 380-385): a list of
+    (tag, simple_value)."""
+
+    def __init__(self):
+        self.value = _SummaryValues()
+
+
 class Session:
     """The reference's __main__ smoke prints through a session (model/losses.py:712-714)."""
     def run(self, fetches):

@@ -139,3 +139,19 @@ def sampler_dataset(seed=3, n=360, laps=2):
     xy = np.stack([rad * np.cos(ang) * 1.4, rad * np.sin(ang)], 1) + rng.normal(0.0, 0.6, (n, 2))
     yaw = np.arctan2(np.cos(ang), -1.4 * np.sin(ang)) + rng.normal(0.0, 0.05, n)
     return xy + np.array([620000.0, 5700000.0]), yaw
+
+
+def localization_inputs(seed, num_q, k):
+    """Inputs of the in-training localisation check (train/train.py:1181-1193): reference / query poses from
+    the sampler course; the 'retrieved' references are the k geographically nearest of a NOISY copy of the
+    query pose (60 % of the queries displaced by ~25 m), so that the curves are neither 0 nor 100 %.
+    -> ref_xy, query_xy, nearest_latent_indices [Q,k], nearest_d_dist [Q,1], nearest_d_indices [Q,1]."""
+    from sklearn.neighbors import KDTree
+    rng = np.random.default_rng(seed)
+    xy, _ = sampler_dataset()
+    ref_xy = xy[::2]
+    query_xy = xy[1::2][rng.permutation(len(xy[1::2]))[:num_q]] + rng.normal(0.0, 1.0, (num_q, 2))
+    noisy = query_xy + rng.normal(0.0, 25.0, query_xy.shape) * (rng.random((num_q, 1)) < 0.6)
+    _, nearest_latent = KDTree(ref_xy).query(noisy, k=k)
+    nearest_d_dist, nearest_d_idx = KDTree(ref_xy).query(query_xy, k=1)
+    return ref_xy, query_xy, nearest_latent, nearest_d_dist, nearest_d_idx
