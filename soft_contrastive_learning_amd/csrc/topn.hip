@@ -917,6 +917,19 @@ constexpr int kTauSplits = 32;        // are expected over the 32 interleaved sp
                                       // pre-pass sees one in sixteen — counts then vary by a factor of 2-3
 constexpr int kTauCompact = 1024;     // candidates the re-rank takes per query (more: the exact pass)
 constexpr int kTauMinRefs = 32768;    // below: the sorted-list scan
+// (diagnostic build: SCL_TAU_STRIDE = 4 .. 64 samples more or fewer tiles — scripts/topn_tau_stride_ab.py)
+inline int tau_stride() {
+#ifdef SCL_DIAG
+  static const int v = [] {
+    const char* e = getenv("SCL_TAU_STRIDE");
+    const int s = e ? atoi(e) : kTauStride;
+    return s >= 4 && s <= 64 ? s : kTauStride;
+  }();
+  return v;
+#else
+  return kTauStride;
+#endif
+}
 struct TauPlan {
   int qtiles, pre_splits, main_splits;
 };
@@ -924,7 +937,7 @@ inline TauPlan tau_plan(int R, int Q) {
   TauPlan t;
   t.qtiles = (Q + 32 * QW - 1) / (32 * QW);
   const int tiles = (R + 31) / 32;
-  const int sampled = (tiles + kTauStride - 1) / kTauStride;
+  const int sampled = (tiles + tau_stride() - 1) / tau_stride();
   // pre-pass: interleaved splits (<= 8: topn_tau_kernel keeps 8 values per lane) that fill the chip
   // once, each with >= 8 sampled tiles
   int sp = (512 + t.qtiles - 1) / t.qtiles;
@@ -1091,7 +1104,7 @@ extern "C" int scl_topn_l2_cert(const float* ref, int R, const float* query, int
     pp.refs_per_split = 0;                                   // interleaved
     pp.splits = tp.pre_splits;
     launch_scan_d<2>(d, bf, pp, scan_ref, scan_lo, refnorm, R, query, Q, pre, (int*)nullptr, st,
-                     kTauStride * tp.pre_splits, nullptr, nullptr, 0, kTauStride);
+                     tau_stride() * tp.pre_splits, nullptr, nullptr, 0, tau_stride());
     SCL_LAUNCH("topn_tau_kernel", topn_tau_kernel, dim3((Q + 3) / 4), dim3(256), 0, st, (const float*)pre, Q,
                tp.pre_splits, tau);
     pp.splits = tp.main_splits;
