@@ -16,7 +16,7 @@ img = torch.randint(0, 256, (24, 480, 640, 3), generator=torch.Generator().manua
 avg = torch.tensor([123.68, 116.78, 103.94], device=dev)
 w = (torch.randn(64, 3, 3, 3) * 0.1).to(dev)
 bias = torch.randn(64).to(dev)
-for var in (0, 70001, 70002, 70004, 70006, 70007, 0):
+for var in (0, 70001, 70002, 70003, 70004, 70005, 70006, 70007, 0):
     lib.scl_debug_set_variant(var)
     for _ in range(2):
         nets._FirstConv.apply(img, avg, w, bias, torch.bfloat16, None)

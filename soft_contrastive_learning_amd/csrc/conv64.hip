@@ -1184,23 +1184,47 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
   unsigned short* scr = lds + F_WIN + wid * 2 * SCR;
 
   // weights: B[k][n], k = 3 * tap + c (k >= 27: zero); lane (j, h) holds k = 16 ks + 8 h + e
+  // (Round 6: the weights go through LDS as a [64 n][32 k] bf16 image — thread t fetches the eight values
+  // (n = t / 4, k = 8 (t % 4) .. + 7) with INDEPENDENT loads (padding slots k >= 27 re-read k = 26 and are
+  // zeroed; the float32 / bf16 branch is taken once around all of them) and a lane's four fragments are four
+  // ds_read_b128.  As `k < 27 ? weight_bf16(..) : 0` per element, each of a lane's 32 loads sat in its own
+  // branch behind an `s_waitcnt vmcnt(0)`: 32 dependent round trips before a workgroup's first tile, with
+  // eight workgroups per CU in the grid.)
   u32x4 wf[2][2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      unsigned short v[8];
+  {
+    unsigned short* wimg = lds + F_WIN;                 // 4 KB of the epilogue scratch, free until the first tile
+    const int n = threadIdx.x >> 2, kc = 8 * (threadIdx.x & 3);
+    unsigned short v[8];
+    if (w_f32) {
+      float wl[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const int k = 16 * ks + 8 * h + e;
-        const int tap = k / 3, c = k % 3;
-        v[e] = k < 27 ? weight_bf16(w, (32 * nt + r) * sk + c * sc + (tap / 3) * sh + (tap % 3) * sw,
-                                    w_f32)
-                      : (unsigned short)0;
+        const int k = kc + e < 27 ? kc + e : 26, tap = k / 3, c = k % 3;
+        wl[e] = static_cast<const float*>(w)[n * sk + c * sc + (tap / 3) * sh + (tap % 3) * sw];
       }
-      wf[ks][nt] = u32x4{(unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16),
-                         (unsigned)v[4] | ((unsigned)v[5] << 16), (unsigned)v[6] | ((unsigned)v[7] << 16)};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = kc + e < 27 ? f32_to_bf16(wl[e]) : (unsigned short)0;
+    } else {
+      unsigned short wl[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = kc + e < 27 ? kc + e : 26, tap = k / 3, c = k % 3;
+        wl[e] = static_cast<const unsigned short*>(w)[n * sk + c * sc + (tap / 3) * sh + (tap % 3) * sw];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = kc + e < 27 ? wl[e] : (unsigned short)0;
     }
+    *reinterpret_cast<u32x4*>(wimg + n * 32 + kc) =
+        u32x4{(unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16),
+              (unsigned)v[4] | ((unsigned)v[5] << 16), (unsigned)v[6] | ((unsigned)v[7] << 16)};
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+        wf[ks][nt] = *reinterpret_cast<const u32x4*>(wimg + (32 * nt + r) * 32 + 16 * ks + 8 * h);
+    __syncthreads();                                    // (the scratch is the waves' again)
+  }
   // A gather offsets (bf16 units, relative to the lane's pixel): window (kh, kw), channel c
   int goff[2][8];
 #pragma unroll
@@ -1212,7 +1236,16 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
       goff[ks][e] = ((tap / 3) * WC + tap % 3) * F_PIX + c;
     }
   const float a0 = avg[0], a1 = avg[1], a2 = avg[2];
-  const float bias0 = bias[r], bias1 = bias[32 + r];
+  // (Round 6: the products run with the operands SWAPPED — weights as A, pixels as B — so that lane
+  // (pixel r, half h) holds in registers 4 g .. 4 g + 3 the four consecutive channels 8 g + 4 h .. + 3 of its
+  // pixel: two v_cvt_pk_bf16_f32 and ONE ds_write_b64 per group instead of four ds_write_b16 — the
+  // epilogue's 32 two-byte LDS stores per m-tile were a quarter of the kernel's time without any global
+  // traffic.  The bias of those channels sits in 32 registers.)
+  float biasv[2][16];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) biasv[nt][q] = bias[32 * nt + acc_row(q, h)];
 
   const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
   const int per_img = tiles_x * tiles_y;
@@ -1284,8 +1317,8 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
         for (int e = 0; e < 8; ++e) v[e] = base[goff[ks][e]];
         const u32x4 af = u32x4{(unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16),
                                (unsigned)v[4] | ((unsigned)v[5] << 16), (unsigned)v[6] | ((unsigned)v[7] << 16)};
-        acc0 = mfma32b(af, wf[ks][0], acc0);
-        acc1 = mfma32b(af, wf[ks][1], acc1);
+        acc0 = mfma32b(wf[ks][0], af, acc0);
+        acc1 = mfma32b(wf[ks][1], af, acc1);
       }
       const int oy = ty + 2 * wid + mt;
       // both n-tiles through the scratch (two planes of 32 channels), then whole 128-byte pixels
@@ -1293,11 +1326,15 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const float* __restrict
       // instruction writes 8 complete lines instead of 32 quarter lines
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
-        const float bb = nt ? bias1 : bias0;
 #pragma unroll
-        for (int q = 0; q < 16; ++q)
-          scr[(32 * nt + acc_row(q, h)) * SCR_LD + r] =
-              f32_to_bf16(fmaxf((nt ? acc1[q] : acc0[q]) + bb, 0.f));
+        for (int g = 0; g < 4; ++g) {
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            v[j] = fmaxf((nt ? acc1[4 * g + j] : acc0[4 * g + j]) + biasv[nt][4 * g + j], 0.f);
+          *reinterpret_cast<uint2*>(scr + (32 * nt + r) * SCR_LD + 8 * g + 4 * h) =
+              make_uint2(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]));
+        }
       }
       __builtin_amdgcn_wave_barrier();
       const int piece = lane & 7;
