@@ -1,12 +1,13 @@
-# Same-box A/B of two builds of the library: soft_contrastive_learning_amd/libscl_hip_base.so (a copy of an earlier
-# build) against libscl_hip_new.so (a copy of the current one), alternating, same command.  Run under gpurun:
-#   bash scripts/lib_ab.sh 3 python3 scripts/convh_variants.py --layer 4_2 --variants 53008
+# Same-box A/B of the train step between the product library and a PREVIOUS build of it: put the other build at
+# soft_contrastive_learning_amd/libscl_hip_prev.so (e.g. `git show HEAD~1:...conv64.hip`, compiled with the
+# Makefile's flags and linked with the current objects), then `gpurun -- 'bash scripts/lib_ab.sh'`.
+cd $GRAFT_REPO_ROOT
 P=soft_contrastive_learning_amd
-N=$1; shift
-for k in $(seq 1 $N); do
-  for which in base new; do
-    cp $P/libscl_hip_$which.so $P/libscl_hip.so
-    "$@" --tag $which 2>/dev/null
+cp $P/libscl_hip.so /tmp/new.so; cp $P/libscl_hip_prev.so /tmp/prev.so
+for r in 1 2 3; do
+  for v in new prev; do
+    cp /tmp/$v.so $P/libscl_hip.so
+    echo -n "$v  "; python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-retrieval --no-batch-sweep --no-telemetry 2>/dev/null | python scripts/bench_field.py value ms_per_step
   done
 done
-cp $P/libscl_hip_new.so $P/libscl_hip.so
+cp /tmp/new.so $P/libscl_hip.so
