@@ -1792,6 +1792,9 @@ __global__ __launch_bounds__(64) void conv_first_davg_kernel(
   __shared__ float part[3][64];
   const int o = threadIdx.x;
   float corner[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+  // (unrolled by 8: the loads of eight images go out together — one image per round trip made this
+  // 64-thread kernel 24 + 27 dependent loads long; the sums keep their order)
+#pragma unroll 8
   for (int b = 0; b < B; ++b) {
     if (compact) {           // gz = [B][4 corners: (0,0) (0,W-1) (H-1,0) (H-1,W-1)][64] — the fused
                              // conv1_2 backward's side buffer (H, W >= 2 there: four distinct pixels)
@@ -1811,14 +1814,39 @@ __global__ __launch_bounds__(64) void conv_first_davg_kernel(
   const float rows[3] = {aux[0 * 64 + o], 0.f, aux[1 * 64 + o]};
   const float cols[3] = {aux[2 * 64 + o], 0.f, aux[3 * 64 + o]};
   float acc[3] = {0.f, 0.f, 0.f};
+  float wv[3][3][3];                   // the 27 weights of channel o: independent loads, one branch
+  if (w_f32) {
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          wv[kh][kw][c] = static_cast<const float*>(w)[o * sk + c * sc + kh * sh + kw * sw];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) wv[kh][kw][c] = bf16_to_f32(f32_to_bf16(wv[kh][kw][c]));
+  } else {
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          wv[kh][kw][c] =
+              bf16_to_f32(static_cast<const unsigned short*>(w)[o * sk + c * sc + kh * sh + kw * sw]);
+  }
+  const float gbo = gb[o];
 #pragma unroll
   for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) {
-      const float s_ = gb[o] - rows[kh] - cols[kw] + corner[kh][kw];
+      const float s_ = gbo - rows[kh] - cols[kw] + corner[kh][kw];
 #pragma unroll
-      for (int c = 0; c < 3; ++c)
-        acc[c] += bf16_to_f32(weight_bf16(w, o * sk + c * sc + kh * sh + kw * sw, w_f32)) * s_;
+      for (int c = 0; c < 3; ++c) acc[c] += wv[kh][kw][c] * s_;
     }
 #pragma unroll
   for (int c = 0; c < 3; ++c) part[c][o] = acc[c];
